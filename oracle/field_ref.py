@@ -1,0 +1,348 @@
+"""oracle/field_ref.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Torch-CPU restatement of the Python half of the reference's watermarked render path:
+the two hash encoders, the spherical-harmonics direction encoding, the two tiny
+MLPs, trunc_exp, NeRFNetwork.forward, NeRFRenderer.run_cuda / run / render and
+Trainer.train_step.  Each function cites the reference lines it follows
+(paths relative to /root/reference).  The native half (marching/compositing) is
+oracle/raymarch_ref.c, reached through oracle/raymarch_ref.py.
+
+Pinning status
+  * hash encoders, SH formulas, trunc_exp, decoder/loss arithmetic: PINNED -- checked in
+    tests/test_oracle_golden.py against vectors produced by importing the real reference
+    modules in the build container (tests/golden/make_golden.py, committed with its output).
+  * MLP arithmetic and its parameter layout: PARITY UNPINNED.  The reference evaluates them
+    with tinycudann (nerf/network_wtmk_tcnn.py:52-88), a third-party CUDA dependency that is
+    neither vendored nor version-pinned by the reference and cannot run here.  What is
+    restated is tiny-cuda-nn's documented FullyFusedMLP behaviour: no biases, ReLU hidden
+    activations, weight matrices stored consecutively in one flat `params` vector, each
+    [out, in] row-major with the first layer's input width and the last layer's output
+    width padded to 16; inputs narrower than the padded width are padded with 1.0; the
+    SphericalHarmonics encoding maps its [0,1] input back to [-1,1].  Arithmetic here is
+    fp32 (tcnn computes in fp16), the stated tolerance of the path being 1e-3.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import raymarch_ref as rm
+
+LOG2_T = 19
+HASH_MASK = (1 << LOG2_T) - 1
+PRIME_Y, PRIME_Z = 2654435761, 805459861  # hash_encoding.py:16
+
+# corner c = (c>>2 & 1, c>>1 & 1, c & 1) = (dx, dy, dz): hash_encoding.py:8
+_CORNERS = torch.tensor([[(c >> 2) & 1, (c >> 1) & 1, c & 1] for c in range(8)], dtype=torch.int64)
+
+
+def level_resolutions(n_levels=16, base_resolution=16, finest_resolution=2048):
+    """Per-level resolution as the fp32 0-dim tensors the reference computes
+    (hash_encoding.py:56-60,100): floor(base * b**i), b = exp((ln finest - ln base)/(L-1))."""
+    base, fine = torch.tensor(base_resolution), torch.tensor(finest_resolution)
+    b = torch.exp((torch.log(fine) - torch.log(base)) / (n_levels - 1))
+    return [torch.floor(base * b ** i) for i in range(n_levels)]
+
+
+def voxel_lookup(x01, resolution):
+    """hash_encoding.py:24-46 for bounding box (0, 1): hashed row index of the 8 cell corners
+    and the interpolation weights.  x01: [M,3] fp32.  Returns (rows [M,8] int64, w [M,3] fp32, cell [M,3] int32)."""
+    xc = torch.clamp(x01, min=0, max=1)            # :33-35 (only indexing sees the clamp)
+    cell_size = 1 / resolution                      # :37, fp32 0-dim
+    cell = torch.floor(xc / cell_size).int()        # :39
+    lo = cell * cell_size                           # :40
+    hi = lo + torch.tensor([1.0, 1.0, 1.0]) * cell_size  # :41
+    corners = cell.unsqueeze(1) + _CORNERS.unsqueeze(0)   # :43 -> int64 [M,8,3]
+    rows = (corners[..., 0] ^ (corners[..., 1] * PRIME_Y) ^ (corners[..., 2] * PRIME_Z)) & HASH_MASK  # :11-22
+    w = (x01 - lo) / (hi - lo)                      # :80 (unclamped x)
+    return rows, w, cell
+
+
+def trilerp(e, w):
+    """hash_encoding.py:73-94.  e: [M,8,F] corner rows, w: [M,3]."""
+    wx, wy, wz = w[:, 0:1], w[:, 1:2], w[:, 2:3]
+    c00 = e[:, 0] * (1 - wx) + e[:, 4] * wx
+    c01 = e[:, 1] * (1 - wx) + e[:, 5] * wx
+    c10 = e[:, 2] * (1 - wx) + e[:, 6] * wx
+    c11 = e[:, 3] * (1 - wx) + e[:, 7] * wx
+    c0 = c00 * (1 - wy) + c10 * wy
+    c1 = c01 * (1 - wy) + c11 * wy
+    return c0 * (1 - wz) + c1 * wz
+
+
+def base_encode(x01, tables):
+    """HashEmbedder.forward, hash_encoding.py:96-111.  tables: 16 x [T,2] -> [M,32]."""
+    outs = []
+    for table, res in zip(tables, level_resolutions(len(tables), 16, 2048)):
+        rows, w, _ = voxel_lookup(x01, res)
+        outs.append(trilerp(table[rows], w))
+    return torch.cat(outs, dim=-1)
+
+
+def codebook_encode(x01, message, tables, faithful=False):
+    """HashEmbedder(msg).forward, hash_encoding_wtmk_bit.py:99-116.  tables: 2D x [T,2];
+    bit i reads table 2i + message[i]; every level has resolution 2048 (b == 1, :63); the D
+    interpolated rows are summed.  faithful=True recomputes the (identical) lookup per bit as
+    the reference does; the result is the same."""
+    D = len(tables) // 2
+    res = level_resolutions(2 * D, 2048, 2048)[0]  # network_wtmk_tcnn.py:43-44 -> b == 1, every level 2048
+    outs = []
+    rows = w = None
+    for i in range(D):
+        if faithful or rows is None:
+            rows, w, _ = voxel_lookup(x01, res)
+        outs.append(trilerp(tables[2 * i + int(message[i])][rows], w))
+    return torch.sum(torch.stack(outs, dim=-1), dim=-1)
+
+
+def sh4(d):
+    """Degree-4 real spherical harmonics of d in [-1,1]^3, hash_encoding.py:157-183 -> [M,16]."""
+    x, y, z = d.unbind(-1)
+    xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+    cols = [
+        torch.full_like(x, 0.28209479177387814),
+        -0.4886025119029199 * y, 0.4886025119029199 * z, -0.4886025119029199 * x,
+        1.0925484305920792 * xy, -1.0925484305920792 * yz, 0.31539156525252005 * (2.0 * zz - xx - yy),
+        -1.0925484305920792 * xz, 0.5462742152960396 * (xx - yy),
+        -0.5900435899266435 * y * (3 * xx - yy), 2.890611442640554 * xy * z,
+        -0.4570457994644658 * y * (4 * zz - xx - yy), 0.3731763325901154 * z * (2 * zz - 3 * xx - 3 * yy),
+        -0.4570457994644658 * x * (4 * zz - xx - yy), 1.445305721320277 * z * (xx - yy),
+        -0.5900435899266435 * x * (xx - 3 * yy),
+    ]
+    return torch.stack(cols, dim=-1)
+
+
+class _TruncExp(torch.autograd.Function):
+    """activation.py:5-15."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g * torch.exp(x.clamp(-15, 15))
+
+
+trunc_exp = _TruncExp.apply
+
+
+def split_mlp_params(params, widths):
+    """Flat tcnn `params` -> list of [out,in] matrices (layout assumption: module docstring)."""
+    mats, off = [], 0
+    for fan_out, fan_in in widths:
+        mats.append(params[off:off + fan_out * fan_in].view(fan_out, fan_in))
+        off += fan_out * fan_in
+    assert off == params.numel()
+    return mats
+
+
+SIGMA_WIDTHS = ((64, 32), (16, 64))             # network_wtmk_tcnn.py:52-62  (32 -> 64 -> 1+15)
+COLOR_WIDTHS = ((64, 32), (64, 64), (16, 64))   # network_wtmk_tcnn.py:78-88  (31 pad 32 -> 64 -> 64 -> 3 pad 16)
+
+
+def mlp(x, mats):
+    h = x
+    for k, W in enumerate(mats):
+        h = h @ W.t()
+        if k + 1 < len(mats):
+            h = torch.relu(h)
+    return h
+
+
+def density(x, message, P):
+    """NeRFNetwork.density, network_wtmk_tcnn.py:126-144."""
+    x01 = (x + P["bound"]) / (2 * P["bound"])
+    feat = base_encode(x01, P["base_tables"])
+    if message is not None:
+        feat = torch.cat([feat[:, :-2], feat[:, -2:] + codebook_encode(x01, message, P["cb_tables"], P.get("faithful", False))], dim=-1)  # :106
+    h = mlp(feat, split_mlp_params(P["sigma_params"], SIGMA_WIDTHS))
+    return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
+
+
+def color(d, geo_feat, P):
+    """NeRFNetwork.color without mask, network_wtmk_tcnn.py:147-176."""
+    d01 = (d + 1) / 2
+    enc = sh4(d01 * 2 - 1)
+    cin = torch.cat([enc, geo_feat, torch.ones_like(enc[:, :1])], dim=-1)
+    return torch.sigmoid(mlp(cin, split_mlp_params(P["color_params"], COLOR_WIDTHS))[:, :3])
+
+
+def field_forward(x, d, message, P):
+    """NeRFNetwork.forward, network_wtmk_tcnn.py:97-124 -> (sigma [M], rgb [M,3])."""
+    dn = density(x, message, P)
+    return dn["sigma"], color(d, dn["geo_feat"], P)
+
+
+class _CompositeTrain(torch.autograd.Function):
+    """raymarching.py:238-291 around the C oracle."""
+
+    @staticmethod
+    def forward(ctx, sigmas, rgbs, deltas, rays, T_thresh):
+        ws, depth, image = rm.composite_rays_train_forward(sigmas.detach().numpy(), rgbs.detach().numpy(), deltas.numpy(), rays.numpy(), T_thresh)
+        ws, depth, image = torch.from_numpy(ws), torch.from_numpy(depth), torch.from_numpy(image)
+        ctx.save_for_backward(sigmas, rgbs, deltas, rays, ws, image)
+        ctx.T_thresh = T_thresh
+        return ws, depth, image
+
+    @staticmethod
+    def backward(ctx, g_ws, g_depth, g_image):
+        sigmas, rgbs, deltas, rays, ws, image = ctx.saved_tensors
+        gs, gc = rm.composite_rays_train_backward(g_ws.contiguous().numpy(), g_image.contiguous().numpy(), sigmas.detach().numpy(), rgbs.detach().numpy(), deltas.numpy(), rays.numpy(), ws.numpy(), image.numpy(), ctx.T_thresh)
+        return torch.from_numpy(gs), torch.from_numpy(gc), None, None, None
+
+
+def run_cuda_train(rays_o, rays_d, message, P, S, dt_gamma=0.0, bg_color=1, max_steps=1024, T_thresh=1e-4, noises=None):
+    """NeRFRenderer.run_cuda, training branch, renderer_wtmk.py:256-321.
+    S: scene dict {bound, cascade, grid_size, density_bitfield (uint8 np), aabb (np[6]), min_near, density_scale}."""
+    prefix = rays_o.shape[:-1]
+    o, d = rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3)
+    nears, fars = rm.near_far_from_aabb(o.numpy(), d.numpy(), S["aabb"], S["min_near"])
+    counter = np.zeros(2, np.int32)
+    xyzs, dirs, deltas, rays = rm.march_rays_train(o.numpy(), d.numpy(), S["bound"], S["density_bitfield"], S["cascade"], S["grid_size"], nears, fars, counter, -1, noises is not None, 128, True, dt_gamma, max_steps, noises=noises)
+    xyzs, dirs, deltas, rays = map(torch.from_numpy, (xyzs, dirs, deltas, rays))
+    sigmas, rgbs = field_forward(xyzs, dirs, message, P)
+    sigmas = S.get("density_scale", 1) * sigmas
+    ws, depth, image = _CompositeTrain.apply(sigmas, rgbs, deltas, rays, T_thresh)
+    image = image + (1 - ws).unsqueeze(-1) * bg_color
+    nears_t, fars_t = torch.from_numpy(nears), torch.from_numpy(fars)
+    depth = torch.clamp(depth - nears_t, min=0) / (fars_t - nears_t)
+    return {"image": image.view(*prefix, 3), "depth": depth.view(*prefix), "weights_sum": ws,
+            "rays": rays, "n_points": int(counter[0]), "xyzs": xyzs, "dirs": dirs, "deltas": deltas,
+            "sigmas": sigmas, "rgbs": rgbs}
+
+
+@torch.no_grad()
+def run_cuda_eval(rays_o, rays_d, message, P, S, dt_gamma=0.0, bg_color=1, max_steps=1024, T_thresh=1e-4):
+    """NeRFRenderer.run_cuda, inference branch, renderer_wtmk.py:323-377."""
+    prefix = rays_o.shape[:-1]
+    o, d = rays_o.contiguous().view(-1, 3).numpy(), rays_d.contiguous().view(-1, 3).numpy()
+    N = o.shape[0]
+    nears, fars = rm.near_far_from_aabb(o, d, S["aabb"], S["min_near"])
+    ws, depth, image = np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros((N, 3), np.float32)
+    rays_alive = np.arange(N, dtype=np.int32)
+    rays_t = nears.copy()
+    step = 0
+    while step < max_steps:
+        n_alive = rays_alive.shape[0]
+        if n_alive <= 0:
+            break
+        n_step = max(min(N // n_alive, 8), 1)
+        xyzs, dirs, deltas = rm.march_rays(n_alive, n_step, rays_alive, rays_t, o, d, S["bound"], S["density_bitfield"], S["cascade"], S["grid_size"], nears, fars, 128, False, dt_gamma, max_steps)
+        sigmas, rgbs = field_forward(torch.from_numpy(xyzs), torch.from_numpy(dirs), message, P)
+        sigmas = S.get("density_scale", 1) * sigmas
+        rm.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas.numpy(), rgbs.numpy(), deltas, ws, depth, image, T_thresh)
+        rays_alive = np.ascontiguousarray(rays_alive[rays_alive >= 0])
+        step += n_step
+    ws_t, depth_t, image_t = torch.from_numpy(ws), torch.from_numpy(depth), torch.from_numpy(image)
+    image_t = image_t + (1 - ws_t).unsqueeze(-1) * bg_color
+    nears_t, fars_t = torch.from_numpy(nears), torch.from_numpy(fars)
+    depth_t = torch.clamp(depth_t - nears_t, min=0) / (fars_t - nears_t)
+    return {"image": image_t.view(*prefix, 3), "depth": depth_t.view(*prefix)}
+
+
+def run_uniform(rays_o, rays_d, message, P, S, num_steps=512, bg_color=1):
+    """NeRFRenderer.run with upsample_steps=0 and perturb=False, renderer_wtmk.py:125-253."""
+    prefix = rays_o.shape[:-1]
+    o, d = rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3)
+    N = o.shape[0]
+    aabb = torch.from_numpy(np.asarray(S["aabb"], np.float32))
+    nears, fars = rm.near_far_from_aabb(o.numpy(), d.numpy(), S["aabb"], S["min_near"])
+    nears, fars = torch.from_numpy(nears).unsqueeze(-1), torch.from_numpy(fars).unsqueeze(-1)
+    z = torch.linspace(0.0, 1.0, num_steps).unsqueeze(0).expand(N, num_steps)
+    z = nears + (fars - nears) * z
+    sample_dist = (fars - nears) / num_steps
+    xyzs = o.unsqueeze(-2) + d.unsqueeze(-2) * z.unsqueeze(-1)
+    xyzs = torch.min(torch.max(xyzs, aabb[:3]), aabb[3:])
+    dn = density(xyzs.reshape(-1, 3), message, P)
+    sigma = dn["sigma"].view(N, num_steps)
+    deltas = torch.cat([z[..., 1:] - z[..., :-1], sample_dist * torch.ones_like(z[..., :1])], dim=-1)
+    alphas = 1 - torch.exp(-deltas * S.get("density_scale", 1) * sigma)
+    shifted = torch.cat([torch.ones_like(alphas[..., :1]), 1 - alphas + 1e-15], dim=-1)
+    weights = alphas * torch.cumprod(shifted, dim=-1)[..., :-1]
+    mask = (weights > 1e-4).reshape(-1)
+    dirs = d.view(-1, 1, 3).expand_as(xyzs).reshape(-1, 3)
+    rgbs = torch.zeros(N * num_steps, 3)
+    if mask.any():
+        rgbs[mask] = color(dirs[mask], dn["geo_feat"][mask], P)
+    rgbs = rgbs.view(N, num_steps, 3)
+    ws = weights.sum(dim=-1)
+    depth = torch.sum(weights * ((z - nears) / (fars - nears)).clamp(0, 1), dim=-1)
+    image = torch.sum(weights.unsqueeze(-1) * rgbs, dim=-2) + (1 - ws).unsqueeze(-1) * bg_color
+    return {"image": image.view(*prefix, 3), "depth": depth.view(*prefix), "weights_sum": ws}
+
+
+def render(rays_o, rays_d, message, P, S, staged=False, max_ray_batch=4096, cuda_ray=True, training=True, **kw):
+    """NeRFRenderer.render, renderer_wtmk.py:541-575."""
+    def _run(o, d):
+        if not cuda_ray:
+            return run_uniform(o, d, message, P, S, **{k: kw[k] for k in ("num_steps", "bg_color") if k in kw})
+        keys = ("dt_gamma", "bg_color", "max_steps", "T_thresh")
+        fn = run_cuda_train if training else run_cuda_eval
+        return fn(o, d, message, P, S, **{k: kw[k] for k in keys if k in kw})
+    if not staged:
+        return _run(rays_o, rays_d)
+    B, N = rays_o.shape[:2]
+    depth, image = torch.empty(B, N), torch.empty(B, N, 3)
+    for b in range(B):
+        for head in range(0, N, max_ray_batch):
+            tail = min(head + max_ray_batch, N)
+            r = _run(rays_o[b:b + 1, head:tail], rays_d[b:b + 1, head:tail])
+            depth[b:b + 1, head:tail], image[b:b + 1, head:tail] = r["depth"].detach(), r["image"].detach()
+    return {"depth": depth, "image": image}
+
+
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)  # hidden_models.py:13
+
+
+def normalize_img(x):
+    mean = torch.tensor(IMAGENET_MEAN, dtype=x.dtype).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, dtype=x.dtype).view(1, 3, 1, 1)
+    return (x - mean) / std
+
+
+def train_step(block_o, block_d, content_o, content_d, gt_rgb, message, P, S, decoder, lambda_w=1.0, lambda_i=1.0, **kw):
+    """Trainer.train_step with distortion 'none', 3-channel images and loss_w='bce',
+    nerf/utils_wtmk_disen.py:579-646 (+ :441 for the loss)."""
+    out = run_cuda_train(block_o, block_d, message, P, S, bg_color=1, **kw)
+    pred = torch.clamp(out["image"], min=0, max=1)                    # :592
+    decoded = decoder(normalize_img(pred.permute(0, 3, 1, 2)))         # :595
+    cont = run_cuda_train(content_o, content_d, message, P, S, bg_color=1, **kw)  # :616
+    lossi = ((cont["image"] - gt_rgb) ** 2).mean()                     # :638 (MSELoss(reduction='none').mean())
+    lossw = torch.nn.functional.binary_cross_entropy_with_logits(decoded * 10.0, message.unsqueeze(-1), reduction="mean")  # :441,641
+    loss = lambda_w * lossw + lambda_i * lossi                         # :644
+    return {"pred_rgb": pred, "content_pred_rgb": cont["image"], "decoded": decoded, "lossi": lossi, "lossw": lossw,
+            "loss": loss, "block": out, "content": cont}
+
+
+def bit_accuracy(pred, truth):
+    """BIT_ACC.update, nerf/utils_wtmk_disen.py:340-343."""
+    same = ~torch.logical_xor(pred > 0, truth > 0)
+    return (torch.sum(same, dim=-1) / same.shape[-1])
+
+
+def psnr(pred, truth):
+    """PSNRMeter.update, nerf/utils_wtmk_disen.py:229-233."""
+    p, t = np.asarray(pred), np.asarray(truth)
+    return float(-10 * np.log10(np.mean((p - t) ** 2)))
+
+
+def get_rays(poses, intrinsics, H, W, inds=None):
+    """get_rays without the random index draw, nerf/utils_wtmk_disen.py:59-143 (inds given or all pixels)."""
+    B = poses.shape[0]
+    fx, fy, cx, cy = intrinsics
+    i, j = torch.meshgrid(torch.linspace(0, W - 1, W), torch.linspace(0, H - 1, H), indexing="ij")
+    i = i.t().reshape(1, H * W).expand(B, H * W) + 0.5
+    j = j.t().reshape(1, H * W).expand(B, H * W) + 0.5
+    if inds is not None:
+        i, j = torch.gather(i, -1, inds), torch.gather(j, -1, inds)
+    zs = torch.ones_like(i)
+    directions = torch.stack(((i - cx) / fx * zs, (j - cy) / fy * zs, zs), dim=-1)
+    directions = directions / torch.norm(directions, dim=-1, keepdim=True)
+    rays_d = directions @ poses[:, :3, :3].transpose(-1, -2)
+    rays_o = poses[..., :3, 3][..., None, :].expand_as(rays_d)
+    return rays_o, rays_d
