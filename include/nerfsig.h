@@ -1,0 +1,175 @@
+/*
+ * nerfsig.h -- C ABI of libnerfsig.so, the MI355X (gfx950) native layer of the watermarked-NeRF
+ * render path.
+ *
+ * This is the drop-in boundary for the reference's native surface
+ *   /root/reference/raymarching/src/raymarching.h:7-17  (prototypes)
+ *   /root/reference/raymarching/src/bindings.cpp:5-18   (pybind module `_raymarching`)
+ * plus the encoder / MLP evaluations the reference performs through PyTorch op chains
+ * (hash_encoding.py, hash_encoding_wtmk_bit.py) and tiny-cuda-nn (nerf/network_wtmk_tcnn.py:52-88).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in `_host`;
+ *   - the caller owns every buffer; nothing is allocated or freed inside; no call synchronises;
+ *   - all kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - arrays are dense row-major fp32 / int32 / uint8 exactly as the reference's tensors;
+ *   - return value 0 = enqueued; non-zero = rejected or launch failure, message in nsig_last_error();
+ *   - calls on distinct streams are thread-safe.
+ *
+ * Ordering contract of the training march (differs from the reference by being deterministic):
+ * ray n owns slot n of `rays`, and its points start at the exclusive prefix sum of the counts of
+ * rays < n; the reference hands out both with atomicAdd (raymarching.cu:405-406) in arrival order.
+ */
+#ifndef NERFSIG_H_
+#define NERFSIG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSIG_OK 0
+#define NSIG_ERR_ARG 1
+#define NSIG_ERR_LAUNCH 2
+
+#define NSIG_TABLE_ROWS (1u << 19) /* log2_hashmap_size = 19, hash_encoding.py:49 */
+#define NSIG_BASE_LEVELS 16
+#define NSIG_MAX_MESSAGE_DIM 64
+
+typedef void *nsig_stream_t;
+
+int nsig_abi_version(void);
+const char *nsig_last_error(void);
+
+/* ------------------------------------------------------------------ raymarching: utilities */
+
+/* replaces near_far_from_aabb (raymarching.h:7, raymarching.cu:92-156) */
+int rm_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float min_near,
+                          float *nears, float *fars, nsig_stream_t stream);
+/* replaces sph_from_ray (raymarching.h:8, raymarching.cu:163-209) */
+int rm_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords,
+                    nsig_stream_t stream);
+/* replaces morton3D / morton3D_invert (raymarching.h:9-10, raymarching.cu:214-260) */
+int rm_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, nsig_stream_t stream);
+int rm_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, nsig_stream_t stream);
+/* replaces packbits (raymarching.h:11, raymarching.cu:268-300); n_bytes = C*H^3/8 */
+int rm_packbits(const float *grid, uint32_t n_bytes, float density_thresh, uint8_t *bitfield, nsig_stream_t stream);
+
+/* ------------------------------------------------------------------ raymarching: training */
+
+/*
+ * march_rays_train (raymarching.h:13, raymarching.cu:312-490) as three enqueues:
+ *   count : per-ray sample count + the parameter t of every sample (t_rec[n*max_steps + s])
+ *   scan  : rays[n] = (n, exclusive-prefix offset, count); counter[0] = total, counter[1] = N
+ *   write : xyzs/dirs/deltas rows [0,total) from t_rec; rows [total, M) are zero-filled
+ * A ray whose range would exceed M is recorded in `rays` but writes nothing (raymarching.cu:416).
+ * t_rec needs rm_march_train_scratch_bytes(N, max_steps) bytes; it need not be initialised.
+ */
+size_t rm_march_train_scratch_bytes(uint32_t N, uint32_t max_steps);
+int rm_march_train_count(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
+                         uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float *nears,
+                         const float *fars, const float *noises, int32_t *counts, float *t_rec,
+                         nsig_stream_t stream);
+int rm_march_train_scan(const int32_t *counts, uint32_t N, int32_t *rays, int32_t *counter, nsig_stream_t stream);
+int rm_march_train_write(const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                         uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears, const float *noises,
+                         const float *t_rec, const int32_t *rays, const int32_t *counter, float *xyzs, float *dirs,
+                         float *deltas, nsig_stream_t stream);
+
+/* replaces composite_rays_train_forward (raymarching.h:14, raymarching.cu:501-588) */
+int rm_composite_train_fwd(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays,
+                           uint32_t M, uint32_t N, float T_thresh, float *weights_sum, float *depth, float *image,
+                           nsig_stream_t stream);
+/* replaces composite_rays_train_backward (raymarching.h:15, raymarching.cu:602-693).
+ * grad_sigmas / grad_rgbs are fully written (rows the reference leaves at their pre-zeroed value are
+ * written as zero), so the caller does not have to clear them (cf. raymarching.py:283-284). */
+int rm_composite_train_bwd(const float *grad_weights_sum, const float *grad_image, const float *sigmas,
+                           const float *rgbs, const float *deltas, const int32_t *rays, const float *weights_sum,
+                           const float *image, uint32_t M, uint32_t N, float T_thresh, float *grad_sigmas,
+                           float *grad_rgbs, nsig_stream_t stream);
+
+/* ------------------------------------------------------------------ raymarching: inference */
+
+/* replaces march_rays (raymarching.h:17, raymarching.cu:701-815); all M_rows rows of the outputs are
+ * written (unused slots as zero), so they need not be pre-zeroed (cf. raymarching.py:334-336). */
+int rm_march(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,
+             const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+             const uint8_t *grid, const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
+             const float *noises, uint32_t M_rows, nsig_stream_t stream);
+/* replaces composite_rays (raymarching.h:18, raymarching.cu:819-914) */
+int rm_composite(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
+                 const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum, float *depth,
+                 float *image, nsig_stream_t stream);
+/* replaces the host-side `rays_alive[rays_alive >= 0]` (nerf/renderer_wtmk.py:363): stable compaction of
+ * the non-negative entries; *n_out (device) receives the survivor count. */
+int rm_compact_alive(const int32_t *rays_alive, uint32_t n_alive, int32_t *rays_alive_out, int32_t *n_out,
+                     nsig_stream_t stream);
+
+/* ------------------------------------------------------------------ hash grids */
+
+/* S[t] = sum_i tables[i][t] over the D selected codebook tables (the tables 2i+bit_i of
+ * hash_encoding_wtmk_bit.py:110).  Interpolation is linear and every codebook level shares one
+ * resolution and hash (network_wtmk_tcnn.py:43-44), so interpolating S equals summing the D
+ * interpolations (hash_encoding_wtmk_bit.py:116).  tables_host: host array of D device pointers. */
+int hg_codebook_presum(const float *const *tables_host, uint32_t D, float *S, nsig_stream_t stream);
+
+/* HashEmbedder.forward (hash_encoding.py:96-111) [+ codebook added into channels 30:32,
+ * network_wtmk_tcnn.py:106, when S != NULL].  x01 in [0,1]; feat is [M,32]. */
+int hg_encode_fwd(const float *x01, uint32_t M, const float *const *base_tables_host, const float *S, float *feat,
+                  nsig_stream_t stream);
+
+/* HashEmbedder(msg).forward evaluated literally: D separate gathers, summed (hash_encoding_wtmk_bit.py:99-116).
+ * out is [M,2]. */
+int hg_codebook_encode_fwd(const float *x01, uint32_t M, const float *const *tables_host, uint32_t D, float *out,
+                           nsig_stream_t stream);
+
+/* Backward of the codebook lookup w.r.t. the tables: G[row] += w_corner * dfeat for the 8 corners of every
+ * point.  All D selected tables receive this same gradient.  G is [T,2] and is accumulated into. */
+int hg_codebook_bwd(const float *x01, uint32_t M, const float *dfeat, float *G, nsig_stream_t stream);
+
+/* grads[i][t] (+)= G[t] for the D selected tables; grads_host: host array of D device pointers. */
+int hg_fanout_grad(const float *G, float *const *grads_host, uint32_t D, int accumulate, nsig_stream_t stream);
+
+/* Test/diagnostic: hashed rows [M,8] (int32) and interpolation weights [M,3] of one level. */
+int hg_level_lookup(const float *x01, uint32_t M, float resolution, int32_t *rows, float *weights,
+                    nsig_stream_t stream);
+
+/* ------------------------------------------------------------------ field network */
+
+/* Re-lays the two flat tcnn-style parameter vectors (sigma: 3072, color: 7168 fp32, layout in
+ * INTEGRATION.md) into split-bf16 MFMA operand order.  packed needs mlp_packed_bytes() bytes. */
+size_t mlp_packed_bytes(void);
+int mlp_pack_weights(const float *sigma_params, const float *color_params, void *packed, nsig_stream_t stream);
+
+#define FIELD_MASK_WORDS 6 /* uint32 words of ReLU masks per point saved by field_fwd for field_bwd */
+
+/*
+ * NeRFNetwork.forward (nerf/network_wtmk_tcnn.py:97-124) for M points, fused:
+ *   x01 = (x+bound)/(2 bound); 16-level hash encode (+ codebook via S, may be NULL = clean model);
+ *   sigma MLP 32->64->16, sigma = exp(h0); SH degree 4 of d; color MLP 32->64->64->3, sigmoid.
+ * Outputs: sigmas [M]; rgbs [M,3] (NULL: skip the color branch = NeRFNetwork.density);
+ *          geo_feat [M,15] (optional); masks [M_pad32, 6] uint32 (optional, needed by field_bwd).
+ */
+int field_fwd(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *const *base_tables_host,
+              const float *S, const void *packed, float *sigmas, float *rgbs, float *geo_feat, uint32_t *masks,
+              nsig_stream_t stream);
+
+/* NeRFNetwork.color (nerf/network_wtmk_tcnn.py:147-176) without the mask: rgb from dirs + geo_feat. */
+int field_color_fwd(const float *dirs, const float *geo_feat, uint32_t M, const void *packed, float *rgbs,
+                    nsig_stream_t stream);
+
+/*
+ * Backward of field_fwd w.r.t. the codebook: (dL/dsigma, dL/drgb) -> MLP input gradients (weights are
+ * frozen, nerf/network_wtmk_tcnn.py:90-95) -> d feature[30:32] -> scatter into G [T,2] (accumulated).
+ * dfeat_out [M,2] (optional) receives d feature[30:32] instead of / in addition to the scatter (G may be NULL).
+ */
+int field_bwd(const float *xyzs, uint32_t M, float bound, const float *grad_sigmas, const float *grad_rgbs,
+              const float *sigmas, const float *rgbs, const uint32_t *masks, const void *packed, float *G,
+              float *dfeat_out, nsig_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFSIG_H_ */

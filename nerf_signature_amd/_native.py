@@ -1,0 +1,129 @@
+"""ctypes loader of libnerfsig.so (the C ABI declared in include/nerfsig.h).
+
+The library is the product path; there is no fallback.  If it is missing the import-time error says
+how to build it, and every call checks its return code and raises with nsig_last_error().
+"""
+import ctypes
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libnerfsig.so")
+
+_c = ctypes
+_vp, _u32, _fl, _int, _sz = _c.c_void_p, _c.c_uint32, _c.c_float, _c.c_int, _c.c_size_t
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/nerfsig.h one to one.
+SIGNATURES = {
+    "nsig_abi_version": [],
+    "nsig_last_error": [],
+    "rm_near_far_from_aabb": [_vp, _vp, _vp, _u32, _fl, _vp, _vp, _vp],
+    "rm_sph_from_ray": [_vp, _vp, _fl, _u32, _vp, _vp],
+    "rm_morton3D": [_vp, _u32, _vp, _vp],
+    "rm_morton3D_invert": [_vp, _u32, _vp, _vp],
+    "rm_packbits": [_vp, _u32, _fl, _vp, _vp],
+    "rm_march_train_scratch_bytes": [_u32, _u32],
+    "rm_march_train_count": [_vp, _vp, _vp, _fl, _fl, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "rm_march_train_scan": [_vp, _u32, _vp, _vp, _vp],
+    "rm_march_train_write": [_vp, _vp, _fl, _fl, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "rm_composite_train_fwd": [_vp, _vp, _vp, _vp, _u32, _u32, _fl, _vp, _vp, _vp, _vp],
+    "rm_composite_train_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _fl, _vp, _vp, _vp],
+    "rm_march": [_u32, _u32, _vp, _vp, _vp, _vp, _fl, _fl, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+    "rm_composite": [_u32, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "rm_compact_alive": [_vp, _u32, _vp, _vp, _vp],
+    "hg_codebook_presum": [_vp, _u32, _vp, _vp],
+    "hg_encode_fwd": [_vp, _u32, _vp, _vp, _vp, _vp],
+    "hg_codebook_encode_fwd": [_vp, _u32, _vp, _u32, _vp, _vp],
+    "hg_codebook_bwd": [_vp, _u32, _vp, _vp, _vp],
+    "hg_fanout_grad": [_vp, _vp, _u32, _int, _vp],
+    "hg_level_lookup": [_vp, _u32, _fl, _vp, _vp, _vp],
+    "mlp_packed_bytes": [],
+    "mlp_pack_weights": [_vp, _vp, _vp, _vp],
+    "field_fwd": [_vp, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "field_color_fwd": [_vp, _vp, _u32, _vp, _vp, _vp],
+    "field_bwd": [_vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+}
+_RESTYPES = {"nsig_last_error": _c.c_char_p, "rm_march_train_scratch_bytes": _sz, "mlp_packed_bytes": _sz}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libnerfsig.so; raises if the library is missing (there is no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(f"{LIB_PATH} not found: the HIP extension is required (no fallback). "
+                          f"Build it with `python -m nerf_signature_amd.build`.")
+    _lib = ctypes.CDLL(LIB_PATH)
+    _lib.nsig_last_error.restype = _c.c_char_p
+    return _lib
+
+
+_bound = {}
+
+
+def fn(name):
+    """Bound entry point `name` with the argtypes of include/nerfsig.h; raises if the library lacks it."""
+    f = _bound.get(name)
+    if f is None:
+        lib = load()
+        try:
+            f = getattr(lib, name)
+        except AttributeError as e:
+            raise NativeError(f"libnerfsig.so does not export {name}; rebuild with `python -m nerf_signature_amd.build --force`") from e
+        f.argtypes = SIGNATURES[name]
+        f.restype = _RESTYPES.get(name, _int)
+        _bound[name] = f
+    return f
+
+
+def verify_exports():
+    """Every symbol declared in the header must be exported (used by the CPU test-suite and build())."""
+    for name in SIGNATURES:
+        fn(name)
+    return sorted(SIGNATURES)
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; non-zero return raises with the library's message."""
+    rc = fn(name)(*args)
+    if rc != 0:
+        msg = load().nsig_last_error().decode("utf-8", "replace")
+        raise (ValueError if rc == 1 else NativeError)(f"{name} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous and on the GPU."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError("libnerfsig entry points take device tensors; got a CPU tensor")
+    if not t.is_contiguous():
+        raise ValueError("libnerfsig entry points take contiguous tensors")
+    return t.data_ptr()
+
+
+def stream():
+    """The current torch stream as a hipStream_t, so launches compose with autograd/autocast/RCCL streams."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr_array(tensors):
+    """Host array of device pointers (for the `*_host` pointer-table arguments)."""
+    arr = (ctypes.c_void_p * len(tensors))(*[ptr(t) for t in tensors])
+    return arr
+
+
+def check(t, dtype, name, shape_last=None):
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if shape_last is not None and t.shape[-1] != shape_last:
+        raise ValueError(f"{name}: expected last dimension {shape_last}, got {tuple(t.shape)}")
+    return t

@@ -1,0 +1,58 @@
+"""Builds libnerfsig.so (hand-written HIP for gfx950) in-tree with plain hipcc.
+
+    python -m nerf_signature_amd.build [--force]
+
+No torch.utils.cpp_extension, no hipify: the sources are HIP and the library has a C ABI
+(include/nerfsig.h), so it is a single `hipcc -shared` of csrc/*.hip.  hipcc cross-compiles for
+gfx950 without a GPU, so this also runs in the build container.
+"""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIB_DIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIB_DIR, "libnerfsig.so")
+ARCH = "gfx950"
+
+# -ffp-contract=off: fused multiply-adds are written explicitly so integer results match the CPU oracle.
+FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
+         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(PKG, "..", "include", "nerfsig.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(LIB_DIR, exist_ok=True)
+    objs = []
+    for src in sources():
+        obj = os.path.join(LIB_DIR, os.path.basename(src)[:-4] + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), *(os.path.getmtime(os.path.join(CSRC, h)) for h in os.listdir(CSRC) if h.endswith(".h"))):
+            cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,197 @@
+// Hash-grid kernels for gfx950: codebook pre-sum, stand-alone encoders, codebook backward scatter,
+// gradient fan-out.  Behavioural references: /root/reference/hash_encoding.py:96-111 (base encoder),
+// /root/reference/hash_encoding_wtmk_bit.py:99-116 (codebook encoder) and their autograd.
+//
+// Two algebraic facts of the reference drive the design (both verified against the reference itself in
+// tests/test_oracle_golden.py):
+//   (1) all D codebook levels have the same resolution (2048) and hash, hence identical corner rows and
+//       weights, and the encoder output is the SUM of the D interpolations.  Interpolation is linear in
+//       the table, so  sum_i lerp(table_i) == lerp(sum_i table_i):  one streaming pass builds
+//       S = sum_i table_{2i+bit_i}  (D x 4 MiB read, 4 MiB written) and every point then needs ONE
+//       8-corner gather in S instead of D of them;
+//   (2) for the same reason every selected table receives the SAME gradient G[T,2]; the backward
+//       scatters once into G and a fan-out pass copies G into the D gradient tensors autograd expects.
+#include "hashgrid.h"
+
+namespace nsig {
+
+// S[e] = sum_i tables[i][e]; float4 per lane (1 KiB per wave-instruction), D independent streams.
+__global__ void __launch_bounds__(256) k_codebook_presum(CodebookPtrs tabs, uint32_t D, float4 *__restrict__ S) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;  // float4 index, T*2/4 of them
+    if (e >= NSIG_TABLE_ROWS / 2) return;
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+    uint32_t i = 0;
+    for (; i + 4 <= D; i += 4) {  // four loads in flight per lane
+        const float4 a = reinterpret_cast<const float4 *>(tabs.p[i])[e];
+        const float4 b = reinterpret_cast<const float4 *>(tabs.p[i + 1])[e];
+        const float4 c = reinterpret_cast<const float4 *>(tabs.p[i + 2])[e];
+        const float4 d = reinterpret_cast<const float4 *>(tabs.p[i + 3])[e];
+        acc.x = (((acc.x + a.x) + b.x) + c.x) + d.x;
+        acc.y = (((acc.y + a.y) + b.y) + c.y) + d.y;
+        acc.z = (((acc.z + a.z) + b.z) + c.z) + d.z;
+        acc.w = (((acc.w + a.w) + b.w) + c.w) + d.w;
+    }
+    for (; i < D; ++i) {
+        const float4 a = reinterpret_cast<const float4 *>(tabs.p[i])[e];
+        acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+    }
+    S[e] = acc;
+}
+
+// Stand-alone base encoder (+ optional codebook via S): one lane per (point, level); a wave covers
+// 4 points x 16 levels and stores 4 full 128-byte feature rows.
+__global__ void __launch_bounds__(256) k_encode(const float *__restrict__ x01, uint32_t M, TablePtrs base, LevelGeom geom,
+                                                const float *__restrict__ S, float *__restrict__ feat) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t m = gid >> 4, l = gid & 15u;
+    if (m >= M) return;
+    const float x = x01[3 * (size_t)m], y = x01[3 * (size_t)m + 1], z = x01[3 * (size_t)m + 2];
+    float2 f = encode_level(base.p[l], x, y, z, geom.cell[l]);
+    if (S != nullptr && l == 15u) {  // network_wtmk_tcnn.py:106: codebook feature added into channels 30:32
+        const float2 c = encode_level(S, x, y, z, geom.cell[NSIG_BASE_LEVELS]);
+        f.x = f.x + c.x;
+        f.y = f.y + c.y;
+    }
+    reinterpret_cast<float2 *>(feat)[(size_t)m * 16 + l] = f;
+}
+
+// The codebook encoder evaluated literally (D gathers per corner, summed in bit order).
+__global__ void __launch_bounds__(256) k_codebook_encode(const float *__restrict__ x01, uint32_t M, CodebookPtrs tabs, uint32_t D,
+                                                         float cell, float *__restrict__ out) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    Corner8 c;
+    corner_rows(x01[3 * (size_t)m], x01[3 * (size_t)m + 1], x01[3 * (size_t)m + 2], cell, c);
+    float2 acc = {0.f, 0.f};
+    for (uint32_t i = 0; i < D; ++i) {
+        float2 e[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = reinterpret_cast<const float2 *>(tabs.p[i])[c.row[k]];
+        const float2 v = trilerp(e, c.wx, c.wy, c.wz);
+        acc.x += v.x;
+        acc.y += v.y;
+    }
+    reinterpret_cast<float2 *>(out)[m] = acc;
+}
+
+// G[row_k] += w_k * dfeat for the 8 corners of every point: 16 lanes per point, lane = (corner, feature),
+// so the two features of a row are adjacent lanes (one 8-byte segment per pair of lanes).
+__global__ void __launch_bounds__(256) k_codebook_bwd(const float *__restrict__ x01, uint32_t M, const float *__restrict__ dfeat,
+                                                      float cell, float *__restrict__ G) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t m = gid >> 4, k = (gid >> 1) & 7u, f = gid & 1u;
+    if (m >= M) return;
+    const float g = dfeat[2 * (size_t)m + f];
+    if (g == 0.0f) return;  // padded rows and rays past early termination carry exact zeros
+    Corner8 c;
+    corner_rows(x01[3 * (size_t)m], x01[3 * (size_t)m + 1], x01[3 * (size_t)m + 2], cell, c);
+    atomicAdd(G + 2 * (size_t)c.row[k] + f, corner_weight(c, (int)k, g));
+}
+
+// grads[i][e] (+)= G[e]: float4 per lane, D output streams.
+__global__ void __launch_bounds__(256) k_fanout(const float4 *__restrict__ G, GradPtrs grads, uint32_t D, int accumulate) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= NSIG_TABLE_ROWS / 2) return;
+    const float4 g = G[e];
+    for (uint32_t i = 0; i < D; ++i) {
+        float4 *dst = reinterpret_cast<float4 *>(grads.p[i]) + e;
+        if (accumulate) {
+            float4 v = *dst;
+            v.x += g.x; v.y += g.y; v.z += g.z; v.w += g.w;
+            *dst = v;
+        } else *dst = g;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_level_lookup(const float *__restrict__ x01, uint32_t M, float cell, int32_t *__restrict__ rows,
+                                                      float *__restrict__ weights) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    Corner8 c;
+    corner_rows(x01[3 * (size_t)m], x01[3 * (size_t)m + 1], x01[3 * (size_t)m + 2], cell, c);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rows[8 * (size_t)m + k] = (int32_t)c.row[k];
+    weights[3 * (size_t)m] = c.wx; weights[3 * (size_t)m + 1] = c.wy; weights[3 * (size_t)m + 2] = c.wz;
+}
+
+}  // namespace nsig
+
+using namespace nsig;
+
+static int aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+NSIG_EXPORT int hg_codebook_presum(const float *const *tables_host, uint32_t D, float *S, nsig_stream_t stream) {
+    NSIG_REQUIRE(tables_host && S, "hg_codebook_presum: null pointer");
+    NSIG_REQUIRE(D >= 1 && D <= NSIG_MAX_MESSAGE_DIM, "hg_codebook_presum: D=%u out of range [1,%d]", D, NSIG_MAX_MESSAGE_DIM);
+    CodebookPtrs tabs{};
+    for (uint32_t i = 0; i < D; ++i) {
+        NSIG_REQUIRE(tables_host[i] && aligned16(tables_host[i]), "hg_codebook_presum: table %u is null or not 16-byte aligned", i);
+        tabs.p[i] = tables_host[i];
+    }
+    NSIG_REQUIRE(aligned16(S), "hg_codebook_presum: S must be 16-byte aligned");
+    k_codebook_presum<<<NSIG_TABLE_ROWS / 2 / 256, 256, 0, as_stream(stream)>>>(tabs, D, reinterpret_cast<float4 *>(S));
+    return check_launch("hg_codebook_presum");
+}
+
+static int fill_base(const float *const *host, TablePtrs &base, const char *who) {
+    NSIG_REQUIRE(host, "%s: null base table list", who);
+    for (int l = 0; l < NSIG_BASE_LEVELS; ++l) {
+        NSIG_REQUIRE(host[l] != nullptr, "%s: base table %d is null", who, l);
+        base.p[l] = host[l];
+    }
+    return NSIG_OK;
+}
+
+NSIG_EXPORT int hg_encode_fwd(const float *x01, uint32_t M, const float *const *base_tables_host, const float *S, float *feat,
+                              nsig_stream_t stream) {
+    NSIG_REQUIRE(x01 && feat, "hg_encode_fwd: null pointer");
+    TablePtrs base{};
+    if (int e = fill_base(base_tables_host, base, "hg_encode_fwd")) return e;
+    if (M == 0) return NSIG_OK;
+    NSIG_REQUIRE(M <= (1u << 27), "hg_encode_fwd: M=%u too large", M);
+    k_encode<<<ceil_div(M * 16u, 256), 256, 0, as_stream(stream)>>>(x01, M, base, make_level_geom(), S, feat);
+    return check_launch("hg_encode_fwd");
+}
+
+NSIG_EXPORT int hg_codebook_encode_fwd(const float *x01, uint32_t M, const float *const *tables_host, uint32_t D, float *out,
+                                       nsig_stream_t stream) {
+    NSIG_REQUIRE(x01 && tables_host && out, "hg_codebook_encode_fwd: null pointer");
+    NSIG_REQUIRE(D >= 1 && D <= NSIG_MAX_MESSAGE_DIM, "hg_codebook_encode_fwd: D=%u out of range", D);
+    CodebookPtrs tabs{};
+    for (uint32_t i = 0; i < D; ++i) {
+        NSIG_REQUIRE(tables_host[i] != nullptr, "hg_codebook_encode_fwd: table %u is null", i);
+        tabs.p[i] = tables_host[i];
+    }
+    if (M == 0) return NSIG_OK;
+    k_codebook_encode<<<ceil_div(M, 256), 256, 0, as_stream(stream)>>>(x01, M, tabs, D, 1.0f / kCodebookResolution, out);
+    return check_launch("hg_codebook_encode_fwd");
+}
+
+NSIG_EXPORT int hg_codebook_bwd(const float *x01, uint32_t M, const float *dfeat, float *G, nsig_stream_t stream) {
+    NSIG_REQUIRE(x01 && dfeat && G, "hg_codebook_bwd: null pointer");
+    if (M == 0) return NSIG_OK;
+    NSIG_REQUIRE(M <= (1u << 27), "hg_codebook_bwd: M=%u too large", M);
+    k_codebook_bwd<<<ceil_div(M * 16u, 256), 256, 0, as_stream(stream)>>>(x01, M, dfeat, 1.0f / kCodebookResolution, G);
+    return check_launch("hg_codebook_bwd");
+}
+
+NSIG_EXPORT int hg_fanout_grad(const float *G, float *const *grads_host, uint32_t D, int accumulate, nsig_stream_t stream) {
+    NSIG_REQUIRE(G && grads_host, "hg_fanout_grad: null pointer");
+    NSIG_REQUIRE(D >= 1 && D <= NSIG_MAX_MESSAGE_DIM, "hg_fanout_grad: D=%u out of range", D);
+    GradPtrs grads{};
+    for (uint32_t i = 0; i < D; ++i) {
+        NSIG_REQUIRE(grads_host[i] && aligned16(grads_host[i]), "hg_fanout_grad: gradient %u is null or not 16-byte aligned", i);
+        grads.p[i] = grads_host[i];
+    }
+    NSIG_REQUIRE(aligned16(G), "hg_fanout_grad: G must be 16-byte aligned");
+    k_fanout<<<NSIG_TABLE_ROWS / 2 / 256, 256, 0, as_stream(stream)>>>(reinterpret_cast<const float4 *>(G), grads, D, accumulate);
+    return check_launch("hg_fanout_grad");
+}
+
+NSIG_EXPORT int hg_level_lookup(const float *x01, uint32_t M, float resolution, int32_t *rows, float *weights, nsig_stream_t stream) {
+    NSIG_REQUIRE(x01 && rows && weights, "hg_level_lookup: null pointer");
+    NSIG_REQUIRE(resolution >= 1.0f, "hg_level_lookup: resolution must be >= 1");
+    if (M == 0) return NSIG_OK;
+    k_level_lookup<<<ceil_div(M, 256), 256, 0, as_stream(stream)>>>(x01, M, 1.0f / resolution, rows, weights);
+    return check_launch("hg_level_lookup");
+}

@@ -1,0 +1,604 @@
+// Ray-marching kernels for gfx950: aabb intersection, morton / bitfield utilities, the occupancy-grid
+// marcher (training: count -> scan -> write; inference: burst march + device-side compaction) and the
+// front-to-back compositor (forward / backward).
+//
+// Behavioural reference: /root/reference/raymarching/src/raymarching.cu (cited per kernel).  The
+// structure is not the reference's: the training march is split so that the serial, divergent part
+// (walking the occupancy grid) runs once and only records the parameter t of every sample; offsets
+// come from a deterministic prefix sum instead of atomics; and the point buffers are then filled by
+// one fully parallel, coalesced pass that also writes the zero padding (no N*max_steps memset).
+//
+// Built with -ffp-contract=off: every fused multiply-add below is explicit, so the integer outputs
+// (sample counts) are reproducible bit-for-bit against the CPU oracle (see oracle/raymarch_ref.c).
+#include "common.h"
+
+#include <float.h>
+
+namespace nsig {
+
+constexpr float kSqrt3 = 1.7320508075688772f;
+constexpr float kInvPi = 0.3183098861837907f;
+
+// ----------------------------------------------------------------------------- small utilities
+
+__global__ void k_near_far(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                           const float *__restrict__ aabb, uint32_t N, float min_near, float *__restrict__ nears,
+                           float *__restrict__ fars) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float tmin = 0.f, tmax = 0.f;
+    bool miss = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float o = rays_o[3 * n + a];
+        const float inv = 1.0f / rays_d[3 * n + a];
+        float lo = (aabb[a] - o) * inv;
+        float hi = (aabb[a + 3] - o) * inv;
+        if (lo > hi) { const float s = lo; lo = hi; hi = s; }
+        if (a == 0) { tmin = lo; tmax = hi; }
+        else if (!miss) {
+            if (tmin > hi || lo > tmax) miss = true;
+            else { if (lo > tmin) tmin = lo; if (hi < tmax) tmax = hi; }
+        }
+    }
+    if (miss) { nears[n] = FLT_MAX; fars[n] = FLT_MAX; return; }
+    nears[n] = tmin < min_near ? min_near : tmin;
+    fars[n] = tmax;
+}
+
+__global__ void k_sph_from_ray(const float *__restrict__ rays_o, const float *__restrict__ rays_d, float radius,
+                               uint32_t N, float *__restrict__ coords) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
+    const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
+    const float A = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    const float B = fmaf(oz, dz, fmaf(oy, dy, ox * dx));
+    const float C = fmaf(oz, oz, fmaf(oy, oy, ox * ox)) - radius * radius;
+    const float t = (-B + sqrtf(B * B - A * C)) / A;
+    const float x = fmaf(t, dx, ox), y = fmaf(t, dy, oy), z = fmaf(t, dz, oz);
+    coords[2 * n] = 2.0f * atan2f(sqrtf(fmaf(z, z, x * x)), y) * kInvPi - 1.0f;
+    coords[2 * n + 1] = atan2f(z, x) * kInvPi;
+}
+
+__global__ void k_morton(const int32_t *__restrict__ coords, uint32_t N, int32_t *__restrict__ indices) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    indices[n] = (int32_t)morton3((uint32_t)coords[3 * n], (uint32_t)coords[3 * n + 1], (uint32_t)coords[3 * n + 2]);
+}
+
+__global__ void k_morton_invert(const int32_t *__restrict__ indices, uint32_t N, int32_t *__restrict__ coords) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int32_t v = indices[n];
+    coords[3 * n] = (int32_t)compact3((uint32_t)v);
+    coords[3 * n + 1] = (int32_t)compact3((uint32_t)(v >> 1));
+    coords[3 * n + 2] = (int32_t)compact3((uint32_t)(v >> 2));
+}
+
+// One thread packs 4 bytes: two float4 loads per byte, 32 B/lane of reads in flight, dword store.
+__global__ void k_packbits(const float *__restrict__ grid, uint32_t n_bytes, float thresh, uint8_t *__restrict__ bits) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;  // word index
+    const uint32_t first = w * 4;
+    if (first >= n_bytes) return;
+    uint32_t word = 0;
+    const uint32_t nb = min(4u, n_bytes - first);
+    for (uint32_t b = 0; b < nb; ++b) {
+        const float4 lo = reinterpret_cast<const float4 *>(grid)[2 * (size_t)(first + b)];
+        const float4 hi = reinterpret_cast<const float4 *>(grid)[2 * (size_t)(first + b) + 1];
+        uint32_t v = (lo.x > thresh) | ((lo.y > thresh) << 1) | ((lo.z > thresh) << 2) | ((lo.w > thresh) << 3) |
+                     ((hi.x > thresh) << 4) | ((hi.y > thresh) << 5) | ((hi.z > thresh) << 6) | ((hi.w > thresh) << 7);
+        word |= v << (8 * b);
+    }
+    if (nb == 4 && (reinterpret_cast<uintptr_t>(bits) & 3) == 0) reinterpret_cast<uint32_t *>(bits)[w] = word;
+    else for (uint32_t b = 0; b < nb; ++b) bits[first + b] = (uint8_t)(word >> (8 * b));
+}
+
+// ----------------------------------------------------------------------------- the occupancy walk
+
+struct GridView {
+    const uint8_t *bits;
+    float bound, dt_gamma, dt_min, dt_max, inv_H, H3f, Hf, Cf, top;
+    double Hd;
+};
+
+__host__ inline GridView make_grid_view(const uint8_t *bits, float bound, float dt_gamma, uint32_t max_steps,
+                                        uint32_t C, uint32_t H) {
+    GridView g;
+    g.bits = bits;
+    g.bound = bound;
+    g.dt_gamma = dt_gamma;
+    g.dt_min = (2.0f * kSqrt3) / (float)max_steps;                      // raymarching.cu:345
+    g.dt_max = ((2.0f * kSqrt3) * (float)(1u << (C - 1))) / (float)H;   // raymarching.cu:346
+    g.inv_H = 1.0f / (float)H;
+    g.H3f = (float)(H * H * H);
+    g.Hf = (float)H;
+    g.Cf = (float)C;
+    g.top = (float)(H - 1);
+    g.Hd = (double)H;
+    return g;
+}
+
+struct Ray {
+    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
+    __device__ Ray(const float *o, const float *d)
+        : ox(o[0]), oy(o[1]), oz(o[2]), dx(d[0]), dy(d[1]), dz(d[2]), rdx(1.0f / d[0]), rdy(1.0f / d[1]), rdz(1.0f / d[2]) {}
+};
+
+__device__ inline float step_len(const GridView &g, float t) { return clampf(t * g.dt_gamma, g.dt_min, g.dt_max); }
+
+__device__ inline int cascade_of(const GridView &g, float x, float y, float z, float dt) {
+    // raymarching.cu:42-54,368: the coarser of "which shell is the point in" and "which shell matches dt".
+    const float m = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    int e_pos, e_dt;
+    frexpf(m, &e_pos);
+    frexpf((float)((double)(dt * g.Hf) * 0.5), &e_dt);
+    const int lp = (int)fminf(g.Cf - 1.0f, fmaxf(0.0f, (float)e_pos));
+    const int ls = (int)fminf(g.Cf - 1.0f, fmaxf(0.0f, (float)e_dt));
+    return max(lp, ls);
+}
+
+__device__ inline int cell_coord(const GridView &g, float v, float inv_extent) {
+    // raymarching.cu:374-376: float bracket, double product, float clamp, truncation.
+    return (int)clampf((float)(0.5 * (double)fmaf(v, inv_extent, 1.0f) * g.Hd), 0.0f, g.top);
+}
+
+// Tests the cell containing o + t d.  Occupied: returns true (x,y,z,dt valid).  Empty: returns false and
+// t_exit = parameter at which the ray leaves the cell (raymarching.cu:390-394).
+__device__ inline bool probe(const GridView &g, const Ray &r, float t, float &x, float &y, float &z, float &dt,
+                             float &t_exit) {
+    x = clampf(fmaf(t, r.dx, r.ox), -g.bound, g.bound);
+    y = clampf(fmaf(t, r.dy, r.oy), -g.bound, g.bound);
+    z = clampf(fmaf(t, r.dz, r.oz), -g.bound, g.bound);
+    dt = step_len(g, t);
+    const int level = cascade_of(g, x, y, z, dt);
+    const float extent = fminf(ldexpf(1.0f, level), g.bound);
+    const float inv_extent = 1.0f / extent;
+    const int nx = cell_coord(g, x, inv_extent), ny = cell_coord(g, y, inv_extent), nz = cell_coord(g, z, inv_extent);
+    const uint32_t bit = (uint32_t)((float)level * g.H3f + (float)morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+    if (g.bits[bit >> 3] & (1u << (bit & 7u))) return true;
+    const float fx = (fmaf(0.5f, copysignf(1.0f, r.dx), (float)nx + 0.5f) * g.inv_H) * 2.0f - 1.0f;
+    const float fy = (fmaf(0.5f, copysignf(1.0f, r.dy), (float)ny + 0.5f) * g.inv_H) * 2.0f - 1.0f;
+    const float fz = (fmaf(0.5f, copysignf(1.0f, r.dz), (float)nz + 0.5f) * g.inv_H) * 2.0f - 1.0f;
+    const float tx = fmaf(fx, extent, -x) * r.rdx;
+    const float ty = fmaf(fy, extent, -y) * r.rdy;
+    const float tz = fmaf(fz, extent, -z) * r.rdz;
+    t_exit = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    return false;
+}
+
+__device__ inline float leave_cell(const GridView &g, float t, float t_exit) {  // raymarching.cu:396-398
+    do { t += step_len(g, t); } while (t < t_exit);
+    return t;
+}
+
+__device__ inline float start_param(const GridView &g, float near, float noise) {  // raymarching.cu:348-351
+    return fmaf(step_len(g, near), noise, near);
+}
+
+// Training march, pass 1 (raymarching.cu:354-400): one lane per ray walks the grid once, records the
+// parameter of every occupied step.  Launched with few active lanes per wave so that a batch of a few
+// thousand rays spreads over all CUs -- the walk is a dependent chain of L1/L2 loads, so latency, not
+// lane utilisation, bounds it.
+__global__ void k_march_count(const float *__restrict__ rays_o, const float *__restrict__ rays_d, GridView g,
+                              uint32_t max_steps, uint32_t N, const float *__restrict__ nears,
+                              const float *__restrict__ fars, const float *__restrict__ noises,
+                              int32_t *__restrict__ counts, float *__restrict__ t_rec) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const Ray r(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n);
+    const float far = fars[n];
+    float t = start_param(g, nears[n], noises ? noises[n] : 0.0f);
+    float *rec = t_rec + (size_t)n * max_steps;
+    uint32_t cnt = 0;
+    float x, y, z, dt, t_exit;
+    while (t < far && cnt < max_steps) {
+        if (probe(g, r, t, x, y, z, dt, t_exit)) { rec[cnt++] = t; t += dt; }
+        else t = leave_cell(g, t, t_exit);
+    }
+    counts[n] = (int32_t)cnt;
+}
+
+// Training march, pass 2: exclusive prefix sum of the counts in ray-id order (replaces the two
+// atomicAdd reservations of raymarching.cu:405-406).  One 1024-thread workgroup; each thread owns a
+// contiguous chunk, wave-level scan by DPP shuffles, wave totals through LDS.
+__global__ void __launch_bounds__(1024) k_march_scan(const int32_t *__restrict__ counts, uint32_t N,
+                                                     int32_t *__restrict__ rays, int32_t *__restrict__ counter) {
+    __shared__ int32_t wave_tot[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t chunk = ceil_div(N, 1024u);
+    const uint32_t beg = min(N, tid * chunk), end = min(N, beg + chunk);
+    int32_t sum = 0;
+    for (uint32_t i = beg; i < end; ++i) sum += counts[i];
+    int32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t v = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += v;
+    }
+    if (lane == 63) wave_tot[wid] = incl;
+    __syncthreads();
+    int32_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int32_t v = wave_tot[w];
+        if (w < (int)wid) base += v;
+        total += v;
+    }
+    int32_t off = base + incl - sum;
+    for (uint32_t i = beg; i < end; ++i) {
+        const int32_t c = counts[i];
+        rays[3 * (size_t)i] = (int32_t)i;
+        rays[3 * (size_t)i + 1] = off;
+        rays[3 * (size_t)i + 2] = c;
+        off += c;
+    }
+    if (tid == 0) { counter[0] = total; counter[1] = (int32_t)N; }
+}
+
+// Training march, pass 3 (raymarching.cu:422-479 without the second walk): one lane per output row.
+__global__ void k_march_write(const float *__restrict__ rays_o, const float *__restrict__ rays_d, GridView g,
+                              uint32_t max_steps, uint32_t N, uint32_t M, const float *__restrict__ nears,
+                              const float *__restrict__ noises, const float *__restrict__ t_rec,
+                              const int32_t *__restrict__ rays, const int32_t *__restrict__ counter,
+                              float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas) {
+    const uint32_t total = (uint32_t)counter[0];
+    for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+        float px = 0, py = 0, pz = 0, qx = 0, qy = 0, qz = 0, d0 = 0, d1 = 0;
+        if (m < total) {
+            // last ray whose offset <= m (rays with no samples share their successor's offset)
+            uint32_t lo = 0, hi = N;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((uint32_t)rays[3 * (size_t)mid + 1] <= m) lo = mid; else hi = mid;
+            }
+            const uint32_t off = (uint32_t)rays[3 * (size_t)lo + 1], cnt = (uint32_t)rays[3 * (size_t)lo + 2];
+            if (off + cnt <= M) {  // raymarching.cu:416: a ray that does not fit writes nothing
+                const uint32_t s = m - off;
+                const float *rec = t_rec + (size_t)lo * max_steps;
+                const float t = rec[s];
+                qx = rays_d[3 * (size_t)lo]; qy = rays_d[3 * (size_t)lo + 1]; qz = rays_d[3 * (size_t)lo + 2];
+                px = clampf(fmaf(t, qx, rays_o[3 * (size_t)lo]), -g.bound, g.bound);
+                py = clampf(fmaf(t, qy, rays_o[3 * (size_t)lo + 1]), -g.bound, g.bound);
+                pz = clampf(fmaf(t, qz, rays_o[3 * (size_t)lo + 2]), -g.bound, g.bound);
+                d0 = step_len(g, t);
+                float last;
+                if (s == 0) last = start_param(g, nears[lo], noises ? noises[lo] : 0.0f);
+                else { const float tp = rec[s - 1]; last = tp + step_len(g, tp); }
+                d1 = (t + d0) - last;
+            }
+        }
+        xyzs[3 * (size_t)m] = px; xyzs[3 * (size_t)m + 1] = py; xyzs[3 * (size_t)m + 2] = pz;
+        dirs[3 * (size_t)m] = qx; dirs[3 * (size_t)m + 1] = qy; dirs[3 * (size_t)m + 2] = qz;
+        deltas[2 * (size_t)m] = d0; deltas[2 * (size_t)m + 1] = d1;
+    }
+}
+
+// ----------------------------------------------------------------------------- compositing (training)
+
+// raymarching.cu:501-577.  One lane per ray slot; __expf is the fast exponential the reference uses.
+__global__ void k_composite_fwd(const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                const float *__restrict__ deltas, const int32_t *__restrict__ rays, uint32_t M,
+                                uint32_t N, float T_thresh, float *__restrict__ weights_sum,
+                                float *__restrict__ depth, float *__restrict__ image) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t id = (uint32_t)rays[3 * (size_t)n], off = (uint32_t)rays[3 * (size_t)n + 1],
+                   cnt = (uint32_t)rays[3 * (size_t)n + 2];
+    float r = 0, g = 0, b = 0, ws = 0, tt = 0, d = 0, T = 1.0f;
+    if (cnt != 0 && off + cnt <= M) {
+        for (uint32_t s = 0; s < cnt; ++s) {
+            const size_t m = (size_t)off + s;
+            const float2 dl = reinterpret_cast<const float2 *>(deltas)[m];
+            const float alpha = 1.0f - __expf(-sigmas[m] * dl.x);
+            const float w = alpha * T;
+            r = fmaf(w, rgbs[3 * m], r);
+            g = fmaf(w, rgbs[3 * m + 1], g);
+            b = fmaf(w, rgbs[3 * m + 2], b);
+            tt += dl.y;
+            d = fmaf(w, tt, d);
+            ws += w;
+            T *= 1.0f - alpha;
+            if (T < T_thresh) break;
+        }
+    }
+    weights_sum[id] = ws;
+    depth[id] = d;
+    image[3 * (size_t)id] = r; image[3 * (size_t)id + 1] = g; image[3 * (size_t)id + 2] = b;
+}
+
+// raymarching.cu:602-682 (grad_depth does not propagate, raymarching.py:275).
+__global__ void k_composite_bwd(const float *__restrict__ grad_ws, const float *__restrict__ grad_image,
+                                const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                const float *__restrict__ deltas, const int32_t *__restrict__ rays,
+                                const float *__restrict__ weights_sum, const float *__restrict__ image, uint32_t M,
+                                uint32_t N, float T_thresh, float *__restrict__ grad_sigmas,
+                                float *__restrict__ grad_rgbs) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t id = (uint32_t)rays[3 * (size_t)n], off = (uint32_t)rays[3 * (size_t)n + 1],
+                   cnt = (uint32_t)rays[3 * (size_t)n + 2];
+    if (cnt == 0 || off + cnt > M) return;
+    const float gws = grad_ws[id];
+    const float g0 = grad_image[3 * (size_t)id], g1 = grad_image[3 * (size_t)id + 1], g2 = grad_image[3 * (size_t)id + 2];
+    const float rf = image[3 * (size_t)id], gf = image[3 * (size_t)id + 1], bf = image[3 * (size_t)id + 2];
+    const float tail = gws * (1.0f - weights_sum[id]);
+    float r = 0, g = 0, b = 0, T = 1.0f;
+    for (uint32_t s = 0; s < cnt; ++s) {
+        const size_t m = (size_t)off + s;
+        const float dt = deltas[2 * m];
+        const float c0 = rgbs[3 * m], c1 = rgbs[3 * m + 1], c2 = rgbs[3 * m + 2];
+        const float alpha = 1.0f - __expf(-sigmas[m] * dt);
+        const float w = alpha * T;
+        r = fmaf(w, c0, r);
+        g = fmaf(w, c1, g);
+        b = fmaf(w, c2, b);
+        T *= 1.0f - alpha;
+        grad_rgbs[3 * m] = g0 * w; grad_rgbs[3 * m + 1] = g1 * w; grad_rgbs[3 * m + 2] = g2 * w;
+        grad_sigmas[m] = dt * (g0 * (T * c0 - (rf - r)) + g1 * (T * c1 - (gf - g)) + g2 * (T * c2 - (bf - b)) + tail);
+        if (T < T_thresh) break;
+    }
+}
+
+// ----------------------------------------------------------------------------- inference
+
+// raymarching.cu:701-805: march up to n_step occupied samples from rays_t[id].
+__global__ void k_march_burst(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
+                              const float *__restrict__ rays_t, const float *__restrict__ rays_o,
+                              const float *__restrict__ rays_d, GridView g, const float *__restrict__ fars,
+                              float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
+                              const float *__restrict__ noises) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const int32_t id = rays_alive[n];
+    const Ray r(rays_o + 3 * (size_t)id, rays_d + 3 * (size_t)id);
+    const float far = fars[id];
+    float t = start_param(g, rays_t[id], noises ? noises[n] : 0.0f);
+    float last = t;
+    float *px = xyzs + 3 * (size_t)n * n_step, *pd = dirs + 3 * (size_t)n * n_step, *pl = deltas + 2 * (size_t)n * n_step;
+    uint32_t step = 0;
+    float x, y, z, dt, t_exit;
+    while (t < far && step < n_step) {
+        if (probe(g, r, t, x, y, z, dt, t_exit)) {
+            px[0] = x; px[1] = y; px[2] = z;
+            pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
+            t += dt;
+            pl[0] = dt; pl[1] = t - last;
+            last = t;
+            px += 3; pd += 3; pl += 2; ++step;
+        } else t = leave_cell(g, t, t_exit);
+    }
+}
+
+// raymarching.cu:819-905: in-place accumulation, T = 1 - weight_sum.
+__global__ void k_composite_burst(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *__restrict__ rays_alive,
+                                  float *__restrict__ rays_t, const float *__restrict__ sigmas,
+                                  const float *__restrict__ rgbs, const float *__restrict__ deltas,
+                                  float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const int32_t id = rays_alive[n];
+    const float *ps = sigmas + (size_t)n * n_step, *pc = rgbs + 3 * (size_t)n * n_step, *pl = deltas + 2 * (size_t)n * n_step;
+    float t = rays_t[id], wsum = weights_sum[id], d = depth[id];
+    float r = image[3 * (size_t)id], g = image[3 * (size_t)id + 1], b = image[3 * (size_t)id + 2];
+    uint32_t step = 0;
+    while (step < n_step) {
+        if (pl[0] == 0.0f) break;
+        const float alpha = 1.0f - __expf(-ps[0] * pl[0]);
+        const float T = 1.0f - wsum;
+        const float w = alpha * T;
+        wsum += w;
+        t += pl[1];
+        d = fmaf(w, t, d);
+        r = fmaf(w, pc[0], r);
+        g = fmaf(w, pc[1], g);
+        b = fmaf(w, pc[2], b);
+        if (T < T_thresh) break;
+        ++ps; pc += 3; pl += 2; ++step;
+    }
+    if (step < n_step) rays_alive[n] = -1;
+    else rays_t[id] = t;
+    weights_sum[id] = wsum;
+    depth[id] = d;
+    image[3 * (size_t)id] = r; image[3 * (size_t)id + 1] = g; image[3 * (size_t)id + 2] = b;
+}
+
+// Stable compaction of the non-negative ray ids: ballot + popcount inside a wave, wave bases through LDS,
+// a running base across 1024-element rounds.  One workgroup (alive lists are at most a few 10^5 long).
+__global__ void __launch_bounds__(1024) k_compact_alive(const int32_t *__restrict__ in, uint32_t n,
+                                                        int32_t *__restrict__ out, int32_t *__restrict__ n_out) {
+    __shared__ uint32_t wave_cnt[16];
+    __shared__ uint32_t running;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) running = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + tid;
+        const int32_t v = i < n ? in[i] : -1;
+        const bool keep = v >= 0;
+        const unsigned long long ballot = __ballot(keep);
+        const uint32_t before = __popcll(ballot & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wid] = __popcll(ballot);
+        __syncthreads();
+        uint32_t wave_base = running, round_total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t c = wave_cnt[w];
+            if (w < (int)wid) wave_base += c;
+            round_total += c;
+        }
+        if (keep) out[wave_base + before] = v;
+        __syncthreads();
+        if (tid == 0) running += round_total;
+        __syncthreads();
+    }
+    if (tid == 0) *n_out = (int32_t)running;
+}
+
+}  // namespace nsig
+
+// ============================================================================= C ABI
+
+using namespace nsig;
+
+static inline uint32_t lanes_for_walk(uint32_t n) {
+    // active lanes per wave for the latency-bound grid walk: spread small batches over all CUs
+    uint32_t lanes = 64;
+    while (lanes > 16 && (uint64_t)ceil_div(n, lanes) < 4ull * kCUs) lanes >>= 1;
+    return lanes;
+}
+
+NSIG_EXPORT int rm_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N,
+                                      float min_near, float *nears, float *fars, nsig_stream_t stream) {
+    NSIG_REQUIRE(rays_o && rays_d && aabb && nears && fars, "rm_near_far_from_aabb: null pointer");
+    if (N == 0) return NSIG_OK;
+    k_near_far<<<ceil_div(N, 256), 256, 0, as_stream(stream)>>>(rays_o, rays_d, aabb, N, min_near, nears, fars);
+    return check_launch("rm_near_far_from_aabb");
+}
+
+NSIG_EXPORT int rm_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords,
+                                nsig_stream_t stream) {
+    NSIG_REQUIRE(rays_o && rays_d && coords, "rm_sph_from_ray: null pointer");
+    if (N == 0) return NSIG_OK;
+    k_sph_from_ray<<<ceil_div(N, 256), 256, 0, as_stream(stream)>>>(rays_o, rays_d, radius, N, coords);
+    return check_launch("rm_sph_from_ray");
+}
+
+NSIG_EXPORT int rm_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, nsig_stream_t stream) {
+    NSIG_REQUIRE(coords && indices, "rm_morton3D: null pointer");
+    if (N == 0) return NSIG_OK;
+    k_morton<<<ceil_div(N, 256), 256, 0, as_stream(stream)>>>(coords, N, indices);
+    return check_launch("rm_morton3D");
+}
+
+NSIG_EXPORT int rm_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, nsig_stream_t stream) {
+    NSIG_REQUIRE(coords && indices, "rm_morton3D_invert: null pointer");
+    if (N == 0) return NSIG_OK;
+    k_morton_invert<<<ceil_div(N, 256), 256, 0, as_stream(stream)>>>(indices, N, coords);
+    return check_launch("rm_morton3D_invert");
+}
+
+NSIG_EXPORT int rm_packbits(const float *grid, uint32_t n_bytes, float density_thresh, uint8_t *bitfield,
+                            nsig_stream_t stream) {
+    NSIG_REQUIRE(grid && bitfield, "rm_packbits: null pointer");
+    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(grid) & 15) == 0, "rm_packbits: grid must be 16-byte aligned");
+    if (n_bytes == 0) return NSIG_OK;
+    k_packbits<<<ceil_div(ceil_div(n_bytes, 4), 256), 256, 0, as_stream(stream)>>>(grid, n_bytes, density_thresh, bitfield);
+    return check_launch("rm_packbits");
+}
+
+NSIG_EXPORT size_t rm_march_train_scratch_bytes(uint32_t N, uint32_t max_steps) {
+    return (size_t)N * max_steps * sizeof(float);
+}
+
+static int check_grid_args(const char *who, uint32_t C, uint32_t H, uint32_t max_steps, float bound) {
+    NSIG_REQUIRE(C >= 1 && C <= 8, "%s: cascade count %u out of range [1,8]", who, C);
+    NSIG_REQUIRE(H >= 8 && H <= 1024 && (H & (H - 1)) == 0, "%s: grid size %u must be a power of two in [8,1024]", who, H);
+    NSIG_REQUIRE(max_steps >= 1, "%s: max_steps must be positive", who);
+    NSIG_REQUIRE(bound > 0.0f, "%s: bound must be positive", who);
+    return NSIG_OK;
+}
+
+NSIG_EXPORT int rm_march_train_count(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound,
+                                     float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                     const float *nears, const float *fars, const float *noises, int32_t *counts,
+                                     float *t_rec, nsig_stream_t stream) {
+    NSIG_REQUIRE(rays_o && rays_d && grid && nears && fars && counts && t_rec, "rm_march_train_count: null pointer");
+    if (int e = check_grid_args("rm_march_train_count", C, H, max_steps, bound)) return e;
+    if (N == 0) return NSIG_OK;
+    const uint32_t lanes = lanes_for_walk(N);
+    k_march_count<<<ceil_div(N, lanes), lanes, 0, as_stream(stream)>>>(
+        rays_o, rays_d, make_grid_view(grid, bound, dt_gamma, max_steps, C, H), max_steps, N, nears, fars, noises, counts, t_rec);
+    return check_launch("rm_march_train_count");
+}
+
+NSIG_EXPORT int rm_march_train_scan(const int32_t *counts, uint32_t N, int32_t *rays, int32_t *counter,
+                                    nsig_stream_t stream) {
+    NSIG_REQUIRE(counts && rays && counter, "rm_march_train_scan: null pointer");
+    k_march_scan<<<1, 1024, 0, as_stream(stream)>>>(counts, N, rays, counter);
+    return check_launch("rm_march_train_scan");
+}
+
+NSIG_EXPORT int rm_march_train_write(const float *rays_o, const float *rays_d, float bound, float dt_gamma,
+                                     uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                     const float *nears, const float *noises, const float *t_rec, const int32_t *rays,
+                                     const int32_t *counter, float *xyzs, float *dirs, float *deltas,
+                                     nsig_stream_t stream) {
+    NSIG_REQUIRE(rays_o && rays_d && nears && t_rec && rays && counter && xyzs && dirs && deltas,
+                 "rm_march_train_write: null pointer");
+    if (int e = check_grid_args("rm_march_train_write", C, H, max_steps, bound)) return e;
+    if (M == 0 || N == 0) return NSIG_OK;
+    const uint32_t blocks = min(ceil_div(M, 256), (uint32_t)(kCUs * 8));
+    k_march_write<<<blocks, 256, 0, as_stream(stream)>>>(rays_o, rays_d, make_grid_view(nullptr, bound, dt_gamma, max_steps, C, H),
+                                                        max_steps, N, M, nears, noises, t_rec, rays, counter, xyzs, dirs, deltas);
+    return check_launch("rm_march_train_write");
+}
+
+NSIG_EXPORT int rm_composite_train_fwd(const float *sigmas, const float *rgbs, const float *deltas,
+                                       const int32_t *rays, uint32_t M, uint32_t N, float T_thresh, float *weights_sum,
+                                       float *depth, float *image, nsig_stream_t stream) {
+    NSIG_REQUIRE(sigmas && rgbs && deltas && rays && weights_sum && depth && image, "rm_composite_train_fwd: null pointer");
+    if (N == 0) return NSIG_OK;
+    const uint32_t lanes = lanes_for_walk(N);
+    k_composite_fwd<<<ceil_div(N, lanes), lanes, 0, as_stream(stream)>>>(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image);
+    return check_launch("rm_composite_train_fwd");
+}
+
+NSIG_EXPORT int rm_composite_train_bwd(const float *grad_weights_sum, const float *grad_image, const float *sigmas,
+                                       const float *rgbs, const float *deltas, const int32_t *rays,
+                                       const float *weights_sum, const float *image, uint32_t M, uint32_t N,
+                                       float T_thresh, float *grad_sigmas, float *grad_rgbs, nsig_stream_t stream) {
+    NSIG_REQUIRE(grad_weights_sum && grad_image && sigmas && rgbs && deltas && rays && weights_sum && image && grad_sigmas && grad_rgbs,
+                 "rm_composite_train_bwd: null pointer");
+    if (M == 0) return NSIG_OK;
+    if (hipMemsetAsync(grad_sigmas, 0, (size_t)M * sizeof(float), as_stream(stream)) != hipSuccess ||
+        hipMemsetAsync(grad_rgbs, 0, (size_t)M * 3 * sizeof(float), as_stream(stream)) != hipSuccess) {
+        set_error("rm_composite_train_bwd: hipMemsetAsync failed");
+        return NSIG_ERR_LAUNCH;
+    }
+    if (N == 0) return NSIG_OK;
+    const uint32_t lanes = lanes_for_walk(N);
+    k_composite_bwd<<<ceil_div(N, lanes), lanes, 0, as_stream(stream)>>>(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays,
+                                                                        weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs);
+    return check_launch("rm_composite_train_bwd");
+}
+
+NSIG_EXPORT int rm_march(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t,
+                         const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                         uint32_t C, uint32_t H, const uint8_t *grid, const float *nears, const float *fars, float *xyzs,
+                         float *dirs, float *deltas, const float *noises, uint32_t M_rows, nsig_stream_t stream) {
+    (void)nears;  // read but unused by the reference as well (raymarching.cu:737)
+    NSIG_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas, "rm_march: null pointer");
+    NSIG_REQUIRE((uint64_t)n_alive * n_step <= M_rows, "rm_march: M_rows=%u < n_alive*n_step", M_rows);
+    if (int e = check_grid_args("rm_march", C, H, max_steps, bound)) return e;
+    if (M_rows == 0) return NSIG_OK;
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(xyzs, 0, (size_t)M_rows * 12, s) != hipSuccess || hipMemsetAsync(dirs, 0, (size_t)M_rows * 12, s) != hipSuccess ||
+        hipMemsetAsync(deltas, 0, (size_t)M_rows * 8, s) != hipSuccess) {
+        set_error("rm_march: hipMemsetAsync failed");
+        return NSIG_ERR_LAUNCH;
+    }
+    if (n_alive == 0) return NSIG_OK;
+    const uint32_t lanes = lanes_for_walk(n_alive);
+    k_march_burst<<<ceil_div(n_alive, lanes), lanes, 0, s>>>(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d,
+                                                            make_grid_view(grid, bound, dt_gamma, max_steps, C, H), fars, xyzs, dirs, deltas, noises);
+    return check_launch("rm_march");
+}
+
+NSIG_EXPORT int rm_composite(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
+                             const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum,
+                             float *depth, float *image, nsig_stream_t stream) {
+    NSIG_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, "rm_composite: null pointer");
+    if (n_alive == 0) return NSIG_OK;
+    k_composite_burst<<<ceil_div(n_alive, 64), 64, 0, as_stream(stream)>>>(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs,
+                                                                           deltas, weights_sum, depth, image);
+    return check_launch("rm_composite");
+}
+
+NSIG_EXPORT int rm_compact_alive(const int32_t *rays_alive, uint32_t n_alive, int32_t *rays_alive_out, int32_t *n_out,
+                                 nsig_stream_t stream) {
+    NSIG_REQUIRE(rays_alive && rays_alive_out && n_out, "rm_compact_alive: null pointer");
+    NSIG_REQUIRE(rays_alive != rays_alive_out, "rm_compact_alive: in-place compaction is not supported");
+    k_compact_alive<<<1, 1024, 0, as_stream(stream)>>>(rays_alive, n_alive, rays_alive_out, n_out);
+    return check_launch("rm_compact_alive");
+}

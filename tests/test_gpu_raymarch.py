@@ -1,0 +1,163 @@
+"""GPU parity of the ray-marching kernels against the CPU oracle, through the C ABI (ctypes -> libnerfsig.so)."""
+import numpy as np
+import pytest
+import torch
+
+import closed_form as cf
+from oracle import field_ref as fr
+from oracle import raymarch_ref as orm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rmod():
+    from nerf_signature_amd import raymarching
+    return raymarching
+
+
+def _cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _scene(n, bound, seed=0, radius=None):
+    grid, bitfield, C = cf.ball_scene(bound=bound)
+    pose, intr, inds = cf.orbit_rays(n, seed=seed, radius=radius or (3.2248 if bound == 1.0 else 1.3))
+    o, d = fr.get_rays(torch.from_numpy(pose)[None], intr, 400, 400, torch.from_numpy(inds)[None])
+    return grid, bitfield, C, o[0].contiguous().numpy(), d[0].contiguous().numpy()
+
+
+def test_utils_bit_exact(rmod):
+    rng = np.random.RandomState(0)
+    c = rng.randint(0, 128, size=(10007, 3)).astype(np.int32)
+    idx = rmod.morton3D(_cuda(c))
+    np.testing.assert_array_equal(idx.cpu().numpy(), orm.morton3D(c))
+    np.testing.assert_array_equal(rmod.morton3D_invert(idx).cpu().numpy(), c)
+    grid = rng.randn(2, 128 ** 3 // 16).astype(np.float32)
+    np.testing.assert_array_equal(rmod.packbits(_cuda(grid), 0.1).cpu().numpy(), orm.packbits(grid, 0.1))
+    odd = rng.randn(1, 8 * 37).astype(np.float32)  # byte count not a multiple of 4
+    np.testing.assert_array_equal(rmod.packbits(_cuda(odd), 0.0).cpu().numpy(), orm.packbits(odd, 0.0))
+
+
+@pytest.mark.parametrize("bound", [1.0, 2.0])
+def test_near_far_bit_exact(rmod, bound):
+    _, _, _, o, d = _scene(4096, bound)
+    d[5] = (0, 1, 0)     # axis-parallel ray (infinite reciprocal)
+    o[6] = (9, 9, 9)     # misses the box
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        n0, f0 = orm.near_far_from_aabb(o, d, aabb, 0.2)
+    n1, f1 = rmod.near_far_from_aabb(_cuda(o), _cuda(d), _cuda(aabb), 0.2)
+    np.testing.assert_array_equal(n1.cpu().numpy(), n0)
+    np.testing.assert_array_equal(f1.cpu().numpy(), f0)
+
+
+def test_sph_from_ray(rmod):
+    _, _, _, o, d = _scene(1024, 1.0)
+    want = orm.sph_from_ray(o * 0.1, d, 4.0)
+    got = rmod.sph_from_ray(_cuda(o * 0.1), _cuda(d), 4.0)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("bound,dt_gamma,n", [(1.0, 0.0, 4096), (2.0, 0.0, 2048), (2.0, 1 / 128, 2048), (1.0, 0.0, 77)])
+def test_march_train_counts_and_points_bit_exact(rmod, bound, dt_gamma, n):
+    _, bitfield, C, o, d = _scene(n, bound)
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = orm.near_far_from_aabb(o, d, aabb, 0.2)
+    ctr0 = np.zeros(2, np.int32)
+    x0, d0, dl0, rays0 = orm.march_rays_train(o, d, bound, bitfield, C, 128, nears, fars, ctr0, -1, False, 128, True, dt_gamma, 1024)
+    ctr1 = torch.zeros(2, dtype=torch.int32, device="cuda")
+    x1, d1, dl1, rays1 = rmod.march_rays_train(_cuda(o), _cuda(d), bound, _cuda(bitfield), C, 128, _cuda(nears), _cuda(fars), ctr1,
+                                               -1, False, 128, True, dt_gamma, 1024)
+    np.testing.assert_array_equal(ctr1.cpu().numpy(), ctr0)           # total point count, ray count
+    np.testing.assert_array_equal(rays1.cpu().numpy(), rays0)         # (id, offset, count) per ray: bit-exact
+    assert ctr0[0] > 0
+    np.testing.assert_array_equal(x1.cpu().numpy(), x0)
+    np.testing.assert_array_equal(d1.cpu().numpy(), d0)
+    np.testing.assert_array_equal(dl1.cpu().numpy(), dl0)
+
+
+def test_march_train_perturbed_and_bounded(rmod):
+    """Fixed noise vector through the C ABI directly (the wrapper draws torch.rand) and the mean_count-bounded mode."""
+    from nerf_signature_amd import _native as nv
+    _, bitfield, C, o, d = _scene(512, 1.0, seed=3)
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    nears, fars = orm.near_far_from_aabb(o, d, aabb, 0.2)
+    noises = np.random.RandomState(1).rand(512).astype(np.float32)
+    ctr0 = np.zeros(2, np.int32)
+    x0, d0, dl0, rays0 = orm.march_rays_train(o, d, 1.0, bitfield, C, 128, nears, fars, ctr0, 3000, True, 128, False, 0.0, 1024, noises=noises)
+    M = x0.shape[0]
+    assert M == 3072 and ctr0[0] > M      # some rays overflow the bound and are dropped
+    ctr1 = torch.zeros(2, dtype=torch.int32, device="cuda")
+    to = lambda a: _cuda(a)
+    _, _, rays1, write = rmod.march_rays_train_device(to(o), to(d), 1.0, to(bitfield), C, 128, to(nears), to(fars), ctr1, to(noises), 0.0, 1024)
+    x1, d1, dl1 = write(M)
+    np.testing.assert_array_equal(rays1.cpu().numpy(), rays0)
+    np.testing.assert_array_equal(x1.cpu().numpy(), x0)
+    np.testing.assert_array_equal(dl1.cpu().numpy(), dl0)
+
+
+def test_composite_train_fwd_bwd(rmod):
+    _, bitfield, C, o, d = _scene(2048, 1.0)
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    nears, fars = orm.near_far_from_aabb(o, d, aabb, 0.2)
+    x0, d0, dl0, rays0 = orm.march_rays_train(o, d, 1.0, bitfield, C, 128, nears, fars, None, -1, False, 128, True, 0.0, 1024)
+    rng = np.random.RandomState(4)
+    M = x0.shape[0]
+    for scale in (2.0, 300.0):   # thin medium, and opaque enough to hit the T < 1e-4 early exit
+        sig = (rng.rand(M) * scale).astype(np.float32)
+        rgb = rng.rand(M, 3).astype(np.float32)
+        ws0, dep0, img0 = orm.composite_rays_train_forward(sig, rgb, dl0, rays0, 1e-4)
+        s1, c1 = _cuda(sig).requires_grad_(True), _cuda(rgb).requires_grad_(True)
+        ws1, dep1, img1 = rmod.composite_rays_train(s1, c1, _cuda(dl0), _cuda(rays0), 1e-4)
+        np.testing.assert_allclose(ws1.detach().cpu().numpy(), ws0, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(dep1.detach().cpu().numpy(), dep0, rtol=0, atol=1e-5)
+        np.testing.assert_allclose(img1.detach().cpu().numpy(), img0, rtol=0, atol=2e-6)
+        g_ws, g_img = rng.randn(2048).astype(np.float32), rng.randn(2048, 3).astype(np.float32)
+        gs0, gc0 = orm.composite_rays_train_backward(g_ws, g_img, sig, rgb, dl0, rays0, ws0, img0, 1e-4)
+        torch.autograd.backward([ws1, img1], [_cuda(g_ws), _cuda(g_img)])
+        np.testing.assert_allclose(c1.grad.cpu().numpy(), gc0, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(s1.grad.cpu().numpy(), gs0, rtol=1e-4, atol=2e-6 * max(1.0, 3.0 / scale))
+
+
+def test_eval_march_composite_compact(rmod):
+    _, bitfield, C, o, d = _scene(1000, 1.0)
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    nears, fars = orm.near_far_from_aabb(o, d, aabb, 0.2)
+    N = 1000
+    sig_of = lambda p: (40.0 * (0.5 + p[:, 0])).astype(np.float32)
+    rgb_of = lambda p: np.stack([0.5 + 0.4 * p[:, 1], 0.3 + 0 * p[:, 1], 0.5 - 0.4 * p[:, 2]], -1).astype(np.float32)
+    ws0, dep0, img0 = np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros((N, 3), np.float32)
+    alive0, t0 = np.arange(N, dtype=np.int32), nears.copy()
+    ws1, dep1, img1 = (torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda"), torch.zeros(N, 3, device="cuda"))
+    alive1, t1 = torch.arange(N, dtype=torch.int32, device="cuda"), _cuda(nears).clone()
+    bf, oc, dc, nc, fc = _cuda(bitfield), _cuda(o), _cuda(d), _cuda(nears), _cuda(fars)
+    step = 0
+    while step < 1024 and alive0.shape[0] > 0:
+        n_alive = alive0.shape[0]
+        n_step = max(min(N // n_alive, 8), 1)
+        p0, dd0, dl0 = orm.march_rays(n_alive, n_step, alive0, t0, o, d, 1.0, bitfield, C, 128, nears, fars, 128, False, 0.0, 1024)
+        p1, dd1, dl1 = rmod.march_rays(n_alive, n_step, alive1, t1, oc, dc, 1.0, bf, C, 128, nc, fc, 128, False, 0.0, 1024)
+        np.testing.assert_array_equal(p1.cpu().numpy(), p0)
+        np.testing.assert_array_equal(dl1.cpu().numpy(), dl0)
+        orm.composite_rays(n_alive, n_step, alive0, t0, sig_of(p0), rgb_of(p0), dl0, ws0, dep0, img0, 1e-2)
+        rmod.composite_rays(n_alive, n_step, alive1, t1, _cuda(sig_of(p0)), _cuda(rgb_of(p0)), dl1, ws1, dep1, img1, 1e-2)
+        np.testing.assert_array_equal(alive1.cpu().numpy(), alive0)      # which rays terminated: bit-exact
+        alive0 = np.ascontiguousarray(alive0[alive0 >= 0])
+        out, n_out = rmod.compact_alive(alive1)
+        assert int(n_out.item()) == alive0.shape[0]
+        alive1 = out[:alive0.shape[0]].contiguous()
+        np.testing.assert_array_equal(alive1.cpu().numpy(), alive0)
+        step += n_step
+    np.testing.assert_allclose(ws1.cpu().numpy(), ws0, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(img1.cpu().numpy(), img0, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(dep1.cpu().numpy(), dep0, rtol=0, atol=2e-5)
+
+
+def test_argument_checks_raise(rmod):
+    from nerf_signature_amd import _native as nv
+    with pytest.raises(ValueError):
+        rmod.march_rays_train(torch.zeros(4, 3, device="cuda"), torch.ones(4, 3, device="cuda"), 1.0, torch.zeros(10, dtype=torch.uint8, device="cuda"),
+                              1, 128, torch.zeros(4, device="cuda"), torch.ones(4, device="cuda"), None, -1, False, 128, True, 0.0, 1024)
+    with pytest.raises(ValueError):
+        nv.call("rm_morton3D", None, 4, None, None)
