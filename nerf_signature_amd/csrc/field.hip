@@ -1,0 +1,442 @@
+// Fused field network for gfx950: hash encode (16 base levels + summed codebook table) -> sigma MLP ->
+// trunc_exp | SH(deg 4) + geo features -> color MLP -> sigmoid, forward and input-gradient backward.
+//
+// Behavioural reference: /root/reference/nerf/network_wtmk_tcnn.py:97-176 (NeRFNetwork.forward / density /
+// color), with the MLP semantics of tiny-cuda-nn's FullyFusedMLP restated in oracle/field_ref.py (the
+// reference delegates them to tinycudann, which is not part of its tree: parity unpinned).
+//
+// Mapping onto CDNA4
+//   * one wave = 32 points.  The point index sits on the MFMA column (lane & 31); the two lane halves
+//     split the K dimension, so lane (p, h) gathers exactly the 8 hash levels whose 16 features are its
+//     share of the B operand of v_mfma_f32_32x32x16_bf16 -- the encoder output never leaves registers
+//     and needs no cross-lane movement before the first layer.
+//   * layers are evaluated transposed (H^T = W . X^T) so that the 32x32 accumulator of one layer (column
+//     = point, rows in registers) is already the B operand of the next one; the K order this implies is
+//     baked into the packed weights (mlp_pack_weights), the activations never touch LDS or HBM.
+//   * weights are frozen and tiny: they are staged once per workgroup into LDS as ready-made A fragments
+//     (16 B per lane, conflict-free ds_read_b128).
+//   * precision: every product is evaluated as split-bf16 (hi*hi + hi*lo + lo*hi, fp32 accumulate), i.e.
+//     ~2^-16 relative error per product on the bf16 matrix pipe; MFMA time stays negligible next to the
+//     gathers (3 x 24 MFMAs per 32 points).
+//   * backward needs only the input gradient of the codebook channels (all network weights are frozen,
+//     network_wtmk_tcnn.py:90-95), so the forward saves just the ReLU sign bits (6 words per point).
+#include "hashgrid.h"
+
+namespace nsig {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ----------------------------------------------------------------------------- packed weight layout
+
+// Forward A fragments (W as stored by tcnn: [out,in]) and backward A fragments (W^T).
+constexpr int F0 = 0;   // sigma L1   W1s[64x32]      2 row blocks x 2 k-steps
+constexpr int F1 = 4;   // sigma L2   W2s[16x64]      1 x 4
+constexpr int F2 = 8;   // color L1   Wc1[64x32]      2 x 2
+constexpr int F3 = 12;  // color L2   Wc2[64x64]      2 x 4
+constexpr int F4 = 20;  // color L3   Wc3[16x64]      1 x 4
+constexpr int kFwdFrags = 24;
+constexpr int B0 = 0;   // Wc3^T [64x16]              2 x 1
+constexpr int B1 = 2;   // Wc2^T [64x64]              2 x 4
+constexpr int B2 = 10;  // Wc1^T rows -> sigma-out    1 x 4
+constexpr int B3 = 14;  // W2s^T [64x16]              2 x 1
+constexpr int B4 = 16;  // W1s[:,30:32]^T             1 x 4
+constexpr int kBwdFrags = 20;
+constexpr int kFragBytes = 64 * 16;  // 64 lanes x 8 bf16
+// packed = [fwd hi | fwd lo | bwd hi | bwd lo]
+constexpr size_t kFwdBytes = (size_t)kFwdFrags * kFragBytes, kBwdBytes = (size_t)kBwdFrags * kFragBytes;
+constexpr size_t kPackedBytes = 2 * kFwdBytes + 2 * kBwdBytes;
+
+constexpr int kSigmaW1 = 0, kSigmaW2 = 2048;                 // offsets in sigma_params (3072)
+constexpr int kColorW1 = 0, kColorW2 = 2048, kColorW3 = 6144;  // offsets in color_params (7168)
+
+// K index carried by element j of lane half h in k-step ks when the B operand is the previous layer's
+// accumulator (registers 8s..8s+7 of row block rb, ks = 2 rb + s).
+__host__ __device__ inline int k_from_acc(int ks, int h, int j) { return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3); }
+// Row of a 32-row accumulator block held in register r (< 8) of lane half h.
+__host__ __device__ inline int row_of_reg(int h, int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ inline float fwd_weight(int frag, int lane, int j, const float *__restrict__ sp, const float *__restrict__ cp) {
+    const int r = lane & 31, h = lane >> 5;
+    if (frag < F1) {
+        const int rb = (frag - F0) >> 1, ks = (frag - F0) & 1;
+        return sp[kSigmaW1 + (32 * rb + r) * 32 + 16 * ks + 8 * h + j];
+    }
+    if (frag < F2) return r < 16 ? sp[kSigmaW2 + r * 64 + k_from_acc(frag - F1, h, j)] : 0.0f;
+    if (frag < F3) {
+        const int rb = (frag - F2) >> 1, ks = (frag - F2) & 1;
+        int cin;
+        if (ks == 0) cin = 8 * h + j;  // SH component
+        else { const int rho = row_of_reg(h, j); cin = rho == 0 ? 31 : 15 + rho; }  // geo feature rho-1, or the padded 1.0 input
+        return cp[kColorW1 + (32 * rb + r) * 32 + cin];
+    }
+    if (frag < F4) {
+        const int rb = (frag - F3) >> 2, ks = (frag - F3) & 3;
+        return cp[kColorW2 + (32 * rb + r) * 64 + k_from_acc(ks, h, j)];
+    }
+    return r < 16 ? cp[kColorW3 + r * 64 + k_from_acc(frag - F4, h, j)] : 0.0f;
+}
+
+__device__ inline float bwd_weight(int frag, int lane, int j, const float *__restrict__ sp, const float *__restrict__ cp) {
+    const int r = lane & 31, h = lane >> 5;
+    if (frag < B1) return cp[kColorW3 + (8 * h + j) * 64 + 32 * (frag - B0) + r];
+    if (frag < B2) {
+        const int rb = (frag - B1) >> 2, ks = (frag - B1) & 3;
+        return cp[kColorW2 + k_from_acc(ks, h, j) * 64 + 32 * rb + r];
+    }
+    if (frag < B3) return (r >= 1 && r < 16) ? cp[kColorW1 + k_from_acc(frag - B2, h, j) * 32 + 15 + r] : 0.0f;
+    if (frag < B4) return sp[kSigmaW2 + row_of_reg(h, j) * 64 + 32 * (frag - B3) + r];
+    return r < 2 ? sp[kSigmaW1 + k_from_acc(frag - B4, h, j) * 32 + 30 + r] : 0.0f;
+}
+
+__global__ void __launch_bounds__(256) k_pack_weights(const float *__restrict__ sp, const float *__restrict__ cp, __bf16 *__restrict__ packed) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;  // (frag, lane, j)
+    const int total = (kFwdFrags + kBwdFrags) * 512;
+    if (e >= total) return;
+    const int frag = e >> 9, lane = (e >> 3) & 63, j = e & 7;
+    const bool fwd = frag < kFwdFrags;
+    const float w = fwd ? fwd_weight(frag, lane, j, sp, cp) : bwd_weight(frag - kFwdFrags, lane, j, sp, cp);
+    const __bf16 hi = (__bf16)w;
+    const __bf16 lo = (__bf16)(w - (float)hi);
+    __bf16 *base_hi = packed + (fwd ? 0 : 2 * kFwdBytes / 2);
+    const int f = fwd ? frag : frag - kFwdFrags;
+    const size_t lo_off = (fwd ? kFwdBytes : kBwdBytes) / 2;
+    base_hi[(size_t)f * 512 + lane * 8 + j] = hi;
+    base_hi[lo_off + (size_t)f * 512 + lane * 8 + j] = lo;
+}
+
+// ----------------------------------------------------------------------------- wave-level building blocks
+
+struct Split8 {
+    bf16x8 hi, lo;
+};
+
+__device__ inline void split_put(Split8 &s, int j, float v) {
+    const __bf16 hi = (__bf16)v;
+    s.hi[j] = hi;
+    s.lo[j] = (__bf16)(v - (float)hi);
+}
+
+// acc[rb] = sum over k-steps of A(frag0 + rb*KS + ks) . B[ks], split-bf16.
+template <int RB, int KS>
+__device__ inline void mfma_layer(const char *__restrict__ lds_hi, const char *__restrict__ lds_lo, int frag0, int lane,
+                                  const Split8 (&b)[KS], f32x16 (&acc)[RB]) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int off = (frag0 + rb * KS + ks) * kFragBytes + lane * 16;
+            const bf16x8 a_hi = *reinterpret_cast<const bf16x8 *>(lds_hi + off);
+            const bf16x8 a_lo = *reinterpret_cast<const bf16x8 *>(lds_lo + off);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b[ks].hi, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b[ks].lo, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b[ks].hi, c, 0, 0, 0);
+        }
+        acc[rb] = c;
+    }
+}
+
+// ReLU a 64-row activation held in two accumulators, return the sign bits, emit the next B operand.
+__device__ inline uint32_t relu_to_operand(const f32x16 (&acc)[2], Split8 (&b)[4]) {
+    uint32_t bits = 0;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[rb][r];
+            const bool on = v > 0.0f;
+            bits |= (uint32_t)on << (rb * 16 + r);
+            split_put(b[2 * rb + (r >> 3)], r & 7, on ? v : 0.0f);
+        }
+    return bits;
+}
+
+// Backward through a ReLU: zero the rows whose forward activation was clamped, emit the next B operand.
+__device__ inline void mask_to_operand(const f32x16 (&acc)[2], uint32_t bits, Split8 (&b)[4]) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) split_put(b[2 * rb + (r >> 3)], r & 7, ((bits >> (rb * 16 + r)) & 1u) ? acc[rb][r] : 0.0f);
+}
+
+// Degree-4 real spherical harmonics (the 16 components of hash_encoding.py:157-183) of d in [-1,1]^3.
+__device__ inline void sh16(float x, float y, float z, float (&o)[16]) {
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    o[0] = 0.28209479177387814f;
+    o[1] = -0.4886025119029199f * y;
+    o[2] = 0.4886025119029199f * z;
+    o[3] = -0.4886025119029199f * x;
+    o[4] = 1.0925484305920792f * xy;
+    o[5] = -1.0925484305920792f * yz;
+    o[6] = 0.31539156525252005f * (2.0f * zz - xx - yy);
+    o[7] = -1.0925484305920792f * xz;
+    o[8] = 0.5462742152960396f * (xx - yy);
+    o[9] = -0.5900435899266435f * y * (3.0f * xx - yy);
+    o[10] = 2.890611442640554f * xy * z;
+    o[11] = -0.4570457994644658f * y * (4.0f * zz - xx - yy);
+    o[12] = 0.3731763325901154f * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+    o[13] = -0.4570457994644658f * x * (4.0f * zz - xx - yy);
+    o[14] = 1.445305721320277f * z * (xx - yy);
+    o[15] = -0.5900435899266435f * x * (xx - 3.0f * yy);
+}
+
+__device__ inline void stage_weights(char *lds, const char *__restrict__ src, int bytes) {
+    for (int o = threadIdx.x * 16; o < bytes; o += blockDim.x * 16)
+        *reinterpret_cast<uint4 *>(lds + o) = *reinterpret_cast<const uint4 *>(src + o);
+    __syncthreads();
+}
+
+__device__ inline void color_branch(const char *lds_hi, const char *lds_lo, int lane, int h, float dx, float dy, float dz,
+                                    const float (&geo8)[8], uint32_t (&mask)[2], float (&rgb)[3]) {
+    // tcnn's SH encoding takes inputs in [0,1] and maps them back (network_wtmk_tcnn.py:114-115)
+    const float ux = (dx + 1.0f) / 2.0f, uy = (dy + 1.0f) / 2.0f, uz = (dz + 1.0f) / 2.0f;
+    float sh[16];
+    sh16(ux * 2.0f - 1.0f, uy * 2.0f - 1.0f, uz * 2.0f - 1.0f, sh);
+    Split8 cin[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        split_put(cin[0], j, h ? sh[8 + j] : sh[j]);
+        split_put(cin[1], j, geo8[j]);
+    }
+    f32x16 hid[2];
+    Split8 b4[4];
+    mfma_layer<2, 2>(lds_hi, lds_lo, F2, lane, cin, hid);
+    mask[0] = relu_to_operand(hid, b4);
+    mfma_layer<2, 4>(lds_hi, lds_lo, F3, lane, b4, hid);
+    mask[1] = relu_to_operand(hid, b4);
+    f32x16 out[1];
+    mfma_layer<1, 4>(lds_hi, lds_lo, F4, lane, b4, out);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rgb[c] = 1.0f / (1.0f + expf(-out[0][c]));  // rows 0..2 live in lane half 0
+}
+
+// ----------------------------------------------------------------------------- forward
+
+__global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyzs, const float *__restrict__ dirs, uint32_t M, float bound,
+                                                   TablePtrs base, LevelGeom geom, const float *__restrict__ S,
+                                                   const char *__restrict__ packed, float *__restrict__ sigmas, float *__restrict__ rgbs,
+                                                   float *__restrict__ geo_out, uint32_t *__restrict__ masks) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    stage_weights(lds, packed, 2 * (int)kFwdBytes);
+    const char *lds_hi = lds, *lds_lo = lds + kFwdBytes;
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    const uint32_t n_tiles = ceil_div(M, 32u);
+    for (uint32_t tile = blockIdx.x * 4 + wid; tile < n_tiles; tile += gridDim.x * 4) {
+        const uint32_t s = tile * 32 + p;
+        const uint32_t sl = min(s, M - 1);
+        const float two_b = 2.0f * bound;
+        const float x = (xyzs[3 * (size_t)sl] + bound) / two_b;       // network_wtmk_tcnn.py:101
+        const float y = (xyzs[3 * (size_t)sl + 1] + bound) / two_b;
+        const float z = (xyzs[3 * (size_t)sl + 2] + bound) / two_b;
+
+        // lane half 0 owns levels {0..3, 8..11}, half 1 owns {4..7, 12..15}: its 16 features are exactly
+        // its elements of the two K-steps of the first layer's B operand.
+        Split8 feat[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int l0 = 8 * g + i, l1 = l0 + 4;
+                float2 f = encode_level(h ? base.p[l1] : base.p[l0], x, y, z, h ? geom.cell[l1] : geom.cell[l0]);
+                if (g == 1 && i == 3 && S != nullptr && h) {  // codebook added into channels 30:32 (:106)
+                    const float2 c = encode_level(S, x, y, z, geom.cell[NSIG_BASE_LEVELS]);
+                    f.x = f.x + c.x;
+                    f.y = f.y + c.y;
+                }
+                split_put(feat[g], 2 * i, f.x);
+                split_put(feat[g], 2 * i + 1, f.y);
+            }
+
+        f32x16 hid[2];
+        Split8 b4[4];
+        mfma_layer<2, 2>(lds_hi, lds_lo, F0, lane, feat, hid);
+        const uint32_t mask_s = relu_to_operand(hid, b4);
+        f32x16 so[1];
+        mfma_layer<1, 4>(lds_hi, lds_lo, F1, lane, b4, so);
+
+        // rows 0..15 of the sigma head: register r (< 8) of half h is row_of_reg(h, r); row 0 is log-density
+        const bool live = s < M;
+        if (live && h == 0) sigmas[s] = expf(so[0][0]);  // trunc_exp forward (activation.py:9)
+        if (geo_out != nullptr && live) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int rho = row_of_reg(h, r);
+                if (rho >= 1) geo_out[15 * (size_t)s + rho - 1] = so[0][r];
+            }
+        }
+        uint32_t mask_c[2] = {0u, 0u};
+        if (rgbs != nullptr) {
+            float geo8[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) geo8[r] = so[0][r];
+            if (h == 0) geo8[0] = 1.0f;  // the slot of row 0 carries the padded constant input (weight column 31)
+            float rgb[3];
+            color_branch(lds_hi, lds_lo, lane, h, dirs[3 * (size_t)sl], dirs[3 * (size_t)sl + 1], dirs[3 * (size_t)sl + 2], geo8, mask_c, rgb);
+            if (live && h == 0) { rgbs[3 * (size_t)s] = rgb[0]; rgbs[3 * (size_t)s + 1] = rgb[1]; rgbs[3 * (size_t)s + 2] = rgb[2]; }
+        }
+        if (masks != nullptr) {
+            uint32_t *mrow = masks + (size_t)tile * 192 + lane;
+            mrow[0] = mask_s; mrow[64] = mask_c[0]; mrow[128] = mask_c[1];
+        }
+    }
+}
+
+// NeRFNetwork.color: geo features come from memory instead of the sigma head.
+__global__ void __launch_bounds__(256) k_field_color(const float *__restrict__ dirs, const float *__restrict__ geo, uint32_t M,
+                                                     const char *__restrict__ packed, float *__restrict__ rgbs) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    stage_weights(lds, packed, 2 * (int)kFwdBytes);
+    const char *lds_hi = lds, *lds_lo = lds + kFwdBytes;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    const uint32_t n_tiles = ceil_div(M, 32u);
+    for (uint32_t tile = blockIdx.x * 4 + wid; tile < n_tiles; tile += gridDim.x * 4) {
+        const uint32_t s = tile * 32 + p;
+        const uint32_t sl = min(s, M - 1);
+        float geo8[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int rho = row_of_reg(h, r);
+            geo8[r] = rho == 0 ? 1.0f : geo[15 * (size_t)sl + rho - 1];
+        }
+        uint32_t mask_c[2];
+        float rgb[3];
+        color_branch(lds_hi, lds_lo, lane, h, dirs[3 * (size_t)sl], dirs[3 * (size_t)sl + 1], dirs[3 * (size_t)sl + 2], geo8, mask_c, rgb);
+        if (s < M && h == 0) { rgbs[3 * (size_t)s] = rgb[0]; rgbs[3 * (size_t)s + 1] = rgb[1]; rgbs[3 * (size_t)s + 2] = rgb[2]; }
+    }
+}
+
+// ----------------------------------------------------------------------------- backward
+
+__global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyzs, uint32_t M, float bound, float cb_cell,
+                                                   const float *__restrict__ g_sigma, const float *__restrict__ g_rgb,
+                                                   const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                                   const uint32_t *__restrict__ masks, const char *__restrict__ packed,
+                                                   float *__restrict__ G, float *__restrict__ dfeat_out) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    stage_weights(lds, packed + 2 * kFwdBytes, 2 * (int)kBwdBytes);
+    const char *lds_hi = lds, *lds_lo = lds + kBwdBytes;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    const uint32_t n_tiles = ceil_div(M, 32u);
+    const float e_lo = expf(-15.0f), e_hi = expf(15.0f);
+    for (uint32_t tile = blockIdx.x * 4 + wid; tile < n_tiles; tile += gridDim.x * 4) {
+        const uint32_t s = tile * 32 + p;
+        const bool live = s < M;
+        const uint32_t sl = min(s, M - 1);
+        const uint32_t *mrow = masks + (size_t)tile * 192 + lane;
+        const uint32_t mask_s = mrow[0], mask_c0 = mrow[64], mask_c1 = mrow[128];
+
+        // d(pre-sigmoid color): only lane half 0, elements 0..2 of the 16-wide K-step are non-zero
+        Split8 dout[1];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = 0.0f;
+            if (j < 3 && h == 0 && live) {
+                const float c = rgbs[3 * (size_t)sl + j];
+                v = g_rgb[3 * (size_t)sl + j] * (c * (1.0f - c));
+            }
+            split_put(dout[0], j, v);
+        }
+        f32x16 hid[2];
+        Split8 b4[4];
+        mfma_layer<2, 1>(lds_hi, lds_lo, B0, lane, dout, hid);
+        mask_to_operand(hid, mask_c1, b4);
+        mfma_layer<2, 4>(lds_hi, lds_lo, B1, lane, b4, hid);
+        mask_to_operand(hid, mask_c0, b4);
+        f32x16 dso[1];
+        mfma_layer<1, 4>(lds_hi, lds_lo, B2, lane, b4, dso);  // rows 1..15 = d geo_feat
+
+        Split8 dhead[1];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) split_put(dhead[0], r, dso[0][r]);
+        if (h == 0) {  // row 0: d log-density = g * exp(clamp(h0, -15, 15)) (activation.py:14), with exp(h0) = sigma
+            const float sg = live ? sigmas[sl] : 0.0f;
+            split_put(dhead[0], 0, (live ? g_sigma[sl] : 0.0f) * fminf(fmaxf(sg, e_lo), e_hi));
+        }
+        mfma_layer<2, 1>(lds_hi, lds_lo, B3, lane, dhead, hid);
+        mask_to_operand(hid, mask_s, b4);
+        f32x16 dfe[1];
+        mfma_layer<1, 4>(lds_hi, lds_lo, B4, lane, b4, dfe);  // rows 0,1 (lane half 0) = d feature[30], d feature[31]
+
+        // both halves of a point share the scatter: half h handles corners 4h..4h+3
+        const float g0 = __shfl(dfe[0][0], p, 64), g1 = __shfl(dfe[0][1], p, 64);
+        if (!live) continue;
+        if (dfeat_out != nullptr && h == 0) { dfeat_out[2 * (size_t)s] = g0; dfeat_out[2 * (size_t)s + 1] = g1; }
+        if (G == nullptr || (g0 == 0.0f && g1 == 0.0f)) continue;
+        const float two_b = 2.0f * bound;
+        Corner8 c;
+        corner_rows((xyzs[3 * (size_t)s] + bound) / two_b, (xyzs[3 * (size_t)s + 1] + bound) / two_b, (xyzs[3 * (size_t)s + 2] + bound) / two_b, cb_cell, c);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if ((k >> 2) != h) continue;
+            float *row = G + 2 * (size_t)c.row[k];
+            atomicAdd(row, corner_weight(c, k, g0));
+            atomicAdd(row + 1, corner_weight(c, k, g1));
+        }
+    }
+}
+
+}  // namespace nsig
+
+using namespace nsig;
+
+NSIG_EXPORT size_t mlp_packed_bytes(void) { return kPackedBytes; }
+
+NSIG_EXPORT int mlp_pack_weights(const float *sigma_params, const float *color_params, void *packed, nsig_stream_t stream) {
+    NSIG_REQUIRE(sigma_params && color_params && packed, "mlp_pack_weights: null pointer");
+    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0, "mlp_pack_weights: packed must be 16-byte aligned");
+    const int total = (kFwdFrags + kBwdFrags) * 512;
+    k_pack_weights<<<ceil_div(total, 256), 256, 0, as_stream(stream)>>>(sigma_params, color_params, reinterpret_cast<__bf16 *>(packed));
+    return check_launch("mlp_pack_weights");
+}
+
+static uint32_t field_grid(uint32_t M) {
+    const uint32_t blocks = ceil_div(ceil_div(M, 32u), 4u);
+    return blocks < (uint32_t)(kCUs * 3) ? blocks : (uint32_t)(kCUs * 3);  // 3 workgroups per CU fit the LDS budget
+}
+
+static int fill_base_tables(const float *const *host, TablePtrs &base, const char *who) {
+    NSIG_REQUIRE(host, "%s: null base table list", who);
+    for (int l = 0; l < NSIG_BASE_LEVELS; ++l) {
+        NSIG_REQUIRE(host[l] != nullptr, "%s: base table %d is null", who, l);
+        base.p[l] = host[l];
+    }
+    return NSIG_OK;
+}
+
+NSIG_EXPORT int field_fwd(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *const *base_tables_host,
+                          const float *S, const void *packed, float *sigmas, float *rgbs, float *geo_feat, uint32_t *masks,
+                          nsig_stream_t stream) {
+    NSIG_REQUIRE(xyzs && packed && sigmas, "field_fwd: null pointer");
+    NSIG_REQUIRE(rgbs == nullptr || dirs != nullptr, "field_fwd: dirs is required when rgbs is requested");
+    NSIG_REQUIRE(bound > 0.0f, "field_fwd: bound must be positive");
+    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0, "field_fwd: packed must be 16-byte aligned");
+    TablePtrs base{};
+    if (int e = fill_base_tables(base_tables_host, base, "field_fwd")) return e;
+    if (M == 0) return NSIG_OK;
+    k_field_fwd<<<field_grid(M), 256, 2 * kFwdBytes, as_stream(stream)>>>(xyzs, dirs, M, bound, base, make_level_geom(), S,
+                                                                         reinterpret_cast<const char *>(packed), sigmas, rgbs, geo_feat, masks);
+    return check_launch("field_fwd");
+}
+
+NSIG_EXPORT int field_color_fwd(const float *dirs, const float *geo_feat, uint32_t M, const void *packed, float *rgbs, nsig_stream_t stream) {
+    NSIG_REQUIRE(dirs && geo_feat && packed && rgbs, "field_color_fwd: null pointer");
+    if (M == 0) return NSIG_OK;
+    k_field_color<<<field_grid(M), 256, 2 * kFwdBytes, as_stream(stream)>>>(dirs, geo_feat, M, reinterpret_cast<const char *>(packed), rgbs);
+    return check_launch("field_color_fwd");
+}
+
+NSIG_EXPORT int field_bwd(const float *xyzs, uint32_t M, float bound, const float *grad_sigmas, const float *grad_rgbs, const float *sigmas,
+                          const float *rgbs, const uint32_t *masks, const void *packed, float *G, float *dfeat_out, nsig_stream_t stream) {
+    NSIG_REQUIRE(xyzs && grad_sigmas && grad_rgbs && sigmas && rgbs && masks && packed, "field_bwd: null pointer");
+    NSIG_REQUIRE(G || dfeat_out, "field_bwd: at least one of G / dfeat_out must be given");
+    NSIG_REQUIRE(bound > 0.0f, "field_bwd: bound must be positive");
+    if (M == 0) return NSIG_OK;
+    k_field_bwd<<<field_grid(M), 256, 2 * kBwdBytes, as_stream(stream)>>>(xyzs, M, bound, 1.0f / kCodebookResolution, grad_sigmas, grad_rgbs,
+                                                                         sigmas, rgbs, masks, reinterpret_cast<const char *>(packed), G, dfeat_out);
+    return check_launch("field_bwd");
+}

@@ -1,0 +1,191 @@
+"""Functional wrappers (tensors in, tensors out) over the hash-grid and field-network entry points of
+libnerfsig (hg_*, mlp_*, field_* in include/nerfsig.h) and the autograd Functions built on them.
+
+These replace, on the GPU, the op chains of the reference's hash_encoding.py / hash_encoding_wtmk_bit.py
+and the tinycudann calls of nerf/network_wtmk_tcnn.py:97-176.  No host synchronisation happens here:
+the message bits are taken from a host-side tuple (see `message_bits`), never read back from the device.
+"""
+import torch
+from torch.autograd import Function
+from torch.amp import custom_bwd, custom_fwd
+
+from . import _native as nv
+
+T_ROWS = 1 << 19
+MASK_WORDS = 6
+
+_fwd32 = custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_bwd = custom_bwd(device_type="cuda")
+
+
+def message_bits(message):
+    """Host tuple of 0/1 ints for a message given as a tensor (CPU: free; GPU: one small D2H copy, which is
+    the single synchronisation the reference performs D times per call, hash_encoding_wtmk_bit.py:110),
+    a list or a tuple."""
+    if message is None:
+        return None
+    if isinstance(message, torch.Tensor):
+        return tuple(int(v) for v in message.detach().to("cpu", torch.float32).tolist())
+    return tuple(int(v) for v in message)
+
+
+def select_tables(tables, bits):
+    """Table 2i + bit_i for every bit (hash_encoding_wtmk_bit.py:110)."""
+    if len(tables) != 2 * len(bits):
+        raise ValueError(f"codebook has {len(tables)} tables but the message has {len(bits)} bits (expected {len(tables) // 2})")
+    return [tables[2 * i + b] for i, b in enumerate(bits)]
+
+
+def _check_table(t, name):
+    if t.dtype != torch.float32 or tuple(t.shape) != (T_ROWS, 2):
+        raise ValueError(f"{name}: expected a float32 [{T_ROWS}, 2] table, got {t.dtype} {tuple(t.shape)}")
+    return t
+
+
+def codebook_presum(selected, out=None):
+    """S = sum of the D selected codebook tables -> hg_codebook_presum."""
+    for i, t in enumerate(selected):
+        _check_table(t, f"codebook table {i}")
+    S = out if out is not None else torch.empty(T_ROWS, 2, dtype=torch.float32, device=selected[0].device)
+    nv.call("hg_codebook_presum", nv.ptr_array([t.detach() for t in selected]), len(selected), nv.ptr(S), nv.stream())
+    return S
+
+
+def encode(x01, base_tables, S=None):
+    """[M,32] features of the base encoder (+ codebook through S) -> hg_encode_fwd."""
+    x01 = x01.contiguous().float()
+    M = x01.shape[0]
+    feat = torch.empty(M, 32, dtype=torch.float32, device=x01.device)
+    nv.call("hg_encode_fwd", nv.ptr(x01), M, nv.ptr_array([_check_table(t.detach(), "base table") for t in base_tables]), nv.ptr(S),
+            nv.ptr(feat), nv.stream())
+    return feat
+
+
+def codebook_encode_literal(x01, selected):
+    """[M,2] codebook feature by D separate gathers -> hg_codebook_encode_fwd."""
+    x01 = x01.contiguous().float()
+    M = x01.shape[0]
+    out = torch.empty(M, 2, dtype=torch.float32, device=x01.device)
+    nv.call("hg_codebook_encode_fwd", nv.ptr(x01), M, nv.ptr_array([_check_table(t.detach(), "codebook table") for t in selected]),
+            len(selected), nv.ptr(out), nv.stream())
+    return out
+
+
+def codebook_scatter(x01, dfeat, G):
+    """G += scatter of dfeat [M,2] through the codebook lookup -> hg_codebook_bwd."""
+    x01 = x01.contiguous().float()
+    dfeat = dfeat.contiguous().float()
+    nv.call("hg_codebook_bwd", nv.ptr(x01), x01.shape[0], nv.ptr(dfeat), nv.ptr(G), nv.stream())
+    return G
+
+
+def fanout_grad(G, grads, accumulate=False):
+    """grads[i] (+)= G for every selected table -> hg_fanout_grad."""
+    nv.call("hg_fanout_grad", nv.ptr(G), nv.ptr_array(grads), len(grads), int(bool(accumulate)), nv.stream())
+
+
+def level_lookup(x01, resolution):
+    x01 = x01.contiguous().float()
+    M = x01.shape[0]
+    rows = torch.empty(M, 8, dtype=torch.int32, device=x01.device)
+    w = torch.empty(M, 3, dtype=torch.float32, device=x01.device)
+    nv.call("hg_level_lookup", nv.ptr(x01), M, float(resolution), nv.ptr(rows), nv.ptr(w), nv.stream())
+    return rows, w
+
+
+def pack_weights(sigma_params, color_params):
+    """Split-bf16 MFMA operand image of the two flat parameter vectors -> mlp_pack_weights."""
+    if sigma_params.numel() != 3072 or color_params.numel() != 7168:
+        raise ValueError(f"expected sigma_params[3072] and color_params[7168], got {sigma_params.numel()} and {color_params.numel()}")
+    sp = sigma_params.detach().contiguous().float()
+    cp = color_params.detach().contiguous().float()
+    packed = torch.empty(int(nv.fn("mlp_packed_bytes")()), dtype=torch.uint8, device=sp.device)
+    nv.call("mlp_pack_weights", nv.ptr(sp), nv.ptr(cp), nv.ptr(packed), nv.stream())
+    return packed
+
+
+def field_forward(xyzs, dirs, bound, base_tables, S, packed, want_rgb=True, want_geo=False, want_masks=False):
+    """sigma [M], rgb [M,3] | None, geo_feat [M,15] | None, masks | None -> field_fwd."""
+    xyzs = xyzs.contiguous().float()
+    M, dev = xyzs.shape[0], xyzs.device
+    sigmas = torch.empty(M, dtype=torch.float32, device=dev)
+    rgbs = torch.empty(M, 3, dtype=torch.float32, device=dev) if want_rgb else None
+    geo = torch.empty(M, 15, dtype=torch.float32, device=dev) if want_geo else None
+    masks = torch.empty((M + 31) // 32 * 32, MASK_WORDS, dtype=torch.int32, device=dev) if want_masks else None
+    if want_rgb:
+        dirs = dirs.contiguous().float()
+    nv.call("field_fwd", nv.ptr(xyzs), nv.ptr(dirs) if want_rgb else None, M, float(bound),
+            nv.ptr_array([_check_table(t.detach(), "base table") for t in base_tables]), nv.ptr(S), nv.ptr(packed), nv.ptr(sigmas),
+            nv.ptr(rgbs), nv.ptr(geo), nv.ptr(masks), nv.stream())
+    return sigmas, rgbs, geo, masks
+
+
+def field_color(dirs, geo_feat, packed):
+    dirs = dirs.contiguous().float()
+    geo_feat = geo_feat.contiguous().float()
+    M = dirs.shape[0]
+    rgbs = torch.empty(M, 3, dtype=torch.float32, device=dirs.device)
+    nv.call("field_color_fwd", nv.ptr(dirs), nv.ptr(geo_feat), M, nv.ptr(packed), nv.ptr(rgbs), nv.stream())
+    return rgbs
+
+
+def field_backward(xyzs, bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, G=None, want_dfeat=False):
+    xyzs = xyzs.contiguous().float()
+    M = xyzs.shape[0]
+    dfeat = torch.empty(M, 2, dtype=torch.float32, device=xyzs.device) if want_dfeat else None
+    nv.call("field_bwd", nv.ptr(xyzs), M, float(bound), nv.ptr(g_sigma.contiguous().float()), nv.ptr(g_rgb.contiguous().float()),
+            nv.ptr(sigmas), nv.ptr(rgbs), nv.ptr(masks), nv.ptr(packed), nv.ptr(G), nv.ptr(dfeat), nv.stream())
+    return dfeat
+
+
+class GradSink:
+    """Where the shared codebook gradient G [T,2] of one optimisation step accumulates.
+
+    Every selected table receives the same gradient (see hashgrid.hip header), so all renders of a step
+    scatter into one 4 MiB buffer; `flush` fans it out into the `.grad` of the selected tables (after an
+    optional all-reduce of G alone in data-parallel runs -- 4 MiB instead of D x 4 MiB)."""
+
+    def __init__(self, device):
+        self.G = torch.zeros(T_ROWS, 2, dtype=torch.float32, device=device)
+        self.dirty = False
+
+    def zero_(self):
+        self.G.zero_()
+        self.dirty = False
+
+
+class _FieldFunction(Function):
+    """NeRFNetwork.forward as one autograd node (network_wtmk_tcnn.py:97-124).
+
+    Inputs after `n_base`: base tables (16, frozen) then the D selected codebook tables (the only
+    differentiable inputs).  Backward returns the same fan-out of the shared gradient for each of them."""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, xyzs, dirs, bound, packed, n_sel, *tables):
+        base, sel = tables[:16], tables[16:16 + n_sel]
+        S = codebook_presum(sel) if n_sel else None
+        need_grad = n_sel > 0 and any(t.requires_grad for t in sel)
+        sigmas, rgbs, _, masks = field_forward(xyzs, dirs, bound, base, S, packed, want_masks=need_grad)
+        ctx.bound, ctx.n_sel, ctx.need_grad = bound, n_sel, need_grad
+        if need_grad:
+            ctx.save_for_backward(xyzs, sigmas, rgbs, masks, packed)
+        return sigmas, rgbs
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, g_sigma, g_rgb):
+        none_head = (None, None, None, None, None) + (None,) * 16
+        if not ctx.need_grad:
+            return none_head + (None,) * ctx.n_sel
+        xyzs, sigmas, rgbs, masks, packed = ctx.saved_tensors
+        G = torch.zeros(T_ROWS, 2, dtype=torch.float32, device=xyzs.device)
+        field_backward(xyzs, ctx.bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, G=G)
+        slab = torch.empty(ctx.n_sel, T_ROWS, 2, dtype=torch.float32, device=xyzs.device)
+        grads = [slab[i] for i in range(ctx.n_sel)]
+        fanout_grad(G, grads, accumulate=False)
+        return none_head + tuple(grads)
+
+
+def field_apply(xyzs, dirs, bound, packed, base_tables, selected):
+    return _FieldFunction.apply(xyzs, dirs, bound, packed, len(selected), *base_tables, *selected)
