@@ -1,0 +1,76 @@
+"""Data-parallel gradient exchange: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on
+ROCm; "gloo" for the CPU tests).
+
+What is exchanged per step: the decoder's gradients (261 893 fp32, one flat bucket) and the
+codebook gradient.  Because every selected codebook table receives the same gradient G [T,2]
+(csrc/hashgrid.hip), ranks all-reduce G alone -- 4 MiB -- and fan it out locally, instead of all-reducing
+D dense [T,2] gradients (128 MiB at D=32).  Rays are sharded by rank (distinct content rays per rank), the
+block render and the message are replicated, so the result equals the single-process gradient of the mean loss."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+class GradExchange:
+    """Mean all-reduce of (shared codebook gradient, decoder gradients) with the decoder in one flat bucket."""
+
+    def __init__(self, decoder_params):
+        self.decoder_params = [p for p in decoder_params if p.requires_grad]
+        n = sum(p.numel() for p in self.decoder_params)
+        p0 = self.decoder_params[0]
+        self.bucket = torch.zeros(n, dtype=torch.float32, device=p0.device)
+        self.bytes_per_step = 0
+
+    def __call__(self, shared_grad):
+        """shared_grad: the GradSink's G (or None).  In-place mean over ranks of G and of every decoder .grad."""
+        world = world_size()
+        if world == 1:
+            return
+        handles = []
+        if shared_grad is not None:
+            handles.append(dist.all_reduce(shared_grad, op=dist.ReduceOp.SUM, async_op=True))
+        off = 0
+        for p in self.decoder_params:
+            n = p.numel()
+            if p.grad is None:
+                self.bucket[off:off + n].zero_()
+            else:
+                self.bucket[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        handles.append(dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, async_op=True))
+        for h in handles:
+            h.wait()
+        inv = 1.0 / world
+        if shared_grad is not None:
+            shared_grad.mul_(inv)
+        off = 0
+        for p in self.decoder_params:
+            n = p.numel()
+            g = self.bucket[off:off + n].view_as(p) * inv
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n
+        self.bytes_per_step = (shared_grad.numel() * 4 if shared_grad is not None else 0) + self.bucket.numel() * 4

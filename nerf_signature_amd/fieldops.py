@@ -141,51 +141,71 @@ def field_backward(xyzs, bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, G=N
 class GradSink:
     """Where the shared codebook gradient G [T,2] of one optimisation step accumulates.
 
-    Every selected table receives the same gradient (see hashgrid.hip header), so all renders of a step
-    scatter into one 4 MiB buffer; `flush` fans it out into the `.grad` of the selected tables (after an
-    optional all-reduce of G alone in data-parallel runs -- 4 MiB instead of D x 4 MiB)."""
+    Every selected table receives the same gradient (see csrc/hashgrid.hip), so all renders of a step
+    scatter into one 4 MiB buffer instead of D of them.  The trainer then (optionally) all-reduces G alone
+    across data-parallel ranks -- 4 MiB instead of D x 4 MiB -- and either fans it out into the `.grad` of
+    the selected tables (`fanout`) or feeds it straight to the fused codebook optimiser."""
 
     def __init__(self, device):
         self.G = torch.zeros(T_ROWS, 2, dtype=torch.float32, device=device)
-        self.dirty = False
+        self.selected = None  # the parameters the pending gradient belongs to
 
     def zero_(self):
         self.G.zero_()
-        self.dirty = False
+        self.selected = None
+
+    def fanout(self, accumulate=False):
+        """Materialise `.grad` of every selected table from G (what autograd would have produced)."""
+        if self.selected is None:
+            return
+        slab = torch.empty(len(self.selected), T_ROWS, 2, dtype=torch.float32, device=self.G.device)
+        grads = [slab[i] for i in range(len(self.selected))]
+        fanout_grad(self.G, grads)
+        for p, g in zip(self.selected, grads):
+            p.grad = g if (p.grad is None or not accumulate) else p.grad + g
 
 
 class _FieldFunction(Function):
     """NeRFNetwork.forward as one autograd node (network_wtmk_tcnn.py:97-124).
 
-    Inputs after `n_base`: base tables (16, frozen) then the D selected codebook tables (the only
-    differentiable inputs).  Backward returns the same fan-out of the shared gradient for each of them."""
+    `tables` = 16 frozen base tables followed by the D selected codebook tables, the only differentiable
+    inputs.  Without a sink, backward returns the fan-out of the shared gradient for each selected table
+    (unselected tables are not inputs, so their grad stays None exactly as in the reference); with a sink
+    the gradient accumulates there and autograd sees None."""
 
     @staticmethod
     @_fwd32
-    def forward(ctx, xyzs, dirs, bound, packed, n_sel, *tables):
+    def forward(ctx, xyzs, dirs, bound, packed, S, sink, n_sel, *tables):
         base, sel = tables[:16], tables[16:16 + n_sel]
-        S = codebook_presum(sel) if n_sel else None
         need_grad = n_sel > 0 and any(t.requires_grad for t in sel)
         sigmas, rgbs, _, masks = field_forward(xyzs, dirs, bound, base, S, packed, want_masks=need_grad)
-        ctx.bound, ctx.n_sel, ctx.need_grad = bound, n_sel, need_grad
+        ctx.bound, ctx.n_sel, ctx.need_grad, ctx.sink = bound, n_sel, need_grad, sink
         if need_grad:
             ctx.save_for_backward(xyzs, sigmas, rgbs, masks, packed)
+            if sink is not None:
+                sink.selected = list(sel)
         return sigmas, rgbs
 
     @staticmethod
     @_bwd
     def backward(ctx, g_sigma, g_rgb):
-        none_head = (None, None, None, None, None) + (None,) * 16
+        head = (None,) * 7 + (None,) * 16
         if not ctx.need_grad:
-            return none_head + (None,) * ctx.n_sel
+            return head + (None,) * ctx.n_sel
         xyzs, sigmas, rgbs, masks, packed = ctx.saved_tensors
+        if ctx.sink is not None:
+            field_backward(xyzs, ctx.bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, G=ctx.sink.G)
+            return head + (None,) * ctx.n_sel
         G = torch.zeros(T_ROWS, 2, dtype=torch.float32, device=xyzs.device)
         field_backward(xyzs, ctx.bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, G=G)
         slab = torch.empty(ctx.n_sel, T_ROWS, 2, dtype=torch.float32, device=xyzs.device)
         grads = [slab[i] for i in range(ctx.n_sel)]
         fanout_grad(G, grads, accumulate=False)
-        return none_head + tuple(grads)
+        return head + tuple(grads)
 
 
-def field_apply(xyzs, dirs, bound, packed, base_tables, selected):
-    return _FieldFunction.apply(xyzs, dirs, bound, packed, len(selected), *base_tables, *selected)
+def field_apply(xyzs, dirs, bound, packed, base_tables, selected, S=None, sink=None):
+    """(sigma, rgb) with autograd to the selected codebook tables.  S: their pre-sum (computed here if omitted)."""
+    if len(selected) and S is None:
+        S = codebook_presum(selected)
+    return _FieldFunction.apply(xyzs, dirs, bound, packed, S, sink, len(selected), *base_tables, *selected)

@@ -1,0 +1,112 @@
+"""NeRFNetwork: the watermarked field network behind the reference's class surface
+(/root/reference/nerf/network_wtmk_tcnn.py:15-194), evaluated by libnerfsig's fused field kernels.
+
+Sub-module names reproduce the reference's state_dict keys: `encoder` (16 base tables), `msg_encoder`
+(2*message_dim codebook tables), `sigma_net.params`, `encoder_dir.params`, `color_net.params`,
+`msg_decoder.*`, plus the renderer's buffers.  As in the reference the base encoder and both MLPs are
+frozen (network_wtmk_tcnn.py:90-95) and `get_params` exposes only the codebook and the decoder."""
+import torch
+
+from . import fieldops as fo
+from . import tcnn_compat as tcnn
+from .hash_encoding import HashEmbedder
+from .hash_encoding_wtmk_bit import HashEmbedder as HashEmbedder_msg
+from .hidden_models import get_hidden_decoder_multi_views, normalize_img
+from .renderer import NeRFRenderer
+
+
+class NeRFNetwork(NeRFRenderer):
+    def __init__(self, num_layers=2, hidden_dim=64, geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64, bound=1, message_dim=16,
+                 n_views=1, finetune_decoder=False, **kwargs):
+        super().__init__(bound, **kwargs)
+        if (num_layers, hidden_dim, geo_feat_dim, num_layers_color, hidden_dim_color) != (2, 64, 15, 3, 64):
+            raise NotImplementedError("the native field network implements the reference's default architecture: "
+                                      "sigma 32->64->1+15, color 16+15->64->64->3")
+        self.finetune_decoder = finetune_decoder
+        self.num_layers, self.hidden_dim, self.geo_feat_dim = num_layers, hidden_dim, geo_feat_dim
+        self.num_layers_color, self.hidden_dim_color = num_layers_color, hidden_dim_color
+        self.message_dim = message_dim
+
+        self.encoder = HashEmbedder(bounding_box=(0, 1), n_levels=16, n_features_per_level=2, log2_hashmap_size=19,
+                                    base_resolution=16, finest_resolution=2048)
+        self.msg_encoder = HashEmbedder_msg(bounding_box=(0, 1), n_levels=message_dim * 2, n_features_per_level=2,
+                                            log2_hashmap_size=19, base_resolution=2048, finest_resolution=2048, message_dim=message_dim)
+        self.msg_decoder = get_hidden_decoder_multi_views(num_bits=1, redundancy=1, num_blocks=8, input_ch=n_views * 3, channels=64)
+        self.normalization = normalize_img
+        mlp = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None"}
+        self.sigma_net = tcnn.Network(n_input_dims=32, n_output_dims=1 + geo_feat_dim,
+                                      network_config={**mlp, "n_neurons": hidden_dim, "n_hidden_layers": num_layers - 1}, seed=1337)
+        self.encoder_dir = tcnn.Encoding(n_input_dims=3, encoding_config={"otype": "SphericalHarmonics", "degree": 4})
+        self.in_dim_color = self.encoder_dir.n_output_dims + geo_feat_dim
+        self.color_net = tcnn.Network(n_input_dims=self.in_dim_color, n_output_dims=3,
+                                      network_config={**mlp, "n_neurons": hidden_dim_color, "n_hidden_layers": num_layers_color - 1}, seed=1338)
+
+        frozen = [*self.encoder.parameters(), *self.color_net.parameters(), *self.sigma_net.parameters()]
+        if finetune_decoder:
+            frozen += [*self.msg_encoder.parameters()]
+        for p in frozen:
+            p.requires_grad = False
+
+        self._packed_cache = None   # (key, packed weight image)
+        self._presum_cache = None   # (key, S)
+        self.grad_sink = None       # optional fieldops.GradSink: backward accumulates the shared gradient there
+
+    # ------------------------------------------------------------------ cached device images
+
+    def _packed(self):
+        sp, cp = self.sigma_net.params, self.color_net.params
+        key = (sp.data_ptr(), sp._version, cp.data_ptr(), cp._version)
+        if self._packed_cache is None or self._packed_cache[0] != key:
+            self._packed_cache = (key, fo.pack_weights(sp, cp))
+        return self._packed_cache[1]
+
+    def _presum(self, selected, bits):
+        """S = sum of the selected codebook tables; reused while neither the message nor the tables change
+        (the two renders of one training step, every chunk of a staged full-image render)."""
+        key = (bits, tuple((t.data_ptr(), t._version) for t in selected))
+        if self._presum_cache is None or self._presum_cache[0] != key:
+            S = self._presum_cache[1] if self._presum_cache is not None else None
+            self._presum_cache = (key, fo.codebook_presum(selected, out=S))
+        return self._presum_cache[1]
+
+    def _select(self, message):
+        if message is None:
+            return (), None, None
+        bits = fo.message_bits(message)
+        if len(bits) != self.message_dim:
+            raise ValueError(f"message has {len(bits)} bits, the network was built with message_dim={self.message_dim}")
+        selected = fo.select_tables(self.msg_encoder.tables(), bits)
+        return selected, bits, self._presum(selected, bits)
+
+    # ------------------------------------------------------------------ reference surface
+
+    def forward(self, x, d, message):
+        """x: [N,3] in [-bound,bound], d: [N,3] unit, message: [message_dim] of 0./1. or None -> (sigma [N], color [N,3])."""
+        selected, _, S = self._select(message)
+        return fo.field_apply(x, d, self.bound, self._packed(), self.encoder.tables(), selected, S, self.grad_sink)
+
+    def density(self, x, message=None):
+        if torch.is_grad_enabled() and message is not None and any(t.requires_grad for t in self.msg_encoder.tables()):
+            raise NotImplementedError("density()/color() are evaluated without autograd (grid updates, the uniform-sample `run` "
+                                      "path under no_grad); training goes through forward() on the occupancy-grid path")
+        _, _, S = self._select(message)
+        sigma, _, geo, _ = fo.field_forward(x, None, self.bound, self.encoder.tables(), S, self._packed(), want_rgb=False, want_geo=True)
+        return {"sigma": sigma, "geo_feat": geo}
+
+    def color(self, x, d, mask=None, geo_feat=None, **kwargs):
+        if mask is not None:
+            rgbs = torch.zeros(mask.shape[0], 3, dtype=torch.float32, device=x.device)
+            if not mask.any():
+                return rgbs
+            rgbs[mask] = fo.field_color(d[mask], geo_feat[mask], self._packed())
+            return rgbs
+        return fo.field_color(d, geo_feat, self._packed())
+
+    def get_params(self, lr):
+        if self.finetune_decoder:
+            params = [{"params": self.msg_decoder.parameters(), "lr": lr}]
+        else:
+            params = [{"params": self.msg_encoder.parameters(), "lr": lr}, {"params": self.msg_decoder.parameters(), "lr": lr}]
+        if self.bg_radius > 0:
+            raise NotImplementedError("background model (bg_radius > 0) is asserted off on this path (main_nerf_wtmk.py:86)")
+        return params

@@ -1,0 +1,269 @@
+"""NeRFRenderer: the host-side mirror of /root/reference/nerf/renderer_wtmk.py:61-575 on top of libnerfsig.
+
+Same constructor, buffers (`density_grid`, `density_bitfield`, `step_counter`, `aabb_train`, `aabb_infer`),
+attributes and methods (`render`, `run_cuda`, `run`, `mark_untrained_grid`, `update_extra_state`,
+`reset_extra_state`) as the reference class, so the reference's Trainer / provider / CLI drive it unchanged.
+`render` accepts and ignores arbitrary extra keyword arguments: the reference splats its whole argparse
+namespace into it (nerf/utils_wtmk_disen.py:590,616)."""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import raymarching
+
+
+def custom_meshgrid(*args):
+    return torch.meshgrid(*args, indexing="ij")
+
+
+class NeRFRenderer(nn.Module):
+    def __init__(self, bound=1, cuda_ray=False, density_scale=1, min_near=0.2, density_thresh=0.01, bg_radius=-1):
+        super().__init__()
+        self.bound = bound
+        self.cascade = 1 + math.ceil(math.log2(bound))
+        self.grid_size = 128
+        self.density_scale = density_scale
+        self.min_near = min_near
+        self.density_thresh = density_thresh
+        self.bg_radius = bg_radius
+        aabb_train = torch.FloatTensor([-bound, -bound, -bound, bound, bound, bound])
+        self.register_buffer("aabb_train", aabb_train)
+        self.register_buffer("aabb_infer", aabb_train.clone())
+        self.cuda_ray = cuda_ray
+        if cuda_ray:
+            self.register_buffer("density_grid", torch.zeros([self.cascade, self.grid_size ** 3]))
+            self.register_buffer("density_bitfield", torch.zeros(self.cascade * self.grid_size ** 3 // 8, dtype=torch.uint8))
+            self.mean_density = 0
+            self.iter_density = 0
+            self.register_buffer("step_counter", torch.zeros(16, 2, dtype=torch.int32))
+            self.mean_count = 0
+            self.local_step = 0
+
+    def forward(self, x, d):
+        raise NotImplementedError()
+
+    def density(self, x):
+        raise NotImplementedError()
+
+    def color(self, x, d, mask=None, **kwargs):
+        raise NotImplementedError()
+
+    def reset_extra_state(self):
+        if not self.cuda_ray:
+            return
+        self.density_grid.zero_()
+        self.mean_density = 0
+        self.iter_density = 0
+        self.step_counter.zero_()
+        self.mean_count = 0
+        self.local_step = 0
+
+    # ------------------------------------------------------------------ shared pieces
+
+    def _flatten_rays(self, rays_o, rays_d):
+        return rays_o.shape[:-1], rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3)
+
+    def _background(self, bg_color):
+        if self.bg_radius > 0:
+            raise NotImplementedError("background model (bg_radius > 0) is asserted off on this path (main_nerf_wtmk.py:86)")
+        return 1 if bg_color is None else bg_color
+
+    @staticmethod
+    def _finish(prefix, image, depth, weights_sum, bg_color, nears, fars):
+        """Background mix and depth normalisation shared by both branches (renderer_wtmk.py:316-319,369-372);
+        depth is NaN for rays that miss the box (near == far == FLT_MAX), as in the reference."""
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+        return image.view(*prefix, 3), depth.view(*prefix)
+
+    # ------------------------------------------------------------------ uniform-sample path (renderer_wtmk.py:125-253)
+
+    def run(self, rays_o, rays_d, message, num_steps=128, upsample_steps=128, bg_color=None, perturb=False, **kwargs):
+        """num_steps samples per ray, uniformly in [near, far]; density everywhere, colour only where the
+        compositing weight exceeds 1e-4 (renderer_wtmk.py:215)."""
+        if upsample_steps > 0:
+            raise NotImplementedError("importance re-sampling (upsample_steps > 0) is not on the watermark path "
+                                      "(main_nerf_wtmk.py:27 defaults it to 0)")
+        bg_color = self._background(bg_color)
+        prefix, o, d = self._flatten_rays(rays_o, rays_d)
+        N, T = o.shape[0], num_steps
+        aabb = self.aabb_train if self.training else self.aabb_infer
+        nears, fars = (t.unsqueeze(-1) for t in raymarching.near_far_from_aabb(o, d, aabb, self.min_near))
+        span = fars - nears
+        z = nears + span * torch.linspace(0.0, 1.0, T, device=o.device).unsqueeze(0).expand(N, T)
+        spacing = span / T
+        if perturb:
+            z = z + (torch.rand(z.shape, device=o.device) - 0.5) * spacing
+        pts = torch.min(torch.max(o.unsqueeze(-2) + d.unsqueeze(-2) * z.unsqueeze(-1), aabb[:3]), aabb[3:])
+        field = self.density(pts.reshape(-1, 3), message=message)
+        step = torch.cat([z[..., 1:] - z[..., :-1], spacing * torch.ones_like(z[..., :1])], dim=-1)
+        alpha = 1 - torch.exp(-step * self.density_scale * field["sigma"].view(N, T))
+        transmittance = torch.cumprod(torch.cat([torch.ones_like(alpha[..., :1]), 1 - alpha + 1e-15], dim=-1), dim=-1)[..., :-1]
+        weights = alpha * transmittance
+        rgbs = self.color(pts.reshape(-1, 3), d.view(-1, 1, 3).expand_as(pts).reshape(-1, 3), mask=(weights > 1e-4).reshape(-1),
+                          geo_feat=field["geo_feat"]).view(N, T, 3)
+        weights_sum = weights.sum(dim=-1)
+        depth = torch.sum(weights * ((z - nears) / span).clamp(0, 1), dim=-1)
+        image = torch.sum(weights.unsqueeze(-1) * rgbs, dim=-2) + (1 - weights_sum).unsqueeze(-1) * bg_color
+        return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "weights_sum": weights_sum}
+
+    # ------------------------------------------------------------------ occupancy-grid path (renderer_wtmk.py:256-377)
+
+    def run_cuda(self, rays_o, rays_d, message, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024,
+                 T_thresh=1e-4, **kwargs):
+        bg_color = self._background(bg_color)
+        prefix, o, d = self._flatten_rays(rays_o, rays_d)
+        nears, fars = raymarching.near_far_from_aabb(o, d, self.aabb_train if self.training else self.aabb_infer, self.min_near)
+        if self.training:
+            weights_sum, depth, image = self._march_and_composite_train(o, d, message, nears, fars, dt_gamma, perturb, force_all_rays,
+                                                                        max_steps, T_thresh)
+        else:
+            weights_sum, depth, image = self._march_and_composite_eval(o, d, message, nears, fars, dt_gamma, perturb, max_steps, T_thresh)
+        image, depth = self._finish(prefix, image, depth, weights_sum, bg_color, nears, fars)
+        results = {"depth": depth, "image": image}
+        if self.training:
+            results["weights_sum"] = weights_sum
+        return results
+
+    def _march_and_composite_train(self, o, d, message, nears, fars, dt_gamma, perturb, force_all_rays, max_steps, T_thresh):
+        """All samples of all rays at once, then one differentiable composite (renderer_wtmk.py:280-321)."""
+        counter = self.step_counter[self.local_step % 16]  # ring of the last 16 (points, rays) totals
+        counter.zero_()
+        self.local_step += 1
+        xyzs, dirs, deltas, rays = raymarching.march_rays_train(o, d, self.bound, self.density_bitfield, self.cascade, self.grid_size,
+                                                               nears, fars, counter, self.mean_count, perturb, 128, force_all_rays,
+                                                               dt_gamma, max_steps)
+        sigmas, rgbs = self(xyzs, dirs, message)
+        return raymarching.composite_rays_train(self.density_scale * sigmas, rgbs, deltas, rays, T_thresh)
+
+    def _march_and_composite_eval(self, o, d, message, nears, fars, dt_gamma, perturb, max_steps, T_thresh):
+        """Bursts of 1..8 samples over the still-alive rays (renderer_wtmk.py:323-367).  The alive list is compacted
+        on the device; only the survivor count crosses to the host each round."""
+        N, device = o.shape[0], o.device
+        weights_sum = torch.zeros(N, dtype=torch.float32, device=device)
+        depth = torch.zeros(N, dtype=torch.float32, device=device)
+        image = torch.zeros(N, 3, dtype=torch.float32, device=device)
+        rays_alive = torch.arange(N, dtype=torch.int32, device=device)
+        rays_t = nears.clone()
+        n_alive, step = N, 0
+        while step < max_steps and n_alive > 0:
+            n_step = max(min(N // n_alive, 8), 1)
+            xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, o, d, self.bound, self.density_bitfield,
+                                                        self.cascade, self.grid_size, nears, fars, 128, perturb if step == 0 else False,
+                                                        dt_gamma, max_steps)
+            sigmas, rgbs = self(xyzs, dirs, message)
+            raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, self.density_scale * sigmas, rgbs, deltas, weights_sum, depth,
+                                       image, T_thresh)
+            compacted, n_out = raymarching.compact_alive(rays_alive[:n_alive])
+            n_alive = int(n_out.item())
+            rays_alive = compacted[:n_alive]
+            step += n_step
+        return weights_sum, depth, image
+
+    # ------------------------------------------------------------------ density-grid maintenance
+
+    def _grid_blocks(self, S):
+        """All grid cells in S^3 blocks: yields (integer coords [n,3], morton index [n]) on the grid's device."""
+        dev = self.density_bitfield.device
+        axis = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
+        for xs in axis:
+            for ys in axis:
+                for zs in axis:
+                    coords = torch.stack(custom_meshgrid(xs, ys, zs), dim=-1).reshape(-1, 3)
+                    yield coords, raymarching.morton3D(coords).long()
+
+    def _cascade_extent(self, cas):
+        extent = min(2 ** cas, self.bound)
+        return extent, extent / self.grid_size  # (half-width of the cascade, half a cell)
+
+    def _cell_centres(self, coords, cas, jitter):
+        """World position of grid cells of cascade `cas` (optionally jittered inside the cell)."""
+        extent, half_cell = self._cascade_extent(cas)
+        pts = (2 * coords.float() / (self.grid_size - 1) - 1) * (extent - half_cell)
+        if jitter:
+            pts += (torch.rand_like(pts) * 2 - 1) * half_cell
+        return pts
+
+    @torch.no_grad()
+    def mark_untrained_grid(self, poses, intrinsic, S=64):
+        """Cells that no training camera sees get density -1 (renderer_wtmk.py:380-442)."""
+        if not self.cuda_ray:
+            return
+        if isinstance(poses, np.ndarray):
+            poses = torch.from_numpy(poses)
+        fx, fy, cx, cy = intrinsic
+        seen = torch.zeros_like(self.density_grid)
+        poses = poses.to(seen.device)
+        for coords, indices in self._grid_blocks(S):
+            for cas in range(self.cascade):
+                _, half_cell = self._cascade_extent(cas)
+                world = self._cell_centres(coords, cas, jitter=False).unsqueeze(0)
+                for head in range(0, poses.shape[0], S):
+                    batch = poses[head:head + S]
+                    cam = (world - batch[:, :3, 3].unsqueeze(1)) @ batch[:, :3, :3]  # world -> camera, [S,n,3]
+                    in_front = cam[:, :, 2] > 0
+                    in_x = torch.abs(cam[:, :, 0]) < cx / fx * cam[:, :, 2] + half_cell * 2
+                    in_y = torch.abs(cam[:, :, 1]) < cy / fy * cam[:, :, 2] + half_cell * 2
+                    seen[cas, indices] += (in_front & in_x & in_y).sum(0).reshape(-1)
+        self.density_grid[seen == 0] = -1
+        print(f"[mark untrained grid] {(seen == 0).sum()} from {self.grid_size ** 3 * self.cascade}")
+
+    def _probe_density(self, coords, cas, message):
+        pts = self._cell_centres(coords, cas, jitter=True)
+        return self.density(pts, message)["sigma"].reshape(-1).detach() * self.density_scale
+
+    @torch.no_grad()
+    def update_extra_state(self, message=None, decay=0.95, S=128):
+        """EMA update of the density grid, re-pack of the bitfield, mean sample count (renderer_wtmk.py:445-538):
+        the first 16 calls probe every cell, later calls a random quarter plus as many occupied cells."""
+        if not self.cuda_ray:
+            return
+        dev = self.density_bitfield.device
+        fresh = -torch.ones_like(self.density_grid)
+        if self.iter_density < 16:
+            for coords, indices in self._grid_blocks(S):
+                for cas in range(self.cascade):
+                    fresh[cas, indices] = self._probe_density(coords, cas, message)
+        else:
+            n = self.grid_size ** 3 // 4
+            for cas in range(self.cascade):
+                rand_coords = torch.randint(0, self.grid_size, (n, 3), device=dev)
+                rand_idx = raymarching.morton3D(rand_coords).long()
+                occupied = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
+                occ_idx = occupied[torch.randint(0, occupied.shape[0], [n], dtype=torch.long, device=dev)]
+                occ_coords = raymarching.morton3D_invert(occ_idx)
+                indices = torch.cat([rand_idx, occ_idx], dim=0)
+                fresh[cas, indices] = self._probe_density(torch.cat([rand_coords, occ_coords], dim=0), cas, message)
+        both = (self.density_grid >= 0) & (fresh >= 0)
+        self.density_grid[both] = torch.maximum(self.density_grid[both] * decay, fresh[both])
+        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+        self.iter_density += 1
+        self.density_bitfield = raymarching.packbits(self.density_grid, min(self.mean_density, self.density_thresh), self.density_bitfield)
+        steps = min(16, self.local_step)
+        if steps > 0:
+            self.mean_count = int(self.step_counter[:steps, 0].sum().item() / steps)
+        self.local_step = 0
+
+    # ------------------------------------------------------------------ entry point (renderer_wtmk.py:541-575)
+
+    def render(self, rays_o, rays_d, message=None, staged=False, max_ray_batch=4096, **kwargs):
+        _run = self.run_cuda if self.cuda_ray else self.run
+        B, N = rays_o.shape[:2]
+        device = rays_o.device
+        if staged:
+            depth = torch.empty((B, N), device=device)
+            image = torch.empty((B, N, 3), device=device)
+            for b in range(B):
+                head = 0
+                while head < N:
+                    tail = min(head + max_ray_batch, N)
+                    results_ = _run(rays_o[b:b + 1, head:tail], rays_d[b:b + 1, head:tail], message, **kwargs)
+                    depth[b:b + 1, head:tail] = results_["depth"]
+                    image[b:b + 1, head:tail] = results_["image"]
+                    head += max_ray_batch
+            results = {"depth": depth, "image": image}
+        else:
+            results = _run(rays_o, rays_d, message, **kwargs)
+        return results

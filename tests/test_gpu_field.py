@@ -164,7 +164,7 @@ def test_field_backward_vs_oracle_autograd(fo, tables):
 
     # autograd path: selected tables get the gradient, unselected get None
     cb_params = [t.clone().requires_grad_(True) for t in cb_d[:64]]
-    s2, c2 = fo.field_apply(pts.cuda(), dirs.cuda(), 1.0, packed, base_d, fo.select_tables(cb_params, bits))
+    s2, c2 = fo.field_apply(pts.cuda(), dirs.cuda(), 1.0, packed, base_d, fo.select_tables(cb_params, bits))  # S computed inside
     ((s2 * gs.cuda()).sum() + (c2 * gc.cuda()).sum()).backward()
     for i, b in enumerate(bits):
         assert cb_params[2 * i + 1 - b].grad is None
