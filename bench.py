@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""Benchmark of the watermark-stage training step (BASELINE.json: training rays/s @4096-ray batches, hotdog, 32-bit
+message).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = the loop body of the reference's train_one_epoch (nerf/utils_wtmk_disen.py:1164-1181) on synthetic scene
+S0: a fresh 32-bit message, the block render (32 blocks x 12 x 12 = 4608 rays) decoded by the
+HiDDeN decoder, the content render (4096 rays), BCE + MSE loss, backward, gradient exchange (N > 1), Adam step on
+the 32 selected codebook tables and the decoder.  Inputs are resident in HBM before the timed region.  Rays are
+sharded by rank (each rank draws its own 4096 content rays; block rays and message are replicated): weak scaling.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md chip table); measured copy ceiling 6.29e12
+BYTES_FWD_PER_POINT = lambda D: 1024 + 64 * D + 48      # 16*8*8 base + D*8*8 codebook + 32 in + 16 out
+BYTES_BWD_PER_POINT = lambda D: 128 * D + 64            # codebook RMW + (dsigma, drgb, ...)
+
+
+class KernelTimer:
+    """HIP-event timing of one native launch site, on the stream the kernel is launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.pairs, self.points, self.enabled = [], [], False
+
+    def wrap(self, fn, n_points_of):
+        def timed(*a, **k):
+            if not self.enabled:
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            self.pairs.append((e0, e1))
+            self.points.append(n_points_of(*a, **k))
+            return out
+        return timed
+
+    def stats(self):
+        ms = [a.elapsed_time(b) for a, b in self.pairs]
+        return (float(np.mean(ms)) * 1e-3 if ms else 0.0), len(ms)
+
+
+def cpu_baseline(model, D):
+    """The oracle (CPU restatement of the reference path, reference-faithful op sequence for the encoders) timed on
+    this box's host cores on a bounded sample of the same workload: 32 blocks of 2x2 rays + 128 content rays
+    (sized for roughly 10-30 s of CPU work).  Thread count: torch intra-op threads, capped at 32 -- the tensor ops of
+    this sample are too small to scale further, and oversubscribing a 256-thread host made it 50x slower."""
+    from nerf_signature_amd import synthetic
+    from oracle import field_ref as fr
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    bo, bd = synthetic.block_rays("hotdog")
+    bo, bd = bo[:, :2, :2].contiguous(), bd[:, :2, :2].contiguous()
+    co, cd = synthetic.content_rays("hotdog", 128, seed=0)
+    gt = torch.rand(1, 128, 3)
+    msg = torch.randint(0, 2, (D,)).float()
+    P = {"bound": 1.0, "faithful": True, "base_tables": [e.weight.detach().cpu() for e in model.encoder.embeddings],
+         "cb_tables": [e.weight.detach().cpu().clone().requires_grad_(True) for e in model.msg_encoder.embeddings],
+         "sigma_params": model.sigma_net.params.detach().cpu(), "color_params": model.color_net.params.detach().cpu()}
+    S = {"bound": 1.0, "cascade": 1, "grid_size": 128, "density_bitfield": model.density_bitfield.cpu().numpy(),
+         "aabb": np.array([-1, -1, -1, 1, 1, 1], np.float32), "min_near": 0.2, "density_scale": 1}
+    dec = copy.deepcopy(model.msg_decoder).cpu()
+    n_rays = bo.shape[0] * 4 + 128
+    t0 = time.perf_counter()
+    out = fr.train_step(bo, bd, co, cd, gt, msg, P, S, dec, dt_gamma=0.0, max_steps=1024)
+    out["loss"].backward()
+    dt = time.perf_counter() - t0
+    pts = out["block"]["n_points"] + out["content"]["n_points"]
+    return {"value": n_rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 train step (fwd+bwd, no optimiser) on {n_rays} rays = 32 blocks of 2x2 + 128 content rays, {pts} points, {dt:.1f} s",
+            "points_per_s": pts / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from nerf_signature_amd import dp, fieldops, synthetic, trainer
+    from nerf_signature_amd.network import NeRFNetwork
+
+    rank, world, local_rank = dp.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    D, scene = 32, "hotdog"
+    cfg = synthetic.SCENES[scene]
+
+    torch.manual_seed(0)
+    model = NeRFNetwork(bound=cfg["bound"], cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1, message_dim=D, n_views=1)
+    synthetic.init_model(model, scene)
+    model.to(dev).train()
+    render_kwargs = dict(dt_gamma=cfg["dt_gamma"], max_steps=1024)
+
+    bo, bd = synthetic.block_rays(scene, dev)
+    co, cd = synthetic.content_rays(scene, args.rays, seed=rank, device=dev)
+    with torch.no_grad():  # "ground truth" = the clean model's render of the same rays (nerf/provider_wtmk.py:415)
+        gt = model.render(co, cd, None, staged=False, bg_color=1, perturb=False, force_all_rays=True, **render_kwargs)["image"]
+    data = {"watermark": {"rays_o_block": bo, "rays_d_block": bd}, "content": {"rays_o": co, "rays_d": cd, "images": gt}}
+    optimizer = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)   # main_nerf_wtmk.py:110
+    loop = trainer.WatermarkLoop(model, optimizer, render_kwargs)
+
+    fwd_timer, bwd_timer = KernelTimer(), KernelTimer()
+    fieldops.field_forward = fwd_timer.wrap(fieldops.field_forward, lambda xyzs, *a, **k: xyzs.shape[0])
+    fieldops.field_backward = bwd_timer.wrap(fieldops.field_backward, lambda xyzs, *a, **k: xyzs.shape[0])
+
+    msg_rng = np.random.RandomState(1234)   # same stream on every rank: the message is replicated
+
+    def one_step():
+        msg = torch.from_numpy(msg_rng.randint(0, 2, D).astype(np.float32))   # fresh message per step (:1165), host side
+        return loop.step(data, msg)
+
+    for _ in range(args.warmup):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    fwd_timer.enabled = bwd_timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    fwd_timer.enabled = bwd_timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    n_block, n_content = int(model.step_counter[(model.local_step - 2) % 16, 0]), int(model.step_counter[(model.local_step - 1) % 16, 0])
+    rays_block, rays_content = bo.shape[0] * bo.shape[1] * bo.shape[2], args.rays
+    rays_per_step = (rays_block + rays_content) * world
+    fwd_s, fwd_n = fwd_timer.stats()
+    bwd_s, bwd_n = bwd_timer.stats()
+    pts_fwd = float(np.mean(fwd_timer.points)) if fwd_timer.points else 0.0     # padded point rows per launch
+    pts_real = (n_block + n_content) / 2.0                                       # real points per launch (2 launches/step)
+    algo_bytes = pts_real * BYTES_FWD_PER_POINT(D)
+    achieved = algo_bytes / fwd_s if fwd_s > 0 else 0.0
+
+    if rank == 0:
+        line = {
+            "metric": "training rays/sec @4096 rays (hotdog, 32-bit msg)",
+            "value": rays_per_step * args.steps / elapsed,
+            "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (hash gather, compositing) + split-bf16 MFMA with f32 accumulate (MLPs)",
+            "data": "synthetic",
+            "config": {
+                "workload": "Blender/hotdog-like synthetic scene S0, --wtmk_tcnn, 4096 content rays + 32x12x12 block rays per rank per step, 32-bit msg, 1xMI355X HIP raymarch+hash+MLP",
+                "rays_per_step_per_rank": rays_block + rays_content, "content_rays": rays_content, "block_rays": rays_block,
+                "points_per_step_per_rank": n_block + n_content, "samples_per_ray_block": n_block / rays_block,
+                "samples_per_ray_content": n_content / rays_content, "content_rays_per_s": rays_content * world * args.steps / elapsed,
+                "message_dim": D, "parallelism": f"dp{world}", "optimizer": "torch.optim.Adam(betas=(0.9,0.99), eps=1e-15)",
+                "grad_exchange_bytes_per_step": loop.exchange.bytes_per_step,
+                "loss": float(out[5].detach()),
+            },
+            "roofline": {
+                "kernel": "k_field_fwd (hash gather + MLPs, forward)", "bound": "hbm",
+                "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+                "traffic": None,
+                "launches": fwd_n, "avg_launch_s": fwd_s, "points_per_launch": pts_real, "padded_rows_per_launch": pts_fwd,
+                "algorithmic_bytes_per_point": BYTES_FWD_PER_POINT(D),
+                "hash_gather_only_frac": (pts_real * (1024 + 64 * D) / fwd_s) / HBM_PEAK if fwd_s > 0 else 0.0,
+                "frac_of_measured_copy_ceiling": achieved / 6.29e12,
+                "backward_kernel": {"kernel": "k_field_bwd", "avg_launch_s": bwd_s, "launches": bwd_n,
+                                    "achieved_GBps": (pts_real * BYTES_BWD_PER_POINT(D) / bwd_s / 1e9) if bwd_s > 0 else 0.0},
+            },
+        }
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                line["roofline"]["traffic"] = json.load(open(pmc)).get("k_field_fwd_hbm_bytes_per_launch")
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(model, D)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
