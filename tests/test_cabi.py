@@ -1,0 +1,66 @@
+"""The C-ABI library loads and exports every symbol include/nerfsig.h declares (no compute calls: no GPU here)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "nerfsig.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"^(?:int|size_t|const char \*)\s*(\w+)\s*\(", text, flags=re.M)))
+
+
+@pytest.fixture(scope="module")
+def native():
+    from nerf_signature_amd import build, _native
+    build.build()
+    return _native
+
+
+def test_header_and_loader_agree(native):
+    assert _declared() == sorted(native.SIGNATURES)
+
+
+def test_every_declared_symbol_is_exported(native):
+    assert native.verify_exports() == _declared()
+    assert native.fn("nsig_abi_version")() == 1
+
+
+def test_host_only_queries(native):
+    assert native.fn("rm_march_train_scratch_bytes")(4096, 1024) == 4096 * 1024 * 4
+    assert native.fn("mlp_packed_bytes")() == 2 * (24 + 20) * 64 * 16
+
+
+def test_argument_validation_needs_no_gpu(native):
+    with pytest.raises(ValueError, match="null pointer"):
+        native.call("rm_morton3D", None, 4, None, None)
+    with pytest.raises(ValueError, match="out of range"):
+        native.call("hg_codebook_presum", (native._vp * 1)(), 0, native._vp(16), None)
+
+
+def test_missing_library_fails_loudly(native, monkeypatch):
+    monkeypatch.setattr(native, "_lib", None)
+    monkeypatch.setattr(native, "_bound", {})
+    monkeypatch.setattr(native, "LIB_PATH", "/nonexistent/libnerfsig.so")
+    with pytest.raises(native.NativeError, match="no fallback"):
+        native.fn("rm_morton3D")
+
+
+def test_product_does_not_import_the_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline leg may use oracle/: the package never imports, links or
+    dlopens it (comments may cite it)."""
+    pkg = os.path.join(ROOT, "nerf_signature_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            path = os.path.join(dirpath, f)
+            if f.endswith(".py"):
+                for line in open(path):
+                    code = line.split("#")[0]
+                    assert not re.search(r"^\s*(from|import)\s+oracle\b", code), path
+                    assert "liboracle" not in code and "raymarch_ref" not in code and "field_ref" not in code, path
+            elif f.endswith((".hip", ".h")):
+                for line in open(path):
+                    assert not (line.lstrip().startswith("#include") and "oracle" in line), path

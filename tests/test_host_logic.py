@@ -1,0 +1,162 @@
+"""CPU tests of the host-side mirror: synthetic inputs, message handling, module surface, meters, DP exchange."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import closed_form as cf
+from oracle import field_ref as fr
+from oracle import raymarch_ref as orm
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_synthetic_morton_and_scene_match_the_oracle():
+    from nerf_signature_amd import synthetic
+    c = np.random.RandomState(0).randint(0, 128, size=(4096, 3))
+    np.testing.assert_array_equal(synthetic.morton3d_np(c), orm.morton3D(c.astype(np.int32)))
+    grid = synthetic.density_grid(1.0)
+    ref_grid, ref_bits, C = cf.ball_scene(1.0)
+    np.testing.assert_array_equal(grid, ref_grid)
+    bits, thresh = synthetic.pack_bits_np(grid, 10.0)
+    np.testing.assert_array_equal(bits, ref_bits)
+    g2 = synthetic.density_grid(2.0)
+    assert g2.shape == (2, 128 ** 3) and g2[1].sum() > g2[0].sum() > 0
+
+
+def test_get_rays_matches_reference_golden():
+    from nerf_signature_amd import synthetic
+    g = np.load(os.path.join(G, "g7_get_rays.npz"))
+    o, d = synthetic.get_rays(torch.from_numpy(g["pose"])[None], g["intrinsics"], 400, 400, torch.from_numpy(g["inds"])[None])
+    np.testing.assert_array_equal(o[0].numpy(), g["rays_o"])
+    np.testing.assert_allclose(d[0].numpy(), g["rays_d"], rtol=0, atol=1e-7)
+
+
+def test_block_and_content_rays_shapes():
+    from nerf_signature_amd import synthetic
+    bo, bd = synthetic.block_rays("hotdog")
+    assert bo.shape == (32, 12, 12, 3) and bd.shape == (32, 12, 12, 3)
+    o, d = synthetic.content_rays("hotdog", 4096, seed=3)
+    assert o.shape == (1, 4096, 3) and torch.allclose(d.norm(dim=-1), torch.ones(1, 4096), atol=1e-5)
+    o2, _ = synthetic.content_rays("hotdog", 4096, seed=4)
+    assert not torch.equal(o, o2)          # ranks draw different cameras / pixels
+    bo48, _ = synthetic.block_rays("fern")
+    assert bo48.shape == (48, 11, 15, 3)   # LLFF/fern: 756x1008 image, 64x64 block grid
+
+
+def test_message_bits_and_table_selection():
+    from nerf_signature_amd import fieldops as fo
+    msg = torch.tensor([1., 0., 0., 1.])
+    assert fo.message_bits(msg) == (1, 0, 0, 1) and fo.message_bits(None) is None and fo.message_bits([0, 1]) == (0, 1)
+    tables = list(range(8))
+    assert fo.select_tables(tables, (1, 0, 0, 1)) == [1, 2, 4, 7]       # table 2i + bit_i
+    with pytest.raises(ValueError):
+        fo.select_tables(tables, (1, 0, 0))
+
+
+def test_network_surface_and_state_dict_contract():
+    from nerf_signature_amd.network import NeRFNetwork
+    g = np.load(os.path.join(G, "g8_g9_glue.npz"))
+    m = NeRFNetwork(bound=1.0, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1, message_dim=32, n_views=1)
+    keys = sorted(m.state_dict().keys())
+    assert keys == list(g["state_dict_keys"])
+    assert [str(tuple(m.state_dict()[k].shape)) for k in keys] == list(g["state_dict_shapes"])
+    groups = m.get_params(1e-2)
+    assert len(groups) == 2 and len(list(groups[0]["params"])) == 64            # codebook, then decoder (network_wtmk_tcnn.py:185-188)
+    assert sum(p.numel() for p in m.msg_decoder.parameters()) == 261893
+    trainable = {n for n, p in m.named_parameters() if p.requires_grad and p.numel() > 0}   # encoder_dir.params is empty
+    assert all(n.startswith(("msg_encoder.", "msg_decoder.")) for n in trainable)
+    assert m.cascade == 1 and m.grid_size == 128 and m.density_bitfield.numel() == 128 ** 3 // 8
+    m2 = NeRFNetwork(bound=2.0, cuda_ray=True, message_dim=48)
+    assert m2.cascade == 2 and len(m2.msg_encoder.embeddings) == 96
+    sd = m.state_dict()
+    missing, unexpected = m.load_state_dict({k: v for k, v in sd.items() if not k.startswith("msg_")}, strict=False)  # a clean checkpoint
+    assert all(k.startswith("msg_") for k in missing) and not unexpected
+    with pytest.raises(ValueError):
+        m._select(torch.zeros(16))
+    with pytest.raises(NotImplementedError):
+        NeRFNetwork(bound=1.0, hidden_dim=128)
+
+
+def test_render_rejects_cpu_tensors_loudly():
+    from nerf_signature_amd.network import NeRFNetwork
+    m = NeRFNetwork(bound=1.0, cuda_ray=True, message_dim=32)
+    with pytest.raises((ValueError, RuntimeError, AssertionError)):
+        m.render(torch.zeros(1, 4, 3), torch.ones(1, 4, 3), None)
+
+
+def test_meters_match_reference_golden():
+    from nerf_signature_amd.trainer import BIT_ACC, PSNRMeter, loss_w_bce
+    g = np.load(os.path.join(G, "g5_g6_decoder_meters.npz"))
+    decoded, msg = torch.from_numpy(g["decoded"]), torch.from_numpy(g["msg"])
+    acc = BIT_ACC()
+    acc.update(decoded.permute(1, 0), msg[None])
+    np.testing.assert_allclose(acc.measure(), float(g["bit_acc"]), atol=1e-7)
+    pm = PSNRMeter()
+    pm.update(torch.from_numpy(g["img"]), torch.from_numpy(g["img"]) * 0.9 + 0.02)
+    np.testing.assert_allclose(pm.measure(), float(g["psnr"]), rtol=1e-5)
+    np.testing.assert_allclose(float(loss_w_bce(decoded, msg.unsqueeze(-1))), float(g["lossw"]), rtol=1e-6)
+
+
+def test_decoder_matches_reference_golden():
+    from nerf_signature_amd.hidden_models import get_hidden_decoder_multi_views, normalize_img
+    g = np.load(os.path.join(G, "g5_g6_decoder_meters.npz"))
+    dec = get_hidden_decoder_multi_views(num_bits=1, redundancy=1, num_blocks=8, input_ch=3, channels=64)
+    dec.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("dec.")})
+    img = torch.from_numpy(g["img"]).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    norm = normalize_img(img)
+    np.testing.assert_allclose(norm.detach().numpy(), g["normalized"], atol=1e-6)
+    out = dec(norm)
+    np.testing.assert_allclose(out.detach().numpy(), g["decoded"], rtol=1e-4, atol=1e-5)
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from nerf_signature_amd import dp
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, w, _ = dp.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    dec = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 1))
+    for i, p in enumerate(dec.parameters()):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    list(dec.parameters())[1].grad = None                     # a parameter without gradient on this rank
+    G = torch.arange(16, dtype=torch.float32).view(8, 2) * (rank + 1)
+    D = 3
+    # route A: what autograd would give without the shared-gradient identity -- D dense gradients, each all-reduced
+    dense = [G.clone() for _ in range(D)]
+    for t in dense:
+        dist.all_reduce(t)
+        t /= w
+    # route B: the product path -- all-reduce G alone, then fan out locally
+    ex = dp.GradExchange(list(dec.parameters()))
+    ex(G)
+    fan = [G.clone() for _ in range(D)]
+    ok = all(torch.equal(a, b) for a, b in zip(dense, fan))
+    grads = [None if p.grad is None else p.grad.clone() for p in dec.parameters()]
+    q.put((rank, ok, G.clone(), grads, ex.bytes_per_step))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_exchange_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29511 + os.getpid() % 200
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    base = torch.arange(16, dtype=torch.float32).view(8, 2)
+    for rank, ok, Gm, grads, nbytes in res:
+        assert ok                                                  # shared-gradient exchange == D dense exchanges
+        assert torch.allclose(Gm, base * 1.5)                      # mean over ranks of G*(rank+1)
+        assert torch.allclose(grads[0], torch.full_like(grads[0], 1.5))
+        assert torch.allclose(grads[1], torch.zeros_like(grads[1]))       # None on every rank -> zeros, stays consistent
+        assert torch.allclose(grads[2], torch.full_like(grads[2], 4.5))
+        assert nbytes == 16 * 4 + sum(g.numel() for g in grads) * 4
+    assert torch.equal(res[0][2], res[1][2])
