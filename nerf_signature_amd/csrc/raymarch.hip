@@ -176,27 +176,129 @@ __device__ inline float start_param(const GridView &g, float near, float noise) 
     return fmaf(step_len(g, near), noise, near);
 }
 
-// Training march, pass 1 (raymarching.cu:354-400): one lane per ray walks the grid once, records the
-// parameter of every occupied step.  Launched with few active lanes per wave so that a batch of a few
-// thousand rays spreads over all CUs -- the walk is a dependent chain of L1/L2 loads, so latency, not
-// lane utilisation, bounds it.
-__global__ void k_march_count(const float *__restrict__ rays_o, const float *__restrict__ rays_d, GridView g,
-                              uint32_t max_steps, uint32_t N, const float *__restrict__ nears,
-                              const float *__restrict__ fars, const float *__restrict__ noises,
-                              int32_t *__restrict__ counts, float *__restrict__ t_rec) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+// Occupancy test specialised for the walk kernels.  kOneCascade: C == 1, so the cascade level is always 0 and the
+// cell extent is loop-invariant.  H is a power of two (checked on the host), so the reference's double-precision
+// product 0.5 * f * H (raymarching.cu:374-376) is an exact scaling and is evaluated in fp32.
+template <bool kOneCascade>
+struct Walker {
+    const GridView &g;
+    const Ray &r;
+    float extent, inv_extent, half_H;
+    int level;
+    __device__ Walker(const GridView &g_, const Ray &r_) : g(g_), r(r_), half_H(0.5f * g_.Hf), level(-1) {
+        if (kOneCascade) { level = 0; extent = fminf(1.0f, g.bound); inv_extent = 1.0f / extent; }
+    }
+    __device__ inline int cell(float v) const { return (int)clampf(fmaf(v, inv_extent, 1.0f) * half_H, 0.0f, g.top); }
+    // returns occupancy at parameter t; when empty, t_exit is where the ray leaves the cell
+    __device__ inline bool probe(float t, float dt, float &t_exit) {
+        const float x = clampf(fmaf(t, r.dx, r.ox), -g.bound, g.bound);
+        const float y = clampf(fmaf(t, r.dy, r.oy), -g.bound, g.bound);
+        const float z = clampf(fmaf(t, r.dz, r.oz), -g.bound, g.bound);
+        if (!kOneCascade) {
+            const int lv = cascade_of(g, x, y, z, dt);
+            if (lv != level) { level = lv; extent = fminf(ldexpf(1.0f, lv), g.bound); inv_extent = 1.0f / extent; }
+        }
+        const int nx = cell(x), ny = cell(y), nz = cell(z);
+        const uint32_t bit = (uint32_t)((float)level * g.H3f + (float)morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+        if (g.bits[bit >> 3] & (1u << (bit & 7u))) return true;
+        const float fx = (fmaf(0.5f, copysignf(1.0f, r.dx), (float)nx + 0.5f) * g.inv_H) * 2.0f - 1.0f;
+        const float fy = (fmaf(0.5f, copysignf(1.0f, r.dy), (float)ny + 0.5f) * g.inv_H) * 2.0f - 1.0f;
+        const float fz = (fmaf(0.5f, copysignf(1.0f, r.dz), (float)nz + 0.5f) * g.inv_H) * 2.0f - 1.0f;
+        const float tx = fmaf(fx, extent, -x) * r.rdx;
+        const float ty = fmaf(fy, extent, -y) * r.rdy;
+        const float tz = fmaf(fz, extent, -z) * r.rdz;
+        t_exit = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        return false;
+    }
+};
+
+// Training march, pass 1 (raymarching.cu:354-400), in index space.
+//
+// Both branches of the reference's loop advance t by the same rule -- an occupied step does t += dt with
+// dt = step(t) (:385-386), an empty cell is left by repeating t += step(t) (:396-398) -- so every parameter the
+// walk can ever visit belongs to ONE sequence t_0 = start, t_{k+1} = t_k + step(t_k) that does not depend on the
+// occupancy grid.  The walk is therefore a pointer chase over indices k of that sequence:
+//     occupied(t_k) : k is a sample, go to k + 1
+//     empty(t_k)    : go to L(k) = the first m > k with t_m >= t_exit(t_k)
+// where occupied(.) and t_exit(.) are functions of t_k alone.  One wave owns one ray: its 64 lanes hold 64
+// consecutive t_k (each accumulated with exactly the sequential rounding), probe the grid for all of them at once
+// (the bitfield loads of a whole chunk are in flight together instead of one dependent load per step), find L(k)
+// by binary search over the chunk's t values in LDS, and the chase itself runs on wave-uniform scalars over the
+// 64-bit occupancy ballot (ctz over runs of occupied steps, v_readlane for the jumps).  A jump that leaves the
+// chunk carries t_exit to the next one.  Counts and sampled parameters are bit-identical to the sequential walk.
+template <bool kOneCascade, bool kConstDt>
+__global__ void __launch_bounds__(256) k_march_index(const float *__restrict__ rays_o, const float *__restrict__ rays_d, GridView g,
+                                                      uint32_t max_steps, uint32_t N, const float *__restrict__ nears,
+                                                      const float *__restrict__ fars, const float *__restrict__ noises,
+                                                      int32_t *__restrict__ counts, float *__restrict__ t_rec) {
+    __shared__ float ts[4][64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint32_t n = blockIdx.x * 4 + wid;  // one wave per ray
     if (n >= N) return;
     const Ray r(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n);
+    Walker<kOneCascade> w(g, r);
     const float far = fars[n];
-    float t = start_param(g, nears[n], noises ? noises[n] : 0.0f);
+    auto step = [&](float t) { return kConstDt ? g.dt_min : step_len(g, t); };  // dt_gamma == 0: clamp(0, dt_min, dt_max) == dt_min
+    float t_base = start_param(g, nears[n], noises ? noises[n] : 0.0f);
     float *rec = t_rec + (size_t)n * max_steps;
+    float *tl = ts[wid];
     uint32_t cnt = 0;
-    float x, y, z, dt, t_exit;
-    while (t < far && cnt < max_steps) {
-        if (probe(g, r, t, x, y, z, dt, t_exit)) { rec[cnt++] = t; t += dt; }
-        else t = leave_cell(g, t, t_exit);
+    float carry_exit = -FLT_MAX;  // the next visited index is the first one with t >= carry_exit
+    while (t_base < far && cnt < max_steps) {
+        // lane j: t_j = t_base advanced j times (its own sequential chain, identical rounding to the one-lane walk)
+        float tj = t_base;
+        for (int i = 0; i < 63; ++i)
+            if (i < lane) tj += step(tj);
+        const float dt = step(tj);
+        tl[lane] = tj;
+        __builtin_amdgcn_wave_barrier();  // the binary search below reads other lanes' entries (same wave: LDS is in order)
+        const bool valid = tj < far;
+        float t_exit = 0.0f;
+        const bool occ = valid && w.probe(tj, dt, t_exit);
+        const unsigned long long occ_mask = __ballot(occ), valid_mask = __ballot(valid);
+        // L(lane): first index m > lane of this chunk with t_m >= t_exit (64 = beyond the chunk); t is increasing
+        int L = 64;
+        if (valid && !occ) {
+            int lo = lane + 1, hi = 64;  // first m in [lo, hi) with t_m >= t_exit, else hi
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (tl[mid] >= t_exit) hi = mid; else lo = mid + 1;
+            }
+            L = lo;
+        }
+        // ---- wave-uniform chase over this chunk
+        const unsigned long long reach = __ballot(tj >= carry_exit);
+        int k = reach ? __builtin_ctzll(reach) : 64;
+        unsigned long long samples = 0ull;
+        bool done = false;
+        while (k < 64) {
+            if (!((valid_mask >> k) & 1ull)) { done = true; break; }  // t_k >= far: the loop condition fails here
+            if ((occ_mask >> k) & 1ull) {
+                const unsigned long long rest = ~(occ_mask >> k);     // zero bits = consecutive occupied steps from k
+                const int run = rest ? __builtin_ctzll(rest) : 64;
+                const int len = run < 64 - k ? run : 64 - k;
+                samples |= (len == 64 ? ~0ull : ((1ull << len) - 1ull)) << k;
+                k += len;
+                carry_exit = -FLT_MAX;                                  // if the run reaches the chunk end, index 0 of the next chunk is visited
+            } else {
+                const int from = __builtin_amdgcn_readfirstlane(k);
+                k = __builtin_amdgcn_readlane(L, from);
+                carry_exit = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_exit), from));
+            }
+        }
+        // ---- sample cap (raymarching.cu:359: num_steps < max_steps) and coalesced store of the sampled parameters
+        uint32_t take = (uint32_t)__popcll(samples);
+        if (cnt + take >= max_steps) {
+            take = max_steps - cnt;
+            done = true;
+        }
+        const uint32_t before = (uint32_t)__popcll(samples & ((1ull << lane) - 1ull));
+        if (((samples >> lane) & 1ull) && before < take) rec[cnt + before] = tj;
+        cnt += take;
+        if (done) break;
+        t_base = __shfl(tj + dt, 63, 64);
     }
-    counts[n] = (int32_t)cnt;
+    if (lane == 0) counts[n] = (int32_t)cnt;
 }
 
 // Training march, pass 2: exclusive prefix sum of the counts in ray-id order (replaces the two
@@ -506,9 +608,13 @@ NSIG_EXPORT int rm_march_train_count(const float *rays_o, const float *rays_d, c
     NSIG_REQUIRE(rays_o && rays_d && grid && nears && fars && counts && t_rec, "rm_march_train_count: null pointer");
     if (int e = check_grid_args("rm_march_train_count", C, H, max_steps, bound)) return e;
     if (N == 0) return NSIG_OK;
-    const uint32_t lanes = lanes_for_walk(N);
-    k_march_count<<<ceil_div(N, lanes), lanes, 0, as_stream(stream)>>>(
-        rays_o, rays_d, make_grid_view(grid, bound, dt_gamma, max_steps, C, H), max_steps, N, nears, fars, noises, counts, t_rec);
+    const GridView gv = make_grid_view(grid, bound, dt_gamma, max_steps, C, H);
+    const uint32_t blocks = ceil_div(N, 4u);
+    hipStream_t st = as_stream(stream);
+    if (C == 1 && dt_gamma == 0.0f) k_march_index<true, true><<<blocks, 256, 0, st>>>(rays_o, rays_d, gv, max_steps, N, nears, fars, noises, counts, t_rec);
+    else if (C == 1) k_march_index<true, false><<<blocks, 256, 0, st>>>(rays_o, rays_d, gv, max_steps, N, nears, fars, noises, counts, t_rec);
+    else if (dt_gamma == 0.0f) k_march_index<false, true><<<blocks, 256, 0, st>>>(rays_o, rays_d, gv, max_steps, N, nears, fars, noises, counts, t_rec);
+    else k_march_index<false, false><<<blocks, 256, 0, st>>>(rays_o, rays_d, gv, max_steps, N, nears, fars, noises, counts, t_rec);
     return check_launch("rm_march_train_count");
 }
 
