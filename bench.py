@@ -116,7 +116,9 @@ def main():
     with torch.no_grad():  # "ground truth" = the clean model's render of the same rays (nerf/provider_wtmk.py:415)
         gt = model.render(co, cd, None, staged=False, bg_color=1, perturb=False, force_all_rays=True, **render_kwargs)["image"]
     data = {"watermark": {"rays_o_block": bo, "rays_d_block": bd}, "content": {"rays_o": co, "rays_d": cd, "images": gt}}
-    optimizer = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)   # main_nerf_wtmk.py:110
+    from nerf_signature_amd.optim import CodebookAdam
+    # main_nerf_wtmk.py:110: Adam(get_params(lr), betas=(0.9, 0.99), eps=1e-15) -- same semantics, the codebook update fused
+    optimizer = CodebookAdam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
     loop = trainer.WatermarkLoop(model, optimizer, render_kwargs)
 
     fwd_timer, bwd_timer = KernelTimer(), KernelTimer()
@@ -173,7 +175,7 @@ def main():
                 "rays_per_step_per_rank": rays_block + rays_content, "content_rays": rays_content, "block_rays": rays_block,
                 "points_per_step_per_rank": n_block + n_content, "samples_per_ray_block": n_block / rays_block,
                 "samples_per_ray_content": n_content / rays_content, "content_rays_per_s": rays_content * world * args.steps / elapsed,
-                "message_dim": D, "parallelism": f"dp{world}", "optimizer": "torch.optim.Adam(betas=(0.9,0.99), eps=1e-15)",
+                "message_dim": D, "parallelism": f"dp{world}", "optimizer": "Adam(betas=(0.9,0.99), eps=1e-15): torch semantics, codebook update fused (opt_codebook_adam)",
                 "grad_exchange_bytes_per_step": loop.exchange.bytes_per_step,
                 "loss": float(out[5].detach()),
             },

@@ -136,6 +136,19 @@ int hg_fanout_grad(const float *G, float *const *grads_host, uint32_t D, int acc
 int hg_level_lookup(const float *x01, uint32_t M, float resolution, int32_t *rows, float *weights,
                     nsig_stream_t stream);
 
+/* ------------------------------------------------------------------ optimiser */
+
+/*
+ * Adam step (torch.optim.Adam semantics, no weight decay / amsgrad; main_nerf_wtmk.py:110) for the D selected
+ * codebook tables, which all carry the same gradient G [T,2]: one pass reads G once and updates param, exp_avg,
+ * exp_avg_sq of every table.  step_size_host[i] = lr / (1 - beta1^step_i), inv_bc2_sqrt_host[i] =
+ * 1 / sqrt(1 - beta2^step_i) (per table: a table's step count advances only when it is selected).
+ * grad_scale multiplies G first (1/world_size, or a loss-scale reciprocal).
+ */
+int opt_codebook_adam(const float *G, float *const *params_host, float *const *exp_avg_host, float *const *exp_avg_sq_host,
+                      uint32_t D, float beta1, float beta2, float eps, const float *step_size_host,
+                      const float *inv_bc2_sqrt_host, float grad_scale, nsig_stream_t stream);
+
 /* ------------------------------------------------------------------ field network */
 
 /* Re-lays the two flat tcnn-style parameter vectors (sigma: 3072, color: 7168 fp32, layout in

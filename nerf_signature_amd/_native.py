@@ -38,6 +38,7 @@ SIGNATURES = {
     "hg_codebook_bwd": [_vp, _u32, _vp, _vp, _vp],
     "hg_fanout_grad": [_vp, _vp, _u32, _int, _vp],
     "hg_level_lookup": [_vp, _u32, _fl, _vp, _vp, _vp],
+    "opt_codebook_adam": [_vp, _vp, _vp, _vp, _u32, _fl, _fl, _fl, _vp, _vp, _fl, _vp],
     "mlp_packed_bytes": [],
     "mlp_pack_weights": [_vp, _vp, _vp, _vp],
     "field_fwd": [_vp, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

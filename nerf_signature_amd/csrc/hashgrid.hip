@@ -114,6 +114,40 @@ __global__ void __launch_bounds__(256) k_level_lookup(const float *__restrict__ 
     weights[3 * (size_t)m] = c.wx; weights[3 * (size_t)m + 1] = c.wy; weights[3 * (size_t)m + 2] = c.wz;
 }
 
+// Fused Adam over the D selected tables (shared gradient): float4 per lane, D x (param, exp_avg, exp_avg_sq) streams.
+struct AdamPtrs {
+    float *p[NSIG_MAX_MESSAGE_DIM];
+    float *m[NSIG_MAX_MESSAGE_DIM];
+    float *v[NSIG_MAX_MESSAGE_DIM];
+    float step_size[NSIG_MAX_MESSAGE_DIM];
+    float inv_bc2_sqrt[NSIG_MAX_MESSAGE_DIM];
+};
+
+__device__ inline void adam_update(float g, float &p, float &m, float &v, float beta1, float beta2, float eps, float step_size, float inv_bc2_sqrt) {
+    m = m + (1.0f - beta1) * (g - m);                 // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * beta2 + ((1.0f - beta2) * g) * g;         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    const float denom = sqrtf(v) * inv_bc2_sqrt + eps;  // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+    p = p - step_size * (m / denom);                  // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+__global__ void __launch_bounds__(256) k_codebook_adam(const float4 *__restrict__ G, AdamPtrs a, uint32_t D, float beta1, float beta2, float eps,
+                                                       float grad_scale) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= NSIG_TABLE_ROWS / 2) return;
+    float4 g = G[e];
+    g.x *= grad_scale; g.y *= grad_scale; g.z *= grad_scale; g.w *= grad_scale;
+    for (uint32_t i = 0; i < D; ++i) {
+        float4 *pp = reinterpret_cast<float4 *>(a.p[i]) + e, *pm = reinterpret_cast<float4 *>(a.m[i]) + e, *pv = reinterpret_cast<float4 *>(a.v[i]) + e;
+        float4 p = *pp, m = *pm, v = *pv;
+        const float ss = a.step_size[i], ib = a.inv_bc2_sqrt[i];
+        adam_update(g.x, p.x, m.x, v.x, beta1, beta2, eps, ss, ib);
+        adam_update(g.y, p.y, m.y, v.y, beta1, beta2, eps, ss, ib);
+        adam_update(g.z, p.z, m.z, v.z, beta1, beta2, eps, ss, ib);
+        adam_update(g.w, p.w, m.w, v.w, beta1, beta2, eps, ss, ib);
+        *pp = p; *pm = m; *pv = v;
+    }
+}
+
 }  // namespace nsig
 
 using namespace nsig;
@@ -194,4 +228,21 @@ NSIG_EXPORT int hg_level_lookup(const float *x01, uint32_t M, float resolution, 
     if (M == 0) return NSIG_OK;
     k_level_lookup<<<ceil_div(M, 256), 256, 0, as_stream(stream)>>>(x01, M, 1.0f / resolution, rows, weights);
     return check_launch("hg_level_lookup");
+}
+
+NSIG_EXPORT int opt_codebook_adam(const float *G, float *const *params_host, float *const *exp_avg_host, float *const *exp_avg_sq_host,
+                                  uint32_t D, float beta1, float beta2, float eps, const float *step_size_host,
+                                  const float *inv_bc2_sqrt_host, float grad_scale, nsig_stream_t stream) {
+    NSIG_REQUIRE(G && params_host && exp_avg_host && exp_avg_sq_host && step_size_host && inv_bc2_sqrt_host, "opt_codebook_adam: null pointer");
+    NSIG_REQUIRE(D >= 1 && D <= NSIG_MAX_MESSAGE_DIM, "opt_codebook_adam: D=%u out of range", D);
+    NSIG_REQUIRE(aligned16(G), "opt_codebook_adam: G must be 16-byte aligned");
+    AdamPtrs a{};
+    for (uint32_t i = 0; i < D; ++i) {
+        NSIG_REQUIRE(params_host[i] && exp_avg_host[i] && exp_avg_sq_host[i], "opt_codebook_adam: table %u has a null pointer", i);
+        NSIG_REQUIRE(aligned16(params_host[i]) && aligned16(exp_avg_host[i]) && aligned16(exp_avg_sq_host[i]), "opt_codebook_adam: table %u is not 16-byte aligned", i);
+        a.p[i] = params_host[i]; a.m[i] = exp_avg_host[i]; a.v[i] = exp_avg_sq_host[i];
+        a.step_size[i] = step_size_host[i]; a.inv_bc2_sqrt[i] = inv_bc2_sqrt_host[i];
+    }
+    k_codebook_adam<<<NSIG_TABLE_ROWS / 2 / 256, 256, 0, as_stream(stream)>>>(reinterpret_cast<const float4 *>(G), a, D, beta1, beta2, eps, grad_scale);
+    return check_launch("opt_codebook_adam");
 }

@@ -1,0 +1,67 @@
+"""CodebookAdam: torch.optim.Adam (the optimiser the reference builds, main_nerf_wtmk.py:110) whose update of the
+selected codebook tables is one native pass (opt_codebook_adam).
+
+Every selected table carries the same gradient G (csrc/hashgrid.hip), so instead of materialising D dense
+gradients and running the generic multi-tensor Adam over them (~10 passes over 128 MiB), one kernel reads G once
+and updates param / exp_avg / exp_avg_sq of the D tables in place.  Semantics are torch.optim.Adam's: per-table
+step counts (a table's step advances only when it is selected, exactly like a parameter whose grad is None is
+skipped), bias correction, eps outside the square root, no weight decay / amsgrad.  State lives in `self.state`
+in torch's own format, so `state_dict()` / `load_state_dict()` interoperate with a plain Adam checkpoint.
+Parameters that have an ordinary `.grad` (the decoder) are handled by the inherited `step()`."""
+import ctypes
+import math
+
+import torch
+
+from . import _native as nv
+
+
+class CodebookAdam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, **kw):
+        if kw.get("weight_decay", 0) or kw.get("amsgrad", False) or kw.get("maximize", False):
+            raise NotImplementedError("CodebookAdam implements plain Adam (the reference's configuration)")
+        super().__init__(params, lr=lr, betas=betas, eps=eps, **kw)
+
+    def _group_of(self, p):
+        for g in self.param_groups:
+            if any(q is p for q in g["params"]):
+                return g
+        raise ValueError("parameter is not managed by this optimiser")
+
+    @torch.no_grad()
+    def step_shared(self, selected, G, grad_scale=1.0):
+        """Adam step of the `selected` tables (all in one param group) with the shared gradient G [T,2]."""
+        if not selected:
+            return
+        group = self._group_of(selected[0])
+        beta1, beta2 = group["betas"]
+        lr, eps = float(group["lr"]), float(group["eps"])
+        ms, vs, step_sizes, inv_bc2 = [], [], [], []
+        for p in selected:
+            st = self.state[p]
+            if len(st) == 0:   # torch.optim.Adam._init_group
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["step"] += 1
+            step = float(st["step"])
+            ms.append(st["exp_avg"])
+            vs.append(st["exp_avg_sq"])
+            step_sizes.append(lr / (1.0 - beta1 ** step))
+            inv_bc2.append(1.0 / math.sqrt(1.0 - beta2 ** step))
+        D = len(selected)
+        f32 = ctypes.c_float * D
+        nv.call("opt_codebook_adam", nv.ptr(G), nv.ptr_array([p.data for p in selected]), nv.ptr_array(ms), nv.ptr_array(vs), D,
+                float(beta1), float(beta2), eps, f32(*step_sizes), f32(*inv_bc2), float(grad_scale), nv.stream())
+        _bump_versions(selected)
+
+
+def _bump_versions(tensors):
+    """The native in-place update is invisible to torch's version counters; caches keyed on them (the pre-summed
+    codebook in NeRFNetwork) must see the change."""
+    setter = getattr(torch._C._autograd, "_unsafe_set_version_counter", None)
+    if setter is not None:
+        setter(list(tensors), [t._version + 1 for t in tensors])
+    else:  # pragma: no cover - older torch: an in-place no-op bumps the counter
+        for t in tensors:
+            t.add_(0)

@@ -60,7 +60,9 @@ class WatermarkLoop:
         out = train_step(self.model, data, message, self.render_kwargs, self.lambda_w, self.lambda_i)
         out[-1].backward()
         self.exchange(self.sink.G if self.sink is not None else None)
-        if self.sink is not None:
+        if self.sink is not None and hasattr(self.optimizer, "step_shared"):
+            self.optimizer.step_shared(self.sink.selected, self.sink.G)   # fused: no per-table gradients are materialised
+        elif self.sink is not None:
             self.sink.fanout()
         self.optimizer.step()
         if self.lr_scheduler is not None:

@@ -151,3 +151,38 @@ def test_loop_step_with_sink_equals_autograd_path():
     assert float((grads[0][0] - grads[1][0]).norm() / grads[0][0].norm()) < 1e-5
     a, b = (torch.cat([t.reshape(-1) for t in g[2]]) for g in grads)
     assert float((a - b).norm() / a.norm()) < 1e-3
+
+
+def test_codebook_adam_matches_torch_adam():
+    """opt_codebook_adam == torch.optim.Adam over several steps, including a table that is skipped for a step."""
+    from nerf_signature_amd.optim import CodebookAdam
+    torch.manual_seed(0)
+    T = 1 << 19
+    init = [torch.randn(T, 2, device="cuda") * 0.05 for _ in range(3)]
+    ref_p = [torch.nn.Parameter(t.clone()) for t in init]
+    our_p = [torch.nn.Parameter(t.clone()) for t in init]
+    extra_ref, extra_our = torch.nn.Parameter(torch.ones(7, device="cuda")), torch.nn.Parameter(torch.ones(7, device="cuda"))
+    kw = dict(betas=(0.9, 0.99), eps=1e-15)
+    ref = torch.optim.Adam([{"params": ref_p, "lr": 1e-2}, {"params": [extra_ref], "lr": 1e-2}], **kw)
+    our = CodebookAdam([{"params": our_p, "lr": 1e-2}, {"params": [extra_our], "lr": 1e-2}], **kw)
+    v0 = our_p[0]._version
+    for it in range(5):
+        G = torch.randn(T, 2, device="cuda") * (10.0 ** -it)
+        G[::3] = 0                                     # untouched rows: zero gradient
+        sel = [0, 1, 2] if it != 2 else [0, 2]         # table 1 is not selected at step 2
+        ref.zero_grad(set_to_none=True)
+        for i in sel:
+            ref_p[i].grad = G.clone()
+        extra_ref.grad = torch.full_like(extra_ref, 0.5)
+        extra_our.grad = torch.full_like(extra_our, 0.5)
+        ref.step()
+        our.step_shared([our_p[i] for i in sel], G)
+        our.step()
+    for a, b in zip(ref_p, our_p):
+        np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-5, atol=1e-7)
+    assert torch.equal(extra_ref, extra_our)
+    assert float(our.state[our_p[1]]["step"]) == 4.0 and float(our.state[our_p[0]]["step"]) == 5.0
+    np.testing.assert_allclose(our.state[our_p[1]]["exp_avg_sq"].cpu().numpy(), ref.state[ref_p[1]]["exp_avg_sq"].cpu().numpy(), rtol=2e-5, atol=1e-12)
+    assert our_p[0]._version > v0                      # caches keyed on tensor versions see the native update
+    sd = our.state_dict()                              # torch-format state: loads into a plain Adam
+    ref.load_state_dict(sd)
