@@ -36,6 +36,7 @@ SIGNATURES = {
     "hg_encode_fwd": [_vp, _u32, _vp, _vp, _vp, _vp],
     "hg_codebook_encode_fwd": [_vp, _u32, _vp, _u32, _vp, _vp],
     "hg_codebook_bwd": [_vp, _u32, _vp, _vp, _vp],
+    "hg_scatter_sliced": [_vp, _u32, _vp, _vp],
     "hg_fanout_grad": [_vp, _vp, _u32, _int, _vp],
     "hg_level_lookup": [_vp, _u32, _fl, _vp, _vp, _vp],
     "opt_codebook_adam": [_vp, _vp, _vp, _vp, _u32, _fl, _fl, _fl, _vp, _vp, _fl, _vp],
@@ -43,7 +44,7 @@ SIGNATURES = {
     "mlp_pack_weights": [_vp, _vp, _vp, _vp],
     "field_fwd": [_vp, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "field_color_fwd": [_vp, _vp, _u32, _vp, _vp, _vp],
-    "field_bwd": [_vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "field_bwd": [_vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 _RESTYPES = {"nsig_last_error": _c.c_char_p, "rm_march_train_scratch_bytes": _sz, "mlp_packed_bytes": _sz}
 

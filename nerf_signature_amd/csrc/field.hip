@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyz
                                                    const float *__restrict__ g_sigma, const float *__restrict__ g_rgb,
                                                    const float *__restrict__ sigmas, const float *__restrict__ rgbs,
                                                    const uint32_t *__restrict__ masks, const char *__restrict__ packed,
-                                                   float *__restrict__ G, float *__restrict__ dfeat_out) {
+                                                   float *__restrict__ G, float *__restrict__ dfeat_out, float *__restrict__ rec_out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     stage_weights(lds, packed + 2 * kFwdBytes, 2 * (int)kBwdBytes);
     const char *lds_hi = lds, *lds_lo = lds + kBwdBytes;
@@ -366,10 +366,15 @@ __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyz
         const float g0 = __shfl(dfe[0][0], p, 64), g1 = __shfl(dfe[0][1], p, 64);
         if (!live) continue;
         if (dfeat_out != nullptr && h == 0) { dfeat_out[2 * (size_t)s] = g0; dfeat_out[2 * (size_t)s + 1] = g1; }
-        if (G == nullptr || (g0 == 0.0f && g1 == 0.0f)) continue;
         const float two_b = 2.0f * bound;
+        const float x01 = (xyzs[3 * (size_t)s] + bound) / two_b, y01 = (xyzs[3 * (size_t)s + 1] + bound) / two_b, z01 = (xyzs[3 * (size_t)s + 2] + bound) / two_b;
+        if (rec_out != nullptr && h == 0) {  // structure of arrays: five coalesced dword stores per 32 points
+            rec_out[s] = x01; rec_out[(size_t)M + s] = y01; rec_out[2 * (size_t)M + s] = z01;
+            rec_out[3 * (size_t)M + s] = g0; rec_out[4 * (size_t)M + s] = g1;
+        }
+        if (G == nullptr || (g0 == 0.0f && g1 == 0.0f)) continue;
         Corner8 c;
-        corner_rows((xyzs[3 * (size_t)s] + bound) / two_b, (xyzs[3 * (size_t)s + 1] + bound) / two_b, (xyzs[3 * (size_t)s + 2] + bound) / two_b, cb_cell, c);
+        corner_rows(x01, y01, z01, cb_cell, c);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             if ((k >> 2) != h) continue;
@@ -431,12 +436,13 @@ NSIG_EXPORT int field_color_fwd(const float *dirs, const float *geo_feat, uint32
 }
 
 NSIG_EXPORT int field_bwd(const float *xyzs, uint32_t M, float bound, const float *grad_sigmas, const float *grad_rgbs, const float *sigmas,
-                          const float *rgbs, const uint32_t *masks, const void *packed, float *G, float *dfeat_out, nsig_stream_t stream) {
+                          const float *rgbs, const uint32_t *masks, const void *packed, float *G, float *dfeat_out, float *rec_out,
+                          nsig_stream_t stream) {
     NSIG_REQUIRE(xyzs && grad_sigmas && grad_rgbs && sigmas && rgbs && masks && packed, "field_bwd: null pointer");
-    NSIG_REQUIRE(G || dfeat_out, "field_bwd: at least one of G / dfeat_out must be given");
+    NSIG_REQUIRE(G || dfeat_out || rec_out, "field_bwd: at least one of G / dfeat_out / rec_out must be given");
     NSIG_REQUIRE(bound > 0.0f, "field_bwd: bound must be positive");
     if (M == 0) return NSIG_OK;
     k_field_bwd<<<field_grid(M), 256, 2 * kBwdBytes, as_stream(stream)>>>(xyzs, M, bound, 1.0f / kCodebookResolution, grad_sigmas, grad_rgbs,
-                                                                         sigmas, rgbs, masks, reinterpret_cast<const char *>(packed), G, dfeat_out);
+                                                                         sigmas, rgbs, masks, reinterpret_cast<const char *>(packed), G, dfeat_out, rec_out);
     return check_launch("field_bwd");
 }

@@ -88,6 +88,52 @@ __global__ void __launch_bounds__(256) k_codebook_bwd(const float *__restrict__ 
     atomicAdd(G + 2 * (size_t)c.row[k] + f, corner_weight(c, (int)k, g));
 }
 
+// Owner-computes scatter.  Memory-side float atomics retire ~2e10 requests/s chip-wide however they are spread
+// (MI355X_MICROARCH.md, Global float atomics), and the point-wise scatter needs >= 4 requests per point; LDS
+// atomics and a contiguous flush need 1/10 of that.  Workgroup (slice s, replica r) owns rows [s*16384, (s+1)*16384)
+// of G in LDS, scans points [r*M/8, (r+1)*M/8) and keeps only the corners whose row falls in its slice (the hash
+// makes that 1 corner in 32, so every workgroup recomputes every point's rows: 32x redundant integer work, which is
+// cheap next to the atomics it replaces).  blockIdx = s*8 + r, so the 32 workgroups that scan the same points share
+// one XCD (blockIdx % 8) and its L2 serves the re-reads.  The codebook resolution is 2^11, so cell index and weights
+// are exact scalings (no division) and bit-identical to corner_rows().
+constexpr int kSliceRows = 16384, kSlices = NSIG_TABLE_ROWS / kSliceRows, kReplicas = 8;
+
+__global__ void __launch_bounds__(1024) k_scatter_sliced(const float *__restrict__ rec, uint32_t M, float *__restrict__ G) {
+    extern __shared__ float acc[];  // [kSliceRows][2]
+    const uint32_t slice = blockIdx.x >> 3, replica = blockIdx.x & 7u;
+    for (uint32_t i = threadIdx.x; i < 2u * kSliceRows; i += blockDim.x) acc[i] = 0.0f;
+    __syncthreads();
+    const uint32_t chunk = ceil_div(M, (uint32_t)kReplicas);
+    const uint32_t beg = min(M, replica * chunk), end = min(M, beg + chunk);
+    for (uint32_t m = beg + threadIdx.x; m < end; m += blockDim.x) {
+        const float g0 = rec[3 * (size_t)M + m], g1 = rec[4 * (size_t)M + m];
+        if (g0 == 0.0f && g1 == 0.0f) continue;  // padding rows and terminated rays
+        const float x = rec[m], y = rec[(size_t)M + m], z = rec[2 * (size_t)M + m];
+        const float res = kCodebookResolution, cell = 1.0f / kCodebookResolution;
+        const int ix = (int)floorf(fminf(fmaxf(x, 0.0f), 1.0f) * res), iy = (int)floorf(fminf(fmaxf(y, 0.0f), 1.0f) * res),
+                  iz = (int)floorf(fminf(fmaxf(z, 0.0f), 1.0f) * res);
+        Corner8 c;
+        c.wx = (x - (float)ix * cell) * res; c.wy = (y - (float)iy * cell) * res; c.wz = (z - (float)iz * cell) * res;
+        const uint32_t hx[2] = {(uint32_t)ix, (uint32_t)ix + 1u};
+        const uint32_t hy[2] = {(uint32_t)iy * kPrimeY, ((uint32_t)iy + 1u) * kPrimeY};
+        const uint32_t hz[2] = {(uint32_t)iz * kPrimeZ, ((uint32_t)iz + 1u) * kPrimeZ};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t row = (hx[(k >> 2) & 1] ^ hy[(k >> 1) & 1] ^ hz[k & 1]) & kRowMask;
+            if ((row >> 14) != slice) continue;
+            float *dst = acc + 2u * (row & (kSliceRows - 1));
+            atomicAdd(dst, corner_weight(c, k, g0));
+            atomicAdd(dst + 1, corner_weight(c, k, g1));
+        }
+    }
+    __syncthreads();
+    float *out = G + 2 * (size_t)slice * kSliceRows;
+    for (uint32_t i = threadIdx.x; i < 2u * kSliceRows; i += blockDim.x) {
+        const float v = acc[i];
+        if (v != 0.0f) atomicAdd(out + i, v);
+    }
+}
+
 // grads[i][e] (+)= G[e]: float4 per lane, D output streams.
 __global__ void __launch_bounds__(256) k_fanout(const float4 *__restrict__ G, GradPtrs grads, uint32_t D, int accumulate) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -245,4 +291,20 @@ NSIG_EXPORT int opt_codebook_adam(const float *G, float *const *params_host, flo
     }
     k_codebook_adam<<<NSIG_TABLE_ROWS / 2 / 256, 256, 0, as_stream(stream)>>>(reinterpret_cast<const float4 *>(G), a, D, beta1, beta2, eps, grad_scale);
     return check_launch("opt_codebook_adam");
+}
+
+NSIG_EXPORT int hg_scatter_sliced(const float *rec, uint32_t M, float *G, nsig_stream_t stream) {
+    NSIG_REQUIRE(rec && G, "hg_scatter_sliced: null pointer");
+    if (M == 0) return NSIG_OK;
+    static bool attr_set = false;
+    const size_t lds = (size_t)kSliceRows * 2 * sizeof(float);
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_sliced), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error("hg_scatter_sliced: cannot reserve %zu bytes of LDS", lds);
+            return NSIG_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    k_scatter_sliced<<<kSlices * kReplicas, 1024, lds, as_stream(stream)>>>(rec, M, G);
+    return check_launch("hg_scatter_sliced");
 }

@@ -129,13 +129,30 @@ def field_color(dirs, geo_feat, packed):
     return rgbs
 
 
-def field_backward(xyzs, bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, G=None, want_dfeat=False):
+def field_backward(xyzs, bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, G=None, want_dfeat=False, want_rec=False):
+    """Input-gradient backward of the field network.  G: direct scatter (global atomics); want_dfeat: [M,2] d feature[30:32];
+    want_rec: the [5,M] scatter record for codebook_scatter_sliced.  Returns dfeat, rec or (dfeat, rec)."""
     xyzs = xyzs.contiguous().float()
     M = xyzs.shape[0]
     dfeat = torch.empty(M, 2, dtype=torch.float32, device=xyzs.device) if want_dfeat else None
+    rec = torch.empty(5, M, dtype=torch.float32, device=xyzs.device) if want_rec else None
     nv.call("field_bwd", nv.ptr(xyzs), M, float(bound), nv.ptr(g_sigma.contiguous().float()), nv.ptr(g_rgb.contiguous().float()),
-            nv.ptr(sigmas), nv.ptr(rgbs), nv.ptr(masks), nv.ptr(packed), nv.ptr(G), nv.ptr(dfeat), nv.stream())
-    return dfeat
+            nv.ptr(sigmas), nv.ptr(rgbs), nv.ptr(masks), nv.ptr(packed), nv.ptr(G), nv.ptr(dfeat), nv.ptr(rec), nv.stream())
+    if want_dfeat and want_rec:
+        return dfeat, rec
+    return rec if want_rec else dfeat
+
+
+def codebook_scatter_sliced(rec, G):
+    """G += scatter of the [5,M] record emitted by field_backward(want_rec=True) -> hg_scatter_sliced."""
+    nv.call("hg_scatter_sliced", nv.ptr(rec), rec.shape[1], nv.ptr(G), nv.stream())
+    return G
+
+
+def field_backward_into(xyzs, bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, G):
+    """The production backward: MLP input gradients -> scatter record -> owner-computes scatter into G."""
+    rec = field_backward(xyzs, bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, want_rec=True)
+    return codebook_scatter_sliced(rec, G)
 
 
 class GradSink:
@@ -194,10 +211,10 @@ class _FieldFunction(Function):
             return head + (None,) * ctx.n_sel
         xyzs, sigmas, rgbs, masks, packed = ctx.saved_tensors
         if ctx.sink is not None:
-            field_backward(xyzs, ctx.bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, G=ctx.sink.G)
+            field_backward_into(xyzs, ctx.bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, ctx.sink.G)
             return head + (None,) * ctx.n_sel
         G = torch.zeros(T_ROWS, 2, dtype=torch.float32, device=xyzs.device)
-        field_backward(xyzs, ctx.bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, G=G)
+        field_backward_into(xyzs, ctx.bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, G)
         slab = torch.empty(ctx.n_sel, T_ROWS, 2, dtype=torch.float32, device=xyzs.device)
         grads = [slab[i] for i in range(ctx.n_sel)]
         fanout_grad(G, grads, accumulate=False)

@@ -200,3 +200,29 @@ def test_trunc_exp_clamp_in_backward(fo, tables):
         scale = float(G0.abs().max())
         np.testing.assert_allclose(G1.cpu().numpy(), G0.numpy(), rtol=5e-3, atol=5e-4 * scale)
     assert seen_hi and seen_lo
+
+
+def test_sliced_scatter_equals_pointwise_scatter(fo, tables):
+    """hg_scatter_sliced (LDS-owned slices) accumulates the same G as the point-wise atomic scatter; rows bit-identical."""
+    base, cb, base_d, cb_d = tables
+    P, sp, cp = _params(tables)
+    packed = fo.pack_weights(sp, cp)
+    rng = np.random.RandomState(3)
+    M = 20011
+    pts = torch.from_numpy((rng.rand(M, 3) * 2 - 1).astype(np.float32)).cuda()
+    pts[:5] = torch.tensor([[-1., -1, -1], [1, 1, 1], [0, 0, 0], [1, -1, 0.5], [0.25, 0.5, 0.75]], device="cuda")   # box faces / exact grid points
+    dirs = torch.from_numpy(cf.unit_dirs(M, seed=8)).cuda()
+    S = fo.codebook_presum(fo.select_tables(cb_d[:64], fo.message_bits(torch.from_numpy(cf.messages(32)[2]))))
+    s1, c1, _, masks = fo.field_forward(pts, dirs, 1.0, base_d, S, packed, want_masks=True)
+    gs, gc = torch.randn(M, device="cuda"), torch.randn(M, 3, device="cuda")
+    gs[100:200] = 0
+    gc[100:200] = 0
+    dfeat, rec = fo.field_backward(pts, 1.0, gs, gc, s1, c1, masks, packed, want_dfeat=True, want_rec=True)
+    assert rec.shape == (5, M) and torch.equal(rec[3:].t().contiguous(), dfeat)
+    np.testing.assert_array_equal(rec[:3].t().cpu().numpy(), ((pts + 1.0) / 2.0).cpu().numpy())
+    G1, G2 = torch.zeros(1 << 19, 2, device="cuda"), torch.full((1 << 19, 2), 0.5, device="cuda")
+    fo.codebook_scatter((pts + 1.0) / 2.0, dfeat, G1)
+    fo.codebook_scatter_sliced(rec, G2)            # accumulates into what is there
+    G2 -= 0.5
+    assert torch.equal(G1 != 0, G2.abs() > 1e-12) or float(((G1 != 0) != (G2.abs() > 1e-9)).float().mean()) < 1e-4
+    assert float((G1 - G2).norm() / G1.norm()) < 1e-5

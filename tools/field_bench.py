@@ -56,5 +56,10 @@ print(f"  field_bwd +atomics{timeit(lambda: fo.field_backward(xyzs, 1.0, gs, gc,
 print(f"  field_bwd dfeat   {timeit(lambda: fo.field_backward(xyzs, 1.0, gs, gc, sig, rgb, masks, packed, G=None, want_dfeat=True)):8.1f} us")
 print(f"  codebook scatter  {timeit(lambda: fo.codebook_scatter(x01, dfeat, G)):8.1f} us")
 extra = [a for a in sys.argv[2:]]
-if hasattr(fo, "codebook_scatter_sliced"):
-    print(f"  sliced scatter    {timeit(lambda: fo.codebook_scatter_sliced(x01, dfeat, G)):8.1f} us")
+rec = fo.field_backward(xyzs, 1.0, gs, gc, sig, rgb, masks, packed, want_rec=True)
+print(f"  field_bwd rec     {timeit(lambda: fo.field_backward(xyzs, 1.0, gs, gc, sig, rgb, masks, packed, want_rec=True)):8.1f} us")
+print(f"  sliced scatter    {timeit(lambda: fo.codebook_scatter_sliced(rec, G)):8.1f} us")
+G1, G2 = torch.zeros_like(G), torch.zeros_like(G)
+fo.codebook_scatter(x01, dfeat, G1)
+fo.codebook_scatter_sliced(rec, G2)
+print("  sliced vs point-wise scatter: rel L2 diff", float((G1 - G2).norm() / G1.norm()), "nonzero rows equal:", bool(((G1 != 0) == (G2 != 0)).all()))
