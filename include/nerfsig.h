@@ -171,10 +171,14 @@ int mlp_pack_weights(const float *sigma_params, const float *color_params, void 
  *   sigma MLP 32->64->16, sigma = exp(h0); SH degree 4 of d; color MLP 32->64->64->3, sigmoid.
  * Outputs: sigmas [M]; rgbs [M,3] (NULL: skip the color branch = NeRFNetwork.density);
  *          geo_feat [M,15] (optional); masks [M_pad32, 6] uint32 (optional, needed by field_bwd).
+ * workspace: NULL = one fused kernel (features gathered inside the MLP kernel); otherwise
+ *   field_fwd_workspace_bytes(M) bytes for the level-major feature planes of the two-kernel route
+ *   (XCD-partitioned encoder, then the MLP kernel), the faster one for large batches.  Both give identical results.
  */
+size_t field_fwd_workspace_bytes(uint32_t M);
 int field_fwd(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *const *base_tables_host,
               const float *S, const void *packed, float *sigmas, float *rgbs, float *geo_feat, uint32_t *masks,
-              nsig_stream_t stream);
+              void *workspace, nsig_stream_t stream);
 
 /* NeRFNetwork.color (nerf/network_wtmk_tcnn.py:147-176) without the mask: rgb from dirs + geo_feat. */
 int field_color_fwd(const float *dirs, const float *geo_feat, uint32_t M, const void *packed, float *rgbs,

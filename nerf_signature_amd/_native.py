@@ -42,11 +42,12 @@ SIGNATURES = {
     "opt_codebook_adam": [_vp, _vp, _vp, _vp, _u32, _fl, _fl, _fl, _vp, _vp, _fl, _vp],
     "mlp_packed_bytes": [],
     "mlp_pack_weights": [_vp, _vp, _vp, _vp],
-    "field_fwd": [_vp, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "field_fwd_workspace_bytes": [_u32],
+    "field_fwd": [_vp, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "field_color_fwd": [_vp, _vp, _u32, _vp, _vp, _vp],
     "field_bwd": [_vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
-_RESTYPES = {"nsig_last_error": _c.c_char_p, "rm_march_train_scratch_bytes": _sz, "mlp_packed_bytes": _sz}
+_RESTYPES = {"nsig_last_error": _c.c_char_p, "rm_march_train_scratch_bytes": _sz, "mlp_packed_bytes": _sz, "field_fwd_workspace_bytes": _sz}
 
 _lib = None
 

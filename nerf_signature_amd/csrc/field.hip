@@ -22,6 +22,8 @@
 //     network_wtmk_tcnn.py:90-95), so the forward saves just the ReLU sign bits (6 words per point).
 #include "hashgrid.h"
 
+#include <stdlib.h>
+
 namespace nsig {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -213,8 +215,46 @@ __device__ inline void color_branch(const char *lds_hi, const char *lds_lo, int 
 
 // ----------------------------------------------------------------------------- forward
 
+// XCD-partitioned, level-major encoder.  The expensive part of the encoder is the 5-6 finest levels: consecutive
+// points of a ray fall into different cells there, so every point costs ~4 distinct cache lines per level, served from
+// beyond L2 when all 17 tables (68 MiB) compete for each XCD's 4 MiB L2.  Workgroups are dealt round-robin over the 8
+// XCDs (blockIdx % 8 labels the XCD group; a speed assumption only), so workgroup (tile, slot = blockIdx % 8) encodes
+// for its tile of 256 points only the levels assigned to that slot: each XCD then gathers from ONE fine table (4 MiB,
+// L2-sized) plus a few coarse ones.  Features are written level-major, planes[level][point] (float2), so the stores of
+// a wave are 512 contiguous bytes; streaming loads/stores are non-temporal to leave L2 to the tables.
+struct SlotTable {
+    uint8_t n[8];
+    uint8_t level[8][8];  // 0..15 base levels, 16 = pre-summed codebook
+};
+
+__global__ void __launch_bounds__(256) k_encode_planes(const float *__restrict__ xyzs, uint32_t M, float bound, TablePtrs base, LevelGeom geom,
+                                                       const float *__restrict__ S, float2 *__restrict__ planes, uint32_t stride, SlotTable tab) {
+    const uint32_t slot = blockIdx.x & 7u;
+    const uint32_t n_tiles = ceil_div(stride, 256u);
+    const int n_levels = tab.n[slot];
+    const float two_b = 2.0f * bound;
+    for (uint32_t tile = blockIdx.x >> 3; tile < n_tiles; tile += gridDim.x >> 3) {
+        const uint32_t m = tile * 256 + threadIdx.x;
+        if (m >= stride) continue;
+        const uint32_t ml = min(m, M - 1);  // rows in [M, stride) replicate the last point (never consumed)
+        const float x = (__builtin_nontemporal_load(xyzs + 3 * (size_t)ml) + bound) / two_b;
+        const float y = (__builtin_nontemporal_load(xyzs + 3 * (size_t)ml + 1) + bound) / two_b;
+        const float z = (__builtin_nontemporal_load(xyzs + 3 * (size_t)ml + 2) + bound) / two_b;
+        for (int i = 0; i < n_levels; ++i) {
+            const int l = tab.level[slot][i];
+            const float2 v = encode_level(l == NSIG_BASE_LEVELS ? S : base.p[l], x, y, z, geom.cell[l]);
+            float *dst = reinterpret_cast<float *>(planes + (size_t)l * stride + m);
+            __builtin_nontemporal_store(v.x, dst);
+            __builtin_nontemporal_store(v.y, dst + 1);
+        }
+    }
+}
+
+// kPlanes = false: gather the features in-kernel (fused); true: read them from the level-major planes.
+template <bool kPlanes>
 __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyzs, const float *__restrict__ dirs, uint32_t M, float bound,
                                                    TablePtrs base, LevelGeom geom, const float *__restrict__ S,
+                                                   const float2 *__restrict__ planes, uint32_t stride,
                                                    const char *__restrict__ packed, float *__restrict__ sigmas, float *__restrict__ rgbs,
                                                    float *__restrict__ geo_out, uint32_t *__restrict__ masks) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -227,28 +267,43 @@ __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyz
     for (uint32_t tile = blockIdx.x * 4 + wid; tile < n_tiles; tile += gridDim.x * 4) {
         const uint32_t s = tile * 32 + p;
         const uint32_t sl = min(s, M - 1);
-        const float two_b = 2.0f * bound;
-        const float x = (xyzs[3 * (size_t)sl] + bound) / two_b;       // network_wtmk_tcnn.py:101
-        const float y = (xyzs[3 * (size_t)sl + 1] + bound) / two_b;
-        const float z = (xyzs[3 * (size_t)sl + 2] + bound) / two_b;
-
         // lane half 0 owns levels {0..3, 8..11}, half 1 owns {4..7, 12..15}: its 16 features are exactly
         // its elements of the two K-steps of the first layer's B operand.
         Split8 feat[2];
+        if (kPlanes) {
+            float2 f[8];
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int l0 = 8 * g + i, l1 = l0 + 4;
-                float2 f = encode_level(h ? base.p[l1] : base.p[l0], x, y, z, h ? geom.cell[l1] : geom.cell[l0]);
-                if (g == 1 && i == 3 && S != nullptr && h) {  // codebook added into channels 30:32 (:106)
-                    const float2 c = encode_level(S, x, y, z, geom.cell[NSIG_BASE_LEVELS]);
-                    f.x = f.x + c.x;
-                    f.y = f.y + c.y;
-                }
-                split_put(feat[g], 2 * i, f.x);
-                split_put(feat[g], 2 * i + 1, f.y);
+            for (int q = 0; q < 8; ++q) f[q] = planes[(size_t)(8 * (q >> 2) + (q & 3) + 4 * h) * stride + s];  // 256 contiguous bytes per half-wave
+            if (S != nullptr && h) {  // codebook added into channels 30:32 (network_wtmk_tcnn.py:106)
+                const float2 c = planes[(size_t)NSIG_BASE_LEVELS * stride + s];
+                f[7].x = f[7].x + c.x;
+                f[7].y = f[7].y + c.y;
             }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                split_put(feat[q >> 2], 2 * (q & 3), f[q].x);
+                split_put(feat[q >> 2], 2 * (q & 3) + 1, f[q].y);
+            }
+        } else {
+            const float two_b = 2.0f * bound;
+            const float x = (xyzs[3 * (size_t)sl] + bound) / two_b;       // network_wtmk_tcnn.py:101
+            const float y = (xyzs[3 * (size_t)sl + 1] + bound) / two_b;
+            const float z = (xyzs[3 * (size_t)sl + 2] + bound) / two_b;
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int l0 = 8 * g + i, l1 = l0 + 4;
+                    float2 f = encode_level(h ? base.p[l1] : base.p[l0], x, y, z, h ? geom.cell[l1] : geom.cell[l0]);
+                    if (g == 1 && i == 3 && S != nullptr && h) {  // codebook added into channels 30:32 (:106)
+                        const float2 c = encode_level(S, x, y, z, geom.cell[NSIG_BASE_LEVELS]);
+                        f.x = f.x + c.x;
+                        f.y = f.y + c.y;
+                    }
+                    split_put(feat[g], 2 * i, f.x);
+                    split_put(feat[g], 2 * i + 1, f.y);
+                }
+        }
 
         f32x16 hid[2];
         Split8 b4[4];
@@ -413,9 +468,32 @@ static int fill_base_tables(const float *const *host, TablePtrs &base, const cha
     return NSIG_OK;
 }
 
+// Level -> XCD-slot assignment of k_encode_planes: the six finest levels each get a slot of their own or share it only
+// with coarse (cache-resident) levels.  NERFSIG_SLOTS="16|15|14|..." overrides it (experiments).
+static SlotTable default_slots(bool with_codebook) {
+    static const char *kWith = "16|15|14|13|12,0,1|11,2,3|10,9,4|8,7,6,5";
+    static const char *kWithout = "15|14|13|12|11,0,1|10,2,3|9,8,4|7,6,5";
+    const char *spec = getenv(with_codebook ? "NERFSIG_SLOTS" : "NERFSIG_SLOTS_CLEAN");
+    if (spec == nullptr || *spec == 0) spec = with_codebook ? kWith : kWithout;
+    SlotTable t{};
+    int slot = 0, cur = -1;
+    for (const char *c = spec;; ++c) {
+        if (*c >= '0' && *c <= '9') cur = (cur < 0 ? 0 : cur * 10) + (*c - '0');
+        else {
+            if (cur >= 0 && slot < 8 && t.n[slot] < 8 && cur <= NSIG_BASE_LEVELS) t.level[slot][t.n[slot]++] = (uint8_t)cur;
+            cur = -1;
+            if (*c == '|') ++slot;
+            if (*c == 0) break;
+        }
+    }
+    return t;
+}
+
+NSIG_EXPORT size_t field_fwd_workspace_bytes(uint32_t M) { return (size_t)(NSIG_BASE_LEVELS + 1) * ceil_div(M, 32u) * 32u * sizeof(float2); }
+
 NSIG_EXPORT int field_fwd(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *const *base_tables_host,
                           const float *S, const void *packed, float *sigmas, float *rgbs, float *geo_feat, uint32_t *masks,
-                          nsig_stream_t stream) {
+                          void *workspace, nsig_stream_t stream) {
     NSIG_REQUIRE(xyzs && packed && sigmas, "field_fwd: null pointer");
     NSIG_REQUIRE(rgbs == nullptr || dirs != nullptr, "field_fwd: dirs is required when rgbs is requested");
     NSIG_REQUIRE(bound > 0.0f, "field_fwd: bound must be positive");
@@ -423,8 +501,28 @@ NSIG_EXPORT int field_fwd(const float *xyzs, const float *dirs, uint32_t M, floa
     TablePtrs base{};
     if (int e = fill_base_tables(base_tables_host, base, "field_fwd")) return e;
     if (M == 0) return NSIG_OK;
-    k_field_fwd<<<field_grid(M), 256, 2 * kFwdBytes, as_stream(stream)>>>(xyzs, dirs, M, bound, base, make_level_geom(), S,
-                                                                         reinterpret_cast<const char *>(packed), sigmas, rgbs, geo_feat, masks);
+    const char *pk = reinterpret_cast<const char *>(packed);
+    hipStream_t st = as_stream(stream);
+    if (workspace == nullptr) {  // fused: gather inside the MLP kernel (small batches)
+        k_field_fwd<false><<<field_grid(M), 256, 2 * kFwdBytes, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, nullptr, 0, pk, sigmas, rgbs,
+                                                                    geo_feat, masks);
+        return check_launch("field_fwd");
+    }
+    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, "field_fwd: workspace must be 8-byte aligned");
+    const uint32_t stride = ceil_div(M, 32u) * 32u;
+    float2 *planes = reinterpret_cast<float2 *>(workspace);
+    const SlotTable tab = default_slots(S != nullptr);
+    bool covered[NSIG_BASE_LEVELS + 1] = {};
+    for (int s = 0; s < 8; ++s)
+        for (int i = 0; i < tab.n[s]; ++i) covered[tab.level[s][i]] = true;
+    for (int l = 0; l < NSIG_BASE_LEVELS + (S != nullptr ? 1 : 0); ++l) NSIG_REQUIRE(covered[l], "field_fwd: slot table does not cover level %d", l);
+    NSIG_REQUIRE(S != nullptr || !covered[NSIG_BASE_LEVELS], "field_fwd: slot table names the codebook level but S is NULL");
+    const uint32_t tiles = ceil_div(stride, 256u);
+    const uint32_t per_slot = tiles < 1024u ? tiles : 1024u;
+    k_encode_planes<<<per_slot * 8, 256, 0, st>>>(xyzs, M, bound, base, make_level_geom(), S, planes, stride, tab);
+    if (int e = check_launch("field_fwd (encode)")) return e;
+    k_field_fwd<true><<<field_grid(M), 256, 2 * kFwdBytes, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, planes, stride, pk, sigmas, rgbs,
+                                                               geo_feat, masks);
     return check_launch("field_fwd");
 }
 

@@ -86,9 +86,14 @@ __device__ inline float2 trilerp(const float2 (&e)[8], float wx, float wy, float
 __device__ inline float2 encode_level(const float *__restrict__ table, float x, float y, float z, float cell) {
     Corner8 c;
     corner_rows(x, y, z, cell, c);
+    // Issue order 0,4,1,5,2,6,3,7: corners k and k+4 differ only in x, i.e. in the low bits of the row index, so
+    // they share a 128-byte line in 15 of 16 cells; back to back, the second load hits the line the first one brought in.
     float2 e[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) e[k] = reinterpret_cast<const float2 *>(table)[c.row[k]];
+    for (int q = 0; q < 8; ++q) {
+        const int k = (q >> 1) + 4 * (q & 1);
+        e[k] = reinterpret_cast<const float2 *>(table)[c.row[k]];
+    }
     return trilerp(e, c.wx, c.wy, c.wz);
 }
 

@@ -104,8 +104,12 @@ def pack_weights(sigma_params, color_params):
     return packed
 
 
-def field_forward(xyzs, dirs, bound, base_tables, S, packed, want_rgb=True, want_geo=False, want_masks=False):
-    """sigma [M], rgb [M,3] | None, geo_feat [M,15] | None, masks | None -> field_fwd."""
+PLANES_MIN_POINTS = 16384  # below this the fused kernel wins (one launch, no feature round trip)
+
+
+def field_forward(xyzs, dirs, bound, base_tables, S, packed, want_rgb=True, want_geo=False, want_masks=False, planes=None):
+    """sigma [M], rgb [M,3] | None, geo_feat [M,15] | None, masks | None -> field_fwd.
+    planes: True/False forces the two-kernel (XCD-partitioned encoder + MLP) / fused route; None picks by size."""
     xyzs = xyzs.contiguous().float()
     M, dev = xyzs.shape[0], xyzs.device
     sigmas = torch.empty(M, dtype=torch.float32, device=dev)
@@ -114,9 +118,11 @@ def field_forward(xyzs, dirs, bound, base_tables, S, packed, want_rgb=True, want
     masks = torch.empty((M + 31) // 32 * 32, MASK_WORDS, dtype=torch.int32, device=dev) if want_masks else None
     if want_rgb:
         dirs = dirs.contiguous().float()
+    use_planes = (M >= PLANES_MIN_POINTS) if planes is None else bool(planes)
+    ws = torch.empty(int(nv.fn("field_fwd_workspace_bytes")(M)), dtype=torch.uint8, device=dev) if use_planes else None
     nv.call("field_fwd", nv.ptr(xyzs), nv.ptr(dirs) if want_rgb else None, M, float(bound),
             nv.ptr_array([_check_table(t.detach(), "base table") for t in base_tables]), nv.ptr(S), nv.ptr(packed), nv.ptr(sigmas),
-            nv.ptr(rgbs), nv.ptr(geo), nv.ptr(masks), nv.stream())
+            nv.ptr(rgbs), nv.ptr(geo), nv.ptr(masks), nv.ptr(ws), nv.stream())
     return sigmas, rgbs, geo, masks
 
 

@@ -48,7 +48,11 @@ x01 = ((xyzs + 1) / 2).contiguous()
 dfeat = fo.field_backward(xyzs, 1.0, gs, gc, sig, rgb, masks, packed, G=None, want_dfeat=True)
 print(f"{which}: M={M}")
 print(f"  presum            {timeit(lambda: fo.codebook_presum(sel, out=S)):8.1f} us")
-print(f"  field_fwd (train) {timeit(lambda: fo.field_forward(xyzs, dirs, 1.0, base, S, packed, want_masks=True)):8.1f} us")
+print(f"  field_fwd (train, fused)  {timeit(lambda: fo.field_forward(xyzs, dirs, 1.0, base, S, packed, want_masks=True, planes=False)):8.1f} us")
+print(f"  field_fwd (train, planes) {timeit(lambda: fo.field_forward(xyzs, dirs, 1.0, base, S, packed, want_masks=True, planes=True)):8.1f} us")
+a = fo.field_forward(xyzs, dirs, 1.0, base, S, packed, want_masks=True, planes=False)
+b = fo.field_forward(xyzs, dirs, 1.0, base, S, packed, want_masks=True, planes=True)
+print("  fused == planes:", torch.equal(a[0], b[0]), torch.equal(a[1], b[1]), torch.equal(a[3], b[3]))
 print(f"  field_fwd (infer) {timeit(lambda: fo.field_forward(xyzs, dirs, 1.0, base, S, packed)):8.1f} us")
 print(f"  field_fwd (clean) {timeit(lambda: fo.field_forward(xyzs, dirs, 1.0, base, None, packed)):8.1f} us")
 print(f"  encode only       {timeit(lambda: fo.encode(x01, base, S)):8.1f} us")
