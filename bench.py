@@ -31,28 +31,32 @@ BYTES_FWD_PER_POINT = lambda D: 1024 + 64 * D + 48      # 16*8*8
 BYTES_BWD_PER_POINT = lambda D: 128 * D + 64            # codebook RMW + (dsigma, drgb, ...)
 
 
-class KernelTimer:
-    """HIP-event timing of one native launch site, on the stream the kernel is launched on (torch's current stream)."""
+class NativeTimer:
+    """HIP-event timing of selected libnerfsig entry points, on the stream the kernels are launched on (torch's current
+    stream).  Installed over nerf_signature_amd._native.call; each timed call records (duration, points)."""
 
-    def __init__(self):
-        self.pairs, self.points, self.enabled = [], [], False
+    POINTS_ARG = {"hg_encode_planes": 1, "field_fwd": 2, "field_bwd": 1, "hg_scatter_sliced": 1}
 
-    def wrap(self, fn, n_points_of):
-        def timed(*a, **k):
-            if not self.enabled:
-                return fn(*a, **k)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = fn(*a, **k)
-            e1.record()
-            self.pairs.append((e0, e1))
-            self.points.append(n_points_of(*a, **k))
-            return out
-        return timed
+    def __init__(self, nv):
+        self.nv, self.orig, self.enabled = nv, nv.call, False
+        self.events = {k: [] for k in self.POINTS_ARG}
+        nv.call = self
 
-    def stats(self):
-        ms = [a.elapsed_time(b) for a, b in self.pairs]
-        return (float(np.mean(ms)) * 1e-3 if ms else 0.0), len(ms)
+    def __call__(self, name, *args):
+        if not (self.enabled and name in self.events):
+            return self.orig(name, *args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.orig(name, *args)
+        e1.record()
+        self.events[name].append((e0, e1, int(args[self.POINTS_ARG[name]])))
+
+    def stats(self, name, min_points=0):
+        """(mean seconds per launch, launches, mean points per launch) over launches with more than min_points rows."""
+        ev = [(a.elapsed_time(b) * 1e-3, m) for a, b, m in self.events[name] if m > min_points]
+        if not ev:
+            return 0.0, 0, 0.0
+        return float(np.mean([t for t, _ in ev])), len(ev), float(np.mean([m for _, m in ev]))
 
 
 def cpu_baseline(model, D):
@@ -92,6 +96,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="run the loop body eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
 
     from nerf_signature_amd import dp, fieldops, synthetic, trainer
@@ -118,25 +123,26 @@ def main():
     data = {"watermark": {"rays_o_block": bo, "rays_d_block": bd}, "content": {"rays_o": co, "rays_d": cd, "images": gt}}
     from nerf_signature_amd.optim import CodebookAdam
     # main_nerf_wtmk.py:110: Adam(get_params(lr), betas=(0.9, 0.99), eps=1e-15) -- same semantics, the codebook update fused
-    optimizer = CodebookAdam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
-    loop = trainer.WatermarkLoop(model, optimizer, render_kwargs)
+    optimizer = CodebookAdam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, capturable=not args.no_graph)
+    if args.no_graph:
+        loop = trainer.WatermarkLoop(model, optimizer, render_kwargs)
+    else:
+        loop = trainer.GraphedWatermarkLoop(model, optimizer, render_kwargs, data)
 
-    fwd_timer, bwd_timer = KernelTimer(), KernelTimer()
-    fieldops.field_forward = fwd_timer.wrap(fieldops.field_forward, lambda xyzs, *a, **k: xyzs.shape[0])
-    fieldops.field_backward = bwd_timer.wrap(fieldops.field_backward, lambda xyzs, *a, **k: xyzs.shape[0])
-
+    from nerf_signature_amd import _native as nv
+    timer = NativeTimer(nv)
     msg_rng = np.random.RandomState(1234)   # same stream on every rank: the message is replicated
 
     def one_step():
         msg = torch.from_numpy(msg_rng.randint(0, 2, D).astype(np.float32))   # fresh message per step (:1165), host side
-        return loop.step(data, msg)
+        return loop.step(data, msg) if args.no_graph else loop.step(msg)
 
     for _ in range(args.warmup):
         one_step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    fwd_timer.enabled = bwd_timer.enabled = True
+    timer.enabled = args.no_graph          # a replayed graph runs no Python: kernels are timed in the eager pass below
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = one_step()
@@ -144,21 +150,39 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    fwd_timer.enabled = bwd_timer.enabled = False
+    timer.enabled = False
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    overflow = None if args.no_graph else bool(loop.overflowed())
+    loss_value = float(out[5].detach())
+
+    if not args.no_graph:
+        # the same kernels, launched eagerly so that HIP events can bracket them (live, same process, same inputs)
+        timer.enabled = True
+        for _ in range(5):
+            optimizer.zero_grad(set_to_none=True)
+            loop._forward_backward()
+            loop.exchange(loop.sink.G)
+            loop._optimise()
+        torch.cuda.synchronize()
+        timer.enabled = False
 
     n_block, n_content = int(model.step_counter[(model.local_step - 2) % 16, 0]), int(model.step_counter[(model.local_step - 1) % 16, 0])
     rays_block, rays_content = bo.shape[0] * bo.shape[1] * bo.shape[2], args.rays
     rays_per_step = (rays_block + rays_content) * world
-    fwd_s, fwd_n = fwd_timer.stats()
-    bwd_s, bwd_n = bwd_timer.stats()
-    pts_fwd = float(np.mean(fwd_timer.points)) if fwd_timer.points else 0.0     # padded point rows per launch
-    pts_real = (n_block + n_content) / 2.0                                       # real points per launch (2 launches/step)
-    algo_bytes = pts_real * BYTES_FWD_PER_POINT(D)
-    achieved = algo_bytes / fwd_s if fwd_s > 0 else 0.0
+    # the dominant kernel: the hash-gather encoder, on the block render (the launch with the most points)
+    big = max(n_block, n_content) // 2
+    enc_s, enc_n, enc_rows = timer.stats("hg_encode_planes", big)
+    mlp_s, _, _ = timer.stats("field_fwd", big)
+    bwd_s, _, _ = timer.stats("field_bwd", big)
+    sct_s, _, _ = timer.stats("hg_scatter_sliced", big)
+    pts_real = float(max(n_block, n_content))
+    gather_bytes = 1024 + 64 * D
+    achieved = pts_real * gather_bytes / enc_s if enc_s > 0 else 0.0
+    fwd_total = enc_s + mlp_s
+    achieved_fwd = pts_real * BYTES_FWD_PER_POINT(D) / fwd_total if fwd_total > 0 else 0.0
 
     if rank == 0:
         line = {
@@ -177,18 +201,26 @@ def main():
                 "samples_per_ray_content": n_content / rays_content, "content_rays_per_s": rays_content * world * args.steps / elapsed,
                 "message_dim": D, "parallelism": f"dp{world}", "optimizer": "Adam(betas=(0.9,0.99), eps=1e-15): torch semantics, codebook update fused (opt_codebook_adam)",
                 "grad_exchange_bytes_per_step": loop.exchange.bytes_per_step,
-                "loss": float(out[5].detach()),
+                "execution": "eager" if args.no_graph else "hipGraph replay (one capture of forward+backward+optimiser)",
+                "capacity_overflow": overflow,
+                "loss": loss_value,
             },
             "roofline": {
-                "kernel": "k_field_fwd (hash gather + MLPs, forward)", "bound": "hbm",
-                "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+                "kernel": "k_encode_planes (16-level hash gather + pre-summed codebook gather, forward) on the block render",
+                "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                 "traffic": None,
-                "launches": fwd_n, "avg_launch_s": fwd_s, "points_per_launch": pts_real, "padded_rows_per_launch": pts_fwd,
-                "algorithmic_bytes_per_point": BYTES_FWD_PER_POINT(D),
-                "hash_gather_only_frac": (pts_real * (1024 + 64 * D) / fwd_s) / HBM_PEAK if fwd_s > 0 else 0.0,
+                "launches": enc_n, "avg_launch_s": enc_s, "points_per_launch": pts_real, "rows_per_launch": enc_rows,
+                "algorithmic_bytes_per_point": gather_bytes,
+                "note": "algorithmic bytes are SURVEY.md 8(d)'s (1024 + 64*D per point, the reference's D separate codebook gathers); "
+                        "the kernel issues 1024 + 64 B/point because the D tables are pre-summed (DESIGN.md section 2)",
+                "issued_gather_bytes_per_point": 1024 + 64,
+                "frac_of_issued_bytes": (pts_real * (1024 + 64) / enc_s) / HBM_PEAK if enc_s > 0 else 0.0,
                 "frac_of_measured_copy_ceiling": achieved / 6.29e12,
-                "backward_kernel": {"kernel": "k_field_bwd", "avg_launch_s": bwd_s, "launches": bwd_n,
-                                    "achieved_GBps": (pts_real * BYTES_BWD_PER_POINT(D) / bwd_s / 1e9) if bwd_s > 0 else 0.0},
+                "forward_encoder_plus_mlp": {"avg_s": fwd_total, "achieved_GBps": achieved_fwd / 1e9, "frac": achieved_fwd / HBM_PEAK,
+                                             "algorithmic_bytes_per_point": BYTES_FWD_PER_POINT(D)},
+                "backward_mlp_plus_scatter": {"avg_s": bwd_s + sct_s, "k_field_bwd_s": bwd_s, "k_scatter_sliced_s": sct_s,
+                                              "achieved_GBps": (pts_real * BYTES_BWD_PER_POINT(D) / (bwd_s + sct_s) / 1e9) if bwd_s + sct_s > 0 else 0.0,
+                                              "algorithmic_bytes_per_point": BYTES_BWD_PER_POINT(D)},
             },
         }
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -115,6 +115,12 @@ int rm_compact_alive(const int32_t *rays_alive, uint32_t n_alive, int32_t *rays_
  * interpolations (hash_encoding_wtmk_bit.py:116).  tables_host: host array of D device pointers. */
 int hg_codebook_presum(const float *const *tables_host, uint32_t D, float *S, nsig_stream_t stream);
 
+/* Same sum with the selection made on the device: all 2D tables are passed (table 2i and 2i+1 for bit i) and
+ * message [D] (device floats, 0. or 1.) picks one of each pair.  Every launch argument is then independent of the
+ * message, which is what lets a whole training step be captured once in a hipGraph and replayed with new messages. */
+int hg_codebook_presum_sel(const float *const *all_tables_host, const float *message, uint32_t D, float *S,
+                           nsig_stream_t stream);
+
 /* HashEmbedder.forward (hash_encoding.py:96-111) [+ codebook added into channels 30:32,
  * network_wtmk_tcnn.py:106, when S != NULL].  x01 in [0,1]; feat is [M,32]. */
 int hg_encode_fwd(const float *x01, uint32_t M, const float *const *base_tables_host, const float *S, float *feat,
@@ -156,6 +162,14 @@ int opt_codebook_adam(const float *G, float *const *params_host, float *const *e
                       uint32_t D, float beta1, float beta2, float eps, const float *step_size_host,
                       const float *inv_bc2_sqrt_host, float grad_scale, nsig_stream_t stream);
 
+/* opt_codebook_adam with the selection, the per-table step counts and the learning rate on the device (graph
+ * replay): params/exp_avg/exp_avg_sq/steps are host arrays of 2D device pointers (steps[j]: one fp32 scalar per
+ * table, torch's capturable-Adam state format), message [D] picks table 2i+bit_i, *lr is read on the device.
+ * scratch: 2*D floats.  Selected tables' step counts are incremented, the others are left untouched. */
+int opt_codebook_adam_sel(const float *G, float *const *params_host, float *const *exp_avg_host, float *const *exp_avg_sq_host,
+                          float *const *steps_host, const float *message, uint32_t D, const float *lr, float beta1,
+                          float beta2, float eps, float grad_scale, float *scratch, nsig_stream_t stream);
+
 /* ------------------------------------------------------------------ field network */
 
 /* Re-lays the two flat tcnn-style parameter vectors (sigma: 3072, color: 7168 fp32, layout in
@@ -171,14 +185,20 @@ int mlp_pack_weights(const float *sigma_params, const float *color_params, void 
  *   sigma MLP 32->64->16, sigma = exp(h0); SH degree 4 of d; color MLP 32->64->64->3, sigmoid.
  * Outputs: sigmas [M]; rgbs [M,3] (NULL: skip the color branch = NeRFNetwork.density);
  *          geo_feat [M,15] (optional); masks [M_pad32, 6] uint32 (optional, needed by field_bwd).
- * workspace: NULL = one fused kernel (features gathered inside the MLP kernel); otherwise
- *   field_fwd_workspace_bytes(M) bytes for the level-major feature planes of the two-kernel route
- *   (XCD-partitioned encoder, then the MLP kernel), the faster one for large batches.  Both give identical results.
+ * planes: NULL = one fused kernel (features gathered inside the MLP kernel); otherwise the level-major feature planes
+ *   written by hg_encode_planes for the same (xyzs, M, bound, tables, S): the two-kernel route (XCD-partitioned
+ *   encoder, then the MLP kernel) is the faster one for large batches.  Both give bit-identical results.
  */
-size_t field_fwd_workspace_bytes(uint32_t M);
 int field_fwd(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *const *base_tables_host,
               const float *S, const void *packed, float *sigmas, float *rgbs, float *geo_feat, uint32_t *masks,
-              void *workspace, nsig_stream_t stream);
+              const void *planes, nsig_stream_t stream);
+
+/* The encoder of field_fwd as its own pass: planes[level][point] (float2; 16 base levels + the pre-summed codebook as
+ * plane 16), hg_planes_bytes(M) bytes.  Workgroup (tile, slot = blockIdx % 8) encodes only the levels assigned to
+ * its slot, so each XCD's L2 serves the gathers of one fine table (see csrc/field.hip). */
+size_t hg_planes_bytes(uint32_t M);
+int hg_encode_planes(const float *xyzs, uint32_t M, float bound, const float *const *base_tables_host, const float *S,
+                     void *planes, nsig_stream_t stream);
 
 /* NeRFNetwork.color (nerf/network_wtmk_tcnn.py:147-176) without the mask: rgb from dirs + geo_feat. */
 int field_color_fwd(const float *dirs, const float *geo_feat, uint32_t M, const void *packed, float *rgbs,

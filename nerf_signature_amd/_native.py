@@ -33,6 +33,7 @@ SIGNATURES = {
     "rm_composite": [_u32, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "rm_compact_alive": [_vp, _u32, _vp, _vp, _vp],
     "hg_codebook_presum": [_vp, _u32, _vp, _vp],
+    "hg_codebook_presum_sel": [_vp, _vp, _u32, _vp, _vp],
     "hg_encode_fwd": [_vp, _u32, _vp, _vp, _vp, _vp],
     "hg_codebook_encode_fwd": [_vp, _u32, _vp, _u32, _vp, _vp],
     "hg_codebook_bwd": [_vp, _u32, _vp, _vp, _vp],
@@ -40,14 +41,16 @@ SIGNATURES = {
     "hg_fanout_grad": [_vp, _vp, _u32, _int, _vp],
     "hg_level_lookup": [_vp, _u32, _fl, _vp, _vp, _vp],
     "opt_codebook_adam": [_vp, _vp, _vp, _vp, _u32, _fl, _fl, _fl, _vp, _vp, _fl, _vp],
+    "opt_codebook_adam_sel": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _fl, _fl, _fl, _fl, _vp, _vp],
     "mlp_packed_bytes": [],
     "mlp_pack_weights": [_vp, _vp, _vp, _vp],
-    "field_fwd_workspace_bytes": [_u32],
+    "hg_planes_bytes": [_u32],
+    "hg_encode_planes": [_vp, _u32, _fl, _vp, _vp, _vp, _vp],
     "field_fwd": [_vp, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "field_color_fwd": [_vp, _vp, _u32, _vp, _vp, _vp],
     "field_bwd": [_vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
-_RESTYPES = {"nsig_last_error": _c.c_char_p, "rm_march_train_scratch_bytes": _sz, "mlp_packed_bytes": _sz, "field_fwd_workspace_bytes": _sz}
+_RESTYPES = {"nsig_last_error": _c.c_char_p, "rm_march_train_scratch_bytes": _sz, "mlp_packed_bytes": _sz, "hg_planes_bytes": _sz}
 
 _lib = None
 

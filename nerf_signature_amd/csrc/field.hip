@@ -489,11 +489,32 @@ static SlotTable default_slots(bool with_codebook) {
     return t;
 }
 
-NSIG_EXPORT size_t field_fwd_workspace_bytes(uint32_t M) { return (size_t)(NSIG_BASE_LEVELS + 1) * ceil_div(M, 32u) * 32u * sizeof(float2); }
+NSIG_EXPORT size_t hg_planes_bytes(uint32_t M) { return (size_t)(NSIG_BASE_LEVELS + 1) * ceil_div(M, 32u) * 32u * sizeof(float2); }
+
+NSIG_EXPORT int hg_encode_planes(const float *xyzs, uint32_t M, float bound, const float *const *base_tables_host, const float *S, void *planes,
+                                 nsig_stream_t stream) {
+    NSIG_REQUIRE(xyzs && planes, "hg_encode_planes: null pointer");
+    NSIG_REQUIRE(bound > 0.0f, "hg_encode_planes: bound must be positive");
+    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 7) == 0, "hg_encode_planes: planes must be 8-byte aligned");
+    TablePtrs base{};
+    if (int e = fill_base_tables(base_tables_host, base, "hg_encode_planes")) return e;
+    if (M == 0) return NSIG_OK;
+    const uint32_t stride = ceil_div(M, 32u) * 32u;
+    const SlotTable tab = default_slots(S != nullptr);
+    bool covered[NSIG_BASE_LEVELS + 1] = {};
+    for (int s = 0; s < 8; ++s)
+        for (int i = 0; i < tab.n[s]; ++i) covered[tab.level[s][i]] = true;
+    for (int l = 0; l < NSIG_BASE_LEVELS + (S != nullptr ? 1 : 0); ++l) NSIG_REQUIRE(covered[l], "hg_encode_planes: slot table does not cover level %d", l);
+    NSIG_REQUIRE(S != nullptr || !covered[NSIG_BASE_LEVELS], "hg_encode_planes: slot table names the codebook level but S is NULL");
+    const uint32_t tiles = ceil_div(stride, 256u);
+    const uint32_t per_slot = tiles < 1024u ? tiles : 1024u;
+    k_encode_planes<<<per_slot * 8, 256, 0, as_stream(stream)>>>(xyzs, M, bound, base, make_level_geom(), S, reinterpret_cast<float2 *>(planes), stride, tab);
+    return check_launch("hg_encode_planes");
+}
 
 NSIG_EXPORT int field_fwd(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *const *base_tables_host,
                           const float *S, const void *packed, float *sigmas, float *rgbs, float *geo_feat, uint32_t *masks,
-                          void *workspace, nsig_stream_t stream) {
+                          const void *planes, nsig_stream_t stream) {
     NSIG_REQUIRE(xyzs && packed && sigmas, "field_fwd: null pointer");
     NSIG_REQUIRE(rgbs == nullptr || dirs != nullptr, "field_fwd: dirs is required when rgbs is requested");
     NSIG_REQUIRE(bound > 0.0f, "field_fwd: bound must be positive");
@@ -503,26 +524,15 @@ NSIG_EXPORT int field_fwd(const float *xyzs, const float *dirs, uint32_t M, floa
     if (M == 0) return NSIG_OK;
     const char *pk = reinterpret_cast<const char *>(packed);
     hipStream_t st = as_stream(stream);
-    if (workspace == nullptr) {  // fused: gather inside the MLP kernel (small batches)
+    if (planes == nullptr) {  // fused: gather inside the MLP kernel (small batches)
         k_field_fwd<false><<<field_grid(M), 256, 2 * kFwdBytes, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, nullptr, 0, pk, sigmas, rgbs,
                                                                     geo_feat, masks);
         return check_launch("field_fwd");
     }
-    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, "field_fwd: workspace must be 8-byte aligned");
+    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 7) == 0, "field_fwd: planes must be 8-byte aligned");
     const uint32_t stride = ceil_div(M, 32u) * 32u;
-    float2 *planes = reinterpret_cast<float2 *>(workspace);
-    const SlotTable tab = default_slots(S != nullptr);
-    bool covered[NSIG_BASE_LEVELS + 1] = {};
-    for (int s = 0; s < 8; ++s)
-        for (int i = 0; i < tab.n[s]; ++i) covered[tab.level[s][i]] = true;
-    for (int l = 0; l < NSIG_BASE_LEVELS + (S != nullptr ? 1 : 0); ++l) NSIG_REQUIRE(covered[l], "field_fwd: slot table does not cover level %d", l);
-    NSIG_REQUIRE(S != nullptr || !covered[NSIG_BASE_LEVELS], "field_fwd: slot table names the codebook level but S is NULL");
-    const uint32_t tiles = ceil_div(stride, 256u);
-    const uint32_t per_slot = tiles < 1024u ? tiles : 1024u;
-    k_encode_planes<<<per_slot * 8, 256, 0, st>>>(xyzs, M, bound, base, make_level_geom(), S, planes, stride, tab);
-    if (int e = check_launch("field_fwd (encode)")) return e;
-    k_field_fwd<true><<<field_grid(M), 256, 2 * kFwdBytes, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, planes, stride, pk, sigmas, rgbs,
-                                                               geo_feat, masks);
+    k_field_fwd<true><<<field_grid(M), 256, 2 * kFwdBytes, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, reinterpret_cast<const float2 *>(planes),
+                                                               stride, pk, sigmas, rgbs, geo_feat, masks);
     return check_launch("field_fwd");
 }
 

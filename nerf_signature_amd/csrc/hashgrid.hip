@@ -194,6 +194,76 @@ __global__ void __launch_bounds__(256) k_codebook_adam(const float4 *__restrict_
     }
 }
 
+// ----------------------------------------------------------------------------- device-side table selection
+// (every launch argument independent of the message: the enclosing step can be captured in a hipGraph)
+
+struct PairPtrs {
+    const float *p[2 * NSIG_MAX_MESSAGE_DIM];
+};
+
+__global__ void __launch_bounds__(256) k_codebook_presum_sel(PairPtrs tabs, const float *__restrict__ message, uint32_t D, float4 *__restrict__ S) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= NSIG_TABLE_ROWS / 2) return;
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+    uint32_t i = 0;
+    for (; i + 4 <= D; i += 4) {
+        const float4 a = reinterpret_cast<const float4 *>(tabs.p[2 * i + (message[i] != 0.0f)])[e];
+        const float4 b = reinterpret_cast<const float4 *>(tabs.p[2 * i + 2 + (message[i + 1] != 0.0f)])[e];
+        const float4 c = reinterpret_cast<const float4 *>(tabs.p[2 * i + 4 + (message[i + 2] != 0.0f)])[e];
+        const float4 d = reinterpret_cast<const float4 *>(tabs.p[2 * i + 6 + (message[i + 3] != 0.0f)])[e];
+        acc.x = (((acc.x + a.x) + b.x) + c.x) + d.x;
+        acc.y = (((acc.y + a.y) + b.y) + c.y) + d.y;
+        acc.z = (((acc.z + a.z) + b.z) + c.z) + d.z;
+        acc.w = (((acc.w + a.w) + b.w) + c.w) + d.w;
+    }
+    for (; i < D; ++i) {
+        const float4 a = reinterpret_cast<const float4 *>(tabs.p[2 * i + (message[i] != 0.0f)])[e];
+        acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+    }
+    S[e] = acc;
+}
+
+struct AdamPairPtrs {
+    float *p[2 * NSIG_MAX_MESSAGE_DIM];
+    float *m[2 * NSIG_MAX_MESSAGE_DIM];
+    float *v[2 * NSIG_MAX_MESSAGE_DIM];
+};
+struct StepPtrs {
+    float *s[2 * NSIG_MAX_MESSAGE_DIM];
+};
+
+// one thread per bit: advance the selected table's step count and derive its bias-correction scalars
+__global__ void k_adam_prepare(StepPtrs steps, const float *__restrict__ message, uint32_t D, const float *__restrict__ lr, float beta1, float beta2,
+                               float *__restrict__ scratch) {
+    const uint32_t i = threadIdx.x;
+    if (i >= D) return;
+    float *sp = steps.s[2 * i + (message[i] != 0.0f)];
+    const float step = *sp + 1.0f;
+    *sp = step;
+    scratch[i] = (float)((double)*lr / (1.0 - pow((double)beta1, (double)step)));
+    scratch[D + i] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+}
+
+__global__ void __launch_bounds__(256) k_codebook_adam_sel(const float4 *__restrict__ G, AdamPairPtrs a, const float *__restrict__ message,
+                                                           const float *__restrict__ scratch, uint32_t D, float beta1, float beta2, float eps,
+                                                           float grad_scale) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= NSIG_TABLE_ROWS / 2) return;
+    float4 g = G[e];
+    g.x *= grad_scale; g.y *= grad_scale; g.z *= grad_scale; g.w *= grad_scale;
+    for (uint32_t i = 0; i < D; ++i) {
+        const uint32_t j = 2 * i + (message[i] != 0.0f);
+        float4 *pp = reinterpret_cast<float4 *>(a.p[j]) + e, *pm = reinterpret_cast<float4 *>(a.m[j]) + e, *pv = reinterpret_cast<float4 *>(a.v[j]) + e;
+        float4 p = *pp, m = *pm, v = *pv;
+        const float ss = scratch[i], ib = scratch[D + i];
+        adam_update(g.x, p.x, m.x, v.x, beta1, beta2, eps, ss, ib);
+        adam_update(g.y, p.y, m.y, v.y, beta1, beta2, eps, ss, ib);
+        adam_update(g.z, p.z, m.z, v.z, beta1, beta2, eps, ss, ib);
+        adam_update(g.w, p.w, m.w, v.w, beta1, beta2, eps, ss, ib);
+        *pp = p; *pm = m; *pv = v;
+    }
+}
+
 }  // namespace nsig
 
 using namespace nsig;
@@ -307,4 +377,37 @@ NSIG_EXPORT int hg_scatter_sliced(const float *rec, uint32_t M, float *G, nsig_s
     }
     k_scatter_sliced<<<kSlices * kReplicas, 1024, lds, as_stream(stream)>>>(rec, M, G);
     return check_launch("hg_scatter_sliced");
+}
+
+NSIG_EXPORT int hg_codebook_presum_sel(const float *const *all_tables_host, const float *message, uint32_t D, float *S, nsig_stream_t stream) {
+    NSIG_REQUIRE(all_tables_host && message && S, "hg_codebook_presum_sel: null pointer");
+    NSIG_REQUIRE(D >= 1 && D <= NSIG_MAX_MESSAGE_DIM, "hg_codebook_presum_sel: D=%u out of range [1,%d]", D, NSIG_MAX_MESSAGE_DIM);
+    PairPtrs tabs{};
+    for (uint32_t j = 0; j < 2 * D; ++j) {
+        NSIG_REQUIRE(all_tables_host[j] && aligned16(all_tables_host[j]), "hg_codebook_presum_sel: table %u is null or not 16-byte aligned", j);
+        tabs.p[j] = all_tables_host[j];
+    }
+    NSIG_REQUIRE(aligned16(S), "hg_codebook_presum_sel: S must be 16-byte aligned");
+    k_codebook_presum_sel<<<NSIG_TABLE_ROWS / 2 / 256, 256, 0, as_stream(stream)>>>(tabs, message, D, reinterpret_cast<float4 *>(S));
+    return check_launch("hg_codebook_presum_sel");
+}
+
+NSIG_EXPORT int opt_codebook_adam_sel(const float *G, float *const *params_host, float *const *exp_avg_host, float *const *exp_avg_sq_host,
+                                      float *const *steps_host, const float *message, uint32_t D, const float *lr, float beta1, float beta2,
+                                      float eps, float grad_scale, float *scratch, nsig_stream_t stream) {
+    NSIG_REQUIRE(G && params_host && exp_avg_host && exp_avg_sq_host && steps_host && message && lr && scratch, "opt_codebook_adam_sel: null pointer");
+    NSIG_REQUIRE(D >= 1 && D <= NSIG_MAX_MESSAGE_DIM, "opt_codebook_adam_sel: D=%u out of range", D);
+    NSIG_REQUIRE(aligned16(G), "opt_codebook_adam_sel: G must be 16-byte aligned");
+    AdamPairPtrs a{};
+    StepPtrs s{};
+    for (uint32_t j = 0; j < 2 * D; ++j) {
+        NSIG_REQUIRE(params_host[j] && exp_avg_host[j] && exp_avg_sq_host[j] && steps_host[j], "opt_codebook_adam_sel: table %u has a null pointer", j);
+        NSIG_REQUIRE(aligned16(params_host[j]) && aligned16(exp_avg_host[j]) && aligned16(exp_avg_sq_host[j]), "opt_codebook_adam_sel: table %u is not 16-byte aligned", j);
+        a.p[j] = params_host[j]; a.m[j] = exp_avg_host[j]; a.v[j] = exp_avg_sq_host[j]; s.s[j] = steps_host[j];
+    }
+    hipStream_t st = as_stream(stream);
+    k_adam_prepare<<<1, NSIG_MAX_MESSAGE_DIM, 0, st>>>(s, message, D, lr, beta1, beta2, scratch);
+    if (int e = check_launch("opt_codebook_adam_sel (prepare)")) return e;
+    k_codebook_adam_sel<<<NSIG_TABLE_ROWS / 2 / 256, 256, 0, st>>>(reinterpret_cast<const float4 *>(G), a, message, scratch, D, beta1, beta2, eps, grad_scale);
+    return check_launch("opt_codebook_adam_sel");
 }

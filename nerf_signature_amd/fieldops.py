@@ -51,6 +51,18 @@ def codebook_presum(selected, out=None):
     return S
 
 
+def codebook_presum_sel(all_tables, message_dev, out=None):
+    """S = sum_i table[2i + message[i]] with the selection made on the device (hg_codebook_presum_sel): nothing about the
+    call depends on the message's value, so it can sit inside a captured graph."""
+    D = len(all_tables) // 2
+    if message_dev.dtype != torch.float32 or message_dev.numel() != D or not message_dev.is_cuda:
+        raise ValueError(f"message must be a CUDA float32 tensor of {D} entries")
+    S = out if out is not None else torch.empty(T_ROWS, 2, dtype=torch.float32, device=message_dev.device)
+    nv.call("hg_codebook_presum_sel", nv.ptr_array([_check_table(t.detach(), "codebook table") for t in all_tables]), nv.ptr(message_dev), D,
+            nv.ptr(S), nv.stream())
+    return S
+
+
 def encode(x01, base_tables, S=None):
     """[M,32] features of the base encoder (+ codebook through S) -> hg_encode_fwd."""
     x01 = x01.contiguous().float()
@@ -119,10 +131,13 @@ def field_forward(xyzs, dirs, bound, base_tables, S, packed, want_rgb=True, want
     if want_rgb:
         dirs = dirs.contiguous().float()
     use_planes = (M >= PLANES_MIN_POINTS) if planes is None else bool(planes)
-    ws = torch.empty(int(nv.fn("field_fwd_workspace_bytes")(M)), dtype=torch.uint8, device=dev) if use_planes else None
-    nv.call("field_fwd", nv.ptr(xyzs), nv.ptr(dirs) if want_rgb else None, M, float(bound),
-            nv.ptr_array([_check_table(t.detach(), "base table") for t in base_tables]), nv.ptr(S), nv.ptr(packed), nv.ptr(sigmas),
-            nv.ptr(rgbs), nv.ptr(geo), nv.ptr(masks), nv.ptr(ws), nv.stream())
+    base_ptrs = nv.ptr_array([_check_table(t.detach(), "base table") for t in base_tables])
+    ws = None
+    if use_planes:
+        ws = torch.empty(int(nv.fn("hg_planes_bytes")(M)), dtype=torch.uint8, device=dev)
+        nv.call("hg_encode_planes", nv.ptr(xyzs), M, float(bound), base_ptrs, nv.ptr(S), nv.ptr(ws), nv.stream())
+    nv.call("field_fwd", nv.ptr(xyzs), nv.ptr(dirs) if want_rgb else None, M, float(bound), base_ptrs, nv.ptr(S), nv.ptr(packed),
+            nv.ptr(sigmas), nv.ptr(rgbs), nv.ptr(geo), nv.ptr(masks), nv.ptr(ws), nv.stream())
     return sigmas, rgbs, geo, masks
 
 

@@ -9,16 +9,26 @@ import torch.nn as nn
 _MEAN, _STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
 
+_CONST = {}
+
+
+def _mean_std(x):
+    """Per-(device, dtype) constants, created once: a host-to-device copy inside a captured stream is not allowed."""
+    key = (x.device, x.dtype)
+    if key not in _CONST:
+        _CONST[key] = (torch.tensor(_MEAN, dtype=x.dtype, device=x.device).view(-1, 1, 1),
+                       torch.tensor(_STD, dtype=x.dtype, device=x.device).view(-1, 1, 1))
+    return _CONST[key]
+
+
 def normalize_img(x):
     """torchvision.transforms.Normalize(mean, std) of hidden_models.py:13 for [B,3,H,W] or [3,H,W] tensors."""
-    mean = torch.tensor(_MEAN, dtype=x.dtype, device=x.device).view(-1, 1, 1)
-    std = torch.tensor(_STD, dtype=x.dtype, device=x.device).view(-1, 1, 1)
+    mean, std = _mean_std(x)
     return (x - mean) / std
 
 
 def unnormalize_img(x):
-    mean = torch.tensor(_MEAN, dtype=x.dtype, device=x.device).view(-1, 1, 1)
-    std = torch.tensor(_STD, dtype=x.dtype, device=x.device).view(-1, 1, 1)
+    mean, std = _mean_std(x)
     return x * std + mean
 
 

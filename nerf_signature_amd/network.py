@@ -50,6 +50,7 @@ class NeRFNetwork(NeRFRenderer):
         self._packed_cache = None   # (key, packed weight image)
         self._presum_cache = None   # (key, S)
         self.grad_sink = None       # optional fieldops.GradSink: backward accumulates the shared gradient there
+        self.device_select = False  # True: CUDA messages select their tables on the device (graph-capturable step)
 
     # ------------------------------------------------------------------ cached device images
 
@@ -80,8 +81,22 @@ class NeRFNetwork(NeRFRenderer):
 
     # ------------------------------------------------------------------ reference surface
 
+    def _select_on_device(self, message):
+        """All 2D tables + the pre-sum chosen by the device-resident message (no host read of its bits)."""
+        tables = self.msg_encoder.tables()
+        key = ("dev", message.data_ptr(), message._version, tuple((t.data_ptr(), t._version) for t in tables))
+        if self._presum_cache is None or self._presum_cache[0] != key:
+            S = self._presum_cache[1] if self._presum_cache is not None else None
+            self._presum_cache = (key, fo.codebook_presum_sel(tables, message, out=S))
+        return tables, self._presum_cache[1]
+
     def forward(self, x, d, message):
         """x: [N,3] in [-bound,bound], d: [N,3] unit, message: [message_dim] of 0./1. or None -> (sigma [N], color [N,3])."""
+        if self.device_select and message is not None and message.is_cuda:
+            if self.grad_sink is None and torch.is_grad_enabled():
+                raise RuntimeError("device_select needs a grad_sink: which tables were selected is not known on the host")
+            tables, S = self._select_on_device(message)
+            return fo.field_apply(x, d, self.bound, self._packed(), self.encoder.tables(), tables, S, self.grad_sink)
         selected, _, S = self._select(message)
         return fo.field_apply(x, d, self.bound, self._packed(), self.encoder.tables(), selected, S, self.grad_sink)
 

@@ -56,6 +56,39 @@ class CodebookAdam(torch.optim.Adam):
         _bump_versions(selected)
 
 
+def _prepare_device_state(opt, tables):
+    """Allocate Adam state for every table up front (static addresses for graph replay); torch's capturable format."""
+    for t in tables:
+        st = opt.state[t]
+        if len(st) == 0:
+            st["step"] = torch.zeros((), dtype=torch.float32, device=t.device)
+            st["exp_avg"] = torch.zeros_like(t, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(t, memory_format=torch.preserve_format)
+        elif not st["step"].is_cuda:
+            st["step"] = st["step"].to(t.device)
+
+
+def _step_shared_sel(opt, tables, message_dev, G, lr_dev, grad_scale=1.0):
+    """Adam step of table 2i + message[i] for every bit, everything message-dependent resolved on the device."""
+    group = opt._group_of(tables[0])
+    beta1, beta2 = group["betas"]
+    cache = getattr(opt, "_sel_cache", None)
+    if cache is None or cache[0] is not tables:
+        _prepare_device_state(opt, tables)
+        D = len(tables) // 2
+        arrays = (nv.ptr_array([t.data for t in tables]), nv.ptr_array([opt.state[t]["exp_avg"] for t in tables]),
+                  nv.ptr_array([opt.state[t]["exp_avg_sq"] for t in tables]), nv.ptr_array([opt.state[t]["step"] for t in tables]))
+        scratch = torch.empty(2 * D, dtype=torch.float32, device=tables[0].device)
+        cache = opt._sel_cache = (tables, arrays, scratch, D)
+    _, (pp, pm, pv, ps), scratch, D = cache
+    nv.call("opt_codebook_adam_sel", nv.ptr(G), pp, pm, pv, ps, nv.ptr(message_dev), D, nv.ptr(lr_dev), float(beta1), float(beta2),
+            float(group["eps"]), float(grad_scale), nv.ptr(scratch), nv.stream())
+    _bump_versions(tables)
+
+
+CodebookAdam.step_shared_sel = torch.no_grad()(_step_shared_sel)
+
+
 def _bump_versions(tensors):
     """The native in-place update is invisible to torch's version counters; caches keyed on them (the pre-summed
     codebook in NeRFNetwork) must see the change."""

@@ -146,6 +146,27 @@ def march_rays_train_device(rays_o, rays_d, bound, density_bitfield, C, H, nears
     return counts, t_rec, rays, write
 
 
+def march_rays_train_capacity(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter, capacity, perturb=False,
+                              dt_gamma=0, max_steps=1024):
+    """march_rays_train with force_all_rays semantics but NO host synchronisation: the point buffers have `capacity` rows
+    (a caller-chosen bound on the padded point count); the real total lands in step_counter[0] on the device, rows past
+    it are zero, and a ray that does not fit is dropped exactly like the reference's bounded mode (raymarching.cu:416) --
+    the caller checks step_counter[0] <= capacity after the fact.  This is what makes a training step graph-capturable."""
+    rays_o = rays_o.contiguous().view(-1, 3).float()
+    rays_d = rays_d.contiguous().view(-1, 3).float()
+    N = rays_o.shape[0]
+    noises = torch.rand(N, dtype=torch.float32, device=rays_o.device) if perturb else None
+    _, _, rays, write = march_rays_train_device(rays_o, rays_d, bound, density_bitfield, C, H, _f32c(nears), _f32c(fars), step_counter, noises,
+                                                dt_gamma, max_steps)
+    xyzs, dirs, deltas = write(int(capacity))
+    return xyzs, dirs, deltas, rays
+
+
+def padded_point_count(m, align=128):
+    """The reference's `m += align - m % align` (raymarching.py:225-226)."""
+    return m + align - m % align
+
+
 class _march_rays_train(Function):
     """raymarching.py:161-233 -> rm_march_train_count / _scan / _write."""
 

@@ -132,9 +132,17 @@ class NeRFRenderer(nn.Module):
         counter = self.step_counter[self.local_step % 16]  # ring of the last 16 (points, rays) totals
         counter.zero_()
         self.local_step += 1
-        xyzs, dirs, deltas, rays = raymarching.march_rays_train(o, d, self.bound, self.density_bitfield, self.cascade, self.grid_size,
-                                                               nears, fars, counter, self.mean_count, perturb, 128, force_all_rays,
-                                                               dt_gamma, max_steps)
+        capacity = getattr(self, "point_capacity", None)
+        capacity = capacity.get(o.shape[0]) if capacity else None
+        if capacity is not None and force_all_rays:
+            # no host round trip: buffers sized by a known bound on the padded point count (see march_rays_train_capacity)
+            xyzs, dirs, deltas, rays = raymarching.march_rays_train_capacity(o, d, self.bound, self.density_bitfield, self.cascade,
+                                                                            self.grid_size, nears, fars, counter, capacity, perturb,
+                                                                            dt_gamma, max_steps)
+        else:
+            xyzs, dirs, deltas, rays = raymarching.march_rays_train(o, d, self.bound, self.density_bitfield, self.cascade, self.grid_size,
+                                                                   nears, fars, counter, self.mean_count, perturb, 128, force_all_rays,
+                                                                   dt_gamma, max_steps)
         sigmas, rgbs = self(xyzs, dirs, message)
         return raymarching.composite_rays_train(self.density_scale * sigmas, rgbs, deltas, rays, T_thresh)
 

@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 
 from . import fieldops as fo
-from .dp import GradExchange
+from .dp import GradExchange, world_size
 
 
 def loss_w_bce(decoded, keys, temp=10.0):
@@ -114,3 +114,161 @@ class PSNRMeter:
 
     def report(self):
         return f"PSNR = {self.measure():.6f}"
+
+
+class GraphedWatermarkLoop:
+    """The same loop body as WatermarkLoop, captured once into a hipGraph and replayed.
+
+    What makes the step capturable: the point buffers of both renders have a fixed capacity, so
+    the march never reads a count back (`march_rays_train_capacity`); the message lives in a device tensor and the
+    pre-sum / Adam kernels select their tables on the device (`hg_codebook_presum_sel`, `opt_codebook_adam_sel`), so no
+    launch argument depends on the message; Adam step counts and the learning rate are device scalars.  Per step the
+    host only copies D message floats, one learning rate and (optionally) new rays into static tensors and replays.
+    With more than one rank the gradient exchange runs between two graphs (forward+backward | optimiser).
+
+    Capacity: `prepare()` runs one ordinary (synchronising) step to learn the padded point counts of the two renders and
+    adds `headroom`; `overflowed()` reports (one host read) whether any replay since the last check produced more
+    points than that -- such a step dropped the rays that did not fit, like the reference's bounded mode."""
+
+    def __init__(self, model, optimizer, render_kwargs, data, lambda_w=1.0, lambda_i=1.0, lr_lambda=None, headroom=0.0):
+        if not hasattr(optimizer, "step_shared_sel"):
+            raise TypeError("GraphedWatermarkLoop needs nerf_signature_amd.optim.CodebookAdam(capturable=True)")
+        self.model, self.optimizer = model, optimizer
+        self.render_kwargs = dict(render_kwargs)
+        self.lambda_w, self.lambda_i = lambda_w, lambda_i
+        self.lr_lambda, self.headroom = lr_lambda, headroom
+        dev = next(model.parameters()).device
+        self.device = dev
+        D = model.message_dim
+        self.sink = fo.GradSink(dev)
+        model.grad_sink = self.sink
+        self.exchange = GradExchange(list(model.msg_decoder.parameters()))
+        self.data = {"watermark": {k: v.clone() for k, v in data["watermark"].items()},
+                     "content": {k: v.clone() for k, v in data["content"].items()}}
+        self.msg_dev = torch.zeros(D, dtype=torch.float32, device=dev)
+        self.msg_host = torch.zeros(D, dtype=torch.float32).pin_memory()
+        self.base_lr = float(optimizer.param_groups[0]["lr"])
+        self.lr_dev = torch.tensor(self.base_lr, dtype=torch.float32, device=dev)
+        for g in optimizer.param_groups:
+            g["lr"] = self.lr_dev          # tensor lr: the captured optimiser reads it on the device
+        self.tables = model.msg_encoder.tables()
+        self.graphs = None
+        self.out = None
+        self.steps_done = 0
+        self.capacity_rows = None
+
+    # -- pieces of one step (executed eagerly during warm-up, then under capture)
+    def _forward_backward(self):
+        self.sink.zero_()
+        out = train_step(self.model, self.data, self.msg_dev, self.render_kwargs, self.lambda_w, self.lambda_i)
+        out[-1].backward()
+        return out
+
+    def _optimise(self):
+        self.optimizer.step_shared_sel(self.tables, self.msg_dev, self.sink.G, self.lr_dev)
+        self.optimizer.step()
+
+    def _set_inputs(self, message, data):
+        self.msg_host.copy_(message.detach().to("cpu", torch.float32))
+        self.msg_dev.copy_(self.msg_host, non_blocking=True)
+        if self.lr_lambda is not None:
+            self.lr_dev.fill_(self.base_lr * self.lr_lambda(self.steps_done))
+        if data is not None:
+            for part in ("watermark", "content"):
+                for k, v in data[part].items():
+                    self.data[part][k].copy_(v, non_blocking=True)
+
+    @torch.no_grad()
+    def _snapshot(self):
+        params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        state = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.optimizer.state[p].items()} for p in params if len(self.optimizer.state[p])}
+        return [(p, p.detach().clone()) for p in params if p.requires_grad], state
+
+    @torch.no_grad()
+    def _restore(self, snapshot):
+        saved_params, saved_state = snapshot
+        for p, v in saved_params:
+            p.copy_(v)
+        for p, st in self.optimizer.state.items():
+            for k, v in st.items():
+                if not torch.is_tensor(v):
+                    continue
+                if p in saved_state and k in saved_state[p]:
+                    v.copy_(saved_state[p][k].to(v.device))
+                else:
+                    v.zero_()      # state created by the warm-up: back to its initial value, same storage (the graph holds its address)
+
+    def prepare(self, message):
+        """One synchronising step to size the point buffers, warm-up on a side stream, then capture."""
+        model = self.model
+        model.device_select = False
+        model.point_capacity = None
+        self.optimizer.zero_grad(set_to_none=True)
+        self.sink.zero_()
+        with torch.no_grad():   # sizes only: the two renders of a step, in order (block, content)
+            model.render(self.data["watermark"]["rays_o_block"], self.data["watermark"]["rays_d_block"], message, staged=False, bg_color=1,
+                         perturb=False, force_all_rays=True, **self.render_kwargs)
+            n_block = int(model.step_counter[(model.local_step - 1) % 16, 0])
+            model.render(self.data["content"]["rays_o"], self.data["content"]["rays_d"], message, staged=False, bg_color=1, perturb=False,
+                         force_all_rays=True, **self.render_kwargs)
+            n_content = int(model.step_counter[(model.local_step - 1) % 16, 0])
+        from .raymarching import padded_point_count
+        rays_block = self.data["watermark"]["rays_o_block"].numel() // 3
+        rays_content = self.data["content"]["rays_o"].numel() // 3
+        if rays_block == rays_content:
+            raise ValueError("block and content renders must have different ray counts to carry separate capacities")
+        cap = lambda m: padded_point_count(int(m * (1.0 + self.headroom)))
+        model.point_capacity = {rays_block: cap(n_block), rays_content: cap(n_content)}
+        model.device_select = True
+        self._set_inputs(message, None)
+
+        # Warm-up on a side stream (library handles, lazily created optimiser state, MIOpen algorithm choice must all
+        # exist before capture).  The warm-up iterations must not train: parameters and optimiser state are restored.
+        snapshot = self._snapshot()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self.optimizer.zero_grad(set_to_none=True)
+                self._forward_backward()
+                self.exchange(self.sink.G)
+                self._optimise()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._restore(snapshot)
+
+        self.optimizer.zero_grad(set_to_none=True)
+        split = world_size() > 1
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            self.out = self._forward_backward()
+            if not split:
+                self._optimise()
+        g2 = None
+        if split:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self._optimise()
+        self.graphs = (g1, g2)
+        self.capacity_rows = [(model.local_step - 2) % 16, (model.local_step - 1) % 16]
+        self.capacities = [cap(n_block), cap(n_content)]
+        return self
+
+    def step(self, message, data=None):
+        """message: CPU float tensor of 0./1.; data: optional new rays/images with the same shapes.  Returns the static
+        output tuple of train_step (valid until the next step; values are ready when the stream reaches them)."""
+        if self.graphs is None:
+            self.prepare(message)
+        self._set_inputs(message, data)
+        g1, g2 = self.graphs
+        g1.replay()
+        if g2 is not None:
+            self.exchange(self.sink.G)
+            g2.replay()
+        self.steps_done += 1
+        return self.out
+
+    def overflowed(self):
+        """True if the last replay produced more points than the buffers hold (one host read of two counters)."""
+        totals = self.model.step_counter[self.capacity_rows, 0].tolist()
+        return any(t > c for t, c in zip(totals, self.capacities))

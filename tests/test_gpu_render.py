@@ -186,3 +186,42 @@ def test_codebook_adam_matches_torch_adam():
     assert our_p[0]._version > v0                      # caches keyed on tensor versions see the native update
     sd = our.state_dict()                              # torch-format state: loads into a plain Adam
     ref.load_state_dict(sd)
+
+
+def test_graphed_loop_matches_eager_loop():
+    """GraphedWatermarkLoop (capacity march, device-side table selection, captured hipGraph) == WatermarkLoop step for step."""
+    from nerf_signature_amd import trainer
+    from nerf_signature_amd.optim import CodebookAdam
+    bo, bd, co, cd, gt = _data(n_content=300)
+    data = {"watermark": {"rays_o_block": bo.cuda(), "rays_d_block": bd.cuda()}, "content": {"rays_o": co.cuda(), "rays_d": cd.cuda(), "images": gt.cuda()}}
+    msgs = [torch.from_numpy(np.random.RandomState(s).randint(0, 2, 32).astype(np.float32)) for s in range(4)]
+    lr_lambda = lambda it: 0.5 ** it
+    runs = []
+    for graphed in (False, True):
+        torch.manual_seed(0)
+        m, _, _ = _model()
+        opt = CodebookAdam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, capturable=graphed)
+        if graphed:
+            loop = trainer.GraphedWatermarkLoop(m, opt, dict(dt_gamma=0, max_steps=1024), data, lr_lambda=lr_lambda)
+            losses = [float(loop.step(msg)[5].detach()) for msg in msgs]
+            assert not loop.overflowed()
+        else:
+            sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda)
+            loop = trainer.WatermarkLoop(m, opt, dict(dt_gamma=0, max_steps=1024), lr_scheduler=sched)
+            losses = [float(loop.step(data, msg)[5].detach()) for msg in msgs]
+        torch.cuda.synchronize()
+        tables = [e.weight.detach().clone() for e in m.msg_encoder.embeddings]
+        dec = torch.cat([p.detach().reshape(-1) for p in m.msg_decoder.parameters()])
+        steps = [float(opt.state[e.weight]["step"]) if len(opt.state[e.weight]) else 0.0 for e in m.msg_encoder.embeddings]
+        runs.append((losses, tables, dec, steps))
+    (l0, t0, d0, s0), (l1, t1, d1, s1) = runs
+    np.testing.assert_allclose(l1, l0, rtol=2e-3, atol=2e-4)
+    assert s0 == s1 and sum(s0) == 4 * 32                       # per-table step counts: one per selection
+    # Adam normalises every touched row to a step of ~lr, so rows whose tiny gradient differs in the last bits (float
+    # atomics) can move differently; compare in aggregate
+    num = sum(float((a - b).pow(2).sum()) for a, b in zip(t0, t1)) ** 0.5
+    den = sum(float((a - cf_t).pow(2).sum()) for a, cf_t in zip(t0, [torch.from_numpy(cf.table(100 + l, scale=0.05)).cuda() for l in range(64)])) ** 0.5
+    assert den > 0 and num / den < 0.05
+    # (the decoder's conv biases sit in front of BatchNorms: their gradient is rounding noise, and Adam with eps=1e-15 turns
+    #  noise into +-lr steps, so the parameter vectors agree only to a few per cent while the loss trajectories agree to 2e-3)
+    assert float((d0 - d1).norm() / d0.norm()) < 0.05
