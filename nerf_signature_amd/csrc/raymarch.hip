@@ -377,67 +377,118 @@ __global__ void k_march_write(const float *__restrict__ rays_o, const float *__r
 }
 
 // ----------------------------------------------------------------------------- compositing (training)
+//
+// One wave per ray.  The reference walks a ray's samples serially (raymarching.cu:540-567); here the 64 lanes take 64
+// consecutive samples (coalesced loads), the transmittance T_j = prod_{i<j} (1 - alpha_i) comes from a wave-level
+// prefix product, the running depth parameter and (backward) the running colour from prefix sums, and the early
+// exit `T < T_thresh` becomes a prefix mask: sample j is accumulated iff the transmittance after sample j-1 is still
+// >= T_thresh (the reference tests after accumulating, :557).  Products and sums associate differently from the
+// serial loop, so results agree to fp32 round-off, not bit for bit (they never could: the reference uses __expf).
 
-// raymarching.cu:501-577.  One lane per ray slot; __expf is the fast exponential the reference uses.
-__global__ void k_composite_fwd(const float *__restrict__ sigmas, const float *__restrict__ rgbs,
-                                const float *__restrict__ deltas, const int32_t *__restrict__ rays, uint32_t M,
-                                uint32_t N, float T_thresh, float *__restrict__ weights_sum,
-                                float *__restrict__ depth, float *__restrict__ image) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const uint32_t id = (uint32_t)rays[3 * (size_t)n], off = (uint32_t)rays[3 * (size_t)n + 1],
-                   cnt = (uint32_t)rays[3 * (size_t)n + 2];
-    float r = 0, g = 0, b = 0, ws = 0, tt = 0, d = 0, T = 1.0f;
-    if (cnt != 0 && off + cnt <= M) {
-        for (uint32_t s = 0; s < cnt; ++s) {
-            const size_t m = (size_t)off + s;
-            const float2 dl = reinterpret_cast<const float2 *>(deltas)[m];
-            const float alpha = 1.0f - __expf(-sigmas[m] * dl.x);
-            const float w = alpha * T;
-            r = fmaf(w, rgbs[3 * m], r);
-            g = fmaf(w, rgbs[3 * m + 1], g);
-            b = fmaf(w, rgbs[3 * m + 2], b);
-            tt += dl.y;
-            d = fmaf(w, tt, d);
-            ws += w;
-            T *= 1.0f - alpha;
-            if (T < T_thresh) break;
-        }
+template <typename Op>
+__device__ inline float wave_scan(float v, int lane, Op op) {  // inclusive scan over the 64 lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float t = __shfl_up(v, d, 64);
+        if (lane >= d) v = op(v, t);
     }
-    weights_sum[id] = ws;
-    depth[id] = d;
-    image[3 * (size_t)id] = r; image[3 * (size_t)id + 1] = g; image[3 * (size_t)id + 2] = b;
+    return v;
 }
 
-// raymarching.cu:602-682 (grad_depth does not propagate, raymarching.py:275).
-__global__ void k_composite_bwd(const float *__restrict__ grad_ws, const float *__restrict__ grad_image,
-                                const float *__restrict__ sigmas, const float *__restrict__ rgbs,
-                                const float *__restrict__ deltas, const int32_t *__restrict__ rays,
-                                const float *__restrict__ weights_sum, const float *__restrict__ image, uint32_t M,
-                                uint32_t N, float T_thresh, float *__restrict__ grad_sigmas,
-                                float *__restrict__ grad_rgbs) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+struct Chunk {
+    float alpha, w, T_after, c0, c1, c2, dt, dreal;
+    bool valid, live;
+};
+
+// loads 64 samples of a ray and derives alpha, weight and transmittance; T_carry = transmittance entering the chunk
+__device__ inline Chunk load_chunk(const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ deltas, size_t m0,
+                                   uint32_t base, uint32_t cnt, int lane, float T_carry, float T_thresh) {
+    Chunk c;
+    c.valid = base + (uint32_t)lane < cnt;
+    const size_t m = m0 + base + lane;
+    float sigma = 0.0f;
+    c.dt = c.dreal = c.c0 = c.c1 = c.c2 = 0.0f;
+    if (c.valid) {
+        sigma = sigmas[m];
+        const float2 dl = reinterpret_cast<const float2 *>(deltas)[m];
+        c.dt = dl.x; c.dreal = dl.y;
+        c.c0 = rgbs[3 * m]; c.c1 = rgbs[3 * m + 1]; c.c2 = rgbs[3 * m + 2];
+    }
+    c.alpha = c.valid ? 1.0f - __expf(-sigma * c.dt) : 0.0f;
+    const float P = wave_scan(1.0f - c.alpha, lane, [](float a, float b) { return a * b; });  // inclusive product
+    float P_excl = __shfl_up(P, 1, 64);
+    if (lane == 0) P_excl = 1.0f;
+    const float T_before = T_carry * P_excl;
+    c.T_after = T_carry * P;
+    c.live = c.valid && T_before >= T_thresh;   // every earlier sample left T >= T_thresh (T_carry itself did)
+    c.w = c.live ? c.alpha * T_before : 0.0f;
+    return c;
+}
+
+__global__ void __launch_bounds__(256) k_composite_fwd(const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                                       const float *__restrict__ deltas, const int32_t *__restrict__ rays, uint32_t M,
+                                                       uint32_t N, float T_thresh, float *__restrict__ weights_sum,
+                                                       float *__restrict__ depth, float *__restrict__ image) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
-    const uint32_t id = (uint32_t)rays[3 * (size_t)n], off = (uint32_t)rays[3 * (size_t)n + 1],
-                   cnt = (uint32_t)rays[3 * (size_t)n + 2];
+    const uint32_t id = (uint32_t)rays[3 * (size_t)n], off = (uint32_t)rays[3 * (size_t)n + 1], cnt = (uint32_t)rays[3 * (size_t)n + 2];
+    float r = 0, g = 0, b = 0, ws = 0, d = 0, T = 1.0f, tt = 0.0f;
+    if (cnt != 0 && off + cnt <= M) {
+        for (uint32_t base = 0; base < cnt; base += 64) {
+            const Chunk c = load_chunk(sigmas, rgbs, deltas, off, base, cnt, lane, T, T_thresh);
+            const float t_incl = tt + wave_scan(c.dreal, lane, [](float a, float b2) { return a + b2; });  // accumulated real deltas (:549)
+            r += c.w * c.c0; g += c.w * c.c1; b += c.w * c.c2; ws += c.w; d += c.w * t_incl;
+            T = __shfl(c.T_after, 63, 64);
+            tt = __shfl(t_incl, 63, 64);
+            if (T < T_thresh) break;  // some sample of this chunk ended the ray
+        }
+        r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); ws = wave_sum(ws); d = wave_sum(d);
+    }
+    if (lane == 0) {
+        weights_sum[id] = ws;
+        depth[id] = d;
+        image[3 * (size_t)id] = r; image[3 * (size_t)id + 1] = g; image[3 * (size_t)id + 2] = b;
+    }
+}
+
+// raymarching.cu:602-682 (grad_depth does not propagate, raymarching.py:275).  grad buffers are pre-zeroed by the host
+// wrapper; only live samples are written.
+__global__ void __launch_bounds__(256) k_composite_bwd(const float *__restrict__ grad_ws, const float *__restrict__ grad_image,
+                                                       const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                                       const float *__restrict__ deltas, const int32_t *__restrict__ rays,
+                                                       const float *__restrict__ weights_sum, const float *__restrict__ image, uint32_t M,
+                                                       uint32_t N, float T_thresh, float *__restrict__ grad_sigmas,
+                                                       float *__restrict__ grad_rgbs) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const uint32_t id = (uint32_t)rays[3 * (size_t)n], off = (uint32_t)rays[3 * (size_t)n + 1], cnt = (uint32_t)rays[3 * (size_t)n + 2];
     if (cnt == 0 || off + cnt > M) return;
-    const float gws = grad_ws[id];
     const float g0 = grad_image[3 * (size_t)id], g1 = grad_image[3 * (size_t)id + 1], g2 = grad_image[3 * (size_t)id + 2];
     const float rf = image[3 * (size_t)id], gf = image[3 * (size_t)id + 1], bf = image[3 * (size_t)id + 2];
-    const float tail = gws * (1.0f - weights_sum[id]);
-    float r = 0, g = 0, b = 0, T = 1.0f;
-    for (uint32_t s = 0; s < cnt; ++s) {
-        const size_t m = (size_t)off + s;
-        const float dt = deltas[2 * m];
-        const float c0 = rgbs[3 * m], c1 = rgbs[3 * m + 1], c2 = rgbs[3 * m + 2];
-        const float alpha = 1.0f - __expf(-sigmas[m] * dt);
-        const float w = alpha * T;
-        r = fmaf(w, c0, r);
-        g = fmaf(w, c1, g);
-        b = fmaf(w, c2, b);
-        T *= 1.0f - alpha;
-        grad_rgbs[3 * m] = g0 * w; grad_rgbs[3 * m + 1] = g1 * w; grad_rgbs[3 * m + 2] = g2 * w;
-        grad_sigmas[m] = dt * (g0 * (T * c0 - (rf - r)) + g1 * (T * c1 - (gf - g)) + g2 * (T * c2 - (bf - b)) + tail);
+    const float tail = grad_ws[id] * (1.0f - weights_sum[id]);
+    float T = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f;  // carries: transmittance and accumulated colour entering the chunk
+    auto add = [](float a, float c) { return a + c; };
+    for (uint32_t base = 0; base < cnt; base += 64) {
+        const Chunk c = load_chunk(sigmas, rgbs, deltas, off, base, cnt, lane, T, T_thresh);
+        const float r_incl = r + wave_scan(c.w * c.c0, lane, add);
+        const float g_incl = g + wave_scan(c.w * c.c1, lane, add);
+        const float b_incl = b + wave_scan(c.w * c.c2, lane, add);
+        if (c.live) {
+            const size_t m = (size_t)off + base + lane;
+            grad_rgbs[3 * m] = g0 * c.w; grad_rgbs[3 * m + 1] = g1 * c.w; grad_rgbs[3 * m + 2] = g2 * c.w;
+            grad_sigmas[m] = c.dt * (g0 * (c.T_after * c.c0 - (rf - r_incl)) + g1 * (c.T_after * c.c1 - (gf - g_incl)) +
+                                     g2 * (c.T_after * c.c2 - (bf - b_incl)) + tail);
+        }
+        T = __shfl(c.T_after, 63, 64);
+        r = __shfl(r_incl, 63, 64); g = __shfl(g_incl, 63, 64); b = __shfl(b_incl, 63, 64);
         if (T < T_thresh) break;
     }
 }
@@ -645,8 +696,7 @@ NSIG_EXPORT int rm_composite_train_fwd(const float *sigmas, const float *rgbs, c
                                        float *depth, float *image, nsig_stream_t stream) {
     NSIG_REQUIRE(sigmas && rgbs && deltas && rays && weights_sum && depth && image, "rm_composite_train_fwd: null pointer");
     if (N == 0) return NSIG_OK;
-    const uint32_t lanes = lanes_for_walk(N);
-    k_composite_fwd<<<ceil_div(N, lanes), lanes, 0, as_stream(stream)>>>(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image);
+    k_composite_fwd<<<ceil_div(N, 4u), 256, 0, as_stream(stream)>>>(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image);
     return check_launch("rm_composite_train_fwd");
 }
 
@@ -663,8 +713,7 @@ NSIG_EXPORT int rm_composite_train_bwd(const float *grad_weights_sum, const floa
         return NSIG_ERR_LAUNCH;
     }
     if (N == 0) return NSIG_OK;
-    const uint32_t lanes = lanes_for_walk(N);
-    k_composite_bwd<<<ceil_div(N, lanes), lanes, 0, as_stream(stream)>>>(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays,
+    k_composite_bwd<<<ceil_div(N, 4u), 256, 0, as_stream(stream)>>>(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays,
                                                                         weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs);
     return check_launch("rm_composite_train_bwd");
 }
