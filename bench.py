@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused-adam", action="store_true", help="torch's multi-tensor instead of its fused Adam kernel for the decoder parameters")
+    ap.add_argument("--no-channels-last", action="store_true", help="keep the decoder in NCHW memory format")
     ap.add_argument("--no-graph", action="store_true", help="run the loop body eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
 
@@ -105,7 +107,7 @@ def main():
     rank, world, local_rank = dp.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())   # (modulo: lets a 1-GPU box exercise the N>1 code path with gloo)
     torch.cuda.set_device(dev)
     D, scene = 32, "hotdog"
     cfg = synthetic.SCENES[scene]
@@ -114,6 +116,8 @@ def main():
     model = NeRFNetwork(bound=cfg["bound"], cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1, message_dim=D, n_views=1)
     synthetic.init_model(model, scene)
     model.to(dev).train()
+    if not args.no_channels_last:
+        model.msg_decoder.to(memory_format=torch.channels_last)   # MIOpen's kernels are NHWC: saves the layout changes around every conv
     render_kwargs = dict(dt_gamma=cfg["dt_gamma"], max_steps=1024)
 
     bo, bd = synthetic.block_rays(scene, dev)
@@ -123,7 +127,7 @@ def main():
     data = {"watermark": {"rays_o_block": bo, "rays_d_block": bd}, "content": {"rays_o": co, "rays_d": cd, "images": gt}}
     from nerf_signature_amd.optim import CodebookAdam
     # main_nerf_wtmk.py:110: Adam(get_params(lr), betas=(0.9, 0.99), eps=1e-15) -- same semantics, the codebook update fused
-    optimizer = CodebookAdam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, capturable=not args.no_graph)
+    optimizer = CodebookAdam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, **({} if args.no_graph else ({"capturable": True} if args.no_fused_adam else {"fused": True, "capturable": True})))
     if args.no_graph:
         loop = trainer.WatermarkLoop(model, optimizer, render_kwargs)
     else:
