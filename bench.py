@@ -230,7 +230,8 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                line["roofline"]["traffic"] = json.load(open(pmc)).get("k_field_fwd_hbm_bytes_per_launch")
+                # HBM bytes per launch of the same kernel on the same inputs, from a separate rocprofv3 --pmc run (profiles/)
+                line["roofline"]["traffic"] = json.load(open(pmc)).get("k_encode_planes_hbm_bytes_per_launch")
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:
