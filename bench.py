@@ -61,16 +61,16 @@ class NativeTimer:
 
 def cpu_baseline(model, D):
     """The oracle (CPU restatement of the reference path, reference-faithful op sequence for the encoders) timed on
-    this box's host cores on a bounded sample of the same workload: 32 blocks of 2x2 rays + 128 content rays
+    this box's host cores on a bounded sample of the same workload: 32 blocks of 8x8 rays + 2048 content rays
     (sized for roughly 10-30 s of CPU work).  Thread count: torch intra-op threads, capped at 32 -- the tensor ops of
     this sample are too small to scale further, and oversubscribing a 256-thread host made it 50x slower."""
     from nerf_signature_amd import synthetic
     from oracle import field_ref as fr
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     bo, bd = synthetic.block_rays("hotdog")
-    bo, bd = bo[:, :2, :2].contiguous(), bd[:, :2, :2].contiguous()
-    co, cd = synthetic.content_rays("hotdog", 128, seed=0)
-    gt = torch.rand(1, 128, 3)
+    bo, bd = bo[:, :8, :8].contiguous(), bd[:, :8, :8].contiguous()
+    co, cd = synthetic.content_rays("hotdog", 2048, seed=0)
+    gt = torch.rand(1, 2048, 3)
     msg = torch.randint(0, 2, (D,)).float()
     P = {"bound": 1.0, "faithful": True, "base_tables": [e.weight.detach().cpu() for e in model.encoder.embeddings],
          "cb_tables": [e.weight.detach().cpu().clone().requires_grad_(True) for e in model.msg_encoder.embeddings],
@@ -78,14 +78,14 @@ def cpu_baseline(model, D):
     S = {"bound": 1.0, "cascade": 1, "grid_size": 128, "density_bitfield": model.density_bitfield.cpu().numpy(),
          "aabb": np.array([-1, -1, -1, 1, 1, 1], np.float32), "min_near": 0.2, "density_scale": 1}
     dec = copy.deepcopy(model.msg_decoder).cpu()
-    n_rays = bo.shape[0] * 4 + 128
+    n_rays = bo.shape[0] * 64 + 2048
     t0 = time.perf_counter()
     out = fr.train_step(bo, bd, co, cd, gt, msg, P, S, dec, dt_gamma=0.0, max_steps=1024)
     out["loss"].backward()
     dt = time.perf_counter() - t0
     pts = out["block"]["n_points"] + out["content"]["n_points"]
     return {"value": n_rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 train step (fwd+bwd, no optimiser) on {n_rays} rays = 32 blocks of 2x2 + 128 content rays, {pts} points, {dt:.1f} s",
+            "sample": f"1 train step (fwd+bwd, no optimiser) on {n_rays} rays = 32 blocks of 8x8 + 2048 content rays, {pts} points, {dt:.1f} s",
             "points_per_s": pts / dt}
 
 
