@@ -107,6 +107,14 @@ int rm_composite(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *ray
 int rm_compact_alive(const int32_t *rays_alive, uint32_t n_alive, int32_t *rays_alive_out, int32_t *n_out,
                      nsig_stream_t stream);
 
+/* ------------------------------------------------------------------ ray generation */
+
+/* The arithmetic of get_rays (nerf/utils_wtmk_disen.py:59-143): pinhole rays through pixel centres, normalised,
+ * rotated by the camera-to-world pose.  poses [B,4,4]; inds [B,N] int64 pixel indices (row-major, i = ind % W,
+ * j = ind / W) or NULL for all H*W pixels in order (then N must be H*W); outputs rays_o, rays_d [B,N,3]. */
+int rg_get_rays(const float *poses, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, const int64_t *inds,
+                uint32_t B, uint32_t N, float *rays_o, float *rays_d, nsig_stream_t stream);
+
 /* ------------------------------------------------------------------ hash grids */
 
 /* S[t] = sum_i tables[i][t] over the D selected codebook tables (the tables 2i+bit_i of

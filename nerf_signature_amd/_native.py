@@ -18,6 +18,7 @@ _vp, _u32, _fl, _int, _sz = _c.c_void_p, _c.c_uint32, _c.c_float, _c.c_int, _c.c
 SIGNATURES = {
     "nsig_abi_version": [],
     "nsig_last_error": [],
+    "rg_get_rays": [_vp, _fl, _fl, _fl, _fl, _u32, _u32, _vp, _u32, _u32, _vp, _vp, _vp],
     "rm_near_far_from_aabb": [_vp, _vp, _vp, _u32, _fl, _vp, _vp, _vp],
     "rm_sph_from_ray": [_vp, _vp, _fl, _u32, _vp, _vp],
     "rm_morton3D": [_vp, _u32, _vp, _vp],

@@ -94,6 +94,27 @@ __global__ void k_packbits(const float *__restrict__ grid, uint32_t n_bytes, flo
     else for (uint32_t b = 0; b < nb; ++b) bits[first + b] = (uint8_t)(word >> (8 * b));
 }
 
+// get_rays (nerf/utils_wtmk_disen.py:121-141) for given pixel indices: one lane per ray, no [B, H*W] meshgrid.
+__global__ void k_get_rays(const float *__restrict__ poses, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W,
+                           const int64_t *__restrict__ inds, uint32_t B, uint32_t N, float *__restrict__ rays_o,
+                           float *__restrict__ rays_d) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= B * N) return;
+    const uint32_t b = gid / N, n = gid % N;
+    const int64_t ind = inds ? inds[(size_t)b * N + n] : (int64_t)n;
+    const float i = (float)(ind % (int64_t)W) + 0.5f, j = (float)(ind / (int64_t)W) + 0.5f;  // pixel centres (:76-77)
+    const float x = (i - cx) / fx, y = (j - cy) / fy, z = 1.0f;                               // (:131-133), zs == 1
+    const float nrm = sqrtf(x * x + y * y + z * z);                                          // torch.norm(dim=-1)
+    const float dx = x / nrm, dy = y / nrm, dz = z / nrm;
+    const float *P = poses + 16 * (size_t)b;                                                  // row-major [4,4]
+    float *o = rays_o + 3 * (size_t)gid, *d = rays_d + 3 * (size_t)gid;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        d[r] = dx * P[4 * r] + dy * P[4 * r + 1] + dz * P[4 * r + 2];                          // directions @ R^T (:135)
+        o[r] = P[4 * r + 3];                                                                 // camera centre (:137)
+    }
+}
+
 // ----------------------------------------------------------------------------- the occupancy walk
 
 struct GridView {
@@ -756,4 +777,15 @@ NSIG_EXPORT int rm_compact_alive(const int32_t *rays_alive, uint32_t n_alive, in
     NSIG_REQUIRE(rays_alive != rays_alive_out, "rm_compact_alive: in-place compaction is not supported");
     k_compact_alive<<<1, 1024, 0, as_stream(stream)>>>(rays_alive, n_alive, rays_alive_out, n_out);
     return check_launch("rm_compact_alive");
+}
+
+NSIG_EXPORT int rg_get_rays(const float *poses, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, const int64_t *inds,
+                            uint32_t B, uint32_t N, float *rays_o, float *rays_d, nsig_stream_t stream) {
+    NSIG_REQUIRE(poses && rays_o && rays_d, "rg_get_rays: null pointer");
+    NSIG_REQUIRE(H > 0 && W > 0 && fx != 0.0f && fy != 0.0f, "rg_get_rays: bad image size or focal length");
+    NSIG_REQUIRE(inds != nullptr || N == H * W, "rg_get_rays: without indices N must equal H*W");
+    NSIG_REQUIRE((uint64_t)B * N < (1ull << 32), "rg_get_rays: too many rays");
+    if (B * N == 0) return NSIG_OK;
+    k_get_rays<<<ceil_div(B * N, 256), 256, 0, as_stream(stream)>>>(poses, fx, fy, cx, cy, H, W, inds, B, N, rays_o, rays_d);
+    return check_launch("rg_get_rays");
 }

@@ -161,3 +161,29 @@ def test_argument_checks_raise(rmod):
                               1, 128, torch.zeros(4, device="cuda"), torch.ones(4, device="cuda"), None, -1, False, 128, True, 0.0, 1024)
     with pytest.raises(ValueError):
         nv.call("rm_morton3D", None, 4, None, None)
+
+
+def test_get_rays_on_device_matches_reference_golden():
+    """rg_get_rays vs the reference's own get_rays output (golden G7) and vs the oracle for whole images / batches."""
+    import os
+    from nerf_signature_amd import rays
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g7_get_rays.npz"))
+    poses = torch.from_numpy(g["pose"])[None].cuda()
+    torch.manual_seed(0)
+    out = rays.get_rays(poses, g["intrinsics"], 400, 400, N=-1)
+    assert out["rays_o"].shape == (1, 160000, 3) and torch.equal(out["inds"][0].cpu(), torch.arange(160000))
+    np.testing.assert_array_equal(out["rays_o"][0, g["inds"]].cpu().numpy(), g["rays_o"])
+    np.testing.assert_allclose(out["rays_d"][0, g["inds"]].cpu().numpy(), g["rays_d"], rtol=0, atol=5e-7)   # 3-term dot product: order/FMA differ by an ulp or two
+    sub = rays.get_rays(poses, g["intrinsics"], 400, 400, N=4096)
+    assert sub["rays_d"].shape == (1, 4096, 3) and sub["inds"].shape == (1, 4096) and int(sub["inds"].max()) < 160000
+    np.testing.assert_array_equal(sub["rays_d"][0].cpu().numpy(), out["rays_d"][0, sub["inds"][0]].cpu().numpy())
+    two = torch.cat([poses, poses.roll(1, 2)], 0)
+    o0, d0 = fr.get_rays(two.cpu(), g["intrinsics"], 30, 50)
+    o1 = rays.get_rays(two, g["intrinsics"], 30, 50)
+    np.testing.assert_allclose(o1["rays_d"].cpu().numpy(), d0.numpy(), rtol=0, atol=5e-7)
+    np.testing.assert_array_equal(o1["rays_o"].cpu().numpy(), o0.numpy())
+    patch = rays.get_rays(poses, g["intrinsics"], 400, 400, N=4096, patch_size=16)
+    assert patch["rays_d"].shape == (1, 4096, 3)
+    em = torch.rand(1, 128 * 128).cuda()
+    coarse = rays.get_rays(poses, g["intrinsics"], 400, 400, N=1024, error_map=em)
+    assert coarse["inds_coarse"].shape == (1, 1024) and coarse["rays_d"].shape == (1, 1024, 3)
