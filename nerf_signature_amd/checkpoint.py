@@ -1,0 +1,64 @@
+"""Checkpoint compatibility: the on-disk format of the reference's Trainer
+(/root/reference/nerf/utils_wtmk_disen.py:1385-1517) -- a torch.save'd dict with 'epoch', 'global_step', 'stats',
+'mean_count', 'mean_density', optionally 'optimizer' / 'lr_scheduler' / 'scaler', and 'model' = state_dict().
+
+The model keeps the reference's parameter surface (names, shapes, fp32), so no re-layout happens here; what this module
+adds is the dict around it and the tolerant loading rules: a bare state_dict is accepted (:1469-1472), loading is
+strict=False with the missing / unexpected keys reported (:1474-1479) -- a clean stage-1 checkpoint has no `msg_encoder.*`
+/ `msg_decoder.*` keys -- tinycudann parameters stored in half precision are widened to fp32, and the derived device
+images of the model (packed MLP weights, pre-summed codebook) are invalidated."""
+import os
+
+import torch
+
+
+def checkpoint_state(model, epoch=0, global_step=0, stats=None, optimizer=None, lr_scheduler=None, scaler=None, full=False):
+    state = {"epoch": epoch, "global_step": global_step, "stats": stats if stats is not None else {}}
+    if getattr(model, "cuda_ray", False):
+        state["mean_count"] = model.mean_count
+        state["mean_density"] = model.mean_density
+    if full:
+        if optimizer is not None:
+            state["optimizer"] = optimizer.state_dict()
+        if lr_scheduler is not None:
+            state["lr_scheduler"] = lr_scheduler.state_dict()
+        if scaler is not None:
+            state["scaler"] = scaler.state_dict()
+    state["model"] = model.state_dict()
+    return state
+
+
+def save_checkpoint(path, model, **kw):
+    """Writes `<path>` (e.g. <workspace>/checkpoints/ngp_ep0010.pth) in the reference's format."""
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    torch.save(checkpoint_state(model, **kw), path)
+    return path
+
+
+def load_checkpoint(path_or_dict, model, optimizer=None, lr_scheduler=None, scaler=None, model_only=False, map_location=None):
+    """Returns (missing_keys, unexpected_keys, meta) where meta holds epoch / global_step / stats when present."""
+    ckpt = torch.load(path_or_dict, map_location=map_location, weights_only=False) if isinstance(path_or_dict, (str, os.PathLike)) else path_or_dict
+    sd = ckpt["model"] if "model" in ckpt else ckpt
+    own = model.state_dict()
+    fixed = {}
+    for k, v in sd.items():
+        if k in own and torch.is_tensor(v) and v.is_floating_point() and v.dtype != own[k].dtype:
+            v = v.to(own[k].dtype)          # e.g. fp16 tcnn params
+        fixed[k] = v
+    missing, unexpected = model.load_state_dict(fixed, strict=False)
+    for attr in ("_packed_cache", "_presum_cache"):
+        if hasattr(model, attr):
+            setattr(model, attr, None)
+    meta = {}
+    if "model" in ckpt:
+        if getattr(model, "cuda_ray", False):
+            if "mean_count" in ckpt:
+                model.mean_count = ckpt["mean_count"]
+            if "mean_density" in ckpt:
+                model.mean_density = ckpt["mean_density"]
+        if not model_only:
+            meta = {k: ckpt[k] for k in ("epoch", "global_step", "stats") if k in ckpt}
+            for obj, key in ((optimizer, "optimizer"), (lr_scheduler, "lr_scheduler"), (scaler, "scaler")):
+                if obj is not None and key in ckpt:
+                    obj.load_state_dict(ckpt[key])
+    return list(missing), list(unexpected), meta

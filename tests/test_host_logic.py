@@ -160,3 +160,36 @@ def test_data_parallel_exchange_gloo_world2():
         assert torch.allclose(grads[2], torch.full_like(grads[2], 4.5))
         assert nbytes == 16 * 4 + sum(g.numel() for g in grads) * 4
     assert torch.equal(res[0][2], res[1][2])
+
+
+def test_checkpoint_round_trip_and_clean_checkpoint(tmp_path):
+    """N4: the reference's checkpoint dict format; strict=False loading of a clean (stage-1) checkpoint; fp16 tcnn params."""
+    from nerf_signature_amd import checkpoint as ck
+    from nerf_signature_amd.network import NeRFNetwork
+    torch.manual_seed(0)
+    a = NeRFNetwork(bound=1.0, cuda_ray=True, message_dim=32)
+    a.mean_count, a.mean_density = 1234, 0.5
+    with torch.no_grad():
+        a.encoder.embeddings[3].weight.uniform_(-1, 1)
+        a.msg_encoder.embeddings[7].weight.uniform_(-1, 1)
+        a.density_bitfield.fill_(7)
+    opt = torch.optim.Adam(a.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    path = ck.save_checkpoint(str(tmp_path / "checkpoints" / "ngp_ep0003.pth"), a, epoch=3, global_step=42, stats={"loss": [1.0]}, optimizer=opt, full=True)
+    raw = torch.load(path, weights_only=False)
+    assert set(raw) >= {"epoch", "global_step", "stats", "mean_count", "mean_density", "optimizer", "model"}
+    b = NeRFNetwork(bound=1.0, cuda_ray=True, message_dim=32)
+    missing, unexpected, meta = ck.load_checkpoint(path, b)
+    assert not missing and not unexpected and meta["epoch"] == 3 and meta["global_step"] == 42 and b.mean_count == 1234
+    for (k1, v1), (k2, v2) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    # a clean checkpoint as stage 1 would write it: no codebook / decoder keys, tcnn parameters in half precision
+    clean = {k: (v.half() if k.endswith("_net.params") else v) for k, v in a.state_dict().items() if not k.startswith("msg_")}
+    c = NeRFNetwork(bound=1.0, cuda_ray=True, message_dim=32)
+    before = c.msg_encoder.embeddings[0].weight.clone()
+    missing, unexpected, _ = ck.load_checkpoint({"model": clean, "epoch": 1, "global_step": 1, "stats": {}}, c, model_only=True)
+    assert all(k.startswith("msg_") for k in missing) and not unexpected
+    assert c.sigma_net.params.dtype == torch.float32 and torch.allclose(c.sigma_net.params, a.sigma_net.params, atol=1e-3)
+    assert torch.equal(c.encoder.embeddings[3].weight, a.encoder.embeddings[3].weight) and torch.equal(c.msg_encoder.embeddings[0].weight, before)
+    assert c._packed_cache is None
+    missing, _, _ = ck.load_checkpoint(a.state_dict(), c)      # a bare state_dict is accepted too
+    assert not missing
