@@ -48,7 +48,7 @@ def scratch_reference():
     for rel in ("hash_encoding.py", "hash_encoding_wtmk_bit.py", "activation.py", "msgencoder.py"):
         shutil.copy(os.path.join(REF, rel), os.path.join(tmp, rel))
     os.makedirs(os.path.join(tmp, "nerf"))
-    for rel in ("hidden_models.py", "utils_wtmk_disen.py", "network_wtmk_tcnn.py", "renderer_wtmk.py"):
+    for rel in ("hidden_models.py", "utils_wtmk_disen.py", "utils_wtmk.py", "provider_wtmk.py", "network_wtmk_tcnn.py", "renderer_wtmk.py"):
         shutil.copy(os.path.join(REF, "nerf", rel), os.path.join(tmp, "nerf", rel))
     open(os.path.join(tmp, "nerf", "__init__.py"), "w").close()
     return tmp
@@ -91,7 +91,15 @@ def install_stubs():
             s = torch.tensor(self.std, dtype=x.dtype).view(-1, 1, 1)
             return (x - m) / s
 
+    class ToPILImage:
+        """torchvision's conversion for float CHW tensors: mul(255).byte(), HWC, mode RGB."""
+
+        def __call__(self, pic):
+            from PIL import Image
+            return Image.fromarray(pic.detach().cpu().mul(255).byte().permute(1, 2, 0).contiguous().numpy(), mode="RGB")
+
     tvt.Normalize = Normalize
+    tvt.ToPILImage = ToPILImage
     tv.transforms = tvt
     sys.modules["torchvision"], sys.modules["torchvision.transforms"] = tv, tvt
 
@@ -305,6 +313,21 @@ def main():
                         cb_grad_rows=nz.numpy().astype(np.int32), cb_grad_vals=sel0[nz].numpy(),
                         state_dict_keys=np.array(sorted(model.state_dict().keys())),
                         state_dict_shapes=np.array([str(tuple(model.state_dict()[k].shape)) for k in sorted(model.state_dict().keys())]))
+    # ---- G10: block selection (provider_wtmk.process_image: JPEG compressibility) and rand_poses -----------------------
+    sys.modules.setdefault("scipy.spatial.transform", __import__("scipy.spatial.transform", fromlist=["x"]))
+    with _CpuTensorCtor():
+        from nerf import provider_wtmk as ref_prov
+    rng = np.random.RandomState(21)
+    yy, xx = np.meshgrid(np.linspace(0, 1, 96), np.linspace(0, 1, 120), indexing="ij")
+    img = np.stack([0.5 + 0.4 * np.sin(6 * xx), 0.5 + 0.4 * np.cos(5 * yy), 0.5 + 0.3 * np.sin(9 * xx * yy)], -1)
+    noise = rng.rand(96, 120, 3) - 0.5
+    for (r, c, amp) in [(1, 2, 0.6), (5, 7, 0.9), (3, 3, 0.3), (6, 0, 0.45), (0, 9, 0.75), (7, 5, 0.2), (2, 8, 0.5)]:
+        img[r * 12:(r + 1) * 12, c * 12:(c + 1) * 12] += amp * noise[r * 12:(r + 1) * 12, c * 12:(c + 1) * 12]
+    img = torch.from_numpy(np.clip(img, 0, 1).astype(np.float32))[None]
+    coords, bh, bw = ref_prov.process_image(img, 8, 10, 6)
+    torch.manual_seed(5)
+    rp = ref_prov.rand_poses(4, "cpu", radius=2.5)
+    np.savez_compressed(os.path.join(HERE, "g10_blocks.npz"), image=img.numpy(), coords=coords.numpy(), bh=np.int32(bh), bw=np.int32(bw), rand_poses=rp.numpy())
     shutil.rmtree(tmp)
     print("golden vectors written to", HERE)
 

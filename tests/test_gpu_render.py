@@ -319,3 +319,22 @@ def test_density_grid_maintenance():
     m.mark_untrained_grid(poses, (555.56, 555.56, 200.0, 200.0))
     marked = (m.density_grid == -1)
     assert bool(marked.any()) and not bool(marked.all())  # cells outside the single camera's frustum are marked untrained
+
+
+def test_clean_render_prepass_matches_oracle():
+    """N2: the clean-render pre-pass (message=None, staged, rays generated on the device) vs the oracle's staged render."""
+    from nerf_signature_amd import blocks
+    m, bitfield, C = _model()
+    P, S = _oracle_params(m, bitfield, C)
+    H, W = 24, 36
+    poses = torch.stack([torch.from_numpy(cf.orbit_rays(1, seed=s)[0]) for s in (0, 1)])
+    poses[1, :3, 3] *= 0.9
+    intr = np.array([40.0, 40.0, W / 2, H / 2], np.float32)
+    imgs = blocks.clean_render(m, poses.cuda(), intr, H, W, dict(dt_gamma=0, max_steps=1024), max_ray_batch=300)
+    assert imgs.shape == (2, H, W, 3)
+    for b in range(2):
+        o, d = fr.get_rays(poses[b:b + 1], intr, H, W)
+        ref = fr.render(o, d, None, P, S, staged=True, max_ray_batch=300, bg_color=1, dt_gamma=0.0, max_steps=1024)
+        np.testing.assert_allclose(imgs[b].reshape(-1, 3).cpu().numpy(), ref["image"][0].numpy(), rtol=0, atol=1e-3)
+    coords, bh, bw = blocks.process_image(imgs[:1].cpu(), 4, 6, 5)
+    assert coords.shape == (5, 4) and (bh, bw) == (6, 6)

@@ -193,3 +193,21 @@ def test_checkpoint_round_trip_and_clean_checkpoint(tmp_path):
     assert c._packed_cache is None
     missing, _, _ = ck.load_checkpoint(a.state_dict(), c)      # a bare state_dict is accepted too
     assert not missing
+
+
+def test_block_selection_matches_reference_golden():
+    """N2: process_image (JPEG compressibility ranking) and rand_poses vs the reference's own outputs (golden G10)."""
+    pytest.importorskip("PIL")
+    from nerf_signature_amd import blocks
+    g = np.load(os.path.join(G, "g10_blocks.npz"))
+    img = torch.from_numpy(g["image"])
+    coords, bh, bw = blocks.process_image(img, 8, 10, 6)
+    assert (bh, bw) == (int(g["bh"]), int(g["bw"])) == (12, 12)
+    np.testing.assert_array_equal(coords.numpy(), g["coords"])
+    o = torch.arange(96 * 120 * 3, dtype=torch.float32).view(1, 96, 120, 3)
+    bo, bd = blocks.block_rays(o, -o, coords)
+    assert bo.shape == (6, 12, 12, 3)
+    r0, c0 = int(coords[2, 0]), int(coords[2, 1])
+    assert torch.equal(bo[2], o[0, r0:r0 + 12, c0:c0 + 12]) and torch.equal(bd[2], -bo[2])
+    torch.manual_seed(5)
+    np.testing.assert_allclose(blocks.rand_poses(4, "cpu", radius=2.5).numpy(), g["rand_poses"], rtol=0, atol=1e-6)
