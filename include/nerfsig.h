@@ -222,6 +222,27 @@ int field_bwd(const float *xyzs, uint32_t M, float bound, const float *grad_sigm
               const float *sigmas, const float *rgbs, const uint32_t *masks, const void *packed, float *G,
               float *dfeat_out, float *rec_out, nsig_stream_t stream);
 
+/* ------------------------------------------------------------------ stage-1 (clean model) training, SURVEY.md 8(f) N3 */
+
+/*
+ * The clean model of stage 1 (nerf/network_hash.py) trains everything: base tables and both MLPs (:154-166).
+ * field_fwd_trace = field_fwd on pre-encoded planes (no codebook) that also saves each layer's input, feature-major
+ * [width][stride] fp32 with stride = M rounded up to 32: act_hs [64], act_cin [32] (16 SH, 15 geometry features, the
+ * padded 1.0), act_h1 [64], act_h2 [64].  field_bwd_trace back-propagates (dL/dsigma, dL/drgb) and writes every
+ * layer's pre-activation gradient (d_hs [64], d_so [16], d_h1 [64], d_h2 [64], d_out [16]; same layout) and the gradient
+ * of all 32 encoder features as level-major planes d_planes [16][stride] float2.  The weight gradients are then plain
+ * GEMMs over the point dimension (d_pre x act^T, left to the BLAS library); hg_scatter_level scatters one level's
+ * feature gradient into that level's table gradient G_l [T,2] (owner-computes, as hg_scatter_sliced).
+ */
+int field_fwd_trace(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *const *base_tables_host,
+                    const void *packed, const void *planes, float *sigmas, float *rgbs, uint32_t *masks, float *act_hs,
+                    float *act_cin, float *act_h1, float *act_h2, nsig_stream_t stream);
+int field_bwd_trace(uint32_t M, const float *grad_sigmas, const float *grad_rgbs, const float *sigmas, const float *rgbs,
+                    const uint32_t *masks, const void *packed, float *d_hs, float *d_so, float *d_h1, float *d_h2, float *d_out,
+                    void *d_planes, nsig_stream_t stream);
+int hg_scatter_level(const float *xyzs, float bound, const void *d_plane, uint32_t M, uint32_t level, float *G,
+                     nsig_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

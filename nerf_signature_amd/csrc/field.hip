@@ -43,7 +43,8 @@ constexpr int B1 = 2;   // Wc2^T [64x64]              2 x 4
 constexpr int B2 = 10;  // Wc1^T rows -> sigma-out    1 x 4
 constexpr int B3 = 14;  // W2s^T [64x16]              2 x 1
 constexpr int B4 = 16;  // W1s[:,30:32]^T             1 x 4
-constexpr int kBwdFrags = 20;
+constexpr int B4F = 20; // W1s^T, all 32 features     1 x 4   (stage-1 training: gradients of the base tables)
+constexpr int kBwdFrags = 24;
 constexpr int kFragBytes = 64 * 16;  // 64 lanes x 8 bf16
 // packed = [fwd hi | fwd lo | bwd hi | bwd lo]
 constexpr size_t kFwdBytes = (size_t)kFwdFrags * kFragBytes, kBwdBytes = (size_t)kBwdFrags * kFragBytes;
@@ -88,7 +89,8 @@ __device__ inline float bwd_weight(int frag, int lane, int j, const float *__res
     }
     if (frag < B3) return (r >= 1 && r < 16) ? cp[kColorW1 + k_from_acc(frag - B2, h, j) * 32 + 15 + r] : 0.0f;
     if (frag < B4) return sp[kSigmaW2 + row_of_reg(h, j) * 64 + 32 * (frag - B3) + r];
-    return r < 2 ? sp[kSigmaW1 + k_from_acc(frag - B4, h, j) * 32 + 30 + r] : 0.0f;
+    if (frag < B4F) return r < 2 ? sp[kSigmaW1 + k_from_acc(frag - B4, h, j) * 32 + 30 + r] : 0.0f;
+    return sp[kSigmaW1 + k_from_acc(frag - B4F, h, j) * 32 + r];
 }
 
 __global__ void __launch_bounds__(256) k_pack_weights(const float *__restrict__ sp, const float *__restrict__ cp, __bf16 *__restrict__ packed) {
@@ -189,8 +191,35 @@ __device__ inline void stage_weights(char *lds, const char *__restrict__ src, in
     __syncthreads();
 }
 
+// Stage-1 (clean model) training needs the gradients of every weight matrix and of all 32 encoder features.  The weight
+// gradients are reductions over all points of (pre-activation gradient) x (layer input) -- plain GEMMs -- so the forward
+// optionally saves each layer's input and the backward each layer's pre-activation gradient, feature-major
+// ([width][stride] fp32: a wave stores 128 contiguous bytes per row), and the host reduces them with library GEMMs.
+struct ActTrace {    // written by the forward
+    float *hs;       // [64][stride] sigma hidden layer, post-ReLU
+    float *cin;      // [32][stride] colour input: 16 SH, 15 geometry features, the padded 1.0
+    float *h1, *h2;  // [64][stride] colour hidden layers, post-ReLU
+};
+struct GradTrace {   // written by the backward
+    float *d_hs, *d_h1, *d_h2;  // [64][stride] pre-activation gradients of the hidden layers
+    float *d_so, *d_out;        // [16][stride] gradients of the two heads' outputs (sigma head rows 0..15; colour rows 0..2)
+    float2 *d_planes;           // [16][stride] gradient of the 32 encoder features, level-major like the forward's planes
+};
+
+// row of a 32-row accumulator block held in register r (0..15) of lane half h
+__device__ inline int row_of_reg16(int h, int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <typename F>
+__device__ inline void store_rows64(float *__restrict__ dst, uint32_t stride, uint32_t s, int h, const f32x16 (&acc)[2], F f) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(size_t)(32 * rb + row_of_reg16(h, r)) * stride + s] = f(acc[rb][r], rb * 16 + r);
+}
+
 __device__ inline void color_branch(const char *lds_hi, const char *lds_lo, int lane, int h, float dx, float dy, float dz,
-                                    const float (&geo8)[8], uint32_t (&mask)[2], float (&rgb)[3]) {
+                                    const float (&geo8)[8], uint32_t (&mask)[2], float (&rgb)[3], const ActTrace *trace = nullptr,
+                                    uint32_t stride = 0, uint32_t s = 0) {
     // tcnn's SH encoding takes inputs in [0,1] and maps them back (network_wtmk_tcnn.py:114-115)
     const float ux = (dx + 1.0f) / 2.0f, uy = (dy + 1.0f) / 2.0f, uz = (dz + 1.0f) / 2.0f;
     float sh[16];
@@ -201,12 +230,23 @@ __device__ inline void color_branch(const char *lds_hi, const char *lds_lo, int 
         split_put(cin[0], j, h ? sh[8 + j] : sh[j]);
         split_put(cin[1], j, geo8[j]);
     }
+    auto relu = [](float v, int) { return v > 0.0f ? v : 0.0f; };
+    if (trace != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            trace->cin[(size_t)(8 * h + j) * stride + s] = h ? sh[8 + j] : sh[j];
+            const int rho = row_of_reg(h, j);  // slot (h, j) of the second K-step carries sigma-head row rho (row 0 -> the padded 1.0)
+            trace->cin[(size_t)(rho == 0 ? 31 : 15 + rho) * stride + s] = geo8[j];
+        }
+    }
     f32x16 hid[2];
     Split8 b4[4];
     mfma_layer<2, 2>(lds_hi, lds_lo, F2, lane, cin, hid);
     mask[0] = relu_to_operand(hid, b4);
+    if (trace != nullptr) store_rows64(trace->h1, stride, s, h, hid, relu);
     mfma_layer<2, 4>(lds_hi, lds_lo, F3, lane, b4, hid);
     mask[1] = relu_to_operand(hid, b4);
+    if (trace != nullptr) store_rows64(trace->h2, stride, s, h, hid, relu);
     f32x16 out[1];
     mfma_layer<1, 4>(lds_hi, lds_lo, F4, lane, b4, out);
 #pragma unroll
@@ -251,12 +291,12 @@ __global__ void __launch_bounds__(256) k_encode_planes(const float *__restrict__
 }
 
 // kPlanes = false: gather the features in-kernel (fused); true: read them from the level-major planes.
-template <bool kPlanes>
+template <bool kPlanes, bool kTrace = false>
 __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyzs, const float *__restrict__ dirs, uint32_t M, float bound,
                                                    TablePtrs base, LevelGeom geom, const float *__restrict__ S,
                                                    const float2 *__restrict__ planes, uint32_t stride,
                                                    const char *__restrict__ packed, float *__restrict__ sigmas, float *__restrict__ rgbs,
-                                                   float *__restrict__ geo_out, uint32_t *__restrict__ masks) {
+                                                   float *__restrict__ geo_out, uint32_t *__restrict__ masks, ActTrace trace = ActTrace{}) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     stage_weights(lds, packed, 2 * (int)kFwdBytes);
     const char *lds_hi = lds, *lds_lo = lds + kFwdBytes;
@@ -309,6 +349,7 @@ __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyz
         Split8 b4[4];
         mfma_layer<2, 2>(lds_hi, lds_lo, F0, lane, feat, hid);
         const uint32_t mask_s = relu_to_operand(hid, b4);
+        if (kTrace) store_rows64(trace.hs, stride, s, h, hid, [](float v, int) { return v > 0.0f ? v : 0.0f; });
         f32x16 so[1];
         mfma_layer<1, 4>(lds_hi, lds_lo, F1, lane, b4, so);
 
@@ -329,7 +370,8 @@ __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyz
             for (int r = 0; r < 8; ++r) geo8[r] = so[0][r];
             if (h == 0) geo8[0] = 1.0f;  // the slot of row 0 carries the padded constant input (weight column 31)
             float rgb[3];
-            color_branch(lds_hi, lds_lo, lane, h, dirs[3 * (size_t)sl], dirs[3 * (size_t)sl + 1], dirs[3 * (size_t)sl + 2], geo8, mask_c, rgb);
+            color_branch(lds_hi, lds_lo, lane, h, dirs[3 * (size_t)sl], dirs[3 * (size_t)sl + 1], dirs[3 * (size_t)sl + 2], geo8, mask_c, rgb,
+                         kTrace ? &trace : nullptr, stride, s);
             if (live && h == 0) { rgbs[3 * (size_t)s] = rgb[0]; rgbs[3 * (size_t)s + 1] = rgb[1]; rgbs[3 * (size_t)s + 2] = rgb[2]; }
         }
         if (masks != nullptr) {
@@ -366,11 +408,13 @@ __global__ void __launch_bounds__(256) k_field_color(const float *__restrict__ d
 
 // ----------------------------------------------------------------------------- backward
 
+template <bool kFull = false>
 __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyzs, uint32_t M, float bound, float cb_cell,
                                                    const float *__restrict__ g_sigma, const float *__restrict__ g_rgb,
                                                    const float *__restrict__ sigmas, const float *__restrict__ rgbs,
                                                    const uint32_t *__restrict__ masks, const char *__restrict__ packed,
-                                                   float *__restrict__ G, float *__restrict__ dfeat_out, float *__restrict__ rec_out) {
+                                                   float *__restrict__ G, float *__restrict__ dfeat_out, float *__restrict__ rec_out,
+                                                   GradTrace gt = GradTrace{}, uint32_t stride = 0) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     stage_weights(lds, packed + 2 * kFwdBytes, 2 * (int)kBwdBytes);
     const char *lds_hi = lds, *lds_lo = lds + kBwdBytes;
@@ -395,25 +439,46 @@ __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyz
                 v = g_rgb[3 * (size_t)sl + j] * (c * (1.0f - c));
             }
             split_put(dout[0], j, v);
+            if (kFull) gt.d_out[(size_t)(8 * h + j) * stride + s] = v;   // rows 3..15 are zero
         }
         f32x16 hid[2];
         Split8 b4[4];
         mfma_layer<2, 1>(lds_hi, lds_lo, B0, lane, dout, hid);
         mask_to_operand(hid, mask_c1, b4);
+        if (kFull) store_rows64(gt.d_h2, stride, s, h, hid, [=](float v, int i) { return ((mask_c1 >> i) & 1u) ? v : 0.0f; });
         mfma_layer<2, 4>(lds_hi, lds_lo, B1, lane, b4, hid);
         mask_to_operand(hid, mask_c0, b4);
+        if (kFull) store_rows64(gt.d_h1, stride, s, h, hid, [=](float v, int i) { return ((mask_c0 >> i) & 1u) ? v : 0.0f; });
         f32x16 dso[1];
         mfma_layer<1, 4>(lds_hi, lds_lo, B2, lane, b4, dso);  // rows 1..15 = d geo_feat
 
         Split8 dhead[1];
+        float head8[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) split_put(dhead[0], r, dso[0][r]);
+        for (int r = 0; r < 8; ++r) head8[r] = dso[0][r];
         if (h == 0) {  // row 0: d log-density = g * exp(clamp(h0, -15, 15)) (activation.py:14), with exp(h0) = sigma
             const float sg = live ? sigmas[sl] : 0.0f;
-            split_put(dhead[0], 0, (live ? g_sigma[sl] : 0.0f) * fminf(fmaxf(sg, e_lo), e_hi));
+            head8[0] = (live ? g_sigma[sl] : 0.0f) * fminf(fmaxf(sg, e_lo), e_hi);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            split_put(dhead[0], r, head8[r]);
+            if (kFull) gt.d_so[(size_t)row_of_reg(h, r) * stride + s] = head8[r];
         }
         mfma_layer<2, 1>(lds_hi, lds_lo, B3, lane, dhead, hid);
         mask_to_operand(hid, mask_s, b4);
+        if (kFull) {
+            store_rows64(gt.d_hs, stride, s, h, hid, [=](float v, int i) { return ((mask_s >> i) & 1u) ? v : 0.0f; });
+            f32x16 dall[1];
+            mfma_layer<1, 4>(lds_hi, lds_lo, B4F, lane, b4, dall);  // row f = d feature[f]; registers (r, r+1), r even, hold one level's pair
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                float2 v;
+                v.x = dall[0][r]; v.y = dall[0][r + 1];
+                gt.d_planes[(size_t)(row_of_reg16(h, r) >> 1) * stride + s] = v;
+            }
+            continue;
+        }
         f32x16 dfe[1];
         mfma_layer<1, 4>(lds_hi, lds_lo, B4, lane, b4, dfe);  // rows 0,1 (lane half 0) = d feature[30], d feature[31]
 
@@ -550,7 +615,39 @@ NSIG_EXPORT int field_bwd(const float *xyzs, uint32_t M, float bound, const floa
     NSIG_REQUIRE(G || dfeat_out || rec_out, "field_bwd: at least one of G / dfeat_out / rec_out must be given");
     NSIG_REQUIRE(bound > 0.0f, "field_bwd: bound must be positive");
     if (M == 0) return NSIG_OK;
-    k_field_bwd<<<field_grid(M), 256, 2 * kBwdBytes, as_stream(stream)>>>(xyzs, M, bound, 1.0f / kCodebookResolution, grad_sigmas, grad_rgbs,
+    k_field_bwd<false><<<field_grid(M), 256, 2 * kBwdBytes, as_stream(stream)>>>(xyzs, M, bound, 1.0f / kCodebookResolution, grad_sigmas, grad_rgbs,
                                                                          sigmas, rgbs, masks, reinterpret_cast<const char *>(packed), G, dfeat_out, rec_out);
     return check_launch("field_bwd");
+}
+
+// ----------------------------------------------------------------------------- stage-1 (clean model) training entry points
+
+NSIG_EXPORT int field_fwd_trace(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *const *base_tables_host,
+                                const void *packed, const void *planes, float *sigmas, float *rgbs, uint32_t *masks, float *act_hs,
+                                float *act_cin, float *act_h1, float *act_h2, nsig_stream_t stream) {
+    NSIG_REQUIRE(xyzs && dirs && packed && planes && sigmas && rgbs && masks && act_hs && act_cin && act_h1 && act_h2, "field_fwd_trace: null pointer");
+    NSIG_REQUIRE(bound > 0.0f, "field_fwd_trace: bound must be positive");
+    TablePtrs base{};
+    if (int e = fill_base_tables(base_tables_host, base, "field_fwd_trace")) return e;
+    if (M == 0) return NSIG_OK;
+    const uint32_t stride = ceil_div(M, 32u) * 32u;
+    ActTrace tr{act_hs, act_cin, act_h1, act_h2};
+    k_field_fwd<true, true><<<field_grid(M), 256, 2 * kFwdBytes, as_stream(stream)>>>(xyzs, dirs, M, bound, base, make_level_geom(), nullptr,
+                                                                                     reinterpret_cast<const float2 *>(planes), stride,
+                                                                                     reinterpret_cast<const char *>(packed), sigmas, rgbs, nullptr, masks, tr);
+    return check_launch("field_fwd_trace");
+}
+
+NSIG_EXPORT int field_bwd_trace(uint32_t M, const float *grad_sigmas, const float *grad_rgbs, const float *sigmas, const float *rgbs,
+                                const uint32_t *masks, const void *packed, float *d_hs, float *d_so, float *d_h1, float *d_h2, float *d_out,
+                                void *d_planes, nsig_stream_t stream) {
+    NSIG_REQUIRE(grad_sigmas && grad_rgbs && sigmas && rgbs && masks && packed && d_hs && d_so && d_h1 && d_h2 && d_out && d_planes,
+                 "field_bwd_trace: null pointer");
+    if (M == 0) return NSIG_OK;
+    const uint32_t stride = ceil_div(M, 32u) * 32u;
+    GradTrace gt{d_hs, d_h1, d_h2, d_so, d_out, reinterpret_cast<float2 *>(d_planes)};
+    k_field_bwd<true><<<field_grid(M), 256, 2 * kBwdBytes, as_stream(stream)>>>(nullptr, M, 1.0f, 1.0f / kCodebookResolution, grad_sigmas, grad_rgbs, sigmas,
+                                                                               rgbs, masks, reinterpret_cast<const char *>(packed), nullptr, nullptr,
+                                                                               nullptr, gt, stride);
+    return check_launch("field_bwd_trace");
 }

@@ -134,6 +134,38 @@ __global__ void __launch_bounds__(1024) k_scatter_sliced(const float *__restrict
     }
 }
 
+// Owner-computes scatter of one base level's feature gradient (stage-1 training): as k_scatter_sliced, with the level's
+// own resolution (not a power of two, so the cell index uses the same IEEE divisions as the forward: corner_rows()).
+__global__ void __launch_bounds__(1024) k_scatter_level(const float *__restrict__ xyzs, float bound, const float2 *__restrict__ dplane, uint32_t M,
+                                                        float cell, float *__restrict__ G) {
+    extern __shared__ float acc[];
+    const uint32_t slice = blockIdx.x >> 3, replica = blockIdx.x & 7u;
+    for (uint32_t i = threadIdx.x; i < 2u * kSliceRows; i += blockDim.x) acc[i] = 0.0f;
+    __syncthreads();
+    const uint32_t chunk = ceil_div(M, (uint32_t)kReplicas);
+    const uint32_t beg = min(M, replica * chunk), end = min(M, beg + chunk);
+    const float two_b = 2.0f * bound;
+    for (uint32_t m = beg + threadIdx.x; m < end; m += blockDim.x) {
+        const float2 g = dplane[m];
+        if (g.x == 0.0f && g.y == 0.0f) continue;
+        Corner8 c;
+        corner_rows((xyzs[3 * (size_t)m] + bound) / two_b, (xyzs[3 * (size_t)m + 1] + bound) / two_b, (xyzs[3 * (size_t)m + 2] + bound) / two_b, cell, c);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if ((c.row[k] >> 14) != slice) continue;
+            float *dst = acc + 2u * (c.row[k] & (kSliceRows - 1));
+            atomicAdd(dst, corner_weight(c, k, g.x));
+            atomicAdd(dst + 1, corner_weight(c, k, g.y));
+        }
+    }
+    __syncthreads();
+    float *out = G + 2 * (size_t)slice * kSliceRows;
+    for (uint32_t i = threadIdx.x; i < 2u * kSliceRows; i += blockDim.x) {
+        const float v = acc[i];
+        if (v != 0.0f) atomicAdd(out + i, v);
+    }
+}
+
 // grads[i][e] (+)= G[e]: float4 per lane, D output streams.
 __global__ void __launch_bounds__(256) k_fanout(const float4 *__restrict__ G, GradPtrs grads, uint32_t D, int accumulate) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -410,4 +442,22 @@ NSIG_EXPORT int opt_codebook_adam_sel(const float *G, float *const *params_host,
     if (int e = check_launch("opt_codebook_adam_sel (prepare)")) return e;
     k_codebook_adam_sel<<<NSIG_TABLE_ROWS / 2 / 256, 256, 0, st>>>(reinterpret_cast<const float4 *>(G), a, message, scratch, D, beta1, beta2, eps, grad_scale);
     return check_launch("opt_codebook_adam_sel");
+}
+
+NSIG_EXPORT int hg_scatter_level(const float *xyzs, float bound, const void *d_plane, uint32_t M, uint32_t level, float *G, nsig_stream_t stream) {
+    NSIG_REQUIRE(xyzs && d_plane && G, "hg_scatter_level: null pointer");
+    NSIG_REQUIRE(level < NSIG_BASE_LEVELS && bound > 0.0f, "hg_scatter_level: level %u out of range or bad bound", level);
+    if (M == 0) return NSIG_OK;
+    static bool attr_set = false;
+    const size_t lds = (size_t)kSliceRows * 2 * sizeof(float);
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_level), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error("hg_scatter_level: cannot reserve %zu bytes of LDS", lds);
+            return NSIG_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    k_scatter_level<<<kSlices * kReplicas, 1024, lds, as_stream(stream)>>>(xyzs, bound, reinterpret_cast<const float2 *>(d_plane), M,
+                                                                         1.0f / kBaseResolution[level], G);
+    return check_launch("hg_scatter_level");
 }

@@ -74,3 +74,28 @@ class GradExchange:
                 p.grad.copy_(g)
             off += n
         self.bytes_per_step = (shared_grad.numel() * 4 if shared_grad is not None else 0) + self.bucket.numel() * 4
+
+
+def allreduce_gradients(params, bucket_bytes=64 << 20):
+    """Mean all-reduce of the .grad of `params` in flat buckets (stage-1 training: base tables + MLPs, 64 MiB + 40 KB):
+    buckets of ~64 MiB keep every xGMI link busy with few, large collectives."""
+    world = world_size()
+    if world == 1:
+        return 0
+    grads = [p.grad for p in params if p.grad is not None]
+    total, i = 0, 0
+    while i < len(grads):
+        j, size = i, 0
+        while j < len(grads) and (size == 0 or size + grads[j].numel() * 4 <= bucket_bytes):
+            size += grads[j].numel() * 4
+            j += 1
+        flat = torch.cat([g.reshape(-1) for g in grads[i:j]])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.mul_(1.0 / world)
+        off = 0
+        for g in grads[i:j]:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+        total += size
+        i = j
+    return total

@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported(native):
 
 def test_host_only_queries(native):
     assert native.fn("rm_march_train_scratch_bytes")(4096, 1024) == 4096 * 1024 * 4
-    assert native.fn("mlp_packed_bytes")() == 2 * (24 + 20) * 64 * 16
+    assert native.fn("mlp_packed_bytes")() == 2 * (24 + 24) * 64 * 16
 
 
 def test_argument_validation_needs_no_gpu(native):

@@ -134,6 +134,12 @@ def _dp_worker(rank, world, port, q):
     fan = [G.clone() for _ in range(D)]
     ok = all(torch.equal(a, b) for a, b in zip(dense, fan))
     grads = [None if p.grad is None else p.grad.clone() for p in dec.parameters()]
+    # stage-1 style: bucketed mean all-reduce of ordinary dense gradients
+    ps = [torch.nn.Parameter(torch.zeros(5, 2)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(3))]
+    ps[0].grad, ps[1].grad = torch.full((5, 2), float(rank)), torch.full((7,), 2.0 * rank + 1)
+    nbytes = dp.allreduce_gradients(ps, bucket_bytes=48)
+    assert nbytes == 68 and ps[2].grad is None
+    assert torch.allclose(ps[0].grad, torch.full((5, 2), 0.5)) and torch.allclose(ps[1].grad, torch.full((7,), 2.0))
     q.put((rank, ok, G.clone(), grads, ex.bytes_per_step))
     dist.barrier()
     dist.destroy_process_group()
