@@ -222,6 +222,21 @@ int field_bwd(const float *xyzs, uint32_t M, float bound, const float *grad_sigm
               const float *sigmas, const float *rgbs, const uint32_t *masks, const void *packed, float *G,
               float *dfeat_out, float *rec_out, nsig_stream_t stream);
 
+/* ------------------------------------------------------------------ decoder glue */
+
+/*
+ * BatchNorm2d with batch statistics (track_running_stats=False, hidden_models.py:26) followed by GELU (erf form), as one
+ * kernel each way for the HiDDeN decoder's ConvBNRelu blocks (hidden_models.py:16-35).  x, y, grads: [N, C, H, W] in
+ * channels-last memory (element (n,c,p) at (n*P + p)*C + c, P = H*W).  save: 2*C floats (mean, inverse std).
+ *   forward : y = gelu(gamma * (x - mean_c) / sqrt(var_c + eps) + beta), var biased over N*P
+ *   backward: dx, dgamma, dbeta from dy (the gradient of y); gelu'(.) is recomputed from x.
+ * One workgroup per channel (the tensors are ~1 MB: the cost is launch count, which this replaces 5:1 and 6:1).
+ */
+int dec_bn_gelu_fwd(const float *x, const float *gamma, const float *beta, uint32_t N, uint32_t C, uint32_t P, float eps, float *y,
+                    float *save, nsig_stream_t stream);
+int dec_bn_gelu_bwd(const float *dy, const float *x, const float *gamma, const float *beta, const float *save, uint32_t N, uint32_t C,
+                    uint32_t P, float *dx, float *dgamma, float *dbeta, nsig_stream_t stream);
+
 /* ------------------------------------------------------------------ stage-1 (clean model) training, SURVEY.md 8(f) N3 */
 
 /*

@@ -49,6 +49,8 @@ SIGNATURES = {
     "hg_encode_planes": [_vp, _u32, _fl, _vp, _vp, _vp, _vp],
     "field_fwd": [_vp, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "field_color_fwd": [_vp, _vp, _u32, _vp, _vp, _vp],
+    "dec_bn_gelu_fwd": [_vp, _vp, _vp, _u32, _u32, _u32, _fl, _vp, _vp, _vp],
+    "dec_bn_gelu_bwd": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp],
     "field_fwd_trace": [_vp, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "field_bwd_trace": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hg_scatter_level": [_vp, _fl, _vp, _u32, _u32, _vp, _vp],

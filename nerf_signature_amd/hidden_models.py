@@ -1,10 +1,15 @@
 """HiDDeN-style watermark decoder (mirror of /root/reference/nerf/hidden_models.py:13-35,104-137,181-183).
 
-This part of the path stays on stock PyTorch-ROCm operators (MIOpen convolutions): SURVEY.md 8(a) R13.
+The convolutions stay on MIOpen; on the GPU the BatchNorm(batch statistics)+GELU pair of every
+block is one libnerfsig kernel each way (dec_bn_gelu_fwd/_bwd) instead of torch's 5 + 6 launch-bound kernels, and the
+convolution's bias -- which BatchNorm's mean subtraction cancels exactly -- is not added (its gradient is identically zero).
 Module/parameter names reproduce the reference's state_dict keys
 (`layers.{0..8}.layers.{0,1}.{weight,bias}`, `linear.{weight,bias}`)."""
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _native as nv
 
 _MEAN, _STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
@@ -32,6 +37,38 @@ def unnormalize_img(x):
     return x * std + mean
 
 
+def _nhwc(t):
+    """Device pointer of a 4-d tensor held channels-last (nv.ptr insists on row-major contiguity)."""
+    import ctypes
+    if not (t.is_cuda and t.is_contiguous(memory_format=torch.channels_last) and t.dtype == torch.float32):
+        raise ValueError("expected a float32 channels-last device tensor")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class _BNGelu(torch.autograd.Function):
+    """gelu(batch_norm(x; batch statistics, eps)) on an NHWC tensor: one kernel forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        N, C, H, W = x.shape
+        x = x.contiguous(memory_format=torch.channels_last)
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        save = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+        nv.call("dec_bn_gelu_fwd", _nhwc(x), nv.ptr(gamma), nv.ptr(beta), N, C, H * W, eps, _nhwc(y), nv.ptr(save), nv.stream())
+        ctx.save_for_backward(x, gamma, beta, save)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, save = ctx.saved_tensors
+        N, C, H, W = x.shape
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx, dgamma, dbeta = torch.empty_like(x, memory_format=torch.channels_last), torch.empty_like(gamma), torch.empty_like(beta)
+        nv.call("dec_bn_gelu_bwd", _nhwc(dy), _nhwc(x), nv.ptr(gamma), nv.ptr(beta), nv.ptr(save), N, C, H * W, _nhwc(dx), nv.ptr(dgamma),
+                nv.ptr(dbeta), nv.stream())
+        return dx, dgamma, dbeta, None
+
+
 class ConvBNRelu(nn.Module):
     """3x3 convolution, BatchNorm that always uses batch statistics (track_running_stats=False), GELU."""
 
@@ -44,6 +81,10 @@ class ConvBNRelu(nn.Module):
         )
 
     def forward(self, x):
+        conv, bn = self.layers[0], self.layers[1]
+        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] * x.shape[2] * x.shape[3] > 1:
+            # BatchNorm subtracts the per-channel batch mean, so conv.bias cancels: skip the add and its (zero) gradient.
+            return _BNGelu.apply(F.conv2d(x, conv.weight, None, 1, 1), bn.weight.float(), bn.bias.float(), bn.eps)
         return self.layers(x)
 
 
