@@ -116,7 +116,7 @@ def main():
     model = NeRFNetwork(bound=cfg["bound"], cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1, message_dim=D, n_views=1)
     synthetic.init_model(model, scene)
     model.to(dev).train()
-    if not args.no_channels_last:
+    if not args.no_channels_last and os.environ.get("NERFSIG_DECODER", "") == "torch":   # only the stock-operator decoder benefits
         model.msg_decoder.to(memory_format=torch.channels_last)   # MIOpen's kernels are NHWC: saves the layout changes around every conv
     render_kwargs = dict(dt_gamma=cfg["dt_gamma"], max_steps=1024)
 

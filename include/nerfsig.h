@@ -237,6 +237,24 @@ int dec_bn_gelu_fwd(const float *x, const float *gamma, const float *beta, uint3
 int dec_bn_gelu_bwd(const float *dy, const float *x, const float *gamma, const float *beta, const float *save, uint32_t N, uint32_t C,
                     uint32_t P, float *dx, float *dgamma, float *dbeta, nsig_stream_t stream);
 
+/*
+ * The whole HiDDeN decoder of hidden_models.py:104-137 -- ConvBNRelu(Cin,64), 7 x ConvBNRelu(64,64), ConvBNRelu(64,1),
+ * AdaptiveAvgPool2d(1), Linear(1,1) -- as one chain of fused kernels per direction (one launch per layer each way: MFMA
+ * implicit-GEMM convolutions with the BatchNorm statistics in their epilogue and BatchNorm+GELU in the consumer's prologue).
+ * Replaces `msg_decoder(img)` and its autograd backward (network_wtmk_tcnn.py:46, utils_wtmk_disen.py:499-505).
+ *   img      [B, Cin, H, W] fp32 (NCHW, already normalised); decoded [B] (the Linear output; num_bits = redundancy = 1)
+ *   params   host array of 29 device pointers: for l = 0..8 {conv weight [Cout,Cin_l,3,3], bn weight, bn bias}, then
+ *            linear weight [1,1], linear bias [1].  conv biases are not inputs: BatchNorm's batch-mean subtraction cancels them.
+ *   grads    host array of 29 device pointers, same order and shapes (written, not accumulated)
+ *   workspace: dec_workspace_bytes(B, Cin, H, W) bytes (0 = shape not supported: H*W <= 1024, Cin <= 32, LDS limits);
+ *            dec_backward reads what dec_forward left there, so the pair must share it and nothing may overwrite it between.
+ */
+size_t dec_workspace_bytes(uint32_t B, uint32_t Cin, uint32_t H, uint32_t W);
+int dec_forward(const float *img, const float *const *params_host, uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, float eps,
+                void *workspace, float *decoded, nsig_stream_t stream);
+int dec_backward(const float *grad_decoded, const float *img, const float *const *params_host, uint32_t B, uint32_t Cin, uint32_t H,
+                 uint32_t W, void *workspace, float *const *grads_host, float *grad_img, nsig_stream_t stream);
+
 /* ------------------------------------------------------------------ stage-1 (clean model) training, SURVEY.md 8(f) N3 */
 
 /*

@@ -1,0 +1,1164 @@
+// The HiDDeN message decoder (/root/reference/nerf/hidden_models.py:104-137: ConvBNRelu(Cin,64), 7 x ConvBNRelu(64,64),
+// ConvBNRelu(64,1), global average pool, Linear(1,1)) as a chain of fused kernels, forward and backward.
+//
+// Why: the decoder sees D images of ~12x12 pixels.  Every stock operator on such a tensor (1.2 MB) is launch-latency
+// bound, and a training step runs ~120 of them (conv, BN statistics, BN apply, GELU, their backward kernels, MIOpen's
+// workspace fills): ~0.9 ms of a 2.25 ms step.  Here a layer is ONE kernel each way:
+//
+//   forward  layer l : prologue  a_{l-1} = GELU(BN(x_{l-1}))      (batch statistics combined from the producer's partials)
+//                      body      x_l = conv3x3(a_{l-1})           (implicit GEMM on MFMA, split-bf16 = fp32-grade products)
+//                      epilogue  store x_l, per-(image, tile) partial statistics (sum, M2) of x_l
+//   backward layer l : prologue  dx_l = BN-backward(dz_l)         (needs the batch sums of dz_l, dz_l*xhat_l: partials again)
+//                      body      G_{l-1} = conv3x3^T(dx_l)  and, in other workgroups of the same launch,
+//                                dW_l   = sum_pixels dx_l (x) a_{l-1}   (K = pixels, shifted-window operand)
+//                      epilogue  dz_{l-1} = G_{l-1} * GELU'(z_{l-1}), partial sums of it
+//
+// The kernel boundary is the batch-wide synchronisation BatchNorm needs; nothing else is exchanged between workgroups.
+// conv biases are not applied: BatchNorm's mean subtraction cancels them exactly (their gradient is identically zero).
+//
+// Latency discipline: the tensors are tiny, so a kernel's time is the number of dependent L2 round trips on its critical
+// path.  Every loop that reads global memory issues its loads in batches before using them; the 72 A fragments of a
+// (rb, tile) unit are all requested before the prologue starts; batch statistics are exchanged as one partial per
+// (image, tile pair).
+//
+// Data layout: activations [B][P][C] fp32 (pixel-major, channels contiguous), P = H*W.  MFMA operands are staged in LDS
+// as bf16 hi/lo planes.  Weights are re-packed once per step into A-fragment order (k_dec_pack).
+#include <algorithm>
+
+#include "common.h"
+
+namespace nsig {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kC = 64;          // hidden channels (hidden_models.py:181)
+constexpr int kLayers = 9;      // ConvBNRelu blocks
+constexpr int kKS = 36;         // k-steps of a 64->64 3x3 conv: 9 taps x 4 chunks of 16 channels
+constexpr int kPitch = 144;     // LDS bytes per halo pixel per plane: 64 bf16 + 16 pad (conflict-free b128 reads)
+constexpr int kSets = 15;       // packed fragment sets: layers 1..7 x {forward, dgrad}, + layer 0 dgrad (towards the image)
+constexpr size_t kSetU4 = (size_t)2 * kKS * 2 * 64;   // uint4 per set: [rb][ks][plane][lane]
+constexpr uint32_t kMaxCin = 32, kMaxP = 1024;
+
+struct DecGeom {
+    uint32_t B, H, W, P, Cin, ntile, npair, rows_max;   // rows_max: most halo rows any tile pair stages
+    uint32_t RS, nband, R;                               // wgrad: halo row stride (multiple of 8), row bands, rows per band
+    uint32_t pd, pa, nks;                                // wgrad: LDS row pitches in bytes (dx, a), k-steps per band
+    float eps;
+};
+
+struct DecWs {
+    float *x[kLayers], *xhat[kLayers], *gprime[kLayers], *dz[kLayers], *act[kLayers - 1];
+    float *stat[kLayers], *bsum[kLayers], *minv[kLayers];
+    float *pool;
+    float *wpart;    // [7][B*nband][9][64][64]
+    float *wpart0;   // [B*npair][64][9*Cin]
+    float *wpart8;   // [B*npair][64][9]
+    uint4 *packed;   // [kSets] fragment sets
+};
+
+struct DecParams {
+    const float *w[kLayers], *gamma[kLayers], *beta[kLayers], *lin_w, *lin_b;
+};
+struct DecGrads {
+    float *w[kLayers], *gamma[kLayers], *beta[kLayers], *lin_w, *lin_b;
+};
+
+__host__ __device__ inline uint32_t tile_count(uint32_t tile, uint32_t P) { return P - 32u * tile < 32u ? P - 32u * tile : 32u; }
+__host__ __device__ inline uint32_t pair_count(uint32_t pair, uint32_t P) { return P - 64u * pair < 64u ? P - 64u * pair : 64u; }
+
+// Chan's update: fold a group (n_b values, sum_b, M2_b about its own mean) into a running (cnt, mean, M2).
+__device__ inline void chan_merge(float &cnt, float &mean, float &M2, float n_b, float sum_b, float M2_b) {
+    if (n_b <= 0.0f) return;
+    const float tot = cnt + n_b, delta = sum_b / n_b - mean;
+    mean += delta * (n_b / tot);
+    M2 += M2_b + delta * delta * (cnt * n_b / tot);
+    cnt = tot;
+}
+
+__device__ inline void gelu_parts(float z, float &a, float &gp) {
+    const float Phi = 0.5f * (1.0f + erff(z * 0.70710678118654752f));
+    const float phi = 0.39894228040143268f * expf(-0.5f * z * z);
+    a = z * Phi;
+    gp = Phi + z * phi;
+}
+
+__device__ inline float half_sum(float v) {   // sum over the 32 lanes that share lane >> 5
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ inline float wave_sum64(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ inline float block_sum256(float v, float *scratch) {   // scratch: 4 floats
+    v = wave_sum64(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+__device__ inline void split_bf16(float v, __bf16 &hi, __bf16 &lo) {
+    hi = (__bf16)v;
+    lo = (__bf16)(v - (float)hi);
+}
+
+// ----------------------------------------------------------------------------- weight packing
+
+// forward set (kind 0):  A[row = co][k = (tap, ci)]   = W[co][ci][tap]
+// dgrad set   (kind 1):  A[row = ci][k = (tap', co)]  = W[co][ci][8 - tap']      (transposed, taps flipped)
+// set 14: layer 0's dgrad, rows = input channel (< Cin, rest zero), W0 is [64][Cin][3][3].
+// fragment (rb, ks = tap*4 + c4), lane (row = lane & 31, h = lane >> 5), element j: k-channel 16*c4 + 8*h + j.
+__global__ void __launch_bounds__(64) k_dec_pack(DecParams prm, uint4 *__restrict__ packed, uint32_t Cin) {
+    const int f = blockIdx.x, ks = f % kKS, rb = (f / kKS) & 1, set = f / (2 * kKS);
+    const int lane = threadIdx.x, row = 32 * rb + (lane & 31), h = lane >> 5, tap = ks >> 2, c4 = ks & 3;
+    const int layer = set < 14 ? 1 + (set >> 1) : 0, kind = set < 14 ? (set & 1) : 1;
+    const float *__restrict__ w = prm.w[layer];
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int kc = 16 * c4 + 8 * h + j;
+        float v;
+        if (layer == 0)
+            v = row < (int)Cin ? w[(kc * Cin + row) * 9 + (8 - tap)] : 0.0f;
+        else
+            v = kind == 0 ? w[(row * kC + kc) * 9 + tap] : w[(kc * kC + row) * 9 + (8 - tap)];
+        __bf16 vh, vl;
+        split_bf16(v, vh, vl);
+        hi[j] = vh;
+        lo[j] = vl;
+    }
+    uint4 *dst = packed + (size_t)set * kSetU4 + ((size_t)rb * kKS + ks) * 128;
+    dst[lane] = *reinterpret_cast<uint4 *>(&hi);
+    dst[64 + lane] = *reinterpret_cast<uint4 *>(&lo);
+}
+
+// ----------------------------------------------------------------------------- batch statistics from partials
+
+// Forward: per-(image, pair) partials (sum, M2 about the pair mean) -> batch mean and 1/sqrt(var + eps), combined with
+// Chan's formula (no E[x^2] - E[x]^2 cancellation).  256 threads; red: 768 floats; out: s_mean[64], s_inv[64].
+__device__ inline void combine_fwd_stats(const float *__restrict__ part, const DecGeom &g, float *red, float *s_mean, float *s_inv) {
+    const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const uint32_t n = g.B * g.npair;
+    const float2 *__restrict__ p2 = reinterpret_cast<const float2 *>(part);
+    float cnt = 0.0f, mean = 0.0f, M2 = 0.0f;
+    for (uint32_t base = grp; base < n; base += 32) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t i = base + 4 * u;
+            v[u] = i < n ? p2[(size_t)i * kC + c] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t i = base + 4 * u;
+            if (i < n) chan_merge(cnt, mean, M2, (float)pair_count(i % g.npair, g.P), v[u].x, v[u].y);
+        }
+    }
+    red[(grp * 64 + c) * 3] = cnt;
+    red[(grp * 64 + c) * 3 + 1] = mean;
+    red[(grp * 64 + c) * 3 + 2] = M2;
+    __syncthreads();
+    if (grp == 0) {
+        for (int k = 1; k < 4; ++k) {
+            const float nb = red[(k * 64 + c) * 3];
+            chan_merge(cnt, mean, M2, nb, red[(k * 64 + c) * 3 + 1] * nb, red[(k * 64 + c) * 3 + 2]);
+        }
+        s_mean[c] = mean;
+        s_inv[c] = 1.0f / sqrtf(M2 / cnt + g.eps);
+    }
+    __syncthreads();
+}
+
+// Backward: k = gamma*inv/N, S1 = sum dz, S2 = sum dz*xhat over the batch.  red: 512 floats; tab: [3][64].
+__device__ inline void combine_bwd_sums(const float *__restrict__ part, const float *__restrict__ gamma, const float *__restrict__ minv,
+                                        const DecGeom &g, float *red, float *tab) {
+    const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const uint32_t n = g.B * g.npair;
+    const float2 *__restrict__ p2 = reinterpret_cast<const float2 *>(part);
+    float s1 = 0.0f, s2 = 0.0f;
+    for (uint32_t base = grp; base < n; base += 32) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t i = base + 4 * u;
+            v[u] = i < n ? p2[(size_t)i * kC + c] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            s1 += v[u].x;
+            s2 += v[u].y;
+        }
+    }
+    red[grp * 64 + c] = s1;
+    red[256 + grp * 64 + c] = s2;
+    __syncthreads();
+    if (grp == 0) {
+        tab[c] = gamma[c] * minv[64 + c] / (float)(g.B * g.P);
+        tab[64 + c] = red[c] + red[64 + c] + red[128 + c] + red[192 + c];
+        tab[128 + c] = red[256 + c] + red[320 + c] + red[384 + c] + red[448 + c];
+    }
+    __syncthreads();
+}
+
+// ----------------------------------------------------------------------------- layer 0 forward: Cin -> 64 on the VALU
+
+// grid (npair, B), 256 threads: thread = (co, quarter of the pair's 64 pixels).  K = 9*Cin is too short for MFMA to matter.
+__global__ void __launch_bounds__(256) k_dec_l0_fwd(const float *__restrict__ img, DecParams prm, DecWs ws, DecGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const uint32_t pair = blockIdx.x, im = blockIdx.y, t = threadIdx.x;
+    const uint32_t W2 = g.W + 2, HW2 = (g.H + 2) * W2, K = 9 * g.Cin;
+    float *s_img = smem;                    // [Cin][(H+2)(W+2)] zero-padded
+    float *s_w = s_img + g.Cin * HW2;       // [64][K]
+    float *s_red = s_w + kC * K;            // [4][64]
+    for (uint32_t i = t; i < g.Cin * HW2; i += 256) {
+        const uint32_t c = i / HW2, pos = i - c * HW2, hr = pos / W2, hc = pos - hr * W2;
+        const bool in = hr >= 1 && hr <= g.H && hc >= 1 && hc <= g.W;
+        s_img[i] = in ? img[((size_t)im * g.Cin + c) * g.P + (hr - 1) * g.W + (hc - 1)] : 0.0f;
+    }
+    for (uint32_t i = t; i < kC * K; i += 256) s_w[i] = prm.w[0][i];   // [co][ci][3][3] row-major = [co][K]
+    __syncthreads();
+    const uint32_t co = t & 63, sub = t >> 6, q0 = pair * 64 + sub * 16;
+    float v[16];
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t q = q0 + j;
+        v[j] = 0.0f;
+        if (q < g.P) {
+            const uint32_t py = q / g.W, px = q - py * g.W;
+            float acc = 0.0f;
+            for (uint32_t c = 0; c < g.Cin; ++c)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap)
+                    acc += s_w[co * K + c * 9 + tap] * s_img[c * HW2 + (py + tap / 3) * W2 + px + tap % 3];
+            v[j] = acc;
+            ws.x[0][((size_t)im * g.P + q) * kC + co] = acc;
+            s += acc;
+        }
+    }
+    // pair statistics, two passes inside the workgroup: sum -> mean, then M2 about it
+    s_red[sub * 64 + co] = s;
+    __syncthreads();
+    const float ts = s_red[co] + s_red[64 + co] + s_red[128 + co] + s_red[192 + co];
+    const float mean = ts / (float)pair_count(pair, g.P);
+    float m2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (q0 + j < g.P) m2 += (v[j] - mean) * (v[j] - mean);
+    __syncthreads();
+    s_red[sub * 64 + co] = m2;
+    __syncthreads();
+    if (sub == 0) {
+        float *po = ws.stat[0] + (((size_t)im * g.npair + pair) * kC + co) * 2;
+        po[0] = ts;
+        po[1] = s_red[co] + s_red[64 + co] + s_red[128 + co] + s_red[192 + co];
+    }
+}
+
+// ----------------------------------------------------------------------------- staging: what a tile pair reads
+
+// Rows of the halo image an (image, pair) workgroup stages: staged row r <-> image row py0 + r - 1.
+struct PairRows {
+    uint32_t q0, q1, py0, nrow;
+};
+__host__ __device__ inline PairRows pair_rows(uint32_t pair, uint32_t P, uint32_t W) {
+    PairRows r;
+    r.q0 = pair * 64;
+    r.q1 = (r.q0 + 64 < P ? r.q0 + 64 : P) - 1;
+    r.py0 = r.q0 / W;
+    r.nrow = r.q1 / W - r.py0 + 3;
+    return r;
+}
+
+// Staged position -> pixel index, or -1 for the zero padding.
+__device__ inline int staged_pixel(uint32_t pos, uint32_t W2, uint32_t py0, const DecGeom &g) {
+    const uint32_t hr = pos / W2, hc = pos - hr * W2;
+    const int iy = (int)(py0 + hr) - 1, ix = (int)hc - 1;
+    return (iy >= 0 && iy < (int)g.H && ix >= 0 && ix < (int)g.W) ? iy * (int)g.W + ix : -1;
+}
+
+// a = GELU(BN(x)) for 4 channels of one pixel; tab = [mean | inv | gamma | beta].
+__device__ inline void bn_gelu4(float4 xv, uint32_t cg, const float *tab, float (&xh)[4], float (&a)[4], float (&gp)[4]) {
+    const float xin[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = cg * 4 + j;
+        xh[j] = (xin[j] - tab[c]) * tab[64 + c];
+        gelu_parts(xh[j] * tab[128 + c] + tab[192 + c], a[j], gp[j]);
+    }
+}
+
+// dx = k * (N*dz - S1 - xhat*S2) for 4 channels of one pixel (BatchNorm backward, batch statistics); tab = [k | S1 | S2].
+__device__ inline float4 bn_bwd4(float4 d, float4 h, uint32_t cg, const float *tab, float N) {
+    const float dv[4] = {d.x, d.y, d.z, d.w}, hv[4] = {h.x, h.y, h.z, h.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = cg * 4 + j;
+        o[j] = tab[c] * (N * dv[j] - tab[64 + c] - hv[j] * tab[128 + c]);
+    }
+    return make_float4(o[0], o[1], o[2], o[3]);
+}
+
+__device__ inline void split4_to_lds(char *lds_hi, char *lds_lo, uint32_t pos, uint32_t cg, const float (&v)[4]) {
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        __bf16 vh, vl;
+        split_bf16(v[j], vh, vl);
+        hi[j] = vh;
+        lo[j] = vl;
+    }
+    *reinterpret_cast<bf16x4 *>(lds_hi + pos * kPitch + cg * 8) = hi;
+    *reinterpret_cast<bf16x4 *>(lds_lo + pos * kPitch + cg * 8) = lo;
+}
+
+constexpr int kBatch = 4;   // prologue items whose loads are in flight together
+
+// Forward prologue shared by the MFMA layers (bf16 hi/lo planes) and layer 8 (fp32 rows): stage GELU(BN(x_prev)) for every
+// position the pair touches; the owner of a pixel also records xhat, GELU' and a for the backward pass.
+template <bool kF32>
+__device__ inline void stage_forward(const float *__restrict__ x, float *__restrict__ xhat, float *__restrict__ gprime, float *__restrict__ act,
+                                     uint32_t im, const PairRows &pr, const DecGeom &g, const float *tab, char *lds_hi, char *lds_lo, float *lds_f32) {
+    const uint32_t W2 = g.W + 2, total = pr.nrow * W2 * 16;
+    for (uint32_t base = threadIdx.x; base < total; base += 256 * kBatch) {
+        float4 xv[kBatch];
+        int q[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const uint32_t i = base + 256 * u;
+            q[u] = i < total ? staged_pixel(i >> 4, W2, pr.py0, g) : -1;
+            xv[u] = q[u] >= 0 ? *reinterpret_cast<const float4 *>(x + ((size_t)im * g.P + q[u]) * kC + (i & 15) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const uint32_t i = base + 256 * u, pos = i >> 4, cg = i & 15;
+            if (i >= total) break;
+            float xh[4], a[4] = {0.f, 0.f, 0.f, 0.f}, gp[4];
+            if (q[u] >= 0) {
+                bn_gelu4(xv[u], cg, tab, xh, a, gp);
+                if ((uint32_t)q[u] >= pr.q0 && (uint32_t)q[u] <= pr.q1) {
+                    const size_t e = ((size_t)im * g.P + q[u]) * kC + cg * 4;
+                    *reinterpret_cast<float4 *>(xhat + e) = make_float4(xh[0], xh[1], xh[2], xh[3]);
+                    *reinterpret_cast<float4 *>(gprime + e) = make_float4(gp[0], gp[1], gp[2], gp[3]);
+                    *reinterpret_cast<float4 *>(act + e) = make_float4(a[0], a[1], a[2], a[3]);
+                }
+            }
+            if (kF32)
+                *reinterpret_cast<float4 *>(lds_f32 + (size_t)pos * kC + cg * 4) = make_float4(a[0], a[1], a[2], a[3]);
+            else
+                split4_to_lds(lds_hi, lds_lo, pos, cg, a);
+        }
+    }
+}
+
+// Backward prologue: stage dx = BN-backward(dz) for every position the pair touches.
+__device__ inline void stage_backward(const float *__restrict__ dz, const float *__restrict__ xhat, uint32_t im, const PairRows &pr, const DecGeom &g,
+                                      const float *tab, char *lds_hi, char *lds_lo) {
+    const uint32_t W2 = g.W + 2, total = pr.nrow * W2 * 16;
+    const float N = (float)(g.B * g.P);
+    for (uint32_t base = threadIdx.x; base < total; base += 256 * kBatch) {
+        float4 dv[kBatch], hv[kBatch];
+        int q[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const uint32_t i = base + 256 * u;
+            q[u] = i < total ? staged_pixel(i >> 4, W2, pr.py0, g) : -1;
+            const size_t e = ((size_t)im * g.P + (q[u] >= 0 ? q[u] : 0)) * kC + (i & 15) * 4;
+            dv[u] = q[u] >= 0 ? *reinterpret_cast<const float4 *>(dz + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+            hv[u] = q[u] >= 0 ? *reinterpret_cast<const float4 *>(xhat + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const uint32_t i = base + 256 * u;
+            if (i >= total) break;
+            const float4 d = q[u] >= 0 ? bn_bwd4(dv[u], hv[u], i & 15, tab, N) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float v[4] = {d.x, d.y, d.z, d.w};
+            split4_to_lds(lds_hi, lds_lo, i >> 4, i & 15, v);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- the 64 -> 64 conv kernel (forward / dgrad)
+
+struct AFrags {
+    uint4 hi[kKS], lo[kKS];   // 288 VGPRs: the whole A operand of one (rb, tile) unit, requested up front
+};
+__device__ inline void load_afrags(const uint4 *__restrict__ A, int lane, AFrags &f) {
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) {
+        f.hi[ks] = A[ks * 128 + lane];
+        f.lo[ks] = A[ks * 128 + 64 + lane];
+    }
+}
+
+// One (rb, tile) unit: acc[32 rows x 32 pixels] = sum over 36 k-steps; B fragments are 16-byte LDS reads of the lane's
+// pixel at the tap's offset.
+__device__ inline f32x16 conv_unit(AFrags &f, const char *lds_hi, const char *lds_lo, uint32_t hp0, uint32_t W2, int lane) {
+    f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int h = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) {
+        const int tap = ks >> 2, c4 = ks & 3, ty = tap / 3, tx = tap % 3;
+        const uint32_t off = (hp0 + ty * W2 + tx) * kPitch + (16 * c4 + 8 * h) * 2;
+        const bf16x8 b_hi = *reinterpret_cast<const bf16x8 *>(lds_hi + off);
+        const bf16x8 b_lo = *reinterpret_cast<const bf16x8 *>(lds_lo + off);
+        const bf16x8 ah = *reinterpret_cast<bf16x8 *>(&f.hi[ks]), al = *reinterpret_cast<bf16x8 *>(&f.lo[ks]);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b_hi, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b_lo, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b_hi, c, 0, 0, 0);
+    }
+    return c;
+}
+
+enum ConvMode { kFwd = 0, kDgrad = 1, kDgradImg = 2 };
+
+// grid (npair, B), 256 threads = 4 waves = the 4 (rb, tile) units of a tile pair.
+//   kFwd      (layer 1..7): consumes x[l-1], stat[l-1]; writes xhat/gprime/act[l-1] (own pixels), minv[l-1], x[l], stat[l].
+//   kDgrad    (layer 7..1): consumes dz[l], xhat[l], bsum[l]; writes dz[l-1], bsum[l-1].
+//   kDgradImg (layer 0)   : consumes dz[0], xhat[0], bsum[0]; writes the gradient of the input image [B][Cin][H][W].
+template <int MODE>
+__global__ void __launch_bounds__(256) k_dec_conv(int layer, DecParams prm, DecWs ws, DecGeom g, float *__restrict__ grad_img) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const uint32_t pair = blockIdx.x, im = blockIdx.y, t = threadIdx.x;
+    const uint32_t W2 = g.W + 2;
+    const PairRows pr = pair_rows(pair, g.P, g.W);
+    const uint32_t plane = g.rows_max * W2 * kPitch;
+    char *lds_hi = smem_raw, *lds_lo = smem_raw + plane;
+    float *s_tab = reinterpret_cast<float *>(smem_raw + 2 * plane);   // [4][64] per-channel constants
+    float *s_red = s_tab + 4 * 64;                                    // [768] scratch
+
+    const int wave = t >> 6, lane = t & 63, rb = wave & 1, p = lane & 31, h = lane >> 5;
+    const uint32_t tile = 2 * pair + (wave >> 1);
+    const bool active = tile < g.ntile && !(MODE == kDgradImg && rb == 1);
+    const int set = MODE == kFwd ? (layer - 1) * 2 : (MODE == kDgrad ? (layer - 1) * 2 + 1 : 14);
+    AFrags af;
+    if (active) load_afrags(ws.packed + (size_t)set * kSetU4 + (size_t)rb * kKS * 128, lane, af);   // in flight during the prologue
+
+    if (MODE == kFwd) {
+        combine_fwd_stats(ws.stat[layer - 1], g, s_red, s_tab, s_tab + 64);
+        if (t < 64) {
+            s_tab[128 + t] = prm.gamma[layer - 1][t];
+            s_tab[192 + t] = prm.beta[layer - 1][t];
+            if (pair == 0 && im == 0) {
+                ws.minv[layer - 1][t] = s_tab[t];
+                ws.minv[layer - 1][64 + t] = s_tab[64 + t];
+            }
+        }
+        __syncthreads();
+        stage_forward<false>(ws.x[layer - 1], ws.xhat[layer - 1], ws.gprime[layer - 1], ws.act[layer - 1], im, pr, g, s_tab, lds_hi, lds_lo, nullptr);
+    } else {
+        combine_bwd_sums(ws.bsum[layer], prm.gamma[layer], ws.minv[layer], g, s_red, s_tab);
+        stage_backward(ws.dz[layer], ws.xhat[layer], im, pr, g, s_tab, lds_hi, lds_lo);
+    }
+    __syncthreads();
+
+    // ---- body: lane holds rows 32*rb + 8*g4 + 4*h + {0..3} (g4 = 0..3) of pixel q
+    const uint32_t q = 32 * tile + p;
+    const bool valid = active && q < g.P;
+    const uint32_t qq = valid ? q : pr.q0, py = qq / g.W, px = qq - py * g.W;
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (active) acc = conv_unit(af, lds_hi, lds_lo, (py - pr.py0) * W2 + px, W2, lane);
+
+    // ---- epilogue
+    float *s_ep = s_red;   // [4 waves][32 channels][2]
+    if (MODE == kFwd) {
+        if (valid) {
+            float *xo = ws.x[layer] + ((size_t)im * g.P + q) * kC + 32 * rb + 4 * h;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) *reinterpret_cast<float4 *>(xo + 8 * g4) = make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
+        }
+        const float n_tile = active ? (float)tile_count(tile, g.P) : 1.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float s = half_sum(valid ? acc[r] : 0.0f);
+            const float d = valid ? acc[r] - s / n_tile : 0.0f;
+            const float m2 = half_sum(d * d);
+            if (p == 0) {
+                s_ep[(wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3)) * 2] = s;
+                s_ep[(wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3)) * 2 + 1] = m2;
+            }
+        }
+        __syncthreads();
+        if (t < 64) {   // merge the pair's two tiles: waves (rb, rb + 2)
+            const int rbm = t >> 5, ch = t & 31;
+            float cnt = (float)tile_count(2 * pair, g.P), mean = s_ep[(rbm * 32 + ch) * 2] / cnt, M2 = s_ep[(rbm * 32 + ch) * 2 + 1];
+            if (2 * pair + 1 < g.ntile)
+                chan_merge(cnt, mean, M2, (float)tile_count(2 * pair + 1, g.P), s_ep[((rbm + 2) * 32 + ch) * 2], s_ep[((rbm + 2) * 32 + ch) * 2 + 1]);
+            float *po = ws.stat[layer] + (((size_t)im * g.npair + pair) * kC + 32 * rbm + ch) * 2;
+            po[0] = mean * cnt;
+            po[1] = M2;
+        }
+    } else if (MODE == kDgrad) {
+        const size_t e = ((size_t)im * g.P + q) * kC + 32 * rb + 4 * h;
+        float4 gp[4], xh[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            gp[g4] = valid ? *reinterpret_cast<const float4 *>(ws.gprime[layer - 1] + e + 8 * g4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xh[g4] = valid ? *reinterpret_cast<const float4 *>(ws.xhat[layer - 1] + e + 8 * g4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float dzv[4] = {acc[4 * g4] * gp[g4].x, acc[4 * g4 + 1] * gp[g4].y, acc[4 * g4 + 2] * gp[g4].z, acc[4 * g4 + 3] * gp[g4].w};
+            const float xhv[4] = {xh[g4].x, xh[g4].y, xh[g4].z, xh[g4].w};
+            if (valid) *reinterpret_cast<float4 *>(ws.dz[layer - 1] + e + 8 * g4) = make_float4(dzv[0], dzv[1], dzv[2], dzv[3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float s1 = half_sum(valid ? dzv[j] : 0.0f), s2 = half_sum(valid ? dzv[j] * xhv[j] : 0.0f);
+                if (p == 0) {
+                    s_ep[(wave * 32 + 8 * g4 + 4 * h + j) * 2] = s1;
+                    s_ep[(wave * 32 + 8 * g4 + 4 * h + j) * 2 + 1] = s2;
+                }
+            }
+        }
+        __syncthreads();
+        if (t < 64) {
+            const int rbm = t >> 5, ch = t & 31;
+            float *po = ws.bsum[layer - 1] + (((size_t)im * g.npair + pair) * kC + 32 * rbm + ch) * 2;
+            po[0] = s_ep[(rbm * 32 + ch) * 2] + s_ep[((rbm + 2) * 32 + ch) * 2];          // inactive waves wrote zeros
+            po[1] = s_ep[(rbm * 32 + ch) * 2 + 1] + s_ep[((rbm + 2) * 32 + ch) * 2 + 1];
+        }
+    } else {
+        // rows = input channels c = 8*g4 + 4*h + j < Cin
+        if (valid)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t c = 8 * (r >> 2) + 4 * h + (r & 3);
+                if (c < g.Cin) grad_img[((size_t)im * g.Cin + c) * g.P + q] = acc[r];
+            }
+    }
+}
+
+// ----------------------------------------------------------------------------- layer 8 (64 -> 1) and the head
+
+// grid (npair, B), 256 threads.  Prologue as kFwd (a_7 kept fp32 in LDS, [pos][64]); wave = 16 pixels, lane = input channel.
+__global__ void __launch_bounds__(256) k_dec_l8_fwd(DecParams prm, DecWs ws, DecGeom g) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const uint32_t pair = blockIdx.x, im = blockIdx.y, t = threadIdx.x, W2 = g.W + 2;
+    const PairRows pr = pair_rows(pair, g.P, g.W);
+    float *s_a = reinterpret_cast<float *>(smem_raw);          // [rows_max*W2][64]
+    float *s_tab = s_a + (size_t)g.rows_max * W2 * kC;          // [4][64]
+    float *s_red = s_tab + 4 * 64;                              // [768]
+    const int wave = t >> 6, lane = t & 63;
+    float w8[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) w8[tap] = prm.w[8][lane * 9 + tap];   // [1][64][3][3]
+    combine_fwd_stats(ws.stat[7], g, s_red, s_tab, s_tab + 64);
+    if (t < 64) {
+        s_tab[128 + t] = prm.gamma[7][t];
+        s_tab[192 + t] = prm.beta[7][t];
+        if (pair == 0 && im == 0) {
+            ws.minv[7][t] = s_tab[t];
+            ws.minv[7][64 + t] = s_tab[64 + t];
+        }
+    }
+    __syncthreads();
+    stage_forward<true>(ws.x[7], ws.xhat[7], ws.gprime[7], ws.act[7], im, pr, g, s_tab, nullptr, nullptr, s_a);
+    __syncthreads();
+    float *s_x = s_red;   // 64 outputs of the pair
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t q = pr.q0 + 16 * wave + j;
+        float v = 0.0f;
+        if (q < g.P) {
+            const uint32_t py = q / g.W, px = q - py * g.W, hp0 = (py - pr.py0) * W2 + px;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) v += w8[tap] * s_a[(size_t)(hp0 + (tap / 3) * W2 + tap % 3) * kC + lane];
+        }
+        v = wave_sum64(v);
+        if (lane == 0) {
+            s_x[16 * wave + j] = v;
+            if (q < g.P) ws.x[8][(size_t)im * g.P + q] = v;
+        }
+    }
+    __syncthreads();
+    if (t < 64) {   // one wave: the pair's (sum, M2)
+        const uint32_t n = pair_count(pair, g.P);
+        const float v = t < n ? s_x[t] : 0.0f, s = wave_sum64(v);
+        const float d = t < n ? v - s / (float)n : 0.0f, m2 = wave_sum64(d * d);
+        if (t == 0) {
+            ws.stat[8][((size_t)im * g.npair + pair) * 2] = s;
+            ws.stat[8][((size_t)im * g.npair + pair) * 2 + 1] = m2;
+        }
+    }
+}
+
+// grid (B), 256 threads: BN + GELU of the single-channel x_8, average pool, Linear(1,1) (hidden_models.py:121-123,131-135).
+__global__ void __launch_bounds__(256) k_dec_head_fwd(DecParams prm, DecWs ws, DecGeom g, float *__restrict__ decoded) {
+    __shared__ float scratch[4];
+    const uint32_t im = blockIdx.x, t = threadIdx.x, n = g.B * g.npair;
+    const float N = (float)(g.B * g.P);
+    float s = 0.0f;
+    for (uint32_t i = t; i < n; i += 256) s += ws.stat[8][(size_t)i * 2];
+    const float mean = block_sum256(s, scratch) / N;
+    float m2 = 0.0f;
+    for (uint32_t i = t; i < n; i += 256) {
+        const float ni = (float)pair_count(i % g.npair, g.P), d = ws.stat[8][(size_t)i * 2] / ni - mean;
+        m2 += ws.stat[8][(size_t)i * 2 + 1] + ni * d * d;
+    }
+    const float inv = 1.0f / sqrtf(block_sum256(m2, scratch) / N + g.eps);
+    const float gamma = prm.gamma[8][0], beta = prm.beta[8][0];
+    float ps = 0.0f;
+    for (uint32_t q = t; q < g.P; q += 256) {
+        const size_t e = (size_t)im * g.P + q;
+        const float xh = (ws.x[8][e] - mean) * inv;
+        float a, gp;
+        gelu_parts(xh * gamma + beta, a, gp);
+        ws.xhat[8][e] = xh;
+        ws.gprime[8][e] = gp;
+        ps += a;
+    }
+    const float pool = block_sum256(ps, scratch) / (float)g.P;
+    if (t == 0) {
+        ws.pool[im] = pool;
+        decoded[im] = pool * prm.lin_w[0] + prm.lin_b[0];
+        if (im == 0) {
+            ws.minv[8][0] = mean;
+            ws.minv[8][1] = inv;
+        }
+    }
+}
+
+// grid (B), 256 threads: d(decoded) -> dz_8 = d(a_8) * GELU'(z_8) and its per-pair sums.
+__global__ void __launch_bounds__(256) k_dec_head_bwd(const float *__restrict__ grad_dec, DecParams prm, DecWs ws, DecGeom g) {
+    __shared__ float s_dz[kMaxP], s_xh[kMaxP];
+    const uint32_t im = blockIdx.x, t = threadIdx.x;
+    const float ga = grad_dec[im] * prm.lin_w[0] / (float)g.P;
+    for (uint32_t q = t; q < g.P; q += 256) {
+        const size_t e = (size_t)im * g.P + q;
+        const float dz = ga * ws.gprime[8][e];
+        ws.dz[8][e] = dz;
+        s_dz[q] = dz;
+        s_xh[q] = ws.xhat[8][e];
+    }
+    __syncthreads();
+    for (uint32_t pair = t >> 6; pair < g.npair; pair += 4) {   // one wave per pair
+        const uint32_t lane = t & 63, q = 64 * pair + lane;
+        const float dz = q < g.P ? s_dz[q] : 0.0f, xh = q < g.P ? s_xh[q] : 0.0f;
+        const float s1 = wave_sum64(dz), s2 = wave_sum64(dz * xh);
+        if (lane == 0) {
+            ws.bsum[8][((size_t)im * g.npair + pair) * 2] = s1;
+            ws.bsum[8][((size_t)im * g.npair + pair) * 2 + 1] = s2;
+        }
+    }
+}
+
+// grid (npair, B), 256 threads: layer 8 backward.  dx_8 (one channel) in LDS; wave = 16 pixels, lane = channel of layer 7:
+//   G_7[q][ci] = sum_tap W8[ci][tap] dx_8[q - (tap - 1)]  ->  dz_7 = G_7 * GELU'(z_7) and its pair sums,
+//   dW8[ci][tap] partial = sum_q dx_8[q] a_7[q + (tap - 1)][ci].
+__global__ void __launch_bounds__(256) k_dec_l8_bwd(DecParams prm, DecWs ws, DecGeom g) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ float scratch[4];
+    const uint32_t pair = blockIdx.x, im = blockIdx.y, t = threadIdx.x, W2 = g.W + 2;
+    const PairRows pr = pair_rows(pair, g.P, g.W);
+    const uint32_t npos = pr.nrow * W2, n = g.B * g.npair;
+    float *s_dx = reinterpret_cast<float *>(smem_raw);   // [rows_max*W2]
+    float *s_red = s_dx + g.rows_max * W2;                // [4][64][11]
+    const float N = (float)(g.B * g.P);
+    const int wave = t >> 6, lane = t & 63;
+    float w8[9], dw[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        w8[tap] = prm.w[8][lane * 9 + tap];
+        dw[tap] = 0.0f;
+    }
+    float s1 = 0.0f, s2 = 0.0f;
+    for (uint32_t i = t; i < n; i += 256) {
+        s1 += ws.bsum[8][(size_t)i * 2];
+        s2 += ws.bsum[8][(size_t)i * 2 + 1];
+    }
+    const float S1 = block_sum256(s1, scratch), S2 = block_sum256(s2, scratch);
+    const float k8 = prm.gamma[8][0] * ws.minv[8][1] / N;
+    for (uint32_t pos = t; pos < npos; pos += 256) {
+        const int q = staged_pixel(pos, W2, pr.py0, g);
+        float v = 0.0f;
+        if (q >= 0) {
+            const size_t e = (size_t)im * g.P + q;
+            v = k8 * (N * ws.dz[8][e] - S1 - ws.xhat[8][e] * S2);
+        }
+        s_dx[pos] = v;
+    }
+    __syncthreads();
+    float b1 = 0.0f, b2 = 0.0f;
+    for (int j0 = 0; j0 < 16; j0 += 4) {
+        // four pixels' operands in flight together
+        float gp[4], xh[4], an[4][9];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t q = pr.q0 + 16 * wave + j0 + u;
+            const bool ok = q < g.P;
+            const uint32_t qq = ok ? q : pr.q0, py = qq / g.W, px = qq - py * g.W;
+            const size_t e = ((size_t)im * g.P + qq) * kC + lane;
+            gp[u] = ok ? ws.gprime[7][e] : 0.0f;
+            xh[u] = ok ? ws.xhat[7][e] : 0.0f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ny = (int)py + tap / 3 - 1, nx = (int)px + tap % 3 - 1;
+                an[u][tap] = (ok && ny >= 0 && ny < (int)g.H && nx >= 0 && nx < (int)g.W) ? ws.act[7][((size_t)im * g.P + ny * g.W + nx) * kC + lane] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t q = pr.q0 + 16 * wave + j0 + u;
+            if (q >= g.P) break;
+            const uint32_t py = q / g.W, px = q - py * g.W, hp = (py - pr.py0 + 1) * W2 + px + 1;   // the pixel itself, staged coordinates
+            float G = 0.0f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) G += w8[tap] * s_dx[hp + (1 - tap / 3) * (int)W2 + (1 - tap % 3)];
+            const float dz = G * gp[u];
+            ws.dz[7][((size_t)im * g.P + q) * kC + lane] = dz;
+            b1 += dz;
+            b2 += dz * xh[u];
+            const float dxq = s_dx[hp];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) dw[tap] += dxq * an[u][tap];
+        }
+    }
+    float *r = s_red + (wave * 64 + lane) * 11;
+    r[0] = b1;
+    r[1] = b2;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) r[2 + tap] = dw[tap];
+    __syncthreads();
+    if (wave == 0) {
+        float *po = ws.bsum[7] + (((size_t)im * g.npair + pair) * kC + lane) * 2;
+        po[0] = s_red[lane * 11] + s_red[(64 + lane) * 11] + s_red[(128 + lane) * 11] + s_red[(192 + lane) * 11];
+        po[1] = s_red[lane * 11 + 1] + s_red[(64 + lane) * 11 + 1] + s_red[(128 + lane) * 11 + 1] + s_red[(192 + lane) * 11 + 1];
+    }
+    if (wave == 1) {
+        float *po = ws.wpart8 + (((size_t)im * g.npair + pair) * kC + lane) * 9;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            float s = 0.0f;
+            for (int w = 0; w < 4; ++w) s += s_red[(w * 64 + lane) * 11 + 2 + tap];
+            po[tap] = s;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- weight gradients of the 64 -> 64 layers
+
+// One launch for all seven layers, after the dgrad chain (dz_l, the batch sums and a_{l-1} are all in the workspace by then):
+// grid (nband, B, 7), 256 threads = 4 waves = the 4 (rb, cb) 32x32 blocks of dW[co][ci], each for all 9 taps.
+// K runs over halo-linear pixel positions r = hr*RS + hc (RS a multiple of 8, so a tap's row shift keeps 16-byte alignment);
+// dx^T [co][r] and a^T [ci][r] live in LDS as bf16 hi/lo planes.  The +-1 column shift of a tap is applied in registers:
+// an aligned 8-element group plus one dword from each neighbour, funnel-shifted by one element (v_alignbyte).
+__device__ inline bf16x8 shift_window(uint4 gq, uint32_t prev, uint32_t next, int tx) {
+    uint4 o = gq;
+    if (tx == 0) {
+        o.x = __builtin_amdgcn_alignbyte(gq.x, prev, 2);
+        o.y = __builtin_amdgcn_alignbyte(gq.y, gq.x, 2);
+        o.z = __builtin_amdgcn_alignbyte(gq.z, gq.y, 2);
+        o.w = __builtin_amdgcn_alignbyte(gq.w, gq.z, 2);
+    } else if (tx == 2) {
+        o.x = __builtin_amdgcn_alignbyte(gq.y, gq.x, 2);
+        o.y = __builtin_amdgcn_alignbyte(gq.z, gq.y, 2);
+        o.z = __builtin_amdgcn_alignbyte(gq.w, gq.z, 2);
+        o.w = __builtin_amdgcn_alignbyte(next, gq.w, 2);
+    }
+    return *reinterpret_cast<bf16x8 *>(&o);
+}
+
+__device__ inline void put_transposed(char *hi, char *lo, uint32_t pitch, uint32_t cg, uint32_t k, float4 v) {
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        __bf16 vh, vl;
+        split_bf16(vv[j], vh, vl);
+        *reinterpret_cast<__bf16 *>(hi + (cg * 4 + j) * pitch + k * 2) = vh;
+        *reinterpret_cast<__bf16 *>(lo + (cg * 4 + j) * pitch + k * 2) = vl;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_dec_wgrad(DecParams prm, DecWs ws, DecGeom g) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const uint32_t band = blockIdx.x, im = blockIdx.y, layer = 1 + blockIdx.z, t = threadIdx.x;
+    const uint32_t Kpad = g.nks * 16, La = Kpad + 2 * g.RS + 16;
+    char *dx_hi = smem_raw, *dx_lo = dx_hi + 64 * g.pd, *a_hi = dx_lo + 64 * g.pd, *a_lo = a_hi + 64 * g.pa;
+    float *s_tab = reinterpret_cast<float *>(a_lo + 64 * g.pa);   // [3][64]
+    float *s_red = s_tab + 3 * 64;                                 // [512]
+    const float N = (float)(g.B * g.P);
+    const uint32_t row_lo = band * g.R, row_hi = min(g.H, row_lo + g.R);   // image rows of this band
+    const int RS = (int)g.RS, rbase = (int)((row_lo + 1) * g.RS), abase = rbase - RS - 8;
+
+    // a^T does not depend on the batch sums: request it first
+    for (uint32_t base = t; base < La * 16; base += 256 * kBatch) {
+        float4 v[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const uint32_t i = base + 256 * u;
+            const int r = abase + (int)(i >> 4), hr = r / RS, hc = r - hr * RS, iy = hr - 1, ix = hc - 1;
+            const bool ok = i < La * 16 && r >= 0 && iy >= 0 && iy < (int)g.H && ix >= 0 && ix < (int)g.W;
+            v[u] = ok ? *reinterpret_cast<const float4 *>(ws.act[layer - 1] + ((size_t)im * g.P + iy * g.W + ix) * kC + (i & 15) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const uint32_t i = base + 256 * u;
+            if (i < La * 16) put_transposed(a_hi, a_lo, g.pa, i & 15, i >> 4, v[u]);
+        }
+    }
+    combine_bwd_sums(ws.bsum[layer], prm.gamma[layer], ws.minv[layer], g, s_red, s_tab);
+    for (uint32_t base = t; base < Kpad * 16; base += 256 * kBatch) {
+        float4 dv[kBatch], hv[kBatch];
+        bool ok[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const uint32_t i = base + 256 * u;
+            const int r = rbase + (int)(i >> 4), hr = r / RS, hc = r - hr * RS, iy = hr - 1, ix = hc - 1;
+            ok[u] = i < Kpad * 16 && iy >= (int)row_lo && iy < (int)row_hi && ix >= 0 && ix < (int)g.W;
+            const size_t e = ((size_t)im * g.P + (ok[u] ? iy * g.W + ix : 0)) * kC + (i & 15) * 4;
+            dv[u] = ok[u] ? *reinterpret_cast<const float4 *>(ws.dz[layer] + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+            hv[u] = ok[u] ? *reinterpret_cast<const float4 *>(ws.xhat[layer] + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const uint32_t i = base + 256 * u;
+            if (i < Kpad * 16) put_transposed(dx_hi, dx_lo, g.pd, i & 15, i >> 4, ok[u] ? bn_bwd4(dv[u], hv[u], i & 15, s_tab, N) : make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+    }
+    __syncthreads();
+
+    const int wave = t >> 6, lane = t & 63, rb = wave & 1, cb = wave >> 1, l31 = lane & 31, h = lane >> 5;
+    f32x16 acc[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tap][r] = 0.0f;
+    const char *pa_hi = a_hi + (32 * cb + l31) * g.pa, *pa_lo = a_lo + (32 * cb + l31) * g.pa;
+    const char *pd_hi = dx_hi + (32 * rb + l31) * g.pd, *pd_lo = dx_lo + (32 * rb + l31) * g.pd;
+    for (uint32_t ks = 0; ks < g.nks; ++ks) {
+        const uint32_t k0 = 16 * ks + 8 * h;
+        const bf16x8 dh = *reinterpret_cast<const bf16x8 *>(pd_hi + k0 * 2), dl = *reinterpret_cast<const bf16x8 *>(pd_lo + k0 * 2);
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+            const uint32_t j0 = (k0 + 8 + ty * g.RS) * 2;   // byte offset of the aligned group for column shift 0
+            const uint4 gh = *reinterpret_cast<const uint4 *>(pa_hi + j0), gl = *reinterpret_cast<const uint4 *>(pa_lo + j0);
+            const uint32_t ph = *reinterpret_cast<const uint32_t *>(pa_hi + j0 - 4), pl = *reinterpret_cast<const uint32_t *>(pa_lo + j0 - 4);
+            const uint32_t nh = *reinterpret_cast<const uint32_t *>(pa_hi + j0 + 16), nl = *reinterpret_cast<const uint32_t *>(pa_lo + j0 + 16);
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+                const bf16x8 bh = shift_window(gh, ph, nh, tx), bl = shift_window(gl, pl, nl, tx);
+                f32x16 c = acc[ty * 3 + tx];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dl, bh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, bl, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, bh, c, 0, 0, 0);
+                acc[ty * 3 + tx] = c;
+            }
+        }
+    }
+    // lane (col = ci, h) holds rows co = 32*rb + 8*(r>>2) + 4*h + (r&3)
+    float *po = ws.wpart + ((size_t)(layer - 1) * g.B * g.nband + (size_t)im * g.nband + band) * 9 * kC * kC;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) po[((size_t)tap * kC + 32 * rb + 8 * (r >> 2) + 4 * h + (r & 3)) * kC + 32 * cb + l31] = acc[tap][r];
+}
+
+// ----------------------------------------------------------------------------- layer 0 weight gradient (VALU)
+
+// grid (npair, B), 256 threads: thread = (co, quarter); dW0[co][c][tap] partial over the pair's pixels.
+__global__ void __launch_bounds__(256) k_dec_l0_wgrad(const float *__restrict__ img, DecParams prm, DecWs ws, DecGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const uint32_t pair = blockIdx.x, im = blockIdx.y, t = threadIdx.x;
+    const uint32_t W2 = g.W + 2, HW2 = (g.H + 2) * W2;
+    float *s_img = smem;                      // [Cin][HW2]
+    float *s_tab = s_img + g.Cin * HW2;       // [3][64]
+    float *s_red = s_tab + 3 * 64;            // [max(512, 4*64*9)]
+    const uint32_t co = t & 63, sub = t >> 6, q0 = pair * 64 + sub * 16;
+    float dzv[16], xhv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t q = q0 + j;
+        const size_t e = ((size_t)im * g.P + (q < g.P ? q : 0)) * kC + co;
+        dzv[j] = q < g.P ? ws.dz[0][e] : 0.0f;
+        xhv[j] = q < g.P ? ws.xhat[0][e] : 0.0f;
+    }
+    for (uint32_t i = t; i < g.Cin * HW2; i += 256) {
+        const uint32_t c = i / HW2, pos = i - c * HW2, hr = pos / W2, hc = pos - hr * W2;
+        const bool in = hr >= 1 && hr <= g.H && hc >= 1 && hc <= g.W;
+        s_img[i] = in ? img[((size_t)im * g.Cin + c) * g.P + (hr - 1) * g.W + (hc - 1)] : 0.0f;
+    }
+    combine_bwd_sums(ws.bsum[0], prm.gamma[0], ws.minv[0], g, s_red, s_tab);
+    const float N = (float)(g.B * g.P);
+    float dx[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dx[j] = q0 + j < g.P ? s_tab[co] * (N * dzv[j] - s_tab[64 + co] - xhv[j] * s_tab[128 + co]) : 0.0f;
+    for (uint32_t c = 0; c < g.Cin; ++c) {
+        float acc[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) acc[tap] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t q = q0 + j;
+            if (q < g.P) {
+                const uint32_t py = q / g.W, px = q - py * g.W;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) acc[tap] += dx[j] * s_img[c * HW2 + (py + tap / 3) * W2 + px + tap % 3];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) s_red[(sub * 64 + co) * 9 + tap] = acc[tap];
+        __syncthreads();
+        if (sub == 0) {
+            float *po = ws.wpart0 + (((size_t)im * g.npair + pair) * kC + co) * 9 * g.Cin + c * 9;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+                po[tap] = s_red[co * 9 + tap] + s_red[(64 + co) * 9 + tap] + s_red[(128 + co) * 9 + tap] + s_red[(192 + co) * 9 + tap];
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- final reductions
+
+// grid (64 co, 7 layers), 576 threads = (tap, ci): dW[co][ci][tap] = sum over the (image, band) partials.
+__global__ void __launch_bounds__(576) k_dec_wreduce(DecWs ws, DecGrads gr, DecGeom g) {
+    const uint32_t co = blockIdx.x, layer = 1 + blockIdx.y, tap = threadIdx.x >> 6, ci = threadIdx.x & 63;
+    const uint32_t nwg = g.B * g.nband;
+    const float *p = ws.wpart + (size_t)(layer - 1) * nwg * 9 * kC * kC + ((size_t)tap * kC + co) * kC + ci;
+    float acc = 0.0f;
+    for (uint32_t w0 = 0; w0 < nwg; w0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = w0 + u < nwg ? p[(size_t)(w0 + u) * 9 * kC * kC] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    gr.w[layer][((size_t)co * kC + ci) * 9 + tap] = acc;
+}
+
+// Sum of `n` partial vectors (stride `stride` floats) for 64 consecutive outputs starting at `e0`; 256 threads = (output, 4 groups).
+__device__ inline float reduce64(const float *__restrict__ part, uint32_t n, size_t stride, uint32_t e0, uint32_t e_end, float *red) {
+    const uint32_t o = threadIdx.x & 63, grp = threadIdx.x >> 6, e = e0 + o;
+    float s = 0.0f;
+    if (e < e_end)
+        for (uint32_t base = grp; base < n; base += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = base + 4 * u < n ? part[(size_t)(base + 4 * u) * stride + e] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+    __syncthreads();
+    red[grp * 64 + o] = s;
+    __syncthreads();
+    return red[o] + red[64 + o] + red[128 + o] + red[192 + o];
+}
+
+// grid (16 + ceil(64*9*Cin/64) + 9 + 1), 256 threads.
+//   blocks [0,16): layer l = b/2 < 8, which = b&1: dbeta_l (sum dz) / dgamma_l (sum dz*xhat)
+//   then dW0 in chunks of 64 outputs, dW8 in 9 chunks, then one block for layer 8's BN and the Linear.
+__global__ void __launch_bounds__(256) k_dec_sreduce(const float *__restrict__ grad_dec, DecWs ws, DecGrads gr, DecGeom g) {
+    __shared__ float red[256];
+    __shared__ float scratch[4];
+    const uint32_t b = blockIdx.x, t = threadIdx.x, n = g.B * g.npair, K0 = kC * 9 * g.Cin, nb0 = ceil_div(K0, 64);
+    if (b < 16) {
+        const uint32_t l = b >> 1, which = b & 1;
+        // partials are [i][c][2]: view as 128 interleaved outputs, take every other one
+        const uint32_t o = t & 63, grp = t >> 6;
+        float s = 0.0f;
+        for (uint32_t base = grp; base < n; base += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = base + 4 * u < n ? ws.bsum[l][((size_t)(base + 4 * u) * kC + o) * 2 + which] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        red[grp * 64 + o] = s;
+        __syncthreads();
+        if (grp == 0) (which ? gr.gamma[l] : gr.beta[l])[o] = red[o] + red[64 + o] + red[128 + o] + red[192 + o];
+    } else if (b < 16 + nb0) {
+        const uint32_t e0 = (b - 16) * 64;
+        const float s = reduce64(ws.wpart0, n, K0, e0, K0, red);
+        if (t < 64 && e0 + t < K0) gr.w[0][e0 + t] = s;
+    } else if (b < 16 + nb0 + 9) {
+        const uint32_t e0 = (b - 16 - nb0) * 64;
+        const float s = reduce64(ws.wpart8, n, kC * 9, e0, kC * 9, red);
+        if (t < 64) gr.w[8][e0 + t] = s;
+    } else {
+        float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, s4 = 0.0f;
+        for (uint32_t i = t; i < n; i += 256) {
+            s1 += ws.bsum[8][(size_t)i * 2];
+            s2 += ws.bsum[8][(size_t)i * 2 + 1];
+        }
+        for (uint32_t i = t; i < g.B; i += 256) {
+            s3 += grad_dec[i] * ws.pool[i];
+            s4 += grad_dec[i];
+        }
+        s1 = block_sum256(s1, scratch);
+        s2 = block_sum256(s2, scratch);
+        s3 = block_sum256(s3, scratch);
+        s4 = block_sum256(s4, scratch);
+        if (t == 0) {
+            gr.beta[8][0] = s1;
+            gr.gamma[8][0] = s2;
+            gr.lin_w[0] = s3;
+            gr.lin_b[0] = s4;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- host side
+
+static inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+constexpr size_t kLdsLimit = 160 * 1024;
+
+static size_t conv_lds(const DecGeom &g) { return (size_t)2 * g.rows_max * (g.W + 2) * kPitch + (4 * 64 + 768) * 4; }
+static size_t l8_lds(const DecGeom &g) { return (size_t)g.rows_max * (g.W + 2) * kC * 4 + (4 * 64 + 768) * 4; }
+static size_t l8b_lds(const DecGeom &g) { return (size_t)g.rows_max * (g.W + 2) * 4 + 4 * 64 * 11 * 4; }
+static size_t l0_lds(const DecGeom &g) { return ((size_t)g.Cin * (g.H + 2) * (g.W + 2) + (size_t)kC * 9 * g.Cin + 4 * 64) * 4; }
+static size_t l0w_lds(const DecGeom &g) { return ((size_t)g.Cin * (g.H + 2) * (g.W + 2) + 3 * 64 + 4 * 64 * 9) * 4; }
+static size_t wgrad_lds(const DecGeom &g) { return (size_t)128 * (g.pd + g.pa) + (3 * 64 + 512) * 4; }
+
+static bool make_geom(uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, float eps, DecGeom &g) {
+    g.B = B; g.H = H; g.W = W; g.P = H * W; g.Cin = Cin; g.eps = eps;
+    g.ntile = ceil_div(g.P, 32);
+    g.npair = ceil_div(g.ntile, 2);
+    g.rows_max = 0;
+    for (uint32_t p = 0; p < g.npair; ++p) g.rows_max = std::max(g.rows_max, pair_rows(p, g.P, W).nrow);
+    g.RS = round_up(W + 2, 8);
+    // wgrad row bands: as few as LDS allows (every band writes a 147 KB partial of dW)
+    for (g.nband = 1;; ++g.nband) {
+        g.R = ceil_div(H, g.nband);
+        g.nks = ceil_div(g.R * g.RS, 16);
+        const uint32_t Kpad = g.nks * 16, La = Kpad + 2 * g.RS + 16;
+        g.pd = round_up(Kpad * 2, 32) + 16;
+        g.pa = round_up(La * 2, 32) + 16;
+        if (wgrad_lds(g) <= kLdsLimit - 1024) break;
+        if (g.nband >= H) return false;
+    }
+    g.nband = ceil_div(H, g.R);   // no empty bands
+    return conv_lds(g) <= kLdsLimit && l8_lds(g) <= kLdsLimit && l0_lds(g) <= 64 * 1024 && l0w_lds(g) <= 64 * 1024;
+}
+
+struct Carver {
+    char *base;
+    size_t off = 0;
+    template <typename T>
+    T *take(size_t count) {
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += (count * sizeof(T) + 255) / 256 * 256;
+        return p;
+    }
+};
+
+static size_t carve(void *base, const DecGeom &g, DecWs &ws) {
+    Carver c{reinterpret_cast<char *>(base)};
+    const size_t BP = (size_t)g.B * g.P, np = (size_t)g.B * g.npair;
+    for (int l = 0; l < kLayers; ++l) {
+        const size_t C = l < 8 ? kC : 1;
+        ws.x[l] = c.take<float>(BP * C);
+        ws.xhat[l] = c.take<float>(BP * C);
+        ws.gprime[l] = c.take<float>(BP * C);
+        ws.dz[l] = c.take<float>(BP * C);
+        if (l < 8) ws.act[l] = c.take<float>(BP * C);
+        ws.stat[l] = c.take<float>(np * C * 2);
+        ws.bsum[l] = c.take<float>(np * C * 2);
+        ws.minv[l] = c.take<float>(2 * C);
+    }
+    ws.pool = c.take<float>(g.B);
+    ws.wpart = c.take<float>((size_t)7 * g.B * g.nband * 9 * kC * kC);
+    ws.wpart0 = c.take<float>((size_t)g.B * g.npair * kC * 9 * g.Cin);
+    ws.wpart8 = c.take<float>((size_t)g.B * g.npair * kC * 9);
+    ws.packed = c.take<uint4>(kSets * kSetU4);
+    return c.off;
+}
+
+static int load_params(const float *const *params, DecParams &p) {
+    for (int l = 0; l < kLayers; ++l) {
+        p.w[l] = params[3 * l];
+        p.gamma[l] = params[3 * l + 1];
+        p.beta[l] = params[3 * l + 2];
+        if (!p.w[l] || !p.gamma[l] || !p.beta[l]) return 1;
+    }
+    p.lin_w = params[27];
+    p.lin_b = params[28];
+    return !(p.lin_w && p.lin_b);
+}
+
+// Dynamic LDS above 64 KB has to be allowed per kernel; remembered per kernel so the attribute call happens once per size.
+template <typename K>
+static int allow_lds(K kernel, size_t bytes, size_t &allowed) {
+    if (bytes <= allowed) return 0;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return 1;
+    allowed = bytes;
+    return 0;
+}
+static int allow_all_lds(const DecGeom &g) {
+    static size_t a[6] = {0, 0, 0, 0, 0, 0};
+    return allow_lds(k_dec_conv<kFwd>, conv_lds(g), a[0]) | allow_lds(k_dec_conv<kDgrad>, conv_lds(g), a[1]) |
+           allow_lds(k_dec_conv<kDgradImg>, conv_lds(g), a[2]) | allow_lds(k_dec_l8_fwd, l8_lds(g), a[3]) |
+           allow_lds(k_dec_l8_bwd, l8b_lds(g), a[4]) | allow_lds(k_dec_wgrad, wgrad_lds(g), a[5]);
+}
+
+}  // namespace nsig
+
+using namespace nsig;
+
+NSIG_EXPORT size_t dec_workspace_bytes(uint32_t B, uint32_t Cin, uint32_t H, uint32_t W) {
+    DecGeom g;
+    DecWs ws;
+    if (B == 0 || Cin == 0 || Cin > kMaxCin || H == 0 || W == 0 || (uint64_t)H * W > kMaxP || (uint64_t)B * H * W < 2 || !make_geom(B, Cin, H, W, 0.0f, g)) return 0;
+    return carve(nullptr, g, ws);
+}
+
+NSIG_EXPORT int dec_forward(const float *img, const float *const *params, uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, float eps,
+                            void *workspace, float *decoded, nsig_stream_t stream) {
+    NSIG_REQUIRE(img && params && workspace && decoded, "dec_forward: null pointer");
+    DecGeom g;
+    NSIG_REQUIRE(B >= 1 && Cin >= 1 && Cin <= kMaxCin && H >= 1 && W >= 1 && (uint64_t)H * W <= kMaxP && (uint64_t)B * H * W > 1 &&
+                     make_geom(B, Cin, H, W, eps, g),
+                 "dec_forward: unsupported image shape %ux%ux%ux%u (see dec_workspace_bytes)", B, Cin, H, W);
+    DecParams prm;
+    NSIG_REQUIRE(load_params(params, prm) == 0, "dec_forward: params must hold 29 device pointers");
+    NSIG_REQUIRE(allow_all_lds(g) == 0, "dec_forward: could not raise the dynamic LDS limit");
+    DecWs ws;
+    carve(workspace, g, ws);
+    hipStream_t s = as_stream(stream);
+    const dim3 grid(g.npair, B);
+    k_dec_pack<<<kSets * 2 * kKS, 64, 0, s>>>(prm, ws.packed, Cin);
+    k_dec_l0_fwd<<<grid, 256, l0_lds(g), s>>>(img, prm, ws, g);
+    for (int l = 1; l <= 7; ++l) k_dec_conv<kFwd><<<grid, 256, conv_lds(g), s>>>(l, prm, ws, g, nullptr);
+    k_dec_l8_fwd<<<grid, 256, l8_lds(g), s>>>(prm, ws, g);
+    k_dec_head_fwd<<<B, 256, 0, s>>>(prm, ws, g, decoded);
+    return check_launch("dec_forward");
+}
+
+NSIG_EXPORT int dec_backward(const float *grad_decoded, const float *img, const float *const *params, uint32_t B, uint32_t Cin, uint32_t H,
+                             uint32_t W, void *workspace, float *const *grads, float *grad_img, nsig_stream_t stream) {
+    NSIG_REQUIRE(grad_decoded && img && params && workspace && grads && grad_img, "dec_backward: null pointer");
+    DecGeom g;
+    NSIG_REQUIRE(B >= 1 && Cin >= 1 && Cin <= kMaxCin && H >= 1 && W >= 1 && (uint64_t)H * W <= kMaxP && make_geom(B, Cin, H, W, 0.0f, g),
+                 "dec_backward: unsupported image shape");
+    DecParams prm;
+    NSIG_REQUIRE(load_params(params, prm) == 0, "dec_backward: params must hold 29 device pointers");
+    DecGrads gr;
+    for (int l = 0; l < kLayers; ++l) {
+        gr.w[l] = grads[3 * l];
+        gr.gamma[l] = grads[3 * l + 1];
+        gr.beta[l] = grads[3 * l + 2];
+        NSIG_REQUIRE(gr.w[l] && gr.gamma[l] && gr.beta[l], "dec_backward: grads must hold 29 device pointers");
+    }
+    gr.lin_w = grads[27];
+    gr.lin_b = grads[28];
+    NSIG_REQUIRE(gr.lin_w && gr.lin_b, "dec_backward: grads must hold 29 device pointers");
+    NSIG_REQUIRE(allow_all_lds(g) == 0, "dec_backward: could not raise the dynamic LDS limit");
+    DecWs ws;
+    carve(workspace, g, ws);
+    hipStream_t s = as_stream(stream);
+    const dim3 grid(g.npair, B);
+    k_dec_head_bwd<<<B, 256, 0, s>>>(grad_decoded, prm, ws, g);
+    k_dec_l8_bwd<<<grid, 256, l8b_lds(g), s>>>(prm, ws, g);
+    for (int l = 7; l >= 1; --l) k_dec_conv<kDgrad><<<grid, 256, conv_lds(g), s>>>(l, prm, ws, g, nullptr);
+    k_dec_conv<kDgradImg><<<grid, 256, conv_lds(g), s>>>(0, prm, ws, g, grad_img);
+    k_dec_wgrad<<<dim3(g.nband, B, 7), 256, wgrad_lds(g), s>>>(prm, ws, g);
+    k_dec_l0_wgrad<<<grid, 256, l0w_lds(g), s>>>(img, prm, ws, g);
+    k_dec_wreduce<<<dim3(kC, 7), 576, 0, s>>>(ws, gr, g);
+    k_dec_sreduce<<<16 + ceil_div(kC * 9 * Cin, 64) + 9 + 1, 256, 0, s>>>(grad_decoded, ws, gr, g);
+    return check_launch("dec_backward");
+}

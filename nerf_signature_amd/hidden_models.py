@@ -1,10 +1,14 @@
 """HiDDeN-style watermark decoder (mirror of /root/reference/nerf/hidden_models.py:13-35,104-137,181-183).
 
-The convolutions stay on MIOpen; on the GPU the BatchNorm(batch statistics)+GELU pair of every
-block is one libnerfsig kernel each way (dec_bn_gelu_fwd/_bwd) instead of torch's 5 + 6 launch-bound kernels, and the
-convolution's bias -- which BatchNorm's mean subtraction cancels exactly -- is not added (its gradient is identically zero).
+On the GPU the decoder of the watermark path (9 ConvBNRelu blocks, 64 channels, one output bit) runs as libnerfsig's fused
+chain (dec_forward/dec_backward: one kernel per layer each way, csrc/decoder_fused.hip) instead of ~120 launch-bound
+stock operators per step.  Other shapes fall back to MIOpen convolutions with the BatchNorm(batch statistics)+GELU pair
+fused (dec_bn_gelu_fwd/_bwd).  Either way a convolution's bias -- which BatchNorm's mean subtraction cancels exactly -- is
+not added, and its gradient (identically zero) is reported as None.  NERFSIG_DECODER=torch forces the stock operator chain.
 Module/parameter names reproduce the reference's state_dict keys
 (`layers.{0..8}.layers.{0,1}.{weight,bias}`, `linear.{weight,bias}`)."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -69,6 +73,32 @@ class _BNGelu(torch.autograd.Function):
         return dx, dgamma, dbeta, None
 
 
+class _FusedDecoder(torch.autograd.Function):
+    """decoded = Linear(AvgPool(ConvBNRelu^9(img))) through dec_forward / dec_backward.  params: for each of the 9 blocks
+    (conv weight, bn weight, bn bias), then the linear weight and bias."""
+
+    @staticmethod
+    def forward(ctx, img, eps, *params):
+        B, Cin, H, W = img.shape
+        img = img.contiguous()
+        ps = [p.detach().contiguous() for p in params]
+        ws = torch.empty(nv.fn("dec_workspace_bytes")(B, Cin, H, W), dtype=torch.uint8, device=img.device)
+        out = torch.empty(B, dtype=torch.float32, device=img.device)
+        nv.call("dec_forward", nv.ptr(img), nv.ptr_array(ps), B, Cin, H, W, eps, nv.ptr(ws), nv.ptr(out), nv.stream())
+        ctx.save_for_backward(img, ws, *ps)
+        return out.view(B, 1)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        img, ws, *ps = ctx.saved_tensors
+        B, Cin, H, W = img.shape
+        grads = [torch.empty_like(p) for p in ps]
+        grad_img = torch.empty_like(img)
+        nv.call("dec_backward", nv.ptr(grad_out.contiguous().view(-1)), nv.ptr(img), nv.ptr_array(ps), B, Cin, H, W, nv.ptr(ws),
+                nv.ptr_array(grads), nv.ptr(grad_img), nv.stream())
+        return (grad_img, None, *grads)
+
+
 class ConvBNRelu(nn.Module):
     """3x3 convolution, BatchNorm that always uses batch statistics (track_running_stats=False), GELU."""
 
@@ -101,7 +131,28 @@ class HiddenDecoder_multi_views(nn.Module):
         self.num_bits = num_bits
         self.redundancy = redundancy
 
+    def _fused_params(self, x):
+        """The 29 parameters dec_forward takes, or None when this decoder / input is not the shape the fused chain implements."""
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4) or os.environ.get("NERFSIG_DECODER", "") == "torch":
+            return None
+        blocks = list(self.layers)[:-1]
+        if len(blocks) != 9 or self.num_bits * self.redundancy != 1:
+            return None
+        convs, bns = [b.layers[0] for b in blocks], [b.layers[1] for b in blocks]
+        want = [(x.shape[1], 64)] + [(64, 64)] * 7 + [(64, 1)]
+        if [(c.in_channels, c.out_channels) for c in convs] != want or len({bn.eps for bn in bns}) != 1:
+            return None
+        if any(p.dtype != torch.float32 for p in self.parameters()) or not nv.fn("dec_workspace_bytes")(*x.shape):
+            return None
+        params = []
+        for c, bn in zip(convs, bns):
+            params += [c.weight, bn.weight, bn.bias]
+        return bns[0].eps, params + [self.linear.weight, self.linear.bias]
+
     def forward(self, img_w):
+        fused = self._fused_params(img_w)
+        if fused is not None:
+            return _FusedDecoder.apply(img_w, fused[0], *fused[1])   # num_bits = redundancy = 1: the view/sum below is the identity
         x = self.layers(img_w).squeeze(-1).squeeze(-1)
         x = self.linear(x)
         x = x.view(-1, self.num_bits, self.redundancy)

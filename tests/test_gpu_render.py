@@ -375,3 +375,35 @@ def test_fused_batchnorm_gelu_matches_torch(shape):
         ga, gb = torch.autograd.grad(out1, p, dy), torch.autograd.grad(out0, p, dy)
         for a, b in zip(ga, gb):
             assert float((a - b).norm() / b.norm()) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(32, 3, 12, 12), (48, 3, 11, 15), (5, 3, 7, 5), (2, 6, 16, 16), (4, 3, 3, 37), (3, 3, 1, 40), (16, 3, 5, 5)])
+def test_fused_decoder_matches_stock_operators(shape, monkeypatch):
+    """dec_forward/dec_backward == the stock PyTorch chain of hidden_models.py:104-137 (Conv2d, BatchNorm2d with batch
+    statistics, GELU, AdaptiveAvgPool2d, Linear): decoded bits, the gradient of the image and of every parameter."""
+    from nerf_signature_amd.hidden_models import get_hidden_decoder_multi_views
+    torch.manual_seed(11)
+    B, Cin, H, W = shape
+    dec = get_hidden_decoder_multi_views(num_bits=1, redundancy=1, num_blocks=8, input_ch=Cin, channels=64).cuda()
+    with torch.no_grad():
+        for p in dec.parameters():               # away from the default init: BN weights != 1, biases != 0
+            p.add_(0.1 * torch.randn_like(p))
+    img = torch.randn(B, Cin, H, W, device="cuda", requires_grad=True)
+    gout = torch.randn(B, 1, device="cuda")
+    assert dec._fused_params(img) is not None
+    out1 = dec(img)
+    g1 = torch.autograd.grad(out1, [img] + [p for p in dec.parameters()], gout, allow_unused=True)
+    monkeypatch.setenv("NERFSIG_DECODER", "torch")
+    dec64 = dec.double()
+    img64 = img.detach().double().requires_grad_(True)
+    out0 = dec64.layers(img64).squeeze(-1).squeeze(-1)
+    out0 = dec64.linear(out0)
+    g0 = torch.autograd.grad(out0, [img64] + [p for p in dec64.parameters()], gout.double())
+    np.testing.assert_allclose(out1.detach().cpu().numpy(), out0.detach().cpu().numpy(), rtol=0, atol=1e-3)
+    names = ["img"] + [n for n, _ in dec64.named_parameters()]
+    for n, a, b in zip(names, g1, g0):
+        if a is None:                             # conv bias in front of a BatchNorm: identically zero
+            assert n.endswith("layers.0.bias") and float(b.abs().max()) < 1e-9 * max(1.0, float(gout.abs().max()))
+            continue
+        rel = float((a.double() - b).norm() / (b.norm() + 1e-30))
+        assert rel < 2e-3, (n, rel)
