@@ -73,10 +73,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise NativeError(f"{LIB_PATH} not found: the HIP extension is required (no fallback). "
+    path = os.environ.get("NERFSIG_LIB", LIB_PATH)   # override: instrumented builds of the same sources (tools/dec_timing.py)
+    if not os.path.exists(path):
+        raise NativeError(f"{path} not found: the HIP extension is required (no fallback). "
                           f"Build it with `python -m nerf_signature_amd.build`.")
-    _lib = ctypes.CDLL(LIB_PATH)
+    _lib = ctypes.CDLL(path)
     _lib.nsig_last_error.restype = _c.c_char_p
     return _lib
 

@@ -45,6 +45,7 @@ struct DecGeom {
     uint32_t B, H, W, P, Cin, ntile, npair, rows_max;   // rows_max: most halo rows any tile pair stages
     uint32_t RS, nband, R;                               // wgrad: halo row stride (multiple of 8), row bands, rows per band
     uint32_t pd, pa, nks;                                // wgrad: LDS row pitches in bytes (dx, a), k-steps per band
+    uint32_t magic_w2;                                   // (pos * magic_w2) >> 16 == pos / (W + 2) for every staged position
     float eps;
 };
 
@@ -77,11 +78,16 @@ __device__ inline void chan_merge(float &cnt, float &mean, float &M2, float n_b,
     cnt = tot;
 }
 
+// GELU (erf form) and its derivative from one exponential: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. at the
+// fp32 rounding level of Phi), sharing exp(-z^2/2) with the Gaussian density.  ~25 VALU operations instead of ~90 for erff + expf.
 __device__ inline void gelu_parts(float z, float &a, float &gp) {
-    const float Phi = 0.5f * (1.0f + erff(z * 0.70710678118654752f));
-    const float phi = 0.39894228040143268f * expf(-0.5f * z * z);
+    const float e = __expf(-0.5f * z * z);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * 0.70710678118654752f * fabsf(z));
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float tail = 0.5f * poly * e;              // 1 - Phi(|z|)
+    const float Phi = z >= 0.0f ? 1.0f - tail : tail;
     a = z * Phi;
-    gp = Phi + z * phi;
+    gp = Phi + z * (0.39894228040143268f * e);
 }
 
 __device__ inline float half_sum(float v) {   // sum over the 32 lanes that share lane >> 5
@@ -139,68 +145,109 @@ __global__ void __launch_bounds__(64) k_dec_pack(DecParams prm, uint4 *__restric
 
 // ----------------------------------------------------------------------------- batch statistics from partials
 
-// Forward: per-(image, pair) partials (sum, M2 about the pair mean) -> batch mean and 1/sqrt(var + eps), combined with
-// Chan's formula (no E[x^2] - E[x]^2 cancellation).  256 threads; red: 768 floats; out: s_mean[64], s_inv[64].
-__device__ inline void combine_fwd_stats(const float *__restrict__ part, const DecGeom &g, float *red, float *s_mean, float *s_inv) {
-    const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const uint32_t n = g.B * g.npair;
-    const float2 *__restrict__ p2 = reinterpret_cast<const float2 *>(part);
-    float cnt = 0.0f, mean = 0.0f, M2 = 0.0f;
-    for (uint32_t base = grp; base < n; base += 32) {
-        float2 v[8];
+// Batch statistics travel between kernels as one partial per (pair, image) and channel: index i = pair*B + image, so the
+// partials of the (possibly shorter) last pair are the contiguous tail and a group's size needs no division.
+constexpr int kPartMax = 24;   // float4 partials per thread held in registers: B*npair <= 8*kPartMax
+
+// 256 threads = 32 channel pairs x 8 groups; thread (cp, grp) holds partials i = grp + 8k of channels 2cp, 2cp+1.
+struct Partials {
+    float4 v[kPartMax];   // (a, b) of channel 2cp, (a, b) of channel 2cp + 1
+};
+template <int K0, int K1>
+__device__ inline void load_partial_range(const float4 *__restrict__ p4, uint32_t n, Partials &pv) {
+    const uint32_t cp = threadIdx.x & 31, grp = threadIdx.x >> 5;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const uint32_t i = base + 4 * u;
-            v[u] = i < n ? p2[(size_t)i * kC + c] : make_float2(0.f, 0.f);
-        }
+    for (int k = K0; k < K1; ++k) pv.v[k] = p4[min(grp + 8u * k, n - 1) * 32 + cp];   // clamped, not predicated: no branches between the loads
+}
+// Entries past the end hold a copy of the last partial; the combine functions mask them by index.
+__device__ inline void load_partials(const float *__restrict__ part, uint32_t n, Partials &pv) {
+    const float4 *__restrict__ p4 = reinterpret_cast<const float4 *>(part);
+    load_partial_range<0, kPartMax / 2>(p4, n, pv);
+    if (n > 8 * (kPartMax / 2)) {
+        load_partial_range<kPartMax / 2, kPartMax>(p4, n, pv);
+    } else {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const uint32_t i = base + 4 * u;
-            if (i < n) chan_merge(cnt, mean, M2, (float)pair_count(i % g.npair, g.P), v[u].x, v[u].y);
-        }
+        for (int k = kPartMax / 2; k < kPartMax; ++k) pv.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    red[(grp * 64 + c) * 3] = cnt;
-    red[(grp * 64 + c) * 3 + 1] = mean;
-    red[(grp * 64 + c) * 3 + 2] = M2;
+}
+
+// Forward: partials (sum, M2 about the pair mean) -> batch mean and 1/sqrt(var + eps): two passes over the registers,
+// M2 = sum_i M2_i + n_i (mean_i - mean)^2 (no E[x^2] - E[x]^2 cancellation, no divisions).  red: 512 floats.
+__device__ inline void combine_fwd_stats(const Partials &pv, const DecGeom &g, float *red, float *s_mean, float *s_inv) {
+    const uint32_t cp = threadIdx.x & 31, grp = threadIdx.x >> 5, c = threadIdx.x & 63;
+    const uint32_t n = g.B * g.npair, last0 = (g.npair - 1) * g.B;
+    const float N = (float)(g.B * g.P), n_last = (float)pair_count(g.npair - 1, g.P), rn_last = 1.0f / n_last;
+    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kPartMax; ++k) {
+        const bool in = grp + 8u * k < n;
+        s0 += in ? pv.v[k].x : 0.0f;
+        s1 += in ? pv.v[k].z : 0.0f;
+    }
+    red[grp * 64 + 2 * cp] = s0;
+    red[grp * 64 + 2 * cp + 1] = s1;
     __syncthreads();
-    if (grp == 0) {
-        for (int k = 1; k < 4; ++k) {
-            const float nb = red[(k * 64 + c) * 3];
-            chan_merge(cnt, mean, M2, nb, red[(k * 64 + c) * 3 + 1] * nb, red[(k * 64 + c) * 3 + 2]);
-        }
-        s_mean[c] = mean;
-        s_inv[c] = 1.0f / sqrtf(M2 / cnt + g.eps);
+    float tot = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += red[k * 64 + c];
+    __syncthreads();
+    if (threadIdx.x < 64) red[c] = tot / N;   // the batch mean of channel c
+    __syncthreads();
+    const float m0 = red[2 * cp], m1 = red[2 * cp + 1];
+    __syncthreads();
+    float q0 = 0.0f, q1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kPartMax; ++k) {
+        const uint32_t i = grp + 8 * k;
+        const bool last = i >= last0;
+        const float ni = last ? n_last : 64.0f, rni = last ? rn_last : 1.0f / 64.0f;
+        const float d0 = pv.v[k].x - ni * m0, d1 = pv.v[k].z - ni * m1;     // n_i * (mean_i - mean)
+        q0 += i < n ? pv.v[k].y + d0 * d0 * rni : 0.0f;
+        q1 += i < n ? pv.v[k].w + d1 * d1 * rni : 0.0f;
+    }
+    if (threadIdx.x < 64) s_mean[c] = red[c];
+    __syncthreads();
+    red[grp * 64 + 2 * cp] = q0;
+    red[grp * 64 + 2 * cp + 1] = q1;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float M2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) M2 += red[k * 64 + c];
+        s_inv[c] = 1.0f / sqrtf(M2 / N + g.eps);
     }
     __syncthreads();
 }
 
-// Backward: k = gamma*inv/N, S1 = sum dz, S2 = sum dz*xhat over the batch.  red: 512 floats; tab: [3][64].
-__device__ inline void combine_bwd_sums(const float *__restrict__ part, const float *__restrict__ gamma, const float *__restrict__ minv,
-                                        const DecGeom &g, float *red, float *tab) {
-    const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+// Backward: k = gamma*inv/N, S1 = sum dz, S2 = sum dz*xhat over the batch.  red: 1024 floats; tab: [3][64].
+__device__ inline void combine_bwd_sums(const Partials &pv, const float *__restrict__ gamma, const float *__restrict__ minv, const DecGeom &g,
+                                        float *red, float *tab) {
+    const uint32_t cp = threadIdx.x & 31, grp = threadIdx.x >> 5, c = threadIdx.x & 63;
     const uint32_t n = g.B * g.npair;
-    const float2 *__restrict__ p2 = reinterpret_cast<const float2 *>(part);
-    float s1 = 0.0f, s2 = 0.0f;
-    for (uint32_t base = grp; base < n; base += 32) {
-        float2 v[8];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const uint32_t i = base + 4 * u;
-            v[u] = i < n ? p2[(size_t)i * kC + c] : make_float2(0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            s1 += v[u].x;
-            s2 += v[u].y;
-        }
+    for (int k = 0; k < kPartMax; ++k) {
+        const bool in = grp + 8u * k < n;
+        s.x += in ? pv.v[k].x : 0.0f;
+        s.y += in ? pv.v[k].y : 0.0f;
+        s.z += in ? pv.v[k].z : 0.0f;
+        s.w += in ? pv.v[k].w : 0.0f;
     }
-    red[grp * 64 + c] = s1;
-    red[256 + grp * 64 + c] = s2;
+    red[grp * 64 + 2 * cp] = s.x;
+    red[grp * 64 + 2 * cp + 1] = s.z;
+    red[512 + grp * 64 + 2 * cp] = s.y;
+    red[512 + grp * 64 + 2 * cp + 1] = s.w;
     __syncthreads();
-    if (grp == 0) {
+    if (threadIdx.x < 64) {
+        float S1 = 0.0f, S2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            S1 += red[k * 64 + c];
+            S2 += red[512 + k * 64 + c];
+        }
         tab[c] = gamma[c] * minv[64 + c] / (float)(g.B * g.P);
-        tab[64 + c] = red[c] + red[64 + c] + red[128 + c] + red[192 + c];
-        tab[128 + c] = red[256 + c] + red[320 + c] + red[384 + c] + red[448 + c];
+        tab[64 + c] = S1;
+        tab[128 + c] = S2;
     }
     __syncthreads();
 }
@@ -254,7 +301,7 @@ __global__ void __launch_bounds__(256) k_dec_l0_fwd(const float *__restrict__ im
     s_red[sub * 64 + co] = m2;
     __syncthreads();
     if (sub == 0) {
-        float *po = ws.stat[0] + (((size_t)im * g.npair + pair) * kC + co) * 2;
+        float *po = ws.stat[0] + (((size_t)pair * g.B + im) * kC + co) * 2;
         po[0] = ts;
         po[1] = s_red[co] + s_red[64 + co] + s_red[128 + co] + s_red[192 + co];
     }
@@ -277,7 +324,7 @@ __host__ __device__ inline PairRows pair_rows(uint32_t pair, uint32_t P, uint32_
 
 // Staged position -> pixel index, or -1 for the zero padding.
 __device__ inline int staged_pixel(uint32_t pos, uint32_t W2, uint32_t py0, const DecGeom &g) {
-    const uint32_t hr = pos / W2, hc = pos - hr * W2;
+    const uint32_t hr = (pos * g.magic_w2) >> 16, hc = pos - hr * W2;   // pos / W2 (magic verified by make_geom for every staged pos)
     const int iy = (int)(py0 + hr) - 1, ix = (int)hc - 1;
     return (iy >= 0 && iy < (int)g.H && ix >= 0 && ix < (int)g.W) ? iy * (int)g.W + ix : -1;
 }
@@ -324,9 +371,9 @@ constexpr int kBatch = 4;   // prologue items whose loads are in flight together
 // position the pair touches; the owner of a pixel also records xhat, GELU' and a for the backward pass.
 template <bool kF32>
 __device__ inline void stage_forward(const float *__restrict__ x, float *__restrict__ xhat, float *__restrict__ gprime, float *__restrict__ act,
-                                     uint32_t im, const PairRows &pr, const DecGeom &g, const float *tab, char *lds_hi, char *lds_lo, float *lds_f32) {
+                                     uint32_t im, const PairRows &pr, const DecGeom &g, const float *tab, char *lds_hi, char *lds_lo, float *lds_f32, uint32_t first = 0, bool record = true) {
     const uint32_t W2 = g.W + 2, total = pr.nrow * W2 * 16;
-    for (uint32_t base = threadIdx.x; base < total; base += 256 * kBatch) {
+    for (uint32_t base = first + threadIdx.x; base < total; base += 256 * kBatch) {
         float4 xv[kBatch];
         int q[kBatch];
 #pragma unroll
@@ -342,7 +389,7 @@ __device__ inline void stage_forward(const float *__restrict__ x, float *__restr
             float xh[4], a[4] = {0.f, 0.f, 0.f, 0.f}, gp[4];
             if (q[u] >= 0) {
                 bn_gelu4(xv[u], cg, tab, xh, a, gp);
-                if ((uint32_t)q[u] >= pr.q0 && (uint32_t)q[u] <= pr.q1) {
+                if (record && (uint32_t)q[u] >= pr.q0 && (uint32_t)q[u] <= pr.q1) {
                     const size_t e = ((size_t)im * g.P + q[u]) * kC + cg * 4;
                     *reinterpret_cast<float4 *>(xhat + e) = make_float4(xh[0], xh[1], xh[2], xh[3]);
                     *reinterpret_cast<float4 *>(gprime + e) = make_float4(gp[0], gp[1], gp[2], gp[3]);
@@ -359,10 +406,10 @@ __device__ inline void stage_forward(const float *__restrict__ x, float *__restr
 
 // Backward prologue: stage dx = BN-backward(dz) for every position the pair touches.
 __device__ inline void stage_backward(const float *__restrict__ dz, const float *__restrict__ xhat, uint32_t im, const PairRows &pr, const DecGeom &g,
-                                      const float *tab, char *lds_hi, char *lds_lo) {
+                                      const float *tab, char *lds_hi, char *lds_lo, uint32_t first = 0) {
     const uint32_t W2 = g.W + 2, total = pr.nrow * W2 * 16;
     const float N = (float)(g.B * g.P);
-    for (uint32_t base = threadIdx.x; base < total; base += 256 * kBatch) {
+    for (uint32_t base = first + threadIdx.x; base < total; base += 256 * kBatch) {
         float4 dv[kBatch], hv[kBatch];
         int q[kBatch];
 #pragma unroll
@@ -386,25 +433,27 @@ __device__ inline void stage_backward(const float *__restrict__ dz, const float 
 
 // ----------------------------------------------------------------------------- the 64 -> 64 conv kernel (forward / dgrad)
 
+constexpr int kKH = kKS / 2;   // k-steps per wave: the 36 k-steps of a unit are split over two waves
+
 struct AFrags {
-    uint4 hi[kKS], lo[kKS];   // 288 VGPRs: the whole A operand of one (rb, tile) unit, requested up front
+    uint4 hi[kKH], lo[kKH];   // 144 VGPRs: the A operand of one (rb, tile, k-half), requested up front
 };
 __device__ inline void load_afrags(const uint4 *__restrict__ A, int lane, AFrags &f) {
 #pragma unroll
-    for (int ks = 0; ks < kKS; ++ks) {
+    for (int ks = 0; ks < kKH; ++ks) {
         f.hi[ks] = A[ks * 128 + lane];
         f.lo[ks] = A[ks * 128 + 64 + lane];
     }
 }
 
-// One (rb, tile) unit: acc[32 rows x 32 pixels] = sum over 36 k-steps; B fragments are 16-byte LDS reads of the lane's
-// pixel at the tap's offset.
-__device__ inline f32x16 conv_unit(AFrags &f, const char *lds_hi, const char *lds_lo, uint32_t hp0, uint32_t W2, int lane) {
+// Half of a (rb, tile) unit: acc[32 rows x 32 pixels] += 18 k-steps starting at ks0 (wave-uniform); B fragments are 16-byte
+// LDS reads of the lane's pixel at the tap's offset.
+__device__ inline f32x16 conv_half(AFrags &f, const char *lds_hi, const char *lds_lo, uint32_t hp0, uint32_t W2, int lane, int ks0) {
     f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int h = lane >> 5;
 #pragma unroll
-    for (int ks = 0; ks < kKS; ++ks) {
-        const int tap = ks >> 2, c4 = ks & 3, ty = tap / 3, tx = tap % 3;
+    for (int ks = 0; ks < kKH; ++ks) {
+        const int kg = ks0 + ks, tap = kg >> 2, c4 = kg & 3, ty = tap / 3, tx = tap - 3 * ty;   // scalar
         const uint32_t off = (hp0 + ty * W2 + tx) * kPitch + (16 * c4 + 8 * h) * 2;
         const bf16x8 b_hi = *reinterpret_cast<const bf16x8 *>(lds_hi + off);
         const bf16x8 b_lo = *reinterpret_cast<const bf16x8 *>(lds_lo + off);
@@ -418,118 +467,244 @@ __device__ inline f32x16 conv_unit(AFrags &f, const char *lds_hi, const char *ld
 
 enum ConvMode { kFwd = 0, kDgrad = 1, kDgradImg = 2 };
 
-// grid (npair, B), 256 threads = 4 waves = the 4 (rb, tile) units of a tile pair.
-//   kFwd      (layer 1..7): consumes x[l-1], stat[l-1]; writes xhat/gprime/act[l-1] (own pixels), minv[l-1], x[l], stat[l].
+#ifdef NSIG_DEC_TIMING
+// Phase stamps of workgroup (0,0), wave 0 (tools/dec_timing.py builds a private copy of the library with this enabled).
+__device__ unsigned long long g_dec_stamps[3][16];
+#define DEC_STAMP(k)                                                                               \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_dec_stamps[MODE][k] = wall_clock64(); \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#else
+#define DEC_STAMP(k)
+#endif
+
+__device__ inline float bcast_lane(float v, int src_lane) {   // src_lane: compile-time constant
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+
+// Per-channel sums over the 32 pixels of a wave's accumulator tile, two quantities at once, through an LDS transpose
+// (pitch 33: conflict-free both ways) instead of 160 cross-lane shuffles.  va/vb: the lane's 16 values (rows 8*g4 + 4*h + j).
+// Returns in lanes (ch = lane & 31) the sums for channel ch, identical in both halves.  scr: 2*32*33 floats per wave.
+__device__ inline float2 tile_channel_sums(const float (&va)[16], const float (&vb)[16], float *scr, int lane) {
+    const int p = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ch = 8 * (r >> 2) + 4 * h + (r & 3);
+        scr[ch * 33 + p] = va[r];
+        scr[32 * 33 + ch * 33 + p] = vb[r];
+    }
+    float sa = 0.0f, sb = 0.0f;   // same wave, same array: program order is enough
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        sa += scr[p * 33 + 16 * h + k];
+        sb += scr[32 * 33 + p * 33 + 16 * h + k];
+    }
+    sa += __shfl_xor(sa, 32, 64);
+    sb += __shfl_xor(sb, 32, 64);
+    return make_float2(sa, sb);
+}
+
+// grid (npair, B, 2 row blocks), 256 threads.  A workgroup owns 32 output rows (rb = blockIdx.z) of one tile pair; its four
+// waves are (tile of the pair) x (k-half), so every wave streams only 36 A fragments and reads 36 B fragments, and the two
+// k-halves of a tile meet through LDS.  All four waves build the B operand (the prologue is the longest phase); the rb = 1
+// workgroup repeats that staging on another CU -- the chip has more CUs (256) than this layer has tile pairs (96).
+//   kFwd      (layer 1..7): consumes x[l-1], stat[l-1]; writes xhat/gprime/act[l-1] (own pixels, rb 0), minv[l-1], x[l], stat[l].
 //   kDgrad    (layer 7..1): consumes dz[l], xhat[l], bsum[l]; writes dz[l-1], bsum[l-1].
-//   kDgradImg (layer 0)   : consumes dz[0], xhat[0], bsum[0]; writes the gradient of the input image [B][Cin][H][W].
+//   kDgradImg (layer 0)   : consumes dz[0], xhat[0], bsum[0]; writes the gradient of the input image [B][Cin][H][W]  (grid z = 1).
+// Order of global requests (loads return in order): batch partials, the prologue inputs, then the A fragments -- which land
+// while the statistics are combined and the prologue computes.
 template <int MODE>
 __global__ void __launch_bounds__(256) k_dec_conv(int layer, DecParams prm, DecWs ws, DecGeom g, float *__restrict__ grad_img) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const uint32_t pair = blockIdx.x, im = blockIdx.y, t = threadIdx.x;
+    const uint32_t pair = blockIdx.x, im = blockIdx.y, rb = blockIdx.z, t = threadIdx.x;
     const uint32_t W2 = g.W + 2;
     const PairRows pr = pair_rows(pair, g.P, g.W);
-    const uint32_t plane = g.rows_max * W2 * kPitch;
+    const uint32_t plane = g.rows_max * W2 * kPitch, total = pr.nrow * W2 * 16;
     char *lds_hi = smem_raw, *lds_lo = smem_raw + plane;
     float *s_tab = reinterpret_cast<float *>(smem_raw + 2 * plane);   // [4][64] per-channel constants
-    float *s_red = s_tab + 4 * 64;                                    // [768] scratch
+    float *s_red = s_tab + 4 * 64;                                    // [1024] scratch
+    float *s_scr = s_red + 1024;                                      // [2 tiles][2*32*33] epilogue transposes
+    float *s_acc = s_scr + 2 * (2 * 32 * 33);                         // [2 tiles][16][64] k-half exchange
+    float *s_ref = s_acc + 2 * 16 * 64;                               // [2 tiles][32]
+    const float N = (float)(g.B * g.P);
 
-    const int wave = t >> 6, lane = t & 63, rb = wave & 1, p = lane & 31, h = lane >> 5;
-    const uint32_t tile = 2 * pair + (wave >> 1);
-    const bool active = tile < g.ntile && !(MODE == kDgradImg && rb == 1);
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, tp = wave & 1, kh = wave >> 1, p = lane & 31, h = lane >> 5;
+    const uint32_t tile = 2 * pair + tp;
+    const bool active = tile < g.ntile;
     const int set = MODE == kFwd ? (layer - 1) * 2 : (MODE == kDgrad ? (layer - 1) * 2 + 1 : 14);
-    AFrags af;
-    if (active) load_afrags(ws.packed + (size_t)set * kSetU4 + (size_t)rb * kKS * 128, lane, af);   // in flight during the prologue
+    const uint32_t img_off = im * g.P * kC;   // element offsets fit 32 bits (checked by make_geom)
+    DEC_STAMP(0);
 
+    // ---- requests
+    Partials pv;
+    load_partials(MODE == kFwd ? ws.stat[layer - 1] : ws.bsum[layer], g.B * g.npair, pv);
+    DEC_STAMP(7);
+    const float *__restrict__ in0 = MODE == kFwd ? ws.x[layer - 1] : ws.dz[layer];
+    const float *__restrict__ in1 = ws.xhat[layer];   // backward only
+    constexpr int kPre = 8;
+    float4 v0[kPre], v1[kPre];
+    int q[kPre];
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+        const uint32_t i = t + 256 * u;
+        q[u] = i < total ? staged_pixel(i >> 4, W2, pr.py0, g) : -1;
+        const uint32_t e = img_off + (q[u] >= 0 ? q[u] : 0) * kC + (i & 15) * 4;
+        v0[u] = q[u] >= 0 ? *reinterpret_cast<const float4 *>(in0 + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE != kFwd) v1[u] = q[u] >= 0 ? *reinterpret_cast<const float4 *>(in1 + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    DEC_STAMP(8);
+    AFrags af;
+    if (active) load_afrags(ws.packed + (size_t)set * kSetU4 + ((size_t)rb * kKS + kh * kKH) * 128, lane, af);
+    DEC_STAMP(1);
+
+    // ---- batch statistics -> per-channel constants
     if (MODE == kFwd) {
-        combine_fwd_stats(ws.stat[layer - 1], g, s_red, s_tab, s_tab + 64);
+        combine_fwd_stats(pv, g, s_red, s_tab, s_tab + 64);
         if (t < 64) {
             s_tab[128 + t] = prm.gamma[layer - 1][t];
             s_tab[192 + t] = prm.beta[layer - 1][t];
-            if (pair == 0 && im == 0) {
+            if (pair == 0 && im == 0 && rb == 0) {
                 ws.minv[layer - 1][t] = s_tab[t];
                 ws.minv[layer - 1][64 + t] = s_tab[64 + t];
             }
         }
         __syncthreads();
-        stage_forward<false>(ws.x[layer - 1], ws.xhat[layer - 1], ws.gprime[layer - 1], ws.act[layer - 1], im, pr, g, s_tab, lds_hi, lds_lo, nullptr);
     } else {
-        combine_bwd_sums(ws.bsum[layer], prm.gamma[layer], ws.minv[layer], g, s_red, s_tab);
-        stage_backward(ws.dz[layer], ws.xhat[layer], im, pr, g, s_tab, lds_hi, lds_lo);
+        combine_bwd_sums(pv, prm.gamma[layer], ws.minv[layer], g, s_red, s_tab);
+    }
+    DEC_STAMP(2);
+
+    // ---- prologue: the B operand of every position this pair touches, halo included
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+        const uint32_t i = t + 256 * u, pos = i >> 4, cg = i & 15;
+        if (i >= total) break;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        if (q[u] >= 0) {
+            if (MODE == kFwd) {
+                float xh[4], gp[4];
+                bn_gelu4(v0[u], cg, s_tab, xh, a, gp);
+                if (rb == 0 && (uint32_t)q[u] >= pr.q0 && (uint32_t)q[u] <= pr.q1) {
+                    const uint32_t e = img_off + q[u] * kC + cg * 4;
+                    *reinterpret_cast<float4 *>(ws.xhat[layer - 1] + e) = make_float4(xh[0], xh[1], xh[2], xh[3]);
+                    *reinterpret_cast<float4 *>(ws.gprime[layer - 1] + e) = make_float4(gp[0], gp[1], gp[2], gp[3]);
+                    *reinterpret_cast<float4 *>(ws.act[layer - 1] + e) = make_float4(a[0], a[1], a[2], a[3]);
+                }
+            } else {
+                const float4 d = bn_bwd4(v0[u], v1[u], cg, s_tab, N);
+                a[0] = d.x; a[1] = d.y; a[2] = d.z; a[3] = d.w;
+            }
+        }
+        split4_to_lds(lds_hi, lds_lo, pos, cg, a);
+    }
+    if (total > 256 * kPre) {   // pairs that stage more than the preloaded batch: the rest, batched
+        if (MODE == kFwd)
+            stage_forward<false>(ws.x[layer - 1], ws.xhat[layer - 1], ws.gprime[layer - 1], ws.act[layer - 1], im, pr, g, s_tab, lds_hi, lds_lo, nullptr, 256 * kPre, rb == 0);
+        else
+            stage_backward(ws.dz[layer], ws.xhat[layer], im, pr, g, s_tab, lds_hi, lds_lo, 256 * kPre);
+    }
+    DEC_STAMP(3);
+
+    // ---- body: lane holds rows 32*rb + 8*g4 + 4*h + {0..3} (g4 = 0..3) of pixel qo
+    const uint32_t qo = 32 * tile + p;
+    const bool valid = active && qo < g.P;
+    const uint32_t qq = valid ? qo : pr.q0, py = qq / g.W, px = qq - py * g.W;
+    const uint32_t eo = img_off + qq * kC + 32 * rb + 4 * h;
+    float4 gp4[4], xh4[4];
+    if (MODE == kDgrad && kh == 0) {   // epilogue operands, requested before the MFMA loop
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            gp4[g4] = valid ? *reinterpret_cast<const float4 *>(ws.gprime[layer - 1] + eo + 8 * g4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xh4[g4] = valid ? *reinterpret_cast<const float4 *>(ws.xhat[layer - 1] + eo + 8 * g4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     __syncthreads();
-
-    // ---- body: lane holds rows 32*rb + 8*g4 + 4*h + {0..3} (g4 = 0..3) of pixel q
-    const uint32_t q = 32 * tile + p;
-    const bool valid = active && q < g.P;
-    const uint32_t qq = valid ? q : pr.q0, py = qq / g.W, px = qq - py * g.W;
+    DEC_STAMP(4);
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (active) acc = conv_unit(af, lds_hi, lds_lo, (py - pr.py0) * W2 + px, W2, lane);
+    if (active) acc = conv_half(af, lds_hi, lds_lo, (py - pr.py0) * W2 + px, W2, lane, kh * kKH);
+    if (kh == 1)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_acc[(tp * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    if (kh == 0)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += s_acc[(tp * 16 + r) * 64 + lane];
+#ifdef NSIG_DEC_TIMING
+    if (acc[0] == 12345.678f) DEC_STAMP(15);   // make the stamp below wait for the accumulators
+#endif
+    DEC_STAMP(5);
 
-    // ---- epilogue
-    float *s_ep = s_red;   // [4 waves][32 channels][2]
+    // ---- epilogue (waves kh == 0 hold the tiles; the others only keep the barriers company)
+    float *scr = s_scr + tp * (2 * 32 * 33), *s_ep = s_red;   // s_ep: [2 tiles][32 channels][2]
     if (MODE == kFwd) {
-        if (valid) {
-            float *xo = ws.x[layer] + ((size_t)im * g.P + q) * kC + 32 * rb + 4 * h;
+        if (kh == 0) {
+            if (valid) {
+                float *xo = ws.x[layer] + eo;
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) *reinterpret_cast<float4 *>(xo + 8 * g4) = make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
-        }
-        const float n_tile = active ? (float)tile_count(tile, g.P) : 1.0f;
+                for (int g4 = 0; g4 < 4; ++g4) *reinterpret_cast<float4 *>(xo + 8 * g4) = make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
+            }
+            // sum and sum of squares about a reference sample of the same channel (the tile's first pixel):
+            // M2 = sum d^2 - (sum d)^2/n cancels only relative to the spread inside the tile.
+            float d[16], d2[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float s = half_sum(valid ? acc[r] : 0.0f);
-            const float d = valid ? acc[r] - s / n_tile : 0.0f;
-            const float m2 = half_sum(d * d);
-            if (p == 0) {
-                s_ep[(wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3)) * 2] = s;
-                s_ep[(wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3)) * 2 + 1] = m2;
+            for (int r = 0; r < 16; ++r) {
+                const float r0 = bcast_lane(acc[r], 0), r1 = bcast_lane(acc[r], 32);
+                const float ref = h ? r1 : r0;
+                d[r] = valid ? acc[r] - ref : 0.0f;
+                d2[r] = d[r] * d[r];
+                if (p == 0) s_ref[tp * 32 + 8 * (r >> 2) + 4 * h + (r & 3)] = ref;
+            }
+            const float2 sums = tile_channel_sums(d, d2, scr, lane);   // lane -> channel p of this row block
+            if (h == 0) {
+                const float n_t = active ? (float)tile_count(tile, g.P) : 0.0f;
+                s_ep[(tp * 32 + p) * 2] = active ? sums.x + n_t * s_ref[tp * 32 + p] : 0.0f;                 // sum of x
+                s_ep[(tp * 32 + p) * 2 + 1] = active ? sums.y - sums.x * sums.x / fmaxf(n_t, 1.0f) : 0.0f;   // M2 about the tile mean
             }
         }
         __syncthreads();
-        if (t < 64) {   // merge the pair's two tiles: waves (rb, rb + 2)
-            const int rbm = t >> 5, ch = t & 31;
-            float cnt = (float)tile_count(2 * pair, g.P), mean = s_ep[(rbm * 32 + ch) * 2] / cnt, M2 = s_ep[(rbm * 32 + ch) * 2 + 1];
-            if (2 * pair + 1 < g.ntile)
-                chan_merge(cnt, mean, M2, (float)tile_count(2 * pair + 1, g.P), s_ep[((rbm + 2) * 32 + ch) * 2], s_ep[((rbm + 2) * 32 + ch) * 2 + 1]);
-            float *po = ws.stat[layer] + (((size_t)im * g.npair + pair) * kC + 32 * rbm + ch) * 2;
+        if (t < 32) {   // merge the pair's two tiles
+            float cnt = (float)tile_count(2 * pair, g.P), mean = s_ep[t * 2] / cnt, M2 = s_ep[t * 2 + 1];
+            if (2 * pair + 1 < g.ntile) chan_merge(cnt, mean, M2, (float)tile_count(2 * pair + 1, g.P), s_ep[(32 + t) * 2], s_ep[(32 + t) * 2 + 1]);
+            float *po = ws.stat[layer] + ((pair * g.B + im) * kC + 32 * rb + t) * 2;
             po[0] = mean * cnt;
             po[1] = M2;
         }
+        DEC_STAMP(6);
     } else if (MODE == kDgrad) {
-        const size_t e = ((size_t)im * g.P + q) * kC + 32 * rb + 4 * h;
-        float4 gp[4], xh[4];
+        if (kh == 0) {
+            float dzv[16], dzx[16];
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            gp[g4] = valid ? *reinterpret_cast<const float4 *>(ws.gprime[layer - 1] + e + 8 * g4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            xh[g4] = valid ? *reinterpret_cast<const float4 *>(ws.xhat[layer - 1] + e + 8 * g4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float gpv[4] = {gp4[g4].x, gp4[g4].y, gp4[g4].z, gp4[g4].w}, xhv[4] = {xh4[g4].x, xh4[g4].y, xh4[g4].z, xh4[g4].w};
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const float dzv[4] = {acc[4 * g4] * gp[g4].x, acc[4 * g4 + 1] * gp[g4].y, acc[4 * g4 + 2] * gp[g4].z, acc[4 * g4 + 3] * gp[g4].w};
-            const float xhv[4] = {xh[g4].x, xh[g4].y, xh[g4].z, xh[g4].w};
-            if (valid) *reinterpret_cast<float4 *>(ws.dz[layer - 1] + e + 8 * g4) = make_float4(dzv[0], dzv[1], dzv[2], dzv[3]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float s1 = half_sum(valid ? dzv[j] : 0.0f), s2 = half_sum(valid ? dzv[j] * xhv[j] : 0.0f);
-                if (p == 0) {
-                    s_ep[(wave * 32 + 8 * g4 + 4 * h + j) * 2] = s1;
-                    s_ep[(wave * 32 + 8 * g4 + 4 * h + j) * 2 + 1] = s2;
+                for (int j = 0; j < 4; ++j) {
+                    dzv[4 * g4 + j] = valid ? acc[4 * g4 + j] * gpv[j] : 0.0f;
+                    dzx[4 * g4 + j] = dzv[4 * g4 + j] * xhv[j];
                 }
+                if (valid) *reinterpret_cast<float4 *>(ws.dz[layer - 1] + eo + 8 * g4) = make_float4(dzv[4 * g4], dzv[4 * g4 + 1], dzv[4 * g4 + 2], dzv[4 * g4 + 3]);
+            }
+            const float2 sums = tile_channel_sums(dzv, dzx, scr, lane);
+            if (h == 0) {
+                s_ep[(tp * 32 + p) * 2] = active ? sums.x : 0.0f;
+                s_ep[(tp * 32 + p) * 2 + 1] = active ? sums.y : 0.0f;
             }
         }
         __syncthreads();
-        if (t < 64) {
-            const int rbm = t >> 5, ch = t & 31;
-            float *po = ws.bsum[layer - 1] + (((size_t)im * g.npair + pair) * kC + 32 * rbm + ch) * 2;
-            po[0] = s_ep[(rbm * 32 + ch) * 2] + s_ep[((rbm + 2) * 32 + ch) * 2];          // inactive waves wrote zeros
-            po[1] = s_ep[(rbm * 32 + ch) * 2 + 1] + s_ep[((rbm + 2) * 32 + ch) * 2 + 1];
+        if (t < 32) {
+            float *po = ws.bsum[layer - 1] + ((pair * g.B + im) * kC + 32 * rb + t) * 2;
+            po[0] = s_ep[t * 2] + s_ep[(32 + t) * 2];
+            po[1] = s_ep[t * 2 + 1] + s_ep[(32 + t) * 2 + 1];
         }
+        DEC_STAMP(6);
     } else {
         // rows = input channels c = 8*g4 + 4*h + j < Cin
-        if (valid)
+        if (kh == 0 && valid)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint32_t c = 8 * (r >> 2) + 4 * h + (r & 3);
-                if (c < g.Cin) grad_img[((size_t)im * g.Cin + c) * g.P + q] = acc[r];
+                if (c < g.Cin) grad_img[((size_t)im * g.Cin + c) * g.P + qo] = acc[r];
             }
     }
 }
@@ -543,12 +718,14 @@ __global__ void __launch_bounds__(256) k_dec_l8_fwd(DecParams prm, DecWs ws, Dec
     const PairRows pr = pair_rows(pair, g.P, g.W);
     float *s_a = reinterpret_cast<float *>(smem_raw);          // [rows_max*W2][64]
     float *s_tab = s_a + (size_t)g.rows_max * W2 * kC;          // [4][64]
-    float *s_red = s_tab + 4 * 64;                              // [768]
+    float *s_red = s_tab + 4 * 64;                              // [1024]
     const int wave = t >> 6, lane = t & 63;
     float w8[9];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) w8[tap] = prm.w[8][lane * 9 + tap];   // [1][64][3][3]
-    combine_fwd_stats(ws.stat[7], g, s_red, s_tab, s_tab + 64);
+    Partials pv;
+    load_partials(ws.stat[7], g.B * g.npair, pv);
+    combine_fwd_stats(pv, g, s_red, s_tab, s_tab + 64);
     if (t < 64) {
         s_tab[128 + t] = prm.gamma[7][t];
         s_tab[192 + t] = prm.beta[7][t];
@@ -581,8 +758,8 @@ __global__ void __launch_bounds__(256) k_dec_l8_fwd(DecParams prm, DecWs ws, Dec
         const float v = t < n ? s_x[t] : 0.0f, s = wave_sum64(v);
         const float d = t < n ? v - s / (float)n : 0.0f, m2 = wave_sum64(d * d);
         if (t == 0) {
-            ws.stat[8][((size_t)im * g.npair + pair) * 2] = s;
-            ws.stat[8][((size_t)im * g.npair + pair) * 2 + 1] = m2;
+            ws.stat[8][((size_t)pair * g.B + im) * 2] = s;
+            ws.stat[8][((size_t)pair * g.B + im) * 2 + 1] = m2;
         }
     }
 }
@@ -597,7 +774,7 @@ __global__ void __launch_bounds__(256) k_dec_head_fwd(DecParams prm, DecWs ws, D
     const float mean = block_sum256(s, scratch) / N;
     float m2 = 0.0f;
     for (uint32_t i = t; i < n; i += 256) {
-        const float ni = (float)pair_count(i % g.npair, g.P), d = ws.stat[8][(size_t)i * 2] / ni - mean;
+        const float ni = (float)pair_count(i / g.B, g.P), d = ws.stat[8][(size_t)i * 2] / ni - mean;
         m2 += ws.stat[8][(size_t)i * 2 + 1] + ni * d * d;
     }
     const float inv = 1.0f / sqrtf(block_sum256(m2, scratch) / N + g.eps);
@@ -641,8 +818,8 @@ __global__ void __launch_bounds__(256) k_dec_head_bwd(const float *__restrict__ 
         const float dz = q < g.P ? s_dz[q] : 0.0f, xh = q < g.P ? s_xh[q] : 0.0f;
         const float s1 = wave_sum64(dz), s2 = wave_sum64(dz * xh);
         if (lane == 0) {
-            ws.bsum[8][((size_t)im * g.npair + pair) * 2] = s1;
-            ws.bsum[8][((size_t)im * g.npair + pair) * 2 + 1] = s2;
+            ws.bsum[8][((size_t)pair * g.B + im) * 2] = s1;
+            ws.bsum[8][((size_t)pair * g.B + im) * 2 + 1] = s2;
         }
     }
 }
@@ -725,7 +902,7 @@ __global__ void __launch_bounds__(256) k_dec_l8_bwd(DecParams prm, DecWs ws, Dec
     for (int tap = 0; tap < 9; ++tap) r[2 + tap] = dw[tap];
     __syncthreads();
     if (wave == 0) {
-        float *po = ws.bsum[7] + (((size_t)im * g.npair + pair) * kC + lane) * 2;
+        float *po = ws.bsum[7] + (((size_t)pair * g.B + im) * kC + lane) * 2;
         po[0] = s_red[lane * 11] + s_red[(64 + lane) * 11] + s_red[(128 + lane) * 11] + s_red[(192 + lane) * 11];
         po[1] = s_red[lane * 11 + 1] + s_red[(64 + lane) * 11 + 1] + s_red[(128 + lane) * 11 + 1] + s_red[(192 + lane) * 11 + 1];
     }
@@ -780,12 +957,14 @@ __global__ void __launch_bounds__(256) k_dec_wgrad(DecParams prm, DecWs ws, DecG
     const uint32_t Kpad = g.nks * 16, La = Kpad + 2 * g.RS + 16;
     char *dx_hi = smem_raw, *dx_lo = dx_hi + 64 * g.pd, *a_hi = dx_lo + 64 * g.pd, *a_lo = a_hi + 64 * g.pa;
     float *s_tab = reinterpret_cast<float *>(a_lo + 64 * g.pa);   // [3][64]
-    float *s_red = s_tab + 3 * 64;                                 // [512]
+    float *s_red = s_tab + 3 * 64;                                 // [1024]
     const float N = (float)(g.B * g.P);
     const uint32_t row_lo = band * g.R, row_hi = min(g.H, row_lo + g.R);   // image rows of this band
     const int RS = (int)g.RS, rbase = (int)((row_lo + 1) * g.RS), abase = rbase - RS - 8;
 
-    // a^T does not depend on the batch sums: request it first
+    Partials pv;
+    load_partials(ws.bsum[layer], g.B * g.npair, pv);
+    // a^T does not depend on the batch sums
     for (uint32_t base = t; base < La * 16; base += 256 * kBatch) {
         float4 v[kBatch];
 #pragma unroll
@@ -801,7 +980,7 @@ __global__ void __launch_bounds__(256) k_dec_wgrad(DecParams prm, DecWs ws, DecG
             if (i < La * 16) put_transposed(a_hi, a_lo, g.pa, i & 15, i >> 4, v[u]);
         }
     }
-    combine_bwd_sums(ws.bsum[layer], prm.gamma[layer], ws.minv[layer], g, s_red, s_tab);
+    combine_bwd_sums(pv, prm.gamma[layer], ws.minv[layer], g, s_red, s_tab);
     for (uint32_t base = t; base < Kpad * 16; base += 256 * kBatch) {
         float4 dv[kBatch], hv[kBatch];
         bool ok[kBatch];
@@ -882,7 +1061,9 @@ __global__ void __launch_bounds__(256) k_dec_l0_wgrad(const float *__restrict__ 
         const bool in = hr >= 1 && hr <= g.H && hc >= 1 && hc <= g.W;
         s_img[i] = in ? img[((size_t)im * g.Cin + c) * g.P + (hr - 1) * g.W + (hc - 1)] : 0.0f;
     }
-    combine_bwd_sums(ws.bsum[0], prm.gamma[0], ws.minv[0], g, s_red, s_tab);
+    Partials pv;
+    load_partials(ws.bsum[0], g.B * g.npair, pv);
+    combine_bwd_sums(pv, prm.gamma[0], ws.minv[0], g, s_red, s_tab);
     const float N = (float)(g.B * g.P);
     float dx[16];
 #pragma unroll
@@ -1008,12 +1189,12 @@ static inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m
 
 constexpr size_t kLdsLimit = 160 * 1024;
 
-static size_t conv_lds(const DecGeom &g) { return (size_t)2 * g.rows_max * (g.W + 2) * kPitch + (4 * 64 + 768) * 4; }
-static size_t l8_lds(const DecGeom &g) { return (size_t)g.rows_max * (g.W + 2) * kC * 4 + (4 * 64 + 768) * 4; }
+static size_t conv_lds(const DecGeom &g) { return (size_t)2 * g.rows_max * (g.W + 2) * kPitch + (4 * 64 + 1024 + 2 * 2 * 32 * 33 + 2 * 16 * 64 + 2 * 32) * 4; }
+static size_t l8_lds(const DecGeom &g) { return (size_t)g.rows_max * (g.W + 2) * kC * 4 + (4 * 64 + 1024) * 4; }
 static size_t l8b_lds(const DecGeom &g) { return (size_t)g.rows_max * (g.W + 2) * 4 + 4 * 64 * 11 * 4; }
 static size_t l0_lds(const DecGeom &g) { return ((size_t)g.Cin * (g.H + 2) * (g.W + 2) + (size_t)kC * 9 * g.Cin + 4 * 64) * 4; }
-static size_t l0w_lds(const DecGeom &g) { return ((size_t)g.Cin * (g.H + 2) * (g.W + 2) + 3 * 64 + 4 * 64 * 9) * 4; }
-static size_t wgrad_lds(const DecGeom &g) { return (size_t)128 * (g.pd + g.pa) + (3 * 64 + 512) * 4; }
+static size_t l0w_lds(const DecGeom &g) { return ((size_t)g.Cin * (g.H + 2) * (g.W + 2) + 3 * 64 + 4 * 64 * 9) * 4; }   // scratch 2304 >= 1024
+static size_t wgrad_lds(const DecGeom &g) { return (size_t)128 * (g.pd + g.pa) + (3 * 64 + 1024) * 4; }
 
 static bool make_geom(uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, float eps, DecGeom &g) {
     g.B = B; g.H = H; g.W = W; g.P = H * W; g.Cin = Cin; g.eps = eps;
@@ -1021,6 +1202,9 @@ static bool make_geom(uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, float ep
     g.npair = ceil_div(g.ntile, 2);
     g.rows_max = 0;
     for (uint32_t p = 0; p < g.npair; ++p) g.rows_max = std::max(g.rows_max, pair_rows(p, g.P, W).nrow);
+    g.magic_w2 = 65536 / (W + 2) + 1;
+    for (uint32_t pos = 0; pos < g.rows_max * (W + 2); ++pos)
+        if (((pos * g.magic_w2) >> 16) != pos / (W + 2)) return false;
     g.RS = round_up(W + 2, 8);
     // wgrad row bands: as few as LDS allows (every band writes a 147 KB partial of dW)
     for (g.nband = 1;; ++g.nband) {
@@ -1033,6 +1217,8 @@ static bool make_geom(uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, float ep
         if (g.nband >= H) return false;
     }
     g.nband = ceil_div(H, g.R);   // no empty bands
+    if (B * g.npair > 8 * kPartMax) return false;        // batch partials are combined from registers
+    if ((uint64_t)B * g.P * kC >= (1u << 30)) return false;   // 32-bit element offsets
     return conv_lds(g) <= kLdsLimit && l8_lds(g) <= kLdsLimit && l0_lds(g) <= 64 * 1024 && l0w_lds(g) <= 64 * 1024;
 }
 
@@ -1100,6 +1286,12 @@ static int allow_all_lds(const DecGeom &g) {
 
 using namespace nsig;
 
+#ifdef NSIG_DEC_TIMING
+NSIG_EXPORT int dec_timing_stamps(unsigned long long *out48) {
+    return hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_dec_stamps), sizeof(unsigned long long) * 48) == hipSuccess ? 0 : 1;
+}
+#endif
+
 NSIG_EXPORT size_t dec_workspace_bytes(uint32_t B, uint32_t Cin, uint32_t H, uint32_t W) {
     DecGeom g;
     DecWs ws;
@@ -1123,7 +1315,7 @@ NSIG_EXPORT int dec_forward(const float *img, const float *const *params, uint32
     const dim3 grid(g.npair, B);
     k_dec_pack<<<kSets * 2 * kKS, 64, 0, s>>>(prm, ws.packed, Cin);
     k_dec_l0_fwd<<<grid, 256, l0_lds(g), s>>>(img, prm, ws, g);
-    for (int l = 1; l <= 7; ++l) k_dec_conv<kFwd><<<grid, 256, conv_lds(g), s>>>(l, prm, ws, g, nullptr);
+    for (int l = 1; l <= 7; ++l) k_dec_conv<kFwd><<<dim3(g.npair, B, 2), 256, conv_lds(g), s>>>(l, prm, ws, g, nullptr);
     k_dec_l8_fwd<<<grid, 256, l8_lds(g), s>>>(prm, ws, g);
     k_dec_head_fwd<<<B, 256, 0, s>>>(prm, ws, g, decoded);
     return check_launch("dec_forward");
@@ -1154,7 +1346,7 @@ NSIG_EXPORT int dec_backward(const float *grad_decoded, const float *img, const 
     const dim3 grid(g.npair, B);
     k_dec_head_bwd<<<B, 256, 0, s>>>(grad_decoded, prm, ws, g);
     k_dec_l8_bwd<<<grid, 256, l8b_lds(g), s>>>(prm, ws, g);
-    for (int l = 7; l >= 1; --l) k_dec_conv<kDgrad><<<grid, 256, conv_lds(g), s>>>(l, prm, ws, g, nullptr);
+    for (int l = 7; l >= 1; --l) k_dec_conv<kDgrad><<<dim3(g.npair, B, 2), 256, conv_lds(g), s>>>(l, prm, ws, g, nullptr);
     k_dec_conv<kDgradImg><<<grid, 256, conv_lds(g), s>>>(0, prm, ws, g, grad_img);
     k_dec_wgrad<<<dim3(g.nband, B, 7), 256, wgrad_lds(g), s>>>(prm, ws, g);
     k_dec_l0_wgrad<<<grid, 256, l0w_lds(g), s>>>(img, prm, ws, g);
