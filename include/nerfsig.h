@@ -222,7 +222,31 @@ int field_bwd(const float *xyzs, uint32_t M, float bound, const float *grad_sigm
               const float *sigmas, const float *rgbs, const uint32_t *masks, const void *packed, float *G,
               float *dfeat_out, float *rec_out, nsig_stream_t stream);
 
-/* ------------------------------------------------------------------ decoder glue */
+/* ------------------------------------------------------------------ elementwise tails, one kernel per direction */
+
+/*
+ * renderer_wtmk.py:316-319 (and 369-372): image_out = image + (1 - weights_sum) * bg_color,
+ * depth_out = clamp(depth - near, min=0) / (far - near).  bg: one colour [3] (bg_stride 0) or per ray [N,3] (bg_stride 3).
+ * Backward: grad_weights_sum = -sum_c grad_image*bg, grad_depth_in = grad_depth/(far-near) where depth >= near
+ * (grad_image passes through unchanged; grad_image / grad_depth / grad_depth_in may be NULL).
+ */
+int rm_finish_fwd(const float *image, const float *depth, const float *weights_sum, const float *nears, const float *fars, const float *bg,
+                  uint32_t bg_stride, uint32_t N, float *image_out, float *depth_out, nsig_stream_t stream);
+int rm_finish_bwd(const float *grad_image, const float *grad_depth, const float *depth, const float *nears, const float *fars, const float *bg,
+                  uint32_t bg_stride, uint32_t N, float *grad_weights_sum, float *grad_depth_in, nsig_stream_t stream);
+
+/*
+ * The losses of Trainer.train_step (utils_wtmk_disen.py:615-640, loss_w = 'bce'):
+ *   losses3 = { mean((content - gt)^2),  mean BCEWithLogits(temp * decoded, message),  lambda_w * loss_w + lambda_i * loss_i }
+ * over n_content floats and D logits.  d_content / d_decoded receive d(loss_i)/d(content), d(loss_w)/d(decoded); wm_loss_bwd
+ * scales them by the incoming gradients of the three outputs (device scalars, NULL = 0).
+ */
+int wm_loss_fwd(const float *content, const float *gt, uint32_t n_content, const float *decoded, const float *message, uint32_t D, float temp,
+                float lambda_w, float lambda_i, float *losses3, float *d_content, float *d_decoded, nsig_stream_t stream);
+int wm_loss_bwd(const float *g_lossi, const float *g_lossw, const float *g_loss, float lambda_w, float lambda_i, const float *d_content,
+                uint32_t n_content, const float *d_decoded, uint32_t D, float *grad_content, float *grad_decoded, nsig_stream_t stream);
+
+/* ------------------------------------------------------------------ decoder */
 
 /*
  * BatchNorm2d with batch statistics (track_running_stats=False, hidden_models.py:26) followed by GELU (erf form), as one

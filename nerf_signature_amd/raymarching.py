@@ -228,15 +228,16 @@ class _composite_rays_train(Function):
                 nv.ptr(weights_sum), nv.ptr(depth), nv.ptr(image), nv.stream())
         ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, depth, image)
         ctx.dims = [M, N, T_thresh]
+        ctx.set_materialize_grads(False)   # the depth gradient is never used: do not make autograd fill a zero tensor for it
         return weights_sum, depth, image
 
     @staticmethod
     @_bwd
     def backward(ctx, grad_weights_sum, grad_depth, grad_image):
         # grad_depth is not propagated (raymarching.py:275)
-        grad_weights_sum = grad_weights_sum.contiguous()
-        grad_image = grad_image.contiguous()
         sigmas, rgbs, deltas, rays, weights_sum, depth, image = ctx.saved_tensors
+        grad_weights_sum = torch.zeros_like(weights_sum) if grad_weights_sum is None else grad_weights_sum.contiguous()
+        grad_image = torch.zeros_like(image) if grad_image is None else grad_image.contiguous()
         M, N, T_thresh = ctx.dims
         grad_sigmas = torch.empty_like(sigmas)
         grad_rgbs = torch.empty_like(rgbs)

@@ -11,11 +11,59 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import _native as nv
 from . import raymarching
 
 
 def custom_meshgrid(*args):
     return torch.meshgrid(*args, indexing="ij")
+
+
+_BG_CONST = {}
+
+
+def _background_tensor(bg_color, image):
+    """bg_color as a [3] or [N,3] float32 device tensor (constants are cached: no fill kernel per call), or None if it is
+    something rm_finish does not take (then the stock operators broadcast it)."""
+    if isinstance(bg_color, (int, float)):
+        key = (image.device, float(bg_color))
+        if key not in _BG_CONST:
+            _BG_CONST[key] = torch.full((3,), float(bg_color), dtype=torch.float32, device=image.device)
+        return _BG_CONST[key]
+    if torch.is_tensor(bg_color) and bg_color.dtype == torch.float32 and bg_color.device == image.device and not bg_color.requires_grad:
+        if bg_color.numel() == 3:
+            return bg_color.reshape(3).contiguous()
+        if bg_color.numel() == image.numel():
+            return bg_color.reshape(-1, 3).contiguous()
+    return None
+
+
+class _Finish(torch.autograd.Function):
+    """rm_finish_fwd / rm_finish_bwd: image + (1 - weights_sum) * bg and clamp(depth - near, 0) / (far - near)."""
+
+    @staticmethod
+    def forward(ctx, image, depth, weights_sum, nears, fars, bg):
+        image, depth, weights_sum = image.contiguous(), depth.contiguous(), weights_sum.contiguous()
+        N = depth.numel()
+        image_out, depth_out = torch.empty_like(image), torch.empty_like(depth)
+        stride = 0 if bg.numel() == 3 else 3
+        nv.call("rm_finish_fwd", nv.ptr(image), nv.ptr(depth), nv.ptr(weights_sum), nv.ptr(nears), nv.ptr(fars), nv.ptr(bg), stride, N,
+                nv.ptr(image_out), nv.ptr(depth_out), nv.stream())
+        ctx.save_for_backward(depth, nears, fars, bg)
+        ctx.set_materialize_grads(False)
+        return image_out, depth_out
+
+    @staticmethod
+    def backward(ctx, g_image, g_depth):
+        depth, nears, fars, bg = ctx.saved_tensors
+        N = depth.numel()
+        if g_image is not None:
+            g_image = g_image.contiguous()
+        g_ws = torch.empty_like(depth)
+        g_depth_in = torch.empty_like(depth) if g_depth is not None else None
+        nv.call("rm_finish_bwd", nv.ptr(g_image), nv.ptr(g_depth.contiguous() if g_depth is not None else None), nv.ptr(depth), nv.ptr(nears),
+                nv.ptr(fars), nv.ptr(bg), 0 if bg.numel() == 3 else 3, N, nv.ptr(g_ws), nv.ptr(g_depth_in), nv.stream())
+        return g_image, g_depth_in, g_ws, None, None, None
 
 
 class NeRFRenderer(nn.Module):
@@ -73,7 +121,12 @@ class NeRFRenderer(nn.Module):
     @staticmethod
     def _finish(prefix, image, depth, weights_sum, bg_color, nears, fars):
         """Background mix and depth normalisation shared by both branches (renderer_wtmk.py:316-319,369-372);
-        depth is NaN for rays that miss the box (near == far == FLT_MAX), as in the reference."""
+        depth is NaN for rays that miss the box (near == far == FLT_MAX), as in the reference.  One kernel each way on the GPU."""
+        if image.is_cuda and image.dtype == torch.float32:
+            bg = _background_tensor(bg_color, image)
+            if bg is not None:
+                image, depth = _Finish.apply(image, depth, weights_sum, nears, fars, bg)
+                return image.view(*prefix, 3), depth.view(*prefix)
         image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
         depth = torch.clamp(depth - nears, min=0) / (fars - nears)
         return image.view(*prefix, 3), depth.view(*prefix)
@@ -144,7 +197,7 @@ class NeRFRenderer(nn.Module):
                                                                    nears, fars, counter, self.mean_count, perturb, 128, force_all_rays,
                                                                    dt_gamma, max_steps)
         sigmas, rgbs = self(xyzs, dirs, message)
-        return raymarching.composite_rays_train(self.density_scale * sigmas, rgbs, deltas, rays, T_thresh)
+        return raymarching.composite_rays_train(sigmas if self.density_scale == 1 else self.density_scale * sigmas, rgbs, deltas, rays, T_thresh)
 
     def _march_and_composite_eval(self, o, d, message, nears, fars, dt_gamma, perturb, max_steps, T_thresh):
         """Bursts of 1..8 samples over the still-alive rays (renderer_wtmk.py:323-367).  The alive list is compacted

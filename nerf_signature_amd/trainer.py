@@ -10,6 +10,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import _native as nv
 from . import fieldops as fo
 from .dp import GradExchange, world_size
 
@@ -20,6 +21,31 @@ def loss_w_bce(decoded, keys, temp=10.0):
 
 def loss_w_mse(decoded, keys, temp=10.0):
     return torch.mean((decoded * temp - (2 * keys - 1)) ** 2)
+
+
+class _WatermarkLoss(torch.autograd.Function):
+    """(lossi, lossw, loss) of train_step -- MSE, BCE-with-logits at temperature 10, weighted sum -- as one kernel each way
+    (wm_loss_fwd / wm_loss_bwd) instead of ~25 stock elementwise/reduction launches."""
+
+    @staticmethod
+    def forward(ctx, content, gt, decoded, keys, lambda_w, lambda_i, temp):
+        content, gt, decoded, keys = content.contiguous(), gt.contiguous(), decoded.contiguous(), keys.contiguous()
+        losses = torch.empty(3, dtype=torch.float32, device=content.device)
+        d_content, d_decoded = torch.empty_like(content), torch.empty_like(decoded)
+        nv.call("wm_loss_fwd", nv.ptr(content), nv.ptr(gt), content.numel(), nv.ptr(decoded), nv.ptr(keys), decoded.numel(), temp, lambda_w, lambda_i,
+                nv.ptr(losses), nv.ptr(d_content), nv.ptr(d_decoded), nv.stream())
+        ctx.save_for_backward(d_content, d_decoded)
+        ctx.lambdas = (lambda_w, lambda_i)
+        ctx.set_materialize_grads(False)
+        return losses[0], losses[1], losses[2]
+
+    @staticmethod
+    def backward(ctx, g_li, g_lw, g_l):
+        d_content, d_decoded = ctx.saved_tensors
+        g_content, g_decoded = torch.empty_like(d_content), torch.empty_like(d_decoded)
+        nv.call("wm_loss_bwd", *(nv.ptr(None if g is None else g.contiguous()) for g in (g_li, g_lw, g_l)), *ctx.lambdas, nv.ptr(d_content),
+                d_content.numel(), nv.ptr(d_decoded), d_decoded.numel(), nv.ptr(g_content), nv.ptr(g_decoded), nv.stream())
+        return g_content, None, g_decoded, None, None, None, None
 
 
 def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce):
@@ -33,9 +59,14 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
     decoded = model.msg_decoder(model.normalization(pred_rgb.permute(0, 3, 1, 2)))
     gt_rgb = content["images"]
     content_pred_rgb = model.render(content["rays_o"], content["rays_d"], message, **kw)["image"]
-    lossi = ((content_pred_rgb - gt_rgb) ** 2).mean()
-    lossw = loss_w(decoded, message.to(decoded.device).unsqueeze(-1))
-    loss = lambda_w * lossw + lambda_i * lossi
+    keys = message.to(decoded.device).unsqueeze(-1)
+    if loss_w is loss_w_bce and decoded.is_cuda and all(t.dtype == torch.float32 for t in (content_pred_rgb, gt_rgb, decoded, keys)) \
+            and gt_rgb.shape == content_pred_rgb.shape and keys.shape == decoded.shape:
+        lossi, lossw, loss = _WatermarkLoss.apply(content_pred_rgb, gt_rgb, decoded, keys, float(lambda_w), float(lambda_i), 10.0)
+    else:
+        lossi = ((content_pred_rgb - gt_rgb) ** 2).mean()
+        lossw = loss_w(decoded, keys)
+        loss = lambda_w * lossw + lambda_i * lossi
     return pred_rgb, gt_rgb, content_pred_rgb, lossi, lossw, loss
 
 

@@ -407,3 +407,39 @@ def test_fused_decoder_matches_stock_operators(shape, monkeypatch):
             continue
         rel = float((a.double() - b).norm() / (b.norm() + 1e-30))
         assert rel < 2e-3, (n, rel)
+
+
+def test_fused_finish_and_loss_match_stock_operators():
+    """rm_finish_* == renderer_wtmk.py:316-319 and wm_loss_* == utils_wtmk_disen.py:615-640 (MSE + BCE-with-logits(10x) + weighted
+    sum), values and gradients, against the stock operator chains in fp64."""
+    from nerf_signature_amd.renderer import _Finish
+    from nerf_signature_amd.trainer import _WatermarkLoss
+    torch.manual_seed(5)
+    N = 1000
+    image, depth, ws = (torch.rand(N, 3, device="cuda").requires_grad_(True), (torch.rand(N, device="cuda") * 4).requires_grad_(True),
+                        torch.rand(N, device="cuda").requires_grad_(True))
+    nears, fars = torch.rand(N, device="cuda") + 0.5, torch.rand(N, device="cuda") + 3.0
+    for bg in (torch.full((3,), 1.0, device="cuda"), torch.rand(N, 3, device="cuda")):
+        gi, gd = torch.randn(N, 3, device="cuda"), torch.randn(N, device="cuda")
+        o1 = _Finish.apply(image, depth, ws, nears, fars, bg)
+        g1 = torch.autograd.grad(o1, (image, depth, ws), (gi, gd))
+        i64, d64, w64 = (t.detach().double().requires_grad_(True) for t in (image, depth, ws))
+        o0 = (i64 + (1 - w64).unsqueeze(-1) * bg.double(), torch.clamp(d64 - nears.double(), min=0) / (fars - nears).double())
+        g0 = torch.autograd.grad(o0, (i64, d64, w64), (gi.double(), gd.double()))
+        for a, b in zip(o1 + g1, o0 + g0):
+            np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    content, gt = torch.rand(1, 4096, 3, device="cuda").requires_grad_(True), torch.rand(1, 4096, 3, device="cuda")
+    decoded = (torch.randn(32, 1, device="cuda") * 3).requires_grad_(True)     # 10x -> logits up to +-90: the stable form matters
+    keys = (torch.rand(32, 1, device="cuda") > 0.5).float()
+    for sel in range(3):
+        out1 = _WatermarkLoss.apply(content, gt, decoded, keys, 0.7, 1.3, 10.0)
+        g1 = torch.autograd.grad(out1[sel], (content, decoded))
+        c64, d64 = content.detach().double().requires_grad_(True), decoded.detach().double().requires_grad_(True)
+        li = ((c64 - gt.double()) ** 2).mean()
+        lw = torch.nn.functional.binary_cross_entropy_with_logits(d64 * 10.0, keys.double(), reduction="mean")
+        out0 = (li, lw, 0.7 * lw + 1.3 * li)
+        g0 = torch.autograd.grad(out0[sel], (c64, d64), allow_unused=True)
+        np.testing.assert_allclose([float(v) for v in out1], [float(v) for v in out0], rtol=2e-6)
+        for a, b in zip(g1, g0):
+            b = torch.zeros_like(a, dtype=torch.float64) if b is None else b
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-9)
