@@ -266,18 +266,24 @@ int dec_bn_gelu_bwd(const float *dy, const float *x, const float *gamma, const f
  * AdaptiveAvgPool2d(1), Linear(1,1) -- as one chain of fused kernels per direction (one launch per layer each way: MFMA
  * implicit-GEMM convolutions with the BatchNorm statistics in their epilogue and BatchNorm+GELU in the consumer's prologue).
  * Replaces `msg_decoder(img)` and its autograd backward (network_wtmk_tcnn.py:46, utils_wtmk_disen.py:499-505).
- *   img      [B, Cin, H, W] fp32 (NCHW, already normalised); decoded [B] (the Linear output; num_bits = redundancy = 1)
+ *   img      input_mode 0: [B, Cin, H, W] fp32 (NCHW, already normalised), mean/std ignored (may be NULL);
+ *            input_mode 1: the rendered blocks [B, H, W, Cin] as the compositor left them: torch.clamp(0,1), the permute and
+ *            normalize_img(mean, std) of utils_wtmk_disen.py:599-601 are applied on load (host arrays of Cin <= 8 floats), their
+ *            backward in dec_backward; clamped_out (optional, [B, H, W, Cin]) receives the clamped blocks (the step's pred_rgb).
+ *   decoded  [B] (the Linear output; num_bits = redundancy = 1)
  *   params   host array of 29 device pointers: for l = 0..8 {conv weight [Cout,Cin_l,3,3], bn weight, bn bias}, then
  *            linear weight [1,1], linear bias [1].  conv biases are not inputs: BatchNorm's batch-mean subtraction cancels them.
- *   grads    host array of 29 device pointers, same order and shapes (written, not accumulated)
+ *   grads    host array of 29 device pointers, same order and shapes (written, not accumulated); grad_img has img's layout
  *   workspace: dec_workspace_bytes(B, Cin, H, W) bytes (0 = shape not supported: H*W <= 1024, Cin <= 32, LDS limits);
  *            dec_backward reads what dec_forward left there, so the pair must share it and nothing may overwrite it between.
  */
 size_t dec_workspace_bytes(uint32_t B, uint32_t Cin, uint32_t H, uint32_t W);
-int dec_forward(const float *img, const float *const *params_host, uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, float eps,
-                void *workspace, float *decoded, nsig_stream_t stream);
-int dec_backward(const float *grad_decoded, const float *img, const float *const *params_host, uint32_t B, uint32_t Cin, uint32_t H,
-                 uint32_t W, void *workspace, float *const *grads_host, float *grad_img, nsig_stream_t stream);
+int dec_forward(const float *img, uint32_t input_mode, const float *mean_host, const float *std_host, const float *const *params_host,
+                uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, float eps, void *workspace, float *decoded, float *clamped_out,
+                nsig_stream_t stream);
+int dec_backward(const float *grad_decoded, const float *img, uint32_t input_mode, const float *mean_host, const float *std_host,
+                 const float *const *params_host, uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, void *workspace,
+                 float *const *grads_host, float *grad_img, nsig_stream_t stream);
 
 /* ------------------------------------------------------------------ stage-1 (clean model) training, SURVEY.md 8(f) N3 */
 

@@ -59,6 +59,18 @@ struct DecWs {
     uint4 *packed;   // [kSets] fragment sets
 };
 
+// How the image reaches layer 0.  mode 0: [B][Cin][H][W], used as it is.  mode 1: the rendered blocks [B][H][W][Cin] straight
+// from the compositor; clamp to [0,1] and (x - mean_c)/std_c (utils_wtmk_disen.py:599-601: torch.clamp, permute, normalize_img)
+// are applied on load, and their backward in the image-gradient epilogue.
+struct DecInput {
+    uint32_t mode;
+    float mean[8], istd[8];
+};
+__device__ inline float input_value(const float *__restrict__ img, const DecInput &in, uint32_t im, uint32_t c, uint32_t pix, uint32_t Cin, uint32_t P) {
+    if (in.mode == 0) return img[((size_t)im * Cin + c) * P + pix];
+    return (fminf(fmaxf(img[((size_t)im * P + pix) * Cin + c], 0.0f), 1.0f) - in.mean[c]) * in.istd[c];
+}
+
 struct DecParams {
     const float *w[kLayers], *gamma[kLayers], *beta[kLayers], *lin_w, *lin_b;
 };
@@ -255,7 +267,7 @@ __device__ inline void combine_bwd_sums(const Partials &pv, const float *__restr
 // ----------------------------------------------------------------------------- layer 0 forward: Cin -> 64 on the VALU
 
 // grid (npair, B), 256 threads: thread = (co, quarter of the pair's 64 pixels).  K = 9*Cin is too short for MFMA to matter.
-__global__ void __launch_bounds__(256) k_dec_l0_fwd(const float *__restrict__ img, DecParams prm, DecWs ws, DecGeom g) {
+__global__ void __launch_bounds__(256) k_dec_l0_fwd(const float *__restrict__ img, DecInput inp, float *__restrict__ clamped_out, DecParams prm, DecWs ws, DecGeom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const uint32_t pair = blockIdx.x, im = blockIdx.y, t = threadIdx.x;
     const uint32_t W2 = g.W + 2, HW2 = (g.H + 2) * W2, K = 9 * g.Cin;
@@ -265,8 +277,13 @@ __global__ void __launch_bounds__(256) k_dec_l0_fwd(const float *__restrict__ im
     for (uint32_t i = t; i < g.Cin * HW2; i += 256) {
         const uint32_t c = i / HW2, pos = i - c * HW2, hr = pos / W2, hc = pos - hr * W2;
         const bool in = hr >= 1 && hr <= g.H && hc >= 1 && hc <= g.W;
-        s_img[i] = in ? img[((size_t)im * g.Cin + c) * g.P + (hr - 1) * g.W + (hc - 1)] : 0.0f;
+        s_img[i] = in ? input_value(img, inp, im, c, (hr - 1) * g.W + (hc - 1), g.Cin, g.P) : 0.0f;
     }
+    if (clamped_out && inp.mode == 1)   // the clamped render the caller reports (pred_rgb), own pixels only
+        for (uint32_t i = t; i < 64 * g.Cin; i += 256) {
+            const uint32_t e = pair * 64 * g.Cin + i;
+            if (e < g.P * g.Cin) clamped_out[(size_t)im * g.P * g.Cin + e] = fminf(fmaxf(img[(size_t)im * g.P * g.Cin + e], 0.0f), 1.0f);
+        }
     for (uint32_t i = t; i < kC * K; i += 256) s_w[i] = prm.w[0][i];   // [co][ci][3][3] row-major = [co][K]
     __syncthreads();
     const uint32_t co = t & 63, sub = t >> 6, q0 = pair * 64 + sub * 16;
@@ -516,7 +533,8 @@ __device__ inline float2 tile_channel_sums(const float (&va)[16], const float (&
 // Order of global requests (loads return in order): batch partials, the prologue inputs, then the A fragments -- which land
 // while the statistics are combined and the prologue computes.
 template <int MODE>
-__global__ void __launch_bounds__(256) k_dec_conv(int layer, DecParams prm, DecWs ws, DecGeom g, float *__restrict__ grad_img) {
+__global__ void __launch_bounds__(256) k_dec_conv(int layer, DecParams prm, DecWs ws, DecGeom g, float *__restrict__ grad_img,
+                                                  const float *__restrict__ img, DecInput inp) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const uint32_t pair = blockIdx.x, im = blockIdx.y, rb = blockIdx.z, t = threadIdx.x;
     const uint32_t W2 = g.W + 2;
@@ -704,7 +722,15 @@ __global__ void __launch_bounds__(256) k_dec_conv(int layer, DecParams prm, DecW
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint32_t c = 8 * (r >> 2) + 4 * h + (r & 3);
-                if (c < g.Cin) grad_img[((size_t)im * g.Cin + c) * g.P + qo] = acc[r];
+                if (c < g.Cin) {
+                    if (inp.mode == 0) {
+                        grad_img[((size_t)im * g.Cin + c) * g.P + qo] = acc[r];
+                    } else {   // through the normalisation and the clamp (gradient passes where 0 <= x <= 1, as torch.clamp)
+                        const size_t e = ((size_t)im * g.P + qo) * g.Cin + c;
+                        const float x = img[e];
+                        grad_img[e] = (x >= 0.0f && x <= 1.0f) ? acc[r] * inp.istd[c] : 0.0f;
+                    }
+                }
             }
     }
 }
@@ -1040,7 +1066,7 @@ __global__ void __launch_bounds__(256) k_dec_wgrad(DecParams prm, DecWs ws, DecG
 // ----------------------------------------------------------------------------- layer 0 weight gradient (VALU)
 
 // grid (npair, B), 256 threads: thread = (co, quarter); dW0[co][c][tap] partial over the pair's pixels.
-__global__ void __launch_bounds__(256) k_dec_l0_wgrad(const float *__restrict__ img, DecParams prm, DecWs ws, DecGeom g) {
+__global__ void __launch_bounds__(256) k_dec_l0_wgrad(const float *__restrict__ img, DecInput inp, DecParams prm, DecWs ws, DecGeom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const uint32_t pair = blockIdx.x, im = blockIdx.y, t = threadIdx.x;
     const uint32_t W2 = g.W + 2, HW2 = (g.H + 2) * W2;
@@ -1059,7 +1085,7 @@ __global__ void __launch_bounds__(256) k_dec_l0_wgrad(const float *__restrict__ 
     for (uint32_t i = t; i < g.Cin * HW2; i += 256) {
         const uint32_t c = i / HW2, pos = i - c * HW2, hr = pos / W2, hc = pos - hr * W2;
         const bool in = hr >= 1 && hr <= g.H && hc >= 1 && hc <= g.W;
-        s_img[i] = in ? img[((size_t)im * g.Cin + c) * g.P + (hr - 1) * g.W + (hc - 1)] : 0.0f;
+        s_img[i] = in ? input_value(img, inp, im, c, (hr - 1) * g.W + (hc - 1), g.Cin, g.P) : 0.0f;
     }
     Partials pv;
     load_partials(ws.bsum[0], g.B * g.npair, pv);
@@ -1299,9 +1325,25 @@ NSIG_EXPORT size_t dec_workspace_bytes(uint32_t B, uint32_t Cin, uint32_t H, uin
     return carve(nullptr, g, ws);
 }
 
-NSIG_EXPORT int dec_forward(const float *img, const float *const *params, uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, float eps,
-                            void *workspace, float *decoded, nsig_stream_t stream) {
+static int make_input(uint32_t mode, const float *mean, const float *stdev, uint32_t Cin, DecInput &in) {
+    in.mode = mode;
+    for (int c = 0; c < 8; ++c) in.mean[c] = 0.0f, in.istd[c] = 1.0f;
+    if (mode == 0) return 0;
+    if (mode != 1 || !mean || !stdev || Cin > 8) return 1;
+    for (uint32_t c = 0; c < Cin; ++c) {
+        if (!(stdev[c] > 0.0f)) return 1;
+        in.mean[c] = mean[c];
+        in.istd[c] = 1.0f / stdev[c];
+    }
+    return 0;
+}
+
+NSIG_EXPORT int dec_forward(const float *img, uint32_t input_mode, const float *mean_host, const float *std_host, const float *const *params,
+                            uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, float eps, void *workspace, float *decoded, float *clamped_out,
+                            nsig_stream_t stream) {
     NSIG_REQUIRE(img && params && workspace && decoded, "dec_forward: null pointer");
+    DecInput inp;
+    NSIG_REQUIRE(make_input(input_mode, mean_host, std_host, Cin, inp) == 0, "dec_forward: input_mode is 0, or 1 with Cin <= 8 means and positive stds");
     DecGeom g;
     NSIG_REQUIRE(B >= 1 && Cin >= 1 && Cin <= kMaxCin && H >= 1 && W >= 1 && (uint64_t)H * W <= kMaxP && (uint64_t)B * H * W > 1 &&
                      make_geom(B, Cin, H, W, eps, g),
@@ -1314,16 +1356,19 @@ NSIG_EXPORT int dec_forward(const float *img, const float *const *params, uint32
     hipStream_t s = as_stream(stream);
     const dim3 grid(g.npair, B);
     k_dec_pack<<<kSets * 2 * kKS, 64, 0, s>>>(prm, ws.packed, Cin);
-    k_dec_l0_fwd<<<grid, 256, l0_lds(g), s>>>(img, prm, ws, g);
-    for (int l = 1; l <= 7; ++l) k_dec_conv<kFwd><<<dim3(g.npair, B, 2), 256, conv_lds(g), s>>>(l, prm, ws, g, nullptr);
+    k_dec_l0_fwd<<<grid, 256, l0_lds(g), s>>>(img, inp, clamped_out, prm, ws, g);
+    for (int l = 1; l <= 7; ++l) k_dec_conv<kFwd><<<dim3(g.npair, B, 2), 256, conv_lds(g), s>>>(l, prm, ws, g, nullptr, nullptr, inp);
     k_dec_l8_fwd<<<grid, 256, l8_lds(g), s>>>(prm, ws, g);
     k_dec_head_fwd<<<B, 256, 0, s>>>(prm, ws, g, decoded);
     return check_launch("dec_forward");
 }
 
-NSIG_EXPORT int dec_backward(const float *grad_decoded, const float *img, const float *const *params, uint32_t B, uint32_t Cin, uint32_t H,
-                             uint32_t W, void *workspace, float *const *grads, float *grad_img, nsig_stream_t stream) {
+NSIG_EXPORT int dec_backward(const float *grad_decoded, const float *img, uint32_t input_mode, const float *mean_host, const float *std_host,
+                             const float *const *params, uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, void *workspace, float *const *grads,
+                             float *grad_img, nsig_stream_t stream) {
     NSIG_REQUIRE(grad_decoded && img && params && workspace && grads && grad_img, "dec_backward: null pointer");
+    DecInput inp;
+    NSIG_REQUIRE(make_input(input_mode, mean_host, std_host, Cin, inp) == 0, "dec_backward: input_mode is 0, or 1 with Cin <= 8 means and positive stds");
     DecGeom g;
     NSIG_REQUIRE(B >= 1 && Cin >= 1 && Cin <= kMaxCin && H >= 1 && W >= 1 && (uint64_t)H * W <= kMaxP && make_geom(B, Cin, H, W, 0.0f, g),
                  "dec_backward: unsupported image shape");
@@ -1346,10 +1391,10 @@ NSIG_EXPORT int dec_backward(const float *grad_decoded, const float *img, const 
     const dim3 grid(g.npair, B);
     k_dec_head_bwd<<<B, 256, 0, s>>>(grad_decoded, prm, ws, g);
     k_dec_l8_bwd<<<grid, 256, l8b_lds(g), s>>>(prm, ws, g);
-    for (int l = 7; l >= 1; --l) k_dec_conv<kDgrad><<<dim3(g.npair, B, 2), 256, conv_lds(g), s>>>(l, prm, ws, g, nullptr);
-    k_dec_conv<kDgradImg><<<grid, 256, conv_lds(g), s>>>(0, prm, ws, g, grad_img);
+    for (int l = 7; l >= 1; --l) k_dec_conv<kDgrad><<<dim3(g.npair, B, 2), 256, conv_lds(g), s>>>(l, prm, ws, g, nullptr, nullptr, inp);
+    k_dec_conv<kDgradImg><<<grid, 256, conv_lds(g), s>>>(0, prm, ws, g, grad_img, img, inp);
     k_dec_wgrad<<<dim3(g.nband, B, 7), 256, wgrad_lds(g), s>>>(prm, ws, g);
-    k_dec_l0_wgrad<<<grid, 256, l0w_lds(g), s>>>(img, prm, ws, g);
+    k_dec_l0_wgrad<<<grid, 256, l0w_lds(g), s>>>(img, inp, prm, ws, g);
     k_dec_wreduce<<<dim3(kC, 7), 576, 0, s>>>(ws, gr, g);
     k_dec_sreduce<<<16 + ceil_div(kC * 9 * Cin, 64) + 9 + 1, 256, 0, s>>>(grad_decoded, ws, gr, g);
     return check_launch("dec_backward");

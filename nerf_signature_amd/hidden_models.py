@@ -7,6 +7,7 @@ fused (dec_bn_gelu_fwd/_bwd).  Either way a convolution's bias -- which BatchNor
 not added, and its gradient (identically zero) is reported as None.  NERFSIG_DECODER=torch forces the stock operator chain.
 Module/parameter names reproduce the reference's state_dict keys
 (`layers.{0..8}.layers.{0,1}.{weight,bias}`, `linear.{weight,bias}`)."""
+import ctypes
 import os
 
 import torch
@@ -75,28 +76,42 @@ class _BNGelu(torch.autograd.Function):
 
 class _FusedDecoder(torch.autograd.Function):
     """decoded = Linear(AvgPool(ConvBNRelu^9(img))) through dec_forward / dec_backward.  params: for each of the 9 blocks
-    (conv weight, bn weight, bn bias), then the linear weight and bias."""
+    (conv weight, bn weight, bn bias), then the linear weight and bias.
+    rendered=False: img is the normalised [B,Cin,H,W] tensor.  rendered=True: img is the compositor's [B,H,W,Cin] output and the
+    clamp / permute / normalize_img of the training step happen inside layer 0; the second output is the clamped image."""
 
     @staticmethod
-    def forward(ctx, img, eps, *params):
-        B, Cin, H, W = img.shape
+    def forward(ctx, img, eps, rendered, *params):
         img = img.contiguous()
+        if rendered:
+            B, H, W, Cin = img.shape
+            mean, std = (ctypes.c_float * Cin)(*_MEAN[:Cin]), (ctypes.c_float * Cin)(*_STD[:Cin])
+            clamped = torch.empty_like(img)
+        else:
+            B, Cin, H, W = img.shape
+            mean = std = clamped = None
         ps = [p.detach().contiguous() for p in params]
         ws = torch.empty(nv.fn("dec_workspace_bytes")(B, Cin, H, W), dtype=torch.uint8, device=img.device)
         out = torch.empty(B, dtype=torch.float32, device=img.device)
-        nv.call("dec_forward", nv.ptr(img), nv.ptr_array(ps), B, Cin, H, W, eps, nv.ptr(ws), nv.ptr(out), nv.stream())
+        nv.call("dec_forward", nv.ptr(img), int(rendered), mean, std, nv.ptr_array(ps), B, Cin, H, W, eps, nv.ptr(ws), nv.ptr(out), nv.ptr(clamped),
+                nv.stream())
         ctx.save_for_backward(img, ws, *ps)
+        ctx.geom = (B, Cin, H, W, bool(rendered))
+        if rendered:
+            ctx.mark_non_differentiable(clamped)
+            return out.view(B, 1), clamped
         return out.view(B, 1)
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, *_):
         img, ws, *ps = ctx.saved_tensors
-        B, Cin, H, W = img.shape
+        B, Cin, H, W, rendered = ctx.geom
+        mean, std = ((ctypes.c_float * Cin)(*_MEAN[:Cin]), (ctypes.c_float * Cin)(*_STD[:Cin])) if rendered else (None, None)
         grads = [torch.empty_like(p) for p in ps]
         grad_img = torch.empty_like(img)
-        nv.call("dec_backward", nv.ptr(grad_out.contiguous().view(-1)), nv.ptr(img), nv.ptr_array(ps), B, Cin, H, W, nv.ptr(ws),
-                nv.ptr_array(grads), nv.ptr(grad_img), nv.stream())
-        return (grad_img, None, *grads)
+        nv.call("dec_backward", nv.ptr(grad_out.contiguous().view(-1)), nv.ptr(img), int(rendered), mean, std, nv.ptr_array(ps), B, Cin, H, W,
+                nv.ptr(ws), nv.ptr_array(grads), nv.ptr(grad_img), nv.stream())
+        return (grad_img, None, None, *grads)
 
 
 class ConvBNRelu(nn.Module):
@@ -131,28 +146,38 @@ class HiddenDecoder_multi_views(nn.Module):
         self.num_bits = num_bits
         self.redundancy = redundancy
 
-    def _fused_params(self, x):
+    def _fused_params(self, B, Cin, H, W, like):
         """The 29 parameters dec_forward takes, or None when this decoder / input is not the shape the fused chain implements."""
-        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4) or os.environ.get("NERFSIG_DECODER", "") == "torch":
+        if not (like.is_cuda and like.dtype == torch.float32) or os.environ.get("NERFSIG_DECODER", "") == "torch":
             return None
         blocks = list(self.layers)[:-1]
         if len(blocks) != 9 or self.num_bits * self.redundancy != 1:
             return None
         convs, bns = [b.layers[0] for b in blocks], [b.layers[1] for b in blocks]
-        want = [(x.shape[1], 64)] + [(64, 64)] * 7 + [(64, 1)]
+        want = [(Cin, 64)] + [(64, 64)] * 7 + [(64, 1)]
         if [(c.in_channels, c.out_channels) for c in convs] != want or len({bn.eps for bn in bns}) != 1:
             return None
-        if any(p.dtype != torch.float32 for p in self.parameters()) or not nv.fn("dec_workspace_bytes")(*x.shape):
+        if any(p.dtype != torch.float32 for p in self.parameters()) or not nv.fn("dec_workspace_bytes")(B, Cin, H, W):
             return None
         params = []
         for c, bn in zip(convs, bns):
             params += [c.weight, bn.weight, bn.bias]
         return bns[0].eps, params + [self.linear.weight, self.linear.bias]
 
-    def forward(self, img_w):
-        fused = self._fused_params(img_w)
+    def decode_rendered(self, image):
+        """The training step's `msg_decoder(normalize_img(clamp(image, 0, 1).permute(0, 3, 1, 2)))` for the compositor's
+        [B, H, W, 3] blocks (utils_wtmk_disen.py:599-603) -> (decoded [B, 1], clamped image).  On the GPU the clamp, the
+        layout change and the normalisation are part of the fused decoder's first layer."""
+        fused = self._fused_params(image.shape[0], image.shape[3], image.shape[1], image.shape[2], image) if image.dim() == 4 and image.shape[3] <= 3 else None
         if fused is not None:
-            return _FusedDecoder.apply(img_w, fused[0], *fused[1])   # num_bits = redundancy = 1: the view/sum below is the identity
+            return _FusedDecoder.apply(image, fused[0], True, *fused[1])
+        pred = torch.clamp(image, min=0, max=1)
+        return self(normalize_img(pred.permute(0, 3, 1, 2))), pred
+
+    def forward(self, img_w):
+        fused = self._fused_params(*img_w.shape, img_w) if img_w.dim() == 4 else None
+        if fused is not None:
+            return _FusedDecoder.apply(img_w, fused[0], False, *fused[1])   # num_bits = redundancy = 1: the view/sum below is the identity
         x = self.layers(img_w).squeeze(-1).squeeze(-1)
         x = self.linear(x)
         x = x.view(-1, self.num_bits, self.redundancy)

@@ -13,6 +13,7 @@ import torch.nn.functional as F
 from . import _native as nv
 from . import fieldops as fo
 from .dp import GradExchange, world_size
+from .hidden_models import normalize_img
 
 
 def loss_w_bce(decoded, keys, temp=10.0):
@@ -55,8 +56,11 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
     kw = dict(render_kwargs)
     kw.update(staged=False, bg_color=1, perturb=False, force_all_rays=True)
     outputs = model.render(wm["rays_o_block"], wm["rays_d_block"], message, **kw)
-    pred_rgb = torch.clamp(outputs["image"], min=0, max=1)
-    decoded = model.msg_decoder(model.normalization(pred_rgb.permute(0, 3, 1, 2)))
+    if model.normalization is normalize_img and hasattr(model.msg_decoder, "decode_rendered"):
+        decoded, pred_rgb = model.msg_decoder.decode_rendered(outputs["image"])    # clamp + permute + normalise inside layer 0
+    else:
+        pred_rgb = torch.clamp(outputs["image"], min=0, max=1)
+        decoded = model.msg_decoder(model.normalization(pred_rgb.permute(0, 3, 1, 2)))
     gt_rgb = content["images"]
     content_pred_rgb = model.render(content["rays_o"], content["rays_d"], message, **kw)["image"]
     keys = message.to(decoded.device).unsqueeze(-1)

@@ -390,7 +390,7 @@ def test_fused_decoder_matches_stock_operators(shape, monkeypatch):
             p.add_(0.1 * torch.randn_like(p))
     img = torch.randn(B, Cin, H, W, device="cuda", requires_grad=True)
     gout = torch.randn(B, 1, device="cuda")
-    assert dec._fused_params(img) is not None
+    assert dec._fused_params(*img.shape, img) is not None
     out1 = dec(img)
     g1 = torch.autograd.grad(out1, [img] + [p for p in dec.parameters()], gout, allow_unused=True)
     monkeypatch.setenv("NERFSIG_DECODER", "torch")
@@ -443,3 +443,27 @@ def test_fused_finish_and_loss_match_stock_operators():
         for a, b in zip(g1, g0):
             b = torch.zeros_like(a, dtype=torch.float64) if b is None else b
             np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-9)
+
+
+def test_fused_decoder_on_rendered_blocks_matches_clamp_permute_normalize():
+    """decode_rendered == msg_decoder(normalize_img(clamp(image, 0, 1).permute(0, 3, 1, 2))) of utils_wtmk_disen.py:599-603,
+    including the gradient through the clamp (zero outside [0, 1])."""
+    from nerf_signature_amd.hidden_models import get_hidden_decoder_multi_views, normalize_img
+    torch.manual_seed(2)
+    dec = get_hidden_decoder_multi_views(num_bits=1, redundancy=1, num_blocks=8, input_ch=3, channels=64).cuda()
+    image = (torch.rand(32, 12, 12, 3, device="cuda") * 1.4 - 0.2).requires_grad_(True)   # some values outside [0, 1]
+    gout = torch.randn(32, 1, device="cuda")
+    out1, pred1 = dec.decode_rendered(image)
+    g1 = torch.autograd.grad(out1, [image] + [p for n, p in dec.named_parameters() if not n.endswith("layers.0.bias")], gout)
+    dec64, im64 = dec.double(), image.detach().double().requires_grad_(True)
+    pred0 = torch.clamp(im64, min=0, max=1)
+    x = (pred0.permute(0, 3, 1, 2) - torch.tensor([0.485, 0.456, 0.406], dtype=torch.float64, device="cuda").view(-1, 1, 1)) / \
+        torch.tensor([0.229, 0.224, 0.225], dtype=torch.float64, device="cuda").view(-1, 1, 1)
+    out0 = dec64.linear(dec64.layers(x).squeeze(-1).squeeze(-1))
+    g0 = torch.autograd.grad(out0, [im64] + [p for n, p in dec64.named_parameters() if not n.endswith("layers.0.bias")], gout.double())
+    assert torch.equal(pred1.double(), pred0.detach()) and not pred1.requires_grad
+    np.testing.assert_allclose(out1.detach().cpu().numpy(), out0.detach().cpu().numpy(), rtol=0, atol=1e-3)
+    outside = (image.detach() < 0) | (image.detach() > 1)
+    assert outside.any() and float(g1[0][outside].abs().max()) == 0.0
+    for a, b in zip(g1, g0):
+        assert float((a.double() - b).norm() / b.norm()) < 2e-3
