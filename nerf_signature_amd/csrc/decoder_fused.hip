@@ -264,29 +264,62 @@ __device__ inline void combine_bwd_sums(const Partials &pv, const float *__restr
     __syncthreads();
 }
 
+// ----------------------------------------------------------------------------- staging: what a tile pair reads
+
+// Rows of the halo image an (image, pair) workgroup stages: staged row r <-> image row py0 + r - 1.
+struct PairRows {
+    uint32_t q0, q1, py0, nrow;
+};
+__host__ __device__ inline PairRows pair_rows(uint32_t pair, uint32_t P, uint32_t W) {
+    PairRows r;
+    r.q0 = pair * 64;
+    r.q1 = (r.q0 + 64 < P ? r.q0 + 64 : P) - 1;
+    r.py0 = r.q0 / W;
+    r.nrow = r.q1 / W - r.py0 + 3;
+    return r;
+}
+
+// Staged position -> pixel index, or -1 for the zero padding.
+__device__ inline int staged_pixel(uint32_t pos, uint32_t W2, uint32_t py0, const DecGeom &g) {
+    const uint32_t hr = (pos * g.magic_w2) >> 16, hc = pos - hr * W2;   // pos / W2 (magic verified by make_geom for every staged pos)
+    const int iy = (int)(py0 + hr) - 1, ix = (int)hc - 1;
+    return (iy >= 0 && iy < (int)g.H && ix >= 0 && ix < (int)g.W) ? iy * (int)g.W + ix : -1;
+}
+
 // ----------------------------------------------------------------------------- layer 0 forward: Cin -> 64 on the VALU
 
 // grid (npair, B), 256 threads: thread = (co, quarter of the pair's 64 pixels).  K = 9*Cin is too short for MFMA to matter.
+// Only the rows the pair touches are staged (rows_max x (W+2) positions per channel); kCin > 0: the thread's 9*kCin weights
+// live in registers (the watermark path has kCin = 3), kCin = 0: any Cin, weights read from LDS.
+template <int kCin>
 __global__ void __launch_bounds__(256) k_dec_l0_fwd(const float *__restrict__ img, DecInput inp, float *__restrict__ clamped_out, DecParams prm, DecWs ws, DecGeom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const uint32_t pair = blockIdx.x, im = blockIdx.y, t = threadIdx.x;
-    const uint32_t W2 = g.W + 2, HW2 = (g.H + 2) * W2, K = 9 * g.Cin;
-    float *s_img = smem;                    // [Cin][(H+2)(W+2)] zero-padded
-    float *s_w = s_img + g.Cin * HW2;       // [64][K]
-    float *s_red = s_w + kC * K;            // [4][64]
-    for (uint32_t i = t; i < g.Cin * HW2; i += 256) {
-        const uint32_t c = i / HW2, pos = i - c * HW2, hr = pos / W2, hc = pos - hr * W2;
-        const bool in = hr >= 1 && hr <= g.H && hc >= 1 && hc <= g.W;
-        s_img[i] = in ? input_value(img, inp, im, c, (hr - 1) * g.W + (hc - 1), g.Cin, g.P) : 0.0f;
-    }
-    if (clamped_out && inp.mode == 1)   // the clamped render the caller reports (pred_rgb), own pixels only
-        for (uint32_t i = t; i < 64 * g.Cin; i += 256) {
-            const uint32_t e = pair * 64 * g.Cin + i;
-            if (e < g.P * g.Cin) clamped_out[(size_t)im * g.P * g.Cin + e] = fminf(fmaxf(img[(size_t)im * g.P * g.Cin + e], 0.0f), 1.0f);
-        }
-    for (uint32_t i = t; i < kC * K; i += 256) s_w[i] = prm.w[0][i];   // [co][ci][3][3] row-major = [co][K]
-    __syncthreads();
+    const uint32_t W2 = g.W + 2, Cin = kCin ? kCin : g.Cin, K = 9 * Cin;
+    const PairRows pr = pair_rows(pair, g.P, g.W);
+    const uint32_t npos = pr.nrow * W2, cap = g.rows_max * W2;
+    float *s_img = smem;                    // [Cin][rows_max*(W+2)] zero-padded rows of the pair
+    float *s_red = s_img + Cin * cap;       // [4][64]
+    float *s_w = s_red + 256;               // [64][K] (kCin == 0 only)
     const uint32_t co = t & 63, sub = t >> 6, q0 = pair * 64 + sub * 16;
+    float wreg[kCin ? 9 * kCin : 1];
+    if (kCin) {
+#pragma unroll
+        for (int k = 0; k < 9 * kCin; ++k) wreg[k] = prm.w[0][co * K + k];   // [co][ci][3][3] row-major = [co][K]
+    } else {
+        for (uint32_t i = t; i < kC * K; i += 256) s_w[i] = prm.w[0][i];
+    }
+    for (uint32_t c = 0; c < Cin; ++c)
+        for (uint32_t pos = t; pos < npos; pos += 256) {
+            const int q = staged_pixel(pos, W2, pr.py0, g);
+            s_img[c * cap + pos] = q >= 0 ? input_value(img, inp, im, c, q, Cin, g.P) : 0.0f;
+        }
+    if (clamped_out && inp.mode == 1)   // the clamped render the caller reports (pred_rgb), own pixels only
+        for (uint32_t i = t; i < 64 * Cin; i += 256) {
+            const uint32_t e = pair * 64 * Cin + i;
+            if (e < g.P * Cin) clamped_out[(size_t)im * g.P * Cin + e] = fminf(fmaxf(img[(size_t)im * g.P * Cin + e], 0.0f), 1.0f);
+        }
+    __syncthreads();
     float v[16];
     float s = 0.0f;
 #pragma unroll
@@ -294,12 +327,18 @@ __global__ void __launch_bounds__(256) k_dec_l0_fwd(const float *__restrict__ im
         const uint32_t q = q0 + j;
         v[j] = 0.0f;
         if (q < g.P) {
-            const uint32_t py = q / g.W, px = q - py * g.W;
+            const uint32_t py = q / g.W, px = q - py * g.W, hp0 = (py - pr.py0) * W2 + px;
             float acc = 0.0f;
-            for (uint32_t c = 0; c < g.Cin; ++c)
+            if (kCin) {
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap)
-                    acc += s_w[co * K + c * 9 + tap] * s_img[c * HW2 + (py + tap / 3) * W2 + px + tap % 3];
+                for (int c = 0; c < (kCin ? kCin : 1); ++c)
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) acc += wreg[c * 9 + tap] * s_img[c * cap + hp0 + (tap / 3) * W2 + tap % 3];
+            } else {
+                for (uint32_t c = 0; c < Cin; ++c)
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) acc += s_w[co * K + c * 9 + tap] * s_img[c * cap + hp0 + (tap / 3) * W2 + tap % 3];
+            }
             v[j] = acc;
             ws.x[0][((size_t)im * g.P + q) * kC + co] = acc;
             s += acc;
@@ -322,28 +361,6 @@ __global__ void __launch_bounds__(256) k_dec_l0_fwd(const float *__restrict__ im
         po[0] = ts;
         po[1] = s_red[co] + s_red[64 + co] + s_red[128 + co] + s_red[192 + co];
     }
-}
-
-// ----------------------------------------------------------------------------- staging: what a tile pair reads
-
-// Rows of the halo image an (image, pair) workgroup stages: staged row r <-> image row py0 + r - 1.
-struct PairRows {
-    uint32_t q0, q1, py0, nrow;
-};
-__host__ __device__ inline PairRows pair_rows(uint32_t pair, uint32_t P, uint32_t W) {
-    PairRows r;
-    r.q0 = pair * 64;
-    r.q1 = (r.q0 + 64 < P ? r.q0 + 64 : P) - 1;
-    r.py0 = r.q0 / W;
-    r.nrow = r.q1 / W - r.py0 + 3;
-    return r;
-}
-
-// Staged position -> pixel index, or -1 for the zero padding.
-__device__ inline int staged_pixel(uint32_t pos, uint32_t W2, uint32_t py0, const DecGeom &g) {
-    const uint32_t hr = (pos * g.magic_w2) >> 16, hc = pos - hr * W2;   // pos / W2 (magic verified by make_geom for every staged pos)
-    const int iy = (int)(py0 + hr) - 1, ix = (int)hc - 1;
-    return (iy >= 0 && iy < (int)g.H && ix >= 0 && ix < (int)g.W) ? iy * (int)g.W + ix : -1;
 }
 
 // a = GELU(BN(x)) for 4 channels of one pixel; tab = [mean | inv | gamma | beta].
@@ -737,20 +754,35 @@ __global__ void __launch_bounds__(256) k_dec_conv(int layer, DecParams prm, DecW
 
 // ----------------------------------------------------------------------------- layer 8 (64 -> 1) and the head
 
-// grid (npair, B), 256 threads.  Prologue as kFwd (a_7 kept fp32 in LDS, [pos][64]); wave = 16 pixels, lane = input channel.
+// grid (npair, B), 256 threads.  Prologue as kFwd (a_7 kept fp32 in LDS, [pos][64]); wave = 16 pixels, lane = input channel;
+// the 64-channel sums of the wave's 16 pixels go through one LDS transpose instead of 16 x 6 dependent shuffles.
 __global__ void __launch_bounds__(256) k_dec_l8_fwd(DecParams prm, DecWs ws, DecGeom g) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const uint32_t pair = blockIdx.x, im = blockIdx.y, t = threadIdx.x, W2 = g.W + 2;
     const PairRows pr = pair_rows(pair, g.P, g.W);
+    const uint32_t total = pr.nrow * W2 * 16, img_off = im * g.P * kC;
     float *s_a = reinterpret_cast<float *>(smem_raw);          // [rows_max*W2][64]
     float *s_tab = s_a + (size_t)g.rows_max * W2 * kC;          // [4][64]
     float *s_red = s_tab + 4 * 64;                              // [1024]
+    float *s_t = s_red + 1024;                                  // [4 waves][16][65]
     const int wave = t >> 6, lane = t & 63;
+
+    // ---- requests: partials, the first batch of x_7, the layer's 9 weights
+    Partials pv;
+    load_partials(ws.stat[7], g.B * g.npair, pv);
+    constexpr int kPre = 8;
+    float4 v0[kPre];
+    int q[kPre];
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+        const uint32_t i = t + 256 * u;
+        q[u] = i < total ? staged_pixel(i >> 4, W2, pr.py0, g) : -1;
+        v0[u] = q[u] >= 0 ? *reinterpret_cast<const float4 *>(ws.x[7] + img_off + q[u] * kC + (i & 15) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     float w8[9];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) w8[tap] = prm.w[8][lane * 9 + tap];   // [1][64][3][3]
-    Partials pv;
-    load_partials(ws.stat[7], g.B * g.npair, pv);
+
     combine_fwd_stats(pv, g, s_red, s_tab, s_tab + 64);
     if (t < 64) {
         s_tab[128 + t] = prm.gamma[7][t];
@@ -761,22 +793,49 @@ __global__ void __launch_bounds__(256) k_dec_l8_fwd(DecParams prm, DecWs ws, Dec
         }
     }
     __syncthreads();
-    stage_forward<true>(ws.x[7], ws.xhat[7], ws.gprime[7], ws.act[7], im, pr, g, s_tab, nullptr, nullptr, s_a);
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+        const uint32_t i = t + 256 * u, pos = i >> 4, cg = i & 15;
+        if (i >= total) break;
+        float xh[4], a[4] = {0.f, 0.f, 0.f, 0.f}, gp[4];
+        if (q[u] >= 0) {
+            bn_gelu4(v0[u], cg, s_tab, xh, a, gp);
+            if ((uint32_t)q[u] >= pr.q0 && (uint32_t)q[u] <= pr.q1) {
+                const uint32_t e = img_off + q[u] * kC + cg * 4;
+                *reinterpret_cast<float4 *>(ws.xhat[7] + e) = make_float4(xh[0], xh[1], xh[2], xh[3]);
+                *reinterpret_cast<float4 *>(ws.gprime[7] + e) = make_float4(gp[0], gp[1], gp[2], gp[3]);
+                *reinterpret_cast<float4 *>(ws.act[7] + e) = make_float4(a[0], a[1], a[2], a[3]);
+            }
+        }
+        *reinterpret_cast<float4 *>(s_a + (size_t)pos * kC + cg * 4) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+    if (total > 256 * kPre) stage_forward<true>(ws.x[7], ws.xhat[7], ws.gprime[7], ws.act[7], im, pr, g, s_tab, nullptr, nullptr, s_a, 256 * kPre);
     __syncthreads();
-    float *s_x = s_red;   // 64 outputs of the pair
+
+    // ---- lane = input channel: its contribution to each of the wave's 16 pixels, then the channel sum by transpose
+    float *tw = s_t + wave * 16 * 65;
+#pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const uint32_t q = pr.q0 + 16 * wave + j;
+        const uint32_t qo = pr.q0 + 16 * wave + j;
         float v = 0.0f;
-        if (q < g.P) {
-            const uint32_t py = q / g.W, px = q - py * g.W, hp0 = (py - pr.py0) * W2 + px;
+        if (qo < g.P) {
+            const uint32_t py = qo / g.W, px = qo - py * g.W, hp0 = (py - pr.py0) * W2 + px;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) v += w8[tap] * s_a[(size_t)(hp0 + (tap / 3) * W2 + tap % 3) * kC + lane];
         }
-        v = wave_sum64(v);
-        if (lane == 0) {
-            s_x[16 * wave + j] = v;
-            if (q < g.P) ws.x[8][(size_t)im * g.P + q] = v;
-        }
+        tw[j * 65 + lane] = v;
+    }
+    const int j = lane & 15, part = lane >> 4;
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum += tw[j * 65 + part * 16 + k];
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    float *s_x = s_red;   // 64 outputs of the pair
+    if (part == 0) {
+        const uint32_t qo = pr.q0 + 16 * wave + j;
+        s_x[16 * wave + j] = sum;
+        if (qo < g.P) ws.x[8][(size_t)im * g.P + qo] = sum;
     }
     __syncthreads();
     if (t < 64) {   // one wave: the pair's (sum, M2)
@@ -850,7 +909,8 @@ __global__ void __launch_bounds__(256) k_dec_head_bwd(const float *__restrict__ 
     }
 }
 
-// grid (npair, B), 256 threads: layer 8 backward.  dx_8 (one channel) in LDS; wave = 16 pixels, lane = channel of layer 7:
+// grid (npair, B), 256 threads: layer 8 backward.  dx_8 (one channel) and a_7 (the pair's rows, halo included) in LDS;
+// wave = 16 pixels, lane = channel of layer 7:
 //   G_7[q][ci] = sum_tap W8[ci][tap] dx_8[q - (tap - 1)]  ->  dz_7 = G_7 * GELU'(z_7) and its pair sums,
 //   dW8[ci][tap] partial = sum_q dx_8[q] a_7[q + (tap - 1)][ci].
 __global__ void __launch_bounds__(256) k_dec_l8_bwd(DecParams prm, DecWs ws, DecGeom g) {
@@ -858,68 +918,82 @@ __global__ void __launch_bounds__(256) k_dec_l8_bwd(DecParams prm, DecWs ws, Dec
     __shared__ float scratch[4];
     const uint32_t pair = blockIdx.x, im = blockIdx.y, t = threadIdx.x, W2 = g.W + 2;
     const PairRows pr = pair_rows(pair, g.P, g.W);
-    const uint32_t npos = pr.nrow * W2, n = g.B * g.npair;
-    float *s_dx = reinterpret_cast<float *>(smem_raw);   // [rows_max*W2]
-    float *s_red = s_dx + g.rows_max * W2;                // [4][64][11]
+    const uint32_t npos = pr.nrow * W2, n = g.B * g.npair, total = npos * 16, img_off = im * g.P * kC;
+    float *s_a = reinterpret_cast<float *>(smem_raw);           // [rows_max*W2][64]
+    float *s_dx = s_a + (size_t)g.rows_max * W2 * kC;            // [rows_max*W2]
+    float *s_red = s_dx + g.rows_max * W2;                       // [4][64][11]
     const float N = (float)(g.B * g.P);
     const int wave = t >> 6, lane = t & 63;
+
+    // ---- requests: sums of layer 8, dz_8/xhat_8 of the staged positions, a_7 rows, the wave's epilogue operands
+    float s1 = 0.0f, s2 = 0.0f;
+    for (uint32_t i = t; i < n; i += 256) {
+        const float2 v = reinterpret_cast<const float2 *>(ws.bsum[8])[i];
+        s1 += v.x;
+        s2 += v.y;
+    }
+    float dzv[2], xhv[2];
+    int qd[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {   // npos <= 512 covers every supported shape (checked on the host)
+        const uint32_t pos = t + 256 * u;
+        qd[u] = pos < npos ? staged_pixel(pos, W2, pr.py0, g) : -1;
+        dzv[u] = qd[u] >= 0 ? ws.dz[8][(size_t)im * g.P + qd[u]] : 0.0f;
+        xhv[u] = qd[u] >= 0 ? ws.xhat[8][(size_t)im * g.P + qd[u]] : 0.0f;
+    }
+    for (uint32_t base = t; base < total; base += 256 * kBatch) {
+        float4 v[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const uint32_t i = base + 256 * u;
+            const int q = i < total ? staged_pixel(i >> 4, W2, pr.py0, g) : -1;
+            v[u] = q >= 0 ? *reinterpret_cast<const float4 *>(ws.act[7] + img_off + q * kC + (i & 15) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const uint32_t i = base + 256 * u;
+            if (i < total) *reinterpret_cast<float4 *>(s_a + (size_t)(i >> 4) * kC + (i & 15) * 4) = v[u];
+        }
+    }
+    float gp[16], xh[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t q = pr.q0 + 16 * wave + j;
+        gp[j] = q < g.P ? ws.gprime[7][img_off + q * kC + lane] : 0.0f;
+        xh[j] = q < g.P ? ws.xhat[7][img_off + q * kC + lane] : 0.0f;
+    }
     float w8[9], dw[9];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         w8[tap] = prm.w[8][lane * 9 + tap];
         dw[tap] = 0.0f;
     }
-    float s1 = 0.0f, s2 = 0.0f;
-    for (uint32_t i = t; i < n; i += 256) {
-        s1 += ws.bsum[8][(size_t)i * 2];
-        s2 += ws.bsum[8][(size_t)i * 2 + 1];
-    }
     const float S1 = block_sum256(s1, scratch), S2 = block_sum256(s2, scratch);
     const float k8 = prm.gamma[8][0] * ws.minv[8][1] / N;
-    for (uint32_t pos = t; pos < npos; pos += 256) {
-        const int q = staged_pixel(pos, W2, pr.py0, g);
-        float v = 0.0f;
-        if (q >= 0) {
-            const size_t e = (size_t)im * g.P + q;
-            v = k8 * (N * ws.dz[8][e] - S1 - ws.xhat[8][e] * S2);
-        }
-        s_dx[pos] = v;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const uint32_t pos = t + 256 * u;
+        if (pos < npos) s_dx[pos] = qd[u] >= 0 ? k8 * (N * dzv[u] - S1 - xhv[u] * S2) : 0.0f;
     }
     __syncthreads();
+
     float b1 = 0.0f, b2 = 0.0f;
-    for (int j0 = 0; j0 < 16; j0 += 4) {
-        // four pixels' operands in flight together
-        float gp[4], xh[4], an[4][9];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t q = pr.q0 + 16 * wave + j0 + u;
-            const bool ok = q < g.P;
-            const uint32_t qq = ok ? q : pr.q0, py = qq / g.W, px = qq - py * g.W;
-            const size_t e = ((size_t)im * g.P + qq) * kC + lane;
-            gp[u] = ok ? ws.gprime[7][e] : 0.0f;
-            xh[u] = ok ? ws.xhat[7][e] : 0.0f;
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t q = pr.q0 + 16 * wave + j;
+        if (q >= g.P) break;
+        const uint32_t py = q / g.W, px = q - py * g.W, hp0 = (py - pr.py0) * W2 + px, hp = hp0 + W2 + 1;   // hp: the pixel itself
+        float G = 0.0f;
+        const float dxq = s_dx[hp];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int ny = (int)py + tap / 3 - 1, nx = (int)px + tap % 3 - 1;
-                an[u][tap] = (ok && ny >= 0 && ny < (int)g.H && nx >= 0 && nx < (int)g.W) ? ws.act[7][((size_t)im * g.P + ny * g.W + nx) * kC + lane] : 0.0f;
-            }
+        for (int tap = 0; tap < 9; ++tap) {
+            G += w8[tap] * s_dx[hp + (1 - tap / 3) * (int)W2 + (1 - tap % 3)];
+            dw[tap] += dxq * s_a[(size_t)(hp0 + (tap / 3) * W2 + tap % 3) * kC + lane];
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t q = pr.q0 + 16 * wave + j0 + u;
-            if (q >= g.P) break;
-            const uint32_t py = q / g.W, px = q - py * g.W, hp = (py - pr.py0 + 1) * W2 + px + 1;   // the pixel itself, staged coordinates
-            float G = 0.0f;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) G += w8[tap] * s_dx[hp + (1 - tap / 3) * (int)W2 + (1 - tap % 3)];
-            const float dz = G * gp[u];
-            ws.dz[7][((size_t)im * g.P + q) * kC + lane] = dz;
-            b1 += dz;
-            b2 += dz * xh[u];
-            const float dxq = s_dx[hp];
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) dw[tap] += dxq * an[u][tap];
-        }
+        const float dz = G * gp[j];
+        ws.dz[7][img_off + q * kC + lane] = dz;
+        b1 += dz;
+        b2 += dz * xh[j];
     }
     float *r = s_red + (wave * 64 + lane) * 11;
     r[0] = b1;
@@ -936,9 +1010,9 @@ __global__ void __launch_bounds__(256) k_dec_l8_bwd(DecParams prm, DecWs ws, Dec
         float *po = ws.wpart8 + (((size_t)im * g.npair + pair) * kC + lane) * 9;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            float s = 0.0f;
-            for (int w = 0; w < 4; ++w) s += s_red[(w * 64 + lane) * 11 + 2 + tap];
-            po[tap] = s;
+            float sacc = 0.0f;
+            for (int w = 0; w < 4; ++w) sacc += s_red[(w * 64 + lane) * 11 + 2 + tap];
+            po[tap] = sacc;
         }
     }
 }
@@ -1216,9 +1290,9 @@ static inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m
 constexpr size_t kLdsLimit = 160 * 1024;
 
 static size_t conv_lds(const DecGeom &g) { return (size_t)2 * g.rows_max * (g.W + 2) * kPitch + (4 * 64 + 1024 + 2 * 2 * 32 * 33 + 2 * 16 * 64 + 2 * 32) * 4; }
-static size_t l8_lds(const DecGeom &g) { return (size_t)g.rows_max * (g.W + 2) * kC * 4 + (4 * 64 + 1024) * 4; }
-static size_t l8b_lds(const DecGeom &g) { return (size_t)g.rows_max * (g.W + 2) * 4 + 4 * 64 * 11 * 4; }
-static size_t l0_lds(const DecGeom &g) { return ((size_t)g.Cin * (g.H + 2) * (g.W + 2) + (size_t)kC * 9 * g.Cin + 4 * 64) * 4; }
+static size_t l8_lds(const DecGeom &g) { return (size_t)g.rows_max * (g.W + 2) * kC * 4 + (4 * 64 + 1024 + 4 * 16 * 65) * 4; }
+static size_t l8b_lds(const DecGeom &g) { return (size_t)g.rows_max * (g.W + 2) * (kC + 1) * 4 + 4 * 64 * 11 * 4; }
+static size_t l0_lds(const DecGeom &g) { return ((size_t)g.Cin * g.rows_max * (g.W + 2) + 4 * 64 + (g.Cin == 3 ? 0 : (size_t)kC * 9 * g.Cin)) * 4; }
 static size_t l0w_lds(const DecGeom &g) { return ((size_t)g.Cin * (g.H + 2) * (g.W + 2) + 3 * 64 + 4 * 64 * 9) * 4; }   // scratch 2304 >= 1024
 static size_t wgrad_lds(const DecGeom &g) { return (size_t)128 * (g.pd + g.pa) + (3 * 64 + 1024) * 4; }
 
@@ -1244,8 +1318,9 @@ static bool make_geom(uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, float ep
     }
     g.nband = ceil_div(H, g.R);   // no empty bands
     if (B * g.npair > 8 * kPartMax) return false;        // batch partials are combined from registers
+    if (g.rows_max * (W + 2) > 512) return false;        // k_dec_l8_bwd stages dx_8 with two positions per thread
     if ((uint64_t)B * g.P * kC >= (1u << 30)) return false;   // 32-bit element offsets
-    return conv_lds(g) <= kLdsLimit && l8_lds(g) <= kLdsLimit && l0_lds(g) <= 64 * 1024 && l0w_lds(g) <= 64 * 1024;
+    return conv_lds(g) <= kLdsLimit && l8_lds(g) <= kLdsLimit && l8b_lds(g) <= kLdsLimit && l0_lds(g) <= 64 * 1024 && l0w_lds(g) <= 64 * 1024;
 }
 
 struct Carver {
@@ -1356,7 +1431,10 @@ NSIG_EXPORT int dec_forward(const float *img, uint32_t input_mode, const float *
     hipStream_t s = as_stream(stream);
     const dim3 grid(g.npair, B);
     k_dec_pack<<<kSets * 2 * kKS, 64, 0, s>>>(prm, ws.packed, Cin);
-    k_dec_l0_fwd<<<grid, 256, l0_lds(g), s>>>(img, inp, clamped_out, prm, ws, g);
+    if (Cin == 3)
+        k_dec_l0_fwd<3><<<grid, 256, l0_lds(g), s>>>(img, inp, clamped_out, prm, ws, g);
+    else
+        k_dec_l0_fwd<0><<<grid, 256, l0_lds(g), s>>>(img, inp, clamped_out, prm, ws, g);
     for (int l = 1; l <= 7; ++l) k_dec_conv<kFwd><<<dim3(g.npair, B, 2), 256, conv_lds(g), s>>>(l, prm, ws, g, nullptr, nullptr, inp);
     k_dec_l8_fwd<<<grid, 256, l8_lds(g), s>>>(prm, ws, g);
     k_dec_head_fwd<<<B, 256, 0, s>>>(prm, ws, g, decoded);
