@@ -444,6 +444,73 @@ NSIG_EXPORT int opt_codebook_adam_sel(const float *G, float *const *params_host,
     return check_launch("opt_codebook_adam_sel");
 }
 
+// ----------------------------------------------------------------------------- dense multi-tensor Adam (the decoder's parameters)
+
+// torch's fused multi-tensor Adam walks 64K-element chunks, one workgroup each: the decoder's 29 tensors (262k parameters) become
+// ~30 workgroups that each stream 64K elements serially (28 us).  Here a chunk is 1024 elements, so the same update is ~260
+// workgroups of one pass (~3 us).  Same arithmetic as adam_update above (torch.optim.Adam, no weight decay / amsgrad).
+constexpr int kDenseMax = 32;
+constexpr uint32_t kDenseChunk = 1024;
+struct DenseAdam {
+    float *p[kDenseMax], *m[kDenseMax], *v[kDenseMax], *step[kDenseMax];
+    const float *g[kDenseMax];
+    uint32_t numel[kDenseMax], chunk0[kDenseMax + 1];   // chunk0: first chunk of tensor i
+};
+
+__global__ void k_adam_dense_prepare(DenseAdam a, uint32_t n, const float *__restrict__ lr, float beta1, float beta2, float *__restrict__ scratch) {
+    const uint32_t i = threadIdx.x;
+    if (i >= n) return;
+    const float step = *a.step[i] + 1.0f;
+    *a.step[i] = step;
+    scratch[i] = (float)((double)*lr / (1.0 - pow((double)beta1, (double)step)));
+    scratch[kDenseMax + i] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+}
+
+__global__ void __launch_bounds__(256) k_adam_dense(DenseAdam a, uint32_t n, const float *__restrict__ scratch, float beta1, float beta2, float eps) {
+    uint32_t i = 0;
+    while (i + 1 < n && blockIdx.x >= a.chunk0[i + 1]) ++i;   // uniform: which tensor this chunk belongs to
+    const uint32_t base = (blockIdx.x - a.chunk0[i]) * kDenseChunk;
+    const float ss = scratch[i], ib = scratch[kDenseMax + i];
+    float *__restrict__ pp = a.p[i], *__restrict__ pm = a.m[i], *__restrict__ pv = a.v[i];
+    const float *__restrict__ pg = a.g[i];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t e = base + u * 256 + threadIdx.x;
+        if (e < a.numel[i]) {
+            float p = pp[e], m = pm[e], v = pv[e];
+            adam_update(pg[e], p, m, v, beta1, beta2, eps, ss, ib);
+            pp[e] = p; pm[e] = m; pv[e] = v;
+        }
+    }
+}
+
+NSIG_EXPORT int opt_adam_dense(uint32_t n, float *const *params_host, const float *const *grads_host, float *const *exp_avg_host,
+                               float *const *exp_avg_sq_host, float *const *steps_host, const uint32_t *numel_host, const float *lr, float beta1,
+                               float beta2, float eps, float *scratch, nsig_stream_t stream) {
+    NSIG_REQUIRE(params_host && grads_host && exp_avg_host && exp_avg_sq_host && steps_host && numel_host && lr && scratch, "opt_adam_dense: null pointer");
+    hipStream_t st = as_stream(stream);
+    for (uint32_t first = 0; first < n; first += kDenseMax) {   // 32 tensors per pair of launches
+        const uint32_t cnt = n - first < (uint32_t)kDenseMax ? n - first : (uint32_t)kDenseMax;
+        DenseAdam a{};
+        uint32_t chunks = 0;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const uint32_t j = first + i;
+            NSIG_REQUIRE(params_host[j] && grads_host[j] && exp_avg_host[j] && exp_avg_sq_host[j] && steps_host[j] && numel_host[j] > 0,
+                         "opt_adam_dense: tensor %u has a null pointer or no elements", j);
+            a.p[i] = params_host[j]; a.g[i] = grads_host[j]; a.m[i] = exp_avg_host[j]; a.v[i] = exp_avg_sq_host[j]; a.step[i] = steps_host[j];
+            a.numel[i] = numel_host[j];
+            a.chunk0[i] = chunks;
+            chunks += ceil_div(numel_host[j], kDenseChunk);
+        }
+        a.chunk0[cnt] = chunks;
+        k_adam_dense_prepare<<<1, kDenseMax, 0, st>>>(a, cnt, lr, beta1, beta2, scratch + (size_t)first * 2);
+        if (int e = check_launch("opt_adam_dense (prepare)")) return e;
+        k_adam_dense<<<chunks, 256, 0, st>>>(a, cnt, scratch + (size_t)first * 2, beta1, beta2, eps);
+        if (int e = check_launch("opt_adam_dense")) return e;
+    }
+    return NSIG_OK;
+}
+
 NSIG_EXPORT int hg_scatter_level(const float *xyzs, float bound, const void *d_plane, uint32_t M, uint32_t level, float *G, nsig_stream_t stream) {
     NSIG_REQUIRE(xyzs && d_plane && G, "hg_scatter_level: null pointer");
     NSIG_REQUIRE(level < NSIG_BASE_LEVELS && bound > 0.0f, "hg_scatter_level: level %u out of range or bad bound", level);

@@ -89,6 +89,46 @@ def _step_shared_sel(opt, tables, message_dev, G, lr_dev, grad_scale=1.0):
 CodebookAdam.step_shared_sel = torch.no_grad()(_step_shared_sel)
 
 
+def _step_dense(opt, lr_dev):
+    """torch.optim.Adam's update of every parameter that carries a dense `.grad` (the decoder) through opt_adam_dense: one
+    pass of 1024-element chunks instead of the generic multi-tensor kernel's 64K-element ones.  State in torch's capturable
+    format (device step counts), so `step()` and `state_dict()` keep working on it."""
+    todo = []
+    for group in opt.param_groups:
+        for p in group["params"]:
+            if p.grad is None:
+                continue
+            if not (p.is_cuda and p.dtype == torch.float32 and p.grad.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
+                raise NotImplementedError("step_dense handles contiguous float32 CUDA parameters")
+            st = opt.state[p]
+            if len(st) == 0:
+                st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            elif not st["step"].is_cuda:
+                st["step"] = st["step"].to(p.device)
+            todo.append((group, p))
+    if not todo:
+        return
+    group = todo[0][0]
+    if any(g["betas"] != group["betas"] or g["eps"] != group["eps"] for g, _ in todo):
+        raise NotImplementedError("step_dense expects one (betas, eps) for all dense parameters")
+    ps = [p for _, p in todo]
+    n = len(ps)
+    scratch = getattr(opt, "_dense_scratch", None)
+    if scratch is None or scratch.numel() < 64 * ((n + 31) // 32):
+        scratch = opt._dense_scratch = torch.empty(64 * ((n + 31) // 32), dtype=torch.float32, device=ps[0].device)
+    numel = (ctypes.c_uint32 * n)(*[p.numel() for p in ps])
+    nv.call("opt_adam_dense", n, nv.ptr_array([p.data for p in ps]), nv.ptr_array([p.grad for p in ps]),
+            nv.ptr_array([opt.state[p]["exp_avg"] for p in ps]), nv.ptr_array([opt.state[p]["exp_avg_sq"] for p in ps]),
+            nv.ptr_array([opt.state[p]["step"] for p in ps]), numel, nv.ptr(lr_dev), float(group["betas"][0]), float(group["betas"][1]),
+            float(group["eps"]), nv.ptr(scratch), nv.stream())
+    _bump_versions(ps)
+
+
+CodebookAdam.step_dense = torch.no_grad()(_step_dense)
+
+
 def _bump_versions(tensors):
     """The native in-place update is invisible to torch's version counters; caches keyed on them (the pre-summed
     codebook in NeRFNetwork) must see the change."""

@@ -165,7 +165,8 @@ class GraphedWatermarkLoop:
     adds `headroom`; `overflowed()` reports (one host read) whether any replay since the last check produced more
     points than that -- such a step dropped the rays that did not fit, like the reference's bounded mode."""
 
-    def __init__(self, model, optimizer, render_kwargs, data, lambda_w=1.0, lambda_i=1.0, lr_lambda=None, headroom=0.0):
+    def __init__(self, model, optimizer, render_kwargs, data, lambda_w=1.0, lambda_i=1.0, lr_lambda=None, headroom=0.0, native_dense_adam=True):
+        self.native_dense_adam = native_dense_adam
         if not hasattr(optimizer, "step_shared_sel"):
             raise TypeError("GraphedWatermarkLoop needs nerf_signature_amd.optim.CodebookAdam(capturable=True)")
         self.model, self.optimizer = model, optimizer
@@ -201,7 +202,10 @@ class GraphedWatermarkLoop:
 
     def _optimise(self):
         self.optimizer.step_shared_sel(self.tables, self.msg_dev, self.sink.G, self.lr_dev)
-        self.optimizer.step()
+        if self.native_dense_adam:
+            self.optimizer.step_dense(self.lr_dev)      # the decoder's parameters: opt_adam_dense
+        else:
+            self.optimizer.step()
 
     def _set_inputs(self, message, data):
         self.msg_host.copy_(message.detach().to("cpu", torch.float32))

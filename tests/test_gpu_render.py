@@ -467,3 +467,27 @@ def test_fused_decoder_on_rendered_blocks_matches_clamp_permute_normalize():
     assert outside.any() and float(g1[0][outside].abs().max()) == 0.0
     for a, b in zip(g1, g0):
         assert float((a.double() - b).norm() / b.norm()) < 2e-3
+
+
+def test_dense_adam_matches_torch_adam():
+    """opt_adam_dense == torch.optim.Adam(betas=(0.9, 0.99), eps=1e-15) on tensors of odd sizes over several steps, a tensor
+    skipped for one step (grad None) included."""
+    from nerf_signature_amd.optim import CodebookAdam
+    torch.manual_seed(1)
+    shapes = [(64, 3, 3, 3), (64,), (64, 64, 3, 3), (1, 64, 3, 3), (1,), (1, 1), (1030,)] * 6   # 42 tensors: two launches of <= 32
+    a = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    oa = CodebookAdam(a, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, capturable=True)
+    ob = torch.optim.Adam(b, lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    lr_dev = torch.tensor(1e-2, device="cuda")
+    for step in range(5):
+        for i, (p, q) in enumerate(zip(a, b)):
+            g = torch.randn_like(p) * (10.0 ** (i % 5 - 4))
+            skip = step == 2 and i == 3
+            p.grad, q.grad = (None, None) if skip else (g.clone(), g.clone())
+        oa.step_dense(lr_dev)
+        ob.step()
+    for i, (p, q) in enumerate(zip(a, b)):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-6, atol=1e-7, err_msg=str(i))
+        assert float(oa.state[p]["step"]) == float(ob.state[q]["step"])
+        np.testing.assert_allclose(oa.state[p]["exp_avg_sq"].cpu().numpy(), ob.state[q]["exp_avg_sq"].cpu().numpy(), rtol=2e-6, atol=0)
