@@ -111,14 +111,26 @@ __global__ void __launch_bounds__(256) k_pack_weights(const float *__restrict__ 
 
 // ----------------------------------------------------------------------------- wave-level building blocks
 
+// A B operand of one K-step (8 values per lane) as split bf16: hi = bf16(v), lo = bf16(v - hi), two values per dword.
 struct Split8 {
-    bf16x8 hi, lo;
+    uint32_t hi[4], lo[4];
 };
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ inline void split_put(Split8 &s, int j, float v) {
-    const __bf16 hi = (__bf16)v;
-    s.hi[j] = hi;
-    s.lo[j] = (__bf16)(v - (float)hi);
+__device__ inline uint32_t cvt_pk_bf16(float a, float b) {   // v_cvt_pk_bf16_f32: round to nearest even, a in the low half
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+// elements 2*jp, 2*jp + 1 of the operand: 6 VALU operations per pair, results already packed
+__device__ inline void split_put2(Split8 &s, int jp, float a, float b) {
+    const uint32_t hi = cvt_pk_bf16(a, b);
+    s.hi[jp] = hi;
+    s.lo[jp] = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+__device__ inline bf16x8 operand(const uint32_t (&w)[4]) {
+    const uint4 u = {w[0], w[1], w[2], w[3]};
+    return __builtin_bit_cast(bf16x8, u);
 }
 
 // acc[rb] = sum over k-steps of A(frag0 + rb*KS + ks) . B[ks], split-bf16.
@@ -133,35 +145,43 @@ __device__ inline void mfma_layer(const char *__restrict__ lds_hi, const char *_
             const int off = (frag0 + rb * KS + ks) * kFragBytes + lane * 16;
             const bf16x8 a_hi = *reinterpret_cast<const bf16x8 *>(lds_hi + off);
             const bf16x8 a_lo = *reinterpret_cast<const bf16x8 *>(lds_lo + off);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b[ks].hi, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b[ks].lo, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b[ks].hi, c, 0, 0, 0);
+            const bf16x8 b_hi = operand(b[ks].hi), b_lo = operand(b[ks].lo);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, c, 0, 0, 0);
         }
         acc[rb] = c;
     }
 }
 
-// ReLU a 64-row activation held in two accumulators, return the sign bits, emit the next B operand.
+// ReLU a 64-row activation held in two accumulators, return the "was positive" bits (bit 16*rb + r), emit the next B operand.
+// No compares (they would hold 32 lane masks in SGPRs): the value is max(v, 0); the flag is the sign bit of 0 - bits(v) --
+// set exactly when v > 0, because an accumulator that starts at +0 never holds -0 -- shifted in with one v_alignbit.
 __device__ inline uint32_t relu_to_operand(const f32x16 (&acc)[2], Split8 (&b)[4]) {
     uint32_t bits = 0;
 #pragma unroll
+    for (int i = 31; i >= 0; --i)   // highest index first: index 0 ends in bit 0
+        bits = __builtin_amdgcn_alignbit(bits, 0u - __float_as_uint(acc[i >> 4][i & 15]), 31);
+#pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float v = acc[rb][r];
-            const bool on = v > 0.0f;
-            bits |= (uint32_t)on << (rb * 16 + r);
-            split_put(b[2 * rb + (r >> 3)], r & 7, on ? v : 0.0f);
-        }
+        for (int r = 0; r < 16; r += 2)
+            split_put2(b[2 * rb + (r >> 3)], (r & 7) >> 1, fmaxf(acc[rb][r], 0.0f), fmaxf(acc[rb][r + 1], 0.0f));
     return bits;
 }
 
 // Backward through a ReLU: zero the rows whose forward activation was clamped, emit the next B operand.
+__device__ inline float masked(float v, uint32_t bits, int i) {   // v where bit i is set, else +0: sign-extended 1-bit field as AND mask
+    uint32_t m;   // inline asm: the compiler would turn the builtin into a compare + select (and a lane mask in SGPRs) again
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(bits), "n"(i));
+    return __uint_as_float(__float_as_uint(v) & m);
+}
 __device__ inline void mask_to_operand(const f32x16 (&acc)[2], uint32_t bits, Split8 (&b)[4]) {
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) split_put(b[2 * rb + (r >> 3)], r & 7, ((bits >> (rb * 16 + r)) & 1u) ? acc[rb][r] : 0.0f);
+        for (int r = 0; r < 16; r += 2)
+            split_put2(b[2 * rb + (r >> 3)], (r & 7) >> 1, masked(acc[rb][r], bits, rb * 16 + r), masked(acc[rb][r + 1], bits, rb * 16 + r + 1));
 }
 
 // Degree-4 real spherical harmonics (the 16 components of hash_encoding.py:157-183) of d in [-1,1]^3.
@@ -226,9 +246,9 @@ __device__ inline void color_branch(const char *lds_hi, const char *lds_lo, int 
     sh16(ux * 2.0f - 1.0f, uy * 2.0f - 1.0f, uz * 2.0f - 1.0f, sh);
     Split8 cin[2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        split_put(cin[0], j, h ? sh[8 + j] : sh[j]);
-        split_put(cin[1], j, geo8[j]);
+    for (int j = 0; j < 8; j += 2) {
+        split_put2(cin[0], j >> 1, h ? sh[8 + j] : sh[j], h ? sh[9 + j] : sh[j + 1]);
+        split_put2(cin[1], j >> 1, geo8[j], geo8[j + 1]);
     }
     auto relu = [](float v, int) { return v > 0.0f ? v : 0.0f; };
     if (trace != nullptr) {
@@ -320,10 +340,7 @@ __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyz
                 f[7].y = f[7].y + c.y;
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                split_put(feat[q >> 2], 2 * (q & 3), f[q].x);
-                split_put(feat[q >> 2], 2 * (q & 3) + 1, f[q].y);
-            }
+            for (int q = 0; q < 8; ++q) split_put2(feat[q >> 2], q & 3, f[q].x, f[q].y);
         } else {
             const float two_b = 2.0f * bound;
             const float x = (xyzs[3 * (size_t)sl] + bound) / two_b;       // network_wtmk_tcnn.py:101
@@ -340,8 +357,7 @@ __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyz
                         f.x = f.x + c.x;
                         f.y = f.y + c.y;
                     }
-                    split_put(feat[g], 2 * i, f.x);
-                    split_put(feat[g], 2 * i + 1, f.y);
+                    split_put2(feat[g], i, f.x, f.y);
                 }
         }
 
@@ -431,6 +447,7 @@ __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyz
 
         // d(pre-sigmoid color): only lane half 0, elements 0..2 of the 16-wide K-step are non-zero
         Split8 dout[1];
+        float dv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float v = 0.0f;
@@ -438,9 +455,11 @@ __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyz
                 const float c = rgbs[3 * (size_t)sl + j];
                 v = g_rgb[3 * (size_t)sl + j] * (c * (1.0f - c));
             }
-            split_put(dout[0], j, v);
+            dv[j] = v;
             if (kFull) gt.d_out[(size_t)(8 * h + j) * stride + s] = v;   // rows 3..15 are zero
         }
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) split_put2(dout[0], j >> 1, dv[j], dv[j + 1]);
         f32x16 hid[2];
         Split8 b4[4];
         mfma_layer<2, 1>(lds_hi, lds_lo, B0, lane, dout, hid);
@@ -461,10 +480,10 @@ __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyz
             head8[0] = (live ? g_sigma[sl] : 0.0f) * fminf(fmaxf(sg, e_lo), e_hi);
         }
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            split_put(dhead[0], r, head8[r]);
+        for (int r = 0; r < 8; ++r)
             if (kFull) gt.d_so[(size_t)row_of_reg(h, r) * stride + s] = head8[r];
-        }
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) split_put2(dhead[0], r >> 1, head8[r], head8[r + 1]);
         mfma_layer<2, 1>(lds_hi, lds_lo, B3, lane, dhead, hid);
         mask_to_operand(hid, mask_s, b4);
         if (kFull) {
