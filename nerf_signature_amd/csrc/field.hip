@@ -158,16 +158,19 @@ __device__ inline void mfma_layer(const char *__restrict__ lds_hi, const char *_
 // No compares (they would hold 32 lane masks in SGPRs): the value is max(v, 0); the flag is the sign bit of 0 - bits(v) --
 // set exactly when v > 0, because an accumulator that starts at +0 never holds -0 -- shifted in with one v_alignbit.
 __device__ inline uint32_t relu_to_operand(const f32x16 (&acc)[2], Split8 (&b)[4]) {
-    uint32_t bits = 0;
-#pragma unroll
-    for (int i = 31; i >= 0; --i)   // highest index first: index 0 ends in bit 0
-        bits = __builtin_amdgcn_alignbit(bits, 0u - __float_as_uint(acc[i >> 4][i & 15]), 31);
+    uint32_t bits = 0;   // filled most-significant-first, reversed at the end: index i ends in bit i
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; r += 2)
-            split_put2(b[2 * rb + (r >> 3)], (r & 7) >> 1, fmaxf(acc[rb][r], 0.0f), fmaxf(acc[rb][r + 1], 0.0f));
-    return bits;
+        for (int r = 0; r < 16; r += 2) {
+            uint32_t u0 = __float_as_uint(acc[rb][r]), u1 = __float_as_uint(acc[rb][r + 1]);
+            asm("" : "+v"(u0), "+v"(u1));   // one copy out of the accumulator registers, used twice
+            bits = __builtin_amdgcn_alignbit(bits, 0u - u0, 31);
+            bits = __builtin_amdgcn_alignbit(bits, 0u - u1, 31);
+            // max(v, 0) as an integer max on the bit patterns (negative floats are negative integers): no NaN canonicalisation
+            split_put2(b[2 * rb + (r >> 3)], (r & 7) >> 1, __uint_as_float((uint32_t)max((int)u0, 0)), __uint_as_float((uint32_t)max((int)u1, 0)));
+        }
+    return __builtin_bitreverse32(bits);
 }
 
 // Backward through a ReLU: zero the rows whose forward activation was clamped, emit the next B operand.
