@@ -143,8 +143,9 @@ int hg_codebook_encode_fwd(const float *x01, uint32_t M, const float *const *tab
  * point.  All D selected tables receive this same gradient.  G is [T,2] and is accumulated into. */
 int hg_codebook_bwd(const float *x01, uint32_t M, const float *dfeat, float *G, nsig_stream_t stream);
 
-/* Same accumulation as hg_codebook_bwd, organised for the memory system: `rec` is the [5, M] structure-of-arrays
- * record field_bwd emits (x01.x, x01.y, x01.z, d feature[30], d feature[31]).  256 workgroups = 32 slices of G x 8
+/* Same accumulation as hg_codebook_bwd, organised for the memory system: `rec` is the [M, 8]-dword record field_bwd emits
+ * per point: { ix | iy << 16, iz (cell of the 2048^3 codebook grid), wx, wy, wz (interpolation weights, fp32),
+ * d feature[30], d feature[31], 0 }.  256 workgroups = 32 slices of G x 8
  * replicas; a workgroup keeps its 16384-row slice (128 KiB) in LDS, scans one eighth of the points, accumulates the
  * corners that hash into its slice with LDS atomics and finally adds the slice to G with contiguous global atomics
  * (1/10 of the scattered atomics' requests).  G is accumulated into. */
@@ -216,7 +217,7 @@ int field_color_fwd(const float *dirs, const float *geo_feat, uint32_t M, const 
  * Backward of field_fwd w.r.t. the codebook: (dL/dsigma, dL/drgb) -> MLP input gradients (weights are
  * frozen, nerf/network_wtmk_tcnn.py:90-95) -> d feature[30:32] -> scatter into G [T,2] (accumulated).
  * Outputs (each optional, at least one required): G -- direct scatter with global atomics; dfeat_out [M,2] --
- * d feature[30:32]; rec_out [5,M] -- the scatter record consumed by hg_scatter_sliced (the fast route).
+ * d feature[30:32]; rec_out [M,8] dwords (32-byte aligned) -- the scatter record consumed by hg_scatter_sliced (the fast route).
  */
 int field_bwd(const float *xyzs, uint32_t M, float bound, const float *grad_sigmas, const float *grad_rgbs,
               const float *sigmas, const float *rgbs, const uint32_t *masks, const void *packed, float *G,

@@ -510,9 +510,17 @@ __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyz
         if (dfeat_out != nullptr && h == 0) { dfeat_out[2 * (size_t)s] = g0; dfeat_out[2 * (size_t)s + 1] = g1; }
         const float two_b = 2.0f * bound;
         const float x01 = (xyzs[3 * (size_t)s] + bound) / two_b, y01 = (xyzs[3 * (size_t)s + 1] + bound) / two_b, z01 = (xyzs[3 * (size_t)s + 2] + bound) / two_b;
-        if (rec_out != nullptr && h == 0) {  // structure of arrays: five coalesced dword stores per 32 points
-            rec_out[s] = x01; rec_out[(size_t)M + s] = y01; rec_out[2 * (size_t)M + s] = z01;
-            rec_out[3 * (size_t)M + s] = g0; rec_out[4 * (size_t)M + s] = g1;
+        if (rec_out != nullptr && h == 0) {
+            // The scatter's 256 workgroups each re-read this record 32 times (once per slice), so what is computed here once is
+            // not recomputed there: integer cell, interpolation weights (codebook resolution 2^11: exact scalings, identical to
+            // corner_rows()), gradients.  32 bytes per point, two 16-byte stores.
+            const float res = kCodebookResolution, cell = 1.0f / kCodebookResolution;
+            const int ix = (int)floorf(fminf(fmaxf(x01, 0.0f), 1.0f) * res), iy = (int)floorf(fminf(fmaxf(y01, 0.0f), 1.0f) * res),
+                      iz = (int)floorf(fminf(fmaxf(z01, 0.0f), 1.0f) * res);
+            const float wx = (x01 - (float)ix * cell) * res, wy = (y01 - (float)iy * cell) * res, wz = (z01 - (float)iz * cell) * res;
+            uint4 *r4 = reinterpret_cast<uint4 *>(rec_out) + 2 * (size_t)s;
+            r4[0] = make_uint4((uint32_t)ix | ((uint32_t)iy << 16), (uint32_t)iz, __float_as_uint(wx), __float_as_uint(wy));
+            r4[1] = make_uint4(__float_as_uint(wz), __float_as_uint(g0), __float_as_uint(g1), 0u);
         }
         if (G == nullptr || (g0 == 0.0f && g1 == 0.0f)) continue;
         Corner8 c;

@@ -92,47 +92,74 @@ __global__ void __launch_bounds__(256) k_codebook_bwd(const float *__restrict__ 
 // (MI355X_MICROARCH.md, Global float atomics), and the point-wise scatter needs >= 4 requests per point; LDS
 // atomics and a contiguous flush need 1/10 of that.  Workgroup (slice s, replica r) owns rows [s*16384, (s+1)*16384)
 // of G in LDS, scans points [r*M/8, (r+1)*M/8) and keeps only the corners whose row falls in its slice (the hash
-// makes that 1 corner in 32, so every workgroup recomputes every point's rows: 32x redundant integer work, which is
-// cheap next to the atomics it replaces).  blockIdx = s*8 + r, so the 32 workgroups that scan the same points share
-// one XCD (blockIdx % 8) and its L2 serves the re-reads.  The codebook resolution is 2^11, so cell index and weights
-// are exact scalings (no division) and bit-identical to corner_rows().
+// makes that 1 corner in 32, so every workgroup tests every point: 32x redundant work, cheap next to the atomics it
+// replaces -- and kept cheap: the record carries the integer cell and the weights, computed once by k_field_bwd).
+// blockIdx = s*8 + r, so the 32 workgroups that scan the same points share one XCD (blockIdx % 8) and its L2 serves the
+// re-reads.  The kernel is VALU-bound (phase stamps: 1.4 us zeroing, ~140 us scan, 6 us flush on 1.29 M points).
 constexpr int kSliceRows = 16384, kSlices = NSIG_TABLE_ROWS / kSliceRows, kReplicas = 8;
+
+#ifdef NSIG_DEC_TIMING
+__device__ unsigned long long g_scatter_stamps[8];
+#define SC_STAMP(k)                                                                      \
+    do {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_scatter_stamps[k] = wall_clock64();   \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+    } while (0)
+#else
+#define SC_STAMP(k)
+#endif
 
 __global__ void __launch_bounds__(1024) k_scatter_sliced(const float *__restrict__ rec, uint32_t M, float *__restrict__ G) {
     extern __shared__ float acc[];  // [kSliceRows][2]
     const uint32_t slice = blockIdx.x >> 3, replica = blockIdx.x & 7u;
+    SC_STAMP(0);
     for (uint32_t i = threadIdx.x; i < 2u * kSliceRows; i += blockDim.x) acc[i] = 0.0f;
     __syncthreads();
+    SC_STAMP(1);
     const uint32_t chunk = ceil_div(M, (uint32_t)kReplicas);
     const uint32_t beg = min(M, replica * chunk), end = min(M, beg + chunk);
+    const uint4 *__restrict__ rec4 = reinterpret_cast<const uint4 *>(rec);
     for (uint32_t m = beg + threadIdx.x; m < end; m += blockDim.x) {
-        const float g0 = rec[3 * (size_t)M + m], g1 = rec[4 * (size_t)M + m];
+        const uint4 ra = rec4[2 * (size_t)m], rb = rec4[2 * (size_t)m + 1];
+        const float g0 = __uint_as_float(rb.y), g1 = __uint_as_float(rb.z);
         if (g0 == 0.0f && g1 == 0.0f) continue;  // padding rows and terminated rays
-        const float x = rec[m], y = rec[(size_t)M + m], z = rec[2 * (size_t)M + m];
-        const float res = kCodebookResolution, cell = 1.0f / kCodebookResolution;
-        const int ix = (int)floorf(fminf(fmaxf(x, 0.0f), 1.0f) * res), iy = (int)floorf(fminf(fmaxf(y, 0.0f), 1.0f) * res),
-                  iz = (int)floorf(fminf(fmaxf(z, 0.0f), 1.0f) * res);
         Corner8 c;
-        c.wx = (x - (float)ix * cell) * res; c.wy = (y - (float)iy * cell) * res; c.wz = (z - (float)iz * cell) * res;
-        const uint32_t hx[2] = {(uint32_t)ix, (uint32_t)ix + 1u};
-        const uint32_t hy[2] = {(uint32_t)iy * kPrimeY, ((uint32_t)iy + 1u) * kPrimeY};
-        const uint32_t hz[2] = {(uint32_t)iz * kPrimeZ, ((uint32_t)iz + 1u) * kPrimeZ};
+        c.wx = __uint_as_float(ra.z); c.wy = __uint_as_float(ra.w); c.wz = __uint_as_float(rb.x);
+        const uint32_t ix = ra.x & 0xffffu, iy = ra.x >> 16, iz = ra.y;
+        const uint32_t hy[2] = {iy * kPrimeY, (iy + 1u) * kPrimeY};
+        const uint32_t hz[2] = {iz * kPrimeZ, (iz + 1u) * kPrimeZ};
+        // ix <= 2^11 never reaches bits 14..18 of the row, so the slice of a corner depends on (dy, dz) only: four tests, and a
+        // hit brings both x-corners.
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t row = (hx[(k >> 2) & 1] ^ hy[(k >> 1) & 1] ^ hz[k & 1]) & kRowMask;
-            if ((row >> 14) != slice) continue;
-            float *dst = acc + 2u * (row & (kSliceRows - 1));
-            atomicAdd(dst, corner_weight(c, k, g0));
-            atomicAdd(dst + 1, corner_weight(c, k, g1));
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t hyz = hy[q >> 1] ^ hz[q & 1];
+            if (((hyz >> 14) & (uint32_t)(kSlices - 1)) != slice) continue;
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int k = 4 * dx + q;   // corner (dx, dy, dz) = (dx, q>>1, q&1)
+                float *dst = acc + 2u * (((ix + dx) ^ hyz) & (uint32_t)(kSliceRows - 1));
+                atomicAdd(dst, corner_weight(c, k, g0));
+                atomicAdd(dst + 1, corner_weight(c, k, g1));
+            }
         }
     }
+    SC_STAMP(2);
     __syncthreads();
+    SC_STAMP(3);
     float *out = G + 2 * (size_t)slice * kSliceRows;
     for (uint32_t i = threadIdx.x; i < 2u * kSliceRows; i += blockDim.x) {
         const float v = acc[i];
         if (v != 0.0f) atomicAdd(out + i, v);
     }
+    SC_STAMP(4);
 }
+
+#ifdef NSIG_DEC_TIMING
+NSIG_EXPORT int scatter_timing_stamps(unsigned long long *out8) {
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_scatter_stamps), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // Owner-computes scatter of one base level's feature gradient (stage-1 training): as k_scatter_sliced, with the level's
 // own resolution (not a power of two, so the cell index uses the same IEEE divisions as the forward: corner_rows()).

@@ -152,11 +152,12 @@ def field_color(dirs, geo_feat, packed):
 
 def field_backward(xyzs, bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, G=None, want_dfeat=False, want_rec=False):
     """Input-gradient backward of the field network.  G: direct scatter (global atomics); want_dfeat: [M,2] d feature[30:32];
-    want_rec: the [5,M] scatter record for codebook_scatter_sliced.  Returns dfeat, rec or (dfeat, rec)."""
+    want_rec: the [M,8] scatter record for codebook_scatter_sliced (32 bytes per point: cell, weights, gradients).
+    Returns dfeat, rec or (dfeat, rec)."""
     xyzs = xyzs.contiguous().float()
     M = xyzs.shape[0]
     dfeat = torch.empty(M, 2, dtype=torch.float32, device=xyzs.device) if want_dfeat else None
-    rec = torch.empty(5, M, dtype=torch.float32, device=xyzs.device) if want_rec else None
+    rec = torch.empty(M, 8, dtype=torch.float32, device=xyzs.device) if want_rec else None
     nv.call("field_bwd", nv.ptr(xyzs), M, float(bound), nv.ptr(g_sigma.contiguous().float()), nv.ptr(g_rgb.contiguous().float()),
             nv.ptr(sigmas), nv.ptr(rgbs), nv.ptr(masks), nv.ptr(packed), nv.ptr(G), nv.ptr(dfeat), nv.ptr(rec), nv.stream())
     if want_dfeat and want_rec:
@@ -165,8 +166,8 @@ def field_backward(xyzs, bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, G=N
 
 
 def codebook_scatter_sliced(rec, G):
-    """G += scatter of the [5,M] record emitted by field_backward(want_rec=True) -> hg_scatter_sliced."""
-    nv.call("hg_scatter_sliced", nv.ptr(rec), rec.shape[1], nv.ptr(G), nv.stream())
+    """G += scatter of the [M,8] record emitted by field_backward(want_rec=True) -> hg_scatter_sliced."""
+    nv.call("hg_scatter_sliced", nv.ptr(rec), rec.shape[0], nv.ptr(G), nv.stream())
     return G
 
 

@@ -218,8 +218,13 @@ def test_sliced_scatter_equals_pointwise_scatter(fo, tables):
     gs[100:200] = 0
     gc[100:200] = 0
     dfeat, rec = fo.field_backward(pts, 1.0, gs, gc, s1, c1, masks, packed, want_dfeat=True, want_rec=True)
-    assert rec.shape == (5, M) and torch.equal(rec[3:].t().contiguous(), dfeat)
-    np.testing.assert_array_equal(rec[:3].t().cpu().numpy(), ((pts + 1.0) / 2.0).cpu().numpy())
+    # the record: integer cell of the 2048^3 codebook grid, interpolation weights, the two feature gradients
+    assert rec.shape == (M, 8) and torch.equal(rec[:, 5:7].contiguous(), dfeat)
+    words = rec.view(torch.int32)
+    x01 = ((pts + 1.0) / 2.0)
+    cell = torch.floor(x01.clamp(0, 1) * 2048.0).int()
+    assert torch.equal(words[:, 0] & 0xFFFF, cell[:, 0]) and torch.equal(words[:, 0] >> 16, cell[:, 1]) and torch.equal(words[:, 1], cell[:, 2])
+    np.testing.assert_array_equal(rec[:, 2:5].cpu().numpy(), ((x01 - cell.float() * (1.0 / 2048.0)) * 2048.0).cpu().numpy())
     G1, G2 = torch.zeros(1 << 19, 2, device="cuda"), torch.full((1 << 19, 2), 0.5, device="cuda")
     fo.codebook_scatter((pts + 1.0) / 2.0, dfeat, G1)
     fo.codebook_scatter_sliced(rec, G2)            # accumulates into what is there
