@@ -95,7 +95,9 @@ __global__ void __launch_bounds__(256) k_codebook_bwd(const float *__restrict__ 
 // makes that 1 corner in 32, so every workgroup tests every point: 32x redundant work, cheap next to the atomics it
 // replaces -- and kept cheap: the record carries the integer cell and the weights, computed once by k_field_bwd).
 // blockIdx = s*8 + r, so the 32 workgroups that scan the same points share one XCD (blockIdx % 8) and its L2 serves the
-// re-reads.  The kernel is VALU-bound (phase stamps: 1.4 us zeroing, ~140 us scan, 6 us flush on 1.29 M points).
+// re-reads.  Phase stamps (tools/scatter_timing.py): 1.4 us zeroing, the scan, 6 us flush; the scan was a chain of exposed L2
+// latencies (one record in flight per thread) until four were prefetched.  Tried and rejected: collecting hits in a bit mask or
+// in a per-wave LDS ring to run the weight/atomic code with full lanes -- both slower than the plain predicated body.
 constexpr int kSliceRows = 16384, kSlices = NSIG_TABLE_ROWS / kSliceRows, kReplicas = 8;
 
 #ifdef NSIG_DEC_TIMING
@@ -120,27 +122,40 @@ __global__ void __launch_bounds__(1024) k_scatter_sliced(const float *__restrict
     const uint32_t chunk = ceil_div(M, (uint32_t)kReplicas);
     const uint32_t beg = min(M, replica * chunk), end = min(M, beg + chunk);
     const uint4 *__restrict__ rec4 = reinterpret_cast<const uint4 *>(rec);
-    for (uint32_t m = beg + threadIdx.x; m < end; m += blockDim.x) {
-        const uint4 ra = rec4[2 * (size_t)m], rb = rec4[2 * (size_t)m + 1];
-        const float g0 = __uint_as_float(rb.y), g1 = __uint_as_float(rb.z);
-        if (g0 == 0.0f && g1 == 0.0f) continue;  // padding rows and terminated rays
-        Corner8 c;
-        c.wx = __uint_as_float(ra.z); c.wy = __uint_as_float(ra.w); c.wz = __uint_as_float(rb.x);
-        const uint32_t ix = ra.x & 0xffffu, iy = ra.x >> 16, iz = ra.y;
-        const uint32_t hy[2] = {iy * kPrimeY, (iy + 1u) * kPrimeY};
-        const uint32_t hz[2] = {iz * kPrimeZ, (iz + 1u) * kPrimeZ};
-        // ix <= 2^11 never reaches bits 14..18 of the row, so the slice of a corner depends on (dy, dz) only: four tests, and a
-        // hit brings both x-corners.
+    // With 16 waves per CU and ~150 points per thread the scan is a chain of exposed L2 latencies unless several points'
+    // records are in flight per thread: four at a time.
+    constexpr int kAhead = 4;
+    for (uint32_t m0 = beg + threadIdx.x; m0 < end; m0 += blockDim.x * kAhead) {
+        uint4 ra[kAhead], rb[kAhead];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t hyz = hy[q >> 1] ^ hz[q & 1];
-            if (((hyz >> 14) & (uint32_t)(kSlices - 1)) != slice) continue;
+        for (int u = 0; u < kAhead; ++u) {
+            const uint32_t m = min(m0 + u * blockDim.x, end - 1);   // clamped: the duplicate is skipped below
+            ra[u] = rec4[2 * (size_t)m];
+            rb[u] = rec4[2 * (size_t)m + 1];
+        }
 #pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                const int k = 4 * dx + q;   // corner (dx, dy, dz) = (dx, q>>1, q&1)
-                float *dst = acc + 2u * (((ix + dx) ^ hyz) & (uint32_t)(kSliceRows - 1));
-                atomicAdd(dst, corner_weight(c, k, g0));
-                atomicAdd(dst + 1, corner_weight(c, k, g1));
+        for (int u = 0; u < kAhead; ++u) {
+            if (m0 + u * blockDim.x >= end) break;
+            const float g0 = __uint_as_float(rb[u].y), g1 = __uint_as_float(rb[u].z);
+            if (g0 == 0.0f && g1 == 0.0f) continue;  // padding rows and terminated rays
+            Corner8 c;
+            c.wx = __uint_as_float(ra[u].z); c.wy = __uint_as_float(ra[u].w); c.wz = __uint_as_float(rb[u].x);
+            const uint32_t ix = ra[u].x & 0xffffu, iy = ra[u].x >> 16, iz = ra[u].y;
+            const uint32_t hy[2] = {iy * kPrimeY, (iy + 1u) * kPrimeY};
+            const uint32_t hz[2] = {iz * kPrimeZ, (iz + 1u) * kPrimeZ};
+            // ix <= 2^11 never reaches bits 14..18 of the row, so the slice of a corner depends on (dy, dz) only: four tests,
+            // and a hit brings both x-corners.
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t hyz = hy[q >> 1] ^ hz[q & 1];
+                if (((hyz >> 14) & (uint32_t)(kSlices - 1)) != slice) continue;
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int k = 4 * dx + q;   // corner (dx, dy, dz) = (dx, q>>1, q&1)
+                    float *dst = acc + 2u * (((ix + dx) ^ hyz) & (uint32_t)(kSliceRows - 1));
+                    atomicAdd(dst, corner_weight(c, k, g0));
+                    atomicAdd(dst + 1, corner_weight(c, k, g1));
+                }
             }
         }
     }
