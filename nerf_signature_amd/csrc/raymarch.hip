@@ -247,6 +247,41 @@ struct Walker {
 // by binary search over the chunk's t values in LDS, and the chase itself runs on wave-uniform scalars over the
 // 64-bit occupancy ballot (ctz over runs of occupied steps, v_readlane for the jumps).  A jump that leaves the
 // chunk carries t_exit to the next one.  Counts and sampled parameters are bit-identical to the sequential walk.
+// The chunk t_j = t_0 advanced j times by the constant step dt, j = 0..63, with the exact rounding of the sequential chain
+// t <- fl(t + dt), in closed form.  Inside a binade [2^e, 2^(e+1)) every t is a multiple of u = ulp; fl(t + dt) adds the
+// constant increment inc = (floor(dt/u) + [frac(dt/u) > 1/2]) * u (a tie, frac == 1/2, would alternate: not handled), so
+// t_j = t_0 + j*inc, a product and a sum that are both exact in fp32.  At most one binade boundary falls inside a chunk
+// (t_0 >= 1/4 and 63*dt below a binade's width are required): the first value past it is one real fp32 addition from
+// its predecessor, and the values after it follow the same rule with u doubled.  Returns false (wave-uniformly) when a
+// precondition fails; the caller then runs the sequential chain.  t0, dt: wave-uniform.
+__device__ inline bool chunk_closed_form(float t0, float dt, int lane, float &tj) {
+    const uint32_t b0 = __float_as_uint(t0);
+    const uint32_t e = b0 & 0x7f800000u;
+    if (!(t0 >= 0.25f) || !(t0 < 1048576.0f) || !(dt > 0.0f) || dt * 64.0f > t0) return false;   // the last test: 63 steps < one binade width
+    const float u = __uint_as_float(e - (23u << 23)), inv_u = __uint_as_float((254u << 23) - (e - (23u << 23)));   // 2^(e-23), 2^-(e-23)
+    const float top = __uint_as_float(e + (1u << 23));
+    const float q = dt * inv_u, n = floorf(q), r = q - n;       // exact: scaling by a power of two
+    if (r == 0.5f || n >= 131072.0f) return false;               // tie, or 64*(n+1) would leave the exact-integer range of fp32
+    const float N = n + (r > 0.5f ? 1.0f : 0.0f), inc = N * u;
+    // first index whose exact value reaches the next binade: jc = ceil((top - t0) / inc), in exact integer arithmetic (units of u)
+    const float D = (top - t0) * inv_u;                          // exact integer < 2^23
+    float jc = floorf(D / N);
+    while (jc * N < D) jc += 1.0f;                               // correct the division's rounding (at most one step each way)
+    while (jc >= 1.0f && (jc - 1.0f) * N >= D) jc -= 1.0f;
+    const float j = (float)lane;
+    if (j < jc) {
+        tj = t0 + j * inc;
+        return true;
+    }
+    // past the boundary: ulp 2u
+    const float tc = (t0 + (jc - 1.0f) * inc) + dt;             // one rounded addition, exactly as the chain does it (jc >= 1: t0 < top)
+    const float q2 = q * 0.5f, n2 = floorf(q2), r2 = q2 - n2;
+    if (r2 == 0.5f) return false;                                // uniform: depends on dt and the binade only
+    const float inc2 = (n2 + (r2 > 0.5f ? 1.0f : 0.0f)) * (2.0f * u);
+    tj = tc + (j - jc) * inc2;
+    return true;
+}
+
 template <bool kOneCascade, bool kConstDt>
 __global__ void __launch_bounds__(256) k_march_index(const float *__restrict__ rays_o, const float *__restrict__ rays_d, GridView g,
                                                       uint32_t max_steps, uint32_t N, const float *__restrict__ nears,
@@ -268,8 +303,17 @@ __global__ void __launch_bounds__(256) k_march_index(const float *__restrict__ r
     while (t_base < far && cnt < max_steps) {
         // lane j: t_j = t_base advanced j times (its own sequential chain, identical rounding to the one-lane walk)
         float tj = t_base;
-        for (int i = 0; i < 63; ++i)
-            if (i < lane) tj += step(tj);
+        bool closed = false;
+        if (kConstDt) {
+            // every return path of chunk_closed_form before the lane-dependent part is wave-uniform; the tie test after the
+            // boundary is uniform too, so `closed` is the same in all lanes
+            closed = chunk_closed_form(t_base, g.dt_min, lane, tj);
+            closed = __all(closed);
+            if (!closed) tj = t_base;
+        }
+        if (!closed)
+            for (int i = 0; i < 63; ++i)
+                if (i < lane) tj += step(tj);
         const float dt = step(tj);
         tl[lane] = tj;
         __builtin_amdgcn_wave_barrier();  // the binary search below reads other lanes' entries (same wave: LDS is in order)
