@@ -276,22 +276,26 @@ struct PairPtrs {
 };
 
 __global__ void __launch_bounds__(256) k_codebook_presum_sel(PairPtrs tabs, const float *__restrict__ message, uint32_t D, float4 *__restrict__ S) {
+    // Resolve the D selected tables once per workgroup (a chain message -> pointer -> data per table would otherwise sit in
+    // front of every load), then stream them eight at a time.
+    __shared__ const float4 *sel[NSIG_MAX_MESSAGE_DIM];
+    if (threadIdx.x < D) sel[threadIdx.x] = reinterpret_cast<const float4 *>(tabs.p[2 * threadIdx.x + (message[threadIdx.x] != 0.0f)]);
+    __syncthreads();
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= NSIG_TABLE_ROWS / 2) return;
     float4 acc = {0.f, 0.f, 0.f, 0.f};
     uint32_t i = 0;
-    for (; i + 4 <= D; i += 4) {
-        const float4 a = reinterpret_cast<const float4 *>(tabs.p[2 * i + (message[i] != 0.0f)])[e];
-        const float4 b = reinterpret_cast<const float4 *>(tabs.p[2 * i + 2 + (message[i + 1] != 0.0f)])[e];
-        const float4 c = reinterpret_cast<const float4 *>(tabs.p[2 * i + 4 + (message[i + 2] != 0.0f)])[e];
-        const float4 d = reinterpret_cast<const float4 *>(tabs.p[2 * i + 6 + (message[i + 3] != 0.0f)])[e];
-        acc.x = (((acc.x + a.x) + b.x) + c.x) + d.x;
-        acc.y = (((acc.y + a.y) + b.y) + c.y) + d.y;
-        acc.z = (((acc.z + a.z) + b.z) + c.z) + d.z;
-        acc.w = (((acc.w + a.w) + b.w) + c.w) + d.w;
+    for (; i + 8 <= D; i += 8) {   // the sum keeps the table order (bit-identical to the serial sum)
+        float4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = sel[i + u][e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w;
+        }
     }
     for (; i < D; ++i) {
-        const float4 a = reinterpret_cast<const float4 *>(tabs.p[2 * i + (message[i] != 0.0f)])[e];
+        const float4 a = sel[i][e];
         acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
     }
     S[e] = acc;
@@ -325,7 +329,25 @@ __global__ void __launch_bounds__(256) k_codebook_adam_sel(const float4 *__restr
     if (e >= NSIG_TABLE_ROWS / 2) return;
     float4 g = G[e];
     g.x *= grad_scale; g.y *= grad_scale; g.z *= grad_scale; g.w *= grad_scale;
-    for (uint32_t i = 0; i < D; ++i) {
+    // two tables per trip: six 16-byte loads in flight per thread before the first dependent store
+    uint32_t i = 0;
+    for (; i + 2 <= D; i += 2) {
+        const uint32_t j0 = 2 * i + (message[i] != 0.0f), j1 = 2 * i + 2 + (message[i + 1] != 0.0f);
+        float4 *pp0 = reinterpret_cast<float4 *>(a.p[j0]) + e, *pm0 = reinterpret_cast<float4 *>(a.m[j0]) + e, *pv0 = reinterpret_cast<float4 *>(a.v[j0]) + e;
+        float4 *pp1 = reinterpret_cast<float4 *>(a.p[j1]) + e, *pm1 = reinterpret_cast<float4 *>(a.m[j1]) + e, *pv1 = reinterpret_cast<float4 *>(a.v[j1]) + e;
+        float4 p0 = *pp0, m0 = *pm0, v0 = *pv0, p1 = *pp1, m1 = *pm1, v1 = *pv1;
+        const float ss0 = scratch[i], ib0 = scratch[D + i], ss1 = scratch[i + 1], ib1 = scratch[D + i + 1];
+        adam_update(g.x, p0.x, m0.x, v0.x, beta1, beta2, eps, ss0, ib0);
+        adam_update(g.y, p0.y, m0.y, v0.y, beta1, beta2, eps, ss0, ib0);
+        adam_update(g.z, p0.z, m0.z, v0.z, beta1, beta2, eps, ss0, ib0);
+        adam_update(g.w, p0.w, m0.w, v0.w, beta1, beta2, eps, ss0, ib0);
+        adam_update(g.x, p1.x, m1.x, v1.x, beta1, beta2, eps, ss1, ib1);
+        adam_update(g.y, p1.y, m1.y, v1.y, beta1, beta2, eps, ss1, ib1);
+        adam_update(g.z, p1.z, m1.z, v1.z, beta1, beta2, eps, ss1, ib1);
+        adam_update(g.w, p1.w, m1.w, v1.w, beta1, beta2, eps, ss1, ib1);
+        *pp0 = p0; *pm0 = m0; *pv0 = v0; *pp1 = p1; *pm1 = m1; *pv1 = v1;
+    }
+    for (; i < D; ++i) {
         const uint32_t j = 2 * i + (message[i] != 0.0f);
         float4 *pp = reinterpret_cast<float4 *>(a.p[j]) + e, *pm = reinterpret_cast<float4 *>(a.m[j]) + e, *pv = reinterpret_cast<float4 *>(a.v[j]) + e;
         float4 p = *pp, m = *pm, v = *pv;
