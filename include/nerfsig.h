@@ -226,11 +226,12 @@ int field_bwd(const float *xyzs, uint32_t M, float bound, const float *grad_sigm
 /*
  * torch.optim.Adam (betas, eps; no weight decay / amsgrad) in its capturable form over n dense fp32 tensors in one pass:
  * steps[i] (device scalar) is incremented, bias corrections use the new value, lr is a device scalar.  Replaces the generic
- * multi-tensor kernel for the decoder's parameters (main_nerf_wtmk.py:110).  scratch: 2 * 32 * ceil(n/32) floats.
+ * multi-tensor kernel for the decoder's parameters (main_nerf_wtmk.py:110).  grad_scale multiplies every gradient first
+ * (1/world after a sum all-reduce).  scratch: 2 * 32 * ceil(n/32) floats.
  */
 int opt_adam_dense(uint32_t n, float *const *params_host, const float *const *grads_host, float *const *exp_avg_host,
                    float *const *exp_avg_sq_host, float *const *steps_host, const uint32_t *numel_host, const float *lr, float beta1,
-                   float beta2, float eps, float *scratch, nsig_stream_t stream);
+                   float beta2, float eps, float grad_scale, float *scratch, nsig_stream_t stream);
 
 /* ------------------------------------------------------------------ elementwise tails, one kernel per direction */
 

@@ -530,7 +530,8 @@ __global__ void k_adam_dense_prepare(DenseAdam a, uint32_t n, const float *__res
     scratch[kDenseMax + i] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
 }
 
-__global__ void __launch_bounds__(256) k_adam_dense(DenseAdam a, uint32_t n, const float *__restrict__ scratch, float beta1, float beta2, float eps) {
+__global__ void __launch_bounds__(256) k_adam_dense(DenseAdam a, uint32_t n, const float *__restrict__ scratch, float beta1, float beta2, float eps,
+                                                    float grad_scale) {
     uint32_t i = 0;
     while (i + 1 < n && blockIdx.x >= a.chunk0[i + 1]) ++i;   // uniform: which tensor this chunk belongs to
     const uint32_t base = (blockIdx.x - a.chunk0[i]) * kDenseChunk;
@@ -542,7 +543,7 @@ __global__ void __launch_bounds__(256) k_adam_dense(DenseAdam a, uint32_t n, con
         const uint32_t e = base + u * 256 + threadIdx.x;
         if (e < a.numel[i]) {
             float p = pp[e], m = pm[e], v = pv[e];
-            adam_update(pg[e], p, m, v, beta1, beta2, eps, ss, ib);
+            adam_update(pg[e] * grad_scale, p, m, v, beta1, beta2, eps, ss, ib);
             pp[e] = p; pm[e] = m; pv[e] = v;
         }
     }
@@ -550,7 +551,7 @@ __global__ void __launch_bounds__(256) k_adam_dense(DenseAdam a, uint32_t n, con
 
 NSIG_EXPORT int opt_adam_dense(uint32_t n, float *const *params_host, const float *const *grads_host, float *const *exp_avg_host,
                                float *const *exp_avg_sq_host, float *const *steps_host, const uint32_t *numel_host, const float *lr, float beta1,
-                               float beta2, float eps, float *scratch, nsig_stream_t stream) {
+                               float beta2, float eps, float grad_scale, float *scratch, nsig_stream_t stream) {
     NSIG_REQUIRE(params_host && grads_host && exp_avg_host && exp_avg_sq_host && steps_host && numel_host && lr && scratch, "opt_adam_dense: null pointer");
     hipStream_t st = as_stream(stream);
     for (uint32_t first = 0; first < n; first += kDenseMax) {   // 32 tensors per pair of launches
@@ -569,7 +570,7 @@ NSIG_EXPORT int opt_adam_dense(uint32_t n, float *const *params_host, const floa
         a.chunk0[cnt] = chunks;
         k_adam_dense_prepare<<<1, kDenseMax, 0, st>>>(a, cnt, lr, beta1, beta2, scratch + (size_t)first * 2);
         if (int e = check_launch("opt_adam_dense (prepare)")) return e;
-        k_adam_dense<<<chunks, 256, 0, st>>>(a, cnt, scratch + (size_t)first * 2, beta1, beta2, eps);
+        k_adam_dense<<<chunks, 256, 0, st>>>(a, cnt, scratch + (size_t)first * 2, beta1, beta2, eps, grad_scale);
         if (int e = check_launch("opt_adam_dense")) return e;
     }
     return NSIG_OK;

@@ -32,10 +32,23 @@ def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
-class GradExchange:
-    """Mean all-reduce of (shared codebook gradient, decoder gradients) with the decoder in one flat bucket."""
+def _common_base(grads):
+    """The tensor all `grads` are views of, if together they tile it exactly (the fused decoder hands out such views)."""
+    base = grads[0]._base if grads else None
+    if base is None or any(g._base is not base for g in grads) or base.dim() != 1 or not base.is_contiguous():
+        return None
+    return base if sum(g.numel() for g in grads) == base.numel() else None
 
-    def __init__(self, decoder_params):
+
+class GradExchange:
+    """All-reduce of (shared codebook gradient, decoder gradients) with the decoder in one flat bucket.
+
+    average=True (default): the mean over ranks, in place.  average=False: the plain sum -- the caller folds 1/world into
+    the optimiser kernels (`grad_scale` of CodebookAdam.step_shared_sel / step_dense), which saves the two scaling
+    launches between the graphs of the captured step."""
+
+    def __init__(self, decoder_params, average=True):
+        self.average = average
         self.decoder_params = [p for p in decoder_params if p.requires_grad]
         n = sum(p.numel() for p in self.decoder_params)
         p0 = self.decoder_params[0]
@@ -50,6 +63,18 @@ class GradExchange:
         handles = []
         if shared_grad is not None:
             handles.append(dist.all_reduce(shared_grad, op=dist.ReduceOp.SUM, async_op=True))
+        grads = [p.grad for p in self.decoder_params if p.grad is not None]
+        flat = _common_base(grads)
+        if flat is not None:   # the gradients already live in one buffer: one collective, no copies
+            handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+            for h in handles:
+                h.wait()
+            if self.average:
+                if shared_grad is not None:
+                    shared_grad.mul_(1.0 / world)
+                flat.mul_(1.0 / world)
+            self.bytes_per_step = (shared_grad.numel() * 4 if shared_grad is not None else 0) + flat.numel() * 4
+            return
         off = 0
         for p in self.decoder_params:
             n = p.numel()
@@ -61,7 +86,7 @@ class GradExchange:
         handles.append(dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, async_op=True))
         for h in handles:
             h.wait()
-        inv = 1.0 / world
+        inv = 1.0 / world if self.average else 1.0
         if shared_grad is not None:
             shared_grad.mul_(inv)
         off = 0

@@ -107,7 +107,13 @@ class _FusedDecoder(torch.autograd.Function):
         img, ws, *ps = ctx.saved_tensors
         B, Cin, H, W, rendered = ctx.geom
         mean, std = ((ctypes.c_float * Cin)(*_MEAN[:Cin]), (ctypes.c_float * Cin)(*_STD[:Cin])) if rendered else (None, None)
-        grads = [torch.empty_like(p) for p in ps]
+        # one flat buffer, the parameter gradients are views of it: the data-parallel exchange all-reduces it in place
+        # (dp.GradExchange) instead of packing 27 tensors into a bucket and unpacking them again
+        flat = torch.empty(sum(p.numel() for p in ps), dtype=torch.float32, device=img.device)
+        grads, off = [], 0
+        for p in ps:
+            grads.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
         grad_img = torch.empty_like(img)
         nv.call("dec_backward", nv.ptr(grad_out.contiguous().view(-1)), nv.ptr(img), int(rendered), mean, std, nv.ptr_array(ps), B, Cin, H, W,
                 nv.ptr(ws), nv.ptr_array(grads), nv.ptr(grad_img), nv.stream())

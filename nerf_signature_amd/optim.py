@@ -89,7 +89,7 @@ def _step_shared_sel(opt, tables, message_dev, G, lr_dev, grad_scale=1.0):
 CodebookAdam.step_shared_sel = torch.no_grad()(_step_shared_sel)
 
 
-def _step_dense(opt, lr_dev):
+def _step_dense(opt, lr_dev, grad_scale=1.0):
     """torch.optim.Adam's update of every parameter that carries a dense `.grad` (the decoder) through opt_adam_dense: one
     pass of 1024-element chunks instead of the generic multi-tensor kernel's 64K-element ones.  State in torch's capturable
     format (device step counts), so `step()` and `state_dict()` keep working on it."""
@@ -122,7 +122,7 @@ def _step_dense(opt, lr_dev):
     nv.call("opt_adam_dense", n, nv.ptr_array([p.data for p in ps]), nv.ptr_array([p.grad for p in ps]),
             nv.ptr_array([opt.state[p]["exp_avg"] for p in ps]), nv.ptr_array([opt.state[p]["exp_avg_sq"] for p in ps]),
             nv.ptr_array([opt.state[p]["step"] for p in ps]), numel, nv.ptr(lr_dev), float(group["betas"][0]), float(group["betas"][1]),
-            float(group["eps"]), nv.ptr(scratch), nv.stream())
+            float(group["eps"]), float(grad_scale), nv.ptr(scratch), nv.stream())
     _bump_versions(ps)
 
 

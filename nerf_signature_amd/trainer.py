@@ -178,7 +178,7 @@ class GraphedWatermarkLoop:
         D = model.message_dim
         self.sink = fo.GradSink(dev)
         model.grad_sink = self.sink
-        self.exchange = GradExchange(list(model.msg_decoder.parameters()))
+        self.exchange = GradExchange(list(model.msg_decoder.parameters()), average=not native_dense_adam)
         self.data = {"watermark": {k: v.clone() for k, v in data["watermark"].items()},
                      "content": {k: v.clone() for k, v in data["content"].items()}}
         self.msg_dev = torch.zeros(D, dtype=torch.float32, device=dev)
@@ -201,9 +201,10 @@ class GraphedWatermarkLoop:
         return out
 
     def _optimise(self):
-        self.optimizer.step_shared_sel(self.tables, self.msg_dev, self.sink.G, self.lr_dev)
+        scale = 1.0 / world_size() if self.native_dense_adam else 1.0    # the exchange leaves sums: the mean is taken here
+        self.optimizer.step_shared_sel(self.tables, self.msg_dev, self.sink.G, self.lr_dev, scale)
         if self.native_dense_adam:
-            self.optimizer.step_dense(self.lr_dev)      # the decoder's parameters: opt_adam_dense
+            self.optimizer.step_dense(self.lr_dev, scale)      # the decoder's parameters: opt_adam_dense
         else:
             self.optimizer.step()
 

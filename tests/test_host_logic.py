@@ -140,6 +140,19 @@ def _dp_worker(rank, world, port, q):
     nbytes = dp.allreduce_gradients(ps, bucket_bytes=48)
     assert nbytes == 68 and ps[2].grad is None
     assert torch.allclose(ps[0].grad, torch.full((5, 2), 0.5)) and torch.allclose(ps[1].grad, torch.full((7,), 2.0))
+    # gradients that are views of one flat buffer (what the fused decoder hands out): all-reduced in place, as a sum
+    dec2 = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 1))
+    ps2 = list(dec2.parameters())
+    flat = torch.arange(sum(p.numel() for p in ps2), dtype=torch.float32) * (rank + 1)
+    off = 0
+    for p in ps2:
+        p.grad = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    G2 = torch.ones(4, 2) * (rank + 1)
+    ex2 = dp.GradExchange(ps2, average=False)
+    ex2(G2)
+    assert torch.equal(flat, torch.arange(flat.numel(), dtype=torch.float32) * 3) and torch.equal(G2, torch.full((4, 2), 3.0))
+    assert all(p.grad._base is flat for p in ps2) and ex2.bytes_per_step == (8 + flat.numel()) * 4
     q.put((rank, ok, G.clone(), grads, ex.bytes_per_step))
     dist.barrier()
     dist.destroy_process_group()
