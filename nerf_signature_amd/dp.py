@@ -33,11 +33,23 @@ def world_size():
 
 
 def _common_base(grads):
-    """The tensor all `grads` are views of, if together they tile it exactly (the fused decoder hands out such views)."""
-    base = grads[0]._base if grads else None
-    if base is None or any(g._base is not base for g in grads) or base.dim() != 1 or not base.is_contiguous():
+    """One flat tensor over the storage all `grads` share, if they are contiguous float32 pieces that tile it exactly (the fused
+    decoder hands out such pieces; autograd keeps them as `.grad` without copying, though not as registered views)."""
+    if not grads or any(g.dtype != torch.float32 or not g.is_contiguous() for g in grads):
         return None
-    return base if sum(g.numel() for g in grads) == base.numel() else None
+    st = grads[0].untyped_storage()
+    if any(g.untyped_storage().data_ptr() != st.data_ptr() for g in grads):
+        return None
+    n = st.nbytes() // 4
+    pieces = sorted((g.storage_offset(), g.numel()) for g in grads)
+    end = 0
+    for off, cnt in pieces:
+        if off != end:
+            return None
+        end += cnt
+    if end != n:
+        return None
+    return torch.empty(0, dtype=torch.float32, device=grads[0].device).set_(st, 0, (n,))
 
 
 class GradExchange:

@@ -491,3 +491,22 @@ def test_dense_adam_matches_torch_adam():
         np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-6, atol=1e-7, err_msg=str(i))
         assert float(oa.state[p]["step"]) == float(ob.state[q]["step"])
         np.testing.assert_allclose(oa.state[p]["exp_avg_sq"].cpu().numpy(), ob.state[q]["exp_avg_sq"].cpu().numpy(), rtol=2e-6, atol=0)
+
+
+def test_fused_decoder_gradients_are_views_of_one_flat_buffer():
+    """What dp.GradExchange relies on for its single in-place all-reduce: after backward() every decoder parameter's .grad is a
+    view of one contiguous buffer that they tile exactly (conv biases, whose gradient is identically zero, have none)."""
+    from nerf_signature_amd.dp import _common_base
+    from nerf_signature_amd.hidden_models import get_hidden_decoder_multi_views
+    torch.manual_seed(4)
+    dec = get_hidden_decoder_multi_views(num_bits=1, redundancy=1, num_blocks=8, input_ch=3, channels=64).cuda()
+    image = torch.rand(32, 12, 12, 3, device="cuda", requires_grad=True)
+    out, _ = dec.decode_rendered(image)
+    out.sum().backward()
+    grads = [p.grad for p in dec.parameters() if p.grad is not None]
+    assert len(grads) == 29 and sum(p.grad is None for p in dec.parameters()) == 9
+    flat = _common_base(grads)
+    assert flat is not None and flat.numel() == sum(g.numel() for g in grads)
+    before = [g.clone() for g in grads]
+    flat.mul_(2.0)                                   # what the exchange does in place reaches every .grad
+    assert all(torch.equal(g, 2.0 * b) for g, b in zip(grads, before))

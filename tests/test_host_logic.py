@@ -152,7 +152,7 @@ def _dp_worker(rank, world, port, q):
     ex2 = dp.GradExchange(ps2, average=False)
     ex2(G2)
     assert torch.equal(flat, torch.arange(flat.numel(), dtype=torch.float32) * 3) and torch.equal(G2, torch.full((4, 2), 3.0))
-    assert all(p.grad._base is flat for p in ps2) and ex2.bytes_per_step == (8 + flat.numel()) * 4
+    assert ex2.bytes_per_step == (8 + flat.numel()) * 4
     q.put((rank, ok, G.clone(), grads, ex.bytes_per_step))
     dist.barrier()
     dist.destroy_process_group()
