@@ -112,14 +112,31 @@ __device__ unsigned long long g_scatter_stamps[8];
 #define SC_STAMP(k)
 #endif
 
-__global__ void __launch_bounds__(1024) k_scatter_sliced(const float *__restrict__ rec, uint32_t M, float *__restrict__ G) {
+// `sets` record arrays of M points each (one for the codebook; 16, one per base level, in stage-1 training), each scattered into
+// its own table.  replicas == 1: every row has one owner, which stores.  Workgroup order for sets = 16: rounds of 8 sets, set =
+// 8*round + blockIdx % 8, so the 32*replicas workgroups that scan one set's records share an XCD (blockIdx % 8) whose L2 holds
+// that one record array (4 MiB at 131 k points); interleaving all 16 sets put two arrays on every XCD and doubled the time.
+struct ScatterTargets {
+    float *g[NSIG_BASE_LEVELS];
+};
+__global__ void __launch_bounds__(1024) k_scatter_sliced(const float *__restrict__ rec_all, uint32_t M, ScatterTargets tg, uint32_t sets, uint32_t replicas) {
     extern __shared__ float acc[];  // [kSliceRows][2]
-    const uint32_t slice = blockIdx.x >> 3, replica = blockIdx.x & 7u;
+    uint32_t set = 0, sr = blockIdx.x;
+    if (sets > 1) {
+        const uint32_t per_round = 8u * kSlices * replicas, round = blockIdx.x / per_round, b = blockIdx.x - round * per_round;
+        set = round * 8u + (b & 7u);
+        sr = b >> 3;
+        if (set >= sets) return;
+    }
+    const uint32_t slice = sr / replicas, replica = sr - slice * replicas;
+    const float *__restrict__ rec = rec_all + (size_t)set * M * 8;
+    float *__restrict__ G = tg.g[set];
+    const uint32_t kReplicasRt = replicas;
     SC_STAMP(0);
     for (uint32_t i = threadIdx.x; i < 2u * kSliceRows; i += blockDim.x) acc[i] = 0.0f;
     __syncthreads();
     SC_STAMP(1);
-    const uint32_t chunk = ceil_div(M, (uint32_t)kReplicas);
+    const uint32_t chunk = ceil_div(M, kReplicasRt);
     const uint32_t beg = min(M, replica * chunk), end = min(M, beg + chunk);
     const uint4 *__restrict__ rec4 = reinterpret_cast<const uint4 *>(rec);
     // With 16 waves per CU and ~150 points per thread the scan is a chain of exposed L2 latencies unless several points'
@@ -163,9 +180,13 @@ __global__ void __launch_bounds__(1024) k_scatter_sliced(const float *__restrict
     __syncthreads();
     SC_STAMP(3);
     float *out = G + 2 * (size_t)slice * kSliceRows;
-    for (uint32_t i = threadIdx.x; i < 2u * kSliceRows; i += blockDim.x) {
-        const float v = acc[i];
-        if (v != 0.0f) atomicAdd(out + i, v);
+    if (replicas == 1) {
+        for (uint32_t i = threadIdx.x; i < 2u * kSliceRows; i += blockDim.x) out[i] = acc[i];
+    } else {
+        for (uint32_t i = threadIdx.x; i < 2u * kSliceRows; i += blockDim.x) {
+            const float v = acc[i];
+            if (v != 0.0f) atomicAdd(out + i, v);
+        }
     }
     SC_STAMP(4);
 }
@@ -206,6 +227,24 @@ __global__ void __launch_bounds__(1024) k_scatter_level(const float *__restrict_
         const float v = acc[i];
         if (v != 0.0f) atomicAdd(out + i, v);
     }
+}
+
+// Stage-1 training scatters into all 16 base tables.  The cell index and weights of a (point, level) need the level's IEEE
+// divisions (corner_rows), which the 32 slice owners of that level would each repeat: instead they are computed once here, into
+// the same 32-byte record the codebook scatter consumes, and k_scatter_sliced runs over 16 record sets.
+__global__ void __launch_bounds__(256) k_level_records(const float *__restrict__ xyzs, float bound, const float2 *__restrict__ dplanes, uint32_t M,
+                                                       uint32_t stride, LevelGeom geom, uint4 *__restrict__ rec) {
+    const uint32_t m = blockIdx.x * 256 + threadIdx.x, level = blockIdx.y;
+    if (m >= M) return;
+    const float2 g = dplanes[(size_t)level * stride + m];
+    const float two_b = 2.0f * bound, cell = geom.cell[level];
+    uint32_t idx[3];
+    float w[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) axis_cell((xyzs[3 * (size_t)m + a] + bound) / two_b, cell, idx[a], w[a]);
+    uint4 *r4 = rec + 2 * ((size_t)level * M + m);
+    r4[0] = make_uint4(idx[0] | (idx[1] << 16), idx[2], __float_as_uint(w[0]), __float_as_uint(w[1]));
+    r4[1] = make_uint4(__float_as_uint(w[2]), __float_as_uint(g.x), __float_as_uint(g.y), 0u);
 }
 
 // grads[i][e] (+)= G[e]: float4 per lane, D output streams.
@@ -471,7 +510,9 @@ NSIG_EXPORT int hg_scatter_sliced(const float *rec, uint32_t M, float *G, nsig_s
         }
         attr_set = true;
     }
-    k_scatter_sliced<<<kSlices * kReplicas, 1024, lds, as_stream(stream)>>>(rec, M, G);
+    ScatterTargets tg{};
+    tg.g[0] = G;
+    k_scatter_sliced<<<kSlices * kReplicas, 1024, lds, as_stream(stream)>>>(rec, M, tg, 1u, (uint32_t)kReplicas);
     return check_launch("hg_scatter_sliced");
 }
 
@@ -574,6 +615,45 @@ NSIG_EXPORT int opt_adam_dense(uint32_t n, float *const *params_host, const floa
         if (int e = check_launch("opt_adam_dense")) return e;
     }
     return NSIG_OK;
+}
+
+NSIG_EXPORT size_t hg_scatter_levels_scratch_bytes(uint32_t M) { return (size_t)NSIG_BASE_LEVELS * M * 32; }
+
+NSIG_EXPORT int hg_scatter_levels(const float *xyzs, float bound, const void *d_planes, uint32_t M, uint32_t stride, float *const *G_host,
+                                  void *scratch, nsig_stream_t stream) {
+    NSIG_REQUIRE(xyzs && d_planes && G_host && scratch, "hg_scatter_levels: null pointer");
+    NSIG_REQUIRE(bound > 0.0f && stride >= M && M < (1u << 30), "hg_scatter_levels: bad bound, stride < M or M >= 2^30");
+    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 15) == 0, "hg_scatter_levels: scratch must be 16-byte aligned");
+    ScatterTargets tg{};
+    for (int l = 0; l < NSIG_BASE_LEVELS; ++l) {
+        NSIG_REQUIRE(G_host[l], "hg_scatter_levels: table %d has a null pointer", l);
+        tg.g[l] = G_host[l];
+    }
+    hipStream_t st = as_stream(stream);
+    const uint32_t replicas = M <= 262144u ? 1u : (ceil_div(M, 262144u) < (uint32_t)kReplicas ? ceil_div(M, 262144u) : (uint32_t)kReplicas);
+    if (replicas > 1 || M == 0) {   // owners accumulate with atomics (or there is nothing to add): the tables start from zero
+        for (int l = 0; l < NSIG_BASE_LEVELS; ++l)
+            if (hipMemsetAsync(tg.g[l], 0, (size_t)NSIG_TABLE_ROWS * 2 * sizeof(float), st) != hipSuccess) {
+                set_error("hg_scatter_levels: hipMemsetAsync failed");
+                return NSIG_ERR_LAUNCH;
+            }
+        if (M == 0) return NSIG_OK;
+    }
+    k_level_records<<<dim3(ceil_div(M, 256u), NSIG_BASE_LEVELS), 256, 0, st>>>(xyzs, bound, reinterpret_cast<const float2 *>(d_planes), M, stride,
+                                                                              make_level_geom(), reinterpret_cast<uint4 *>(scratch));
+    if (int e = check_launch("hg_scatter_levels (records)")) return e;
+    static bool attr_set = false;
+    const size_t lds = (size_t)kSliceRows * 2 * sizeof(float);
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_sliced), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error("hg_scatter_levels: cannot reserve %zu bytes of LDS", lds);
+            return NSIG_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    k_scatter_sliced<<<ceil_div((uint32_t)NSIG_BASE_LEVELS, 8u) * 8u * kSlices * replicas, 1024, lds, st>>>(reinterpret_cast<const float *>(scratch), M, tg,
+                                                                                                   (uint32_t)NSIG_BASE_LEVELS, replicas);
+    return check_launch("hg_scatter_levels");
 }
 
 NSIG_EXPORT int hg_scatter_level(const float *xyzs, float bound, const void *d_plane, uint32_t M, uint32_t level, float *G, nsig_stream_t stream) {

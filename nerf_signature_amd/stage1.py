@@ -64,15 +64,22 @@ class _CleanFieldFunction(Function):
         dWc3 = d_out[:, :M] @ a_h2[:, :M].t()
         g_sp = torch.cat([dW1s.reshape(-1), dW2s.reshape(-1)])
         g_cp = torch.cat([dWc1.reshape(-1), dWc2.reshape(-1), dWc3.reshape(-1)])
-        # base-table gradients: one owner-computes scatter per level
-        grads = []
-        for level, need in enumerate(ctx.table_grads):
-            if not need:
-                grads.append(None)
-                continue
-            G = torch.zeros(T_ROWS, 2, dtype=torch.float32, device=dev)
-            nv.call("hg_scatter_level", nv.ptr(xyzs), ctx.bound, nv.ptr(d_planes[level]), M, level, nv.ptr(G), nv.stream())
-            grads.append(G)
+        # base-table gradients: owner-computes scatter, all 16 levels in one launch (every row written by its owner: no zero fill)
+        if all(ctx.table_grads):
+            tables = torch.empty(16, T_ROWS, 2, dtype=torch.float32, device=dev)
+            scratch = torch.empty(nv.fn("hg_scatter_levels_scratch_bytes")(M), dtype=torch.uint8, device=dev)
+            nv.call("hg_scatter_levels", nv.ptr(xyzs), ctx.bound, nv.ptr(d_planes), M, stride, nv.ptr_array([tables[l] for l in range(16)]),
+                    nv.ptr(scratch), nv.stream())
+            grads = list(tables.unbind(0))
+        else:
+            grads = []
+            for level, need in enumerate(ctx.table_grads):
+                if not need:
+                    grads.append(None)
+                    continue
+                G = torch.zeros(T_ROWS, 2, dtype=torch.float32, device=dev)
+                nv.call("hg_scatter_level", nv.ptr(xyzs), ctx.bound, nv.ptr(d_planes[level]), M, level, nv.ptr(G), nv.stream())
+                grads.append(G)
         return (None, None, None, g_sp, g_cp) + tuple(grads)
 
 
