@@ -17,8 +17,10 @@ LIB = os.path.join(LIB_DIR, "libnerfsig.so")
 ARCH = "gfx950"
 
 # -ffp-contract=off: fused multiply-adds are written explicitly so integer results match the CPU oracle.
+# -amdgpu-mfma-vgpr-form: MFMA results in ordinary VGPRs -- the MLP kernels post-process every accumulator element on the VALU, and
+#  from the accumulator file each element costs an extra v_accvgpr_read (10 % of their instructions).
 FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
-         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def sources():
