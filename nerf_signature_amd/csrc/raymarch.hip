@@ -496,10 +496,18 @@ __device__ inline Chunk load_chunk(const float *__restrict__ sigmas, const float
     return c;
 }
 
+// Optional tail of the render (renderer_wtmk.py:316-319) done by the ray's wave instead of a separate launch: background mix
+// and depth normalisation in the forward, the weights_sum gradient of the background mix in the backward.
+struct FinishArgs {
+    const float *nears, *fars, *bg;   // bg == nullptr: no tail
+    uint32_t bg_stride;               // 0: one colour [3]; 3: per ray
+    float *image_out, *depth_out;     // forward outputs
+};
+
 __global__ void __launch_bounds__(256) k_composite_fwd(const float *__restrict__ sigmas, const float *__restrict__ rgbs,
                                                        const float *__restrict__ deltas, const int32_t *__restrict__ rays, uint32_t M,
                                                        uint32_t N, float T_thresh, float *__restrict__ weights_sum,
-                                                       float *__restrict__ depth, float *__restrict__ image) {
+                                                       float *__restrict__ depth, float *__restrict__ image, FinishArgs fin = FinishArgs{}) {
     const int lane = threadIdx.x & 63;
     const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
@@ -520,6 +528,14 @@ __global__ void __launch_bounds__(256) k_composite_fwd(const float *__restrict__
         weights_sum[id] = ws;
         depth[id] = d;
         image[3 * (size_t)id] = r; image[3 * (size_t)id + 1] = g; image[3 * (size_t)id + 2] = b;
+        if (fin.bg != nullptr) {   // the arithmetic of k_finish_fwd, operation by operation
+            const float rest = 1.0f - ws;
+            const float *bgp = fin.bg + (size_t)id * fin.bg_stride;
+            fin.image_out[3 * (size_t)id] = r + rest * bgp[0];
+            fin.image_out[3 * (size_t)id + 1] = g + rest * bgp[1];
+            fin.image_out[3 * (size_t)id + 2] = b + rest * bgp[2];
+            fin.depth_out[id] = fmaxf(d - fin.nears[id], 0.0f) / (fin.fars[id] - fin.nears[id]);
+        }
     }
 }
 
@@ -530,7 +546,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd(const float *__restrict__
                                                        const float *__restrict__ deltas, const int32_t *__restrict__ rays,
                                                        const float *__restrict__ weights_sum, const float *__restrict__ image, uint32_t M,
                                                        uint32_t N, float T_thresh, float *__restrict__ grad_sigmas,
-                                                       float *__restrict__ grad_rgbs) {
+                                                       float *__restrict__ grad_rgbs, FinishArgs fin = FinishArgs{}) {
     const int lane = threadIdx.x & 63;
     const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
@@ -538,7 +554,14 @@ __global__ void __launch_bounds__(256) k_composite_bwd(const float *__restrict__
     if (cnt == 0 || off + cnt > M) return;
     const float g0 = grad_image[3 * (size_t)id], g1 = grad_image[3 * (size_t)id + 1], g2 = grad_image[3 * (size_t)id + 2];
     const float rf = image[3 * (size_t)id], gf = image[3 * (size_t)id + 1], bf = image[3 * (size_t)id + 2];
-    const float tail = grad_ws[id] * (1.0f - weights_sum[id]);
+    float gws = grad_ws != nullptr ? grad_ws[id] : 0.0f;
+    if (fin.bg != nullptr) {   // image_out = image + (1 - weights_sum) * bg  =>  d weights_sum -= sum_c grad_image_c * bg_c (k_finish_bwd)
+        const float *bgp = fin.bg + (size_t)id * fin.bg_stride;
+        float sgb = 0.0f;
+        sgb += g0 * bgp[0]; sgb += g1 * bgp[1]; sgb += g2 * bgp[2];
+        gws = gws + (-sgb);
+    }
+    const float tail = gws * (1.0f - weights_sum[id]);
     float T = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f;  // carries: transmittance and accumulated colour entering the chunk
     auto add = [](float a, float c) { return a + c; };
     for (uint32_t base = 0; base < cnt; base += 64) {
@@ -763,6 +786,39 @@ NSIG_EXPORT int rm_composite_train_fwd(const float *sigmas, const float *rgbs, c
     if (N == 0) return NSIG_OK;
     k_composite_fwd<<<ceil_div(N, 4u), 256, 0, as_stream(stream)>>>(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image);
     return check_launch("rm_composite_train_fwd");
+}
+
+NSIG_EXPORT int rm_composite_train_finish_fwd(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays, uint32_t M,
+                                              uint32_t N, float T_thresh, const float *nears, const float *fars, const float *bg,
+                                              uint32_t bg_stride, float *weights_sum, float *depth, float *image, float *image_out,
+                                              float *depth_out, nsig_stream_t stream) {
+    NSIG_REQUIRE(sigmas && rgbs && deltas && rays && weights_sum && depth && image && nears && fars && bg && image_out && depth_out,
+                 "rm_composite_train_finish_fwd: null pointer");
+    NSIG_REQUIRE(bg_stride == 0 || bg_stride == 3, "rm_composite_train_finish_fwd: bg_stride is 0 (one colour) or 3 (per ray)");
+    if (N == 0) return NSIG_OK;
+    const FinishArgs fin{nears, fars, bg, bg_stride, image_out, depth_out};
+    k_composite_fwd<<<ceil_div(N, 4u), 256, 0, as_stream(stream)>>>(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image, fin);
+    return check_launch("rm_composite_train_finish_fwd");
+}
+
+NSIG_EXPORT int rm_composite_train_finish_bwd(const float *grad_weights_sum, const float *grad_image_out, const float *sigmas, const float *rgbs,
+                                              const float *deltas, const int32_t *rays, const float *weights_sum, const float *image,
+                                              const float *bg, uint32_t bg_stride, uint32_t M, uint32_t N, float T_thresh, float *grad_sigmas,
+                                              float *grad_rgbs, nsig_stream_t stream) {
+    NSIG_REQUIRE(grad_image_out && sigmas && rgbs && deltas && rays && weights_sum && image && bg && grad_sigmas && grad_rgbs,
+                 "rm_composite_train_finish_bwd: null pointer");
+    NSIG_REQUIRE(bg_stride == 0 || bg_stride == 3, "rm_composite_train_finish_bwd: bg_stride is 0 (one colour) or 3 (per ray)");
+    if (M == 0) return NSIG_OK;
+    if (hipMemsetAsync(grad_sigmas, 0, (size_t)M * sizeof(float), as_stream(stream)) != hipSuccess ||
+        hipMemsetAsync(grad_rgbs, 0, (size_t)M * 3 * sizeof(float), as_stream(stream)) != hipSuccess) {
+        set_error("rm_composite_train_finish_bwd: hipMemsetAsync failed");
+        return NSIG_ERR_LAUNCH;
+    }
+    if (N == 0) return NSIG_OK;
+    const FinishArgs fin{nullptr, nullptr, bg, bg_stride, nullptr, nullptr};
+    k_composite_bwd<<<ceil_div(N, 4u), 256, 0, as_stream(stream)>>>(grad_weights_sum, grad_image_out, sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
+                                                                    T_thresh, grad_sigmas, grad_rgbs, fin);
+    return check_launch("rm_composite_train_finish_bwd");
 }
 
 NSIG_EXPORT int rm_composite_train_bwd(const float *grad_weights_sum, const float *grad_image, const float *sigmas,

@@ -66,6 +66,38 @@ class _Finish(torch.autograd.Function):
         return g_image, g_depth_in, g_ws, None, None, None
 
 
+class _CompositeFinish(torch.autograd.Function):
+    """composite_rays_train + the render tail in one launch each way (rm_composite_train_finish_fwd/_bwd)."""
+
+    @staticmethod
+    def forward(ctx, sigmas, rgbs, deltas, rays, nears, fars, bg, T_thresh):
+        sigmas, rgbs, deltas = sigmas.contiguous(), rgbs.contiguous(), deltas.contiguous()
+        M, N = sigmas.shape[0], rays.shape[0]
+        dev = sigmas.device
+        weights_sum, depth, image = (torch.empty(N, dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev),
+                                     torch.empty(N, 3, dtype=torch.float32, device=dev))
+        image_out, depth_out = torch.empty_like(image), torch.empty_like(depth)
+        stride = 0 if bg.numel() == 3 else 3
+        nv.call("rm_composite_train_finish_fwd", nv.ptr(sigmas), nv.ptr(rgbs), nv.ptr(deltas), nv.ptr(rays), M, N, float(T_thresh), nv.ptr(nears),
+                nv.ptr(fars), nv.ptr(bg), stride, nv.ptr(weights_sum), nv.ptr(depth), nv.ptr(image), nv.ptr(image_out), nv.ptr(depth_out), nv.stream())
+        ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, image, bg)
+        ctx.dims = (M, N, float(T_thresh), stride)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(depth_out)     # the depth gradient does not propagate (raymarching.py:275)
+        return weights_sum, depth_out, image_out
+
+    @staticmethod
+    def backward(ctx, g_ws, g_depth, g_image):
+        sigmas, rgbs, deltas, rays, weights_sum, image, bg = ctx.saved_tensors
+        M, N, T_thresh, stride = ctx.dims
+        g_image = torch.zeros_like(image) if g_image is None else g_image.contiguous()
+        grad_sigmas, grad_rgbs = torch.empty_like(sigmas), torch.empty_like(rgbs)
+        nv.call("rm_composite_train_finish_bwd", nv.ptr(None if g_ws is None else g_ws.contiguous()), nv.ptr(g_image), nv.ptr(sigmas), nv.ptr(rgbs),
+                nv.ptr(deltas), nv.ptr(rays), nv.ptr(weights_sum), nv.ptr(image), nv.ptr(bg), stride, M, N, T_thresh, nv.ptr(grad_sigmas),
+                nv.ptr(grad_rgbs), nv.stream())
+        return grad_sigmas, grad_rgbs, None, None, None, None, None, None
+
+
 class NeRFRenderer(nn.Module):
     def __init__(self, bound=1, cuda_ray=False, density_scale=1, min_near=0.2, density_thresh=0.01, bg_radius=-1):
         super().__init__()
@@ -170,8 +202,12 @@ class NeRFRenderer(nn.Module):
         prefix, o, d = self._flatten_rays(rays_o, rays_d)
         nears, fars = raymarching.near_far_from_aabb(o, d, self.aabb_train if self.training else self.aabb_infer, self.min_near)
         if self.training:
-            weights_sum, depth, image = self._march_and_composite_train(o, d, message, nears, fars, dt_gamma, perturb, force_all_rays,
-                                                                        max_steps, T_thresh)
+            bg = _background_tensor(bg_color, o) if o.is_cuda else None
+            out = self._march_and_composite_train(o, d, message, nears, fars, dt_gamma, perturb, force_all_rays, max_steps, T_thresh, finish=bg)
+            if bg is not None:   # the tail was done by the compositing launch
+                weights_sum, depth, image = out
+                return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "weights_sum": weights_sum}
+            weights_sum, depth, image = out
         else:
             weights_sum, depth, image = self._march_and_composite_eval(o, d, message, nears, fars, dt_gamma, perturb, max_steps, T_thresh)
         image, depth = self._finish(prefix, image, depth, weights_sum, bg_color, nears, fars)
@@ -180,13 +216,14 @@ class NeRFRenderer(nn.Module):
             results["weights_sum"] = weights_sum
         return results
 
-    def _march_and_composite_train(self, o, d, message, nears, fars, dt_gamma, perturb, force_all_rays, max_steps, T_thresh):
+    def _march_and_composite_train(self, o, d, message, nears, fars, dt_gamma, perturb, force_all_rays, max_steps, T_thresh, finish=None):
         """All samples of all rays at once, then one differentiable composite (renderer_wtmk.py:280-321)."""
         counter = self.step_counter[self.local_step % 16]  # ring of the last 16 (points, rays) totals
-        counter.zero_()
         self.local_step += 1
         capacity = getattr(self, "point_capacity", None)
         capacity = capacity.get(o.shape[0]) if capacity else None
+        if not (capacity is not None and force_all_rays):
+            counter.zero_()   # (the capacity path's scan kernel writes both entries itself: one launch less in the captured step)
         if capacity is not None and force_all_rays:
             # no host round trip: buffers sized by a known bound on the padded point count (see march_rays_train_capacity)
             xyzs, dirs, deltas, rays = raymarching.march_rays_train_capacity(o, d, self.bound, self.density_bitfield, self.cascade,
@@ -197,7 +234,10 @@ class NeRFRenderer(nn.Module):
                                                                    nears, fars, counter, self.mean_count, perturb, 128, force_all_rays,
                                                                    dt_gamma, max_steps)
         sigmas, rgbs = self(xyzs, dirs, message)
-        return raymarching.composite_rays_train(sigmas if self.density_scale == 1 else self.density_scale * sigmas, rgbs, deltas, rays, T_thresh)
+        sigmas = sigmas if self.density_scale == 1 else self.density_scale * sigmas
+        if finish is not None:
+            return _CompositeFinish.apply(sigmas, rgbs, deltas, rays, nears, fars, finish, T_thresh)
+        return raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
 
     def _march_and_composite_eval(self, o, d, message, nears, fars, dt_gamma, perturb, max_steps, T_thresh):
         """Bursts of 1..8 samples over the still-alive rays (renderer_wtmk.py:323-367).  The alive list is compacted

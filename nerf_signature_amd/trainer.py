@@ -38,6 +38,7 @@ class _WatermarkLoss(torch.autograd.Function):
         ctx.save_for_backward(d_content, d_decoded)
         ctx.lambdas = (lambda_w, lambda_i)
         ctx.set_materialize_grads(False)
+        _WatermarkLoss.stash = (d_content, d_decoded)   # see backward_from_loss_kernel
         return losses[0], losses[1], losses[2]
 
     @staticmethod
@@ -47,6 +48,20 @@ class _WatermarkLoss(torch.autograd.Function):
         nv.call("wm_loss_bwd", *(nv.ptr(None if g is None else g.contiguous()) for g in (g_li, g_lw, g_l)), *ctx.lambdas, nv.ptr(d_content),
                 d_content.numel(), nv.ptr(d_decoded), d_decoded.numel(), nv.ptr(g_content), nv.ptr(g_decoded), nv.stream())
         return g_content, None, g_decoded, None, None, None, None
+
+
+def backward_from_loss_kernel(out):
+    """`out[-1].backward()` for a train_step whose losses came from wm_loss_fwd, without the ones-fill and the wm_loss_bwd launch:
+    the forward kernel already left d(loss_i)/d(content) and d(loss_w)/d(decoded); for an upstream gradient of 1 they only need
+    the lambdas, which are applied here as the (host-side) scale of the seed."""
+    last = getattr(_WatermarkLoss, "last", None)
+    _WatermarkLoss.last = None
+    if last is None or last[0] is not out[-1]:
+        out[-1].backward()
+        return
+    _, content, decoded, d_content, d_decoded, lambda_w, lambda_i = last
+    seeds = [d_content if lambda_i == 1.0 else d_content * lambda_i, d_decoded if lambda_w == 1.0 else d_decoded * lambda_w]
+    torch.autograd.backward([content, decoded], seeds)
 
 
 def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce):
@@ -67,6 +82,7 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
     if loss_w is loss_w_bce and decoded.is_cuda and all(t.dtype == torch.float32 for t in (content_pred_rgb, gt_rgb, decoded, keys)) \
             and gt_rgb.shape == content_pred_rgb.shape and keys.shape == decoded.shape:
         lossi, lossw, loss = _WatermarkLoss.apply(content_pred_rgb, gt_rgb, decoded, keys, float(lambda_w), float(lambda_i), 10.0)
+        _WatermarkLoss.last = (loss, content_pred_rgb, decoded, *_WatermarkLoss.stash, float(lambda_w), float(lambda_i))
     else:
         lossi = ((content_pred_rgb - gt_rgb) ** 2).mean()
         lossw = loss_w(decoded, keys)
@@ -197,7 +213,7 @@ class GraphedWatermarkLoop:
     def _forward_backward(self):
         self.sink.zero_()
         out = train_step(self.model, self.data, self.msg_dev, self.render_kwargs, self.lambda_w, self.lambda_i)
-        out[-1].backward()
+        backward_from_loss_kernel(out)
         return out
 
     def _optimise(self):
