@@ -296,14 +296,16 @@ class GraphedWatermarkLoop:
         self.optimizer.zero_grad(set_to_none=True)
         split = world_size() > 1
         g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
+        # thread_local: with more than one rank the process group's watchdog thread queries events while we capture; only this
+        # thread's calls belong to the capture
+        with torch.cuda.graph(g1, capture_error_mode="thread_local"):
             self.out = self._forward_backward()
             if not split:
                 self._optimise()
         g2 = None
         if split:
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=g1.pool()):
+            with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
                 self._optimise()
         self.graphs = (g1, g2)
         self.capacity_rows = [(model.local_step - 2) % 16, (model.local_step - 1) % 16]
