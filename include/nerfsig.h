@@ -238,14 +238,17 @@ int opt_adam_dense(uint32_t n, float *const *params_host, const float *const *gr
  * and the normalised depth next to the raw weights_sum / depth / image, which the backward still needs), and
  * rm_composite_train_bwd with rm_finish_bwd's weights_sum term folded in: grad_image_out is the gradient of image_out,
  * grad_weights_sum (optional) any further gradient of weights_sum; the depth gradient is not propagated (raymarching.py:275).
+ * rays_in_order != 0: the caller guarantees what rm_march_train_scan produces -- rays in ascending, gapless offset order
+ * (offset[n+1] = offset[n] + count[n]) -- and the kernel then zero-fills every gradient row it does not write itself
+ * (terminated samples, rays that did not fit, the padding past the last ray) instead of two memsets over all M rows.
  */
 int rm_composite_train_finish_fwd(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays, uint32_t M, uint32_t N,
                                   float T_thresh, const float *nears, const float *fars, const float *bg, uint32_t bg_stride,
                                   float *weights_sum, float *depth, float *image, float *image_out, float *depth_out, nsig_stream_t stream);
 int rm_composite_train_finish_bwd(const float *grad_weights_sum, const float *grad_image_out, const float *sigmas, const float *rgbs,
                                   const float *deltas, const int32_t *rays, const float *weights_sum, const float *image, const float *bg,
-                                  uint32_t bg_stride, uint32_t M, uint32_t N, float T_thresh, float *grad_sigmas, float *grad_rgbs,
-                                  nsig_stream_t stream);
+                                  uint32_t bg_stride, uint32_t M, uint32_t N, float T_thresh, uint32_t rays_in_order, float *grad_sigmas,
+                                  float *grad_rgbs, nsig_stream_t stream);
 
 /* ------------------------------------------------------------------ elementwise tails, one kernel per direction */
 

@@ -51,7 +51,7 @@ SIGNATURES = {
     "field_color_fwd": [_vp, _vp, _u32, _vp, _vp, _vp],
     "opt_adam_dense": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _fl, _fl, _fl, _fl, _vp, _vp],
     "rm_composite_train_finish_fwd": [_vp, _vp, _vp, _vp, _u32, _u32, _fl, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp],
-    "rm_composite_train_finish_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _fl, _vp, _vp, _vp],
+    "rm_composite_train_finish_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _fl, _u32, _vp, _vp, _vp],
     "rm_finish_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp],
     "rm_finish_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp],
     "wm_loss_fwd": [_vp, _vp, _u32, _vp, _vp, _u32, _fl, _fl, _fl, _vp, _vp, _vp, _vp],

@@ -502,6 +502,7 @@ struct FinishArgs {
     const float *nears, *fars, *bg;   // bg == nullptr: no tail
     uint32_t bg_stride;               // 0: one colour [3]; 3: per ray
     float *image_out, *depth_out;     // forward outputs
+    uint32_t self_zero;               // backward: the kernel zero-fills every gradient row it does not write (no memsets before it)
 };
 
 __global__ void __launch_bounds__(256) k_composite_fwd(const float *__restrict__ sigmas, const float *__restrict__ rgbs,
@@ -548,10 +549,29 @@ __global__ void __launch_bounds__(256) k_composite_bwd(const float *__restrict__
                                                        uint32_t N, float T_thresh, float *__restrict__ grad_sigmas,
                                                        float *__restrict__ grad_rgbs, FinishArgs fin = FinishArgs{}) {
     const int lane = threadIdx.x & 63;
+    if (fin.self_zero && blockIdx.x >= ceil_div(N, 4u)) {
+        // tail blocks: rows past the last ray's samples (padding / unused capacity).  Rays are in ascending, gapless offset order.
+        const uint32_t total = (uint32_t)rays[3 * (size_t)(N - 1) + 1] + (uint32_t)rays[3 * (size_t)(N - 1) + 2];
+        for (size_t m = (size_t)total + (size_t)(blockIdx.x - ceil_div(N, 4u)) * 256 + threadIdx.x; m < M; m += (size_t)(gridDim.x - ceil_div(N, 4u)) * 256) {
+            grad_sigmas[m] = 0.0f;
+            grad_rgbs[3 * m] = 0.0f; grad_rgbs[3 * m + 1] = 0.0f; grad_rgbs[3 * m + 2] = 0.0f;
+        }
+        return;
+    }
     const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
     const uint32_t id = (uint32_t)rays[3 * (size_t)n], off = (uint32_t)rays[3 * (size_t)n + 1], cnt = (uint32_t)rays[3 * (size_t)n + 2];
-    if (cnt == 0 || off + cnt > M) return;
+    auto zero_rows = [&](uint32_t first, uint32_t last) {   // [first, last) of this ray's range, clipped to M
+        for (size_t m = (size_t)off + first + lane; m < (size_t)off + last && m < M; m += 64) {
+            grad_sigmas[m] = 0.0f;
+            grad_rgbs[3 * m] = 0.0f; grad_rgbs[3 * m + 1] = 0.0f; grad_rgbs[3 * m + 2] = 0.0f;
+        }
+    };
+    if (cnt == 0) return;
+    if (off + cnt > M) {   // a ray that did not fit (bounded mode): no gradient, but its rows below M belong to nobody else
+        if (fin.self_zero) zero_rows(0, cnt);
+        return;
+    }
     const float g0 = grad_image[3 * (size_t)id], g1 = grad_image[3 * (size_t)id + 1], g2 = grad_image[3 * (size_t)id + 2];
     const float rf = image[3 * (size_t)id], gf = image[3 * (size_t)id + 1], bf = image[3 * (size_t)id + 2];
     float gws = grad_ws != nullptr ? grad_ws[id] : 0.0f;
@@ -574,10 +594,17 @@ __global__ void __launch_bounds__(256) k_composite_bwd(const float *__restrict__
             grad_rgbs[3 * m] = g0 * c.w; grad_rgbs[3 * m + 1] = g1 * c.w; grad_rgbs[3 * m + 2] = g2 * c.w;
             grad_sigmas[m] = c.dt * (g0 * (c.T_after * c.c0 - (rf - r_incl)) + g1 * (c.T_after * c.c1 - (gf - g_incl)) +
                                      g2 * (c.T_after * c.c2 - (bf - b_incl)) + tail);
+        } else if (fin.self_zero && base + lane < cnt) {
+            const size_t m = (size_t)off + base + lane;
+            grad_sigmas[m] = 0.0f;
+            grad_rgbs[3 * m] = 0.0f; grad_rgbs[3 * m + 1] = 0.0f; grad_rgbs[3 * m + 2] = 0.0f;
         }
         T = __shfl(c.T_after, 63, 64);
         r = __shfl(r_incl, 63, 64); g = __shfl(g_incl, 63, 64); b = __shfl(b_incl, 63, 64);
-        if (T < T_thresh) break;
+        if (T < T_thresh) {   // the ray ended in this chunk: later samples get no gradient
+            if (fin.self_zero) zero_rows(base + 64, cnt);
+            break;
+        }
     }
 }
 
@@ -796,27 +823,28 @@ NSIG_EXPORT int rm_composite_train_finish_fwd(const float *sigmas, const float *
                  "rm_composite_train_finish_fwd: null pointer");
     NSIG_REQUIRE(bg_stride == 0 || bg_stride == 3, "rm_composite_train_finish_fwd: bg_stride is 0 (one colour) or 3 (per ray)");
     if (N == 0) return NSIG_OK;
-    const FinishArgs fin{nears, fars, bg, bg_stride, image_out, depth_out};
+    const FinishArgs fin{nears, fars, bg, bg_stride, image_out, depth_out, 0u};
     k_composite_fwd<<<ceil_div(N, 4u), 256, 0, as_stream(stream)>>>(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image, fin);
     return check_launch("rm_composite_train_finish_fwd");
 }
 
 NSIG_EXPORT int rm_composite_train_finish_bwd(const float *grad_weights_sum, const float *grad_image_out, const float *sigmas, const float *rgbs,
                                               const float *deltas, const int32_t *rays, const float *weights_sum, const float *image,
-                                              const float *bg, uint32_t bg_stride, uint32_t M, uint32_t N, float T_thresh, float *grad_sigmas,
-                                              float *grad_rgbs, nsig_stream_t stream) {
+                                              const float *bg, uint32_t bg_stride, uint32_t M, uint32_t N, float T_thresh, uint32_t rays_in_order,
+                                              float *grad_sigmas, float *grad_rgbs, nsig_stream_t stream) {
     NSIG_REQUIRE(grad_image_out && sigmas && rgbs && deltas && rays && weights_sum && image && bg && grad_sigmas && grad_rgbs,
                  "rm_composite_train_finish_bwd: null pointer");
     NSIG_REQUIRE(bg_stride == 0 || bg_stride == 3, "rm_composite_train_finish_bwd: bg_stride is 0 (one colour) or 3 (per ray)");
     if (M == 0) return NSIG_OK;
-    if (hipMemsetAsync(grad_sigmas, 0, (size_t)M * sizeof(float), as_stream(stream)) != hipSuccess ||
-        hipMemsetAsync(grad_rgbs, 0, (size_t)M * 3 * sizeof(float), as_stream(stream)) != hipSuccess) {
+    const bool self_zero = rays_in_order != 0 && N != 0;
+    if (!self_zero && (hipMemsetAsync(grad_sigmas, 0, (size_t)M * sizeof(float), as_stream(stream)) != hipSuccess ||
+                       hipMemsetAsync(grad_rgbs, 0, (size_t)M * 3 * sizeof(float), as_stream(stream)) != hipSuccess)) {
         set_error("rm_composite_train_finish_bwd: hipMemsetAsync failed");
         return NSIG_ERR_LAUNCH;
     }
     if (N == 0) return NSIG_OK;
-    const FinishArgs fin{nullptr, nullptr, bg, bg_stride, nullptr, nullptr};
-    k_composite_bwd<<<ceil_div(N, 4u), 256, 0, as_stream(stream)>>>(grad_weights_sum, grad_image_out, sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
+    const FinishArgs fin{nullptr, nullptr, bg, bg_stride, nullptr, nullptr, self_zero ? 1u : 0u};
+    k_composite_bwd<<<ceil_div(N, 4u) + (self_zero ? 64u : 0u), 256, 0, as_stream(stream)>>>(grad_weights_sum, grad_image_out, sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
                                                                     T_thresh, grad_sigmas, grad_rgbs, fin);
     return check_launch("rm_composite_train_finish_bwd");
 }

@@ -67,7 +67,8 @@ class _Finish(torch.autograd.Function):
 
 
 class _CompositeFinish(torch.autograd.Function):
-    """composite_rays_train + the render tail in one launch each way (rm_composite_train_finish_fwd/_bwd)."""
+    """composite_rays_train + the render tail in one launch each way (rm_composite_train_finish_fwd/_bwd).  `rays` must come from
+    this package's marcher (ascending, gapless offsets): the backward relies on it to zero-fill unwritten rows itself."""
 
     @staticmethod
     def forward(ctx, sigmas, rgbs, deltas, rays, nears, fars, bg, T_thresh):
@@ -93,7 +94,7 @@ class _CompositeFinish(torch.autograd.Function):
         g_image = torch.zeros_like(image) if g_image is None else g_image.contiguous()
         grad_sigmas, grad_rgbs = torch.empty_like(sigmas), torch.empty_like(rgbs)
         nv.call("rm_composite_train_finish_bwd", nv.ptr(None if g_ws is None else g_ws.contiguous()), nv.ptr(g_image), nv.ptr(sigmas), nv.ptr(rgbs),
-                nv.ptr(deltas), nv.ptr(rays), nv.ptr(weights_sum), nv.ptr(image), nv.ptr(bg), stride, M, N, T_thresh, nv.ptr(grad_sigmas),
+                nv.ptr(deltas), nv.ptr(rays), nv.ptr(weights_sum), nv.ptr(image), nv.ptr(bg), stride, M, N, T_thresh, 1, nv.ptr(grad_sigmas),
                 nv.ptr(grad_rgbs), nv.stream())
         return grad_sigmas, grad_rgbs, None, None, None, None, None, None
 

@@ -187,3 +187,45 @@ def test_get_rays_on_device_matches_reference_golden():
     em = torch.rand(1, 128 * 128).cuda()
     coarse = rays.get_rays(poses, g["intrinsics"], 400, 400, N=1024, error_map=em)
     assert coarse["inds_coarse"].shape == (1, 1024) and coarse["rays_d"].shape == (1, 1024, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("capacity_frac", [None, 0.6])
+def test_composite_with_fused_tail_matches_separate_launches(capacity_frac):
+    """rm_composite_train_finish_fwd/_bwd == composite_rays_train followed by the render tail, values and gradients -- including the
+    rows the fused backward zero-fills itself: samples after early termination, rays dropped by a too-small point buffer, padding."""
+    import torch
+    from nerf_signature_amd import raymarching as rm
+    from nerf_signature_amd.renderer import _CompositeFinish, _Finish
+    dev = torch.device("cuda")
+    _, bitfield, _, o, d = _scene(700, 1.0, seed=2, radius=1.6)
+    bits, o, d = _cuda(bitfield), _cuda(o), _cuda(d)
+    aabb = torch.tensor([-1., -1, -1, 1, 1, 1], device=dev)
+    nears, fars = rm.near_far_from_aabb(o, d, aabb, 0.2)
+    counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    if capacity_frac is None:
+        xyzs, dirs, deltas, rays = rm.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, counter, -1, False, 128, True, 0.0, 1024)
+    else:
+        full = rm.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, None, -1, False, 128, True, 0.0, 1024)[0].shape[0]
+        xyzs, dirs, deltas, rays = rm.march_rays_train_capacity(o, d, 1.0, bits, 1, 128, nears, fars, counter, rm.padded_point_count(int(full * capacity_frac)))
+        assert int(counter[0]) > xyzs.shape[0]                     # some rays did not fit
+    M = xyzs.shape[0]
+    torch.manual_seed(0)
+    sig = (torch.rand(M, device=dev) * 60).requires_grad_(True)     # dense enough for early termination (T < 1e-4) inside rays
+    rgb = torch.rand(M, 3, device=dev).requires_grad_(True)
+    bg = torch.rand(o.shape[0], 3, device=dev)
+    gi, gw = torch.randn(o.shape[0], 3, device=dev), torch.randn(o.shape[0], device=dev)
+    ws0, dp0, im0 = rm.composite_rays_train(sig, rgb, deltas, rays, 1e-4)
+    im0f, dp0f = _Finish.apply(im0, dp0, ws0, nears, fars, bg)
+    g0 = torch.autograd.grad([im0f, ws0], [sig, rgb], [gi, gw])
+    junk = torch.full((4 * M + 1024,), float("nan"), device=dev)   # so that recycled allocations do not happen to hold zeros
+    del junk
+    ws1, dp1, im1 = _CompositeFinish.apply(sig, rgb, deltas, rays, nears, fars, bg, 1e-4)
+    g1 = torch.autograd.grad([im1, ws1], [sig, rgb], [gi, gw])
+    assert torch.equal(ws0, ws1) and torch.equal(im0f, im1)
+    assert torch.equal(torch.nan_to_num(dp0f), torch.nan_to_num(dp1))
+    for a, b in zip(g0, g1):
+        assert torch.isfinite(b).all()
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    terminated = (g0[1].abs().sum(dim=1) == 0) & (deltas[:, 0] > 0)
+    assert bool(terminated.any())                                   # the early-termination rows were exercised
