@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="issue the content render on the main stream instead of overlapping it with the block render / decoder")
     ap.add_argument("--no-fused-adam", action="store_true", help="torch's multi-tensor instead of its fused Adam kernel for the decoder parameters")
     ap.add_argument("--no-channels-last", action="store_true", help="keep the decoder in NCHW memory format")
     ap.add_argument("--no-graph", action="store_true", help="run the loop body eagerly instead of replaying the captured hipGraph")
@@ -129,9 +130,9 @@ def main():
     # main_nerf_wtmk.py:110: Adam(get_params(lr), betas=(0.9, 0.99), eps=1e-15) -- same semantics, the codebook update fused
     optimizer = CodebookAdam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, **({} if args.no_graph else ({"capturable": True} if args.no_fused_adam else {"fused": True, "capturable": True})))
     if args.no_graph:
-        loop = trainer.WatermarkLoop(model, optimizer, render_kwargs)
+        loop = trainer.WatermarkLoop(model, optimizer, render_kwargs, side_stream=None if args.no_overlap else torch.cuda.Stream())
     else:
-        loop = trainer.GraphedWatermarkLoop(model, optimizer, render_kwargs, data)
+        loop = trainer.GraphedWatermarkLoop(model, optimizer, render_kwargs, data, overlap_content=not args.no_overlap)
 
     from nerf_signature_amd import _native as nv
     timer = NativeTimer(nv)
@@ -148,8 +149,11 @@ def main():
     torch.cuda.synchronize()
     timer.enabled = args.no_graph          # a replayed graph runs no Python: kernels are timed in the eager pass below
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    trace = os.environ.get("NERFSIG_BENCH_TRACE")          # diagnostics only: synchronises every step
+    for i in range(args.steps):
         out = one_step()
+        if trace and rank == 0 and i % 5 == 4:
+            print(f"[trace] step {args.warmup + i + 1}: loss_image {float(out[3]):.3e} loss_watermark {float(out[4]):.4f}", file=sys.stderr)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -161,6 +165,7 @@ def main():
         elapsed = float(t.item())
     overflow = None if args.no_graph else bool(loop.overflowed())
     loss_value = float(out[5].detach())
+    loss_parts = (float(out[3].detach()), float(out[4].detach()))
 
     if not args.no_graph:
         # the same kernels, launched eagerly so that HIP events can bracket them (live, same process, same inputs)
@@ -207,7 +212,7 @@ def main():
                 "grad_exchange_bytes_per_step": loop.exchange.bytes_per_step,
                 "execution": "eager" if args.no_graph else "hipGraph replay (one capture of forward+backward+optimiser)",
                 "capacity_overflow": overflow,
-                "loss": loss_value,
+                "loss": loss_value, "loss_image": loss_parts[0], "loss_watermark": loss_parts[1],
             },
             "roofline": {
                 "kernel": "k_encode_planes (16-level hash gather + pre-summed codebook gather, forward) on the block render",

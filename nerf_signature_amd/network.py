@@ -90,6 +90,16 @@ class NeRFNetwork(NeRFRenderer):
             self._presum_cache = (key, fo.codebook_presum_sel(tables, message, out=S))
         return tables, self._presum_cache[1]
 
+    def prepare_message(self, message):
+        """Compute (or find cached) the pre-summed codebook of `message` now, on the current stream -- so that renders issued on
+        different streams afterwards (trainer.train_step's overlapped content render) only read it."""
+        if message is None:
+            return
+        if self.device_select and message.is_cuda:
+            self._select_on_device(message)
+        else:
+            self._select(message)
+
     def forward(self, x, d, message):
         """x: [N,3] in [-bound,bound], d: [N,3] unit, message: [message_dim] of 0./1. or None -> (sigma [N], color [N,3])."""
         if self.device_select and message is not None and message.is_cuda:

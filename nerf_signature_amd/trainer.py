@@ -64,20 +64,36 @@ def backward_from_loss_kernel(out):
     torch.autograd.backward([content, decoded], seeds)
 
 
-def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce):
+def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce, side_stream=None):
     """data = {'watermark': {'rays_o_block', 'rays_d_block'}, 'content': {'rays_o', 'rays_d', 'images'}}.
-    Returns (pred_rgb, gt_rgb, content_pred_rgb, lossi, lossw, loss) like the reference."""
+    Returns (pred_rgb, gt_rgb, content_pred_rgb, lossi, lossw, loss) like the reference.
+
+    side_stream: a torch.cuda.Stream on which the content render is issued.  It depends on nothing the block render or the
+    decoder produce, and both chains are sequences of small latency-bound launches, so they overlap (forward and -- autograd
+    replays a node on the stream it ran on -- backward); the shared codebook gradient is accumulated with atomics by both."""
     wm, content = data["watermark"], data["content"]
     kw = dict(render_kwargs)
     kw.update(staged=False, bg_color=1, perturb=False, force_all_rays=True)
+    main = None
+    if side_stream is not None and wm["rays_o_block"].is_cuda:
+        main = torch.cuda.current_stream()
+        model.prepare_message(message)          # both renders read the pre-summed codebook: it must exist before the fork
+        side_stream.wait_stream(main)
     outputs = model.render(wm["rays_o_block"], wm["rays_d_block"], message, **kw)
+    if main is not None:
+        with torch.cuda.stream(side_stream):
+            content_pred_rgb = model.render(content["rays_o"], content["rays_d"], message, **kw)["image"]
+        content_pred_rgb.record_stream(main)
     if model.normalization is normalize_img and hasattr(model.msg_decoder, "decode_rendered"):
         decoded, pred_rgb = model.msg_decoder.decode_rendered(outputs["image"])    # clamp + permute + normalise inside layer 0
     else:
         pred_rgb = torch.clamp(outputs["image"], min=0, max=1)
         decoded = model.msg_decoder(model.normalization(pred_rgb.permute(0, 3, 1, 2)))
     gt_rgb = content["images"]
-    content_pred_rgb = model.render(content["rays_o"], content["rays_d"], message, **kw)["image"]
+    if main is not None:
+        main.wait_stream(side_stream)
+    else:
+        content_pred_rgb = model.render(content["rays_o"], content["rays_d"], message, **kw)["image"]
     keys = message.to(decoded.device).unsqueeze(-1)
     if loss_w is loss_w_bce and decoded.is_cuda and all(t.dtype == torch.float32 for t in (content_pred_rgb, gt_rgb, decoded, keys)) \
             and gt_rgb.shape == content_pred_rgb.shape and keys.shape == decoded.shape:
@@ -93,7 +109,8 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
 class WatermarkLoop:
     """Loop body of train_one_epoch (utils_wtmk_disen.py:1164-1181) for one model replica."""
 
-    def __init__(self, model, optimizer, render_kwargs, lambda_w=1.0, lambda_i=1.0, lr_scheduler=None, use_sink=True):
+    def __init__(self, model, optimizer, render_kwargs, lambda_w=1.0, lambda_i=1.0, lr_scheduler=None, use_sink=True, side_stream=None):
+        self.side_stream = side_stream
         self.model, self.optimizer, self.lr_scheduler = model, optimizer, lr_scheduler
         self.render_kwargs = dict(render_kwargs)
         self.lambda_w, self.lambda_i = lambda_w, lambda_i
@@ -108,8 +125,10 @@ class WatermarkLoop:
         self.optimizer.zero_grad(set_to_none=True)
         if self.sink is not None:
             self.sink.zero_()
-        out = train_step(self.model, data, message, self.render_kwargs, self.lambda_w, self.lambda_i)
+        out = train_step(self.model, data, message, self.render_kwargs, self.lambda_w, self.lambda_i, side_stream=self.side_stream)
         out[-1].backward()
+        if self.side_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.side_stream)
         self.exchange(self.sink.G if self.sink is not None else None)
         if self.sink is not None and hasattr(self.optimizer, "step_shared"):
             self.optimizer.step_shared(self.sink.selected, self.sink.G)   # fused: no per-table gradients are materialised
@@ -181,8 +200,10 @@ class GraphedWatermarkLoop:
     adds `headroom`; `overflowed()` reports (one host read) whether any replay since the last check produced more
     points than that -- such a step dropped the rays that did not fit, like the reference's bounded mode."""
 
-    def __init__(self, model, optimizer, render_kwargs, data, lambda_w=1.0, lambda_i=1.0, lr_lambda=None, headroom=0.0, native_dense_adam=True):
+    def __init__(self, model, optimizer, render_kwargs, data, lambda_w=1.0, lambda_i=1.0, lr_lambda=None, headroom=0.0, native_dense_adam=True,
+                 overlap_content=True):
         self.native_dense_adam = native_dense_adam
+        self.side_stream = torch.cuda.Stream() if overlap_content else None
         if not hasattr(optimizer, "step_shared_sel"):
             raise TypeError("GraphedWatermarkLoop needs nerf_signature_amd.optim.CodebookAdam(capturable=True)")
         self.model, self.optimizer = model, optimizer
@@ -198,7 +219,10 @@ class GraphedWatermarkLoop:
         self.data = {"watermark": {k: v.clone() for k, v in data["watermark"].items()},
                      "content": {k: v.clone() for k, v in data["content"].items()}}
         self.msg_dev = torch.zeros(D, dtype=torch.float32, device=dev)
-        self.msg_host = torch.zeros(D, dtype=torch.float32).pin_memory()
+        # The host runs ahead of the GPU by many replays, so the pinned staging buffer of a step must not be rewritten until its
+        # asynchronous copy has executed: a ring of buffers, each guarded by an event.
+        self.msg_ring = [torch.zeros(D, dtype=torch.float32).pin_memory() for _ in range(16)]
+        self.msg_events = [None] * len(self.msg_ring)
         self.base_lr = float(optimizer.param_groups[0]["lr"])
         self.lr_dev = torch.tensor(self.base_lr, dtype=torch.float32, device=dev)
         for g in optimizer.param_groups:
@@ -212,8 +236,10 @@ class GraphedWatermarkLoop:
     # -- pieces of one step (executed eagerly during warm-up, then under capture)
     def _forward_backward(self):
         self.sink.zero_()
-        out = train_step(self.model, self.data, self.msg_dev, self.render_kwargs, self.lambda_w, self.lambda_i)
+        out = train_step(self.model, self.data, self.msg_dev, self.render_kwargs, self.lambda_w, self.lambda_i, side_stream=self.side_stream)
         backward_from_loss_kernel(out)
+        if self.side_stream is not None:   # the content render's backward ends in a side effect (the shared gradient): join it explicitly
+            torch.cuda.current_stream().wait_stream(self.side_stream)
         return out
 
     def _optimise(self):
@@ -225,8 +251,14 @@ class GraphedWatermarkLoop:
             self.optimizer.step()
 
     def _set_inputs(self, message, data):
-        self.msg_host.copy_(message.detach().to("cpu", torch.float32))
-        self.msg_dev.copy_(self.msg_host, non_blocking=True)
+        slot = self.steps_done % len(self.msg_ring)
+        if self.msg_events[slot] is not None:
+            self.msg_events[slot].synchronize()      # blocks only if the GPU is a whole ring behind
+        self.msg_ring[slot].copy_(message.detach().to("cpu", torch.float32))
+        self.msg_dev.copy_(self.msg_ring[slot], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.msg_events[slot] = ev
         if self.lr_lambda is not None:
             self.lr_dev.fill_(self.base_lr * self.lr_lambda(self.steps_done))
         if data is not None:

@@ -209,7 +209,10 @@ def test_graphed_loop_matches_eager_loop():
         opt = CodebookAdam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, capturable=graphed)
         if graphed:
             loop = trainer.GraphedWatermarkLoop(m, opt, dict(dt_gamma=0, max_steps=1024), data, lr_lambda=lr_lambda)
-            losses = [float(loop.step(msg)[5].detach()) for msg in msgs]
+            # no host synchronisation between the steps (how the loop is meant to run): the host is then several replays ahead of
+            # the GPU, which is what once let a step read a later step's message out of the pinned staging buffer
+            held = [loop.step(msg)[5].detach().clone() for msg in msgs]
+            losses = [float(v) for v in held]
             assert not loop.overflowed()
         else:
             sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda)

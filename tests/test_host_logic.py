@@ -153,7 +153,8 @@ def _dp_worker(rank, world, port, q):
     ex2(G2)
     assert torch.equal(flat, torch.arange(flat.numel(), dtype=torch.float32) * 3) and torch.equal(G2, torch.full((4, 2), 3.0))
     assert ex2.bytes_per_step == (8 + flat.numel()) * 4
-    q.put((rank, ok, G.clone(), grads, ex.bytes_per_step))
+    # numpy, not tensors: a tensor travels through the queue as a file descriptor that dies with this process
+    q.put((rank, ok, G.numpy().copy(), [None if g is None else g.numpy().copy() for g in grads], ex.bytes_per_step))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -171,6 +172,7 @@ def test_data_parallel_exchange_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     base = torch.arange(16, dtype=torch.float32).view(8, 2)
+    res = [(r, ok, torch.from_numpy(Gm), [None if g is None else torch.from_numpy(g) for g in grads], nb) for r, ok, Gm, grads, nb in res]
     for rank, ok, Gm, grads, nbytes in res:
         assert ok                                                  # shared-gradient exchange == D dense exchanges
         assert torch.allclose(Gm, base * 1.5)                      # mean over ranks of G*(rank+1)
