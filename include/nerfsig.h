@@ -304,6 +304,9 @@ int dec_bn_gelu_bwd(const float *dy, const float *x, const float *gamma, const f
  *   grads    host array of 29 device pointers, same order and shapes (written, not accumulated); grad_img has img's layout
  *   workspace: dec_workspace_bytes(B, Cin, H, W) bytes (0 = shape not supported: H*W <= 1024, Cin <= 32, LDS limits);
  *            dec_backward reads what dec_forward left there, so the pair must share it and nothing may overwrite it between.
+ *   weights_stream: pass `stream` again for one in-order launch sequence.  A different stream receives the parameter-gradient
+ *            kernels (ordered after the data-gradient chain by an event), so that grad_img's consumers on `stream` need not wait
+ *            for them; the caller then joins weights_stream before reading `grads`.
  */
 size_t dec_workspace_bytes(uint32_t B, uint32_t Cin, uint32_t H, uint32_t W);
 int dec_forward(const float *img, uint32_t input_mode, const float *mean_host, const float *std_host, const float *const *params_host,
@@ -311,7 +314,7 @@ int dec_forward(const float *img, uint32_t input_mode, const float *mean_host, c
                 nsig_stream_t stream);
 int dec_backward(const float *grad_decoded, const float *img, uint32_t input_mode, const float *mean_host, const float *std_host,
                  const float *const *params_host, uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, void *workspace,
-                 float *const *grads_host, float *grad_img, nsig_stream_t stream);
+                 float *const *grads_host, float *grad_img, nsig_stream_t stream, nsig_stream_t weights_stream);
 
 /* ------------------------------------------------------------------ stage-1 (clean model) training, SURVEY.md 8(f) N3 */
 

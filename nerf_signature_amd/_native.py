@@ -60,7 +60,7 @@ SIGNATURES = {
     "dec_bn_gelu_bwd": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp],
     "dec_workspace_bytes": [_u32, _u32, _u32, _u32],
     "dec_forward": [_vp, _u32, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _fl, _vp, _vp, _vp, _vp],
-    "dec_backward": [_vp, _vp, _u32, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp],
+    "dec_backward": [_vp, _vp, _u32, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp],
     "field_fwd_trace": [_vp, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "field_bwd_trace": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hg_scatter_level": [_vp, _fl, _vp, _u32, _u32, _vp, _vp],

@@ -1443,7 +1443,7 @@ NSIG_EXPORT int dec_forward(const float *img, uint32_t input_mode, const float *
 
 NSIG_EXPORT int dec_backward(const float *grad_decoded, const float *img, uint32_t input_mode, const float *mean_host, const float *std_host,
                              const float *const *params, uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, void *workspace, float *const *grads,
-                             float *grad_img, nsig_stream_t stream) {
+                             float *grad_img, nsig_stream_t stream, nsig_stream_t weights_stream) {
     NSIG_REQUIRE(grad_decoded && img && params && workspace && grads && grad_img, "dec_backward: null pointer");
     DecInput inp;
     NSIG_REQUIRE(make_input(input_mode, mean_host, std_host, Cin, inp) == 0, "dec_backward: input_mode is 0, or 1 with Cin <= 8 means and positive stds");
@@ -1471,9 +1471,23 @@ NSIG_EXPORT int dec_backward(const float *grad_decoded, const float *img, uint32
     k_dec_l8_bwd<<<grid, 256, l8b_lds(g), s>>>(prm, ws, g);
     for (int l = 7; l >= 1; --l) k_dec_conv<kDgrad><<<dim3(g.npair, B, 2), 256, conv_lds(g), s>>>(l, prm, ws, g, nullptr, nullptr, inp);
     k_dec_conv<kDgradImg><<<grid, 256, conv_lds(g), s>>>(0, prm, ws, g, grad_img, img, inp);
-    k_dec_wgrad<<<dim3(g.nband, B, 7), 256, wgrad_lds(g), s>>>(prm, ws, g);
-    k_dec_l0_wgrad<<<grid, 256, l0w_lds(g), s>>>(img, inp, prm, ws, g);
-    k_dec_wreduce<<<dim3(kC, 7), 576, 0, s>>>(ws, gr, g);
-    k_dec_sreduce<<<16 + ceil_div(kC * 9 * Cin, 64) + 9 + 1, 256, 0, s>>>(grad_decoded, ws, gr, g);
+    // The parameter gradients are not needed before the optimiser; what waits on this function is the image gradient (the block
+    // render's backward).  On request they are queued on a second stream, ordered after the data-gradient chain by an event.
+    hipStream_t sw = as_stream(weights_stream);
+    if (sw != s) {
+        static hipEvent_t chain_done = nullptr;
+        if (chain_done == nullptr && hipEventCreateWithFlags(&chain_done, hipEventDisableTiming) != hipSuccess) {
+            set_error("dec_backward: hipEventCreateWithFlags failed");
+            return NSIG_ERR_LAUNCH;
+        }
+        if (hipEventRecord(chain_done, s) != hipSuccess || hipStreamWaitEvent(sw, chain_done, 0) != hipSuccess) {
+            set_error("dec_backward: could not order the weight-gradient stream after the data-gradient chain");
+            return NSIG_ERR_LAUNCH;
+        }
+    }
+    k_dec_wgrad<<<dim3(g.nband, B, 7), 256, wgrad_lds(g), sw>>>(prm, ws, g);
+    k_dec_l0_wgrad<<<grid, 256, l0w_lds(g), sw>>>(img, inp, prm, ws, g);
+    k_dec_wreduce<<<dim3(kC, 7), 576, 0, sw>>>(ws, gr, g);
+    k_dec_sreduce<<<16 + ceil_div(kC * 9 * Cin, 64) + 9 + 1, 256, 0, sw>>>(grad_decoded, ws, gr, g);
     return check_launch("dec_backward");
 }

@@ -74,6 +74,16 @@ class _BNGelu(torch.autograd.Function):
         return dx, dgamma, dbeta, None
 
 
+_WEIGHTS_STREAM = None
+
+
+def set_weights_stream(stream):
+    """The stream the fused decoder's parameter-gradient kernels are queued on (None: the stream of the backward itself).  Whoever
+    sets one joins it before the optimiser reads the gradients (trainer.GraphedWatermarkLoop does)."""
+    global _WEIGHTS_STREAM
+    _WEIGHTS_STREAM = stream
+
+
 class _FusedDecoder(torch.autograd.Function):
     """decoded = Linear(AvgPool(ConvBNRelu^9(img))) through dec_forward / dec_backward.  params: for each of the 9 blocks
     (conv weight, bn weight, bn bias), then the linear weight and bias.
@@ -115,8 +125,12 @@ class _FusedDecoder(torch.autograd.Function):
             grads.append(flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         grad_img = torch.empty_like(img)
+        side = _WEIGHTS_STREAM
+        if side is not None:   # the buffers below are allocated on this stream but also read / written on the side stream
+            for t in (flat, ws, img, grad_out, *ps):
+                t.record_stream(side)
         nv.call("dec_backward", nv.ptr(grad_out.contiguous().view(-1)), nv.ptr(img), int(rendered), mean, std, nv.ptr_array(ps), B, Cin, H, W,
-                nv.ptr(ws), nv.ptr_array(grads), nv.ptr(grad_img), nv.stream())
+                nv.ptr(ws), nv.ptr_array(grads), nv.ptr(grad_img), nv.stream(), nv.stream() if side is None else side.cuda_stream)
         return (grad_img, None, None, *grads)
 
 

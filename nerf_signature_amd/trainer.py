@@ -13,7 +13,7 @@ import torch.nn.functional as F
 from . import _native as nv
 from . import fieldops as fo
 from .dp import GradExchange, world_size
-from .hidden_models import normalize_img
+from .hidden_models import normalize_img, set_weights_stream
 
 
 def loss_w_bce(decoded, keys, temp=10.0):
@@ -237,7 +237,11 @@ class GraphedWatermarkLoop:
     def _forward_backward(self):
         self.sink.zero_()
         out = train_step(self.model, self.data, self.msg_dev, self.render_kwargs, self.lambda_w, self.lambda_i, side_stream=self.side_stream)
-        backward_from_loss_kernel(out)
+        set_weights_stream(self.side_stream)     # the decoder's parameter gradients go there too: the block render's backward only waits for the image gradient
+        try:
+            backward_from_loss_kernel(out)
+        finally:
+            set_weights_stream(None)
         if self.side_stream is not None:   # the content render's backward ends in a side effect (the shared gradient): join it explicitly
             torch.cuda.current_stream().wait_stream(self.side_stream)
         return out
