@@ -222,6 +222,8 @@ def main():
                 "algorithmic_bytes_per_point": gather_bytes,
                 "note": "algorithmic bytes are SURVEY.md 8(d)'s (1024 + 64*D per point, the reference's D separate codebook gathers); "
                         "the kernel issues 1024 + 64 B/point because the D tables are pre-summed (DESIGN.md section 2)",
+                "limiter": "texture-address path: PMC TA busy 84 % of the kernel, ~1.3 cycles per L1 tag lookup, 35.5 lookups per wave-level "
+                           "gather (profiles/r01_pmc_encode_block_launch.txt, tools/micro/gather_rate.hip); HBM moves 412 MB per launch",
                 "issued_gather_bytes_per_point": 1024 + 64,
                 "frac_of_issued_bytes": (pts_real * (1024 + 64) / enc_s) / HBM_PEAK if enc_s > 0 else 0.0,
                 "frac_of_measured_copy_ceiling": achieved / 6.29e12,
