@@ -151,6 +151,12 @@ int hg_codebook_bwd(const float *x01, uint32_t M, const float *dfeat, float *G, 
  * (1/10 of the scattered atomics' requests).  G is accumulated into. */
 int hg_scatter_sliced(const float *rec, uint32_t M, float *G, nsig_stream_t stream);
 
+/* The same accumulation with the redundancy removed: the (point, corner-pair) hits are first grouped by slice with an exact
+ * two-pass counting sort (self-contained 16-byte entries in `scratch`: hg_scatter_binned_scratch_bytes(M) bytes, 16-byte
+ * aligned), then every slice owner streams only its own entries.  Three launches instead of one, ~3x less time on a million points. */
+size_t hg_scatter_binned_scratch_bytes(uint32_t M);
+int hg_scatter_binned(const float *rec, uint32_t M, float *G, void *scratch, nsig_stream_t stream);
+
 /* grads[i][t] (+)= G[t] for the D selected tables; grads_host: host array of D device pointers. */
 int hg_fanout_grad(const float *G, float *const *grads_host, uint32_t D, int accumulate, nsig_stream_t stream);
 

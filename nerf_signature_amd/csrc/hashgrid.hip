@@ -229,6 +229,186 @@ __global__ void __launch_bounds__(1024) k_scatter_level(const float *__restrict_
     }
 }
 
+// ----------------------------------------------------------------------------- binned scatter
+//
+// Two measurements shape this version (tools/micro/lds_atomic_rate.hip, tools/scatter_timing.py):
+//  * ds_add_f32 retires 0.33 lane-operations per clock per CU; ds_add_u64 4.4 (ds_add_u32 5.2).  The scatter's 20.6 M LDS float
+//    atomics alone are 100 us -- that, not the instruction count, bounded k_scatter_sliced.  So the owners accumulate in 64-bit
+//    FIXED POINT: contribution * 2^k rounded to an integer, k chosen from the largest |gradient| of the launch so that 2^11
+//    maximal contributions cannot overflow; everything up to 2^-51 of that maximum is represented, the integer sum is exact
+//    and independent of the order of the atomics, and the owner converts back once per row.
+//  * with 16 bytes per (row, feature pair) an LDS slice holds 8192 rows: 64 slices.  Letting every owner test every point would
+//    double the redundant work, so the (point, (dy,dz) pair) hits are first grouped by slice with an exact two-pass counting
+//    sort -- count, then write at atomically reserved positions -- and an owner streams only its own entries.  An entry is
+//    self-contained (16 bytes: x cell, the pair's 13 row bits, the x weight, the two gradients already multiplied by the y and
+//    z weights); gathering 32-byte records at random from the 41 MB array instead made this slower than what it replaced.
+// The slice of a pair depends on (iy, iz, dy, dz) only (ix < 2^12 stays below bit 13), and a hit carries both x corners.
+constexpr uint32_t kBinThreads = 1024, kBinSlices = 64, kBinRows = NSIG_TABLE_ROWS / kBinSlices, kBinReplicas = 4;
+static_assert(kBinRows == 8192, "slice layout");
+
+constexpr uint32_t kBinGrid = 256;   // workgroups of the two binning passes (each walks chunks w, w + kBinGrid, ...)
+
+struct BinHeader {                 // scratch header
+    uint32_t counts[kBinSlices];   // entries per slice (written by k_bin_scan)
+    uint32_t gmax_bits;            // max |gradient| of the launch as a float bit pattern (zeroed before k_bin_count)
+    uint32_t pad[3];
+    uint32_t wg[kBinGrid][kBinSlices];   // k_bin_count: entries of slice s found by workgroup w; k_bin_scan: its write offset
+};
+
+__device__ inline bool record_pairs(const uint4 *__restrict__ rec4, uint32_t m, uint32_t (&slices)[4], float &gabs) {
+    const uint4 ra = rec4[2 * (size_t)m], rb = rec4[2 * (size_t)m + 1];
+    const float g0 = __uint_as_float(rb.y), g1 = __uint_as_float(rb.z);
+    if (g0 == 0.0f && g1 == 0.0f) return false;   // padding rows and terminated rays
+    gabs = fmaxf(fabsf(g0), fabsf(g1));
+    const uint32_t hy0 = (ra.x >> 16) * kPrimeY, hz0 = ra.y * kPrimeZ;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) slices[q] = (((hy0 + (q >> 1) * kPrimeY) ^ (hz0 + (q & 1u) * kPrimeZ)) >> 13) & (kBinSlices - 1);
+    return true;
+}
+
+// Pass 1: wg[w][s] = entries of slice s among the chunks of workgroup w (plain stores: no global atomics); gmax = max |gradient|.
+__global__ void __launch_bounds__(kBinThreads) k_bin_count(const float *__restrict__ rec, uint32_t M, BinHeader *__restrict__ hd) {
+    __shared__ uint32_t h[kBinSlices], gm;
+    if (threadIdx.x < kBinSlices) h[threadIdx.x] = 0;
+    if (threadIdx.x == 0) gm = 0;
+    __syncthreads();
+    uint32_t gb = 0;
+    for (uint32_t m = blockIdx.x * kBinThreads + threadIdx.x; m < M; m += gridDim.x * kBinThreads) {
+        uint32_t sl[4];
+        float gabs;
+        if (record_pairs(reinterpret_cast<const uint4 *>(rec), m, sl, gabs)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) atomicAdd(&h[sl[q]], 1u);
+            gb = max(gb, __float_as_uint(gabs));   // non-negative floats (and +inf, NaN) order like their bit patterns
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) gb = max(gb, (uint32_t)__shfl_xor((int)gb, d, 64));
+    if ((threadIdx.x & 63) == 0 && gb) atomicMax(&gm, gb);
+    __syncthreads();
+    if (threadIdx.x < kBinSlices) hd->wg[blockIdx.x][threadIdx.x] = h[threadIdx.x];
+    if (threadIdx.x == 0 && gm) atomicMax(&hd->gmax_bits, gm);
+}
+
+// One workgroup: slice totals, slice starts, and every (workgroup, slice) write offset -- the queue order is a pure function of
+// the input, so the whole scatter is reproducible bit for bit up to the final float adds of the four replicas.
+__global__ void __launch_bounds__(1024) k_bin_scan(BinHeader *__restrict__ hd, uint32_t n_wg) {
+    __shared__ uint32_t seg[16][kBinSlices], start[kBinSlices];
+    const uint32_t s = threadIdx.x & (kBinSlices - 1), g = threadIdx.x >> 6;   // 16 segments of 16 workgroups
+    uint32_t c[16], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t w = g * 16 + i;
+        c[i] = w < n_wg ? hd->wg[w][s] : 0u;
+        sum += c[i];
+    }
+    seg[g][s] = sum;
+    __syncthreads();
+    if (threadIdx.x < kBinSlices) {
+        uint32_t tot = 0;
+        for (int k = 0; k < 16; ++k) tot += seg[k][threadIdx.x];
+        hd->counts[threadIdx.x] = tot;
+        start[threadIdx.x] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t k = 0; k < kBinSlices; ++k) {
+            const uint32_t t = start[k];
+            start[k] = run;
+            run += t;
+        }
+    }
+    __syncthreads();
+    uint32_t off = start[s];
+    for (uint32_t k = 0; k < g; ++k) off += seg[k][s];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t w = g * 16 + i;
+        if (w < n_wg) hd->wg[w][s] = off;
+        off += c[i];
+    }
+}
+
+// Pass 2: queue[offset of (w, s) + rank] = entry
+__global__ void __launch_bounds__(kBinThreads) k_bin_write(const float *__restrict__ rec, uint32_t M, const BinHeader *__restrict__ hd,
+                                                           uint4 *__restrict__ queue) {
+    __shared__ uint32_t h[kBinSlices], running[kBinSlices];
+    if (threadIdx.x < kBinSlices) running[threadIdx.x] = hd->wg[blockIdx.x][threadIdx.x];
+    const uint4 *__restrict__ rec4 = reinterpret_cast<const uint4 *>(rec);
+    for (uint32_t m0 = blockIdx.x * kBinThreads; m0 < M; m0 += gridDim.x * kBinThreads) {   // uniform trip count: barriers inside
+        if (threadIdx.x < kBinSlices) h[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t m = m0 + threadIdx.x;
+        uint32_t sl[4], local[4];
+        float gabs;
+        const bool live = m < M && record_pairs(rec4, m, sl, gabs);
+        if (live)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) local[q] = atomicAdd(&h[sl[q]], 1u);
+        __syncthreads();
+        if (live) {
+            const uint4 ra = rec4[2 * (size_t)m], rb = rec4[2 * (size_t)m + 1];
+            const float wy = __uint_as_float(ra.w), wz = __uint_as_float(rb.x);
+            const float g0 = __uint_as_float(rb.y), g1 = __uint_as_float(rb.z);
+            const uint32_t ix = ra.x & 0xffffu, hy0 = (ra.x >> 16) * kPrimeY, hz0 = ra.y * kPrimeZ;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                // corner (dx, dy, dz) = (dx, q >> 1, q & 1); the weight is built in corner_weight()'s order ((g*fz)*fy)*fx
+                const uint32_t hyz = (hy0 + (q >> 1) * kPrimeY) ^ (hz0 + (q & 1u) * kPrimeZ);
+                const float fz = (q & 1u) ? wz : 1.0f - wz, fy = (q >> 1) ? wy : 1.0f - wy;
+                queue[running[sl[q]] + local[q]] = make_uint4(ix | ((hyz & (kBinRows - 1)) << 16), ra.z, __float_as_uint((g0 * fz) * fy),
+                                                              __float_as_uint((g1 * fz) * fy));
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < kBinSlices) running[threadIdx.x] += h[threadIdx.x];
+    }
+}
+
+__device__ inline long long to_fixed(float c, int k) { return __double2ll_rn(ldexp((double)c, k)); }
+
+// blockIdx = slice * kBinReplicas + replica: the slice's entries, split evenly over the replicas
+__global__ void __launch_bounds__(1024) k_scatter_binned(const BinHeader *__restrict__ hd, const uint4 *__restrict__ queue, float *__restrict__ G) {
+    extern __shared__ unsigned long long acc64[];  // [kBinRows][2] fixed point
+    const uint32_t slice = blockIdx.x / kBinReplicas, replica = blockIdx.x - slice * kBinReplicas;
+    for (uint32_t i = threadIdx.x; i < 2u * kBinRows; i += blockDim.x) acc64[i] = 0ull;
+    uint32_t start = 0;
+    for (uint32_t j = 0; j < slice; ++j) start += hd->counts[j];
+    const uint32_t n = hd->counts[slice], chunk = ceil_div(n, kBinReplicas);
+    const uint32_t beg = min(n, replica * chunk), end = min(n, beg + chunk);
+    // |contribution| <= gmax < 2^E; 2^11 of them stay below 2^62 with k = 51 - E.  Non-finite gradients: k = 0, the row sums are
+    // then meaningless exactly like the float sums of NaN/inf would be.
+    const uint32_t gb = hd->gmax_bits;
+    int E;
+    frexpf(__uint_as_float(gb), &E);
+    const int k = gb >= 0x7f800000u ? 0 : 51 - E;
+    __syncthreads();
+    constexpr int kAhead = 4;
+    for (uint32_t i0 = beg + threadIdx.x; i0 < end; i0 += blockDim.x * kAhead) {
+        uint4 e[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) e[u] = queue[start + min(i0 + u * blockDim.x, end - 1)];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            if (i0 + u * blockDim.x >= end) break;
+            const uint32_t ix = e[u].x & 0xffffu, hyz = e[u].x >> 16;     // hyz: the pair's 13 row bits
+            const float wx = __uint_as_float(e[u].y), a0 = __uint_as_float(e[u].z), a1 = __uint_as_float(e[u].w);
+            unsigned long long *d0 = acc64 + 2u * ((ix ^ hyz) & (kBinRows - 1)), *d1 = acc64 + 2u * (((ix + 1u) ^ hyz) & (kBinRows - 1));
+            atomicAdd(d0, (unsigned long long)to_fixed(a0 * (1.0f - wx), k));
+            atomicAdd(d0 + 1, (unsigned long long)to_fixed(a1 * (1.0f - wx), k));
+            atomicAdd(d1, (unsigned long long)to_fixed(a0 * wx, k));
+            atomicAdd(d1 + 1, (unsigned long long)to_fixed(a1 * wx, k));
+        }
+    }
+    __syncthreads();
+    float *out = G + 2 * (size_t)slice * kBinRows;
+    for (uint32_t i = threadIdx.x; i < 2u * kBinRows; i += blockDim.x) {
+        const long long v = (long long)acc64[i];
+        if (v != 0) atomicAdd(out + i, (float)ldexp((double)v, -k));
+    }
+}
+
 // Stage-1 training scatters into all 16 base tables.  The cell index and weights of a (point, level) need the level's IEEE
 // divisions (corner_rows), which the 32 slice owners of that level would each repeat: instead they are computed once here, into
 // the same 32-byte record the codebook scatter consumes, and k_scatter_sliced runs over 16 record sets.
@@ -616,6 +796,38 @@ NSIG_EXPORT int opt_adam_dense(uint32_t n, float *const *params_host, const floa
         if (int e = check_launch("opt_adam_dense")) return e;
     }
     return NSIG_OK;
+}
+
+NSIG_EXPORT size_t hg_scatter_binned_scratch_bytes(uint32_t M) { return (size_t)4 * M * sizeof(uint4) + sizeof(BinHeader); }
+
+NSIG_EXPORT int hg_scatter_binned(const float *rec, uint32_t M, float *G, void *scratch, nsig_stream_t stream) {
+    NSIG_REQUIRE(rec && G && scratch, "hg_scatter_binned: null pointer");
+    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(rec) & 15) == 0 && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0 && M < (1u << 30),
+                 "hg_scatter_binned: rec and scratch must be 16-byte aligned and M < 2^30");
+    if (M == 0) return NSIG_OK;
+    static_assert(sizeof(BinHeader) % 16 == 0 && kBinGrid == 16 * 16, "the queue follows the header 16-byte aligned; k_bin_scan walks 16 x 16 workgroups");
+    hipStream_t st = as_stream(stream);
+    BinHeader *hd = reinterpret_cast<BinHeader *>(scratch);
+    uint4 *queue = reinterpret_cast<uint4 *>(hd + 1);
+    if (hipMemsetAsync(&hd->gmax_bits, 0, sizeof(uint32_t), st) != hipSuccess) {
+        set_error("hg_scatter_binned: hipMemsetAsync failed");
+        return NSIG_ERR_LAUNCH;
+    }
+    static bool attr_set = false;
+    const size_t lds = (size_t)kBinRows * 2 * sizeof(unsigned long long);
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_binned), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error("hg_scatter_binned: cannot reserve %zu bytes of LDS", lds);
+            return NSIG_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const uint32_t blocks = ceil_div(M, kBinThreads) < kBinGrid ? ceil_div(M, kBinThreads) : kBinGrid;
+    k_bin_count<<<blocks, kBinThreads, 0, st>>>(rec, M, hd);
+    k_bin_scan<<<1, 1024, 0, st>>>(hd, blocks);
+    k_bin_write<<<blocks, kBinThreads, 0, st>>>(rec, M, hd, queue);
+    k_scatter_binned<<<kBinSlices * kBinReplicas, 1024, lds, st>>>(hd, queue, G);
+    return check_launch("hg_scatter_binned");
 }
 
 NSIG_EXPORT size_t hg_scatter_levels_scratch_bytes(uint32_t M) { return (size_t)NSIG_BASE_LEVELS * M * 32; }

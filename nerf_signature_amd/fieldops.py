@@ -165,9 +165,18 @@ def field_backward(xyzs, bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, G=N
     return rec if want_rec else dfeat
 
 
-def codebook_scatter_sliced(rec, G):
-    """G += scatter of the [M,8] record emitted by field_backward(want_rec=True) -> hg_scatter_sliced."""
-    nv.call("hg_scatter_sliced", nv.ptr(rec), rec.shape[0], nv.ptr(G), nv.stream())
+BINNED_MIN_POINTS = 65536   # below this the three launches of the binned route cost more than they save
+
+
+def codebook_scatter_sliced(rec, G, binned=None):
+    """G += scatter of the [M,8] record emitted by field_backward(want_rec=True).  binned: True -> hg_scatter_binned (hits
+    grouped by slice first), False -> hg_scatter_sliced (every owner tests every point), None -> by size."""
+    M = rec.shape[0]
+    if (M >= BINNED_MIN_POINTS) if binned is None else binned:
+        scratch = torch.empty(int(nv.fn("hg_scatter_binned_scratch_bytes")(M)), dtype=torch.uint8, device=rec.device)
+        nv.call("hg_scatter_binned", nv.ptr(rec), M, nv.ptr(G), nv.ptr(scratch), nv.stream())
+    else:
+        nv.call("hg_scatter_sliced", nv.ptr(rec), M, nv.ptr(G), nv.stream())
     return G
 
 

@@ -225,9 +225,17 @@ def test_sliced_scatter_equals_pointwise_scatter(fo, tables):
     cell = torch.floor(x01.clamp(0, 1) * 2048.0).int()
     assert torch.equal(words[:, 0] & 0xFFFF, cell[:, 0]) and torch.equal(words[:, 0] >> 16, cell[:, 1]) and torch.equal(words[:, 1], cell[:, 2])
     np.testing.assert_array_equal(rec[:, 2:5].cpu().numpy(), ((x01 - cell.float() * (1.0 / 2048.0)) * 2048.0).cpu().numpy())
-    G1, G2 = torch.zeros(1 << 19, 2, device="cuda"), torch.full((1 << 19, 2), 0.5, device="cuda")
+    G1 = torch.zeros(1 << 19, 2, device="cuda")
     fo.codebook_scatter((pts + 1.0) / 2.0, dfeat, G1)
-    fo.codebook_scatter_sliced(rec, G2)            # accumulates into what is there
-    G2 -= 0.5
-    assert torch.equal(G1 != 0, G2.abs() > 1e-12) or float(((G1 != 0) != (G2.abs() > 1e-9)).float().mean()) < 1e-4
-    assert float((G1 - G2).norm() / G1.norm()) < 1e-5
+    for binned in (False, True):                       # every owner tests every point | hits grouped by slice first
+        G2 = torch.full((1 << 19, 2), 0.5, device="cuda")
+        fo.codebook_scatter_sliced(rec, G2, binned=binned)            # accumulates into what is there
+        G2 -= 0.5
+        assert torch.equal(G1 != 0, G2.abs() > 1e-12) or float(((G1 != 0) != (G2.abs() > 1e-9)).float().mean()) < 1e-4
+        assert float((G1 - G2).norm() / G1.norm()) < 1e-5
+    # degenerate input: every point in one cell (all hits land in at most four slices)
+    same = rec[:1].repeat(5000, 1).contiguous()
+    Ga, Gb = torch.zeros(1 << 19, 2, device="cuda"), torch.zeros(1 << 19, 2, device="cuda")
+    fo.codebook_scatter_sliced(same, Ga, binned=False)
+    fo.codebook_scatter_sliced(same, Gb, binned=True)
+    assert float((Ga - Gb).norm() / Ga.norm()) < 1e-5 and int((Gb != 0).sum()) <= 16
