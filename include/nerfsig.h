@@ -344,9 +344,9 @@ int hg_scatter_level(const float *xyzs, float bound, const void *d_plane, uint32
                      nsig_stream_t stream);
 /* All 16 levels at once: d_planes is field_bwd_trace's [16][stride] float2 output, G_host 16 device tables [T,2] that are
  * WRITTEN (not accumulated into).  The (point, level) cell indices and weights are computed once into `scratch`
- * (hg_scatter_levels_scratch_bytes(M) bytes, 16-byte aligned: sixteen [M,8] records in hg_scatter_sliced's format), then one
- * owner-computes launch scatters all levels.  Up to 262144 points every table row has a single owner workgroup that stores it
- * (no atomics, no zero-fill); above that the point range is split over replicas that accumulate atomically into zeroed tables. */
+ * (hg_scatter_levels_scratch_bytes(M) bytes, 16-byte aligned: sixteen [M,8] records in hg_scatter_sliced's format plus the
+ * binning scratch), then the binned fixed-point scatter of hg_scatter_binned runs over the 16 record sets at once; every table
+ * row has a single owner workgroup that stores it (no atomics, no zero-fill, bit-reproducible). */
 size_t hg_scatter_levels_scratch_bytes(uint32_t M);
 int hg_scatter_levels(const float *xyzs, float bound, const void *d_planes, uint32_t M, uint32_t stride, float *const *G_host,
                       void *scratch, nsig_stream_t stream);

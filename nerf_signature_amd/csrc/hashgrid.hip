@@ -267,7 +267,10 @@ __device__ inline bool record_pairs(const uint4 *__restrict__ rec4, uint32_t m, 
 }
 
 // Pass 1: wg[w][s] = entries of slice s among the chunks of workgroup w (plain stores: no global atomics); gmax = max |gradient|.
-__global__ void __launch_bounds__(kBinThreads) k_bin_count(const float *__restrict__ rec, uint32_t M, BinHeader *__restrict__ hd) {
+// (all four kernels: blockIdx.y = record set -- one for the codebook, 16 base levels in stage-1 training)
+__global__ void __launch_bounds__(kBinThreads) k_bin_count(const float *__restrict__ rec_all, uint32_t M, BinHeader *__restrict__ hd_all) {
+    const float *__restrict__ rec = rec_all + (size_t)blockIdx.y * M * 8;
+    BinHeader *__restrict__ hd = hd_all + blockIdx.y;
     __shared__ uint32_t h[kBinSlices], gm;
     if (threadIdx.x < kBinSlices) h[threadIdx.x] = 0;
     if (threadIdx.x == 0) gm = 0;
@@ -292,7 +295,8 @@ __global__ void __launch_bounds__(kBinThreads) k_bin_count(const float *__restri
 
 // One workgroup: slice totals, slice starts, and every (workgroup, slice) write offset -- the queue order is a pure function of
 // the input, so the whole scatter is reproducible bit for bit up to the final float adds of the four replicas.
-__global__ void __launch_bounds__(1024) k_bin_scan(BinHeader *__restrict__ hd, uint32_t n_wg) {
+__global__ void __launch_bounds__(1024) k_bin_scan(BinHeader *__restrict__ hd_all, uint32_t n_wg) {
+    BinHeader *__restrict__ hd = hd_all + blockIdx.x;
     __shared__ uint32_t seg[16][kBinSlices], start[kBinSlices];
     const uint32_t s = threadIdx.x & (kBinSlices - 1), g = threadIdx.x >> 6;   // 16 segments of 16 workgroups
     uint32_t c[16], sum = 0;
@@ -331,8 +335,11 @@ __global__ void __launch_bounds__(1024) k_bin_scan(BinHeader *__restrict__ hd, u
 }
 
 // Pass 2: queue[offset of (w, s) + rank] = entry
-__global__ void __launch_bounds__(kBinThreads) k_bin_write(const float *__restrict__ rec, uint32_t M, const BinHeader *__restrict__ hd,
-                                                           uint4 *__restrict__ queue) {
+__global__ void __launch_bounds__(kBinThreads) k_bin_write(const float *__restrict__ rec_all, uint32_t M, const BinHeader *__restrict__ hd_all,
+                                                           uint4 *__restrict__ queue_all) {
+    const float *__restrict__ rec = rec_all + (size_t)blockIdx.y * M * 8;
+    const BinHeader *__restrict__ hd = hd_all + blockIdx.y;
+    uint4 *__restrict__ queue = queue_all + (size_t)blockIdx.y * 4 * M;
     __shared__ uint32_t h[kBinSlices], running[kBinSlices];
     if (threadIdx.x < kBinSlices) running[threadIdx.x] = hd->wg[blockIdx.x][threadIdx.x];
     const uint4 *__restrict__ rec4 = reinterpret_cast<const uint4 *>(rec);
@@ -368,14 +375,19 @@ __global__ void __launch_bounds__(kBinThreads) k_bin_write(const float *__restri
 
 __device__ inline long long to_fixed(float c, int k) { return __double2ll_rn(ldexp((double)c, k)); }
 
-// blockIdx = slice * kBinReplicas + replica: the slice's entries, split evenly over the replicas
-__global__ void __launch_bounds__(1024) k_scatter_binned(const BinHeader *__restrict__ hd, const uint4 *__restrict__ queue, float *__restrict__ G) {
+// blockIdx.x = slice * replicas + replica: the slice's entries, split evenly over the replicas.  replicas == 1: the owner is
+// alone and stores its rows (no atomics, no zero-fill of the table, bit-reproducible); otherwise float atomics into G.
+__global__ void __launch_bounds__(1024) k_scatter_binned(const BinHeader *__restrict__ hd_all, const uint4 *__restrict__ queue_all, uint32_t M,
+                                                         ScatterTargets tg, uint32_t replicas) {
     extern __shared__ unsigned long long acc64[];  // [kBinRows][2] fixed point
-    const uint32_t slice = blockIdx.x / kBinReplicas, replica = blockIdx.x - slice * kBinReplicas;
+    const BinHeader *__restrict__ hd = hd_all + blockIdx.y;
+    const uint4 *__restrict__ queue = queue_all + (size_t)blockIdx.y * 4 * M;
+    float *__restrict__ G = tg.g[blockIdx.y];
+    const uint32_t slice = blockIdx.x / replicas, replica = blockIdx.x - slice * replicas;
     for (uint32_t i = threadIdx.x; i < 2u * kBinRows; i += blockDim.x) acc64[i] = 0ull;
     uint32_t start = 0;
     for (uint32_t j = 0; j < slice; ++j) start += hd->counts[j];
-    const uint32_t n = hd->counts[slice], chunk = ceil_div(n, kBinReplicas);
+    const uint32_t n = hd->counts[slice], chunk = ceil_div(n, replicas);
     const uint32_t beg = min(n, replica * chunk), end = min(n, beg + chunk);
     // |contribution| <= gmax < 2^E; 2^11 of them stay below 2^62 with k = 51 - E.  Non-finite gradients: k = 0, the row sums are
     // then meaningless exactly like the float sums of NaN/inf would be.
@@ -405,7 +417,8 @@ __global__ void __launch_bounds__(1024) k_scatter_binned(const BinHeader *__rest
     float *out = G + 2 * (size_t)slice * kBinRows;
     for (uint32_t i = threadIdx.x; i < 2u * kBinRows; i += blockDim.x) {
         const long long v = (long long)acc64[i];
-        if (v != 0) atomicAdd(out + i, (float)ldexp((double)v, -k));
+        if (replicas == 1) out[i] = v != 0 ? (float)ldexp((double)v, -k) : 0.0f;
+        else if (v != 0) atomicAdd(out + i, (float)ldexp((double)v, -k));
     }
 }
 
@@ -798,44 +811,56 @@ NSIG_EXPORT int opt_adam_dense(uint32_t n, float *const *params_host, const floa
     return NSIG_OK;
 }
 
-NSIG_EXPORT size_t hg_scatter_binned_scratch_bytes(uint32_t M) { return (size_t)4 * M * sizeof(uint4) + sizeof(BinHeader); }
+static size_t binned_scratch_bytes(uint32_t M, uint32_t sets) { return (size_t)sets * (sizeof(BinHeader) + (size_t)4 * M * sizeof(uint4)); }
 
-NSIG_EXPORT int hg_scatter_binned(const float *rec, uint32_t M, float *G, void *scratch, nsig_stream_t stream) {
-    NSIG_REQUIRE(rec && G && scratch, "hg_scatter_binned: null pointer");
-    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(rec) & 15) == 0 && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0 && M < (1u << 30),
-                 "hg_scatter_binned: rec and scratch must be 16-byte aligned and M < 2^30");
-    if (M == 0) return NSIG_OK;
-    static_assert(sizeof(BinHeader) % 16 == 0 && kBinGrid == 16 * 16, "the queue follows the header 16-byte aligned; k_bin_scan walks 16 x 16 workgroups");
-    hipStream_t st = as_stream(stream);
+// sets record arrays [sets][M][8] -> sets tables; scratch = sets headers, then sets queues
+static int launch_binned(const float *rec, uint32_t M, uint32_t sets, const ScatterTargets &tg, uint32_t replicas, void *scratch, hipStream_t st,
+                         const char *who) {
+    static_assert(sizeof(BinHeader) % 16 == 0 && kBinGrid == 16 * 16, "the queues follow the headers 16-byte aligned; k_bin_scan walks 16 x 16 workgroups");
     BinHeader *hd = reinterpret_cast<BinHeader *>(scratch);
-    uint4 *queue = reinterpret_cast<uint4 *>(hd + 1);
-    if (hipMemsetAsync(&hd->gmax_bits, 0, sizeof(uint32_t), st) != hipSuccess) {
-        set_error("hg_scatter_binned: hipMemsetAsync failed");
-        return NSIG_ERR_LAUNCH;
-    }
+    uint4 *queue = reinterpret_cast<uint4 *>(hd + sets);
+    for (uint32_t i = 0; i < sets; ++i)
+        if (hipMemsetAsync(&hd[i].gmax_bits, 0, sizeof(uint32_t), st) != hipSuccess) {
+            set_error("%s: hipMemsetAsync failed", who);
+            return NSIG_ERR_LAUNCH;
+        }
     static bool attr_set = false;
     const size_t lds = (size_t)kBinRows * 2 * sizeof(unsigned long long);
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_binned), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            set_error("hg_scatter_binned: cannot reserve %zu bytes of LDS", lds);
+            set_error("%s: cannot reserve %zu bytes of LDS", who, lds);
             return NSIG_ERR_LAUNCH;
         }
         attr_set = true;
     }
     const uint32_t blocks = ceil_div(M, kBinThreads) < kBinGrid ? ceil_div(M, kBinThreads) : kBinGrid;
-    k_bin_count<<<blocks, kBinThreads, 0, st>>>(rec, M, hd);
-    k_bin_scan<<<1, 1024, 0, st>>>(hd, blocks);
-    k_bin_write<<<blocks, kBinThreads, 0, st>>>(rec, M, hd, queue);
-    k_scatter_binned<<<kBinSlices * kBinReplicas, 1024, lds, st>>>(hd, queue, G);
-    return check_launch("hg_scatter_binned");
+    k_bin_count<<<dim3(blocks, sets), kBinThreads, 0, st>>>(rec, M, hd);
+    k_bin_scan<<<sets, 1024, 0, st>>>(hd, blocks);
+    k_bin_write<<<dim3(blocks, sets), kBinThreads, 0, st>>>(rec, M, hd, queue);
+    k_scatter_binned<<<dim3(kBinSlices * replicas, sets), 1024, lds, st>>>(hd, queue, M, tg, replicas);
+    return check_launch(who);
 }
 
-NSIG_EXPORT size_t hg_scatter_levels_scratch_bytes(uint32_t M) { return (size_t)NSIG_BASE_LEVELS * M * 32; }
+NSIG_EXPORT size_t hg_scatter_binned_scratch_bytes(uint32_t M) { return binned_scratch_bytes(M, 1); }
+
+NSIG_EXPORT int hg_scatter_binned(const float *rec, uint32_t M, float *G, void *scratch, nsig_stream_t stream) {
+    NSIG_REQUIRE(rec && G && scratch, "hg_scatter_binned: null pointer");
+    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(rec) & 15) == 0 && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0 && M < (1u << 28),
+                 "hg_scatter_binned: rec and scratch must be 16-byte aligned and M < 2^28");
+    if (M == 0) return NSIG_OK;
+    ScatterTargets tg{};
+    tg.g[0] = G;
+    return launch_binned(rec, M, 1, tg, kBinReplicas, scratch, as_stream(stream), "hg_scatter_binned");
+}
+
+NSIG_EXPORT size_t hg_scatter_levels_scratch_bytes(uint32_t M) {
+    return (size_t)NSIG_BASE_LEVELS * M * 32 + binned_scratch_bytes(M, NSIG_BASE_LEVELS);   // the 16 record arrays, then the binning scratch
+}
 
 NSIG_EXPORT int hg_scatter_levels(const float *xyzs, float bound, const void *d_planes, uint32_t M, uint32_t stride, float *const *G_host,
                                   void *scratch, nsig_stream_t stream) {
     NSIG_REQUIRE(xyzs && d_planes && G_host && scratch, "hg_scatter_levels: null pointer");
-    NSIG_REQUIRE(bound > 0.0f && stride >= M && M < (1u << 30), "hg_scatter_levels: bad bound, stride < M or M >= 2^30");
+    NSIG_REQUIRE(bound > 0.0f && stride >= M && M < (1u << 28), "hg_scatter_levels: bad bound, stride < M or M >= 2^28");
     NSIG_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 15) == 0, "hg_scatter_levels: scratch must be 16-byte aligned");
     ScatterTargets tg{};
     for (int l = 0; l < NSIG_BASE_LEVELS; ++l) {
@@ -843,30 +868,21 @@ NSIG_EXPORT int hg_scatter_levels(const float *xyzs, float bound, const void *d_
         tg.g[l] = G_host[l];
     }
     hipStream_t st = as_stream(stream);
-    const uint32_t replicas = M <= 262144u ? 1u : (ceil_div(M, 262144u) < (uint32_t)kReplicas ? ceil_div(M, 262144u) : (uint32_t)kReplicas);
-    if (replicas > 1 || M == 0) {   // owners accumulate with atomics (or there is nothing to add): the tables start from zero
+    if (M == 0) {
         for (int l = 0; l < NSIG_BASE_LEVELS; ++l)
             if (hipMemsetAsync(tg.g[l], 0, (size_t)NSIG_TABLE_ROWS * 2 * sizeof(float), st) != hipSuccess) {
                 set_error("hg_scatter_levels: hipMemsetAsync failed");
                 return NSIG_ERR_LAUNCH;
             }
-        if (M == 0) return NSIG_OK;
+        return NSIG_OK;
     }
+    uint4 *rec = reinterpret_cast<uint4 *>(scratch);
     k_level_records<<<dim3(ceil_div(M, 256u), NSIG_BASE_LEVELS), 256, 0, st>>>(xyzs, bound, reinterpret_cast<const float2 *>(d_planes), M, stride,
-                                                                              make_level_geom(), reinterpret_cast<uint4 *>(scratch));
+                                                                              make_level_geom(), rec);
     if (int e = check_launch("hg_scatter_levels (records)")) return e;
-    static bool attr_set = false;
-    const size_t lds = (size_t)kSliceRows * 2 * sizeof(float);
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_sliced), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            set_error("hg_scatter_levels: cannot reserve %zu bytes of LDS", lds);
-            return NSIG_ERR_LAUNCH;
-        }
-        attr_set = true;
-    }
-    k_scatter_sliced<<<ceil_div((uint32_t)NSIG_BASE_LEVELS, 8u) * 8u * kSlices * replicas, 1024, lds, st>>>(reinterpret_cast<const float *>(scratch), M, tg,
-                                                                                                   (uint32_t)NSIG_BASE_LEVELS, replicas);
-    return check_launch("hg_scatter_levels");
+    // every (level, slice) has a single owner, which stores its rows: the tables are written, not accumulated into
+    return launch_binned(reinterpret_cast<const float *>(rec), M, NSIG_BASE_LEVELS, tg, 1u,
+                         reinterpret_cast<char *>(scratch) + (size_t)NSIG_BASE_LEVELS * M * 32, st, "hg_scatter_levels");
 }
 
 NSIG_EXPORT int hg_scatter_level(const float *xyzs, float bound, const void *d_plane, uint32_t M, uint32_t level, float *G, nsig_stream_t stream) {
