@@ -300,15 +300,15 @@ __global__ void __launch_bounds__(256) k_encode_planes(const float *__restrict__
         const uint32_t m = tile * 256 + threadIdx.x;
         if (m >= stride) continue;
         const uint32_t ml = min(m, M - 1);  // rows in [M, stride) replicate the last point (never consumed)
-        const float x = (__builtin_nontemporal_load(xyzs + 3 * (size_t)ml) + bound) / two_b;
-        const float y = (__builtin_nontemporal_load(xyzs + 3 * (size_t)ml + 1) + bound) / two_b;
-        const float z = (__builtin_nontemporal_load(xyzs + 3 * (size_t)ml + 2) + bound) / two_b;
+        // one 12-byte load and one 8-byte streaming store per level: the kernel is bound by the address path, every instruction counts
+        const float3 pt = *reinterpret_cast<const float3 *>(xyzs + 3 * (size_t)ml);
+        const float x = (pt.x + bound) / two_b, y = (pt.y + bound) / two_b, z = (pt.z + bound) / two_b;
         for (int i = 0; i < n_levels; ++i) {
             const int l = tab.level[slot][i];
             const float2 v = encode_level(l == NSIG_BASE_LEVELS ? S : base.p[l], x, y, z, geom.cell[l]);
-            float *dst = reinterpret_cast<float *>(planes + (size_t)l * stride + m);
-            __builtin_nontemporal_store(v.x, dst);
-            __builtin_nontemporal_store(v.y, dst + 1);
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            const f32x2_t vv = {v.x, v.y};
+            __builtin_nontemporal_store(vv, reinterpret_cast<f32x2_t *>(planes + (size_t)l * stride + m));
         }
     }
 }
