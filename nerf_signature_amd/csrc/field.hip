@@ -290,24 +290,68 @@ struct SlotTable {
     uint8_t level[8][8];  // 0..15 base levels, 16 = pre-summed codebook
 };
 
+// Lane pairs cooperate on the gathers.  A gather costs ~2.4 clk per distinct 128-byte line per instruction plus ~1 clk per lane
+// (tools/micro/gather_rate.hip), and the two x-neighbours of a (dy, dz) pair share a line in 15 of 16 cells.  With one lane per
+// point they sit in two different instructions (64 lines each: one misses L1, the next hits it); here lanes 2i and 2i+1 first
+// fetch the x = 0 / x = 1 sides of point 2i, then of point 2i+1, so every instruction touches 32 lines instead of 64 and none
+// relies on L1 to keep a line until its partner instruction arrives.  Same number of gather instructions, same values; the
+// cell hashes travel from the owner to its neighbour by DPP, the fetched corners back the same way.
+__device__ inline uint32_t dpp_u(uint32_t v, int ctrl) {
+    switch (ctrl) {   // quad_perm selectors must be immediates
+        case 0: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xA0, 0xF, 0xF, true);    // [0,0,2,2]: the even lane's value
+        case 1: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xF5, 0xF, 0xF, true);    // [1,1,3,3]: the odd lane's value
+        default: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);   // [1,0,3,2]: swap with the neighbour
+    }
+}
+
 __global__ void __launch_bounds__(256) k_encode_planes(const float *__restrict__ xyzs, uint32_t M, float bound, TablePtrs base, LevelGeom geom,
                                                        const float *__restrict__ S, float2 *__restrict__ planes, uint32_t stride, SlotTable tab) {
     const uint32_t slot = blockIdx.x & 7u;
     const uint32_t n_tiles = ceil_div(stride, 256u);
     const int n_levels = tab.n[slot];
     const float two_b = 2.0f * bound;
+    const uint32_t xs = threadIdx.x & 1u;   // which x side of the cell this lane fetches
     for (uint32_t tile = blockIdx.x >> 3; tile < n_tiles; tile += gridDim.x >> 3) {
         const uint32_t m = tile * 256 + threadIdx.x;
-        if (m >= stride) continue;
+        if (m >= stride) continue;          // stride is a multiple of 32: lane pairs (and DPP quads) are in or out together
         const uint32_t ml = min(m, M - 1);  // rows in [M, stride) replicate the last point (never consumed)
         // one 12-byte load and one 8-byte streaming store per level: the kernel is bound by the address path, every instruction counts
         const float3 pt = *reinterpret_cast<const float3 *>(xyzs + 3 * (size_t)ml);
         const float x = (pt.x + bound) / two_b, y = (pt.y + bound) / two_b, z = (pt.z + bound) / two_b;
         for (int i = 0; i < n_levels; ++i) {
             const int l = tab.level[slot][i];
-            const float2 v = encode_level(l == NSIG_BASE_LEVELS ? S : base.p[l], x, y, z, geom.cell[l]);
+            const float2 *__restrict__ table = reinterpret_cast<const float2 *>(l == NSIG_BASE_LEVELS ? S : base.p[l]);
+            const float cell = geom.cell[l];
+            uint32_t ix, iy, iz;
+            float wx, wy, wz;
+            axis_cell(x, cell, ix, wx);
+            axis_cell(y, cell, iy, wy);
+            axis_cell(z, cell, iz, wz);
+            const uint32_t hy0 = iy * kPrimeY, hy1 = (iy + 1u) * kPrimeY, hz0 = iz * kPrimeZ, hz1 = (iz + 1u) * kPrimeZ;   // corner_rows()
+            float2 v[2][4];   // v[P][q]: this lane's x side of point P of the pair, corner (dy, dz) = (q >> 1, q & 1)
+#pragma unroll
+            for (int P = 0; P < 2; ++P) {
+                const uint32_t hx = dpp_u(ix, P) + xs;
+                const uint32_t a0 = dpp_u(hy0, P), a1 = dpp_u(hy1, P), b0 = dpp_u(hz0, P), b1 = dpp_u(hz1, P);
+                v[P][0] = table[(hx ^ a0 ^ b0) & kRowMask];
+                v[P][1] = table[(hx ^ a0 ^ b1) & kRowMask];
+                v[P][2] = table[(hx ^ a1 ^ b0) & kRowMask];
+                v[P][3] = table[(hx ^ a1 ^ b1) & kRowMask];
+            }
+            float2 e[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float2 mine = xs ? v[1][q] : v[0][q];      // my own point, my x side
+                const float2 give = xs ? v[0][q] : v[1][q];      // the neighbour's point, my x side
+                float2 got;                                       // my own point, the other x side (fetched by the neighbour)
+                got.x = __uint_as_float(dpp_u(__float_as_uint(give.x), 2));
+                got.y = __uint_as_float(dpp_u(__float_as_uint(give.y), 2));
+                e[q] = xs ? got : mine;          // corner k = 4*dx + q
+                e[4 + q] = xs ? mine : got;
+            }
+            const float2 val = trilerp(e, wx, wy, wz);
             typedef float f32x2_t __attribute__((ext_vector_type(2)));
-            const f32x2_t vv = {v.x, v.y};
+            const f32x2_t vv = {val.x, val.y};
             __builtin_nontemporal_store(vv, reinterpret_cast<f32x2_t *>(planes + (size_t)l * stride + m));
         }
     }
