@@ -35,7 +35,8 @@ class NativeTimer:
     """HIP-event timing of selected libnerfsig entry points, on the stream the kernels are launched on (torch's current
     stream).  Installed over nerf_signature_amd._native.call; each timed call records (duration, points)."""
 
-    POINTS_ARG = {"hg_encode_planes": 1, "field_fwd": 2, "field_bwd": 1, "hg_scatter_sliced": 1, "hg_scatter_binned": 1}
+    POINTS_ARG = {"hg_encode_planes": 1, "field_fwd": 2, "field_bwd": 1, "field_bwd_planned": 1, "hg_scatter_sliced": 1, "hg_scatter_binned": 1,
+                  "hg_scatter_planned": 1, "hg_scatter_plan": 1}
 
     def __init__(self, nv):
         self.nv, self.orig, self.enabled = nv, nv.call, False
@@ -185,10 +186,14 @@ def main():
     big = max(n_block, n_content) // 2
     enc_s, enc_n, enc_rows = timer.stats("hg_encode_planes", big)
     mlp_s, _, _ = timer.stats("field_fwd", big)
-    bwd_s, _, _ = timer.stats("field_bwd", big)
-    sct_s, _, _ = timer.stats("hg_scatter_binned", big)          # the block render goes through the binned route
-    if sct_s == 0.0:
-        sct_s, _, _ = timer.stats("hg_scatter_sliced", big)
+    bwd_s, _, _ = timer.stats("field_bwd_planned", big)          # the block render goes through the planned binned route
+    sct_s, _, _ = timer.stats("hg_scatter_planned", big)
+    plan_s, _, _ = timer.stats("hg_scatter_plan", big)           # (beside the forward pass: not on the critical path)
+    if bwd_s == 0.0:
+        bwd_s, _, _ = timer.stats("field_bwd", big)
+        sct_s, _, _ = timer.stats("hg_scatter_binned", big)
+        if sct_s == 0.0:
+            sct_s, _, _ = timer.stats("hg_scatter_sliced", big)
     pts_real = float(max(n_block, n_content))
     gather_bytes = 1024 + 64 * D
     achieved = pts_real * gather_bytes / enc_s if enc_s > 0 else 0.0
@@ -231,7 +236,7 @@ def main():
                 "frac_of_measured_copy_ceiling": achieved / 6.29e12,
                 "forward_encoder_plus_mlp": {"avg_s": fwd_total, "achieved_GBps": achieved_fwd / 1e9, "frac": achieved_fwd / HBM_PEAK,
                                              "algorithmic_bytes_per_point": BYTES_FWD_PER_POINT(D)},
-                "backward_mlp_plus_scatter": {"avg_s": bwd_s + sct_s, "k_field_bwd_s": bwd_s, "scatter_s": sct_s,
+                "backward_mlp_plus_scatter": {"avg_s": bwd_s + sct_s, "k_field_bwd_s": bwd_s, "scatter_s": sct_s, "plan_s_off_path": plan_s,
                                               "achieved_GBps": (pts_real * BYTES_BWD_PER_POINT(D) / (bwd_s + sct_s) / 1e9) if bwd_s + sct_s > 0 else 0.0,
                                               "algorithmic_bytes_per_point": BYTES_BWD_PER_POINT(D)},
             },

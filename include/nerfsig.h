@@ -157,6 +157,16 @@ int hg_scatter_sliced(const float *rec, uint32_t M, float *G, nsig_stream_t stre
 size_t hg_scatter_binned_scratch_bytes(uint32_t M);
 int hg_scatter_binned(const float *rec, uint32_t M, float *G, void *scratch, nsig_stream_t stream);
 
+/* The binned scatter with its sort planned ahead: where a (point, corner pair) entry goes in the slice-sorted queue depends on
+ * the point's position only, so hg_scatter_plan computes counts, offsets and per-point destinations from xyzs [M,3] as soon as
+ * the samples exist (any stream, typically beside the forward pass); field_bwd_planned then writes the gradients straight into
+ * the queue and hg_scatter_planned runs the slice owners.  `plan`: hg_scatter_plan_bytes(M) bytes, 16-byte aligned, must stay
+ * untouched between the three calls.  Same sums as hg_scatter_binned (fixed-point per slice: order-independent).  G is
+ * accumulated into.  Replaces the same reference step as hg_codebook_bwd (autograd of hash_encoding.py:73-94). */
+size_t hg_scatter_plan_bytes(uint32_t M);
+int hg_scatter_plan(const float *xyzs, uint32_t M, float bound, void *plan, nsig_stream_t stream);
+int hg_scatter_planned(const void *plan, uint32_t M, float *G, nsig_stream_t stream);
+
 /* grads[i][t] (+)= G[t] for the D selected tables; grads_host: host array of D device pointers. */
 int hg_fanout_grad(const float *G, float *const *grads_host, uint32_t D, int accumulate, nsig_stream_t stream);
 
@@ -228,6 +238,10 @@ int field_color_fwd(const float *dirs, const float *geo_feat, uint32_t M, const 
 int field_bwd(const float *xyzs, uint32_t M, float bound, const float *grad_sigmas, const float *grad_rgbs,
               const float *sigmas, const float *rgbs, const uint32_t *masks, const void *packed, float *G,
               float *dfeat_out, float *rec_out, nsig_stream_t stream);
+/* The same backward with the planned scatter's queue as its only output (see hg_scatter_plan). */
+int field_bwd_planned(const float *xyzs, uint32_t M, float bound, const float *grad_sigmas, const float *grad_rgbs,
+                      const float *sigmas, const float *rgbs, const uint32_t *masks, const void *packed, void *plan,
+                      nsig_stream_t stream);
 
 /*
  * torch.optim.Adam (betas, eps; no weight decay / amsgrad) in its capturable form over n dense fp32 tensors in one pass:

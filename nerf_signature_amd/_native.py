@@ -69,8 +69,12 @@ SIGNATURES = {
     "hg_scatter_levels_scratch_bytes": [_u32],
     "hg_scatter_levels": [_vp, _fl, _vp, _u32, _u32, _vp, _vp, _vp],
     "field_bwd": [_vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "field_bwd_planned": [_vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "hg_scatter_plan_bytes": [_u32],
+    "hg_scatter_plan": [_vp, _u32, _fl, _vp, _vp],
+    "hg_scatter_planned": [_vp, _u32, _vp, _vp],
 }
-_RESTYPES = {"nsig_last_error": _c.c_char_p, "rm_march_train_scratch_bytes": _sz, "mlp_packed_bytes": _sz, "hg_planes_bytes": _sz, "dec_workspace_bytes": _sz, "hg_scatter_levels_scratch_bytes": _sz, "hg_scatter_binned_scratch_bytes": _sz}
+_RESTYPES = {"nsig_last_error": _c.c_char_p, "rm_march_train_scratch_bytes": _sz, "mlp_packed_bytes": _sz, "hg_planes_bytes": _sz, "dec_workspace_bytes": _sz, "hg_scatter_levels_scratch_bytes": _sz, "hg_scatter_binned_scratch_bytes": _sz, "hg_scatter_plan_bytes": _sz}
 
 _lib = None
 

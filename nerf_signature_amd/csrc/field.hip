@@ -477,7 +477,7 @@ __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyz
                                                    const float *__restrict__ sigmas, const float *__restrict__ rgbs,
                                                    const uint32_t *__restrict__ masks, const char *__restrict__ packed,
                                                    float *__restrict__ G, float *__restrict__ dfeat_out, float *__restrict__ rec_out,
-                                                   GradTrace gt = GradTrace{}, uint32_t stride = 0) {
+                                                   GradTrace gt = GradTrace{}, uint32_t stride = 0, ScatterPlan plan = ScatterPlan{}) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     stage_weights(lds, packed + 2 * kFwdBytes, 2 * (int)kBwdBytes);
     const char *lds_hi = lds, *lds_lo = lds + kBwdBytes;
@@ -485,12 +485,24 @@ __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyz
     const int p = lane & 31, h = lane >> 5;
     const uint32_t n_tiles = ceil_div(M, 32u);
     const float e_lo = expf(-15.0f), e_hi = expf(15.0f);
-    for (uint32_t tile = blockIdx.x * 4 + wid; tile < n_tiles; tile += gridDim.x * 4) {
+    const bool planned = !kFull && plan.hd != nullptr;
+    uint32_t gbits = 0;   // planned scatter: running max |gradient| of this lane's points, as a bit pattern
+    // Tile order: a 1024-point chunk (32 tiles, the unit the scatter plan sorts by) is handled by 8 workgroups of ONE XCD at the
+    // same time (workgroup b runs on XCD b % 8), so the 16-byte queue entries of a (chunk, slice) run -- written by many waves --
+    // merge into whole lines in that XCD's L2 instead of leaving eight L2s with partial lines each.  gridDim.x % 8 == 0.
+    const uint32_t xcd = blockIdx.x & 7u, per_xcd = gridDim.x >> 3, n_chunks = ceil_div(n_tiles, 32u);
+    for (uint32_t lq = blockIdx.x >> 3;; lq += per_xcd) {
+        const uint32_t chunk = (lq >> 3) * 8u + xcd;
+        if (chunk >= n_chunks) break;
+        const uint32_t tile = (chunk * 8u + (lq & 7u)) * 4u + wid;
+        if (tile >= n_tiles) continue;
         const uint32_t s = tile * 32 + p;
         const bool live = s < M;
         const uint32_t sl = min(s, M - 1);
         const uint32_t *mrow = masks + (size_t)tile * 192 + lane;
         const uint32_t mask_s = mrow[0], mask_c0 = mrow[64], mask_c1 = mrow[128];
+        uint4 dst = make_uint4(0u, 0u, 0u, 0u);
+        if (planned) dst = plan.dest[sl];   // issued with the masks: long done when the gradients are
 
         // d(pre-sigmoid color): only lane half 0, elements 0..2 of the 16-wide K-step are non-zero
         Split8 dout[1];
@@ -554,16 +566,30 @@ __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyz
         if (dfeat_out != nullptr && h == 0) { dfeat_out[2 * (size_t)s] = g0; dfeat_out[2 * (size_t)s + 1] = g1; }
         const float two_b = 2.0f * bound;
         const float x01 = (xyzs[3 * (size_t)s] + bound) / two_b, y01 = (xyzs[3 * (size_t)s + 1] + bound) / two_b, z01 = (xyzs[3 * (size_t)s + 2] + bound) / two_b;
+        if (planned) {
+            // The entries' places in the slice-sorted queue were fixed from the positions alone (hg_scatter_plan): lane half h
+            // writes the two (dy, dz) pairs with dy = h.  Nothing else stands between this kernel and the slice owners.
+            uint32_t ix, iy, iz;
+            float wx, wy, wz;
+            codebook_axis(x01, ix, wx);
+            codebook_axis(y01, iy, wy);
+            codebook_axis(z01, iz, wz);
+            const uint32_t q0 = 2u * (uint32_t)h;
+            plan.queue[h ? dst.z : dst.x] = pair_entry(ix, pair_hash(iy, iz, q0), wx, wy, wz, g0, g1, q0);
+            plan.queue[h ? dst.w : dst.y] = pair_entry(ix, pair_hash(iy, iz, q0 + 1u), wx, wy, wz, g0, g1, q0 + 1u);
+            gbits = max(gbits, __float_as_uint(fmaxf(fabsf(g0), fabsf(g1))));   // non-negative floats order like their bit patterns
+            continue;
+        }
         if (rec_out != nullptr && h == 0) {
-            // The scatter's 256 workgroups each re-read this record 32 times (once per slice), so what is computed here once is
-            // not recomputed there: integer cell, interpolation weights (codebook resolution 2^11: exact scalings, identical to
-            // corner_rows()), gradients.  32 bytes per point, two 16-byte stores.
-            const float res = kCodebookResolution, cell = 1.0f / kCodebookResolution;
-            const int ix = (int)floorf(fminf(fmaxf(x01, 0.0f), 1.0f) * res), iy = (int)floorf(fminf(fmaxf(y01, 0.0f), 1.0f) * res),
-                      iz = (int)floorf(fminf(fmaxf(z01, 0.0f), 1.0f) * res);
-            const float wx = (x01 - (float)ix * cell) * res, wy = (y01 - (float)iy * cell) * res, wz = (z01 - (float)iz * cell) * res;
+            // The scatter's workgroups re-read this record, so what is computed here once is not recomputed there: integer
+            // cell, interpolation weights, gradients.  32 bytes per point, two 16-byte stores.
+            uint32_t ix, iy, iz;
+            float wx, wy, wz;
+            codebook_axis(x01, ix, wx);
+            codebook_axis(y01, iy, wy);
+            codebook_axis(z01, iz, wz);
             uint4 *r4 = reinterpret_cast<uint4 *>(rec_out) + 2 * (size_t)s;
-            r4[0] = make_uint4((uint32_t)ix | ((uint32_t)iy << 16), (uint32_t)iz, __float_as_uint(wx), __float_as_uint(wy));
+            r4[0] = make_uint4(ix | (iy << 16), iz, __float_as_uint(wx), __float_as_uint(wy));
             r4[1] = make_uint4(__float_as_uint(wz), __float_as_uint(g0), __float_as_uint(g1), 0u);
         }
         if (G == nullptr || (g0 == 0.0f && g1 == 0.0f)) continue;
@@ -576,6 +602,13 @@ __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyz
             atomicAdd(row, corner_weight(c, k, g0));
             atomicAdd(row + 1, corner_weight(c, k, g1));
         }
+    }
+    if (planned) {   // the owners' fixed-point scale comes from the launch's largest |gradient|
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) gbits = max(gbits, (uint32_t)__shfl_xor((int)gbits, d, 64));
+        // 3072 waves finish together: atomics on one address serialise (~10 ns each), so only a wave that would raise the
+        // maximum issues one -- after the first few, almost none does
+        if (lane == 0 && gbits > __hip_atomic_load(&plan.hd->gmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&plan.hd->gmax_bits, gbits);
     }
 }
 
@@ -594,7 +627,7 @@ NSIG_EXPORT int mlp_pack_weights(const float *sigma_params, const float *color_p
 }
 
 static uint32_t field_grid(uint32_t M) {
-    const uint32_t blocks = ceil_div(ceil_div(M, 32u), 4u);
+    const uint32_t blocks = ceil_div(ceil_div(ceil_div(M, 32u), 4u), 8u) * 8u;   // a multiple of 8: k_field_bwd's XCD-aware tile order
     return blocks < (uint32_t)(kCUs * 3) ? blocks : (uint32_t)(kCUs * 3);  // 3 workgroups per CU fit the LDS budget
 }
 
@@ -692,6 +725,19 @@ NSIG_EXPORT int field_bwd(const float *xyzs, uint32_t M, float bound, const floa
     k_field_bwd<false><<<field_grid(M), 256, 2 * kBwdBytes, as_stream(stream)>>>(xyzs, M, bound, 1.0f / kCodebookResolution, grad_sigmas, grad_rgbs,
                                                                          sigmas, rgbs, masks, reinterpret_cast<const char *>(packed), G, dfeat_out, rec_out);
     return check_launch("field_bwd");
+}
+
+// field_bwd with the codebook scatter's queue as its output: `plan` was prepared by hg_scatter_plan from the same xyzs; follow with
+// hg_scatter_planned.  (reference: the autograd backward of network_wtmk_tcnn.py:97-124 down to the index_add of hash_encoding.py)
+NSIG_EXPORT int field_bwd_planned(const float *xyzs, uint32_t M, float bound, const float *grad_sigmas, const float *grad_rgbs, const float *sigmas,
+                                  const float *rgbs, const uint32_t *masks, const void *packed, void *plan, nsig_stream_t stream) {
+    NSIG_REQUIRE(xyzs && grad_sigmas && grad_rgbs && sigmas && rgbs && masks && packed && plan, "field_bwd_planned: null pointer");
+    NSIG_REQUIRE(bound > 0.0f && (reinterpret_cast<uintptr_t>(plan) & 15) == 0 && M < (1u << 28), "field_bwd_planned: bound must be positive, plan 16-byte aligned, M < 2^28");
+    if (M == 0) return NSIG_OK;
+    k_field_bwd<false><<<field_grid(M), 256, 2 * kBwdBytes, as_stream(stream)>>>(xyzs, M, bound, 1.0f / kCodebookResolution, grad_sigmas, grad_rgbs,
+                                                                         sigmas, rgbs, masks, reinterpret_cast<const char *>(packed), nullptr, nullptr, nullptr,
+                                                                         GradTrace{}, 0, scatter_plan_view(plan, M));
+    return check_launch("field_bwd_planned");
 }
 
 // ----------------------------------------------------------------------------- stage-1 (clean model) training entry points

@@ -106,4 +106,51 @@ __device__ inline float corner_weight(const Corner8 &c, int k, float g) {
     return ((g * fz) * fy) * fx;
 }
 
+// ---- slice-binned codebook scatter: the layout shared by the binning passes (hashgrid.hip) and the producer of the queue
+// entries (k_field_bwd in field.hip, or k_bin_write from 32-byte records).  See the comment above BinHeader's users.
+constexpr uint32_t kBinThreads = 1024, kBinSlices = 64, kBinRows = NSIG_TABLE_ROWS / kBinSlices, kBinReplicas = 4;
+constexpr uint32_t kBinGrid = 256;   // workgroups of the binning passes (each walks chunks w, w + kBinGrid, ...)
+
+struct BinHeader {                 // scratch header
+    uint32_t counts[kBinSlices];   // entries per slice (written by k_bin_scan)
+    uint32_t gmax_bits;            // max |gradient| of the launch as a float bit pattern
+    uint32_t pad[3];
+    uint32_t wg[kBinGrid][kBinSlices];   // count pass: entries of slice s found by workgroup w; k_bin_scan: its write offset
+};
+
+// integer cell and interpolation weight of one axis at the codebook level (resolution 2^11: exact scalings, identical to
+// corner_rows() with cell = 2^-11)
+__device__ inline void codebook_axis(float v01, uint32_t &i, float &w) {
+    const float res = kCodebookResolution, cell = 1.0f / kCodebookResolution;
+    const int c = (int)floorf(fminf(fmaxf(v01, 0.0f), 1.0f) * res);
+    i = (uint32_t)c;
+    w = (v01 - (float)c * cell) * res;
+}
+
+// hash bits shared by the two x corners of the (dy, dz) = (q >> 1, q & 1) pair of cell (., iy, iz); its slice is bits 13..18
+__device__ inline uint32_t pair_hash(uint32_t iy, uint32_t iz, uint32_t q) { return ((iy + (q >> 1)) * kPrimeY) ^ ((iz + (q & 1u)) * kPrimeZ); }
+__device__ inline uint32_t pair_slice(uint32_t hyz) { return (hyz >> 13) & (kBinSlices - 1); }
+
+// queue entry of one pair: x cell | the pair's 13 row bits, the x weight, the two gradients times the z and y weights
+// (built in corner_weight()'s order ((g*fz)*fy)*fx; the owner applies fx)
+__device__ inline uint4 pair_entry(uint32_t ix, uint32_t hyz, float wx, float wy, float wz, float g0, float g1, uint32_t q) {
+    const float fz = (q & 1u) ? wz : 1.0f - wz, fy = (q >> 1) ? wy : 1.0f - wy;
+    return make_uint4(ix | ((hyz & (kBinRows - 1)) << 16), __float_as_uint(wx), __float_as_uint((g0 * fz) * fy), __float_as_uint((g1 * fz) * fy));
+}
+
+// A planned scatter's scratch: header, queue [4M] entries, destinations [M] (queue index of each of the point's four pairs)
+struct ScatterPlan {
+    BinHeader *hd;
+    uint4 *queue;
+    uint4 *dest;
+};
+inline size_t scatter_plan_bytes(uint32_t M) { return sizeof(BinHeader) + (size_t)5 * M * sizeof(uint4); }
+inline ScatterPlan scatter_plan_view(void *scratch, uint32_t M) {
+    ScatterPlan pl;
+    pl.hd = reinterpret_cast<BinHeader *>(scratch);
+    pl.queue = reinterpret_cast<uint4 *>(pl.hd + 1);
+    pl.dest = pl.queue + (size_t)4 * M;
+    return pl;
+}
+
 }  // namespace nsig

@@ -243,26 +243,15 @@ __global__ void __launch_bounds__(1024) k_scatter_level(const float *__restrict_
 //    self-contained (16 bytes: x cell, the pair's 13 row bits, the x weight, the two gradients already multiplied by the y and
 //    z weights); gathering 32-byte records at random from the 41 MB array instead made this slower than what it replaced.
 // The slice of a pair depends on (iy, iz, dy, dz) only (ix < 2^12 stays below bit 13), and a hit carries both x corners.
-constexpr uint32_t kBinThreads = 1024, kBinSlices = 64, kBinRows = NSIG_TABLE_ROWS / kBinSlices, kBinReplicas = 4;
-static_assert(kBinRows == 8192, "slice layout");
-
-constexpr uint32_t kBinGrid = 256;   // workgroups of the two binning passes (each walks chunks w, w + kBinGrid, ...)
-
-struct BinHeader {                 // scratch header
-    uint32_t counts[kBinSlices];   // entries per slice (written by k_bin_scan)
-    uint32_t gmax_bits;            // max |gradient| of the launch as a float bit pattern (zeroed before k_bin_count)
-    uint32_t pad[3];
-    uint32_t wg[kBinGrid][kBinSlices];   // k_bin_count: entries of slice s found by workgroup w; k_bin_scan: its write offset
-};
+static_assert(kBinRows == 8192, "slice layout");   // constants and BinHeader: hashgrid.h
 
 __device__ inline bool record_pairs(const uint4 *__restrict__ rec4, uint32_t m, uint32_t (&slices)[4], float &gabs) {
     const uint4 ra = rec4[2 * (size_t)m], rb = rec4[2 * (size_t)m + 1];
     const float g0 = __uint_as_float(rb.y), g1 = __uint_as_float(rb.z);
     if (g0 == 0.0f && g1 == 0.0f) return false;   // padding rows and terminated rays
     gabs = fmaxf(fabsf(g0), fabsf(g1));
-    const uint32_t hy0 = (ra.x >> 16) * kPrimeY, hz0 = ra.y * kPrimeZ;
 #pragma unroll
-    for (uint32_t q = 0; q < 4; ++q) slices[q] = (((hy0 + (q >> 1) * kPrimeY) ^ (hz0 + (q & 1u) * kPrimeZ)) >> 13) & (kBinSlices - 1);
+    for (uint32_t q = 0; q < 4; ++q) slices[q] = pair_slice(pair_hash(ra.x >> 16, ra.y, q));
     return true;
 }
 
@@ -358,21 +347,67 @@ __global__ void __launch_bounds__(kBinThreads) k_bin_write(const float *__restri
             const uint4 ra = rec4[2 * (size_t)m], rb = rec4[2 * (size_t)m + 1];
             const float wy = __uint_as_float(ra.w), wz = __uint_as_float(rb.x);
             const float g0 = __uint_as_float(rb.y), g1 = __uint_as_float(rb.z);
-            const uint32_t ix = ra.x & 0xffffu, hy0 = (ra.x >> 16) * kPrimeY, hz0 = ra.y * kPrimeZ;
 #pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) {
-                // corner (dx, dy, dz) = (dx, q >> 1, q & 1); the weight is built in corner_weight()'s order ((g*fz)*fy)*fx
-                const uint32_t hyz = (hy0 + (q >> 1) * kPrimeY) ^ (hz0 + (q & 1u) * kPrimeZ);
-                const float fz = (q & 1u) ? wz : 1.0f - wz, fy = (q >> 1) ? wy : 1.0f - wy;
-                queue[running[sl[q]] + local[q]] = make_uint4(ix | ((hyz & (kBinRows - 1)) << 16), ra.z, __float_as_uint((g0 * fz) * fy),
-                                                              __float_as_uint((g1 * fz) * fy));
-            }
+            for (uint32_t q = 0; q < 4; ++q)
+                queue[running[sl[q]] + local[q]] = pair_entry(ra.x & 0xffffu, pair_hash(ra.x >> 16, ra.y, q), __uint_as_float(ra.z), wy, wz, g0, g1, q);
         }
         __syncthreads();
         if (threadIdx.x < kBinSlices) running[threadIdx.x] += h[threadIdx.x];
     }
 }
 
+// ---- planned variant: where an entry goes depends on the point's position only, so the count, the scan and the destinations
+// are computed from xyzs while the forward pass is still running (off the critical path, on a side stream), and k_field_bwd
+// writes its gradients straight into the queue: no 32-byte record round trip and no binning passes between the MLP backward
+// and the owners.  Every point gets its four entries (a zero gradient adds zero).
+__device__ inline void point_slices(const float *__restrict__ xyzs, uint32_t m, float bound, uint32_t (&sl)[4]) {
+    const float two_b = 2.0f * bound;
+    uint32_t iy, iz;
+    float w;
+    codebook_axis((xyzs[3 * (size_t)m + 1] + bound) / two_b, iy, w);
+    codebook_axis((xyzs[3 * (size_t)m + 2] + bound) / two_b, iz, w);
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) sl[q] = pair_slice(pair_hash(iy, iz, q));
+}
+
+__global__ void __launch_bounds__(kBinThreads) k_plan_count(const float *__restrict__ xyzs, uint32_t M, float bound, BinHeader *__restrict__ hd) {
+    __shared__ uint32_t h[kBinSlices];
+    if (threadIdx.x < kBinSlices) h[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) hd->gmax_bits = 0;   // k_field_bwd raises it (stream-ordered after the plan)
+    __syncthreads();
+    for (uint32_t m = blockIdx.x * kBinThreads + threadIdx.x; m < M; m += gridDim.x * kBinThreads) {
+        uint32_t sl[4];
+        point_slices(xyzs, m, bound, sl);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) atomicAdd(&h[sl[q]], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kBinSlices) hd->wg[blockIdx.x][threadIdx.x] = h[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(kBinThreads) k_plan_dest(const float *__restrict__ xyzs, uint32_t M, float bound, const BinHeader *__restrict__ hd,
+                                                           uint4 *__restrict__ dest) {
+    __shared__ uint32_t h[kBinSlices], running[kBinSlices];
+    if (threadIdx.x < kBinSlices) running[threadIdx.x] = hd->wg[blockIdx.x][threadIdx.x];
+    for (uint32_t m0 = blockIdx.x * kBinThreads; m0 < M; m0 += gridDim.x * kBinThreads) {   // uniform trip count: barriers inside
+        if (threadIdx.x < kBinSlices) h[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t m = m0 + threadIdx.x;
+        uint32_t sl[4], local[4];
+        if (m < M) {
+            point_slices(xyzs, m, bound, sl);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) local[q] = atomicAdd(&h[sl[q]], 1u);
+        }
+        __syncthreads();
+        if (m < M) dest[m] = make_uint4(running[sl[0]] + local[0], running[sl[1]] + local[1], running[sl[2]] + local[2], running[sl[3]] + local[3]);
+        __syncthreads();
+        if (threadIdx.x < kBinSlices) running[threadIdx.x] += h[threadIdx.x];
+    }
+}
+
+// (a single-precision formulation of this conversion -- split at bit 27, two exact cvt_i32 -- changes nothing: the owners are
+// bound by their LDS atomics and entry loads, not by the f64 instructions)
 __device__ inline long long to_fixed(float c, int k) { return __double2ll_rn(ldexp((double)c, k)); }
 
 // blockIdx.x = slice * replicas + replica: the slice's entries, split evenly over the replicas.  replicas == 1: the owner is
@@ -813,6 +848,19 @@ NSIG_EXPORT int opt_adam_dense(uint32_t n, float *const *params_host, const floa
 
 static size_t binned_scratch_bytes(uint32_t M, uint32_t sets) { return (size_t)sets * (sizeof(BinHeader) + (size_t)4 * M * sizeof(uint4)); }
 
+static int reserve_owner_lds(const char *who) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)kBinRows * 2 * sizeof(unsigned long long);
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_binned), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error("%s: cannot reserve %zu bytes of LDS", who, lds);
+            return NSIG_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    return NSIG_OK;
+}
+
 // sets record arrays [sets][M][8] -> sets tables; scratch = sets headers, then sets queues
 static int launch_binned(const float *rec, uint32_t M, uint32_t sets, const ScatterTargets &tg, uint32_t replicas, void *scratch, hipStream_t st,
                          const char *who) {
@@ -824,15 +872,8 @@ static int launch_binned(const float *rec, uint32_t M, uint32_t sets, const Scat
             set_error("%s: hipMemsetAsync failed", who);
             return NSIG_ERR_LAUNCH;
         }
-    static bool attr_set = false;
     const size_t lds = (size_t)kBinRows * 2 * sizeof(unsigned long long);
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_binned), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            set_error("%s: cannot reserve %zu bytes of LDS", who, lds);
-            return NSIG_ERR_LAUNCH;
-        }
-        attr_set = true;
-    }
+    if (int e = reserve_owner_lds(who)) return e;
     const uint32_t blocks = ceil_div(M, kBinThreads) < kBinGrid ? ceil_div(M, kBinThreads) : kBinGrid;
     k_bin_count<<<dim3(blocks, sets), kBinThreads, 0, st>>>(rec, M, hd);
     k_bin_scan<<<sets, 1024, 0, st>>>(hd, blocks);
@@ -851,6 +892,35 @@ NSIG_EXPORT int hg_scatter_binned(const float *rec, uint32_t M, float *G, void *
     ScatterTargets tg{};
     tg.g[0] = G;
     return launch_binned(rec, M, 1, tg, kBinReplicas, scratch, as_stream(stream), "hg_scatter_binned");
+}
+
+NSIG_EXPORT size_t hg_scatter_plan_bytes(uint32_t M) { return scatter_plan_bytes(M); }
+
+NSIG_EXPORT int hg_scatter_plan(const float *xyzs, uint32_t M, float bound, void *plan, nsig_stream_t stream) {
+    NSIG_REQUIRE(xyzs && plan, "hg_scatter_plan: null pointer");
+    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(plan) & 15) == 0 && M < (1u << 28) && bound > 0.0f, "hg_scatter_plan: plan must be 16-byte aligned, M < 2^28, bound > 0");
+    if (M == 0) return NSIG_OK;
+    const ScatterPlan pl = scatter_plan_view(plan, M);
+    hipStream_t st = as_stream(stream);
+    const uint32_t blocks = ceil_div(M, kBinThreads) < kBinGrid ? ceil_div(M, kBinThreads) : kBinGrid;
+    k_plan_count<<<blocks, kBinThreads, 0, st>>>(xyzs, M, bound, pl.hd);
+    k_bin_scan<<<1, 1024, 0, st>>>(pl.hd, blocks);
+    k_plan_dest<<<blocks, kBinThreads, 0, st>>>(xyzs, M, bound, pl.hd, pl.dest);
+    return check_launch("hg_scatter_plan");
+}
+
+NSIG_EXPORT int hg_scatter_planned(const void *plan, uint32_t M, float *G, nsig_stream_t stream) {
+    NSIG_REQUIRE(plan && G, "hg_scatter_planned: null pointer");
+    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(plan) & 15) == 0 && M < (1u << 28), "hg_scatter_planned: plan must be 16-byte aligned and M < 2^28");
+    if (M == 0) return NSIG_OK;
+    if (int e = reserve_owner_lds("hg_scatter_planned")) return e;
+    const ScatterPlan pl = scatter_plan_view(const_cast<void *>(plan), M);
+    ScatterTargets tg{};
+    tg.g[0] = G;
+    // replicas: 1 -> 63 us, 2 -> 40, 4 -> 32, 8 -> 43 on 5.2 M entries (more owners stream less each, but merge with more float atomics)
+    k_scatter_binned<<<dim3(kBinSlices * kBinReplicas, 1), 1024, (size_t)kBinRows * 2 * sizeof(unsigned long long), as_stream(stream)>>>(pl.hd, pl.queue, M, tg,
+                                                                                                                                           kBinReplicas);
+    return check_launch("hg_scatter_planned");
 }
 
 NSIG_EXPORT size_t hg_scatter_levels_scratch_bytes(uint32_t M) {

@@ -180,8 +180,82 @@ def codebook_scatter_sliced(rec, G, binned=None):
     return G
 
 
-def field_backward_into(xyzs, bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, G):
-    """The production backward: MLP input gradients -> scatter record -> owner-computes scatter into G."""
+_PLAN_STREAM = None
+_PENDING_PLANS = []
+
+
+def set_plan_stream(stream):
+    """Stream on which scatter plans are computed (None: the current stream, immediately).  A plan needs the sample positions
+    only; with a plan stream its launches are deferred until flush_plans() -- the caller decides what they queue behind -- or
+    until the backward pass asks for the plan, whichever comes first.  Returns the previous setting."""
+    global _PLAN_STREAM
+    prev, _PLAN_STREAM = _PLAN_STREAM, stream
+    return prev
+
+
+def flush_plans():
+    """Enqueue every deferred scatter plan on its plan stream (behind whatever that stream already holds)."""
+    while _PENDING_PLANS:
+        _PENDING_PLANS.pop(0).launch()
+
+
+class ScatterPlan:
+    """Counts, offsets and per-point queue destinations of the slice-binned codebook scatter -> hg_scatter_plan."""
+
+    def __init__(self, xyzs, bound):
+        self.M, self.xyzs, self.bound = xyzs.shape[0], xyzs, float(bound)
+        self.buf = torch.empty(int(nv.fn("hg_scatter_plan_bytes")(self.M)), dtype=torch.uint8, device=xyzs.device)
+        self.stream, self.ready, self.launched = _PLAN_STREAM, None, False
+        if self.stream is not None and self.stream == torch.cuda.current_stream():
+            self.stream = None
+        if self.stream is None:
+            self.launch()
+        else:
+            self.src_ready = torch.cuda.Event()      # the positions are produced on the current stream
+            self.src_ready.record()
+            _PENDING_PLANS.append(self)
+
+    def launch(self):
+        if self.launched:
+            return
+        self.launched = True
+        if self.stream is None:
+            nv.call("hg_scatter_plan", nv.ptr(self.xyzs), self.M, self.bound, nv.ptr(self.buf), nv.stream())
+        else:
+            self.stream.wait_event(self.src_ready)
+            nv.call("hg_scatter_plan", nv.ptr(self.xyzs), self.M, self.bound, nv.ptr(self.buf), self.stream.cuda_stream)
+            self.xyzs.record_stream(self.stream)
+            self.buf.record_stream(self.stream)
+            self.ready = torch.cuda.Event()     # the consumer waits for the plan, not for whatever else that stream runs later
+            self.ready.record(self.stream)
+        self.xyzs = None
+
+    def join(self):
+        """Called on the consumer's stream before the plan is read."""
+        if not self.launched:                   # nobody flushed: compute it here
+            if self in _PENDING_PLANS:
+                _PENDING_PLANS.remove(self)
+            self.stream = None
+            self.launch()
+        elif self.ready is not None:
+            torch.cuda.current_stream().wait_event(self.ready)
+            self.ready = None
+
+
+def field_backward_planned(xyzs, bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, plan, G):
+    """MLP input gradients written straight into the planned queue, then the slice owners -> field_bwd_planned, hg_scatter_planned."""
+    plan.join()
+    nv.call("field_bwd_planned", nv.ptr(xyzs), plan.M, float(bound), nv.ptr(g_sigma.contiguous().float()), nv.ptr(g_rgb.contiguous().float()),
+            nv.ptr(sigmas), nv.ptr(rgbs), nv.ptr(masks), nv.ptr(packed), nv.ptr(plan.buf), nv.stream())
+    nv.call("hg_scatter_planned", nv.ptr(plan.buf), plan.M, nv.ptr(G), nv.stream())
+    return G
+
+
+def field_backward_into(xyzs, bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, G, plan=None):
+    """The production backward: MLP input gradients -> owner-computes scatter into G (through the planned queue when the
+    forward pass prepared one, through the 32-byte scatter record otherwise)."""
+    if plan is not None:
+        return field_backward_planned(xyzs, bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, plan, G)
     rec = field_backward(xyzs, bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, want_rec=True)
     return codebook_scatter_sliced(rec, G)
 
@@ -226,6 +300,9 @@ class _FieldFunction(Function):
     def forward(ctx, xyzs, dirs, bound, packed, S, sink, n_sel, *tables):
         base, sel = tables[:16], tables[16:16 + n_sel]
         need_grad = n_sel > 0 and any(t.requires_grad for t in sel)
+        xyzs = xyzs.contiguous().float()
+        # before the encoder is enqueued: a plan on its own stream forks right behind the march, not behind this forward pass
+        ctx.plan = ScatterPlan(xyzs, bound) if need_grad and xyzs.shape[0] >= BINNED_MIN_POINTS else None
         sigmas, rgbs, _, masks = field_forward(xyzs, dirs, bound, base, S, packed, want_masks=need_grad)
         ctx.bound, ctx.n_sel, ctx.need_grad, ctx.sink = bound, n_sel, need_grad, sink
         if need_grad:
@@ -241,11 +318,12 @@ class _FieldFunction(Function):
         if not ctx.need_grad:
             return head + (None,) * ctx.n_sel
         xyzs, sigmas, rgbs, masks, packed = ctx.saved_tensors
+        plan, ctx.plan = ctx.plan, None
         if ctx.sink is not None:
-            field_backward_into(xyzs, ctx.bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, ctx.sink.G)
+            field_backward_into(xyzs, ctx.bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, ctx.sink.G, plan)
             return head + (None,) * ctx.n_sel
         G = torch.zeros(T_ROWS, 2, dtype=torch.float32, device=xyzs.device)
-        field_backward_into(xyzs, ctx.bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, G)
+        field_backward_into(xyzs, ctx.bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, G, plan)
         slab = torch.empty(ctx.n_sel, T_ROWS, 2, dtype=torch.float32, device=xyzs.device)
         grads = [slab[i] for i in range(ctx.n_sel)]
         fanout_grad(G, grads, accumulate=False)

@@ -84,6 +84,7 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
         with torch.cuda.stream(side_stream):
             content_pred_rgb = model.render(content["rays_o"], content["rays_d"], message, **kw)["image"]
         content_pred_rgb.record_stream(main)
+        fo.flush_plans()          # the block render's scatter plan: on the plan stream, behind the content render
     if model.normalization is normalize_img and hasattr(model.msg_decoder, "decode_rendered"):
         decoded, pred_rgb = model.msg_decoder.decode_rendered(outputs["image"])    # clamp + permute + normalise inside layer 0
     else:
@@ -111,6 +112,7 @@ class WatermarkLoop:
 
     def __init__(self, model, optimizer, render_kwargs, lambda_w=1.0, lambda_i=1.0, lr_scheduler=None, use_sink=True, side_stream=None):
         self.side_stream = side_stream
+        self.plan_stream = side_stream   # scatter plans queue behind the content render
         self.model, self.optimizer, self.lr_scheduler = model, optimizer, lr_scheduler
         self.render_kwargs = dict(render_kwargs)
         self.lambda_w, self.lambda_i = lambda_w, lambda_i
@@ -125,7 +127,11 @@ class WatermarkLoop:
         self.optimizer.zero_grad(set_to_none=True)
         if self.sink is not None:
             self.sink.zero_()
-        out = train_step(self.model, data, message, self.render_kwargs, self.lambda_w, self.lambda_i, side_stream=self.side_stream)
+        prev = fo.set_plan_stream(self.plan_stream)    # the scatter plans of both renders leave the critical path too
+        try:
+            out = train_step(self.model, data, message, self.render_kwargs, self.lambda_w, self.lambda_i, side_stream=self.side_stream)
+        finally:
+            fo.set_plan_stream(prev)
         out[-1].backward()
         if self.side_stream is not None:
             torch.cuda.current_stream().wait_stream(self.side_stream)
@@ -204,6 +210,7 @@ class GraphedWatermarkLoop:
                  overlap_content=True):
         self.native_dense_adam = native_dense_adam
         self.side_stream = torch.cuda.Stream() if overlap_content else None
+        self.plan_stream = self.side_stream   # scatter plans queue behind the content render (a third captured stream crashes hipStreamEndCapture on this runtime)
         if not hasattr(optimizer, "step_shared_sel"):
             raise TypeError("GraphedWatermarkLoop needs nerf_signature_amd.optim.CodebookAdam(capturable=True)")
         self.model, self.optimizer = model, optimizer
@@ -236,7 +243,11 @@ class GraphedWatermarkLoop:
     # -- pieces of one step (executed eagerly during warm-up, then under capture)
     def _forward_backward(self):
         self.sink.zero_()
-        out = train_step(self.model, self.data, self.msg_dev, self.render_kwargs, self.lambda_w, self.lambda_i, side_stream=self.side_stream)
+        prev = fo.set_plan_stream(self.plan_stream)    # the scatter plans need the sample positions only: beside the forward pass
+        try:
+            out = train_step(self.model, self.data, self.msg_dev, self.render_kwargs, self.lambda_w, self.lambda_i, side_stream=self.side_stream)
+        finally:
+            fo.set_plan_stream(prev)
         set_weights_stream(self.side_stream)     # the decoder's parameter gradients go there too: the block render's backward only waits for the image gradient
         try:
             backward_from_loss_kernel(out)

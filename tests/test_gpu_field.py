@@ -239,3 +239,32 @@ def test_sliced_scatter_equals_pointwise_scatter(fo, tables):
     fo.codebook_scatter_sliced(same, Ga, binned=False)
     fo.codebook_scatter_sliced(same, Gb, binned=True)
     assert float((Ga - Gb).norm() / Ga.norm()) < 1e-5 and int((Gb != 0).sum()) <= 16
+    # planned route: destinations from the positions alone (also on a side stream), gradients written straight into the queue
+    for stream in (None, torch.cuda.Stream()):
+        prev = fo.set_plan_stream(stream)
+        try:
+            plan = fo.ScatterPlan(pts, 1.0)
+        finally:
+            fo.set_plan_stream(prev)
+        G3 = torch.full((1 << 19, 2), 0.5, device="cuda")
+        fo.field_backward_planned(pts, 1.0, gs, gc, s1, c1, masks, packed, plan, G3)
+        G3 -= 0.5
+        assert float((G1 - G3).norm() / G1.norm()) < 1e-5
+        assert float(((G1 != 0) != (G3.abs() > 1e-9)).float().mean()) < 1e-4
+    # queue contents: the plan's destinations are a permutation of [0, 4M) grouped by slice, and the entries equal k_bin_write's
+    M4 = 4 * M
+    hdr = 4 * (64 + 4 + 256 * 64)
+    dest = plan.buf[hdr + 16 * M4: hdr + 16 * M4 + 16 * M].view(torch.int32).view(M, 4)
+    assert torch.equal(torch.sort(dest.reshape(-1)).values, torch.arange(M4, device="cuda", dtype=torch.int32))
+    counts = plan.buf[:256].view(torch.int32)
+    assert int(counts.sum()) == M4
+    queue = plan.buf[hdr: hdr + 16 * M4].view(torch.int32).view(M4, 4)
+    hy = (cell[:, 1].long() * 2654435761) & 0xFFFFFFFF
+    hz = (cell[:, 2].long() * 805459861) & 0xFFFFFFFF
+    starts = torch.cumsum(counts.long(), 0) - counts.long()
+    sl0 = ((hy ^ hz) >> 13) & 63                              # the (dy, dz) = (0, 0) pair
+    d0 = dest[:, 0].long()
+    assert bool(((d0 >= starts[sl0]) & (d0 < starts[sl0] + counts.long()[sl0])).all())
+    e0 = queue[d0]
+    assert torch.equal(e0[:, 0] & 0xFFFF, cell[:, 0]) and torch.equal((e0[:, 0] >> 16) & 0x1FFF, ((hy ^ hz) & 0x1FFF).int())
+    assert torch.equal(e0[:, 1], words[:, 2])                 # the x weight, bit for bit

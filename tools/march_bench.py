@@ -58,3 +58,10 @@ for name, (o, d) in {"block": synthetic.block_rays("hotdog", dev), "content": sy
     c = counts.cpu().numpy()
     print(f"{name}: N={N} M={M} max_count={c.max()} mean={c.mean():.1f} | count {timeit(count):.1f}us scan {timeit(scan):.1f}us "
           f"write {timeit(write):.1f}us composite fwd {timeit(comp):.1f}us bwd {timeit(cbwd):.1f}us")
+    # how the index pass scales with the number of rays: flat = bound by one ray's dependent chain, linear = by issue rate
+    parts = []
+    for frac in (2, 4, 16, 64):
+        n = N // frac
+        fn = lambda: nv.call("rm_march_train_count", nv.ptr(o), nv.ptr(d), nv.ptr(bf), 1.0, 0.0, 1024, n, 1, 128, nv.ptr(nears), nv.ptr(fars), None, nv.ptr(counts), nv.ptr(t_rec), s)
+        parts.append(f"N/{frac} {timeit(fn):.1f}us")
+    print("   count pass on the first", " ".join(parts))
