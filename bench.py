@@ -180,6 +180,8 @@ def main():
         timer.enabled = False
 
     n_block, n_content = int(model.step_counter[(model.local_step - 2) % 16, 0]), int(model.step_counter[(model.local_step - 1) % 16, 0])
+    if not args.no_overlap:      # counters are written in issue order: the overlapped step issues the content render first
+        n_block, n_content = n_content, n_block
     rays_block, rays_content = bo.shape[0] * bo.shape[1] * bo.shape[2], args.rays
     rays_per_step = (rays_block + rays_content) * world
     # the dominant kernel: the hash-gather encoder, on the block render (the launch with the most points)

@@ -68,7 +68,24 @@ class NeRFNetwork(NeRFRenderer):
         if self._presum_cache is None or self._presum_cache[0] != key:
             S = self._presum_cache[1] if self._presum_cache is not None else None
             self._presum_cache = (key, fo.codebook_presum(selected, out=S))
+            self._presum_produced()
+        else:
+            self._presum_consumed()
         return self._presum_cache[1]
+
+    def _presum_produced(self):
+        """Remember where the pre-sum was computed: a render on another stream must wait for it (trainer.train_step issues the
+        content render first, on its side stream, so the pre-sum runs beside the block render's march instead of before it)."""
+        if self._presum_cache[1].is_cuda:
+            self._presum_stream = torch.cuda.current_stream()
+            self._presum_event = torch.cuda.Event()
+            self._presum_event.record(self._presum_stream)
+
+    def _presum_consumed(self):
+        ev = getattr(self, "_presum_event", None)
+        if ev is not None and self._presum_cache[1].is_cuda and torch.cuda.current_stream() != self._presum_stream:
+            torch.cuda.current_stream().wait_event(ev)
+            self._presum_cache[1].record_stream(torch.cuda.current_stream())
 
     def _select(self, message):
         if message is None:
@@ -88,6 +105,9 @@ class NeRFNetwork(NeRFRenderer):
         if self._presum_cache is None or self._presum_cache[0] != key:
             S = self._presum_cache[1] if self._presum_cache is not None else None
             self._presum_cache = (key, fo.codebook_presum_sel(tables, message, out=S))
+            self._presum_produced()
+        else:
+            self._presum_consumed()
         return tables, self._presum_cache[1]
 
     def prepare_message(self, message):

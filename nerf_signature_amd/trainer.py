@@ -77,13 +77,15 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
     main = None
     if side_stream is not None and wm["rays_o_block"].is_cuda:
         main = torch.cuda.current_stream()
-        model.prepare_message(message)          # both renders read the pre-summed codebook: it must exist before the fork
         side_stream.wait_stream(main)
-    outputs = model.render(wm["rays_o_block"], wm["rays_d_block"], message, **kw)
-    if main is not None:
+        # Issued first: the content render's field pass finds no pre-summed codebook yet and computes it right behind its own
+        # march, on the side stream -- beside the block render's march, which does not need it; the block render's field pass
+        # then waits for that event only (network._presum_consumed).
         with torch.cuda.stream(side_stream):
             content_pred_rgb = model.render(content["rays_o"], content["rays_d"], message, **kw)["image"]
         content_pred_rgb.record_stream(main)
+    outputs = model.render(wm["rays_o_block"], wm["rays_d_block"], message, **kw)
+    if main is not None:
         fo.flush_plans()          # the block render's scatter plan: on the plan stream, behind the content render
     if model.normalization is normalize_img and hasattr(model.msg_decoder, "decode_rendered"):
         decoded, pred_rgb = model.msg_decoder.decode_rendered(outputs["image"])    # clamp + permute + normalise inside layer 0
@@ -356,7 +358,8 @@ class GraphedWatermarkLoop:
                 self._optimise()
         self.graphs = (g1, g2)
         self.capacity_rows = [(model.local_step - 2) % 16, (model.local_step - 1) % 16]
-        self.capacities = [cap(n_block), cap(n_content)]
+        # the counters are written in issue order: with a side stream train_step issues the content render first
+        self.capacities = [cap(n_block), cap(n_content)] if self.side_stream is None else [cap(n_content), cap(n_block)]
         return self
 
     def step(self, message, data=None):
