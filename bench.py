@@ -175,13 +175,16 @@ def main():
             optimizer.zero_grad(set_to_none=True)
             loop._forward_backward()
             loop.exchange(loop.sink.G)
-            loop._optimise()
+            loop._optimise_and_march()
         torch.cuda.synchronize()
         timer.enabled = False
 
-    n_block, n_content = int(model.step_counter[(model.local_step - 2) % 16, 0]), int(model.step_counter[(model.local_step - 1) % 16, 0])
-    if not args.no_overlap:      # counters are written in issue order: the overlapped step issues the content render first
-        n_block, n_content = n_content, n_block
+    if args.no_graph:
+        n_block, n_content = int(model.step_counter[(model.local_step - 2) % 16, 0]), int(model.step_counter[(model.local_step - 1) % 16, 0])
+        if not args.no_overlap:      # counters are written in issue order: the overlapped step issues the content render first
+            n_block, n_content = n_content, n_block
+    else:
+        n_block, n_content = loop.point_counts()
     rays_block, rays_content = bo.shape[0] * bo.shape[1] * bo.shape[2], args.rays
     rays_per_step = (rays_block + rays_content) * world
     # the dominant kernel: the hash-gather encoder, on the block render (the launch with the most points)

@@ -50,6 +50,13 @@ class _near_far_from_aabb(Function):
 near_far_from_aabb = _near_far_from_aabb.apply
 
 
+def near_far_into(rays_o, rays_d, aabb, min_near, nears, fars):
+    """near_far_from_aabb written into existing [N] float32 tensors (a step marched ahead re-uses its buffers)."""
+    N = rays_o.shape[0]
+    nv.call("rm_near_far_from_aabb", nv.ptr(rays_o), nv.ptr(rays_d), nv.ptr(_f32c(aabb)), N, float(min_near), nv.ptr(nears), nv.ptr(fars), nv.stream())
+    return nears, fars
+
+
 class _sph_from_ray(Function):
     """raymarching.py:52-78 -> rm_sph_from_ray."""
 
@@ -119,25 +126,30 @@ packbits = _packbits.apply
 # ----------------------------------------------------------------------------------------- training
 
 def march_rays_train_device(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, counter, noises, dt_gamma,
-                            max_steps, capacity=None):
+                            max_steps, capacity=None, out=None):
     """The three enqueues of the training march with no host synchronisation.
 
-    Returns (counts, t_rec, rays, write) where `write(M)` fills freshly allocated xyzs/dirs/deltas of M rows.
-    `counter` (int32[2]) receives (total points, N) on the device."""
+    Returns (counts, t_rec, rays, write) where `write(M)` fills xyzs/dirs/deltas of M rows -- freshly allocated, or the
+    tensors of `out` = (xyzs, dirs, deltas, rays) when given.  `counter` (int32[2]) receives (total points, N) on the device."""
     N = rays_o.shape[0]
     dev = rays_o.device
     counts = torch.empty(N, dtype=torch.int32, device=dev)
     t_rec = torch.empty(N * max_steps, dtype=torch.float32, device=dev)
-    rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+    rays = torch.empty(N, 3, dtype=torch.int32, device=dev) if out is None else out[3]
     s = nv.stream()
     nv.call("rm_march_train_count", nv.ptr(rays_o), nv.ptr(rays_d), nv.ptr(density_bitfield), float(bound), float(dt_gamma),
             int(max_steps), N, int(C), int(H), nv.ptr(nears), nv.ptr(fars), nv.ptr(noises), nv.ptr(counts), nv.ptr(t_rec), s)
     nv.call("rm_march_train_scan", nv.ptr(counts), N, nv.ptr(rays), nv.ptr(counter), s)
 
     def write(M):
-        xyzs = torch.empty(M, 3, dtype=torch.float32, device=dev)
-        dirs = torch.empty(M, 3, dtype=torch.float32, device=dev)
-        deltas = torch.empty(M, 2, dtype=torch.float32, device=dev)
+        if out is not None:
+            xyzs, dirs, deltas = out[:3]
+            if xyzs.shape[0] != M or rays.shape[0] != N:
+                raise ValueError(f"march buffers hold {xyzs.shape[0]} points / {rays.shape[0]} rays, the march needs {M} / {N}")
+        else:
+            xyzs = torch.empty(M, 3, dtype=torch.float32, device=dev)
+            dirs = torch.empty(M, 3, dtype=torch.float32, device=dev)
+            deltas = torch.empty(M, 2, dtype=torch.float32, device=dev)
         nv.call("rm_march_train_write", nv.ptr(rays_o), nv.ptr(rays_d), float(bound), float(dt_gamma), int(max_steps), N, int(C),
                 int(H), M, nv.ptr(nears), nv.ptr(noises), nv.ptr(t_rec), nv.ptr(rays), nv.ptr(counter), nv.ptr(xyzs),
                 nv.ptr(dirs), nv.ptr(deltas), nv.stream())
@@ -147,7 +159,7 @@ def march_rays_train_device(rays_o, rays_d, bound, density_bitfield, C, H, nears
 
 
 def march_rays_train_capacity(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter, capacity, perturb=False,
-                              dt_gamma=0, max_steps=1024):
+                              dt_gamma=0, max_steps=1024, out=None):
     """march_rays_train with force_all_rays semantics but NO host synchronisation: the point buffers have `capacity` rows
     (a caller-chosen bound on the padded point count); the real total lands in step_counter[0] on the device, rows past
     it are zero, and a ray that does not fit is dropped exactly like the reference's bounded mode (raymarching.cu:416) --
@@ -157,7 +169,7 @@ def march_rays_train_capacity(rays_o, rays_d, bound, density_bitfield, C, H, nea
     N = rays_o.shape[0]
     noises = torch.rand(N, dtype=torch.float32, device=rays_o.device) if perturb else None
     _, _, rays, write = march_rays_train_device(rays_o, rays_d, bound, density_bitfield, C, H, _f32c(nears), _f32c(fars), step_counter, noises,
-                                                dt_gamma, max_steps)
+                                                dt_gamma, max_steps, out=out)
     xyzs, dirs, deltas = write(int(capacity))
     return xyzs, dirs, deltas, rays
 

@@ -197,14 +197,60 @@ class NeRFRenderer(nn.Module):
 
     # ------------------------------------------------------------------ occupancy-grid path (renderer_wtmk.py:256-377)
 
+    # ------------------------------------------------------------------ samples marched ahead of their step
+
+    @staticmethod
+    def _rays_key(o, d):
+        return (o.data_ptr(), o._version, d.data_ptr(), d._version, o.shape[0])
+
+    def march_ahead(self, rays_o, rays_d, dt_gamma=0, max_steps=1024, perturb=False):
+        """March the training samples of these rays now, for a render issued later with the same (unmodified) ray tensors.
+
+        The march needs the rays and the occupancy grid only -- nothing a training step updates -- so a loop that knows its next
+        rays runs it beside the optimiser of the current step (an HBM stream that leaves the ALUs idle) instead of at the head of
+        the next one.  Needs `point_capacity` (the no-host-sync march); a repeated call for the same tensors re-marches into the
+        same buffers.  run_cuda picks the samples up by the tensors' addresses and versions; any in-place change of the rays after
+        the call makes it march again as usual."""
+        if not hasattr(self, "_marched"):
+            self._marched = {}
+        prefix, o, d = self._flatten_rays(rays_o, rays_d)
+        capacity = getattr(self, "point_capacity", None)
+        capacity = capacity.get(o.shape[0]) if capacity else None
+        if capacity is None or not o.is_cuda:
+            raise RuntimeError("march_ahead needs point_capacity for this ray count (see trainer.GraphedWatermarkLoop.prepare) and CUDA rays")
+        rec = next((r for r in self._marched.values() if r["ptrs"] == (o.data_ptr(), d.data_ptr(), o.shape[0]) and r["capacity"] == capacity), None)
+        if rec is None:
+            N, dev = o.shape[0], o.device
+            f32 = dict(dtype=torch.float32, device=dev)
+            rec = {"ptrs": (o.data_ptr(), d.data_ptr(), N), "capacity": capacity, "nears": torch.empty(N, **f32), "fars": torch.empty(N, **f32),
+                   "xyzs": torch.empty(capacity, 3, **f32), "dirs": torch.empty(capacity, 3, **f32), "deltas": torch.empty(capacity, 2, **f32),
+                   "rays": torch.empty(N, 3, dtype=torch.int32, device=dev), "counter": torch.zeros(2, dtype=torch.int32, device=dev), "key": None}
+        raymarching.near_far_into(o, d, self.aabb_train, self.min_near, rec["nears"], rec["fars"])
+        raymarching.march_rays_train_capacity(o, d, self.bound, self.density_bitfield, self.cascade, self.grid_size, rec["nears"], rec["fars"],
+                                              rec["counter"], capacity, perturb, dt_gamma, max_steps,
+                                              out=(rec["xyzs"], rec["dirs"], rec["deltas"], rec["rays"]))
+        self._marched = {k: r for k, r in self._marched.items() if r is not rec}
+        rec["key"] = self._rays_key(o, d)
+        self._marched[rec["key"]] = rec
+        return rec
+
+    def drop_marched(self):
+        self._marched = {}
+
     def run_cuda(self, rays_o, rays_d, message, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024,
                  T_thresh=1e-4, **kwargs):
         bg_color = self._background(bg_color)
         prefix, o, d = self._flatten_rays(rays_o, rays_d)
-        nears, fars = raymarching.near_far_from_aabb(o, d, self.aabb_train if self.training else self.aabb_infer, self.min_near)
+        marched = getattr(self, "_marched", None)
+        marched = marched.get(self._rays_key(o, d)) if marched and self.training and force_all_rays and not perturb else None
+        if marched is not None:
+            nears, fars = marched["nears"], marched["fars"]
+        else:
+            nears, fars = raymarching.near_far_from_aabb(o, d, self.aabb_train if self.training else self.aabb_infer, self.min_near)
         if self.training:
             bg = _background_tensor(bg_color, o) if o.is_cuda else None
-            out = self._march_and_composite_train(o, d, message, nears, fars, dt_gamma, perturb, force_all_rays, max_steps, T_thresh, finish=bg)
+            out = self._march_and_composite_train(o, d, message, nears, fars, dt_gamma, perturb, force_all_rays, max_steps, T_thresh, finish=bg,
+                                                  marched=marched)
             if bg is not None:   # the tail was done by the compositing launch
                 weights_sum, depth, image = out
                 return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "weights_sum": weights_sum}
@@ -217,8 +263,15 @@ class NeRFRenderer(nn.Module):
             results["weights_sum"] = weights_sum
         return results
 
-    def _march_and_composite_train(self, o, d, message, nears, fars, dt_gamma, perturb, force_all_rays, max_steps, T_thresh, finish=None):
+    def _march_and_composite_train(self, o, d, message, nears, fars, dt_gamma, perturb, force_all_rays, max_steps, T_thresh, finish=None,
+                                   marched=None):
         """All samples of all rays at once, then one differentiable composite (renderer_wtmk.py:280-321)."""
+        if marched is not None:      # the samples were marched ahead of this step (march_ahead)
+            sigmas, rgbs = self(marched["xyzs"], marched["dirs"], message)
+            sigmas = sigmas if self.density_scale == 1 else self.density_scale * sigmas
+            if finish is not None:
+                return _CompositeFinish.apply(sigmas, rgbs, marched["deltas"], marched["rays"], nears, fars, finish, T_thresh)
+            return raymarching.composite_rays_train(sigmas, rgbs, marched["deltas"], marched["rays"], T_thresh)
         counter = self.step_counter[self.local_step % 16]  # ring of the last 16 (points, rays) totals
         self.local_step += 1
         capacity = getattr(self, "point_capacity", None)

@@ -64,7 +64,7 @@ def backward_from_loss_kernel(out):
     torch.autograd.backward([content, decoded], seeds)
 
 
-def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce, side_stream=None):
+def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce, side_stream=None, presum_first=False):
     """data = {'watermark': {'rays_o_block', 'rays_d_block'}, 'content': {'rays_o', 'rays_d', 'images'}}.
     Returns (pred_rgb, gt_rgb, content_pred_rgb, lossi, lossw, loss) like the reference.
 
@@ -77,6 +77,8 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
     main = None
     if side_stream is not None and wm["rays_o_block"].is_cuda:
         main = torch.cuda.current_stream()
+        if presum_first:       # the block render's samples were marched ahead: nothing on the main stream to hide the pre-sum behind
+            model.prepare_message(message)
         side_stream.wait_stream(main)
         # Issued first: the content render's field pass finds no pre-summed codebook yet and computes it right behind its own
         # march, on the side stream -- beside the block render's march, which does not need it; the block render's field pass
@@ -209,7 +211,18 @@ class GraphedWatermarkLoop:
     points than that -- such a step dropped the rays that did not fit, like the reference's bounded mode."""
 
     def __init__(self, model, optimizer, render_kwargs, data, lambda_w=1.0, lambda_i=1.0, lr_lambda=None, headroom=0.0, native_dense_adam=True,
-                 overlap_content=True):
+                 overlap_content=True, march_ahead=None):
+        """march_ahead (default: with overlap_content): the block render's samples are marched at the end of the previous
+        replay, beside the optimiser (the march needs rays and occupancy grid only -- nothing a step updates -- and the
+        codebook Adam is an HBM stream that leaves the ALUs idle: 166 us together against 224 us one after the other,
+        tools/overlap_probe.py).  The block rays of the NEXT step therefore have to be in the static buffers when a replay
+        starts: pass the next step's data as `step(..., next_data=...)` (its content part is applied at that step);
+        `step(..., data=...)` still works -- it re-marches before the replay, un-overlapped.  The content render's march stays
+        at the head of its own step on the side stream: next to the optimiser as well, the two marches took longer than the
+        optimiser and the pre-sum lost its cover."""
+        self.march_ahead = overlap_content if march_ahead is None else bool(march_ahead)
+        self.marched = None
+        self._pending_content = None
         self.native_dense_adam = native_dense_adam
         self.side_stream = torch.cuda.Stream() if overlap_content else None
         self.plan_stream = self.side_stream   # scatter plans queue behind the content render (a third captured stream crashes hipStreamEndCapture on this runtime)
@@ -247,7 +260,8 @@ class GraphedWatermarkLoop:
         self.sink.zero_()
         prev = fo.set_plan_stream(self.plan_stream)    # the scatter plans need the sample positions only: beside the forward pass
         try:
-            out = train_step(self.model, self.data, self.msg_dev, self.render_kwargs, self.lambda_w, self.lambda_i, side_stream=self.side_stream)
+            out = train_step(self.model, self.data, self.msg_dev, self.render_kwargs, self.lambda_w, self.lambda_i, side_stream=self.side_stream,
+                             presum_first=self.marched is not None)
         finally:
             fo.set_plan_stream(prev)
         set_weights_stream(self.side_stream)     # the decoder's parameter gradients go there too: the block render's backward only waits for the image gradient
@@ -267,7 +281,36 @@ class GraphedWatermarkLoop:
         else:
             self.optimizer.step()
 
-    def _set_inputs(self, message, data):
+    def _march_ahead(self):
+        kw, wm, ct = self.render_kwargs, self.data["watermark"], self.data["content"]
+        args = (kw.get("dt_gamma", 0), kw.get("max_steps", 1024))
+        # the block render's march only: the content render's stays at the head of its step, on the side stream, where it
+        # overlaps the pre-sum and the block encoder (both marches next to the optimiser took longer than the optimiser)
+        self.marched = (self.model.march_ahead(wm["rays_o_block"], wm["rays_d_block"], *args),)
+
+    def _optimise_and_march(self):
+        """The optimiser step and, beside it on the side stream, the march of the next step's samples."""
+        if not self.march_ahead:
+            return self._optimise()
+        main = torch.cuda.current_stream()
+        if self.side_stream is not None:
+            self.side_stream.wait_stream(main)      # both backward passes of this step are done with the buffers
+            with torch.cuda.stream(self.side_stream):
+                self._march_ahead()
+        self._optimise()
+        if self.side_stream is not None:
+            main.wait_stream(self.side_stream)
+        else:
+            self._march_ahead()
+
+    def point_counts(self):
+        """(block, content) sample totals of the last step (one host read)."""
+        if self.marched is not None:      # the block render has its own counter, the content render the ring's latest row
+            return int(self.marched[0]["counter"][0]), int(self.model.step_counter[self.capacity_rows[-1], 0])
+        a, b = self.model.step_counter[self.capacity_rows, 0].tolist()
+        return (a, b) if self.side_stream is None else (b, a)     # issue order: with a side stream the content render comes first
+
+    def _set_inputs(self, message, data, next_data=None):
         slot = self.steps_done % len(self.msg_ring)
         if self.msg_events[slot] is not None:
             self.msg_events[slot].synchronize()      # blocks only if the GPU is a whole ring behind
@@ -278,10 +321,22 @@ class GraphedWatermarkLoop:
         self.msg_events[slot] = ev
         if self.lr_lambda is not None:
             self.lr_dev.fill_(self.base_lr * self.lr_lambda(self.steps_done))
+        if self._pending_content is not None:     # the content part that came with the block rays marched at the end of the last replay
+            for k, v in self._pending_content.items():
+                self.data["content"][k].copy_(v, non_blocking=True)
+            self._pending_content = None
         if data is not None:
             for part in ("watermark", "content"):
                 for k, v in data[part].items():
                     self.data[part][k].copy_(v, non_blocking=True)
+            if self.march_ahead and self.graphs is not None:
+                self._march_ahead()             # this step's rays arrived only now: march them before the replay
+        if next_data is not None:
+            if not self.march_ahead:
+                raise ValueError("next_data needs march_ahead=True")
+            for k, v in next_data["watermark"].items():     # nothing in the replay reads the block rays before its closing march
+                self.data["watermark"][k].copy_(v, non_blocking=True)
+            self._pending_content = next_data["content"]     # marched (and compared with its images) inside its own step
 
     @torch.no_grad()
     def _snapshot(self):
@@ -347,27 +402,36 @@ class GraphedWatermarkLoop:
         g1 = torch.cuda.CUDAGraph()
         # thread_local: with more than one rank the process group's watchdog thread queries events while we capture; only this
         # thread's calls belong to the capture
+        if self.march_ahead:
+            self._march_ahead()      # the first replay's samples (buffers outside the graph's pool, re-marched in place by every replay)
         with torch.cuda.graph(g1, capture_error_mode="thread_local"):
             self.out = self._forward_backward()
             if not split:
-                self._optimise()
+                self._optimise_and_march()
         g2 = None
         if split:
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
-                self._optimise()
+                self._optimise_and_march()
         self.graphs = (g1, g2)
         self.capacity_rows = [(model.local_step - 2) % 16, (model.local_step - 1) % 16]
         # the counters are written in issue order: with a side stream train_step issues the content render first
         self.capacities = [cap(n_block), cap(n_content)] if self.side_stream is None else [cap(n_content), cap(n_block)]
+        self.content_capacity = cap(n_content)
+        if self.marched is not None:        # only the content render used the ring during the capture
+            self.capacity_rows = [(model.local_step - 1) % 16]
         return self
 
-    def step(self, message, data=None):
-        """message: CPU float tensor of 0./1.; data: optional new rays/images with the same shapes.  Returns the static
-        output tuple of train_step (valid until the next step; values are ready when the stream reaches them)."""
+    def step(self, message, data=None, next_data=None):
+        """message: CPU float tensor of 0./1.; data: optional new rays/images of THIS step, next_data: of the next one (same
+        shapes; see march_ahead).  Returns the static output tuple of train_step (valid until the next step; values are ready
+        when the stream reaches them)."""
         if self.graphs is None:
+            if data is not None:
+                self._set_inputs(message, data)
+                data = None
             self.prepare(message)
-        self._set_inputs(message, data)
+        self._set_inputs(message, data, next_data)
         g1, g2 = self.graphs
         g1.replay()
         if g2 is not None:
@@ -378,5 +442,8 @@ class GraphedWatermarkLoop:
 
     def overflowed(self):
         """True if the last replay produced more points than the buffers hold (one host read of two counters)."""
+        if self.marched is not None:
+            return int(self.marched[0]["counter"][0]) > self.marched[0]["capacity"] or \
+                int(self.model.step_counter[self.capacity_rows[-1], 0]) > self.content_capacity
         totals = self.model.step_counter[self.capacity_rows, 0].tolist()
         return any(t > c for t, c in zip(totals, self.capacities))

@@ -71,7 +71,7 @@ def test_render_matches_reference_glue_golden():
     np.testing.assert_allclose(ev["depth"].cpu().numpy(), g["depth_eval"], rtol=0, atol=1e-3, equal_nan=True)
 
 
-def _data(n_content=512, seed=0, scene_bound=1.0, block=6):
+def _data(n_content=512, seed=0, scene_bound=1.0, block=6, shift=0):
     pose, intr, inds = cf.orbit_rays(n_content, seed=seed)
     o, d = fr.get_rays(torch.from_numpy(pose)[None], intr, 400, 400, torch.from_numpy(inds)[None])
     # D blocks of block x block pixels around the image centre (rays through the ball)
@@ -79,7 +79,7 @@ def _data(n_content=512, seed=0, scene_bound=1.0, block=6):
     full_o, full_d = full_o.view(400, 400, 3), full_d.view(400, 400, 3)
     bo, bd = [], []
     for k in range(32):
-        r, c = 150 + (k // 8) * 20, 130 + (k % 8) * 18
+        r, c = 150 + shift + (k // 8) * 20, 130 + shift + (k % 8) * 18
         bo.append(full_o[r:r + block, c:c + block])
         bd.append(full_d[r:r + block, c:c + block])
     gt = torch.from_numpy(np.random.RandomState(5).rand(1, n_content, 3).astype(np.float32))
@@ -234,6 +234,49 @@ def test_graphed_loop_matches_eager_loop():
     # (the decoder's conv biases sit in front of BatchNorms: their gradient is rounding noise, and Adam with eps=1e-15 turns
     #  noise into +-lr steps, so the parameter vectors agree only to a few per cent while the loss trajectories agree to 2e-3)
     assert float((d0 - d1).norm() / d0.norm()) < 0.05
+
+
+def test_graphed_loop_marches_ahead_with_changing_rays():
+    """march_ahead: the block render's samples are marched at the end of the previous replay.  With different rays and images
+    every step -- handed over one step early (`next_data`) or at the step itself (`data`, which re-marches before the replay) --
+    the loss trajectory equals the eager loop's."""
+    from nerf_signature_amd import trainer
+    from nerf_signature_amd.optim import CodebookAdam
+
+    def make(seed):
+        bo, bd, co, cd, gt = _data(n_content=300, seed=seed, shift=3 * seed)
+        return {"watermark": {"rays_o_block": bo.cuda(), "rays_d_block": bd.cuda()},
+                "content": {"rays_o": co.cuda(), "rays_d": cd.cuda(), "images": (gt * (0.4 + 0.15 * seed)).cuda()}}
+
+    datas = [make(s) for s in range(4)]
+    assert not torch.equal(datas[0]["watermark"]["rays_d_block"], datas[1]["watermark"]["rays_d_block"])
+    msgs = [torch.from_numpy(np.random.RandomState(10 + s).randint(0, 2, 32).astype(np.float32)) for s in range(4)]
+    kw = dict(dt_gamma=0, max_steps=1024)
+    runs = {}
+    for mode in ("eager", "next_data", "data"):
+        torch.manual_seed(0)
+        m, _, _ = _model()
+        opt = CodebookAdam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, capturable=mode != "eager")
+        if mode == "eager":
+            loop = trainer.WatermarkLoop(m, opt, kw)
+            runs[mode] = [[float(v.detach()) for v in loop.step(datas[k], msgs[k])[3:6]] for k in range(4)]
+            continue
+        loop = trainer.GraphedWatermarkLoop(m, opt, kw, datas[0], headroom=0.5)
+        assert loop.march_ahead
+        held = []
+        for k in range(4):
+            if mode == "next_data":
+                out = loop.step(msgs[k], next_data=datas[k + 1] if k + 1 < 4 else None)
+            else:
+                out = loop.step(msgs[k], data=datas[k])
+            held.append([v.detach().clone() for v in out[3:6]])
+        runs[mode] = [[float(v) for v in row] for row in held]
+        assert not loop.overflowed()
+        n_block, n_content = loop.point_counts()
+        assert n_block > 0 and n_content > 0
+    for mode in ("next_data", "data"):
+        np.testing.assert_allclose(runs[mode], runs["eager"], rtol=2e-3, atol=2e-4)
+    assert abs(runs["eager"][0][0] - runs["eager"][1][0]) > 1e-4          # the steps really saw different data
 
 
 def _oracle_and_model(D, bound, scene_seed=0):
