@@ -161,38 +161,42 @@ __global__ void __launch_bounds__(64) k_dec_pack(DecParams prm, uint4 *__restric
 // partials of the (possibly shorter) last pair are the contiguous tail and a group's size needs no division.
 constexpr int kPartMax = 24;   // float4 partials per thread held in registers: B*npair <= 8*kPartMax
 
-// 256 threads = 32 channel pairs x 8 groups; thread (cp, grp) holds partials i = grp + 8k of channels 2cp, 2cp+1.
+// kT threads = 32 channel pairs x kT/32 groups; thread (cp, grp) holds partials i = grp + (kT/32) k of channels 2cp, 2cp+1.
 struct Partials {
     float4 v[kPartMax];   // (a, b) of channel 2cp, (a, b) of channel 2cp + 1
 };
-template <int K0, int K1>
+template <int K0, int K1, int kT>
 __device__ inline void load_partial_range(const float4 *__restrict__ p4, uint32_t n, Partials &pv) {
     const uint32_t cp = threadIdx.x & 31, grp = threadIdx.x >> 5;
 #pragma unroll
-    for (int k = K0; k < K1; ++k) pv.v[k] = p4[min(grp + 8u * k, n - 1) * 32 + cp];   // clamped, not predicated: no branches between the loads
+    for (int k = K0; k < K1; ++k) pv.v[k] = p4[min(grp + (uint32_t)(kT / 32) * k, n - 1) * 32 + cp];   // clamped, not predicated: no branches between the loads
 }
 // Entries past the end hold a copy of the last partial; the combine functions mask them by index.
+template <int kT = 256>
 __device__ inline void load_partials(const float *__restrict__ part, uint32_t n, Partials &pv) {
+    constexpr int kHeld = kPartMax * 256 / kT;   // partials per thread: 24 with 8 groups, 12 with 16
     const float4 *__restrict__ p4 = reinterpret_cast<const float4 *>(part);
-    load_partial_range<0, kPartMax / 2>(p4, n, pv);
-    if (n > 8 * (kPartMax / 2)) {
-        load_partial_range<kPartMax / 2, kPartMax>(p4, n, pv);
+    load_partial_range<0, kHeld / 2, kT>(p4, n, pv);
+    if (n > (kT / 32) * (kHeld / 2)) {
+        load_partial_range<kHeld / 2, kHeld, kT>(p4, n, pv);
     } else {
 #pragma unroll
-        for (int k = kPartMax / 2; k < kPartMax; ++k) pv.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = kHeld / 2; k < kHeld; ++k) pv.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
 // Forward: partials (sum, M2 about the pair mean) -> batch mean and 1/sqrt(var + eps): two passes over the registers,
-// M2 = sum_i M2_i + n_i (mean_i - mean)^2 (no E[x^2] - E[x]^2 cancellation, no divisions).  red: 512 floats.
+// M2 = sum_i M2_i + n_i (mean_i - mean)^2 (no E[x^2] - E[x]^2 cancellation, no divisions).  red: 64 * kT/32 floats.
+template <int kT = 256>
 __device__ inline void combine_fwd_stats(const Partials &pv, const DecGeom &g, float *red, float *s_mean, float *s_inv) {
+    constexpr int kG = kT / 32, kHeld = kPartMax * 256 / kT;
     const uint32_t cp = threadIdx.x & 31, grp = threadIdx.x >> 5, c = threadIdx.x & 63;
     const uint32_t n = g.B * g.npair, last0 = (g.npair - 1) * g.B;
     const float N = (float)(g.B * g.P), n_last = (float)pair_count(g.npair - 1, g.P), rn_last = 1.0f / n_last;
     float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
-    for (int k = 0; k < kPartMax; ++k) {
-        const bool in = grp + 8u * k < n;
+    for (int k = 0; k < kHeld; ++k) {
+        const bool in = grp + (uint32_t)kG * k < n;
         s0 += in ? pv.v[k].x : 0.0f;
         s1 += in ? pv.v[k].z : 0.0f;
     }
@@ -201,7 +205,7 @@ __device__ inline void combine_fwd_stats(const Partials &pv, const DecGeom &g, f
     __syncthreads();
     float tot = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) tot += red[k * 64 + c];
+    for (int k = 0; k < kG; ++k) tot += red[k * 64 + c];
     __syncthreads();
     if (threadIdx.x < 64) red[c] = tot / N;   // the batch mean of channel c
     __syncthreads();
@@ -209,8 +213,8 @@ __device__ inline void combine_fwd_stats(const Partials &pv, const DecGeom &g, f
     __syncthreads();
     float q0 = 0.0f, q1 = 0.0f;
 #pragma unroll
-    for (int k = 0; k < kPartMax; ++k) {
-        const uint32_t i = grp + 8 * k;
+    for (int k = 0; k < kHeld; ++k) {
+        const uint32_t i = grp + kG * k;
         const bool last = i >= last0;
         const float ni = last ? n_last : 64.0f, rni = last ? rn_last : 1.0f / 64.0f;
         const float d0 = pv.v[k].x - ni * m0, d1 = pv.v[k].z - ni * m1;     // n_i * (mean_i - mean)
@@ -225,21 +229,23 @@ __device__ inline void combine_fwd_stats(const Partials &pv, const DecGeom &g, f
     if (threadIdx.x < 64) {
         float M2 = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) M2 += red[k * 64 + c];
+        for (int k = 0; k < kG; ++k) M2 += red[k * 64 + c];
         s_inv[c] = 1.0f / sqrtf(M2 / N + g.eps);
     }
     __syncthreads();
 }
 
-// Backward: k = gamma*inv/N, S1 = sum dz, S2 = sum dz*xhat over the batch.  red: 1024 floats; tab: [3][64].
+// Backward: k = gamma*inv/N, S1 = sum dz, S2 = sum dz*xhat over the batch.  red: 2 * 64 * kT/32 floats; tab: [3][64].
+template <int kT = 256>
 __device__ inline void combine_bwd_sums(const Partials &pv, const float *__restrict__ gamma, const float *__restrict__ minv, const DecGeom &g,
                                         float *red, float *tab) {
+    constexpr int kG = kT / 32, kHeld = kPartMax * 256 / kT;
     const uint32_t cp = threadIdx.x & 31, grp = threadIdx.x >> 5, c = threadIdx.x & 63;
     const uint32_t n = g.B * g.npair;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int k = 0; k < kPartMax; ++k) {
-        const bool in = grp + 8u * k < n;
+    for (int k = 0; k < kHeld; ++k) {
+        const bool in = grp + (uint32_t)kG * k < n;
         s.x += in ? pv.v[k].x : 0.0f;
         s.y += in ? pv.v[k].y : 0.0f;
         s.z += in ? pv.v[k].z : 0.0f;
@@ -247,15 +253,15 @@ __device__ inline void combine_bwd_sums(const Partials &pv, const float *__restr
     }
     red[grp * 64 + 2 * cp] = s.x;
     red[grp * 64 + 2 * cp + 1] = s.z;
-    red[512 + grp * 64 + 2 * cp] = s.y;
-    red[512 + grp * 64 + 2 * cp + 1] = s.w;
+    red[64 * kG + grp * 64 + 2 * cp] = s.y;
+    red[64 * kG + grp * 64 + 2 * cp + 1] = s.w;
     __syncthreads();
     if (threadIdx.x < 64) {
         float S1 = 0.0f, S2 = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < kG; ++k) {
             S1 += red[k * 64 + c];
-            S2 += red[512 + k * 64 + c];
+            S2 += red[64 * kG + k * 64 + c];
         }
         tab[c] = gamma[c] * minv[64 + c] / (float)(g.B * g.P);
         tab[64 + c] = S1;
@@ -403,22 +409,22 @@ constexpr int kBatch = 4;   // prologue items whose loads are in flight together
 
 // Forward prologue shared by the MFMA layers (bf16 hi/lo planes) and layer 8 (fp32 rows): stage GELU(BN(x_prev)) for every
 // position the pair touches; the owner of a pixel also records xhat, GELU' and a for the backward pass.
-template <bool kF32>
+template <bool kF32, int kT = 256>
 __device__ inline void stage_forward(const float *__restrict__ x, float *__restrict__ xhat, float *__restrict__ gprime, float *__restrict__ act,
                                      uint32_t im, const PairRows &pr, const DecGeom &g, const float *tab, char *lds_hi, char *lds_lo, float *lds_f32, uint32_t first = 0, bool record = true) {
     const uint32_t W2 = g.W + 2, total = pr.nrow * W2 * 16;
-    for (uint32_t base = first + threadIdx.x; base < total; base += 256 * kBatch) {
+    for (uint32_t base = first + threadIdx.x; base < total; base += kT * kBatch) {
         float4 xv[kBatch];
         int q[kBatch];
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
-            const uint32_t i = base + 256 * u;
+            const uint32_t i = base + kT * u;
             q[u] = i < total ? staged_pixel(i >> 4, W2, pr.py0, g) : -1;
             xv[u] = q[u] >= 0 ? *reinterpret_cast<const float4 *>(x + ((size_t)im * g.P + q[u]) * kC + (i & 15) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
-            const uint32_t i = base + 256 * u, pos = i >> 4, cg = i & 15;
+            const uint32_t i = base + kT * u, pos = i >> 4, cg = i & 15;
             if (i >= total) break;
             float xh[4], a[4] = {0.f, 0.f, 0.f, 0.f}, gp[4];
             if (q[u] >= 0) {
@@ -439,16 +445,17 @@ __device__ inline void stage_forward(const float *__restrict__ x, float *__restr
 }
 
 // Backward prologue: stage dx = BN-backward(dz) for every position the pair touches.
+template <int kT = 256>
 __device__ inline void stage_backward(const float *__restrict__ dz, const float *__restrict__ xhat, uint32_t im, const PairRows &pr, const DecGeom &g,
                                       const float *tab, char *lds_hi, char *lds_lo, uint32_t first = 0) {
     const uint32_t W2 = g.W + 2, total = pr.nrow * W2 * 16;
     const float N = (float)(g.B * g.P);
-    for (uint32_t base = first + threadIdx.x; base < total; base += 256 * kBatch) {
+    for (uint32_t base = first + threadIdx.x; base < total; base += kT * kBatch) {
         float4 dv[kBatch], hv[kBatch];
         int q[kBatch];
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
-            const uint32_t i = base + 256 * u;
+            const uint32_t i = base + kT * u;
             q[u] = i < total ? staged_pixel(i >> 4, W2, pr.py0, g) : -1;
             const size_t e = ((size_t)im * g.P + (q[u] >= 0 ? q[u] : 0)) * kC + (i & 15) * 4;
             dv[u] = q[u] >= 0 ? *reinterpret_cast<const float4 *>(dz + e) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -456,7 +463,7 @@ __device__ inline void stage_backward(const float *__restrict__ dz, const float 
         }
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
-            const uint32_t i = base + 256 * u;
+            const uint32_t i = base + kT * u;
             if (i >= total) break;
             const float4 d = q[u] >= 0 ? bn_bwd4(dv[u], hv[u], i & 15, tab, N) : make_float4(0.f, 0.f, 0.f, 0.f);
             const float v[4] = {d.x, d.y, d.z, d.w};
@@ -549,8 +556,8 @@ __device__ inline float2 tile_channel_sums(const float (&va)[16], const float (&
 //   kDgradImg (layer 0)   : consumes dz[0], xhat[0], bsum[0]; writes the gradient of the input image [B][Cin][H][W]  (grid z = 1).
 // Order of global requests (loads return in order): batch partials, the prologue inputs, then the A fragments -- which land
 // while the statistics are combined and the prologue computes.
-template <int MODE>
-__global__ void __launch_bounds__(256) k_dec_conv(int layer, DecParams prm, DecWs ws, DecGeom g, float *__restrict__ grad_img,
+template <int MODE, int kT>
+__global__ void __launch_bounds__(kT) k_dec_conv(int layer, DecParams prm, DecWs ws, DecGeom g, float *__restrict__ grad_img,
                                                   const float *__restrict__ img, DecInput inp) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const uint32_t pair = blockIdx.x, im = blockIdx.y, rb = blockIdx.z, t = threadIdx.x;
@@ -565,38 +572,46 @@ __global__ void __launch_bounds__(256) k_dec_conv(int layer, DecParams prm, DecW
     float *s_ref = s_acc + 2 * 16 * 64;                               // [2 tiles][32]
     const float N = (float)(g.B * g.P);
 
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, tp = wave & 1, kh = wave >> 1, p = lane & 31, h = lane >> 5;
+    // kT = 512: waves 4..7 are helpers -- they take half of the request, statistics and prologue work (the longest phases,
+    // all per-thread element counts), then only keep the barriers company
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, tp = wave & 1, kh = (wave >> 1) & 1, p = lane & 31, h = lane >> 5;
+    const bool mfma_wave = wave < 4;
     const uint32_t tile = 2 * pair + tp;
-    const bool active = tile < g.ntile;
+    const bool active = mfma_wave && tile < g.ntile;
     const int set = MODE == kFwd ? (layer - 1) * 2 : (MODE == kDgrad ? (layer - 1) * 2 + 1 : 14);
     const uint32_t img_off = im * g.P * kC;   // element offsets fit 32 bits (checked by make_geom)
     DEC_STAMP(0);
 
     // ---- requests
     Partials pv;
-    load_partials(MODE == kFwd ? ws.stat[layer - 1] : ws.bsum[layer], g.B * g.npair, pv);
+    load_partials<kT>(MODE == kFwd ? ws.stat[layer - 1] : ws.bsum[layer], g.B * g.npair, pv);
     DEC_STAMP(7);
     const float *__restrict__ in0 = MODE == kFwd ? ws.x[layer - 1] : ws.dz[layer];
     const float *__restrict__ in1 = ws.xhat[layer];   // backward only
-    constexpr int kPre = 8;
+    constexpr int kPre = 2048 / kT;
     float4 v0[kPre], v1[kPre];
     int q[kPre];
 #pragma unroll
     for (int u = 0; u < kPre; ++u) {
-        const uint32_t i = t + 256 * u;
+        const uint32_t i = t + kT * u;
         q[u] = i < total ? staged_pixel(i >> 4, W2, pr.py0, g) : -1;
         const uint32_t e = img_off + (q[u] >= 0 ? q[u] : 0) * kC + (i & 15) * 4;
         v0[u] = q[u] >= 0 ? *reinterpret_cast<const float4 *>(in0 + e) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (MODE != kFwd) v1[u] = q[u] >= 0 ? *reinterpret_cast<const float4 *>(in1 + e) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     DEC_STAMP(8);
+    // (forward with helper waves: the fragments are requested after the statistics instead -- partials, prologue inputs and 144
+    // fragment registers together exceed the 256 registers a wave of a 512-thread workgroup gets, and the spills stalled the
+    // request stream by 2 us; the prologue that follows still covers the fragments' flight)
+    constexpr bool kLateFrags = kT == 512 && MODE == kFwd;
     AFrags af;
-    if (active) load_afrags(ws.packed + (size_t)set * kSetU4 + ((size_t)rb * kKS + kh * kKH) * 128, lane, af);
+    const uint4 *afrag_src = ws.packed + (size_t)set * kSetU4 + ((size_t)rb * kKS + kh * kKH) * 128;
+    if (!kLateFrags && active) load_afrags(afrag_src, lane, af);
     DEC_STAMP(1);
 
     // ---- batch statistics -> per-channel constants
     if (MODE == kFwd) {
-        combine_fwd_stats(pv, g, s_red, s_tab, s_tab + 64);
+        combine_fwd_stats<kT>(pv, g, s_red, s_tab, s_tab + 64);
         if (t < 64) {
             s_tab[128 + t] = prm.gamma[layer - 1][t];
             s_tab[192 + t] = prm.beta[layer - 1][t];
@@ -606,15 +621,16 @@ __global__ void __launch_bounds__(256) k_dec_conv(int layer, DecParams prm, DecW
             }
         }
         __syncthreads();
+        if (kLateFrags && active) load_afrags(afrag_src, lane, af);
     } else {
-        combine_bwd_sums(pv, prm.gamma[layer], ws.minv[layer], g, s_red, s_tab);
+        combine_bwd_sums<kT>(pv, prm.gamma[layer], ws.minv[layer], g, kT == 256 ? s_red : s_scr, s_tab);   // (s_scr: 4224 floats, idle until the epilogue)
     }
     DEC_STAMP(2);
 
     // ---- prologue: the B operand of every position this pair touches, halo included
 #pragma unroll
     for (int u = 0; u < kPre; ++u) {
-        const uint32_t i = t + 256 * u, pos = i >> 4, cg = i & 15;
+        const uint32_t i = t + kT * u, pos = i >> 4, cg = i & 15;
         if (i >= total) break;
         float a[4] = {0.f, 0.f, 0.f, 0.f};
         if (q[u] >= 0) {
@@ -634,11 +650,11 @@ __global__ void __launch_bounds__(256) k_dec_conv(int layer, DecParams prm, DecW
         }
         split4_to_lds(lds_hi, lds_lo, pos, cg, a);
     }
-    if (total > 256 * kPre) {   // pairs that stage more than the preloaded batch: the rest, batched
+    if (total > kT * kPre) {   // pairs that stage more than the preloaded batch: the rest, batched
         if (MODE == kFwd)
-            stage_forward<false>(ws.x[layer - 1], ws.xhat[layer - 1], ws.gprime[layer - 1], ws.act[layer - 1], im, pr, g, s_tab, lds_hi, lds_lo, nullptr, 256 * kPre, rb == 0);
+            stage_forward<false, kT>(ws.x[layer - 1], ws.xhat[layer - 1], ws.gprime[layer - 1], ws.act[layer - 1], im, pr, g, s_tab, lds_hi, lds_lo, nullptr, kT * kPre, rb == 0);
         else
-            stage_backward(ws.dz[layer], ws.xhat[layer], im, pr, g, s_tab, lds_hi, lds_lo, 256 * kPre);
+            stage_backward<kT>(ws.dz[layer], ws.xhat[layer], im, pr, g, s_tab, lds_hi, lds_lo, kT * kPre);
     }
     DEC_STAMP(3);
 
@@ -648,7 +664,7 @@ __global__ void __launch_bounds__(256) k_dec_conv(int layer, DecParams prm, DecW
     const uint32_t qq = valid ? qo : pr.q0, py = qq / g.W, px = qq - py * g.W;
     const uint32_t eo = img_off + qq * kC + 32 * rb + 4 * h;
     float4 gp4[4], xh4[4];
-    if (MODE == kDgrad && kh == 0) {   // epilogue operands, requested before the MFMA loop
+    if (MODE == kDgrad && mfma_wave && kh == 0) {   // epilogue operands, requested before the MFMA loop
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             gp4[g4] = valid ? *reinterpret_cast<const float4 *>(ws.gprime[layer - 1] + eo + 8 * g4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -659,11 +675,11 @@ __global__ void __launch_bounds__(256) k_dec_conv(int layer, DecParams prm, DecW
     DEC_STAMP(4);
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (active) acc = conv_half(af, lds_hi, lds_lo, (py - pr.py0) * W2 + px, W2, lane, kh * kKH);
-    if (kh == 1)
+    if (mfma_wave && kh == 1)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s_acc[(tp * 16 + r) * 64 + lane] = acc[r];
     __syncthreads();
-    if (kh == 0)
+    if (mfma_wave && kh == 0)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] += s_acc[(tp * 16 + r) * 64 + lane];
 #ifdef NSIG_DEC_TIMING
@@ -674,7 +690,7 @@ __global__ void __launch_bounds__(256) k_dec_conv(int layer, DecParams prm, DecW
     // ---- epilogue (waves kh == 0 hold the tiles; the others only keep the barriers company)
     float *scr = s_scr + tp * (2 * 32 * 33), *s_ep = s_red;   // s_ep: [2 tiles][32 channels][2]
     if (MODE == kFwd) {
-        if (kh == 0) {
+        if (mfma_wave && kh == 0) {
             if (valid) {
                 float *xo = ws.x[layer] + eo;
 #pragma unroll
@@ -708,7 +724,7 @@ __global__ void __launch_bounds__(256) k_dec_conv(int layer, DecParams prm, DecW
         }
         DEC_STAMP(6);
     } else if (MODE == kDgrad) {
-        if (kh == 0) {
+        if (mfma_wave && kh == 0) {
             float dzv[16], dzx[16];
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -735,7 +751,7 @@ __global__ void __launch_bounds__(256) k_dec_conv(int layer, DecParams prm, DecW
         DEC_STAMP(6);
     } else {
         // rows = input channels c = 8*g4 + 4*h + j < Cin
-        if (kh == 0 && valid)
+        if (mfma_wave && kh == 0 && valid)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint32_t c = 8 * (r >> 2) + 4 * h + (r & 3);
@@ -1377,10 +1393,30 @@ static int allow_lds(K kernel, size_t bytes, size_t &allowed) {
     return 0;
 }
 static int allow_all_lds(const DecGeom &g) {
-    static size_t a[6] = {0, 0, 0, 0, 0, 0};
-    return allow_lds(k_dec_conv<kFwd>, conv_lds(g), a[0]) | allow_lds(k_dec_conv<kDgrad>, conv_lds(g), a[1]) |
-           allow_lds(k_dec_conv<kDgradImg>, conv_lds(g), a[2]) | allow_lds(k_dec_l8_fwd, l8_lds(g), a[3]) |
-           allow_lds(k_dec_l8_bwd, l8b_lds(g), a[4]) | allow_lds(k_dec_wgrad, wgrad_lds(g), a[5]);
+    static size_t a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    return allow_lds(k_dec_conv<kFwd, 256>, conv_lds(g), a[0]) | allow_lds(k_dec_conv<kDgrad, 256>, conv_lds(g), a[1]) |
+           allow_lds(k_dec_conv<kDgradImg, 256>, conv_lds(g), a[2]) | allow_lds(k_dec_l8_fwd, l8_lds(g), a[3]) |
+           allow_lds(k_dec_l8_bwd, l8b_lds(g), a[4]) | allow_lds(k_dec_wgrad, wgrad_lds(g), a[5]) |
+           allow_lds(k_dec_conv<kFwd, 512>, conv_lds(g), a[6]) | allow_lds(k_dec_conv<kDgrad, 512>, conv_lds(g), a[7]) |
+           allow_lds(k_dec_conv<kDgradImg, 512>, conv_lds(g), a[8]);
+}
+
+// Threads per conv workgroup: 512 = four MFMA waves + four helper waves for the request / statistics / prologue phases
+// (NERFSIG_DEC_THREADS=256 selects the four-wave form; experiments).
+static int conv_threads() {
+    static const int n = [] {
+        const char *e = getenv("NERFSIG_DEC_THREADS");
+        return e && atoi(e) == 256 ? 256 : 512;
+    }();
+    return n;
+}
+template <int MODE>
+static void launch_conv(dim3 grid, size_t lds, hipStream_t s, int layer, const DecParams &prm, const DecWs &ws, const DecGeom &g, float *grad_img,
+                        const float *img, const DecInput &inp) {
+    if (conv_threads() == 512)
+        k_dec_conv<MODE, 512><<<grid, 512, lds, s>>>(layer, prm, ws, g, grad_img, img, inp);
+    else
+        k_dec_conv<MODE, 256><<<grid, 256, lds, s>>>(layer, prm, ws, g, grad_img, img, inp);
 }
 
 }  // namespace nsig
@@ -1435,7 +1471,7 @@ NSIG_EXPORT int dec_forward(const float *img, uint32_t input_mode, const float *
         k_dec_l0_fwd<3><<<grid, 256, l0_lds(g), s>>>(img, inp, clamped_out, prm, ws, g);
     else
         k_dec_l0_fwd<0><<<grid, 256, l0_lds(g), s>>>(img, inp, clamped_out, prm, ws, g);
-    for (int l = 1; l <= 7; ++l) k_dec_conv<kFwd><<<dim3(g.npair, B, 2), 256, conv_lds(g), s>>>(l, prm, ws, g, nullptr, nullptr, inp);
+    for (int l = 1; l <= 7; ++l) launch_conv<kFwd>(dim3(g.npair, B, 2), conv_lds(g), s, l, prm, ws, g, nullptr, nullptr, inp);
     k_dec_l8_fwd<<<grid, 256, l8_lds(g), s>>>(prm, ws, g);
     k_dec_head_fwd<<<B, 256, 0, s>>>(prm, ws, g, decoded);
     return check_launch("dec_forward");
@@ -1469,8 +1505,8 @@ NSIG_EXPORT int dec_backward(const float *grad_decoded, const float *img, uint32
     const dim3 grid(g.npair, B);
     k_dec_head_bwd<<<B, 256, 0, s>>>(grad_decoded, prm, ws, g);
     k_dec_l8_bwd<<<grid, 256, l8b_lds(g), s>>>(prm, ws, g);
-    for (int l = 7; l >= 1; --l) k_dec_conv<kDgrad><<<dim3(g.npair, B, 2), 256, conv_lds(g), s>>>(l, prm, ws, g, nullptr, nullptr, inp);
-    k_dec_conv<kDgradImg><<<grid, 256, conv_lds(g), s>>>(0, prm, ws, g, grad_img, img, inp);
+    for (int l = 7; l >= 1; --l) launch_conv<kDgrad>(dim3(g.npair, B, 2), conv_lds(g), s, l, prm, ws, g, nullptr, nullptr, inp);
+    launch_conv<kDgradImg>(grid, conv_lds(g), s, 0, prm, ws, g, grad_img, img, inp);
     // The parameter gradients are not needed before the optimiser; what waits on this function is the image gradient (the block
     // render's backward).  On request they are queued on a second stream, ordered after the data-gradient chain by an event.
     hipStream_t sw = as_stream(weights_stream);
