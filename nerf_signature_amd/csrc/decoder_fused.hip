@@ -474,26 +474,29 @@ __device__ inline void stage_backward(const float *__restrict__ dz, const float 
 
 // ----------------------------------------------------------------------------- the 64 -> 64 conv kernel (forward / dgrad)
 
-constexpr int kKH = kKS / 2;   // k-steps per wave: the 36 k-steps of a unit are split over two waves
-
+// k-steps per wave: the 36 k-steps of a (rb, tile) unit are split over the waves that share the tile -- two in a 256-thread
+// workgroup (18 each), four in a 512-thread one (9 each)
+template <int K>
 struct AFrags {
-    uint4 hi[kKH], lo[kKH];   // 144 VGPRs: the A operand of one (rb, tile, k-half), requested up front
+    uint4 hi[K], lo[K];   // the A operand of one (rb, tile, k-part), requested up front (8 VGPRs per k-step)
 };
-__device__ inline void load_afrags(const uint4 *__restrict__ A, int lane, AFrags &f) {
+template <int K>
+__device__ inline void load_afrags(const uint4 *__restrict__ A, int lane, AFrags<K> &f) {
 #pragma unroll
-    for (int ks = 0; ks < kKH; ++ks) {
+    for (int ks = 0; ks < K; ++ks) {
         f.hi[ks] = A[ks * 128 + lane];
         f.lo[ks] = A[ks * 128 + 64 + lane];
     }
 }
 
-// Half of a (rb, tile) unit: acc[32 rows x 32 pixels] += 18 k-steps starting at ks0 (wave-uniform); B fragments are 16-byte
+// One k-part of a (rb, tile) unit: acc[32 rows x 32 pixels] += K k-steps starting at ks0 (wave-uniform); B fragments are 16-byte
 // LDS reads of the lane's pixel at the tap's offset.
-__device__ inline f32x16 conv_half(AFrags &f, const char *lds_hi, const char *lds_lo, uint32_t hp0, uint32_t W2, int lane, int ks0) {
+template <int K>
+__device__ inline f32x16 conv_part(AFrags<K> &f, const char *lds_hi, const char *lds_lo, uint32_t hp0, uint32_t W2, int lane, int ks0) {
     f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int h = lane >> 5;
 #pragma unroll
-    for (int ks = 0; ks < kKH; ++ks) {
+    for (int ks = 0; ks < K; ++ks) {
         const int kg = ks0 + ks, tap = kg >> 2, c4 = kg & 3, ty = tap / 3, tx = tap - 3 * ty;   // scalar
         const uint32_t off = (hp0 + ty * W2 + tx) * kPitch + (16 * c4 + 8 * h) * 2;
         const bf16x8 b_hi = *reinterpret_cast<const bf16x8 *>(lds_hi + off);
@@ -547,10 +550,11 @@ __device__ inline float2 tile_channel_sums(const float (&va)[16], const float (&
     return make_float2(sa, sb);
 }
 
-// grid (npair, B, 2 row blocks), 256 threads.  A workgroup owns 32 output rows (rb = blockIdx.z) of one tile pair; its four
-// waves are (tile of the pair) x (k-half), so every wave streams only 36 A fragments and reads 36 B fragments, and the two
-// k-halves of a tile meet through LDS.  All four waves build the B operand (the prologue is the longest phase); the rb = 1
-// workgroup repeats that staging on another CU -- the chip has more CUs (256) than this layer has tile pairs (96).
+// grid (npair, B, 2 row blocks), kT threads.  A workgroup owns 32 output rows (rb = blockIdx.z) of one tile pair; its waves are
+// (tile of the pair) x (k-part) -- k-halves with 256 threads, k-quarters with 512 -- so every wave streams only its share of the
+// 72 A fragments, and the k-parts of a tile meet through LDS.  All waves build the B operand (the prologue is the longest phase:
+// that, not the MFMA count, is why the workgroup has eight waves); the rb = 1 workgroup repeats that staging on another CU -- the
+// chip has more CUs (256) than this layer has tile pairs (96).
 //   kFwd      (layer 1..7): consumes x[l-1], stat[l-1]; writes xhat/gprime/act[l-1] (own pixels, rb 0), minv[l-1], x[l], stat[l].
 //   kDgrad    (layer 7..1): consumes dz[l], xhat[l], bsum[l]; writes dz[l-1], bsum[l-1].
 //   kDgradImg (layer 0)   : consumes dz[0], xhat[0], bsum[0]; writes the gradient of the input image [B][Cin][H][W]  (grid z = 1).
@@ -568,16 +572,16 @@ __global__ void __launch_bounds__(kT) k_dec_conv(int layer, DecParams prm, DecWs
     float *s_tab = reinterpret_cast<float *>(smem_raw + 2 * plane);   // [4][64] per-channel constants
     float *s_red = s_tab + 4 * 64;                                    // [1024] scratch
     float *s_scr = s_red + 1024;                                      // [2 tiles][2*32*33] epilogue transposes
-    float *s_acc = s_scr + 2 * (2 * 32 * 33);                         // [2 tiles][16][64] k-half exchange
-    float *s_ref = s_acc + 2 * 16 * 64;                               // [2 tiles][32]
+    float *s_acc = s_scr + 2 * (2 * 32 * 33);                         // [2 tiles][3][16][64] k-part exchange
+    float *s_ref = s_acc + 2 * 3 * 16 * 64;                           // [2 tiles][32]
     const float N = (float)(g.B * g.P);
 
-    // kT = 512: waves 4..7 are helpers -- they take half of the request, statistics and prologue work (the longest phases,
-    // all per-thread element counts), then only keep the barriers company
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, tp = wave & 1, kh = (wave >> 1) & 1, p = lane & 31, h = lane >> 5;
-    const bool mfma_wave = wave < 4;
+    // waves = (tile of the pair) x (k-part): kT / 128 waves share a tile; the one with kp == 0 owns its epilogue.  The request,
+    // statistics and prologue phases -- the longest ones, all per-thread element counts -- are spread over every thread.
+    constexpr int kParts = kT / 128, kK = kKS / kParts;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, tp = wave & 1, kp = wave >> 1, p = lane & 31, h = lane >> 5;
     const uint32_t tile = 2 * pair + tp;
-    const bool active = mfma_wave && tile < g.ntile;
+    const bool active = tile < g.ntile;
     const int set = MODE == kFwd ? (layer - 1) * 2 : (MODE == kDgrad ? (layer - 1) * 2 + 1 : 14);
     const uint32_t img_off = im * g.P * kC;   // element offsets fit 32 bits (checked by make_geom)
     DEC_STAMP(0);
@@ -600,13 +604,8 @@ __global__ void __launch_bounds__(kT) k_dec_conv(int layer, DecParams prm, DecWs
         if (MODE != kFwd) v1[u] = q[u] >= 0 ? *reinterpret_cast<const float4 *>(in1 + e) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     DEC_STAMP(8);
-    // (forward with helper waves: the fragments are requested after the statistics instead -- partials, prologue inputs and 144
-    // fragment registers together exceed the 256 registers a wave of a 512-thread workgroup gets, and the spills stalled the
-    // request stream by 2 us; the prologue that follows still covers the fragments' flight)
-    constexpr bool kLateFrags = kT == 512 && MODE == kFwd;
-    AFrags af;
-    const uint4 *afrag_src = ws.packed + (size_t)set * kSetU4 + ((size_t)rb * kKS + kh * kKH) * 128;
-    if (!kLateFrags && active) load_afrags(afrag_src, lane, af);
+    AFrags<kK> af;
+    if (active) load_afrags(ws.packed + (size_t)set * kSetU4 + ((size_t)rb * kKS + kp * kK) * 128, lane, af);
     DEC_STAMP(1);
 
     // ---- batch statistics -> per-channel constants
@@ -621,7 +620,6 @@ __global__ void __launch_bounds__(kT) k_dec_conv(int layer, DecParams prm, DecWs
             }
         }
         __syncthreads();
-        if (kLateFrags && active) load_afrags(afrag_src, lane, af);
     } else {
         combine_bwd_sums<kT>(pv, prm.gamma[layer], ws.minv[layer], g, kT == 256 ? s_red : s_scr, s_tab);   // (s_scr: 4224 floats, idle until the epilogue)
     }
@@ -664,7 +662,7 @@ __global__ void __launch_bounds__(kT) k_dec_conv(int layer, DecParams prm, DecWs
     const uint32_t qq = valid ? qo : pr.q0, py = qq / g.W, px = qq - py * g.W;
     const uint32_t eo = img_off + qq * kC + 32 * rb + 4 * h;
     float4 gp4[4], xh4[4];
-    if (MODE == kDgrad && mfma_wave && kh == 0) {   // epilogue operands, requested before the MFMA loop
+    if (MODE == kDgrad && kp == 0) {   // epilogue operands, requested before the MFMA loop
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             gp4[g4] = valid ? *reinterpret_cast<const float4 *>(ws.gprime[layer - 1] + eo + 8 * g4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -674,23 +672,25 @@ __global__ void __launch_bounds__(kT) k_dec_conv(int layer, DecParams prm, DecWs
     __syncthreads();
     DEC_STAMP(4);
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (active) acc = conv_half(af, lds_hi, lds_lo, (py - pr.py0) * W2 + px, W2, lane, kh * kKH);
-    if (mfma_wave && kh == 1)
+    if (active) acc = conv_part(af, lds_hi, lds_lo, (py - pr.py0) * W2 + px, W2, lane, kp * kK);
+    if (kp != 0)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s_acc[(tp * 16 + r) * 64 + lane] = acc[r];
+        for (int r = 0; r < 16; ++r) s_acc[((tp * 3 + kp - 1) * 16 + r) * 64 + lane] = acc[r];
     __syncthreads();
-    if (mfma_wave && kh == 0)
+    if (kp == 0)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += s_acc[(tp * 16 + r) * 64 + lane];
+        for (int q = 0; q < kParts - 1; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += s_acc[((tp * 3 + q) * 16 + r) * 64 + lane];
 #ifdef NSIG_DEC_TIMING
     if (acc[0] == 12345.678f) DEC_STAMP(15);   // make the stamp below wait for the accumulators
 #endif
     DEC_STAMP(5);
 
-    // ---- epilogue (waves kh == 0 hold the tiles; the others only keep the barriers company)
+    // ---- epilogue (waves kp == 0 hold the tiles; the others only keep the barriers company)
     float *scr = s_scr + tp * (2 * 32 * 33), *s_ep = s_red;   // s_ep: [2 tiles][32 channels][2]
     if (MODE == kFwd) {
-        if (mfma_wave && kh == 0) {
+        if (kp == 0) {
             if (valid) {
                 float *xo = ws.x[layer] + eo;
 #pragma unroll
@@ -724,7 +724,7 @@ __global__ void __launch_bounds__(kT) k_dec_conv(int layer, DecParams prm, DecWs
         }
         DEC_STAMP(6);
     } else if (MODE == kDgrad) {
-        if (mfma_wave && kh == 0) {
+        if (kp == 0) {
             float dzv[16], dzx[16];
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -751,7 +751,7 @@ __global__ void __launch_bounds__(kT) k_dec_conv(int layer, DecParams prm, DecWs
         DEC_STAMP(6);
     } else {
         // rows = input channels c = 8*g4 + 4*h + j < Cin
-        if (mfma_wave && kh == 0 && valid)
+        if (kp == 0 && valid)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint32_t c = 8 * (r >> 2) + 4 * h + (r & 3);
@@ -1305,7 +1305,7 @@ static inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m
 
 constexpr size_t kLdsLimit = 160 * 1024;
 
-static size_t conv_lds(const DecGeom &g) { return (size_t)2 * g.rows_max * (g.W + 2) * kPitch + (4 * 64 + 1024 + 2 * 2 * 32 * 33 + 2 * 16 * 64 + 2 * 32) * 4; }
+static size_t conv_lds(const DecGeom &g) { return (size_t)2 * g.rows_max * (g.W + 2) * kPitch + (4 * 64 + 1024 + 2 * 2 * 32 * 33 + 2 * 3 * 16 * 64 + 2 * 32) * 4; }
 static size_t l8_lds(const DecGeom &g) { return (size_t)g.rows_max * (g.W + 2) * kC * 4 + (4 * 64 + 1024 + 4 * 16 * 65) * 4; }
 static size_t l8b_lds(const DecGeom &g) { return (size_t)g.rows_max * (g.W + 2) * (kC + 1) * 4 + 4 * 64 * 11 * 4; }
 static size_t l0_lds(const DecGeom &g) { return ((size_t)g.Cin * g.rows_max * (g.W + 2) + 4 * 64 + (g.Cin == 3 ? 0 : (size_t)kC * 9 * g.Cin)) * 4; }
