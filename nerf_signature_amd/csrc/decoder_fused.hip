@@ -186,13 +186,16 @@ __device__ inline void load_partials(const float *__restrict__ part, uint32_t n,
 }
 
 // Forward: partials (sum, M2 about the pair mean) -> batch mean and 1/sqrt(var + eps): two passes over the registers,
-// M2 = sum_i M2_i + n_i (mean_i - mean)^2 (no E[x^2] - E[x]^2 cancellation, no divisions).  red: 64 * kT/32 floats.
+// M2 = sum_i M2_i + n_i (mean_i - mean)^2 (no E[x^2] - E[x]^2 cancellation, no divisions).  red: 2 * 64 * kT/32 floats (the group
+// sums of the two passes side by side: three barriers in all -- every thread adds up the group sums of its own two channels
+// instead of waiting for 64 threads to publish the means).
 template <int kT = 256>
 __device__ inline void combine_fwd_stats(const Partials &pv, const DecGeom &g, float *red, float *s_mean, float *s_inv) {
     constexpr int kG = kT / 32, kHeld = kPartMax * 256 / kT;
     const uint32_t cp = threadIdx.x & 31, grp = threadIdx.x >> 5, c = threadIdx.x & 63;
     const uint32_t n = g.B * g.npair, last0 = (g.npair - 1) * g.B;
     const float N = (float)(g.B * g.P), n_last = (float)pair_count(g.npair - 1, g.P), rn_last = 1.0f / n_last;
+    float *red2 = red + 64 * kG;
     float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
     for (int k = 0; k < kHeld; ++k) {
@@ -200,17 +203,17 @@ __device__ inline void combine_fwd_stats(const Partials &pv, const DecGeom &g, f
         s0 += in ? pv.v[k].x : 0.0f;
         s1 += in ? pv.v[k].z : 0.0f;
     }
-    red[grp * 64 + 2 * cp] = s0;
-    red[grp * 64 + 2 * cp + 1] = s1;
+    *reinterpret_cast<float2 *>(red + grp * 64 + 2 * cp) = make_float2(s0, s1);
     __syncthreads();
-    float tot = 0.0f;
+    float m0 = 0.0f, m1 = 0.0f;
 #pragma unroll
-    for (int k = 0; k < kG; ++k) tot += red[k * 64 + c];
-    __syncthreads();
-    if (threadIdx.x < 64) red[c] = tot / N;   // the batch mean of channel c
-    __syncthreads();
-    const float m0 = red[2 * cp], m1 = red[2 * cp + 1];
-    __syncthreads();
+    for (int k = 0; k < kG; ++k) {
+        const float2 v = *reinterpret_cast<const float2 *>(red + k * 64 + 2 * cp);
+        m0 += v.x;
+        m1 += v.y;
+    }
+    m0 = m0 / N;   // the batch means of channels 2cp, 2cp + 1 (the same operations in every thread that shares them)
+    m1 = m1 / N;
     float q0 = 0.0f, q1 = 0.0f;
 #pragma unroll
     for (int k = 0; k < kHeld; ++k) {
@@ -221,15 +224,13 @@ __device__ inline void combine_fwd_stats(const Partials &pv, const DecGeom &g, f
         q0 += i < n ? pv.v[k].y + d0 * d0 * rni : 0.0f;
         q1 += i < n ? pv.v[k].w + d1 * d1 * rni : 0.0f;
     }
-    if (threadIdx.x < 64) s_mean[c] = red[c];
-    __syncthreads();
-    red[grp * 64 + 2 * cp] = q0;
-    red[grp * 64 + 2 * cp + 1] = q1;
+    *reinterpret_cast<float2 *>(red2 + grp * 64 + 2 * cp) = make_float2(q0, q1);
+    if (grp == 0) *reinterpret_cast<float2 *>(s_mean + 2 * cp) = make_float2(m0, m1);
     __syncthreads();
     if (threadIdx.x < 64) {
         float M2 = 0.0f;
 #pragma unroll
-        for (int k = 0; k < kG; ++k) M2 += red[k * 64 + c];
+        for (int k = 0; k < kG; ++k) M2 += red2[k * 64 + c];
         s_inv[c] = 1.0f / sqrtf(M2 / N + g.eps);
     }
     __syncthreads();
