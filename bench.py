@@ -103,6 +103,12 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="run the loop body eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line: RCCL prints its version banner to stdout when the process group starts, so
+    # everything until the result goes to stderr's descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     from nerf_signature_amd import dp, fieldops, synthetic, trainer
     from nerf_signature_amd.network import NeRFNetwork
 
@@ -145,7 +151,7 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = args.no_graph          # a replayed graph runs no Python: kernels are timed in the eager pass below
@@ -155,12 +161,12 @@ def main():
         out = one_step()
         if trace and rank == 0 and i % 5 == 4:
             print(f"[trace] step {args.warmup + i + 1}: loss_image {float(out[3]):.3e} loss_watermark {float(out[4]):.4f}", file=sys.stderr)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -222,7 +228,8 @@ def main():
                 "samples_per_ray_content": n_content / rays_content, "content_rays_per_s": rays_content * world * args.steps / elapsed,
                 "message_dim": D, "parallelism": f"dp{world}", "optimizer": "Adam(betas=(0.9,0.99), eps=1e-15): torch semantics, codebook update fused (opt_codebook_adam)",
                 "grad_exchange_bytes_per_step": loop.exchange.bytes_per_step,
-                "execution": "eager" if args.no_graph else "hipGraph replay (one capture of forward+backward+optimiser)",
+                "execution": "eager" if args.no_graph else ("hipGraph replay (forward+backward | RCCL exchange | optimiser)" if dp.exchange_active()
+                                                            else "hipGraph replay (one capture of forward+backward+optimiser)"),
                 "capacity_overflow": overflow,
                 "loss": loss_value, "loss_image": loss_parts[0], "loss_watermark": loss_parts[1],
             },
@@ -255,8 +262,11 @@ def main():
                 pass
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, D)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+        os.dup2(2, 1)
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -17,7 +17,7 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("NERFSIG_FORCE_EXCHANGE", "") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -30,6 +30,15 @@ def init_from_env(backend=None):
 
 def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def exchange_active():
+    """True when a step has an exchange phase: more than one rank, or NERFSIG_FORCE_EXCHANGE=1 with an initialised process
+    group of ANY size -- a one-GPU box can then rehearse the multi-rank execution (two graphs with the RCCL collectives
+    between them) through a world-size-1 "nccl" group; the sums over one rank leave every value unchanged."""
+    if not dist.is_initialized():
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("NERFSIG_FORCE_EXCHANGE", "") == "1"
 
 
 def _common_base(grads):
@@ -70,7 +79,7 @@ class GradExchange:
     def __call__(self, shared_grad):
         """shared_grad: the GradSink's G (or None).  In-place mean over ranks of G and of every decoder .grad."""
         world = world_size()
-        if world == 1:
+        if not exchange_active():
             return
         handles = []
         if shared_grad is not None:

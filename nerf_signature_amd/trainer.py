@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 from . import _native as nv
 from . import fieldops as fo
-from .dp import GradExchange, world_size
+from .dp import GradExchange, exchange_active, world_size
 from .hidden_models import normalize_img, set_weights_stream
 
 
@@ -398,7 +398,7 @@ class GraphedWatermarkLoop:
         self._restore(snapshot)
 
         self.optimizer.zero_grad(set_to_none=True)
-        split = world_size() > 1
+        split = exchange_active()
         g1 = torch.cuda.CUDAGraph()
         # thread_local: with more than one rank the process group's watchdog thread queries events while we capture; only this
         # thread's calls belong to the capture
