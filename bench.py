@@ -253,6 +253,20 @@ def main():
                                               "algorithmic_bytes_per_point": BYTES_BWD_PER_POINT(D)},
             },
         }
+        # the MLP kernel against the matrix-core roof (north_star: "MFMA utilisation on the MLP against chip peak").  Issued work:
+        # 72 v_mfma_f32_32x32x16_bf16 (32 768 FLOP each) per 32-point wave = three split-bf16 products per algorithmic one;
+        # algorithmic work: SURVEY.md 8(d)'s 10 240 MAC = 20 480 FLOP per point.  PMC cross-check (profiles/r01_pmc_mfma_summary.txt):
+        # SQ_INSTS_MFMA = 2.903e6 and SQ_VALU_MFMA_BUSY_CYCLES = 9.29e7 (= 32 cycles x MFMAs) per 1.29 M-point launch.
+        rows = float(enc_rows) if enc_rows else pts_real
+        issued_flop = rows / 32.0 * 72 * 32768
+        line["roofline_mlp"] = {
+            "kernel": "k_field_fwd<planes> (sigma MLP + SH + colour MLP, split-bf16 MFMA, fp32 accumulate) on the block render",
+            "bound": "mfma", "achieved": (issued_flop / mlp_s / 1e12) if mlp_s > 0 else 0.0, "peak": 2500.0, "unit": "TFLOP/s",
+            "frac": (issued_flop / mlp_s / 2.5e15) if mlp_s > 0 else 0.0, "avg_launch_s": mlp_s,
+            "algorithmic_TFLOPs": (pts_real * 20480 / mlp_s / 1e12) if mlp_s > 0 else 0.0,
+            "note": "achieved = issued bf16 MFMA FLOP/s (3 split-bf16 MFMAs per algorithmic product keep fp32-level accuracy); "
+                    "the algorithmic rate is a third of it; the kernel is co-limited by the VALU work of splitting activations into bf16 pairs",
+        }
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
