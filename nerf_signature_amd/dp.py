@@ -41,6 +41,23 @@ def exchange_active():
     return dist.get_world_size() > 1 or os.environ.get("NERFSIG_FORCE_EXCHANGE", "") == "1"
 
 
+def _tiled_range(grads):
+    """(storage, first element, one-past-last element) if `grads` are contiguous float32 pieces of ONE storage that tile a
+    contiguous element range without gaps or overlaps; else None."""
+    if not grads or any(g.dtype != torch.float32 or not g.is_contiguous() for g in grads):
+        return None
+    st = grads[0].untyped_storage()
+    if any(g.untyped_storage().data_ptr() != st.data_ptr() for g in grads):
+        return None
+    pieces = sorted((g.storage_offset(), g.numel()) for g in grads)
+    end = pieces[0][0]
+    for off, cnt in pieces:
+        if off != end:
+            return None
+        end += cnt
+    return st, pieces[0][0], end
+
+
 def _common_base(grads):
     """One flat tensor over the storage all `grads` share, if they are contiguous float32 pieces that tile it exactly (the fused
     decoder hands out such pieces; autograd keeps them as `.grad` without copying, though not as registered views)."""
@@ -75,16 +92,30 @@ class GradExchange:
         p0 = self.decoder_params[0]
         self.bucket = torch.zeros(n, dtype=torch.float32, device=p0.device)
         self.bytes_per_step = 0
+        self.collectives_per_step = 2
 
     def __call__(self, shared_grad):
         """shared_grad: the GradSink's G (or None).  In-place mean over ranks of G and of every decoder .grad."""
         world = world_size()
         if not exchange_active():
             return
+        grads = [p.grad for p in self.decoder_params if p.grad is not None]
+        if shared_grad is not None and shared_grad.is_contiguous() and shared_grad.dtype == torch.float32:
+            # G and the decoder's gradient block behind it in one allocation (GradSink(tail=...) + hidden_models.set_grad_arena):
+            # ONE collective for the whole step -- on xGMI a 5 MiB all-reduce costs a latency, not bandwidth, so two cost twice
+            rng = _tiled_range(grads)
+            g0 = shared_grad.storage_offset()
+            if rng is not None and rng[0].data_ptr() == shared_grad.untyped_storage().data_ptr() and rng[1] == g0 + shared_grad.numel():
+                both = torch.empty(0, dtype=torch.float32, device=shared_grad.device).set_(rng[0], g0, (rng[2] - g0,))
+                dist.all_reduce(both, op=dist.ReduceOp.SUM)
+                if self.average:
+                    both.mul_(1.0 / world)
+                self.bytes_per_step = both.numel() * 4
+                self.collectives_per_step = 1
+                return
         handles = []
         if shared_grad is not None:
             handles.append(dist.all_reduce(shared_grad, op=dist.ReduceOp.SUM, async_op=True))
-        grads = [p.grad for p in self.decoder_params if p.grad is not None]
         flat = _common_base(grads)
         if flat is not None:   # the gradients already live in one buffer: one collective, no copies
             handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))

@@ -268,8 +268,12 @@ class GradSink:
     across data-parallel ranks -- 4 MiB instead of D x 4 MiB -- and either fans it out into the `.grad` of
     the selected tables (`fanout`) or feeds it straight to the fused codebook optimiser."""
 
-    def __init__(self, device):
-        self.G = torch.zeros(T_ROWS, 2, dtype=torch.float32, device=device)
+    def __init__(self, device, tail=0):
+        # `tail` extra floats behind G in the same allocation: room for gradients that travel in the same collective
+        # (the decoder's flat gradient block, hidden_models.set_grad_arena)
+        self.arena = torch.zeros(T_ROWS * 2 + tail, dtype=torch.float32, device=device)
+        self.G = self.arena[:T_ROWS * 2].view(T_ROWS, 2)
+        self.tail = self.arena[T_ROWS * 2:]
         self.selected = None  # the parameters the pending gradient belongs to
 
     def zero_(self):

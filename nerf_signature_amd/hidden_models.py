@@ -84,6 +84,17 @@ def set_weights_stream(stream):
     _WEIGHTS_STREAM = stream
 
 
+_GRAD_ARENA = None
+
+
+def set_grad_arena(buffer):
+    """A float32 device buffer the fused decoder's backward carves its flat parameter-gradient block from (its first n elements)
+    instead of allocating one.  The data-parallel loop hands in the tail of the allocation that also holds the shared codebook
+    gradient G, so that one all-reduce covers both (dp.GradExchange).  None: allocate per backward."""
+    global _GRAD_ARENA
+    _GRAD_ARENA = buffer
+
+
 class _FusedDecoder(torch.autograd.Function):
     """decoded = Linear(AvgPool(ConvBNRelu^9(img))) through dec_forward / dec_backward.  params: for each of the 9 blocks
     (conv weight, bn weight, bn bias), then the linear weight and bias.
@@ -119,7 +130,12 @@ class _FusedDecoder(torch.autograd.Function):
         mean, std = ((ctypes.c_float * Cin)(*_MEAN[:Cin]), (ctypes.c_float * Cin)(*_STD[:Cin])) if rendered else (None, None)
         # one flat buffer, the parameter gradients are views of it: the data-parallel exchange all-reduces it in place
         # (dp.GradExchange) instead of packing 27 tensors into a bucket and unpacking them again
-        flat = torch.empty(sum(p.numel() for p in ps), dtype=torch.float32, device=img.device)
+        n_flat = sum(p.numel() for p in ps)
+        arena = _GRAD_ARENA
+        if arena is not None and arena.device == img.device and arena.numel() >= n_flat:
+            flat = arena[:n_flat]
+        else:
+            flat = torch.empty(n_flat, dtype=torch.float32, device=img.device)
         grads, off = [], 0
         for p in ps:
             grads.append(flat[off:off + p.numel()].view_as(p))

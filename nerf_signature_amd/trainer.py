@@ -13,7 +13,7 @@ import torch.nn.functional as F
 from . import _native as nv
 from . import fieldops as fo
 from .dp import GradExchange, exchange_active, world_size
-from .hidden_models import normalize_img, set_weights_stream
+from .hidden_models import normalize_img, set_grad_arena, set_weights_stream
 
 
 def loss_w_bce(decoded, keys, temp=10.0):
@@ -235,7 +235,8 @@ class GraphedWatermarkLoop:
         dev = next(model.parameters()).device
         self.device = dev
         D = model.message_dim
-        self.sink = fo.GradSink(dev)
+        # G and (behind it) room for the decoder's flat gradient block in one allocation: one all-reduce per step (dp.GradExchange)
+        self.sink = fo.GradSink(dev, tail=sum(p.numel() for p in model.msg_decoder.parameters()))
         model.grad_sink = self.sink
         self.exchange = GradExchange(list(model.msg_decoder.parameters()), average=not native_dense_adam)
         self.data = {"watermark": {k: v.clone() for k, v in data["watermark"].items()},
@@ -265,10 +266,12 @@ class GraphedWatermarkLoop:
         finally:
             fo.set_plan_stream(prev)
         set_weights_stream(self.side_stream)     # the decoder's parameter gradients go there too: the block render's backward only waits for the image gradient
+        set_grad_arena(self.sink.tail)
         try:
             backward_from_loss_kernel(out)
         finally:
             set_weights_stream(None)
+            set_grad_arena(None)
         if self.side_stream is not None:   # the content render's backward ends in a side effect (the shared gradient): join it explicitly
             torch.cuda.current_stream().wait_stream(self.side_stream)
         return out

@@ -265,6 +265,7 @@ def test_split_graphs_with_rccl_exchange_rehearsed_on_one_rank():
         assert dp.exchange_active()
         loop1, l1, t1 = run()
         assert loop1.graphs[1] is not None                               # two graphs, the exchange between them
+        assert loop1.exchange.collectives_per_step == 1                  # G and the decoder's gradient block travel together
         assert loop1.exchange.bytes_per_step == (1 << 19) * 2 * 4 + sum(p.numel() for p in loop1.model.msg_decoder.parameters() if p.grad is not None) * 4
     finally:
         os.environ.pop("NERFSIG_FORCE_EXCHANGE", None)

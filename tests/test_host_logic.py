@@ -152,7 +152,24 @@ def _dp_worker(rank, world, port, q):
     ex2 = dp.GradExchange(ps2, average=False)
     ex2(G2)
     assert torch.equal(flat, torch.arange(flat.numel(), dtype=torch.float32) * 3) and torch.equal(G2, torch.full((4, 2), 3.0))
-    assert ex2.bytes_per_step == (8 + flat.numel()) * 4
+    assert ex2.bytes_per_step == (8 + flat.numel()) * 4 and ex2.collectives_per_step == 2
+    # G and the decoder's gradient block in one allocation (GradSink(tail=...)): ONE collective covers both; unused tail
+    # elements behind the block stay out of it
+    n3 = sum(p.numel() for p in ps2)
+    arena = torch.zeros(8 + n3 + 5)
+    G3 = arena[:8].view(4, 2)
+    G3 += rank + 1
+    arena[8:8 + n3] = torch.arange(n3, dtype=torch.float32) * (rank + 1)
+    arena[8 + n3:] = 7.0 + rank
+    off = 8
+    for p in ps2:
+        p.grad = arena[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    ex3 = dp.GradExchange(ps2, average=False)
+    ex3(G3)
+    assert ex3.collectives_per_step == 1 and ex3.bytes_per_step == (8 + n3) * 4
+    assert torch.equal(G3, torch.full((4, 2), 3.0)) and torch.equal(arena[8:8 + n3], torch.arange(n3, dtype=torch.float32) * 3), arena
+    assert torch.equal(arena[8 + n3:], torch.full((5,), 7.0 + rank))
     # numpy, not tensors: a tensor travels through the queue as a file descriptor that dies with this process
     q.put((rank, ok, G.numpy().copy(), [None if g is None else g.numpy().copy() for g in grads], ex.bytes_per_step))
     dist.barrier()
