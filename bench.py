@@ -145,9 +145,15 @@ def main():
     timer = NativeTimer(nv)
     msg_rng = np.random.RandomState(1234)   # same stream on every rank: the message is replicated
 
+    draw = lambda: torch.from_numpy(msg_rng.randint(0, 2, D).astype(np.float32))   # fresh message per step (:1165), host side
+    upcoming = [draw()]
+
     def one_step():
-        msg = torch.from_numpy(msg_rng.randint(0, 2, D).astype(np.float32))   # fresh message per step (:1165), host side
-        return loop.step(data, msg) if args.no_graph else loop.step(msg)
+        # the captured loop is told the next step's message one step early (the same sequence of draws, looked ahead by one):
+        # its optimiser kernel then leaves that message's pre-summed codebook behind (GraphedWatermarkLoop, presum_in_adam)
+        msg = upcoming.pop()
+        upcoming.append(draw())
+        return loop.step(data, msg) if args.no_graph else loop.step(msg, next_message=upcoming[0])
 
     for _ in range(args.warmup):
         one_step()

@@ -195,6 +195,15 @@ int opt_codebook_adam_sel(const float *G, float *const *params_host, float *cons
                           float *const *steps_host, const float *message, uint32_t D, const float *lr, float beta1,
                           float beta2, float eps, float grad_scale, float *scratch, nsig_stream_t stream);
 
+/* opt_codebook_adam_sel that also leaves, in S_next [2^19,2], the pre-summed codebook of the NEXT step's message
+ * (next_message [D] on the device): sum_i table[2i + next_i] over the tables as updated by this very step, bit-identical to
+ * hg_codebook_presum_sel run afterwards -- the next step then starts without its 128 MiB pre-sum pass (the reference
+ * re-gathers every selected table per point, hash_encoding_wtmk_bit.py:99-116; see hg_codebook_presum). */
+int opt_codebook_adam_sel_next(const float *G, float *const *params_host, float *const *exp_avg_host, float *const *exp_avg_sq_host,
+                               float *const *steps_host, const float *message, uint32_t D, const float *lr, float beta1,
+                               float beta2, float eps, float grad_scale, float *scratch, const float *next_message,
+                               float *S_next, nsig_stream_t stream);
+
 /* ------------------------------------------------------------------ field network */
 
 /* Re-lays the two flat tcnn-style parameter vectors (sigma: 3072, color: 7168 fp32, layout in

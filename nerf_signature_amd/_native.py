@@ -43,6 +43,7 @@ SIGNATURES = {
     "hg_level_lookup": [_vp, _u32, _fl, _vp, _vp, _vp],
     "opt_codebook_adam": [_vp, _vp, _vp, _vp, _u32, _fl, _fl, _fl, _vp, _vp, _fl, _vp],
     "opt_codebook_adam_sel": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _fl, _fl, _fl, _fl, _vp, _vp],
+    "opt_codebook_adam_sel_next": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _fl, _fl, _fl, _fl, _vp, _vp, _vp, _vp],
     "mlp_packed_bytes": [],
     "mlp_pack_weights": [_vp, _vp, _vp, _vp],
     "hg_planes_bytes": [_u32],

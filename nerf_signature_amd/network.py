@@ -110,6 +110,18 @@ class NeRFNetwork(NeRFRenderer):
             self._presum_consumed()
         return tables, self._presum_cache[1]
 
+    def adopt_presum(self, message):
+        """Declare the existing pre-sum buffer valid for the device-resident `message` WITHOUT computing it: whoever calls this has
+        arranged for the buffer to be filled before the renders run (the captured loop's optimiser kernel writes the next step's
+        pre-sum, opt_codebook_adam_sel_next).  Returns the buffer."""
+        if self._presum_cache is None:
+            raise RuntimeError("adopt_presum: no pre-sum buffer exists yet (run prepare_message once)")
+        tables = self.msg_encoder.tables()
+        key = ("dev", message.data_ptr(), message._version, tuple((t.data_ptr(), t._version) for t in tables))
+        self._presum_cache = (key, self._presum_cache[1])
+        self._presum_produced()
+        return self._presum_cache[1]
+
     def prepare_message(self, message):
         """Compute (or find cached) the pre-summed codebook of `message` now, on the current stream -- so that renders issued on
         different streams afterwards (trainer.train_step's overlapped content render) only read it."""

@@ -68,8 +68,10 @@ def _prepare_device_state(opt, tables):
             st["step"] = st["step"].to(t.device)
 
 
-def _step_shared_sel(opt, tables, message_dev, G, lr_dev, grad_scale=1.0):
-    """Adam step of table 2i + message[i] for every bit, everything message-dependent resolved on the device."""
+def _step_shared_sel(opt, tables, message_dev, G, lr_dev, grad_scale=1.0, next_message_dev=None, S_next=None):
+    """Adam step of table 2i + message[i] for every bit, everything message-dependent resolved on the device.
+    next_message_dev + S_next: the same pass also writes the pre-summed codebook of the next step's message into S_next
+    (opt_codebook_adam_sel_next)."""
     group = opt._group_of(tables[0])
     beta1, beta2 = group["betas"]
     cache = getattr(opt, "_sel_cache", None)
@@ -81,8 +83,14 @@ def _step_shared_sel(opt, tables, message_dev, G, lr_dev, grad_scale=1.0):
         scratch = torch.empty(2 * D, dtype=torch.float32, device=tables[0].device)
         cache = opt._sel_cache = (tables, arrays, scratch, D)
     _, (pp, pm, pv, ps), scratch, D = cache
-    nv.call("opt_codebook_adam_sel", nv.ptr(G), pp, pm, pv, ps, nv.ptr(message_dev), D, nv.ptr(lr_dev), float(beta1), float(beta2),
-            float(group["eps"]), float(grad_scale), nv.ptr(scratch), nv.stream())
+    if next_message_dev is not None:
+        if S_next is None or S_next.dtype != torch.float32 or not S_next.is_contiguous() or S_next.numel() != tables[0].numel():
+            raise ValueError("step_shared_sel: S_next must be a contiguous float32 tensor of one table's size")
+        nv.call("opt_codebook_adam_sel_next", nv.ptr(G), pp, pm, pv, ps, nv.ptr(message_dev), D, nv.ptr(lr_dev), float(beta1), float(beta2),
+                float(group["eps"]), float(grad_scale), nv.ptr(scratch), nv.ptr(next_message_dev), nv.ptr(S_next), nv.stream())
+    else:
+        nv.call("opt_codebook_adam_sel", nv.ptr(G), pp, pm, pv, ps, nv.ptr(message_dev), D, nv.ptr(lr_dev), float(beta1), float(beta2),
+                float(group["eps"]), float(grad_scale), nv.ptr(scratch), nv.stream())
     _bump_versions(tables)
 
 

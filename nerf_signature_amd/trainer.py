@@ -64,7 +64,8 @@ def backward_from_loss_kernel(out):
     torch.autograd.backward([content, decoded], seeds)
 
 
-def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce, side_stream=None, presum_first=False):
+def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce, side_stream=None, presum_first=False,
+               presum_adopt=False):
     """data = {'watermark': {'rays_o_block', 'rays_d_block'}, 'content': {'rays_o', 'rays_d', 'images'}}.
     Returns (pred_rgb, gt_rgb, content_pred_rgb, lossi, lossw, loss) like the reference.
 
@@ -74,6 +75,8 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
     wm, content = data["watermark"], data["content"]
     kw = dict(render_kwargs)
     kw.update(staged=False, bg_color=1, perturb=False, force_all_rays=True)
+    if presum_adopt:   # the previous step's optimiser kernel left this message's pre-sum in the buffer (GraphedWatermarkLoop): no pass here
+        model.adopt_presum(message)
     main = None
     if side_stream is not None and wm["rays_o_block"].is_cuda:
         main = torch.cuda.current_stream()
@@ -211,8 +214,13 @@ class GraphedWatermarkLoop:
     points than that -- such a step dropped the rays that did not fit, like the reference's bounded mode."""
 
     def __init__(self, model, optimizer, render_kwargs, data, lambda_w=1.0, lambda_i=1.0, lr_lambda=None, headroom=0.0, native_dense_adam=True,
-                 overlap_content=True, march_ahead=None):
-        """march_ahead (default: with overlap_content): the block render's samples are marched at the end of the previous
+                 overlap_content=True, march_ahead=None, presum_in_adam=True):
+        """presum_in_adam: the captured optimiser kernel also writes the pre-summed codebook of the NEXT step's message
+        (opt_codebook_adam_sel_next: +9 % traffic inside an HBM-streaming kernel instead of a 128 MiB pass at the head of every step).
+        The next message is handed over one step early -- `step(message_k, next_message=message_k1)`, a one-element look-ahead over
+        the random draws of utils_wtmk_disen.py:1165; a step whose message was not announced runs the stand-alone pre-sum before
+        its replay, so `step(message)` alone stays correct.
+        march_ahead (default: with overlap_content): the block render's samples are marched at the end of the previous
         replay, beside the optimiser (the march needs rays and occupancy grid only -- nothing a step updates -- and the
         codebook Adam is an HBM stream that leaves the ALUs idle: 166 us together against 224 us one after the other,
         tools/overlap_probe.py).  The block rays of the NEXT step therefore have to be in the static buffers when a replay
@@ -221,6 +229,8 @@ class GraphedWatermarkLoop:
         at the head of its own step on the side stream: next to the optimiser as well, the two marches took longer than the
         optimiser and the pre-sum lost its cover."""
         self.march_ahead = overlap_content if march_ahead is None else bool(march_ahead)
+        self.presum_in_adam = bool(presum_in_adam)
+        self._s_for = None            # host copy of the message the pre-sum buffer currently belongs to (None: unknown / stale)
         self.marched = None
         self._pending_content = None
         self.native_dense_adam = native_dense_adam
@@ -241,10 +251,11 @@ class GraphedWatermarkLoop:
         self.exchange = GradExchange(list(model.msg_decoder.parameters()), average=not native_dense_adam)
         self.data = {"watermark": {k: v.clone() for k, v in data["watermark"].items()},
                      "content": {k: v.clone() for k, v in data["content"].items()}}
-        self.msg_dev = torch.zeros(D, dtype=torch.float32, device=dev)
+        self.msg_all = torch.zeros(2 * D, dtype=torch.float32, device=dev)     # this step's message, then the next step's
+        self.msg_dev, self.msg_next_dev = self.msg_all[:D], self.msg_all[D:]
         # The host runs ahead of the GPU by many replays, so the pinned staging buffer of a step must not be rewritten until its
         # asynchronous copy has executed: a ring of buffers, each guarded by an event.
-        self.msg_ring = [torch.zeros(D, dtype=torch.float32).pin_memory() for _ in range(16)]
+        self.msg_ring = [torch.zeros(2 * D, dtype=torch.float32).pin_memory() for _ in range(16)]
         self.msg_events = [None] * len(self.msg_ring)
         self.base_lr = float(optimizer.param_groups[0]["lr"])
         self.lr_dev = torch.tensor(self.base_lr, dtype=torch.float32, device=dev)
@@ -262,7 +273,8 @@ class GraphedWatermarkLoop:
         prev = fo.set_plan_stream(self.plan_stream)    # the scatter plans need the sample positions only: beside the forward pass
         try:
             out = train_step(self.model, self.data, self.msg_dev, self.render_kwargs, self.lambda_w, self.lambda_i, side_stream=self.side_stream,
-                             presum_first=self.marched is not None)
+                             presum_first=self.marched is not None,
+                             presum_adopt=self.presum_in_adam and torch.cuda.is_current_stream_capturing())
         finally:
             fo.set_plan_stream(prev)
         set_weights_stream(self.side_stream)     # the decoder's parameter gradients go there too: the block render's backward only waits for the image gradient
@@ -278,7 +290,11 @@ class GraphedWatermarkLoop:
 
     def _optimise(self):
         scale = 1.0 / world_size() if self.native_dense_adam else 1.0    # the exchange leaves sums: the mean is taken here
-        self.optimizer.step_shared_sel(self.tables, self.msg_dev, self.sink.G, self.lr_dev, scale)
+        if self.presum_in_adam:     # ... and the next step's pre-sum, in place (both renders of this step are done with the buffer)
+            self.optimizer.step_shared_sel(self.tables, self.msg_dev, self.sink.G, self.lr_dev, scale, next_message_dev=self.msg_next_dev,
+                                           S_next=self.model._presum_cache[1])
+        else:
+            self.optimizer.step_shared_sel(self.tables, self.msg_dev, self.sink.G, self.lr_dev, scale)
         if self.native_dense_adam:
             self.optimizer.step_dense(self.lr_dev, scale)      # the decoder's parameters: opt_adam_dense
         else:
@@ -313,12 +329,15 @@ class GraphedWatermarkLoop:
         a, b = self.model.step_counter[self.capacity_rows, 0].tolist()
         return (a, b) if self.side_stream is None else (b, a)     # issue order: with a side stream the content render comes first
 
-    def _set_inputs(self, message, data, next_data=None):
+    def _set_inputs(self, message, data, next_data=None, next_message=None):
         slot = self.steps_done % len(self.msg_ring)
         if self.msg_events[slot] is not None:
             self.msg_events[slot].synchronize()      # blocks only if the GPU is a whole ring behind
-        self.msg_ring[slot].copy_(message.detach().to("cpu", torch.float32))
-        self.msg_dev.copy_(self.msg_ring[slot], non_blocking=True)
+        D = self.msg_dev.numel()
+        self.msg_ring[slot][:D].copy_(message.detach().to("cpu", torch.float32))
+        # an unannounced next message: the optimiser pre-sums for this step's bits again (harmless) and _s_for goes stale
+        self.msg_ring[slot][D:].copy_((message if next_message is None else next_message).detach().to("cpu", torch.float32))
+        self.msg_all.copy_(self.msg_ring[slot], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self.msg_events[slot] = ev
@@ -425,7 +444,7 @@ class GraphedWatermarkLoop:
             self.capacity_rows = [(model.local_step - 1) % 16]
         return self
 
-    def step(self, message, data=None, next_data=None):
+    def step(self, message, data=None, next_data=None, next_message=None):
         """message: CPU float tensor of 0./1.; data: optional new rays/images of THIS step, next_data: of the next one (same
         shapes; see march_ahead).  Returns the static output tuple of train_step (valid until the next step; values are ready
         when the stream reaches them)."""
@@ -434,7 +453,12 @@ class GraphedWatermarkLoop:
                 self._set_inputs(message, data)
                 data = None
             self.prepare(message)
-        self._set_inputs(message, data, next_data)
+        self._set_inputs(message, data, next_data, next_message)
+        if self.presum_in_adam:
+            msg_cpu = message.detach().to("cpu", torch.float32)
+            if self._s_for is None or not torch.equal(self._s_for, msg_cpu):
+                self.model.prepare_message(self.msg_dev)     # not announced one step early: the stand-alone pass, before the replay
+            self._s_for = None if next_message is None else next_message.detach().to("cpu", torch.float32).clone()
         g1, g2 = self.graphs
         g1.replay()
         if g2 is not None:

@@ -194,6 +194,35 @@ def test_codebook_adam_matches_torch_adam():
     ref.load_state_dict(sd)
 
 
+def test_codebook_adam_sel_with_next_presum():
+    """opt_codebook_adam_sel_next: the same parameter / state update as opt_codebook_adam_sel, and S_next is bit-identical to the
+    pre-sum of the NEXT message over the tables as updated (odd D exercises the tail of the two-tables-per-trip loop)."""
+    from nerf_signature_amd import fieldops as fo
+    from nerf_signature_amd.optim import CodebookAdam
+    for D in (5, 32):
+        torch.manual_seed(D)
+        init = [torch.randn(1 << 19, 2, device="cuda") * 0.05 for _ in range(2 * D)]
+        runs = []
+        for with_next in (False, True):
+            ps = [torch.nn.Parameter(t.clone()) for t in init]
+            opt = CodebookAdam([{"params": ps, "lr": 1e-2}], betas=(0.9, 0.99), eps=1e-15, capturable=True)
+            lr = torch.tensor(1e-2, device="cuda")
+            S = torch.empty(1 << 19, 2, device="cuda")
+            for it in range(3):
+                torch.manual_seed(100 * D + it)
+                G = torch.randn(1 << 19, 2, device="cuda") * (10.0 ** -it)
+                msg = torch.from_numpy(np.random.RandomState(10 * D + it).randint(0, 2, D).astype(np.float32)).cuda()
+                nxt = torch.from_numpy(np.random.RandomState(10 * D + it + 1).randint(0, 2, D).astype(np.float32)).cuda()
+                if with_next:
+                    opt.step_shared_sel(ps, msg, G, lr, 0.5, next_message_dev=nxt, S_next=S)
+                    assert torch.equal(S, fo.codebook_presum_sel(ps, nxt))
+                else:
+                    opt.step_shared_sel(ps, msg, G, lr, 0.5)
+            runs.append(([p.detach().clone() for p in ps], [float(opt.state[p]["step"]) if len(opt.state[p]) else 0.0 for p in ps]))
+        assert runs[0][1] == runs[1][1] and sum(runs[0][1]) == 3 * D
+        assert all(torch.equal(a, b) for a, b in zip(runs[0][0], runs[1][0]))
+
+
 def test_graphed_loop_matches_eager_loop():
     """GraphedWatermarkLoop (capacity march, device-side table selection, captured hipGraph) == WatermarkLoop step for step."""
     from nerf_signature_amd import trainer
@@ -203,15 +232,19 @@ def test_graphed_loop_matches_eager_loop():
     msgs = [torch.from_numpy(np.random.RandomState(s).randint(0, 2, 32).astype(np.float32)) for s in range(4)]
     lr_lambda = lambda it: 0.5 ** it
     runs = []
-    for graphed in (False, True):
+    for graphed in (False, True, "announced", "half-announced"):
         torch.manual_seed(0)
         m, _, _ = _model()
-        opt = CodebookAdam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, capturable=graphed)
+        opt = CodebookAdam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, capturable=bool(graphed))
         if graphed:
             loop = trainer.GraphedWatermarkLoop(m, opt, dict(dt_gamma=0, max_steps=1024), data, lr_lambda=lr_lambda)
             # no host synchronisation between the steps (how the loop is meant to run): the host is then several replays ahead of
-            # the GPU, which is what once let a step read a later step's message out of the pinned staging buffer
-            held = [loop.step(msg)[5].detach().clone() for msg in msgs]
+            # the GPU, which is what once let a step read a later step's message out of the pinned staging buffer.
+            # "announced": every next message handed over one step early (the optimiser kernel leaves its pre-sum behind);
+            # "half-announced": only some, and one of them wrongly -- those steps must fall back to the stand-alone pre-sum
+            nxt = {True: lambda k: None, "announced": lambda k: msgs[k + 1] if k + 1 < len(msgs) else None,
+                   "half-announced": lambda k: {0: msgs[1], 1: 1 - msgs[2]}.get(k)}[graphed]
+            held = [loop.step(msg, next_message=nxt(k))[5].detach().clone() for k, msg in enumerate(msgs)]
             losses = [float(v) for v in held]
             assert not loop.overflowed()
         else:
@@ -223,7 +256,10 @@ def test_graphed_loop_matches_eager_loop():
         dec = torch.cat([p.detach().reshape(-1) for p in m.msg_decoder.parameters()])
         steps = [float(opt.state[e.weight]["step"]) if len(opt.state[e.weight]) else 0.0 for e in m.msg_encoder.embeddings]
         runs.append((losses, tables, dec, steps))
-    (l0, t0, d0, s0), (l1, t1, d1, s1) = runs
+    for other in runs[2:]:      # the look-ahead variants replay the same graph: identical to the plain graphed run up to atomics' order
+        np.testing.assert_allclose(other[0], runs[1][0], rtol=1e-4, atol=1e-5)
+        assert other[3] == runs[1][3]
+    (l0, t0, d0, s0), (l1, t1, d1, s1) = runs[:2]
     np.testing.assert_allclose(l1, l0, rtol=2e-3, atol=2e-4)
     assert s0 == s1 and sum(s0) == 4 * 32                       # per-table step counts: one per selection
     # Adam normalises every touched row to a step of ~lr, so rows whose tiny gradient differs in the last bits (float
