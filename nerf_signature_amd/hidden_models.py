@@ -118,6 +118,7 @@ class _FusedDecoder(torch.autograd.Function):
                 nv.stream())
         ctx.save_for_backward(img, ws, *ps)
         ctx.geom = (B, Cin, H, W, bool(rendered))
+        ctx.set_materialize_grads(False)   # no zero-filled gradient tensor for the non-differentiable `clamped` output (one fill launch on the backward's critical path)
         if rendered:
             ctx.mark_non_differentiable(clamped)
             return out.view(B, 1), clamped
@@ -125,6 +126,8 @@ class _FusedDecoder(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out, *_):
+        if grad_out is None:
+            return (None,) * (3 + len(ctx.saved_tensors) - 2)
         img, ws, *ps = ctx.saved_tensors
         B, Cin, H, W, rendered = ctx.geom
         mean, std = ((ctypes.c_float * Cin)(*_MEAN[:Cin]), (ctypes.c_float * Cin)(*_STD[:Cin])) if rendered else (None, None)
