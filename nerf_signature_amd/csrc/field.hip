@@ -20,6 +20,7 @@
 //     gathers (3 x 24 MFMAs per 32 points).
 //   * backward needs only the input gradient of the codebook channels (all network weights are frozen,
 //     network_wtmk_tcnn.py:90-95), so the forward saves just the ReLU sign bits (6 words per point).
+#include <cstdlib>
 #include "hashgrid.h"
 
 #include <stdlib.h>
@@ -679,7 +680,10 @@ NSIG_EXPORT int hg_encode_planes(const float *xyzs, uint32_t M, float bound, con
     for (int l = 0; l < NSIG_BASE_LEVELS + (S != nullptr ? 1 : 0); ++l) NSIG_REQUIRE(covered[l], "hg_encode_planes: slot table does not cover level %d", l);
     NSIG_REQUIRE(S != nullptr || !covered[NSIG_BASE_LEVELS], "hg_encode_planes: slot table names the codebook level but S is NULL");
     const uint32_t tiles = ceil_div(stride, 256u);
-    const uint32_t per_slot = tiles < 1024u ? tiles : 1024u;
+    // tiles per XCD slot handled by distinct workgroups before they start looping: with one tile per workgroup (cap >= tiles) the block
+    // render's launch takes 244-247 us against 258-261 us with 1024 looping workgroups per slot (same-box sweep, profiles/r01_k_encoder_grid_sweep.txt)
+    static const uint32_t cap = getenv("NERFSIG_ENC_PER_SLOT") ? (uint32_t)atoi(getenv("NERFSIG_ENC_PER_SLOT")) : 8192u;
+    const uint32_t per_slot = tiles < cap ? tiles : cap;
     k_encode_planes<<<per_slot * 8, 256, 0, as_stream(stream)>>>(xyzs, M, bound, base, make_level_geom(), S, reinterpret_cast<float2 *>(planes), stride, tab);
     return check_launch("hg_encode_planes");
 }
