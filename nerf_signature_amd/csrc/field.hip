@@ -627,9 +627,15 @@ NSIG_EXPORT int mlp_pack_weights(const float *sigma_params, const float *color_p
     return check_launch("mlp_pack_weights");
 }
 
-static uint32_t field_grid(uint32_t M) {
+static uint32_t field_grid(uint32_t M, bool forward = false) {
     const uint32_t blocks = ceil_div(ceil_div(ceil_div(M, 32u), 4u), 8u) * 8u;   // a multiple of 8: k_field_bwd's XCD-aware tile order
-    return blocks < (uint32_t)(kCUs * 3) ? blocks : (uint32_t)(kCUs * 3);  // 3 workgroups per CU fit the LDS budget
+    // persistent workgroups (the packed weights are staged once per workgroup): 3 per CU fit the LDS budget.  Same-box sweeps
+    // (profiles/r01_k_field_grid_sweep.txt): the backward is fastest with exactly the resident 768 (113-117 us; 128 with 512 or 1024),
+    // the forward with 512 or 1024 (117-120 us against 124-125 with 768) and the step with 1024 (1.118-1.123 ms against 1.132-1.133).
+    static const uint32_t cap_f = getenv("NERFSIG_FIELD_FWD_WGS") ? (uint32_t)atoi(getenv("NERFSIG_FIELD_FWD_WGS")) : (uint32_t)(kCUs * 4);
+    static const uint32_t cap_b = getenv("NERFSIG_FIELD_BWD_WGS") ? (uint32_t)atoi(getenv("NERFSIG_FIELD_BWD_WGS")) : (uint32_t)(kCUs * 3);
+    const uint32_t cap = forward ? cap_f : cap_b;
+    return blocks < cap ? blocks : cap;
 }
 
 static int fill_base_tables(const float *const *host, TablePtrs &base, const char *who) {
@@ -701,13 +707,13 @@ NSIG_EXPORT int field_fwd(const float *xyzs, const float *dirs, uint32_t M, floa
     const char *pk = reinterpret_cast<const char *>(packed);
     hipStream_t st = as_stream(stream);
     if (planes == nullptr) {  // fused: gather inside the MLP kernel (small batches)
-        k_field_fwd<false><<<field_grid(M), 256, 2 * kFwdBytes, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, nullptr, 0, pk, sigmas, rgbs,
+        k_field_fwd<false><<<field_grid(M, true), 256, 2 * kFwdBytes, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, nullptr, 0, pk, sigmas, rgbs,
                                                                     geo_feat, masks);
         return check_launch("field_fwd");
     }
     NSIG_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 7) == 0, "field_fwd: planes must be 8-byte aligned");
     const uint32_t stride = ceil_div(M, 32u) * 32u;
-    k_field_fwd<true><<<field_grid(M), 256, 2 * kFwdBytes, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, reinterpret_cast<const float2 *>(planes),
+    k_field_fwd<true><<<field_grid(M, true), 256, 2 * kFwdBytes, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, reinterpret_cast<const float2 *>(planes),
                                                                stride, pk, sigmas, rgbs, geo_feat, masks);
     return check_launch("field_fwd");
 }
