@@ -591,17 +591,36 @@ __global__ void k_adam_prepare(StepPtrs steps, const float *__restrict__ message
     scratch[D + i] = (float)(1.0 / sqrt(1.0 - exp((double)step * log((double)beta2))));
 }
 
+// Streaming accesses of the optimiser pass: 836 MiB go through once per step; marked non-temporal so that they do not displace the
+// base tables (64 MiB) from the L2 / Infinity Cache right before the next step's gather.
+typedef float nsig_f32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 ld4(const float4 *p) {
+    if (!NT) return *p;
+    const nsig_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nsig_f32x4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+template <bool NT>
+__device__ __forceinline__ void st4(float4 *p, const float4 &a) {
+    if (!NT) {
+        *p = a;
+        return;
+    }
+    const nsig_f32x4 v = {a.x, a.y, a.z, a.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<nsig_f32x4 *>(p));
+}
+
 // NEXT: the same pass also produces the pre-summed codebook of the NEXT step's message, S_next = sum_i table[2i + next_i]: where the
 // next bit equals the current one the freshly updated row is already in registers, otherwise the partner table's row is read
 // (about D/2 extra 4 MiB streams: +9 % traffic) -- instead of a separate 128 MiB pre-sum pass at the head of the next step.
 // The sum keeps the table order, so S_next is bit-identical to k_codebook_presum_sel's.
-template <bool NEXT>
+template <bool NEXT, bool NT>
 __global__ void __launch_bounds__(256) k_codebook_adam_sel(const float4 *__restrict__ G, AdamPairPtrs a, const float *__restrict__ message,
                                                            const float *__restrict__ scratch, uint32_t D, float beta1, float beta2, float eps,
                                                            float grad_scale, const float *__restrict__ next_message, float4 *__restrict__ S_next) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= NSIG_TABLE_ROWS / 2) return;
-    float4 g = G[e];
+    float4 g = ld4<NT>(G + e);
     g.x *= grad_scale; g.y *= grad_scale; g.z *= grad_scale; g.w *= grad_scale;
     float4 acc = {0.f, 0.f, 0.f, 0.f};
     const float4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -616,10 +635,10 @@ __global__ void __launch_bounds__(256) k_codebook_adam_sel(const float4 *__restr
         if (NEXT) {
             other0 = (next_message[i] != 0.0f) != (message[i] != 0.0f);
             other1 = (next_message[i + 1] != 0.0f) != (message[i + 1] != 0.0f);
-            if (other0) o0 = *(reinterpret_cast<const float4 *>(a.p[j0 ^ 1u]) + e);
-            if (other1) o1 = *(reinterpret_cast<const float4 *>(a.p[j1 ^ 1u]) + e);
+            if (other0) o0 = ld4<NT>(reinterpret_cast<const float4 *>(a.p[j0 ^ 1u]) + e);
+            if (other1) o1 = ld4<NT>(reinterpret_cast<const float4 *>(a.p[j1 ^ 1u]) + e);
         }
-        float4 p0 = *pp0, m0 = *pm0, v0 = *pv0, p1 = *pp1, m1 = *pm1, v1 = *pv1;
+        float4 p0 = ld4<NT>(pp0), m0 = ld4<NT>(pm0), v0 = ld4<NT>(pv0), p1 = ld4<NT>(pp1), m1 = ld4<NT>(pm1), v1 = ld4<NT>(pv1);
         const float ss0 = scratch[i], ib0 = scratch[D + i], ss1 = scratch[i + 1], ib1 = scratch[D + i + 1];
         adam_update(g.x, p0.x, m0.x, v0.x, beta1, beta2, eps, ss0, ib0);
         adam_update(g.y, p0.y, m0.y, v0.y, beta1, beta2, eps, ss0, ib0);
@@ -629,7 +648,7 @@ __global__ void __launch_bounds__(256) k_codebook_adam_sel(const float4 *__restr
         adam_update(g.y, p1.y, m1.y, v1.y, beta1, beta2, eps, ss1, ib1);
         adam_update(g.z, p1.z, m1.z, v1.z, beta1, beta2, eps, ss1, ib1);
         adam_update(g.w, p1.w, m1.w, v1.w, beta1, beta2, eps, ss1, ib1);
-        *pp0 = p0; *pm0 = m0; *pv0 = v0; *pp1 = p1; *pm1 = m1; *pv1 = v1;
+        st4<NT>(pp0, p0); st4<NT>(pm0, m0); st4<NT>(pv0, v0); st4<NT>(pp1, p1); st4<NT>(pm1, m1); st4<NT>(pv1, v1);
         if (NEXT) {
             const float4 c0 = other0 ? o0 : p0, c1 = other1 ? o1 : p1;
             acc.x += c0.x; acc.y += c0.y; acc.z += c0.z; acc.w += c0.w;
@@ -643,92 +662,15 @@ __global__ void __launch_bounds__(256) k_codebook_adam_sel(const float4 *__restr
         float4 o = zero;
         if (NEXT) {
             other = (next_message[i] != 0.0f) != (message[i] != 0.0f);
-            if (other) o = *(reinterpret_cast<const float4 *>(a.p[j ^ 1u]) + e);
+            if (other) o = ld4<NT>(reinterpret_cast<const float4 *>(a.p[j ^ 1u]) + e);
         }
-        float4 p = *pp, m = *pm, v = *pv;
+        float4 p = ld4<NT>(pp), m = ld4<NT>(pm), v = ld4<NT>(pv);
         const float ss = scratch[i], ib = scratch[D + i];
         adam_update(g.x, p.x, m.x, v.x, beta1, beta2, eps, ss, ib);
         adam_update(g.y, p.y, m.y, v.y, beta1, beta2, eps, ss, ib);
         adam_update(g.z, p.z, m.z, v.z, beta1, beta2, eps, ss, ib);
         adam_update(g.w, p.w, m.w, v.w, beta1, beta2, eps, ss, ib);
-        *pp = p; *pm = m; *pv = v;
-        if (NEXT) {
-            const float4 c = other ? o : p;
-            acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
-        }
-    }
-    if (NEXT) S_next[e] = acc;
-}
-
-// Streaming accesses of the optimiser pass: 836 MiB go through once per step; marked non-temporal so that they do not displace the
-// base tables (64 MiB) from the L2 / Infinity Cache right before the next step's gather.
-typedef float nsig_f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 nt_load4(const float4 *p) {
-    const nsig_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nsig_f32x4 *>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void nt_store4(float4 *p, const float4 &a) {
-    const nsig_f32x4 v = {a.x, a.y, a.z, a.w};
-    __builtin_nontemporal_store(v, reinterpret_cast<nsig_f32x4 *>(p));
-}
-
-template <bool NEXT>
-__global__ void __launch_bounds__(256) k_codebook_adam_sel_nt(const float4 *__restrict__ G, AdamPairPtrs a, const float *__restrict__ message,
-                                                           const float *__restrict__ scratch, uint32_t D, float beta1, float beta2, float eps,
-                                                           float grad_scale, const float *__restrict__ next_message, float4 *__restrict__ S_next) {
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= NSIG_TABLE_ROWS / 2) return;
-    float4 g = nt_load4(G + e);
-    g.x *= grad_scale; g.y *= grad_scale; g.z *= grad_scale; g.w *= grad_scale;
-    float4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float4 zero = {0.f, 0.f, 0.f, 0.f};
-    // two tables per trip: six 16-byte loads in flight per thread before the first dependent store
-    uint32_t i = 0;
-    for (; i + 2 <= D; i += 2) {
-        const uint32_t j0 = 2 * i + (message[i] != 0.0f), j1 = 2 * i + 2 + (message[i + 1] != 0.0f);
-        float4 *pp0 = reinterpret_cast<float4 *>(a.p[j0]) + e, *pm0 = reinterpret_cast<float4 *>(a.m[j0]) + e, *pv0 = reinterpret_cast<float4 *>(a.v[j0]) + e;
-        float4 *pp1 = reinterpret_cast<float4 *>(a.p[j1]) + e, *pm1 = reinterpret_cast<float4 *>(a.m[j1]) + e, *pv1 = reinterpret_cast<float4 *>(a.v[j1]) + e;
-        bool other0 = false, other1 = false;      // wave-uniform
-        float4 o0 = zero, o1 = zero;
-        if (NEXT) {
-            other0 = (next_message[i] != 0.0f) != (message[i] != 0.0f);
-            other1 = (next_message[i + 1] != 0.0f) != (message[i + 1] != 0.0f);
-            if (other0) o0 = nt_load4(reinterpret_cast<const float4 *>(a.p[j0 ^ 1u]) + e);
-            if (other1) o1 = nt_load4(reinterpret_cast<const float4 *>(a.p[j1 ^ 1u]) + e);
-        }
-        float4 p0 = nt_load4(pp0), m0 = nt_load4(pm0), v0 = nt_load4(pv0), p1 = nt_load4(pp1), m1 = nt_load4(pm1), v1 = nt_load4(pv1);
-        const float ss0 = scratch[i], ib0 = scratch[D + i], ss1 = scratch[i + 1], ib1 = scratch[D + i + 1];
-        adam_update(g.x, p0.x, m0.x, v0.x, beta1, beta2, eps, ss0, ib0);
-        adam_update(g.y, p0.y, m0.y, v0.y, beta1, beta2, eps, ss0, ib0);
-        adam_update(g.z, p0.z, m0.z, v0.z, beta1, beta2, eps, ss0, ib0);
-        adam_update(g.w, p0.w, m0.w, v0.w, beta1, beta2, eps, ss0, ib0);
-        adam_update(g.x, p1.x, m1.x, v1.x, beta1, beta2, eps, ss1, ib1);
-        adam_update(g.y, p1.y, m1.y, v1.y, beta1, beta2, eps, ss1, ib1);
-        adam_update(g.z, p1.z, m1.z, v1.z, beta1, beta2, eps, ss1, ib1);
-        adam_update(g.w, p1.w, m1.w, v1.w, beta1, beta2, eps, ss1, ib1);
-        nt_store4(pp0, p0); nt_store4(pm0, m0); nt_store4(pv0, v0); nt_store4(pp1, p1); nt_store4(pm1, m1); nt_store4(pv1, v1);
-        if (NEXT) {
-            const float4 c0 = other0 ? o0 : p0, c1 = other1 ? o1 : p1;
-            acc.x += c0.x; acc.y += c0.y; acc.z += c0.z; acc.w += c0.w;
-            acc.x += c1.x; acc.y += c1.y; acc.z += c1.z; acc.w += c1.w;
-        }
-    }
-    for (; i < D; ++i) {
-        const uint32_t j = 2 * i + (message[i] != 0.0f);
-        float4 *pp = reinterpret_cast<float4 *>(a.p[j]) + e, *pm = reinterpret_cast<float4 *>(a.m[j]) + e, *pv = reinterpret_cast<float4 *>(a.v[j]) + e;
-        bool other = false;
-        float4 o = zero;
-        if (NEXT) {
-            other = (next_message[i] != 0.0f) != (message[i] != 0.0f);
-            if (other) o = nt_load4(reinterpret_cast<const float4 *>(a.p[j ^ 1u]) + e);
-        }
-        float4 p = nt_load4(pp), m = nt_load4(pm), v = nt_load4(pv);
-        const float ss = scratch[i], ib = scratch[D + i];
-        adam_update(g.x, p.x, m.x, v.x, beta1, beta2, eps, ss, ib);
-        adam_update(g.y, p.y, m.y, v.y, beta1, beta2, eps, ss, ib);
-        adam_update(g.z, p.z, m.z, v.z, beta1, beta2, eps, ss, ib);
-        adam_update(g.w, p.w, m.w, v.w, beta1, beta2, eps, ss, ib);
-        nt_store4(pp, p); nt_store4(pm, m); nt_store4(pv, v);
+        st4<NT>(pp, p); st4<NT>(pm, m); st4<NT>(pv, v);
         if (NEXT) {
             const float4 c = other ? o : p;
             acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
@@ -887,13 +829,13 @@ static int codebook_adam_sel(const char *who, const float *G, float *const *para
     // accesses; the kernel alone takes the same 160-164 us either way, the next step's gather gains); NERFSIG_ADAM_NT=0 selects the plain form
     static const bool use_nt = !(getenv("NERFSIG_ADAM_NT") && getenv("NERFSIG_ADAM_NT")[0] == '0');
     if (next_message && use_nt)
-        k_codebook_adam_sel_nt<true><<<NSIG_TABLE_ROWS / 2 / 256, 256, 0, st>>>(reinterpret_cast<const float4 *>(G), a, message, scratch, D, beta1, beta2, eps,
+        k_codebook_adam_sel<true, true><<<NSIG_TABLE_ROWS / 2 / 256, 256, 0, st>>>(reinterpret_cast<const float4 *>(G), a, message, scratch, D, beta1, beta2, eps,
                                                                                  grad_scale, next_message, reinterpret_cast<float4 *>(S_next));
     else if (next_message)
-        k_codebook_adam_sel<true><<<NSIG_TABLE_ROWS / 2 / 256, 256, 0, st>>>(reinterpret_cast<const float4 *>(G), a, message, scratch, D, beta1, beta2, eps,
+        k_codebook_adam_sel<true, false><<<NSIG_TABLE_ROWS / 2 / 256, 256, 0, st>>>(reinterpret_cast<const float4 *>(G), a, message, scratch, D, beta1, beta2, eps,
                                                                               grad_scale, next_message, reinterpret_cast<float4 *>(S_next));
     else
-        k_codebook_adam_sel<false><<<NSIG_TABLE_ROWS / 2 / 256, 256, 0, st>>>(reinterpret_cast<const float4 *>(G), a, message, scratch, D, beta1, beta2, eps,
+        k_codebook_adam_sel<false, false><<<NSIG_TABLE_ROWS / 2 / 256, 256, 0, st>>>(reinterpret_cast<const float4 *>(G), a, message, scratch, D, beta1, beta2, eps,
                                                                                grad_scale, nullptr, nullptr);
     return check_launch(who);
 }
