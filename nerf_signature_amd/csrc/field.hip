@@ -650,7 +650,9 @@ static int fill_base_tables(const float *const *host, TablePtrs &base, const cha
 // Level -> XCD-slot assignment of k_encode_planes: the six finest levels each get a slot of their own or share it only
 // with coarse (cache-resident) levels.  NERFSIG_SLOTS="16|15|14|..." overrides it (experiments).
 static SlotTable default_slots(bool with_codebook) {
-    static const char *kWith = "16|15|14|13|12,0,1|11,2,3|10,9,4|8,7,6,5";
+    // (with one tile per workgroup the two finest levels alone, the next two with one coarse level each: 236-239 us against 251-254 us
+    //  for "16|15|14|13|12,0,1|11,2,3|10,9,4|8,7,6,5", same-box sweep in profiles/r01_k_encoder_slots_sweep.txt)
+    static const char *kWith = "16|15|14,0|13,1|12,2,3|11,4,5|10,9|8,7,6";
     static const char *kWithout = "15|14|13|12|11,0,1|10,2,3|9,8,4|7,6,5";
     const char *spec = getenv(with_codebook ? "NERFSIG_SLOTS" : "NERFSIG_SLOTS_CLEAN");
     if (spec == nullptr || *spec == 0) spec = with_codebook ? kWith : kWithout;
