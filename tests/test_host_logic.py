@@ -200,6 +200,40 @@ def test_data_parallel_exchange_gloo_world2():
     assert torch.equal(res[0][2], res[1][2])
 
 
+def _force_exchange_worker(q):
+    import torch.distributed as dist
+    from nerf_signature_amd import dp
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{29800 + os.getpid() % 150}", rank=0, world_size=1)
+    lin = torch.nn.Linear(3, 2)
+    for p in lin.parameters():
+        p.grad = torch.ones_like(p)
+    G = torch.full((4, 2), 2.0)
+    ex = dp.GradExchange(list(lin.parameters()), average=False)
+    inactive = not dp.exchange_active()
+    ex(G)                                              # one rank, no switch: nothing runs
+    idle_bytes = ex.bytes_per_step
+    os.environ["NERFSIG_FORCE_EXCHANGE"] = "1"
+    active = dp.exchange_active()
+    ex(G)                                              # rehearsal: the collectives run over the one-rank group, values unchanged
+    q.put((inactive, idle_bytes, active, ex.bytes_per_step, float(G.sum()), float(lin.weight.grad.sum())))
+    dist.destroy_process_group()
+
+
+def test_exchange_rehearsal_switch_on_one_rank():
+    """NERFSIG_FORCE_EXCHANGE=1 makes a world-size-1 process group run the exchange (what the GPU rehearsal of the multi-rank
+    execution relies on); without it a one-rank group exchanges nothing."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_force_exchange_worker, args=(q,))
+    p.start()
+    inactive, idle_bytes, active, nbytes, g_sum, w_sum = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert inactive and idle_bytes == 0 and active
+    assert nbytes == (8 + 6 + 2) * 4 and g_sum == 16.0 and w_sum == 6.0
+
+
 def test_checkpoint_round_trip_and_clean_checkpoint(tmp_path):
     """N4: the reference's checkpoint dict format; strict=False loading of a clean (stage-1) checkpoint; fp16 tcnn params."""
     from nerf_signature_amd import checkpoint as ck
