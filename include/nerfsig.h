@@ -293,6 +293,19 @@ int rm_finish_bwd(const float *grad_image, const float *grad_depth, const float 
                   uint32_t bg_stride, uint32_t N, float *grad_weights_sum, float *grad_depth_in, nsig_stream_t stream);
 
 /*
+ * Opening launch of a captured training step (the loop body of utils_wtmk_disen.py:1164-1181 replayed as a hipGraph): zero-fills
+ * G [n_floats] (optimizer.zero_grad for the shared codebook gradient) and copies `width` floats of slot (*counter % slots) of a
+ * ring in PINNED host memory (ring_dev = its device-side address, [slots][width]: this step's message and the next one's, :1165) into msg [width], then
+ * advances *counter (device uint32).  The host fills slot k % slots before launching replay k and must not overwrite a slot
+ * before the replay that reads it has finished.
+ */
+int loop_step_begin(float *G, uint32_t n_floats, const float *ring_dev, uint32_t slots, uint32_t width, uint32_t *counter, float *msg,
+                    nsig_stream_t stream);
+/* The device-side address of pinned (hipHostMalloc / torch pin_memory) host memory, or NULL: ring_dev above is
+ * nsig_host_device_pointer(ring_host), resolved once, outside any stream capture. */
+void *nsig_host_device_pointer(const void *pinned_host);
+
+/*
  * The losses of Trainer.train_step (utils_wtmk_disen.py:615-640, loss_w = 'bce'):
  *   losses3 = { mean((content - gt)^2),  mean BCEWithLogits(temp * decoded, message),  lambda_w * loss_w + lambda_i * loss_i }
  * over n_content floats and D logits.  d_content / d_decoded receive d(loss_i)/d(content), d(loss_w)/d(decoded); wm_loss_bwd

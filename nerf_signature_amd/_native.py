@@ -18,6 +18,7 @@ _vp, _u32, _fl, _int, _sz = _c.c_void_p, _c.c_uint32, _c.c_float, _c.c_int, _c.c
 SIGNATURES = {
     "nsig_abi_version": [],
     "nsig_last_error": [],
+    "nsig_host_device_pointer": [_vp],
     "rg_get_rays": [_vp, _fl, _fl, _fl, _fl, _u32, _u32, _vp, _u32, _u32, _vp, _vp, _vp],
     "rm_near_far_from_aabb": [_vp, _vp, _vp, _u32, _fl, _vp, _vp, _vp],
     "rm_sph_from_ray": [_vp, _vp, _fl, _u32, _vp, _vp],
@@ -55,6 +56,7 @@ SIGNATURES = {
     "rm_composite_train_finish_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _fl, _u32, _vp, _vp, _vp],
     "rm_finish_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp],
     "rm_finish_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp],
+    "loop_step_begin": [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp],
     "wm_loss_fwd": [_vp, _vp, _u32, _vp, _vp, _u32, _fl, _fl, _fl, _vp, _vp, _vp, _vp],
     "wm_loss_bwd": [_vp, _vp, _vp, _fl, _fl, _vp, _u32, _vp, _u32, _vp, _vp, _vp],
     "dec_bn_gelu_fwd": [_vp, _vp, _vp, _u32, _u32, _u32, _fl, _vp, _vp, _vp],
@@ -75,7 +77,7 @@ SIGNATURES = {
     "hg_scatter_plan": [_vp, _u32, _fl, _vp, _vp],
     "hg_scatter_planned": [_vp, _u32, _vp, _vp],
 }
-_RESTYPES = {"nsig_last_error": _c.c_char_p, "rm_march_train_scratch_bytes": _sz, "mlp_packed_bytes": _sz, "hg_planes_bytes": _sz, "dec_workspace_bytes": _sz, "hg_scatter_levels_scratch_bytes": _sz, "hg_scatter_binned_scratch_bytes": _sz, "hg_scatter_plan_bytes": _sz}
+_RESTYPES = {"nsig_last_error": _c.c_char_p, "nsig_host_device_pointer": _c.c_void_p, "rm_march_train_scratch_bytes": _sz, "mlp_packed_bytes": _sz, "hg_planes_bytes": _sz, "dec_workspace_bytes": _sz, "hg_scatter_levels_scratch_bytes": _sz, "hg_scatter_binned_scratch_bytes": _sz, "hg_scatter_plan_bytes": _sz}
 
 _lib = None
 

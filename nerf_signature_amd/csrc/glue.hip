@@ -85,9 +85,44 @@ __global__ void __launch_bounds__(256) k_wm_loss_bwd(const float *__restrict__ g
     if (i < D) g_decoded[i] = cw * d_decoded[i];
 }
 
+// Opening kernel of a captured training step: zero-fills the shared gradient buffer (torch's zero_grad) and stages this
+// step's message words from a ring in pinned host memory into the device tensor the step's kernels read -- slot = the number
+// of replays so far modulo `slots`, counted on the device, so a replayed graph needs no host-to-device copy in front of it.
+__global__ void __launch_bounds__(256) k_step_begin(float4 *__restrict__ G4, uint32_t n4, const float *__restrict__ ring, uint32_t slots, uint32_t width,
+                                                    uint32_t *__restrict__ counter, float *__restrict__ msg) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) G4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (blockIdx.x == 0) {
+        const uint32_t slot = *counter % slots;      // every thread reads the count before thread 0 advances it
+        if (threadIdx.x < width) msg[threadIdx.x] = ring[(size_t)slot * width + threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == 0) *counter = *counter + 1u;
+    }
+}
+
 }  // namespace nsig
 
 using namespace nsig;
+
+NSIG_EXPORT void *nsig_host_device_pointer(const void *pinned_host) {
+    void *dev = nullptr;
+    if (pinned_host == nullptr || hipHostGetDevicePointer(&dev, const_cast<void *>(pinned_host), 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return dev;
+}
+
+NSIG_EXPORT int loop_step_begin(float *G, uint32_t n_floats, const float *ring_dev, uint32_t slots, uint32_t width, uint32_t *counter, float *msg,
+                                nsig_stream_t stream) {
+    NSIG_REQUIRE(G && ring_dev && counter && msg, "loop_step_begin: null pointer");
+    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(G) & 15) == 0 && n_floats % 4 == 0, "loop_step_begin: G must be 16-byte aligned with a multiple of 4 floats");
+    NSIG_REQUIRE(slots >= 1 && width >= 1 && width <= 256, "loop_step_begin: slots >= 1 and 1 <= width <= 256");
+    const uint32_t n4 = n_floats / 4;
+    k_step_begin<<<ceil_div(n4 > 0 ? n4 : 1u, 256u), 256, 0, as_stream(stream)>>>(reinterpret_cast<float4 *>(G), n4, ring_dev, slots,
+                                                                                 width, counter, msg);
+    return check_launch("loop_step_begin");
+}
 
 NSIG_EXPORT int rm_finish_fwd(const float *image, const float *depth, const float *weights_sum, const float *nears, const float *fars,
                               const float *bg, uint32_t bg_stride, uint32_t N, float *image_out, float *depth_out, nsig_stream_t stream) {

@@ -6,6 +6,9 @@ distortion 'none', loss_w 'bce'): a block render decoded into message logits, a 
 with the clean image, loss = lambda_w * BCE(10 * logits, message) + lambda_i * MSE.
 `WatermarkLoop.step` is the loop body: zero grads, train_step, backward, gradient exchange, optimiser step --
 with no host synchronisation of its own (losses stay on the device)."""
+import ctypes
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -214,7 +217,7 @@ class GraphedWatermarkLoop:
     points than that -- such a step dropped the rays that did not fit, like the reference's bounded mode."""
 
     def __init__(self, model, optimizer, render_kwargs, data, lambda_w=1.0, lambda_i=1.0, lr_lambda=None, headroom=0.0, native_dense_adam=True,
-                 overlap_content=True, march_ahead=None, presum_in_adam=True):
+                 overlap_content=True, march_ahead=None, presum_in_adam=True, stage_in_graph=True):
         """presum_in_adam: the captured optimiser kernel also writes the pre-summed codebook of the NEXT step's message
         (opt_codebook_adam_sel_next: +9 % traffic inside an HBM-streaming kernel instead of a 128 MiB pass at the head of every step).
         The next message is handed over one step early -- `step(message_k, next_message=message_k1)`, a one-element look-ahead over
@@ -230,6 +233,9 @@ class GraphedWatermarkLoop:
         optimiser and the pre-sum lost its cover."""
         self.march_ahead = overlap_content if march_ahead is None else bool(march_ahead)
         self.presum_in_adam = bool(presum_in_adam)
+        # stage_in_graph: the captured step opens with loop_step_begin, which zero-fills G and fetches the step's message words from the
+        # pinned ring itself (slot = replays so far, counted on the device) -- no host-to-device copy command between two replays
+        self.stage_in_graph = bool(stage_in_graph) and os.environ.get("NERFSIG_STAGE_IN_GRAPH", "1") != "0"
         self._s_for = None            # host copy of the message the pre-sum buffer currently belongs to (None: unknown / stale)
         self.marched = None
         self._pending_content = None
@@ -255,8 +261,12 @@ class GraphedWatermarkLoop:
         self.msg_dev, self.msg_next_dev = self.msg_all[:D], self.msg_all[D:]
         # The host runs ahead of the GPU by many replays, so the pinned staging buffer of a step must not be rewritten until its
         # asynchronous copy has executed: a ring of buffers, each guarded by an event.
-        self.msg_ring = [torch.zeros(2 * D, dtype=torch.float32).pin_memory() for _ in range(16)]
+        self.msg_ring = torch.zeros(16, 2 * D, dtype=torch.float32).pin_memory()      # one row per in-flight step
         self.msg_events = [None] * len(self.msg_ring)
+        self.stage_counter = torch.zeros(1, dtype=torch.int32, device=dev)           # replays so far (advanced by loop_step_begin)
+        self.ring_dev = nv.fn("nsig_host_device_pointer")(ctypes.c_void_p(self.msg_ring.data_ptr())) if self.stage_in_graph else None
+        if self.stage_in_graph and not self.ring_dev:
+            self.stage_in_graph = False         # the ring is not device-mapped on this platform: keep the per-step copy
         self.base_lr = float(optimizer.param_groups[0]["lr"])
         self.lr_dev = torch.tensor(self.base_lr, dtype=torch.float32, device=dev)
         for g in optimizer.param_groups:
@@ -269,7 +279,11 @@ class GraphedWatermarkLoop:
 
     # -- pieces of one step (executed eagerly during warm-up, then under capture)
     def _forward_backward(self):
-        self.sink.zero_()
+        if self.stage_in_graph and torch.cuda.is_current_stream_capturing():
+            nv.call("loop_step_begin", nv.ptr(self.sink.G), self.sink.G.numel(), ctypes.c_void_p(self.ring_dev), len(self.msg_ring),
+                    self.msg_all.numel(), nv.ptr(self.stage_counter), nv.ptr(self.msg_all), nv.stream())
+        else:
+            self.sink.zero_()
         prev = fo.set_plan_stream(self.plan_stream)    # the scatter plans need the sample positions only: beside the forward pass
         try:
             out = train_step(self.model, self.data, self.msg_dev, self.render_kwargs, self.lambda_w, self.lambda_i, side_stream=self.side_stream,
@@ -329,18 +343,19 @@ class GraphedWatermarkLoop:
         a, b = self.model.step_counter[self.capacity_rows, 0].tolist()
         return (a, b) if self.side_stream is None else (b, a)     # issue order: with a side stream the content render comes first
 
-    def _set_inputs(self, message, data, next_data=None, next_message=None):
-        slot = self.steps_done % len(self.msg_ring)
+    def _set_inputs(self, message, data, next_data=None, next_message=None, eager_copy=True):
+        slot = self.steps_done % len(self.msg_ring)      # == the device's replay count modulo the ring: every step() replays exactly once
         if self.msg_events[slot] is not None:
             self.msg_events[slot].synchronize()      # blocks only if the GPU is a whole ring behind
         D = self.msg_dev.numel()
         self.msg_ring[slot][:D].copy_(message.detach().to("cpu", torch.float32))
         # an unannounced next message: the optimiser pre-sums for this step's bits again (harmless) and _s_for goes stale
         self.msg_ring[slot][D:].copy_((message if next_message is None else next_message).detach().to("cpu", torch.float32))
-        self.msg_all.copy_(self.msg_ring[slot], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self.msg_events[slot] = ev
+        if eager_copy:      # (a replay with stage_in_graph fetches the row itself; step() then guards the slot with an event behind the replay)
+            self.msg_all.copy_(self.msg_ring[slot], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.msg_events[slot] = ev
         if self.lr_lambda is not None:
             self.lr_dev.fill_(self.base_lr * self.lr_lambda(self.steps_done))
         if self._pending_content is not None:     # the content part that came with the block rays marched at the end of the last replay
@@ -453,14 +468,21 @@ class GraphedWatermarkLoop:
                 self._set_inputs(message, data)
                 data = None
             self.prepare(message)
-        self._set_inputs(message, data, next_data, next_message)
+        unannounced = False
         if self.presum_in_adam:
             msg_cpu = message.detach().to("cpu", torch.float32)
-            if self._s_for is None or not torch.equal(self._s_for, msg_cpu):
+            unannounced = self._s_for is None or not torch.equal(self._s_for, msg_cpu)
+        self._set_inputs(message, data, next_data, next_message, eager_copy=unannounced or not self.stage_in_graph)
+        if self.presum_in_adam:
+            if unannounced:
                 self.model.prepare_message(self.msg_dev)     # not announced one step early: the stand-alone pass, before the replay
             self._s_for = None if next_message is None else next_message.detach().to("cpu", torch.float32).clone()
         g1, g2 = self.graphs
         g1.replay()
+        if self.stage_in_graph:      # the ring row of this step may be rewritten once this replay's opening kernel has read it
+            ev = torch.cuda.Event()
+            ev.record()
+            self.msg_events[self.steps_done % len(self.msg_ring)] = ev
         if g2 is not None:
             self.exchange(self.sink.G)
             g2.replay()

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     text = open(os.path.join(ROOT, "include", "nerfsig.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"^(?:int|size_t|const char \*)\s*(\w+)\s*\(", text, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|size_t|const char \*|void \*)\s*(\w+)\s*\(", text, flags=re.M)))
 
 
 @pytest.fixture(scope="module")
