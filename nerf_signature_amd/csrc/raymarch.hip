@@ -119,7 +119,7 @@ __global__ void k_get_rays(const float *__restrict__ poses, float fx, float fy, 
 
 struct GridView {
     const uint8_t *bits;
-    float bound, dt_gamma, dt_min, dt_max, inv_H, H3f, Hf, Cf, top;
+    float bound, dt_gamma, dt_min, dt_max, dt_const, inv_H, H3f, Hf, Cf, top;
     double Hd;
 };
 
@@ -131,6 +131,7 @@ __host__ inline GridView make_grid_view(const uint8_t *bits, float bound, float 
     g.dt_gamma = dt_gamma;
     g.dt_min = (2.0f * kSqrt3) / (float)max_steps;                      // raymarching.cu:345
     g.dt_max = ((2.0f * kSqrt3) * (float)(1u << (C - 1))) / (float)H;   // raymarching.cu:346
+    g.dt_const = fminf(g.dt_max, fmaxf(g.dt_min, 0.0f));                 // the step when dt_gamma == 0: clamp(0, dt_min, dt_max), which is dt_max when max_steps is so small that dt_min > dt_max
     g.inv_H = 1.0f / (float)H;
     g.H3f = (float)(H * H * H);
     g.Hf = (float)H;
@@ -294,7 +295,7 @@ __global__ void __launch_bounds__(256) k_march_index(const float *__restrict__ r
     const Ray r(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n);
     Walker<kOneCascade> w(g, r);
     const float far = fars[n];
-    auto step = [&](float t) { return kConstDt ? g.dt_min : step_len(g, t); };  // dt_gamma == 0: clamp(0, dt_min, dt_max) == dt_min
+    auto step = [&](float t) { return kConstDt ? g.dt_const : step_len(g, t); };  // dt_gamma == 0: clamp(0, dt_min, dt_max), a constant
     float t_base = start_param(g, nears[n], noises ? noises[n] : 0.0f);
     float *rec = t_rec + (size_t)n * max_steps;
     float *tl = ts[wid];
@@ -307,7 +308,7 @@ __global__ void __launch_bounds__(256) k_march_index(const float *__restrict__ r
         if (kConstDt) {
             // every return path of chunk_closed_form before the lane-dependent part is wave-uniform; the tie test after the
             // boundary is uniform too, so `closed` is the same in all lanes
-            closed = chunk_closed_form(t_base, g.dt_min, lane, tj);
+            closed = chunk_closed_form(t_base, g.dt_const, lane, tj);
             closed = __all(closed);
             if (!closed) tj = t_base;
         }
