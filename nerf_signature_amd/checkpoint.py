@@ -46,9 +46,7 @@ def load_checkpoint(path_or_dict, model, optimizer=None, lr_scheduler=None, scal
             v = v.to(own[k].dtype)          # e.g. fp16 tcnn params
         fixed[k] = v
     missing, unexpected = model.load_state_dict(fixed, strict=False)
-    for attr in ("_packed_cache", "_presum_cache"):
-        if hasattr(model, attr):
-            setattr(model, attr, None)
+    invalidate_derived(model)
     meta = {}
     if "model" in ckpt:
         if getattr(model, "cuda_ray", False):
@@ -58,7 +56,58 @@ def load_checkpoint(path_or_dict, model, optimizer=None, lr_scheduler=None, scal
                 model.mean_density = ckpt["mean_density"]
         if not model_only:
             meta = {k: ckpt[k] for k in ("epoch", "global_step", "stats") if k in ckpt}
+            # like the reference (:1497-1517): a section that does not fit (e.g. a plain-Adam state of another parameter grouping)
+            # is reported and skipped, the model-only resume continues
             for obj, key in ((optimizer, "optimizer"), (lr_scheduler, "lr_scheduler"), (scaler, "scaler")):
                 if obj is not None and key in ckpt:
-                    obj.load_state_dict(ckpt[key])
+                    try:
+                        if key == "optimizer":
+                            _load_optimizer(obj, ckpt[key])
+                        else:
+                            obj.load_state_dict(ckpt[key])
+                    except Exception as e:          # noqa: BLE001 -- the reference catches everything here and warns
+                        meta.setdefault("skipped", []).append(key)
+                        print(f"[WARN] Failed to load {key}: {type(e).__name__}: {e}")
     return list(missing), list(unexpected), meta
+
+
+def invalidate_derived(model):
+    """The model's derived device images after its parameters were overwritten.  Both BUFFERS -- the packed MLP weights and the
+    pre-summed codebook -- are kept and only their keys invalidated: a captured GraphedWatermarkLoop holds them by raw address
+    (field_fwd's weight image; adopt_presum, S_next of opt_codebook_adam_sel_next), so returning them to the allocator would leave
+    later replays reading and writing freed memory.  A loop registered on the model re-packs the weights now (no replay would) and
+    forgets which message the pre-sum belongs to."""
+    for attr in ("_packed_cache", "_presum_cache"):
+        cache = getattr(model, attr, None)
+        if cache is not None:
+            setattr(model, attr, (None, cache[1]))
+    for loop in list(getattr(model, "_graphed_loops", ())):
+        loop.invalidate()
+
+
+def _load_optimizer(optimizer, state):
+    """optimizer.load_state_dict that keeps every existing state tensor and device scalar IN PLACE.  A captured
+    GraphedWatermarkLoop holds the addresses of exp_avg / exp_avg_sq / step and of the learning-rate tensor it installed into the
+    param groups; torch's load_state_dict would replace them by fresh tensors (and the tensor lr by a float), leaving the replays
+    updating freed memory and detached from the loaded values.  Here the loaded values are copied into the old storage; state the
+    checkpoint does not hold for a parameter that had some is reset to zero (Adam's initial state) in the old storage."""
+    lr_tensors = [g["lr"] if torch.is_tensor(g.get("lr")) else None for g in optimizer.param_groups]
+    old = {p: dict(st) for p, st in optimizer.state.items() if len(st)}
+    optimizer.load_state_dict(state)
+    for g, lr_dev in zip(optimizer.param_groups, lr_tensors):
+        if lr_dev is not None:
+            lr_dev.fill_(float(g["lr"]))
+            g["lr"] = lr_dev
+    for p, before in old.items():
+        st = optimizer.state[p]
+        for k, ov in before.items():
+            if not torch.is_tensor(ov):
+                continue
+            nv_ = st.get(k)
+            if torch.is_tensor(nv_) and nv_.shape == ov.shape:
+                ov.copy_(nv_.to(ov.device, ov.dtype))
+            elif nv_ is None:
+                ov.zero_()
+            else:
+                continue
+            st[k] = ov

@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyz
             const uint32_t q0 = 2u * (uint32_t)h;
             plan.queue[h ? dst.z : dst.x] = pair_entry(ix, pair_hash(iy, iz, q0), wx, wy, wz, g0, g1, q0);
             plan.queue[h ? dst.w : dst.y] = pair_entry(ix, pair_hash(iy, iz, q0 + 1u), wx, wy, wz, g0, g1, q0 + 1u);
-            gbits = max(gbits, __float_as_uint(fmaxf(fabsf(g0), fabsf(g1))));   // non-negative floats order like their bit patterns
+            gbits = max(gbits, max(__float_as_uint(g0) & 0x7fffffffu, __float_as_uint(g1) & 0x7fffffffu));   // |x| as bit patterns: ordered like the values, NaN above +inf (fmaxf would drop a NaN)
             continue;
         }
         if (rec_out != nullptr && h == 0) {

@@ -250,7 +250,7 @@ __device__ inline bool record_pairs(const uint4 *__restrict__ rec4, uint32_t m, 
     const uint4 ra = rec4[2 * (size_t)m], rb = rec4[2 * (size_t)m + 1];
     const float g0 = __uint_as_float(rb.y), g1 = __uint_as_float(rb.z);
     if (g0 == 0.0f && g1 == 0.0f) return false;   // padding rows and terminated rays
-    gabs = fmaxf(fabsf(g0), fabsf(g1));
+    gabs = __uint_as_float(max(__float_as_uint(g0) & 0x7fffffffu, __float_as_uint(g1) & 0x7fffffffu));   // integer max of |bits|: a NaN stays visible
 #pragma unroll
     for (uint32_t q = 0; q < 4; ++q) slices[q] = pair_slice(pair_hash(ra.x >> 16, ra.y, q));
     return true;
@@ -425,12 +425,14 @@ __global__ void __launch_bounds__(1024) k_scatter_binned(const BinHeader *__rest
     for (uint32_t j = 0; j < slice; ++j) start += hd->counts[j];
     const uint32_t n = hd->counts[slice], chunk = ceil_div(n, replicas);
     const uint32_t beg = min(n, replica * chunk), end = min(n, beg + chunk);
-    // |contribution| <= gmax < 2^E; 2^11 of them stay below 2^62 with k = 51 - E.  Non-finite gradients: k = 0, the row sums are
-    // then meaningless exactly like the float sums of NaN/inf would be.
+    // |contribution| <= gmax < 2^E; 2^11 of them stay below 2^62 with k = 51 - E.  A non-finite gradient anywhere in the launch
+    // (an overflowing scaled loss under torch's GradScaler) poisons every row of G with NaN, so that the scaler's inf check sees it
+    // exactly as it sees the inf/NaN float sums of the reference's dense gradients and skips the step.
     const uint32_t gb = hd->gmax_bits;
+    const bool poisoned = gb >= 0x7f800000u;
     int E;
-    frexpf(__uint_as_float(gb), &E);
-    const int k = gb >= 0x7f800000u ? 0 : 51 - E;
+    frexpf(__uint_as_float(poisoned ? 0x3f800000u : gb), &E);
+    const int k = poisoned ? 0 : 51 - E;
     __syncthreads();
     constexpr int kAhead = 4;
     for (uint32_t i0 = beg + threadIdx.x; i0 < end; i0 += blockDim.x * kAhead) {
@@ -453,7 +455,8 @@ __global__ void __launch_bounds__(1024) k_scatter_binned(const BinHeader *__rest
     float *out = G + 2 * (size_t)slice * kBinRows;
     for (uint32_t i = threadIdx.x; i < 2u * kBinRows; i += blockDim.x) {
         const long long v = (long long)acc64[i];
-        if (replicas == 1) out[i] = v != 0 ? (float)ldexp((double)v, -k) : 0.0f;
+        if (poisoned) out[i] = __uint_as_float(0x7fc00000u);
+        else if (replicas == 1) out[i] = v != 0 ? (float)ldexp((double)v, -k) : 0.0f;
         else if (v != 0) atomicAdd(out + i, (float)ldexp((double)v, -k));
     }
 }

@@ -105,13 +105,14 @@ def level_lookup(x01, resolution):
     return rows, w
 
 
-def pack_weights(sigma_params, color_params):
-    """Split-bf16 MFMA operand image of the two flat parameter vectors -> mlp_pack_weights."""
+def pack_weights(sigma_params, color_params, out=None):
+    """Split-bf16 MFMA operand image of the two flat parameter vectors -> mlp_pack_weights (into `out` when given)."""
     if sigma_params.numel() != 3072 or color_params.numel() != 7168:
         raise ValueError(f"expected sigma_params[3072] and color_params[7168], got {sigma_params.numel()} and {color_params.numel()}")
     sp = sigma_params.detach().contiguous().float()
     cp = color_params.detach().contiguous().float()
-    packed = torch.empty(int(nv.fn("mlp_packed_bytes")()), dtype=torch.uint8, device=sp.device)
+    n = int(nv.fn("mlp_packed_bytes")())
+    packed = out if out is not None and out.numel() == n and out.device == sp.device else torch.empty(n, dtype=torch.uint8, device=sp.device)
     nv.call("mlp_pack_weights", nv.ptr(sp), nv.ptr(cp), nv.ptr(packed), nv.stream())
     return packed
 

@@ -58,14 +58,15 @@ class NeRFNetwork(NeRFRenderer):
         sp, cp = self.sigma_net.params, self.color_net.params
         key = (sp.data_ptr(), sp._version, cp.data_ptr(), cp._version)
         if self._packed_cache is None or self._packed_cache[0] != key:
-            self._packed_cache = (key, fo.pack_weights(sp, cp))
+            # re-packed IN PLACE when a buffer exists: a captured graph holds its address (checkpoint.invalidate_derived)
+            self._packed_cache = (key, fo.pack_weights(sp, cp, out=None if self._packed_cache is None else self._packed_cache[1]))
         return self._packed_cache[1]
 
     def _presum(self, selected, bits):
         """S = sum of the selected codebook tables; reused while neither the message nor the tables change
         (the two renders of one training step, every chunk of a staged full-image render)."""
         key = (bits, tuple((t.data_ptr(), t._version) for t in selected))
-        if self._presum_cache is None or self._presum_cache[0] != key:
+        if self._presum_cache is None or self._presum_cache[0] is None or self._presum_cache[0] != key:
             S = self._presum_cache[1] if self._presum_cache is not None else None
             self._presum_cache = (key, fo.codebook_presum(selected, out=S))
             self._presum_produced()
@@ -102,7 +103,7 @@ class NeRFNetwork(NeRFRenderer):
         """All 2D tables + the pre-sum chosen by the device-resident message (no host read of its bits)."""
         tables = self.msg_encoder.tables()
         key = ("dev", message.data_ptr(), message._version, tuple((t.data_ptr(), t._version) for t in tables))
-        if self._presum_cache is None or self._presum_cache[0] != key:
+        if self._presum_cache is None or self._presum_cache[0] is None or self._presum_cache[0] != key:
             S = self._presum_cache[1] if self._presum_cache is not None else None
             self._presum_cache = (key, fo.codebook_presum_sel(tables, message, out=S))
             self._presum_produced()

@@ -134,6 +134,9 @@ class WatermarkLoop:
 
     def step(self, data, message):
         """message: float tensor of 0./1. (keep it on the CPU to avoid the D2H read of its bits)."""
+        if getattr(self.model, "device_select", False):
+            raise RuntimeError("the model is in device-select mode (a GraphedWatermarkLoop prepared it): its sink records all 2D tables as "
+                               "selected, which the eager optimiser step would update wrongly; call GraphedWatermarkLoop.close() first")
         self.optimizer.zero_grad(set_to_none=True)
         if self.sink is not None:
             self.sink.zero_()
@@ -275,7 +278,25 @@ class GraphedWatermarkLoop:
         self.graphs = None
         self.out = None
         self.steps_done = 0
+        self._replays = 0             # replays of the opening graph so far == the device's stage_counter (ring slot of the next step)
         self.capacity_rows = None
+        if not hasattr(model, "_graphed_loops"):
+            model._graphed_loops = []
+        model._graphed_loops.append(self)
+
+    def invalidate(self):
+        """The model's parameters were overwritten from outside (checkpoint.load_checkpoint): the pre-sum buffer no longer belongs to
+        any announced message, so the next step runs the stand-alone pre-sum before its replay; the packed MLP weights are refreshed
+        here, in the buffer the graph reads (the captured step never re-packs)."""
+        self._s_for = None
+        self.model._packed()
+
+    def close(self):
+        """Detach from the model: the eager loop (or another graphed loop) may drive it again."""
+        self.model.device_select = False
+        self.model.point_capacity = None
+        if self in getattr(self.model, "_graphed_loops", ()):
+            self.model._graphed_loops.remove(self)
 
     # -- pieces of one step (executed eagerly during warm-up, then under capture)
     def _forward_backward(self):
@@ -344,7 +365,7 @@ class GraphedWatermarkLoop:
         return (a, b) if self.side_stream is None else (b, a)     # issue order: with a side stream the content render comes first
 
     def _set_inputs(self, message, data, next_data=None, next_message=None, eager_copy=True):
-        slot = self.steps_done % len(self.msg_ring)      # == the device's replay count modulo the ring: every step() replays exactly once
+        slot = self._replays % len(self.msg_ring)        # == the device's replay count modulo the ring (advanced right behind every replay of g1)
         if self.msg_events[slot] is not None:
             self.msg_events[slot].synchronize()      # blocks only if the GPU is a whole ring behind
         D = self.msg_dev.numel()
@@ -479,10 +500,12 @@ class GraphedWatermarkLoop:
             self._s_for = None if next_message is None else next_message.detach().to("cpu", torch.float32).clone()
         g1, g2 = self.graphs
         g1.replay()
+        slot = self._replays % len(self.msg_ring)
+        self._replays += 1           # immediately: the device counter has advanced whatever happens to the rest of this step (exchange, g2)
         if self.stage_in_graph:      # the ring row of this step may be rewritten once this replay's opening kernel has read it
             ev = torch.cuda.Event()
             ev.record()
-            self.msg_events[self.steps_done % len(self.msg_ring)] = ev
+            self.msg_events[slot] = ev
         if g2 is not None:
             self.exchange(self.sink.G)
             g2.replay()

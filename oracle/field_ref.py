@@ -346,3 +346,96 @@ def get_rays(poses, intrinsics, H, W, inds=None):
     rays_d = directions @ poses[:, :3, :3].transpose(-1, -2)
     rays_o = poses[..., :3, 3][..., None, :].expand_as(rays_d)
     return rays_o, rays_d
+
+
+# ------------------------------------------------------------------ density-grid maintenance
+
+def _grid_cells(G, S):
+    """Grid cells in S^3 blocks, x outermost (renderer_wtmk.py:393-408 / 463-472): yields (coords [n,3] int32, morton index [n] int64)."""
+    from . import raymarch_ref as orm
+    axis = torch.arange(G, dtype=torch.int32).split(S)
+    for xs in axis:
+        for ys in axis:
+            for zs in axis:
+                xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
+                coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
+                yield coords, torch.from_numpy(orm.morton3D(coords.numpy())).long()
+
+
+def mark_untrained_grid(state, poses, intrinsic, S=64):
+    """renderer_wtmk.py:380-442.  state: {'density_grid' [C,G^3] torch fp32, 'bound', 'grid_size'}; cells seen by no camera get -1.
+    Returns the number of marked cells."""
+    grid, bound, G = state["density_grid"], state["bound"], state["grid_size"]
+    C = grid.shape[0]
+    poses = torch.as_tensor(poses)
+    B = poses.shape[0]
+    fx, fy, cx, cy = intrinsic
+    count = torch.zeros_like(grid)
+    for coords, indices in _grid_cells(G, S):
+        world = (2 * coords.float() / (G - 1) - 1).unsqueeze(0)                    # :411
+        for cas in range(C):
+            b = min(2 ** cas, bound)
+            half = b / G
+            cas_world = world * (b - half)                                         # :418
+            head = 0
+            while head < B:
+                tail = min(head + S, B)
+                cam = cas_world - poses[head:tail, :3, 3].unsqueeze(1)             # :426
+                cam = cam @ poses[head:tail, :3, :3]
+                mask_z = cam[:, :, 2] > 0
+                mask_x = torch.abs(cam[:, :, 0]) < cx / fx * cam[:, :, 2] + half * 2
+                mask_y = torch.abs(cam[:, :, 1]) < cy / fy * cam[:, :, 2] + half * 2
+                count[cas, indices] += (mask_z & mask_x & mask_y).sum(0).reshape(-1)
+                head += S
+    grid[count == 0] = -1                                                          # :439
+    return int((count == 0).sum())
+
+
+def update_extra_state(state, density_fn, message=None, decay=0.95, S=128, rand_like=torch.rand_like, randint=torch.randint):
+    """renderer_wtmk.py:445-538.  state: density_grid [C,G^3], density_bitfield, bound, grid_size, density_scale, density_thresh,
+    iter_density, mean_density, step_counter [16,2] int32, local_step, mean_count.  density_fn(x [n,3], message) -> {'sigma': [n]}.
+    `rand_like` / `randint`: the two draws the reference makes on its device generator (:478,488,492,514)."""
+    from . import raymarch_ref as orm
+    grid, bound, G = state["density_grid"], state["bound"], state["grid_size"]
+    C = grid.shape[0]
+    tmp = -torch.ones_like(grid)
+    hits = torch.zeros(grid.shape, dtype=torch.int64)                              # (oracle only) how often a cell is written
+    if state["iter_density"] < 16:                                                 # :456 full update
+        for coords, indices in _grid_cells(G, S):
+            xyzs = 2 * coords.float() / (G - 1) - 1
+            for cas in range(C):
+                b = min(2 ** cas, bound)
+                half = b / G
+                cas_xyzs = xyzs * (b - half)
+                cas_xyzs += (rand_like(cas_xyzs) * 2 - 1) * half                   # :478
+                sig = density_fn(cas_xyzs, message)["sigma"].reshape(-1).detach() * state["density_scale"]
+                tmp[cas, indices] = sig
+    else:                                                                          # :486 partial update
+        N = G ** 3 // 4
+        for cas in range(C):
+            coords = randint(0, G, (N, 3))
+            indices = torch.from_numpy(orm.morton3D(coords.int().numpy())).long()
+            occ = torch.nonzero(grid[cas] > 0).squeeze(-1)
+            occ = occ[randint(0, occ.shape[0], [N], dtype=torch.long)]
+            occ_coords = torch.from_numpy(orm.morton3D_invert(occ.int().numpy()))
+            indices = torch.cat([indices, occ], dim=0)
+            coords = torch.cat([coords, occ_coords], dim=0)
+            xyzs = 2 * coords.float() / (G - 1) - 1
+            b = min(2 ** cas, bound)
+            half = b / G
+            cas_xyzs = xyzs * (b - half)
+            cas_xyzs += (rand_like(cas_xyzs) * 2 - 1) * half
+            sig = density_fn(cas_xyzs, message)["sigma"].reshape(-1).detach() * state["density_scale"]
+            tmp[cas, indices] = sig                                                # :520 (a cell drawn twice keeps ONE of its values, which one is unspecified:
+            hits[cas] += torch.bincount(indices, minlength=G ** 3)                 #  index_put_ with duplicates -- `hits` lets tests exclude those cells)
+    valid = (grid >= 0) & (tmp >= 0)                                               # :522 EMA
+    grid[valid] = torch.maximum(grid[valid] * decay, tmp[valid])
+    state["mean_density"] = torch.mean(grid.clamp(min=0)).item()
+    state["iter_density"] += 1
+    thresh = min(state["mean_density"], state["density_thresh"])                   # :529
+    state["density_bitfield"] = torch.from_numpy(orm.packbits(grid.numpy(), thresh))
+    total = min(16, state["local_step"])                                           # :533
+    if total > 0:
+        state["mean_count"] = int(state["step_counter"][:total, 0].sum().item() / total)
+    state["local_step"] = 0
+    return tmp, hits

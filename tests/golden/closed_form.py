@@ -85,3 +85,61 @@ def orbit_rays(n, radius=3.2248, seed=0, H=400, W=400, focal=555.56):
     pose[:3, 0], pose[:3, 1], pose[:3, 2], pose[:3, 3] = right, -up, fwd, c
     inds = rng.randint(0, H * W, size=n)
     return pose, np.array([focal, focal, W / 2, H / 2], np.float32), inds.astype(np.int64)
+
+
+def uniform(n, stream):
+    """n fp32 values in [0,1) from an integer hash of (index, stream): the stand-in for torch.rand_like / torch.randint draws
+    wherever the reference draws on its own device generator (density-grid jitter, renderer_wtmk.py:478,514; partial-update cell
+    choice :488,492) -- the golden capture and the tests patch both functions with this generator, so the draws are identical on
+    the CPU, on the GPU and in the reference run."""
+    idx = (np.arange(n, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(stream) * np.uint64(0x85EBCA6B) + np.uint64(777)) & np.uint64(0xFFFFFFFF)
+    idx = (idx ^ (idx >> np.uint64(16))) * np.uint64(2246822519) & np.uint64(0xFFFFFFFF)
+    idx = (idx ^ (idx >> np.uint64(13))) * np.uint64(3266489917) & np.uint64(0xFFFFFFFF)
+    idx = idx ^ (idx >> np.uint64(16))
+    return ((idx >> np.uint64(8)).astype(np.float32) / np.float32(1 << 24)).astype(np.float32)
+
+
+class PatchedDraws:
+    """Context manager: torch.rand_like / torch.randint answer from `uniform` (one stream per call, in call order)."""
+
+    def __enter__(self):
+        import torch
+        self.torch, self.calls = torch, 0
+        self.orig = (torch.rand_like, torch.randint)
+
+        def rand_like(t, **kw):
+            self.calls += 1
+            return torch.from_numpy(uniform(t.numel(), self.calls)).view(t.shape).to(device=t.device, dtype=t.dtype)
+
+        def randint(low, high, size, dtype=torch.int64, device=None, **kw):
+            self.calls += 1
+            n = int(np.prod(size))
+            v = low + np.floor(uniform(n, self.calls).astype(np.float64) * (high - low)).astype(np.int64)
+            return torch.from_numpy(v).view(*size).to(device=device, dtype=dtype)
+
+        torch.rand_like, torch.randint = rand_like, randint
+        return self
+
+    def __exit__(self, *exc):
+        self.torch.rand_like, self.torch.randint = self.orig
+
+
+def grid_density(x, message=None):
+    """Closed-form density field for the density-grid maintenance vectors: only +, -, *, clamp on single elements, so the CPU, the
+    GPU and the reference run produce identical fp32 values.  x: torch [n,3]."""
+    r2 = x[:, 0] * x[:, 0] + x[:, 1] * x[:, 1] + x[:, 2] * x[:, 2]
+    return {"sigma": (30.0 * (1.0 - r2 * 1.5)).clamp(min=0.0) + 0.004 * (x[:, 0] + 2.0).clamp(min=0.0)}
+
+
+def grid_poses():
+    """Three camera-to-world poses around the origin (radius 1.3, looking inwards) + intrinsics (fx, fy, cx, cy) with a narrow view."""
+    poses = []
+    for th, ph in ((1.1, 0.7), (1.4, 2.9), (0.6, 4.4)):
+        c = np.array([1.3 * np.sin(th) * np.sin(ph), 1.3 * np.cos(th), 1.3 * np.sin(th) * np.cos(ph)], np.float32)
+        fwd = -c / np.linalg.norm(c)
+        right = np.cross(fwd, np.array([0, 1, 0], np.float32)); right /= np.linalg.norm(right)
+        up = np.cross(right, fwd)
+        pose = np.eye(4, dtype=np.float32)
+        pose[:3, 0], pose[:3, 1], pose[:3, 2], pose[:3, 3] = right, -up, fwd, c
+        poses.append(pose)
+    return np.stack(poses), np.array([300.0, 300.0, 100.0, 100.0], np.float32)

@@ -166,11 +166,47 @@ def raymarching_standin():
     for f in (near_far_from_aabb, march_rays_train, composite_rays_train, march_rays, composite_rays):
         setattr(mod, f.__name__, f)
     mod.morton3D = lambda c: t(rm.morton3D(c.numpy()))
+    mod.morton3D_invert = lambda i: t(rm.morton3D_invert(i.numpy()))
     mod.packbits = lambda g, th, bf=None: t(rm.packbits(g.numpy(), th))
     return mod
 
 
 ball_scene, orbit_rays = cf.ball_scene, cf.orbit_rays
+
+
+def grid_maintenance(ref_rend):
+    """G11: the reference's own NeRFRenderer.mark_untrained_grid / update_extra_state (renderer_wtmk.py:380-538) on a 32^3, two-cascade
+    grid with a closed-form density field and closed-form draws (closed_form.PatchedDraws): -1 marks, two full updates, one partial
+    update; grid, bitfield, mean density and mean count after every call."""
+
+    class Field(ref_rend.NeRFRenderer):
+        def density(self, x, message=None):
+            return cf.grid_density(x, message)
+
+    r = Field(bound=2, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=0.6, bg_radius=-1)
+    G = 32
+    r.grid_size = G
+    r.density_grid = torch.zeros(r.cascade, G ** 3)
+    r.density_bitfield = torch.zeros(r.cascade * G ** 3 // 8, dtype=torch.uint8)
+    poses, intr = cf.grid_poses()
+    out = {"poses": poses, "intrinsics": intr, "grid_size": np.int32(G)}
+    r.mark_untrained_grid(poses, intr, S=16)
+    out["grid_marked"] = r.density_grid.numpy().copy()
+    r.iter_density = 14
+    r.local_step = 5
+    r.step_counter[:5, 0] = torch.tensor([1000, 1203, 990, 1500, 20], dtype=torch.int32)
+    with cf.PatchedDraws() as draws:
+        for k in range(3):          # iter_density 14, 15: every cell; 16: a random quarter + as many occupied cells
+            if k == 2:
+                r.local_step = 20
+                r.step_counter[:, 0] = torch.arange(16, dtype=torch.int32) * 100 + 7
+            r.update_extra_state(message=None, decay=0.95, S=16)
+            out[f"grid_{k}"] = r.density_grid.numpy().copy()
+            out[f"bitfield_{k}"] = r.density_bitfield.numpy().copy()
+            out[f"mean_density_{k}"] = np.float64(r.mean_density)
+            out[f"mean_count_{k}"] = np.int64(r.mean_count)
+            out[f"draw_calls_{k}"] = np.int64(draws.calls)
+    np.savez_compressed(os.path.join(HERE, "g11_grid_maintenance.npz"), **out)
 
 
 def main():
@@ -179,6 +215,13 @@ def main():
     install_stubs()
     sys.modules["tinycudann"] = tcnn_standin()
     sys.modules["raymarching"] = raymarching_standin()
+    if "--only-g11" in sys.argv:
+        with _CpuTensorCtor():
+            from nerf import renderer_wtmk as ref_rend
+        grid_maintenance(ref_rend)
+        shutil.rmtree(tmp)
+        print("g11 written to", HERE)
+        return
     with _CpuTensorCtor():
         import hash_encoding as ref_he
         import hash_encoding_wtmk_bit as ref_cb
@@ -328,6 +371,9 @@ def main():
     torch.manual_seed(5)
     rp = ref_prov.rand_poses(4, "cpu", radius=2.5)
     np.savez_compressed(os.path.join(HERE, "g10_blocks.npz"), image=img.numpy(), coords=coords.numpy(), bh=np.int32(bh), bw=np.int32(bw), rand_poses=rp.numpy())
+    # ---- G11: density-grid maintenance ------------------------------------------------------------------------------------
+    from nerf import renderer_wtmk as ref_rend
+    grid_maintenance(ref_rend)
     shutil.rmtree(tmp)
     print("golden vectors written to", HERE)
 

@@ -1,0 +1,213 @@
+"""The reference Trainer's AMP loop around this repo's train_step, and the checkpoint shim on the GPU.
+
+AMP (utils_wtmk_disen.py:1172-1178, `-O` => fp16=True, main_nerf_wtmk.py:79-82): `with autocast(fp16): train_step(...)`,
+`scaler.scale(loss).backward()`, `scaler.step(optimizer)`, `scaler.update()` with a plain torch.optim.Adam over get_params() -- the
+reference's own objects, no GradSink.  Checked: the update equals the fp32 loop's within tolerance (every native entry point keeps
+fp32 arithmetic under autocast; 65536x gradients pass through k_field_bwd's fixed-point scatter and are unscaled on the fanned-out
+table gradients), and a non-finite loss skips the step and halves the scale.
+
+N4: save -> load -> bit-identical render; a checkpoint loaded between two replays of the captured loop."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import closed_form as cf
+from test_gpu_render import _data, _model
+
+pytestmark = pytest.mark.gpu
+KW = dict(dt_gamma=0, max_steps=1024)
+
+
+def _cuda_data(n_content=400, block=6, big=False):
+    bo, bd, co, cd, gt = _data(n_content=n_content, block=block)
+    return {"watermark": {"rays_o_block": bo.cuda(), "rays_d_block": bd.cuda()}, "content": {"rays_o": co.cuda(), "rays_d": cd.cuda(), "images": gt.cuda()}}
+
+
+def _snapshot(m):
+    return [e.weight.detach().clone() for e in m.msg_encoder.embeddings], torch.cat([p.detach().reshape(-1) for p in m.msg_decoder.parameters()])
+
+
+@pytest.mark.parametrize("n_content,block", [(400, 6), (3000, 12)])     # small: record scatter with float atomics; large: binned fixed-point scatter
+def test_train_step_under_autocast_and_gradscaler(n_content, block):
+    from nerf_signature_amd import trainer
+    data = _cuda_data(n_content, block)
+    msgs = [torch.from_numpy(np.random.RandomState(60 + s).randint(0, 2, 32).astype(np.float32)).cuda() for s in range(3)]
+    results = []
+    for amp in (False, True):
+        torch.manual_seed(0)
+        m, _, _ = _model()
+        m.grad_sink = None
+        opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+        scaler = torch.amp.GradScaler("cuda", enabled=amp)           # init_scale 65536
+        losses = []
+        for msg in msgs:
+            opt.zero_grad()
+            with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+                out = trainer.train_step(m, data, msg, dict(KW, fp16=True, workspace="w"))
+            assert out[2].dtype == torch.float32 and out[5].dtype == torch.float32        # fp32 arithmetic behind the C ABI under autocast
+            scaler.scale(out[5]).backward()
+            if amp:      # the scaled gradient really went through the native backward
+                sel = [e.weight for e in m.msg_encoder.embeddings if e.weight.grad is not None]
+                assert len(sel) == 32 and all(torch.isfinite(t.grad).all() for t in sel)
+            scaler.step(opt)
+            scaler.update()
+            losses.append([float(v.detach()) for v in out[3:6]])
+        results.append((np.array(losses), *_snapshot(m), scaler.get_scale() if amp else 1.0))
+    (l0, t0, d0, _), (l1, t1, d1, scale) = results
+    assert scale == 65536.0                                           # no overflow: the scale was never reduced
+    np.testing.assert_allclose(l1, l0, rtol=2e-3, atol=2e-5)
+    init = [torch.from_numpy(cf.table(100 + l, scale=0.05)).cuda() for l in range(64)]
+    moved = sum(float((a - b).pow(2).sum()) for a, b in zip(t0, init)) ** 0.5
+    diff = sum(float((a - b).pow(2).sum()) for a, b in zip(t0, t1)) ** 0.5
+    assert moved > 0 and diff / moved < 0.05                          # (Adam turns last-bit differences of tiny gradients into +-lr steps)
+    assert float((d0 - d1).norm() / d0.norm()) < 0.05
+    # unselected tables never moved on either side
+    bits = [[int(v) for v in msg.cpu()] for msg in msgs]
+    for l in range(64):
+        if all(b[l // 2] != l % 2 for b in bits):
+            assert torch.equal(t1[l], init[l]) and torch.equal(t0[l], init[l])
+
+
+@pytest.mark.parametrize("n_content,block", [(400, 6), (3000, 12)])
+def test_gradscaler_skips_a_non_finite_step(n_content, block):
+    """Overflow handling of `scaler.step` (utils_wtmk_disen.py:1175-1178): a scaled loss that overflows must leave non-finite values in
+    the gradients the scaler inspects -- including the table gradients that come out of the integer scatter -- so the step is skipped,
+    no parameter moves, and the scale is halved; the next (finite) step trains again."""
+    from nerf_signature_amd import trainer
+    data = _cuda_data(n_content, block)
+    m, _, _ = _model()
+    m.grad_sink = None
+    opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    scaler = torch.amp.GradScaler("cuda", init_scale=65536.0)
+    msg = torch.from_numpy(cf.messages(32)[2]).cuda()
+    before = _snapshot(m)
+    bad = copy.deepcopy(data)
+    bad["content"]["images"].fill_(3e37)                              # d(MSE)/d(pred) overflows fp32 once scaled by 65536: inf in the content render's gradient only
+    opt.zero_grad()
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = trainer.train_step(m, bad, msg, KW)
+    scaler.scale(out[5]).backward()
+    grads = [e.weight.grad for e in m.msg_encoder.embeddings if e.weight.grad is not None]
+    assert len(grads) == 32 and not bool(torch.isfinite(grads[0]).all())   # the table gradient itself shows the overflow
+    scaler.step(opt)
+    scaler.update()
+    after = _snapshot(m)
+    assert all(torch.equal(a, b) for a, b in zip(before[0], after[0])) and torch.equal(before[1], after[1])
+    assert scaler.get_scale() == 32768.0
+    opt.zero_grad()
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = trainer.train_step(m, data, msg, KW)
+    scaler.scale(out[5]).backward()
+    scaler.step(opt)
+    scaler.update()
+    assert not torch.equal(before[1], _snapshot(m)[1]) and scaler.get_scale() == 32768.0 and bool(torch.isfinite(out[5]))
+
+
+def test_checkpoint_save_load_renders_bit_identically(tmp_path):
+    """N4 on the GPU: a trained model saved in the reference's dict format and loaded into a fresh model renders the same bits
+    (training-mode and eval-mode paths, with and without a message); a clean stage-1 checkpoint (no codebook/decoder keys) loads with
+    strict=False and renders the clean image."""
+    from nerf_signature_amd import checkpoint as ck, trainer
+    data = _cuda_data()
+    m, _, _ = _model()
+    opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    loop = trainer.WatermarkLoop(m, opt, KW)
+    msg = torch.from_numpy(cf.messages(32)[2])
+    for _ in range(2):
+        loop.step(data, msg)
+    path = ck.save_checkpoint(str(tmp_path / "checkpoints" / "ngp_ep0002.pth"), m, epoch=2, global_step=2, optimizer=opt, full=True)
+    fresh, _, _ = _model()
+    with torch.no_grad():
+        for p in fresh.msg_decoder.parameters():
+            p.add_(0.01)
+    opt2 = torch.optim.Adam(fresh.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    missing, unexpected, meta = ck.load_checkpoint(path, fresh, optimizer=opt2, map_location="cuda")
+    assert missing == [] and unexpected == [] and meta["epoch"] == 2 and "skipped" not in meta
+    o, d = data["content"]["rays_o"], data["content"]["rays_d"]
+    for model_msg in (msg, None):
+        for mode in ("train", "eval"):
+            getattr(m, mode)(), getattr(fresh, mode)()
+            with torch.no_grad():
+                a = m.render(o, d, model_msg, staged=False, bg_color=1, perturb=False, force_all_rays=True, **KW)
+                b = fresh.render(o, d, model_msg, staged=False, bg_color=1, perturb=False, force_all_rays=True, **KW)
+            assert torch.equal(a["image"], b["image"]) and torch.equal(torch.nan_to_num(a["depth"]), torch.nan_to_num(b["depth"]))
+    m.train(), fresh.train()
+    # the restored optimiser continues identically
+    la = loop.step(data, msg)[5].detach().clone()
+    lb = trainer.WatermarkLoop(fresh, opt2, KW).step(data, msg)[5].detach().clone()
+    np.testing.assert_allclose(float(la), float(lb), rtol=1e-5)
+    clean = {k: v for k, v in m.state_dict().items() if not k.startswith("msg_")}
+    clean["sigma_net.params"] = clean["sigma_net.params"].half()
+    target, _, _ = _model()
+    missing, unexpected, _ = ck.load_checkpoint({"model": clean, "epoch": 1, "global_step": 1, "stats": {}}, target, model_only=True)
+    assert unexpected == [] and all(k.startswith("msg_") for k in missing)
+
+
+def test_checkpoint_loaded_between_replays_of_the_captured_loop():
+    """load_checkpoint on a model that a GraphedWatermarkLoop has captured.  The pre-sum buffer and the optimiser state
+    tensors are held by the graph by address: they must survive the load in place, the announced-message bookkeeping must be reset,
+    and the following replays must equal an eager loop that loaded the same checkpoint."""
+    from nerf_signature_amd import checkpoint as ck, trainer
+    from nerf_signature_amd.optim import CodebookAdam
+    data = _cuda_data(n_content=300)
+    msgs = [torch.from_numpy(np.random.RandomState(s).randint(0, 2, 32).astype(np.float32)) for s in range(5)]
+    # the checkpoint: two eager steps from the initial state
+    torch.manual_seed(0)
+    src, _, _ = _model()
+    opt_src = CodebookAdam(src.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    loop_src = trainer.WatermarkLoop(src, opt_src, KW)
+    for k in range(2):
+        loop_src.step(data, msgs[k])
+    state = copy.deepcopy(ck.checkpoint_state(src, epoch=1, global_step=2, optimizer=opt_src, full=True))
+    runs = []
+    for graphed in (False, True):
+        torch.manual_seed(0)
+        m, _, _ = _model()
+        opt = CodebookAdam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, capturable=graphed)
+        if graphed:
+            loop = trainer.GraphedWatermarkLoop(m, opt, KW, data)
+            step = lambda k: loop.step(msgs[k], next_message=msgs[k + 1] if k + 1 < len(msgs) else None)
+        else:
+            loop = trainer.WatermarkLoop(m, opt, KW)
+            step = lambda k: loop.step(data, msgs[k])
+        step(0)                                   # diverge from the checkpoint's history ...
+        if graphed:
+            s_buf = m._presum_cache[1].data_ptr()
+            state_ptrs = {id(p): opt.state[p]["exp_avg"].data_ptr() for p in m.msg_encoder.parameters() if len(opt.state[p])}
+        missing, unexpected, meta = ck.load_checkpoint(copy.deepcopy(state), m, optimizer=opt)    # ... then resume from it
+        assert missing == [] and unexpected == [] and "skipped" not in meta
+        if graphed:
+            assert m._presum_cache[1].data_ptr() == s_buf and m._presum_cache[0] is None and loop._s_for is None
+            assert all(opt.state[p]["exp_avg"].data_ptr() == state_ptrs[id(p)] for p in m.msg_encoder.parameters() if id(p) in state_ptrs)
+            assert torch.is_tensor(opt.param_groups[0]["lr"]) and opt.param_groups[0]["lr"].is_cuda
+        losses = [float(step(k)[5].detach()) for k in (2, 3, 4)]
+        torch.cuda.synchronize()
+        if graphed:
+            assert not loop.overflowed()
+        runs.append((losses, _snapshot(m)))
+    (l0, (t0, d0)), (l1, (t1, d1)) = runs
+    np.testing.assert_allclose(l1, l0, rtol=2e-3, atol=2e-4)
+    init = [torch.from_numpy(cf.table(100 + l, scale=0.05)).cuda() for l in range(64)]
+    moved = sum(float((a - b).pow(2).sum()) for a, b in zip(t0, init)) ** 0.5
+    diff = sum(float((a - b).pow(2).sum()) for a, b in zip(t0, t1)) ** 0.5
+    assert moved > 0 and diff / moved < 0.05
+
+
+def test_eager_loop_refuses_a_model_left_in_device_select_mode():
+    from nerf_signature_amd import trainer
+    from nerf_signature_amd.optim import CodebookAdam
+    data = _cuda_data(n_content=300)
+    m, _, _ = _model()
+    opt = CodebookAdam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, capturable=True)
+    g = trainer.GraphedWatermarkLoop(m, opt, KW, data)
+    msg = torch.from_numpy(cf.messages(32)[2])
+    g.step(msg)
+    eager = trainer.WatermarkLoop(m, opt, KW)
+    with pytest.raises(RuntimeError, match="device-select"):
+        eager.step(data, msg.cuda())
+    g.close()
+    eager.step(data, msg)          # host-side selection again: only the 32 selected tables are recorded in the sink
+    assert len(eager.sink.selected) == 32

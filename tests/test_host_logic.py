@@ -267,6 +267,42 @@ def test_checkpoint_round_trip_and_clean_checkpoint(tmp_path):
     assert not missing
 
 
+def test_checkpoint_loading_is_tolerant_and_keeps_optimizer_state_in_place(tmp_path, capsys):
+    """utils_wtmk_disen.py:1497-1517: an optimizer / scheduler section that does not fit is reported and skipped, the rest of the resume
+    goes on.  A section that does fit is loaded INTO the existing state tensors (a captured graph holds their addresses), and a learning
+    rate that lives in a tensor keeps living there."""
+    from nerf_signature_amd import checkpoint as ck
+    from nerf_signature_amd.network import NeRFNetwork
+    torch.manual_seed(0)
+    a = NeRFNetwork(bound=1.0, cuda_ray=True, message_dim=4)
+    opt = torch.optim.Adam(a.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    for p in a.msg_decoder.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    state = ck.checkpoint_state(a, epoch=1, global_step=1, optimizer=opt, full=True)
+    b = NeRFNetwork(bound=1.0, cuda_ray=True, message_dim=4)
+    opt_b = torch.optim.Adam(b.get_params(5e-3), betas=(0.9, 0.99), eps=1e-15)
+    for p in b.msg_decoder.parameters():
+        p.grad = torch.full_like(p, 2.0)
+    opt_b.step()
+    lr_dev = torch.tensor(5e-3)
+    for g in opt_b.param_groups:
+        g["lr"] = lr_dev
+    p0 = next(iter(b.msg_decoder.parameters()))
+    kept = opt_b.state[p0]["exp_avg"]
+    _, _, meta = ck.load_checkpoint(state, b, optimizer=opt_b)
+    assert "skipped" not in meta
+    assert opt_b.state[p0]["exp_avg"] is kept and torch.equal(kept, opt.state[next(iter(a.msg_decoder.parameters()))]["exp_avg"])
+    assert all(g["lr"] is lr_dev for g in opt_b.param_groups) and float(lr_dev) == pytest.approx(1e-2)
+    # a checkpoint whose optimizer section belongs to another parameter grouping: warned about, skipped, model still loaded
+    other = torch.optim.Adam([next(iter(a.msg_decoder.parameters()))], lr=1e-3)
+    bad = dict(state, optimizer=other.state_dict(), lr_scheduler={"nonsense": 1})
+    sched = torch.optim.lr_scheduler.LambdaLR(opt_b, lambda it: 1.0)
+    _, _, meta = ck.load_checkpoint(bad, b, optimizer=opt_b, lr_scheduler=sched)
+    assert meta["skipped"] == ["optimizer", "lr_scheduler"] and "Failed to load optimizer" in capsys.readouterr().out
+    assert meta["epoch"] == 1
+
+
 def test_block_selection_matches_reference_golden():
     """N2: process_image (JPEG compressibility ranking) and rand_poses vs the reference's own outputs (golden G10)."""
     pytest.importorskip("PIL")

@@ -139,3 +139,46 @@ def test_state_dict_contract_matches_reference():
     keys = list(g["state_dict_keys"])
     assert "encoder.embeddings.0.weight" in keys and "msg_encoder.embeddings.63.weight" in keys
     assert "sigma_net.params" in keys and "color_net.params" in keys and "density_bitfield" in keys
+
+
+def _grid_state():
+    g = _load("g11_grid_maintenance.npz")
+    G = int(g["grid_size"])
+    state = {"density_grid": torch.zeros(2, G ** 3), "density_bitfield": None, "bound": 2, "grid_size": G, "density_scale": 1, "density_thresh": 0.6,
+             "iter_density": 0, "mean_density": 0, "step_counter": torch.zeros(16, 2, dtype=torch.int32), "local_step": 0, "mean_count": 0}
+    return g, state
+
+
+def test_g11_density_grid_maintenance_matches_reference():
+    """The oracle's mark_untrained_grid / update_extra_state against the reference's own NeRFRenderer methods (golden G11:
+    renderer_wtmk.py:380-538 run on a 32^3 two-cascade grid with closed-form density and draws): grid values, -1 marks, bitfield,
+    mean density and mean count identical after the marking, two full updates and one partial update."""
+    import closed_form as cf
+    g, st = _grid_state()
+    n_marked = fr.mark_untrained_grid(st, g["poses"], g["intrinsics"], S=16)
+    np.testing.assert_array_equal(st["density_grid"].numpy(), g["grid_marked"])
+    assert n_marked == int((g["grid_marked"] < 0).sum()) > 0
+    st["iter_density"], st["local_step"] = 14, 5
+    st["step_counter"][:5, 0] = torch.tensor([1000, 1203, 990, 1500, 20], dtype=torch.int32)
+    with cf.PatchedDraws() as draws:
+        for k in range(3):
+            if k == 2:
+                st["local_step"] = 20
+                st["step_counter"][:, 0] = torch.arange(16, dtype=torch.int32) * 100 + 7
+            _, hits = fr.update_extra_state(st, cf.grid_density, None, 0.95, 16, rand_like=torch.rand_like, randint=torch.randint)
+            # a cell the partial update draws more than once keeps one of its probes, unspecified which (index_put_ with duplicate
+            # indices, renderer_wtmk.py:520): those cells are compared by bounds only
+            once = (hits <= 1).numpy()
+            assert once.all() == (k < 2) and once.mean() > 0.85
+            got, want = st["density_grid"].numpy(), g[f"grid_{k}"]
+            np.testing.assert_array_equal(got[once], want[once])
+            np.testing.assert_array_equal((got < 0), (want < 0))
+            bits = lambda b: np.unpackbits(b, bitorder="little").reshape(once.shape).astype(bool)
+            np.testing.assert_array_equal(bits(st["density_bitfield"].numpy())[once], bits(g[f"bitfield_{k}"])[once])
+            if k < 2:
+                assert st["mean_density"] == float(g[f"mean_density_{k}"])
+            else:
+                assert abs(st["mean_density"] - float(g[f"mean_density_{k}"])) < 1e-3 * float(g[f"mean_density_{k}"])
+            assert st["mean_count"] == int(g[f"mean_count_{k}"])
+            assert draws.calls == int(g[f"draw_calls_{k}"])
+    assert st["iter_density"] == 17 and st["local_step"] == 0
