@@ -2,20 +2,27 @@
 """Benchmark of the watermark-stage training step (BASELINE.json: training rays/s @4096-ray batches, hotdog, 32-bit
 message).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1: starts its own N rank processes (one per GPU, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --config counter|fern                  # secondary workloads (BASELINE.json configs 3 and 5), not the headline
 
-One step = the loop body of the reference's train_one_epoch (nerf/utils_wtmk_disen.py:1164-1181) on synthetic scene
-S0: a fresh 32-bit message, the block render (32 blocks x 12 x 12 = 4608 rays) decoded by the
-HiDDeN decoder, the content render (4096 rays), BCE + MSE loss, backward, gradient exchange (N > 1), Adam step on
-the 32 selected codebook tables and the decoder.  Inputs are resident in HBM before the timed region.  Rays are
-sharded by rank (each rank draws its own 4096 content rays; block rays and message are replicated): weak scaling.
-Rank 0 prints ONE JSON line.
+One step = the loop body of the reference's train_one_epoch (nerf/utils_wtmk_disen.py:1164-1181) on synthetic scene S0
+(SURVEY.md 8(d)): a NEW pose and 4096 new random pixels (rays generated on the device, rg_get_rays; ground truth gathered
+from that pose's clean render), a fresh 32-bit message, the block render (32 blocks x 12 x 12 = 4608 rays of the fixed
+watermark pose) decoded by the HiDDeN decoder, the content render (4096 rays), BCE + MSE, backward, gradient exchange
+(N > 1), Adam on the 32 selected codebook tables and the decoder.  Inputs (poses, clean images, block rays, tables) are
+resident in HBM before the timed region.
+
+Multi-GPU: content rays shard by rank (own poses/pixels); the D blocks are split over the ranks and the
+rendered blocks all-gathered in front of the replicated decoder.  `value` = content rays (the metric's "@4096 rays" basis) x
+ranks / time; the block rays are counted once in `config.all_rays_per_s`.  Weak scaling.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import copy
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,9 +34,100 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md chip table); measured copy ceiling 6.29e12
-BYTES_FWD_PER_POINT = lambda D: 1024 + 64 * D + 48      # 16*8*8 base + D*8*8 codebook + 32 in + 16 out
-BYTES_BWD_PER_POINT = lambda D: 128 * D + 64            # codebook RMW + (dsigma, drgb, ...)
+MFMA_PEAK = {"f16": 2.5e15, "bf16": 2.5e15}     # dense FLOP/s
+T_BYTES = (1 << 19) * 2 * 4                      # one [2^19, 2] fp32 table
 
+
+# --------------------------------------------------------------------------------------------- launcher (no GPU call in here)
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--config", choices=["hotdog", "counter", "fern"], default="hotdog", help="hotdog = the headline (BASELINE configs 2/4); counter / fern = secondary lines")
+    ap.add_argument("--poses", type=int, default=8, help="pre-rendered clean views the per-step poses rotate through")
+    ap.add_argument("--dry-launch", action="store_true", help="start the N rank processes over gloo, run the collectives of a step on CPU tensors, no kernels")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="issue the content render on the main stream instead of overlapping it with the block render / decoder")
+    ap.add_argument("--no-fused-adam", action="store_true", help="torch's multi-tensor instead of its fused Adam kernel for the decoder parameters")
+    ap.add_argument("--no-graph", action="store_true", help="run the loop body eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--fixed-rays", action="store_true", help="replay one ray set every step (round-1 behaviour; diagnostics)")
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their
+    environment), wait, exit with the worst return code.  Decided before anything touches the GPU; children are new processes, never
+    an exec of one that initialised the device.  Rank 0 inherits stdout (the one JSON line)."""
+    n = args.gpus
+    backend = os.environ.get("NERFSIG_DIST_BACKEND", "")
+    if not args.dry_launch and backend != "gloo":
+        have = torch.cuda.device_count()          # (does not initialise the device)
+        if have < n:
+            raise SystemExit(f"--gpus {n} but {have} GPU(s) visible (NERFSIG_DIST_BACKEND=gloo rehearses N ranks on fewer GPUs)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:       # a rank died: the others would wait in a collective for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    raise SystemExit(rc)
+
+
+def dry_launch(args):
+    """The launcher path and the step's collectives on gloo / CPU tensors (no kernels): proves `--gpus N` starts N ranks that meet."""
+    from nerf_signature_amd import dp
+    rank, world, _ = dp.init_from_env(backend="gloo")
+    D = 32
+    ok = True
+    shard = dp.block_shard(D)
+    if world > 1:
+        ok = shard == (rank * D // world, (rank + 1) * D // world)
+        local = torch.full((D // world, 2, 2, 3), float(rank))
+        gathered = dp.gather_blocks(local, D, shard[0])
+        ok = ok and all(float(gathered[k * (D // world)].mean()) == k for k in range(world))
+    lin = torch.nn.Linear(3, 2)
+    for p in lin.parameters():
+        p.grad = torch.ones_like(p)
+    G = torch.full((4, 2), float(rank + 1))
+    ex = dp.GradExchange(list(lin.parameters()), shared_scale=1.0)
+    ex(G)
+    ok = ok and float(G[0, 0]) == world * (world + 1) / 2
+    t = torch.tensor([1.0 if ok else 0.0])
+    if dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "world_size_seen": dp.world_size(), "backend": dist.get_backend() if dist.is_initialized() else None,
+                          "block_shard_rank0": shard, "collectives_ok": bool(t.item()), "grad_exchange_bytes_per_step": ex.bytes_per_step}), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    raise SystemExit(0 if t.item() else 1)
+
+
+# --------------------------------------------------------------------------------------------- measurement helpers
 
 class NativeTimer:
     """HIP-event timing of selected libnerfsig entry points, on the stream the kernels are launched on (torch's current
@@ -61,17 +159,23 @@ class NativeTimer:
 
 
 def cpu_baseline(model, D):
-    """The oracle (CPU restatement of the reference path, reference-faithful op sequence for the encoders) timed on
-    this box's host cores on a bounded sample of the same workload: 32 blocks of 8x8 rays + 2048 content rays
-    (sized for roughly 10-30 s of CPU work).  Thread count: torch intra-op threads, capped at 32 -- the tensor ops of
-    this sample are too small to scale further, and oversubscribing a 256-thread host made it 50x slower."""
+    """the oracle (CPU restatement of the reference path; reference-faithful per-bit op sequence for the
+    encoders) timed on this box's host cores in BOTH shapes, 1 warm-up + 3 timed batches each, forward + backward:
+      run_cuda shape (occupancy-grid march, raymarching.cu:312-693 semantics): one train step = the full 4096-ray content batch +
+        the 32 watermark blocks at 4x4 of their 12x12 rays (block rays subsampled 1/9 to bound the run; stated in `sample`);
+      run shape (renderer_wtmk.py:125-253: 512 uniform samples per ray, every point through encoders + sigma MLP): 512 of the 4096
+        content rays (1/8), MSE against the clean image, backward to the codebook.
+    Threads: torch intra-op threads = the CPUs this process may run on, capped at 32 (a 256-thread host oversubscribed these small
+    tensor ops 50x in round 1); os.cpu_count() is reported beside it."""
     from nerf_signature_amd import synthetic
     from oracle import field_ref as fr
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    host_cpus = os.cpu_count() or 1
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host_cpus
+    torch.set_num_threads(max(1, min(allowed, 32)))
     bo, bd = synthetic.block_rays("hotdog")
-    bo, bd = bo[:, :8, :8].contiguous(), bd[:, :8, :8].contiguous()
-    co, cd = synthetic.content_rays("hotdog", 2048, seed=0)
-    gt = torch.rand(1, 2048, 3)
+    bo, bd = bo[:, :4, :4].contiguous(), bd[:, :4, :4].contiguous()
+    co, cd = synthetic.content_rays("hotdog", 4096, seed=0)
+    gt = torch.rand(1, 4096, 3)
     msg = torch.randint(0, 2, (D,)).float()
     P = {"bound": 1.0, "faithful": True, "base_tables": [e.weight.detach().cpu() for e in model.encoder.embeddings],
          "cb_tables": [e.weight.detach().cpu().clone().requires_grad_(True) for e in model.msg_encoder.embeddings],
@@ -79,81 +183,116 @@ def cpu_baseline(model, D):
     S = {"bound": 1.0, "cascade": 1, "grid_size": 128, "density_bitfield": model.density_bitfield.cpu().numpy(),
          "aabb": np.array([-1, -1, -1, 1, 1, 1], np.float32), "min_near": 0.2, "density_scale": 1}
     dec = copy.deepcopy(model.msg_decoder).cpu()
-    n_rays = bo.shape[0] * 64 + 2048
-    t0 = time.perf_counter()
-    out = fr.train_step(bo, bd, co, cd, gt, msg, P, S, dec, dt_gamma=0.0, max_steps=1024)
-    out["loss"].backward()
-    dt = time.perf_counter() - t0
-    pts = out["block"]["n_points"] + out["content"]["n_points"]
-    return {"value": n_rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 train step (fwd+bwd, no optimiser) on {n_rays} rays = 32 blocks of 8x8 + 2048 content rays, {pts} points, {dt:.1f} s",
-            "points_per_s": pts / dt}
+
+    def zero():
+        for t in P["cb_tables"]:
+            t.grad = None
+        dec.zero_grad(set_to_none=True)
+
+    def step_cuda_shape():
+        zero()
+        out = fr.train_step(bo, bd, co, cd, gt, msg, P, S, dec, dt_gamma=0.0, max_steps=1024)
+        out["loss"].backward()
+        return out["block"]["n_points"] + out["content"]["n_points"]
+
+    def step_run_shape():
+        zero()
+        out = fr.run_uniform(co[:, :512], cd[:, :512], msg, P, S, num_steps=512, bg_color=1)
+        ((out["image"] - gt[:, :512]) ** 2).mean().backward()
+        return 512 * 512
+
+    res = {}
+    for name, fn, rays in (("run_cuda", step_cuda_shape, 4096 + bo.shape[0] * 16), ("run", step_run_shape, 512)):
+        pts = fn()                                     # warm-up
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            pts = fn()
+            times.append(time.perf_counter() - t0)
+        res[name] = {"rays_per_s": rays / float(np.mean(times)), "points_per_s": pts / float(np.mean(times)), "rays": rays, "points": pts,
+                     "batch_s": [round(t, 3) for t in times]}
+    a, b = res["run_cuda"], res["run"]
+    return {"value": a["rays_per_s"], "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"run_cuda shape: 1 warm-up + 3 timed train steps (fwd+bwd, no optimiser) of {a['rays']} rays = the full 4096-ray content batch + "
+                      f"32 blocks at 4x4 of their 12x12 rays (block rays subsampled 1/9), {a['points']} points, {np.mean(a['batch_s']):.1f} s per step",
+            "points_per_s": a["points_per_s"], "host_cpus": host_cpus, "cpus_allowed": allowed, "torch_threads": torch.get_num_threads(),
+            "run_shape": {"value": b["rays_per_s"], "unit": "rays/s", "points_per_s": b["points_per_s"],
+                          "sample": f"run shape (512 uniform samples/ray, renderer_wtmk.py:125-253): 1 warm-up + 3 timed fwd+bwd batches of 512 of the 4096 content rays "
+                                    f"(1/8), {b['points']} points, {np.mean(b['batch_s']):.1f} s per batch"},
+            "batch_seconds": {"run_cuda": a["batch_s"], "run": b["batch_s"]}}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rays", type=int, default=4096)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="issue the content render on the main stream instead of overlapping it with the block render / decoder")
-    ap.add_argument("--no-fused-adam", action="store_true", help="torch's multi-tensor instead of its fused Adam kernel for the decoder parameters")
-    ap.add_argument("--no-channels-last", action="store_true", help="keep the decoder in NCHW memory format")
-    ap.add_argument("--no-graph", action="store_true", help="run the loop body eagerly instead of replaying the captured hipGraph")
-    args = ap.parse_args()
-
-    # stdout carries exactly one JSON line: RCCL prints its version banner to stdout when the process group starts, so
-    # everything until the result goes to stderr's descriptor
+def emit(line, real_stdout):
     sys.stdout.flush()
-    real_stdout = os.dup(1)
+    os.dup2(real_stdout, 1)
+    print(json.dumps(line), flush=True)
     os.dup2(2, 1)
 
-    from nerf_signature_amd import dp, fieldops, synthetic, trainer
+
+# --------------------------------------------------------------------------------------------- the training-step benchmark
+
+def bench_training(args, scene, real_stdout):
+    from nerf_signature_amd import _native as nv
+    from nerf_signature_amd import blocks, dp, rays, synthetic, trainer
     from nerf_signature_amd.network import NeRFNetwork
+    from nerf_signature_amd.optim import CodebookAdam
 
     rank, world, local_rank = dp.init_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    dev = torch.device("cuda", local_rank % torch.cuda.device_count())   # (modulo: lets a 1-GPU box exercise the N>1 code path with gloo)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())   # (modulo: a 1-GPU box rehearses N ranks over gloo)
     torch.cuda.set_device(dev)
-    D, scene = 32, "hotdog"
     cfg = synthetic.SCENES[scene]
+    D = cfg["message_dim"]
+    H, W = cfg["H"], cfg["W"]
+    intr = (cfg["focal"], cfg["focal"], W / 2, H / 2)
 
     torch.manual_seed(0)
     model = NeRFNetwork(bound=cfg["bound"], cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1, message_dim=D, n_views=1)
     synthetic.init_model(model, scene)
     model.to(dev).train()
-    if not args.no_channels_last and os.environ.get("NERFSIG_DECODER", "") == "torch":   # only the stock-operator decoder benefits
-        model.msg_decoder.to(memory_format=torch.channels_last)   # MIOpen's kernels are NHWC: saves the layout changes around every conv
     render_kwargs = dict(dt_gamma=cfg["dt_gamma"], max_steps=1024)
 
     bo, bd = synthetic.block_rays(scene, dev)
-    co, cd = synthetic.content_rays(scene, args.rays, seed=rank, device=dev)
-    with torch.no_grad():  # "ground truth" = the clean model's render of the same rays (nerf/provider_wtmk.py:415)
-        gt = model.render(co, cd, None, staged=False, bg_color=1, perturb=False, force_all_rays=True, **render_kwargs)["image"]
-    data = {"watermark": {"rays_o_block": bo, "rays_d_block": bd}, "content": {"rays_o": co, "rays_d": cd, "images": gt}}
-    from nerf_signature_amd.optim import CodebookAdam
+    # the poses the per-step content batches come from, and their clean renders ("ground truth" = the clean model's render of the
+    # same pose, nerf/provider_wtmk.py:408-416): resident before the timed region
+    prng = np.random.RandomState(77)
+    poses = torch.from_numpy(np.stack([synthetic.orbit_pose(0.6 + 0.9 * prng.rand(), 2 * np.pi * prng.rand(), cfg["radius"]) for _ in range(args.poses)])).to(dev)
+    with torch.no_grad():
+        clean = blocks.clean_render(model, poses, intr, H, W, render_kwargs, max_ray_batch=H * W).reshape(args.poses, H * W, 3).clamp_(0, 1).contiguous()
+    torch.manual_seed(1000 + rank)          # pixel draws (torch.randint on the device, utils_wtmk_disen.py:105) differ per rank
+
+    def draw_content(step_index):
+        """A new pose + new pixels: rays on the device (N1, rg_get_rays) and the matching ground-truth pixels."""
+        k = (step_index * world + rank) % args.poses
+        r = rays.get_rays(poses[k:k + 1], intr, H, W, N=args.rays)
+        return {"rays_o": r["rays_o"], "rays_d": r["rays_d"], "images": clean[k][r["inds"][0]].unsqueeze(0)}
+
+    first = draw_content(0)
+    data = {"watermark": {"rays_o_block": bo, "rays_d_block": bd}, "content": first}
     # main_nerf_wtmk.py:110: Adam(get_params(lr), betas=(0.9, 0.99), eps=1e-15) -- same semantics, the codebook update fused
     optimizer = CodebookAdam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, **({} if args.no_graph else ({"capturable": True} if args.no_fused_adam else {"fused": True, "capturable": True})))
     if args.no_graph:
         loop = trainer.WatermarkLoop(model, optimizer, render_kwargs, side_stream=None if args.no_overlap else torch.cuda.Stream())
     else:
-        loop = trainer.GraphedWatermarkLoop(model, optimizer, render_kwargs, data, overlap_content=not args.no_overlap)
+        loop = trainer.GraphedWatermarkLoop(model, optimizer, render_kwargs, data, overlap_content=not args.no_overlap, content_headroom=0.25)
 
-    from nerf_signature_amd import _native as nv
     timer = NativeTimer(nv)
     msg_rng = np.random.RandomState(1234)   # same stream on every rank: the message is replicated
-
     draw = lambda: torch.from_numpy(msg_rng.randint(0, 2, D).astype(np.float32))   # fresh message per step (:1165), host side
     upcoming = [draw()]
+    counter = [0]
 
     def one_step():
         # the captured loop is told the next step's message one step early (the same sequence of draws, looked ahead by one):
         # its optimiser kernel then leaves that message's pre-summed codebook behind (GraphedWatermarkLoop, presum_in_adam)
         msg = upcoming.pop()
         upcoming.append(draw())
-        return loop.step(data, msg) if args.no_graph else loop.step(msg, next_message=upcoming[0])
+        step_data = None if args.fixed_rays else {"content": draw_content(counter[0])}
+        counter[0] += 1
+        if args.no_graph:
+            return loop.step(data if step_data is None else {"watermark": data["watermark"], "content": step_data["content"]}, msg)
+        return loop.step(msg, data=step_data, next_message=upcoming[0])
 
     for _ in range(args.warmup):
         one_step()
@@ -161,12 +300,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = args.no_graph          # a replayed graph runs no Python: kernels are timed in the eager pass below
+    overflow = False
     t0 = time.perf_counter()
-    trace = os.environ.get("NERFSIG_BENCH_TRACE")          # diagnostics only: synchronises every step
     for i in range(args.steps):
         out = one_step()
-        if trace and rank == 0 and i % 5 == 4:
-            print(f"[trace] step {args.warmup + i + 1}: loss_image {float(out[3]):.3e} loss_watermark {float(out[4]):.4f}", file=sys.stderr)
     if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
@@ -197,9 +334,11 @@ def main():
             n_block, n_content = n_content, n_block
     else:
         n_block, n_content = loop.point_counts()
-    rays_block, rays_content = bo.shape[0] * bo.shape[1] * bo.shape[2], args.rays
-    rays_per_step = (rays_block + rays_content) * world
-    # the dominant kernel: the hash-gather encoder, on the block render (the launch with the most points)
+    sharded = bool(getattr(loop, "sharded", False)) or (args.no_graph and dp.block_shard(bo.shape[0]) is not None)
+    rays_block_all = bo.shape[0] * bo.shape[1] * bo.shape[2]
+    rays_block_rank = rays_block_all // world if sharded else rays_block_all
+    rays_content = args.rays
+    # the dominant kernel: the hash-gather encoder, on the launch with the most points (N = 1: the block render)
     big = max(n_block, n_content) // 2
     enc_s, enc_n, enc_rows = timer.stats("hg_encode_planes", big)
     mlp_s, _, _ = timer.stats("field_fwd", big)
@@ -211,81 +350,165 @@ def main():
         sct_s, _, _ = timer.stats("hg_scatter_binned", big)
         if sct_s == 0.0:
             sct_s, _, _ = timer.stats("hg_scatter_sliced", big)
-    pts_real = float(max(n_block, n_content))
-    gather_bytes = 1024 + 64 * D
-    achieved = pts_real * gather_bytes / enc_s if enc_s > 0 else 0.0
-    fwd_total = enc_s + mlp_s
-    achieved_fwd = pts_real * BYTES_FWD_PER_POINT(D) / fwd_total if fwd_total > 0 else 0.0
+    pts_big = float(max(n_block, n_content))
+    pts_step = float(n_block + n_content)
+    ms = elapsed / args.steps * 1e3
 
-    if rank == 0:
-        line = {
-            "metric": "training rays/sec @4096 rays (hotdog, 32-bit msg)",
-            "value": rays_per_step * args.steps / elapsed,
-            "unit": "rays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (hash gather, compositing) + split-bf16 MFMA with f32 accumulate (MLPs)",
-            "data": "synthetic",
-            "config": {
-                "workload": "Blender/hotdog-like synthetic scene S0, --wtmk_tcnn, 4096 content rays + 32x12x12 block rays per rank per step, 32-bit msg, 1xMI355X HIP raymarch+hash+MLP",
-                "rays_per_step_per_rank": rays_block + rays_content, "content_rays": rays_content, "block_rays": rays_block,
-                "points_per_step_per_rank": n_block + n_content, "samples_per_ray_block": n_block / rays_block,
-                "samples_per_ray_content": n_content / rays_content, "content_rays_per_s": rays_content * world * args.steps / elapsed,
-                "message_dim": D, "parallelism": f"dp{world}", "optimizer": "Adam(betas=(0.9,0.99), eps=1e-15): torch semantics, codebook update fused (opt_codebook_adam)",
-                "grad_exchange_bytes_per_step": loop.exchange.bytes_per_step,
-                "execution": "eager" if args.no_graph else ("hipGraph replay (forward+backward | RCCL exchange | optimiser)" if dp.exchange_active()
-                                                            else "hipGraph replay (one capture of forward+backward+optimiser)"),
-                "capacity_overflow": overflow,
-                "loss": loss_value, "loss_image": loss_parts[0], "loss_watermark": loss_parts[1],
-            },
-            "roofline": {
-                "kernel": "k_encode_planes (16-level hash gather + pre-summed codebook gather, forward) on the block render",
-                "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                "traffic": None,
-                "launches": enc_n, "avg_launch_s": enc_s, "points_per_launch": pts_real, "rows_per_launch": enc_rows,
-                "algorithmic_bytes_per_point": gather_bytes,
-                "note": "algorithmic bytes are SURVEY.md 8(d)'s (1024 + 64*D per point, the reference's D separate codebook gathers); "
-                        "the kernel issues 1024 + 64 B/point because the D tables are pre-summed (DESIGN.md section 2)",
-                "limiter": "texture-address path: PMC TA busy 84 % of the kernel, ~1.3 cycles per L1 tag lookup, 35.5 lookups per wave-level "
-                           "gather (profiles/r01_pmc_encode_block_launch.txt, tools/micro/gather_rate.hip); HBM moves 412 MB per launch",
-                "issued_gather_bytes_per_point": 1024 + 64,
-                "frac_of_issued_bytes": (pts_real * (1024 + 64) / enc_s) / HBM_PEAK if enc_s > 0 else 0.0,
-                "frac_of_measured_copy_ceiling": achieved / 6.29e12,
-                "forward_encoder_plus_mlp": {"avg_s": fwd_total, "achieved_GBps": achieved_fwd / 1e9, "frac": achieved_fwd / HBM_PEAK,
-                                             "algorithmic_bytes_per_point": BYTES_FWD_PER_POINT(D)},
-                "backward_mlp_plus_scatter": {"avg_s": bwd_s + sct_s, "k_field_bwd_s": bwd_s, "scatter_s": sct_s, "plan_s_off_path": plan_s,
-                                              "achieved_GBps": (pts_real * BYTES_BWD_PER_POINT(D) / (bwd_s + sct_s) / 1e9) if bwd_s + sct_s > 0 else 0.0,
-                                              "algorithmic_bytes_per_point": BYTES_BWD_PER_POINT(D)},
-            },
-        }
-        # the MLP kernel against the matrix-core roof (north_star: "MFMA utilisation on the MLP against chip peak").  Issued work:
-        # 72 v_mfma_f32_32x32x16_bf16 (32 768 FLOP each) per 32-point wave = three split-bf16 products per algorithmic one;
-        # algorithmic work: SURVEY.md 8(d)'s 10 240 MAC = 20 480 FLOP per point.  PMC cross-check (profiles/r01_pmc_mfma_summary.txt):
-        # SQ_INSTS_MFMA = 2.903e6 and SQ_VALU_MFMA_BUSY_CYCLES = 9.29e7 (= 32 cycles x MFMAs) per 1.29 M-point launch.
-        rows = float(enc_rows) if enc_rows else pts_real
-        issued_flop = rows / 32.0 * 72 * 32768
-        line["roofline_mlp"] = {
-            "kernel": "k_field_fwd<planes> (sigma MLP + SH + colour MLP, split-bf16 MFMA, fp32 accumulate) on the block render",
-            "bound": "mfma", "achieved": (issued_flop / mlp_s / 1e12) if mlp_s > 0 else 0.0, "peak": 2500.0, "unit": "TFLOP/s",
-            "frac": (issued_flop / mlp_s / 2.5e15) if mlp_s > 0 else 0.0, "avg_launch_s": mlp_s,
-            "algorithmic_TFLOPs": (pts_real * 20480 / mlp_s / 1e12) if mlp_s > 0 else 0.0,
-            "note": "achieved = issued bf16 MFMA FLOP/s (3 split-bf16 MFMAs per algorithmic product keep fp32-level accuracy); "
-                    "the algorithmic rate is a third of it; the kernel is co-limited by the VALU work of splitting activations into bf16 pairs",
-        }
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                # HBM bytes per launch of the same kernel on the same inputs, from a separate rocprofv3 --pmc run (profiles/)
-                line["roofline"]["traffic"] = json.load(open(pmc)).get("k_encode_planes_hbm_bytes_per_launch")
-            except Exception:
-                pass
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(model, D)
-        sys.stdout.flush()
-        os.dup2(real_stdout, 1)
-        print(json.dumps(line), flush=True)
-        os.dup2(2, 1)
+    if rank != 0:
+        return
+    # ---- bytes.  IMPLEMENTED algorithm: the D selected codebook tables are pre-summed into one (linearity of the
+    # trilinear interpolation), so a point gathers 16 base levels + 1 summed level, 8 corners x 8 B each.
+    gather_impl = 16 * 64 + 64                     # 1088 B/point actually gathered by k_encode_planes
+    gather_ref = 16 * 64 + 64 * D                  # the reference algorithm's D separate codebook gathers (side value only)
+    achieved = pts_big * gather_impl / enc_s if enc_s > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:   # HBM bytes per launch of the same kernel on the same inputs, from a separate rocprofv3 --pmc run (profiles/)
+            traffic = json.load(open(pmc)).get("k_encode_planes_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    # whole step, implemented bytes: per point forward 1088 gathered + 32 (xyz, dir, deltas) + 16 (sigma, rgb); backward 64 (upstream
+    # gradients, saved sigma/rgb/masks) + 128 (four 16-byte scatter-queue entries written and read); per step the optimiser's streams:
+    # G once, param/exp_avg/exp_avg_sq of D tables read+written (6 D tables), ~D/2 partner tables + S written for the next pre-sum
+    step_bytes = pts_step * (gather_impl + 48 + 64 + 128) + (1 + 6 * D + D / 2 + 1) * T_BYTES
+    line = {
+        "metric": "training rays/sec @4096 rays (hotdog, 32-bit msg)" if scene == "hotdog" else f"training rays/sec @4096 rays ({scene}, {D}-bit msg)",
+        "value": rays_content * world * args.steps / elapsed,
+        "unit": "rays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (hash gather, compositing) + " + nv.mlp_precision_name(),
+        "data": "synthetic",
+        "config": {
+            "workload": f"Blender/hotdog-like synthetic scene S0, --wtmk_tcnn, per rank and step: {rays_content} content rays of a new pose + its share of the 32x12x12 "
+                        f"watermark-block rays, 32-bit msg, {world}xMI355X HIP raymarch+hash+MLP" if scene == "hotdog" else
+                        f"Mip-NeRF360/counter-like synthetic scene S1 (bound 2, two cascades, camera inside), {rays_content} content rays + 32x12x12 block rays, {D}-bit msg, {world}xMI355X",
+            "value_basis": "content rays (the metric's 4096-ray batch) x ranks / time; block rays excluded",
+            "all_rays_per_s": (rays_content * world + rays_block_all) * args.steps / elapsed,
+            "points_per_s": (n_content * world + (n_block * world if sharded else n_block)) * args.steps / elapsed,
+            "content_rays": rays_content, "block_rays_total": rays_block_all, "block_rays_this_rank": rays_block_rank, "blocks_sharded_over_ranks": sharded,
+            "points_per_step_per_rank": n_block + n_content, "samples_per_ray_block": n_block / max(rays_block_rank, 1),
+            "samples_per_ray_content": n_content / rays_content,
+            "ray_sets": "fixed" if args.fixed_rays else f"new pose (of {args.poses} pre-rendered clean views) + new random pixels every step, rays generated on the device inside the timed loop",
+            "message_dim": D, "parallelism": f"dp{world}", "optimizer": "Adam(betas=(0.9,0.99), eps=1e-15): torch semantics, codebook update fused (opt_codebook_adam)",
+            "grad_exchange_bytes_per_step": loop.exchange.bytes_per_step + (rays_block_all * 12 if sharded else 0),
+            "collectives_per_step": (loop.exchange.collectives_per_step + (1 if sharded else 0)) if dp.exchange_active() else 0,
+            "world_size_seen_by_backend": dp.world_size(), "backend": dist.get_backend() if dist.is_initialized() else None,
+            "execution": "eager" if args.no_graph else f"hipGraph replay, {len(loop.segments)} captured segment(s)" + (" with the RCCL collectives between them" if len(loop.segments) > 1 else ""),
+            "capacity_overflow": overflow,
+            "loss": loss_value, "loss_image": loss_parts[0], "loss_watermark": loss_parts[1],
+        },
+        "roofline": {
+            "kernel": "k_encode_planes (16-level hash gather + pre-summed codebook gather, forward) on the launch with the most points",
+            "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+            "traffic": traffic,
+            "launches": enc_n, "avg_launch_s": enc_s, "points_per_launch": pts_big, "rows_per_launch": enc_rows,
+            "algorithmic_bytes_per_point": gather_impl,
+            "basis": "bytes of the IMPLEMENTED algorithm: 16 base levels + the pre-summed codebook level, 8 corners x 8 B (DESIGN.md sections 2 and 6)",
+            "observed_limiter": "not HBM: the working set (64 MiB base + 4 MiB pre-sum) is L2/MALL-resident; PMC shows the texture-address path busy ~85 % and "
+                                "the L2->L1 line fills (~4 GB per launch) as the limiter (profiles/*pmc_encode*)",
+            "frac_hbm_counters": (traffic / enc_s / HBM_PEAK) if (traffic and enc_s > 0) else None,
+            "reference_algorithm": {"bytes_per_point": gather_ref, "note": "SURVEY.md 8(d) formula (D separate codebook gathers); the kernel does not move these bytes, "
+                                    "so this is a speed-up factor over a literal implementation, NOT a roofline fraction",
+                                    "equivalent_GBps": (pts_big * gather_ref / enc_s / 1e9) if enc_s > 0 else 0.0},
+            "forward_encoder_plus_mlp_s": enc_s + mlp_s,
+            "backward_mlp_plus_scatter": {"avg_s": bwd_s + sct_s, "k_field_bwd_s": bwd_s, "scatter_s": sct_s, "plan_s_off_path": plan_s},
+            "whole_step": {"implemented_bytes_per_step": step_bytes, "achieved_GBps": step_bytes / (ms * 1e-3) / 1e9, "frac": step_bytes / (ms * 1e-3) / HBM_PEAK,
+                           "note": "all kernels of the step (march, decoder, compositing, losses included in the time, not in the bytes)"},
+        },
+    }
+    # the MLP kernel against the matrix-core roof (north_star: "MFMA utilisation on the MLP against chip peak").
+    rows = float(enc_rows) if enc_rows else pts_big
+    mfma_per_wave, kind = nv.mlp_mfma_per_wave()
+    issued_flop = rows / 32.0 * mfma_per_wave * 32768
+    line["roofline_mlp"] = {
+        "kernel": f"k_field_fwd<planes> (sigma MLP + SH + colour MLP, {nv.mlp_precision_name()}) on the same launch",
+        "bound": "mfma", "achieved": (issued_flop / mlp_s / 1e12) if mlp_s > 0 else 0.0, "peak": MFMA_PEAK[kind] / 1e12, "unit": "TFLOP/s",
+        "frac": (issued_flop / mlp_s / MFMA_PEAK[kind]) if mlp_s > 0 else 0.0, "avg_launch_s": mlp_s,
+        "algorithmic_TFLOPs": (pts_big * 20480 / mlp_s / 1e12) if mlp_s > 0 else 0.0,
+        "frac_algorithmic": (pts_big * 20480 / mlp_s / MFMA_PEAK[kind]) if mlp_s > 0 else 0.0,
+        "mfma_per_32_points": mfma_per_wave,
+        "note": "achieved = issued MFMA FLOP/s (v_mfma_f32_32x32x16: 32768 FLOP each); algorithmic = 20 480 FLOP per point (SURVEY.md 8(d))",
+    }
+    if world == 1 and not args.no_cpu_baseline and scene == "hotdog":
+        line["cpu_baseline"] = cpu_baseline(model, D)
+    emit(line, real_stdout)
+
+
+# --------------------------------------------------------------------------------------------- config 5: full-image eval + decoder
+
+def bench_fern(args, real_stdout):
+    """BASELINE.json config 5 (LLFF/fern-like scene S2): 48-bit message, 64x64 block grid, bound 2 / two cascades / dt_gamma 1/128;
+    one step = the watermarked full-image render of a 1008x756 view, staged in 4096-ray chunks (187 chunks, renderer_wtmk.py:555-570)
+    under no_grad with the model in training mode (utils_wtmk_disen.py:832: test_image never calls model.eval()), then the 48 selected
+    11x15 blocks through the HiDDeN decoder and the bit accuracy (eval_step, :648-702)."""
+    from nerf_signature_amd import rays, synthetic, trainer
+    from nerf_signature_amd.network import NeRFNetwork
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    scene = "fern"
+    cfg = synthetic.SCENES[scene]
+    D, H, W = cfg["message_dim"], cfg["H"], cfg["W"]
+    intr = (cfg["focal"], cfg["focal"], W / 2, H / 2)
+    torch.manual_seed(0)
+    model = NeRFNetwork(bound=cfg["bound"], cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1, message_dim=D, n_views=1)
+    synthetic.init_model(model, scene)
+    model.to(dev).train()
+    kw = dict(dt_gamma=cfg["dt_gamma"], max_steps=1024)
+    pose = torch.from_numpy(synthetic.orbit_pose(1.1, 0.7, cfg["radius"]))[None].to(dev)
+    bh, bw = H // cfg["rows"], W // cfg["cols"]
+    bo, _ = synthetic.block_rays(scene, dev)
+    assert bo.shape[:3] == (D, bh, bw)
+    msg = torch.from_numpy(np.random.RandomState(5).randint(0, 2, D).astype(np.float32))
+    acc = trainer.BIT_ACC()
+    r = rays.get_rays(pose, intr, H, W, -1)
+    bo_all, bd_all = synthetic.block_rays(scene, dev)
+
+    @torch.no_grad()
+    def one_image():
+        img = model.render(r["rays_o"], r["rays_d"], msg, staged=True, max_ray_batch=4096, bg_color=1, perturb=False, force_all_rays=True, **kw)["image"]
+        blocks_img = model.render(bo_all, bd_all, msg, staged=False, bg_color=1, perturb=False, force_all_rays=True, **kw)["image"]
+        decoded = model.msg_decoder(model.normalization(blocks_img.clamp(0, 1).permute(0, 3, 1, 2)))
+        return img, decoded
+
+    for _ in range(max(args.warmup, 1)):
+        one_image()
+    torch.cuda.synchronize()
+    steps = max(1, min(args.steps, 10))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        img, decoded = one_image()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    acc.update(decoded.permute(1, 0), msg[None].to(dev))
+    n_chunks = (H * W + 4095) // 4096
+    emit({"metric": "full-image watermarked render + decoder eval (fern, 48-bit msg)", "value": steps / elapsed, "unit": "images/s", "n_gpus": 1, "steps": steps,
+          "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+          "dtype": "f32 (hash gather, compositing) + " + __import__("nerf_signature_amd._native", fromlist=["x"]).mlp_precision_name(), "data": "synthetic",
+          "config": {"workload": f"LLFF/fern-like synthetic scene S2: {W}x{H} view staged in {n_chunks} chunks of 4096 rays (training-mode kernels under no_grad, "
+                                 f"as the reference's test_image runs them) + {D} blocks of {bh}x{bw} through the HiDDeN decoder, 48-bit msg, 64x64 block grid, 1xMI355X",
+                     "rays_per_s": (H * W + D * bh * bw) * steps / elapsed, "chunks": n_chunks, "bit_accuracy_random_init": acc.measure(),
+                     "image_mean": float(img.mean()), "secondary": True}}, real_stdout)
+
+
+def main():
+    args = parse_args()
+    in_rank = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and not in_rank:
+        launch_ranks(args)                       # never returns
+    if args.dry_launch:
+        dry_launch(args)                         # never returns
+    # stdout carries exactly one JSON line: RCCL prints its version banner to stdout when the process group starts, so
+    # everything until the result goes to stderr's descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    if args.config == "fern":
+        bench_fern(args, real_stdout)
+    else:
+        bench_training(args, args.config, real_stdout)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -207,9 +207,18 @@ int opt_codebook_adam_sel_next(const float *G, float *const *params_host, float 
 /* ------------------------------------------------------------------ field network */
 
 /* Re-lays the two flat tcnn-style parameter vectors (sigma: 3072, color: 7168 fp32, layout in
- * INTEGRATION.md) into split-bf16 MFMA operand order.  packed needs mlp_packed_bytes() bytes. */
+ * INTEGRATION.md) into MFMA operand order, as split-bf16 (hi, lo) AND as fp16 fragments.  packed needs mlp_packed_bytes() bytes. */
 size_t mlp_packed_bytes(void);
 int mlp_pack_weights(const float *sigma_params, const float *color_params, void *packed, nsig_stream_t stream);
+
+/* Arithmetic of the MLP kernels (field_fwd / field_color_fwd / field_bwd / field_bwd_planned), process-wide:
+ *   0 = split-bf16: three v_mfma_f32_32x32x16_bf16 per product (hi*hi + hi*lo + lo*hi), fp32 accumulate, ~2^-16 per product;
+ *   1 = fp16: one v_mfma_f32_32x32x16_f16 per product, fp32 accumulate (tinycudann's FullyFusedMLP, which the reference calls at
+ *       nerf/network_wtmk_tcnn.py:52-88, computes in fp16 with fp16 accumulate); the backward normalises every point's upstream
+ *       gradient by a power of two, so loss-scaled gradients neither overflow nor underflow.
+ * Default: environment variable NERFSIG_MLP ("bf16x3" | "f16"), else 1.  The stage-1 trace entry points always use mode 0. */
+int mlp_get_precision(void);
+int mlp_set_precision(int mode);
 
 #define FIELD_MASK_WORDS 6 /* uint32 words of ReLU masks per point saved by field_fwd for field_bwd */
 

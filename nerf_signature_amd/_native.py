@@ -46,6 +46,8 @@ SIGNATURES = {
     "opt_codebook_adam_sel": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _fl, _fl, _fl, _fl, _vp, _vp],
     "opt_codebook_adam_sel_next": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _fl, _fl, _fl, _fl, _vp, _vp, _vp, _vp],
     "mlp_packed_bytes": [],
+    "mlp_get_precision": [],
+    "mlp_set_precision": [_int],
     "mlp_pack_weights": [_vp, _vp, _vp, _vp],
     "hg_planes_bytes": [_u32],
     "hg_encode_planes": [_vp, _u32, _fl, _vp, _vp, _vp, _vp],
@@ -131,6 +133,21 @@ def call(name, *args):
     if rc != 0:
         msg = load().nsig_last_error().decode("utf-8", "replace")
         raise (ValueError if rc == 1 else NativeError)(f"{name} failed (code {rc}): {msg}")
+
+
+def mlp_precision_name():
+    """Human-readable arithmetic of the MLP kernels as currently selected (mlp_get_precision)."""
+    return ("fp16 MFMA with f32 accumulate (MLPs)" if fn("mlp_get_precision")() == 1 else "split-bf16 MFMA (3 per product) with f32 accumulate (MLPs)")
+
+
+def mlp_mfma_per_wave():
+    """(MFMAs the forward MLP kernel issues per 32 points, operand dtype key) for the selected arithmetic."""
+    return (24, "f16") if fn("mlp_get_precision")() == 1 else (72, "bf16")
+
+
+def set_mlp_precision(name):
+    """'f16' or 'bf16x3' (mlp_set_precision)."""
+    call("mlp_set_precision", {"bf16x3": 0, "f16": 1}[name])
 
 
 def ptr(t):

@@ -15,9 +15,14 @@
 //     baked into the packed weights (mlp_pack_weights), the activations never touch LDS or HBM.
 //   * weights are frozen and tiny: they are staged once per workgroup into LDS as ready-made A fragments
 //     (16 B per lane, conflict-free ds_read_b128).
-//   * precision: every product is evaluated as split-bf16 (hi*hi + hi*lo + lo*hi, fp32 accumulate), i.e.
-//     ~2^-16 relative error per product on the bf16 matrix pipe; MFMA time stays negligible next to the
-//     gathers (3 x 24 MFMAs per 32 points).
+//   * precision, two selectable variants of every MFMA kernel (mlp_set_precision / NERFSIG_MLP):
+//       Bf16x3: every product is evaluated as split-bf16 (hi*hi + hi*lo + lo*hi, fp32 accumulate), ~2^-16 relative error per
+//               product, 3 x 24 MFMAs per 32 points forward and ~6 VALU operations per operand pair for the split;
+//       F16   : operands rounded once to fp16 (2^-11), ONE v_mfma_f32_32x32x16_f16 per product with fp32 accumulate (the
+//               reference's tcnn FullyFusedMLP computes in fp16 WITH fp16 accumulate, network_wtmk_tcnn.py:52-88): 24 MFMAs
+//               forward / 20 backward per 32 points, one v_cvt_pk per operand pair, half the LDS.  The backward normalises each
+//               point's upstream gradient by a power of two first (exact), so loss-scaled gradients (GradScaler's 65536x) can
+//               neither overflow nor underflow fp16.
 //   * backward needs only the input gradient of the codebook channels (all network weights are frozen,
 //     network_wtmk_tcnn.py:90-95), so the forward saves just the ReLU sign bits (6 words per point).
 #include <cstdlib>
@@ -28,6 +33,8 @@
 namespace nsig {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ----------------------------------------------------------------------------- packed weight layout
@@ -47,9 +54,10 @@ constexpr int B4 = 16;  // W1s[:,30:32]^T             1 x 4
 constexpr int B4F = 20; // W1s^T, all 32 features     1 x 4   (stage-1 training: gradients of the base tables)
 constexpr int kBwdFrags = 24;
 constexpr int kFragBytes = 64 * 16;  // 64 lanes x 8 bf16
-// packed = [fwd hi | fwd lo | bwd hi | bwd lo]
+// packed = [fwd hi | fwd lo | bwd hi | bwd lo] (bf16) | [fwd | bwd] (fp16)
 constexpr size_t kFwdBytes = (size_t)kFwdFrags * kFragBytes, kBwdBytes = (size_t)kBwdFrags * kFragBytes;
-constexpr size_t kPackedBytes = 2 * kFwdBytes + 2 * kBwdBytes;
+constexpr size_t kPackedBf16Bytes = 2 * kFwdBytes + 2 * kBwdBytes;
+constexpr size_t kPackedBytes = kPackedBf16Bytes + kFwdBytes + kBwdBytes;
 
 constexpr int kSigmaW1 = 0, kSigmaW2 = 2048;                 // offsets in sigma_params (3072)
 constexpr int kColorW1 = 0, kColorW2 = 2048, kColorW3 = 6144;  // offsets in color_params (7168)
@@ -108,6 +116,8 @@ __global__ void __launch_bounds__(256) k_pack_weights(const float *__restrict__ 
     const size_t lo_off = (fwd ? kFwdBytes : kBwdBytes) / 2;
     base_hi[(size_t)f * 512 + lane * 8 + j] = hi;
     base_hi[lo_off + (size_t)f * 512 + lane * 8 + j] = lo;
+    _Float16 *half_base = reinterpret_cast<_Float16 *>(reinterpret_cast<char *>(packed) + kPackedBf16Bytes) + (fwd ? 0 : kFwdBytes / 2);
+    half_base[(size_t)f * 512 + lane * 8 + j] = (_Float16)w;
 }
 
 // ----------------------------------------------------------------------------- wave-level building blocks
@@ -116,6 +126,10 @@ __global__ void __launch_bounds__(256) k_pack_weights(const float *__restrict__ 
 struct Split8 {
     uint32_t hi[4], lo[4];
 };
+// ... and as plain fp16, two values per dword.
+struct Half8 {
+    uint32_t v[4];
+};
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -123,34 +137,60 @@ __device__ inline uint32_t cvt_pk_bf16(float a, float b) {   // v_cvt_pk_bf16_f3
     const f32x2 v = {a, b};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
-// elements 2*jp, 2*jp + 1 of the operand: 6 VALU operations per pair, results already packed
-__device__ inline void split_put2(Split8 &s, int jp, float a, float b) {
-    const uint32_t hi = cvt_pk_bf16(a, b);
-    s.hi[jp] = hi;
-    s.lo[jp] = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+__device__ inline uint32_t cvt_pk_f16(float a, float b) {    // round to nearest even, a in the low half
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
 }
 __device__ inline bf16x8 operand(const uint32_t (&w)[4]) {
     const uint4 u = {w[0], w[1], w[2], w[3]};
     return __builtin_bit_cast(bf16x8, u);
 }
+__device__ inline f16x8 operand_h(const uint32_t (&w)[4]) {
+    const uint4 u = {w[0], w[1], w[2], w[3]};
+    return __builtin_bit_cast(f16x8, u);
+}
 
-// acc[rb] = sum over k-steps of A(frag0 + rb*KS + ks) . B[ks], split-bf16.
-template <int RB, int KS>
-__device__ inline void mfma_layer(const char *__restrict__ lds_hi, const char *__restrict__ lds_lo, int frag0, int lane,
-                                  const Split8 (&b)[KS], f32x16 (&acc)[RB]) {
+// The two precisions of the MFMA kernels.  A tag names the operand type, how a pair of fp32 values enters it, where the A
+// fragments of the forward / backward weights sit in the packed image and how many LDS bytes they take.
+struct Bf16x3 {
+    typedef Split8 Op;
+    static constexpr int kMfmaPerProduct = 3;
+    static constexpr size_t kFwdOffset = 0, kBwdOffset = 2 * kFwdBytes, kFwdLds = 2 * kFwdBytes, kBwdLds = 2 * kBwdBytes;
+    // elements 2*jp, 2*jp + 1 of the operand: 6 VALU operations per pair, results already packed
+    __device__ static inline void put2(Split8 &s, int jp, float a, float b) {
+        const uint32_t hi = cvt_pk_bf16(a, b);
+        s.hi[jp] = hi;
+        s.lo[jp] = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+    }
+    // c += A(fragment at byte offset off) . B: lo parts first, hi*hi last
+    __device__ static inline f32x16 mac(const char *__restrict__ lds, size_t half_bytes, int off, const Split8 &b, f32x16 c) {
+        const bf16x8 a_hi = *reinterpret_cast<const bf16x8 *>(lds + off);
+        const bf16x8 a_lo = *reinterpret_cast<const bf16x8 *>(lds + half_bytes + off);
+        const bf16x8 b_hi = operand(b.hi), b_lo = operand(b.lo);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, c, 0, 0, 0);
+    }
+};
+struct F16 {
+    typedef Half8 Op;
+    static constexpr int kMfmaPerProduct = 1;
+    static constexpr size_t kFwdOffset = kPackedBf16Bytes, kBwdOffset = kPackedBf16Bytes + kFwdBytes, kFwdLds = kFwdBytes, kBwdLds = kBwdBytes;
+    __device__ static inline void put2(Half8 &s, int jp, float a, float b) { s.v[jp] = cvt_pk_f16(a, b); }
+    __device__ static inline f32x16 mac(const char *__restrict__ lds, size_t, int off, const Half8 &b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(lds + off), operand_h(b.v), c, 0, 0, 0);
+    }
+};
+
+// acc[rb] = sum over k-steps of A(frag0 + rb*KS + ks) . B[ks].  lds: the staged fragments; half_bytes: distance from the hi to the
+// lo fragments (Bf16x3 only).
+template <typename P, int RB, int KS>
+__device__ inline void mfma_layer(const char *__restrict__ lds, size_t half_bytes, int frag0, int lane, const typename P::Op (&b)[KS], f32x16 (&acc)[RB]) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int off = (frag0 + rb * KS + ks) * kFragBytes + lane * 16;
-            const bf16x8 a_hi = *reinterpret_cast<const bf16x8 *>(lds_hi + off);
-            const bf16x8 a_lo = *reinterpret_cast<const bf16x8 *>(lds_lo + off);
-            const bf16x8 b_hi = operand(b[ks].hi), b_lo = operand(b[ks].lo);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, c, 0, 0, 0);
-        }
+        for (int ks = 0; ks < KS; ++ks) c = P::mac(lds, half_bytes, (frag0 + rb * KS + ks) * kFragBytes + lane * 16, b[ks], c);
         acc[rb] = c;
     }
 }
@@ -158,7 +198,8 @@ __device__ inline void mfma_layer(const char *__restrict__ lds_hi, const char *_
 // ReLU a 64-row activation held in two accumulators, return the "was positive" bits (bit 16*rb + r), emit the next B operand.
 // No compares (they would hold 32 lane masks in SGPRs): the value is max(v, 0); the flag is the sign bit of 0 - bits(v) --
 // set exactly when v > 0, because an accumulator that starts at +0 never holds -0 -- shifted in with one v_alignbit.
-__device__ inline uint32_t relu_to_operand(const f32x16 (&acc)[2], Split8 (&b)[4]) {
+template <typename P>
+__device__ inline uint32_t relu_to_operand(const f32x16 (&acc)[2], typename P::Op (&b)[4]) {
     uint32_t bits = 0;   // filled most-significant-first, reversed at the end: index i ends in bit i
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -169,7 +210,7 @@ __device__ inline uint32_t relu_to_operand(const f32x16 (&acc)[2], Split8 (&b)[4
             bits = __builtin_amdgcn_alignbit(bits, 0u - u0, 31);
             bits = __builtin_amdgcn_alignbit(bits, 0u - u1, 31);
             // max(v, 0) as an integer max on the bit patterns (negative floats are negative integers): no NaN canonicalisation
-            split_put2(b[2 * rb + (r >> 3)], (r & 7) >> 1, __uint_as_float((uint32_t)max((int)u0, 0)), __uint_as_float((uint32_t)max((int)u1, 0)));
+            P::put2(b[2 * rb + (r >> 3)], (r & 7) >> 1, __uint_as_float((uint32_t)max((int)u0, 0)), __uint_as_float((uint32_t)max((int)u1, 0)));
         }
     return __builtin_bitreverse32(bits);
 }
@@ -180,12 +221,13 @@ __device__ inline float masked(float v, uint32_t bits, int i) {   // v where bit
     asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(bits), "n"(i));
     return __uint_as_float(__float_as_uint(v) & m);
 }
-__device__ inline void mask_to_operand(const f32x16 (&acc)[2], uint32_t bits, Split8 (&b)[4]) {
+template <typename P>
+__device__ inline void mask_to_operand(const f32x16 (&acc)[2], uint32_t bits, typename P::Op (&b)[4]) {
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int r = 0; r < 16; r += 2)
-            split_put2(b[2 * rb + (r >> 3)], (r & 7) >> 1, masked(acc[rb][r], bits, rb * 16 + r), masked(acc[rb][r + 1], bits, rb * 16 + r + 1));
+            P::put2(b[2 * rb + (r >> 3)], (r & 7) >> 1, masked(acc[rb][r], bits, rb * 16 + r), masked(acc[rb][r + 1], bits, rb * 16 + r + 1));
 }
 
 // Degree-4 real spherical harmonics (the 16 components of hash_encoding.py:157-183) of d in [-1,1]^3.
@@ -241,18 +283,20 @@ __device__ inline void store_rows64(float *__restrict__ dst, uint32_t stride, ui
         for (int r = 0; r < 16; ++r) dst[(size_t)(32 * rb + row_of_reg16(h, r)) * stride + s] = f(acc[rb][r], rb * 16 + r);
 }
 
-__device__ inline void color_branch(const char *lds_hi, const char *lds_lo, int lane, int h, float dx, float dy, float dz,
+template <typename P>
+__device__ inline void color_branch(const char *lds, int lane, int h, float dx, float dy, float dz,
                                     const float (&geo8)[8], uint32_t (&mask)[2], float (&rgb)[3], const ActTrace *trace = nullptr,
                                     uint32_t stride = 0, uint32_t s = 0) {
+    constexpr size_t kHalf = kFwdBytes;
     // tcnn's SH encoding takes inputs in [0,1] and maps them back (network_wtmk_tcnn.py:114-115)
     const float ux = (dx + 1.0f) / 2.0f, uy = (dy + 1.0f) / 2.0f, uz = (dz + 1.0f) / 2.0f;
     float sh[16];
     sh16(ux * 2.0f - 1.0f, uy * 2.0f - 1.0f, uz * 2.0f - 1.0f, sh);
-    Split8 cin[2];
+    typename P::Op cin[2];
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
-        split_put2(cin[0], j >> 1, h ? sh[8 + j] : sh[j], h ? sh[9 + j] : sh[j + 1]);
-        split_put2(cin[1], j >> 1, geo8[j], geo8[j + 1]);
+        P::put2(cin[0], j >> 1, h ? sh[8 + j] : sh[j], h ? sh[9 + j] : sh[j + 1]);
+        P::put2(cin[1], j >> 1, geo8[j], geo8[j + 1]);
     }
     auto relu = [](float v, int) { return v > 0.0f ? v : 0.0f; };
     if (trace != nullptr) {
@@ -264,15 +308,15 @@ __device__ inline void color_branch(const char *lds_hi, const char *lds_lo, int 
         }
     }
     f32x16 hid[2];
-    Split8 b4[4];
-    mfma_layer<2, 2>(lds_hi, lds_lo, F2, lane, cin, hid);
-    mask[0] = relu_to_operand(hid, b4);
+    typename P::Op b4[4];
+    mfma_layer<P, 2, 2>(lds, kHalf, F2, lane, cin, hid);
+    mask[0] = relu_to_operand<P>(hid, b4);
     if (trace != nullptr) store_rows64(trace->h1, stride, s, h, hid, relu);
-    mfma_layer<2, 4>(lds_hi, lds_lo, F3, lane, b4, hid);
-    mask[1] = relu_to_operand(hid, b4);
+    mfma_layer<P, 2, 4>(lds, kHalf, F3, lane, b4, hid);
+    mask[1] = relu_to_operand<P>(hid, b4);
     if (trace != nullptr) store_rows64(trace->h2, stride, s, h, hid, relu);
     f32x16 out[1];
-    mfma_layer<1, 4>(lds_hi, lds_lo, F4, lane, b4, out);
+    mfma_layer<P, 1, 4>(lds, kHalf, F4, lane, b4, out);
 #pragma unroll
     for (int c = 0; c < 3; ++c) rgb[c] = 1.0f / (1.0f + expf(-out[0][c]));  // rows 0..2 live in lane half 0
 }
@@ -359,15 +403,15 @@ __global__ void __launch_bounds__(256) k_encode_planes(const float *__restrict__
 }
 
 // kPlanes = false: gather the features in-kernel (fused); true: read them from the level-major planes.
-template <bool kPlanes, bool kTrace = false>
+template <typename P, bool kPlanes, bool kTrace = false>
 __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyzs, const float *__restrict__ dirs, uint32_t M, float bound,
                                                    TablePtrs base, LevelGeom geom, const float *__restrict__ S,
                                                    const float2 *__restrict__ planes, uint32_t stride,
                                                    const char *__restrict__ packed, float *__restrict__ sigmas, float *__restrict__ rgbs,
                                                    float *__restrict__ geo_out, uint32_t *__restrict__ masks, ActTrace trace = ActTrace{}) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    stage_weights(lds, packed, 2 * (int)kFwdBytes);
-    const char *lds_hi = lds, *lds_lo = lds + kFwdBytes;
+    stage_weights(lds, packed + P::kFwdOffset, (int)P::kFwdLds);
+    constexpr size_t kHalf = kFwdBytes;
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int p = lane & 31, h = lane >> 5;
@@ -377,7 +421,7 @@ __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyz
         const uint32_t sl = min(s, M - 1);
         // lane half 0 owns levels {0..3, 8..11}, half 1 owns {4..7, 12..15}: its 16 features are exactly
         // its elements of the two K-steps of the first layer's B operand.
-        Split8 feat[2];
+        typename P::Op feat[2];
         if (kPlanes) {
             float2 f[8];
 #pragma unroll
@@ -388,7 +432,7 @@ __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyz
                 f[7].y = f[7].y + c.y;
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) split_put2(feat[q >> 2], q & 3, f[q].x, f[q].y);
+            for (int q = 0; q < 8; ++q) P::put2(feat[q >> 2], q & 3, f[q].x, f[q].y);
         } else {
             const float two_b = 2.0f * bound;
             const float x = (xyzs[3 * (size_t)sl] + bound) / two_b;       // network_wtmk_tcnn.py:101
@@ -405,17 +449,17 @@ __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyz
                         f.x = f.x + c.x;
                         f.y = f.y + c.y;
                     }
-                    split_put2(feat[g], i, f.x, f.y);
+                    P::put2(feat[g], i, f.x, f.y);
                 }
         }
 
         f32x16 hid[2];
-        Split8 b4[4];
-        mfma_layer<2, 2>(lds_hi, lds_lo, F0, lane, feat, hid);
-        const uint32_t mask_s = relu_to_operand(hid, b4);
+        typename P::Op b4[4];
+        mfma_layer<P, 2, 2>(lds, kHalf, F0, lane, feat, hid);
+        const uint32_t mask_s = relu_to_operand<P>(hid, b4);
         if (kTrace) store_rows64(trace.hs, stride, s, h, hid, [](float v, int) { return v > 0.0f ? v : 0.0f; });
         f32x16 so[1];
-        mfma_layer<1, 4>(lds_hi, lds_lo, F1, lane, b4, so);
+        mfma_layer<P, 1, 4>(lds, kHalf, F1, lane, b4, so);
 
         // rows 0..15 of the sigma head: register r (< 8) of half h is row_of_reg(h, r); row 0 is log-density
         const bool live = s < M;
@@ -434,8 +478,8 @@ __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyz
             for (int r = 0; r < 8; ++r) geo8[r] = so[0][r];
             if (h == 0) geo8[0] = 1.0f;  // the slot of row 0 carries the padded constant input (weight column 31)
             float rgb[3];
-            color_branch(lds_hi, lds_lo, lane, h, dirs[3 * (size_t)sl], dirs[3 * (size_t)sl + 1], dirs[3 * (size_t)sl + 2], geo8, mask_c, rgb,
-                         kTrace ? &trace : nullptr, stride, s);
+            color_branch<P>(lds, lane, h, dirs[3 * (size_t)sl], dirs[3 * (size_t)sl + 1], dirs[3 * (size_t)sl + 2], geo8, mask_c, rgb,
+                            kTrace ? &trace : nullptr, stride, s);
             if (live && h == 0) { rgbs[3 * (size_t)s] = rgb[0]; rgbs[3 * (size_t)s + 1] = rgb[1]; rgbs[3 * (size_t)s + 2] = rgb[2]; }
         }
         if (masks != nullptr) {
@@ -446,11 +490,11 @@ __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyz
 }
 
 // NeRFNetwork.color: geo features come from memory instead of the sigma head.
+template <typename P>
 __global__ void __launch_bounds__(256) k_field_color(const float *__restrict__ dirs, const float *__restrict__ geo, uint32_t M,
                                                      const char *__restrict__ packed, float *__restrict__ rgbs) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    stage_weights(lds, packed, 2 * (int)kFwdBytes);
-    const char *lds_hi = lds, *lds_lo = lds + kFwdBytes;
+    stage_weights(lds, packed + P::kFwdOffset, (int)P::kFwdLds);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int p = lane & 31, h = lane >> 5;
     const uint32_t n_tiles = ceil_div(M, 32u);
@@ -465,14 +509,14 @@ __global__ void __launch_bounds__(256) k_field_color(const float *__restrict__ d
         }
         uint32_t mask_c[2];
         float rgb[3];
-        color_branch(lds_hi, lds_lo, lane, h, dirs[3 * (size_t)sl], dirs[3 * (size_t)sl + 1], dirs[3 * (size_t)sl + 2], geo8, mask_c, rgb);
+        color_branch<P>(lds, lane, h, dirs[3 * (size_t)sl], dirs[3 * (size_t)sl + 1], dirs[3 * (size_t)sl + 2], geo8, mask_c, rgb);
         if (s < M && h == 0) { rgbs[3 * (size_t)s] = rgb[0]; rgbs[3 * (size_t)s + 1] = rgb[1]; rgbs[3 * (size_t)s + 2] = rgb[2]; }
     }
 }
 
 // ----------------------------------------------------------------------------- backward
 
-template <bool kFull = false>
+template <typename P, bool kFull = false>
 __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyzs, uint32_t M, float bound, float cb_cell,
                                                    const float *__restrict__ g_sigma, const float *__restrict__ g_rgb,
                                                    const float *__restrict__ sigmas, const float *__restrict__ rgbs,
@@ -480,8 +524,12 @@ __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyz
                                                    float *__restrict__ G, float *__restrict__ dfeat_out, float *__restrict__ rec_out,
                                                    GradTrace gt = GradTrace{}, uint32_t stride = 0, ScatterPlan plan = ScatterPlan{}) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    stage_weights(lds, packed + 2 * kFwdBytes, 2 * (int)kBwdBytes);
-    const char *lds_hi = lds, *lds_lo = lds + kBwdBytes;
+    stage_weights(lds, packed + P::kBwdOffset, (int)P::kBwdLds);
+    constexpr size_t kHalf = kBwdBytes;
+    // F16: the backward is linear in the point's upstream gradient, so that gradient is first scaled by a power of two that brings
+    // its largest component into [1, 2) (exact), and the result scaled back: fp16's 5-bit exponent then never overflows or
+    // underflows, whatever loss scale the caller's GradScaler applies.  (The stage-1 trace path stores intermediates: Bf16x3 only.)
+    constexpr bool kNormalise = P::kMfmaPerProduct == 1 && !kFull;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int p = lane & 31, h = lane >> 5;
     const uint32_t n_tiles = ceil_div(M, 32u);
@@ -506,7 +554,7 @@ __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyz
         if (planned) dst = plan.dest[sl];   // issued with the masks: long done when the gradients are
 
         // d(pre-sigmoid color): only lane half 0, elements 0..2 of the 16-wide K-step are non-zero
-        Split8 dout[1];
+        typename P::Op dout[1];
         float dv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -518,38 +566,49 @@ __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyz
             dv[j] = v;
             if (kFull) gt.d_out[(size_t)(8 * h + j) * stride + s] = v;   // rows 3..15 are zero
         }
+        // d log-density = g * exp(clamp(h0, -15, 15)) (activation.py:14), with exp(h0) = sigma: enters at the sigma head, row 0 (half 0)
+        float head0 = 0.0f;
+        if (h == 0 && live) head0 = g_sigma[sl] * fminf(fmaxf(sigmas[sl], e_lo), e_hi);
+        float unscale = 1.0f;
+        if (kNormalise) {
+            float amp = fmaxf(fmaxf(fabsf(dv[0]), fabsf(dv[1])), fmaxf(fabsf(dv[2]), fabsf(head0)));   // (half 1 holds zeros)
+            amp = fmaxf(amp, __shfl_xor(amp, 32, 64));
+            const uint32_t e = (__float_as_uint(amp) >> 23) & 0xffu;
+            if (e >= 1u && e <= 253u) {          // zero, subnormal and non-finite amplitudes pass through unscaled
+                const float sc = __uint_as_float((254u - e) << 23);
+                unscale = __uint_as_float(e << 23);
+                dv[0] *= sc; dv[1] *= sc; dv[2] *= sc; head0 *= sc;
+            }
+        }
 #pragma unroll
-        for (int j = 0; j < 8; j += 2) split_put2(dout[0], j >> 1, dv[j], dv[j + 1]);
+        for (int j = 0; j < 8; j += 2) P::put2(dout[0], j >> 1, dv[j], dv[j + 1]);
         f32x16 hid[2];
-        Split8 b4[4];
-        mfma_layer<2, 1>(lds_hi, lds_lo, B0, lane, dout, hid);
-        mask_to_operand(hid, mask_c1, b4);
+        typename P::Op b4[4];
+        mfma_layer<P, 2, 1>(lds, kHalf, B0, lane, dout, hid);
+        mask_to_operand<P>(hid, mask_c1, b4);
         if (kFull) store_rows64(gt.d_h2, stride, s, h, hid, [=](float v, int i) { return ((mask_c1 >> i) & 1u) ? v : 0.0f; });
-        mfma_layer<2, 4>(lds_hi, lds_lo, B1, lane, b4, hid);
-        mask_to_operand(hid, mask_c0, b4);
+        mfma_layer<P, 2, 4>(lds, kHalf, B1, lane, b4, hid);
+        mask_to_operand<P>(hid, mask_c0, b4);
         if (kFull) store_rows64(gt.d_h1, stride, s, h, hid, [=](float v, int i) { return ((mask_c0 >> i) & 1u) ? v : 0.0f; });
         f32x16 dso[1];
-        mfma_layer<1, 4>(lds_hi, lds_lo, B2, lane, b4, dso);  // rows 1..15 = d geo_feat
+        mfma_layer<P, 1, 4>(lds, kHalf, B2, lane, b4, dso);  // rows 1..15 = d geo_feat
 
-        Split8 dhead[1];
+        typename P::Op dhead[1];
         float head8[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) head8[r] = dso[0][r];
-        if (h == 0) {  // row 0: d log-density = g * exp(clamp(h0, -15, 15)) (activation.py:14), with exp(h0) = sigma
-            const float sg = live ? sigmas[sl] : 0.0f;
-            head8[0] = (live ? g_sigma[sl] : 0.0f) * fminf(fmaxf(sg, e_lo), e_hi);
-        }
+        if (h == 0) head8[0] = head0;  // row 0: d log-density
 #pragma unroll
         for (int r = 0; r < 8; ++r)
             if (kFull) gt.d_so[(size_t)row_of_reg(h, r) * stride + s] = head8[r];
 #pragma unroll
-        for (int r = 0; r < 8; r += 2) split_put2(dhead[0], r >> 1, head8[r], head8[r + 1]);
-        mfma_layer<2, 1>(lds_hi, lds_lo, B3, lane, dhead, hid);
-        mask_to_operand(hid, mask_s, b4);
+        for (int r = 0; r < 8; r += 2) P::put2(dhead[0], r >> 1, head8[r], head8[r + 1]);
+        mfma_layer<P, 2, 1>(lds, kHalf, B3, lane, dhead, hid);
+        mask_to_operand<P>(hid, mask_s, b4);
         if (kFull) {
             store_rows64(gt.d_hs, stride, s, h, hid, [=](float v, int i) { return ((mask_s >> i) & 1u) ? v : 0.0f; });
             f32x16 dall[1];
-            mfma_layer<1, 4>(lds_hi, lds_lo, B4F, lane, b4, dall);  // row f = d feature[f]; registers (r, r+1), r even, hold one level's pair
+            mfma_layer<P, 1, 4>(lds, kHalf, B4F, lane, b4, dall);  // row f = d feature[f]; registers (r, r+1), r even, hold one level's pair
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 float2 v;
@@ -559,10 +618,10 @@ __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyz
             continue;
         }
         f32x16 dfe[1];
-        mfma_layer<1, 4>(lds_hi, lds_lo, B4, lane, b4, dfe);  // rows 0,1 (lane half 0) = d feature[30], d feature[31]
+        mfma_layer<P, 1, 4>(lds, kHalf, B4, lane, b4, dfe);  // rows 0,1 (lane half 0) = d feature[30], d feature[31]
 
         // both halves of a point share the scatter: half h handles corners 4h..4h+3
-        const float g0 = __shfl(dfe[0][0], p, 64), g1 = __shfl(dfe[0][1], p, 64);
+        const float g0 = __shfl(dfe[0][0], p, 64) * unscale, g1 = __shfl(dfe[0][1], p, 64) * unscale;
         if (!live) continue;
         if (dfeat_out != nullptr && h == 0) { dfeat_out[2 * (size_t)s] = g0; dfeat_out[2 * (size_t)s + 1] = g1; }
         const float two_b = 2.0f * bound;
@@ -618,6 +677,23 @@ __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyz
 using namespace nsig;
 
 NSIG_EXPORT size_t mlp_packed_bytes(void) { return kPackedBytes; }
+
+// 0 = Bf16x3 (split-bf16, three MFMAs per product, fp32-level accuracy), 1 = F16 (one fp16 MFMA per product, fp32 accumulate).
+// Process-wide; default from NERFSIG_MLP ("bf16x3" | "f16").  Both operand images live in every packed buffer.
+static int g_mlp_precision = -1;
+static int mlp_precision() {
+    if (g_mlp_precision < 0) {
+        const char *e = getenv("NERFSIG_MLP");
+        g_mlp_precision = (e != nullptr && (e[0] == 'b' || e[0] == 'B')) ? 0 : 1;
+    }
+    return g_mlp_precision;
+}
+NSIG_EXPORT int mlp_get_precision(void) { return mlp_precision(); }
+NSIG_EXPORT int mlp_set_precision(int mode) {
+    NSIG_REQUIRE(mode == 0 || mode == 1, "mlp_set_precision: 0 (bf16x3) or 1 (f16)");
+    g_mlp_precision = mode;
+    return NSIG_OK;
+}
 
 NSIG_EXPORT int mlp_pack_weights(const float *sigma_params, const float *color_params, void *packed, nsig_stream_t stream) {
     NSIG_REQUIRE(sigma_params && color_params && packed, "mlp_pack_weights: null pointer");
@@ -708,22 +784,25 @@ NSIG_EXPORT int field_fwd(const float *xyzs, const float *dirs, uint32_t M, floa
     if (M == 0) return NSIG_OK;
     const char *pk = reinterpret_cast<const char *>(packed);
     hipStream_t st = as_stream(stream);
+    const bool f16 = mlp_precision() == 1;
     if (planes == nullptr) {  // fused: gather inside the MLP kernel (small batches)
-        k_field_fwd<false><<<field_grid(M, true), 256, 2 * kFwdBytes, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, nullptr, 0, pk, sigmas, rgbs,
-                                                                    geo_feat, masks);
+        if (f16) k_field_fwd<F16, false><<<field_grid(M, true), 256, F16::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, nullptr, 0, pk, sigmas, rgbs, geo_feat, masks);
+        else k_field_fwd<Bf16x3, false><<<field_grid(M, true), 256, Bf16x3::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, nullptr, 0, pk, sigmas, rgbs, geo_feat, masks);
         return check_launch("field_fwd");
     }
     NSIG_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 7) == 0, "field_fwd: planes must be 8-byte aligned");
     const uint32_t stride = ceil_div(M, 32u) * 32u;
-    k_field_fwd<true><<<field_grid(M, true), 256, 2 * kFwdBytes, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, reinterpret_cast<const float2 *>(planes),
-                                                               stride, pk, sigmas, rgbs, geo_feat, masks);
+    const float2 *pl = reinterpret_cast<const float2 *>(planes);
+    if (f16) k_field_fwd<F16, true><<<field_grid(M, true), 256, F16::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, geo_feat, masks);
+    else k_field_fwd<Bf16x3, true><<<field_grid(M, true), 256, Bf16x3::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, geo_feat, masks);
     return check_launch("field_fwd");
 }
 
 NSIG_EXPORT int field_color_fwd(const float *dirs, const float *geo_feat, uint32_t M, const void *packed, float *rgbs, nsig_stream_t stream) {
     NSIG_REQUIRE(dirs && geo_feat && packed && rgbs, "field_color_fwd: null pointer");
     if (M == 0) return NSIG_OK;
-    k_field_color<<<field_grid(M), 256, 2 * kFwdBytes, as_stream(stream)>>>(dirs, geo_feat, M, reinterpret_cast<const char *>(packed), rgbs);
+    if (mlp_precision() == 1) k_field_color<F16><<<field_grid(M), 256, F16::kFwdLds, as_stream(stream)>>>(dirs, geo_feat, M, reinterpret_cast<const char *>(packed), rgbs);
+    else k_field_color<Bf16x3><<<field_grid(M), 256, Bf16x3::kFwdLds, as_stream(stream)>>>(dirs, geo_feat, M, reinterpret_cast<const char *>(packed), rgbs);
     return check_launch("field_color_fwd");
 }
 
@@ -734,8 +813,12 @@ NSIG_EXPORT int field_bwd(const float *xyzs, uint32_t M, float bound, const floa
     NSIG_REQUIRE(G || dfeat_out || rec_out, "field_bwd: at least one of G / dfeat_out / rec_out must be given");
     NSIG_REQUIRE(bound > 0.0f, "field_bwd: bound must be positive");
     if (M == 0) return NSIG_OK;
-    k_field_bwd<false><<<field_grid(M), 256, 2 * kBwdBytes, as_stream(stream)>>>(xyzs, M, bound, 1.0f / kCodebookResolution, grad_sigmas, grad_rgbs,
-                                                                         sigmas, rgbs, masks, reinterpret_cast<const char *>(packed), G, dfeat_out, rec_out);
+    if (mlp_precision() == 1)
+        k_field_bwd<F16, false><<<field_grid(M), 256, F16::kBwdLds, as_stream(stream)>>>(xyzs, M, bound, 1.0f / kCodebookResolution, grad_sigmas, grad_rgbs, sigmas, rgbs, masks,
+                                                                                 reinterpret_cast<const char *>(packed), G, dfeat_out, rec_out);
+    else
+        k_field_bwd<Bf16x3, false><<<field_grid(M), 256, Bf16x3::kBwdLds, as_stream(stream)>>>(xyzs, M, bound, 1.0f / kCodebookResolution, grad_sigmas, grad_rgbs, sigmas, rgbs,
+                                                                                       masks, reinterpret_cast<const char *>(packed), G, dfeat_out, rec_out);
     return check_launch("field_bwd");
 }
 
@@ -746,9 +829,14 @@ NSIG_EXPORT int field_bwd_planned(const float *xyzs, uint32_t M, float bound, co
     NSIG_REQUIRE(xyzs && grad_sigmas && grad_rgbs && sigmas && rgbs && masks && packed && plan, "field_bwd_planned: null pointer");
     NSIG_REQUIRE(bound > 0.0f && (reinterpret_cast<uintptr_t>(plan) & 15) == 0 && M < (1u << 28), "field_bwd_planned: bound must be positive, plan 16-byte aligned, M < 2^28");
     if (M == 0) return NSIG_OK;
-    k_field_bwd<false><<<field_grid(M), 256, 2 * kBwdBytes, as_stream(stream)>>>(xyzs, M, bound, 1.0f / kCodebookResolution, grad_sigmas, grad_rgbs,
-                                                                         sigmas, rgbs, masks, reinterpret_cast<const char *>(packed), nullptr, nullptr, nullptr,
-                                                                         GradTrace{}, 0, scatter_plan_view(plan, M));
+    if (mlp_precision() == 1)
+        k_field_bwd<F16, false><<<field_grid(M), 256, F16::kBwdLds, as_stream(stream)>>>(xyzs, M, bound, 1.0f / kCodebookResolution, grad_sigmas, grad_rgbs, sigmas, rgbs, masks,
+                                                                                 reinterpret_cast<const char *>(packed), nullptr, nullptr, nullptr, GradTrace{}, 0,
+                                                                                 scatter_plan_view(plan, M));
+    else
+        k_field_bwd<Bf16x3, false><<<field_grid(M), 256, Bf16x3::kBwdLds, as_stream(stream)>>>(xyzs, M, bound, 1.0f / kCodebookResolution, grad_sigmas, grad_rgbs, sigmas, rgbs,
+                                                                                       masks, reinterpret_cast<const char *>(packed), nullptr, nullptr, nullptr, GradTrace{}, 0,
+                                                                                       scatter_plan_view(plan, M));
     return check_launch("field_bwd_planned");
 }
 
@@ -764,7 +852,7 @@ NSIG_EXPORT int field_fwd_trace(const float *xyzs, const float *dirs, uint32_t M
     if (M == 0) return NSIG_OK;
     const uint32_t stride = ceil_div(M, 32u) * 32u;
     ActTrace tr{act_hs, act_cin, act_h1, act_h2};
-    k_field_fwd<true, true><<<field_grid(M), 256, 2 * kFwdBytes, as_stream(stream)>>>(xyzs, dirs, M, bound, base, make_level_geom(), nullptr,
+    k_field_fwd<Bf16x3, true, true><<<field_grid(M), 256, Bf16x3::kFwdLds, as_stream(stream)>>>(xyzs, dirs, M, bound, base, make_level_geom(), nullptr,
                                                                                      reinterpret_cast<const float2 *>(planes), stride,
                                                                                      reinterpret_cast<const char *>(packed), sigmas, rgbs, nullptr, masks, tr);
     return check_launch("field_fwd_trace");
@@ -778,7 +866,7 @@ NSIG_EXPORT int field_bwd_trace(uint32_t M, const float *grad_sigmas, const floa
     if (M == 0) return NSIG_OK;
     const uint32_t stride = ceil_div(M, 32u) * 32u;
     GradTrace gt{d_hs, d_h1, d_h2, d_so, d_out, reinterpret_cast<float2 *>(d_planes)};
-    k_field_bwd<true><<<field_grid(M), 256, 2 * kBwdBytes, as_stream(stream)>>>(nullptr, M, 1.0f, 1.0f / kCodebookResolution, grad_sigmas, grad_rgbs, sigmas,
+    k_field_bwd<Bf16x3, true><<<field_grid(M), 256, Bf16x3::kBwdLds, as_stream(stream)>>>(nullptr, M, 1.0f, 1.0f / kCodebookResolution, grad_sigmas, grad_rgbs, sigmas,
                                                                                rgbs, masks, reinterpret_cast<const char *>(packed), nullptr, nullptr,
                                                                                nullptr, gt, stride);
     return check_launch("field_bwd_trace");

@@ -1,15 +1,45 @@
-"""Data-parallel gradient exchange: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on
-ROCm; "gloo" for the CPU tests).
+"""Data parallelism of the watermark step: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on
+ROCm; "gloo" for the CPU tests and for rehearsing N ranks on a one-GPU box).
 
-What is exchanged per step: the decoder's gradients (261 893 fp32, one flat bucket) and the
-codebook gradient.  Because every selected codebook table receives the same gradient G [T,2]
-(csrc/hashgrid.hip), ranks all-reduce G alone -- 4 MiB -- and fan it out locally, instead of all-reducing
-D dense [T,2] gradients (128 MiB at D=32).  Rays are sharded by rank (distinct content rays per rank), the
-block render and the message are replicated, so the result equals the single-process gradient of the mean loss."""
+Partitioning.  Rays shard: rank r draws its own content rays, and the D watermark blocks are split
+too -- rank r renders blocks [r*D/R, (r+1)*D/R).  The HiDDeN decoder's BatchNorm uses batch statistics over the D blocks
+(hidden_models.py:26), so the decoder itself is replicated: the rendered blocks ([D,bh,bw,3], 55 KB at hotdog) are
+ALL-GATHERED, every rank decodes all D of them and back-propagates the image gradient of its own blocks only.
+
+Two collectives per step:
+  1. all-gather of the rendered blocks (gather_blocks), in the middle of the forward pass;
+  2. one all-reduce (SUM) of [G | decoder gradients] (GradExchange).  Every selected codebook table receives the same
+     gradient G [T,2] (csrc/hashgrid.hip), so ranks reduce G alone -- 4 MiB -- instead of D dense gradients (128 MiB at D=32).
+     With sharded blocks the block parts of G add up (sum) and the content parts are averaged: the step seeds the content
+     loss's backward with 1/R (content_grad_scale), so a plain SUM yields  sum_r G_block_r + mean_r G_content_r, the
+     single-process gradient of  lambda_w * BCE(all D blocks) + lambda_i * MSE(all R*4096 content rays).  The decoder's
+     gradients are identical on every rank (same gathered images); their sum is divided by R (keeps replicas in lockstep).
+Without sharding (D not divisible by R, or NERFSIG_REPLICATE_BLOCKS=1) the block render is replicated and everything is
+averaged, as in round 1.
+
+Inside a captured step a collective is a SEGMENT BOUNDARY: `collective(fn)` hands `fn` to the capturing loop, which ends the
+running graph capture, remembers `fn` to be executed eagerly at that point of every replay, and begins the next segment."""
 import os
 
 import torch
 import torch.distributed as dist
+
+_BOUNDARY = None      # installed by a capturing loop (trainer.GraphedWatermarkLoop): callable(fn)
+
+
+def set_boundary(handler):
+    """handler(fn): called instead of fn() when a collective is reached while the current stream is capturing.  Returns the previous one."""
+    global _BOUNDARY
+    prev, _BOUNDARY = _BOUNDARY, handler
+    return prev
+
+
+def collective(fn):
+    """Run the eager collective(s) in `fn` now -- or, under a segmented capture, make this point a segment boundary."""
+    if _BOUNDARY is not None and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        _BOUNDARY(fn)
+    else:
+        fn()
 
 
 def init_from_env(backend=None):
@@ -39,6 +69,56 @@ def exchange_active():
     if not dist.is_initialized():
         return False
     return dist.get_world_size() > 1 or os.environ.get("NERFSIG_FORCE_EXCHANGE", "") == "1"
+
+
+def rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+def block_shard(D):
+    """(first, one-past-last) watermark block of this rank, or None when the block render is replicated (no exchange phase, D not
+    divisible by the world size, or NERFSIG_REPLICATE_BLOCKS=1).  A world-size-1 rehearsal group shards into one piece."""
+    if not exchange_active() or os.environ.get("NERFSIG_REPLICATE_BLOCKS", "") == "1":
+        return None
+    world = dist.get_world_size()
+    if D % world != 0:
+        return None
+    n = D // world
+    return dist.get_rank() * n, (dist.get_rank() + 1) * n
+
+
+def content_grad_scale(sharded):
+    """Factor on the content loss's backward seed: 1/R with sharded blocks (the exchange then only sums), else 1."""
+    return 1.0 / world_size() if sharded else 1.0
+
+
+def _all_gather_into(out, local):
+    if dist.get_backend() == "gloo":     # (no all_gather_into_tensor on gloo: chunk views of `out` as the output list)
+        dist.all_gather(list(out.chunk(dist.get_world_size(), dim=0)), local)
+    else:
+        dist.all_gather_into_tensor(out, local)
+
+
+class _GatherBlocks(torch.autograd.Function):
+    """[D/R, ...] rendered blocks of this rank -> [D, ...] of all ranks (rank-major = block order).  Backward: every rank holds the
+    full image gradient (the decoder is replicated), so it just keeps the rows of its own blocks -- no communication."""
+
+    @staticmethod
+    def forward(ctx, local, D, first):
+        local = local.contiguous()
+        out = torch.empty((D,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        ctx.rows = (first, local.shape[0])
+        collective(lambda: _all_gather_into(out, local))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        first, n = ctx.rows
+        return g[first:first + n].contiguous(), None, None
+
+
+def gather_blocks(local_image, D, first):
+    return _GatherBlocks.apply(local_image, D, first)
 
 
 def _tiled_range(grads):
@@ -81,12 +161,14 @@ def _common_base(grads):
 class GradExchange:
     """All-reduce of (shared codebook gradient, decoder gradients) with the decoder in one flat bucket.
 
-    average=True (default): the mean over ranks, in place.  average=False: the plain sum -- the caller folds 1/world into
-    the optimiser kernels (`grad_scale` of CodebookAdam.step_shared_sel / step_dense), which saves the two scaling
-    launches between the graphs of the captured step."""
+    average=True (default): after the SUM, G is multiplied by `shared_scale` (default 1/world) and the decoder's gradients by
+    1/world, in place.  average=False: the plain sum -- the caller folds the factors into the optimiser kernels (`grad_scale` of
+    CodebookAdam.step_shared_sel / step_dense), which saves the scaling launches of the captured step.
+    shared_scale: 1.0 when the blocks are sharded and the content seeds already carry 1/world (module docstring)."""
 
-    def __init__(self, decoder_params, average=True):
+    def __init__(self, decoder_params, average=True, shared_scale=None):
         self.average = average
+        self.shared_scale = shared_scale
         self.decoder_params = [p for p in decoder_params if p.requires_grad]
         n = sum(p.numel() for p in self.decoder_params)
         p0 = self.decoder_params[0]
@@ -99,6 +181,8 @@ class GradExchange:
         world = world_size()
         if not exchange_active():
             return
+        s_shared = (1.0 / world) if self.shared_scale is None else float(self.shared_scale)
+        s_dec = 1.0 / world
         grads = [p.grad for p in self.decoder_params if p.grad is not None]
         if shared_grad is not None and shared_grad.is_contiguous() and shared_grad.dtype == torch.float32:
             # G and the decoder's gradient block behind it in one allocation (GradSink(tail=...) + hidden_models.set_grad_arena):
@@ -107,24 +191,29 @@ class GradExchange:
             g0 = shared_grad.storage_offset()
             if rng is not None and rng[0].data_ptr() == shared_grad.untyped_storage().data_ptr() and rng[1] == g0 + shared_grad.numel():
                 both = torch.empty(0, dtype=torch.float32, device=shared_grad.device).set_(rng[0], g0, (rng[2] - g0,))
-                dist.all_reduce(both, op=dist.ReduceOp.SUM)
+                collective(lambda: dist.all_reduce(both, op=dist.ReduceOp.SUM))
                 if self.average:
-                    both.mul_(1.0 / world)
+                    if s_shared == s_dec:
+                        both.mul_(s_dec)
+                    else:
+                        both[:shared_grad.numel()].mul_(s_shared)
+                        both[shared_grad.numel():].mul_(s_dec)
                 self.bytes_per_step = both.numel() * 4
                 self.collectives_per_step = 1
                 return
-        handles = []
-        if shared_grad is not None:
-            handles.append(dist.all_reduce(shared_grad, op=dist.ReduceOp.SUM, async_op=True))
         flat = _common_base(grads)
         if flat is not None:   # the gradients already live in one buffer: one collective, no copies
-            handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
-            for h in handles:
-                h.wait()
+
+            def both_reduces():
+                hs = [dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True) for t in (shared_grad, flat) if t is not None]
+                for h in hs:
+                    h.wait()
+
+            collective(both_reduces)
             if self.average:
                 if shared_grad is not None:
-                    shared_grad.mul_(1.0 / world)
-                flat.mul_(1.0 / world)
+                    shared_grad.mul_(s_shared)
+                flat.mul_(s_dec)
             self.bytes_per_step = (shared_grad.numel() * 4 if shared_grad is not None else 0) + flat.numel() * 4
             return
         off = 0
@@ -135,12 +224,16 @@ class GradExchange:
             else:
                 self.bucket[off:off + n].copy_(p.grad.reshape(-1))
             off += n
-        handles.append(dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, async_op=True))
-        for h in handles:
-            h.wait()
-        inv = 1.0 / world if self.average else 1.0
-        if shared_grad is not None:
-            shared_grad.mul_(inv)
+
+        def bucket_reduces():
+            hs = [dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True) for t in (shared_grad, self.bucket) if t is not None]
+            for h in hs:
+                h.wait()
+
+        collective(bucket_reduces)
+        inv = s_dec if self.average else 1.0
+        if shared_grad is not None and self.average:
+            shared_grad.mul_(s_shared)
         off = 0
         for p in self.decoder_params:
             n = p.numel()

@@ -183,6 +183,7 @@ def codebook_scatter_sliced(rec, G, binned=None):
 
 _PLAN_STREAM = None
 _PENDING_PLANS = []
+_LIVE_PLANS = []        # weak references to plans whose `ready` event may still be waited on
 
 
 def set_plan_stream(stream):
@@ -198,6 +199,20 @@ def flush_plans():
     """Enqueue every deferred scatter plan on its plan stream (behind whatever that stream already holds)."""
     while _PENDING_PLANS:
         _PENDING_PLANS.pop(0).launch()
+
+
+def forget_plan_events():
+    """A captured segment ended (trainer.GraphedWatermarkLoop): every launched plan is complete before the next segment starts (the
+    segments replay one after the other on one stream), and an event recorded inside a finished capture cannot be waited on in the
+    next one -- drop them.  (Deferred plans were flushed by train_step before the streams joined.)"""
+    alive = []
+    for ref in _LIVE_PLANS:
+        plan = ref()
+        if plan is not None:
+            if plan.launched:
+                plan.ready = None
+            alive.append(ref)
+    _LIVE_PLANS[:] = alive
 
 
 class ScatterPlan:
@@ -229,6 +244,8 @@ class ScatterPlan:
             self.buf.record_stream(self.stream)
             self.ready = torch.cuda.Event()     # the consumer waits for the plan, not for whatever else that stream runs later
             self.ready.record(self.stream)
+            import weakref
+            _LIVE_PLANS.append(weakref.ref(self))
         self.xyzs = None
 
     def join(self):

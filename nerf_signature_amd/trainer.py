@@ -15,6 +15,7 @@ import torch.nn.functional as F
 
 from . import _native as nv
 from . import fieldops as fo
+from . import dp
 from .dp import GradExchange, exchange_active, world_size
 from .hidden_models import normalize_img, set_grad_arena, set_weights_stream
 
@@ -53,18 +54,35 @@ class _WatermarkLoss(torch.autograd.Function):
         return g_content, None, g_decoded, None, None, None, None
 
 
-def backward_from_loss_kernel(out):
+def backward_from_loss_kernel(out, content_scale=1.0):
     """`out[-1].backward()` for a train_step whose losses came from wm_loss_fwd, without the ones-fill and the wm_loss_bwd launch:
     the forward kernel already left d(loss_i)/d(content) and d(loss_w)/d(decoded); for an upstream gradient of 1 they only need
-    the lambdas, which are applied here as the (host-side) scale of the seed."""
+    the lambdas, which are applied here as the (host-side) scale of the seed.
+    content_scale: extra factor on the content loss's seed (dp.content_grad_scale: 1/world when the watermark blocks are sharded
+    over the ranks, so that the gradient exchange is a plain sum)."""
     last = getattr(_WatermarkLoss, "last", None)
     _WatermarkLoss.last = None
     if last is None or last[0] is not out[-1]:
-        out[-1].backward()
+        if content_scale == 1.0:
+            out[-1].backward()
+        else:                       # loss = lambda_w * lossw + lambda_i * lossi (train_step): re-weight the image term
+            lambda_w, lambda_i = getattr(train_step, "last_lambdas", (1.0, 1.0))
+            (lambda_w * out[4] + (lambda_i * content_scale) * out[3]).backward()
         return
     _, content, decoded, d_content, d_decoded, lambda_w, lambda_i = last
-    seeds = [d_content if lambda_i == 1.0 else d_content * lambda_i, d_decoded if lambda_w == 1.0 else d_decoded * lambda_w]
+    ci = lambda_i * content_scale
+    seeds = [d_content if ci == 1.0 else d_content * ci, d_decoded if lambda_w == 1.0 else d_decoded * lambda_w]
     torch.autograd.backward([content, decoded], seeds)
+
+
+def local_blocks(wm):
+    """The watermark-block rays this rank renders: all of them, or its shard (dp.block_shard) as views of the same tensors.
+    Returns (rays_o, rays_d, shard or None)."""
+    o, d = wm["rays_o_block"], wm["rays_d_block"]
+    shard = dp.block_shard(o.shape[0]) if o.dim() == 4 else None
+    if shard is None:
+        return o, d, None
+    return o[shard[0]:shard[1]], d[shard[0]:shard[1]], shard
 
 
 def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce, side_stream=None, presum_first=False,
@@ -92,17 +110,26 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
         with torch.cuda.stream(side_stream):
             content_pred_rgb = model.render(content["rays_o"], content["rays_d"], message, **kw)["image"]
         content_pred_rgb.record_stream(main)
-    outputs = model.render(wm["rays_o_block"], wm["rays_d_block"], message, **kw)
+    block_o, block_d, shard = local_blocks(wm)
+    outputs = model.render(block_o, block_d, message, **kw)
     if main is not None:
         fo.flush_plans()          # the block render's scatter plan: on the plan stream, behind the content render
+    image = outputs["image"]
+    if shard is not None:
+        # the decoder's BatchNorm needs all D blocks (batch statistics, hidden_models.py:26): all-gather the rendered blocks, decode
+        # them on every rank; the backward keeps this rank's rows.  A collective ends a captured segment, so both streams meet first.
+        if main is not None:
+            main.wait_stream(side_stream)
+        image = dp.gather_blocks(image, wm["rays_o_block"].shape[0], shard[0])
     if model.normalization is normalize_img and hasattr(model.msg_decoder, "decode_rendered"):
-        decoded, pred_rgb = model.msg_decoder.decode_rendered(outputs["image"])    # clamp + permute + normalise inside layer 0
+        decoded, pred_rgb = model.msg_decoder.decode_rendered(image)    # clamp + permute + normalise inside layer 0
     else:
-        pred_rgb = torch.clamp(outputs["image"], min=0, max=1)
+        pred_rgb = torch.clamp(image, min=0, max=1)
         decoded = model.msg_decoder(model.normalization(pred_rgb.permute(0, 3, 1, 2)))
     gt_rgb = content["images"]
     if main is not None:
-        main.wait_stream(side_stream)
+        if shard is None:
+            main.wait_stream(side_stream)
     else:
         content_pred_rgb = model.render(content["rays_o"], content["rays_d"], message, **kw)["image"]
     keys = message.to(decoded.device).unsqueeze(-1)
@@ -114,6 +141,7 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
         lossi = ((content_pred_rgb - gt_rgb) ** 2).mean()
         lossw = loss_w(decoded, keys)
         loss = lambda_w * lossw + lambda_i * lossi
+    train_step.last_lambdas = (float(lambda_w), float(lambda_i))
     return pred_rgb, gt_rgb, content_pred_rgb, lossi, lossw, loss
 
 
@@ -132,6 +160,9 @@ class WatermarkLoop:
         self.exchange = GradExchange(list(model.msg_decoder.parameters()))
         self.last = None
 
+    def _sharded(self, data):
+        return local_blocks(data["watermark"])[2] is not None
+
     def step(self, data, message):
         """message: float tensor of 0./1. (keep it on the CPU to avoid the D2H read of its bits)."""
         if getattr(self.model, "device_select", False):
@@ -145,9 +176,13 @@ class WatermarkLoop:
             out = train_step(self.model, data, message, self.render_kwargs, self.lambda_w, self.lambda_i, side_stream=self.side_stream)
         finally:
             fo.set_plan_stream(prev)
-        out[-1].backward()
+        sharded = self._sharded(data)
+        backward_from_loss_kernel(out, dp.content_grad_scale(sharded))
         if self.side_stream is not None:
             torch.cuda.current_stream().wait_stream(self.side_stream)
+        if self.sink is None and exchange_active():
+            raise RuntimeError("data-parallel steps need the GradSink route (use_sink=True): per-table gradients are not exchanged")
+        self.exchange.shared_scale = 1.0 if sharded else None      # sharded blocks: G is a plain sum (content seeds carry 1/world)
         self.exchange(self.sink.G if self.sink is not None else None)
         if self.sink is not None and hasattr(self.optimizer, "step_shared"):
             self.optimizer.step_shared(self.sink.selected, self.sink.G)   # fused: no per-table gradients are materialised
@@ -220,7 +255,7 @@ class GraphedWatermarkLoop:
     points than that -- such a step dropped the rays that did not fit, like the reference's bounded mode."""
 
     def __init__(self, model, optimizer, render_kwargs, data, lambda_w=1.0, lambda_i=1.0, lr_lambda=None, headroom=0.0, native_dense_adam=True,
-                 overlap_content=True, march_ahead=None, presum_in_adam=True, stage_in_graph=True):
+                 overlap_content=True, march_ahead=None, presum_in_adam=True, stage_in_graph=True, content_headroom=None):
         """presum_in_adam: the captured optimiser kernel also writes the pre-summed codebook of the NEXT step's message
         (opt_codebook_adam_sel_next: +9 % traffic inside an HBM-streaming kernel instead of a 128 MiB pass at the head of every step).
         The next message is handed over one step early -- `step(message_k, next_message=message_k1)`, a one-element look-ahead over
@@ -251,6 +286,8 @@ class GraphedWatermarkLoop:
         self.render_kwargs = dict(render_kwargs)
         self.lambda_w, self.lambda_i = lambda_w, lambda_i
         self.lr_lambda, self.headroom = lr_lambda, headroom
+        # content rays change every step (a new pose / new pixels, utils_wtmk_disen.py:1164), so their sample total varies: own headroom
+        self.content_headroom = headroom if content_headroom is None else content_headroom
         dev = next(model.parameters()).device
         self.device = dev
         D = model.message_dim
@@ -276,6 +313,8 @@ class GraphedWatermarkLoop:
             g["lr"] = self.lr_dev          # tensor lr: the captured optimiser reads it on the device
         self.tables = model.msg_encoder.tables()
         self.graphs = None
+        self.segments, self.between = [], []
+        self.sharded = False
         self.out = None
         self.steps_done = 0
         self._replays = 0             # replays of the opening graph so far == the device's stage_counter (ring slot of the next step)
@@ -315,7 +354,7 @@ class GraphedWatermarkLoop:
         set_weights_stream(self.side_stream)     # the decoder's parameter gradients go there too: the block render's backward only waits for the image gradient
         set_grad_arena(self.sink.tail)
         try:
-            backward_from_loss_kernel(out)
+            backward_from_loss_kernel(out, dp.content_grad_scale(self.sharded))
         finally:
             set_weights_stream(None)
             set_grad_arena(None)
@@ -325,11 +364,13 @@ class GraphedWatermarkLoop:
 
     def _optimise(self):
         scale = 1.0 / world_size() if self.native_dense_adam else 1.0    # the exchange leaves sums: the mean is taken here
+        # sharded blocks: G is already sum_r G_block_r + mean_r G_content_r (the content seeds carried 1/world): no factor
+        scale_cb = 1.0 if (self.sharded and self.native_dense_adam) else scale
         if self.presum_in_adam:     # ... and the next step's pre-sum, in place (both renders of this step are done with the buffer)
-            self.optimizer.step_shared_sel(self.tables, self.msg_dev, self.sink.G, self.lr_dev, scale, next_message_dev=self.msg_next_dev,
+            self.optimizer.step_shared_sel(self.tables, self.msg_dev, self.sink.G, self.lr_dev, scale_cb, next_message_dev=self.msg_next_dev,
                                            S_next=self.model._presum_cache[1])
         else:
-            self.optimizer.step_shared_sel(self.tables, self.msg_dev, self.sink.G, self.lr_dev, scale)
+            self.optimizer.step_shared_sel(self.tables, self.msg_dev, self.sink.G, self.lr_dev, scale_cb)
         if self.native_dense_adam:
             self.optimizer.step_dense(self.lr_dev, scale)      # the decoder's parameters: opt_adam_dense
         else:
@@ -340,7 +381,8 @@ class GraphedWatermarkLoop:
         args = (kw.get("dt_gamma", 0), kw.get("max_steps", 1024))
         # the block render's march only: the content render's stays at the head of its step, on the side stream, where it
         # overlaps the pre-sum and the block encoder (both marches next to the optimiser took longer than the optimiser)
-        self.marched = (self.model.march_ahead(wm["rays_o_block"], wm["rays_d_block"], *args),)
+        block_o, block_d, _ = local_blocks(wm)       # (this rank's shard of the blocks when they are split over the ranks)
+        self.marched = (self.model.march_ahead(block_o, block_d, *args),)
 
     def _optimise_and_march(self):
         """The optimiser step and, beside it on the side stream, the march of the next step's samples."""
@@ -383,12 +425,12 @@ class GraphedWatermarkLoop:
             for k, v in self._pending_content.items():
                 self.data["content"][k].copy_(v, non_blocking=True)
             self._pending_content = None
-        if data is not None:
+        if data is not None:           # either part may be omitted: the watermark pose is fixed per dataset, content rays change every step
             for part in ("watermark", "content"):
-                for k, v in data[part].items():
+                for k, v in data.get(part, {}).items():
                     self.data[part][k].copy_(v, non_blocking=True)
-            if self.march_ahead and self.graphs is not None:
-                self._march_ahead()             # this step's rays arrived only now: march them before the replay
+            if self.march_ahead and self.graphs is not None and "watermark" in data:
+                self._march_ahead()             # this step's block rays arrived only now: march them before the replay
         if next_data is not None:
             if not self.march_ahead:
                 raise ValueError("next_data needs march_ahead=True")
@@ -423,20 +465,24 @@ class GraphedWatermarkLoop:
         model.point_capacity = None
         self.optimizer.zero_grad(set_to_none=True)
         self.sink.zero_()
+        block_o, block_d, shard = local_blocks(self.data["watermark"])
+        self.sharded = shard is not None
+        self.exchange.shared_scale = 1.0 if self.sharded else None
         with torch.no_grad():   # sizes only: the two renders of a step, in order (block, content)
-            model.render(self.data["watermark"]["rays_o_block"], self.data["watermark"]["rays_d_block"], message, staged=False, bg_color=1,
+            model.render(block_o, block_d, message, staged=False, bg_color=1,
                          perturb=False, force_all_rays=True, **self.render_kwargs)
             n_block = int(model.step_counter[(model.local_step - 1) % 16, 0])
             model.render(self.data["content"]["rays_o"], self.data["content"]["rays_d"], message, staged=False, bg_color=1, perturb=False,
                          force_all_rays=True, **self.render_kwargs)
             n_content = int(model.step_counter[(model.local_step - 1) % 16, 0])
         from .raymarching import padded_point_count
-        rays_block = self.data["watermark"]["rays_o_block"].numel() // 3
+        rays_block = block_o.numel() // 3
         rays_content = self.data["content"]["rays_o"].numel() // 3
         if rays_block == rays_content:
             raise ValueError("block and content renders must have different ray counts to carry separate capacities")
-        cap = lambda m: padded_point_count(int(m * (1.0 + self.headroom)))
-        model.point_capacity = {rays_block: cap(n_block), rays_content: cap(n_content)}
+        cap_block = padded_point_count(int(n_block * (1.0 + self.headroom)))
+        cap_content = padded_point_count(int(n_content * (1.0 + self.content_headroom)))
+        model.point_capacity = {rays_block: cap_block, rays_content: cap_content}
         model.device_select = True
         self._set_inputs(message, None)
 
@@ -456,26 +502,45 @@ class GraphedWatermarkLoop:
         self._restore(snapshot)
 
         self.optimizer.zero_grad(set_to_none=True)
-        split = exchange_active()
-        g1 = torch.cuda.CUDAGraph()
-        # thread_local: with more than one rank the process group's watchdog thread queries events while we capture; only this
-        # thread's calls belong to the capture
         if self.march_ahead:
             self._march_ahead()      # the first replay's samples (buffers outside the graph's pool, re-marched in place by every replay)
-        with torch.cuda.graph(g1, capture_error_mode="thread_local"):
-            self.out = self._forward_backward()
-            if not split:
+        # Segmented capture: one hipGraph per stretch between collectives.  A collective reached while capturing (dp.collective: the
+        # all-gather of the rendered blocks, the gradient all-reduce) ends the running capture, is remembered as the eager call that
+        # follows that segment in every replay, and the next segment begins in the same memory pool.  One rank: a single segment.
+        # thread_local: with more than one rank the process group's watchdog thread queries events while we capture; only this
+        # thread's calls belong to the capture.
+        self.segments, self.between = [torch.cuda.CUDAGraph()], []
+
+        def boundary(fn):
+            self.segments[-1].capture_end()
+            fo.forget_plan_events()          # events recorded in the finished capture must not be waited on in the next one
+            self.model._presum_event = None
+            self.between.append(fn)
+            g = torch.cuda.CUDAGraph()
+            self.segments.append(g)
+            g.capture_begin(pool=self.segments[0].pool(), capture_error_mode="thread_local")
+
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        capture_stream = torch.cuda.Stream()
+        capture_stream.wait_stream(torch.cuda.current_stream())
+        prev = dp.set_boundary(boundary)
+        try:
+            with torch.cuda.stream(capture_stream):
+                self.segments[0].capture_begin(capture_error_mode="thread_local")
+                self.out = self._forward_backward()
+                self.exchange(self.sink.G)
                 self._optimise_and_march()
-        g2 = None
-        if split:
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
-                self._optimise_and_march()
-        self.graphs = (g1, g2)
+                self.segments[-1].capture_end()
+        finally:
+            dp.set_boundary(prev)
+        torch.cuda.current_stream().wait_stream(capture_stream)
+        self.graphs = tuple(self.segments)
         self.capacity_rows = [(model.local_step - 2) % 16, (model.local_step - 1) % 16]
         # the counters are written in issue order: with a side stream train_step issues the content render first
-        self.capacities = [cap(n_block), cap(n_content)] if self.side_stream is None else [cap(n_content), cap(n_block)]
-        self.content_capacity = cap(n_content)
+        self.capacities = [cap_block, cap_content] if self.side_stream is None else [cap_content, cap_block]
+        self.content_capacity = cap_content
         if self.marched is not None:        # only the content render used the ring during the capture
             self.capacity_rows = [(model.local_step - 1) % 16]
         return self
@@ -498,17 +563,17 @@ class GraphedWatermarkLoop:
             if unannounced:
                 self.model.prepare_message(self.msg_dev)     # not announced one step early: the stand-alone pass, before the replay
             self._s_for = None if next_message is None else next_message.detach().to("cpu", torch.float32).clone()
-        g1, g2 = self.graphs
-        g1.replay()
-        slot = self._replays % len(self.msg_ring)
-        self._replays += 1           # immediately: the device counter has advanced whatever happens to the rest of this step (exchange, g2)
-        if self.stage_in_graph:      # the ring row of this step may be rewritten once this replay's opening kernel has read it
-            ev = torch.cuda.Event()
-            ev.record()
-            self.msg_events[slot] = ev
-        if g2 is not None:
-            self.exchange(self.sink.G)
-            g2.replay()
+        for i, g in enumerate(self.segments):
+            g.replay()
+            if i == 0:
+                slot = self._replays % len(self.msg_ring)
+                self._replays += 1       # immediately: the device counter has advanced whatever happens to the rest of this step
+                if self.stage_in_graph:  # the ring row of this step may be rewritten once this replay's opening kernel has read it
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    self.msg_events[slot] = ev
+            if i < len(self.between):
+                self.between[i]()        # the collective between two segments (RCCL; ordered after the segment on this stream)
         self.steps_done += 1
         return self.out
 

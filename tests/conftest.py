@@ -16,3 +16,26 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(params=["bf16x3", "f16"])
+def mlp_prec(request):
+    """Run a GPU test under both arithmetics of the MLP kernels (include/nerfsig.h: mlp_set_precision) and restore the default."""
+    from nerf_signature_amd import _native as nv
+    before = nv.fn("mlp_get_precision")()
+    nv.set_mlp_precision(request.param)
+    yield request.param
+    nv.call("mlp_set_precision", before)
+
+
+@pytest.fixture
+def strict_mlp():
+    """fp32-class arithmetic (split-bf16) for tests that compare GRADIENTS element-wise with the fp32 oracle: at fp16 operand precision
+    ~6 % of the points have some ReLU pre-activation so close to zero that the kernel and the oracle take different sides of the kink,
+    and such a point's gradient differs by a finite amount whatever the accumulate precision (tests/test_gpu_field.py::
+    test_field_backward_away_from_relu_kinks quantifies this; the reference's tinycudann MLP is fp16 with fp16 accumulate)."""
+    from nerf_signature_amd import _native as nv
+    before = nv.fn("mlp_get_precision")()
+    nv.set_mlp_precision("bf16x3")
+    yield
+    nv.call("mlp_set_precision", before)

@@ -31,7 +31,16 @@ def test_every_declared_symbol_is_exported(native):
 
 def test_host_only_queries(native):
     assert native.fn("rm_march_train_scratch_bytes")(4096, 1024) == 4096 * 1024 * 4
-    assert native.fn("mlp_packed_bytes")() == 2 * (24 + 24) * 64 * 16
+    assert native.fn("mlp_packed_bytes")() == 3 * (24 + 24) * 64 * 16          # split-bf16 hi + lo and fp16 fragments, forward + backward
+    before = native.fn("mlp_get_precision")()
+    assert before in (0, 1)
+    native.set_mlp_precision("bf16x3")
+    assert native.fn("mlp_get_precision")() == 0 and "split-bf16" in native.mlp_precision_name() and native.mlp_mfma_per_wave() == (72, "bf16")
+    native.set_mlp_precision("f16")
+    assert native.fn("mlp_get_precision")() == 1 and native.mlp_mfma_per_wave() == (24, "f16")
+    with pytest.raises(ValueError):
+        native.call("mlp_set_precision", 7)
+    native.call("mlp_set_precision", before)
 
 
 def test_argument_validation_needs_no_gpu(native):

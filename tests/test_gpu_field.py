@@ -91,8 +91,12 @@ def _params(tables, D=32):
     return P, sp.cuda(), cp.cuda()
 
 
+# measured agreement per arithmetic (max relative sigma error, max absolute rgb error): both far inside the stated 1e-3
+MEASURED = {"bf16x3": (2e-4, 5e-5), "f16": (5e-4, 2.5e-4)}
+
+
 @pytest.mark.parametrize("bound", [1.0, 2.0])
-def test_field_forward_vs_oracle_and_reference_glue(fo, tables, bound):
+def test_field_forward_vs_oracle_and_reference_glue(fo, tables, bound, mlp_prec):
     base, cb, base_d, cb_d = tables
     P, sp, cp = _params(tables)
     P["bound"] = bound
@@ -112,7 +116,7 @@ def test_field_forward_vs_oracle_and_reference_glue(fo, tables, bound):
         np.testing.assert_allclose(c1.cpu().numpy(), c0.numpy(), rtol=0, atol=1e-3)
         np.testing.assert_allclose(geo1.cpu().numpy(), geo0.numpy(), rtol=0, atol=1e-3)
         # measured agreement is far inside the stated tolerance
-        assert float((s1.cpu() / s0 - 1).abs().max()) < 2e-4 and float((c1.cpu() - c0).abs().max()) < 5e-5
+        assert float((s1.cpu() / s0 - 1).abs().max()) < MEASURED[mlp_prec][0] and float((c1.cpu() - c0).abs().max()) < MEASURED[mlp_prec][1]
         # density-only and color-only entry points agree with the fused one
         s2, none_rgb, geo2, _ = fo.field_forward(pts.cuda(), None, bound, base_d, S, packed, want_rgb=False, want_geo=True)
         assert none_rgb is None and torch.equal(s2, s1) and torch.equal(geo2, geo1)
@@ -128,7 +132,7 @@ def test_field_forward_vs_oracle_and_reference_glue(fo, tables, bound):
         np.testing.assert_allclose(s1.cpu().numpy(), g["sigma_clean"], rtol=1e-3, atol=1e-6)
 
 
-def test_field_backward_vs_oracle_autograd(fo, tables):
+def test_field_backward_vs_oracle_autograd(fo, tables, strict_mlp):
     base, cb, base_d, cb_d = tables
     P, sp, cp = _params(tables)
     packed = fo.pack_weights(sp, cp)
@@ -171,7 +175,61 @@ def test_field_backward_vs_oracle_autograd(fo, tables):
         np.testing.assert_allclose(cb_params[2 * i + b].grad.cpu().numpy(), G0.numpy(), rtol=1e-3, atol=1e-4 * scale)
 
 
-def test_trunc_exp_clamp_in_backward(fo, tables):
+def _oracle_per_point(pts, dirs, msg, P, gs, gc):
+    """fp32 oracle forward with every ReLU pre-activation exposed, and its per-point gradient w.r.t. the codebook feature (channels
+    30:32): returns (dfeat [M,2], smallest |pre-activation| of the point over the 192 hidden neurons)."""
+    x01 = (pts + P["bound"]) / (2 * P["bound"])
+    cbf = fr.codebook_encode(x01, msg, P["cb_tables"]).detach().requires_grad_(True)
+    base = fr.base_encode(x01, P["base_tables"]).detach()
+    feat = torch.cat([base[:, :-2], base[:, -2:] + cbf], dim=-1)
+    ws, wc = fr.split_mlp_params(P["sigma_params"], fr.SIGMA_WIDTHS), fr.split_mlp_params(P["color_params"], fr.COLOR_WIDTHS)
+    pre_s = feat @ ws[0].t()
+    h = torch.relu(pre_s) @ ws[1].t()
+    sigma = fr.trunc_exp(h[:, 0])
+    cin = torch.cat([fr.sh4(((dirs + 1) / 2) * 2 - 1), h[:, 1:], torch.ones_like(h[:, :1])], dim=-1)
+    pre_1 = cin @ wc[0].t()
+    pre_2 = torch.relu(pre_1) @ wc[1].t()
+    rgb = torch.sigmoid((torch.relu(pre_2) @ wc[2].t())[:, :3])
+    ((sigma * gs).sum() + (rgb * gc).sum()).backward()
+    margin = torch.cat([pre_s, pre_1, pre_2], dim=-1).detach().abs().min(dim=-1).values
+    return cbf.grad, margin
+
+
+def test_field_backward_away_from_relu_kinks(fo, tables, mlp_prec):
+    """What limits gradient agreement with the fp32 oracle at fp16 operand precision is WHICH SIDE of a ReLU kink a pre-activation
+    within rounding of zero lands on, not the arithmetic: per point, d feature[30:32] agrees to 5e-3 relative L2 over all points whose
+    192 hidden pre-activations keep a margin from zero, in both arithmetics; the points inside the margin are counted."""
+    base, cb, base_d, cb_d = tables
+    P, sp, cp = _params(tables)
+    packed = fo.pack_weights(sp, cp)
+    rng = np.random.RandomState(11)
+    M = 20000
+    pts = torch.from_numpy((rng.rand(M, 3) * 2 - 1).astype(np.float32))
+    dirs = torch.from_numpy(cf.unit_dirs(M, seed=12))
+    msg = torch.from_numpy(cf.messages(32)[2])
+    gs, gc = torch.from_numpy(rng.randn(M).astype(np.float32)), torch.from_numpy(rng.randn(M, 3).astype(np.float32))
+    d0, margin = _oracle_per_point(pts, dirs, msg, P, gs, gc)
+    S = fo.codebook_presum(fo.select_tables(cb_d[:64], fo.message_bits(msg)))
+    s1, c1, _, masks = fo.field_forward(pts.cuda(), dirs.cuda(), 1.0, base_d, S, packed, want_masks=True)
+    d1 = fo.field_backward(pts.cuda(), 1.0, gs.cuda(), gc.cuda(), s1, c1, masks, packed, want_dfeat=True).cpu()
+    delta = {"bf16x3": 2e-5, "f16": 1e-3}[mlp_prec]           # ~4x the largest pre-activation error of the arithmetic
+    safe = margin > delta
+    frac_near = 1.0 - float(safe.float().mean())
+    rel_safe = float((d1[safe] - d0[safe]).norm() / d0[safe].norm())
+    rel_all = float((d1 - d0).norm() / d0.norm())
+    print(f"\n[{mlp_prec}] points within {delta:g} of a ReLU kink: {100 * frac_near:.2f} %; d feature rel. L2 error: {rel_safe:.2e} away from kinks, {rel_all:.2e} over all points")
+    assert frac_near < {"bf16x3": 0.01, "f16": 0.25}[mlp_prec]
+    assert rel_safe < {"bf16x3": 1e-4, "f16": 5e-3}[mlp_prec]
+    assert rel_all < {"bf16x3": 5e-3, "f16": 5e-2}[mlp_prec]
+    # loss-scaled upstream gradients (GradScaler's 65536x and far beyond fp16's range): the result scales exactly
+    big = fo.field_backward(pts.cuda(), 1.0, gs.cuda() * 65536.0 * 1024.0, gc.cuda() * 65536.0 * 1024.0, s1, c1, masks, packed, want_dfeat=True).cpu()
+    assert torch.isfinite(big).all()
+    np.testing.assert_allclose((big / (65536.0 * 1024.0)).numpy(), d1.numpy(), rtol=1e-6, atol=0)
+    tiny = fo.field_backward(pts.cuda(), 1.0, gs.cuda() * 2.0 ** -60, gc.cuda() * 2.0 ** -60, s1, c1, masks, packed, want_dfeat=True).cpu()
+    np.testing.assert_allclose((tiny * 2.0 ** 60).numpy(), d1.numpy(), rtol=1e-6, atol=0)
+
+
+def test_trunc_exp_clamp_in_backward(fo, tables, strict_mlp):
     """Log-densities beyond +-15 use the clamped derivative (activation.py:14)."""
     base, cb, base_d, cb_d = tables
     rng = np.random.RandomState(2)

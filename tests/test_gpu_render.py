@@ -39,7 +39,7 @@ def _oracle_params(m, bitfield, C, bound=1.0):
     return P, S
 
 
-def test_render_matches_reference_glue_golden():
+def test_render_matches_reference_glue_golden(mlp_prec):
     g = np.load(os.path.join(G, "g8_g9_glue.npz"))
     m, _, _ = _model()
     o, d, msg = (torch.from_numpy(g[k]).cuda() for k in ("rays_o", "rays_d", "msg"))
@@ -49,7 +49,7 @@ def test_render_matches_reference_glue_golden():
     np.testing.assert_allclose(out["image"].detach().cpu().numpy(), g["image"], rtol=0, atol=1e-3)
     np.testing.assert_allclose(out["weights_sum"].detach().cpu().numpy(), g["weights_sum"], rtol=0, atol=1e-3)
     np.testing.assert_allclose(out["depth"].detach().cpu().numpy(), g["depth"], rtol=0, atol=1e-3, equal_nan=True)
-    assert float(np.abs(out["image"].detach().cpu().numpy() - g["image"]).max()) < 5e-5
+    assert float(np.abs(out["image"].detach().cpu().numpy() - g["image"]).max()) < {"bf16x3": 5e-5, "f16": 3e-4}[mlp_prec]
     (out["image"] * torch.from_numpy(g["gvec"]).cuda()).sum().backward()
     bits = [int(v) for v in g["msg"]]
     g0 = m.msg_encoder.embeddings[bits[0]].weight.grad
@@ -58,7 +58,11 @@ def test_render_matches_reference_glue_golden():
     nz = torch.nonzero(g0.abs().sum(-1)).squeeze(-1)
     np.testing.assert_array_equal(nz.cpu().numpy().astype(np.int32), g["cb_grad_rows"])
     scale = float(np.abs(g["cb_grad_vals"]).max())
-    np.testing.assert_allclose(g0[nz].cpu().numpy(), g["cb_grad_vals"], rtol=1e-3, atol=1e-4 * scale)
+    if mlp_prec == "bf16x3":
+        np.testing.assert_allclose(g0[nz].cpu().numpy(), g["cb_grad_vals"], rtol=1e-3, atol=1e-4 * scale)
+    else:       # fp16 operands: ReLU kinks taken on the other side at a few per cent of the points (conftest.strict_mlp) -- aggregate bound
+        rel = float(np.linalg.norm(g0[nz].cpu().numpy() - g["cb_grad_vals"]) / np.linalg.norm(g["cb_grad_vals"]))
+        assert rel < 5e-2, rel
     with torch.no_grad():
         st = m.render(o, d, msg, staged=True, max_ray_batch=24, bg_color=1, perturb=False, force_all_rays=True, dt_gamma=0, max_steps=1024)
         cl = m.render(o, d, None, staged=False, bg_color=1, perturb=False, force_all_rays=True, dt_gamma=0, max_steps=1024)
@@ -92,7 +96,7 @@ def _decoder_grad_vector(decoder):
     return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in decoder.parameters()])
 
 
-def test_train_step_losses_and_gradients_vs_oracle():
+def test_train_step_losses_and_gradients_vs_oracle(mlp_prec):
     from nerf_signature_amd import trainer
     m, bitfield, C = _model()
     P, S = _oracle_params(m, bitfield, C)
@@ -121,8 +125,11 @@ def test_train_step_losses_and_gradients_vs_oracle():
     # the split-bf16 kernel; its point then contributes a different (finite) gradient to 16 table entries.  About one
     # in 1e5 activations does, so the gradient is compared in the aggregate plus an outlier budget, not element-wise.
     diff = (G1.cpu() - G0)
-    assert float(diff.norm() / G0.norm()) < 5e-3
-    assert float((diff.abs() > 2e-3 * scale).float().mean()) < 1e-3
+    rel_G = float(diff.norm() / G0.norm())
+    print(f"\n[{mlp_prec}] shared codebook gradient rel. L2 vs oracle: {rel_G:.3e}")
+    # fp16 operands: a few per cent of the points take a ReLU kink on the other side (test_field_backward_away_from_relu_kinks)
+    assert rel_G < {"bf16x3": 5e-3, "f16": 5e-2}[mlp_prec]
+    assert float((diff.abs() > 2e-3 * scale).float().mean()) < {"bf16x3": 1e-3, "f16": 2e-2}[mlp_prec]
     # decoder gradients as one vector (conv biases in front of a BatchNorm have a mathematically zero gradient,
     # so a per-tensor relative comparison would compare rounding noise)
     d1 = _decoder_grad_vector(m.msg_decoder).cpu()
@@ -135,8 +142,8 @@ def test_train_step_losses_and_gradients_vs_oracle():
     v1 = torch.cat([p1[n].grad.reshape(-1).cpu() for n in keep])
     v0 = torch.cat([p0[n].grad.reshape(-1) for n in keep])
     rel = float((v1 - v0).norm() / v0.norm())
-    print(f"\ndecoder gradient (no conv biases) rel. L2 vs oracle: {rel:.3e}")
-    assert rel < 5e-3
+    print(f"\n[{mlp_prec}] decoder gradient (no conv biases) rel. L2 vs oracle: {rel:.3e}")
+    assert rel < {"bf16x3": 1e-3, "f16": 5e-3}[mlp_prec]
 
 
 def test_loop_step_with_sink_equals_autograd_path():
@@ -302,14 +309,14 @@ def test_split_graphs_with_rccl_exchange_rehearsed_on_one_rank():
         return loop, [float(v) for v in held], torch.cat([e.weight.detach().reshape(-1) for e in m.msg_encoder.embeddings])
 
     loop0, l0, t0 = run()
-    assert loop0.graphs[1] is None and loop0.exchange.bytes_per_step == 0
+    assert len(loop0.segments) == 1 and loop0.exchange.bytes_per_step == 0
     assert not dist.is_initialized()
     os.environ["NERFSIG_FORCE_EXCHANGE"] = "1"
     try:
         dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{29700 + os.getpid() % 200}", rank=0, world_size=1)
         assert dp.exchange_active()
         loop1, l1, t1 = run()
-        assert loop1.graphs[1] is not None                               # two graphs, the exchange between them
+        assert len(loop1.segments) == 3 and len(loop1.between) == 2 and loop1.sharded    # render | all-gather | decode+backward | all-reduce | optimiser
         assert loop1.exchange.collectives_per_step == 1                  # G and the decoder's gradient block travel together
         assert loop1.exchange.bytes_per_step == (1 << 19) * 2 * 4 + sum(p.numel() for p in loop1.model.msg_decoder.parameters() if p.grad is not None) * 4
     finally:

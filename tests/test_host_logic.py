@@ -200,6 +200,76 @@ def test_data_parallel_exchange_gloo_world2():
     assert torch.equal(res[0][2], res[1][2])
 
 
+def _toy_problem():
+    """A stand-in with the structure of the watermark step: a table theta [T,2] 'rendered' into D block images and N content pixels,
+    a decoder with batch-statistics BatchNorm over the D blocks, BCE on its logits + MSE on the content pixels."""
+    g = torch.Generator().manual_seed(11)
+    T, D, P, N = 12, 4, 5, 6
+    A_block = torch.randn(D, P, T * 2, generator=g)          # block d, pixel p: image = A_block[d,p] . theta
+    A_content = [torch.randn(N, T * 2, generator=g) for _ in range(2)]   # per-rank content rays
+    gt = [torch.randn(N, generator=g) for _ in range(2)]
+    theta0 = torch.randn(T * 2, generator=g)
+    msg = torch.tensor([1.0, 0.0, 0.0, 1.0])
+    torch.manual_seed(3)
+    dec = torch.nn.Sequential(torch.nn.Linear(P, 3), torch.nn.BatchNorm1d(3, track_running_stats=False), torch.nn.GELU(), torch.nn.Linear(3, 1))
+    return A_block, A_content, gt, theta0, msg, dec
+
+
+def _sharded_blocks_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from nerf_signature_amd import dp
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dp.init_from_env(backend="gloo")
+    A_block, A_content, gt, theta0, msg, dec = _toy_problem()
+    D = A_block.shape[0]
+    first, last = dp.block_shard(D)
+    assert (first, last) == (rank * D // world, (rank + 1) * D // world) and dp.block_shard(D + 1) is None
+    theta = theta0.clone().requires_grad_(True)
+    local = A_block[first:last] @ theta                               # this rank's blocks only
+    images = dp.gather_blocks(local, D, first)                         # [D,P] on every rank
+    lossw = torch.nn.functional.binary_cross_entropy_with_logits(dec(images) * 10.0, msg[:, None])
+    lossi = ((A_content[rank] @ theta - gt[rank]) ** 2).mean()
+    (lossw + dp.content_grad_scale(True) * lossi).backward()           # what backward_from_loss_kernel(out, 1/world) seeds
+    G = theta.grad.view(-1, 2).clone()
+    ex = dp.GradExchange(list(dec.parameters()), shared_scale=1.0)
+    ex(G)
+    q.put((rank, images.detach().numpy().copy(), G.numpy().copy(), [p.grad.numpy().copy() for p in dec.parameters()], float(lossw.detach()), float(lossi.detach())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_block_render_equals_single_process_gradient_gloo_world2():
+    """Multi-GPU partitioning on two gloo ranks, GPU-free: each rank renders D/2 blocks, the blocks are
+    all-gathered, the decoder (BatchNorm over all D blocks) runs replicated, each rank back-propagates its own blocks' image gradient
+    plus its own content rays with the 1/world seed, ONE sum all-reduce of G follows -- and the result is the single-process gradient of
+    lambda_w * BCE(D blocks) + lambda_i * MSE(all content rays of both ranks)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + os.getpid() % 200
+    procs = [ctx.Process(target=_sharded_blocks_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    A_block, A_content, gt, theta0, msg, dec = _toy_problem()
+    theta = theta0.clone().requires_grad_(True)
+    images = A_block @ theta
+    lossw = torch.nn.functional.binary_cross_entropy_with_logits(dec(images) * 10.0, msg[:, None])
+    lossi = ((torch.cat(A_content) @ theta - torch.cat(gt)) ** 2).mean()
+    (lossw + lossi).backward()
+    for rank, img, G, dgrads, lw, li in res:
+        np.testing.assert_allclose(img, images.detach().numpy(), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(G, theta.grad.view(-1, 2).numpy(), rtol=1e-5, atol=1e-6)
+        for got, p in zip(dgrads, dec.parameters()):
+            np.testing.assert_allclose(got, p.grad.numpy(), rtol=1e-5, atol=1e-6)
+        assert abs(lw - float(lossw.detach())) < 1e-6
+    assert abs(0.5 * (res[0][5] + res[1][5]) - float(lossi.detach())) < 1e-6 * float(lossi.detach())
+    assert np.array_equal(res[0][2], res[1][2])
+
+
 def _force_exchange_worker(q):
     import torch.distributed as dist
     from nerf_signature_amd import dp
@@ -319,3 +389,20 @@ def test_block_selection_matches_reference_golden():
     assert torch.equal(bo[2], o[0, r0:r0 + 12, c0:c0 + 12]) and torch.equal(bd[2], -bo[2])
     torch.manual_seed(5)
     np.testing.assert_allclose(blocks.rand_poses(4, "cpu", radius=2.5).numpy(), g["rand_poses"], rtol=0, atol=1e-6)
+
+
+def test_bench_starts_its_own_ranks_dry_launch():
+    """`python bench.py --gpus 2` must start the two rank processes itself (the driver's scaling run has no external launcher):
+    --dry-launch takes that path over gloo with the step's collectives (block all-gather, gradient all-reduce) on CPU tensors."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                      # exactly one JSON line, from rank 0
+    line = json.loads(lines[0])
+    assert line["dry_launch"] and line["n_gpus"] == 2 and line["world_size_seen"] == 2 and line["collectives_ok"]
+    assert line["block_shard_rank0"] == [0, 16] and line["backend"] == "gloo"
