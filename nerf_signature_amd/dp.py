@@ -92,6 +92,7 @@ def content_grad_scale(sharded):
     return 1.0 / world_size() if sharded else 1.0
 
 
+@torch.no_grad()
 def _all_gather_into(out, local):
     if dist.get_backend() == "gloo":     # (no all_gather_into_tensor on gloo: chunk views of `out` as the output list)
         dist.all_gather(list(out.chunk(dist.get_world_size(), dim=0)), local)
@@ -108,7 +109,8 @@ class _GatherBlocks(torch.autograd.Function):
         local = local.contiguous()
         out = torch.empty((D,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         ctx.rows = (first, local.shape[0])
-        collective(lambda: _all_gather_into(out, local))
+        dst, src = out.detach(), local.detach()     # aliases outside autograd: a replay runs this call long after `out` became a graph output
+        collective(lambda: _all_gather_into(dst, src))
         return out
 
     @staticmethod
