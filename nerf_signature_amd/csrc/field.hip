@@ -332,7 +332,10 @@ __device__ inline void color_branch(const char *lds, int lane, int h, float dx, 
 // a wave are 512 contiguous bytes; streaming loads/stores are non-temporal to leave L2 to the tables.
 struct SlotTable {
     uint8_t n[8];
-    uint8_t level[8][8];  // 0..15 base levels, 16 = pre-summed codebook
+    uint8_t level[8][8];      // 0..15 base levels, 16 = pre-summed codebook
+    uint16_t lo[8][8], hi[8][8];   // the slot encodes the level for tiles in [lo, hi) / 4096 of the tile range (a level may be split over two slots)
+    uint8_t sc1_from;         // levels >= this gather with agent-scope (L1-bypassing, L2-served) loads; 255 = none (experiment: never faster)
+    uint32_t skip_mask;       // diagnostics: levels whose bit is set are not encoded (per-level cost measurements)
 };
 
 // Lane pairs cooperate on the gathers.  A gather costs ~2.4 clk per distinct 128-byte line per instruction plus ~1 clk per lane
@@ -349,6 +352,48 @@ __device__ inline uint32_t dpp_u(uint32_t v, int ctrl) {
     }
 }
 
+// One level of one 256-point tile: lane pairs fetch the two x sides (see above), trilinear interpolation, one streaming store.
+__device__ inline void encode_tile_level(const float2 *__restrict__ table, float cell, bool sc1, uint32_t xs, float x, float y, float z,
+                                         float2 *__restrict__ out) {
+    auto ld = [&](uint32_t row) -> float2 {
+        if (!sc1) return table[row];
+        const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(table + row), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return __builtin_bit_cast(float2, u);
+    };
+    uint32_t ix, iy, iz;
+    float wx, wy, wz;
+    axis_cell(x, cell, ix, wx);
+    axis_cell(y, cell, iy, wy);
+    axis_cell(z, cell, iz, wz);
+    const uint32_t hy0 = iy * kPrimeY, hy1 = (iy + 1u) * kPrimeY, hz0 = iz * kPrimeZ, hz1 = (iz + 1u) * kPrimeZ;   // corner_rows()
+    float2 v[2][4];   // v[P][q]: this lane's x side of point P of the pair, corner (dy, dz) = (q >> 1, q & 1)
+#pragma unroll
+    for (int P = 0; P < 2; ++P) {
+        const uint32_t hx = dpp_u(ix, P) + xs;
+        const uint32_t a0 = dpp_u(hy0, P), a1 = dpp_u(hy1, P), b0 = dpp_u(hz0, P), b1 = dpp_u(hz1, P);
+        v[P][0] = ld((hx ^ a0 ^ b0) & kRowMask);
+        v[P][1] = ld((hx ^ a0 ^ b1) & kRowMask);
+        v[P][2] = ld((hx ^ a1 ^ b0) & kRowMask);
+        v[P][3] = ld((hx ^ a1 ^ b1) & kRowMask);
+    }
+    float2 e[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float2 mine = xs ? v[1][q] : v[0][q];      // my own point, my x side
+        const float2 give = xs ? v[0][q] : v[1][q];      // the neighbour's point, my x side
+        float2 got;                                       // my own point, the other x side (fetched by the neighbour)
+        got.x = __uint_as_float(dpp_u(__float_as_uint(give.x), 2));
+        got.y = __uint_as_float(dpp_u(__float_as_uint(give.y), 2));
+        e[q] = xs ? got : mine;          // corner k = 4*dx + q
+        e[4 + q] = xs ? mine : got;
+    }
+    const float2 val = trilerp(e, wx, wy, wz);
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t vv = {val.x, val.y};
+    __builtin_nontemporal_store(vv, reinterpret_cast<f32x2_t *>(out));
+}
+
+// Workgroup (tile, slot) encodes, for its 256 points, the levels (or the part of a level's tile range) assigned to its XCD slot.
 __global__ void __launch_bounds__(256) k_encode_planes(const float *__restrict__ xyzs, uint32_t M, float bound, TablePtrs base, LevelGeom geom,
                                                        const float *__restrict__ S, float2 *__restrict__ planes, uint32_t stride, SlotTable tab) {
     const uint32_t slot = blockIdx.x & 7u;
@@ -365,39 +410,11 @@ __global__ void __launch_bounds__(256) k_encode_planes(const float *__restrict__
         const float x = (pt.x + bound) / two_b, y = (pt.y + bound) / two_b, z = (pt.z + bound) / two_b;
         for (int i = 0; i < n_levels; ++i) {
             const int l = tab.level[slot][i];
-            const float2 *__restrict__ table = reinterpret_cast<const float2 *>(l == NSIG_BASE_LEVELS ? S : base.p[l]);
-            const float cell = geom.cell[l];
-            uint32_t ix, iy, iz;
-            float wx, wy, wz;
-            axis_cell(x, cell, ix, wx);
-            axis_cell(y, cell, iy, wy);
-            axis_cell(z, cell, iz, wz);
-            const uint32_t hy0 = iy * kPrimeY, hy1 = (iy + 1u) * kPrimeY, hz0 = iz * kPrimeZ, hz1 = (iz + 1u) * kPrimeZ;   // corner_rows()
-            float2 v[2][4];   // v[P][q]: this lane's x side of point P of the pair, corner (dy, dz) = (q >> 1, q & 1)
-#pragma unroll
-            for (int P = 0; P < 2; ++P) {
-                const uint32_t hx = dpp_u(ix, P) + xs;
-                const uint32_t a0 = dpp_u(hy0, P), a1 = dpp_u(hy1, P), b0 = dpp_u(hz0, P), b1 = dpp_u(hz1, P);
-                v[P][0] = table[(hx ^ a0 ^ b0) & kRowMask];
-                v[P][1] = table[(hx ^ a0 ^ b1) & kRowMask];
-                v[P][2] = table[(hx ^ a1 ^ b0) & kRowMask];
-                v[P][3] = table[(hx ^ a1 ^ b1) & kRowMask];
-            }
-            float2 e[8];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float2 mine = xs ? v[1][q] : v[0][q];      // my own point, my x side
-                const float2 give = xs ? v[0][q] : v[1][q];      // the neighbour's point, my x side
-                float2 got;                                       // my own point, the other x side (fetched by the neighbour)
-                got.x = __uint_as_float(dpp_u(__float_as_uint(give.x), 2));
-                got.y = __uint_as_float(dpp_u(__float_as_uint(give.y), 2));
-                e[q] = xs ? got : mine;          // corner k = 4*dx + q
-                e[4 + q] = xs ? mine : got;
-            }
-            const float2 val = trilerp(e, wx, wy, wz);
-            typedef float f32x2_t __attribute__((ext_vector_type(2)));
-            const f32x2_t vv = {val.x, val.y};
-            __builtin_nontemporal_store(vv, reinterpret_cast<f32x2_t *>(planes + (size_t)l * stride + m));
+            if ((tab.skip_mask >> l) & 1u) continue;
+            const unsigned long long pos = (unsigned long long)tile * 4096ull;       // wave-uniform range test
+            if (pos < (unsigned long long)tab.lo[slot][i] * n_tiles || pos >= (unsigned long long)tab.hi[slot][i] * n_tiles) continue;
+            encode_tile_level(reinterpret_cast<const float2 *>(l == NSIG_BASE_LEVELS ? S : base.p[l]), geom.cell[l], l >= (int)tab.sc1_from, xs, x, y, z,
+                              planes + (size_t)l * stride + m);
         }
     }
 }
@@ -725,22 +742,69 @@ static int fill_base_tables(const float *const *host, TablePtrs &base, const cha
 
 // Level -> XCD-slot assignment of k_encode_planes: the six finest levels each get a slot of their own or share it only
 // with coarse (cache-resident) levels.  NERFSIG_SLOTS="16|15|14|..." overrides it (experiments).
+// Cost of encoding one level for the block render's 1.29 M points on ONE XCD slot, in us (profiles/r02_encoder_levels.txt: every level
+// measured alone, minus the 34 us an empty launch takes): ~45 for the eight coarse levels, whose cells span several consecutive
+// samples, up to 175 for the codebook level, where every sample touches four fresh 128-byte lines.
+static const float kLevelCost[NSIG_BASE_LEVELS + 1] = {43.4f, 41.9f, 44.7f, 47.5f, 44.3f, 47.2f, 47.2f, 46.8f, 52.7f, 77.7f, 110.2f, 132.0f, 151.4f, 148.6f, 170.0f, 159.6f, 174.7f};
+
 static SlotTable default_slots(bool with_codebook) {
-    // (with one tile per workgroup the two finest levels alone, the next two with one coarse level each: 236-239 us against 251-254 us
-    //  for "16|15|14|13|12,0,1|11,2,3|10,9,4|8,7,6,5", same-box sweep in profiles/r01_k_encoder_slots_sweep.txt)
+    SlotTable t{};
+    t.sc1_from = getenv("NERFSIG_ENC_SC1_FROM") ? (uint8_t)atoi(getenv("NERFSIG_ENC_SC1_FROM")) : (uint8_t)255;
+    t.skip_mask = getenv("NERFSIG_ENC_SKIP") ? (uint32_t)strtoul(getenv("NERFSIG_ENC_SKIP"), nullptr, 0) : 0u;
+    // Default: whole levels per slot, the assignment that won round 1's same-box sweeps (profiles/r01_k_encoder_slots_sweep.txt).
+    // NERFSIG_SLOTS=balanced selects the cost-balanced split below instead: by the single-slot costs it should take 226 us against
+    // 275, measured it takes 287-292 against 283 (profiles/r02_encoder_experiments.txt) -- with all eight XCDs busy the levels do not
+    // cost what they cost alone, the launch is bound chip-wide (L2->L1 line fills), not by its fullest slot.
     static const char *kWith = "16|15|14,0|13,1|12,2,3|11,4,5|10,9|8,7,6";
     static const char *kWithout = "15|14|13|12|11,0,1|10,2,3|9,8,4|7,6,5";
     const char *spec = getenv(with_codebook ? "NERFSIG_SLOTS" : "NERFSIG_SLOTS_CLEAN");
     if (spec == nullptr || *spec == 0) spec = with_codebook ? kWith : kWithout;
-    SlotTable t{};
-    int slot = 0, cur = -1;
-    for (const char *c = spec;; ++c) {
-        if (*c >= '0' && *c <= '9') cur = (cur < 0 ? 0 : cur * 10) + (*c - '0');
-        else {
-            if (cur >= 0 && slot < 8 && t.n[slot] < 8 && cur <= NSIG_BASE_LEVELS) t.level[slot][t.n[slot]++] = (uint8_t)cur;
-            cur = -1;
-            if (*c == '|') ++slot;
-            if (*c == 0) break;
+    if (spec[0] != 'b') {
+        // explicit assignment of WHOLE levels
+        int slot = 0, cur = -1;
+        for (const char *c = spec;; ++c) {
+            if (*c >= '0' && *c <= '9') cur = (cur < 0 ? 0 : cur * 10) + (*c - '0');
+            else {
+                if (cur >= 0 && slot < 8 && t.n[slot] < 8 && cur <= NSIG_BASE_LEVELS) {
+                    const int k = t.n[slot]++;
+                    t.level[slot][k] = (uint8_t)cur; t.lo[slot][k] = 0; t.hi[slot][k] = 4096;
+                }
+                cur = -1;
+                if (*c == '|') ++slot;
+                if (*c == 0) break;
+            }
+        }
+        return t;
+    }
+    // Balanced assignment (McNaughton's wrap-around rule): levels in descending cost fill slot after slot up to total / 8; the level
+    // that overflows a slot is cut there -- by tile range -- and continues in the next one.  Every slot carries the same load, a
+    // level is cut at most once (its 4 MiB table then lives in two L2s), a slot holds at most two partial levels.
+    const int n_levels = NSIG_BASE_LEVELS + (with_codebook ? 1 : 0);
+    int order[NSIG_BASE_LEVELS + 1];
+    for (int i = 0; i < n_levels; ++i) order[i] = i;
+    for (int i = 0; i < n_levels; ++i)
+        for (int j = i + 1; j < n_levels; ++j)
+            if (kLevelCost[order[j]] > kLevelCost[order[i]]) { const int tmp = order[i]; order[i] = order[j]; order[j] = tmp; }
+    double total = 0.0;
+    for (int i = 0; i < n_levels; ++i) total += kLevelCost[i];
+    const double cap = total / 8.0;
+    int slot = 0;
+    double room = cap;
+    for (int i = 0; i < n_levels; ++i) {
+        const int l = order[i];
+        const double c = kLevelCost[l];
+        double done = 0.0;                       // fraction of the level already placed
+        while (done < 1.0 - 1e-9) {
+            double part = 1.0 - done;
+            if (part * c > room + 1e-9 && slot < 7) part = room / c;
+            const int lo = (int)(done * 4096.0 + 0.5), hi = (done + part >= 1.0 - 1e-9) ? 4096 : (int)((done + part) * 4096.0 + 0.5);
+            if (hi > lo && t.n[slot] < 8) {
+                const int k = t.n[slot]++;
+                t.level[slot][k] = (uint8_t)l; t.lo[slot][k] = (uint16_t)lo; t.hi[slot][k] = (uint16_t)hi;
+            }
+            room -= part * c;
+            done += part;
+            if (room <= 1e-6 && slot < 7) { ++slot; room = cap; }
         }
     }
     return t;
@@ -758,11 +822,12 @@ NSIG_EXPORT int hg_encode_planes(const float *xyzs, uint32_t M, float bound, con
     if (M == 0) return NSIG_OK;
     const uint32_t stride = ceil_div(M, 32u) * 32u;
     const SlotTable tab = default_slots(S != nullptr);
-    bool covered[NSIG_BASE_LEVELS + 1] = {};
+    int covered[NSIG_BASE_LEVELS + 1] = {};     // 4096ths of the tile range assigned, per level
     for (int s = 0; s < 8; ++s)
-        for (int i = 0; i < tab.n[s]; ++i) covered[tab.level[s][i]] = true;
-    for (int l = 0; l < NSIG_BASE_LEVELS + (S != nullptr ? 1 : 0); ++l) NSIG_REQUIRE(covered[l], "hg_encode_planes: slot table does not cover level %d", l);
-    NSIG_REQUIRE(S != nullptr || !covered[NSIG_BASE_LEVELS], "hg_encode_planes: slot table names the codebook level but S is NULL");
+        for (int i = 0; i < tab.n[s]; ++i) covered[tab.level[s][i]] += (int)tab.hi[s][i] - (int)tab.lo[s][i];
+    for (int l = 0; l < NSIG_BASE_LEVELS + (S != nullptr ? 1 : 0); ++l)
+        NSIG_REQUIRE(covered[l] == 4096 || ((tab.skip_mask >> l) & 1u), "hg_encode_planes: slot table covers %d/4096 of level %d", covered[l], l);
+    NSIG_REQUIRE(S != nullptr || covered[NSIG_BASE_LEVELS] == 0, "hg_encode_planes: slot table names the codebook level but S is NULL");
     const uint32_t tiles = ceil_div(stride, 256u);
     // tiles per XCD slot handled by distinct workgroups before they start looping: with one tile per workgroup (cap >= tiles) the block
     // render's launch takes 244-247 us against 258-261 us with 1024 looping workgroups per slot (same-box sweep, profiles/r01_k_encoder_grid_sweep.txt)
