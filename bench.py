@@ -54,6 +54,8 @@ def parse_args():
     ap.add_argument("--no-fused-adam", action="store_true", help="torch's multi-tensor instead of its fused Adam kernel for the decoder parameters")
     ap.add_argument("--no-graph", action="store_true", help="run the loop body eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--fixed-rays", action="store_true", help="replay one ray set every step (round-1 behaviour; diagnostics)")
+    ap.add_argument("--host-rays", action="store_true", help="hand every step's rays over from the host loop (randint + rg_get_rays + gather + copies between replays) "
+                                                                "instead of drawing them inside the captured step (rg_sample_rays)")
     return ap.parse_args()
 
 
@@ -270,12 +272,15 @@ def bench_training(args, scene, real_stdout):
 
     first = draw_content(0)
     data = {"watermark": {"rays_o_block": bo, "rays_d_block": bd}, "content": first}
+    # graph mode: the captured step draws its own batch from the device-resident pose / image store (rg_sample_rays, one launch)
+    sampler = None if (args.no_graph or args.fixed_rays or args.host_rays) else rays.DeviceRaySampler(poses, clean, intr, H, W, args.rays, stride=world, offset=rank,
+                                                                                                      seed=1000 + rank)
     # main_nerf_wtmk.py:110: Adam(get_params(lr), betas=(0.9, 0.99), eps=1e-15) -- same semantics, the codebook update fused
     optimizer = CodebookAdam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, **({} if args.no_graph else ({"capturable": True} if args.no_fused_adam else {"fused": True, "capturable": True})))
     if args.no_graph:
         loop = trainer.WatermarkLoop(model, optimizer, render_kwargs, side_stream=None if args.no_overlap else torch.cuda.Stream())
     else:
-        loop = trainer.GraphedWatermarkLoop(model, optimizer, render_kwargs, data, overlap_content=not args.no_overlap, content_headroom=0.25)
+        loop = trainer.GraphedWatermarkLoop(model, optimizer, render_kwargs, data, overlap_content=not args.no_overlap, content_headroom=0.25, content_sampler=sampler)
 
     timer = NativeTimer(nv)
     msg_rng = np.random.RandomState(1234)   # same stream on every rank: the message is replicated
@@ -288,11 +293,14 @@ def bench_training(args, scene, real_stdout):
         # its optimiser kernel then leaves that message's pre-summed codebook behind (GraphedWatermarkLoop, presum_in_adam)
         msg = upcoming.pop()
         upcoming.append(draw())
-        step_data = None if args.fixed_rays else {"content": draw_content(counter[0])}
         counter[0] += 1
+        if args.fixed_rays or sampler is not None:
+            return loop.step(data, msg) if args.no_graph else loop.step(msg, next_message=upcoming[0])
         if args.no_graph:
-            return loop.step(data if step_data is None else {"watermark": data["watermark"], "content": step_data["content"]}, msg)
-        return loop.step(msg, data=step_data, next_message=upcoming[0])
+            return loop.step({"watermark": data["watermark"], "content": draw_content(counter[0] - 1)}, msg)
+        if loop.content_ahead:      # the rays of the NEXT step: marched at the end of this replay, beside the optimiser
+            return loop.step(msg, next_data={"content": draw_content(counter[0])}, next_message=upcoming[0])
+        return loop.step(msg, data={"content": draw_content(counter[0] - 1)} if counter[0] > 1 else None, next_message=upcoming[0])
 
     for _ in range(args.warmup):
         one_step()
@@ -391,7 +399,9 @@ def bench_training(args, scene, real_stdout):
             "content_rays": rays_content, "block_rays_total": rays_block_all, "block_rays_this_rank": rays_block_rank, "blocks_sharded_over_ranks": sharded,
             "points_per_step_per_rank": n_block + n_content, "samples_per_ray_block": n_block / max(rays_block_rank, 1),
             "samples_per_ray_content": n_content / rays_content,
-            "ray_sets": "fixed" if args.fixed_rays else f"new pose (of {args.poses} pre-rendered clean views) + new random pixels every step, rays generated on the device inside the timed loop",
+            "ray_sets": "fixed" if args.fixed_rays else f"new pose (of {args.poses} pre-rendered clean views) + new random pixels every step, " +
+                        ("drawn inside the captured step from the device-resident pose/image store (rg_sample_rays)" if sampler is not None else "rays generated on the device inside the timed loop (host-driven: randint, rg_get_rays, gather, copies)"),
+            "content_march": "ahead (end of the previous replay)" if getattr(loop, "content_ahead", False) else "head of the step",
             "message_dim": D, "parallelism": f"dp{world}", "optimizer": "Adam(betas=(0.9,0.99), eps=1e-15): torch semantics, codebook update fused (opt_codebook_adam)",
             "grad_exchange_bytes_per_step": loop.exchange.bytes_per_step + (rays_block_all * 12 if sharded else 0),
             "collectives_per_step": (loop.exchange.collectives_per_step + (1 if sharded else 0)) if dp.exchange_active() else 0,

@@ -115,6 +115,16 @@ int rm_compact_alive(const int32_t *rays_alive, uint32_t n_alive, int32_t *rays_
 int rg_get_rays(const float *poses, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, const int64_t *inds,
                 uint32_t B, uint32_t N, float *rays_o, float *rays_d, nsig_stream_t stream);
 
+/* A whole training batch from a device-resident store (the loader step in front of the path: nerf/provider_wtmk.py:585-600 hands one pose per
+ * step to get_rays(..., N), nerf/utils_wtmk_disen.py:103-106 draws N pixel indices with torch.randint on the device).  poses [P,4,4],
+ * images [P,H*W,3] or NULL; pose p = (step * stride + offset) mod P where step = *step_counter (a DEVICE int32, NULL = 0; stride/offset =
+ * world size / rank shard the pose sequence); N indices uniform in [0,H*W) from a counter-based hash of (seed, step, ray): same distribution as
+ * the reference's draw, a different generator.  Writes rays_o, rays_d [N,3], gt [N,3] (images[p][ind]; NULL to skip), optionally the drawn
+ * indices (int64 [N]) and the pose number (int32 [1]).  No host value enters the launch: it can sit inside a captured step. */
+int rg_sample_rays(const float *poses, uint32_t P, const float *images, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W,
+                   uint32_t N, const int32_t *step_counter, uint32_t stride, uint32_t offset, uint64_t seed, float *rays_o, float *rays_d,
+                   float *gt, int64_t *inds_out, int32_t *pose_out, nsig_stream_t stream);
+
 /* ------------------------------------------------------------------ hash grids */
 
 /* S[t] = sum_i tables[i][t] over the D selected codebook tables (the tables 2i+bit_i of

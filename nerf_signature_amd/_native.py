@@ -19,6 +19,7 @@ SIGNATURES = {
     "nsig_abi_version": [],
     "nsig_last_error": [],
     "nsig_host_device_pointer": [_vp],
+    "rg_sample_rays": [_vp, _u32, _vp, _fl, _fl, _fl, _fl, _u32, _u32, _u32, _vp, _u32, _u32, _c.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp],
     "rg_get_rays": [_vp, _fl, _fl, _fl, _fl, _u32, _u32, _vp, _u32, _u32, _vp, _vp, _vp],
     "rm_near_far_from_aabb": [_vp, _vp, _vp, _u32, _fl, _vp, _vp, _vp],
     "rm_sph_from_ray": [_vp, _vp, _fl, _u32, _vp, _vp],

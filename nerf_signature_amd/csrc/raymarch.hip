@@ -115,6 +115,45 @@ __global__ void k_get_rays(const float *__restrict__ poses, float fx, float fy, 
     }
 }
 
+// One training batch straight from a device-resident store of poses and images (the loader step in front of the
+// path, nerf/provider_wtmk.py:585-600 + get_rays with N > 0, nerf/utils_wtmk_disen.py:103-106,121-141): pose p = (step * stride +
+// offset) mod P with `step` read from a device counter, N pixel indices drawn uniformly from a counter-based hash of (seed, step, ray)
+// (the reference draws torch.randint on its device: same distribution, another generator), their rays, and the pixels' colours of
+// image p as ground truth.  One launch, no host value in it: it sits inside a captured training step.
+__device__ inline uint32_t mix32(uint32_t v) {   // a finaliser with full avalanche (murmur3)
+    v ^= v >> 16; v *= 0x85ebca6bu; v ^= v >> 13; v *= 0xc2b2ae35u; v ^= v >> 16;
+    return v;
+}
+
+__global__ void k_sample_rays(const float *__restrict__ poses, uint32_t P, const float *__restrict__ images, float fx, float fy, float cx, float cy,
+                              uint32_t H, uint32_t W, uint32_t N, const int32_t *__restrict__ step_counter, uint32_t stride, uint32_t offset,
+                              uint32_t seed_lo, uint32_t seed_hi, float *__restrict__ rays_o, float *__restrict__ rays_d, float *__restrict__ gt,
+                              int64_t *__restrict__ inds_out, int32_t *__restrict__ pose_out) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t step = step_counter ? (uint32_t)step_counter[0] : 0u;
+    const uint32_t p = (uint32_t)(((uint64_t)step * stride + offset) % P);
+    const uint32_t r = mix32(mix32(mix32(seed_lo ^ (step * 0x9e3779b9u)) + seed_hi) ^ (n * 0x85ebca6bu + 0x6b43a9b5u));
+    const uint32_t ind = (uint32_t)(((uint64_t)r * ((uint64_t)H * W)) >> 32);                  // uniform in [0, H*W)
+    const float i = (float)(ind % W) + 0.5f, j = (float)(ind / W) + 0.5f;                      // as k_get_rays
+    const float x = (i - cx) / fx, y = (j - cy) / fy, z = 1.0f;
+    const float nrm = sqrtf(x * x + y * y + z * z);
+    const float dx = x / nrm, dy = y / nrm, dz = z / nrm;
+    const float *Pm = poses + 16 * (size_t)p;
+    float *o = rays_o + 3 * (size_t)n, *d = rays_d + 3 * (size_t)n;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        d[c] = dx * Pm[4 * c] + dy * Pm[4 * c + 1] + dz * Pm[4 * c + 2];
+        o[c] = Pm[4 * c + 3];
+    }
+    if (gt != nullptr) {
+        const float *px = images + 3 * ((size_t)p * H * W + ind);
+        gt[3 * (size_t)n] = px[0]; gt[3 * (size_t)n + 1] = px[1]; gt[3 * (size_t)n + 2] = px[2];
+    }
+    if (inds_out != nullptr) inds_out[n] = (int64_t)ind;
+    if (pose_out != nullptr && n == 0) pose_out[0] = (int32_t)p;
+}
+
 // ----------------------------------------------------------------------------- the occupancy walk
 
 struct GridView {
@@ -908,6 +947,19 @@ NSIG_EXPORT int rm_compact_alive(const int32_t *rays_alive, uint32_t n_alive, in
     NSIG_REQUIRE(rays_alive != rays_alive_out, "rm_compact_alive: in-place compaction is not supported");
     k_compact_alive<<<1, 1024, 0, as_stream(stream)>>>(rays_alive, n_alive, rays_alive_out, n_out);
     return check_launch("rm_compact_alive");
+}
+
+NSIG_EXPORT int rg_sample_rays(const float *poses, uint32_t P, const float *images, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W,
+                               uint32_t N, const int32_t *step_counter, uint32_t stride, uint32_t offset, uint64_t seed, float *rays_o, float *rays_d,
+                               float *gt, int64_t *inds_out, int32_t *pose_out, nsig_stream_t stream) {
+    NSIG_REQUIRE(poses && rays_o && rays_d, "rg_sample_rays: null pointer");
+    NSIG_REQUIRE(P > 0 && H > 0 && W > 0 && fx != 0.0f && fy != 0.0f, "rg_sample_rays: empty pose store, bad image size or focal length");
+    NSIG_REQUIRE(gt == nullptr || images != nullptr, "rg_sample_rays: ground truth requested without an image store");
+    NSIG_REQUIRE((uint64_t)H * W < (1ull << 32), "rg_sample_rays: image too large");
+    if (N == 0) return NSIG_OK;
+    k_sample_rays<<<ceil_div(N, 256u), 256, 0, as_stream(stream)>>>(poses, P, images, fx, fy, cx, cy, H, W, N, step_counter, stride, offset, (uint32_t)seed,
+                                                                    (uint32_t)(seed >> 32), rays_o, rays_d, gt, inds_out, pose_out);
+    return check_launch("rg_sample_rays");
 }
 
 NSIG_EXPORT int rg_get_rays(const float *poses, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, const int64_t *inds,

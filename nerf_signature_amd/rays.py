@@ -54,3 +54,32 @@ def get_rays(poses, intrinsics, H, W, N=-1, error_map=None, patch_size=1):
     results["rays_o"] = rays_o
     results["rays_d"] = rays_d
     return results
+
+
+class DeviceRaySampler:
+    """The loader step of the training loop on the device (rg_sample_rays): a store of poses [P,4,4] and (optionally) their images
+    [P,H*W,3] resident in HBM; every call writes one batch -- pose (step * stride + offset) mod P, N uniformly drawn pixels, their rays
+    and ground-truth colours -- into caller-owned buffers, with `step` read from a device counter.  Nothing in the call depends on a
+    host value, so trainer.GraphedWatermarkLoop captures it at the head of its step (`content_sampler=`): the per-step hand-over of
+    rays costs one 5 us launch inside the graph instead of a randint, a ray kernel, a gather and three copies between two replays."""
+
+    def __init__(self, poses, images, intrinsics, H, W, n_rays, stride=1, offset=0, seed=0):
+        if not poses.is_cuda:
+            raise ValueError("DeviceRaySampler: poses must be on the GPU")
+        self.poses = poses.contiguous().float()
+        self.images = None if images is None else images.contiguous().float().view(self.poses.shape[0], H * W, 3)
+        self.intr = tuple(float(v) for v in intrinsics)
+        self.H, self.W, self.n_rays, self.stride, self.offset, self.seed = int(H), int(W), int(n_rays), int(stride), int(offset), int(seed)
+
+    @torch.no_grad()
+    def sample_into(self, step_counter, rays_o, rays_d, gt=None, inds_out=None, pose_out=None):
+        """step_counter: int32 device tensor [1] (or None = step 0).  rays_o / rays_d / gt: float32 buffers of n_rays * 3 elements."""
+        for t in (rays_o, rays_d, gt):
+            if t is not None and (t.numel() != self.n_rays * 3 or t.dtype != torch.float32):
+                raise ValueError(f"DeviceRaySampler: buffers must hold {self.n_rays} x 3 float32 values")
+        if gt is not None and self.images is None:
+            raise ValueError("DeviceRaySampler: no image store to take the ground truth from")
+        fx, fy, cx, cy = self.intr
+        nv.call("rg_sample_rays", nv.ptr(self.poses), self.poses.shape[0], nv.ptr(self.images), fx, fy, cx, cy, self.H, self.W, self.n_rays,
+                nv.ptr(step_counter), self.stride, self.offset, self.seed, nv.ptr(rays_o), nv.ptr(rays_d), nv.ptr(gt), nv.ptr(inds_out), nv.ptr(pose_out),
+                nv.stream())

@@ -255,7 +255,8 @@ class GraphedWatermarkLoop:
     points than that -- such a step dropped the rays that did not fit, like the reference's bounded mode."""
 
     def __init__(self, model, optimizer, render_kwargs, data, lambda_w=1.0, lambda_i=1.0, lr_lambda=None, headroom=0.0, native_dense_adam=True,
-                 overlap_content=True, march_ahead=None, presum_in_adam=True, stage_in_graph=True, content_headroom=None):
+                 overlap_content=True, march_ahead=None, presum_in_adam=True, stage_in_graph=True, content_headroom=None, content_ahead=None,
+                 content_sampler=None):
         """presum_in_adam: the captured optimiser kernel also writes the pre-summed codebook of the NEXT step's message
         (opt_codebook_adam_sel_next: +9 % traffic inside an HBM-streaming kernel instead of a 128 MiB pass at the head of every step).
         The next message is handed over one step early -- `step(message_k, next_message=message_k1)`, a one-element look-ahead over
@@ -270,6 +271,21 @@ class GraphedWatermarkLoop:
         at the head of its own step on the side stream: next to the optimiser as well, the two marches took longer than the
         optimiser and the pre-sum lost its cover."""
         self.march_ahead = overlap_content if march_ahead is None else bool(march_ahead)
+        # content_sampler (rays.DeviceRaySampler): the step draws its own content batch -- pose, pixels, rays, ground truth -- on the
+        # device, inside the captured graph, from the replay count; `data` / `next_data` then carry no content part
+        self.content_sampler = content_sampler
+        # content_ahead: the content render's samples are marched at the end of the previous replay as well.  The head of a step then
+        # holds no march at all: both encoders start right behind the opening kernel (the runtime starts the block encoder only when the
+        # whole content-march chain in front of it has finished, ~95 us of small kernels: DESIGN.md section 8).  The content rays of the
+        # NEXT step therefore have to be in the static buffers when a replay starts: `step(..., next_data={"content": ...})`; their
+        # ground-truth pixels are held back until that step.
+        # Off by default: same-box A/B of the bench step 1.095-1.100 ms without against 1.130-1.167 ms with it
+        # (profiles/r02_content_ahead_ab.txt) -- both marches beside the optimiser outlast it, as round 1 found with the pre-sum.
+        if content_ahead is None:
+            content_ahead = os.environ.get("NERFSIG_CONTENT_AHEAD", "0") == "1"
+        self.content_ahead = self.march_ahead and bool(content_ahead)
+        if self.content_ahead and content_sampler is not None:
+            raise ValueError("content_sampler draws the batch at the head of its own step: incompatible with content_ahead")
         self.presum_in_adam = bool(presum_in_adam)
         # stage_in_graph: the captured step opens with loop_step_begin, which zero-fills G and fetches the step's message words from the
         # pinned ring itself (slot = replays so far, counted on the device) -- no host-to-device copy command between two replays
@@ -278,7 +294,8 @@ class GraphedWatermarkLoop:
         self.marched = None
         self._pending_content = None
         self.native_dense_adam = native_dense_adam
-        self.side_stream = torch.cuda.Stream() if overlap_content else None
+        # NERFSIG_SIDE_PRIORITY=-1: the content chain (small latency-bound launches) on a high-priority stream
+        self.side_stream = torch.cuda.Stream(priority=int(os.environ.get("NERFSIG_SIDE_PRIORITY", "0"))) if overlap_content else None
         self.plan_stream = self.side_stream   # scatter plans queue behind the content render (a third captured stream crashes hipStreamEndCapture on this runtime)
         if not hasattr(optimizer, "step_shared_sel"):
             raise TypeError("GraphedWatermarkLoop needs nerf_signature_amd.optim.CodebookAdam(capturable=True)")
@@ -344,6 +361,11 @@ class GraphedWatermarkLoop:
                     self.msg_all.numel(), nv.ptr(self.stage_counter), nv.ptr(self.msg_all), nv.stream())
         else:
             self.sink.zero_()
+            if self.content_sampler is not None and torch.cuda.is_current_stream_capturing():
+                self.stage_counter += 1      # (the opening kernel counts the replays when it stages the message)
+        if self.content_sampler is not None:
+            ct = self.data["content"]
+            self.content_sampler.sample_into(self.stage_counter, ct["rays_o"], ct["rays_d"], ct["images"])
         prev = fo.set_plan_stream(self.plan_stream)    # the scatter plans need the sample positions only: beside the forward pass
         try:
             out = train_step(self.model, self.data, self.msg_dev, self.render_kwargs, self.lambda_w, self.lambda_i, side_stream=self.side_stream,
@@ -383,6 +405,8 @@ class GraphedWatermarkLoop:
         # overlaps the pre-sum and the block encoder (both marches next to the optimiser took longer than the optimiser)
         block_o, block_d, _ = local_blocks(wm)       # (this rank's shard of the blocks when they are split over the ranks)
         self.marched = (self.model.march_ahead(block_o, block_d, *args),)
+        if self.content_ahead:
+            self.marched += (self.model.march_ahead(ct["rays_o"], ct["rays_d"], *args),)
 
     def _optimise_and_march(self):
         """The optimiser step and, beside it on the side stream, the march of the next step's samples."""
@@ -401,6 +425,8 @@ class GraphedWatermarkLoop:
 
     def point_counts(self):
         """(block, content) sample totals of the last step (one host read)."""
+        if self.marched is not None and len(self.marched) > 1:   # both renders marched ahead: each has its own counter
+            return int(self.marched[0]["counter"][0]), int(self.marched[1]["counter"][0])
         if self.marched is not None:      # the block render has its own counter, the content render the ring's latest row
             return int(self.marched[0]["counter"][0]), int(self.model.step_counter[self.capacity_rows[-1], 0])
         a, b = self.model.step_counter[self.capacity_rows, 0].tolist()
@@ -429,14 +455,22 @@ class GraphedWatermarkLoop:
             for part in ("watermark", "content"):
                 for k, v in data.get(part, {}).items():
                     self.data[part][k].copy_(v, non_blocking=True)
-            if self.march_ahead and self.graphs is not None and "watermark" in data:
-                self._march_ahead()             # this step's block rays arrived only now: march them before the replay
+            if self.march_ahead and self.graphs is not None and ("watermark" in data or (self.content_ahead and "content" in data)):
+                self._march_ahead()             # this step's rays arrived only now: march them before the replay
         if next_data is not None:
             if not self.march_ahead:
                 raise ValueError("next_data needs march_ahead=True")
-            for k, v in next_data["watermark"].items():     # nothing in the replay reads the block rays before its closing march
+            for k, v in next_data.get("watermark", {}).items():     # nothing in the replay reads the block rays before its closing march
                 self.data["watermark"][k].copy_(v, non_blocking=True)
-            self._pending_content = next_data["content"]     # marched (and compared with its images) inside its own step
+            content = next_data.get("content")
+            if content is not None and self.content_ahead:
+                # the rays go in now (this replay renders from samples marched earlier and marches these at its end); the ground-truth
+                # pixels wait for their own step
+                for k in ("rays_o", "rays_d"):
+                    self.data["content"][k].copy_(content[k], non_blocking=True)
+                self._pending_content = {"images": content["images"]}
+            elif content is not None:
+                self._pending_content = content              # marched (and compared with its images) inside its own step
 
     @torch.no_grad()
     def _snapshot(self):
@@ -579,6 +613,8 @@ class GraphedWatermarkLoop:
 
     def overflowed(self):
         """True if the last replay produced more points than the buffers hold (one host read of two counters)."""
+        if self.marched is not None and len(self.marched) > 1:
+            return any(int(r["counter"][0]) > r["capacity"] for r in self.marched)
         if self.marched is not None:
             return int(self.marched[0]["counter"][0]) > self.marched[0]["capacity"] or \
                 int(self.model.step_counter[self.capacity_rows[-1], 0]) > self.content_capacity

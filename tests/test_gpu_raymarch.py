@@ -229,3 +229,33 @@ def test_composite_with_fused_tail_matches_separate_launches(capacity_frac):
         np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-6, atol=1e-7)
     terminated = (g0[1].abs().sum(dim=1) == 0) & (deltas[:, 0] > 0)
     assert bool(terminated.any())                                   # the early-termination rows were exercised
+
+
+def test_device_ray_sampler_matches_get_rays():
+    """rg_sample_rays: pose (step * stride + offset) mod P from a device counter, uniformly drawn pixels, rays identical to rg_get_rays for
+    the same (pose, indices), ground truth = the stored image's pixels; a new step draws new pixels, the same step the same ones."""
+    from nerf_signature_amd import rays
+    P, H, W, N = 5, 60, 80, 4096
+    intr = (70.0, 72.0, W / 2, H / 2)
+    poses = torch.stack([torch.from_numpy(cf.orbit_rays(1, seed=0, radius=2.0 + 0.1 * k)[0]) for k in range(P)]).cuda()
+    images = torch.rand(P, H * W, 3, device="cuda")
+    s = rays.DeviceRaySampler(poses, images, intr, H, W, N, stride=2, offset=1, seed=99)
+    ctr = torch.zeros(1, dtype=torch.int32, device="cuda")
+    o, d, gt = (torch.empty(1, N, 3, device="cuda") for _ in range(3))
+    inds, pose = torch.empty(N, dtype=torch.int64, device="cuda"), torch.empty(1, dtype=torch.int32, device="cuda")
+    seen = []
+    for step in (0, 1, 2, 7, 7):
+        ctr.fill_(step)
+        s.sample_into(ctr, o, d, gt, inds, pose)
+        k = (step * 2 + 1) % P
+        assert int(pose) == k and int(inds.min()) >= 0 and int(inds.max()) < H * W
+        want = rays.get_rays(poses[k:k + 1], intr, H, W, N=-1)
+        assert torch.equal(o[0], want["rays_o"][0, inds]) and torch.equal(d[0], want["rays_d"][0, inds])
+        assert torch.equal(gt[0], images[k][inds])
+        seen.append(inds.clone())
+    assert torch.equal(seen[3], seen[4]) and not torch.equal(seen[0], seen[1])
+    # uniform: every quarter of the image receives its share (4096 draws: +-5 sigma)
+    q = torch.bincount((seen[0] * 4 // (H * W)), minlength=4).float()
+    assert float((q - N / 4).abs().max()) < 5 * (N * 0.25 * 0.75) ** 0.5
+    with pytest.raises(ValueError):
+        s.sample_into(ctr, o[:, :10], d, gt)
