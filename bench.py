@@ -304,6 +304,7 @@ def bench_training(args, scene, real_stdout):
 
     for _ in range(args.warmup):
         one_step()
+    recaptured = False if args.no_graph else bool(loop.ensure_capacity())       # (a host read; outside the timed region)
     if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
@@ -407,7 +408,7 @@ def bench_training(args, scene, real_stdout):
             "collectives_per_step": (loop.exchange.collectives_per_step + (1 if sharded else 0)) if dp.exchange_active() else 0,
             "world_size_seen_by_backend": dp.world_size(), "backend": dist.get_backend() if dist.is_initialized() else None,
             "execution": "eager" if args.no_graph else f"hipGraph replay, {len(loop.segments)} captured segment(s)" + (" with the RCCL collectives between them" if len(loop.segments) > 1 else ""),
-            "capacity_overflow": overflow,
+            "capacity_overflow": overflow, "recaptured_with_more_headroom_after_warmup": recaptured,
             "loss": loss_value, "loss_image": loss_parts[0], "loss_watermark": loss_parts[1],
         },
         "roofline": {

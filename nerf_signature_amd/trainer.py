@@ -611,6 +611,22 @@ class GraphedWatermarkLoop:
         self.steps_done += 1
         return self.out
 
+    def ensure_capacity(self, growth=1.25):
+        """One host read: if the last replay produced more points than the buffers hold (its overflowing rays were dropped, like the
+        reference's bounded mode), re-size from the current rays with `growth` times the headroom and capture again.  Returns True when
+        it re-captured.  Callers that draw new rays every step call this now and then, outside their timed region."""
+        if self.graphs is None or not self.overflowed():
+            return False
+        self.headroom = (1.0 + self.headroom) * growth - 1.0
+        self.content_headroom = (1.0 + self.content_headroom) * growth - 1.0
+        message = self.msg_dev.detach().to("cpu", torch.float32)
+        torch.cuda.synchronize()
+        self.graphs, self.segments, self.between, self.marched = None, [], [], None
+        self.model.drop_marched()
+        self._s_for = None
+        self.prepare(message)
+        return True
+
     def overflowed(self):
         """True if the last replay produced more points than the buffers hold (one host read of two counters)."""
         if self.marched is not None and len(self.marched) > 1:

@@ -211,3 +211,37 @@ def test_eager_loop_refuses_a_model_left_in_device_select_mode():
     g.close()
     eager.step(data, msg)          # host-side selection again: only the 32 selected tables are recorded in the sink
     assert len(eager.sink.selected) == 32
+
+
+def test_capacity_overflow_is_detected_and_recaptured():
+    """an overflowing replay (more sample points than the captured buffers hold) drops rays like the reference's bounded
+    mode and used to be reported only after the fact.  ensure_capacity() re-sizes from the current rays and captures again; the next
+    step is whole again and equals the eager loop's."""
+    from nerf_signature_amd import trainer
+    from nerf_signature_amd.optim import CodebookAdam
+    data = _cuda_data(n_content=300)
+    dense = {"watermark": data["watermark"],      # content rays that all cross the ball: several times the points the capture was sized for
+             "content": {"rays_o": data["watermark"]["rays_o_block"].reshape(1, -1, 3)[:, :300].contiguous(),
+                         "rays_d": data["watermark"]["rays_d_block"].reshape(1, -1, 3)[:, :300].contiguous(), "images": data["content"]["images"]}}
+    msg = torch.from_numpy(cf.messages(32)[2])
+    torch.manual_seed(0)
+    m, _, _ = _model()
+    opt = CodebookAdam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, capturable=True)
+    loop = trainer.GraphedWatermarkLoop(m, opt, KW, data)
+    loop.step(msg)
+    assert not loop.overflowed() and not loop.ensure_capacity()
+    loop.step(msg, data={"content": dense["content"]})
+    assert loop.overflowed()
+    cap_before = loop.content_capacity
+    assert loop.ensure_capacity() and loop.content_capacity > cap_before
+    out = loop.step(msg)
+    torch.cuda.synchronize()
+    assert not loop.overflowed()
+    torch.manual_seed(0)
+    ref_m, _, _ = _model()
+    ref_m.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        want = trainer.train_step(ref_m, dense, msg, KW)
+    # (the parameters moved by one more optimiser step between the two evaluations: compare the image loss loosely, the point is that
+    #  no ray is dropped any more: the loss of a render with dropped rays is off by orders of magnitude)
+    assert abs(float(out[3]) - float(want[3])) < 0.05 * float(want[3]) + 1e-4
