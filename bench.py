@@ -59,25 +59,19 @@ def parse_args():
     return ap.parse_args()
 
 
-def launch_ranks(args):
-    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their
-    environment), wait, exit with the worst return code.  Decided before anything touches the GPU; children are new processes, never
-    an exec of one that initialised the device.  Rank 0 inherits stdout (the one JSON line)."""
-    n = args.gpus
-    backend = os.environ.get("NERFSIG_DIST_BACKEND", "")
-    if not args.dry_launch and backend != "gloo":
-        have = torch.cuda.device_count()          # (does not initialise the device)
-        if have < n:
-            raise SystemExit(f"--gpus {n} but {have} GPU(s) visible (NERFSIG_DIST_BACKEND=gloo rehearses N ranks on fewer GPUs)")
+def _run_ranks(args, n, extra_env, timeout_s, capture_stdout):
+    """Start n rank processes, wait for them; returns (return code, rank 0's stdout or None).  A rank that dies takes the others down (they
+    would wait in a collective for ever); a run that outlasts `timeout_s` is killed the same way -- by the exact PIDs started here."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **extra_env)
+        out = subprocess.PIPE if (capture_stdout and r == 0) else None
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out, text=bool(out)))
+    rc, t0, text = 0, time.time(), None
     try:
         pending = list(procs)
         while pending:
@@ -88,19 +82,59 @@ def launch_ranks(args):
                 pending.remove(p)
                 if code != 0:
                     rc = rc or code
-                    for q in pending:       # a rank died: the others would wait in a collective for ever
+                    for q in pending:
                         q.terminate()
+            if pending and timeout_s and time.time() - t0 > timeout_s:
+                rc = rc or 124
+                for q in pending:
+                    q.terminate()
+                time.sleep(5)
+                break
             time.sleep(0.05)
+        if procs[0].stdout is not None:
+            text = procs[0].stdout.read()
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
+    return rc, text
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their
+    environment), wait, exit with the worst return code.  Decided before anything touches the GPU; children are new processes, never
+    an exec of one that initialised the device.  Rank 0's stdout carries the one JSON line.
+
+    Execution mode of the captured step for N > 1: first with the RCCL collectives captured INSIDE the step's
+    hipGraph (one graph per step; measured 60 us per step faster on a world-size-1 nccl group, profiles/r02_capture_collectives_world1.txt)
+    under a watchdog; if that run fails or outlasts the watchdog, the ranks are started again with the collectives BETWEEN captured segments
+    (the conservative form).  NERFSIG_CAPTURE_COLLECTIVES=0|1 in the environment pins the mode (no second attempt)."""
+    n = args.gpus
+    backend = os.environ.get("NERFSIG_DIST_BACKEND", "")
+    if not args.dry_launch and backend != "gloo":
+        have = torch.cuda.device_count()          # (does not initialise the device)
+        if have < n:
+            raise SystemExit(f"--gpus {n} but {have} GPU(s) visible (NERFSIG_DIST_BACKEND=gloo rehearses N ranks on fewer GPUs)")
+    pinned = os.environ.get("NERFSIG_CAPTURE_COLLECTIVES")
+    test_hook = os.environ.get("NERFSIG_TEST_FAIL_CAPTURED") == "1"      # (tests: the first attempt's ranks exit with code 3)
+    if ((args.dry_launch or backend == "gloo") and not test_hook) or args.no_graph or pinned is not None:
+        rc, _ = _run_ranks(args, n, {}, None, capture_stdout=False)
+        raise SystemExit(rc)
+    rc, text = _run_ranks(args, n, {"NERFSIG_CAPTURE_COLLECTIVES": "1"}, float(os.environ.get("NERFSIG_LAUNCH_WATCHDOG_S", "240")), capture_stdout=True)
+    if rc != 0 or not text or "{" not in text:
+        print(f"[bench] the run with captured collectives ended with code {rc}; starting the ranks again with the collectives between segments", file=sys.stderr)
+        rc, text = _run_ranks(args, n, {"NERFSIG_CAPTURE_COLLECTIVES": "0"}, None, capture_stdout=True)
+    if text:
+        sys.stdout.write(text)
+        sys.stdout.flush()
     raise SystemExit(rc)
 
 
 def dry_launch(args):
     """The launcher path and the step's collectives on gloo / CPU tensors (no kernels): proves `--gpus N` starts N ranks that meet."""
     from nerf_signature_amd import dp
+    if os.environ.get("NERFSIG_TEST_FAIL_CAPTURED") == "1" and os.environ.get("NERFSIG_CAPTURE_COLLECTIVES") == "1":
+        raise SystemExit(3)
     rank, world, _ = dp.init_from_env(backend="gloo")
     D = 32
     ok = True
@@ -122,7 +156,8 @@ def dry_launch(args):
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
     if rank == 0:
         print(json.dumps({"dry_launch": True, "n_gpus": world, "world_size_seen": dp.world_size(), "backend": dist.get_backend() if dist.is_initialized() else None,
-                          "block_shard_rank0": shard, "collectives_ok": bool(t.item()), "grad_exchange_bytes_per_step": ex.bytes_per_step}), flush=True)
+                          "block_shard_rank0": shard, "collectives_ok": bool(t.item()), "grad_exchange_bytes_per_step": ex.bytes_per_step,
+                          "capture_collectives_env": os.environ.get("NERFSIG_CAPTURE_COLLECTIVES")}), flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
@@ -407,7 +442,8 @@ def bench_training(args, scene, real_stdout):
             "grad_exchange_bytes_per_step": loop.exchange.bytes_per_step + (rays_block_all * 12 if sharded else 0),
             "collectives_per_step": (loop.exchange.collectives_per_step + (1 if sharded else 0)) if dp.exchange_active() else 0,
             "world_size_seen_by_backend": dp.world_size(), "backend": dist.get_backend() if dist.is_initialized() else None,
-            "execution": "eager" if args.no_graph else f"hipGraph replay, {len(loop.segments)} captured segment(s)" + (" with the RCCL collectives between them" if len(loop.segments) > 1 else ""),
+            "execution": "eager" if args.no_graph else f"hipGraph replay, {len(loop.segments)} captured segment(s)" + (" with the RCCL collectives between them" if len(loop.segments) > 1 else
+                                                                  (" with the RCCL collectives captured inside" if dp.exchange_active() else "")),
             "capacity_overflow": overflow, "recaptured_with_more_headroom_after_warmup": recaptured,
             "loss": loss_value, "loss_image": loss_parts[0], "loss_watermark": loss_parts[1],
         },

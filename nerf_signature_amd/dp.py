@@ -35,9 +35,14 @@ def set_boundary(handler):
 
 
 def collective(fn):
-    """Run the eager collective(s) in `fn` now -- or, under a segmented capture, make this point a segment boundary."""
+    """Run the eager collective(s) in `fn` now -- or, under a segmented capture, make this point a segment boundary.
+    NERFSIG_CAPTURE_COLLECTIVES=1 (opt-in) leaves the RCCL calls INSIDE the capture instead: one hipGraph per step for any world size,
+    no eager launches between segments.  Rehearsed on a world-size-1 nccl group only (the pool has one-GPU boxes), hence not the default."""
     if _BOUNDARY is not None and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-        _BOUNDARY(fn)
+        if os.environ.get("NERFSIG_CAPTURE_COLLECTIVES", "") == "1":
+            fn()
+        else:
+            _BOUNDARY(fn)
     else:
         fn()
 

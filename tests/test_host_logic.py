@@ -406,3 +406,21 @@ def test_bench_starts_its_own_ranks_dry_launch():
     line = json.loads(lines[0])
     assert line["dry_launch"] and line["n_gpus"] == 2 and line["world_size_seen"] == 2 and line["collectives_ok"]
     assert line["block_shard_rank0"] == [0, 16] and line["backend"] == "gloo"
+
+
+def test_bench_launcher_falls_back_when_the_first_attempt_fails():
+    """The launcher first starts the ranks with the collectives captured inside the step's graph; if those ranks fail (here: a test hook
+    makes them exit with code 3) it starts them again with the collectives between captured segments, and only the successful attempt's
+    JSON line reaches stdout."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "NERFSIG_CAPTURE_COLLECTIVES")}
+    env["NERFSIG_TEST_FAIL_CAPTURED"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and "starting the ranks again" in out.stderr
+    line = json.loads(lines[0])
+    assert line["collectives_ok"] and line["capture_collectives_env"] == "0"
