@@ -6,6 +6,7 @@ attributes and methods (`render`, `run_cuda`, `run`, `mark_untrained_grid`, `upd
 `render` accepts and ignores arbitrary extra keyword arguments: the reference splats its whole argparse
 namespace into it (nerf/utils_wtmk_disen.py:590,616)."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -287,6 +288,7 @@ class NeRFRenderer(nn.Module):
             xyzs, dirs, deltas, rays = raymarching.march_rays_train(o, d, self.bound, self.density_bitfield, self.cascade, self.grid_size,
                                                                    nears, fars, counter, self.mean_count, perturb, 128, force_all_rays,
                                                                    dt_gamma, max_steps)
+        self._last_rays = rays if getattr(self, "_keep_rays", False) else None      # (render's fused staging reads the per-ray counts)
         sigmas, rgbs = self(xyzs, dirs, message)
         sigmas = sigmas if self.density_scale == 1 else self.density_scale * sigmas
         if finish is not None:
@@ -403,10 +405,53 @@ class NeRFRenderer(nn.Module):
 
     # ------------------------------------------------------------------ entry point (renderer_wtmk.py:541-575)
 
+    # rays per launch sequence of the fused staged render: 64 of the reference's 4096-ray chunks (1 GiB of march scratch)
+    STAGED_SUPER_RAYS = 1 << 18
+
+    def _render_staged_fused(self, rays_o, rays_d, message, max_ray_batch, **kwargs):
+        """render(staged=True) without gradients on the occupancy-grid training path (what the reference's test_image / test_bitacc and
+        the clean-render pre-pass run, utils_wtmk_disen.py:832, provider_wtmk.py:415): the reference walks the image in max_ray_batch
+        chunks because its march zero-fills 134 MB per 4096 rays and reads a count back per chunk; every ray's samples and colour are
+        independent of the chunking (ray-id ordered march), so here up to 64 chunks go through ONE march / encode / MLP / composite
+        sequence with ONE count read-back.  The visible side effects of the per-chunk calls -- `local_step` and the 16-row `step_counter`
+        ring of (points, rays) per call (renderer_wtmk.py:282-284) -- are reproduced from the per-ray counts."""
+        B, N = rays_o.shape[:2]
+        device = rays_o.device
+        depth = torch.empty((B, N), device=device)
+        image = torch.empty((B, N, 3), device=device)
+        self._keep_rays = True
+        try:
+            for b in range(B):
+                for head in range(0, N, self.STAGED_SUPER_RAYS):
+                    tail = min(head + self.STAGED_SUPER_RAYS, N)
+                    first_call = self.local_step
+                    out = self.run_cuda(rays_o[b:b + 1, head:tail], rays_d[b:b + 1, head:tail], message, **kwargs)
+                    depth[b:b + 1, head:tail] = out["depth"]
+                    image[b:b + 1, head:tail] = out["image"]
+                    counts = self._last_rays[:, 2].long()                                   # ray-id order
+                    bounds = list(range(0, tail - head, max_ray_batch)) + [tail - head]
+                    csum = torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)])
+                    idx = torch.tensor(bounds, device=device)
+                    totals = (csum[idx[1:]] - csum[idx[:-1]]).to(torch.int32)
+                    n_calls = len(bounds) - 1
+                    for k in range(max(0, n_calls - 16), n_calls):                         # the ring rows the per-chunk calls would have left
+                        row = (first_call + k) % 16
+                        self.step_counter[row, 0] = totals[k]
+                        self.step_counter[row, 1] = bounds[k + 1] - bounds[k]
+                    self.local_step = first_call + n_calls
+        finally:
+            self._keep_rays = False
+            self._last_rays = None
+        return {"depth": depth, "image": image}
+
     def render(self, rays_o, rays_d, message=None, staged=False, max_ray_batch=4096, **kwargs):
         _run = self.run_cuda if self.cuda_ray else self.run
         B, N = rays_o.shape[:2]
         device = rays_o.device
+        if (staged and self.cuda_ray and self.training and not torch.is_grad_enabled() and rays_o.is_cuda and N > max_ray_batch
+                and kwargs.get("force_all_rays", False) and not kwargs.get("perturb", False) and getattr(self, "point_capacity", None) is None
+                and os.environ.get("NERFSIG_STAGED_FUSED", "1") != "0"):
+            return self._render_staged_fused(rays_o, rays_d, message, max_ray_batch, **kwargs)
         if staged:
             depth = torch.empty((B, N), device=device)
             image = torch.empty((B, N, 3), device=device)

@@ -724,3 +724,31 @@ def test_fused_decoder_gradients_are_views_of_one_flat_buffer():
     before = [g.clone() for g in grads]
     flat.mul_(2.0)                                   # what the exchange does in place reaches every .grad
     assert all(torch.equal(g, 2.0 * b) for g, b in zip(grads, before))
+
+
+def test_fused_staged_render_equals_chunked(monkeypatch):
+    """render(staged=True) under no_grad on the training path: many max_ray_batch chunks per launch sequence (one count read-back)
+    give bit-identical images and depths, and leave `local_step` and the `step_counter` ring as the reference's per-chunk calls
+    (renderer_wtmk.py:555-570, 282-284) leave them."""
+    m, _, _ = _model()
+    pose, intr, inds = cf.orbit_rays(10000, seed=4)
+    o, d = fr.get_rays(torch.from_numpy(pose)[None], intr, 400, 400, torch.from_numpy(inds)[None])
+    o, d = o.cuda(), d.cuda()
+    msg = torch.from_numpy(cf.messages(32)[2])
+    kw = dict(staged=True, max_ray_batch=1024, bg_color=1, perturb=False, force_all_rays=True, dt_gamma=0, max_steps=1024)
+    monkeypatch.setattr(type(m), "STAGED_SUPER_RAYS", 4096)          # three launch sequences: 4 + 4 + 2 chunks (the last one ragged)
+    results = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("NERFSIG_STAGED_FUSED", fused)
+        m.local_step = 5
+        m.step_counter.zero_()
+        with torch.no_grad():
+            out = m.render(o, d, msg, **kw)
+        results[fused] = (out["image"].clone(), out["depth"].clone(), m.local_step, m.step_counter.clone())
+    (i0, d0, s0, c0), (i1, d1, s1, c1) = results["0"], results["1"]
+    assert torch.equal(i0, i1) and torch.equal(torch.nan_to_num(d0), torch.nan_to_num(d1))
+    assert s0 == s1 == 5 + 10 and torch.equal(c0, c1) and int(c0[:, 1].sum()) > 0
+    with torch.enable_grad():                                        # with gradients enabled the chunked route is taken (and still agrees)
+        monkeypatch.setenv("NERFSIG_STAGED_FUSED", "1")
+        out = m.render(o, d, msg, **kw)
+    assert torch.equal(out["image"].detach(), i0)
