@@ -105,10 +105,11 @@ def launch_ranks(args):
     environment), wait, exit with the worst return code.  Decided before anything touches the GPU; children are new processes, never
     an exec of one that initialised the device.  Rank 0's stdout carries the one JSON line.
 
-    Execution mode of the captured step for N > 1: first with the RCCL collectives captured INSIDE the step's
-    hipGraph (one graph per step; measured 60 us per step faster on a world-size-1 nccl group, profiles/r02_capture_collectives_world1.txt)
-    under a watchdog; if that run fails or outlasts the watchdog, the ranks are started again with the collectives BETWEEN captured segments
-    (the conservative form).  NERFSIG_CAPTURE_COLLECTIVES=0|1 in the environment pins the mode (no second attempt)."""
+    Execution mode of the captured step for N > 1: the RCCL collectives run BETWEEN captured segments.
+    NERFSIG_CAPTURE_COLLECTIVES=try makes the launcher first start the ranks with the collectives captured INSIDE the step's hipGraph (one
+    graph per step: 1.112 against 1.197 ms on a world-size-1 nccl group, profiles/r02_capture_collectives_world1.txt) under a watchdog and
+    fall back to segments if that run fails or outlasts it -- opt-in, because one of four rehearsals died in ProcessGroupNCCL's watchdog
+    thread (an event query racing the capture).  NERFSIG_CAPTURE_COLLECTIVES=0|1 pins the mode (no second attempt)."""
     n = args.gpus
     backend = os.environ.get("NERFSIG_DIST_BACKEND", "")
     if not args.dry_launch and backend != "gloo":
@@ -117,7 +118,7 @@ def launch_ranks(args):
             raise SystemExit(f"--gpus {n} but {have} GPU(s) visible (NERFSIG_DIST_BACKEND=gloo rehearses N ranks on fewer GPUs)")
     pinned = os.environ.get("NERFSIG_CAPTURE_COLLECTIVES")
     test_hook = os.environ.get("NERFSIG_TEST_FAIL_CAPTURED") == "1"      # (tests: the first attempt's ranks exit with code 3)
-    if ((args.dry_launch or backend == "gloo") and not test_hook) or args.no_graph or pinned is not None:
+    if (pinned != "try" and not test_hook) or args.no_graph or ((args.dry_launch or backend == "gloo") and not test_hook):
         rc, _ = _run_ranks(args, n, {}, None, capture_stdout=False)
         raise SystemExit(rc)
     rc, text = _run_ranks(args, n, {"NERFSIG_CAPTURE_COLLECTIVES": "1"}, float(os.environ.get("NERFSIG_LAUNCH_WATCHDOG_S", "240")), capture_stdout=True)
@@ -439,8 +440,9 @@ def bench_training(args, scene, real_stdout):
                         ("drawn inside the captured step from the device-resident pose/image store (rg_sample_rays)" if sampler is not None else "rays generated on the device inside the timed loop (host-driven: randint, rg_get_rays, gather, copies)"),
             "content_march": "ahead (end of the previous replay)" if getattr(loop, "content_ahead", False) else "head of the step",
             "message_dim": D, "parallelism": f"dp{world}", "optimizer": "Adam(betas=(0.9,0.99), eps=1e-15): torch semantics, codebook update fused (opt_codebook_adam)",
-            "grad_exchange_bytes_per_step": loop.exchange.bytes_per_step + (rays_block_all * 12 if sharded else 0),
-            "collectives_per_step": (loop.exchange.collectives_per_step + (1 if sharded else 0)) if dp.exchange_active() else 0,
+            "grad_exchange_bytes_per_step": loop.exchange.bytes_per_step + (rays_block_all * 12 if sharded else 0) + (T_BYTES if getattr(loop, "opt_shard", None) else 0),
+            "collectives_per_step": (loop.exchange.collectives_per_step + (1 if sharded else 0) + (1 if getattr(loop, "opt_shard", None) else 0)) if dp.exchange_active() else 0,
+            "codebook_optimizer": ("sharded over the ranks (each updates the tables of D/R bits, partial pre-sums all-reduced)" if getattr(loop, "opt_shard", None) else "replicated"),
             "world_size_seen_by_backend": dp.world_size(), "backend": dist.get_backend() if dist.is_initialized() else None,
             "execution": "eager" if args.no_graph else f"hipGraph replay, {len(loop.segments)} captured segment(s)" + (" with the RCCL collectives between them" if len(loop.segments) > 1 else
                                                                   (" with the RCCL collectives captured inside" if dp.exchange_active() else "")),

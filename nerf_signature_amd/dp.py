@@ -37,7 +37,8 @@ def set_boundary(handler):
 def collective(fn):
     """Run the eager collective(s) in `fn` now -- or, under a segmented capture, make this point a segment boundary.
     NERFSIG_CAPTURE_COLLECTIVES=1 (opt-in) leaves the RCCL calls INSIDE the capture instead: one hipGraph per step for any world size,
-    no eager launches between segments.  Rehearsed on a world-size-1 nccl group only (the pool has one-GPU boxes), hence not the default."""
+    no eager launches between segments (-85 us per step on a world-size-1 nccl group).  Not the default: rehearsed on one rank only, and
+    one of four rehearsals died in ProcessGroupNCCL's watchdog thread (an event query racing the capture)."""
     if _BOUNDARY is not None and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
         if os.environ.get("NERFSIG_CAPTURE_COLLECTIVES", "") == "1":
             fn()
@@ -90,6 +91,18 @@ def block_shard(D):
         return None
     n = D // world
     return dist.get_rank() * n, (dist.get_rank() + 1) * n
+
+
+def optimizer_shard(D):
+    """(first, one-past-last) message BIT whose two codebook tables this rank's optimiser owns, or None (every rank updates all tables).
+    With the blocks sharded the step never reads a codebook table directly -- both renders read the pre-summed table S, and the
+    backward writes the shared gradient G -- so Adam over the D selected tables (836 MiB of HBM traffic, the largest replicated item of a
+    rank's step) is split like ZeRO: rank r updates the tables of its bits with the all-reduced G and contributes its PARTIAL pre-sum of
+    the next message to one more 4 MiB all-reduce.  Tables a rank does not own go stale there until GraphedWatermarkLoop.gather_codebook().
+    NERFSIG_SHARD_OPTIMIZER=0 keeps the replicated optimiser."""
+    if os.environ.get("NERFSIG_SHARD_OPTIMIZER", "1") == "0":
+        return None
+    return block_shard(D)
 
 
 def content_grad_scale(sharded):

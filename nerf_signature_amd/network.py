@@ -51,6 +51,7 @@ class NeRFNetwork(NeRFRenderer):
         self._presum_cache = None   # (key, S)
         self.grad_sink = None       # optional fieldops.GradSink: backward accumulates the shared gradient there
         self.device_select = False  # True: CUDA messages select their tables on the device (graph-capturable step)
+        self.codebook_shard = None  # (first bit, last bit) this rank's optimiser owns (dp.optimizer_shard): pre-sums are partial + all-reduced
 
     # ------------------------------------------------------------------ cached device images
 
@@ -105,7 +106,15 @@ class NeRFNetwork(NeRFRenderer):
         key = ("dev", message.data_ptr(), message._version, tuple((t.data_ptr(), t._version) for t in tables))
         if self._presum_cache is None or self._presum_cache[0] is None or self._presum_cache[0] != key:
             S = self._presum_cache[1] if self._presum_cache is not None else None
-            self._presum_cache = (key, fo.codebook_presum_sel(tables, message, out=S))
+            if self.codebook_shard is not None:       # this rank holds current values only for the tables of its own bits
+                import torch.distributed as dist
+                from . import dp
+                b0, b1 = self.codebook_shard
+                S = fo.codebook_presum_sel(tables[2 * b0:2 * b1], message[b0:b1], out=S)
+                dp.collective(lambda: dist.all_reduce(S, op=dist.ReduceOp.SUM))
+                self._presum_cache = (key, S)
+            else:
+                self._presum_cache = (key, fo.codebook_presum_sel(tables, message, out=S))
             self._presum_produced()
         else:
             self._presum_consumed()

@@ -75,13 +75,13 @@ def _step_shared_sel(opt, tables, message_dev, G, lr_dev, grad_scale=1.0, next_m
     group = opt._group_of(tables[0])
     beta1, beta2 = group["betas"]
     cache = getattr(opt, "_sel_cache", None)
-    if cache is None or cache[0] is not tables:
+    if cache is None or len(cache[0]) != len(tables) or any(a is not b for a, b in zip(cache[0], tables)):
         _prepare_device_state(opt, tables)
         D = len(tables) // 2
         arrays = (nv.ptr_array([t.data for t in tables]), nv.ptr_array([opt.state[t]["exp_avg"] for t in tables]),
                   nv.ptr_array([opt.state[t]["exp_avg_sq"] for t in tables]), nv.ptr_array([opt.state[t]["step"] for t in tables]))
         scratch = torch.empty(2 * D, dtype=torch.float32, device=tables[0].device)
-        cache = opt._sel_cache = (tables, arrays, scratch, D)
+        cache = opt._sel_cache = (list(tables), arrays, scratch, D)
     _, (pp, pm, pv, ps), scratch, D = cache
     if next_message_dev is not None:
         if S_next is None or S_next.dtype != torch.float32 or not S_next.is_contiguous() or S_next.numel() != tables[0].numel():

@@ -332,6 +332,7 @@ class GraphedWatermarkLoop:
         self.graphs = None
         self.segments, self.between = [], []
         self.sharded = False
+        self.opt_shard = None
         self.out = None
         self.steps_done = 0
         self._replays = 0             # replays of the opening graph so far == the device's stage_counter (ring slot of the next step)
@@ -347,8 +348,35 @@ class GraphedWatermarkLoop:
         self._s_for = None
         self.model._packed()
 
+    @torch.no_grad()
+    def gather_codebook(self, optimizer_state=True):
+        """With the optimiser sharded over the ranks (dp.optimizer_shard) a rank's copies of the tables it does not own are stale.  Brings
+        every rank's codebook (and, optionally, Adam's moments and step counts of those tables) up to date with one all-gather per kind:
+        call before saving a checkpoint, evaluating with a message through the host-side selection, or leaving the captured loop."""
+        if self.opt_shard is None:
+            return
+        import torch.distributed as dist
+        from .optim import _prepare_device_state
+        b0, b1 = self.opt_shard
+        world = dist.get_world_size()
+        _prepare_device_state(self.optimizer, self.tables)      # (state of tables this rank never stepped: zeros, about to be overwritten)
+        kinds = [lambda t: t.data]
+        if optimizer_state:
+            dp_state = self.optimizer.state
+            kinds += [lambda t, k=k: dp_state[t][k] for k in ("exp_avg", "exp_avg_sq", "step") if all(k in dp_state[t] for t in self.tables)]
+        for get in kinds:
+            own = torch.stack([get(t).reshape(-1) for t in self.tables[2 * b0:2 * b1]])          # [2 * bits per rank, n]
+            every = torch.empty((world,) + tuple(own.shape), dtype=own.dtype, device=own.device)
+            dp._all_gather_into(every.view(world * own.shape[0], -1), own)
+            for i, t in enumerate(self.tables):
+                get(t).reshape(-1).copy_(every.view(len(self.tables), -1)[i])
+        from .optim import _bump_versions
+        _bump_versions(self.tables)
+
     def close(self):
         """Detach from the model: the eager loop (or another graphed loop) may drive it again."""
+        self.gather_codebook()
+        self.model.codebook_shard = None
         self.model.device_select = False
         self.model.point_capacity = None
         if self in getattr(self.model, "_graphed_loops", ()):
@@ -384,19 +412,33 @@ class GraphedWatermarkLoop:
             torch.cuda.current_stream().wait_stream(self.side_stream)
         return out
 
-    def _optimise(self):
+    def _optimise(self, defer_collective=False):
+        """The optimiser step.  defer_collective: return the sharded optimiser's closing all-reduce as a callable instead of running it
+        (the caller runs it once every forked stream has joined: a collective may end a captured segment)."""
+        post = None
         scale = 1.0 / world_size() if self.native_dense_adam else 1.0    # the exchange leaves sums: the mean is taken here
         # sharded blocks: G is already sum_r G_block_r + mean_r G_content_r (the content seeds carried 1/world): no factor
         scale_cb = 1.0 if (self.sharded and self.native_dense_adam) else scale
+        tables, msg, msg_next = self.tables, self.msg_dev, self.msg_next_dev
+        if self.opt_shard is not None:      # ZeRO-style: this rank updates the tables of its own bits only (dp.optimizer_shard)
+            b0, b1 = self.opt_shard
+            tables, msg, msg_next = self.tables[2 * b0:2 * b1], self.msg_dev[b0:b1], self.msg_next_dev[b0:b1]
         if self.presum_in_adam:     # ... and the next step's pre-sum, in place (both renders of this step are done with the buffer)
-            self.optimizer.step_shared_sel(self.tables, self.msg_dev, self.sink.G, self.lr_dev, scale_cb, next_message_dev=self.msg_next_dev,
-                                           S_next=self.model._presum_cache[1])
+            S = self.model._presum_cache[1]
+            self.optimizer.step_shared_sel(tables, msg, self.sink.G, self.lr_dev, scale_cb, next_message_dev=msg_next, S_next=S)
+            if self.opt_shard is not None:  # the ranks' partial pre-sums of the next message add up to the whole one
+                import torch.distributed as dist
+                post = lambda: dp.collective(lambda: dist.all_reduce(S, op=dist.ReduceOp.SUM))
         else:
-            self.optimizer.step_shared_sel(self.tables, self.msg_dev, self.sink.G, self.lr_dev, scale_cb)
+            self.optimizer.step_shared_sel(tables, msg, self.sink.G, self.lr_dev, scale_cb)
         if self.native_dense_adam:
             self.optimizer.step_dense(self.lr_dev, scale)      # the decoder's parameters: opt_adam_dense
         else:
             self.optimizer.step()
+        if post is not None and not defer_collective:
+            post()
+            post = None
+        return post
 
     def _march_ahead(self):
         kw, wm, ct = self.render_kwargs, self.data["watermark"], self.data["content"]
@@ -417,11 +459,13 @@ class GraphedWatermarkLoop:
             self.side_stream.wait_stream(main)      # both backward passes of this step are done with the buffers
             with torch.cuda.stream(self.side_stream):
                 self._march_ahead()
-        self._optimise()
+        post = self._optimise(defer_collective=True)
         if self.side_stream is not None:
             main.wait_stream(self.side_stream)
         else:
             self._march_ahead()
+        if post is not None:
+            post()                                  # (a collective: only after the streams have joined)
 
     def point_counts(self):
         """(block, content) sample totals of the last step (one host read)."""
@@ -502,6 +546,8 @@ class GraphedWatermarkLoop:
         block_o, block_d, shard = local_blocks(self.data["watermark"])
         self.sharded = shard is not None
         self.exchange.shared_scale = 1.0 if self.sharded else None
+        self.opt_shard = dp.optimizer_shard(model.message_dim) if self.sharded else None
+        model.codebook_shard = self.opt_shard
         with torch.no_grad():   # sizes only: the two renders of a step, in order (block, content)
             model.render(block_o, block_d, message, staged=False, bg_color=1,
                          perturb=False, force_all_rays=True, **self.render_kwargs)

@@ -161,3 +161,47 @@ def test_two_rank_step_equals_single_process_step(monkeypatch, strict_mlp):
     assert rel_dec <= 1e-4
     kinds = sorted({k for k, _, _ in group.log})
     assert kinds == ["all_gather", "all_reduce"]
+
+
+def test_sharded_codebook_optimizer_equals_replicated(strict_mlp):
+    """dp.optimizer_shard: rank r runs the fused codebook Adam on the tables of ITS bits only and contributes a partial pre-sum of the next
+    message.  Emulated on one GPU with three replicas of the same tables and the same (all-reduced) gradient G: one replica takes the
+    replicated step over all D bits, the other two play ranks 0 and 1.  Owned tables, their Adam moments and step counts must equal the
+    replicated result bit for bit, the other rank's tables must stay untouched, and the two partial pre-sums must add up to the
+    replicated one."""
+    from nerf_signature_amd.optim import CodebookAdam
+    D = 32
+    torch.manual_seed(0)
+    G = torch.randn(1 << 19, 2, device="cuda") * 1e-3
+    msg = torch.from_numpy(cf.messages(D)[2]).cuda()
+    nxt = (1 - msg).contiguous()
+    nxt[::3] = msg[::3]
+    lr = torch.tensor(1e-2, device="cuda")
+
+    def replica():
+        tables = [torch.nn.Parameter(torch.from_numpy(cf.table(100 + l, scale=0.05)).cuda()) for l in range(2 * D)]
+        return tables, CodebookAdam([{"params": tables}], lr=1e-2, betas=(0.9, 0.99), eps=1e-15, capturable=True)
+
+    t_ref, o_ref = replica()
+    S_ref = torch.zeros(1 << 19, 2, device="cuda")
+    for _ in range(2):                                  # two steps: the second one sees non-zero moments
+        o_ref.step_shared_sel(t_ref, msg, G, lr, 1.0, next_message_dev=nxt, S_next=S_ref)
+    parts = []
+    for r in range(2):
+        b0, b1 = r * D // 2, (r + 1) * D // 2
+        t, o = replica()
+        S = torch.zeros(1 << 19, 2, device="cuda")
+        for _ in range(2):
+            o.step_shared_sel(t[2 * b0:2 * b1], msg[b0:b1], G, lr, 1.0, next_message_dev=nxt[b0:b1], S_next=S)
+        parts.append(S)
+        init = [torch.from_numpy(cf.table(100 + l, scale=0.05)).cuda() for l in range(2 * D)]
+        for l in range(2 * D):
+            if 2 * b0 <= l < 2 * b1:
+                assert torch.equal(t[l], t_ref[l])
+                if len(o_ref.state[t_ref[l]]):
+                    for k in ("exp_avg", "exp_avg_sq", "step"):
+                        assert torch.equal(o.state[t[l]][k], o_ref.state[t_ref[l]][k])
+            else:
+                assert torch.equal(t[l], init[l]) and len(o.state[t[l]]) == 0
+    np.testing.assert_allclose((parts[0] + parts[1]).cpu().numpy(), S_ref.cpu().numpy(), rtol=0, atol=1e-6)   # fp32 summation order (values up to ~1.6)
+    assert float(S_ref.abs().max()) > 0.1

@@ -409,9 +409,9 @@ def test_bench_starts_its_own_ranks_dry_launch():
 
 
 def test_bench_launcher_falls_back_when_the_first_attempt_fails():
-    """The launcher first starts the ranks with the collectives captured inside the step's graph; if those ranks fail (here: a test hook
-    makes them exit with code 3) it starts them again with the collectives between captured segments, and only the successful attempt's
-    JSON line reaches stdout."""
+    """NERFSIG_CAPTURE_COLLECTIVES=try: the launcher first starts the ranks with the collectives captured inside the step's graph; if those
+    ranks fail (here: a test hook makes them exit with code 3) it starts them again with the collectives between captured segments, and
+    only the successful attempt's JSON line reaches stdout."""
     import json
     import subprocess
     import sys
