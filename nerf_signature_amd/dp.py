@@ -34,7 +34,7 @@ def set_boundary(handler):
     return prev
 
 
-def collective(fn):
+def collective(fn, last=False):
     """Run the eager collective(s) in `fn` now -- or, under a segmented capture, make this point a segment boundary.
     NERFSIG_CAPTURE_COLLECTIVES=1 (opt-in) leaves the RCCL calls INSIDE the capture instead: one hipGraph per step for any world size,
     no eager launches between segments (-85 us per step on a world-size-1 nccl group).  Not the default: rehearsed on one rank only, and
@@ -43,7 +43,7 @@ def collective(fn):
         if os.environ.get("NERFSIG_CAPTURE_COLLECTIVES", "") == "1":
             fn()
         else:
-            _BOUNDARY(fn)
+            _BOUNDARY(fn, last)        # last: nothing of the step follows this collective -- no further segment is opened
     else:
         fn()
 
@@ -99,8 +99,10 @@ def optimizer_shard(D):
     backward writes the shared gradient G -- so Adam over the D selected tables (836 MiB of HBM traffic, the largest replicated item of a
     rank's step) is split like ZeRO: rank r updates the tables of its bits with the all-reduced G and contributes its PARTIAL pre-sum of
     the next message to one more 4 MiB all-reduce.  Tables a rank does not own go stale there until GraphedWatermarkLoop.gather_codebook().
-    NERFSIG_SHARD_OPTIMIZER=0 keeps the replicated optimiser."""
-    if os.environ.get("NERFSIG_SHARD_OPTIMIZER", "1") == "0":
+    It pays from four ranks on: it saves (1 - 1/R) of a ~150 us HBM-bound kernel and costs one more latency-bound collective (~40 us).
+    NERFSIG_SHARD_OPTIMIZER=0 / 1 forces it off / on."""
+    mode = os.environ.get("NERFSIG_SHARD_OPTIMIZER", "")
+    if mode == "0" or (mode != "1" and world_size() < 4 and os.environ.get("NERFSIG_FORCE_EXCHANGE", "") != "1"):
         return None
     return block_shard(D)
 

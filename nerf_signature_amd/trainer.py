@@ -428,7 +428,7 @@ class GraphedWatermarkLoop:
             self.optimizer.step_shared_sel(tables, msg, self.sink.G, self.lr_dev, scale_cb, next_message_dev=msg_next, S_next=S)
             if self.opt_shard is not None:  # the ranks' partial pre-sums of the next message add up to the whole one
                 import torch.distributed as dist
-                post = lambda: dp.collective(lambda: dist.all_reduce(S, op=dist.ReduceOp.SUM))
+                post = lambda: dp.collective(lambda: dist.all_reduce(S, op=dist.ReduceOp.SUM), last=True)
         else:
             self.optimizer.step_shared_sel(tables, msg, self.sink.G, self.lr_dev, scale_cb)
         if self.native_dense_adam:
@@ -591,11 +591,16 @@ class GraphedWatermarkLoop:
         # thread's calls belong to the capture.
         self.segments, self.between = [torch.cuda.CUDAGraph()], []
 
-        def boundary(fn):
+        open_capture = [True]
+
+        def boundary(fn, last=False):
             self.segments[-1].capture_end()
             fo.forget_plan_events()          # events recorded in the finished capture must not be waited on in the next one
             self.model._presum_event = None
             self.between.append(fn)
+            if last:                         # the step ends with this collective: no empty segment behind it
+                open_capture[0] = False
+                return
             g = torch.cuda.CUDAGraph()
             self.segments.append(g)
             g.capture_begin(pool=self.segments[0].pool(), capture_error_mode="thread_local")
@@ -612,7 +617,8 @@ class GraphedWatermarkLoop:
                 self.out = self._forward_backward()
                 self.exchange(self.sink.G)
                 self._optimise_and_march()
-                self.segments[-1].capture_end()
+                if open_capture[0]:
+                    self.segments[-1].capture_end()
         finally:
             dp.set_boundary(prev)
         torch.cuda.current_stream().wait_stream(capture_stream)

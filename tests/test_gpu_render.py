@@ -316,8 +316,8 @@ def test_split_graphs_with_rccl_exchange_rehearsed_on_one_rank():
         dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{29700 + os.getpid() % 200}", rank=0, world_size=1)
         assert dp.exchange_active()
         loop1, l1, t1 = run()
-        # render | all-gather | decode+backward | all-reduce | optimiser (own tables) | all-reduce of the partial pre-sums | (end)
-        assert len(loop1.segments) == 4 and len(loop1.between) == 3 and loop1.sharded and loop1.opt_shard == (0, 32)
+        # render | all-gather | decode+backward | all-reduce | optimiser (own tables) | all-reduce of the partial pre-sums (closes the step)
+        assert len(loop1.segments) == 3 and len(loop1.between) == 3 and loop1.sharded and loop1.opt_shard == (0, 32)
         assert loop1.exchange.collectives_per_step == 1                  # G and the decoder's gradient block travel together
         assert loop1.exchange.bytes_per_step == (1 << 19) * 2 * 4 + sum(p.numel() for p in loop1.model.msg_decoder.parameters() if p.grad is not None) * 4
     finally:
