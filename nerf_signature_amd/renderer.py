@@ -204,14 +204,18 @@ class NeRFRenderer(nn.Module):
     def _rays_key(o, d):
         return (o.data_ptr(), o._version, d.data_ptr(), d._version, o.shape[0])
 
-    def march_ahead(self, rays_o, rays_d, dt_gamma=0, max_steps=1024, perturb=False):
+    def march_ahead(self, rays_o, rays_d, dt_gamma=0, max_steps=1024, perturb=False, phase="all"):
         """March the training samples of these rays now, for a render issued later with the same (unmodified) ray tensors.
 
         The march needs the rays and the occupancy grid only -- nothing a training step updates -- so a loop that knows its next
         rays runs it beside the optimiser of the current step (an HBM stream that leaves the ALUs idle) instead of at the head of
         the next one.  Needs `point_capacity` (the no-host-sync march); a repeated call for the same tensors re-marches into the
         same buffers.  run_cuda picks the samples up by the tensors' addresses and versions; any in-place change of the rays after
-        the call makes it march again as usual."""
+        the call makes it march again as usual.
+
+        phase: "all", or the two halves separately -- "count" (near/far and the occupancy walk: writes only per-ray counts and the
+        sampled parameters, scratch nobody else reads) and "write" (prefix sum + the sample buffers, which overwrite what the current
+        step's backward still reads).  A loop may therefore run "count" while the current step is still in flight and "write" at its end."""
         if not hasattr(self, "_marched"):
             self._marched = {}
         prefix, o, d = self._flatten_rays(rays_o, rays_d)
@@ -225,11 +229,23 @@ class NeRFRenderer(nn.Module):
             f32 = dict(dtype=torch.float32, device=dev)
             rec = {"ptrs": (o.data_ptr(), d.data_ptr(), N), "capacity": capacity, "nears": torch.empty(N, **f32), "fars": torch.empty(N, **f32),
                    "xyzs": torch.empty(capacity, 3, **f32), "dirs": torch.empty(capacity, 3, **f32), "deltas": torch.empty(capacity, 2, **f32),
-                   "rays": torch.empty(N, 3, dtype=torch.int32, device=dev), "counter": torch.zeros(2, dtype=torch.int32, device=dev), "key": None}
-        raymarching.near_far_into(o, d, self.aabb_train, self.min_near, rec["nears"], rec["fars"])
-        raymarching.march_rays_train_capacity(o, d, self.bound, self.density_bitfield, self.cascade, self.grid_size, rec["nears"], rec["fars"],
-                                              rec["counter"], capacity, perturb, dt_gamma, max_steps,
-                                              out=(rec["xyzs"], rec["dirs"], rec["deltas"], rec["rays"]))
+                   "rays": torch.empty(N, 3, dtype=torch.int32, device=dev), "counter": torch.zeros(2, dtype=torch.int32, device=dev), "key": None,
+                   "counts": torch.empty(N, dtype=torch.int32, device=dev), "t_rec": torch.empty(N * int(max_steps), **f32), "max_steps": int(max_steps),
+                   "noises": None}
+        if rec["max_steps"] != int(max_steps):
+            raise ValueError("march_ahead: max_steps changed for rays that were marched before")
+        N = o.shape[0]
+        geom = (float(self.bound), float(dt_gamma), int(max_steps), N, int(self.cascade), int(self.grid_size))
+        if phase in ("all", "count"):
+            raymarching.near_far_into(o, d, self.aabb_train, self.min_near, rec["nears"], rec["fars"])
+            rec["noises"] = torch.rand(N, dtype=torch.float32, device=o.device) if perturb else None
+            nv.call("rm_march_train_count", nv.ptr(o), nv.ptr(d), nv.ptr(self.density_bitfield), *geom, nv.ptr(rec["nears"]), nv.ptr(rec["fars"]),
+                    nv.ptr(rec["noises"]), nv.ptr(rec["counts"]), nv.ptr(rec["t_rec"]), nv.stream())
+        if phase in ("all", "write"):
+            nv.call("rm_march_train_scan", nv.ptr(rec["counts"]), N, nv.ptr(rec["rays"]), nv.ptr(rec["counter"]), nv.stream())
+            nv.call("rm_march_train_write", nv.ptr(o), nv.ptr(d), geom[0], geom[1], geom[2], N, geom[4], geom[5], capacity, nv.ptr(rec["nears"]),
+                    nv.ptr(rec["noises"]), nv.ptr(rec["t_rec"]), nv.ptr(rec["rays"]), nv.ptr(rec["counter"]), nv.ptr(rec["xyzs"]), nv.ptr(rec["dirs"]),
+                    nv.ptr(rec["deltas"]), nv.stream())
         self._marched = {k: r for k, r in self._marched.items() if r is not rec}
         rec["key"] = self._rays_key(o, d)
         self._marched[rec["key"]] = rec

@@ -442,7 +442,7 @@ class GraphedWatermarkLoop:
 
     def _march_ahead(self):
         kw, wm, ct = self.render_kwargs, self.data["watermark"], self.data["content"]
-        args = (kw.get("dt_gamma", 0), kw.get("max_steps", 1024))
+        args = (kw.get("dt_gamma", 0), kw.get("max_steps", 1024))   # (march_ahead(..., phase="count" | "write") could split the walk from the writes: measured, slower)
         # the block render's march only: the content render's stays at the head of its step, on the side stream, where it
         # overlaps the pre-sum and the block encoder (both marches next to the optimiser took longer than the optimiser)
         block_o, block_d, _ = local_blocks(wm)       # (this rank's shard of the blocks when they are split over the ranks)
