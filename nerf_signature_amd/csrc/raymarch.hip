@@ -371,6 +371,21 @@ __global__ void __launch_bounds__(256) k_march_index(const float *__restrict__ r
             }
             L = lo;
         }
+        // ---- chains of empty cells collapsed in parallel.  The chase below used to visit every empty cell on its own (one trip of ~30 dependent
+        // scalar instructions per cell, ~14 cells per chunk in empty space: 22 of the 34 us a ray's walk takes, profiles/r02_march_pipelined_experiment.txt).
+        // An empty index k goes to L(k), which is again an index of this chunk or 64; following L from k until the first index that is not an
+        // empty one (an occupied index, one with t >= far, or 64) is a composition of the SAME map, so six rounds of pointer doubling over
+        // the 64 lanes give every empty index its chain's end (`hop & 0xff`) and the last empty index of the chain (`hop >> 8`, whose exit
+        // parameter is what the serial walk would carry out of the chunk).  The chase then takes ONE trip per chain of empty cells.
+        const bool empty = valid && !occ;
+        const unsigned long long link_mask = __ballot(empty);        // indices whose successor is another jump
+        int hop = empty ? (L | (lane << 8)) : (lane | (lane << 8));
+#pragma unroll
+        for (int round = 0; round < 6; ++round) {
+            const int j = hop & 0xff;
+            const int other = __shfl(hop, j < 64 ? j : lane, 64);
+            if (empty && j < 64 && ((link_mask >> j) & 1ull)) hop = other;
+        }
         // ---- wave-uniform chase over this chunk
         const unsigned long long reach = __ballot(tj >= carry_exit);
         int k = reach ? __builtin_ctzll(reach) : 64;
@@ -387,8 +402,9 @@ __global__ void __launch_bounds__(256) k_march_index(const float *__restrict__ r
                 carry_exit = -FLT_MAX;                                  // if the run reaches the chunk end, index 0 of the next chunk is visited
             } else {
                 const int from = __builtin_amdgcn_readfirstlane(k);
-                k = __builtin_amdgcn_readlane(L, from);
-                carry_exit = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_exit), from));
+                const int chain = __builtin_amdgcn_readlane(hop, from);
+                k = chain & 0xff;
+                carry_exit = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_exit), chain >> 8));
             }
         }
         // ---- sample cap (raymarching.cu:359: num_steps < max_steps) and coalesced store of the sampled parameters
