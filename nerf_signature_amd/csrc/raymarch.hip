@@ -364,12 +364,28 @@ __global__ void __launch_bounds__(256) k_march_index(const float *__restrict__ r
         // L(lane): first index m > lane of this chunk with t_m >= t_exit (64 = beyond the chunk); t is increasing
         int L = 64;
         if (valid && !occ) {
-            int lo = lane + 1, hi = 64;  // first m in [lo, hi) with t_m >= t_exit, else hi
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (tl[mid] >= t_exit) hi = mid; else lo = mid + 1;
+            // first m in (lane, 64) with t_m >= t_exit, else 64.  With a constant step that is lane + ceil((t_exit - t_lane) / dt) up to
+            // rounding: start there and step to the exact index with the chunk's actual values (two LDS reads in flight instead of the six
+            // dependent rounds of a binary search)
+            const float q = kConstDt ? (t_exit - tj) / dt : -1.0f;
+            if (kConstDt && q >= 0.0f && q < 1.0e6f) {
+                int m = lane + max(1, (int)ceilf(q));
+                m = m > 64 ? 64 : m;
+                for (;;) {
+                    const float a = m > lane + 1 ? tl[m - 1] : -FLT_MAX, b = m < 64 ? tl[m] : FLT_MAX;
+                    if (a >= t_exit) { --m; continue; }
+                    if (b < t_exit) { ++m; continue; }
+                    break;
+                }
+                L = m;
+            } else {
+                int lo = lane + 1, hi = 64;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (tl[mid] >= t_exit) hi = mid; else lo = mid + 1;
+                }
+                L = lo;
             }
-            L = lo;
         }
         // ---- chains of empty cells collapsed in parallel.  The chase below used to visit every empty cell on its own (one trip of ~30 dependent
         // scalar instructions per cell, ~14 cells per chunk in empty space: 22 of the 34 us a ray's walk takes, profiles/r02_march_pipelined_experiment.txt).
