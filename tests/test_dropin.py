@@ -30,6 +30,28 @@ m = nerf.network_wtmk_tcnn.NeRFNetwork(bound=1.0, cuda_ray=True, density_scale=1
 import torch
 opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
 assert len(opt.param_groups) == 2
+# main_nerf_wtmk.py:110-119: the reference's OWN Trainer around this repo's model (no render on the CPU: construction, its parameter
+# count, its save_checkpoint / load_checkpoint code on our state_dict, and a fresh model resumed from that file by the reference's code)
+import argparse, os, tempfile
+ws = tempfile.mkdtemp()
+o = argparse.Namespace(lambda_w=1.0, lambda_i=1.0, distortion="none", loss_w="bce", patch_size=1, rand_pose=-1, error_map=False, color_space="srgb")
+optimizer = lambda model: torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+tr = u.Trainer("ngp", o, m, optimizer=optimizer, device=torch.device("cpu"), workspace=ws, fp16=False, use_checkpoint="scratch", use_tensorboardX=False,
+               message_dim=32, n_views=1, metrics=[u.PSNRMeter()], metrics_message=[u.BIT_ACC(device="cpu")], mute=True)
+assert tr.model is m and isinstance(tr.optimizer, torch.optim.Adam)
+with torch.no_grad():
+    m.msg_encoder.embeddings[5].weight.uniform_(-1, 1)
+    m.density_bitfield.fill_(9)
+tr.epoch, tr.global_step = 3, 77
+tr.save_checkpoint(full=True, best=False)
+files = sorted(os.listdir(os.path.join(ws, "checkpoints")))
+assert files == ["ngp_ep0003.pth"], files
+m2 = nerf.network_wtmk_tcnn.NeRFNetwork(bound=1.0, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1, message_dim=32, n_views=1)
+tr2 = u.Trainer("ngp", o, m2, optimizer=optimizer, device=torch.device("cpu"), workspace=ws, fp16=False, use_checkpoint="latest", use_tensorboardX=False,
+                message_dim=32, n_views=1, mute=True)
+assert tr2.epoch == 3 and tr2.global_step == 77
+for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+    assert k1 == k2 and torch.equal(v1, v2), k1
 print("DROPIN_OK")
 '''
 
