@@ -667,7 +667,15 @@ class GraphedWatermarkLoop:
         """One host read: if the last replay produced more points than the buffers hold (its overflowing rays were dropped, like the
         reference's bounded mode), re-size from the current rays with `growth` times the headroom and capture again.  Returns True when
         it re-captured.  Callers that draw new rays every step call this now and then, outside their timed region."""
-        if self.graphs is None or not self.overflowed():
+        if self.graphs is None:
+            return False
+        over = bool(self.overflowed())
+        if exchange_active():       # re-capturing runs warm-up steps with collectives in them: every rank or none
+            import torch.distributed as dist
+            flag = torch.tensor([1.0 if over else 0.0], device=self.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            over = bool(flag.item() > 0)
+        if not over:
             return False
         self.headroom = (1.0 + self.headroom) * growth - 1.0
         self.content_headroom = (1.0 + self.content_headroom) * growth - 1.0
