@@ -1,0 +1,93 @@
+"""Edge cases of the path through the public surface and the C ABI: empty and ragged inputs, rays that miss everything, sample caps,
+one-ray batches, an empty alive list.  (The reference has no tests; these pin the behaviours its kernels and wrappers imply:
+raymarching.cu:121-124,416,521-528, raymarching.py:196-233.)"""
+import numpy as np
+import pytest
+import torch
+
+import closed_form as cf
+from oracle import raymarch_ref as orm
+from test_gpu_render import _model
+
+pytestmark = pytest.mark.gpu
+KW = dict(staged=False, bg_color=1, perturb=False, force_all_rays=True, dt_gamma=0, max_steps=1024)
+
+
+def test_rays_that_miss_the_box_render_background_and_carry_no_gradient():
+    m, _, _ = _model()
+    msg = torch.from_numpy(cf.messages(32)[2])
+    o = torch.tensor([[[5.0, 5.0, 5.0], [0.0, 3.0, 0.0], [4.0, 0.0, 0.0]]], device="cuda")
+    d = torch.nn.functional.normalize(torch.tensor([[[1.0, 0.2, 0.1], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]], device="cuda"), dim=-1)
+    out = m.render(o, d, msg, **KW)
+    assert out["image"].shape == (1, 3, 3) and torch.equal(out["image"], torch.ones_like(out["image"]))      # only the background
+    assert torch.equal(out["weights_sum"], torch.zeros(3, device="cuda")) and bool(torch.isnan(out["depth"]).all())   # (FLT_MAX - FLT_MAX) / ..., as in the reference
+    assert int(m.step_counter[0, 0]) == 0 and int(m.step_counter[0, 1]) == 3
+    out["image"].sum().backward()
+    assert all(e.weight.grad is None or not bool(e.weight.grad.any()) for e in m.msg_encoder.embeddings)
+
+
+@pytest.mark.parametrize("n", [1, 63, 65, 129])
+def test_ragged_ray_counts_match_the_oracle(n):
+    from nerf_signature_amd import raymarching as rm
+    _, bitfield, C = cf.ball_scene(bound=1.0)
+    pose, intr, inds = cf.orbit_rays(n, seed=11)
+    from oracle import field_ref as fr
+    o, d = fr.get_rays(torch.from_numpy(pose)[None], intr, 400, 400, torch.from_numpy(np.minimum(inds, 80200 + np.arange(n)))[None])   # pixels near the centre: hits
+    o, d = o[0].contiguous().numpy(), d[0].contiguous().numpy()
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    nears, fars = orm.near_far_from_aabb(o, d, aabb, 0.2)
+    x0, _, dl0, rays0 = orm.march_rays_train(o, d, 1.0, bitfield, C, 128, nears, fars, None, -1, False, 128, True, 0.0, 1024)
+    c = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    x1, _, dl1, rays1 = rm.march_rays_train(c(o), c(d), 1.0, c(bitfield), C, 128, c(nears), c(fars), None, -1, False, 128, True, 0.0, 1024)
+    np.testing.assert_array_equal(rays1.cpu().numpy(), rays0)
+    np.testing.assert_array_equal(x1.cpu().numpy(), x0)
+    np.testing.assert_array_equal(dl1.cpu().numpy(), dl0)
+    assert x1.shape[0] % 128 == 0 and x1.shape[0] > int(rays0[:, 2].sum())          # `m += 128 - m % 128` always adds (raymarching.py:225-226)
+
+
+def test_sample_cap_and_fully_occupied_grid():
+    """Every cell occupied: each ray takes exactly min(max_steps, steps across the box) samples; the cap is raymarching.cu:359."""
+    from nerf_signature_amd import raymarching as rm
+    bitfield = np.full(128 ** 3 // 8, 255, np.uint8)
+    pose, intr, inds = cf.orbit_rays(200, seed=2)
+    from oracle import field_ref as fr
+    o, d = fr.get_rays(torch.from_numpy(pose)[None], intr, 400, 400, torch.from_numpy(inds)[None])
+    o, d = o[0].contiguous().numpy(), d[0].contiguous().numpy()
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    nears, fars = orm.near_far_from_aabb(o, d, aabb, 0.2)
+    c = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for max_steps in (1024, 128, 7):
+        _, _, _, rays0 = orm.march_rays_train(o, d, 1.0, bitfield, 1, 128, nears, fars, None, -1, False, 128, True, 0.0, max_steps)
+        _, _, _, rays1 = rm.march_rays_train(c(o), c(d), 1.0, c(bitfield), 1, 128, c(nears), c(fars), None, -1, False, 128, True, 0.0, max_steps)
+        np.testing.assert_array_equal(rays1.cpu().numpy(), rays0)
+        hit = fars < 1e30
+        # step = clamp(0, dt_min, dt_max) with dt_min = 2*sqrt(3)/max_steps, dt_max = 2*sqrt(3)*2^(C-1)/H (raymarching.cu:345-346,365): the
+        # longest chord takes span/step samples (+-1) unless the cap cuts it, which with these rays only max_steps = 7 does
+        step = min(2 * np.sqrt(3.0) / max_steps, 2 * np.sqrt(3.0) / 128)
+        longest = float((fars - nears)[hit].max()) / step
+        n_max = int(rays0[hit, 2].max())
+        assert n_max <= max_steps and abs(n_max - min(max_steps, longest + 0.5)) <= 1.0
+    assert n_max == 7
+
+
+def test_empty_inputs_through_the_functional_layer():
+    from nerf_signature_amd import fieldops as fo
+    from nerf_signature_amd import raymarching as rm
+    m, _, _ = _model()
+    base = m.encoder.tables()
+    packed = m._packed()
+    empty3 = torch.empty(0, 3, device="cuda")
+    sig, rgb, _, _ = fo.field_forward(empty3, empty3, 1.0, base, None, packed)
+    assert sig.shape == (0,) and rgb.shape == (0, 3)
+    assert fo.encode(empty3, base).shape == (0, 32)
+    out, n_out = rm.compact_alive(torch.full((5,), -1, dtype=torch.int32, device="cuda"))
+    assert int(n_out) == 0
+    out, n_out = rm.compact_alive(torch.tensor([3, -1, 0, -1, 9], dtype=torch.int32, device="cuda"))
+    assert int(n_out) == 3 and out[:3].tolist() == [3, 0, 9]
+    # an eval-mode render whose rays all die in the first round
+    m.eval()
+    o = torch.tensor([[[5.0, 5.0, 5.0]]], device="cuda")
+    d = torch.tensor([[[1.0, 0.0, 0.0]]], device="cuda")
+    with torch.no_grad():
+        out = m.render(o, d, None, staged=False, bg_color=1, perturb=False, dt_gamma=0, max_steps=1024)
+    assert torch.equal(out["image"], torch.ones(1, 1, 3, device="cuda"))
