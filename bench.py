@@ -53,13 +53,15 @@ def parse_args():
     ap.add_argument("--no-overlap", action="store_true", help="issue the content render on the main stream instead of overlapping it with the block render / decoder")
     ap.add_argument("--no-fused-adam", action="store_true", help="torch's multi-tensor instead of its fused Adam kernel for the decoder parameters")
     ap.add_argument("--no-graph", action="store_true", help="run the loop body eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--fixed-blocks", action="store_true", help="march the (per-dataset constant) watermark-block rays once and keep their base-level feature planes and "
+                                                                   "scatter plan; a step gathers only the codebook level for them (GraphedWatermarkLoop(fixed_blocks=True))")
     ap.add_argument("--fixed-rays", action="store_true", help="replay one ray set every step (round-1 behaviour; diagnostics)")
     ap.add_argument("--host-rays", action="store_true", help="hand every step's rays over from the host loop (randint + rg_get_rays + gather + copies between replays) "
                                                                 "instead of drawing them inside the captured step (rg_sample_rays)")
     return ap.parse_args()
 
 
-def _run_ranks(args, n, extra_env, timeout_s, capture_stdout):
+def _run_ranks(args, n, extra_env, timeout_s, capture_stdout, extra_argv=()):
     """Start n rank processes, wait for them; returns (return code, rank 0's stdout or None).  A rank that dies takes the others down (they
     would wait in a collective for ever); a run that outlasts `timeout_s` is killed the same way -- by the exact PIDs started here."""
     with socket.socket() as s:
@@ -70,7 +72,7 @@ def _run_ranks(args, n, extra_env, timeout_s, capture_stdout):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **extra_env)
         out = subprocess.PIPE if (capture_stdout and r == 0) else None
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out, text=bool(out)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + list(extra_argv), env=env, stdout=out, text=bool(out)))
     rc, t0, text = 0, time.time(), None
     try:
         pending = list(procs)
@@ -105,11 +107,16 @@ def launch_ranks(args):
     environment), wait, exit with the worst return code.  Decided before anything touches the GPU; children are new processes, never
     an exec of one that initialised the device.  Rank 0's stdout carries the one JSON line.
 
-    Execution mode of the captured step for N > 1: the RCCL collectives run BETWEEN captured segments.
-    NERFSIG_CAPTURE_COLLECTIVES=try makes the launcher first start the ranks with the collectives captured INSIDE the step's hipGraph (one
-    graph per step: 1.112 against 1.197 ms on a world-size-1 nccl group, profiles/r02_capture_collectives_world1.txt) under a watchdog and
-    fall back to segments if that run fails or outlasts it -- opt-in, because one of four rehearsals died in ProcessGroupNCCL's watchdog
-    thread (an event query racing the capture).  NERFSIG_CAPTURE_COLLECTIVES=0|1 pins the mode (no second attempt)."""
+    A chain of attempts, each a fresh set of ranks under a watchdog; only the first one that ends well reaches stdout and the line says
+    which it was (`config.launch_attempt`).  A multi-rank run that dies or hangs would otherwise leave no scaling point at all, and
+    the modes further down the chain give up speed, not correctness:
+      0. (only with NERFSIG_CAPTURE_COLLECTIVES=try) the RCCL collectives captured INSIDE the step's hipGraph (one graph per step:
+         1.112 against 1.197 ms on a world-size-1 nccl group, profiles/r02_capture_collectives_world1.txt) -- opt-in, because one of
+         four rehearsals died in ProcessGroupNCCL's watchdog thread (an event query racing the capture);
+      1. the default: collectives BETWEEN captured segments, blocks sharded, codebook optimiser sharded from four ranks (DESIGN.md 7);
+      2. the same with the codebook optimiser replicated (NERFSIG_SHARD_OPTIMIZER=0: one collective less per step);
+      3. blocks replicated too (NERFSIG_REPLICATE_BLOCKS=1: round 1's partitioning, one all-reduce per step), eager launches (--no-graph).
+    NERFSIG_CAPTURE_COLLECTIVES=0|1 or NERFSIG_LAUNCH_FALLBACK=0 pin the first attempt's mode (no second attempt)."""
     n = args.gpus
     backend = os.environ.get("NERFSIG_DIST_BACKEND", "")
     if not args.dry_launch and backend != "gloo":
@@ -118,14 +125,29 @@ def launch_ranks(args):
             raise SystemExit(f"--gpus {n} but {have} GPU(s) visible (NERFSIG_DIST_BACKEND=gloo rehearses N ranks on fewer GPUs)")
     pinned = os.environ.get("NERFSIG_CAPTURE_COLLECTIVES")
     test_hook = os.environ.get("NERFSIG_TEST_FAIL_CAPTURED") == "1"      # (tests: the first attempt's ranks exit with code 3)
-    if (pinned != "try" and not test_hook) or args.no_graph or ((args.dry_launch or backend == "gloo") and not test_hook):
+    rehearsal = args.dry_launch or backend == "gloo"
+    watchdog = float(os.environ.get("NERFSIG_LAUNCH_WATCHDOG_S", "300"))
+    if ((pinned in ("0", "1") or os.environ.get("NERFSIG_LAUNCH_FALLBACK") == "0" or args.no_graph or rehearsal) and not test_hook):
         rc, _ = _run_ranks(args, n, {}, None, capture_stdout=False)
         raise SystemExit(rc)
-    rc, text = _run_ranks(args, n, {"NERFSIG_CAPTURE_COLLECTIVES": "1"}, float(os.environ.get("NERFSIG_LAUNCH_WATCHDOG_S", "240")), capture_stdout=True)
-    if rc != 0 or not text or "{" not in text:
-        print(f"[bench] the run with captured collectives ended with code {rc}; starting the ranks again with the collectives between segments", file=sys.stderr)
-        rc, text = _run_ranks(args, n, {"NERFSIG_CAPTURE_COLLECTIVES": "0"}, None, capture_stdout=True)
-    if text:
+    attempts = []
+    if pinned == "try" or test_hook:
+        attempts.append(("collectives captured inside the step's graph", {"NERFSIG_CAPTURE_COLLECTIVES": "1"}, []))
+    attempts.append(("default", {"NERFSIG_CAPTURE_COLLECTIVES": "0"}, []))
+    if not rehearsal:
+        attempts.append(("codebook optimiser replicated", {"NERFSIG_CAPTURE_COLLECTIVES": "0", "NERFSIG_SHARD_OPTIMIZER": "0"}, []))
+        attempts.append(("blocks and optimiser replicated, eager launches", {"NERFSIG_CAPTURE_COLLECTIVES": "0", "NERFSIG_SHARD_OPTIMIZER": "0",
+                                                                            "NERFSIG_REPLICATE_BLOCKS": "1"}, ["--no-graph"]))
+    rc, text = 1, None
+    for k, (name, env, extra) in enumerate(attempts):
+        last = k == len(attempts) - 1
+        env = dict(env, NERFSIG_LAUNCH_ATTEMPT=f"{k}: {name}")
+        rc, text = _run_ranks(args, n, env, None if last else watchdog, capture_stdout=True, extra_argv=extra)
+        if rc == 0 and text and "{" in text:
+            break
+        if not last:
+            print(f"[bench] attempt {k} ({name}) ended with code {rc}; starting the ranks again: {attempts[k + 1][0]}", file=sys.stderr)
+    if text and rc == 0:
         sys.stdout.write(text)
         sys.stdout.flush()
     raise SystemExit(rc)
@@ -171,7 +193,7 @@ class NativeTimer:
     """HIP-event timing of selected libnerfsig entry points, on the stream the kernels are launched on (torch's current
     stream).  Installed over nerf_signature_amd._native.call; each timed call records (duration, points)."""
 
-    POINTS_ARG = {"hg_encode_planes": 1, "field_fwd": 2, "field_bwd": 1, "field_bwd_planned": 1, "hg_scatter_sliced": 1, "hg_scatter_binned": 1,
+    POINTS_ARG = {"hg_encode_planes": 1, "hg_encode_codebook_plane": 1, "field_fwd": 2, "field_bwd": 1, "field_bwd_planned": 1, "hg_scatter_sliced": 1, "hg_scatter_binned": 1,
                   "hg_scatter_planned": 1, "hg_scatter_plan": 1}
 
     def __init__(self, nv):
@@ -316,7 +338,8 @@ def bench_training(args, scene, real_stdout):
     if args.no_graph:
         loop = trainer.WatermarkLoop(model, optimizer, render_kwargs, side_stream=None if args.no_overlap else torch.cuda.Stream())
     else:
-        loop = trainer.GraphedWatermarkLoop(model, optimizer, render_kwargs, data, overlap_content=not args.no_overlap, content_headroom=0.25, content_sampler=sampler)
+        loop = trainer.GraphedWatermarkLoop(model, optimizer, render_kwargs, data, overlap_content=not args.no_overlap, content_headroom=0.25, content_sampler=sampler,
+                                            fixed_blocks=True if args.fixed_blocks else None)
 
     timer = NativeTimer(nv)
     msg_rng = np.random.RandomState(1234)   # same stream on every rank: the message is replicated
@@ -324,9 +347,12 @@ def bench_training(args, scene, real_stdout):
     upcoming = [draw()]
     counter = [0]
 
+    running = [loop]        # (the loop one_step drives: the headline loop, later the fixed-blocks variant)
+
     def one_step():
         # the captured loop is told the next step's message one step early (the same sequence of draws, looked ahead by one):
         # its optimiser kernel then leaves that message's pre-summed codebook behind (GraphedWatermarkLoop, presum_in_adam)
+        loop = running[0]
         msg = upcoming.pop()
         upcoming.append(draw())
         counter[0] += 1
@@ -379,14 +405,47 @@ def bench_training(args, scene, real_stdout):
             n_block, n_content = n_content, n_block
     else:
         n_block, n_content = loop.point_counts()
+
+    # ---- secondary figure, same process, same model: the step with the watermark-block rays declared constant (they are one pair of
+    # tensors per dataset, nerf/provider_wtmk.py:442-494): marched once, base-level planes and scatter plan kept, only the codebook level
+    # gathered per step (GraphedWatermarkLoop(fixed_blocks=True); bit-identical renders, tests/test_gpu_fixed.py).  NOT the headline:
+    # `value` above is the step that recomputes everything every step, like the reference.
+    variant = None
+    if world == 1 and scene == "hotdog" and not (args.no_graph or args.fixed_blocks or args.fixed_rays or args.host_rays) and os.environ.get("NERFSIG_BENCH_VARIANT", "1") != "0":
+        try:
+            loop.close()
+            loop2 = trainer.GraphedWatermarkLoop(model, optimizer, render_kwargs, data, overlap_content=not args.no_overlap, content_headroom=0.25, content_sampler=sampler,
+                                                 fixed_blocks=True)
+            running[0] = loop2
+            for _ in range(max(args.warmup, 2)):
+                one_step()
+            loop2.ensure_capacity()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                out2 = one_step()
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - t1
+            variant = {"what": "watermark-block rays declared constant (one pair of tensors per dataset, provider_wtmk.py:442-494): samples marched once, their 16 base-level "
+                               "feature planes and scatter plan kept, per step only the codebook level is gathered for them; MLPs, compositing, decoder, backward, scatter and "
+                               "optimiser run every step; renders bit-identical to the recomputing step (tests/test_gpu_fixed.py); opt-in: GraphedWatermarkLoop(fixed_blocks=True), "
+                               "NERFSIG_FIXED_BLOCKS=1, bench.py --fixed-blocks",
+                       "ms_per_step": el2 / args.steps * 1e3, "content_rays_per_s": args.rays * args.steps / el2, "steps": args.steps,
+                       "loss": float(out2[5].detach()), "capacity_overflow": bool(loop2.overflowed())}
+        except Exception as e:      # a secondary figure must not take the headline down
+            variant = {"error": repr(e)}
     sharded = bool(getattr(loop, "sharded", False)) or (args.no_graph and dp.block_shard(bo.shape[0]) is not None)
     rays_block_all = bo.shape[0] * bo.shape[1] * bo.shape[2]
     rays_block_rank = rays_block_all // world if sharded else rays_block_all
     rays_content = args.rays
     # the dominant kernel: the hash-gather encoder, on the launch with the most points (N = 1: the block render)
     big = max(n_block, n_content) // 2
-    enc_s, enc_n, enc_rows = timer.stats("hg_encode_planes", big)
-    mlp_s, _, _ = timer.stats("field_fwd", big)
+    enc_big = big
+    enc_s, enc_n, enc_rows = timer.stats("hg_encode_planes", enc_big)
+    if enc_n == 0:      # --fixed-blocks: the block render no longer runs the 17-level encoder per step; the content render's launch is the largest left
+        enc_big = 0
+        enc_s, enc_n, enc_rows = timer.stats("hg_encode_planes", enc_big)
+    mlp_s, _, mlp_rows = timer.stats("field_fwd", big)
     bwd_s, _, _ = timer.stats("field_bwd_planned", big)          # the block render goes through the planned binned route
     sct_s, _, _ = timer.stats("hg_scatter_planned", big)
     plan_s, _, _ = timer.stats("hg_scatter_plan", big)           # (beside the forward pass: not on the critical path)
@@ -395,7 +454,7 @@ def bench_training(args, scene, real_stdout):
         sct_s, _, _ = timer.stats("hg_scatter_binned", big)
         if sct_s == 0.0:
             sct_s, _, _ = timer.stats("hg_scatter_sliced", big)
-    pts_big = float(max(n_block, n_content))
+    pts_big = float(max(n_block, n_content)) if enc_big else float(n_content)
     pts_step = float(n_block + n_content)
     ms = elapsed / args.steps * 1e3
 
@@ -444,9 +503,12 @@ def bench_training(args, scene, real_stdout):
             "collectives_per_step": (loop.exchange.collectives_per_step + (1 if sharded else 0) + (1 if getattr(loop, "opt_shard", None) else 0)) if dp.exchange_active() else 0,
             "codebook_optimizer": ("sharded over the ranks (each updates the tables of D/R bits, partial pre-sums all-reduced)" if getattr(loop, "opt_shard", None) else "replicated"),
             "world_size_seen_by_backend": dp.world_size(), "backend": dist.get_backend() if dist.is_initialized() else None,
+            "launch_attempt": os.environ.get("NERFSIG_LAUNCH_ATTEMPT", "n/a (single process or external launcher)"),
             "execution": "eager" if args.no_graph else f"hipGraph replay, {len(loop.segments)} captured segment(s)" + (" with the RCCL collectives between them" if len(loop.segments) > 1 else
                                                                   (" with the RCCL collectives captured inside" if dp.exchange_active() else "")),
             "capacity_overflow": overflow, "recaptured_with_more_headroom_after_warmup": recaptured,
+            "block_rays_policy": "declared constant: marched once, base-level planes + scatter plan kept (--fixed-blocks)" if getattr(loop, "fixed_blocks", False) else
+                                 "recomputed every step (march, 17-level gather, scatter plan), like the reference",
             "loss": loss_value, "loss_image": loss_parts[0], "loss_watermark": loss_parts[1],
         },
         "roofline": {
@@ -469,18 +531,20 @@ def bench_training(args, scene, real_stdout):
         },
     }
     # the MLP kernel against the matrix-core roof (north_star: "MFMA utilisation on the MLP against chip peak").
-    rows = float(enc_rows) if enc_rows else pts_big
+    rows = float(mlp_rows) if mlp_rows else pts_big
     mfma_per_wave, kind = nv.mlp_mfma_per_wave()
     issued_flop = rows / 32.0 * mfma_per_wave * 32768
     line["roofline_mlp"] = {
         "kernel": f"k_field_fwd<planes> (sigma MLP + SH + colour MLP, {nv.mlp_precision_name()}) on the same launch",
         "bound": "mfma", "achieved": (issued_flop / mlp_s / 1e12) if mlp_s > 0 else 0.0, "peak": MFMA_PEAK[kind] / 1e12, "unit": "TFLOP/s",
         "frac": (issued_flop / mlp_s / MFMA_PEAK[kind]) if mlp_s > 0 else 0.0, "avg_launch_s": mlp_s,
-        "algorithmic_TFLOPs": (pts_big * 20480 / mlp_s / 1e12) if mlp_s > 0 else 0.0,
-        "frac_algorithmic": (pts_big * 20480 / mlp_s / MFMA_PEAK[kind]) if mlp_s > 0 else 0.0,
+        "algorithmic_TFLOPs": (float(max(n_block, n_content)) * 20480 / mlp_s / 1e12) if mlp_s > 0 else 0.0,
+        "frac_algorithmic": (float(max(n_block, n_content)) * 20480 / mlp_s / MFMA_PEAK[kind]) if mlp_s > 0 else 0.0,
         "mfma_per_32_points": mfma_per_wave,
         "note": "achieved = issued MFMA FLOP/s (v_mfma_f32_32x32x16: 32768 FLOP each); algorithmic = 20 480 FLOP per point (SURVEY.md 8(d))",
     }
+    if variant is not None:
+        line["config"]["fixed_blocks_variant"] = variant
     if world == 1 and not args.no_cpu_baseline and scene == "hotdog":
         line["cpu_baseline"] = cpu_baseline(model, D)
     emit(line, real_stdout)

@@ -253,6 +253,16 @@ size_t hg_planes_bytes(uint32_t M);
 int hg_encode_planes(const float *xyzs, uint32_t M, float bound, const float *const *base_tables_host, const float *S,
                      void *planes, nsig_stream_t stream);
 
+/* Rays that do not change between training steps (the watermark blocks: nerf/provider_wtmk.py:442-494 computes
+ * rays_o_block / rays_d_block once per dataset and hands the same tensors to every train_step, utils_wtmk_disen.py:588-590;
+ * the occupancy grid, the base tables and both MLPs are frozen in the watermark stage, network_wtmk_tcnn.py:90-95) keep their
+ * samples and the 16 base-level planes (hg_encode_planes with S = NULL, once); per step only the codebook level -- the one
+ * thing a step changes -- is gathered again, into plane 16 of the same plane set.  Same interpolation code, bit-identical planes.
+ * plan_to_reset: NULL, or a scatter plan (hg_scatter_plan) kept across steps for the same points: its per-launch largest-gradient
+ * word is cleared here, ahead of the step's field_bwd_planned. */
+int hg_encode_codebook_plane(const float *xyzs, uint32_t M, float bound, const float *S, void *planes, void *plan_to_reset,
+                             nsig_stream_t stream);
+
 /* NeRFNetwork.color (nerf/network_wtmk_tcnn.py:147-176) without the mask: rgb from dirs + geo_feat. */
 int field_color_fwd(const float *dirs, const float *geo_feat, uint32_t M, const void *packed, float *rgbs,
                     nsig_stream_t stream);

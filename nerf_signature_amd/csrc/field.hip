@@ -419,6 +419,22 @@ __global__ void __launch_bounds__(256) k_encode_planes(const float *__restrict__
     }
 }
 
+// The codebook level alone, into plane 16 of a plane set whose base planes are already there (hg_encode_codebook_plane: rays that
+// do not change between steps).  One tile per workgroup, all XCDs: S (4 MiB) is the only table, every L2 holds its own copy.
+// reset: the header of a scatter plan kept across steps -- its largest-gradient word starts every step at zero (k_plan_dest does
+// that for a plan computed per step).
+__global__ void __launch_bounds__(256) k_encode_codebook_plane(const float *__restrict__ xyzs, uint32_t M, float bound, float cell, const float *__restrict__ S,
+                                                               float2 *__restrict__ plane, uint32_t stride, BinHeader *__restrict__ reset) {
+    if (reset != nullptr && blockIdx.x == 0 && threadIdx.x == 0) reset->gmax_bits = 0;
+    const uint32_t m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= stride) return;                // stride is a multiple of 32: lane pairs (and DPP quads) are in or out together
+    const uint32_t ml = min(m, M - 1);
+    const float two_b = 2.0f * bound;
+    const float3 pt = *reinterpret_cast<const float3 *>(xyzs + 3 * (size_t)ml);
+    const float x = (pt.x + bound) / two_b, y = (pt.y + bound) / two_b, z = (pt.z + bound) / two_b;
+    encode_tile_level(reinterpret_cast<const float2 *>(S), cell, false, threadIdx.x & 1u, x, y, z, plane + m);
+}
+
 // kPlanes = false: gather the features in-kernel (fused); true: read them from the level-major planes.
 template <typename P, bool kPlanes, bool kTrace = false>
 __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyzs, const float *__restrict__ dirs, uint32_t M, float bound,
@@ -814,12 +830,12 @@ NSIG_EXPORT size_t hg_planes_bytes(uint32_t M) { return (size_t)(NSIG_BASE_LEVEL
 
 NSIG_EXPORT int hg_encode_planes(const float *xyzs, uint32_t M, float bound, const float *const *base_tables_host, const float *S, void *planes,
                                  nsig_stream_t stream) {
+    if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(xyzs && planes, "hg_encode_planes: null pointer");
     NSIG_REQUIRE(bound > 0.0f, "hg_encode_planes: bound must be positive");
     NSIG_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 7) == 0, "hg_encode_planes: planes must be 8-byte aligned");
     TablePtrs base{};
     if (int e = fill_base_tables(base_tables_host, base, "hg_encode_planes")) return e;
-    if (M == 0) return NSIG_OK;
     const uint32_t stride = ceil_div(M, 32u) * 32u;
     const SlotTable tab = default_slots(S != nullptr);
     int covered[NSIG_BASE_LEVELS + 1] = {};     // 4096ths of the tile range assigned, per level
@@ -837,16 +853,30 @@ NSIG_EXPORT int hg_encode_planes(const float *xyzs, uint32_t M, float bound, con
     return check_launch("hg_encode_planes");
 }
 
+NSIG_EXPORT int hg_encode_codebook_plane(const float *xyzs, uint32_t M, float bound, const float *S, void *planes, void *plan_to_reset,
+                                         nsig_stream_t stream) {
+    if (M == 0) return NSIG_OK;
+    NSIG_REQUIRE(xyzs && S && planes, "hg_encode_codebook_plane: null pointer");
+    NSIG_REQUIRE(bound > 0.0f, "hg_encode_codebook_plane: bound must be positive");
+    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 7) == 0, "hg_encode_codebook_plane: planes must be 8-byte aligned");
+    NSIG_REQUIRE(plan_to_reset == nullptr || (reinterpret_cast<uintptr_t>(plan_to_reset) & 15) == 0, "hg_encode_codebook_plane: plan must be 16-byte aligned");
+    const uint32_t stride = ceil_div(M, 32u) * 32u;
+    float2 *plane = reinterpret_cast<float2 *>(planes) + (size_t)NSIG_BASE_LEVELS * stride;
+    k_encode_codebook_plane<<<ceil_div(stride, 256u), 256, 0, as_stream(stream)>>>(xyzs, M, bound, make_level_geom().cell[NSIG_BASE_LEVELS], S, plane, stride,
+                                                                                  reinterpret_cast<BinHeader *>(plan_to_reset));
+    return check_launch("hg_encode_codebook_plane");
+}
+
 NSIG_EXPORT int field_fwd(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *const *base_tables_host,
                           const float *S, const void *packed, float *sigmas, float *rgbs, float *geo_feat, uint32_t *masks,
                           const void *planes, nsig_stream_t stream) {
+    if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(xyzs && packed && sigmas, "field_fwd: null pointer");
     NSIG_REQUIRE(rgbs == nullptr || dirs != nullptr, "field_fwd: dirs is required when rgbs is requested");
     NSIG_REQUIRE(bound > 0.0f, "field_fwd: bound must be positive");
     NSIG_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0, "field_fwd: packed must be 16-byte aligned");
     TablePtrs base{};
     if (int e = fill_base_tables(base_tables_host, base, "field_fwd")) return e;
-    if (M == 0) return NSIG_OK;
     const char *pk = reinterpret_cast<const char *>(packed);
     hipStream_t st = as_stream(stream);
     const bool f16 = mlp_precision() == 1;
@@ -864,8 +894,8 @@ NSIG_EXPORT int field_fwd(const float *xyzs, const float *dirs, uint32_t M, floa
 }
 
 NSIG_EXPORT int field_color_fwd(const float *dirs, const float *geo_feat, uint32_t M, const void *packed, float *rgbs, nsig_stream_t stream) {
-    NSIG_REQUIRE(dirs && geo_feat && packed && rgbs, "field_color_fwd: null pointer");
     if (M == 0) return NSIG_OK;
+    NSIG_REQUIRE(dirs && geo_feat && packed && rgbs, "field_color_fwd: null pointer");
     if (mlp_precision() == 1) k_field_color<F16><<<field_grid(M), 256, F16::kFwdLds, as_stream(stream)>>>(dirs, geo_feat, M, reinterpret_cast<const char *>(packed), rgbs);
     else k_field_color<Bf16x3><<<field_grid(M), 256, Bf16x3::kFwdLds, as_stream(stream)>>>(dirs, geo_feat, M, reinterpret_cast<const char *>(packed), rgbs);
     return check_launch("field_color_fwd");
@@ -874,10 +904,10 @@ NSIG_EXPORT int field_color_fwd(const float *dirs, const float *geo_feat, uint32
 NSIG_EXPORT int field_bwd(const float *xyzs, uint32_t M, float bound, const float *grad_sigmas, const float *grad_rgbs, const float *sigmas,
                           const float *rgbs, const uint32_t *masks, const void *packed, float *G, float *dfeat_out, float *rec_out,
                           nsig_stream_t stream) {
+    if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(xyzs && grad_sigmas && grad_rgbs && sigmas && rgbs && masks && packed, "field_bwd: null pointer");
     NSIG_REQUIRE(G || dfeat_out || rec_out, "field_bwd: at least one of G / dfeat_out / rec_out must be given");
     NSIG_REQUIRE(bound > 0.0f, "field_bwd: bound must be positive");
-    if (M == 0) return NSIG_OK;
     if (mlp_precision() == 1)
         k_field_bwd<F16, false><<<field_grid(M), 256, F16::kBwdLds, as_stream(stream)>>>(xyzs, M, bound, 1.0f / kCodebookResolution, grad_sigmas, grad_rgbs, sigmas, rgbs, masks,
                                                                                  reinterpret_cast<const char *>(packed), G, dfeat_out, rec_out);
@@ -891,9 +921,9 @@ NSIG_EXPORT int field_bwd(const float *xyzs, uint32_t M, float bound, const floa
 // hg_scatter_planned.  (reference: the autograd backward of network_wtmk_tcnn.py:97-124 down to the index_add of hash_encoding.py)
 NSIG_EXPORT int field_bwd_planned(const float *xyzs, uint32_t M, float bound, const float *grad_sigmas, const float *grad_rgbs, const float *sigmas,
                                   const float *rgbs, const uint32_t *masks, const void *packed, void *plan, nsig_stream_t stream) {
+    if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(xyzs && grad_sigmas && grad_rgbs && sigmas && rgbs && masks && packed && plan, "field_bwd_planned: null pointer");
     NSIG_REQUIRE(bound > 0.0f && (reinterpret_cast<uintptr_t>(plan) & 15) == 0 && M < (1u << 28), "field_bwd_planned: bound must be positive, plan 16-byte aligned, M < 2^28");
-    if (M == 0) return NSIG_OK;
     if (mlp_precision() == 1)
         k_field_bwd<F16, false><<<field_grid(M), 256, F16::kBwdLds, as_stream(stream)>>>(xyzs, M, bound, 1.0f / kCodebookResolution, grad_sigmas, grad_rgbs, sigmas, rgbs, masks,
                                                                                  reinterpret_cast<const char *>(packed), nullptr, nullptr, nullptr, GradTrace{}, 0,
@@ -910,11 +940,11 @@ NSIG_EXPORT int field_bwd_planned(const float *xyzs, uint32_t M, float bound, co
 NSIG_EXPORT int field_fwd_trace(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *const *base_tables_host,
                                 const void *packed, const void *planes, float *sigmas, float *rgbs, uint32_t *masks, float *act_hs,
                                 float *act_cin, float *act_h1, float *act_h2, nsig_stream_t stream) {
+    if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(xyzs && dirs && packed && planes && sigmas && rgbs && masks && act_hs && act_cin && act_h1 && act_h2, "field_fwd_trace: null pointer");
     NSIG_REQUIRE(bound > 0.0f, "field_fwd_trace: bound must be positive");
     TablePtrs base{};
     if (int e = fill_base_tables(base_tables_host, base, "field_fwd_trace")) return e;
-    if (M == 0) return NSIG_OK;
     const uint32_t stride = ceil_div(M, 32u) * 32u;
     ActTrace tr{act_hs, act_cin, act_h1, act_h2};
     k_field_fwd<Bf16x3, true, true><<<field_grid(M), 256, Bf16x3::kFwdLds, as_stream(stream)>>>(xyzs, dirs, M, bound, base, make_level_geom(), nullptr,
@@ -926,9 +956,9 @@ NSIG_EXPORT int field_fwd_trace(const float *xyzs, const float *dirs, uint32_t M
 NSIG_EXPORT int field_bwd_trace(uint32_t M, const float *grad_sigmas, const float *grad_rgbs, const float *sigmas, const float *rgbs,
                                 const uint32_t *masks, const void *packed, float *d_hs, float *d_so, float *d_h1, float *d_h2, float *d_out,
                                 void *d_planes, nsig_stream_t stream) {
+    if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(grad_sigmas && grad_rgbs && sigmas && rgbs && masks && packed && d_hs && d_so && d_h1 && d_h2 && d_out && d_planes,
                  "field_bwd_trace: null pointer");
-    if (M == 0) return NSIG_OK;
     const uint32_t stride = ceil_div(M, 32u) * 32u;
     GradTrace gt{d_hs, d_h1, d_h2, d_so, d_out, reinterpret_cast<float2 *>(d_planes)};
     k_field_bwd<Bf16x3, true><<<field_grid(M), 256, Bf16x3::kBwdLds, as_stream(stream)>>>(nullptr, M, 1.0f, 1.0f / kCodebookResolution, grad_sigmas, grad_rgbs, sigmas,

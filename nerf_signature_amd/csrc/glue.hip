@@ -126,18 +126,18 @@ NSIG_EXPORT int loop_step_begin(float *G, uint32_t n_floats, const float *ring_d
 
 NSIG_EXPORT int rm_finish_fwd(const float *image, const float *depth, const float *weights_sum, const float *nears, const float *fars,
                               const float *bg, uint32_t bg_stride, uint32_t N, float *image_out, float *depth_out, nsig_stream_t stream) {
+    if (N == 0) return NSIG_OK;
     NSIG_REQUIRE(image && depth && weights_sum && nears && fars && bg && image_out && depth_out, "rm_finish_fwd: null pointer");
     NSIG_REQUIRE(bg_stride == 0 || bg_stride == 3, "rm_finish_fwd: bg_stride is 0 (one colour) or 3 (per ray)");
-    if (N == 0) return NSIG_OK;
     k_finish_fwd<<<ceil_div(N, 256u), 256, 0, as_stream(stream)>>>(image, depth, weights_sum, nears, fars, bg, bg_stride, N, image_out, depth_out);
     return check_launch("rm_finish_fwd");
 }
 
 NSIG_EXPORT int rm_finish_bwd(const float *grad_image, const float *grad_depth, const float *depth, const float *nears, const float *fars,
                               const float *bg, uint32_t bg_stride, uint32_t N, float *grad_weights_sum, float *grad_depth_in, nsig_stream_t stream) {
+    if (N == 0) return NSIG_OK;
     NSIG_REQUIRE(depth && nears && fars && bg && grad_weights_sum, "rm_finish_bwd: null pointer");
     NSIG_REQUIRE(bg_stride == 0 || bg_stride == 3, "rm_finish_bwd: bg_stride is 0 (one colour) or 3 (per ray)");
-    if (N == 0) return NSIG_OK;
     k_finish_bwd<<<ceil_div(N, 256u), 256, 0, as_stream(stream)>>>(grad_image, grad_depth, depth, nears, fars, bg, bg_stride, N, grad_weights_sum, grad_depth_in);
     return check_launch("rm_finish_bwd");
 }

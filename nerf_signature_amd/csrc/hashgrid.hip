@@ -712,10 +712,10 @@ static int fill_base(const float *const *host, TablePtrs &base, const char *who)
 
 NSIG_EXPORT int hg_encode_fwd(const float *x01, uint32_t M, const float *const *base_tables_host, const float *S, float *feat,
                               nsig_stream_t stream) {
+    if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(x01 && feat, "hg_encode_fwd: null pointer");
     TablePtrs base{};
     if (int e = fill_base(base_tables_host, base, "hg_encode_fwd")) return e;
-    if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(M <= (1u << 27), "hg_encode_fwd: M=%u too large", M);
     k_encode<<<ceil_div(M * 16u, 256), 256, 0, as_stream(stream)>>>(x01, M, base, make_level_geom(), S, feat);
     return check_launch("hg_encode_fwd");
@@ -723,6 +723,7 @@ NSIG_EXPORT int hg_encode_fwd(const float *x01, uint32_t M, const float *const *
 
 NSIG_EXPORT int hg_codebook_encode_fwd(const float *x01, uint32_t M, const float *const *tables_host, uint32_t D, float *out,
                                        nsig_stream_t stream) {
+    if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(x01 && tables_host && out, "hg_codebook_encode_fwd: null pointer");
     NSIG_REQUIRE(D >= 1 && D <= NSIG_MAX_MESSAGE_DIM, "hg_codebook_encode_fwd: D=%u out of range", D);
     CodebookPtrs tabs{};
@@ -730,14 +731,13 @@ NSIG_EXPORT int hg_codebook_encode_fwd(const float *x01, uint32_t M, const float
         NSIG_REQUIRE(tables_host[i] != nullptr, "hg_codebook_encode_fwd: table %u is null", i);
         tabs.p[i] = tables_host[i];
     }
-    if (M == 0) return NSIG_OK;
     k_codebook_encode<<<ceil_div(M, 256), 256, 0, as_stream(stream)>>>(x01, M, tabs, D, 1.0f / kCodebookResolution, out);
     return check_launch("hg_codebook_encode_fwd");
 }
 
 NSIG_EXPORT int hg_codebook_bwd(const float *x01, uint32_t M, const float *dfeat, float *G, nsig_stream_t stream) {
-    NSIG_REQUIRE(x01 && dfeat && G, "hg_codebook_bwd: null pointer");
     if (M == 0) return NSIG_OK;
+    NSIG_REQUIRE(x01 && dfeat && G, "hg_codebook_bwd: null pointer");
     NSIG_REQUIRE(M <= (1u << 27), "hg_codebook_bwd: M=%u too large", M);
     k_codebook_bwd<<<ceil_div(M * 16u, 256), 256, 0, as_stream(stream)>>>(x01, M, dfeat, 1.0f / kCodebookResolution, G);
     return check_launch("hg_codebook_bwd");
@@ -757,9 +757,9 @@ NSIG_EXPORT int hg_fanout_grad(const float *G, float *const *grads_host, uint32_
 }
 
 NSIG_EXPORT int hg_level_lookup(const float *x01, uint32_t M, float resolution, int32_t *rows, float *weights, nsig_stream_t stream) {
+    if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(x01 && rows && weights, "hg_level_lookup: null pointer");
     NSIG_REQUIRE(resolution >= 1.0f, "hg_level_lookup: resolution must be >= 1");
-    if (M == 0) return NSIG_OK;
     k_level_lookup<<<ceil_div(M, 256), 256, 0, as_stream(stream)>>>(x01, M, 1.0f / resolution, rows, weights);
     return check_launch("hg_level_lookup");
 }
@@ -782,8 +782,8 @@ NSIG_EXPORT int opt_codebook_adam(const float *G, float *const *params_host, flo
 }
 
 NSIG_EXPORT int hg_scatter_sliced(const float *rec, uint32_t M, float *G, nsig_stream_t stream) {
-    NSIG_REQUIRE(rec && G, "hg_scatter_sliced: null pointer");
     if (M == 0) return NSIG_OK;
+    NSIG_REQUIRE(rec && G, "hg_scatter_sliced: null pointer");
     static bool attr_set = false;
     const size_t lds = (size_t)kSliceRows * 2 * sizeof(float);
     if (!attr_set) {
@@ -966,10 +966,10 @@ static int launch_binned(const float *rec, uint32_t M, uint32_t sets, const Scat
 NSIG_EXPORT size_t hg_scatter_binned_scratch_bytes(uint32_t M) { return binned_scratch_bytes(M, 1); }
 
 NSIG_EXPORT int hg_scatter_binned(const float *rec, uint32_t M, float *G, void *scratch, nsig_stream_t stream) {
+    if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(rec && G && scratch, "hg_scatter_binned: null pointer");
     NSIG_REQUIRE((reinterpret_cast<uintptr_t>(rec) & 15) == 0 && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0 && M < (1u << 28),
                  "hg_scatter_binned: rec and scratch must be 16-byte aligned and M < 2^28");
-    if (M == 0) return NSIG_OK;
     ScatterTargets tg{};
     tg.g[0] = G;
     return launch_binned(rec, M, 1, tg, kBinReplicas, scratch, as_stream(stream), "hg_scatter_binned");
@@ -978,9 +978,9 @@ NSIG_EXPORT int hg_scatter_binned(const float *rec, uint32_t M, float *G, void *
 NSIG_EXPORT size_t hg_scatter_plan_bytes(uint32_t M) { return scatter_plan_bytes(M); }
 
 NSIG_EXPORT int hg_scatter_plan(const float *xyzs, uint32_t M, float bound, void *plan, nsig_stream_t stream) {
+    if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(xyzs && plan, "hg_scatter_plan: null pointer");
     NSIG_REQUIRE((reinterpret_cast<uintptr_t>(plan) & 15) == 0 && M < (1u << 28) && bound > 0.0f, "hg_scatter_plan: plan must be 16-byte aligned, M < 2^28, bound > 0");
-    if (M == 0) return NSIG_OK;
     const ScatterPlan pl = scatter_plan_view(plan, M);
     hipStream_t st = as_stream(stream);
     const uint32_t blocks = ceil_div(M, kBinThreads) < kBinGrid ? ceil_div(M, kBinThreads) : kBinGrid;
@@ -991,9 +991,9 @@ NSIG_EXPORT int hg_scatter_plan(const float *xyzs, uint32_t M, float bound, void
 }
 
 NSIG_EXPORT int hg_scatter_planned(const void *plan, uint32_t M, float *G, nsig_stream_t stream) {
+    if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(plan && G, "hg_scatter_planned: null pointer");
     NSIG_REQUIRE((reinterpret_cast<uintptr_t>(plan) & 15) == 0 && M < (1u << 28), "hg_scatter_planned: plan must be 16-byte aligned and M < 2^28");
-    if (M == 0) return NSIG_OK;
     if (int e = reserve_owner_lds("hg_scatter_planned")) return e;
     const ScatterPlan pl = scatter_plan_view(const_cast<void *>(plan), M);
     ScatterTargets tg{};
@@ -1037,9 +1037,9 @@ NSIG_EXPORT int hg_scatter_levels(const float *xyzs, float bound, const void *d_
 }
 
 NSIG_EXPORT int hg_scatter_level(const float *xyzs, float bound, const void *d_plane, uint32_t M, uint32_t level, float *G, nsig_stream_t stream) {
+    if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(xyzs && d_plane && G, "hg_scatter_level: null pointer");
     NSIG_REQUIRE(level < NSIG_BASE_LEVELS && bound > 0.0f, "hg_scatter_level: level %u out of range or bad bound", level);
-    if (M == 0) return NSIG_OK;
     static bool attr_set = false;
     const size_t lds = (size_t)kSliceRows * 2 * sizeof(float);
     if (!attr_set) {

@@ -792,30 +792,30 @@ static inline uint32_t lanes_for_walk(uint32_t n) {
 
 NSIG_EXPORT int rm_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N,
                                       float min_near, float *nears, float *fars, nsig_stream_t stream) {
-    NSIG_REQUIRE(rays_o && rays_d && aabb && nears && fars, "rm_near_far_from_aabb: null pointer");
     if (N == 0) return NSIG_OK;
+    NSIG_REQUIRE(rays_o && rays_d && aabb && nears && fars, "rm_near_far_from_aabb: null pointer");
     k_near_far<<<ceil_div(N, 256), 256, 0, as_stream(stream)>>>(rays_o, rays_d, aabb, N, min_near, nears, fars);
     return check_launch("rm_near_far_from_aabb");
 }
 
 NSIG_EXPORT int rm_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords,
                                 nsig_stream_t stream) {
-    NSIG_REQUIRE(rays_o && rays_d && coords, "rm_sph_from_ray: null pointer");
     if (N == 0) return NSIG_OK;
+    NSIG_REQUIRE(rays_o && rays_d && coords, "rm_sph_from_ray: null pointer");
     k_sph_from_ray<<<ceil_div(N, 256), 256, 0, as_stream(stream)>>>(rays_o, rays_d, radius, N, coords);
     return check_launch("rm_sph_from_ray");
 }
 
 NSIG_EXPORT int rm_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, nsig_stream_t stream) {
-    NSIG_REQUIRE(coords && indices, "rm_morton3D: null pointer");
     if (N == 0) return NSIG_OK;
+    NSIG_REQUIRE(coords && indices, "rm_morton3D: null pointer");
     k_morton<<<ceil_div(N, 256), 256, 0, as_stream(stream)>>>(coords, N, indices);
     return check_launch("rm_morton3D");
 }
 
 NSIG_EXPORT int rm_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, nsig_stream_t stream) {
-    NSIG_REQUIRE(coords && indices, "rm_morton3D_invert: null pointer");
     if (N == 0) return NSIG_OK;
+    NSIG_REQUIRE(coords && indices, "rm_morton3D_invert: null pointer");
     k_morton_invert<<<ceil_div(N, 256), 256, 0, as_stream(stream)>>>(indices, N, coords);
     return check_launch("rm_morton3D_invert");
 }
@@ -845,9 +845,9 @@ NSIG_EXPORT int rm_march_train_count(const float *rays_o, const float *rays_d, c
                                      float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                                      const float *nears, const float *fars, const float *noises, int32_t *counts,
                                      float *t_rec, nsig_stream_t stream) {
+    if (N == 0) return NSIG_OK;
     NSIG_REQUIRE(rays_o && rays_d && grid && nears && fars && counts && t_rec, "rm_march_train_count: null pointer");
     if (int e = check_grid_args("rm_march_train_count", C, H, max_steps, bound)) return e;
-    if (N == 0) return NSIG_OK;
     const GridView gv = make_grid_view(grid, bound, dt_gamma, max_steps, C, H);
     const uint32_t blocks = ceil_div(N, 4u);
     hipStream_t st = as_stream(stream);
@@ -883,8 +883,8 @@ NSIG_EXPORT int rm_march_train_write(const float *rays_o, const float *rays_d, f
 NSIG_EXPORT int rm_composite_train_fwd(const float *sigmas, const float *rgbs, const float *deltas,
                                        const int32_t *rays, uint32_t M, uint32_t N, float T_thresh, float *weights_sum,
                                        float *depth, float *image, nsig_stream_t stream) {
-    NSIG_REQUIRE(sigmas && rgbs && deltas && rays && weights_sum && depth && image, "rm_composite_train_fwd: null pointer");
     if (N == 0) return NSIG_OK;
+    NSIG_REQUIRE(sigmas && rgbs && deltas && rays && weights_sum && depth && image, "rm_composite_train_fwd: null pointer");
     k_composite_fwd<<<ceil_div(N, 4u), 256, 0, as_stream(stream)>>>(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image);
     return check_launch("rm_composite_train_fwd");
 }
@@ -893,10 +893,10 @@ NSIG_EXPORT int rm_composite_train_finish_fwd(const float *sigmas, const float *
                                               uint32_t N, float T_thresh, const float *nears, const float *fars, const float *bg,
                                               uint32_t bg_stride, float *weights_sum, float *depth, float *image, float *image_out,
                                               float *depth_out, nsig_stream_t stream) {
+    if (N == 0) return NSIG_OK;
     NSIG_REQUIRE(sigmas && rgbs && deltas && rays && weights_sum && depth && image && nears && fars && bg && image_out && depth_out,
                  "rm_composite_train_finish_fwd: null pointer");
     NSIG_REQUIRE(bg_stride == 0 || bg_stride == 3, "rm_composite_train_finish_fwd: bg_stride is 0 (one colour) or 3 (per ray)");
-    if (N == 0) return NSIG_OK;
     const FinishArgs fin{nears, fars, bg, bg_stride, image_out, depth_out, 0u};
     k_composite_fwd<<<ceil_div(N, 4u), 256, 0, as_stream(stream)>>>(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image, fin);
     return check_launch("rm_composite_train_finish_fwd");
@@ -906,10 +906,10 @@ NSIG_EXPORT int rm_composite_train_finish_bwd(const float *grad_weights_sum, con
                                               const float *deltas, const int32_t *rays, const float *weights_sum, const float *image,
                                               const float *bg, uint32_t bg_stride, uint32_t M, uint32_t N, float T_thresh, uint32_t rays_in_order,
                                               float *grad_sigmas, float *grad_rgbs, nsig_stream_t stream) {
+    if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(grad_image_out && sigmas && rgbs && deltas && rays && weights_sum && image && bg && grad_sigmas && grad_rgbs,
                  "rm_composite_train_finish_bwd: null pointer");
     NSIG_REQUIRE(bg_stride == 0 || bg_stride == 3, "rm_composite_train_finish_bwd: bg_stride is 0 (one colour) or 3 (per ray)");
-    if (M == 0) return NSIG_OK;
     const bool self_zero = rays_in_order != 0 && N != 0;
     if (!self_zero && (hipMemsetAsync(grad_sigmas, 0, (size_t)M * sizeof(float), as_stream(stream)) != hipSuccess ||
                        hipMemsetAsync(grad_rgbs, 0, (size_t)M * 3 * sizeof(float), as_stream(stream)) != hipSuccess)) {
@@ -927,9 +927,9 @@ NSIG_EXPORT int rm_composite_train_bwd(const float *grad_weights_sum, const floa
                                        const float *rgbs, const float *deltas, const int32_t *rays,
                                        const float *weights_sum, const float *image, uint32_t M, uint32_t N,
                                        float T_thresh, float *grad_sigmas, float *grad_rgbs, nsig_stream_t stream) {
+    if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(grad_weights_sum && grad_image && sigmas && rgbs && deltas && rays && weights_sum && image && grad_sigmas && grad_rgbs,
                  "rm_composite_train_bwd: null pointer");
-    if (M == 0) return NSIG_OK;
     if (hipMemsetAsync(grad_sigmas, 0, (size_t)M * sizeof(float), as_stream(stream)) != hipSuccess ||
         hipMemsetAsync(grad_rgbs, 0, (size_t)M * 3 * sizeof(float), as_stream(stream)) != hipSuccess) {
         set_error("rm_composite_train_bwd: hipMemsetAsync failed");
@@ -945,6 +945,7 @@ NSIG_EXPORT int rm_march(uint32_t n_alive, uint32_t n_step, const int32_t *rays_
                          const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps,
                          uint32_t C, uint32_t H, const uint8_t *grid, const float *nears, const float *fars, float *xyzs,
                          float *dirs, float *deltas, const float *noises, uint32_t M_rows, nsig_stream_t stream) {
+    if (n_alive == 0) return NSIG_OK;
     (void)nears;  // read but unused by the reference as well (raymarching.cu:737)
     NSIG_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas, "rm_march: null pointer");
     NSIG_REQUIRE((uint64_t)n_alive * n_step <= M_rows, "rm_march: M_rows=%u < n_alive*n_step", M_rows);
@@ -956,7 +957,6 @@ NSIG_EXPORT int rm_march(uint32_t n_alive, uint32_t n_step, const int32_t *rays_
         set_error("rm_march: hipMemsetAsync failed");
         return NSIG_ERR_LAUNCH;
     }
-    if (n_alive == 0) return NSIG_OK;
     const uint32_t lanes = lanes_for_walk(n_alive);
     k_march_burst<<<ceil_div(n_alive, lanes), lanes, 0, s>>>(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d,
                                                             make_grid_view(grid, bound, dt_gamma, max_steps, C, H), fars, xyzs, dirs, deltas, noises);
@@ -966,8 +966,8 @@ NSIG_EXPORT int rm_march(uint32_t n_alive, uint32_t n_step, const int32_t *rays_
 NSIG_EXPORT int rm_composite(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
                              const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum,
                              float *depth, float *image, nsig_stream_t stream) {
-    NSIG_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, "rm_composite: null pointer");
     if (n_alive == 0) return NSIG_OK;
+    NSIG_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, "rm_composite: null pointer");
     k_composite_burst<<<ceil_div(n_alive, 64), 64, 0, as_stream(stream)>>>(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs,
                                                                            deltas, weights_sum, depth, image);
     return check_launch("rm_composite");
@@ -984,11 +984,11 @@ NSIG_EXPORT int rm_compact_alive(const int32_t *rays_alive, uint32_t n_alive, in
 NSIG_EXPORT int rg_sample_rays(const float *poses, uint32_t P, const float *images, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W,
                                uint32_t N, const int32_t *step_counter, uint32_t stride, uint32_t offset, uint64_t seed, float *rays_o, float *rays_d,
                                float *gt, int64_t *inds_out, int32_t *pose_out, nsig_stream_t stream) {
+    if (N == 0) return NSIG_OK;
     NSIG_REQUIRE(poses && rays_o && rays_d, "rg_sample_rays: null pointer");
     NSIG_REQUIRE(P > 0 && H > 0 && W > 0 && fx != 0.0f && fy != 0.0f, "rg_sample_rays: empty pose store, bad image size or focal length");
     NSIG_REQUIRE(gt == nullptr || images != nullptr, "rg_sample_rays: ground truth requested without an image store");
     NSIG_REQUIRE((uint64_t)H * W < (1ull << 32), "rg_sample_rays: image too large");
-    if (N == 0) return NSIG_OK;
     k_sample_rays<<<ceil_div(N, 256u), 256, 0, as_stream(stream)>>>(poses, P, images, fx, fy, cx, cy, H, W, N, step_counter, stride, offset, (uint32_t)seed,
                                                                     (uint32_t)(seed >> 32), rays_o, rays_d, gt, inds_out, pose_out);
     return check_launch("rg_sample_rays");

@@ -142,15 +142,34 @@ class NeRFNetwork(NeRFRenderer):
         else:
             self._select(message)
 
-    def forward(self, x, d, message):
-        """x: [N,3] in [-bound,bound], d: [N,3] unit, message: [message_dim] of 0./1. or None -> (sigma [N], color [N,3])."""
+    def forward(self, x, d, message, fixed=None):
+        """x: [N,3] in [-bound,bound], d: [N,3] unit, message: [message_dim] of 0./1. or None -> (sigma [N], color [N,3]).
+        fixed: the fieldops.FixedPoints of exactly these points (fix_rays), or None."""
         if self.device_select and message is not None and message.is_cuda:
             if self.grad_sink is None and torch.is_grad_enabled():
                 raise RuntimeError("device_select needs a grad_sink: which tables were selected is not known on the host")
             tables, S = self._select_on_device(message)
-            return fo.field_apply(x, d, self.bound, self._packed(), self.encoder.tables(), tables, S, self.grad_sink)
+            return fo.field_apply(x, d, self.bound, self._packed(), self.encoder.tables(), tables, S, self.grad_sink, fixed)
         selected, _, S = self._select(message)
-        return fo.field_apply(x, d, self.bound, self._packed(), self.encoder.tables(), selected, S, self.grad_sink)
+        return fo.field_apply(x, d, self.bound, self._packed(), self.encoder.tables(), selected, S, self.grad_sink, fixed)
+
+    def fix_rays(self, rays_o, rays_d, dt_gamma=0, max_steps=1024):
+        """Declare these ray tensors constant from step to step -- the watermark-block rays, one pair of tensors per dataset
+        (nerf/provider_wtmk.py:442-494), rendered without jitter through a grid the watermark stage never updates: their samples are
+        marched now, once, and the part of the field pass no step changes (the 16 frozen base levels' features, the scatter plan) is
+        kept beside them (fieldops.FixedPoints).  Training renders of the same, unmodified tensors (`render(..., perturb=False,
+        force_all_rays=True)`, the way train_step calls it) then gather only the codebook level, evaluate the MLPs and composite --
+        bit-identical results.  An in-place change of the rays drops them out of the cache by itself (run_cuda matches tensors by
+        address AND version); a changed occupancy grid or base table is noticed at the next eager render and refreshed in place.
+        Needs `point_capacity` for this ray count (like march_ahead).  Calling it again re-marches and refreshes in place."""
+        rec = self.march_ahead(rays_o, rays_d, dt_gamma, max_steps)
+        if rec.get("fixed") is None:
+            rec["fixed"] = fo.FixedPoints(rec["xyzs"], self.bound, self.encoder.tables())
+        else:
+            rec["fixed"].refresh(rec["xyzs"], self.encoder.tables())
+        rec["fixed_args"] = (dt_gamma, max_steps)
+        rec["grid_key"] = (self.density_bitfield.data_ptr(), self.density_bitfield._version)
+        return rec
 
     def density(self, x, message=None):
         if torch.is_grad_enabled() and message is not None and any(t.requires_grad for t in self.msg_encoder.tables()):

@@ -284,7 +284,13 @@ class NeRFRenderer(nn.Module):
                                    marched=None):
         """All samples of all rays at once, then one differentiable composite (renderer_wtmk.py:280-321)."""
         if marched is not None:      # the samples were marched ahead of this step (march_ahead)
-            sigmas, rgbs = self(marched["xyzs"], marched["dirs"], message)
+            fixed = marched.get("fixed")
+            if fixed is not None:    # rays declared constant (NeRFNetwork.fix_rays): the grid they were marched through must still be the one
+                if marched["grid_key"] != (self.density_bitfield.data_ptr(), self.density_bitfield._version) and not torch.cuda.is_current_stream_capturing():
+                    self.fix_rays(o, d, *marched["fixed_args"])
+                sigmas, rgbs = self(marched["xyzs"], marched["dirs"], message, fixed=fixed)
+            else:
+                sigmas, rgbs = self(marched["xyzs"], marched["dirs"], message)
             sigmas = sigmas if self.density_scale == 1 else self.density_scale * sigmas
             if finish is not None:
                 return _CompositeFinish.apply(sigmas, rgbs, marched["deltas"], marched["rays"], nears, fars, finish, T_thresh)

@@ -256,7 +256,7 @@ class GraphedWatermarkLoop:
 
     def __init__(self, model, optimizer, render_kwargs, data, lambda_w=1.0, lambda_i=1.0, lr_lambda=None, headroom=0.0, native_dense_adam=True,
                  overlap_content=True, march_ahead=None, presum_in_adam=True, stage_in_graph=True, content_headroom=None, content_ahead=None,
-                 content_sampler=None):
+                 content_sampler=None, fixed_blocks=None):
         """presum_in_adam: the captured optimiser kernel also writes the pre-summed codebook of the NEXT step's message
         (opt_codebook_adam_sel_next: +9 % traffic inside an HBM-streaming kernel instead of a 128 MiB pass at the head of every step).
         The next message is handed over one step early -- `step(message_k, next_message=message_k1)`, a one-element look-ahead over
@@ -271,6 +271,16 @@ class GraphedWatermarkLoop:
         at the head of its own step on the side stream: next to the optimiser as well, the two marches took longer than the
         optimiser and the pre-sum lost its cover."""
         self.march_ahead = overlap_content if march_ahead is None else bool(march_ahead)
+        # fixed_blocks (NERFSIG_FIXED_BLOCKS=1; off by default): the watermark-block rays are one pair of tensors per dataset
+        # (nerf/provider_wtmk.py:442-494) and everything their field pass reads except the codebook is frozen in this stage, so the
+        # loop marches them ONCE, keeps the base-level feature planes and the scatter plan (NeRFNetwork.fix_rays / fieldops.FixedPoints)
+        # and a step only gathers the codebook level for them -- same kernels' results, bit-identical training
+        # (test_fixed_block_cache_trains_bit_identically).  New block rays (`data` / `next_data` with a "watermark" part), a loaded
+        # checkpoint (invalidate) or a re-sized capture refresh the kept buffers in place before the next replay.
+        if fixed_blocks is None:
+            fixed_blocks = os.environ.get("NERFSIG_FIXED_BLOCKS", "0") == "1"
+        self.fixed_blocks = bool(fixed_blocks)
+        self._refix_pending = False
         # content_sampler (rays.DeviceRaySampler): the step draws its own content batch -- pose, pixels, rays, ground truth -- on the
         # device, inside the captured graph, from the replay count; `data` / `next_data` then carry no content part
         self.content_sampler = content_sampler
@@ -347,6 +357,8 @@ class GraphedWatermarkLoop:
         here, in the buffer the graph reads (the captured step never re-packs)."""
         self._s_for = None
         self.model._packed()
+        if self.fixed_blocks and self.graphs is not None:
+            self._fix_blocks()       # the base tables may have been overwritten: the kept feature planes, in place
 
     @torch.no_grad()
     def gather_codebook(self, optimizer_state=True):
@@ -446,13 +458,25 @@ class GraphedWatermarkLoop:
         # the block render's march only: the content render's stays at the head of its step, on the side stream, where it
         # overlaps the pre-sum and the block encoder (both marches next to the optimiser took longer than the optimiser)
         block_o, block_d, _ = local_blocks(wm)       # (this rank's shard of the blocks when they are split over the ranks)
-        self.marched = (self.model.march_ahead(block_o, block_d, *args),)
+        if self.fixed_blocks:                        # marched once, outside the step (_fix_blocks)
+            self.marched = self.marched[:1]
+        else:
+            self.marched = (self.model.march_ahead(block_o, block_d, *args),)
         if self.content_ahead:
             self.marched += (self.model.march_ahead(ct["rays_o"], ct["rays_d"], *args),)
 
+    @torch.no_grad()
+    def _fix_blocks(self):
+        """(Re-)march this rank's block rays and (re-)compute what their field pass keeps across steps, in place (eager, between replays)."""
+        kw = self.render_kwargs
+        block_o, block_d, _ = local_blocks(self.data["watermark"])
+        rec = self.model.fix_rays(block_o, block_d, kw.get("dt_gamma", 0), kw.get("max_steps", 1024))
+        self.marched = (rec,) + tuple(self.marched[1:] if self.marched else ())
+        self._refix_pending = False
+
     def _optimise_and_march(self):
         """The optimiser step and, beside it on the side stream, the march of the next step's samples."""
-        if not self.march_ahead:
+        if not self.march_ahead or (self.fixed_blocks and not self.content_ahead):
             return self._optimise()
         main = torch.cuda.current_stream()
         if self.side_stream is not None:
@@ -477,6 +501,8 @@ class GraphedWatermarkLoop:
         return (a, b) if self.side_stream is None else (b, a)     # issue order: with a side stream the content render comes first
 
     def _set_inputs(self, message, data, next_data=None, next_message=None, eager_copy=True):
+        if self._refix_pending:      # the previous call's next_data brought new block rays: they are this step's now
+            self._fix_blocks()
         slot = self._replays % len(self.msg_ring)        # == the device's replay count modulo the ring (advanced right behind every replay of g1)
         if self.msg_events[slot] is not None:
             self.msg_events[slot].synchronize()      # blocks only if the GPU is a whole ring behind
@@ -499,13 +525,16 @@ class GraphedWatermarkLoop:
             for part in ("watermark", "content"):
                 for k, v in data.get(part, {}).items():
                     self.data[part][k].copy_(v, non_blocking=True)
-            if self.march_ahead and self.graphs is not None and ("watermark" in data or (self.content_ahead and "content" in data)):
+            if self.fixed_blocks and self.graphs is not None and "watermark" in data:
+                self._fix_blocks()              # new block rays: marched and their kept planes refreshed before the replay
+            if self.march_ahead and self.graphs is not None and (("watermark" in data and not self.fixed_blocks) or (self.content_ahead and "content" in data)):
                 self._march_ahead()             # this step's rays arrived only now: march them before the replay
         if next_data is not None:
             if not self.march_ahead:
                 raise ValueError("next_data needs march_ahead=True")
             for k, v in next_data.get("watermark", {}).items():     # nothing in the replay reads the block rays before its closing march
                 self.data["watermark"][k].copy_(v, non_blocking=True)
+                self._refix_pending = self.fixed_blocks             # (no closing march with fixed blocks: re-fixed ahead of the next replay)
             content = next_data.get("content")
             if content is not None and self.content_ahead:
                 # the rays go in now (this replay renders from samples marched earlier and marches these at its end); the ground-truth
@@ -569,6 +598,10 @@ class GraphedWatermarkLoop:
         # Warm-up on a side stream (library handles, lazily created optimiser state, MIOpen algorithm choice must all
         # exist before capture).  The warm-up iterations must not train: parameters and optimiser state are restored.
         snapshot = self._snapshot()
+        if self.fixed_blocks:
+            if not self.march_ahead:
+                raise ValueError("fixed_blocks needs march_ahead=True (the kept samples live in the march-ahead record)")
+            self._fix_blocks()       # before the warm-up, so that it runs -- and loads -- the kernels the captured step will use
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -582,7 +615,7 @@ class GraphedWatermarkLoop:
         self._restore(snapshot)
 
         self.optimizer.zero_grad(set_to_none=True)
-        if self.march_ahead:
+        if self.march_ahead and not (self.fixed_blocks and not self.content_ahead):
             self._march_ahead()      # the first replay's samples (buffers outside the graph's pool, re-marched in place by every replay)
         # Segmented capture: one hipGraph per stretch between collectives.  A collective reached while capturing (dp.collective: the
         # all-gather of the rendered blocks, the gradient all-reduce) ends the running capture, is remembered as the eager call that
