@@ -193,7 +193,7 @@ class NativeTimer:
     """HIP-event timing of selected libnerfsig entry points, on the stream the kernels are launched on (torch's current
     stream).  Installed over nerf_signature_amd._native.call; each timed call records (duration, points)."""
 
-    POINTS_ARG = {"hg_encode_planes": 1, "hg_encode_codebook_plane": 1, "field_fwd": 2, "field_bwd": 1, "field_bwd_planned": 1, "hg_scatter_sliced": 1, "hg_scatter_binned": 1,
+    POINTS_ARG = {"hg_encode_planes": 1, "hg_encode_codebook_plane": 1, "field_fwd_kept": 2, "field_fwd": 2, "field_bwd": 1, "field_bwd_planned": 1, "hg_scatter_sliced": 1, "hg_scatter_binned": 1,
                   "hg_scatter_planned": 1, "hg_scatter_plan": 1}
 
     def __init__(self, nv):

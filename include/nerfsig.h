@@ -263,6 +263,12 @@ int hg_encode_planes(const float *xyzs, uint32_t M, float bound, const float *co
 int hg_encode_codebook_plane(const float *xyzs, uint32_t M, float bound, const float *S, void *planes, void *plan_to_reset,
                              nsig_stream_t stream);
 
+/* field_fwd for such points in ONE launch: the 16 base levels come from `planes` (kept), the codebook level is gathered inside the
+ * MLP kernel from S (NULL = clean model) -- the two lane halves of a wave fetch the two x sides of each corner pair and swap them.
+ * Bit-identical to hg_encode_codebook_plane + field_fwd(planes).  plan_to_reset as above. */
+int field_fwd_kept(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *S, const void *packed, float *sigmas,
+                   float *rgbs, uint32_t *masks, const void *planes, void *plan_to_reset, nsig_stream_t stream);
+
 /* NeRFNetwork.color (nerf/network_wtmk_tcnn.py:147-176) without the mask: rgb from dirs + geo_feat. */
 int field_color_fwd(const float *dirs, const float *geo_feat, uint32_t M, const void *packed, float *rgbs,
                     nsig_stream_t stream);

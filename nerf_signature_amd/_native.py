@@ -53,6 +53,7 @@ SIGNATURES = {
     "hg_planes_bytes": [_u32],
     "hg_encode_planes": [_vp, _u32, _fl, _vp, _vp, _vp, _vp],
     "hg_encode_codebook_plane": [_vp, _u32, _fl, _vp, _vp, _vp, _vp],
+    "field_fwd_kept": [_vp, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "field_fwd": [_vp, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "field_color_fwd": [_vp, _vp, _u32, _vp, _vp, _vp],
     "opt_adam_dense": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _fl, _fl, _fl, _fl, _vp, _vp],

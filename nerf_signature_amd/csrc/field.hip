@@ -435,16 +435,44 @@ __global__ void __launch_bounds__(256) k_encode_codebook_plane(const float *__re
     encode_tile_level(reinterpret_cast<const float2 *>(S), cell, false, threadIdx.x & 1u, x, y, z, plane + m);
 }
 
-// kPlanes = false: gather the features in-kernel (fused); true: read them from the level-major planes.
-template <typename P, bool kPlanes, bool kTrace = false>
+// The codebook level gathered inside the MLP kernel (kPlanes == 2): the two lane halves of a wave hold the same 32 points, so
+// half 0 fetches the x = 0 side of every (dy, dz) pair and half 1 the x = 1 side -- one instruction touches 32 lines, like the
+// lane pairs of encode_tile_level -- and the halves swap what they fetched.  Same rows, same trilerp(): bit-identical to the plane.
+__device__ inline float2 codebook_half_gather(const float2 *__restrict__ S, float cell, uint32_t xs, float x, float y, float z) {
+    uint32_t ix, iy, iz;
+    float wx, wy, wz;
+    axis_cell(x, cell, ix, wx);
+    axis_cell(y, cell, iy, wy);
+    axis_cell(z, cell, iz, wz);
+    const uint32_t hx = ix + xs, hy[2] = {iy * kPrimeY, (iy + 1u) * kPrimeY}, hz[2] = {iz * kPrimeZ, (iz + 1u) * kPrimeZ};
+    float2 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = S[(hx ^ hy[q >> 1] ^ hz[q & 1]) & kRowMask];
+    float2 e[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float2 got;
+        got.x = __shfl_xor(v[q].x, 32, 64);
+        got.y = __shfl_xor(v[q].y, 32, 64);
+        e[q] = xs ? got : v[q];          // corner k = 4*dx + q
+        e[4 + q] = xs ? v[q] : got;
+    }
+    return trilerp(e, wx, wy, wz);
+}
+
+// kPlanes = 0: gather the features in-kernel (fused); 1: read all 17 from the level-major planes; 2: the 16 base levels from the
+// planes, the codebook level gathered here (field_fwd_kept: points whose base planes are kept across steps).
+template <typename P, int kPlanes, bool kTrace = false>
 __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyzs, const float *__restrict__ dirs, uint32_t M, float bound,
                                                    TablePtrs base, LevelGeom geom, const float *__restrict__ S,
                                                    const float2 *__restrict__ planes, uint32_t stride,
                                                    const char *__restrict__ packed, float *__restrict__ sigmas, float *__restrict__ rgbs,
-                                                   float *__restrict__ geo_out, uint32_t *__restrict__ masks, ActTrace trace = ActTrace{}) {
+                                                   float *__restrict__ geo_out, uint32_t *__restrict__ masks, ActTrace trace = ActTrace{},
+                                                   BinHeader *__restrict__ plan_reset = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     stage_weights(lds, packed + P::kFwdOffset, (int)P::kFwdLds);
     constexpr size_t kHalf = kFwdBytes;
+    if (kPlanes == 2 && plan_reset != nullptr && blockIdx.x == 0 && threadIdx.x == 0) plan_reset->gmax_bits = 0;   // (as hg_encode_codebook_plane)
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int p = lane & 31, h = lane >> 5;
@@ -459,7 +487,18 @@ __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyz
             float2 f[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) f[q] = planes[(size_t)(8 * (q >> 2) + (q & 3) + 4 * h) * stride + s];  // 256 contiguous bytes per half-wave
-            if (S != nullptr && h) {  // codebook added into channels 30:32 (network_wtmk_tcnn.py:106)
+            if (kPlanes == 2) {
+                if (S != nullptr) {   // both halves gather (one x side each); half 1 owns level 15 and takes the sum
+                    const float two_b = 2.0f * bound;
+                    const float3 pt = *reinterpret_cast<const float3 *>(xyzs + 3 * (size_t)sl);
+                    const float2 c = codebook_half_gather(reinterpret_cast<const float2 *>(S), geom.cell[NSIG_BASE_LEVELS], (uint32_t)h,
+                                                          (pt.x + bound) / two_b, (pt.y + bound) / two_b, (pt.z + bound) / two_b);
+                    if (h) {
+                        f[7].x = f[7].x + c.x;
+                        f[7].y = f[7].y + c.y;
+                    }
+                }
+            } else if (S != nullptr && h) {  // codebook added into channels 30:32 (network_wtmk_tcnn.py:106)
                 const float2 c = planes[(size_t)NSIG_BASE_LEVELS * stride + s];
                 f[7].x = f[7].x + c.x;
                 f[7].y = f[7].y + c.y;
@@ -881,16 +920,35 @@ NSIG_EXPORT int field_fwd(const float *xyzs, const float *dirs, uint32_t M, floa
     hipStream_t st = as_stream(stream);
     const bool f16 = mlp_precision() == 1;
     if (planes == nullptr) {  // fused: gather inside the MLP kernel (small batches)
-        if (f16) k_field_fwd<F16, false><<<field_grid(M, true), 256, F16::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, nullptr, 0, pk, sigmas, rgbs, geo_feat, masks);
-        else k_field_fwd<Bf16x3, false><<<field_grid(M, true), 256, Bf16x3::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, nullptr, 0, pk, sigmas, rgbs, geo_feat, masks);
+        if (f16) k_field_fwd<F16, 0><<<field_grid(M, true), 256, F16::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, nullptr, 0, pk, sigmas, rgbs, geo_feat, masks);
+        else k_field_fwd<Bf16x3, 0><<<field_grid(M, true), 256, Bf16x3::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, nullptr, 0, pk, sigmas, rgbs, geo_feat, masks);
         return check_launch("field_fwd");
     }
     NSIG_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 7) == 0, "field_fwd: planes must be 8-byte aligned");
     const uint32_t stride = ceil_div(M, 32u) * 32u;
     const float2 *pl = reinterpret_cast<const float2 *>(planes);
-    if (f16) k_field_fwd<F16, true><<<field_grid(M, true), 256, F16::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, geo_feat, masks);
-    else k_field_fwd<Bf16x3, true><<<field_grid(M, true), 256, Bf16x3::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, geo_feat, masks);
+    if (f16) k_field_fwd<F16, 1><<<field_grid(M, true), 256, F16::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, geo_feat, masks);
+    else k_field_fwd<Bf16x3, 1><<<field_grid(M, true), 256, Bf16x3::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, geo_feat, masks);
     return check_launch("field_fwd");
+}
+
+NSIG_EXPORT int field_fwd_kept(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *S, const void *packed, float *sigmas,
+                               float *rgbs, uint32_t *masks, const void *planes, void *plan_to_reset, nsig_stream_t stream) {
+    if (M == 0) return NSIG_OK;
+    NSIG_REQUIRE(xyzs && dirs && packed && sigmas && rgbs && planes, "field_fwd_kept: null pointer");
+    NSIG_REQUIRE(bound > 0.0f, "field_fwd_kept: bound must be positive");
+    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(planes) & 7) == 0, "field_fwd_kept: packed must be 16-byte, planes 8-byte aligned");
+    NSIG_REQUIRE(plan_to_reset == nullptr || (reinterpret_cast<uintptr_t>(plan_to_reset) & 15) == 0, "field_fwd_kept: plan must be 16-byte aligned");
+    const char *pk = reinterpret_cast<const char *>(packed);
+    hipStream_t st = as_stream(stream);
+    const uint32_t stride = ceil_div(M, 32u) * 32u;
+    const float2 *pl = reinterpret_cast<const float2 *>(planes);
+    BinHeader *hd = reinterpret_cast<BinHeader *>(plan_to_reset);
+    if (mlp_precision() == 1)
+        k_field_fwd<F16, 2><<<field_grid(M, true), 256, F16::kFwdLds, st>>>(xyzs, dirs, M, bound, TablePtrs{}, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, nullptr, masks, ActTrace{}, hd);
+    else
+        k_field_fwd<Bf16x3, 2><<<field_grid(M, true), 256, Bf16x3::kFwdLds, st>>>(xyzs, dirs, M, bound, TablePtrs{}, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, nullptr, masks, ActTrace{}, hd);
+    return check_launch("field_fwd_kept");
 }
 
 NSIG_EXPORT int field_color_fwd(const float *dirs, const float *geo_feat, uint32_t M, const void *packed, float *rgbs, nsig_stream_t stream) {
@@ -947,7 +1005,7 @@ NSIG_EXPORT int field_fwd_trace(const float *xyzs, const float *dirs, uint32_t M
     if (int e = fill_base_tables(base_tables_host, base, "field_fwd_trace")) return e;
     const uint32_t stride = ceil_div(M, 32u) * 32u;
     ActTrace tr{act_hs, act_cin, act_h1, act_h2};
-    k_field_fwd<Bf16x3, true, true><<<field_grid(M), 256, Bf16x3::kFwdLds, as_stream(stream)>>>(xyzs, dirs, M, bound, base, make_level_geom(), nullptr,
+    k_field_fwd<Bf16x3, 1, true><<<field_grid(M), 256, Bf16x3::kFwdLds, as_stream(stream)>>>(xyzs, dirs, M, bound, base, make_level_geom(), nullptr,
                                                                                      reinterpret_cast<const float2 *>(planes), stride,
                                                                                      reinterpret_cast<const char *>(packed), sigmas, rgbs, nullptr, masks, tr);
     return check_launch("field_fwd_trace");

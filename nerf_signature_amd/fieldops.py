@@ -5,6 +5,8 @@ These replace, on the GPU, the op chains of the reference's hash_encoding.py / h
 and the tinycudann calls of nerf/network_wtmk_tcnn.py:97-176.  No host synchronisation happens here:
 the message bits are taken from a host-side tuple (see `message_bits`), never read back from the device.
 """
+import os
+
 import torch
 from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
@@ -118,6 +120,10 @@ def pack_weights(sigma_params, color_params, out=None):
 
 
 PLANES_MIN_POINTS = 16384  # below this the fused kernel wins (one launch, no feature round trip)
+# FixedPoints: field_fwd_kept (codebook level gathered inside the MLP kernel) instead of hg_encode_codebook_plane + field_fwd.  Bit-identical;
+# measured slower (0.790-0.791 against 0.779-0.784 ms per step, profiles/r02_fixed_blocks_ab.txt): the gather lengthens the latency-bound
+# MLP kernel by more than the 31 us launch it removes.  Off by default.
+KEPT_ONE_LAUNCH = os.environ.get("NERFSIG_KEPT_ONE_LAUNCH", "0") == "1"
 
 
 def field_forward(xyzs, dirs, bound, base_tables, S, packed, want_rgb=True, want_geo=False, want_masks=False, planes=None, fixed=None):
@@ -138,8 +144,13 @@ def field_forward(xyzs, dirs, bound, base_tables, S, packed, want_rgb=True, want
     if fixed is not None:
         fixed.check(xyzs, bound, base_tables)
         ws = fixed.planes
+        reset = nv.ptr(fixed.plan.buf) if want_masks else None
+        if want_rgb and not want_geo and KEPT_ONE_LAUNCH:     # the codebook level gathered inside the MLP kernel
+            nv.call("field_fwd_kept", nv.ptr(xyzs), nv.ptr(dirs), M, float(bound), nv.ptr(S), nv.ptr(packed), nv.ptr(sigmas), nv.ptr(rgbs), nv.ptr(masks),
+                    nv.ptr(ws), reset, nv.stream())
+            return sigmas, rgbs, geo, masks
         if S is not None:      # (a clean render -- no message -- reads the base planes only)
-            nv.call("hg_encode_codebook_plane", nv.ptr(xyzs), M, float(bound), nv.ptr(S), nv.ptr(ws), nv.ptr(fixed.plan.buf) if want_masks else None, nv.stream())
+            nv.call("hg_encode_codebook_plane", nv.ptr(xyzs), M, float(bound), nv.ptr(S), nv.ptr(ws), reset, nv.stream())
     elif use_planes:
         ws = torch.empty(int(nv.fn("hg_planes_bytes")(M)), dtype=torch.uint8, device=dev)
         nv.call("hg_encode_planes", nv.ptr(xyzs), M, float(bound), base_ptrs, nv.ptr(S), nv.ptr(ws), nv.stream())
