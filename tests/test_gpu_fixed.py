@@ -127,3 +127,25 @@ def test_fixed_block_cache_trains_like_the_loop_that_recomputes():
     np.testing.assert_allclose(l1, l0, rtol=1e-4, atol=1e-6)
     start = torch.cat([torch.from_numpy(cf.table(100 + l, scale=0.05)).reshape(-1) for l in range(64)]).cuda()
     assert float((t1 - t0).norm()) <= 0.02 * float((t0 - start).norm())
+
+
+def test_kept_forward_in_one_launch_equals_plane_plus_forward(monkeypatch):
+    """field_fwd_kept (codebook level gathered inside the MLP kernel, lane halves swapping the two x sides) against
+    hg_encode_codebook_plane + field_fwd(planes) and against the ordinary 17-level route: sigma, rgb and the ReLU masks bit for bit."""
+    from nerf_signature_amd import fieldops as fo
+    m, _, _ = _model()
+    rng = np.random.RandomState(3)
+    n = 20000 + 7                                        # not a multiple of 32: the padded tail of the last tile
+    xyzs = torch.from_numpy((rng.rand(n, 3) * 1.2 - 0.6).astype(np.float32)).cuda()
+    xyzs[:3] = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0], [0.0, 0.0, 0.0]])      # box corners, cell boundaries
+    dirs = torch.nn.functional.normalize(torch.from_numpy(rng.randn(n, 3).astype(np.float32)), dim=-1).cuda()
+    base, packed = m.encoder.tables(), m._packed()
+    S = fo.codebook_presum(fo.select_tables(m.msg_encoder.tables(), tuple(int(v) for v in cf.messages(32)[2])))
+    want = fo.field_forward(xyzs, dirs, 1.0, base, S, packed, want_masks=True, planes=True)
+    kept = fo.FixedPoints(xyzs, 1.0, base)
+    for one_launch in (False, True):
+        monkeypatch.setattr(fo, "KEPT_ONE_LAUNCH", one_launch)
+        got = fo.field_forward(xyzs, dirs, 1.0, base, S, packed, want_masks=True, fixed=kept)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[3], want[3])
+        clean = fo.field_forward(xyzs, dirs, 1.0, base, None, packed, fixed=kept)          # no codebook: base planes only
+        assert torch.equal(clean[0], fo.field_forward(xyzs, dirs, 1.0, base, None, packed, planes=True)[0])
