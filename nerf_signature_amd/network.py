@@ -153,6 +153,21 @@ class NeRFNetwork(NeRFRenderer):
         selected, _, S = self._select(message)
         return fo.field_apply(x, d, self.bound, self._packed(), self.encoder.tables(), selected, S, self.grad_sink, fixed)
 
+    def _count_points(self, o, d, dt_gamma, max_steps):
+        """Padded sample total of these rays through the current grid (one counting march, one host read)."""
+        from . import _native as nv
+        from . import raymarching
+        N, dev = o.shape[0], o.device
+        nears, fars = raymarching.near_far_from_aabb(o, d, self.aabb_train, self.min_near)
+        counts = torch.empty(N, dtype=torch.int32, device=dev)
+        t_rec = torch.empty(N * int(max_steps), dtype=torch.float32, device=dev)
+        rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+        counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        nv.call("rm_march_train_count", nv.ptr(o), nv.ptr(d), nv.ptr(self.density_bitfield), float(self.bound), float(dt_gamma), int(max_steps), N,
+                int(self.cascade), int(self.grid_size), nv.ptr(nears), nv.ptr(fars), None, nv.ptr(counts), nv.ptr(t_rec), nv.stream())
+        nv.call("rm_march_train_scan", nv.ptr(counts), N, nv.ptr(rays), nv.ptr(counter), nv.stream())
+        return raymarching.padded_point_count(int(counter[0]))
+
     def fix_rays(self, rays_o, rays_d, dt_gamma=0, max_steps=1024):
         """Declare these ray tensors constant from step to step -- the watermark-block rays, one pair of tensors per dataset
         (nerf/provider_wtmk.py:442-494), rendered without jitter through a grid the watermark stage never updates: their samples are
@@ -161,8 +176,26 @@ class NeRFNetwork(NeRFRenderer):
         force_all_rays=True)`, the way train_step calls it) then gather only the codebook level, evaluate the MLPs and composite --
         bit-identical results.  An in-place change of the rays drops them out of the cache by itself (run_cuda matches tensors by
         address AND version); a changed occupancy grid or base table is noticed at the next eager render and refreshed in place.
-        Needs `point_capacity` for this ray count (like march_ahead).  Calling it again re-marches and refreshes in place."""
-        rec = self.march_ahead(rays_o, rays_d, dt_gamma, max_steps)
+        Buffer sizes: `point_capacity` for this ray count when a captured loop set one (trainer.GraphedWatermarkLoop: its overflow check
+        covers these rays), otherwise one counting march here (a host read -- this is a set-up call) sizes them, and a later re-march
+        that no longer fits (the grid changed) sizes them again.  Calling it again re-marches and refreshes in place.
+
+        For the reference's own Trainer driving this model: one call after the dataset exists,
+        `model.fix_rays(dataset.rays_o_block, dataset.rays_d_block, opt.dt_gamma, opt.max_steps)`, and train_step's block render
+        (utils_wtmk_disen.py:590) takes this route."""
+        from . import raymarching
+        _, o, d = self._flatten_rays(rays_o, rays_d)
+        N = o.shape[0]
+        loop_capacity = (getattr(self, "point_capacity", None) or {}).get(N)
+        marched = getattr(self, "_marched", None) or {}
+        known = next((r for r in marched.values() if r["ptrs"] == (o.data_ptr(), d.data_ptr(), N) and r.get("fixed") is not None), None)
+        capacity = loop_capacity if loop_capacity is not None else (known["capacity"] if known is not None else None)
+        if capacity is None:
+            capacity = self._count_points(o, d, dt_gamma, max_steps)
+        rec = self.march_ahead(rays_o, rays_d, dt_gamma, max_steps, capacity=capacity)
+        if loop_capacity is None and int(rec["counter"][0]) > capacity:       # self-sized and outgrown: new buffers (nothing captured holds them)
+            capacity = raymarching.padded_point_count(int(rec["counter"][0]))
+            rec = self.march_ahead(rays_o, rays_d, dt_gamma, max_steps, capacity=capacity)
         if rec.get("fixed") is None:
             rec["fixed"] = fo.FixedPoints(rec["xyzs"], self.bound, self.encoder.tables())
         else:

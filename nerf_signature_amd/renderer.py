@@ -204,7 +204,7 @@ class NeRFRenderer(nn.Module):
     def _rays_key(o, d):
         return (o.data_ptr(), o._version, d.data_ptr(), d._version, o.shape[0])
 
-    def march_ahead(self, rays_o, rays_d, dt_gamma=0, max_steps=1024, perturb=False, phase="all"):
+    def march_ahead(self, rays_o, rays_d, dt_gamma=0, max_steps=1024, perturb=False, phase="all", capacity=None):
         """March the training samples of these rays now, for a render issued later with the same (unmodified) ray tensors.
 
         The march needs the rays and the occupancy grid only -- nothing a training step updates -- so a loop that knows its next
@@ -219,8 +219,9 @@ class NeRFRenderer(nn.Module):
         if not hasattr(self, "_marched"):
             self._marched = {}
         prefix, o, d = self._flatten_rays(rays_o, rays_d)
-        capacity = getattr(self, "point_capacity", None)
-        capacity = capacity.get(o.shape[0]) if capacity else None
+        if capacity is None:      # (an explicit capacity: NeRFNetwork.fix_rays sizing its own buffers)
+            capacity = getattr(self, "point_capacity", None)
+            capacity = capacity.get(o.shape[0]) if capacity else None
         if capacity is None or not o.is_cuda:
             raise RuntimeError("march_ahead needs point_capacity for this ray count (see trainer.GraphedWatermarkLoop.prepare) and CUDA rays")
         rec = next((r for r in self._marched.values() if r["ptrs"] == (o.data_ptr(), d.data_ptr(), o.shape[0]) and r["capacity"] == capacity), None)
@@ -260,6 +261,9 @@ class NeRFRenderer(nn.Module):
         prefix, o, d = self._flatten_rays(rays_o, rays_d)
         marched = getattr(self, "_marched", None)
         marched = marched.get(self._rays_key(o, d)) if marched and self.training and force_all_rays and not perturb else None
+        if marched is not None and marched.get("fixed") is not None and not torch.cuda.is_current_stream_capturing() and \
+                marched["grid_key"] != (self.density_bitfield.data_ptr(), self.density_bitfield._version):
+            marched = self.fix_rays(o, d, *marched["fixed_args"])      # rays declared constant, but the grid they were marched through changed
         if marched is not None:
             nears, fars = marched["nears"], marched["fars"]
         else:
@@ -285,9 +289,7 @@ class NeRFRenderer(nn.Module):
         """All samples of all rays at once, then one differentiable composite (renderer_wtmk.py:280-321)."""
         if marched is not None:      # the samples were marched ahead of this step (march_ahead)
             fixed = marched.get("fixed")
-            if fixed is not None:    # rays declared constant (NeRFNetwork.fix_rays): the grid they were marched through must still be the one
-                if marched["grid_key"] != (self.density_bitfield.data_ptr(), self.density_bitfield._version) and not torch.cuda.is_current_stream_capturing():
-                    self.fix_rays(o, d, *marched["fixed_args"])
+            if fixed is not None:    # rays declared constant (NeRFNetwork.fix_rays): base planes and scatter plan are kept beside the samples
                 sigmas, rgbs = self(marched["xyzs"], marched["dirs"], message, fixed=fixed)
             else:
                 sigmas, rgbs = self(marched["xyzs"], marched["dirs"], message)

@@ -34,9 +34,9 @@ def test_fixed_rays_render_is_bit_identical_and_follows_its_inputs():
         clean = m.render(bo, bd, None, **KW)["image"].clone()
     from nerf_signature_amd.raymarching import padded_point_count
     n_points = int(m.step_counter[(m.local_step - 1) % 16, 0])
-    m.point_capacity = {bo.numel() // 3: padded_point_count(n_points)}
-    rec = m.fix_rays(bo, bd, dt_gamma=0, max_steps=1024)
-    assert int(rec["counter"][0]) == n_points and rec["fixed"].refreshes == 1
+    rec = m.fix_rays(bo, bd, dt_gamma=0, max_steps=1024)              # no point_capacity: sized by one counting march
+    assert int(rec["counter"][0]) == n_points and rec["capacity"] == padded_point_count(n_points) and rec["fixed"].refreshes == 1
+    assert getattr(m, "point_capacity", None) is None                  # other renders with as many rays are not capped by it
     for msg, (img, depth, grad) in zip(msgs, want):
         got = render(msg)
         assert torch.equal(got[0], img) and torch.allclose(got[1], depth, rtol=0, atol=0, equal_nan=True)
@@ -51,9 +51,7 @@ def test_fixed_rays_render_is_bit_identical_and_follows_its_inputs():
     planes_ptr = rec["fixed"].planes.data_ptr()
     with torch.no_grad():
         m.encoder.embeddings[15].weight.mul_(0.5)
-        m.point_capacity = None
         want2 = m.render(bo.clone(), bd.clone(), msgs[0], **KW)["image"].clone()    # (fresh tensors: the ordinary path)
-        m.point_capacity = {bo.numel() // 3: padded_point_count(n_points)}
         got2 = m.render(bo, bd, msgs[0], **KW)["image"]
     assert rec["fixed"].refreshes == 2 and rec["fixed"].planes.data_ptr() == planes_ptr
     assert torch.equal(got2, want2) and not torch.equal(got2, want[0][0])
@@ -65,19 +63,25 @@ def test_fixed_rays_render_is_bit_identical_and_follows_its_inputs():
         m.density_grid.copy_(grid)
         from nerf_signature_amd import raymarching
         m.density_bitfield.copy_(raymarching.packbits(m.density_grid, 10.0))
-        m.point_capacity = None
         want3 = m.render(bo.clone(), bd.clone(), msgs[0], **KW)["image"].clone()
-        m.point_capacity = {bo.numel() // 3: padded_point_count(n_points)}
         got3 = m.render(bo, bd, msgs[0], **KW)["image"]
     assert rec["fixed"].refreshes == 3 and torch.equal(got3, want3) and not torch.equal(got3, got2)
+    # ... and a grid with MORE occupied cells than the buffers were sized for: sized again (new buffers), nothing dropped
+    with torch.no_grad():
+        m.density_grid.fill_(100.0)
+        m.density_bitfield.copy_(raymarching.packbits(m.density_grid, 10.0))
+        want3b = m.render(bo.clone(), bd.clone(), msgs[0], **KW)["image"].clone()
+        got3b = m.render(bo, bd, msgs[0], **KW)["image"]
+        rec = next(r for r in m._marched.values() if r.get("fixed") is not None)
+    assert rec["capacity"] > padded_point_count(n_points) and int(rec["counter"][0]) <= rec["capacity"] and torch.equal(got3b, want3b)
+    refreshes = rec["fixed"].refreshes
 
     # the rays change in place: they drop out of the cache by themselves (matched by address AND version)
     with torch.no_grad():
         bd.copy_(torch.nn.functional.normalize(bd + 0.01, dim=-1))
-        m.point_capacity = None
         want4 = m.render(bo.clone(), bd.clone(), msgs[0], **KW)["image"].clone()
         got4 = m.render(bo, bd, msgs[0], **KW)["image"]
-    assert rec["fixed"].refreshes == 3 and torch.equal(got4, want4)
+    assert rec["fixed"].refreshes == refreshes and torch.equal(got4, want4)
 
 
 def test_fixed_block_cache_trains_like_the_loop_that_recomputes():

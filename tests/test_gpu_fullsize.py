@@ -143,3 +143,35 @@ def test_full_workload_field_and_composite_properties(workload, marched):
     g_rgb0 = torch.zeros_like(rgb_g).double().index_put_((idx[valid],), cg.grad[valid], accumulate=True)
     rel = lambda a, b: float((a.double() - b).norm() / b.norm())
     assert rel(sig_g.grad, g_sig0) < 1e-3 and rel(rgb_g.grad, g_rgb0) < 1e-3
+
+
+def test_full_workload_block_render_with_kept_planes_is_bit_identical(workload):
+    """The bench's 4608 block rays (1.29 M points) declared constant (NeRFNetwork.fix_rays): image, depth and weights of the render that
+    gathers only the codebook level per step == the render that recomputes all 17 levels, bit for bit, for two messages; the
+    codebook gradient agrees to the order of the sums (both routes are the fixed-point slice-binned scatter at this size)."""
+    from nerf_signature_amd import synthetic
+    m, _, _ = workload
+    bo, bd = (t.cuda() for t in synthetic.block_rays("hotdog"))
+    kw = dict(staged=False, bg_color=1, perturb=False, force_all_rays=True, dt_gamma=0, max_steps=1024)
+    gvec = torch.rand(bo.shape, device="cuda")
+    msgs = [torch.from_numpy(np.random.RandomState(s).randint(0, 2, D).astype(np.float32)) for s in (1, 2)]
+
+    def render(o, d, msg):
+        for e in m.msg_encoder.embeddings:
+            e.weight.grad = None
+        out = m.render(o, d, msg, **kw)
+        (out["image"] * gvec).sum().backward()
+        grad = m.msg_encoder.embeddings[int(msg[0])].weight.grad
+        return out["image"].detach().clone(), out["weights_sum"].detach().clone(), out["depth"].detach().clone(), grad.clone()
+
+    want = [render(bo.clone(), bd.clone(), msg) for msg in msgs]
+    rec = m.fix_rays(bo, bd, dt_gamma=0, max_steps=1024)
+    try:
+        assert int(rec["counter"][0]) > 1_250_000
+        for msg, w in zip(msgs, want):
+            got = render(bo, bd, msg)
+            assert torch.equal(got[0], w[0]) and torch.equal(got[1], w[1]) and torch.allclose(got[2], w[2], rtol=0, atol=0, equal_nan=True)
+            assert float((got[3] - w[3]).norm() / w[3].norm()) < 1e-6
+        assert rec["fixed"].refreshes == 1
+    finally:
+        m.drop_marched()
