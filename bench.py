@@ -107,13 +107,15 @@ def launch_ranks(args):
     environment), wait, exit with the worst return code.  Decided before anything touches the GPU; children are new processes, never
     an exec of one that initialised the device.  Rank 0's stdout carries the one JSON line.
 
-    A chain of attempts, each a fresh set of ranks under a watchdog; only the first one that ends well reaches stdout and the line says
-    which it was (`config.launch_attempt`).  A multi-rank run that dies or hangs would otherwise leave no scaling point at all, and
-    the modes further down the chain give up speed, not correctness:
-      0. (only with NERFSIG_CAPTURE_COLLECTIVES=try) the RCCL collectives captured INSIDE the step's hipGraph (one graph per step:
-         1.112 against 1.197 ms on a world-size-1 nccl group, profiles/r02_capture_collectives_world1.txt) -- opt-in, because one of
-         four rehearsals died in ProcessGroupNCCL's watchdog thread (an event query racing the capture);
-      1. the default: collectives BETWEEN captured segments, blocks sharded, codebook optimiser sharded from four ranks (DESIGN.md 7);
+    A chain of attempts, each a fresh set of ranks under a watchdog; only the first one that ends well -- exit code 0, which includes
+    the ranks agreeing on the values that must be replicated (`config.ranks_agree_on_replicated_values`) -- reaches stdout and the line
+    says which it was (`config.launch_attempt`).  A multi-rank run that dies or hangs would otherwise leave no scaling point at all,
+    and the modes further down the chain give up speed, not correctness:
+      0. the RCCL collectives captured INSIDE the step's hipGraph (one graph per step: 1.10-1.13 against 1.175-1.20 ms on a world-size-1
+         nccl group with all three collectives of a step, profiles/r02_capture_collectives_world1.txt).  Rehearsable on one rank only
+         here, hence the chain behind it; the one failure seen in rehearsal (ProcessGroupNCCL's watchdog thread querying the warm-up's
+         events while the step was being captured) is closed by letting the watchdog drain before the capture: 12 of 12 clean since;
+      1. collectives BETWEEN captured segments, blocks sharded, codebook optimiser sharded from four ranks (DESIGN.md 7);
       2. the same with the codebook optimiser replicated (NERFSIG_SHARD_OPTIMIZER=0: one collective less per step);
       3. blocks replicated too (NERFSIG_REPLICATE_BLOCKS=1: round 1's partitioning, one all-reduce per step), eager launches (--no-graph).
     NERFSIG_CAPTURE_COLLECTIVES=0|1 or NERFSIG_LAUNCH_FALLBACK=0 pin the first attempt's mode (no second attempt)."""
@@ -125,13 +127,13 @@ def launch_ranks(args):
             raise SystemExit(f"--gpus {n} but {have} GPU(s) visible (NERFSIG_DIST_BACKEND=gloo rehearses N ranks on fewer GPUs)")
     pinned = os.environ.get("NERFSIG_CAPTURE_COLLECTIVES")
     test_hook = os.environ.get("NERFSIG_TEST_FAIL_CAPTURED") == "1"      # (tests: the first attempt's ranks exit with code 3)
-    rehearsal = args.dry_launch or backend == "gloo"
-    watchdog = float(os.environ.get("NERFSIG_LAUNCH_WATCHDOG_S", "300"))
+    rehearsal = (args.dry_launch or backend == "gloo") and os.environ.get("NERFSIG_LAUNCH_CHAIN") != "1"   # (=1: walk the chain in a gloo rehearsal too)
+    watchdog = float(os.environ.get("NERFSIG_LAUNCH_WATCHDOG_S", "180"))
     if ((pinned in ("0", "1") or os.environ.get("NERFSIG_LAUNCH_FALLBACK") == "0" or args.no_graph or rehearsal) and not test_hook):
         rc, _ = _run_ranks(args, n, {}, None, capture_stdout=False)
         raise SystemExit(rc)
     attempts = []
-    if pinned == "try" or test_hook:
+    if pinned in (None, "", "try") or test_hook:
         attempts.append(("collectives captured inside the step's graph", {"NERFSIG_CAPTURE_COLLECTIVES": "1"}, []))
     attempts.append(("default", {"NERFSIG_CAPTURE_COLLECTIVES": "0"}, []))
     if not rehearsal:
@@ -387,6 +389,19 @@ def bench_training(args, scene, real_stdout):
     overflow = None if args.no_graph else bool(loop.overflowed())
     loss_value = float(out[5].detach())
     loss_parts = (float(out[3].detach()), float(out[4].detach()))
+    # Replicated quantities must be the same number on every rank: the watermark loss (every rank decodes the same all-gathered blocks) and
+    # the pre-summed codebook (all-reduced, or built from tables every rank updated with the same all-reduced gradient).  A run whose
+    # collectives did not do their job ends non-zero (the launcher then starts the next, more conservative attempt).
+    ranks_agree = None
+    if dist.is_initialized() and world > 1:
+        S_now = model._presum_cache[1] if getattr(model, "_presum_cache", None) else None
+        probe = torch.stack([out[4].detach().double().reshape(()), (S_now.double().abs().sum() if S_now is not None else torch.zeros((), dtype=torch.float64, device=dev))])
+        hi, lo = probe.clone(), probe.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        ranks_agree = bool(((hi - lo).abs() <= 1e-6 * hi.abs() + 1e-12).all().item()) and bool(torch.isfinite(hi).all().item())
+        if not ranks_agree:
+            print(f"[bench] rank {rank}: replicated quantities differ between the ranks (max {hi.tolist()}, min {lo.tolist()})", file=sys.stderr)
 
     if not args.no_graph:
         # the same kernels, launched eagerly so that HIP events can bracket them (live, same process, same inputs)
@@ -459,6 +474,8 @@ def bench_training(args, scene, real_stdout):
     ms = elapsed / args.steps * 1e3
 
     if rank != 0:
+        if ranks_agree is False:
+            raise SystemExit(4)
         return
     # ---- bytes.  IMPLEMENTED algorithm: the D selected codebook tables are pre-summed into one (linearity of the
     # trilinear interpolation), so a point gathers 16 base levels + 1 summed level, 8 corners x 8 B each.
@@ -504,6 +521,7 @@ def bench_training(args, scene, real_stdout):
             "codebook_optimizer": ("sharded over the ranks (each updates the tables of D/R bits, partial pre-sums all-reduced)" if getattr(loop, "opt_shard", None) else "replicated"),
             "world_size_seen_by_backend": dp.world_size(), "backend": dist.get_backend() if dist.is_initialized() else None,
             "launch_attempt": os.environ.get("NERFSIG_LAUNCH_ATTEMPT", "n/a (single process or external launcher)"),
+            "ranks_agree_on_replicated_values": ranks_agree,
             "execution": "eager" if args.no_graph else f"hipGraph replay, {len(loop.segments)} captured segment(s)" + (" with the RCCL collectives between them" if len(loop.segments) > 1 else
                                                                   (" with the RCCL collectives captured inside" if dp.exchange_active() else "")),
             "capacity_overflow": overflow, "recaptured_with_more_headroom_after_warmup": recaptured,
@@ -547,6 +565,8 @@ def bench_training(args, scene, real_stdout):
         line["config"]["fixed_blocks_variant"] = variant
     if world == 1 and not args.no_cpu_baseline and scene == "hotdog":
         line["cpu_baseline"] = cpu_baseline(model, D)
+    if ranks_agree is False:
+        raise SystemExit(4)
     emit(line, real_stdout)
 
 

@@ -641,6 +641,13 @@ class GraphedWatermarkLoop:
         import gc
         gc.collect()
         torch.cuda.synchronize()
+        if exchange_active():
+            # ProcessGroupNCCL's watchdog thread polls the events of the warm-up's collectives (every 100 ms) until it has seen them complete;
+            # an event query from that thread while this one captures killed one rehearsal in four (WorkNCCL::isCompleted raising inside
+            # Watchdog::runLoop).  Everything is complete by now: give the watchdog time to notice and empty its list.  Collectives issued
+            # under capture are not handed to the watchdog at all.
+            import time
+            time.sleep(float(os.environ.get("NERFSIG_WATCHDOG_DRAIN_S", "0.5")))
         capture_stream = torch.cuda.Stream()
         capture_stream.wait_stream(torch.cuda.current_stream())
         prev = dp.set_boundary(boundary)
