@@ -145,6 +145,47 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
     return pred_rgb, gt_rgb, content_pred_rgb, lossi, lossw, loss
 
 
+def eval_step(model, data, message, render_kwargs, render_whole=True, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce):
+    """Trainer.eval_step (utils_wtmk_disen.py:648-702) for its default configuration (3-channel images, srgb, distortion 'none').
+    render_whole=False: the watermark blocks rendered with the message, decoded, BCE against the message (+ MSE against
+    data['images_block'] when given) -- what test_bitacc evaluates; render_whole=True: the full view staged in max_ray_batch chunks
+    (`render(staged=True)`) against data['images'] -- what test_image evaluates.  The reference never calls model.eval() on these
+    paths (:832, :951), so whether the training- or the eval-mode kernels run is the caller's `model.train()` / `model.eval()`.
+    Returns (pred_rgb, pred_depth, gt_rgb, decoded_message, lossi, lossw, loss) like the reference."""
+    dev = message.device
+    decoded, gt_rgb = None, None
+    lossi, lossw, loss = (torch.zeros(1, device=dev) for _ in range(3))
+    kw = dict(render_kwargs)
+    if not render_whole:
+        out = model.render(data["rays_o_block"], data["rays_d_block"], message, staged=False, bg_color=1, perturb=False, force_all_rays=True, **kw)
+        pred_rgb, pred_depth = torch.clamp(out["image"], min=0, max=1), out["depth"]
+        decoded = model.msg_decoder(model.normalization(pred_rgb.permute(0, 3, 1, 2)))
+        gt_rgb = data.get("images_block")
+        if gt_rgb is not None:
+            lossi = ((pred_rgb - gt_rgb) ** 2).mean()
+        lossw = loss_w(decoded, message.to(decoded.device).unsqueeze(-1))
+        loss = lambda_w * lossw + lambda_i * lossi
+    else:
+        B, H, W, C = data["images"].shape
+        if C != 3:
+            raise NotImplementedError("eval_step mirrors the reference's 3-channel configuration (RGBA ground truth is blended by the reference's own Trainer)")
+        gt_rgb = data["images"]
+        out = model.render(data["rays_o"], data["rays_d"], message, staged=True, bg_color=1, perturb=False, force_all_rays=True, **kw)
+        pred_rgb = torch.clamp(out["image"].reshape(-1, H, W, 3), min=0, max=1)
+        pred_depth = out["depth"].reshape(-1, H, W)
+    return pred_rgb, pred_depth, gt_rgb, decoded, lossi, lossw, loss
+
+
+def test_step(model, data, message, render_kwargs, bg_color=None, perturb=False):
+    """Trainer.test_step (utils_wtmk_disen.py:704-722): a staged full-view render, clamped.  Returns (pred_rgb [B,H,W,3], pred_depth [B,H,W])."""
+    H, W = data["H"], data["W"]
+    out = model.render(data["rays_o"], data["rays_d"], message, staged=True, bg_color=bg_color, perturb=perturb, **dict(render_kwargs))
+    return torch.clamp(out["image"].reshape(-1, H, W, 3), min=0, max=1), out["depth"].reshape(-1, H, W)
+
+
+test_step.__test__ = False      # (not a pytest test, whatever its name)
+
+
 class WatermarkLoop:
     """Loop body of train_one_epoch (utils_wtmk_disen.py:1164-1181) for one model replica."""
 

@@ -424,6 +424,45 @@ def test_fern_like_48bit_staged_full_image_and_decoder():
     assert abs(a1.measure() - a0.measure()) <= 1.0 / D              # within one bit (north_star)
 
 
+def test_eval_step_and_test_step_mirror_the_reference_callers():
+    """trainer.eval_step / test_step (utils_wtmk_disen.py:648-722): the block branch (render, clamp, decode, BCE + MSE) and the whole-view
+    branch (staged render against the ground truth) against the oracle's renders and the stock loss arithmetic."""
+    import copy
+    from nerf_signature_amd import trainer
+    m, bitfield, C = _model()
+    P, S = _oracle_params(m, bitfield, C)
+    bo, bd, _, _, _ = _data(n_content=8, block=4)
+    msg = torch.from_numpy(cf.messages(32)[1])
+    kw = dict(dt_gamma=0, max_steps=1024, some_cli_flag=True)
+    gt_blocks = torch.rand(32, 4, 4, 3)
+    data = {"H": 400, "W": 400, "rays_o_block": bo.cuda(), "rays_d_block": bd.cuda(), "images_block": gt_blocks.cuda()}
+    with torch.no_grad():
+        pred, depth, gt, decoded, li, lw, l = trainer.eval_step(m, data, msg.cuda(), kw, render_whole=False)
+        ref = fr.render(bo, bd, msg, P, S, bg_color=1, dt_gamma=0.0, max_steps=1024)
+        img0 = ref["image"].reshape(32, 4, 4, 3).clamp(0, 1)
+        dec0 = copy.deepcopy(m.msg_decoder).cpu()(fr.normalize_img(img0.permute(0, 3, 1, 2)))
+    np.testing.assert_allclose(pred.cpu().numpy(), img0.numpy(), rtol=0, atol=1e-3)
+    np.testing.assert_allclose(decoded.cpu().numpy(), dec0.numpy(), rtol=0, atol=2e-3)
+    lw0 = torch.nn.functional.binary_cross_entropy_with_logits(dec0 * 10.0, msg.unsqueeze(-1))
+    li0 = ((img0 - gt_blocks) ** 2).mean()
+    assert abs(float(lw) - float(lw0)) < 2e-3 and abs(float(li) - float(li0)) < 1e-3 and abs(float(l) - float(lw0 + li0)) < 3e-3
+    assert gt is data["images_block"] and pred.shape == (32, 4, 4, 3) and depth.shape == (32, 4, 4)
+    # whole view (reduced): staged in chunks, ground truth handed back, no decoder on this branch
+    H, W = 20, 24
+    pose, _, _ = cf.orbit_rays(1, seed=3)
+    intr = np.array([30.0, 30.0, W / 2, H / 2], np.float32)
+    o, d = fr.get_rays(torch.from_numpy(pose)[None], intr, H, W)
+    images = torch.rand(1, H, W, 3)
+    whole = {"H": H, "W": W, "rays_o": o.cuda(), "rays_d": d.cuda(), "images": images.cuda()}
+    with torch.no_grad():
+        pred, depth, gt, decoded, li, lw, l = trainer.eval_step(m, whole, msg.cuda(), dict(kw, max_ray_batch=100), render_whole=True)
+        ref = fr.render(o, d, msg, P, S, staged=True, max_ray_batch=100, bg_color=1, dt_gamma=0.0, max_steps=1024)
+        t_rgb, t_depth = trainer.test_step(m, whole, msg.cuda(), dict(kw, max_ray_batch=100), bg_color=1)
+    assert decoded is None and float(l) == 0.0 and pred.shape == (1, H, W, 3) and depth.shape == (1, H, W) and gt is whole["images"]
+    np.testing.assert_allclose(pred.cpu().numpy().reshape(-1, 3), ref["image"].clamp(0, 1).numpy().reshape(-1, 3), rtol=0, atol=1e-3)
+    assert torch.equal(t_rgb, pred) and torch.equal(torch.nan_to_num(t_depth), torch.nan_to_num(depth))
+
+
 def test_training_trajectory_psnr_and_bit_accuracy_track_the_oracle():
     """north_star: "rendered PSNR and 32-bit watermark bit-accuracy matching the reference within 0.1 dB / 1 bit".  Both sides
     train the codebook + decoder for six steps of the reference's loop body (fresh message per step, Adam(0.9, 0.99, eps 1e-15),
