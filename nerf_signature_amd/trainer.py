@@ -311,6 +311,8 @@ class GraphedWatermarkLoop:
         `step(..., data=...)` still works -- it re-marches before the replay, un-overlapped.  The content render's march stays
         at the head of its own step on the side stream: next to the optimiser as well, the two marches took longer than the
         optimiser and the pre-sum lost its cover."""
+        if march_ahead is None and os.environ.get("NERFSIG_MARCH_AHEAD") in ("0", "1"):
+            march_ahead = os.environ["NERFSIG_MARCH_AHEAD"] == "1"
         self.march_ahead = overlap_content if march_ahead is None else bool(march_ahead)
         # fixed_blocks (NERFSIG_FIXED_BLOCKS=1; off by default): the watermark-block rays are one pair of tensors per dataset
         # (nerf/provider_wtmk.py:442-494) and everything their field pass reads except the codebook is frozen in this stage, so the
