@@ -20,5 +20,19 @@ for key in ("k_encode_planes", "k_field_fwd", "k_field_bwd", "k_scatter_binned",
     for k, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
         print(f"{key:22s} grid={k[0]:>9s} wg={k[1]:>5s} n={len(v):4d} avg={sum(v)/len(v):8.1f} min={min(v):8.1f} max={max(v):8.1f}")
 PY
+python - $out >> gpurun_out/${tag}_summary.txt <<'PY'
+import csv, glob, sys
+f = sorted(glob.glob(sys.argv[1] + "/**/*_kernel_trace.csv", recursive=True))[-1]
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+enc = [r for r in rows if "k_encode_planes" in r["Kernel_Name"]]
+big = max(int(r.get("Grid_Size_X") or r.get("Grid_Size")) for r in enc if int(r.get("Grid_Size_X") or r.get("Grid_Size")) < 12000000)
+seq = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in enc if int(r.get("Grid_Size_X") or r.get("Grid_Size")) == big]
+print(f"\n# k_encode_planes, the block render's launch (grid {big}), every launch of the run in order, us:")
+print("#   prepare (sizing + 3 warm-up) | 25 graph replays (beside the content render's kernels: inflated) | the 5 EAGER launches bench.py's HIP events bracket | the variant's set-up")
+print("  " + " ".join(f"{v:.0f}" for v in seq))
+if len(seq) >= 34:
+    eager = seq[29:34]
+    print(f"#   eager launches {eager}: avg {sum(eager) / 5:.1f} us  (compare roofline.avg_launch_s of the bench line of the same box)")
+PY
 python tools/timeline.py $out k_adam_prepare 8 > gpurun_out/${tag}_timeline_graph_replay.txt
 cp $(ls $out/*/*_kernel_stats.csv | tail -1) gpurun_out/${tag}_kernel_stats.csv
