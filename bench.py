@@ -128,7 +128,7 @@ def launch_ranks(args):
     pinned = os.environ.get("NERFSIG_CAPTURE_COLLECTIVES")
     test_hook = os.environ.get("NERFSIG_TEST_FAIL_CAPTURED") == "1"      # (tests: the first attempt's ranks exit with code 3)
     rehearsal = (args.dry_launch or backend == "gloo") and os.environ.get("NERFSIG_LAUNCH_CHAIN") != "1"   # (=1: walk the chain in a gloo rehearsal too)
-    watchdog = float(os.environ.get("NERFSIG_LAUNCH_WATCHDOG_S", "180"))
+    watchdog = float(os.environ.get("NERFSIG_LAUNCH_WATCHDOG_S", "240"))
     if ((pinned in ("0", "1") or os.environ.get("NERFSIG_LAUNCH_FALLBACK") == "0" or args.no_graph or rehearsal) and not test_hook):
         rc, _ = _run_ranks(args, n, {}, None, capture_stdout=False)
         raise SystemExit(rc)
