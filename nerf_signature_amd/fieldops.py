@@ -119,7 +119,7 @@ def pack_weights(sigma_params, color_params, out=None):
     return packed
 
 
-PLANES_MIN_POINTS = 16384  # below this the fused kernel wins (one launch, no feature round trip)
+PLANES_MIN_POINTS = int(os.environ.get("NERFSIG_PLANES_MIN", "16384"))  # below this the fused kernel wins (one launch, no feature round trip)
 # FixedPoints: field_fwd_kept (codebook level gathered inside the MLP kernel) instead of hg_encode_codebook_plane + field_fwd.  Bit-identical;
 # measured slower (0.790-0.791 against 0.779-0.784 ms per step, profiles/r02_fixed_blocks_ab.txt): the gather lengthens the latency-bound
 # MLP kernel by more than the 31 us launch it removes.  Off by default.

@@ -297,7 +297,7 @@ class GraphedWatermarkLoop:
 
     def __init__(self, model, optimizer, render_kwargs, data, lambda_w=1.0, lambda_i=1.0, lr_lambda=None, headroom=0.0, native_dense_adam=True,
                  overlap_content=True, march_ahead=None, presum_in_adam=True, stage_in_graph=True, content_headroom=None, content_ahead=None,
-                 content_sampler=None, fixed_blocks=None):
+                 content_sampler=None, fixed_blocks=None, encode_ahead=None):
         """presum_in_adam: the captured optimiser kernel also writes the pre-summed codebook of the NEXT step's message
         (opt_codebook_adam_sel_next: +9 % traffic inside an HBM-streaming kernel instead of a 128 MiB pass at the head of every step).
         The next message is handed over one step early -- `step(message_k, next_message=message_k1)`, a one-element look-ahead over
@@ -324,6 +324,19 @@ class GraphedWatermarkLoop:
             fixed_blocks = os.environ.get("NERFSIG_FIXED_BLOCKS", "0") == "1"
         self.fixed_blocks = bool(fixed_blocks)
         self._refix_pending = False
+        # encode_ahead (with march_ahead): the NEXT step's block samples are not only marched beside this step's optimiser but also pushed
+        # through the 16 base levels of the encoder and the scatter's binning passes there -- none of which reads anything a step updates
+        # (frozen base tables, positions) -- so the hash gather, the step's longest kernel and bound by L2->L1 line fills, runs in the
+        # shadow of the optimiser's HBM stream instead of at the head of the next step's critical path; that step then gathers the one
+        # level a step does change, the codebook, for these points (hg_encode_codebook_plane).  Every step still runs every kernel once:
+        # this is scheduling, not reuse across steps (that is fixed_blocks).  NERFSIG_ENCODE_AHEAD=0|1.
+        # OFF by default -- measured slower, 1.106-1.108 against 1.061-1.083 ms (profiles/r02_encode_ahead.txt): beside the optimiser the
+        # march chain that feeds the encoder is starved (its single-workgroup scan waits ~90 us on loads behind the optimiser's HBM
+        # stream), so the encoder starts when the optimiser ends; and the two do not overlap anyway (side by side 447 us, one after the
+        # other 463 us: tools/overlap_probe2.py).
+        if encode_ahead is None:
+            encode_ahead = os.environ.get("NERFSIG_ENCODE_AHEAD", "0") == "1"
+        self.encode_ahead = bool(encode_ahead) and self.march_ahead and not self.fixed_blocks
         # content_sampler (rays.DeviceRaySampler): the step draws its own content batch -- pose, pixels, rays, ground truth -- on the
         # device, inside the captured graph, from the replay count; `data` / `next_data` then carry no content part
         self.content_sampler = content_sampler
@@ -402,6 +415,8 @@ class GraphedWatermarkLoop:
         self.model._packed()
         if self.fixed_blocks and self.graphs is not None:
             self._fix_blocks()       # the base tables may have been overwritten: the kept feature planes, in place
+        elif self.encode_ahead and self.graphs is not None:
+            self._march_ahead()      # ... likewise the planes the last replay encoded ahead for the next one
 
     @torch.no_grad()
     def gather_codebook(self, optimizer_state=True):
@@ -503,6 +518,8 @@ class GraphedWatermarkLoop:
         block_o, block_d, _ = local_blocks(wm)       # (this rank's shard of the blocks when they are split over the ranks)
         if self.fixed_blocks:                        # marched once, outside the step (_fix_blocks)
             self.marched = self.marched[:1]
+        elif self.encode_ahead:                      # march + base-level planes + scatter plan of the next step's block samples
+            self.marched = (self.model.fix_rays(block_o, block_d, *args),)
         else:
             self.marched = (self.model.march_ahead(block_o, block_d, *args),)
         if self.content_ahead:
@@ -645,6 +662,8 @@ class GraphedWatermarkLoop:
             if not self.march_ahead:
                 raise ValueError("fixed_blocks needs march_ahead=True (the kept samples live in the march-ahead record)")
             self._fix_blocks()       # before the warm-up, so that it runs -- and loads -- the kernels the captured step will use
+        elif self.encode_ahead:
+            self._march_ahead()      # likewise: the warm-up then renders the blocks from planes encoded ahead, as the captured step will
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
