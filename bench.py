@@ -43,8 +43,8 @@ T_BYTES = (1 << 19) * 2 * 4                      # one [2^19, 2] fp32 table
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--config", choices=["hotdog", "counter", "fern"], default="hotdog", help="hotdog = the headline (BASELINE configs 2/4); counter / fern = secondary lines")
     ap.add_argument("--poses", type=int, default=8, help="pre-rendered clean views the per-step poses rotate through")
