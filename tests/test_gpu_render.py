@@ -792,3 +792,53 @@ def test_fused_staged_render_equals_chunked(monkeypatch):
         monkeypatch.setenv("NERFSIG_STAGED_FUSED", "1")
         out = m.render(o, d, msg, **kw)
     assert torch.equal(out["image"].detach(), i0)
+
+
+@pytest.mark.parametrize("D", [16, 48])
+def test_other_message_lengths_train_step_and_captured_loop(D):
+    """--message_dim is a CLI option of the reference (main_nerf_wtmk.py); the north_star names 32 and (config 5) 48 bits.  One train_step at
+    D bits against the oracle (point counts exact, images / losses 1e-3, shared gradient in aggregate), then the captured loop against the eager
+    loop for three steps at that D (96 table pointers at D = 48 go through the by-value pointer tables of the pre-sum / Adam kernels)."""
+    import copy
+    from nerf_signature_amd import trainer
+    from nerf_signature_amd.optim import CodebookAdam
+    m, bitfield, C = _model(D=D)
+    P, S = _oracle_params(m, bitfield, C)
+    bo, bd, co, cd, gt = _data(n_content=200, block=5)
+    reps = (D + 31) // 32
+    bo, bd = torch.cat([bo] * reps)[:D].contiguous(), torch.cat([bd + 0.002 * k for k in range(reps)])[:D].contiguous()
+    bd = torch.nn.functional.normalize(bd, dim=-1)
+    msg = torch.from_numpy(cf.messages(D)[2])
+    dec_cpu = copy.deepcopy(m.msg_decoder).cpu()
+    ref = fr.train_step(bo, bd, co, cd, gt, msg, P, S, dec_cpu, dt_gamma=0.0, max_steps=1024)
+    ref["loss"].backward()
+    data = {"watermark": {"rays_o_block": bo.cuda(), "rays_d_block": bd.cuda()}, "content": {"rays_o": co.cuda(), "rays_d": cd.cuda(), "images": gt.cuda()}}
+    out = trainer.train_step(m, data, msg, dict(dt_gamma=0, max_steps=1024))
+    out[5].backward()
+    assert int(m.step_counter[0, 0]) == ref["block"]["n_points"] and int(m.step_counter[1, 0]) == ref["content"]["n_points"]
+    assert out[0].shape == (D, 5, 5, 3)
+    np.testing.assert_allclose(out[0].detach().cpu().numpy(), ref["pred_rgb"].detach().numpy(), rtol=0, atol=1e-3)
+    np.testing.assert_allclose(out[2].detach().cpu().numpy(), ref["content_pred_rgb"].detach().numpy(), rtol=0, atol=1e-3)
+    for k, name in ((3, "lossi"), (4, "lossw"), (5, "loss")):
+        np.testing.assert_allclose(float(out[k].detach()), float(ref[name].detach()), rtol=1e-3, atol=1e-3)
+    bits = [int(v) for v in msg]
+    for i in (0, D - 1):      # first and last bit: selected table has the shared gradient, its partner none
+        g1, g0 = m.msg_encoder.embeddings[2 * i + bits[i]].weight.grad, P["cb_tables"][2 * i + bits[i]].grad
+        assert float((g1.cpu() - g0).norm() / g0.norm()) < 5e-2
+        assert m.msg_encoder.embeddings[2 * i + 1 - bits[i]].weight.grad is None
+    # captured loop == eager loop at this D
+    msgs = [torch.from_numpy(np.random.RandomState(40 + s).randint(0, 2, D).astype(np.float32)) for s in range(3)]
+    losses = {}
+    for graphed in (False, True):
+        torch.manual_seed(0)
+        m2, _, _ = _model(D=D)
+        opt = CodebookAdam(m2.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, capturable=graphed)
+        if graphed:
+            loop = trainer.GraphedWatermarkLoop(m2, opt, dict(dt_gamma=0, max_steps=1024), data)
+            held = [loop.step(msg_k, next_message=msgs[k + 1] if k + 1 < 3 else None)[5].detach().clone() for k, msg_k in enumerate(msgs)]
+            losses[graphed] = [float(v) for v in held]
+            assert not loop.overflowed()
+        else:
+            loop = trainer.WatermarkLoop(m2, opt, dict(dt_gamma=0, max_steps=1024))
+            losses[graphed] = [float(loop.step(data, msg_k)[5].detach()) for msg_k in msgs]
+    np.testing.assert_allclose(losses[True], losses[False], rtol=2e-3, atol=2e-4)
