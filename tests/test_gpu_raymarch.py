@@ -59,7 +59,8 @@ def test_sph_from_ray(rmod):
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=2e-6)
 
 
-@pytest.mark.parametrize("bound,dt_gamma,n", [(1.0, 0.0, 4096), (2.0, 0.0, 2048), (2.0, 1 / 128, 2048), (1.0, 0.0, 77)])
+@pytest.mark.parametrize("bound,dt_gamma,n", [(1.0, 0.0, 4096), (2.0, 0.0, 2048), (2.0, 1 / 128, 2048), (1.0, 0.0, 77), (8.0, 1 / 128, 1024), (16.0, 1 / 256, 1024),
+                                              (1.5, 0.0, 1024)])
 def test_march_train_counts_and_points_bit_exact(rmod, bound, dt_gamma, n):
     _, bitfield, C, o, d = _scene(n, bound)
     aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)

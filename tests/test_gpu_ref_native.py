@@ -103,7 +103,9 @@ def test_sph_from_ray_vs_reference(rmod):
 
 
 MARCH_CASES = [(1.0, 0.0, 4096, 1024, False), (2.0, 0.0, 2048, 1024, False), (2.0, 1 / 128, 2048, 1024, False), (1.0, 0.0, 77, 1024, False),
-               (1.0, 0.0, 2048, 1024, True), (2.0, 1 / 128, 1024, 1024, True), (1.0, 0.0, 1024, 256, False), (1.0, 0.0, 512, 64, False)]
+               (1.0, 0.0, 2048, 1024, True), (2.0, 1 / 128, 1024, 1024, True), (1.0, 0.0, 1024, 256, False), (1.0, 0.0, 512, 64, False),
+               # more cascades (bound 8 -> 4, bound 16 -> 5: the 360-degree scenes' settings), a bound that is not a power of two
+               (8.0, 1 / 128, 1024, 1024, False), (16.0, 1 / 256, 1024, 1024, True), (1.5, 0.0, 1024, 1024, False)]
 
 
 @pytest.mark.parametrize("bound,dt_gamma,n,max_steps,perturb", MARCH_CASES)
