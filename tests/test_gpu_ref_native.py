@@ -79,7 +79,7 @@ def test_morton_packbits_vs_reference(rmod):
         np.testing.assert_array_equal(orm.packbits(grid, thresh), _np(want))
 
 
-@pytest.mark.parametrize("bound", [1.0, 2.0])
+@pytest.mark.parametrize("bound", [1.0, 2.0, 8.0])
 def test_near_far_vs_reference(rmod, bound):
     _, _, _, o, d = _scene(4096, bound)
     d[5] = (0, 1, 0)     # axis-parallel ray (infinite reciprocal)
@@ -200,7 +200,7 @@ def test_composite_train_vs_reference(rmod):
         np.testing.assert_allclose(gs0, _np(gs_r), rtol=1e-4, atol=2e-6 * max(1.0, 3.0 / scale))
 
 
-@pytest.mark.parametrize("bound,dt_gamma", [(1.0, 0.0), (2.0, 1 / 128)])
+@pytest.mark.parametrize("bound,dt_gamma", [(1.0, 0.0), (2.0, 1 / 128), (8.0, 1 / 128)])
 def test_eval_loop_vs_reference(rmod, bound, dt_gamma):
     """kernel_march_rays / kernel_composite_rays (raymarching.cu:701-914) driven like renderer_wtmk.py:335-367, reference and product
     side by side: sample bursts and alive lists bit-exact every round, accumulated outputs within summation-order tolerance."""
