@@ -339,6 +339,9 @@ def bench_training(args, scene, real_stdout):
     optimizer = CodebookAdam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, **({} if args.no_graph else ({"capturable": True} if args.no_fused_adam else {"fused": True, "capturable": True})))
     if args.no_graph:
         loop = trainer.WatermarkLoop(model, optimizer, render_kwargs, side_stream=None if args.no_overlap else torch.cuda.Stream())
+        if args.fixed_blocks:      # the eager loop (what the reference's own Trainer drives): the one-call form of the same declaration
+            blk_o, blk_d, _ = trainer.local_blocks(data["watermark"])
+            model.fix_rays(blk_o, blk_d, render_kwargs["dt_gamma"], render_kwargs["max_steps"])
     else:
         loop = trainer.GraphedWatermarkLoop(model, optimizer, render_kwargs, data, overlap_content=not args.no_overlap, content_headroom=0.25, content_sampler=sampler,
                                             fixed_blocks=True if args.fixed_blocks else None)

@@ -153,3 +153,31 @@ def test_kept_forward_in_one_launch_equals_plane_plus_forward(monkeypatch):
         assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[3], want[3])
         clean = fo.field_forward(xyzs, dirs, 1.0, base, None, packed, fixed=kept)          # no codebook: base planes only
         assert torch.equal(clean[0], fo.field_forward(xyzs, dirs, 1.0, base, None, packed, planes=True)[0])
+
+
+def test_fixed_rays_under_autocast_and_a_scaled_loss():
+    """The reference's Trainer wraps train_step in autocast(fp16) and scales the loss by 65536 (utils_wtmk_disen.py:1172-1178): the kept route
+    under both equals the recomputing route under both (the kept scatter plan's largest-gradient word is cleared every step, so a step with
+    a 65536-fold gradient does not coarsen the fixed-point scale of the next one)."""
+    m, _, _ = _model()
+    bo, bd, _, _, _ = _data(n_content=64)
+    bo, bd = bo.cuda(), bd.cuda()
+    msg = torch.from_numpy(cf.messages(32)[2])
+    gvec = torch.rand(32, 6, 6, 3, device="cuda")
+    tab = m.msg_encoder.embeddings[int(msg[0])].weight
+
+    def run(o, d, scale):
+        tab.grad = None
+        with torch.autocast("cuda", dtype=torch.float16):
+            out = m.render(o, d, msg, **KW)
+        ((out["image"].float() * gvec).sum() * scale).backward()
+        return out["image"].detach().clone(), tab.grad.clone()
+
+    want_big, want_one = run(bo.clone(), bd.clone(), 65536.0), run(bo.clone(), bd.clone(), 1.0)
+    rec = m.fix_rays(bo, bd, dt_gamma=0, max_steps=1024)
+    got_big, got_one = run(bo, bd, 65536.0), run(bo, bd, 1.0)          # the large step first: its scale must not leak into the next
+    assert rec["fixed"].refreshes == 1
+    for got, want in ((got_big, want_big), (got_one, want_one)):
+        assert got[0].dtype == want[0].dtype and torch.equal(got[0], want[0])
+        assert bool(torch.isfinite(got[1]).all()) and float((got[1] - want[1]).norm() / want[1].norm()) < 1e-5
+    assert float((got_big[1] / 65536.0 - got_one[1]).norm() / got_one[1].norm()) < 1e-4
