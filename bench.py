@@ -487,15 +487,25 @@ def bench_training(args, scene, real_stdout):
     # ---- bytes.  IMPLEMENTED algorithm: the D selected codebook tables are pre-summed into one (linearity of the
     # trilinear interpolation), so a point gathers 16 base levels + 1 summed level, 8 corners x 8 B each.
     gather_impl = 16 * 64 + 64                     # 1088 B/point actually gathered by k_encode_planes
+    split_encoder_early = bool(getattr(loop, "encode_ahead", False) or getattr(loop, "fixed_blocks", False))
     split_encoder = bool(getattr(loop, "encode_ahead", False) or getattr(loop, "fixed_blocks", False)) and enc_big != 0
     gather_launch = 16 * 64 if split_encoder else gather_impl   # encode-ahead: the timed launch gathers the 16 base levels; the codebook level is its own 64 B/point launch
     gather_ref = 16 * 64 + 64 * D                  # the reference algorithm's D separate codebook gathers (side value only)
     achieved = pts_big * gather_launch / enc_s if enc_s > 0 else 0.0
-    traffic = None
+    traffic, l1_model = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:   # HBM bytes per launch of the same kernel on the same inputs, from a separate rocprofv3 --pmc run (profiles/)
-            traffic = json.load(open(pmc)).get("k_encode_planes_hbm_bytes_per_launch")
+            counters = json.load(open(pmc))
+            traffic = counters.get("k_encode_planes_hbm_bytes_per_launch")
+            # what actually bounds the launch: the CU's vector-L1 pipe looks up one line per clock and fills a missing one
+            # in 2.4 clk (tools/micro/gather_rate.hip); counters of the block render's launch (17 levels, 1.29 M points)
+            enc = counters.get("k_encode_planes", {})
+            if enc.get("TCP_TOTAL_CACHE_ACCESSES") and enc.get("TCP_TCC_READ_REQ") and enc_big and not split_encoder_early:
+                clk = (enc["TCP_TOTAL_CACHE_ACCESSES"] + 1.4 * enc["TCP_TCC_READ_REQ"]) / 256.0
+                l1_model = {"tag_lookups_per_launch": enc["TCP_TOTAL_CACHE_ACCESSES"], "misses_to_L2_per_launch": enc["TCP_TCC_READ_REQ"],
+                            "model_s_at_2.4GHz": clk / 2.4e9, "model": "(lookups x 1 clk + misses x 1.4 clk) / 256 CUs",
+                            "measured_over_model": (enc_s / (clk / 2.4e9)) if enc_s > 0 else None}
         except Exception:
             traffic = None
     # whole step, implemented bytes: per point forward 1088 gathered + 32 (xyz, dir, deltas) + 16 (sigma, rgb); backward 64 (upstream
@@ -552,6 +562,7 @@ def bench_training(args, scene, real_stdout):
             "observed_limiter": "not HBM: the working set (64 MiB base + 4 MiB pre-sum) is L2/MALL-resident; PMC shows the texture-address path busy ~85 % and "
                                 "the L2->L1 line fills (~4 GB per launch) as the limiter (profiles/*pmc_encode*)",
             "frac_hbm_counters": (traffic / enc_s / HBM_PEAK) if (traffic and enc_s > 0) else None,
+            "l1_lookup_rate_model": l1_model,
             "reference_algorithm": {"bytes_per_point": gather_ref, "note": "SURVEY.md 8(d) formula (D separate codebook gathers); the kernel does not move these bytes, "
                                     "so this is a speed-up factor over a literal implementation, NOT a roofline fraction",
                                     "equivalent_GBps": (pts_big * gather_ref / enc_s / 1e9) if enc_s > 0 else 0.0},
