@@ -201,6 +201,7 @@ class NeRFNetwork(NeRFRenderer):
         else:
             rec["fixed"].refresh(rec["xyzs"], self.encoder.tables())
         rec["fixed_args"] = (dt_gamma, max_steps)
+        rec["rays_ref"] = (rays_o, rays_d)      # the cache is keyed by address + version: keep the tensors alive, or a later allocation could take the address
         rec["grid_key"] = (self.density_bitfield.data_ptr(), self.density_bitfield._version)
         return rec
 
