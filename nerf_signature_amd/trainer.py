@@ -318,7 +318,7 @@ class GraphedWatermarkLoop:
         # (nerf/provider_wtmk.py:442-494) and everything their field pass reads except the codebook is frozen in this stage, so the
         # loop marches them ONCE, keeps the base-level feature planes and the scatter plan (NeRFNetwork.fix_rays / fieldops.FixedPoints)
         # and a step only gathers the codebook level for them -- same kernels' results, bit-identical training
-        # (test_fixed_block_cache_trains_bit_identically).  New block rays (`data` / `next_data` with a "watermark" part), a loaded
+        # (tests/test_gpu_fixed.py).  New block rays (`data` / `next_data` with a "watermark" part), a loaded
         # checkpoint (invalidate) or a re-sized capture refresh the kept buffers in place before the next replay.
         if fixed_blocks is None:
             fixed_blocks = os.environ.get("NERFSIG_FIXED_BLOCKS", "0") == "1"
