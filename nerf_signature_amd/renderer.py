@@ -85,8 +85,7 @@ class _CompositeFinish(torch.autograd.Function):
         ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, image, bg)
         ctx.dims = (M, N, float(T_thresh), stride)
         ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(depth_out)     # the depth gradient does not propagate (raymarching.py:275)
-        return weights_sum, depth_out, image_out
+        return weights_sum, depth_out, image_out      # (depth stays differentiable as in the reference; its gradient is ignored below, raymarching.py:275)
 
     @staticmethod
     def backward(ctx, g_ws, g_depth, g_image):
