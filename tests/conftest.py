@@ -11,6 +11,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The oracle's tensor ops are small; on a many-core host (a GPU box reports 256 logical CPUs of which a job may use a share) torch's default
+    # of one intra-op thread per logical CPU oversubscribes them by an order of magnitude (the trajectory test: 267 s against ~35 s on 8 cores).
+    import torch
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(allowed, 16)))
 
 
 @pytest.fixture(scope="session")

@@ -506,11 +506,14 @@ def test_training_trajectory_psnr_and_bit_accuracy_track_the_oracle():
     m.eval()
     dec_cpu.eval()
     psnr1, psnr0, acc1, acc0 = PSNRMeter(), PSNRMeter(), BIT_ACC(), BIT_ACC()
+    held1, held0 = [], []        # the watermarked content renders of the three held-out messages (used again below)
     with torch.no_grad():
         for s in range(3):
             msg = torch.from_numpy(np.random.RandomState(90 + s).randint(0, 2, 32).astype(np.float32))
             img1 = m.render(co.cuda(), cd.cuda(), msg, staged=False, bg_color=1, perturb=False, **kw)["image"].cpu()
             img0 = fr.render(co, cd, msg, P, S, training=False, bg_color=1, **kw)["image"]
+            held1.append(img1.double())
+            held0.append(img0.double())
             psnr1.update(img1, gt)
             psnr0.update(img0, gt)
             blk1 = m.render(bo.cuda(), bd.cuda(), msg, staged=False, bg_color=1, perturb=False, **kw)["image"]
@@ -525,15 +528,10 @@ def test_training_trajectory_psnr_and_bit_accuracy_track_the_oracle():
     # PSNR of the watermarked render against each side's OWN clean render measures the watermark's perturbation itself (fp64 MSE):
     # a rendering error of the order of the perturbation moves it by whole dB.
     with torch.no_grad():
-        wm1, wm0 = [], []
-        for s in range(3):
-            msg = torch.from_numpy(np.random.RandomState(90 + s).randint(0, 2, 32).astype(np.float32))
-            c1 = m.render(co.cuda(), cd.cuda(), None, staged=False, bg_color=1, perturb=False, **kw)["image"].cpu().double()
-            c0 = fr.render(co, cd, None, P, S, training=False, bg_color=1, **kw)["image"].double()
-            i1 = m.render(co.cuda(), cd.cuda(), msg, staged=False, bg_color=1, perturb=False, **kw)["image"].cpu().double()
-            i0 = fr.render(co, cd, msg, P, S, training=False, bg_color=1, **kw)["image"].double()
-            wm1.append(-10 * np.log10(float(((i1 - c1) ** 2).mean())))
-            wm0.append(-10 * np.log10(float(((i0 - c0) ** 2).mean())))
+        c1 = m.render(co.cuda(), cd.cuda(), None, staged=False, bg_color=1, perturb=False, **kw)["image"].cpu().double()     # (no message: the same for all three)
+        c0 = fr.render(co, cd, None, P, S, training=False, bg_color=1, **kw)["image"].double()
+        wm1 = [-10 * np.log10(float(((i1 - c1) ** 2).mean())) for i1 in held1]
+        wm0 = [-10 * np.log10(float(((i0 - c0) ** 2).mean())) for i0 in held0]
     print("PSNR of the watermarked render vs the clean render (dB): gpu", np.round(wm1, 3), "oracle", np.round(wm0, 3))
     assert all(20.0 < v < 80.0 for v in wm0)                      # a real, visible-in-fp32 perturbation
     np.testing.assert_allclose(wm1, wm0, rtol=0, atol=0.1)        # dB
