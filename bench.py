@@ -233,7 +233,16 @@ def cpu_baseline(model, D):
     from oracle import field_ref as fr
     host_cpus = os.cpu_count() or 1
     allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host_cpus
-    torch.set_num_threads(max(1, min(allowed, 32)))
+    quota = None
+    try:      # the container's CPU share (cgroup v2 cpu.max = "<quota> <period>", or "max"): threads beyond it only take turns
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else max(1, int(int(q) / int(per)))
+    except Exception:
+        pass
+    allowed = min(allowed, quota) if quota else allowed
+    # one intra-op thread per CPU this process may really use, at most 32 (same box, tools/cpu_baseline_threads.py: 4 threads 1.7e3 rays/s,
+    # 8: 3.0e3, 16 = the box's share: 4.4e3, 32: 2.1e3, 64: 1.1e3, 128: 1.7e2 -- the oracle's tensor ops are small)
+    torch.set_num_threads(int(os.environ.get("NERFSIG_CPU_THREADS", 0)) or max(1, min(allowed, 32)))
     bo, bd = synthetic.block_rays("hotdog")
     bo, bd = bo[:, :4, :4].contiguous(), bd[:, :4, :4].contiguous()
     co, cd = synthetic.content_rays("hotdog", 4096, seed=0)
@@ -277,7 +286,7 @@ def cpu_baseline(model, D):
     return {"value": a["rays_per_s"], "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"run_cuda shape: 1 warm-up + 3 timed train steps (fwd+bwd, no optimiser) of {a['rays']} rays = the full 4096-ray content batch + "
                       f"32 blocks at 4x4 of their 12x12 rays (block rays subsampled 1/9), {a['points']} points, {np.mean(a['batch_s']):.1f} s per step",
-            "points_per_s": a["points_per_s"], "host_cpus": host_cpus, "cpus_allowed": allowed, "torch_threads": torch.get_num_threads(),
+            "points_per_s": a["points_per_s"], "host_cpus": host_cpus, "cpus_allowed": allowed, "cgroup_cpu_quota": quota, "torch_threads": torch.get_num_threads(),
             "run_shape": {"value": b["rays_per_s"], "unit": "rays/s", "points_per_s": b["points_per_s"],
                           "sample": f"run shape (512 uniform samples/ray, renderer_wtmk.py:125-253): 1 warm-up + 3 timed fwd+bwd batches of 512 of the 4096 content rays "
                                     f"(1/8), {b['points']} points, {np.mean(b['batch_s']):.1f} s per batch"},

@@ -15,6 +15,11 @@ def pytest_configure(config):
     # of one intra-op thread per logical CPU oversubscribes them by an order of magnitude (the trajectory test: 267 s against ~35 s on 8 cores).
     import torch
     allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:      # the container's CPU share (cgroup v2)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        allowed = allowed if q == "max" else min(allowed, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
     torch.set_num_threads(max(1, min(allowed, 16)))
 
 
