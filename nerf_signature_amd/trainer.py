@@ -324,6 +324,7 @@ class GraphedWatermarkLoop:
             fixed_blocks = os.environ.get("NERFSIG_FIXED_BLOCKS", "0") == "1"
         self.fixed_blocks = bool(fixed_blocks)
         self._refix_pending = False
+        self._kept_key = None
         # encode_ahead (with march_ahead): the NEXT step's block samples are not only marched beside this step's optimiser but also pushed
         # through the 16 base levels of the encoder and the scatter's binning passes there -- none of which reads anything a step updates
         # (frozen base tables, positions) -- so the hash gather, the step's longest kernel and bound by L2->L1 line fills, runs in the
@@ -533,6 +534,7 @@ class GraphedWatermarkLoop:
         rec = self.model.fix_rays(block_o, block_d, kw.get("dt_gamma", 0), kw.get("max_steps", 1024))
         self.marched = (rec,) + tuple(self.marched[1:] if self.marched else ())
         self._refix_pending = False
+        self._kept_key = self._kept_inputs_key()
 
     def _optimise_and_march(self):
         """The optimiser step and, beside it on the side stream, the march of the next step's samples."""
@@ -560,7 +562,14 @@ class GraphedWatermarkLoop:
         a, b = self.model.step_counter[self.capacity_rows, 0].tolist()
         return (a, b) if self.side_stream is None else (b, a)     # issue order: with a side stream the content render comes first
 
+    def _kept_inputs_key(self):
+        """Versions of everything the kept planes / marched samples were computed from (in-place writes through torch bump them)."""
+        m = self.model
+        return (m.density_bitfield.data_ptr(), m.density_bitfield._version) + tuple((t.data_ptr(), t._version) for t in m.encoder.tables())
+
     def _set_inputs(self, message, data, next_data=None, next_message=None, eager_copy=True):
+        if self.fixed_blocks and self.graphs is not None and not self._refix_pending and self._kept_key != self._kept_inputs_key():
+            self._refix_pending = True      # a base table or the occupancy grid was written since the blocks were fixed (17 attribute reads per step)
         if self._refix_pending:      # the previous call's next_data brought new block rays: they are this step's now
             self._fix_blocks()
         slot = self._replays % len(self.msg_ring)        # == the device's replay count modulo the ring (advanced right behind every replay of g1)

@@ -181,3 +181,32 @@ def test_fixed_rays_under_autocast_and_a_scaled_loss():
         assert got[0].dtype == want[0].dtype and torch.equal(got[0], want[0])
         assert bool(torch.isfinite(got[1]).all()) and float((got[1] - want[1]).norm() / want[1].norm()) < 1e-5
     assert float((got_big[1] / 65536.0 - got_one[1]).norm() / got_one[1].norm()) < 1e-4
+
+
+def test_fixed_blocks_loop_notices_a_base_table_written_between_replays():
+    """A captured replay runs no Python, so the kept planes cannot notice a changed base table by themselves: step() compares the versions
+    of the 16 base tables and the occupancy bitfield with those the blocks were fixed under and re-fixes before the replay."""
+    from nerf_signature_amd import trainer
+    from nerf_signature_amd.optim import CodebookAdam
+    bo, bd, co, cd, gt = _data(n_content=300)
+    data = {"watermark": {"rays_o_block": bo.cuda(), "rays_d_block": bd.cuda()}, "content": {"rays_o": co.cuda(), "rays_d": cd.cuda(), "images": gt.cuda()}}
+    msgs = [torch.from_numpy(np.random.RandomState(60 + s).randint(0, 2, 32).astype(np.float32)) for s in range(4)]
+    runs = {}
+    for fixed in (False, True):
+        torch.manual_seed(0)
+        m, _, _ = _model()
+        opt = CodebookAdam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, capturable=True)
+        loop = trainer.GraphedWatermarkLoop(m, opt, dict(dt_gamma=0, max_steps=1024), data, fixed_blocks=fixed)
+        held = []
+        for k, msg in enumerate(msgs):
+            if k == 2:
+                with torch.no_grad():
+                    m.encoder.embeddings[14].weight.mul_(0.25)           # e.g. new stage-1 weights copied in, no invalidate() call
+            held.append(loop.step(msg)[3:6])
+            held[-1] = [v.detach().clone() for v in held[-1]]
+        torch.cuda.synchronize()
+        runs[fixed] = [[float(v) for v in row] for row in held]
+        if fixed:
+            assert loop.marched[0]["fixed"].refreshes == 2
+    np.testing.assert_allclose(runs[True], runs[False], rtol=1e-4, atol=1e-6)
+    assert abs(runs[False][2][1] - runs[False][1][1]) > 1e-6
