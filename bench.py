@@ -560,6 +560,7 @@ def bench_training(args, scene, real_stdout):
         "roofline": {
             "kernel": "k_encode_planes (the hash gather, forward) on the launch with the most points",
             "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+            "frac_of_measured_copy_ceiling": achieved / 6.29e12,      # (6.29 TB/s: the stream-copy rate MI355X_MICROARCH.md measures)
             "traffic": traffic,
             "launches": enc_n, "avg_launch_s": enc_s, "points_per_launch": pts_big, "rows_per_launch": enc_rows,
             "algorithmic_bytes_per_point": gather_launch,
