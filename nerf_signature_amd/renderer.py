@@ -183,13 +183,25 @@ class NeRFRenderer(nn.Module):
         if perturb:
             z = z + (torch.rand(z.shape, device=o.device) - 0.5) * spacing
         pts = torch.min(torch.max(o.unsqueeze(-2) + d.unsqueeze(-2) * z.unsqueeze(-1), aabb[:3]), aabb[3:])
-        field = self.density(pts.reshape(-1, 3), message=message)
         step = torch.cat([z[..., 1:] - z[..., :-1], spacing * torch.ones_like(z[..., :1])], dim=-1)
-        alpha = 1 - torch.exp(-step * self.density_scale * field["sigma"].view(N, T))
+        differentiable = torch.is_grad_enabled() and message is not None and any(p.requires_grad for p in self.parameters())
+        if differentiable:
+            # Training through this path (the reference trains through density() + masked color() when --cuda_ray is off): one joint,
+            # differentiable field pass over all samples, colour zeroed where the reference does not evaluate it.  Same values -- a
+            # masked-out sample's colour is 0 there too -- and the same gradient: the mask is a constant of the backward pass in both.
+            sigma_all, rgb_all = self(pts.reshape(-1, 3), d.view(-1, 1, 3).expand_as(pts).reshape(-1, 3).contiguous(), message)
+            sigma = sigma_all.view(N, T)
+        else:
+            field = self.density(pts.reshape(-1, 3), message=message)
+            sigma = field["sigma"].view(N, T)
+        alpha = 1 - torch.exp(-step * self.density_scale * sigma)
         transmittance = torch.cumprod(torch.cat([torch.ones_like(alpha[..., :1]), 1 - alpha + 1e-15], dim=-1), dim=-1)[..., :-1]
         weights = alpha * transmittance
-        rgbs = self.color(pts.reshape(-1, 3), d.view(-1, 1, 3).expand_as(pts).reshape(-1, 3), mask=(weights > 1e-4).reshape(-1),
-                          geo_feat=field["geo_feat"]).view(N, T, 3)
+        if differentiable:
+            rgbs = rgb_all.view(N, T, 3) * (weights > 1e-4).unsqueeze(-1)
+        else:
+            rgbs = self.color(pts.reshape(-1, 3), d.view(-1, 1, 3).expand_as(pts).reshape(-1, 3), mask=(weights > 1e-4).reshape(-1),
+                              geo_feat=field["geo_feat"]).view(N, T, 3)
         weights_sum = weights.sum(dim=-1)
         depth = torch.sum(weights * ((z - nears) / span).clamp(0, 1), dim=-1)
         image = torch.sum(weights.unsqueeze(-1) * rgbs, dim=-2) + (1 - weights_sum).unsqueeze(-1) * bg_color

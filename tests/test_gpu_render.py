@@ -556,6 +556,27 @@ def test_uniform_sample_path_run_matches_oracle():
     np.testing.assert_allclose(out["depth"].cpu()[hit].numpy(), ref["depth"][hit].numpy(), rtol=0, atol=1e-3)
 
 
+def test_uniform_sample_path_trains_the_codebook(strict_mlp):
+    """NeRFRenderer.run with gradients (what `main_nerf_wtmk.py` without --cuda_ray trains through: density() + masked color(),
+    renderer_wtmk.py:187-229): image and the codebook gradient of an MSE loss against the oracle's autograd through the same path."""
+    m, bitfield, C = _model()
+    P, S = _oracle_params(m, bitfield, C)
+    m.cuda_ray = False
+    pose, intr, inds = cf.orbit_rays(48, seed=8)
+    o, d = fr.get_rays(torch.from_numpy(pose)[None], intr, 400, 400, torch.from_numpy(np.minimum(inds, 80200 + 7 * np.arange(48)))[None])
+    msg = torch.from_numpy(cf.messages(32)[2])
+    gt = torch.rand(1, 48, 3)
+    ref = fr.render(o, d, msg, P, S, cuda_ray=False, num_steps=128, bg_color=1)
+    ((ref["image"] - gt) ** 2).mean().backward()
+    out = m.render(o.cuda(), d.cuda(), msg, staged=False, num_steps=128, upsample_steps=0, bg_color=1, perturb=False)
+    ((out["image"] - gt.cuda()) ** 2).mean().backward()
+    np.testing.assert_allclose(out["image"].detach().cpu().numpy(), ref["image"].detach().numpy(), rtol=0, atol=1e-3)
+    bits = [int(v) for v in msg]
+    g1, g0 = m.msg_encoder.embeddings[bits[0]].weight.grad.cpu(), P["cb_tables"][bits[0]].grad
+    assert float(g0.norm()) > 0 and float((g1 - g0).norm() / g0.norm()) < 5e-3
+    assert m.msg_encoder.embeddings[1 - bits[0]].weight.grad is None and all(p.grad is None for p in m.encoder.parameters())
+
+
 def test_density_grid_maintenance():
     """update_extra_state / mark_untrained_grid (renderer_wtmk.py:380-538) on the GPU: bitfield == packbits(grid), EMA rule, -1 marking."""
     from oracle import raymarch_ref as orm
