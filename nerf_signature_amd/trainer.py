@@ -72,7 +72,10 @@ def backward_from_loss_kernel(out, content_scale=1.0):
     _, content, decoded, d_content, d_decoded, lambda_w, lambda_i = last
     ci = lambda_i * content_scale
     seeds = [d_content if ci == 1.0 else d_content * ci, d_decoded if lambda_w == 1.0 else d_decoded * lambda_w]
-    torch.autograd.backward([content, decoded], seeds)
+    # (finetune_decoder: the codebook is frozen too, the content render then has no trainable input and no grad_fn)
+    pairs = [(t, g) for t, g in zip((content, decoded), seeds) if t.requires_grad]
+    if pairs:
+        torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
 
 
 def local_blocks(wm):

@@ -861,3 +861,40 @@ def test_other_message_lengths_train_step_and_captured_loop(D):
             loop = trainer.WatermarkLoop(m2, opt, dict(dt_gamma=0, max_steps=1024))
             losses[graphed] = [float(loop.step(data, msg_k)[5].detach()) for msg_k in msgs]
     np.testing.assert_allclose(losses[True], losses[False], rtol=2e-3, atol=2e-4)
+
+
+def test_finetune_decoder_mode_trains_the_decoder_only():
+    """NeRFNetwork(finetune_decoder=True) (network_wtmk_tcnn.py:90-95, :180-181): the codebook is frozen too, get_params exposes the decoder
+    alone; a training step must still run -- through train_step's fused loss path and through the loops -- and move only the decoder."""
+    import copy
+    from nerf_signature_amd import trainer
+    from nerf_signature_amd.network import NeRFNetwork
+    m0, bitfield, C = _model()
+    m = NeRFNetwork(bound=1.0, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1, message_dim=32, n_views=1, finetune_decoder=True)
+    m.load_state_dict(m0.state_dict())
+    m.cuda().train()
+    assert not any(p.requires_grad for p in m.msg_encoder.parameters()) and len(m.get_params(1e-2)) == 1
+    P, S = _oracle_params(m, bitfield, C)
+    bo, bd, co, cd, gt = _data(n_content=128, block=4)
+    msg = torch.from_numpy(cf.messages(32)[2])
+    dec_cpu = copy.deepcopy(m.msg_decoder).cpu()
+    ref = fr.train_step(bo, bd, co, cd, gt, msg, P, S, dec_cpu, dt_gamma=0.0, max_steps=1024)
+    ref["lossw"].backward()          # (the image loss has no trainable input in this mode)
+    data = {"watermark": {"rays_o_block": bo.cuda(), "rays_d_block": bd.cuda()}, "content": {"rays_o": co.cuda(), "rays_d": cd.cuda(), "images": gt.cuda()}}
+    out = trainer.train_step(m, data, msg, dict(dt_gamma=0, max_steps=1024))
+    trainer.backward_from_loss_kernel(out)
+    np.testing.assert_allclose(float(out[5].detach()), float(ref["loss"].detach()), rtol=1e-3, atol=1e-3)
+    assert all(e.weight.grad is None for e in m.msg_encoder.embeddings)
+    keep = [n for n, _ in m.msg_decoder.named_parameters() if not n.endswith("layers.0.bias")]
+    p1, p0 = dict(m.msg_decoder.named_parameters()), dict(dec_cpu.named_parameters())
+    v1 = torch.cat([p1[n].grad.reshape(-1).cpu() for n in keep])
+    v0 = torch.cat([p0[n].grad.reshape(-1) for n in keep])
+    assert float((v1 - v0).norm() / v0.norm()) < 5e-3
+    # the eager loop with the reference's optimiser construction
+    opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    loop = trainer.WatermarkLoop(m, opt, dict(dt_gamma=0, max_steps=1024))
+    before = torch.cat([p.detach().reshape(-1).clone() for p in m.msg_decoder.parameters()])
+    tables = [e.weight.detach().clone() for e in m.msg_encoder.embeddings[:4]]
+    l = [float(loop.step(data, msg)[4].detach()) for _ in range(3)]
+    after = torch.cat([p.detach().reshape(-1) for p in m.msg_decoder.parameters()])
+    assert not torch.equal(before, after) and all(torch.equal(a, e.weight) for a, e in zip(tables, m.msg_encoder.embeddings[:4])) and l[-1] < l[0]
