@@ -369,6 +369,9 @@ class GraphedWatermarkLoop:
         self.plan_stream = self.side_stream   # scatter plans queue behind the content render (a third captured stream crashes hipStreamEndCapture on this runtime)
         if not hasattr(optimizer, "step_shared_sel"):
             raise TypeError("GraphedWatermarkLoop needs nerf_signature_amd.optim.CodebookAdam(capturable=True)")
+        if not any(t.requires_grad for t in model.msg_encoder.tables()):
+            raise NotImplementedError("GraphedWatermarkLoop captures the step that trains the codebook; with a frozen codebook "
+                                      "(finetune_decoder=True) drive the model with WatermarkLoop")
         self.model, self.optimizer = model, optimizer
         self.render_kwargs = dict(render_kwargs)
         self.lambda_w, self.lambda_i = lambda_w, lambda_i
