@@ -898,3 +898,36 @@ def test_finetune_decoder_mode_trains_the_decoder_only():
     l = [float(loop.step(data, msg)[4].detach()) for _ in range(3)]
     after = torch.cat([p.detach().reshape(-1) for p in m.msg_decoder.parameters()])
     assert not torch.equal(before, after) and all(torch.equal(a, e.weight) for a, e in zip(tables, m.msg_encoder.embeddings[:4])) and l[-1] < l[0]
+
+
+@pytest.mark.parametrize("bound,dt_gamma,T_thresh,training", [(1.0, 0.0, 1e-2, True), (1.0, 0.0, 1e-2, False), (2.0, 1 / 128, 1e-4, True),
+                                                              (2.0, 1 / 128, 1e-3, False), (1.0, 0.0, 1e-4, False)])
+def test_opaque_field_early_termination_through_render(bound, dt_gamma, T_thresh, training, strict_mlp):
+    """A field dense enough to end rays early (sigma head's log-density row scaled up): the `T < T_thresh` exits of the training compositor
+    (raymarching.cu:542-557: the sample that crosses the threshold is still accumulated) and of the eval loop's bursts (:868, alive-list
+    compaction) at the level of render(), for several thresholds / cascades / cone angles, against the oracle.  Tolerance 3e-3 instead of
+    the path's 1e-3: sigma = exp(40 h0) multiplies the MLP's rounding error in h0 by 40 (this test is about where rays stop, the MLP's
+    accuracy has its own tests)."""
+    tol = 3e-3
+    m, P, S = _oracle_and_model(32, bound)
+    with torch.no_grad():
+        w = m.sigma_net.params.detach().clone()
+        w2 = w[2048:].view(16, 64)
+        w2[0] *= 40.0                                            # row 0 = log-density: sigma = exp(40 h0) is opaque wherever h0 > 0
+        m.sigma_net.params.copy_(w)
+    P["sigma_params"] = m.sigma_net.params.detach().cpu()
+    pose, intr, inds = cf.orbit_rays(160, seed=12, radius=3.2248 if bound == 1.0 else 1.3)
+    o, d = fr.get_rays(torch.from_numpy(pose)[None], intr, 400, 400, torch.from_numpy(inds)[None])
+    msg = torch.from_numpy(cf.messages(32)[2])
+    kw = dict(bg_color=1, dt_gamma=dt_gamma, max_steps=1024, T_thresh=T_thresh)
+    with torch.no_grad():
+        ref = fr.render(o, d, msg, P, S, training=training, **kw)
+        m.train(training)
+        out = m.render(o.cuda(), d.cuda(), msg, staged=False, perturb=False, force_all_rays=True, **kw)
+    ws = ref.get("weights_sum")
+    np.testing.assert_allclose(out["image"].cpu().numpy(), ref["image"].numpy(), rtol=0, atol=tol)
+    hit = ~torch.isnan(ref["depth"])
+    np.testing.assert_allclose(out["depth"].cpu()[hit].numpy(), ref["depth"][hit].numpy(), rtol=0, atol=tol)
+    if training:
+        np.testing.assert_allclose(out["weights_sum"].cpu().numpy(), ws.numpy(), rtol=0, atol=tol)
+        assert float((ws > 1 - 2 * T_thresh).float().mean()) > 0.02        # some rays really are opaque: they ended on the threshold
