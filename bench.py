@@ -61,19 +61,42 @@ def parse_args():
     return ap.parse_args()
 
 
-def _run_ranks(args, n, extra_env, timeout_s, capture_stdout, extra_argv=()):
-    """Start n rank processes, wait for them; returns (return code, rank 0's stdout or None).  A rank that dies takes the others down (they
-    would wait in a collective for ever); a run that outlasts `timeout_s` is killed the same way -- by the exact PIDs started here."""
+def _run_ranks(args, n, extra_env, timeout_s, capture, extra_argv=()):
+    """Start n rank processes, wait for them; returns (return code, rank 0's stdout or None, tail of rank 0's stderr or None).  A rank that
+    dies takes the others down (they would wait in a collective for ever); a run that outlasts `timeout_s` is killed the same way -- by the
+    exact PIDs started here, SIGTERM first, SIGKILL for whatever ignores it.  capture: rank 0's stdout and stderr go to temporary FILES
+    (never pipes: nothing here can block on a wedged child) and are read once every process is gone."""
+    import tempfile
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
+    f_out = tempfile.TemporaryFile(mode="w+") if capture else None
+    f_err = tempfile.TemporaryFile(mode="w+") if capture else None
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **extra_env)
-        out = subprocess.PIPE if (capture_stdout and r == 0) else None
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + list(extra_argv), env=env, stdout=out, text=bool(out)))
-    rc, t0, text = 0, time.time(), None
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), NERFSIG_LAUNCHED_BY_BENCH="1", **extra_env)
+        first = capture and r == 0
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + list(extra_argv), env=env,
+                                      stdout=f_out if first else None, stderr=f_err if first else None))
+    rc, t0 = 0, time.time()
+
+    def stop(ps):
+        for q in ps:
+            if q.poll() is None:
+                q.terminate()
+        deadline = time.time() + 5.0
+        while time.time() < deadline and any(q.poll() is None for q in ps):
+            time.sleep(0.05)
+        for q in ps:
+            if q.poll() is None:
+                q.kill()
+        for q in ps:
+            try:
+                q.wait(timeout=10)
+            except subprocess.TimeoutExpired:      # (unkillable: stuck in the driver; its files are still safe to read)
+                pass
+
     try:
         pending = list(procs)
         while pending:
@@ -82,24 +105,106 @@ def _run_ranks(args, n, extra_env, timeout_s, capture_stdout, extra_argv=()):
                 if code is None:
                     continue
                 pending.remove(p)
-                if code != 0:
-                    rc = rc or code
-                    for q in pending:
-                        q.terminate()
+                if code != 0 and rc == 0:
+                    rc = code
+                    stop(pending)
             if pending and timeout_s and time.time() - t0 > timeout_s:
                 rc = rc or 124
-                for q in pending:
-                    q.terminate()
-                time.sleep(5)
+                stop(pending)
                 break
             time.sleep(0.05)
-        if procs[0].stdout is not None:
-            text = procs[0].stdout.read()
     finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-    return rc, text
+        stop(procs)
+    text = err = None
+    if capture:
+        f_out.seek(0)
+        text = f_out.read()
+        f_err.seek(0)
+        err = "".join(f_err.readlines()[-20:])
+        f_out.close()
+        f_err.close()
+    return rc, text, err
+
+
+def _attempt_chain(pinned, test_hook, rehearsal):
+    attempts = []
+    if pinned in (None, "", "try") or test_hook:
+        attempts.append(("collectives captured inside the step's graph", {"NERFSIG_CAPTURE_COLLECTIVES": "1"}, []))
+    attempts.append(("default", {"NERFSIG_CAPTURE_COLLECTIVES": "0"}, []))
+    if not rehearsal:
+        attempts.append(("codebook optimiser replicated", {"NERFSIG_CAPTURE_COLLECTIVES": "0", "NERFSIG_SHARD_OPTIMIZER": "0"}, []))
+        attempts.append(("blocks and optimiser replicated, eager launches", {"NERFSIG_CAPTURE_COLLECTIVES": "0", "NERFSIG_SHARD_OPTIMIZER": "0",
+                                                                            "NERFSIG_REPLICATE_BLOCKS": "1"}, ["--no-graph"]))
+    return attempts
+
+
+def _failure_line(args, n, failures, t_chain, watchdog):
+    return json.dumps({"metric": "training rays/sec @4096 rays (hotdog, 32-bit msg)", "value": None, "unit": "rays/s", "n_gpus": n, "steps": args.steps,
+                       "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+                       "config": {"workload": "no attempt of the launcher's chain produced a line", "launch_failures": failures,
+                                  "chain_seconds": round(time.time() - t_chain, 1), "watchdog_s_per_attempt": watchdog}})
+
+
+def supervise_rank(args):
+    """Under an EXTERNAL launcher (the driver's `python -m torch.distributed.run ... bench.py --gpus N`: RANK / WORLD_SIZE are already set)
+    the launcher's chain cannot restart all ranks from one place, so every rank process becomes a supervisor of its own worker: it never
+    touches the GPU, starts the real rank as a CHILD process (same RANK / WORLD_SIZE; a rendezvous of its own on MASTER_PORT + 101 + 7k, not
+    the launcher's store, so a failed attempt leaves nothing behind in it), watches it with the same watchdog and walks the same chain of
+    modes.  The supervisors do not talk to each other: when one rank of an attempt dies the others hang in their next collective until their
+    own watchdog fires, and all of them arrive at attempt k + 1 within one watchdog period, where the fresh rendezvous waits for the last.
+    Rank 0's supervisor prints its worker's JSON line, or -- when no attempt succeeded -- the `"value": null` line with the reasons.
+    NERFSIG_LAUNCH_FALLBACK=0 (or a pinned NERFSIG_CAPTURE_COLLECTIVES=0|1) runs the worker in this process instead, as before."""
+    import tempfile
+    rank, n = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    hook = os.environ.get("NERFSIG_TEST_FAIL_CAPTURED", "")
+    rehearsal = (args.dry_launch or os.environ.get("NERFSIG_DIST_BACKEND", "") == "gloo") and os.environ.get("NERFSIG_LAUNCH_CHAIN") != "1" and hook not in ("all", "hang")
+    attempts = _attempt_chain(None, hook != "", rehearsal)
+    watchdog = float(os.environ.get("NERFSIG_LAUNCH_WATCHDOG_S", "90"))
+    base_port = int(os.environ.get("MASTER_PORT", "29500"))
+    failures, t_chain, rc, text = [], time.time(), 1, None
+    for k, (name, env, extra) in enumerate(attempts):
+        last = k == len(attempts) - 1
+        port = 1024 + (base_port + 101 + 7 * k - 1024) % 60000
+        child_env = {key: v for key, v in os.environ.items() if not key.startswith("TORCHELASTIC_")}
+        child_env.update(env, NERFSIG_SUPERVISED="1", NERFSIG_LAUNCH_ATTEMPT=f"{k}: {name} (supervised under an external launcher)", MASTER_ADDR="127.0.0.1",
+                         MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        t_attempt = time.time()
+        with tempfile.TemporaryFile(mode="w+") as f_out, tempfile.TemporaryFile(mode="w+") as f_err:
+            p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + list(extra), env=child_env, stdout=f_out, stderr=f_err)
+            try:
+                rc = p.wait(timeout=watchdog)
+            except subprocess.TimeoutExpired:
+                rc = 124
+                p.terminate()
+                try:
+                    p.wait(timeout=5)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    try:
+                        p.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        pass
+            f_out.seek(0)
+            text = f_out.read()
+            f_err.seek(0)
+            err = "".join(f_err.readlines()[-20:])
+        if rc == 0 and (rank != 0 or (text and "{" in text)):
+            break
+        why = "killed by the supervisor's watchdog" if rc == 124 else ("no JSON line on rank 0's stdout" if rc == 0 else "the worker exited non-zero")
+        failures.append({"attempt": k, "mode": name, "rc": rc, "why": why, "seconds": round(time.time() - t_attempt, 1), "rank": rank, "rank_stderr_tail": err[-4000:]})
+        rc = rc or 1
+        if rank == 0 or rc not in (124,):
+            print(f"[bench] rank {rank}: attempt {k} ({name}) failed: rc {rc} ({why}) after {failures[-1]['seconds']} s; last stderr lines:\n"
+                  + "".join("    | " + l + "\n" for l in err.splitlines()[-20:])
+                  + (f"[bench] rank {rank}: next attempt: {attempts[k + 1][0]}" if not last else f"[bench] rank {rank}: no attempt left"), file=sys.stderr, flush=True)
+    if rc == 0:
+        if rank == 0:
+            sys.stdout.write(text)
+            sys.stdout.flush()
+        raise SystemExit(0)
+    if rank == 0:
+        print(_failure_line(args, n, failures, t_chain, watchdog), flush=True)
+    raise SystemExit(rc)
 
 
 def launch_ranks(args):
@@ -118,6 +223,11 @@ def launch_ranks(args):
       1. collectives BETWEEN captured segments, blocks sharded, codebook optimiser sharded from four ranks (DESIGN.md 7);
       2. the same with the codebook optimiser replicated (NERFSIG_SHARD_OPTIMIZER=0: one collective less per step);
       3. blocks replicated too (NERFSIG_REPLICATE_BLOCKS=1: round 1's partitioning, one all-reduce per step), eager launches (--no-graph).
+    Every attempt -- the last one too -- runs under a watchdog (NERFSIG_LAUNCH_WATCHDOG_S, default 90 s: a healthy run takes well under
+    30 s), so the whole chain ends within about four watchdogs + the kills, inside the driver's 600 s.  Every failed attempt leaves ONE
+    stderr block (mode, return code, the last 20 lines of rank 0's stderr).  If no attempt succeeds the launcher still prints a JSON line
+    -- `"value": null` with the reasons in `config.launch_failures` -- and exits non-zero: a scaling point that failed is on record as
+    failed, not missing.
     NERFSIG_CAPTURE_COLLECTIVES=0|1 or NERFSIG_LAUNCH_FALLBACK=0 pin the first attempt's mode (no second attempt)."""
     n = args.gpus
     backend = os.environ.get("NERFSIG_DIST_BACKEND", "")
@@ -126,40 +236,47 @@ def launch_ranks(args):
         if have < n:
             raise SystemExit(f"--gpus {n} but {have} GPU(s) visible (NERFSIG_DIST_BACKEND=gloo rehearses N ranks on fewer GPUs)")
     pinned = os.environ.get("NERFSIG_CAPTURE_COLLECTIVES")
-    test_hook = os.environ.get("NERFSIG_TEST_FAIL_CAPTURED") == "1"      # (tests: the first attempt's ranks exit with code 3)
-    rehearsal = (args.dry_launch or backend == "gloo") and os.environ.get("NERFSIG_LAUNCH_CHAIN") != "1"   # (=1: walk the chain in a gloo rehearsal too)
-    watchdog = float(os.environ.get("NERFSIG_LAUNCH_WATCHDOG_S", "240"))
+    hook = os.environ.get("NERFSIG_TEST_FAIL_CAPTURED", "")      # tests: "1" the first attempt's ranks exit with code 3; "all": every attempt's; "hang": they sleep
+    test_hook = hook != ""
+    rehearsal = (args.dry_launch or backend == "gloo") and os.environ.get("NERFSIG_LAUNCH_CHAIN") != "1" and hook not in ("all", "hang")
+    watchdog = float(os.environ.get("NERFSIG_LAUNCH_WATCHDOG_S", "90"))
     if ((pinned in ("0", "1") or os.environ.get("NERFSIG_LAUNCH_FALLBACK") == "0" or args.no_graph or rehearsal) and not test_hook):
-        rc, _ = _run_ranks(args, n, {}, None, capture_stdout=False)
+        rc, _, _ = _run_ranks(args, n, {}, None, capture=False)
         raise SystemExit(rc)
-    attempts = []
-    if pinned in (None, "", "try") or test_hook:
-        attempts.append(("collectives captured inside the step's graph", {"NERFSIG_CAPTURE_COLLECTIVES": "1"}, []))
-    attempts.append(("default", {"NERFSIG_CAPTURE_COLLECTIVES": "0"}, []))
-    if not rehearsal:
-        attempts.append(("codebook optimiser replicated", {"NERFSIG_CAPTURE_COLLECTIVES": "0", "NERFSIG_SHARD_OPTIMIZER": "0"}, []))
-        attempts.append(("blocks and optimiser replicated, eager launches", {"NERFSIG_CAPTURE_COLLECTIVES": "0", "NERFSIG_SHARD_OPTIMIZER": "0",
-                                                                            "NERFSIG_REPLICATE_BLOCKS": "1"}, ["--no-graph"]))
-    rc, text = 1, None
+    attempts = _attempt_chain(pinned, test_hook, rehearsal)
+    rc, text, failures = 1, None, []
+    t_chain = time.time()
     for k, (name, env, extra) in enumerate(attempts):
         last = k == len(attempts) - 1
         env = dict(env, NERFSIG_LAUNCH_ATTEMPT=f"{k}: {name}")
-        rc, text = _run_ranks(args, n, env, None if last else watchdog, capture_stdout=True, extra_argv=extra)
+        t_attempt = time.time()
+        rc, text, err = _run_ranks(args, n, env, watchdog, capture=True, extra_argv=extra)
         if rc == 0 and text and "{" in text:
             break
-        if not last:
-            print(f"[bench] attempt {k} ({name}) ended with code {rc}; starting the ranks again: {attempts[k + 1][0]}", file=sys.stderr)
+        why = "killed by the launcher's watchdog" if rc == 124 else ("no JSON line on rank 0's stdout" if rc == 0 else "a rank exited non-zero")
+        failures.append({"attempt": k, "mode": name, "rc": rc, "why": why, "seconds": round(time.time() - t_attempt, 1), "rank0_stderr_tail": (err or "")[-4000:]})
+        rc = rc or 1
+        print(f"[bench] attempt {k} ({name}) failed: rc {rc} ({why}) after {failures[-1]['seconds']} s; rank 0's last stderr lines:\n"
+              + "".join("    | " + l + "\n" for l in (err or "").splitlines()[-20:])
+              + (f"[bench] starting the ranks again: {attempts[k + 1][0]}" if not last else "[bench] no attempt left"), file=sys.stderr, flush=True)
     if text and rc == 0:
         sys.stdout.write(text)
         sys.stdout.flush()
+        raise SystemExit(0)
+    # every attempt failed: the point is on record as failed
+    print(_failure_line(args, n, failures, t_chain, watchdog), flush=True)
     raise SystemExit(rc)
 
 
 def dry_launch(args):
     """The launcher path and the step's collectives on gloo / CPU tensors (no kernels): proves `--gpus N` starts N ranks that meet."""
     from nerf_signature_amd import dp
-    if os.environ.get("NERFSIG_TEST_FAIL_CAPTURED") == "1" and os.environ.get("NERFSIG_CAPTURE_COLLECTIVES") == "1":
+    hook = os.environ.get("NERFSIG_TEST_FAIL_CAPTURED", "")
+    if (hook == "1" and os.environ.get("NERFSIG_CAPTURE_COLLECTIVES") == "1") or hook == "all":
+        print(f"[dry-launch] test hook: rank {os.environ.get('RANK')} fails on purpose ({os.environ.get('NERFSIG_LAUNCH_ATTEMPT')})", file=sys.stderr)
         raise SystemExit(3)
+    if hook == "hang":
+        time.sleep(3600)
     rank, world, _ = dp.init_from_env(backend="gloo")
     D = 32
     ok = True
@@ -665,6 +782,10 @@ def main():
     in_rank = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if args.gpus > 1 and not in_rank:
         launch_ranks(args)                       # never returns
+    if (args.gpus > 1 and in_rank and os.environ.get("NERFSIG_SUPERVISED") != "1" and os.environ.get("NERFSIG_LAUNCHED_BY_BENCH") != "1"
+            and os.environ.get("NERFSIG_LAUNCH_FALLBACK") != "0" and os.environ.get("NERFSIG_CAPTURE_COLLECTIVES") not in ("0", "1")
+            and not args.no_graph and int(os.environ.get("WORLD_SIZE", "1")) > 1):
+        supervise_rank(args)                     # an external launcher started this rank: never returns
     if args.dry_launch:
         dry_launch(args)                         # never returns
     # stdout carries exactly one JSON line: RCCL prints its version banner to stdout when the process group starts, so

@@ -12,7 +12,24 @@ import os
 import torch
 
 
-def checkpoint_state(model, epoch=0, global_step=0, stats=None, optimizer=None, lr_scheduler=None, scaler=None, full=False):
+def gather_sharded_codebook(model, gather=True):
+    """With the codebook optimiser sharded over the ranks (dp.optimizer_shard; on by default from four ranks) a rank's copies of the tables
+    and Adam moments it does not own are stale after every captured step until GraphedWatermarkLoop.gather_codebook() has run.  Whoever
+    reads the tables on the host side -- a checkpoint, an evaluation through the host-side selection -- calls this first.  gather=True
+    brings them up to date (a COLLECTIVE: every rank must call it, also the ranks that do not write the file); gather=False refuses."""
+    if not getattr(model, "_codebook_stale", False):
+        return
+    loops = [l for l in getattr(model, "_graphed_loops", ()) if getattr(l, "opt_shard", None) is not None]
+    if not gather or not loops:
+        raise RuntimeError("the codebook optimiser is sharded over the ranks and this rank's copies of the other ranks' tables are stale: "
+                           "call GraphedWatermarkLoop.gather_codebook() on EVERY rank first (checkpoint_state(..., gather=True) does)")
+    for loop in loops:
+        loop.gather_codebook()
+
+
+def checkpoint_state(model, epoch=0, global_step=0, stats=None, optimizer=None, lr_scheduler=None, scaler=None, full=False, gather=True):
+    """gather: see gather_sharded_codebook -- with a sharded codebook optimiser this is a collective call (all ranks enter it, rank 0 saves)."""
+    gather_sharded_codebook(model, gather)
     state = {"epoch": epoch, "global_step": global_step, "stats": stats if stats is not None else {}}
     if getattr(model, "cuda_ray", False):
         state["mean_count"] = model.mean_count

@@ -92,6 +92,9 @@ class NeRFNetwork(NeRFRenderer):
     def _select(self, message):
         if message is None:
             return (), None, None
+        if getattr(self, "_codebook_stale", False):
+            raise RuntimeError("host-side table selection while the codebook optimiser is sharded over the ranks: this rank's copies of the "
+                               "other ranks' tables are stale -- call GraphedWatermarkLoop.gather_codebook() on every rank first")
         bits = fo.message_bits(message)
         if len(bits) != self.message_dim:
             raise ValueError(f"message has {len(bits)} bits, the network was built with message_dim={self.message_dim}")
@@ -202,7 +205,7 @@ class NeRFNetwork(NeRFRenderer):
             rec["fixed"].refresh(rec["xyzs"], self.encoder.tables())
         rec["fixed_args"] = (dt_gamma, max_steps)
         rec["rays_ref"] = (rays_o, rays_d)      # the cache is keyed by address + version: keep the tensors alive, or a later allocation could take the address
-        rec["grid_key"] = (self.density_bitfield.data_ptr(), self.density_bitfield._version)
+        rec["grid_key"] = self.grid_key()
         return rec
 
     def density(self, x, message=None):

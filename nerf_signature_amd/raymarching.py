@@ -115,6 +115,8 @@ class _packbits(Function):
         N = C * H3 // 8
         if bitfield is None:
             bitfield = torch.empty(N, dtype=torch.uint8, device=grid.device)
+        else:
+            ctx.mark_dirty(bitfield)      # written in place through its raw pointer: bump its version (keys of kept samples compare it)
         nv.check(bitfield, torch.uint8, "bitfield")
         nv.call("rm_packbits", nv.ptr(grid), N, float(thresh), nv.ptr(bitfield), nv.stream())
         return bitfield

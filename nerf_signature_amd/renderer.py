@@ -121,6 +121,17 @@ class NeRFRenderer(nn.Module):
             self.register_buffer("step_counter", torch.zeros(16, 2, dtype=torch.int32))
             self.mean_count = 0
             self.local_step = 0
+        self._grid_epoch = 0      # bumped by everything that rewrites the occupancy grid (see grid_key)
+
+    def grid_key(self):
+        """Identity of the occupancy grid the marcher reads: address and version of the bitfield AND an explicit epoch.  The version alone
+        misses writes through a raw pointer (packbits re-packs the bitfield in place); samples kept across steps (fix_rays, the captured
+        loop's fixed blocks) compare this key."""
+        return (self.density_bitfield.data_ptr(), self.density_bitfield._version, self._grid_epoch)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._grid_epoch = getattr(self, "_grid_epoch", 0) + 1      # a checkpoint may have brought another grid
 
     def forward(self, x, d):
         raise NotImplementedError()
@@ -140,6 +151,7 @@ class NeRFRenderer(nn.Module):
         self.step_counter.zero_()
         self.mean_count = 0
         self.local_step = 0
+        self._grid_epoch += 1
 
     # ------------------------------------------------------------------ shared pieces
 
@@ -273,7 +285,7 @@ class NeRFRenderer(nn.Module):
         marched = getattr(self, "_marched", None)
         marched = marched.get(self._rays_key(o, d)) if marched and self.training and force_all_rays and not perturb else None
         if marched is not None and marched.get("fixed") is not None and not torch.cuda.is_current_stream_capturing() and \
-                marched["grid_key"] != (self.density_bitfield.data_ptr(), self.density_bitfield._version):
+                marched["grid_key"] != self.grid_key():
             marched = self.fix_rays(o, d, *marched["fixed_args"])      # rays declared constant, but the grid they were marched through changed
         if marched is not None:
             nears, fars = marched["nears"], marched["fars"]
@@ -400,6 +412,7 @@ class NeRFRenderer(nn.Module):
                     in_y = torch.abs(cam[:, :, 1]) < cy / fy * cam[:, :, 2] + half_cell * 2
                     seen[cas, indices] += (in_front & in_x & in_y).sum(0).reshape(-1)
         self.density_grid[seen == 0] = -1
+        self._grid_epoch += 1
         print(f"[mark untrained grid] {(seen == 0).sum()} from {self.grid_size ** 3 * self.cascade}")
 
     def _probe_density(self, coords, cas, message):
@@ -433,6 +446,7 @@ class NeRFRenderer(nn.Module):
         self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
         self.iter_density += 1
         self.density_bitfield = raymarching.packbits(self.density_grid, min(self.mean_density, self.density_thresh), self.density_bitfield)
+        self._grid_epoch += 1
         steps = min(16, self.local_step)
         if steps > 0:
             self.mean_count = int(self.step_counter[:steps, 0].sum().item() / steps)

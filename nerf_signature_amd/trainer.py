@@ -104,7 +104,10 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
     main = None
     if side_stream is not None and wm["rays_o_block"].is_cuda:
         main = torch.cuda.current_stream()
-        if presum_first:       # the block render's samples were marched ahead: nothing on the main stream to hide the pre-sum behind
+        # presum_first: the block render's samples were marched ahead -- nothing on the main stream to hide the pre-sum behind.  A sharded
+        # codebook optimiser: the pre-sum ends in a collective (a segment boundary of a captured step), which must not be reached on
+        # the forked side stream -- the capture would end with an unjoined stream.
+        if presum_first or getattr(model, "codebook_shard", None) is not None:
             model.prepare_message(message)
         side_stream.wait_stream(main)
         # Issued first: the content render's field pass finds no pre-summed codebook yet and computes it right behind its own
@@ -449,6 +452,7 @@ class GraphedWatermarkLoop:
                 get(t).reshape(-1).copy_(every.view(len(self.tables), -1)[i])
         from .optim import _bump_versions
         _bump_versions(self.tables)
+        self.model._codebook_stale = False
 
     def close(self):
         """Detach from the model: the eager loop (or another graphed loop) may drive it again."""
@@ -571,7 +575,7 @@ class GraphedWatermarkLoop:
     def _kept_inputs_key(self):
         """Versions of everything the kept planes / marched samples were computed from (in-place writes through torch bump them)."""
         m = self.model
-        return (m.density_bitfield.data_ptr(), m.density_bitfield._version) + tuple((t.data_ptr(), t._version) for t in m.encoder.tables())
+        return m.grid_key() + tuple((t.data_ptr(), t._version) for t in m.encoder.tables())
 
     def _set_inputs(self, message, data, next_data=None, next_message=None, eager_copy=True):
         if self.fixed_blocks and self.graphs is not None and not self._refix_pending and self._kept_key != self._kept_inputs_key():
@@ -778,6 +782,8 @@ class GraphedWatermarkLoop:
             if i < len(self.between):
                 self.between[i]()        # the collective between two segments (RCCL; ordered after the segment on this stream)
         self.steps_done += 1
+        if self.opt_shard is not None:
+            self.model._codebook_stale = True      # tables of the other ranks' bits: stale here until gather_codebook()
         return self.out
 
     def ensure_capacity(self, growth=1.25):

@@ -76,6 +76,21 @@ def test_fixed_rays_render_is_bit_identical_and_follows_its_inputs():
     assert rec["capacity"] > padded_point_count(n_points) and int(rec["counter"][0]) <= rec["capacity"] and torch.equal(got3b, want3b)
     refreshes = rec["fixed"].refreshes
 
+    # the model re-packs its own grid (update_extra_state -> packbits writes the bitfield IN PLACE through its raw pointer: neither the
+    # address nor -- without mark_dirty -- the version would move): the explicit grid epoch and the dirty mark make the kept samples notice
+    with torch.no_grad():
+        key_before, version_before = m.grid_key(), m.density_bitfield._version
+        ptr_before = m.density_bitfield.data_ptr()
+        m.iter_density = 0
+        m.density_grid.zero_()                     # (the update then leaves the field's own densities: a grid unlike the all-occupied one)
+        m.update_extra_state(message=None)
+        assert m.density_bitfield.data_ptr() == ptr_before and m.grid_key() != key_before and m.density_bitfield._version > version_before
+        want3c = m.render(bo.clone(), bd.clone(), msgs[0], **KW)["image"].clone()
+        got3c = m.render(bo, bd, msgs[0], **KW)["image"]
+        rec = next(r for r in m._marched.values() if r.get("fixed") is not None)
+    assert rec["fixed"].refreshes > refreshes and torch.equal(got3c, want3c) and not torch.equal(got3c, got3b)
+    refreshes = rec["fixed"].refreshes
+
     # the rays change in place: they drop out of the cache by themselves (matched by address AND version)
     with torch.no_grad():
         bd.copy_(torch.nn.functional.normalize(bd + 0.01, dim=-1))
