@@ -1,7 +1,13 @@
-"""The bench workload itself (BASELINE.json configs[1]: hotdog-like scene S0, 4608 block rays + 4096 content rays, 32-bit
-message, 1.4 M sample points) through the C ABI at FULL size.  Integer outputs are compared with the C oracle outright (the
-scalar march of 8704 rays takes a second); the floating-point stages, too large for the CPU oracle, are checked through
-size-independent properties plus a random sample of points against the oracle."""
+"""The bench workloads themselves through the C ABI at FULL size:
+  * BASELINE.json configs[1] (hotdog-like scene S0: 4608 block rays + 4096 content rays, 32-bit message, 1.4 M sample points),
+  * configs[2] (Mip-NeRF360/counter-like scene S1: bound 2, TWO cascades, camera inside the box, the same 4608 + 4096 rays at
+    ~500 / ~240 samples per ray = 3 M points -- capacity sizing, cascade selection `mip_from_pos` / `mip_from_dt`
+    (raymarching.cu:42-54,368) and the cascade-1 dt_max at the size the secondary bench line times),
+  * configs[4] (LLFF/fern-like scene S2: 1008x756 view staged in 187 chunks of 4096 rays, 48-bit message, 64x64 block grid,
+    48 blocks of 11x15 through the HiDDeN decoder).
+Integer outputs are compared with the C oracle outright (the scalar march of 8704 rays takes seconds); the floating-point
+stages, too large for the CPU oracle, are checked through size-independent properties plus a random sample of points /
+pixels against the oracle."""
 import numpy as np
 import pytest
 import torch
@@ -13,19 +19,30 @@ pytestmark = pytest.mark.gpu
 D = 32
 
 
-@pytest.fixture(scope="module")
-def workload():
+def _build(scene, message_dim):
     from nerf_signature_amd import synthetic
     from nerf_signature_amd.network import NeRFNetwork
     torch.manual_seed(0)
-    m = NeRFNetwork(bound=1.0, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1, message_dim=D, n_views=1)
-    synthetic.init_model(m, "hotdog")
-    m.cuda().train()
-    bo, bd = synthetic.block_rays("hotdog")
-    co, cd = synthetic.content_rays("hotdog", 4096, seed=0)
+    cfg = synthetic.SCENES[scene]
+    m = NeRFNetwork(bound=cfg["bound"], cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1, message_dim=message_dim, n_views=1)
+    synthetic.init_model(m, scene)
+    return m.cuda().train(), cfg
+
+
+@pytest.fixture(scope="module", params=["hotdog", "counter"])
+def workload(request):
+    """(model, rays_o, rays_d) of one training step of the scene: its 4608 block rays followed by 4096 content rays (CPU tensors)."""
+    from nerf_signature_amd import synthetic
+    scene = request.param
+    m, cfg = _build(scene, D)
+    bo, bd = synthetic.block_rays(scene)
+    co, cd = synthetic.content_rays(scene, 4096, seed=0)
     o = torch.cat([bo.reshape(-1, 3), co.reshape(-1, 3)]).contiguous()
     d = torch.cat([bd.reshape(-1, 3), cd.reshape(-1, 3)]).contiguous()
-    return m, o, d
+    m.scene_name, m.scene_cfg = scene, cfg
+    yield m, o, d
+    del m
+    torch.cuda.empty_cache()
 
 
 @pytest.fixture(scope="module")
@@ -35,7 +52,8 @@ def marched(workload):
     oc, dc = o.cuda(), d.cuda()
     nears, fars = rm.near_far_from_aabb(oc, dc, m.aabb_train, 0.2)
     ctr = torch.zeros(2, dtype=torch.int32, device="cuda")
-    xyzs, dirs, deltas, rays = rm.march_rays_train(oc, dc, 1.0, m.density_bitfield, 1, 128, nears, fars, ctr, -1, False, 128, True, 0.0, 1024)
+    xyzs, dirs, deltas, rays = rm.march_rays_train(oc, dc, m.bound, m.density_bitfield, m.cascade, 128, nears, fars, ctr, -1, False, 128, True,
+                                                   m.scene_cfg["dt_gamma"], 1024)
     return nears, fars, ctr, xyzs, dirs, deltas, rays
 
 
@@ -44,13 +62,18 @@ def test_full_workload_march_is_bit_exact(workload, marched):
     m, o, d = workload
     nears, fars, ctr, xyzs, dirs, deltas, rays = marched
     bitfield = m.density_bitfield.cpu().numpy()
-    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    b = float(m.bound)
+    aabb = np.array([-b, -b, -b, b, b, b], np.float32)
     n0, f0 = orm.near_far_from_aabb(o.numpy(), d.numpy(), aabb, 0.2)
     np.testing.assert_array_equal(nears.cpu().numpy(), n0)
     np.testing.assert_array_equal(fars.cpu().numpy(), f0)
     ctr0 = np.zeros(2, np.int32)
-    x0, d0, dl0, rays0 = orm.march_rays_train(o.numpy(), d.numpy(), 1.0, bitfield, 1, 128, n0, f0, ctr0, -1, False, 128, True, 0.0, 1024)
-    assert ctr0[0] > 1_400_000 and ctr0[1] == 8704
+    x0, d0, dl0, rays0 = orm.march_rays_train(o.numpy(), d.numpy(), b, bitfield, m.cascade, 128, n0, f0, ctr0, -1, False, 128, True,
+                                              m.scene_cfg["dt_gamma"], 1024)
+    # hotdog: 280 / 30 samples per block / content ray; counter (camera inside, shell on the coarse cascade): ~500 / ~240
+    assert ctr0[0] > {"hotdog": 1_400_000, "counter": 2_500_000}[m.scene_name] and ctr0[1] == 8704
+    if m.scene_name == "counter":       # both cascades are really sampled: steps of the fine cascade (dt_min) and coarser ones beyond |p| > 1
+        assert m.cascade == 2 and float(np.abs(x0).max()) > 1.5 and len(np.unique(np.round(dl0[:int(ctr0[0]), 0], 6))) > 1
     np.testing.assert_array_equal(ctr.cpu().numpy(), ctr0)
     np.testing.assert_array_equal(rays.cpu().numpy(), rays0)
     np.testing.assert_array_equal(xyzs.cpu().numpy(), x0)
@@ -71,7 +94,7 @@ def test_full_workload_encoder_linearity_and_sampled_parity(workload, marched):
     m, _, _ = workload
     xyzs = marched[3]
     M = int(marched[2][0])
-    x01 = ((xyzs[:M] + 1.0) / 2.0).contiguous()
+    x01 = ((xyzs[:M] + m.bound) / (2.0 * m.bound)).contiguous()
     msg = torch.from_numpy(np.random.RandomState(3).randint(0, 2, D).astype(np.float32))
     base = m.encoder.tables()
     sel = fo.select_tables(m.msg_encoder.tables(), fo.message_bits(msg))
@@ -90,8 +113,8 @@ def test_full_workload_encoder_linearity_and_sampled_parity(workload, marched):
     # (b) the training forward (planes route for large batches) against the fused-gather route on all rows
     packed = m._packed()
     dirs = marched[4]
-    a = fo.field_forward(xyzs, dirs, 1.0, base, S, packed, want_masks=True, planes=True)
-    b = fo.field_forward(xyzs, dirs, 1.0, base, S, packed, want_masks=True, planes=False)
+    a = fo.field_forward(xyzs, dirs, m.bound, base, S, packed, want_masks=True, planes=True)
+    b = fo.field_forward(xyzs, dirs, m.bound, base, S, packed, want_masks=True, planes=False)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
 
 
@@ -108,9 +131,9 @@ def test_full_workload_field_and_composite_properties(workload, marched):
     base = m.encoder.tables()
     sel = fo.select_tables(m.msg_encoder.tables(), fo.message_bits(msg))
     S = fo.codebook_presum(sel)
-    sig, rgb = fo.field_forward(xyzs, dirs, 1.0, base, S, m._packed())[:2]
+    sig, rgb = fo.field_forward(xyzs, dirs, m.bound, base, S, m._packed())[:2]
     pick = torch.from_numpy(np.random.RandomState(5).choice(M, 4096, replace=False)).cuda()
-    P = {"bound": 1.0, "base_tables": [t.detach().cpu() for t in base], "cb_tables": [t.detach().cpu() for t in m.msg_encoder.tables()],
+    P = {"bound": float(m.bound), "base_tables": [t.detach().cpu() for t in base], "cb_tables": [t.detach().cpu() for t in m.msg_encoder.tables()],
          "sigma_params": m.sigma_net.params.detach().cpu(), "color_params": m.color_net.params.detach().cpu()}
     with torch.no_grad():
         s0, c0 = fr.field_forward(xyzs[pick].cpu(), dirs[pick].cpu(), msg, P)
@@ -151,8 +174,8 @@ def test_full_workload_block_render_with_kept_planes_is_bit_identical(workload):
     codebook gradient agrees to the order of the sums (both routes are the fixed-point slice-binned scatter at this size)."""
     from nerf_signature_amd import synthetic
     m, _, _ = workload
-    bo, bd = (t.cuda() for t in synthetic.block_rays("hotdog"))
-    kw = dict(staged=False, bg_color=1, perturb=False, force_all_rays=True, dt_gamma=0, max_steps=1024)
+    bo, bd = (t.cuda() for t in synthetic.block_rays(m.scene_name))
+    kw = dict(staged=False, bg_color=1, perturb=False, force_all_rays=True, dt_gamma=m.scene_cfg["dt_gamma"], max_steps=1024)
     gvec = torch.rand(bo.shape, device="cuda")
     msgs = [torch.from_numpy(np.random.RandomState(s).randint(0, 2, D).astype(np.float32)) for s in (1, 2)]
 
@@ -165,7 +188,7 @@ def test_full_workload_block_render_with_kept_planes_is_bit_identical(workload):
         return out["image"].detach().clone(), out["weights_sum"].detach().clone(), out["depth"].detach().clone(), grad.clone()
 
     want = [render(bo.clone(), bd.clone(), msg) for msg in msgs]
-    rec = m.fix_rays(bo, bd, dt_gamma=0, max_steps=1024)
+    rec = m.fix_rays(bo, bd, dt_gamma=m.scene_cfg["dt_gamma"], max_steps=1024)
     try:
         assert int(rec["counter"][0]) > 1_250_000
         for msg, w in zip(msgs, want):
@@ -175,3 +198,114 @@ def test_full_workload_block_render_with_kept_planes_is_bit_identical(workload):
         assert rec["fixed"].refreshes == 1
     finally:
         m.drop_marched()
+
+
+# ------------------------------------------------------------------------------------------------ config 3 as a whole training step
+
+def test_counter_full_train_step_sampled_rays_vs_oracle():
+    """One full-size training-mode render of each kind on scene S1 (4608 block rays, 4096 content rays, two cascades) against the oracle on a
+    random sample of 192 rays each (the oracle's result for a ray does not depend on which other rays are in the batch): image, weights,
+    depth within 1e-3; the whole batch's point count equals the C oracle's."""
+    from nerf_signature_amd import synthetic
+    m, cfg = _build("counter", D)
+    msg = torch.from_numpy(np.random.RandomState(11).randint(0, 2, D).astype(np.float32))
+    P = {"bound": 2.0, "base_tables": [t.detach().cpu() for t in m.encoder.tables()], "cb_tables": [t.detach().cpu() for t in m.msg_encoder.tables()],
+         "sigma_params": m.sigma_net.params.detach().cpu(), "color_params": m.color_net.params.detach().cpu()}
+    S = {"bound": 2.0, "cascade": 2, "grid_size": 128, "density_bitfield": m.density_bitfield.cpu().numpy(), "aabb": np.array([-2, -2, -2, 2, 2, 2], np.float32),
+         "min_near": 0.2, "density_scale": 1}
+    kw = dict(staged=False, bg_color=1, perturb=False, force_all_rays=True, dt_gamma=0, max_steps=1024)
+    bo, bd = synthetic.block_rays("counter")
+    co, cd = synthetic.content_rays("counter", 4096, seed=0)
+    for o, d in ((bo.reshape(1, -1, 3), bd.reshape(1, -1, 3)), (co, cd)):
+        with torch.no_grad():
+            out = m.render(o.cuda(), d.cuda(), msg, **kw)
+        n_points = int(m.step_counter[(m.local_step - 1) % 16, 0])
+        nears, fars = orm.near_far_from_aabb(o[0].numpy(), d[0].numpy(), S["aabb"], 0.2)
+        _, total = orm.march_counts(o[0].numpy(), d[0].numpy(), 2.0, S["density_bitfield"], 2, 128, nears, fars, 0.0, 1024)
+        assert n_points == total > 900_000
+        pick = np.random.RandomState(12).choice(o.shape[1], 192, replace=False)
+        with torch.no_grad():
+            ref = fr.render(o[:, pick], d[:, pick], msg, P, S, staged=False, bg_color=1, dt_gamma=0.0, max_steps=1024)
+        np.testing.assert_allclose(out["image"][0, pick].cpu().numpy(), ref["image"][0].numpy(), rtol=0, atol=1e-3)
+        np.testing.assert_allclose(out["weights_sum"][pick].cpu().numpy(), ref["weights_sum"].numpy(), rtol=0, atol=1e-3)
+        hit = ~torch.isnan(ref["depth"][0])
+        np.testing.assert_allclose(out["depth"][0, pick].cpu()[hit].numpy(), ref["depth"][0][hit].numpy(), rtol=0, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ config 5: fern, full image
+
+@pytest.fixture(scope="module")
+def fern():
+    from nerf_signature_amd import rays, synthetic
+    m, cfg = _build("fern", 48)
+    H, W = cfg["H"], cfg["W"]
+    intr = (cfg["focal"], cfg["focal"], W / 2, H / 2)
+    pose = torch.from_numpy(synthetic.orbit_pose(1.1, 0.7, cfg["radius"]))[None].cuda()
+    r = rays.get_rays(pose, intr, H, W, -1)
+    msg = torch.from_numpy(np.random.RandomState(5).randint(0, 2, 48).astype(np.float32))
+    P = {"bound": 2.0, "base_tables": [t.detach().cpu() for t in m.encoder.tables()], "cb_tables": [t.detach().cpu() for t in m.msg_encoder.tables()],
+         "sigma_params": m.sigma_net.params.detach().cpu(), "color_params": m.color_net.params.detach().cpu()}
+    S = {"bound": 2.0, "cascade": 2, "grid_size": 128, "density_bitfield": m.density_bitfield.cpu().numpy(), "aabb": np.array([-2, -2, -2, 2, 2, 2], np.float32),
+         "min_near": 0.2, "density_scale": 1}
+    yield m, cfg, r["rays_o"], r["rays_d"], msg, P, S
+    del m
+    torch.cuda.empty_cache()
+
+
+def test_fern_full_image_fused_staging_equals_chunk_by_chunk_and_sampled_pixels_vs_oracle(fern, monkeypatch):
+    """The 1008x756 view (762 048 rays = 187 chunks of 4096, renderer_wtmk.py:555-570) under no_grad with the model in training mode, as
+    the reference's test_image runs it: (a) the fused staged render (up to 64 chunks per launch sequence) is BIT-IDENTICAL to walking the
+    image chunk by chunk, image and depth, and leaves the same local_step / step_counter ring behind; (b) 2048 random pixels agree with
+    the oracle's render of exactly those rays to 1e-3 (image, depth)."""
+    m, cfg, ro, rd, msg, P, S = fern
+    H, W = cfg["H"], cfg["W"]
+    assert ro.shape == (1, H * W, 3) and (H * W + 4095) // 4096 == 187
+    kw = dict(staged=True, max_ray_batch=4096, bg_color=1, perturb=False, force_all_rays=True, dt_gamma=cfg["dt_gamma"], max_steps=1024)
+    with torch.no_grad():
+        m.local_step = 0
+        m.step_counter.zero_()
+        fused = m.render(ro, rd, msg, **kw)
+        ring_fused, steps_fused = m.step_counter.clone(), m.local_step
+        monkeypatch.setenv("NERFSIG_STAGED_FUSED", "0")
+        m.local_step = 0
+        m.step_counter.zero_()
+        chunked = m.render(ro, rd, msg, **kw)
+        ring_chunked, steps_chunked = m.step_counter.clone(), m.local_step
+        monkeypatch.delenv("NERFSIG_STAGED_FUSED")
+    assert torch.equal(fused["image"], chunked["image"])
+    assert torch.allclose(fused["depth"], chunked["depth"], rtol=0, atol=0, equal_nan=True)
+    assert steps_fused == steps_chunked == 187 and torch.equal(ring_fused, ring_chunked)
+    assert 0.05 < float((fused["image"] < 0.999).any(-1).float().mean())          # a real picture, not only background
+    pick = np.random.RandomState(21).choice(H * W, 2048, replace=False)
+    with torch.no_grad():
+        ref = fr.render(ro[:, pick].cpu(), rd[:, pick].cpu(), msg, P, S, staged=False, bg_color=1, dt_gamma=cfg["dt_gamma"], max_steps=1024)
+    assert ref["n_points"] > 100_000
+    np.testing.assert_allclose(fused["image"][0, pick].cpu().numpy(), ref["image"][0].numpy(), rtol=0, atol=1e-3)
+    hit = ~torch.isnan(ref["depth"][0])
+    np.testing.assert_allclose(fused["depth"][0, pick].cpu()[hit].numpy(), ref["depth"][0][hit].numpy(), rtol=0, atol=1e-3)
+
+
+def test_fern_48_blocks_decoder_logits_and_bit_accuracy_vs_oracle(fern):
+    """The 48 selected 11x15 blocks (64x64 block grid over 1008x756) rendered with the message and decoded (eval_step's block branch,
+    utils_wtmk_disen.py:662-680): rendered blocks, decoder logits and bit accuracy against the oracle's render of the same 7920 rays
+    through the stock decoder on the CPU."""
+    import copy
+    from nerf_signature_amd import synthetic
+    from nerf_signature_amd.trainer import BIT_ACC
+    m, cfg, _, _, msg, P, S = fern
+    bo, bd = synthetic.block_rays("fern")
+    assert bo.shape == (48, 11, 15, 3)
+    with torch.no_grad():
+        out = m.render(bo.cuda(), bd.cuda(), msg, staged=False, bg_color=1, perturb=False, force_all_rays=True, dt_gamma=cfg["dt_gamma"], max_steps=1024)
+        img1 = out["image"].clamp(0, 1)
+        dec1 = m.msg_decoder(m.normalization(img1.permute(0, 3, 1, 2)))
+        ref = fr.render(bo.reshape(1, -1, 3), bd.reshape(1, -1, 3), msg, P, S, staged=True, max_ray_batch=11 * 15 * 6, bg_color=1,
+                        dt_gamma=cfg["dt_gamma"], max_steps=1024)
+        img0 = ref["image"].reshape(48, 11, 15, 3).clamp(0, 1)
+        dec0 = copy.deepcopy(m.msg_decoder).cpu()(fr.normalize_img(img0.permute(0, 3, 1, 2)))
+    np.testing.assert_allclose(img1.cpu().numpy(), img0.numpy(), rtol=0, atol=1e-3)
+    np.testing.assert_allclose(dec1.cpu().numpy(), dec0.numpy(), rtol=0, atol=2e-3)
+    a1, a0 = BIT_ACC(), BIT_ACC()
+    a1.update(dec1.cpu().permute(1, 0), msg[None])
+    a0.update(dec0.permute(1, 0), msg[None])
+    assert abs(a1.measure() - a0.measure()) <= 1.0 / 48                 # within one bit (north_star)

@@ -144,24 +144,31 @@ def test_march_train_vs_reference(rmod, bound, dt_gamma, n, max_steps, perturb):
     np.testing.assert_array_equal(dl0[:total], _np(dl_r))
 
 
-def test_bench_workload_march_vs_reference(rmod):
-    """All 4608 block rays + 4096 content rays of the bench step (scene S0): counts and samples bit-exact against the reference kernel."""
+@pytest.mark.parametrize("scene", ["hotdog", "counter"])
+def test_bench_workload_march_vs_reference(rmod, scene):
+    """All 4608 block rays + 4096 content rays of the bench step -- scene S0 (hotdog-like, one cascade) and scene S1 (counter-like: bound 2,
+    two cascades, camera inside, ~500 / ~240 samples per ray, the cascade chosen per sample by mip_from_pos / mip_from_dt,
+    raymarching.cu:42-54,368) -- counts and every sample bit-exact against the reference's own kernel."""
     from nerf_signature_amd import synthetic
-    bits = torch.from_numpy(cf.ball_scene(bound=1.0)[1]).cuda()
-    aabb = torch.tensor([-1., -1, -1, 1, 1, 1], device="cuda")
-    bo, bd = synthetic.block_rays("hotdog", "cuda")
-    co, cd = synthetic.content_rays("hotdog", 4096, seed=0, device="cuda")
+    cfg = synthetic.SCENES[scene]
+    b = cfg["bound"]
+    C = 1 if b == 1.0 else 2
+    bits = torch.from_numpy(synthetic.pack_bits_np(synthetic.density_grid(b), 10.0)[0]).cuda()
+    aabb = torch.tensor([-b, -b, -b, b, b, b], device="cuda")
+    bo, bd = synthetic.block_rays(scene, "cuda")
+    co, cd = synthetic.content_rays(scene, 4096, seed=0, device="cuda")
     for o, d in ((bo.reshape(-1, 3), bd.reshape(-1, 3)), (co.reshape(-1, 3), cd.reshape(-1, 3))):
         o, d = o.contiguous(), d.contiguous()
         n = o.shape[0]
         nears, fars = ref.near_far_from_aabb(o, d, aabb, 0.2)
-        x_r, d_r, dl_r, rays_r, ctr_r = ref.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars)
+        x_r, d_r, dl_r, rays_r, ctr_r = ref.march_rays_train(o, d, b, bits, C, 128, nears, fars, dt_gamma=cfg["dt_gamma"])
         rays_r = _by_ray_id(rays_r)
         total = int(ctr_r[0])
         x_r, dl_r = _gather_points(rays_r, x_r, dl_r)
         ctr1 = torch.zeros(2, dtype=torch.int32, device="cuda")
-        x1, d1, dl1, rays1 = rmod.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, ctr1, -1, False, 128, True, 0.0, 1024)
+        x1, d1, dl1, rays1 = rmod.march_rays_train(o, d, b, bits, C, 128, nears, fars, ctr1, -1, False, 128, True, cfg["dt_gamma"], 1024)
         assert int(ctr1[0]) == total and torch.equal(rays1[:, 2].long(), rays_r[:, 2])
+        assert total > (100_000 if scene == "hotdog" else 900_000)
         assert torch.equal(x1[:total], x_r) and torch.equal(dl1[:total], dl_r)
         assert not bool(x1[total:].any())                    # alignment padding is zero rows (raymarching.py:205-207,225-229)
 

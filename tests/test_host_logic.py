@@ -566,3 +566,33 @@ def test_bench_under_an_external_launcher_supervises_its_own_worker_and_walks_th
     assert len(lines) == 1, out.stdout
     line = json.loads(lines[0])
     assert line["value"] is None and [f["attempt"] for f in line["config"]["launch_failures"]] == [0, 1, 2, 3]
+
+
+def test_tcnn_layout_checker_recovers_every_hypothesis_and_agrees_with_the_oracle_under_the_documented_one():
+    """tools/check_tcnn_layout.py: the checker for the one unpinnable part of the path.  (a) its self-test: each
+    of the 48 layout hypotheses is recovered from a dump generated under it, and a transposed / zero-padded checkpoint converts into the
+    documented layout; (b) under the documented layout its own field evaluation (written independently, no oracle import) equals the
+    oracle's NeRFNetwork.forward restatement, with and without a message -- so "matches the documented layout" means "matches what the
+    kernels are tested against"."""
+    import importlib.util
+    from oracle import field_ref as fr
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_tcnn_layout", os.path.join(root, "tools", "check_tcnn_layout.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    assert tool.self_test() == 48
+    src = open(os.path.join(root, "tools", "check_tcnn_layout.py")).read()
+    assert "import oracle" not in src and "from oracle" not in src
+    g = torch.Generator().manual_seed(3)
+    base = [(torch.rand(1 << 19, 2, generator=g) - 0.5) for _ in range(16)]
+    cb = [(torch.rand(1 << 19, 2, generator=g) - 0.5) * 0.1 for _ in range(8)]
+    sp, cp = torch.randn(3072, generator=g) * 0.2, torch.randn(7168, generator=g) * 0.2
+    x = (torch.rand(300, 3, generator=g) * 2 - 1) * 1.8
+    d = torch.nn.functional.normalize(torch.randn(300, 3, generator=g), dim=-1)
+    P = {"bound": 2.0, "base_tables": base, "cb_tables": cb, "sigma_params": sp, "color_params": cp}
+    for msg in (None, torch.tensor([1.0, 0.0, 1.0, 1.0])):
+        s0, c0 = fr.field_forward(x, d, msg, P)
+        feat = tool.features(x, 2.0, base, cb, None if msg is None else msg.numpy())
+        s1, c1 = tool.evaluate(feat, d, sp, cp, tool.ASSUMED)
+        np.testing.assert_allclose(s1.numpy(), s0.numpy(), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(c1.numpy(), c0.numpy(), rtol=0, atol=2e-6)
