@@ -455,6 +455,8 @@ def run_secondaries(args):
         t0 = time.time()
         try:
             env = dict(os.environ, NERFSIG_BENCH_VARIANT="0")
+            if name == "rank_of_8_emulated":       # the mode the launcher's chain tries first for N > 1: the collectives captured inside the step's graph
+                env.setdefault("NERFSIG_CAPTURE_COLLECTIVES", "1")
             r = subprocess.run([sys.executable] + argv, env=env, capture_output=True, text=True, timeout=float(os.environ.get("NERFSIG_SECONDARY_TIMEOUT_S", "150")))
             lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not lines:
