@@ -78,6 +78,23 @@ int rm_march_train_write(const float *rays_o, const float *rays_d, float bound, 
                          const float *t_rec, const int32_t *rays, const int32_t *counter, float *xyzs, float *dirs,
                          float *deltas, nsig_stream_t stream);
 
+/*
+ * The same march in TWO enqueues (what a captured training step runs):
+ *   rm_march_train_count_nf  = near_far_from_aabb (raymarching.h:7) + count: the walk computes each ray's limits itself (same
+ *                              arithmetic as rm_near_far_from_aabb, bit for bit) and stores them to nears / fars for the kernels behind it;
+ *   rm_march_train_scan_write = scan + write: every workgroup scans the N counts for itself (N + 1 offsets in LDS), so no
+ *                              single-workgroup launch sits between the walk and the writes; N <= rm_march_train_scan_write_max_rays().
+ * Results (rays, counter, every row, the zero padding) are identical to the three-enqueue form.
+ */
+int rm_march_train_count_nf(const float *rays_o, const float *rays_d, const float *aabb, float min_near, const uint8_t *grid,
+                            float bound, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                            const float *noises, float *nears, float *fars, int32_t *counts, float *t_rec, nsig_stream_t stream);
+int rm_march_train_scan_write_max_rays(void);
+int rm_march_train_scan_write(const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t N,
+                              uint32_t C, uint32_t H, uint32_t M, const float *nears, const float *noises, const float *t_rec,
+                              const int32_t *counts, int32_t *rays, int32_t *counter, float *xyzs, float *dirs, float *deltas,
+                              nsig_stream_t stream);
+
 /* replaces composite_rays_train_forward (raymarching.h:14, raymarching.cu:501-588) */
 int rm_composite_train_fwd(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays,
                            uint32_t M, uint32_t N, float T_thresh, float *weights_sum, float *depth, float *image,

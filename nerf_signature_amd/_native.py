@@ -30,6 +30,9 @@ SIGNATURES = {
     "rm_march_train_count": [_vp, _vp, _vp, _fl, _fl, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp],
     "rm_march_train_scan": [_vp, _u32, _vp, _vp, _vp],
     "rm_march_train_write": [_vp, _vp, _fl, _fl, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "rm_march_train_count_nf": [_vp, _vp, _vp, _fl, _vp, _fl, _fl, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "rm_march_train_scan_write_max_rays": [],
+    "rm_march_train_scan_write": [_vp, _vp, _fl, _fl, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "rm_composite_train_fwd": [_vp, _vp, _vp, _vp, _u32, _u32, _fl, _vp, _vp, _vp, _vp],
     "rm_composite_train_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _fl, _vp, _vp, _vp],
     "rm_march": [_u32, _u32, _vp, _vp, _vp, _vp, _fl, _fl, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],

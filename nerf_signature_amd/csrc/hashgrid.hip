@@ -386,10 +386,41 @@ __global__ void __launch_bounds__(kBinThreads) k_plan_count(const float *__restr
     if (threadIdx.x < kBinSlices) hd->wg[blockIdx.x][threadIdx.x] = h[threadIdx.x];
 }
 
-__global__ void __launch_bounds__(kBinThreads) k_plan_dest(const float *__restrict__ xyzs, uint32_t M, float bound, const BinHeader *__restrict__ hd,
+// Every workgroup derives its own write offsets from the count table (wg[w][s], 64 KiB at most, L2-resident): slice starts = exclusive
+// prefix over the slice totals, plus what the workgroups in front of it found for that slice -- the single-workgroup scan launch that
+// used to sit between the two passes (k_bin_scan: 2-16 us in a chain of small launches) is gone.  Workgroup 0 stores the slice totals
+// the owners read.  Same queue order as count -> scan -> dest.
+__global__ void __launch_bounds__(kBinThreads) k_plan_dest(const float *__restrict__ xyzs, uint32_t M, float bound, BinHeader *__restrict__ hd,
                                                            uint4 *__restrict__ dest) {
-    __shared__ uint32_t h[kBinSlices], running[kBinSlices];
-    if (threadIdx.x < kBinSlices) running[threadIdx.x] = hd->wg[blockIdx.x][threadIdx.x];
+    __shared__ uint32_t h[kBinSlices], running[kBinSlices], seg_tot[16][kBinSlices], seg_before[16][kBinSlices];
+    {
+        static_assert(kBinThreads == 16 * kBinSlices && kBinGrid == 256, "16 segments of 16 workgroups, one thread per (segment, slice)");
+        const uint32_t s = threadIdx.x & (kBinSlices - 1), g = threadIdx.x >> 6, n_wg = gridDim.x;
+        uint32_t tot = 0, before = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t w = g * 16 + i;
+            const uint32_t c = w < n_wg ? hd->wg[w][s] : 0u;
+            tot += c;
+            if (w < blockIdx.x) before += c;
+        }
+        seg_tot[g][s] = tot;
+        seg_before[g][s] = before;
+        __syncthreads();
+        if (threadIdx.x < kBinSlices) {      // one wave: slice totals, their exclusive prefix, this workgroup's offset inside each slice
+            uint32_t t = 0, b = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { t += seg_tot[k][threadIdx.x]; b += seg_before[k][threadIdx.x]; }
+            uint32_t incl = t;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t v = (uint32_t)__shfl_up((int)incl, d, 64);
+                if ((int)threadIdx.x >= d) incl += v;
+            }
+            running[threadIdx.x] = incl - t + b;
+            if (blockIdx.x == 0) hd->counts[threadIdx.x] = t;
+        }
+    }
     for (uint32_t m0 = blockIdx.x * kBinThreads; m0 < M; m0 += gridDim.x * kBinThreads) {   // uniform trip count: barriers inside
         if (threadIdx.x < kBinSlices) h[threadIdx.x] = 0;
         __syncthreads();
@@ -985,7 +1016,6 @@ NSIG_EXPORT int hg_scatter_plan(const float *xyzs, uint32_t M, float bound, void
     hipStream_t st = as_stream(stream);
     const uint32_t blocks = ceil_div(M, kBinThreads) < kBinGrid ? ceil_div(M, kBinThreads) : kBinGrid;
     k_plan_count<<<blocks, kBinThreads, 0, st>>>(xyzs, M, bound, pl.hd);
-    k_bin_scan<<<1, 1024, 0, st>>>(pl.hd, blocks);
     k_plan_dest<<<blocks, kBinThreads, 0, st>>>(xyzs, M, bound, pl.hd, pl.dest);
     return check_launch("hg_scatter_plan");
 }

@@ -18,20 +18,20 @@ namespace nsig {
 
 constexpr float kSqrt3 = 1.7320508075688772f;
 constexpr float kInvPi = 0.3183098861837907f;
+constexpr uint32_t kScanWriteMaxRays = 12288;   // k_march_scan_write keeps N + 1 offsets in LDS (48 KiB: three workgroups per CU at the limit)
 
 // ----------------------------------------------------------------------------- small utilities
 
-__global__ void k_near_far(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                           const float *__restrict__ aabb, uint32_t N, float min_near, float *__restrict__ nears,
-                           float *__restrict__ fars) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+// raymarching.cu:92-145.  One definition for the stand-alone kernel and for the march that computes its own limits: same instructions,
+// same results bit for bit.
+__device__ inline void near_far_of(const float *__restrict__ o3, const float *__restrict__ d3, const float *__restrict__ aabb, float min_near,
+                                   float &near, float &far) {
     float tmin = 0.f, tmax = 0.f;
     bool miss = false;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float o = rays_o[3 * n + a];
-        const float inv = 1.0f / rays_d[3 * n + a];
+        const float o = o3[a];
+        const float inv = 1.0f / d3[a];
         float lo = (aabb[a] - o) * inv;
         float hi = (aabb[a + 3] - o) * inv;
         if (lo > hi) { const float s = lo; lo = hi; hi = s; }
@@ -41,9 +41,20 @@ __global__ void k_near_far(const float *__restrict__ rays_o, const float *__rest
             else { if (lo > tmin) tmin = lo; if (hi < tmax) tmax = hi; }
         }
     }
-    if (miss) { nears[n] = FLT_MAX; fars[n] = FLT_MAX; return; }
-    nears[n] = tmin < min_near ? min_near : tmin;
-    fars[n] = tmax;
+    if (miss) { near = FLT_MAX; far = FLT_MAX; return; }
+    near = tmin < min_near ? min_near : tmin;
+    far = tmax;
+}
+
+__global__ void k_near_far(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                           const float *__restrict__ aabb, uint32_t N, float min_near, float *__restrict__ nears,
+                           float *__restrict__ fars) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float near, far;
+    near_far_of(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, aabb, min_near, near, far);
+    nears[n] = near;
+    fars[n] = far;
 }
 
 __global__ void k_sph_from_ray(const float *__restrict__ rays_o, const float *__restrict__ rays_d, float radius,
@@ -322,20 +333,30 @@ __device__ inline bool chunk_closed_form(float t0, float dt, int lane, float &tj
     return true;
 }
 
+// aabb != nullptr: the ray's limits are computed here (near_far_of) and stored to nears / fars for the kernels behind the march --
+// the stand-alone near/far launch in front of every training march disappears (rm_march_train_count_nf).
 template <bool kOneCascade, bool kConstDt>
 __global__ void __launch_bounds__(256) k_march_index(const float *__restrict__ rays_o, const float *__restrict__ rays_d, GridView g,
-                                                      uint32_t max_steps, uint32_t N, const float *__restrict__ nears,
-                                                      const float *__restrict__ fars, const float *__restrict__ noises,
-                                                      int32_t *__restrict__ counts, float *__restrict__ t_rec) {
+                                                      uint32_t max_steps, uint32_t N, float *__restrict__ nears,
+                                                      float *__restrict__ fars, const float *__restrict__ noises,
+                                                      int32_t *__restrict__ counts, float *__restrict__ t_rec,
+                                                      const float *__restrict__ aabb, float min_near) {
     __shared__ float ts[4][64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint32_t n = blockIdx.x * 4 + wid;  // one wave per ray
     if (n >= N) return;
     const Ray r(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n);
     Walker<kOneCascade> w(g, r);
-    const float far = fars[n];
+    float near, far;
+    if (aabb != nullptr) {      // (wave-uniform: every lane computes the same two numbers)
+        near_far_of(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, aabb, min_near, near, far);
+        if (lane == 0) { nears[n] = near; fars[n] = far; }
+    } else {
+        near = nears[n];
+        far = fars[n];
+    }
     auto step = [&](float t) { return kConstDt ? g.dt_const : step_len(g, t); };  // dt_gamma == 0: clamp(0, dt_min, dt_max), a constant
-    float t_base = start_param(g, nears[n], noises ? noises[n] : 0.0f);
+    float t_base = start_param(g, near, noises ? noises[n] : 0.0f);
     float *rec = t_rec + (size_t)n * max_steps;
     float *tl = ts[wid];
     uint32_t cnt = 0;
@@ -509,6 +530,87 @@ __global__ void k_march_write(const float *__restrict__ rays_o, const float *__r
             }
         }
         // three stores per row instead of eight (12 + 12 + 8 bytes)
+        *reinterpret_cast<float3 *>(xyzs + 3 * (size_t)m) = make_float3(px, py, pz);
+        *reinterpret_cast<float3 *>(dirs + 3 * (size_t)m) = make_float3(qx, qy, qz);
+        *reinterpret_cast<float2 *>(deltas + 2 * (size_t)m) = make_float2(d0, d1);
+    }
+}
+
+// Passes 2 + 3 in ONE launch for ray counts whose offsets fit in LDS (the training step's 4096 / 4608 rays): every workgroup computes the
+// whole exclusive prefix sum of the counts for itself -- N int32 from L2, a 256-thread scan, ~2 us overlapped across the eight resident
+// workgroups of a CU -- instead of one single-workgroup launch between the walk and the writes (5 us alone, 60-90 us when its loads
+// queue behind the optimiser's HBM stream, profiles/r02_f_kernel_stats.csv); a row's ray is then found by a binary search in LDS
+// (13 dependent ~50-cycle reads instead of 13 dependent L2 round trips).  Workgroup 0 also stores the (id, offset, count) table
+// and the totals.  Same ray-id order, same rows, same padding as k_march_scan + k_march_write.
+__global__ void __launch_bounds__(256) k_march_scan_write(const float *__restrict__ rays_o, const float *__restrict__ rays_d, GridView g,
+                                                          uint32_t max_steps, uint32_t N, uint32_t M, const float *__restrict__ nears,
+                                                          const float *__restrict__ noises, const float *__restrict__ t_rec,
+                                                          const int32_t *__restrict__ counts, int32_t *__restrict__ rays,
+                                                          int32_t *__restrict__ counter, float *__restrict__ xyzs, float *__restrict__ dirs,
+                                                          float *__restrict__ deltas) {
+    extern __shared__ int32_t off[];      // [N + 1]: counts, then in place their exclusive prefix sums; off[N] = total
+    __shared__ int32_t wave_tot[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (uint32_t i = tid; i < N; i += 256) off[i] = counts[i];
+    __syncthreads();
+    const uint32_t chunk = ceil_div(N, 256u);
+    const uint32_t beg = min(N, tid * chunk), end = min(N, beg + chunk);
+    int32_t sum = 0;
+    for (uint32_t i = beg; i < end; ++i) sum += off[i];
+    int32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t v = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += v;
+    }
+    if (lane == 63) wave_tot[wid] = incl;
+    __syncthreads();
+    int32_t run = incl - sum;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        if (w < (int)wid) run += wave_tot[w];
+    const bool first = blockIdx.x == 0;
+    for (uint32_t i = beg; i < end; ++i) {
+        const int32_t c = off[i];
+        off[i] = run;
+        if (first) {
+            rays[3 * (size_t)i] = (int32_t)i;
+            rays[3 * (size_t)i + 1] = run;
+            rays[3 * (size_t)i + 2] = c;
+        }
+        run += c;
+    }
+    if (tid == 255) {
+        off[N] = run;
+        if (first) { counter[0] = run; counter[1] = (int32_t)N; }
+    }
+    __syncthreads();
+    const uint32_t total = (uint32_t)off[N];
+    for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+        float px = 0, py = 0, pz = 0, qx = 0, qy = 0, qz = 0, d0 = 0, d1 = 0;
+        if (m < total) {
+            uint32_t lo = 0, hi = N;      // last ray whose offset <= m (rays with no samples share their successor's offset)
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((uint32_t)off[mid] <= m) lo = mid; else hi = mid;
+            }
+            const uint32_t o0 = (uint32_t)off[lo], cnt = (uint32_t)off[lo + 1] - o0;
+            if (o0 + cnt <= M) {  // raymarching.cu:416: a ray that does not fit writes nothing
+                const uint32_t s = m - o0;
+                const float *rec = t_rec + (size_t)lo * max_steps;
+                const float t = rec[s];
+                const float3 rd = *reinterpret_cast<const float3 *>(rays_d + 3 * (size_t)lo), ro = *reinterpret_cast<const float3 *>(rays_o + 3 * (size_t)lo);
+                qx = rd.x; qy = rd.y; qz = rd.z;
+                px = clampf(fmaf(t, qx, ro.x), -g.bound, g.bound);
+                py = clampf(fmaf(t, qy, ro.y), -g.bound, g.bound);
+                pz = clampf(fmaf(t, qz, ro.z), -g.bound, g.bound);
+                d0 = step_len(g, t);
+                float last;
+                if (s == 0) last = start_param(g, nears[lo], noises ? noises[lo] : 0.0f);
+                else { const float tp = rec[s - 1]; last = tp + step_len(g, tp); }
+                d1 = (t + d0) - last;
+            }
+        }
         *reinterpret_cast<float3 *>(xyzs + 3 * (size_t)m) = make_float3(px, py, pz);
         *reinterpret_cast<float3 *>(dirs + 3 * (size_t)m) = make_float3(qx, qy, qz);
         *reinterpret_cast<float2 *>(deltas + 2 * (size_t)m) = make_float2(d0, d1);
@@ -841,21 +943,37 @@ static int check_grid_args(const char *who, uint32_t C, uint32_t H, uint32_t max
     return NSIG_OK;
 }
 
+static int launch_march_index(const char *who, const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
+                              uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, float *nears, float *fars, const float *noises,
+                              int32_t *counts, float *t_rec, const float *aabb, float min_near, nsig_stream_t stream) {
+    if (int e = check_grid_args(who, C, H, max_steps, bound)) return e;
+    const GridView gv = make_grid_view(grid, bound, dt_gamma, max_steps, C, H);
+    const uint32_t blocks = ceil_div(N, 4u);
+    hipStream_t st = as_stream(stream);
+    if (C == 1 && dt_gamma == 0.0f) k_march_index<true, true><<<blocks, 256, 0, st>>>(rays_o, rays_d, gv, max_steps, N, nears, fars, noises, counts, t_rec, aabb, min_near);
+    else if (C == 1) k_march_index<true, false><<<blocks, 256, 0, st>>>(rays_o, rays_d, gv, max_steps, N, nears, fars, noises, counts, t_rec, aabb, min_near);
+    else if (dt_gamma == 0.0f) k_march_index<false, true><<<blocks, 256, 0, st>>>(rays_o, rays_d, gv, max_steps, N, nears, fars, noises, counts, t_rec, aabb, min_near);
+    else k_march_index<false, false><<<blocks, 256, 0, st>>>(rays_o, rays_d, gv, max_steps, N, nears, fars, noises, counts, t_rec, aabb, min_near);
+    return check_launch(who);
+}
+
 NSIG_EXPORT int rm_march_train_count(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound,
                                      float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                                      const float *nears, const float *fars, const float *noises, int32_t *counts,
                                      float *t_rec, nsig_stream_t stream) {
     if (N == 0) return NSIG_OK;
     NSIG_REQUIRE(rays_o && rays_d && grid && nears && fars && counts && t_rec, "rm_march_train_count: null pointer");
-    if (int e = check_grid_args("rm_march_train_count", C, H, max_steps, bound)) return e;
-    const GridView gv = make_grid_view(grid, bound, dt_gamma, max_steps, C, H);
-    const uint32_t blocks = ceil_div(N, 4u);
-    hipStream_t st = as_stream(stream);
-    if (C == 1 && dt_gamma == 0.0f) k_march_index<true, true><<<blocks, 256, 0, st>>>(rays_o, rays_d, gv, max_steps, N, nears, fars, noises, counts, t_rec);
-    else if (C == 1) k_march_index<true, false><<<blocks, 256, 0, st>>>(rays_o, rays_d, gv, max_steps, N, nears, fars, noises, counts, t_rec);
-    else if (dt_gamma == 0.0f) k_march_index<false, true><<<blocks, 256, 0, st>>>(rays_o, rays_d, gv, max_steps, N, nears, fars, noises, counts, t_rec);
-    else k_march_index<false, false><<<blocks, 256, 0, st>>>(rays_o, rays_d, gv, max_steps, N, nears, fars, noises, counts, t_rec);
-    return check_launch("rm_march_train_count");
+    return launch_march_index("rm_march_train_count", rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, const_cast<float *>(nears),
+                              const_cast<float *>(fars), noises, counts, t_rec, nullptr, 0.0f, stream);
+}
+
+NSIG_EXPORT int rm_march_train_count_nf(const float *rays_o, const float *rays_d, const float *aabb, float min_near, const uint8_t *grid,
+                                        float bound, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                        const float *noises, float *nears, float *fars, int32_t *counts, float *t_rec, nsig_stream_t stream) {
+    if (N == 0) return NSIG_OK;
+    NSIG_REQUIRE(rays_o && rays_d && aabb && grid && nears && fars && counts && t_rec, "rm_march_train_count_nf: null pointer");
+    return launch_march_index("rm_march_train_count_nf", rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, noises, counts, t_rec,
+                              aabb, min_near, stream);
 }
 
 NSIG_EXPORT int rm_march_train_scan(const int32_t *counts, uint32_t N, int32_t *rays, int32_t *counter,
@@ -878,6 +996,22 @@ NSIG_EXPORT int rm_march_train_write(const float *rays_o, const float *rays_d, f
     k_march_write<<<blocks, 256, 0, as_stream(stream)>>>(rays_o, rays_d, make_grid_view(nullptr, bound, dt_gamma, max_steps, C, H),
                                                         max_steps, N, M, nears, noises, t_rec, rays, counter, xyzs, dirs, deltas);
     return check_launch("rm_march_train_write");
+}
+
+NSIG_EXPORT int rm_march_train_scan_write_max_rays(void) { return (int)kScanWriteMaxRays; }
+
+NSIG_EXPORT int rm_march_train_scan_write(const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t N,
+                                          uint32_t C, uint32_t H, uint32_t M, const float *nears, const float *noises, const float *t_rec,
+                                          const int32_t *counts, int32_t *rays, int32_t *counter, float *xyzs, float *dirs, float *deltas,
+                                          nsig_stream_t stream) {
+    NSIG_REQUIRE(rays_o && rays_d && nears && t_rec && counts && rays && counter, "rm_march_train_scan_write: null pointer");
+    NSIG_REQUIRE(M == 0 || (xyzs && dirs && deltas), "rm_march_train_scan_write: null point buffers");
+    NSIG_REQUIRE(N >= 1 && N <= kScanWriteMaxRays, "rm_march_train_scan_write: N=%u outside [1, %u] (use rm_march_train_scan + rm_march_train_write)", N, kScanWriteMaxRays);
+    if (int e = check_grid_args("rm_march_train_scan_write", C, H, max_steps, bound)) return e;
+    const uint32_t blocks = max(1u, min(ceil_div(M, 256), (uint32_t)(kCUs * 8)));     // (M == 0: workgroup 0 still writes the ray table and the totals)
+    k_march_scan_write<<<blocks, 256, (N + 1) * sizeof(int32_t), as_stream(stream)>>>(rays_o, rays_d, make_grid_view(nullptr, bound, dt_gamma, max_steps, C, H),
+                                                                                      max_steps, N, M, nears, noises, t_rec, counts, rays, counter, xyzs, dirs, deltas);
+    return check_launch("rm_march_train_scan_write");
 }
 
 NSIG_EXPORT int rm_composite_train_fwd(const float *sigmas, const float *rgbs, const float *deltas,

@@ -10,6 +10,8 @@ nerf/renderer_wtmk.py work unchanged.  Differences that are part of the contract
     allocated at their final padded size;
   * kernels run on torch's current stream; arguments are validated (device, dtype, contiguity).
 """
+import os
+
 import torch
 from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
@@ -127,21 +129,42 @@ packbits = _packbits.apply
 
 # ----------------------------------------------------------------------------------------- training
 
+_SCAN_WRITE_MAX = None
+
+
+def scan_write_max_rays():
+    """Largest ray count rm_march_train_scan_write takes (its N + 1 offsets live in LDS)."""
+    global _SCAN_WRITE_MAX
+    if _SCAN_WRITE_MAX is None:      # NERFSIG_MARCH_FUSED=0: the four-enqueue form everywhere (A/B measurements)
+        _SCAN_WRITE_MAX = 0 if os.environ.get("NERFSIG_MARCH_FUSED", "1") == "0" else int(nv.fn("rm_march_train_scan_write_max_rays")())
+    return _SCAN_WRITE_MAX
+
+
 def march_rays_train_device(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, counter, noises, dt_gamma,
-                            max_steps, capacity=None, out=None):
-    """The three enqueues of the training march with no host synchronisation.
+                            max_steps, capacity=None, out=None, limits=None):
+    """The enqueues of the training march with no host synchronisation.
 
     Returns (counts, t_rec, rays, write) where `write(M)` fills xyzs/dirs/deltas of M rows -- freshly allocated, or the
-    tensors of `out` = (xyzs, dirs, deltas, rays) when given.  `counter` (int32[2]) receives (total points, N) on the device."""
+    tensors of `out` = (xyzs, dirs, deltas, rays) when given.  `counter` (int32[2]) receives (total points, N) on the device.
+    capacity: the row count is known up front (no host read of the total in between), so for ray counts whose offsets fit in LDS the
+    prefix sum rides in the write launch (rm_march_train_scan_write) instead of a single-workgroup launch of its own.
+    limits = (aabb, min_near): `nears` / `fars` are OUTPUTS, filled by the walk itself (rm_march_train_count_nf) instead of a
+    near_far_from_aabb launch in front of it."""
     N = rays_o.shape[0]
     dev = rays_o.device
     counts = torch.empty(N, dtype=torch.int32, device=dev)
     t_rec = torch.empty(N * max_steps, dtype=torch.float32, device=dev)
     rays = torch.empty(N, 3, dtype=torch.int32, device=dev) if out is None else out[3]
     s = nv.stream()
-    nv.call("rm_march_train_count", nv.ptr(rays_o), nv.ptr(rays_d), nv.ptr(density_bitfield), float(bound), float(dt_gamma),
-            int(max_steps), N, int(C), int(H), nv.ptr(nears), nv.ptr(fars), nv.ptr(noises), nv.ptr(counts), nv.ptr(t_rec), s)
-    nv.call("rm_march_train_scan", nv.ptr(counts), N, nv.ptr(rays), nv.ptr(counter), s)
+    if limits is not None:
+        nv.call("rm_march_train_count_nf", nv.ptr(rays_o), nv.ptr(rays_d), nv.ptr(_f32c(limits[0])), float(limits[1]), nv.ptr(density_bitfield), float(bound),
+                float(dt_gamma), int(max_steps), N, int(C), int(H), nv.ptr(noises), nv.ptr(nears), nv.ptr(fars), nv.ptr(counts), nv.ptr(t_rec), s)
+    else:
+        nv.call("rm_march_train_count", nv.ptr(rays_o), nv.ptr(rays_d), nv.ptr(density_bitfield), float(bound), float(dt_gamma),
+                int(max_steps), N, int(C), int(H), nv.ptr(nears), nv.ptr(fars), nv.ptr(noises), nv.ptr(counts), nv.ptr(t_rec), s)
+    fused = capacity is not None and 1 <= N <= scan_write_max_rays()
+    if not fused:
+        nv.call("rm_march_train_scan", nv.ptr(counts), N, nv.ptr(rays), nv.ptr(counter), s)
 
     def write(M):
         if out is not None:
@@ -152,16 +175,21 @@ def march_rays_train_device(rays_o, rays_d, bound, density_bitfield, C, H, nears
             xyzs = torch.empty(M, 3, dtype=torch.float32, device=dev)
             dirs = torch.empty(M, 3, dtype=torch.float32, device=dev)
             deltas = torch.empty(M, 2, dtype=torch.float32, device=dev)
-        nv.call("rm_march_train_write", nv.ptr(rays_o), nv.ptr(rays_d), float(bound), float(dt_gamma), int(max_steps), N, int(C),
-                int(H), M, nv.ptr(nears), nv.ptr(noises), nv.ptr(t_rec), nv.ptr(rays), nv.ptr(counter), nv.ptr(xyzs),
-                nv.ptr(dirs), nv.ptr(deltas), nv.stream())
+        if fused:
+            nv.call("rm_march_train_scan_write", nv.ptr(rays_o), nv.ptr(rays_d), float(bound), float(dt_gamma), int(max_steps), N, int(C), int(H), M,
+                    nv.ptr(nears), nv.ptr(noises), nv.ptr(t_rec), nv.ptr(counts), nv.ptr(rays), nv.ptr(counter), nv.ptr(xyzs), nv.ptr(dirs),
+                    nv.ptr(deltas), nv.stream())
+        else:
+            nv.call("rm_march_train_write", nv.ptr(rays_o), nv.ptr(rays_d), float(bound), float(dt_gamma), int(max_steps), N, int(C),
+                    int(H), M, nv.ptr(nears), nv.ptr(noises), nv.ptr(t_rec), nv.ptr(rays), nv.ptr(counter), nv.ptr(xyzs),
+                    nv.ptr(dirs), nv.ptr(deltas), nv.stream())
         return xyzs, dirs, deltas
 
     return counts, t_rec, rays, write
 
 
 def march_rays_train_capacity(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter, capacity, perturb=False,
-                              dt_gamma=0, max_steps=1024, out=None):
+                              dt_gamma=0, max_steps=1024, out=None, limits=None):
     """march_rays_train with force_all_rays semantics but NO host synchronisation: the point buffers have `capacity` rows
     (a caller-chosen bound on the padded point count); the real total lands in step_counter[0] on the device, rows past
     it are zero, and a ray that does not fit is dropped exactly like the reference's bounded mode (raymarching.cu:416) --
@@ -171,7 +199,7 @@ def march_rays_train_capacity(rays_o, rays_d, bound, density_bitfield, C, H, nea
     N = rays_o.shape[0]
     noises = torch.rand(N, dtype=torch.float32, device=rays_o.device) if perturb else None
     _, _, rays, write = march_rays_train_device(rays_o, rays_d, bound, density_bitfield, C, H, _f32c(nears), _f32c(fars), step_counter, noises,
-                                                dt_gamma, max_steps, out=out)
+                                                dt_gamma, max_steps, capacity=int(capacity), out=out, limits=limits)
     xyzs, dirs, deltas = write(int(capacity))
     return xyzs, dirs, deltas, rays
 

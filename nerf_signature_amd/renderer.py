@@ -260,16 +260,25 @@ class NeRFRenderer(nn.Module):
             raise ValueError("march_ahead: max_steps changed for rays that were marched before")
         N = o.shape[0]
         geom = (float(self.bound), float(dt_gamma), int(max_steps), N, int(self.cascade), int(self.grid_size))
-        if phase in ("all", "count"):
+        if phase in ("all", "count") and raymarching.scan_write_max_rays() == 0:
             raymarching.near_far_into(o, d, self.aabb_train, self.min_near, rec["nears"], rec["fars"])
             rec["noises"] = torch.rand(N, dtype=torch.float32, device=o.device) if perturb else None
             nv.call("rm_march_train_count", nv.ptr(o), nv.ptr(d), nv.ptr(self.density_bitfield), *geom, nv.ptr(rec["nears"]), nv.ptr(rec["fars"]),
                     nv.ptr(rec["noises"]), nv.ptr(rec["counts"]), nv.ptr(rec["t_rec"]), nv.stream())
+        elif phase in ("all", "count"):       # the walk computes the rays' limits itself: no near/far launch in front of it
+            rec["noises"] = torch.rand(N, dtype=torch.float32, device=o.device) if perturb else None
+            nv.call("rm_march_train_count_nf", nv.ptr(o), nv.ptr(d), nv.ptr(self.aabb_train), float(self.min_near), nv.ptr(self.density_bitfield), *geom,
+                    nv.ptr(rec["noises"]), nv.ptr(rec["nears"]), nv.ptr(rec["fars"]), nv.ptr(rec["counts"]), nv.ptr(rec["t_rec"]), nv.stream())
         if phase in ("all", "write"):
-            nv.call("rm_march_train_scan", nv.ptr(rec["counts"]), N, nv.ptr(rec["rays"]), nv.ptr(rec["counter"]), nv.stream())
-            nv.call("rm_march_train_write", nv.ptr(o), nv.ptr(d), geom[0], geom[1], geom[2], N, geom[4], geom[5], capacity, nv.ptr(rec["nears"]),
-                    nv.ptr(rec["noises"]), nv.ptr(rec["t_rec"]), nv.ptr(rec["rays"]), nv.ptr(rec["counter"]), nv.ptr(rec["xyzs"]), nv.ptr(rec["dirs"]),
-                    nv.ptr(rec["deltas"]), nv.stream())
+            if N <= raymarching.scan_write_max_rays():      # prefix sum inside the write launch (no single-workgroup launch between the two)
+                nv.call("rm_march_train_scan_write", nv.ptr(o), nv.ptr(d), geom[0], geom[1], geom[2], N, geom[4], geom[5], capacity, nv.ptr(rec["nears"]),
+                        nv.ptr(rec["noises"]), nv.ptr(rec["t_rec"]), nv.ptr(rec["counts"]), nv.ptr(rec["rays"]), nv.ptr(rec["counter"]), nv.ptr(rec["xyzs"]),
+                        nv.ptr(rec["dirs"]), nv.ptr(rec["deltas"]), nv.stream())
+            else:
+                nv.call("rm_march_train_scan", nv.ptr(rec["counts"]), N, nv.ptr(rec["rays"]), nv.ptr(rec["counter"]), nv.stream())
+                nv.call("rm_march_train_write", nv.ptr(o), nv.ptr(d), geom[0], geom[1], geom[2], N, geom[4], geom[5], capacity, nv.ptr(rec["nears"]),
+                        nv.ptr(rec["noises"]), nv.ptr(rec["t_rec"]), nv.ptr(rec["rays"]), nv.ptr(rec["counter"]), nv.ptr(rec["xyzs"]), nv.ptr(rec["dirs"]),
+                        nv.ptr(rec["deltas"]), nv.stream())
         self._marched = {k: r for k, r in self._marched.items() if r is not rec}
         rec["key"] = self._rays_key(o, d)
         self._marched[rec["key"]] = rec
@@ -287,14 +296,20 @@ class NeRFRenderer(nn.Module):
         if marched is not None and marched.get("fixed") is not None and not torch.cuda.is_current_stream_capturing() and \
                 marched["grid_key"] != self.grid_key():
             marched = self.fix_rays(o, d, *marched["fixed_args"])      # rays declared constant, but the grid they were marched through changed
+        capacity = getattr(self, "point_capacity", None)
+        capacity = capacity.get(o.shape[0]) if capacity else None
+        fused_limits = (marched is None and self.training and capacity is not None and force_all_rays and o.is_cuda and o.dtype == torch.float32
+                        and raymarching.scan_write_max_rays() > 0)
         if marched is not None:
             nears, fars = marched["nears"], marched["fars"]
+        elif fused_limits:       # the capacity march (a captured step) fills them itself: rm_march_train_count_nf
+            nears, fars = torch.empty(o.shape[0], dtype=torch.float32, device=o.device), torch.empty(o.shape[0], dtype=torch.float32, device=o.device)
         else:
             nears, fars = raymarching.near_far_from_aabb(o, d, self.aabb_train if self.training else self.aabb_infer, self.min_near)
         if self.training:
             bg = _background_tensor(bg_color, o) if o.is_cuda else None
             out = self._march_and_composite_train(o, d, message, nears, fars, dt_gamma, perturb, force_all_rays, max_steps, T_thresh, finish=bg,
-                                                  marched=marched)
+                                                  marched=marched, limits=(self.aabb_train, self.min_near) if fused_limits else None)
             if bg is not None:   # the tail was done by the compositing launch
                 weights_sum, depth, image = out
                 return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "weights_sum": weights_sum}
@@ -308,7 +323,7 @@ class NeRFRenderer(nn.Module):
         return results
 
     def _march_and_composite_train(self, o, d, message, nears, fars, dt_gamma, perturb, force_all_rays, max_steps, T_thresh, finish=None,
-                                   marched=None):
+                                   marched=None, limits=None):
         """All samples of all rays at once, then one differentiable composite (renderer_wtmk.py:280-321)."""
         if marched is not None:      # the samples were marched ahead of this step (march_ahead)
             fixed = marched.get("fixed")
@@ -330,7 +345,7 @@ class NeRFRenderer(nn.Module):
             # no host round trip: buffers sized by a known bound on the padded point count (see march_rays_train_capacity)
             xyzs, dirs, deltas, rays = raymarching.march_rays_train_capacity(o, d, self.bound, self.density_bitfield, self.cascade,
                                                                             self.grid_size, nears, fars, counter, capacity, perturb,
-                                                                            dt_gamma, max_steps)
+                                                                            dt_gamma, max_steps, limits=limits)
         else:
             xyzs, dirs, deltas, rays = raymarching.march_rays_train(o, d, self.bound, self.density_bitfield, self.cascade, self.grid_size,
                                                                    nears, fars, counter, self.mean_count, perturb, 128, force_all_rays,

@@ -260,3 +260,48 @@ def test_device_ray_sampler_matches_get_rays():
     assert float((q - N / 4).abs().max()) < 5 * (N * 0.25 * 0.75) ** 0.5
     with pytest.raises(ValueError):
         s.sample_into(ctr, o[:, :10], d, gt)
+
+
+@pytest.mark.parametrize("bound,dt_gamma,n,perturb", [(1.0, 0.0, 4608, False), (1.0, 0.0, 1, False), (1.0, 0.0, 63, True), (2.0, 0.0, 8704, False),
+                                                      (2.0, 1.0 / 128, 4096, True), (1.0, 0.0, 12288, False)])
+def test_two_enqueue_march_equals_the_four_enqueue_march(rmod, bound, dt_gamma, n, perturb):
+    """The captured step's march -- rm_march_train_count_nf (the walk computes near / far itself) + rm_march_train_scan_write (every
+    workgroup scans the counts for itself, offsets in LDS) -- against near_far + count + scan + write: limits, ray table, totals, every
+    row and the zero padding bit for bit; a capacity smaller than the total drops the same rays (raymarching.cu:416); and against the C
+    oracle's counts."""
+    from nerf_signature_amd import _native as nv
+    _, bitfield, C, o, d = _scene(n, bound, seed=3)
+    oc, dc, bits = _cuda(o), _cuda(d), _cuda(bitfield)
+    aabb = torch.tensor([-bound] * 3 + [bound] * 3, device="cuda")
+    noises = torch.rand(n, device="cuda") if perturb else None
+    nears, fars = rmod.near_far_from_aabb(oc, dc, aabb, 0.2)
+    ctr = torch.zeros(2, dtype=torch.int32, device="cuda")
+    counts, t_rec, rays, write = rmod.march_rays_train_device(oc, dc, bound, bits, C, 128, nears, fars, ctr, noises, dt_gamma, 1024)
+    total = int(ctr[0])
+    rays0, total0 = orm.march_counts(o, d, bound, bitfield, C, 128, nears.cpu().numpy(), fars.cpu().numpy(), dt_gamma, 1024,
+                                     noises=None if noises is None else noises.cpu().numpy())
+    assert total == total0 and np.array_equal(rays[:, 2].cpu().numpy(), rays0[:, 2])
+    assert n <= rmod.scan_write_max_rays() == 12288
+    for M in (rmod.padded_point_count(total), max(128, (total // 2) // 128 * 128), 0):
+        x4, d4, dl4 = write(M) if M else (None, None, None)
+        nears2, fars2 = torch.full((n,), -1.0, device="cuda"), torch.full((n,), -1.0, device="cuda")
+        ctr2 = torch.full((2,), -5, dtype=torch.int32, device="cuda")
+        out = None
+        if M:
+            out = (torch.full((M, 3), 7.0, device="cuda"), torch.full((M, 3), 7.0, device="cuda"), torch.full((M, 2), 7.0, device="cuda"),
+                   torch.full((n, 3), -9, dtype=torch.int32, device="cuda"))
+        _, _, rays2, write2 = rmod.march_rays_train_device(oc, dc, bound, bits, C, 128, nears2, fars2, ctr2, noises, dt_gamma, 1024, capacity=M, out=out,
+                                                           limits=(aabb, 0.2))
+        if M:
+            x2, d2, dl2 = write2(M)
+            assert torch.equal(x2, x4) and torch.equal(d2, d4) and torch.equal(dl2, dl4)
+        else:      # no rows: the launch still leaves the ray table and the totals
+            empty = torch.empty(0, 3, device="cuda")
+            nv.call("rm_march_train_scan_write", nv.ptr(oc), nv.ptr(dc), float(bound), float(dt_gamma), 1024, n, C, 128, 0, nv.ptr(nears2), nv.ptr(noises),
+                    nv.ptr(t_rec), nv.ptr(counts), nv.ptr(rays2), nv.ptr(ctr2), None, None, None, nv.stream())
+            del empty
+        assert torch.equal(nears2, nears) and torch.equal(fars2, fars)
+        assert torch.equal(rays2, rays) and torch.equal(ctr2, ctr)
+    with pytest.raises(ValueError, match="outside"):
+        nv.call("rm_march_train_scan_write", nv.ptr(oc), nv.ptr(dc), float(bound), float(dt_gamma), 1024, 12289, C, 128, 128, nv.ptr(nears), None,
+                nv.ptr(t_rec), nv.ptr(counts), nv.ptr(rays), nv.ptr(ctr), nv.ptr(oc), nv.ptr(oc), nv.ptr(oc), nv.stream())
