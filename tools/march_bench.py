@@ -55,6 +55,13 @@ for name, (o, d) in {"block": synthetic.block_rays("hotdog", dev), "content": sy
     gws, gimg = torch.rand(N, device=dev), torch.rand(N, 3, device=dev)
     comp()
     cbwd = lambda: nv.call("rm_composite_train_bwd", nv.ptr(gws), nv.ptr(gimg), nv.ptr(sig), nv.ptr(rgb), nv.ptr(deltas), nv.ptr(rays), nv.ptr(ws), nv.ptr(img), M, N, 1e-4, nv.ptr(gs), nv.ptr(gc), s)
+    # the two-enqueue form (round 3): near/far inside the walk, prefix sum inside the write launch
+    nf = lambda: nv.call("rm_near_far_from_aabb", nv.ptr(o), nv.ptr(d), nv.ptr(aabb), N, 0.2, nv.ptr(nears), nv.ptr(fars), s)
+    count_nf = lambda: nv.call("rm_march_train_count_nf", nv.ptr(o), nv.ptr(d), nv.ptr(aabb), 0.2, nv.ptr(bf), 1.0, 0.0, 1024, N, 1, 128, None, nv.ptr(nears), nv.ptr(fars), nv.ptr(counts), nv.ptr(t_rec), s)
+    scan_write = lambda: nv.call("rm_march_train_scan_write", nv.ptr(o), nv.ptr(d), 1.0, 0.0, 1024, N, 1, 128, M, nv.ptr(nears), None, nv.ptr(t_rec), nv.ptr(counts), nv.ptr(rays), nv.ptr(ctr), nv.ptr(xyzs), nv.ptr(dirs), nv.ptr(deltas), s)
+    four = lambda: (nf(), count(), scan(), write())
+    two = lambda: (count_nf(), scan_write())
+    print(f"{name}: near/far {timeit(nf):.1f}us | count_nf {timeit(count_nf):.1f}us scan_write {timeit(scan_write):.1f}us | chain of four {timeit(four):.1f}us, chain of two {timeit(two):.1f}us")
     c = counts.cpu().numpy()
     print(f"{name}: N={N} M={M} max_count={c.max()} mean={c.mean():.1f} | count {timeit(count):.1f}us scan {timeit(scan):.1f}us "
           f"write {timeit(write):.1f}us composite fwd {timeit(comp):.1f}us bwd {timeit(cbwd):.1f}us")
