@@ -135,9 +135,14 @@ _SCAN_WRITE_MAX = None
 def scan_write_max_rays():
     """Largest ray count rm_march_train_scan_write takes (its N + 1 offsets live in LDS)."""
     global _SCAN_WRITE_MAX
-    if _SCAN_WRITE_MAX is None:      # NERFSIG_MARCH_FUSED=0: the four-enqueue form everywhere (A/B measurements)
-        _SCAN_WRITE_MAX = 0 if os.environ.get("NERFSIG_MARCH_FUSED", "1") == "0" else int(nv.fn("rm_march_train_scan_write_max_rays")())
+    if _SCAN_WRITE_MAX is None:      # NERFSIG_MARCH_FUSED=0 | nf: the stand-alone scan + write launches (A/B measurements)
+        _SCAN_WRITE_MAX = 0 if os.environ.get("NERFSIG_MARCH_FUSED", "1") in ("0", "nf") else int(nv.fn("rm_march_train_scan_write_max_rays")())
     return _SCAN_WRITE_MAX
+
+
+def fused_limits():
+    """True: the training march computes near / far itself (rm_march_train_count_nf).  NERFSIG_MARCH_FUSED=0 | sw: a launch of its own."""
+    return os.environ.get("NERFSIG_MARCH_FUSED", "1") not in ("0", "sw")
 
 
 def march_rays_train_device(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, counter, noises, dt_gamma,

@@ -260,7 +260,7 @@ class NeRFRenderer(nn.Module):
             raise ValueError("march_ahead: max_steps changed for rays that were marched before")
         N = o.shape[0]
         geom = (float(self.bound), float(dt_gamma), int(max_steps), N, int(self.cascade), int(self.grid_size))
-        if phase in ("all", "count") and raymarching.scan_write_max_rays() == 0:
+        if phase in ("all", "count") and not raymarching.fused_limits():
             raymarching.near_far_into(o, d, self.aabb_train, self.min_near, rec["nears"], rec["fars"])
             rec["noises"] = torch.rand(N, dtype=torch.float32, device=o.device) if perturb else None
             nv.call("rm_march_train_count", nv.ptr(o), nv.ptr(d), nv.ptr(self.density_bitfield), *geom, nv.ptr(rec["nears"]), nv.ptr(rec["fars"]),
@@ -299,7 +299,7 @@ class NeRFRenderer(nn.Module):
         capacity = getattr(self, "point_capacity", None)
         capacity = capacity.get(o.shape[0]) if capacity else None
         fused_limits = (marched is None and self.training and capacity is not None and force_all_rays and o.is_cuda and o.dtype == torch.float32
-                        and raymarching.scan_write_max_rays() > 0)
+                        and raymarching.fused_limits())
         if marched is not None:
             nears, fars = marched["nears"], marched["fars"]
         elif fused_limits:       # the capacity march (a captured step) fills them itself: rm_march_train_count_nf
