@@ -401,7 +401,21 @@ int dec_bn_gelu_bwd(const float *dy, const float *x, const float *gamma, const f
  *   weights_stream: pass `stream` again for one in-order launch sequence.  A different stream receives the parameter-gradient
  *            kernels (ordered after the data-gradient chain by an event), so that grad_img's consumers on `stream` need not wait
  *            for them; the caller then joins weights_stream before reading `grads`.
+ *
+ * The seven 64 -> 64 layers in the middle run as ONE persistent launch each way (csrc/decoder_persist.inc) when the shape allows it
+ * (at most 64 images of at most 192 pixels): a workgroup owns an image for all seven layers, activations stay in LDS, and the
+ * images exchange only BatchNorm's per-channel partial statistics.  Arithmetic of that route: fp16 operands, ONE MFMA per product,
+ * fp32 accumulate -- what the reference's autocast(fp16) run of this module computes in (nerf/utils_wtmk_disen.py:1172); the
+ * per-layer chain is split-bf16 (fp32-class).  dec_set_mode(0) selects the per-layer chain for every shape, dec_set_mode(1)
+ * (default; env NERFSIG_DECODER_CHAIN=layers|persist) the persistent launches where dec_persistent_for(...) says 1.
+ * dec_persist_status reads the workspace's status word back (it synchronises `stream`): 0 = every exchange of the last
+ * dec_forward / dec_backward completed; bit 0 / bit 1 = a workgroup of the forward / backward launch gave up waiting for another
+ * image's partials (every wait is bounded: the launch cannot hang, its results are then invalid).
  */
+int dec_get_mode(void);
+int dec_set_mode(int mode);
+int dec_persistent_for(uint32_t B, uint32_t Cin, uint32_t H, uint32_t W);
+int dec_persist_status(const void *workspace, uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, nsig_stream_t stream);
 size_t dec_workspace_bytes(uint32_t B, uint32_t Cin, uint32_t H, uint32_t W);
 int dec_forward(const float *img, uint32_t input_mode, const float *mean_host, const float *std_host, const float *const *params_host,
                 uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, float eps, void *workspace, float *decoded, float *clamped_out,
