@@ -687,7 +687,10 @@ def test_fused_decoder_matches_stock_operators(shape, mode, monkeypatch):
     amp = None
     if persistent:      # the reference's own precision for this module: the stock chain under autocast(fp16)
         with torch.autocast("cuda", dtype=torch.float16):
-            out_amp = dec.linear(dec.layers(img).squeeze(-1).squeeze(-1))
+            x = img
+            for blk in list(dec.layers)[:-1]:
+                x = blk.layers(x)                     # Conv2d (bias included), BatchNorm2d with batch statistics, GELU: the stock modules
+            out_amp = dec.linear(dec.layers[-1](x).squeeze(-1).squeeze(-1))
         g_amp = torch.autograd.grad(out_amp.float(), [img] + [p for p in dec.parameters()], gout, allow_unused=True)
         amp = (out_amp.detach().double(), [None if g is None else g.detach().double() for g in g_amp])
     dec64 = dec.double()
