@@ -1467,6 +1467,9 @@ using namespace nsig;
 NSIG_EXPORT int dec_timing_stamps(unsigned long long *out48) {
     return hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_dec_stamps), sizeof(unsigned long long) * 48) == hipSuccess ? 0 : 1;
 }
+NSIG_EXPORT int dec_persist_stamps(unsigned long long *out192) {
+    return hipMemcpyFromSymbol(out192, HIP_SYMBOL(g_persist_stamps), sizeof(unsigned long long) * 192) == hipSuccess ? 0 : 1;
+}
 #endif
 
 NSIG_EXPORT int dec_get_mode(void) { return dec_mode(); }
