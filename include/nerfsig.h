@@ -402,12 +402,14 @@ int dec_bn_gelu_bwd(const float *dy, const float *x, const float *gamma, const f
  *            kernels (ordered after the data-gradient chain by an event), so that grad_img's consumers on `stream` need not wait
  *            for them; the caller then joins weights_stream before reading `grads`.
  *
- * The seven 64 -> 64 layers in the middle run as ONE persistent launch each way (csrc/decoder_persist.inc) when the shape allows it
- * (at most 64 images of at most 192 pixels): a workgroup owns an image for all seven layers, activations stay in LDS, and the
- * images exchange only BatchNorm's per-channel partial statistics.  Arithmetic of that route: fp16 operands, ONE MFMA per product,
- * fp32 accumulate -- what the reference's autocast(fp16) run of this module computes in (nerf/utils_wtmk_disen.py:1172); the
- * per-layer chain is split-bf16 (fp32-class).  dec_set_mode(0) selects the per-layer chain for every shape, dec_set_mode(1)
- * (default; env NERFSIG_DECODER_CHAIN=layers|persist) the persistent launches where dec_persistent_for(...) says 1.
+ * Opt-in alternative for the seven 64 -> 64 layers in the middle: ONE persistent launch each way (csrc/decoder_persist.inc) when the
+ * shape allows it (at most 64 images of at most 192 pixels): a workgroup owns an image for all seven layers, activations stay in
+ * LDS, and the images exchange only BatchNorm's per-channel partial statistics.  Arithmetic of that route: fp16 operands, ONE MFMA
+ * per product, fp32 accumulate -- what the reference's autocast(fp16) run of this module computes in (nerf/utils_wtmk_disen.py:1172);
+ * the per-layer chain is split-bf16 (fp32-class).  dec_set_mode(0) (default) selects the per-layer chain for every shape,
+ * dec_set_mode(1) (env NERFSIG_DECODER_CHAIN=persist) the persistent launches where dec_persistent_for(...) then says 1.  Measured
+ * on MI355X the persistent route is NOT faster (the per-layer all-to-all exchange costs what a kernel boundary costs): it stays
+ * opt-in, tested in both modes.
  * dec_persist_status reads the workspace's status word back (it synchronises `stream`): 0 = every exchange of the last
  * dec_forward / dec_backward completed; bit 0 / bit 1 = a workgroup of the forward / backward launch gave up waiting for another
  * image's partials (every wait is bounded: the launch cannot hang, its results are then invalid).

@@ -1427,14 +1427,19 @@ static int conv_threads() {
     }();
     return n;
 }
-// The seven 64 -> 64 layers as one persistent launch each way (decoder_persist.inc) when the shape allows it: one workgroup per image, all
-// of them resident together, at most six 32-pixel tiles and the halo image + scratch within LDS.  dec_set_mode(0) / NERFSIG_DECODER_CHAIN=layers
-// select the per-layer chain (fp32-class split-bf16 arithmetic) for every shape.
-static int g_dec_mode = -1;      // -1: not read yet; 0: per-layer chain; 1: persistent launches where the shape allows
+// The seven 64 -> 64 layers as one persistent launch each way (decoder_persist.inc) when asked for and the shape allows it: one workgroup
+// per image, all of them resident together, at most six 32-pixel tiles and the halo image + scratch within LDS.
+// OPT-IN (dec_set_mode(1) / NERFSIG_DECODER_CHAIN=persist): measured on MI355X it does not beat the per-layer chain -- forward 69 us
+// against 7 x 10.7 = 75 us, backward 94 us against 7 x 8.3 = 58 us, the training step 1.085 against 1.067-1.081 ms
+// (profiles/r03_persistent_decoder.txt).  Phase stamps (tools/dec_timing.py --persist) say why: per layer the all-to-all exchange of
+// BatchNorm's partials among the 32 workgroups costs 1.3 us of polling plus ~2 us of skew between the images (every layer
+// waits for the slowest workgroup) -- as much as the kernel boundary it replaces -- and with one workgroup per image the
+// element-wise work of a layer (statistics 1.2 us, BatchNorm + GELU + records 2.3 us) runs on 32 CUs instead of 192.
+static int g_dec_mode = -1;      // -1: not read yet; 0: per-layer chain (default); 1: persistent launches where the shape allows
 static int dec_mode() {
     if (g_dec_mode < 0) {
         const char *e = getenv("NERFSIG_DECODER_CHAIN");
-        g_dec_mode = (e && (!strcmp(e, "layers") || !strcmp(e, "0"))) ? 0 : 1;
+        g_dec_mode = (e && (!strcmp(e, "persist") || !strcmp(e, "1"))) ? 1 : 0;
     }
     return g_dec_mode;
 }
