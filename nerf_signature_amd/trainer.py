@@ -290,7 +290,7 @@ class PSNRMeter:
 class GraphedWatermarkLoop:
     """The same loop body as WatermarkLoop, captured once into a hipGraph and replayed.
 
-    What makes the step capturable: the point buffers of both renders have a fixed capacity, so
+    What makes the step capturable (LABNOTES.md section 8): the point buffers of both renders have a fixed capacity, so
     the march never reads a count back (`march_rays_train_capacity`); the message lives in a device tensor and the
     pre-sum / Adam kernels select their tables on the device (`hg_codebook_presum_sel`, `opt_codebook_adam_sel`), so no
     launch argument depends on the message; Adam step counts and the learning rate are device scalars.  Per step the
@@ -349,7 +349,7 @@ class GraphedWatermarkLoop:
         self.content_sampler = content_sampler
         # content_ahead: the content render's samples are marched at the end of the previous replay as well.  The head of a step then
         # holds no march at all: both encoders start right behind the opening kernel (the runtime starts the block encoder only when the
-        # whole content-march chain in front of it has finished, ~95 us of small kernels: DESIGN.md section 8).  The content rays of the
+        # whole content-march chain in front of it has finished, ~95 us of small kernels: LABNOTES.md section 8).  The content rays of the
         # NEXT step therefore have to be in the static buffers when a replay starts: `step(..., next_data={"content": ...})`; their
         # ground-truth pixels are held back until that step.
         # Off by default: same-box A/B of the bench step 1.095-1.100 ms without against 1.130-1.167 ms with it
