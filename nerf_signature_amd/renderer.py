@@ -20,6 +20,32 @@ def custom_meshgrid(*args):
     return torch.meshgrid(*args, indexing="ij")
 
 
+def sample_pdf(bins, weights, n_samples, det=False):
+    """Inverse-CDF samples of the piecewise-constant density `weights` over `bins` (renderer_wtmk.py:12-47; NeRF's):
+    bins [B, T] (old depths), weights [B, T - 1] -> new depths [B, n_samples].  det: evenly spaced quantiles instead of random ones."""
+    weights = weights + 1e-5
+    pdf = weights / torch.sum(weights, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    if det:
+        u = torch.linspace(0.0 + 0.5 / n_samples, 1.0 - 0.5 / n_samples, steps=n_samples).to(weights.device)
+        u = u.expand(list(cdf.shape[:-1]) + [n_samples])
+    else:
+        u = torch.rand(list(cdf.shape[:-1]) + [n_samples]).to(weights.device)
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    below = torch.max(torch.zeros_like(inds - 1), inds - 1)
+    above = torch.min((cdf.shape[-1] - 1) * torch.ones_like(inds), inds)
+    inds_g = torch.stack([below, above], -1)
+    shape = [inds_g.shape[0], inds_g.shape[1], cdf.shape[-1]]
+    cdf_g = torch.gather(cdf.unsqueeze(1).expand(shape), 2, inds_g)
+    bins_g = torch.gather(bins.unsqueeze(1).expand(shape), 2, inds_g)
+    denom = cdf_g[..., 1] - cdf_g[..., 0]
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    t = (u - cdf_g[..., 0]) / denom
+    return bins_g[..., 0] + t * (bins_g[..., 1] - bins_g[..., 0])
+
+
 _BG_CONST = {}
 
 
@@ -179,11 +205,11 @@ class NeRFRenderer(nn.Module):
     # ------------------------------------------------------------------ uniform-sample path (renderer_wtmk.py:125-253)
 
     def run(self, rays_o, rays_d, message, num_steps=128, upsample_steps=128, bg_color=None, perturb=False, **kwargs):
-        """num_steps samples per ray, uniformly in [near, far]; density everywhere, colour only where the
-        compositing weight exceeds 1e-4 (renderer_wtmk.py:215)."""
-        if upsample_steps > 0:
-            raise NotImplementedError("importance re-sampling (upsample_steps > 0) is not on the watermark path "
-                                      "(main_nerf_wtmk.py:27 defaults it to 0)")
+        """num_steps samples per ray, uniformly in [near, far]; with upsample_steps > 0 that many more drawn from the first pass's weights
+        (sample_pdf: evenly spaced quantiles in eval mode, random ones in training mode) and merged in depth order; density everywhere,
+        colour only where the compositing weight exceeds 1e-4 (renderer_wtmk.py:125-253).
+        As in the reference the re-sampled points are evaluated WITHOUT the message (renderer_wtmk.py:187 calls density(new_xyzs) with its
+        default message=None): they see the clean field, and no gradient reaches the codebook through them."""
         bg_color = self._background(bg_color)
         prefix, o, d = self._flatten_rays(rays_o, rays_d)
         N, T = o.shape[0], num_steps
@@ -195,25 +221,52 @@ class NeRFRenderer(nn.Module):
         if perturb:
             z = z + (torch.rand(z.shape, device=o.device) - 0.5) * spacing
         pts = torch.min(torch.max(o.unsqueeze(-2) + d.unsqueeze(-2) * z.unsqueeze(-1), aabb[:3]), aabb[3:])
-        step = torch.cat([z[..., 1:] - z[..., :-1], spacing * torch.ones_like(z[..., :1])], dim=-1)
         differentiable = torch.is_grad_enabled() and message is not None and any(p.requires_grad for p in self.parameters())
+        dirs_of = lambda p: d.view(-1, 1, 3).expand_as(p).reshape(-1, 3).contiguous()
         if differentiable:
             # Training through this path (the reference trains through density() + masked color() when --cuda_ray is off): one joint,
             # differentiable field pass over all samples, colour zeroed where the reference does not evaluate it.  Same values -- a
             # masked-out sample's colour is 0 there too -- and the same gradient: the mask is a constant of the backward pass in both.
-            sigma_all, rgb_all = self(pts.reshape(-1, 3), d.view(-1, 1, 3).expand_as(pts).reshape(-1, 3).contiguous(), message)
-            sigma = sigma_all.view(N, T)
+            sigma_all, rgb_all = self(pts.reshape(-1, 3), dirs_of(pts), message)
+            sigma, rgb_all = sigma_all.view(N, T), rgb_all.view(N, T, 3)
+            geo = None
         else:
             field = self.density(pts.reshape(-1, 3), message=message)
-            sigma = field["sigma"].view(N, T)
+            sigma, geo = field["sigma"].view(N, T), field["geo_feat"].view(N, T, -1)
+            rgb_all = None
+        if upsample_steps > 0:
+            with torch.no_grad():
+                step0 = torch.cat([z[..., 1:] - z[..., :-1], spacing * torch.ones_like(z[..., :1])], dim=-1)
+                alpha0 = 1 - torch.exp(-step0 * self.density_scale * sigma.detach())
+                w0 = alpha0 * torch.cumprod(torch.cat([torch.ones_like(alpha0[..., :1]), 1 - alpha0 + 1e-15], dim=-1), dim=-1)[..., :-1]
+                z_mid = z[..., :-1] + 0.5 * step0[..., :-1]
+                new_z = sample_pdf(z_mid, w0[:, 1:-1], upsample_steps, det=not self.training).detach()
+                new_pts = torch.min(torch.max(o.unsqueeze(-2) + d.unsqueeze(-2) * new_z.unsqueeze(-1), aabb[:3]), aabb[3:])
+            t = upsample_steps
+            if differentiable:       # no message: the clean field, nothing to differentiate (renderer_wtmk.py:187)
+                with torch.no_grad():
+                    s_new, c_new = self(new_pts.reshape(-1, 3), dirs_of(new_pts), None)
+                new_sigma, new_rgb = s_new.view(N, t), c_new.view(N, t, 3)
+            else:
+                nf = self.density(new_pts.reshape(-1, 3))
+                new_sigma, new_geo = nf["sigma"].view(N, t), nf["geo_feat"].view(N, t, -1)
+            z, order = torch.sort(torch.cat([z, new_z], dim=1), dim=1)
+            gather = lambda a, b: torch.gather(torch.cat([a, b], dim=1), 1, order.unsqueeze(-1).expand(-1, -1, a.shape[-1]) if a.dim() == 3 else order)
+            pts = gather(pts, new_pts)
+            sigma = gather(sigma, new_sigma)
+            if differentiable:
+                rgb_all = gather(rgb_all, new_rgb)
+            else:
+                geo = gather(geo, new_geo)
+            T = T + t
+        step = torch.cat([z[..., 1:] - z[..., :-1], spacing * torch.ones_like(z[..., :1])], dim=-1)
         alpha = 1 - torch.exp(-step * self.density_scale * sigma)
         transmittance = torch.cumprod(torch.cat([torch.ones_like(alpha[..., :1]), 1 - alpha + 1e-15], dim=-1), dim=-1)[..., :-1]
         weights = alpha * transmittance
         if differentiable:
-            rgbs = rgb_all.view(N, T, 3) * (weights > 1e-4).unsqueeze(-1)
+            rgbs = rgb_all * (weights > 1e-4).unsqueeze(-1)
         else:
-            rgbs = self.color(pts.reshape(-1, 3), d.view(-1, 1, 3).expand_as(pts).reshape(-1, 3), mask=(weights > 1e-4).reshape(-1),
-                              geo_feat=field["geo_feat"]).view(N, T, 3)
+            rgbs = self.color(pts.reshape(-1, 3), dirs_of(pts), mask=(weights > 1e-4).reshape(-1), geo_feat=geo.reshape(N * T, -1)).view(N, T, 3)
         weights_sum = weights.sum(dim=-1)
         depth = torch.sum(weights * ((z - nears) / span).clamp(0, 1), dim=-1)
         image = torch.sum(weights.unsqueeze(-1) * rgbs, dim=-2) + (1 - weights_sum).unsqueeze(-1) * bg_color

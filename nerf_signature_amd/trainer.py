@@ -88,8 +88,13 @@ def local_blocks(wm):
     return o[shard[0]:shard[1]], d[shard[0]:shard[1]], shard
 
 
+def srgb_to_linear(x):
+    """utils_wtmk_disen.py:54-55."""
+    return torch.where(x < 0.04045, x / 12.92, ((x + 0.055) / 1.055) ** 2.4)
+
+
 def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce, side_stream=None, presum_first=False,
-               presum_adopt=False):
+               presum_adopt=False, color_space="srgb"):
     """data = {'watermark': {'rays_o_block', 'rays_d_block'}, 'content': {'rays_o', 'rays_d', 'images'}}.
     Returns (pred_rgb, gt_rgb, content_pred_rgb, lossi, lossw, loss) like the reference.
 
@@ -132,6 +137,13 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
     else:
         pred_rgb = torch.clamp(image, min=0, max=1)
         decoded = model.msg_decoder(model.normalization(pred_rgb.permute(0, 3, 1, 2)))
+    if color_space == "linear":      # utils_wtmk_disen.py:603-604: converted IN PLACE, every step, as the reference does (its loader hands out fresh tensors)
+        content["images"][..., :3] = srgb_to_linear(content["images"][..., :3])
+    if content["images"].shape[-1] != 3:
+        # C == 4: the reference itself cannot run this branch in the watermark stage -- `bg_color` is assigned only when C == 3 or bg_radius > 0
+        # (utils_wtmk_disen.py:585-586) and read unconditionally at :590: UnboundLocalError
+        raise NotImplementedError("RGBA ground truth: the reference's train_step raises UnboundLocalError here (bg_color is only assigned for 3-channel images, "
+                                  "utils_wtmk_disen.py:585-590); blend the alpha channel into the images before the step")
     gt_rgb = content["images"]
     if main is not None:
         if shard is None:
@@ -151,7 +163,7 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
     return pred_rgb, gt_rgb, content_pred_rgb, lossi, lossw, loss
 
 
-def eval_step(model, data, message, render_kwargs, render_whole=True, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce):
+def eval_step(model, data, message, render_kwargs, render_whole=True, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce, color_space="srgb"):
     """Trainer.eval_step (utils_wtmk_disen.py:648-702) for its default configuration (3-channel images, srgb, distortion 'none').
     render_whole=False: the watermark blocks rendered with the message, decoded, BCE against the message (+ MSE against
     data['images_block'] when given) -- what test_bitacc evaluates; render_whole=True: the full view staged in max_ray_batch chunks
@@ -173,9 +185,11 @@ def eval_step(model, data, message, render_kwargs, render_whole=True, lambda_w=1
         loss = lambda_w * lossw + lambda_i * lossi
     else:
         B, H, W, C = data["images"].shape
-        if C != 3:
-            raise NotImplementedError("eval_step mirrors the reference's 3-channel configuration (RGBA ground truth is blended by the reference's own Trainer)")
-        gt_rgb = data["images"]
+        images = data["images"]
+        if color_space == "linear":      # :691-692, in place like the reference
+            images[..., :3] = srgb_to_linear(images[..., :3])
+        # evaluation uses a fixed white background (:695-699)
+        gt_rgb = images[..., :3] * images[..., 3:] + 1 * (1 - images[..., 3:]) if C == 4 else images
         out = model.render(data["rays_o"], data["rays_d"], message, staged=True, bg_color=1, perturb=False, force_all_rays=True, **kw)
         pred_rgb = torch.clamp(out["image"].reshape(-1, H, W, 3), min=0, max=1)
         pred_depth = out["depth"].reshape(-1, H, W)

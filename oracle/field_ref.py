@@ -245,31 +245,71 @@ def run_cuda_eval(rays_o, rays_d, message, P, S, dt_gamma=0.0, bg_color=1, max_s
     return {"image": image_t.view(*prefix, 3), "depth": depth_t.view(*prefix)}
 
 
-def run_uniform(rays_o, rays_d, message, P, S, num_steps=512, bg_color=1):
-    """NeRFRenderer.run with upsample_steps=0 and perturb=False, renderer_wtmk.py:125-253."""
+def sample_pdf(bins, weights, n_samples, det=True, u=None):
+    """renderer_wtmk.py:12-47 (NeRF's inverse-CDF sampling): bins [B,T], weights [B,T-1] -> [B,n_samples].  det=False takes the
+    uniform draws `u` [B,n_samples] from the caller (the reference draws torch.rand)."""
+    weights = weights + 1e-5                                    # :20
+    pdf = weights / torch.sum(weights, -1, keepdim=True)        # :21
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)  # :23
+    if det:                                                     # :25-27
+        u = torch.linspace(0.0 + 0.5 / n_samples, 1.0 - 0.5 / n_samples, steps=n_samples).expand(list(cdf.shape[:-1]) + [n_samples])
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)               # :33
+    below = torch.clamp(inds - 1, min=0)
+    above = torch.clamp(inds, max=cdf.shape[-1] - 1)
+    cdf_b, cdf_a = torch.gather(cdf, 1, below), torch.gather(cdf, 1, above)        # :38-40 (the gather over an expanded copy, written directly)
+    bin_b, bin_a = torch.gather(bins, 1, below), torch.gather(bins, 1, above)
+    denom = cdf_a - cdf_b
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)               # :43
+    return bin_b + (u - cdf_b) / denom * (bin_a - bin_b)                           # :44-45
+
+
+def run_uniform(rays_o, rays_d, message, P, S, num_steps=512, bg_color=1, upsample_steps=0, training=True, aabb=None, u=None):
+    """NeRFRenderer.run with perturb=False, renderer_wtmk.py:125-253.  upsample_steps > 0: the importance re-sampling branch :166-201 --
+    note that the reference evaluates the re-sampled points with density(new_xyzs), i.e. message=None: the CLEAN field (:187)."""
     prefix = rays_o.shape[:-1]
     o, d = rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3)
     N = o.shape[0]
-    aabb = torch.from_numpy(np.asarray(S["aabb"], np.float32))
-    nears, fars = rm.near_far_from_aabb(o.numpy(), d.numpy(), S["aabb"], S["min_near"])
+    box = np.asarray(S["aabb"] if aabb is None else aabb, np.float32)
+    aabb_t = torch.from_numpy(box)
+    nears, fars = rm.near_far_from_aabb(o.numpy(), d.numpy(), box, S["min_near"])
     nears, fars = torch.from_numpy(nears).unsqueeze(-1), torch.from_numpy(fars).unsqueeze(-1)
     z = torch.linspace(0.0, 1.0, num_steps).unsqueeze(0).expand(N, num_steps)
     z = nears + (fars - nears) * z
     sample_dist = (fars - nears) / num_steps
-    xyzs = o.unsqueeze(-2) + d.unsqueeze(-2) * z.unsqueeze(-1)
-    xyzs = torch.min(torch.max(xyzs, aabb[:3]), aabb[3:])
+    clip = lambda p: torch.min(torch.max(p, aabb_t[:3]), aabb_t[3:])
+    xyzs = clip(o.unsqueeze(-2) + d.unsqueeze(-2) * z.unsqueeze(-1))
     dn = density(xyzs.reshape(-1, 3), message, P)
-    sigma = dn["sigma"].view(N, num_steps)
+    sigma, geo = dn["sigma"].view(N, num_steps), dn["geo_feat"].view(N, num_steps, -1)
+    scale = S.get("density_scale", 1)
+    T = num_steps
+    if upsample_steps > 0:
+        with torch.no_grad():
+            deltas = torch.cat([z[..., 1:] - z[..., :-1], sample_dist * torch.ones_like(z[..., :1])], dim=-1)       # :169-170
+            alphas = 1 - torch.exp(-deltas * scale * sigma.detach())
+            shifted = torch.cat([torch.ones_like(alphas[..., :1]), 1 - alphas + 1e-15], dim=-1)
+            weights = alphas * torch.cumprod(shifted, dim=-1)[..., :-1]
+            z_mid = z[..., :-1] + 0.5 * deltas[..., :-1]                                                              # :177
+            new_z = sample_pdf(z_mid, weights[:, 1:-1], upsample_steps, det=not training, u=u)                       # :178
+            new_xyzs = clip(o.unsqueeze(-2) + d.unsqueeze(-2) * new_z.unsqueeze(-1))                                  # :180-181
+        nd = density(new_xyzs.reshape(-1, 3), None, P)                                                                # :187: no message
+        z, order = torch.sort(torch.cat([z, new_z], dim=1), dim=1)                                                    # :193-194
+        xyzs = torch.gather(torch.cat([xyzs, new_xyzs], dim=1), 1, order.unsqueeze(-1).expand(-1, -1, 3))
+        sigma = torch.gather(torch.cat([sigma, nd["sigma"].view(N, upsample_steps)], dim=1), 1, order)
+        g_all = torch.cat([geo, nd["geo_feat"].view(N, upsample_steps, -1)], dim=1)
+        geo = torch.gather(g_all, 1, order.unsqueeze(-1).expand(-1, -1, g_all.shape[-1]))
+        T = num_steps + upsample_steps
     deltas = torch.cat([z[..., 1:] - z[..., :-1], sample_dist * torch.ones_like(z[..., :1])], dim=-1)
-    alphas = 1 - torch.exp(-deltas * S.get("density_scale", 1) * sigma)
+    alphas = 1 - torch.exp(-deltas * scale * sigma)
     shifted = torch.cat([torch.ones_like(alphas[..., :1]), 1 - alphas + 1e-15], dim=-1)
     weights = alphas * torch.cumprod(shifted, dim=-1)[..., :-1]
     mask = (weights > 1e-4).reshape(-1)
     dirs = d.view(-1, 1, 3).expand_as(xyzs).reshape(-1, 3)
-    rgbs = torch.zeros(N * num_steps, 3)
+    rgbs = torch.zeros(N * T, 3)
     if mask.any():
-        rgbs[mask] = color(dirs[mask], dn["geo_feat"][mask], P)
-    rgbs = rgbs.view(N, num_steps, 3)
+        rgbs[mask] = color(dirs[mask], geo.reshape(N * T, -1)[mask], P)
+    rgbs = rgbs.view(N, T, 3)
     ws = weights.sum(dim=-1)
     depth = torch.sum(weights * ((z - nears) / (fars - nears)).clamp(0, 1), dim=-1)
     image = torch.sum(weights.unsqueeze(-1) * rgbs, dim=-2) + (1 - ws).unsqueeze(-1) * bg_color
@@ -280,7 +320,7 @@ def render(rays_o, rays_d, message, P, S, staged=False, max_ray_batch=4096, cuda
     """NeRFRenderer.render, renderer_wtmk.py:541-575."""
     def _run(o, d):
         if not cuda_ray:
-            return run_uniform(o, d, message, P, S, **{k: kw[k] for k in ("num_steps", "bg_color") if k in kw})
+            return run_uniform(o, d, message, P, S, training=training, **{k: kw[k] for k in ("num_steps", "bg_color", "upsample_steps", "u") if k in kw})
         keys = ("dt_gamma", "bg_color", "max_steps", "T_thresh")
         fn = run_cuda_train if training else run_cuda_eval
         return fn(o, d, message, P, S, **{k: kw[k] for k in keys if k in kw})

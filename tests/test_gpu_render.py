@@ -556,6 +556,76 @@ def test_uniform_sample_path_run_matches_oracle():
     np.testing.assert_allclose(out["depth"].cpu()[hit].numpy(), ref["depth"][hit].numpy(), rtol=0, atol=1e-3)
 
 
+def test_step_mirrors_colour_space_and_alpha_handling():
+    """train_step / eval_step with `color_space="linear"` (utils_wtmk_disen.py:603-604, 691-692: converted in place) and eval_step's RGBA blend
+    against a white background (:695-699); train_step with RGBA images raises like the reference's (whose bg_color is unassigned there, :585-590)."""
+    from nerf_signature_amd import trainer
+    m, bitfield, C = _model()
+    bo, bd, co, cd, gt = _data(n_content=64, block=4)
+    msg = torch.from_numpy(cf.messages(32)[1]).cuda()
+    kw = dict(dt_gamma=0, max_steps=1024)
+    data = {"watermark": {"rays_o_block": bo.cuda(), "rays_d_block": bd.cuda()}, "content": {"rays_o": co.cuda(), "rays_d": cd.cuda(), "images": gt.cuda().clone()}}
+    want_gt = torch.where(gt < 0.04045, gt / 12.92, ((gt + 0.055) / 1.055) ** 2.4).cuda()
+    out = trainer.train_step(m, data, msg, kw, color_space="linear")
+    assert torch.allclose(out[1], want_gt, rtol=0, atol=1e-7) and out[1] is data["content"]["images"]          # in place, as the reference does it
+    assert abs(float(out[3]) - float(((out[2] - want_gt) ** 2).mean())) < 1e-7
+    data["content"]["images"] = torch.rand(1, 64, 4, device="cuda")
+    with pytest.raises(NotImplementedError, match="UnboundLocalError"):
+        trainer.train_step(m, data, msg, kw)
+    H = W = 8
+    pose, intr, _ = cf.orbit_rays(1, seed=3)
+    o, d = fr.get_rays(torch.from_numpy(pose)[None], intr * np.array([0.02, 0.02, 0.02, 0.02], np.float32), H, W)
+    rgba = torch.rand(1, H, W, 4, device="cuda")
+    ev = {"H": H, "W": W, "rays_o": o.cuda(), "rays_d": d.cuda(), "images": rgba.clone()}
+    with torch.no_grad():
+        pred, depth, gt_rgb, decoded, li, lw, l = trainer.eval_step(m, ev, msg, kw, render_whole=True, color_space="linear")
+    lin = torch.where(rgba[..., :3] < 0.04045, rgba[..., :3] / 12.92, ((rgba[..., :3] + 0.055) / 1.055) ** 2.4)
+    assert torch.allclose(gt_rgb, lin * rgba[..., 3:] + (1 - rgba[..., 3:]), rtol=0, atol=1e-6) and pred.shape == (1, H, W, 3) and decoded is None
+
+
+def test_uniform_sample_path_with_importance_resampling_matches_oracle(strict_mlp):
+    """NeRFRenderer.run with upsample_steps > 0 (renderer_wtmk.py:166-201, sample_pdf :12-47): 96 coarse + 64 re-sampled depths per ray, merged
+    in depth order; the re-sampled points see the CLEAN field (the reference calls density(new_xyzs) without the message, :187).  Eval mode
+    (evenly spaced quantiles: deterministic) without gradients against the oracle; then with gradients: image and codebook gradient of an MSE
+    loss against the oracle's autograd (gradient flows through the coarse samples only); training mode (random quantiles): finite, and the
+    same coarse-only picture within the re-sampling noise."""
+    m, bitfield, C = _model()
+    P, S = _oracle_params(m, bitfield, C)
+    m.cuda_ray = False
+    pose, intr, inds = cf.orbit_rays(64, seed=9)
+    o, d = fr.get_rays(torch.from_numpy(pose)[None], intr, 400, 400, torch.from_numpy(np.minimum(inds, 80200 + 5 * np.arange(64)))[None])
+    msg = torch.from_numpy(cf.messages(32)[2])
+    kw = dict(staged=False, num_steps=96, upsample_steps=64, bg_color=1, perturb=False)
+    m.eval()
+    with torch.no_grad():
+        ref = fr.render(o, d, msg, P, S, cuda_ray=False, training=False, num_steps=96, upsample_steps=64, bg_color=1)
+        out = m.render(o.cuda(), d.cuda(), msg, **kw)
+        coarse = m.render(o.cuda(), d.cuda(), msg, **dict(kw, upsample_steps=0))
+    assert set(out) == {"image", "depth", "weights_sum"}
+    np.testing.assert_allclose(out["image"].cpu().numpy(), ref["image"].numpy(), rtol=0, atol=1e-3)
+    np.testing.assert_allclose(out["weights_sum"].cpu().numpy(), ref["weights_sum"].numpy(), rtol=0, atol=1e-3)
+    hit = ~torch.isnan(ref["depth"])
+    np.testing.assert_allclose(out["depth"].cpu()[hit].numpy(), ref["depth"][hit].numpy(), rtol=0, atol=1e-3)
+    assert float((out["image"] - coarse["image"]).abs().max()) > 1e-4          # the extra samples do change the picture
+    # with gradients
+    gt = torch.rand(1, 64, 3)
+    ref = fr.render(o, d, msg, P, S, cuda_ray=False, training=False, num_steps=96, upsample_steps=64, bg_color=1)
+    ((ref["image"] - gt) ** 2).mean().backward()
+    out = m.render(o.cuda(), d.cuda(), msg, **kw)
+    ((out["image"] - gt.cuda()) ** 2).mean().backward()
+    np.testing.assert_allclose(out["image"].detach().cpu().numpy(), ref["image"].detach().numpy(), rtol=0, atol=1e-3)
+    bits = [int(v) for v in msg]
+    for i in (0, 7, 31):
+        g1, g0 = m.msg_encoder.embeddings[2 * i + bits[i]].weight.grad.cpu(), P["cb_tables"][2 * i + bits[i]].grad
+        assert float((g1 - g0).norm() / g0.norm()) < 5e-3
+        assert m.msg_encoder.embeddings[2 * i + 1 - bits[i]].weight.grad is None
+    # training mode: random quantiles
+    m.train()
+    with torch.no_grad():
+        rnd = m.render(o.cuda(), d.cuda(), msg, **kw)
+    assert torch.isfinite(rnd["image"]).all() and float((rnd["image"] - out["image"].detach()).abs().max()) < 0.05
+
+
 def test_uniform_sample_path_trains_the_codebook(strict_mlp):
     """NeRFRenderer.run with gradients (what `main_nerf_wtmk.py` without --cuda_ray trains through: density() + masked color(),
     renderer_wtmk.py:187-229): image and the codebook gradient of an MSE loss against the oracle's autograd through the same path."""
