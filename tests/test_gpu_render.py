@@ -567,8 +567,8 @@ def test_step_mirrors_colour_space_and_alpha_handling():
     data = {"watermark": {"rays_o_block": bo.cuda(), "rays_d_block": bd.cuda()}, "content": {"rays_o": co.cuda(), "rays_d": cd.cuda(), "images": gt.cuda().clone()}}
     want_gt = torch.where(gt < 0.04045, gt / 12.92, ((gt + 0.055) / 1.055) ** 2.4).cuda()
     out = trainer.train_step(m, data, msg, kw, color_space="linear")
-    assert torch.allclose(out[1], want_gt, rtol=0, atol=1e-7) and out[1] is data["content"]["images"]          # in place, as the reference does it
-    assert abs(float(out[3]) - float(((out[2] - want_gt) ** 2).mean())) < 1e-7
+    assert torch.allclose(out[1], want_gt, rtol=0, atol=2e-6) and out[1] is data["content"]["images"]          # in place, as the reference does it
+    assert abs(float(out[3]) - float(((out[2] - want_gt) ** 2).mean())) < 1e-6
     data["content"]["images"] = torch.rand(1, 64, 4, device="cuda")
     with pytest.raises(NotImplementedError, match="UnboundLocalError"):
         trainer.train_step(m, data, msg, kw)
