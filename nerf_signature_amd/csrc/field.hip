@@ -195,24 +195,52 @@ __device__ inline void mfma_layer(const char *__restrict__ lds, size_t half_byte
     }
 }
 
-// ReLU a 64-row activation held in two accumulators, return the "was positive" bits (bit 16*rb + r), emit the next B operand.
+// Where the "was positive" flag of activation i = 16*rb + r (row block rb, accumulator register r) sits in the 32-bit mask word.
+// Bf16x3: bit i.  F16: the flags are the inverted fp16 SIGN bits of the packed operand dwords, collected pairwise -- the pair
+// k = 8*rb + r/2 lands with its even element in bit k and its odd element in bit 16 + k (relu_to_operand<F16>).
+template <typename P>
+__host__ __device__ constexpr int mask_bit(int i) {
+    return P::kMfmaPerProduct == 1 ? ((i & 1) ? 16 + ((i >> 4) * 8 + ((i & 15) >> 1)) : ((i >> 4) * 8 + ((i & 15) >> 1))) : i;
+}
+
+// ReLU a 64-row activation held in two accumulators, return the "was positive" bits (bit mask_bit<P>(16*rb + r)), emit the next B operand.
 // No compares (they would hold 32 lane masks in SGPRs): the value is max(v, 0); the flag is the sign bit of 0 - bits(v) --
 // set exactly when v > 0, because an accumulator that starts at +0 never holds -0 -- shifted in with one v_alignbit.
 template <typename P>
 __device__ inline uint32_t relu_to_operand(const f32x16 (&acc)[2], typename P::Op (&b)[4]) {
-    uint32_t bits = 0;   // filled most-significant-first, reversed at the end: index i ends in bit i
+    if constexpr (P::kMfmaPerProduct == 1) {
+        // fp16 operands: round the PAIR first (one v_cvt_pk), clamp it packed (one v_pk_max_f16), and take the flags from the packed
+        // value's two sign bits -- shifted into a running word with one v_lshrrev + one v_bfi: four vector instructions per pair
+        // instead of seven (two subtractions, two v_alignbit, two integer max, one pack).  Rounding is monotonic, so the operand is the
+        // same value as max(v, 0) rounded; the flag of an activation that is exactly +0 reads "positive" here (its upstream
+        // gradient then passes a ReLU whose output was 0 either way: only all-zero padding rows have exact zeros, and their
+        // gradients are zero).
+        uint32_t neg = 0;
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            uint32_t u0 = __float_as_uint(acc[rb][r]), u1 = __float_as_uint(acc[rb][r + 1]);
-            asm("" : "+v"(u0), "+v"(u1));   // one copy out of the accumulator registers, used twice
-            bits = __builtin_amdgcn_alignbit(bits, 0u - u0, 31);
-            bits = __builtin_amdgcn_alignbit(bits, 0u - u1, 31);
-            // max(v, 0) as an integer max on the bit patterns (negative floats are negative integers): no NaN canonicalisation
-            P::put2(b[2 * rb + (r >> 3)], (r & 7) >> 1, __uint_as_float((uint32_t)max((int)u0, 0)), __uint_as_float((uint32_t)max((int)u1, 0)));
-        }
-    return __builtin_bitreverse32(bits);
+            for (int r = 0; r < 16; r += 2) {
+                const uint32_t x = cvt_pk_f16(acc[rb][r], acc[rb][r + 1]);
+                const f16x2 zero = {(_Float16)0.0f, (_Float16)0.0f};
+                b[2 * rb + (r >> 3)].v[(r & 7) >> 1] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(f16x2, x), zero));
+                neg = (x & 0x80008000u) | ((neg >> 1) & 0x7fff7fffu);      // v_bfi_b32: after the 16th pair, pair k sits in bits k and 16 + k
+            }
+        return ~neg;
+    } else {
+        uint32_t bits = 0;   // filled most-significant-first, reversed at the end: index i ends in bit i
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                uint32_t u0 = __float_as_uint(acc[rb][r]), u1 = __float_as_uint(acc[rb][r + 1]);
+                asm("" : "+v"(u0), "+v"(u1));   // one copy out of the accumulator registers, used twice
+                bits = __builtin_amdgcn_alignbit(bits, 0u - u0, 31);
+                bits = __builtin_amdgcn_alignbit(bits, 0u - u1, 31);
+                // max(v, 0) as an integer max on the bit patterns (negative floats are negative integers): no NaN canonicalisation
+                P::put2(b[2 * rb + (r >> 3)], (r & 7) >> 1, __uint_as_float((uint32_t)max((int)u0, 0)), __uint_as_float((uint32_t)max((int)u1, 0)));
+            }
+        return __builtin_bitreverse32(bits);
+    }
 }
 
 // Backward through a ReLU: zero the rows whose forward activation was clamped, emit the next B operand.
@@ -227,7 +255,7 @@ __device__ inline void mask_to_operand(const f32x16 (&acc)[2], uint32_t bits, ty
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int r = 0; r < 16; r += 2)
-            P::put2(b[2 * rb + (r >> 3)], (r & 7) >> 1, masked(acc[rb][r], bits, rb * 16 + r), masked(acc[rb][r + 1], bits, rb * 16 + r + 1));
+            P::put2(b[2 * rb + (r >> 3)], (r & 7) >> 1, masked(acc[rb][r], bits, mask_bit<P>(rb * 16 + r)), masked(acc[rb][r + 1], bits, mask_bit<P>(rb * 16 + r + 1)));
 }
 
 // Degree-4 real spherical harmonics (the 16 components of hash_encoding.py:157-183) of d in [-1,1]^3.
@@ -658,10 +686,10 @@ __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyz
         typename P::Op b4[4];
         mfma_layer<P, 2, 1>(lds, kHalf, B0, lane, dout, hid);
         mask_to_operand<P>(hid, mask_c1, b4);
-        if (kFull) store_rows64(gt.d_h2, stride, s, h, hid, [=](float v, int i) { return ((mask_c1 >> i) & 1u) ? v : 0.0f; });
+        if (kFull) store_rows64(gt.d_h2, stride, s, h, hid, [=](float v, int i) { return ((mask_c1 >> mask_bit<P>(i)) & 1u) ? v : 0.0f; });
         mfma_layer<P, 2, 4>(lds, kHalf, B1, lane, b4, hid);
         mask_to_operand<P>(hid, mask_c0, b4);
-        if (kFull) store_rows64(gt.d_h1, stride, s, h, hid, [=](float v, int i) { return ((mask_c0 >> i) & 1u) ? v : 0.0f; });
+        if (kFull) store_rows64(gt.d_h1, stride, s, h, hid, [=](float v, int i) { return ((mask_c0 >> mask_bit<P>(i)) & 1u) ? v : 0.0f; });
         f32x16 dso[1];
         mfma_layer<P, 1, 4>(lds, kHalf, B2, lane, b4, dso);  // rows 1..15 = d geo_feat
 
@@ -678,7 +706,7 @@ __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyz
         mfma_layer<P, 2, 1>(lds, kHalf, B3, lane, dhead, hid);
         mask_to_operand<P>(hid, mask_s, b4);
         if (kFull) {
-            store_rows64(gt.d_hs, stride, s, h, hid, [=](float v, int i) { return ((mask_s >> i) & 1u) ? v : 0.0f; });
+            store_rows64(gt.d_hs, stride, s, h, hid, [=](float v, int i) { return ((mask_s >> mask_bit<P>(i)) & 1u) ? v : 0.0f; });
             f32x16 dall[1];
             mfma_layer<P, 1, 4>(lds, kHalf, B4F, lane, b4, dall);  // row f = d feature[f]; registers (r, r+1), r even, hold one level's pair
 #pragma unroll
