@@ -73,6 +73,11 @@ int rm_march_train_count(const float *rays_o, const float *rays_d, const uint8_t
                          const float *fars, const float *noises, int32_t *counts, float *t_rec,
                          nsig_stream_t stream);
 int rm_march_train_scan(const int32_t *counts, uint32_t N, int32_t *rays, int32_t *counter, nsig_stream_t stream);
+/* the same table for MANY rays (staged full-image renders march up to 262 144 rays per launch sequence) in two launches of
+ * 4096-ray workgroups; block_sums: caller-owned scratch of rm_march_train_scan_blocks(N) int32 words, need not be initialised */
+int rm_march_train_scan_blocks(uint32_t N);
+int rm_march_train_scan_wide(const int32_t *counts, uint32_t N, int32_t *rays, int32_t *counter, int32_t *block_sums,
+                             nsig_stream_t stream);
 int rm_march_train_write(const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps,
                          uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears, const float *noises,
                          const float *t_rec, const int32_t *rays, const int32_t *counter, float *xyzs, float *dirs,

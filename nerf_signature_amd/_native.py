@@ -29,6 +29,8 @@ SIGNATURES = {
     "rm_march_train_scratch_bytes": [_u32, _u32],
     "rm_march_train_count": [_vp, _vp, _vp, _fl, _fl, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp],
     "rm_march_train_scan": [_vp, _u32, _vp, _vp, _vp],
+    "rm_march_train_scan_blocks": [_u32],
+    "rm_march_train_scan_wide": [_vp, _u32, _vp, _vp, _vp, _vp],
     "rm_march_train_write": [_vp, _vp, _fl, _fl, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "rm_march_train_count_nf": [_vp, _vp, _vp, _fl, _vp, _fl, _fl, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp],
     "rm_march_train_scan_write_max_rays": [],

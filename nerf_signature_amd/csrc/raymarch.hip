@@ -496,6 +496,83 @@ __global__ void __launch_bounds__(1024) k_march_scan(const int32_t *__restrict__
     if (tid == 0) { counter[0] = total; counter[1] = (int32_t)N; }
 }
 
+// The same prefix sum for MANY rays (a staged full-image render marches up to 262 144 rays per launch sequence: the single workgroup above
+// takes 316 us there, 8 % of a 1008 x 756 image, profiles/r03_fern_kernel_stats.txt): two launches of workgroups that own 4096 rays each --
+// (1) every workgroup's total, (2) every workgroup adds up the totals in front of it (at most a few hundred values) and scans its own rays.
+// Same ray-id order, same table.
+constexpr uint32_t kScanChunk = 4096;      // rays per workgroup: 4 per thread
+__global__ void __launch_bounds__(1024) k_march_scan_sums(const int32_t *__restrict__ counts, uint32_t N, int32_t *__restrict__ sums) {
+    __shared__ int32_t wave_tot[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, base = blockIdx.x * kScanChunk;
+    int32_t s = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t i = base + tid + 1024u * u;
+        s += i < N ? counts[i] : 0;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (lane == 0) wave_tot[wid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        int32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += wave_tot[w];
+        sums[blockIdx.x] = t;
+    }
+}
+__global__ void __launch_bounds__(1024) k_march_scan_apply(const int32_t *__restrict__ counts, uint32_t N, const int32_t *__restrict__ sums,
+                                                           int32_t *__restrict__ rays, int32_t *__restrict__ counter) {
+    __shared__ int32_t wave_tot[16], part[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, base = blockIdx.x * kScanChunk;
+    // the totals in front of this workgroup (and, for the last one, the grand total)
+    int32_t before = 0, all = 0;
+    for (uint32_t b = tid; b < gridDim.x; b += 1024u) {
+        const int32_t v = sums[b];
+        all += v;
+        if (b < blockIdx.x) before += v;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { before += __shfl_xor(before, d, 64); all += __shfl_xor(all, d, 64); }
+    if (lane == 0) { wave_tot[wid] = before; part[wid] = all; }
+    __syncthreads();
+    before = 0; all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { before += wave_tot[w]; all += part[w]; }
+    __syncthreads();
+    // own rays: thread t owns the 4 consecutive rays base + 4 t ..
+    const uint32_t first = base + 4u * tid;
+    int32_t c[4], sum = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+        c[u] = first + u < N ? counts[first + u] : 0;
+        sum += c[u];
+    }
+    int32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t v = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += v;
+    }
+    if (lane == 63) wave_tot[wid] = incl;
+    __syncthreads();
+    int32_t off = before + incl - sum;
+#pragma unroll
+    for (int w = 0; w < 16; ++w)
+        if (w < (int)wid) off += wave_tot[w];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t i = first + u;
+        if (i < N) {
+            rays[3 * (size_t)i] = (int32_t)i;
+            rays[3 * (size_t)i + 1] = off;
+            rays[3 * (size_t)i + 2] = c[u];
+        }
+        off += c[u];
+    }
+    if (blockIdx.x == 0 && tid == 0) { counter[0] = all; counter[1] = (int32_t)N; }
+}
+
 // Training march, pass 3 (raymarching.cu:422-479 without the second walk): one lane per output row.
 __global__ void k_march_write(const float *__restrict__ rays_o, const float *__restrict__ rays_d, GridView g,
                               uint32_t max_steps, uint32_t N, uint32_t M, const float *__restrict__ nears,
@@ -992,6 +1069,19 @@ NSIG_EXPORT int rm_march_train_scan(const int32_t *counts, uint32_t N, int32_t *
     NSIG_REQUIRE(counts && rays && counter, "rm_march_train_scan: null pointer");
     k_march_scan<<<1, 1024, 0, as_stream(stream)>>>(counts, N, rays, counter);
     return check_launch("rm_march_train_scan");
+}
+
+// The same table for many rays in two launches of 4096-ray workgroups; `block_sums` is caller-owned scratch of
+// rm_march_train_scan_blocks(N) int32 words (one total per workgroup), need not be initialised.
+NSIG_EXPORT int rm_march_train_scan_blocks(uint32_t N) { return (int)ceil_div(N, kScanChunk); }
+NSIG_EXPORT int rm_march_train_scan_wide(const int32_t *counts, uint32_t N, int32_t *rays, int32_t *counter, int32_t *block_sums,
+                                         nsig_stream_t stream) {
+    NSIG_REQUIRE(counts && rays && counter && block_sums, "rm_march_train_scan_wide: null pointer");
+    NSIG_REQUIRE(N >= 1, "rm_march_train_scan_wide: N must be positive");
+    const uint32_t nb = ceil_div(N, kScanChunk);
+    k_march_scan_sums<<<nb, 1024, 0, as_stream(stream)>>>(counts, N, block_sums);
+    k_march_scan_apply<<<nb, 1024, 0, as_stream(stream)>>>(counts, N, block_sums, rays, counter);
+    return check_launch("rm_march_train_scan_wide");
 }
 
 NSIG_EXPORT int rm_march_train_write(const float *rays_o, const float *rays_d, float bound, float dt_gamma,

@@ -168,7 +168,10 @@ def march_rays_train_device(rays_o, rays_d, bound, density_bitfield, C, H, nears
         nv.call("rm_march_train_count", nv.ptr(rays_o), nv.ptr(rays_d), nv.ptr(density_bitfield), float(bound), float(dt_gamma),
                 int(max_steps), N, int(C), int(H), nv.ptr(nears), nv.ptr(fars), nv.ptr(noises), nv.ptr(counts), nv.ptr(t_rec), s)
     fused = capacity is not None and 1 <= N <= scan_write_max_rays()
-    if not fused:
+    if not fused and N > 16384:      # many rays (a staged full-image render): the two-launch scan of 4096-ray workgroups
+        sums = torch.empty(int(nv.fn("rm_march_train_scan_blocks")(N)), dtype=torch.int32, device=dev)
+        nv.call("rm_march_train_scan_wide", nv.ptr(counts), N, nv.ptr(rays), nv.ptr(counter), nv.ptr(sums), s)
+    elif not fused:
         nv.call("rm_march_train_scan", nv.ptr(counts), N, nv.ptr(rays), nv.ptr(counter), s)
 
     def write(M):

@@ -305,3 +305,28 @@ def test_two_enqueue_march_equals_the_four_enqueue_march(rmod, bound, dt_gamma, 
     with pytest.raises(ValueError, match="outside"):
         nv.call("rm_march_train_scan_write", nv.ptr(oc), nv.ptr(dc), float(bound), float(dt_gamma), 1024, 12289, C, 128, 128, nv.ptr(nears), None,
                 nv.ptr(t_rec), nv.ptr(counts), nv.ptr(rays), nv.ptr(ctr), nv.ptr(oc), nv.ptr(oc), nv.ptr(oc), nv.stream())
+
+
+@pytest.mark.parametrize("n", [1, 4095, 4096, 4097, 20000, 262144])
+def test_wide_scan_equals_the_single_workgroup_scan(n):
+    """rm_march_train_scan_wide (two launches of 4096-ray workgroups: what a staged full-image render's 262 144-ray march uses) == rm_march_train_scan
+    (one workgroup): the (id, offset, count) table and the totals, bit for bit, for ray counts around the workgroup size and at the largest size."""
+    from nerf_signature_amd import _native as nv
+    rng = np.random.RandomState(n % 1000)
+    counts = torch.from_numpy(rng.randint(0, 1025, n).astype(np.int32)).cuda()
+    counts[rng.randint(0, n, max(1, n // 7))] = 0                      # rays without samples share their successor's offset
+    out = []
+    for wide in (False, True):
+        rays = torch.full((n, 3), -3, dtype=torch.int32, device="cuda")
+        ctr = torch.full((2,), -3, dtype=torch.int32, device="cuda")
+        if wide:
+            sums = torch.full((int(nv.fn("rm_march_train_scan_blocks")(n)),), -77, dtype=torch.int32, device="cuda")
+            nv.call("rm_march_train_scan_wide", nv.ptr(counts), n, nv.ptr(rays), nv.ptr(ctr), nv.ptr(sums), nv.stream())
+        else:
+            nv.call("rm_march_train_scan", nv.ptr(counts), n, nv.ptr(rays), nv.ptr(ctr), nv.stream())
+        out.append((rays, ctr))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    c = counts.cpu().numpy().astype(np.int64)
+    r = out[1][0].cpu().numpy().astype(np.int64)
+    assert np.array_equal(r[:, 0], np.arange(n)) and np.array_equal(r[:, 2], c) and np.array_equal(r[:, 1], np.concatenate([[0], np.cumsum(c)[:-1]]))
+    assert out[1][1].tolist() == [int(c.sum()), n]
