@@ -5,7 +5,7 @@ tag=$1
 cd $GRAFT_REPO_ROOT
 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || exit 1
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out.log 2>&1) || exit 1
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --windows 1 > $out.log 2>&1) || exit 1
 python tools/kstats.py $out 30 40 > gpurun_out/${tag}_summary.txt
 python - $out >> gpurun_out/${tag}_summary.txt <<'PY'
 import csv, glob, sys, collections
