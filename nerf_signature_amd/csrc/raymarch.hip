@@ -614,34 +614,40 @@ __global__ void k_march_write(const float *__restrict__ rays_o, const float *__r
 }
 
 // Passes 2 + 3 in ONE launch for ray counts whose offsets fit in LDS (the training step's 4096 / 4608 rays): every workgroup computes the
-// whole exclusive prefix sum of the counts for itself -- N int32 from L2 in one batch of loads, a 1024-thread scan -- instead of one single-workgroup launch between the walk and the writes (5 us alone, 60-90 us when its loads
+// whole exclusive prefix sum of the counts for itself -- N int32 from L2 in batches of 16 loads per thread, a 256-thread scan -- instead of one single-workgroup launch between the walk and the writes (5 us alone, 60-90 us when its loads
 // queue behind the optimiser's HBM stream, profiles/r02_f_kernel_stats.csv); a row's ray is then found by a binary search in LDS
 // (13 dependent ~50-cycle reads instead of 13 dependent L2 round trips).  Workgroup 0 also stores the (id, offset, count) table
 // and the totals.  Same ray-id order, same rows, same padding as k_march_scan + k_march_write.
-__global__ void __launch_bounds__(1024) k_march_scan_write(const float *__restrict__ rays_o, const float *__restrict__ rays_d, GridView g,
-                                                           uint32_t max_steps, uint32_t N, uint32_t M, const float *__restrict__ nears,
-                                                           const float *__restrict__ noises, const float *__restrict__ t_rec,
-                                                           const int32_t *__restrict__ counts, int32_t *__restrict__ rays,
-                                                           int32_t *__restrict__ counter, float *__restrict__ xyzs, float *__restrict__ dirs,
-                                                           float *__restrict__ deltas) {
+// 256-thread workgroups ON PURPOSE: beside the block render's encoder (40 320 workgroups of 256 threads that backfill every freed wave
+// slot) a 1024-thread workgroup needs half a CU's wave slots free AT ONCE and almost never finds them -- the first version of this kernel
+// took 258 us there instead of 8 (profiles/r03_b_timeline_headline.txt), and so did the single 1024-thread scan workgroup before it (67 us).
+__global__ void __launch_bounds__(256) k_march_scan_write(const float *__restrict__ rays_o, const float *__restrict__ rays_d, GridView g,
+                                                          uint32_t max_steps, uint32_t N, uint32_t M, const float *__restrict__ nears,
+                                                          const float *__restrict__ noises, const float *__restrict__ t_rec,
+                                                          const int32_t *__restrict__ counts, int32_t *__restrict__ rays,
+                                                          int32_t *__restrict__ counter, float *__restrict__ xyzs, float *__restrict__ dirs,
+                                                          float *__restrict__ deltas) {
     extern __shared__ int32_t off[];      // [N + 1]: counts, then in place their exclusive prefix sums; off[N] = total
-    __shared__ int32_t wave_tot[16];
+    __shared__ int32_t wave_tot[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    {   // all of a thread's loads in flight together (one L2 round trip, not one per element): N <= 12 * 1024
-        int32_t v[kScanWriteMaxRays / 1024];
+    {   // all of a thread's loads in flight together (one L2 round trip per batch of 16, not one per element): N <= 48 * 256
+        constexpr uint32_t kBatchLoads = 16;
+        for (uint32_t base = 0; base < N; base += 256u * kBatchLoads) {
+            int32_t v[kBatchLoads];
 #pragma unroll
-        for (uint32_t u = 0; u < kScanWriteMaxRays / 1024; ++u) {
-            const uint32_t i = tid + 1024u * u;
-            v[u] = i < N ? counts[i] : 0;
-        }
+            for (uint32_t u = 0; u < kBatchLoads; ++u) {
+                const uint32_t i = base + tid + 256u * u;
+                v[u] = i < N ? counts[i] : 0;
+            }
 #pragma unroll
-        for (uint32_t u = 0; u < kScanWriteMaxRays / 1024; ++u) {
-            const uint32_t i = tid + 1024u * u;
-            if (i < N) off[i] = v[u];
+            for (uint32_t u = 0; u < kBatchLoads; ++u) {
+                const uint32_t i = base + tid + 256u * u;
+                if (i < N) off[i] = v[u];
+            }
         }
     }
     __syncthreads();
-    const uint32_t chunk = ceil_div(N, 1024u);
+    const uint32_t chunk = ceil_div(N, 256u);
     const uint32_t beg = min(N, tid * chunk), end = min(N, beg + chunk);
     int32_t sum = 0;
     for (uint32_t i = beg; i < end; ++i) sum += off[i];
@@ -655,7 +661,7 @@ __global__ void __launch_bounds__(1024) k_march_scan_write(const float *__restri
     __syncthreads();
     int32_t run = incl - sum;
 #pragma unroll
-    for (int w = 0; w < 16; ++w)
+    for (int w = 0; w < 4; ++w)
         if (w < (int)wid) run += wave_tot[w];
     const bool first = blockIdx.x == 0;
     for (uint32_t i = beg; i < end; ++i) {
@@ -668,7 +674,7 @@ __global__ void __launch_bounds__(1024) k_march_scan_write(const float *__restri
         }
         run += c;
     }
-    if (tid == 1023) {
+    if (tid == 255) {
         off[N] = run;
         if (first) { counter[0] = run; counter[1] = (int32_t)N; }
     }
@@ -1109,8 +1115,8 @@ NSIG_EXPORT int rm_march_train_scan_write(const float *rays_o, const float *rays
     NSIG_REQUIRE(M == 0 || (xyzs && dirs && deltas), "rm_march_train_scan_write: null point buffers");
     NSIG_REQUIRE(N >= 1 && N <= kScanWriteMaxRays, "rm_march_train_scan_write: N=%u outside [1, %u] (use rm_march_train_scan + rm_march_train_write)", N, kScanWriteMaxRays);
     if (int e = check_grid_args("rm_march_train_scan_write", C, H, max_steps, bound)) return e;
-    const uint32_t blocks = max(1u, min(ceil_div(M, 1024), (uint32_t)(kCUs * 2)));     // (M == 0: workgroup 0 still writes the ray table and the totals)
-    k_march_scan_write<<<blocks, 1024, (N + 1) * sizeof(int32_t), as_stream(stream)>>>(rays_o, rays_d, make_grid_view(nullptr, bound, dt_gamma, max_steps, C, H),
+    const uint32_t blocks = max(1u, min(ceil_div(M, 1024), (uint32_t)(kCUs * 4)));     // (M == 0: workgroup 0 still writes the ray table and the totals)
+    k_march_scan_write<<<blocks, 256, (N + 1) * sizeof(int32_t), as_stream(stream)>>>(rays_o, rays_d, make_grid_view(nullptr, bound, dt_gamma, max_steps, C, H),
                                                                                       max_steps, N, M, nears, noises, t_rec, counts, rays, counter, xyzs, dirs, deltas);
     return check_launch("rm_march_train_scan_write");
 }
