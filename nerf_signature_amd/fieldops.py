@@ -239,13 +239,18 @@ class ScatterPlan:
         self.M, self.xyzs, self.bound = xyzs.shape[0], xyzs, float(bound)
         self.buf = torch.empty(int(nv.fn("hg_scatter_plan_bytes")(self.M)), dtype=torch.uint8, device=xyzs.device)
         self.stream, self.ready, self.launched = _PLAN_STREAM, None, False
-        if self.stream is not None and self.stream == torch.cuda.current_stream():
-            self.stream = None
+        self.src_ready = None
         if self.stream is None:
             self.launch()
         else:
-            self.src_ready = torch.cuda.Event()      # the positions are produced on the current stream
-            self.src_ready.record()
+            # Deferred until flush_plans() -- also when this render itself runs on the plan stream (the content render of the overlapped
+            # training step): launched inline, the plan's 1024-thread workgroups sat between that render's march and its encoder, and
+            # beside the block render's encoder (40 320 workgroups of 256 threads backfilling every freed wave slot) a 1024-thread
+            # workgroup almost never finds half a CU free -- k_plan_count took 231 us there and held the whole content render back
+            # until the block encoder had finished (profiles/r03_c_timeline_headline.txt).
+            if self.stream != torch.cuda.current_stream():
+                self.src_ready = torch.cuda.Event()      # the positions are produced on the current stream
+                self.src_ready.record()
             _PENDING_PLANS.append(self)
 
     def launch(self):
@@ -255,7 +260,8 @@ class ScatterPlan:
         if self.stream is None:
             nv.call("hg_scatter_plan", nv.ptr(self.xyzs), self.M, self.bound, nv.ptr(self.buf), nv.stream())
         else:
-            self.stream.wait_event(self.src_ready)
+            if self.src_ready is not None:
+                self.stream.wait_event(self.src_ready)
             nv.call("hg_scatter_plan", nv.ptr(self.xyzs), self.M, self.bound, nv.ptr(self.buf), self.stream.cuda_stream)
             self.xyzs.record_stream(self.stream)
             self.buf.record_stream(self.stream)
