@@ -279,7 +279,8 @@ class ScatterPlan:
             self.stream = None
             self.launch()
         elif self.ready is not None:
-            torch.cuda.current_stream().wait_event(self.ready)
+            if self.stream is None or torch.cuda.current_stream() != self.stream:      # (same stream: already in order -- and an event waited on
+                torch.cuda.current_stream().wait_event(self.ready)                     #  by the stream that recorded it crashes hipStreamEndCapture)
             self.ready = None
 
 
