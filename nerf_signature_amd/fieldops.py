@@ -240,6 +240,8 @@ class ScatterPlan:
         self.buf = torch.empty(int(nv.fn("hg_scatter_plan_bytes")(self.M)), dtype=torch.uint8, device=xyzs.device)
         self.stream, self.ready, self.launched = _PLAN_STREAM, None, False
         self.src_ready = None
+        if self.stream is not None and self.stream == torch.cuda.current_stream() and os.environ.get("NERFSIG_PLAN_INLINE", "0") == "1":
+            self.stream = None      # (round-2 behaviour, for A/B measurements: a render running on the plan stream launches its plan in line)
         if self.stream is None:
             self.launch()
         else:
