@@ -240,16 +240,18 @@ class ScatterPlan:
         self.buf = torch.empty(int(nv.fn("hg_scatter_plan_bytes")(self.M)), dtype=torch.uint8, device=xyzs.device)
         self.stream, self.ready, self.launched = _PLAN_STREAM, None, False
         self.src_ready = None
-        if self.stream is not None and self.stream == torch.cuda.current_stream() and os.environ.get("NERFSIG_PLAN_INLINE", "0") == "1":
-            self.stream = None      # (round-2 behaviour, for A/B measurements: a render running on the plan stream launches its plan in line)
+        # A render that itself runs on the plan stream (the content render of the overlapped training step) launches its plan IN LINE, between its
+        # march and its encoder.  Round 3 tried deferring it like the block render's (NERFSIG_PLAN_INLINE=0): beside the block render's encoder
+        # the plan's 1024-thread workgroups starve for wave slots (k_plan_count 231 us instead of 8) and hold the content render back until
+        # that encoder has finished -- which turns out to be the better schedule: the content render's encoder then runs beside the block
+        # render's MLP (different bottlenecks) instead of beside its encoder (the same texture-address path: block encoder 285 -> 312 us, and
+        # the content MLP's 150-VGPR waves find no register space, 180 us instead of 15).  Deferred: 1.056-1.063 ms per step, in line:
+        # 1.046-1.057 (profiles/r03_content_plan_deferred_ab.txt).
+        if self.stream is not None and self.stream == torch.cuda.current_stream() and os.environ.get("NERFSIG_PLAN_INLINE", "1") != "0":
+            self.stream = None
         if self.stream is None:
             self.launch()
         else:
-            # Deferred until flush_plans() -- also when this render itself runs on the plan stream (the content render of the overlapped
-            # training step): launched inline, the plan's 1024-thread workgroups sat between that render's march and its encoder, and
-            # beside the block render's encoder (40 320 workgroups of 256 threads backfilling every freed wave slot) a 1024-thread
-            # workgroup almost never finds half a CU free -- k_plan_count took 231 us there and held the whole content render back
-            # until the block encoder had finished (profiles/r03_c_timeline_headline.txt).
             if self.stream != torch.cuda.current_stream():
                 self.src_ready = torch.cuda.Event()      # the positions are produced on the current stream
                 self.src_ready.record()
