@@ -48,6 +48,12 @@ def collective(fn, last=False):
         fn()
 
 
+def collective_ends_segment():
+    """True when a collective issued now would end the running capture segment (see collective): forked streams have to join in front of it."""
+    return (_BOUNDARY is not None and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+            and os.environ.get("NERFSIG_CAPTURE_COLLECTIVES", "") != "1")
+
+
 def init_from_env(backend=None):
     """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -54,7 +54,7 @@ class _WatermarkLoss(torch.autograd.Function):
         return g_content, None, g_decoded, None, None, None, None
 
 
-def backward_from_loss_kernel(out, content_scale=1.0):
+def backward_from_loss_kernel(out, content_scale=1.0, content_stream=None, content_first=False):
     """`out[-1].backward()` for a train_step whose losses came from wm_loss_fwd, without the ones-fill and the wm_loss_bwd launch:
     the forward kernel already left d(loss_i)/d(content) and d(loss_w)/d(decoded); for an upstream gradient of 1 they only need
     the lambdas, which are applied here as the (host-side) scale of the seed.
@@ -74,7 +74,18 @@ def backward_from_loss_kernel(out, content_scale=1.0):
     seeds = [d_content if ci == 1.0 else d_content * ci, d_decoded if lambda_w == 1.0 else d_decoded * lambda_w]
     # (finetune_decoder: the codebook is frozen too, the content render then has no trainable input and no grad_fn)
     pairs = [(t, g) for t, g in zip((content, decoded), seeds) if t.requires_grad]
-    if pairs:
+    if len(pairs) == 2 and content_stream is not None and content_first:
+        # Two disjoint autograd graphs (they meet only in the shared gradient G, a side effect).  In one backward call over both, the content
+        # render's backward -- whose nodes are the oldest, so the engine runs them last -- starts only when everything the main stream holds by
+        # then (the decoder's and the block render's backward) is done, and queues behind the decoder's parameter gradients on its own stream:
+        # it ends up at the step's tail (kernel timelines: profiles/r03_backward_schedule.txt).  Issued first, from its own stream (the engine
+        # joins the streams a call used into the CALLER's stream when it returns), it starts right behind the loss kernel and runs beside the
+        # decoder's backward chain.
+        content_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(content_stream):
+            torch.autograd.backward([pairs[0][0]], [pairs[0][1]])
+        torch.autograd.backward([pairs[1][0]], [pairs[1][1]])
+    elif pairs:
         torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
 
 
@@ -128,8 +139,10 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
     image = outputs["image"]
     if shard is not None:
         # the decoder's BatchNorm needs all D blocks (batch statistics, hidden_models.py:26): all-gather the rendered blocks, decode
-        # them on every rank; the backward keeps this rank's rows.  A collective ends a captured segment, so both streams meet first.
-        if main is not None:
+        # them on every rank; the backward keeps this rank's rows.  Where the collective ends a captured segment both streams meet first
+        # (a capture cannot end with a forked stream); captured inside the graph or issued eagerly it leaves the content render running
+        # beside the decoder.
+        if main is not None and dp.collective_ends_segment():
             main.wait_stream(side_stream)
         image = dp.gather_blocks(image, wm["rays_o_block"].shape[0], shard[0])
     if model.normalization is normalize_img and hasattr(model.msg_decoder, "decode_rendered"):
@@ -146,8 +159,7 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
                                   "utils_wtmk_disen.py:585-590); blend the alpha channel into the images before the step")
     gt_rgb = content["images"]
     if main is not None:
-        if shard is None:
-            main.wait_stream(side_stream)
+        main.wait_stream(side_stream)
     else:
         content_pred_rgb = model.render(content["rays_o"], content["rays_d"], message, **kw)["image"]
     keys = message.to(decoded.device).unsqueeze(-1)
@@ -383,7 +395,18 @@ class GraphedWatermarkLoop:
         self.native_dense_adam = native_dense_adam
         # NERFSIG_SIDE_PRIORITY=-1: the content chain (small latency-bound launches) on a high-priority stream
         self.side_stream = torch.cuda.Stream(priority=int(os.environ.get("NERFSIG_SIDE_PRIORITY", "0"))) if overlap_content else None
-        self.plan_stream = self.side_stream   # scatter plans queue behind the content render (a third captured stream crashes hipStreamEndCapture on this runtime)
+        self.plan_stream = self.side_stream   # scatter plans queue behind the content render
+        # The decoder's parameter-gradient kernels (~85 us, needed only by the optimiser) leave the main stream, so that the block render's backward
+        # waits for the image gradient alone.  Two schedules of the backward pass (decided in prepare(), once the block shard is known):
+        #   "tail"   (one rank): they queue on the content render's stream and the content render's backward behind them, at the step's tail, beside
+        #            the block render's MLP backward and scatter, which are long enough to cover both;
+        #   "beside" (blocks sharded over ranks: every kernel of a render is short): a stream of their own, and the content render's backward issued
+        #            first (backward_from_loss_kernel) -- it runs beside the decoder's backward chain.  Emulated rank of 2 / 4 / 8: 0.866 -> 0.845,
+        #            0.645 -> 0.605, 0.566 -> 0.530 ms per step; one rank: no gain (the decoder's chain slows down by what the content kernels
+        #            take).  profiles/r03_backward_schedule.txt.  NERFSIG_BACKWARD_SCHEDULE=tail|beside overrides.
+        self.backward_schedule = os.environ.get("NERFSIG_BACKWARD_SCHEDULE", "auto")
+        self.weights_stream = self.side_stream
+        self.content_backward_first = False
         if not hasattr(optimizer, "step_shared_sel"):
             raise TypeError("GraphedWatermarkLoop needs nerf_signature_amd.optim.CodebookAdam(capturable=True)")
         if not any(t.requires_grad for t in model.msg_encoder.tables()):
@@ -496,15 +519,17 @@ class GraphedWatermarkLoop:
                              presum_adopt=self.presum_in_adam and torch.cuda.is_current_stream_capturing())
         finally:
             fo.set_plan_stream(prev)
-        set_weights_stream(self.side_stream)     # the decoder's parameter gradients go there too: the block render's backward only waits for the image gradient
+        set_weights_stream(self.weights_stream)
         set_grad_arena(self.sink.tail)
         try:
-            backward_from_loss_kernel(out, dp.content_grad_scale(self.sharded))
+            backward_from_loss_kernel(out, dp.content_grad_scale(self.sharded), self.side_stream, self.content_backward_first)
         finally:
             set_weights_stream(None)
             set_grad_arena(None)
         if self.side_stream is not None:   # the content render's backward ends in a side effect (the shared gradient): join it explicitly
             torch.cuda.current_stream().wait_stream(self.side_stream)
+        if self.weights_stream is not None and self.weights_stream is not self.side_stream:
+            torch.cuda.current_stream().wait_stream(self.weights_stream)
         return out
 
     def _optimise(self, defer_collective=False):
@@ -670,6 +695,10 @@ class GraphedWatermarkLoop:
         self.exchange.shared_scale = 1.0 if self.sharded else None
         self.opt_shard = dp.optimizer_shard(model.message_dim) if self.sharded else None
         model.codebook_shard = self.opt_shard
+        beside = self.side_stream is not None and (self.backward_schedule == "beside" or (self.backward_schedule == "auto" and self.sharded))
+        self.content_backward_first = beside
+        self.weights_stream = self.side_stream if not beside else (getattr(self, "_own_weights_stream", None) or torch.cuda.Stream())
+        self._own_weights_stream = self.weights_stream if beside else None
         with torch.no_grad():   # sizes only: the two renders of a step, in order (block, content)
             model.render(block_o, block_d, message, staged=False, bg_color=1,
                          perturb=False, force_all_rays=True, **self.render_kwargs)

@@ -1,0 +1,187 @@
+// How does this HIP runtime schedule the branches of a stream-captured graph?  Stand-alone probe: spin kernels that stamp their start and end
+// (100 MHz wall clock) captured into small two- and three-stream graphs whose shapes mirror the training step's (fork, join, a branch that hangs off
+// the middle of a chain, the order in which the branches were captured); prints every node's start/end relative to the graph's first node.
+// build: hipcc -O2 --offload-arch=gfx950 tools/micro/graph_sched.hip -o tools/_build/graph_sched
+// run:   tools/_build/graph_sched            (LD_LIBRARY_PATH=<torch>/lib to probe the runtime bundled with torch)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s failed: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+__global__ void spin(unsigned long long *stamps, int id, int us) {
+    const unsigned long long t0 = wall_clock64();
+    if (threadIdx.x == 0) stamps[2 * id] = t0;
+    while (wall_clock64() - t0 < (unsigned long long)us * 100ull) {}
+    if (threadIdx.x == 0) stamps[2 * id + 1] = wall_clock64();
+}
+
+struct Probe {
+    unsigned long long *stamps;
+    std::vector<std::string> names;
+    hipStream_t s[3];
+    std::vector<hipEvent_t> events;
+    Probe() {
+        CK(hipMalloc(&stamps, 2 * 64 * sizeof(unsigned long long)));
+        for (auto &x : s) CK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+    }
+    void k(int stream, const char *name, int us) {
+        const int id = (int)names.size();
+        names.push_back(name);
+        spin<<<1, 64, 0, s[stream]>>>(stamps, id, us);
+    }
+    // stream `to` waits for what `from` holds now
+    void dep(int from, int to) {
+        hipEvent_t e;
+        CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        CK(hipEventRecord(e, s[from]));
+        CK(hipStreamWaitEvent(s[to], e, 0));
+        events.push_back(e);
+    }
+    hipEvent_t mark(int from) {
+        hipEvent_t e;
+        CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        CK(hipEventRecord(e, s[from]));
+        events.push_back(e);
+        return e;
+    }
+    void wait(int to, hipEvent_t e) { CK(hipStreamWaitEvent(s[to], e, 0)); }
+    template <class F> void run(const char *title, F body) {
+        names.clear();
+        CK(hipMemset(stamps, 0, 2 * 64 * sizeof(unsigned long long)));
+        hipGraph_t g;
+        hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(s[0], hipStreamCaptureModeThreadLocal));
+        body();
+        CK(hipStreamEndCapture(s[0], &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        for (int rep = 0; rep < 3; ++rep) CK(hipGraphLaunch(ge, s[0]));
+        CK(hipStreamSynchronize(s[0]));
+        std::vector<unsigned long long> h(2 * names.size());
+        CK(hipMemcpy(h.data(), stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (size_t i = 0; i < names.size(); ++i) { if (h[2 * i] < t0) t0 = h[2 * i]; if (h[2 * i + 1] > t1) t1 = h[2 * i + 1]; }
+        printf("== %s   (span %.0f us)\n", title, (t1 - t0) / 100.0);
+        for (size_t i = 0; i < names.size(); ++i)
+            printf("   %-6s %7.1f -> %7.1f\n", names[i].c_str(), (h[2 * i] - t0) / 100.0, (h[2 * i + 1] - t0) / 100.0);
+        CK(hipGraphExecDestroy(ge));
+        CK(hipGraphDestroy(g));
+    }
+};
+
+int main() {
+    Probe p;
+    const int U = 20;   // us per node
+    p.run("T1 fork at R: side chain captured FIRST, main chain second, join at J", [&] {
+        p.k(0, "R", U);
+        p.dep(0, 1);
+        for (const char *n : {"S1", "S2", "S3", "S4"}) p.k(1, n, U);
+        for (const char *n : {"M1", "M2", "M3", "M4"}) p.k(0, n, U);
+        p.dep(1, 0);
+        p.k(0, "J", U);
+    });
+    p.run("T2 fork at R: main chain captured first, side chain second, join at J", [&] {
+        p.k(0, "R", U);
+        p.dep(0, 1);
+        for (const char *n : {"M1", "M2", "M3", "M4"}) p.k(0, n, U);
+        for (const char *n : {"S1", "S2", "S3", "S4"}) p.k(1, n, U);
+        p.dep(1, 0);
+        p.k(0, "J", U);
+    });
+    p.run("T3 a branch hangs off the MIDDLE of the main chain (after M2), captured after the whole main chain; join at J", [&] {
+        p.k(0, "R", U);
+        p.k(0, "M1", U);
+        p.k(0, "M2", U);
+        hipEvent_t e = p.mark(0);
+        for (const char *n : {"M3", "M4", "M5", "M6"}) p.k(0, n, U);
+        p.wait(1, e);
+        for (const char *n : {"S1", "S2"}) p.k(1, n, U);
+        p.dep(1, 0);
+        p.k(0, "J", U);
+    });
+    p.run("T4 as T3, the branch captured right at the fork (before M3..M6)", [&] {
+        p.k(0, "R", U);
+        p.k(0, "M1", U);
+        p.k(0, "M2", U);
+        p.dep(0, 1);
+        for (const char *n : {"S1", "S2"}) p.k(1, n, U);
+        for (const char *n : {"M3", "M4", "M5", "M6"}) p.k(0, n, U);
+        p.dep(1, 0);
+        p.k(0, "J", U);
+    });
+    p.run("T5 as T3 plus a redundant second parent for M3 (event recorded after M1, waited on again before M3)", [&] {
+        p.k(0, "R", U);
+        p.k(0, "M1", U);
+        hipEvent_t e1 = p.mark(0);
+        p.k(0, "M2", U);
+        hipEvent_t e = p.mark(0);
+        p.wait(0, e1);
+        for (const char *n : {"M3", "M4", "M5", "M6"}) p.k(0, n, U);
+        p.wait(1, e);
+        for (const char *n : {"S1", "S2"}) p.k(1, n, U);
+        p.dep(1, 0);
+        p.k(0, "J", U);
+    });
+    p.run("T6 the step's shape: side = content forward (C1..C3) from R, main = block forward (B1..B3), join at L (loss), then main = decoder backward "
+          "(D1..D4) + block backward (E1, E2), side = content backward (X1, X2) hanging off L and captured LAST, join at J",
+          [&] {
+              p.k(0, "R", U);
+              p.dep(0, 1);
+              for (const char *n : {"C1", "C2", "C3"}) p.k(1, n, U);
+              for (const char *n : {"B1", "B2", "B3"}) p.k(0, n, U);
+              p.dep(1, 0);
+              p.k(0, "L", U);
+              hipEvent_t e = p.mark(0);
+              for (const char *n : {"D1", "D2", "D3", "D4", "E1", "E2"}) p.k(0, n, U);
+              p.wait(1, e);
+              for (const char *n : {"X1", "X2"}) p.k(1, n, U);
+              p.dep(1, 0);
+              p.k(0, "J", U);
+          });
+    p.run("T7 as T6, content backward on a THIRD stream", [&] {
+        p.k(0, "R", U);
+        p.dep(0, 1);
+        for (const char *n : {"C1", "C2", "C3"}) p.k(1, n, U);
+        for (const char *n : {"B1", "B2", "B3"}) p.k(0, n, U);
+        p.dep(1, 0);
+        p.k(0, "L", U);
+        hipEvent_t e = p.mark(0);
+        for (const char *n : {"D1", "D2", "D3", "D4", "E1", "E2"}) p.k(0, n, U);
+        p.wait(2, e);
+        for (const char *n : {"X1", "X2"}) p.k(2, n, U);
+        p.dep(2, 0);
+        p.k(0, "J", U);
+    });
+    p.run("T8 as T6, content backward captured right behind L (before D1..)", [&] {
+        p.k(0, "R", U);
+        p.dep(0, 1);
+        for (const char *n : {"C1", "C2", "C3"}) p.k(1, n, U);
+        for (const char *n : {"B1", "B2", "B3"}) p.k(0, n, U);
+        p.dep(1, 0);
+        p.k(0, "L", U);
+        p.dep(0, 1);
+        for (const char *n : {"X1", "X2"}) p.k(1, n, U);
+        for (const char *n : {"D1", "D2", "D3", "D4", "E1", "E2"}) p.k(0, n, U);
+        p.dep(1, 0);
+        p.k(0, "J", U);
+    });
+    p.run("T9 as T6, with a redundant second parent for D1 (event recorded after B3, before the join, waited on again before D1)", [&] {
+        p.k(0, "R", U);
+        p.dep(0, 1);
+        for (const char *n : {"C1", "C2", "C3"}) p.k(1, n, U);
+        for (const char *n : {"B1", "B2", "B3"}) p.k(0, n, U);
+        hipEvent_t eb = p.mark(0);
+        p.dep(1, 0);
+        p.k(0, "L", U);
+        hipEvent_t e = p.mark(0);
+        p.wait(0, eb);
+        for (const char *n : {"D1", "D2", "D3", "D4", "E1", "E2"}) p.k(0, n, U);
+        p.wait(1, e);
+        for (const char *n : {"X1", "X2"}) p.k(1, n, U);
+        p.dep(1, 0);
+        p.k(0, "J", U);
+    });
+    return 0;
+}
