@@ -105,7 +105,7 @@ def srgb_to_linear(x):
 
 
 def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce, side_stream=None, presum_first=False,
-               presum_adopt=False, color_space="srgb"):
+               presum_adopt=False, color_space="srgb", blocks_first=False):
     """data = {'watermark': {'rays_o_block', 'rays_d_block'}, 'content': {'rays_o', 'rays_d', 'images'}}.
     Returns (pred_rgb, gt_rgb, content_pred_rgb, lossi, lossw, loss) like the reference.
 
@@ -129,11 +129,17 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
         # Issued first: the content render's field pass finds no pre-summed codebook yet and computes it right behind its own
         # march, on the side stream -- beside the block render's march, which does not need it; the block render's field pass
         # then waits for that event only (network._presum_consumed).
+        if not blocks_first:
+            with torch.cuda.stream(side_stream):
+                content_pred_rgb = model.render(content["rays_o"], content["rays_d"], message, **kw)["image"]
+            content_pred_rgb.record_stream(main)
+    block_o, block_d, shard = local_blocks(wm)
+    outputs = model.render(block_o, block_d, message, **kw)
+    if main is not None and blocks_first:
+        # (the fork above is the content render's only parent; captured BEHIND the block render it is enqueued behind it: GraphedWatermarkLoop)
         with torch.cuda.stream(side_stream):
             content_pred_rgb = model.render(content["rays_o"], content["rays_d"], message, **kw)["image"]
         content_pred_rgb.record_stream(main)
-    block_o, block_d, shard = local_blocks(wm)
-    outputs = model.render(block_o, block_d, message, **kw)
     if main is not None:
         fo.flush_plans()          # the block render's scatter plan: on the plan stream, behind the content render
     image = outputs["image"]
@@ -516,7 +522,8 @@ class GraphedWatermarkLoop:
         try:
             out = train_step(self.model, self.data, self.msg_dev, self.render_kwargs, self.lambda_w, self.lambda_i, side_stream=self.side_stream,
                              presum_first=self.marched is not None,
-                             presum_adopt=self.presum_in_adam and torch.cuda.is_current_stream_capturing())
+                             presum_adopt=self.presum_in_adam and torch.cuda.is_current_stream_capturing(),
+                             blocks_first=self.side_stream is not None and self._blocks_issued_first())
         finally:
             fo.set_plan_stream(prev)
         set_weights_stream(self.weights_stream)
@@ -609,7 +616,16 @@ class GraphedWatermarkLoop:
         if self.marched is not None:      # the block render has its own counter, the content render the ring's latest row
             return int(self.marched[0]["counter"][0]), int(self.model.step_counter[self.capacity_rows[-1], 0])
         a, b = self.model.step_counter[self.capacity_rows, 0].tolist()
-        return (a, b) if self.side_stream is None else (b, a)     # issue order: with a side stream the content render comes first
+        return (a, b) if self._blocks_issued_first() else (b, a)     # issue order: with a side stream the content render comes first
+
+    def _blocks_issued_first(self):
+        """Which render train_step issues (and a capture records) first.  One rank: the content render, on its side stream.  Blocks sharded over
+        ranks ("beside" schedule): the block render.  With its default packet capture this runtime starts a node whose parent sits on another of
+        the graph's internal streams only when that stream has finished the whole run of nodes it was handed in one piece (tools/graph_dot.py,
+        profiles/r03_graph_capture_order.txt): captured behind the content render's nine short kernels, the block render -- and the all-gather and
+        the decoder behind it -- started when all nine were done; captured first, it is the content render that waits (for the decoder's forward
+        chain, beside whose backward chain it then runs): emulated rank of 2 / 4 / 8: 0.846 -> 0.828, 0.610 -> 0.605, 0.534 -> 0.527 ms."""
+        return self.side_stream is None or (self.content_backward_first and os.environ.get("NERFSIG_BLOCKS_FIRST", "1") == "1")
 
     def _kept_inputs_key(self):
         """Versions of everything the kept planes / marched samples were computed from (in-place writes through torch bump them)."""
@@ -789,7 +805,7 @@ class GraphedWatermarkLoop:
         self.graphs = tuple(self.segments)
         self.capacity_rows = [(model.local_step - 2) % 16, (model.local_step - 1) % 16]
         # the counters are written in issue order: with a side stream train_step issues the content render first
-        self.capacities = [cap_block, cap_content] if self.side_stream is None else [cap_content, cap_block]
+        self.capacities = [cap_block, cap_content] if self._blocks_issued_first() else [cap_content, cap_block]
         self.content_capacity = cap_content
         if self.marched is not None:        # only the content render used the ring during the capture
             self.capacity_rows = [(model.local_step - 1) % 16]

@@ -528,9 +528,9 @@ def test_bench_launcher_walks_the_whole_chain_and_still_prints_a_line_when_every
     line = json.loads(lines[0])
     assert line["value"] is None and line["n_gpus"] == 2
     fails = line["config"]["launch_failures"]
-    assert [f["attempt"] for f in fails] == [0, 1, 2, 3] and all(f["rc"] == 3 for f in fails)
-    assert all("fails on purpose" in f["rank0_stderr_tail"] for f in fails)
-    assert out.stderr.count("failed: rc 3") == 4 and "no attempt left" in out.stderr
+    assert [f["attempt"] for f in fails] == [0, 1, 2, 3] and all(f["rc"] == 3 for f in fails), (fails, out.stderr[-3000:])
+    assert all("fails on purpose" in f["rank0_stderr_tail"] for f in fails), fails
+    assert out.stderr.count("failed: rc 3") == 4 and "no attempt left" in out.stderr, out.stderr[-3000:]
     # hung ranks: every attempt is cut by the watchdog; the chain takes about attempts x (watchdog + kill)
     env["NERFSIG_TEST_FAIL_CAPTURED"] = "hang"
     env["NERFSIG_LAUNCH_WATCHDOG_S"] = "4"
@@ -539,7 +539,7 @@ def test_bench_launcher_walks_the_whole_chain_and_still_prints_a_line_when_every
     took = time.time() - t0
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert out.returncode != 0 and line["value"] is None
-    assert [f["rc"] for f in line["config"]["launch_failures"]] == [124] * 4 and took < 120
+    assert [f["rc"] for f in line["config"]["launch_failures"]] == [124] * 4 and took < 120, (took, line["config"]["launch_failures"], out.stderr[-3000:])
 
 
 def test_bench_under_an_external_launcher_supervises_its_own_worker_and_walks_the_chain():

@@ -71,8 +71,46 @@ struct Probe {
     }
 };
 
-int main() {
+int main(int argc, char **argv) {
+    // argv[1]: number of extra streams created (and used once) BEFORE the probe's own -- do the graph's internal streams share hardware queues with them?
+    const int extra = argc > 1 ? atoi(argv[1]) : 0;
+    std::vector<hipStream_t> pad(extra);
+    for (auto &x : pad) { CK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking)); CK(hipMemsetAsync(nullptr, 0, 0, x)); }
     Probe p;
+    if (argc > 2) {     // the step's head only: S = k_sample_rays, content chain C1..C6 captured first, block chain B1..B6 second (both children of S)
+        for (int rep = 0; rep < 2; ++rep)
+        p.run("H1 content chain captured first", [&] {
+            p.k(0, "R", 5); p.k(0, "S", 5);
+            p.dep(0, 1);
+            for (const char *n : {"C1", "C2", "C3", "C4", "C5", "C6"}) p.k(1, n, 20);
+            for (const char *n : {"B1", "B2", "B3", "B4", "B5", "B6"}) p.k(0, n, 20);
+            p.dep(1, 0);
+            p.k(0, "L", 5);
+        });
+        for (int rep = 0; rep < 2; ++rep)
+        p.run("H2 as H1 with a device-to-device copy node between B3 and B4 (the all-gather's place)", [&] {
+            p.k(0, "R", 5); p.k(0, "S", 5);
+            p.dep(0, 1);
+            for (const char *n : {"C1", "C2", "C3", "C4", "C5", "C6"}) p.k(1, n, 20);
+            for (const char *n : {"B1", "B2", "B3"}) p.k(0, n, 20);
+            CK(hipMemcpyAsync(p.stamps + 100, p.stamps + 110, 64, hipMemcpyDeviceToDevice, p.s[0]));
+            for (const char *n : {"B4", "B5", "B6"}) p.k(0, n, 20);
+            p.dep(1, 0);
+            p.k(0, "L", 5);
+        });
+        for (int rep = 0; rep < 2; ++rep)
+        p.run("H3 as H2, block chain captured first", [&] {
+            p.k(0, "R", 5); p.k(0, "S", 5);
+            p.dep(0, 1);
+            for (const char *n : {"B1", "B2", "B3"}) p.k(0, n, 20);
+            CK(hipMemcpyAsync(p.stamps + 100, p.stamps + 110, 64, hipMemcpyDeviceToDevice, p.s[0]));
+            for (const char *n : {"B4", "B5", "B6"}) p.k(0, n, 20);
+            for (const char *n : {"C1", "C2", "C3", "C4", "C5", "C6"}) p.k(1, n, 20);
+            p.dep(1, 0);
+            p.k(0, "L", 5);
+        });
+        return 0;
+    }
     const int U = 20;   // us per node
     p.run("T1 fork at R: side chain captured FIRST, main chain second, join at J", [&] {
         p.k(0, "R", U);
