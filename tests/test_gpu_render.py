@@ -320,11 +320,21 @@ def test_split_graphs_with_rccl_exchange_rehearsed_on_one_rank():
         assert len(loop1.segments) == 3 and len(loop1.between) == 3 and loop1.sharded and loop1.opt_shard == (0, 32)
         assert loop1.exchange.collectives_per_step == 1                  # G and the decoder's gradient block travel together
         assert loop1.exchange.bytes_per_step == (1 << 19) * 2 * 4 + sum(p.numel() for p in loop1.model.msg_decoder.parameters() if p.grad is not None) * 4
+        # sharded blocks take the "beside" schedule: block render captured first, the content render's backward issued first from its own stream,
+        # the decoder's parameter gradients on a third stream
+        assert loop1.content_backward_first and loop1._blocks_issued_first() and loop1.weights_stream is not loop1.side_stream
+        # ... and the same step with the collectives captured INSIDE the graph (what bench.py's launcher tries first for N > 1): one segment, the
+        # content render not joined in front of the all-gather
+        os.environ["NERFSIG_CAPTURE_COLLECTIVES"] = "1"
+        loop2, l2, t2 = run()
+        assert len(loop2.segments) == 1 and len(loop2.between) == 0 and loop2.sharded and loop2.content_backward_first
     finally:
         os.environ.pop("NERFSIG_FORCE_EXCHANGE", None)
+        os.environ.pop("NERFSIG_CAPTURE_COLLECTIVES", None)
         if dist.is_initialized():
             dist.destroy_process_group()
     np.testing.assert_allclose(l1, l0, rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(l2, l0, rtol=2e-3, atol=2e-4)
     assert float((t1 - t0).norm()) <= 0.05 * float((t0 - torch.cat([torch.from_numpy(cf.table(100 + l, scale=0.05)).reshape(-1) for l in range(64)]).cuda()).norm())
 
 
