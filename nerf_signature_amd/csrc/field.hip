@@ -26,6 +26,7 @@
 //   * backward needs only the input gradient of the codebook channels (all network weights are frozen,
 //     network_wtmk_tcnn.py:90-95), so the forward saves just the ReLU sign bits (6 words per point).
 #include <cstdlib>
+#include <cstring>
 #include "hashgrid.h"
 
 #include <stdlib.h>
@@ -201,6 +202,23 @@ __device__ inline void mfma_layer(const char *__restrict__ lds, size_t half_byte
 template <typename P>
 __host__ __device__ constexpr int mask_bit(int i) {
     return P::kMfmaPerProduct == 1 ? ((i & 1) ? 16 + ((i >> 4) * 8 + ((i & 15) >> 1)) : ((i >> 4) * 8 + ((i & 15) >> 1))) : i;
+}
+
+// fp16: a layer's A fragments fetched from LDS into registers in one burst, and the layer evaluated from them (see field_fwd_pipelined)
+template <int N>
+__device__ inline void load_frags(const char *__restrict__ lds, int frag0, int lane, f16x8 (&a)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) a[i] = *reinterpret_cast<const f16x8 *>(lds + (frag0 + i) * kFragBytes + lane * 16);
+}
+template <int RB, int KS>
+__device__ inline void mfma_regs(const f16x8 (&a)[RB * KS], const Half8 (&b)[KS], f32x16 (&acc)[RB]) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb * KS + ks], operand_h(b[ks].v), c, 0, 0, 0);
+        acc[rb] = c;
+    }
 }
 
 // ReLU a 64-row activation held in two accumulators, return the "was positive" bits (bit mask_bit<P>(16*rb + r)), emit the next B operand.
@@ -490,6 +508,139 @@ __device__ inline float2 codebook_half_gather(const float2 *__restrict__ S, floa
 
 // kPlanes = 0: gather the features in-kernel (fused); 1: read all 17 from the level-major planes; 2: the 16 base levels from the
 // planes, the codebook level gathered here (field_fwd_kept: points whose base planes are kept across steps).
+// The training render's forward launch (all 17 feature planes in memory, sigma + rgb + ReLU masks out), software-pipelined over a wave's tiles.
+// The plain loop -- load, evaluate, store, next tile -- spends most of a tile's ~4.9 us waiting, three times: for the planes at its head, for the
+// view directions in front of the colour branch (a load issued there drains, in order, everything requested before it), and at the head of the
+// next tile for the acknowledgement of its own stores (on gfx9 stores count in vmcnt like loads) -- with three waves per SIMD the arithmetic
+// (~0.9 us of a tile) cannot cover that.  Here every wait is for something issued a whole evaluation earlier:
+//     head of tile i:  wait for planes + directions of tile i (requested at the head of tile i-1)
+//                      -> issue the STORES of tile i-1's results (held in 7 registers) -> request planes + directions of tile i+1 -> evaluate tile i.
+template <typename P>
+__device__ inline void field_fwd_pipelined(const char *lds, int lane, const float *__restrict__ dirs, uint32_t M, bool add_codebook,
+                                           const float2 *__restrict__ planes, uint32_t stride, float *__restrict__ sigmas, float *__restrict__ rgbs,
+                                           uint32_t *__restrict__ masks) {
+    constexpr size_t kHalf = kFwdBytes;
+    const int p = lane & 31, h = lane >> 5;
+    const uint32_t n_tiles = ceil_div(M, 32u);
+    const uint32_t first = blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), step = gridDim.x * 4;
+    float2 nf[8], nc = make_float2(0.0f, 0.0f);
+    typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+    f32x3u nd = {0.0f, 0.0f, 0.0f};      // one 12-byte value across the loop: as three scalars the loaded triple is copied into their registers right behind the load -- a wait
+    auto request = [&](uint32_t tile) {
+        const uint32_t s = tile * 32 + p, sl = min(s, M - 1);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) nf[q] = planes[(size_t)(8 * (q >> 2) + (q & 3) + 4 * h) * stride + s];  // 256 contiguous bytes per half-wave
+        if (add_codebook && h) nc = planes[(size_t)NSIG_BASE_LEVELS * stride + s];
+        nd = *reinterpret_cast<const f32x3u *>(dirs + 3 * (size_t)sl);
+    };
+    if (first >= n_tiles) return;
+    request(first);
+    uint32_t ptile = 0;
+    bool have = false;
+    float psigma = 0.0f, prgb[3] = {0.0f, 0.0f, 0.0f};
+    uint32_t pmask[3] = {0u, 0u, 0u};
+    auto store_prev = [&]() {
+        const uint32_t s = ptile * 32 + p;
+        if (s < M && h == 0) {
+            sigmas[s] = psigma;
+            rgbs[3 * (size_t)s] = prgb[0]; rgbs[3 * (size_t)s + 1] = prgb[1]; rgbs[3 * (size_t)s + 2] = prgb[2];
+        }
+        uint32_t *mrow = masks + (size_t)ptile * 192 + lane;
+        mrow[0] = pmask[0]; mrow[64] = pmask[1]; mrow[128] = pmask[2];
+    };
+    for (uint32_t tile = first; tile < n_tiles; tile += step) {
+        typename P::Op feat[2];
+        if (add_codebook && h) {  // codebook added into channels 30:32 (network_wtmk_tcnn.py:106)
+            nf[7].x = nf[7].x + nc.x;
+            nf[7].y = nf[7].y + nc.y;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) P::put2(feat[q >> 2], q & 3, nf[q].x, nf[q].y);
+        float dx = nd.x, dy = nd.y, dz = nd.z;
+        // A compiler barrier that consumes this tile's inputs: the wait for them (vmcnt counts in order) is placed HERE, where only they and
+        // long-acknowledged stores are outstanding -- left free, the compiler issues the next tile's requests first and then has to drain them too.
+        if constexpr (P::kMfmaPerProduct == 1)
+            asm volatile("" : "+v"(feat[0].v[0]), "+v"(feat[0].v[1]), "+v"(feat[0].v[2]), "+v"(feat[0].v[3]), "+v"(feat[1].v[0]), "+v"(feat[1].v[1]),
+                         "+v"(feat[1].v[2]), "+v"(feat[1].v[3]), "+v"(dx), "+v"(dy), "+v"(dz) :: "memory");
+        else
+            asm volatile("" : "+v"(dx), "+v"(dy), "+v"(dz) :: "memory");
+        if (have) store_prev();
+        if (tile + step < n_tiles) request(tile + step);
+        asm volatile("" ::: "memory");
+
+        f32x16 hid[2];
+        typename P::Op b4[4];
+        f32x16 so[1];
+        if constexpr (P::kMfmaPerProduct == 1) {
+            // fp16: every layer's weight fragments are fetched from LDS as ONE burst, issued in front of the vector work that precedes the layer
+            // (the ReLU / packing of the layer before: ~260 cycles) -- fetched one by one, each right in front of its MFMA, a fragment's LDS
+            // latency (~100 cycles) was paid 24 times per tile: half of a wave's cycles were spent parked on lgkmcnt (SQ_WAIT_ANY).
+            f16x8 a0[4], a1[4];
+            load_frags(lds, F0, lane, a0);
+            load_frags(lds, F1, lane, a1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_regs<2, 2>(a0, feat, hid);
+            pmask[0] = relu_to_operand<P>(hid, b4);
+            mfma_regs<1, 4>(a1, b4, so);
+        } else {
+            mfma_layer<P, 2, 2>(lds, kHalf, F0, lane, feat, hid);
+            pmask[0] = relu_to_operand<P>(hid, b4);
+            mfma_layer<P, 1, 4>(lds, kHalf, F1, lane, b4, so);
+        }
+        psigma = expf(so[0][0]);  // trunc_exp forward (activation.py:9); row 0 of the sigma head lives in lane half 0
+        float geo8[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) geo8[r] = so[0][r];
+        if (h == 0) geo8[0] = 1.0f;  // the slot of row 0 carries the padded constant input (weight column 31)
+        if constexpr (P::kMfmaPerProduct == 1) {     // color_branch() with the fragment bursts in front of the vector work
+            f16x8 a2[4], a3[8], a4[4];
+            load_frags(lds, F2, lane, a2);
+            load_frags(lds, F3, lane, a3);
+            __builtin_amdgcn_sched_barrier(0);
+            const float ux = (dx + 1.0f) / 2.0f, uy = (dy + 1.0f) / 2.0f, uz = (dz + 1.0f) / 2.0f;   // (network_wtmk_tcnn.py:114-115)
+            float sh[16];
+            sh16(ux * 2.0f - 1.0f, uy * 2.0f - 1.0f, uz * 2.0f - 1.0f, sh);
+            typename P::Op cin[2];
+            const uint32_t hm = 0u - (uint32_t)h;     // a bit select (v_bfi): written as `h ? sh[8 + j] : sh[j]` the compiler indexes a scratch copy of sh[]
+            auto pick = [&](int j) { return __uint_as_float((__float_as_uint(sh[j]) & ~hm) | (__float_as_uint(sh[8 + j]) & hm)); };
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                P::put2(cin[0], j >> 1, pick(j), pick(j + 1));
+                P::put2(cin[1], j >> 1, geo8[j], geo8[j + 1]);
+            }
+            mfma_regs<2, 2>(a2, cin, hid);
+            load_frags(lds, F4, lane, a4);
+            __builtin_amdgcn_sched_barrier(0);
+            pmask[1] = relu_to_operand<P>(hid, b4);
+            mfma_regs<2, 4>(a3, b4, hid);
+            pmask[2] = relu_to_operand<P>(hid, b4);
+            mfma_regs<1, 4>(a4, b4, so);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) prgb[c] = 1.0f / (1.0f + expf(-so[0][c]));  // rows 0..2 live in lane half 0
+        } else {
+            uint32_t mask_c[2] = {0u, 0u};
+            color_branch<P>(lds, lane, h, dx, dy, dz, geo8, mask_c, prgb);
+            pmask[1] = mask_c[0];
+            pmask[2] = mask_c[1];
+        }
+        ptile = tile;
+        have = true;
+    }
+    store_prev();
+}
+
+// 164 registers: three waves per SIMD would fit, but the launch uses TWO workgroups per CU (field_grid(.., 2)): the kernel takes 57 us with 512, 768 or
+// 1024 workgroups (71 us for the plain loop it replaces), and the step is shortest with 512 -- the content render's kernels run beside this launch
+// (same box, three rounds: 1.051-1.063 ms against 1.064-1.070 with 768 and 1.062-1.074 with 1024).
+template <typename P>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+k_field_fwd_train(const float *__restrict__ dirs, uint32_t M, bool add_codebook, const float2 *__restrict__ planes, uint32_t stride,
+                  const char *__restrict__ packed, float *__restrict__ sigmas, float *__restrict__ rgbs, uint32_t *__restrict__ masks) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    stage_weights(lds, packed + P::kFwdOffset, (int)P::kFwdLds);
+    field_fwd_pipelined<P>(lds, threadIdx.x & 63, dirs, M, add_codebook, planes, stride, sigmas, rgbs, masks);
+}
+
 template <typename P, int kPlanes, bool kTrace = false>
 __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyzs, const float *__restrict__ dirs, uint32_t M, float bound,
                                                    TablePtrs base, LevelGeom geom, const float *__restrict__ S,
@@ -803,14 +954,18 @@ NSIG_EXPORT int mlp_pack_weights(const float *sigma_params, const float *color_p
     return check_launch("mlp_pack_weights");
 }
 
-static uint32_t field_grid(uint32_t M, bool forward = false) {
+static bool fwd_pipelined() {     // NERFSIG_FWD_PIPELINE=0: the plain loop (k_field_fwd<F16, 1>) for the training render's forward as well
+    static const bool v = !(getenv("NERFSIG_FWD_PIPELINE") && !strcmp(getenv("NERFSIG_FWD_PIPELINE"), "0"));
+    return v;
+}
+static uint32_t field_grid(uint32_t M, bool forward = false, uint32_t per_cu = 0) {
     const uint32_t blocks = ceil_div(ceil_div(ceil_div(M, 32u), 4u), 8u) * 8u;   // a multiple of 8: k_field_bwd's XCD-aware tile order
     // persistent workgroups (the packed weights are staged once per workgroup): 3 per CU fit the LDS budget.  Same-box sweeps
     // (profiles/r01_k_field_grid_sweep.txt): the backward is fastest with exactly the resident 768 (113-117 us; 128 with 512 or 1024),
     // the forward with 512 or 1024 (117-120 us against 124-125 with 768) and the step with 1024 (1.118-1.123 ms against 1.132-1.133).
     static const uint32_t cap_f = getenv("NERFSIG_FIELD_FWD_WGS") ? (uint32_t)atoi(getenv("NERFSIG_FIELD_FWD_WGS")) : (uint32_t)(kCUs * 4);
     static const uint32_t cap_b = getenv("NERFSIG_FIELD_BWD_WGS") ? (uint32_t)atoi(getenv("NERFSIG_FIELD_BWD_WGS")) : (uint32_t)(kCUs * 3);
-    const uint32_t cap = forward ? cap_f : cap_b;
+    const uint32_t cap = per_cu ? (getenv("NERFSIG_FIELD_FWD_WGS") ? cap_f : (uint32_t)kCUs * per_cu) : (forward ? cap_f : cap_b);
     return blocks < cap ? blocks : cap;
 }
 
@@ -955,6 +1110,10 @@ NSIG_EXPORT int field_fwd(const float *xyzs, const float *dirs, uint32_t M, floa
     NSIG_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 7) == 0, "field_fwd: planes must be 8-byte aligned");
     const uint32_t stride = ceil_div(M, 32u) * 32u;
     const float2 *pl = reinterpret_cast<const float2 *>(planes);
+    if (f16 && fwd_pipelined() && dirs != nullptr && rgbs != nullptr && masks != nullptr && geo_feat == nullptr) {    // the training render's launch
+        k_field_fwd_train<F16><<<field_grid(M, true, 2), 256, F16::kFwdLds, st>>>(dirs, M, S != nullptr, pl, stride, pk, sigmas, rgbs, masks);
+        return check_launch("field_fwd");
+    }
     if (f16) k_field_fwd<F16, 1><<<field_grid(M, true), 256, F16::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, geo_feat, masks);
     else k_field_fwd<Bf16x3, 1><<<field_grid(M, true), 256, Bf16x3::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, geo_feat, masks);
     return check_launch("field_fwd");
