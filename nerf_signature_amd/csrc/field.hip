@@ -923,6 +923,156 @@ __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyz
     }
 }
 
+// The training render's backward launch (planned scatter: gradients written straight into the slice-sorted queue), software-pipelined over a wave's
+// tiles like field_fwd_pipelined: at the head of tile i the wave waits for tile i's inputs (requested at the head of tile i-1), computes and stores
+// tile i-1's two queue entries per lane (held back as 7 registers: position, the two gradients, the two queue slots), requests tile i+1's inputs, and
+// only then evaluates tile i.  The plain loop waited three times per tile -- for the inputs at its head, for the position in front of the queue
+// entries, and at the next head for the acknowledgement of its own stores: 72 % of a wave's cycles parked (SQ_WAIT_ANY) at six waves per SIMD.
+template <typename P>
+__device__ inline void field_bwd_pipelined(const char *lds, int lane, const float *__restrict__ xyzs, uint32_t M, float bound,
+                                           const float *__restrict__ g_sigma, const float *__restrict__ g_rgb, const float *__restrict__ sigmas,
+                                           const float *__restrict__ rgbs, const uint32_t *__restrict__ masks, ScatterPlan plan) {
+    constexpr size_t kHalf = kBwdBytes;
+    constexpr bool kNormalise = P::kMfmaPerProduct == 1;
+    const int p = lane & 31, h = lane >> 5;
+    const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t n_tiles = ceil_div(M, 32u);
+    const float e_lo = expf(-15.0f), e_hi = expf(15.0f), two_b = 2.0f * bound;
+    uint32_t gbits = 0;   // running max |gradient| of this lane's points, as a bit pattern
+    // tile order: see k_field_bwd (a 1024-point chunk is handled by 8 workgroups of one XCD at the same time)
+    const uint32_t xcd = blockIdx.x & 7u, per_xcd = gridDim.x >> 3, n_chunks = ceil_div(n_tiles, 32u);
+    uint32_t lq = blockIdx.x >> 3;
+    auto next_tile = [&]() -> uint32_t {      // the wave's next tile, or ~0u when it has none left
+        for (;; lq += per_xcd) {
+            const uint32_t chunk = (lq >> 3) * 8u + xcd;
+            if (chunk >= n_chunks) return ~0u;
+            const uint32_t tile = (chunk * 8u + (lq & 7u)) * 4u + wid;
+            if (tile < n_tiles) {
+                lq += per_xcd;
+                return tile;
+            }
+        }
+    };
+    typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+    // requested inputs of the next tile (one value per load instruction: see field_fwd_pipelined on loop-carried triples)
+    uint32_t n_mask[3] = {0u, 0u, 0u};
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 n_dst = {0u, 0u, 0u, 0u};
+    f32x3u n_rgb = {0.0f, 0.0f, 0.0f}, n_grgb = {0.0f, 0.0f, 0.0f}, n_xyz = {0.0f, 0.0f, 0.0f};
+    float n_gs = 0.0f, n_sig = 0.0f;
+    auto request = [&](uint32_t tile) {
+        const uint32_t s = tile * 32 + p, sl = min(s, M - 1);
+        const uint32_t *mrow = masks + (size_t)tile * 192 + lane;
+        n_mask[0] = mrow[0]; n_mask[1] = mrow[64]; n_mask[2] = mrow[128];
+        n_dst = *reinterpret_cast<const u32x4 *>(plan.dest + sl);
+        n_rgb = *reinterpret_cast<const f32x3u *>(rgbs + 3 * (size_t)sl);
+        n_grgb = *reinterpret_cast<const f32x3u *>(g_rgb + 3 * (size_t)sl);
+        n_xyz = *reinterpret_cast<const f32x3u *>(xyzs + 3 * (size_t)sl);
+        n_gs = g_sigma[sl];
+        n_sig = sigmas[sl];
+    };
+    // results of the previous tile, not stored yet
+    bool have = false;
+    float p_x = 0.0f, p_y = 0.0f, p_z = 0.0f, p_g0 = 0.0f, p_g1 = 0.0f;
+    uint32_t p_d0 = 0u, p_d1 = 0u;
+    bool p_live = false;
+    auto store_prev = [&]() {
+        if (!p_live) return;
+        // The entries' places in the slice-sorted queue were fixed from the positions alone (hg_scatter_plan): lane half h
+        // writes the two (dy, dz) pairs with dy = h.  Nothing else stands between this kernel and the slice owners.
+        uint32_t ix, iy, iz;
+        float wx, wy, wz;
+        codebook_axis((p_x + bound) / two_b, ix, wx);
+        codebook_axis((p_y + bound) / two_b, iy, wy);
+        codebook_axis((p_z + bound) / two_b, iz, wz);
+        const uint32_t q0 = 2u * (uint32_t)h;
+        plan.queue[p_d0] = pair_entry(ix, pair_hash(iy, iz, q0), wx, wy, wz, p_g0, p_g1, q0);
+        plan.queue[p_d1] = pair_entry(ix, pair_hash(iy, iz, q0 + 1u), wx, wy, wz, p_g0, p_g1, q0 + 1u);
+        gbits = max(gbits, max(__float_as_uint(p_g0) & 0x7fffffffu, __float_as_uint(p_g1) & 0x7fffffffu));   // |x| as bit patterns: ordered like the values, NaN above +inf
+    };
+    uint32_t tile = next_tile();
+    if (tile != ~0u) request(tile);
+    while (tile != ~0u) {
+        const uint32_t s = tile * 32 + p;
+        const bool live = s < M;
+        // consume the inputs: d(pre-sigmoid color) -- only lane half 0, elements 0..2 of the 16-wide K-step are non-zero -- and
+        // d log-density = g * exp(clamp(h0, -15, 15)) (activation.py:14), with exp(h0) = sigma: enters at the sigma head, row 0 (half 0)
+        float dv[3] = {0.0f, 0.0f, 0.0f}, head0 = 0.0f;
+        if (h == 0 && live) {
+            dv[0] = n_grgb.x * (n_rgb.x * (1.0f - n_rgb.x));
+            dv[1] = n_grgb.y * (n_rgb.y * (1.0f - n_rgb.y));
+            dv[2] = n_grgb.z * (n_rgb.z * (1.0f - n_rgb.z));
+            head0 = n_gs * fminf(fmaxf(n_sig, e_lo), e_hi);
+        }
+        uint32_t mask_s = n_mask[0], mask_c0 = n_mask[1], mask_c1 = n_mask[2];
+        uint32_t d0 = h ? n_dst.z : n_dst.x, d1 = h ? n_dst.w : n_dst.y;
+        float cx = n_xyz.x, cy = n_xyz.y, cz = n_xyz.z;
+        // compiler barrier that consumes the inputs: the wait for them stands here, in front of the stores and requests below
+        asm volatile("" : "+v"(dv[0]), "+v"(dv[1]), "+v"(dv[2]), "+v"(head0), "+v"(mask_s), "+v"(mask_c0), "+v"(mask_c1), "+v"(d0), "+v"(d1),
+                     "+v"(cx), "+v"(cy), "+v"(cz) :: "memory");
+        if (have) store_prev();
+        const uint32_t upcoming = next_tile();
+        if (upcoming != ~0u) request(upcoming);
+        asm volatile("" ::: "memory");
+
+        float unscale = 1.0f;
+        if (kNormalise) {    // (see k_field_bwd: the upstream gradient scaled into [1, 2) by a power of two, the result scaled back)
+            float amp = fmaxf(fmaxf(fabsf(dv[0]), fabsf(dv[1])), fmaxf(fabsf(dv[2]), fabsf(head0)));   // (half 1 holds zeros)
+            amp = fmaxf(amp, __shfl_xor(amp, 32, 64));
+            const uint32_t e = (__float_as_uint(amp) >> 23) & 0xffu;
+            if (e >= 1u && e <= 253u) {          // zero, subnormal and non-finite amplitudes pass through unscaled
+                const float sc = __uint_as_float((254u - e) << 23);
+                unscale = __uint_as_float(e << 23);
+                dv[0] *= sc; dv[1] *= sc; dv[2] *= sc; head0 *= sc;
+            }
+        }
+        typename P::Op dout[1];
+        P::put2(dout[0], 0, dv[0], dv[1]);
+        P::put2(dout[0], 1, dv[2], 0.0f);
+        P::put2(dout[0], 2, 0.0f, 0.0f);
+        P::put2(dout[0], 3, 0.0f, 0.0f);
+        f32x16 hid[2];
+        typename P::Op b4[4];
+        mfma_layer<P, 2, 1>(lds, kHalf, B0, lane, dout, hid);
+        mask_to_operand<P>(hid, mask_c1, b4);
+        mfma_layer<P, 2, 4>(lds, kHalf, B1, lane, b4, hid);
+        mask_to_operand<P>(hid, mask_c0, b4);
+        f32x16 dso[1];
+        mfma_layer<P, 1, 4>(lds, kHalf, B2, lane, b4, dso);  // rows 1..15 = d geo_feat
+        typename P::Op dhead[1];
+        float head8[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) head8[r] = dso[0][r];
+        if (h == 0) head8[0] = head0;  // row 0: d log-density
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) P::put2(dhead[0], r >> 1, head8[r], head8[r + 1]);
+        mfma_layer<P, 2, 1>(lds, kHalf, B3, lane, dhead, hid);
+        mask_to_operand<P>(hid, mask_s, b4);
+        f32x16 dfe[1];
+        mfma_layer<P, 1, 4>(lds, kHalf, B4, lane, b4, dfe);  // rows 0,1 (lane half 0) = d feature[30], d feature[31]
+        // both halves of a point share the scatter: half h handles corners 4h..4h+3
+        p_g0 = __shfl(dfe[0][0], p, 64) * unscale;
+        p_g1 = __shfl(dfe[0][1], p, 64) * unscale;
+        p_x = cx; p_y = cy; p_z = cz; p_d0 = d0; p_d1 = d1; p_live = live;
+        have = true;
+        tile = upcoming;
+    }
+    if (have) store_prev();
+    // the owners' fixed-point scale comes from the launch's largest |gradient|
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) gbits = max(gbits, (uint32_t)__shfl_xor((int)gbits, d, 64));
+    if (lane == 0 && gbits > __hip_atomic_load(&plan.hd->gmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&plan.hd->gmax_bits, gbits);
+}
+
+template <typename P>
+__global__ void __launch_bounds__(256) k_field_bwd_train(const float *__restrict__ xyzs, uint32_t M, float bound, const float *__restrict__ g_sigma,
+                                                         const float *__restrict__ g_rgb, const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                                         const uint32_t *__restrict__ masks, const char *__restrict__ packed, ScatterPlan plan) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    stage_weights(lds, packed + P::kBwdOffset, (int)P::kBwdLds);
+    field_bwd_pipelined<P>(lds, threadIdx.x & 63, xyzs, M, bound, g_sigma, g_rgb, sigmas, rgbs, masks, plan);
+}
+
 }  // namespace nsig
 
 using namespace nsig;
@@ -956,6 +1106,10 @@ NSIG_EXPORT int mlp_pack_weights(const float *sigma_params, const float *color_p
 
 static bool fwd_pipelined() {     // NERFSIG_FWD_PIPELINE=0: the plain loop (k_field_fwd<F16, 1>) for the training render's forward as well
     static const bool v = !(getenv("NERFSIG_FWD_PIPELINE") && !strcmp(getenv("NERFSIG_FWD_PIPELINE"), "0"));
+    return v;
+}
+static bool bwd_pipelined() {     // NERFSIG_BWD_PIPELINE=0: the plain loop (k_field_bwd<F16>) for the training render's planned backward as well
+    static const bool v = !(getenv("NERFSIG_BWD_PIPELINE") && !strcmp(getenv("NERFSIG_BWD_PIPELINE"), "0"));
     return v;
 }
 static uint32_t field_grid(uint32_t M, bool forward = false, uint32_t per_cu = 0) {
@@ -1169,7 +1323,10 @@ NSIG_EXPORT int field_bwd_planned(const float *xyzs, uint32_t M, float bound, co
     if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(xyzs && grad_sigmas && grad_rgbs && sigmas && rgbs && masks && packed && plan, "field_bwd_planned: null pointer");
     NSIG_REQUIRE(bound > 0.0f && (reinterpret_cast<uintptr_t>(plan) & 15) == 0 && M < (1u << 28), "field_bwd_planned: bound must be positive, plan 16-byte aligned, M < 2^28");
-    if (mlp_precision() == 1)
+    if (mlp_precision() == 1 && bwd_pipelined())
+        k_field_bwd_train<F16><<<field_grid(M), 256, F16::kBwdLds, as_stream(stream)>>>(xyzs, M, bound, grad_sigmas, grad_rgbs, sigmas, rgbs, masks,
+                                                                                reinterpret_cast<const char *>(packed), scatter_plan_view(plan, M));
+    else if (mlp_precision() == 1)
         k_field_bwd<F16, false><<<field_grid(M), 256, F16::kBwdLds, as_stream(stream)>>>(xyzs, M, bound, 1.0f / kCodebookResolution, grad_sigmas, grad_rgbs, sigmas, rgbs, masks,
                                                                                  reinterpret_cast<const char *>(packed), nullptr, nullptr, nullptr, GradTrace{}, 0,
                                                                                  scatter_plan_view(plan, M));

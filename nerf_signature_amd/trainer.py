@@ -403,13 +403,15 @@ class GraphedWatermarkLoop:
         self.side_stream = torch.cuda.Stream(priority=int(os.environ.get("NERFSIG_SIDE_PRIORITY", "0"))) if overlap_content else None
         self.plan_stream = self.side_stream   # scatter plans queue behind the content render
         # The decoder's parameter-gradient kernels (~85 us, needed only by the optimiser) leave the main stream, so that the block render's backward
-        # waits for the image gradient alone.  Two schedules of the backward pass (decided in prepare(), once the block shard is known):
-        #   "tail"   (one rank): they queue on the content render's stream and the content render's backward behind them, at the step's tail, beside
-        #            the block render's MLP backward and scatter, which are long enough to cover both;
-        #   "beside" (blocks sharded over ranks: every kernel of a render is short): a stream of their own, and the content render's backward issued
-        #            first (backward_from_loss_kernel) -- it runs beside the decoder's backward chain.  Emulated rank of 2 / 4 / 8: 0.866 -> 0.845,
-        #            0.645 -> 0.605, 0.566 -> 0.530 ms per step; one rank: no gain (the decoder's chain slows down by what the content kernels
-        #            take).  profiles/r03_backward_schedule.txt.  NERFSIG_BACKWARD_SCHEDULE=tail|beside overrides.
+        # waits for the image gradient alone.  Two schedules of the backward pass (NERFSIG_BACKWARD_SCHEDULE=tail|beside):
+        #   "tail"   they queue on the content render's stream and the content render's backward behind them (one autograd call runs its nodes
+        #            last), at the step's tail, beside the block render's MLP backward and scatter;
+        #   "beside" (default) a stream of their own, the content render's backward issued first (backward_from_loss_kernel) -- it runs beside the
+        #            decoder's backward chain -- and the block render captured first (_blocks_issued_first).
+        # Round 3, before the MLP kernels were pipelined: "beside" paid only with the blocks sharded over ranks (emulated rank of 2 / 4 / 8:
+        # 0.866 -> 0.845, 0.645 -> 0.605, 0.566 -> 0.530 ms per step; one rank: +1.5 %, the block render's 95 us MLP backward covered the tail).
+        # With k_field_bwd_train (71 us) the content render's backward at the tail became the step's end: one rank 1.055-1.058 -> 1.023-1.042 ms.
+        # profiles/r03_backward_schedule.txt.
         self.backward_schedule = os.environ.get("NERFSIG_BACKWARD_SCHEDULE", "auto")
         self.weights_stream = self.side_stream
         self.content_backward_first = False
@@ -619,12 +621,13 @@ class GraphedWatermarkLoop:
         return (a, b) if self._blocks_issued_first() else (b, a)     # issue order: with a side stream the content render comes first
 
     def _blocks_issued_first(self):
-        """Which render train_step issues (and a capture records) first.  One rank: the content render, on its side stream.  Blocks sharded over
-        ranks ("beside" schedule): the block render.  With its default packet capture this runtime starts a node whose parent sits on another of
+        """Which render train_step issues (and a capture records) first: the block render ("beside" schedule) or the content render, on its side
+        stream ("tail").  With its default packet capture this runtime starts a node whose parent sits on another of
         the graph's internal streams only when that stream has finished the whole run of nodes it was handed in one piece (tools/graph_dot.py,
         profiles/r03_graph_capture_order.txt): captured behind the content render's nine short kernels, the block render -- and the all-gather and
         the decoder behind it -- started when all nine were done; captured first, it is the content render that waits (for the decoder's forward
-        chain, beside whose backward chain it then runs): emulated rank of 2 / 4 / 8: 0.846 -> 0.828, 0.610 -> 0.605, 0.534 -> 0.527 ms."""
+        chain, beside whose backward chain it then runs): emulated rank of 2 / 4 / 8: 0.846 -> 0.828, 0.610 -> 0.605, 0.534 -> 0.527 ms; one rank
+        (where the wait keeps the content render's encoder away from the block render's): 1.050-1.068 -> 1.025-1.045 ms."""
         return self.side_stream is None or (self.content_backward_first and os.environ.get("NERFSIG_BLOCKS_FIRST", "1") == "1")
 
     def _kept_inputs_key(self):
@@ -711,7 +714,7 @@ class GraphedWatermarkLoop:
         self.exchange.shared_scale = 1.0 if self.sharded else None
         self.opt_shard = dp.optimizer_shard(model.message_dim) if self.sharded else None
         model.codebook_shard = self.opt_shard
-        beside = self.side_stream is not None and (self.backward_schedule == "beside" or (self.backward_schedule == "auto" and self.sharded))
+        beside = self.side_stream is not None and self.backward_schedule != "tail"
         self.content_backward_first = beside
         self.weights_stream = self.side_stream if not beside else (getattr(self, "_own_weights_stream", None) or torch.cuda.Stream())
         self._own_weights_stream = self.weights_stream if beside else None
