@@ -337,8 +337,7 @@ class NativeTimer:
 
     def __init__(self, nv):
         self.nv, self.orig, self.enabled = nv, nv.call, False
-        self.alone = False      # drain the device in front of every timed launch: the events then bracket the kernel ALONE (the eager pass behind a
-                                # captured run; never inside a timed region) -- the step's streams otherwise run other kernels beside it
+
         self.events = {k: [] for k in self.POINTS_ARG}
         nv.call = self
 
@@ -346,8 +345,6 @@ class NativeTimer:
         if not (self.enabled and name in self.events):
             return self.orig(name, *args)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        if self.alone:
-            torch.cuda.synchronize()
         e0.record()
         self.orig(name, *args)
         e1.record()
@@ -626,7 +623,13 @@ def bench_training(args, scene, real_stdout, secondary=None):
 
     if not args.no_graph:
         # the same kernels, launched eagerly so that HIP events can bracket them (live, same process, same inputs)
-        timer.enabled = timer.alone = True
+        # ... on ONE stream, back to back: the events then bracket each kernel alone, with the device busy before and after it.  (With the
+        # step's streams the content render's kernels run beside the block render's: the MLP forward read 65 us instead of 57.  Draining the
+        # device in front of each timed launch instead reads the encoder 10 % SLOWER, 284 us against 258: it starts on an idle device.)
+        streams = (loop.side_stream, loop.plan_stream, loop.weights_stream, loop.content_backward_first)
+        loop.side_stream = loop.plan_stream = loop.weights_stream = None
+        loop.content_backward_first = False
+        timer.enabled = True
         for _ in range(5):
             optimizer.zero_grad(set_to_none=True)
             loop._forward_backward()
@@ -637,7 +640,8 @@ def bench_training(args, scene, real_stdout, secondary=None):
             else:
                 loop._optimise_and_march()
         torch.cuda.synchronize()
-        timer.enabled = timer.alone = False
+        timer.enabled = False
+        loop.side_stream, loop.plan_stream, loop.weights_stream, loop.content_backward_first = streams
 
     if args.no_graph:
         n_block, n_content = int(model.step_counter[(model.local_step - 2) % 16, 0]), int(model.step_counter[(model.local_step - 1) % 16, 0])
@@ -784,7 +788,7 @@ def bench_training(args, scene, real_stdout, secondary=None):
                       "head of the step, k_encode_codebook_plane: 64 B/point, timed below)" if split_encoder else
                       "bytes of the IMPLEMENTED algorithm: 16 base levels + the pre-summed codebook level, 8 corners x 8 B (DESIGN.md sections 2 and 6)"),
             "codebook_level_launch_s": timer.stats("hg_encode_codebook_plane", big)[0] if split_encoder else None,
-            "scheduling": ("this launch encodes the NEXT step's block samples beside this step's optimiser (encode-ahead); timed here alone, eagerly" if getattr(loop, "encode_ahead", False) else "head of the step") + "; timed alone (device drained in front of each of the 5 eager launches)",
+            "scheduling": ("this launch encodes the NEXT step's block samples beside this step's optimiser (encode-ahead); timed here alone, eagerly" if getattr(loop, "encode_ahead", False) else "head of the step") + "; timed in 5 eager steps issued on one stream (no kernel beside it)",
             "observed_limiter": "not HBM: the working set (64 MiB base + 4 MiB pre-sum) is L2/MALL-resident; PMC shows the texture-address path busy ~85 % and "
                                 "the L2->L1 line fills (~4 GB per launch) as the limiter (profiles/*pmc_encode*)",
             "frac_hbm_counters": (traffic / enc_s / HBM_PEAK) if (traffic and enc_s > 0) else None,
