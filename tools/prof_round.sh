@@ -34,5 +34,5 @@ if len(seq) >= 34:
     eager = seq[29:34]
     print(f"#   eager launches {eager}: avg {sum(eager) / 5:.1f} us  (compare roofline.avg_launch_s of the bench line of the same box)")
 PY
-python tools/timeline.py $out k_adam_prepare 8 > gpurun_out/${tag}_timeline_graph_replay.txt
+python tools/timeline.py $out k_adam_prepare ${TL_BACK:-8} > gpurun_out/${tag}_timeline_graph_replay.txt
 cp $(ls $out/*/*_kernel_stats.csv | tail -1) gpurun_out/${tag}_kernel_stats.csv
