@@ -275,6 +275,12 @@ size_t hg_planes_bytes(uint32_t M);
 int hg_encode_planes(const float *xyzs, uint32_t M, float bound, const float *const *base_tables_host, const float *S,
                      void *planes, nsig_stream_t stream);
 
+/* Reads the 16 base tables (and S when given) once, each through the XCD whose workgroups will gather from it in hg_encode_planes, so that
+ * the launch finds its tables in L2 instead of starting on caches a streaming pass (the optimiser's) has flushed: the bench workload's block
+ * launch 282 -> 258 us; the pass itself takes ~20 us alone -- it pays where it can run beside something else (trainer.GraphedWatermarkLoop).
+ * Replaces nothing in the reference (a scheduling aid); sink: one writable float, never written. */
+int hg_warm_tables(const float *const *base_tables_host, const float *S, float *sink, nsig_stream_t stream);
+
 /* Rays that do not change between training steps (the watermark blocks: nerf/provider_wtmk.py:442-494 computes
  * rays_o_block / rays_d_block once per dataset and hands the same tensors to every train_step, utils_wtmk_disen.py:588-590;
  * the occupancy grid, the base tables and both MLPs are frozen in the watermark stage, network_wtmk_tcnn.py:90-95) keep their

@@ -57,6 +57,7 @@ SIGNATURES = {
     "mlp_pack_weights": [_vp, _vp, _vp, _vp],
     "hg_planes_bytes": [_u32],
     "hg_encode_planes": [_vp, _u32, _fl, _vp, _vp, _vp, _vp],
+    "hg_warm_tables": [_vp, _vp, _vp, _vp],
     "hg_encode_codebook_plane": [_vp, _u32, _fl, _vp, _vp, _vp, _vp],
     "field_fwd_kept": [_vp, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "field_fwd": [_vp, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -439,6 +439,22 @@ __device__ inline void encode_tile_level(const float2 *__restrict__ table, float
     __builtin_nontemporal_store(vv, reinterpret_cast<f32x2_t *>(out));
 }
 
+// Reads the tables of a slot through that slot's XCD (blockIdx % 8): its L2 then holds the slot's fine table when the encoder starts.
+__global__ void __launch_bounds__(256) k_warm_tables(TablePtrs base, const float *__restrict__ S, SlotTable tab, float *__restrict__ sink) {
+    const uint32_t slot = blockIdx.x & 7u, wg = blockIdx.x >> 3, n_wg = gridDim.x >> 3;
+    float acc = 0.0f;
+    for (int i = 0; i < tab.n[slot]; ++i) {
+        const int l = tab.level[slot][i];
+        const float4 *t = reinterpret_cast<const float4 *>(l == NSIG_BASE_LEVELS ? S : base.p[l]);
+        if (t == nullptr) continue;
+        for (uint32_t e = wg * 256 + threadIdx.x; e < NSIG_TABLE_ROWS / 2; e += n_wg * 256) {
+            const float4 v = t[e];
+            acc += v.x + v.y + v.z + v.w;
+        }
+    }
+    if (acc == 1.2345e-33f) *sink = acc;      // (never: keeps the loads)
+}
+
 // Workgroup (tile, slot) encodes, for its 256 points, the levels (or the part of a level's tile range) assigned to its XCD slot.
 __global__ void __launch_bounds__(256) k_encode_planes(const float *__restrict__ xyzs, uint32_t M, float bound, TablePtrs base, LevelGeom geom,
                                                        const float *__restrict__ S, float2 *__restrict__ planes, uint32_t stride, SlotTable tab) {
@@ -1200,6 +1216,14 @@ static SlotTable default_slots(bool with_codebook) {
         }
     }
     return t;
+}
+
+NSIG_EXPORT int hg_warm_tables(const float *const *base_tables_host, const float *S, float *sink, nsig_stream_t stream) {
+    NSIG_REQUIRE(sink != nullptr, "hg_warm_tables: sink is one writable float (never written)");
+    TablePtrs base{};
+    if (int e = fill_base_tables(base_tables_host, base, "hg_warm_tables")) return e;
+    k_warm_tables<<<8 * 128, 256, 0, as_stream(stream)>>>(base, S, default_slots(S != nullptr), sink);
+    return check_launch("hg_warm_tables");
 }
 
 NSIG_EXPORT size_t hg_planes_bytes(uint32_t M) { return (size_t)(NSIG_BASE_LEVELS + 1) * ceil_div(M, 32u) * 32u * sizeof(float2); }

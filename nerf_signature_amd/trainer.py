@@ -428,6 +428,7 @@ class GraphedWatermarkLoop:
         self.content_headroom = headroom if content_headroom is None else content_headroom
         dev = next(model.parameters()).device
         self.device = dev
+        self._warm_sink = torch.zeros(1, dtype=torch.float32, device=dev)      # (hg_warm_tables: never written)
         D = model.message_dim
         # G and (behind it) room for the decoder's flat gradient block in one allocation: one all-reduce per step (dp.GradExchange)
         self.sink = fo.GradSink(dev, tail=sum(p.numel() for p in model.msg_decoder.parameters()))
@@ -603,13 +604,25 @@ class GraphedWatermarkLoop:
             self.side_stream.wait_stream(main)      # both backward passes of this step are done with the buffers
             with torch.cuda.stream(self.side_stream):
                 self._march_ahead()
+                self._warm_tables()
         post = self._optimise(defer_collective=True)
         if self.side_stream is not None:
             main.wait_stream(self.side_stream)
         else:
             self._march_ahead()
+            self._warm_tables()
         if post is not None:
             post()                                  # (a collective: only after the streams have joined)
+
+    def _warm_tables(self):
+        """The frozen base tables read once, each through the XCD that will gather from it (hg_warm_tables), behind the march of the next step's
+        block samples and beside the optimiser: the next step's block encoder -- the step's longest kernel, at its head -- otherwise starts on
+        caches the optimiser's 836 MiB stream has flushed (282-290 us; 258-270 us behind this pass, which takes ~20 us alone).  Same-box A/B of
+        the bench step: 1.026-1.031 -> 1.005-1.019 ms (profiles/r03_warm_tables.txt).  NERFSIG_WARM_TABLES=0 switches it off."""
+        if os.environ.get("NERFSIG_WARM_TABLES", "1") != "1" or self.fixed_blocks or getattr(self.model, "_presum_cache", None) is None:
+            return
+        tables = nv.ptr_array([t.detach() for t in self.model.encoder.tables()])
+        nv.call("hg_warm_tables", tables, nv.ptr(self.model._presum_cache[1]), nv.ptr(self._warm_sink), nv.stream())
 
     def point_counts(self):
         """(block, content) sample totals of the last step (one host read)."""
