@@ -618,8 +618,11 @@ class GraphedWatermarkLoop:
         """The frozen base tables read once, each through the XCD that will gather from it (hg_warm_tables), behind the march of the next step's
         block samples and beside the optimiser: the next step's block encoder -- the step's longest kernel, at its head -- otherwise starts on
         caches the optimiser's 836 MiB stream has flushed (282-290 us; 258-270 us behind this pass, which takes ~20 us alone).  Same-box A/B of
-        the bench step: 1.026-1.031 -> 1.005-1.019 ms (profiles/r03_warm_tables.txt).  NERFSIG_WARM_TABLES=0 switches it off."""
-        if os.environ.get("NERFSIG_WARM_TABLES", "1") != "1" or self.fixed_blocks or getattr(self.model, "_presum_cache", None) is None:
+        the bench step: 1.026-1.031 -> 1.005-1.019 ms (profiles/r03_warm_tables.txt).  Only where the optimiser outlasts it: with the codebook
+        optimiser sharded over >= 4 ranks (a 22 us pass over D/R tables) the warm-up would end the step (emulated rank of 4 / 8: +1.5 / +2 %).
+        NERFSIG_WARM_TABLES=0|1 forces it off / on."""
+        want = os.environ.get("NERFSIG_WARM_TABLES")
+        if want == "0" or (want != "1" and self.opt_shard is not None) or self.fixed_blocks or getattr(self.model, "_presum_cache", None) is None:
             return
         tables = nv.ptr_array([t.detach() for t in self.model.encoder.tables()])
         nv.call("hg_warm_tables", tables, nv.ptr(self.model._presum_cache[1]), nv.ptr(self._warm_sink), nv.stream())
