@@ -105,7 +105,7 @@ def srgb_to_linear(x):
 
 
 def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce, side_stream=None, presum_first=False,
-               presum_adopt=False, color_space="srgb", blocks_first=False):
+               presum_adopt=False, color_space="srgb", blocks_first=False, content_backward_now=None):
     """data = {'watermark': {'rays_o_block', 'rays_d_block'}, 'content': {'rays_o', 'rays_d', 'images'}}.
     Returns (pred_rgb, gt_rgb, content_pred_rgb, lossi, lossw, loss) like the reference.
 
@@ -135,10 +135,24 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
             content_pred_rgb.record_stream(main)
     block_o, block_d, shard = local_blocks(wm)
     outputs = model.render(block_o, block_d, message, **kw)
+    content_done = early_seed = None
+    new_segment = False       # (a collective in front of the decoder ended the running capture segment: the side stream has to be forked again)
     if main is not None and blocks_first:
         # (the fork above is the content render's only parent; captured BEHIND the block render it is enqueued behind it: GraphedWatermarkLoop)
         with torch.cuda.stream(side_stream):
             content_pred_rgb = model.render(content["rays_o"], content["rays_d"], message, **kw)["image"]
+            if content_backward_now is not None and color_space == "srgb" and content["images"].shape == content_pred_rgb.shape \
+                    and content_pred_rgb.requires_grad:
+                # content_backward_now = the scale of the image loss's seed (lambda_i x the data-parallel factor).  d(mean((c - gt)^2))/dc needs
+                # nothing of the block render or the decoder, so the content render's backward follows its forward directly, on its stream: one chain
+                # from the march to the scatter, no fork at the loss kernel (which then has ONE child, the decoder's backward: it stays on the
+                # loss kernel's queue instead of hopping to another one, ~10 us of queue work on this runtime).  The loss kernel below still
+                # computes the same MSE for the returned value, from the detached prediction; the seed is the same number it would leave.
+                content_done = torch.cuda.Event()
+                content_done.record(side_stream)      # what the loss kernel waits for: the forward, not the backward behind it
+                early_seed = (content_pred_rgb.detach() - content["images"]) * (2.0 / content_pred_rgb.numel())
+                if float(content_backward_now) != 1.0:
+                    early_seed = early_seed * float(content_backward_now)
         content_pred_rgb.record_stream(main)
     if main is not None:
         fo.flush_plans()          # the block render's scatter plan: on the plan stream, behind the content render
@@ -150,6 +164,7 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
         # beside the decoder.
         if main is not None and dp.collective_ends_segment():
             main.wait_stream(side_stream)
+            new_segment = True
         image = dp.gather_blocks(image, wm["rays_o_block"].shape[0], shard[0])
     if model.normalization is normalize_img and hasattr(model.msg_decoder, "decode_rendered"):
         decoded, pred_rgb = model.msg_decoder.decode_rendered(image)    # clamp + permute + normalise inside layer 0
@@ -164,7 +179,17 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
         raise NotImplementedError("RGBA ground truth: the reference's train_step raises UnboundLocalError here (bg_color is only assigned for 3-channel images, "
                                   "utils_wtmk_disen.py:585-590); blend the alpha channel into the images before the step")
     gt_rgb = content["images"]
-    if main is not None:
+    if main is not None and content_done is not None:
+        # issued HERE, behind the decoder's forward launches: this runtime signals another queue only at the end of the run of launches a queue was
+        # handed in one piece -- issued right behind the content render's forward, the loss kernel would wait for this backward as well
+        if new_segment:
+            side_stream.wait_stream(main)
+        with torch.cuda.stream(side_stream):
+            torch.autograd.backward([content_pred_rgb], [early_seed])
+        content_pred_rgb = content_pred_rgb.detach()
+        if not new_segment:       # (both streams met in front of the collective; the event belongs to the finished segment)
+            main.wait_event(content_done)
+    elif main is not None:
         main.wait_stream(side_stream)
     else:
         content_pred_rgb = model.render(content["rays_o"], content["rays_d"], message, **kw)["image"]
@@ -526,7 +551,9 @@ class GraphedWatermarkLoop:
             out = train_step(self.model, self.data, self.msg_dev, self.render_kwargs, self.lambda_w, self.lambda_i, side_stream=self.side_stream,
                              presum_first=self.marched is not None,
                              presum_adopt=self.presum_in_adam and torch.cuda.is_current_stream_capturing(),
-                             blocks_first=self.side_stream is not None and self._blocks_issued_first())
+                             blocks_first=self.side_stream is not None and self._blocks_issued_first(),
+                             content_backward_now=(self.lambda_i * dp.content_grad_scale(self.sharded)) if (self.content_backward_first and
+                                                   self.side_stream is not None and os.environ.get("NERFSIG_CONTENT_BWD_NOW", "1") == "1") else None)
         finally:
             fo.set_plan_stream(prev)
         set_weights_stream(self.weights_stream)

@@ -18,6 +18,18 @@ __global__ void spin(unsigned long long *stamps, int id, int us) {
     if (threadIdx.x == 0) stamps[2 * id + 1] = wall_clock64();
 }
 
+// replay-boundary probe: every replay's first node stamps its start, its last node its end (slot = replay index, counted on the device)
+__global__ void first_node(unsigned long long *stamps, unsigned int *replay, int us) {
+    const unsigned long long t0 = wall_clock64();
+    if (threadIdx.x == 0) stamps[2 * *replay] = t0;
+    while (wall_clock64() - t0 < (unsigned long long)us * 100ull) {}
+}
+__global__ void last_node(unsigned long long *stamps, unsigned int *replay, int us) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)us * 100ull) {}
+    if (threadIdx.x == 0) { stamps[2 * *replay + 1] = wall_clock64(); *replay += 1; }
+}
+
 struct Probe {
     unsigned long long *stamps;
     std::vector<std::string> names;
@@ -77,6 +89,41 @@ int main(int argc, char **argv) {
     std::vector<hipStream_t> pad(extra);
     for (auto &x : pad) { CK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking)); CK(hipMemsetAsync(nullptr, 0, 0, x)); }
     Probe p;
+    if (argc > 2 && std::string(argv[2]) == "gap") {
+        // the gap between two replays of the same graph on one stream: (a) one chain, (b) fork/join over two streams, (c) over three
+        unsigned int *replay;
+        CK(hipMalloc(&replay, sizeof(unsigned int)));
+        for (int streams = 1; streams <= 3; ++streams) {
+            CK(hipMemset(replay, 0, sizeof(unsigned int)));
+            CK(hipMemset(p.stamps, 0, 2 * 64 * sizeof(unsigned long long)));
+            hipGraph_t g;
+            hipGraphExec_t ge;
+            CK(hipStreamBeginCapture(p.s[0], hipStreamCaptureModeThreadLocal));
+            first_node<<<1, 64, 0, p.s[0]>>>(p.stamps, replay, 10);
+            for (int k = 1; k < streams; ++k) p.dep(0, k);
+            for (int k = 0; k < streams; ++k)
+                for (int j = 0; j < 3; ++j) spin<<<1, 64, 0, p.s[k]>>>(p.stamps + 100, 0, 10);
+            for (int k = 1; k < streams; ++k) p.dep(k, 0);
+            last_node<<<1, 64, 0, p.s[0]>>>(p.stamps, replay, 10);
+            CK(hipStreamEndCapture(p.s[0], &g));
+            CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            hipStream_t launch = getenv("PROBE_NULL") ? nullptr : p.s[0];      // (torch replays on the stream that is current: by default the null stream)
+            hipEvent_t evs[20];
+            for (int rep = 0; rep < 20; ++rep) {
+                CK(hipGraphLaunch(ge, launch));
+                if (getenv("PROBE_EVENT")) { CK(hipEventCreateWithFlags(&evs[rep], hipEventDisableTiming)); CK(hipEventRecord(evs[rep], launch)); }
+            }
+            CK(hipStreamSynchronize(launch));
+            unsigned long long h[40];
+            CK(hipMemcpy(h, p.stamps, sizeof(h), hipMemcpyDeviceToHost));
+            printf("== replay gap, %d captured stream(s): span of a replay %.1f us; gaps between replays (us):", streams, (h[2 * 10 + 1] - h[2 * 10]) / 100.0);
+            for (int rep = 5; rep < 19; ++rep) printf(" %.1f", (h[2 * (rep + 1)] - h[2 * rep + 1]) / 100.0);
+            printf("\n");
+            CK(hipGraphExecDestroy(ge));
+            CK(hipGraphDestroy(g));
+        }
+        return 0;
+    }
     if (argc > 2) {     // the step's head only: S = k_sample_rays, content chain C1..C6 captured first, block chain B1..B6 second (both children of S)
         for (int rep = 0; rep < 2; ++rep)
         p.run("H1 content chain captured first", [&] {
