@@ -605,6 +605,14 @@ def bench_training(args, scene, real_stdout, secondary=None):
             dist.barrier()
         torch.cuda.synchronize()
         window_ms.append((time.perf_counter() - tw) / args.steps * 1e3)
+    if os.environ.get("NERFSIG_BENCH_REPLAY_ONLY") == "1" and not args.no_graph and len(loop.segments) == 1:
+        # diagnostics: the captured graph replayed back to back with NO host work between two replays (stale messages: timing only)
+        torch.cuda.synchronize()
+        tw = time.perf_counter()
+        for i in range(args.steps):
+            loop.segments[0].replay()
+        torch.cuda.synchronize()
+        print(f"[bench] raw replays: {(time.perf_counter() - tw) / args.steps * 1e3:.4f} ms per replay (loop.step: {window_ms[-1]:.4f})", file=sys.stderr)
     loss_value = float(out[5].detach())
     loss_parts = (float(out[3].detach()), float(out[4].detach()))
     # Replicated quantities must be the same number on every rank: the watermark loss (every rank decodes the same all-gathered blocks) and
