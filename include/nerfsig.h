@@ -251,6 +251,13 @@ int mlp_pack_weights(const float *sigma_params, const float *color_params, void 
  * Default: environment variable NERFSIG_MLP ("bf16x3" | "f16"), else 1.  The stage-1 trace entry points always use mode 0. */
 int mlp_get_precision(void);
 int mlp_set_precision(int mode);
+/* Which launches evaluate the MLPs of the TRAINING render at fp16 precision: bit 0 set = the forward (all 17 planes in, sigma + rgb + masks out)
+ * runs software-pipelined over a wave's tiles (next tile's inputs requested and the previous tile's results stored at a tile's head, every layer's
+ * weight fragments fetched from LDS in one burst); bit 1 set = the planned backward likewise.  Cleared bits select the plain per-tile loops.
+ * Results are bit-identical either way (tests/test_gpu_field.py); default 3, or from NERFSIG_FWD_PIPELINE / NERFSIG_BWD_PIPELINE = 0.
+ * No counterpart in the reference (tinycudann's fully fused MLP is one fixed kernel). */
+int mlp_get_pipelined(void);
+int mlp_set_pipelined(int mask);
 
 #define FIELD_MASK_WORDS 6 /* uint32 words of ReLU masks per point saved by field_fwd for field_bwd */
 

@@ -54,6 +54,8 @@ SIGNATURES = {
     "mlp_packed_bytes": [],
     "mlp_get_precision": [],
     "mlp_set_precision": [_int],
+    "mlp_get_pipelined": [],
+    "mlp_set_pipelined": [_int],
     "mlp_pack_weights": [_vp, _vp, _vp, _vp],
     "hg_planes_bytes": [_u32],
     "hg_encode_planes": [_vp, _u32, _fl, _vp, _vp, _vp, _vp],

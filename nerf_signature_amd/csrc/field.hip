@@ -1120,13 +1120,24 @@ NSIG_EXPORT int mlp_pack_weights(const float *sigma_params, const float *color_p
     return check_launch("mlp_pack_weights");
 }
 
-static bool fwd_pipelined() {     // NERFSIG_FWD_PIPELINE=0: the plain loop (k_field_fwd<F16, 1>) for the training render's forward as well
-    static const bool v = !(getenv("NERFSIG_FWD_PIPELINE") && !strcmp(getenv("NERFSIG_FWD_PIPELINE"), "0"));
-    return v;
+// Bit 0: the training render's forward goes through k_field_fwd_train, bit 1: its planned backward through k_field_bwd_train (the software-pipelined
+// launches; results bit-identical to the plain loops k_field_fwd<F16, 1> / k_field_bwd<F16>).  Default both; NERFSIG_FWD_PIPELINE=0 /
+// NERFSIG_BWD_PIPELINE=0 or mlp_set_pipelined() select the plain loops.
+static int g_mlp_pipelined = -1;
+static int mlp_pipelined() {
+    if (g_mlp_pipelined < 0) {
+        const char *f = getenv("NERFSIG_FWD_PIPELINE"), *b = getenv("NERFSIG_BWD_PIPELINE");
+        g_mlp_pipelined = ((f && !strcmp(f, "0")) ? 0 : 1) | ((b && !strcmp(b, "0")) ? 0 : 2);
+    }
+    return g_mlp_pipelined;
 }
-static bool bwd_pipelined() {     // NERFSIG_BWD_PIPELINE=0: the plain loop (k_field_bwd<F16>) for the training render's planned backward as well
-    static const bool v = !(getenv("NERFSIG_BWD_PIPELINE") && !strcmp(getenv("NERFSIG_BWD_PIPELINE"), "0"));
-    return v;
+static bool fwd_pipelined() { return (mlp_pipelined() & 1) != 0; }
+static bool bwd_pipelined() { return (mlp_pipelined() & 2) != 0; }
+NSIG_EXPORT int mlp_get_pipelined(void) { return mlp_pipelined(); }
+NSIG_EXPORT int mlp_set_pipelined(int mask) {
+    NSIG_REQUIRE(mask >= 0 && mask <= 3, "mlp_set_pipelined: bit 0 = forward, bit 1 = backward");
+    g_mlp_pipelined = mask;
+    return NSIG_OK;
 }
 static uint32_t field_grid(uint32_t M, bool forward = false, uint32_t per_cu = 0) {
     const uint32_t blocks = ceil_div(ceil_div(ceil_div(M, 32u), 4u), 8u) * 8u;   // a multiple of 8: k_field_bwd's XCD-aware tile order

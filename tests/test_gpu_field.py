@@ -326,3 +326,50 @@ def test_sliced_scatter_equals_pointwise_scatter(fo, tables):
     e0 = queue[d0]
     assert torch.equal(e0[:, 0] & 0xFFFF, cell[:, 0]) and torch.equal((e0[:, 0] >> 16) & 0x1FFF, ((hy ^ hz) & 0x1FFF).int())
     assert torch.equal(e0[:, 1], words[:, 2])                 # the x weight, bit for bit
+
+
+def test_pipelined_training_launches_equal_the_plain_loops_bit_for_bit(fo, tables):
+    """k_field_fwd_train / k_field_bwd_train (software-pipelined over a wave's tiles: include/nerfsig.h mlp_set_pipelined) against the plain per-tile
+    loops they replace on the training render's path: sigma and rgb bit for bit, the scattered codebook gradient G to half an ulp of its largest entry
+    (what two runs of the same kernels differ by), for point counts that are and are not multiples of the tile; and hg_warm_tables changes nothing."""
+    from nerf_signature_amd import _native as nv
+    base, cb, base_d, cb_d = tables
+    _, sp, cp = _params(tables)
+    packed = fo.pack_weights(sp, cp)
+    before_prec, before_pipe = nv.fn("mlp_get_precision")(), nv.fn("mlp_get_pipelined")()
+    nv.set_mlp_precision("f16")
+    try:
+        for M in (70001, 262144):           # (both above fieldops.BINNED_MIN_POINTS: the planned backward)
+            rng = np.random.RandomState(M)
+            pts = torch.from_numpy((rng.rand(M, 3) * 2 - 1).astype(np.float32)).cuda()
+            dirs = torch.from_numpy(cf.unit_dirs(M, seed=5)).cuda()
+            msg = torch.from_numpy(cf.messages(32)[1])
+            selected = fo.select_tables(cb_d[:64], fo.message_bits(msg))
+            gs, gc = torch.from_numpy(rng.randn(M).astype(np.float32)).cuda(), torch.from_numpy(rng.randn(M, 3).astype(np.float32)).cuda()
+            got = {}
+            for mask in (0, 3, 1, 2):
+                nv.call("mlp_set_pipelined", mask)
+                sink = fo.GradSink(pts.device)
+                for t in selected:
+                    t.requires_grad_(True)
+                sigma, rgb = fo.field_apply(pts, dirs, 1.0, packed, base_d, selected, sink=sink)
+                torch.autograd.backward([sigma, rgb], [gs, gc])
+                torch.cuda.synchronize()
+                got[mask] = (sigma.detach().clone(), rgb.detach().clone(), sink.G.clone())
+            assert fo.BINNED_MIN_POINTS <= M
+            for k in (3, 1, 2):
+                assert torch.equal(got[0][0], got[k][0]) and torch.equal(got[0][1], got[k][1])
+                # G: the owners' fixed-point scale is re-derived per launch and the sum rounded to fp32 once: two runs of the SAME kernels differ
+                # by half an ulp in a few rows; the queue entries (gradient pairs) themselves are identical
+                np.testing.assert_allclose(got[k][2].cpu().numpy(), got[0][2].cpu().numpy(), rtol=0, atol=1.2e-7 * float(got[0][2].abs().max()))
+            assert float(got[3][2].abs().max()) > 0
+        # the warm-up pass only reads
+        S = fo.codebook_presum(selected)
+        snap = [t.clone() for t in base_d] + [S.clone()]
+        sink_word = torch.zeros(1, dtype=torch.float32, device="cuda")
+        nv.call("hg_warm_tables", nv.ptr_array([t.detach() for t in base_d]), nv.ptr(S), nv.ptr(sink_word), nv.stream())
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(snap, base_d + [S])) and float(sink_word) == 0.0
+    finally:
+        nv.call("mlp_set_precision", before_prec)
+        nv.call("mlp_set_pipelined", before_pipe)
