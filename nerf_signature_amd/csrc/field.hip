@@ -561,8 +561,10 @@ __device__ inline void field_fwd_pipelined(const char *lds, int lane, const floa
             sigmas[s] = psigma;
             rgbs[3 * (size_t)s] = prgb[0]; rgbs[3 * (size_t)s + 1] = prgb[1]; rgbs[3 * (size_t)s + 2] = prgb[2];
         }
-        uint32_t *mrow = masks + (size_t)ptile * 192 + lane;
-        mrow[0] = pmask[0]; mrow[64] = pmask[1]; mrow[128] = pmask[2];
+        if (masks != nullptr) {      // (a render without gradients keeps no ReLU masks)
+            uint32_t *mrow = masks + (size_t)ptile * 192 + lane;
+            mrow[0] = pmask[0]; mrow[64] = pmask[1]; mrow[128] = pmask[2];
+        }
     };
     for (uint32_t tile = first; tile < n_tiles; tile += step) {
         typename P::Op feat[2];
@@ -1299,7 +1301,7 @@ NSIG_EXPORT int field_fwd(const float *xyzs, const float *dirs, uint32_t M, floa
     NSIG_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 7) == 0, "field_fwd: planes must be 8-byte aligned");
     const uint32_t stride = ceil_div(M, 32u) * 32u;
     const float2 *pl = reinterpret_cast<const float2 *>(planes);
-    if (f16 && fwd_pipelined() && dirs != nullptr && rgbs != nullptr && masks != nullptr && geo_feat == nullptr) {    // the training render's launch
+    if (f16 && fwd_pipelined() && dirs != nullptr && rgbs != nullptr && geo_feat == nullptr) {    // the training render's launch (masks) and staged no-grad renders
         k_field_fwd_train<F16><<<field_grid(M, true, 2), 256, F16::kFwdLds, st>>>(dirs, M, S != nullptr, pl, stride, pk, sigmas, rgbs, masks);
         return check_launch("field_fwd");
     }
