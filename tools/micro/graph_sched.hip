@@ -101,8 +101,9 @@ int main(int argc, char **argv) {
             CK(hipStreamBeginCapture(p.s[0], hipStreamCaptureModeThreadLocal));
             first_node<<<1, 64, 0, p.s[0]>>>(p.stamps, replay, 10);
             for (int k = 1; k < streams; ++k) p.dep(0, k);
+            const int per_stream = getenv("PROBE_NODES") ? atoi(getenv("PROBE_NODES")) : 3;      // (does the gap grow with the graph's node count?)
             for (int k = 0; k < streams; ++k)
-                for (int j = 0; j < 3; ++j) spin<<<1, 64, 0, p.s[k]>>>(p.stamps + 100, 0, 10);
+                for (int j = 0; j < per_stream; ++j) spin<<<1, 64, 0, p.s[k]>>>(p.stamps + 100, 0, 10);
             for (int k = 1; k < streams; ++k) p.dep(k, 0);
             last_node<<<1, 64, 0, p.s[0]>>>(p.stamps, replay, 10);
             CK(hipStreamEndCapture(p.s[0], &g));
