@@ -368,8 +368,13 @@ def test_pipelined_training_launches_equal_the_plain_loops_bit_for_bit(fo, table
         snap = [t.clone() for t in base_d] + [S.clone()]
         sink_word = torch.zeros(1, dtype=torch.float32, device="cuda")
         nv.call("hg_warm_tables", nv.ptr_array([t.detach() for t in base_d]), nv.ptr(S), nv.ptr(sink_word), nv.stream())
+        nv.call("hg_warm_tables", nv.ptr_array([t.detach() for t in base_d]), None, nv.ptr(sink_word), nv.stream())      # (a clean model: no pre-sum)
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(snap, base_d + [S])) and float(sink_word) == 0.0
+        with pytest.raises(ValueError):       # (argument errors surface as ValueError: _native.call)
+            nv.call("hg_warm_tables", nv.ptr_array([t.detach() for t in base_d]), nv.ptr(S), None, nv.stream())
+        with pytest.raises(ValueError):
+            nv.call("mlp_set_pipelined", 4)
     finally:
         nv.call("mlp_set_precision", before_prec)
         nv.call("mlp_set_pipelined", before_pipe)
