@@ -1439,19 +1439,22 @@ static int g_dec_mode = -1;      // -1: not read yet; 0: per-layer chain (defaul
 static int dec_mode() {
     if (g_dec_mode < 0) {
         const char *e = getenv("NERFSIG_DECODER_CHAIN");
-        g_dec_mode = (e && (!strcmp(e, "persist") || !strcmp(e, "1"))) ? 1 : 0;
+        g_dec_mode = (e && (!strcmp(e, "persist") || !strcmp(e, "1"))) ? 1 : (e && (!strcmp(e, "hybrid") || !strcmp(e, "2"))) ? 2 : 0;
     }
     return g_dec_mode;
 }
-static bool persist_ok(const DecGeom &g) {
-    return dec_mode() == 1 && g.B >= 1 && g.B <= kPMaxB && g.ntile <= kPMaxTiles && persist_lds(g.H, g.W).total <= kLdsLimit - 2048 && g.B * g.npair <= 16 * 12;
+// backward == false: the forward's route (modes 1 and 2 run the 64 -> 64 layers as ONE persistent launch); backward == true: only mode 1 does --
+// mode 2 ("hybrid") pairs the persistent forward (it also records GELU' for that purpose) with the per-layer backward chain.
+static bool persist_ok(const DecGeom &g, bool backward = false) {
+    return (backward ? dec_mode() == 1 : dec_mode() >= 1) && g.B >= 1 && g.B <= kPMaxB && g.ntile <= kPMaxTiles &&
+           persist_lds(g.H, g.W).total <= kLdsLimit - 2048 && g.B * g.npair <= 16 * 12;
 }
 template <int MODE>
 static int launch_persist(const DecParams &prm, const DecWs &ws, const DecGeom &g, hipStream_t s) {
     static size_t allowed = 0;
     const size_t lds = persist_lds(g.H, g.W).total;
     if (allow_lds(k_dec_persist<MODE>, lds, allowed)) return 1;
-    k_dec_persist<MODE><<<g.B, kPT, lds, s>>>(prm, ws, g, ws.packed16, ws.sync);
+    k_dec_persist<MODE><<<g.B, kPT, lds, s>>>(prm, ws, g, ws.packed16, ws.sync, dec_mode() == 2);      // (hybrid: GELU' recorded for the per-layer backward)
     return 0;
 }
 
@@ -1479,7 +1482,7 @@ NSIG_EXPORT int dec_persist_stamps(unsigned long long *out192) {
 
 NSIG_EXPORT int dec_get_mode(void) { return dec_mode(); }
 NSIG_EXPORT int dec_set_mode(int mode) {
-    NSIG_REQUIRE(mode == 0 || mode == 1, "dec_set_mode: 0 = per-layer chain (split-bf16), 1 = persistent launches (fp16 operands) where the shape allows");
+    NSIG_REQUIRE(mode >= 0 && mode <= 2, "dec_set_mode: 0 = per-layer chain (split-bf16), 1 = persistent launches (fp16 operands) where the shape allows, 2 = persistent forward + per-layer backward");
     g_dec_mode = mode;
     return NSIG_OK;
 }
@@ -1587,7 +1590,7 @@ NSIG_EXPORT int dec_backward(const float *grad_decoded, const float *img, uint32
     const dim3 grid(g.npair, B);
     k_dec_head_bwd<<<B, 256, 0, s>>>(grad_decoded, prm, ws, g);
     k_dec_l8_bwd<<<grid, 256, l8b_lds(g), s>>>(prm, ws, g);
-    if (persist_ok(g)) {      // (the forward pass of this workspace packed the fp16 fragments and cleared the sync block)
+    if (persist_ok(g, true)) {      // (the forward pass of this workspace packed the fp16 fragments and cleared the sync block)
         NSIG_REQUIRE(launch_persist<kPBwd>(prm, ws, g, s) == 0, "dec_backward: could not raise the dynamic LDS limit (persistent launch)");
     } else {
         for (int l = 7; l >= 1; --l) launch_conv<kDgrad>(dim3(g.npair, B, 2), conv_lds(g), s, l, prm, ws, g, nullptr, nullptr, inp);

@@ -730,7 +730,7 @@ def test_fused_batchnorm_gelu_matches_torch(shape):
             assert float((a - b).norm() / b.norm()) < 1e-4
 
 
-@pytest.mark.parametrize("mode", ["layers", "persist"])
+@pytest.mark.parametrize("mode", ["layers", "persist", "hybrid"])
 @pytest.mark.parametrize("shape", [(32, 3, 12, 12), (48, 3, 11, 15), (5, 3, 7, 5), (2, 6, 16, 16), (4, 3, 3, 37), (3, 3, 1, 40), (16, 3, 5, 5), (64, 3, 12, 16), (1, 3, 8, 8)])
 def test_fused_decoder_matches_stock_operators(shape, mode, monkeypatch):
     """dec_forward/dec_backward == the stock PyTorch chain of hidden_models.py:104-137 (Conv2d, BatchNorm2d with batch
@@ -747,10 +747,10 @@ def test_fused_decoder_matches_stock_operators(shape, mode, monkeypatch):
     torch.manual_seed(11)
     B, Cin, H, W = shape
     before = nv.fn("dec_get_mode")()
-    nv.call("dec_set_mode", 1 if mode == "persist" else 0)
+    nv.call("dec_set_mode", {"layers": 0, "persist": 1, "hybrid": 2}[mode])      # hybrid: the persistent FORWARD, the per-layer backward chain
     try:
         persistent = bool(nv.fn("dec_persistent_for")(B, Cin, H, W))
-        assert persistent == (mode == "persist" and H * W <= 192 and B <= 64)
+        assert persistent == (mode != "layers" and H * W <= 192 and B <= 64)
         dec = get_hidden_decoder_multi_views(num_bits=1, redundancy=1, num_blocks=8, input_ch=Cin, channels=64).cuda()
         with torch.no_grad():
             for p in dec.parameters():               # away from the default init: BN weights != 1, biases != 0
