@@ -57,19 +57,32 @@ def lr_lambda(iters):
     return lambda it: 0.1 ** min(it / iters, 1)       # main_nerf_wtmk.py:115
 
 
+def snapshot(stage, optimizer, lr=README["lr"]):
+    """The trainable state of a run on the host -- codebook, decoder, Adam moments and step counts -- in a form `train(..., resume=)` loads into
+    a fresh stage under ANY mode (the captured loop keeps its learning rate and step counts in device tensors: normalised here)."""
+    model = stage["model"]
+    sd = optimizer.state_dict()
+    groups = [{k: (lr if k == "lr" else v) for k, v in g.items() if k != "initial_lr"} for g in sd["param_groups"]]
+    state = {k: {n: (v.detach().to("cpu", copy=True) if torch.is_tensor(v) else v) for n, v in st.items()} for k, st in sd["state"].items()}
+    params = {k: v.detach().to("cpu", copy=True) for k, v in model.state_dict().items() if k.startswith(("msg_encoder.", "msg_decoder."))}
+    return {"params": params, "optimizer": {"state": state, "param_groups": groups}}
+
+
 def train(stage, steps=None, mode="graphed", lambda_w=README["lambda_w"], lambda_i=README["lambda_i"], lr=README["lr"], iters=None, distortion="none",
-          msg_seed=1234, sampler_seed=1000, log_every=100, check_every=250):
+          msg_seed=1234, sampler_seed=1000, log_every=100, check_every=250, start=0, resume=None):
     """Runs `steps` training steps on stage['model'] in place.  Returns a record: losses sampled every `log_every` steps (host reads happen
-    only there and at the capacity checks every `check_every` steps), wall time, capacity overflow, per-table Adam step counts."""
+    only there and at the capacity checks every `check_every` steps), wall time, capacity overflow, per-table Adam step counts.
+    start / resume: continue a run at step `start` (messages, content batches and learning rate of steps start .. start+steps-1) from a
+    `snapshot` taken there."""
     from .optim import CodebookAdam
     steps = README["iters"] if steps is None else steps
-    iters = steps if iters is None else iters
+    iters = start + steps if iters is None else iters
     model, dev, D, kw = stage["model"], stage["device"], stage["D"], stage["render_kwargs"]
     H, W, n_rays = stage["H"], stage["W"], stage["n_rays"]
-    msgs = messages(D, steps + 1, msg_seed)
+    msgs = messages(D, start + steps + 1, msg_seed)[start:]
     sampler = rays.DeviceRaySampler(stage["poses"], stage["clean"], stage["intr"], H, W, n_rays, stride=1, offset=0, seed=sampler_seed)
     content = {k: torch.empty(1, n_rays, 3, dtype=torch.float32, device=dev) for k in ("rays_o", "rays_d", "images")}
-    counter = torch.zeros(1, dtype=torch.int32, device=dev)
+    counter = torch.full((1,), start, dtype=torch.int32, device=dev)
     sampler.sample_into(counter, content["rays_o"], content["rays_d"], content["images"])
     data = {"watermark": {"rays_o_block": stage["block_o"], "rays_d_block": stage["block_d"]}, "content": content}
     extra = {} if distortion == "none" else {"distortion": distortion}
@@ -79,23 +92,39 @@ def train(stage, steps=None, mode="graphed", lambda_w=README["lambda_w"], lambda
         if not dp.exchange_active():
             raise RuntimeError("mode 'rccl1' needs the world-size-1 RCCL group: NERFSIG_FORCE_EXCHANGE=1 RANK=0 WORLD_SIZE=1 NERFSIG_SHARD_OPTIMIZER=1 + dp.init_from_env()")
     optimizer = CodebookAdam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15, **({"fused": True, "capturable": True} if graphed else {}))
+    if resume is not None:
+        missing, unexpected = model.load_state_dict(resume["params"], strict=False)
+        if unexpected:
+            raise ValueError(f"resume: unexpected keys {unexpected}")
+        optimizer.load_state_dict(resume["optimizer"])
+    schedule = lr_lambda(iters)
+    shifted = (lambda it: schedule(it + start)) if (schedule is not None and start) else schedule
     if graphed:
-        loop = trainer.GraphedWatermarkLoop(model, optimizer, kw, data, lambda_w=lambda_w, lambda_i=lambda_i, lr_lambda=lr_lambda(iters), content_headroom=0.25,
+        loop = trainer.GraphedWatermarkLoop(model, optimizer, kw, data, lambda_w=lambda_w, lambda_i=lambda_i, lr_lambda=schedule, content_headroom=0.25,
                                             content_sampler=sampler, fixed_blocks=True if mode == "fixed" else None, **extra)
+        if start:
+            loop.resume_at(start)
         one = lambda k: loop.step(msgs[k], next_message=msgs[k + 1])
     elif mode == "eager":
-        sched = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda(iters))
+        sched = None if shifted is None else torch.optim.lr_scheduler.LambdaLR(optimizer, shifted)
         loop = trainer.WatermarkLoop(model, optimizer, kw, lambda_w=lambda_w, lambda_i=lambda_i, lr_scheduler=sched, side_stream=torch.cuda.Stream(), **extra)
 
         def one(k):
-            counter.fill_(k + 1)          # the captured loop's opening kernel counts the replay before the step draws its batch
+            counter.fill_(start + k + 1)  # the captured loop's opening kernel counts the replay before the step draws its batch
             sampler.sample_into(counter, content["rays_o"], content["rays_d"], content["images"])
+            used_lr[0] = float(optimizer.param_groups[0]["lr"])
             return loop.step(data, msgs[k])
     else:
         raise ValueError(f"mode {mode!r}: graphed | eager | fixed | rccl1")
     log, recaptures, overflow = [], 0, False
+    used_lr = [None]       # the learning rate the LAST step ran with
     torch.cuda.synchronize()
+    t_prep = time.perf_counter()
+    if graphed:          # sizing march, warm-up steps (restored afterwards), capture: set-up, timed apart from the steps
+        loop.prepare(msgs[0])
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
+    t_prep = t0 - t_prep
     for k in range(steps):
         out = one(k)
         if log_every and (k % log_every == 0 or k == steps - 1):
@@ -111,8 +140,8 @@ def train(stage, steps=None, mode="graphed", lambda_w=README["lambda_w"], lambda
         loop.close()
     tables = model.msg_encoder.tables()
     counts = [float(optimizer.state[t]["step"]) if len(optimizer.state[t]) else 0.0 for t in tables]
-    return dict(mode=mode, steps=steps, wall_s=wall, ms_per_step=wall / steps * 1e3, log=log, overflowed=bool(overflow), recaptures=recaptures,
-                adam_steps=counts, optimizer=optimizer, last_lr=float(optimizer.param_groups[0]["lr"]), loss_image=log[-1][1] if log else None,
+    return dict(mode=mode, steps=steps, wall_s=wall, prepare_s=t_prep, ms_per_step=wall / steps * 1e3, log=log, overflowed=bool(overflow), recaptures=recaptures,
+                adam_steps=counts, optimizer=optimizer, last_lr=float(optimizer.param_groups[0]["lr"]) if used_lr[0] is None else used_lr[0], loss_image=log[-1][1] if log else None,
                 loss_watermark=log[-1][2] if log else None)
 
 
@@ -167,7 +196,7 @@ def run(mode="graphed", steps=None, scene="hotdog", n_messages=200, **train_kw):
     torch.cuda.synchronize()
     sel = [c for c in rec["adam_steps"]]
     return {"mode": mode, "steps": rec["steps"], "bit_acc": acc, "wrong_bits_mean": wrong_mean, "wrong_bits_worst_message": wrong_max, "psnr_db": psnr,
-            "wall_s": rec["wall_s"], "train_ms_per_step": rec["ms_per_step"], "eval_wall_s": time.perf_counter() - t0, "bit_acc_before_training": before,
+            "wall_s": rec["wall_s"], "capture_s": rec["prepare_s"], "train_ms_per_step": rec["ms_per_step"], "eval_wall_s": time.perf_counter() - t0, "bit_acc_before_training": before,
             "n_messages": n_messages, "n_test_views": int(stage["test_poses"].shape[0]), "overflowed": rec["overflowed"], "recaptures": rec["recaptures"],
             "adam_steps_total": sum(sel), "adam_steps_min_max": [min(sel), max(sel)], "loss_image": rec["loss_image"], "loss_watermark": rec["loss_watermark"],
             "loss_log": [(k, round(a, 8), round(b, 5)) for k, a, b in rec["log"]],

@@ -488,6 +488,15 @@ class GraphedWatermarkLoop:
             model._graphed_loops = []
         model._graphed_loops.append(self)
 
+    def resume_at(self, step):
+        """Continue a run at iteration `step` (before the first replay): the learning-rate schedule, the device-side loader's batch
+        sequence and the message ring's slot all count from there."""
+        if self.graphs is not None and self._replays:
+            raise RuntimeError("resume_at: the loop has already replayed steps")
+        self.steps_done = int(step)
+        self._replays = int(step)
+        self.stage_counter.fill_(int(step))
+
     def invalidate(self):
         """The model's parameters were overwritten from outside (checkpoint.load_checkpoint): the pre-sum buffer no longer belongs to
         any announced message, so the next step runs the stand-alone pre-sum before its replay; the packed MLP weights are refreshed
