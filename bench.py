@@ -449,7 +449,8 @@ def run_secondaries(args):
     not start others on this pool, and the headline must not share the GPU with them).  A failing child costs its own entry only."""
     out = {}
     k = str(min(args.steps, 50))
-    jobs = (("counter", [os.path.abspath(__file__), "--config", "counter", "--steps", k, "--warmup", str(min(args.warmup, 5)), "--no-cpu-baseline", "--no-secondary", "--windows", "1"]),
+    jobs = (("quality", [os.path.join(ROOT, "tools", "converge.py"), "graphed", "--steps", "1000", "--messages", "200"]),
+            ("counter", [os.path.abspath(__file__), "--config", "counter", "--steps", k, "--warmup", str(min(args.warmup, 5)), "--no-cpu-baseline", "--no-secondary", "--windows", "1"]),
             ("fern", [os.path.abspath(__file__), "--config", "fern", "--steps", "5", "--warmup", "1", "--no-secondary"]),
             ("rank_of_8_emulated", [os.path.join(ROOT, "tools", "emulate_rank.py"), "8", "--steps", k, "--warmup", str(min(args.warmup, 5)), "--no-secondary", "--windows", "1"]))
     for name, argv in jobs:
@@ -465,7 +466,9 @@ def run_secondaries(args):
                 continue
             j = json.loads(lines[-1])
             c = j.get("config", {})
-            if name == "counter":
+            if name == "quality":
+                out[name] = j
+            elif name == "counter":
                 out[name] = {"ms_per_step": j["ms_per_step"], "content_rays_per_s": j["value"], "points_per_s": c.get("points_per_s"), "points_per_step": c.get("points_per_step_per_rank"),
                              "samples_per_ray_block": c.get("samples_per_ray_block"), "samples_per_ray_content": c.get("samples_per_ray_content"), "steps": j["steps"],
                              "workload": "BASELINE config 3: Mip-NeRF360/counter-like synthetic scene S1 (bound 2, two cascades, camera inside), 4096 content + 4608 block rays, 32-bit msg",
@@ -538,14 +541,18 @@ def bench_training(args, scene, real_stdout, secondary=None):
                                                                                                       seed=1000 + rank)
     # main_nerf_wtmk.py:110: Adam(get_params(lr), betas=(0.9, 0.99), eps=1e-15) -- same semantics, the codebook update fused
     optimizer = CodebookAdam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, **({} if args.no_graph else ({"capturable": True} if args.no_fused_adam else {"fused": True, "capturable": True})))
+    # README.md:45 (--lambda_w 0.005 --lambda_i 1.0 --iters 1000) and main_nerf_wtmk.py:115 (lr decayed every step): no effect on the timing beyond the
+    # per-step learning-rate write, but these are the hyper-parameters the `quality` record below is trained with
+    hp = dict(lambda_w=0.005, lambda_i=1.0)
+    lr_lambda = lambda it: 0.1 ** min(it / 1000, 1)
     if args.no_graph:
-        loop = trainer.WatermarkLoop(model, optimizer, render_kwargs, side_stream=None if args.no_overlap else torch.cuda.Stream())
+        loop = trainer.WatermarkLoop(model, optimizer, render_kwargs, side_stream=None if args.no_overlap else torch.cuda.Stream(), lr_scheduler=torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda), **hp)
         if args.fixed_blocks:      # the eager loop (what the reference's own Trainer drives): the one-call form of the same declaration
             blk_o, blk_d, _ = trainer.local_blocks(data["watermark"])
             model.fix_rays(blk_o, blk_d, render_kwargs["dt_gamma"], render_kwargs["max_steps"])
     else:
         loop = trainer.GraphedWatermarkLoop(model, optimizer, render_kwargs, data, overlap_content=not args.no_overlap, content_headroom=0.25, content_sampler=sampler,
-                                            fixed_blocks=True if args.fixed_blocks else None)
+                                            fixed_blocks=True if args.fixed_blocks else None, lr_lambda=lr_lambda, **hp)
 
     timer = NativeTimer(nv)
     msg_rng = np.random.RandomState(1234)   # same stream on every rank: the message is replicated
@@ -667,7 +674,7 @@ def bench_training(args, scene, real_stdout, secondary=None):
         try:
             loop.close()
             loop2 = trainer.GraphedWatermarkLoop(model, optimizer, render_kwargs, data, overlap_content=not args.no_overlap, content_headroom=0.25, content_sampler=sampler,
-                                                 fixed_blocks=True)
+                                                 fixed_blocks=True, lr_lambda=lr_lambda, **hp)
             running[0] = loop2
             for _ in range(max(args.warmup, 2)):
                 one_step()
@@ -768,6 +775,7 @@ def bench_training(args, scene, real_stdout, secondary=None):
                         ("drawn inside the captured step from the device-resident pose/image store (rg_sample_rays)" if sampler is not None else "rays generated on the device inside the timed loop (host-driven: randint, rg_get_rays, gather, copies)"),
             "content_march": "ahead (end of the previous replay)" if getattr(loop, "content_ahead", False) else "head of the step",
             "message_dim": D, "parallelism": f"dp{world}", "optimizer": "Adam(betas=(0.9,0.99), eps=1e-15): torch semantics, codebook update fused (opt_codebook_adam)",
+            "hyper_parameters": "README.md:45: lambda_w 0.005, lambda_i 1.0, lr 1e-2 * 0.1 ** min(it / 1000, 1) written every step",
             "grad_exchange_bytes_per_step": loop.exchange.bytes_per_step + (rays_block_all * 12 if sharded else 0) + (T_BYTES if getattr(loop, "opt_shard", None) else 0),
             "collectives_per_step": (loop.exchange.collectives_per_step + (1 if sharded else 0) + (1 if getattr(loop, "opt_shard", None) else 0)) if dp.exchange_active() else 0,
             "codebook_optimizer": ("sharded over the ranks (each updates the tables of D/R bits, partial pre-sums all-reduced)" if getattr(loop, "opt_shard", None) else "replicated"),
@@ -828,6 +836,9 @@ def bench_training(args, scene, real_stdout, secondary=None):
     if world == 1 and not args.no_cpu_baseline and scene == "hotdog":
         line["cpu_baseline"] = cpu_baseline(model, D, full_step_points=pts_step)
     if secondary is not None:
+        quality = secondary.pop("quality", None)
+        if quality is not None:      # the reference's whole run on this path (1000 steps, README hyper-parameters) + test_bitacc / test_image: nerf_signature_amd/quality.py
+            line["quality"] = quality
         line["secondary"] = secondary
     if ranks_agree is False:
         raise SystemExit(4)

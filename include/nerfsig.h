@@ -446,6 +446,35 @@ int dec_backward(const float *grad_decoded, const float *img, uint32_t input_mod
                  const float *const *params_host, uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, void *workspace,
                  float *const *grads_host, float *grad_img, nsig_stream_t stream, nsig_stream_t weights_stream);
 
+/*
+ * The distortion layer of the training step (Trainer.distortion_layer, nerf/utils_wtmk_disen.py:551-577; applied to the clamped block
+ * renders in front of the decoder, :594; `--distortion`, main_nerf_wtmk.py:75).  distortion: 0 none, 1 noise (x + n, the reference
+ * draws n ~ N(0, 0.1) per element), 2 brightness (torchvision ColorJitter(brightness=0.5): clamp(f * x, 0, 1), one f in [0.5, 1.5]
+ * per call), 3 blurring (torchvision GaussianBlur(3, sigma in [0.01, 0.5]): taps exp(-0.5 (d / sigma)^2) normalised, reflect padding).
+ * rotation / scaling change the image geometry (and, for scaling, the decoder's input width): they stay on stock operators.
+ *   dist_param  device float[1]: f (2) or sigma (3), read on the device -- a captured step draws it itself (wm_distort_draw);
+ *   dist_noise  device [B, H, W, Cin] (1).
+ * dec_forward_distorted / dec_backward_distorted = dec_forward / dec_backward with input_mode 1 and the layer applied on load, between
+ * the clamp and the normalisation (no extra launch; the blur's adjoint is one small launch behind the image-gradient epilogue and needs
+ * grad_scratch [B, H, W, Cin]); clamped_out still receives the UNdistorted clamped blocks (the step's pred_rgb, :592).
+ * wm_distort_fwd / _bwd: the layer alone on [B, H, W, C] (img = the unclamped render; out = D(clamp(img)); grad_img through the clamp).
+ * wm_distort_draw: counter-based draws, a pure function of (seed, *step_counter, element): param_out[0] ~ U[0.5, 1.5] (2) /
+ * U[0.01, 0.5] (3), noise_out[0 .. n_noise) ~ N(0, 0.1) (1).  step_counter may be NULL (step 0).
+ */
+int dec_forward_distorted(const float *img, const float *mean_host, const float *std_host, const float *const *params_host, uint32_t B,
+                          uint32_t Cin, uint32_t H, uint32_t W, float eps, void *workspace, float *decoded, float *clamped_out,
+                          uint32_t distortion, const float *dist_param, const float *dist_noise, nsig_stream_t stream);
+int dec_backward_distorted(const float *grad_decoded, const float *img, const float *mean_host, const float *std_host,
+                           const float *const *params_host, uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, void *workspace,
+                           float *const *grads_host, float *grad_img, uint32_t distortion, const float *dist_param,
+                           const float *dist_noise, float *grad_scratch, nsig_stream_t stream, nsig_stream_t weights_stream);
+int wm_distort_draw(uint32_t distortion, uint64_t seed, const uint32_t *step_counter, uint32_t n_noise, float *param_out,
+                    float *noise_out, nsig_stream_t stream);
+int wm_distort_fwd(const float *img, uint32_t B, uint32_t H, uint32_t W, uint32_t C, uint32_t distortion, const float *dist_param,
+                   const float *dist_noise, float *out, nsig_stream_t stream);
+int wm_distort_bwd(const float *grad_out, const float *img, uint32_t B, uint32_t H, uint32_t W, uint32_t C, uint32_t distortion,
+                   const float *dist_param, const float *dist_noise, float *grad_img, nsig_stream_t stream);
+
 /* ------------------------------------------------------------------ stage-1 (clean model) training, SURVEY.md 8(f) N3 */
 
 /*

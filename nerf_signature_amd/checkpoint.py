@@ -46,9 +46,22 @@ def checkpoint_state(model, epoch=0, global_step=0, stats=None, optimizer=None, 
 
 
 def save_checkpoint(path, model, **kw):
-    """Writes `<path>` (e.g. <workspace>/checkpoints/ngp_ep0010.pth) in the reference's format."""
-    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-    torch.save(checkpoint_state(model, **kw), path)
+    """Writes `<path>` (e.g. <workspace>/checkpoints/ngp_ep0010.pth) in the reference's format.  More than one rank: rank 0 writes.
+
+    With the codebook optimiser sharded over the ranks (on by default from four ranks) the tables are gathered first -- a COLLECTIVE, so
+    every rank has to make this call, not only rank 0 as in the reference's `if self.local_rank == 0: self.save_checkpoint(...)`; the
+    other ranks take part in the gather, skip the write and leave through a barrier, i.e. when the file exists.  A caller that cannot
+    arrange that passes gather=False: the call then raises on stale tables instead of entering a collective alone (and blocking until the
+    process group's timeout)."""
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    gathered = multi and bool(getattr(model, "_codebook_stale", False)) and kw.get("gather", True)
+    state = checkpoint_state(model, **kw)            # (gathers the sharded tables: all ranks)
+    if not multi or dist.get_rank() == 0:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        torch.save(state, path)
+    if gathered:                                     # every rank came through the gather above, so every rank reaches this barrier
+        dist.barrier()
     return path
 
 

@@ -68,10 +68,50 @@ struct DecWs {
 struct DecInput {
     uint32_t mode;
     float mean[8], istd[8];
+    // The distortion layer of the training step (Trainer.distortion_layer, utils_wtmk_disen.py:551-577, applied at :594 between the clamp and the
+    // normalisation; mode 1 only).  0 none; 1 noise: x + noise[b][y][x][c] (the reference draws N(0, 0.1) per element); 2 brightness: clamp(f * x, 0, 1)
+    // (torchvision ColorJitter(brightness=0.5): ONE factor f in [0.5, 1.5] per call, blended against black); 3 blurring: the 3x3 Gaussian of
+    // torchvision GaussianBlur(3, sigma in [0.01, 0.5]) -- taps exp(-0.5 (d / sigma)^2), d in {-1, 0, 1}, normalised, reflect padding.
+    // f / sigma are read from dparam[0] ON THE DEVICE (so a captured step can draw them itself), the noise from dnoise.
+    uint32_t distort, H, W;
+    const float *dparam, *dnoise;
 };
+enum : uint32_t { kDistNone = 0, kDistNoise = 1, kDistBrightness = 2, kDistBlur = 3 };
+
+__device__ inline float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+__device__ inline int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }   // torch 'reflect' padding by one (n >= 2)
+// side weight a and centre weight b of the normalised 1-d kernel [a, b, a]
+__device__ inline void blur_taps(float sigma, float &a, float &b) {
+    const float e = __expf(-0.5f / (sigma * sigma));
+    b = 1.0f / (1.0f + 2.0f * e);
+    a = e * b;
+}
+// the distorted value of channel c at pixel pix of image im, from the rendered blocks [B][H][W][Cin] (before the normalisation)
+__device__ inline float distorted_value(const float *__restrict__ img, const DecInput &in, uint32_t im, uint32_t c, uint32_t pix, uint32_t Cin, uint32_t P) {
+    const float *base = img + (size_t)im * P * Cin + c;
+    if (in.distort == kDistBlur) {
+        float a, b;
+        blur_taps(in.dparam[0], a, b);
+        const int y = (int)(pix / in.W), x = (int)(pix - (uint32_t)y * in.W);
+        float acc = 0.0f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = reflect1(y + dy, (int)in.H);
+            float row = 0.0f;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) row += (dx == 0 ? b : a) * clamp01(base[(size_t)(yy * (int)in.W + reflect1(x + dx, (int)in.W)) * Cin]);
+            acc += (dy == 0 ? b : a) * row;
+        }
+        return acc;
+    }
+    const float x = clamp01(base[(size_t)pix * Cin]);
+    if (in.distort == kDistNoise) return x + in.dnoise[((size_t)im * P + pix) * Cin + c];
+    if (in.distort == kDistBrightness) return clamp01(in.dparam[0] * x);
+    return x;
+}
 __device__ inline float input_value(const float *__restrict__ img, const DecInput &in, uint32_t im, uint32_t c, uint32_t pix, uint32_t Cin, uint32_t P) {
     if (in.mode == 0) return img[((size_t)im * Cin + c) * P + pix];
-    return (fminf(fmaxf(img[((size_t)im * P + pix) * Cin + c], 0.0f), 1.0f) - in.mean[c]) * in.istd[c];
+    return (distorted_value(img, in, im, c, pix, Cin, P) - in.mean[c]) * in.istd[c];
 }
 
 struct DecParams {
@@ -774,7 +814,16 @@ __global__ void __launch_bounds__(kT) k_dec_conv(int layer, DecParams prm, DecWs
                     } else {   // through the normalisation and the clamp (gradient passes where 0 <= x <= 1, as torch.clamp)
                         const size_t e = ((size_t)im * g.P + qo) * g.Cin + c;
                         const float x = img[e];
-                        grad_img[e] = (x >= 0.0f && x <= 1.0f) ? acc[r] * inp.istd[c] : 0.0f;
+                        float gy = acc[r] * inp.istd[c];          // d loss / d (distorted value)
+                        if (inp.distort == kDistBlur) {           // the blur's adjoint needs the neighbours' gradients: k_dec_blur_adjoint finishes the job
+                            grad_img[e] = gy;
+                        } else {
+                            if (inp.distort == kDistBrightness) {
+                                const float f = inp.dparam[0], fx = f * clamp01(x);
+                                gy = (fx >= 0.0f && fx <= 1.0f) ? gy * f : 0.0f;
+                            }
+                            grad_img[e] = (x >= 0.0f && x <= 1.0f) ? gy : 0.0f;
+                        }
                     }
                 }
             }
@@ -1514,8 +1563,82 @@ NSIG_EXPORT size_t dec_workspace_bytes(uint32_t B, uint32_t Cin, uint32_t H, uin
     return carve(nullptr, g, ws);
 }
 
+// grad_img (through the clamp) = clamp mask x the transposed blur of gy: gx[p] = sum over the (q, tap) whose reflected source is p of k[tap] * gy[q].
+// One thread per (image, pixel, channel); the 3 x 3 outputs q around p are visited and each one's taps re-reflected.
+__global__ void __launch_bounds__(256) k_dec_blur_adjoint(const float *__restrict__ gy, const float *__restrict__ img, const float *__restrict__ dparam, uint32_t B,
+                                                          uint32_t H, uint32_t W, uint32_t Cin, float *__restrict__ grad_img) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * H * W * Cin) return;
+    const uint32_t c = i % Cin, pix = (i / Cin) % (H * W), im = i / (Cin * H * W);
+    const int y = (int)(pix / W), x = (int)(pix % W);
+    float a, b;
+    blur_taps(dparam[0], a, b);
+    float acc = 0.0f;
+    for (int qy = y - 2; qy <= y + 2; ++qy) {
+        if (qy < 0 || qy >= (int)H) continue;
+        float wy = 0.0f;          // total weight with which output row qy reads input row y (reflection can map two taps onto it)
+        for (int dy = -1; dy <= 1; ++dy)
+            if (reflect1(qy + dy, (int)H) == y) wy += dy == 0 ? b : a;
+        if (wy == 0.0f) continue;
+        for (int qx = x - 2; qx <= x + 2; ++qx) {
+            if (qx < 0 || qx >= (int)W) continue;
+            float wx = 0.0f;
+            for (int dx = -1; dx <= 1; ++dx)
+                if (reflect1(qx + dx, (int)W) == x) wx += dx == 0 ? b : a;
+            if (wx != 0.0f) acc += wy * wx * gy[((size_t)im * H * W + (size_t)qy * W + qx) * Cin + c];
+        }
+    }
+    const float v = img[i];
+    grad_img[i] = (v >= 0.0f && v <= 1.0f) ? acc : 0.0f;
+}
+
+// The step's random draws, counter-based: everything is a function of (seed, *step, element) -- a replayed graph draws fresh values every
+// step without a host-side generator.  param[0]: brightness factor U[0.5, 1.5] / blur sigma U[0.01, 0.5]; noise[i] ~ N(0, 0.1) (Box-Muller).
+__device__ inline uint64_t mix64(uint64_t z) {      // splitmix64's finaliser
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(256) k_distort_draw(uint32_t kind, uint64_t seed, const uint32_t *__restrict__ step, uint32_t n, float *__restrict__ param,
+                                                      float *__restrict__ noise) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint64_t key = mix64(seed ^ (0x9E3779B97F4A7C15ull * ((uint64_t)(step ? step[0] : 0u) + 1ull)));
+    if (i == 0 && param) {
+        const float u = (float)(mix64(key ^ 0xFFFFFFFFFFFFFFFFull) >> 40) * (1.0f / 16777216.0f);      // [0, 1)
+        param[0] = kind == kDistBrightness ? 0.5f + u : (kind == kDistBlur ? 0.01f + 0.49f * u : 0.0f);
+    }
+    if (kind == kDistNoise && noise && i < n) {
+        const uint64_t h = mix64(key + 0xD1B54A32D192ED03ull * ((uint64_t)i + 1ull));
+        const float u1 = ((float)(uint32_t)(h >> 40) + 1.0f) * (1.0f / 16777216.0f);                   // (0, 1]
+        const float u2 = (float)(uint32_t)((h >> 8) & 0xFFFFFFu) * (1.0f / 16777216.0f);              // [0, 1)
+        noise[i] = 0.316227766016837933f * sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958648f * u2);  // sigma = sqrt(0.1)
+    }
+}
+
+// the layer alone, [B][H][W][C] -> [B][H][W][C] (decoder shapes the fused chain does not implement; tests)
+__global__ void __launch_bounds__(256) k_distort_fwd(const float *__restrict__ img, DecInput in, uint32_t B, uint32_t Cin, float *__restrict__ out) {
+    const uint32_t P = in.H * in.W, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * P * Cin) return;
+    out[i] = distorted_value(img, in, i / (P * Cin), i % Cin, (i / Cin) % P, Cin, P);
+}
+__global__ void __launch_bounds__(256) k_distort_bwd(const float *__restrict__ gy, const float *__restrict__ img, DecInput in, uint32_t B, uint32_t Cin,
+                                                     float *__restrict__ gx) {
+    const uint32_t P = in.H * in.W, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * P * Cin) return;
+    const float x = img[i];
+    float g = gy[i];
+    if (in.distort == kDistBrightness) {
+        const float f = in.dparam[0], fx = f * clamp01(x);
+        g = (fx >= 0.0f && fx <= 1.0f) ? g * f : 0.0f;
+    }
+    gx[i] = (x >= 0.0f && x <= 1.0f) ? g : 0.0f;
+}
+
 static int make_input(uint32_t mode, const float *mean, const float *stdev, uint32_t Cin, DecInput &in) {
     in.mode = mode;
+    in.distort = kDistNone;
+    in.H = in.W = 0;
+    in.dparam = in.dnoise = nullptr;
     for (int c = 0; c < 8; ++c) in.mean[c] = 0.0f, in.istd[c] = 1.0f;
     if (mode == 0) return 0;
     if (mode != 1 || !mean || !stdev || Cin > 8) return 1;
@@ -1527,12 +1650,27 @@ static int make_input(uint32_t mode, const float *mean, const float *stdev, uint
     return 0;
 }
 
-NSIG_EXPORT int dec_forward(const float *img, uint32_t input_mode, const float *mean_host, const float *std_host, const float *const *params,
+static int set_distortion(DecInput &in, uint32_t distortion, const float *param, const float *noise, uint32_t H, uint32_t W) {
+    if (distortion == kDistNone) return 0;
+    if (in.mode != 1 || distortion > kDistBlur) return 1;
+    if (distortion == kDistNoise ? noise == nullptr : param == nullptr) return 1;
+    if (distortion == kDistBlur && (H < 2 || W < 2)) return 1;      // reflect padding by one needs two pixels
+    in.distort = distortion;
+    in.H = H;
+    in.W = W;
+    in.dparam = param;
+    in.dnoise = noise;
+    return 0;
+}
+
+static int dec_forward_impl(const float *img, uint32_t input_mode, const float *mean_host, const float *std_host, const float *const *params,
                             uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, float eps, void *workspace, float *decoded, float *clamped_out,
-                            nsig_stream_t stream) {
+                            uint32_t distortion, const float *dist_param, const float *dist_noise, nsig_stream_t stream) {
     NSIG_REQUIRE(img && params && workspace && decoded, "dec_forward: null pointer");
     DecInput inp;
     NSIG_REQUIRE(make_input(input_mode, mean_host, std_host, Cin, inp) == 0, "dec_forward: input_mode is 0, or 1 with Cin <= 8 means and positive stds");
+    NSIG_REQUIRE(set_distortion(inp, distortion, dist_param, dist_noise, H, W) == 0,
+                 "dec_forward_distorted: distortion is 0..3, needs input_mode 1, its device parameter (2, 3) or noise tensor (1), and H, W >= 2 for the blur");
     DecGeom g;
     NSIG_REQUIRE(B >= 1 && Cin >= 1 && Cin <= kMaxCin && H >= 1 && W >= 1 && (uint64_t)H * W <= kMaxP && (uint64_t)B * H * W > 1 &&
                      make_geom(B, Cin, H, W, eps, g),
@@ -1562,12 +1700,27 @@ NSIG_EXPORT int dec_forward(const float *img, uint32_t input_mode, const float *
     return check_launch("dec_forward");
 }
 
-NSIG_EXPORT int dec_backward(const float *grad_decoded, const float *img, uint32_t input_mode, const float *mean_host, const float *std_host,
+NSIG_EXPORT int dec_forward(const float *img, uint32_t input_mode, const float *mean_host, const float *std_host, const float *const *params,
+                            uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, float eps, void *workspace, float *decoded, float *clamped_out,
+                            nsig_stream_t stream) {
+    return dec_forward_impl(img, input_mode, mean_host, std_host, params, B, Cin, H, W, eps, workspace, decoded, clamped_out, kDistNone, nullptr, nullptr, stream);
+}
+
+NSIG_EXPORT int dec_forward_distorted(const float *img, const float *mean_host, const float *std_host, const float *const *params, uint32_t B, uint32_t Cin,
+                                      uint32_t H, uint32_t W, float eps, void *workspace, float *decoded, float *clamped_out, uint32_t distortion,
+                                      const float *dist_param, const float *dist_noise, nsig_stream_t stream) {
+    return dec_forward_impl(img, 1, mean_host, std_host, params, B, Cin, H, W, eps, workspace, decoded, clamped_out, distortion, dist_param, dist_noise, stream);
+}
+
+static int dec_backward_impl(const float *grad_decoded, const float *img, uint32_t input_mode, const float *mean_host, const float *std_host,
                              const float *const *params, uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, void *workspace, float *const *grads,
-                             float *grad_img, nsig_stream_t stream, nsig_stream_t weights_stream) {
+                             float *grad_img, uint32_t distortion, const float *dist_param, const float *dist_noise, float *grad_scratch,
+                             nsig_stream_t stream, nsig_stream_t weights_stream) {
     NSIG_REQUIRE(grad_decoded && img && params && workspace && grads && grad_img, "dec_backward: null pointer");
     DecInput inp;
     NSIG_REQUIRE(make_input(input_mode, mean_host, std_host, Cin, inp) == 0, "dec_backward: input_mode is 0, or 1 with Cin <= 8 means and positive stds");
+    NSIG_REQUIRE(set_distortion(inp, distortion, dist_param, dist_noise, H, W) == 0 && (distortion != kDistBlur || grad_scratch != nullptr),
+                 "dec_backward_distorted: distortion is 0..3, needs input_mode 1, its device parameter / noise tensor, and for the blur a scratch image");
     DecGeom g;
     NSIG_REQUIRE(B >= 1 && Cin >= 1 && Cin <= kMaxCin && H >= 1 && W >= 1 && (uint64_t)H * W <= kMaxP && make_geom(B, Cin, H, W, 0.0f, g),
                  "dec_backward: unsupported image shape");
@@ -1595,7 +1748,12 @@ NSIG_EXPORT int dec_backward(const float *grad_decoded, const float *img, uint32
     } else {
         for (int l = 7; l >= 1; --l) launch_conv<kDgrad>(dim3(g.npair, B, 2), conv_lds(g), s, l, prm, ws, g, nullptr, nullptr, inp);
     }
-    launch_conv<kDgradImg>(grid, conv_lds(g), s, 0, prm, ws, g, grad_img, img, inp);
+    if (inp.distort == kDistBlur) {     // the epilogue leaves d loss / d (blurred image) in the scratch image; the blur's adjoint and the clamp mask follow
+        launch_conv<kDgradImg>(grid, conv_lds(g), s, 0, prm, ws, g, grad_scratch, img, inp);
+        k_dec_blur_adjoint<<<ceil_div(B * H * W * Cin, 256u), 256, 0, s>>>(grad_scratch, img, inp.dparam, B, H, W, Cin, grad_img);
+    } else {
+        launch_conv<kDgradImg>(grid, conv_lds(g), s, 0, prm, ws, g, grad_img, img, inp);
+    }
     // The parameter gradients are not needed before the optimiser; what waits on this function is the image gradient (the block
     // render's backward).  On request they are queued on a second stream, ordered after the data-gradient chain by an event.
     hipStream_t sw = as_stream(weights_stream);
@@ -1615,4 +1773,59 @@ NSIG_EXPORT int dec_backward(const float *grad_decoded, const float *img, uint32
     k_dec_wreduce<<<dim3(kC, 7), 576, 0, sw>>>(ws, gr, g);
     k_dec_sreduce<<<16 + ceil_div(kC * 9 * Cin, 64) + 9 + 1, 256, 0, sw>>>(grad_decoded, ws, gr, g);
     return check_launch("dec_backward");
+}
+
+NSIG_EXPORT int dec_backward(const float *grad_decoded, const float *img, uint32_t input_mode, const float *mean_host, const float *std_host,
+                             const float *const *params, uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, void *workspace, float *const *grads,
+                             float *grad_img, nsig_stream_t stream, nsig_stream_t weights_stream) {
+    return dec_backward_impl(grad_decoded, img, input_mode, mean_host, std_host, params, B, Cin, H, W, workspace, grads, grad_img, kDistNone, nullptr, nullptr,
+                             nullptr, stream, weights_stream);
+}
+
+NSIG_EXPORT int dec_backward_distorted(const float *grad_decoded, const float *img, const float *mean_host, const float *std_host, const float *const *params,
+                                       uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, void *workspace, float *const *grads, float *grad_img,
+                                       uint32_t distortion, const float *dist_param, const float *dist_noise, float *grad_scratch, nsig_stream_t stream,
+                                       nsig_stream_t weights_stream) {
+    return dec_backward_impl(grad_decoded, img, 1, mean_host, std_host, params, B, Cin, H, W, workspace, grads, grad_img, distortion, dist_param, dist_noise,
+                             grad_scratch, stream, weights_stream);
+}
+
+NSIG_EXPORT int wm_distort_draw(uint32_t distortion, uint64_t seed, const uint32_t *step_counter, uint32_t n_noise, float *param_out, float *noise_out,
+                                nsig_stream_t stream) {
+    NSIG_REQUIRE(distortion >= kDistNoise && distortion <= kDistBlur, "wm_distort_draw: distortion is 1 (noise), 2 (brightness) or 3 (blurring)");
+    NSIG_REQUIRE(distortion == kDistNoise ? (noise_out != nullptr && n_noise >= 1) : param_out != nullptr, "wm_distort_draw: missing output buffer");
+    const uint32_t n = distortion == kDistNoise ? n_noise : 1u;
+    k_distort_draw<<<ceil_div(n, 256u), 256, 0, as_stream(stream)>>>(distortion, seed, step_counter, n, param_out, noise_out);
+    return check_launch("wm_distort_draw");
+}
+
+static int standalone_input(DecInput &in, uint32_t distortion, const float *param, const float *noise, uint32_t H, uint32_t W) {
+    in.mode = 1;
+    for (int c = 0; c < 8; ++c) in.mean[c] = 0.0f, in.istd[c] = 1.0f;
+    in.distort = kDistNone;
+    in.H = H;
+    in.W = W;
+    in.dparam = in.dnoise = nullptr;
+    return set_distortion(in, distortion, param, noise, H, W);
+}
+
+NSIG_EXPORT int wm_distort_fwd(const float *img, uint32_t B, uint32_t H, uint32_t W, uint32_t C, uint32_t distortion, const float *dist_param,
+                               const float *dist_noise, float *out, nsig_stream_t stream) {
+    NSIG_REQUIRE(img && out && B >= 1 && H >= 1 && W >= 1 && C >= 1 && (uint64_t)B * H * W * C < (1ull << 31), "wm_distort_fwd: bad arguments");
+    DecInput in;
+    NSIG_REQUIRE(standalone_input(in, distortion, dist_param, dist_noise, H, W) == 0, "wm_distort_fwd: distortion is 0..3 with its device parameter / noise tensor (blur: H, W >= 2)");
+    k_distort_fwd<<<ceil_div(B * H * W * C, 256u), 256, 0, as_stream(stream)>>>(img, in, B, C, out);
+    return check_launch("wm_distort_fwd");
+}
+
+NSIG_EXPORT int wm_distort_bwd(const float *grad_out, const float *img, uint32_t B, uint32_t H, uint32_t W, uint32_t C, uint32_t distortion,
+                               const float *dist_param, const float *dist_noise, float *grad_img, nsig_stream_t stream) {
+    NSIG_REQUIRE(grad_out && img && grad_img && B >= 1 && H >= 1 && W >= 1 && C >= 1 && (uint64_t)B * H * W * C < (1ull << 31), "wm_distort_bwd: bad arguments");
+    DecInput in;
+    NSIG_REQUIRE(standalone_input(in, distortion, dist_param, dist_noise, H, W) == 0, "wm_distort_bwd: distortion is 0..3 with its device parameter / noise tensor (blur: H, W >= 2)");
+    if (distortion == kDistBlur)
+        k_dec_blur_adjoint<<<ceil_div(B * H * W * C, 256u), 256, 0, as_stream(stream)>>>(grad_out, img, dist_param, B, H, W, C, grad_img);
+    else
+        k_distort_bwd<<<ceil_div(B * H * W * C, 256u), 256, 0, as_stream(stream)>>>(grad_out, img, in, B, C, grad_img);
+    return check_launch("wm_distort_bwd");
 }

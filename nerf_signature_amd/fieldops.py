@@ -413,6 +413,8 @@ class _FieldFunction(Function):
         sigmas, rgbs, _, masks = field_forward(xyzs, dirs, bound, base, S, packed, want_masks=need_grad, fixed=fixed)
         ctx.bound, ctx.n_sel, ctx.need_grad, ctx.sink = bound, n_sel, need_grad, sink
         if need_grad:
+            # the saved ReLU masks are laid out for the arithmetic the forward ran in (csrc/field.hip mask_bit<P>): the backward must run in the same
+            ctx.mlp_precision = nv.fn("mlp_get_precision")()
             ctx.save_for_backward(xyzs, sigmas, rgbs, masks, packed)
             if sink is not None:
                 sink.selected = list(sel)
@@ -426,6 +428,9 @@ class _FieldFunction(Function):
             return head + (None,) * ctx.n_sel
         xyzs, sigmas, rgbs, masks, packed = ctx.saved_tensors
         plan, ctx.plan = ctx.plan, None
+        if nv.fn("mlp_get_precision")() != ctx.mlp_precision:
+            raise RuntimeError("mlp_set_precision was called between a field forward pass and its backward: the saved ReLU masks belong to the forward's "
+                               "arithmetic (run the backward before switching, or switch before the forward)")
         if ctx.sink is not None:
             field_backward_into(xyzs, ctx.bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, ctx.sink.G, plan)
             return head + (None,) * ctx.n_sel

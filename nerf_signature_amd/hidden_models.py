@@ -102,7 +102,8 @@ class _FusedDecoder(torch.autograd.Function):
     clamp / permute / normalize_img of the training step happen inside layer 0; the second output is the clamped image."""
 
     @staticmethod
-    def forward(ctx, img, eps, rendered, *params):
+    def forward(ctx, img, eps, rendered, distortion, *params):
+        """distortion: a distortion.DistortionLayer of a native kind whose draws are in its device buffers (rendered=True only), or None."""
         img = img.contiguous()
         if rendered:
             B, H, W, Cin = img.shape
@@ -114,8 +115,16 @@ class _FusedDecoder(torch.autograd.Function):
         ps = [p.detach().contiguous() for p in params]
         ws = torch.empty(nv.fn("dec_workspace_bytes")(B, Cin, H, W), dtype=torch.uint8, device=img.device)
         out = torch.empty(B, dtype=torch.float32, device=img.device)
-        nv.call("dec_forward", nv.ptr(img), int(rendered), mean, std, nv.ptr_array(ps), B, Cin, H, W, eps, nv.ptr(ws), nv.ptr(out), nv.ptr(clamped),
-                nv.stream())
+        dist = distortion if (distortion is not None and distortion.native) else None
+        if dist is not None:
+            if not rendered:
+                raise ValueError("the fused distortion layer acts on the rendered blocks (rendered=True)")
+            nv.call("dec_forward_distorted", nv.ptr(img), mean, std, nv.ptr_array(ps), B, Cin, H, W, eps, nv.ptr(ws), nv.ptr(out), nv.ptr(clamped), dist.kind,
+                    nv.ptr(dist.param), nv.ptr(dist.noise), nv.stream())
+        else:
+            nv.call("dec_forward", nv.ptr(img), int(rendered), mean, std, nv.ptr_array(ps), B, Cin, H, W, eps, nv.ptr(ws), nv.ptr(out), nv.ptr(clamped),
+                    nv.stream())
+        ctx.dist = dist
         ctx.save_for_backward(img, ws, *ps)
         ctx.geom = (B, Cin, H, W, bool(rendered))
         ctx.dec_mode = nv.fn("dec_get_mode")()      # dec_backward must take the route dec_forward took (the workspace holds that route's operands)
@@ -128,7 +137,7 @@ class _FusedDecoder(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out, *_):
         if grad_out is None:
-            return (None,) * (3 + len(ctx.saved_tensors) - 2)
+            return (None,) * (4 + len(ctx.saved_tensors) - 2)
         img, ws, *ps = ctx.saved_tensors
         B, Cin, H, W, rendered = ctx.geom
         mean, std = ((ctypes.c_float * Cin)(*_MEAN[:Cin]), (ctypes.c_float * Cin)(*_STD[:Cin])) if rendered else (None, None)
@@ -153,12 +162,19 @@ class _FusedDecoder(torch.autograd.Function):
         if mode_now != ctx.dec_mode:
             nv.call("dec_set_mode", ctx.dec_mode)
         try:
-            nv.call("dec_backward", nv.ptr(grad_out.contiguous().view(-1)), nv.ptr(img), int(rendered), mean, std, nv.ptr_array(ps), B, Cin, H, W,
-                    nv.ptr(ws), nv.ptr_array(grads), nv.ptr(grad_img), nv.stream(), nv.stream() if side is None else side.cuda_stream)
+            if ctx.dist is not None:     # (the draws in its buffers are still this step's: they are refreshed at the head of the next one)
+                d = ctx.dist
+                scratch = torch.empty_like(img) if d.kind == 3 else None
+                nv.call("dec_backward_distorted", nv.ptr(grad_out.contiguous().view(-1)), nv.ptr(img), mean, std, nv.ptr_array(ps), B, Cin, H, W, nv.ptr(ws),
+                        nv.ptr_array(grads), nv.ptr(grad_img), d.kind, nv.ptr(d.param), nv.ptr(d.noise), nv.ptr(scratch), nv.stream(),
+                        nv.stream() if side is None else side.cuda_stream)
+            else:
+                nv.call("dec_backward", nv.ptr(grad_out.contiguous().view(-1)), nv.ptr(img), int(rendered), mean, std, nv.ptr_array(ps), B, Cin, H, W,
+                        nv.ptr(ws), nv.ptr_array(grads), nv.ptr(grad_img), nv.stream(), nv.stream() if side is None else side.cuda_stream)
         finally:
             if mode_now != ctx.dec_mode:
                 nv.call("dec_set_mode", mode_now)
-        return (grad_img, None, None, *grads)
+        return (grad_img, None, None, None, *grads)
 
 
 class ConvBNRelu(nn.Module):
@@ -211,20 +227,23 @@ class HiddenDecoder_multi_views(nn.Module):
             params += [c.weight, bn.weight, bn.bias]
         return bns[0].eps, params + [self.linear.weight, self.linear.bias]
 
-    def decode_rendered(self, image):
-        """The training step's `msg_decoder(normalize_img(clamp(image, 0, 1).permute(0, 3, 1, 2)))` for the compositor's
-        [B, H, W, 3] blocks (utils_wtmk_disen.py:599-603) -> (decoded [B, 1], clamped image).  On the GPU the clamp, the
-        layout change and the normalisation are part of the fused decoder's first layer."""
+    def decode_rendered(self, image, distortion=None):
+        """The training step's `msg_decoder(normalize_img(distortion_layer(clamp(image, 0, 1)).permute(0, 3, 1, 2)))` for the compositor's
+        [B, H, W, 3] blocks (utils_wtmk_disen.py:592-595) -> (decoded [B, 1], clamped image).  On the GPU the clamp, the distortion
+        (noise / brightness / blurring: distortion.DistortionLayer with this step's draws in its buffers), the layout change and the
+        normalisation are part of the fused decoder's first layer."""
         fused = self._fused_params(image.shape[0], image.shape[3], image.shape[1], image.shape[2], image) if image.dim() == 4 and image.shape[3] <= 3 else None
-        if fused is not None:
-            return _FusedDecoder.apply(image, fused[0], True, *fused[1])
+        native = distortion is not None and distortion.native
+        if fused is not None and (distortion is None or native or distortion.name == "none"):
+            return _FusedDecoder.apply(image, fused[0], True, distortion if native else None, *fused[1])
         pred = torch.clamp(image, min=0, max=1)
-        return self(normalize_img(pred.permute(0, 3, 1, 2))), pred
+        dist = pred if distortion is None else distortion(pred, raw=image)
+        return self(normalize_img(dist.permute(0, 3, 1, 2))), pred
 
     def forward(self, img_w):
         fused = self._fused_params(*img_w.shape, img_w) if img_w.dim() == 4 else None
         if fused is not None:
-            return _FusedDecoder.apply(img_w, fused[0], False, *fused[1])   # num_bits = redundancy = 1: the view/sum below is the identity
+            return _FusedDecoder.apply(img_w, fused[0], False, None, *fused[1])   # num_bits = redundancy = 1: the view/sum below is the identity
         x = self.layers(img_w).squeeze(-1).squeeze(-1)
         x = self.linear(x)
         x = x.view(-1, self.num_bits, self.redundancy)

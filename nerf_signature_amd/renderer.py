@@ -21,29 +21,27 @@ def custom_meshgrid(*args):
 
 
 def sample_pdf(bins, weights, n_samples, det=False):
-    """Inverse-CDF samples of the piecewise-constant density `weights` over `bins` (renderer_wtmk.py:12-47; NeRF's):
-    bins [B, T] (old depths), weights [B, T - 1] -> new depths [B, n_samples].  det: evenly spaced quantiles instead of random ones."""
-    weights = weights + 1e-5
-    pdf = weights / torch.sum(weights, -1, keepdim=True)
-    cdf = torch.cumsum(pdf, -1)
-    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    """Importance re-sampling of depths: `n_samples` quantiles of the piecewise-constant density `weights` [B, T-1] over the
+    intervals between `bins` [B, T], by inverting its CDF (what renderer_wtmk.py:12-47 computes; same 1e-5 floors, and in the
+    random mode the same single host-side torch.rand draw of B x n_samples numbers, so seeded runs consume the generator alike).
+    det: the midpoints of n_samples equal quantile intervals instead of random quantiles.  Returns [B, n_samples]."""
+    B, T = bins.shape
+    mass = weights + 1e-5
+    cdf = torch.zeros(B, T, dtype=mass.dtype, device=mass.device)
+    torch.cumsum(mass / mass.sum(-1, keepdim=True), -1, out=cdf[:, 1:])
     if det:
-        u = torch.linspace(0.0 + 0.5 / n_samples, 1.0 - 0.5 / n_samples, steps=n_samples).to(weights.device)
-        u = u.expand(list(cdf.shape[:-1]) + [n_samples])
+        q = ((torch.arange(n_samples, dtype=mass.dtype) + 0.5) / n_samples).to(mass.device).expand(B, n_samples)
     else:
-        u = torch.rand(list(cdf.shape[:-1]) + [n_samples]).to(weights.device)
-    u = u.contiguous()
-    inds = torch.searchsorted(cdf, u, right=True)
-    below = torch.max(torch.zeros_like(inds - 1), inds - 1)
-    above = torch.min((cdf.shape[-1] - 1) * torch.ones_like(inds), inds)
-    inds_g = torch.stack([below, above], -1)
-    shape = [inds_g.shape[0], inds_g.shape[1], cdf.shape[-1]]
-    cdf_g = torch.gather(cdf.unsqueeze(1).expand(shape), 2, inds_g)
-    bins_g = torch.gather(bins.unsqueeze(1).expand(shape), 2, inds_g)
-    denom = cdf_g[..., 1] - cdf_g[..., 0]
-    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
-    t = (u - cdf_g[..., 0]) / denom
-    return bins_g[..., 0] + t * (bins_g[..., 1] - bins_g[..., 0])
+        q = torch.rand(B, n_samples).to(mass.device)
+    q = q.contiguous()
+    hi = torch.searchsorted(cdf, q, right=True)          # first knot whose CDF exceeds the quantile
+    lo = (hi - 1).clamp_(min=0)
+    hi = hi.clamp_(max=T - 1)
+    c_lo, c_hi = torch.take_along_dim(cdf, lo, -1), torch.take_along_dim(cdf, hi, -1)
+    z_lo, z_hi = torch.take_along_dim(bins, lo, -1), torch.take_along_dim(bins, hi, -1)
+    span = c_hi - c_lo
+    span = torch.where(span < 1e-5, torch.ones_like(span), span)       # an (almost) empty interval: keep its left end
+    return z_lo + (q - c_lo) / span * (z_hi - z_lo)
 
 
 _BG_CONST = {}
@@ -243,9 +241,10 @@ class NeRFRenderer(nn.Module):
                 new_z = sample_pdf(z_mid, w0[:, 1:-1], upsample_steps, det=not self.training).detach()
                 new_pts = torch.min(torch.max(o.unsqueeze(-2) + d.unsqueeze(-2) * new_z.unsqueeze(-1), aabb[:3]), aabb[3:])
             t = upsample_steps
-            if differentiable:       # no message: the clean field, nothing to differentiate (renderer_wtmk.py:187)
-                with torch.no_grad():
-                    s_new, c_new = self(new_pts.reshape(-1, 3), dirs_of(new_pts), None)
+            if differentiable:
+                # no message: the clean field (renderer_wtmk.py:187).  Evaluated with gradients enabled like the reference's call; in this network
+                # every parameter such a pass reads is frozen (network_wtmk_tcnn.py:90-95), so autograd records nothing for it
+                s_new, c_new = self(new_pts.reshape(-1, 3), dirs_of(new_pts), None)
                 new_sigma, new_rgb = s_new.view(N, t), c_new.view(N, t, 3)
             else:
                 nf = self.density(new_pts.reshape(-1, 3))

@@ -17,6 +17,7 @@ from . import _native as nv
 from . import fieldops as fo
 from . import dp
 from .dp import GradExchange, exchange_active, world_size
+from .distortion import DistortionLayer
 from .hidden_models import normalize_img, set_grad_arena, set_weights_stream
 
 
@@ -89,6 +90,19 @@ def backward_from_loss_kernel(out, content_scale=1.0, content_stream=None, conte
         torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
 
 
+def join_stream(main, other):
+    """main.wait_stream(other) -- except while `main` is capturing and `other` was never forked into that capture (it then holds no work of the
+    step, and a captured stream must not wait for an event recorded outside its capture)."""
+    if other is None or other is main:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        with torch.cuda.stream(other):
+            forked = torch.cuda.is_current_stream_capturing()
+        if not forked:
+            return
+    main.wait_stream(other)
+
+
 def local_blocks(wm):
     """The watermark-block rays this rank renders: all of them, or its shard (dp.block_shard) as views of the same tensors.
     Returns (rays_o, rays_d, shard or None)."""
@@ -105,9 +119,12 @@ def srgb_to_linear(x):
 
 
 def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce, side_stream=None, presum_first=False,
-               presum_adopt=False, color_space="srgb", blocks_first=False, content_backward_now=None):
+               presum_adopt=False, color_space="srgb", blocks_first=False, content_backward_now=None, distortion=None):
     """data = {'watermark': {'rays_o_block', 'rays_d_block'}, 'content': {'rays_o', 'rays_d', 'images'}}.
     Returns (pred_rgb, gt_rgb, content_pred_rgb, lossi, lossw, loss) like the reference.
+
+    distortion: the reference's `--distortion` (utils_wtmk_disen.py:551-577,594): a name (none | noise | rotation | scaling | blurring |
+    brightness; this call then draws the step's random parameters) or a distortion.DistortionLayer whose owner has drawn them (the loops).
 
     side_stream: a torch.cuda.Stream on which the content render is issued.  It depends on nothing the block render or the
     decoder produce, and both chains are sequences of small latency-bound launches, so they overlap (forward and -- autograd
@@ -166,11 +183,16 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
             main.wait_stream(side_stream)
             new_segment = True
         image = dp.gather_blocks(image, wm["rays_o_block"].shape[0], shard[0])
+    if isinstance(distortion, str):
+        distortion = DistortionLayer(distortion) if distortion != "none" else None
+        if distortion is not None:
+            distortion.draw(tuple(image.shape), image.device)
     if model.normalization is normalize_img and hasattr(model.msg_decoder, "decode_rendered"):
-        decoded, pred_rgb = model.msg_decoder.decode_rendered(image)    # clamp + permute + normalise inside layer 0
+        decoded, pred_rgb = model.msg_decoder.decode_rendered(image, distortion)    # clamp + distortion + permute + normalise inside layer 0
     else:
         pred_rgb = torch.clamp(image, min=0, max=1)
-        decoded = model.msg_decoder(model.normalization(pred_rgb.permute(0, 3, 1, 2)))
+        pred_rgb_dist = pred_rgb if distortion is None else distortion(pred_rgb, raw=image)
+        decoded = model.msg_decoder(model.normalization(pred_rgb_dist.permute(0, 3, 1, 2)))
     if color_space == "linear":      # utils_wtmk_disen.py:603-604: converted IN PLACE, every step, as the reference does (its loader hands out fresh tensors)
         content["images"][..., :3] = srgb_to_linear(content["images"][..., :3])
     if content["images"].shape[-1] != 3:
@@ -189,9 +211,11 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
         content_pred_rgb = content_pred_rgb.detach()
         if not new_segment:       # (both streams met in front of the collective; the event belongs to the finished segment)
             main.wait_event(content_done)
-    elif main is not None:
+    elif main is not None and not new_segment:
+        # (new_segment: both streams already met in front of the collective and the side stream has not been forked into the new capture segment --
+        #  waiting for it here would make the capturing stream depend on an event recorded outside the capture)
         main.wait_stream(side_stream)
-    else:
+    elif main is None:
         content_pred_rgb = model.render(content["rays_o"], content["rays_d"], message, **kw)["image"]
     keys = message.to(decoded.device).unsqueeze(-1)
     if loss_w is loss_w_bce and decoded.is_cuda and all(t.dtype == torch.float32 for t in (content_pred_rgb, gt_rgb, decoded, keys)) \
@@ -252,7 +276,9 @@ test_step.__test__ = False      # (not a pytest test, whatever its name)
 class WatermarkLoop:
     """Loop body of train_one_epoch (utils_wtmk_disen.py:1164-1181) for one model replica."""
 
-    def __init__(self, model, optimizer, render_kwargs, lambda_w=1.0, lambda_i=1.0, lr_scheduler=None, use_sink=True, side_stream=None):
+    def __init__(self, model, optimizer, render_kwargs, lambda_w=1.0, lambda_i=1.0, lr_scheduler=None, use_sink=True, side_stream=None, distortion="none",
+                 distortion_seed=0):
+        self.distortion = None if distortion in (None, "none") else (distortion if isinstance(distortion, DistortionLayer) else DistortionLayer(distortion, distortion_seed))
         self.side_stream = side_stream
         self.plan_stream = side_stream   # scatter plans queue behind the content render
         self.model, self.optimizer, self.lr_scheduler = model, optimizer, lr_scheduler
@@ -275,9 +301,12 @@ class WatermarkLoop:
         self.optimizer.zero_grad(set_to_none=True)
         if self.sink is not None:
             self.sink.zero_()
+        if self.distortion is not None:      # this step's random draws (all D blocks reach the decoder, sharded or not)
+            o = data["watermark"]["rays_o_block"]
+            self.distortion.draw(tuple(o.shape), o.device)
         prev = fo.set_plan_stream(self.plan_stream)    # the scatter plans of both renders leave the critical path too
         try:
-            out = train_step(self.model, data, message, self.render_kwargs, self.lambda_w, self.lambda_i, side_stream=self.side_stream)
+            out = train_step(self.model, data, message, self.render_kwargs, self.lambda_w, self.lambda_i, side_stream=self.side_stream, distortion=self.distortion)
         finally:
             fo.set_plan_stream(prev)
         sharded = self._sharded(data)
@@ -360,8 +389,11 @@ class GraphedWatermarkLoop:
 
     def __init__(self, model, optimizer, render_kwargs, data, lambda_w=1.0, lambda_i=1.0, lr_lambda=None, headroom=0.0, native_dense_adam=True,
                  overlap_content=True, march_ahead=None, presum_in_adam=True, stage_in_graph=True, content_headroom=None, content_ahead=None,
-                 content_sampler=None, fixed_blocks=None, encode_ahead=None):
-        """presum_in_adam: the captured optimiser kernel also writes the pre-summed codebook of the NEXT step's message
+                 content_sampler=None, fixed_blocks=None, encode_ahead=None, distortion="none", distortion_seed=0):
+        """distortion: noise | brightness | blurring run inside the captured step -- the layer is part of the decoder's first launch and its random
+        parameters are re-drawn on the device every replay (wm_distort_draw, keyed by distortion_seed and the replay count); rotation / scaling are
+        host-driven stock operators (scaling changes the decoder's input shape): WatermarkLoop only.
+        presum_in_adam: the captured optimiser kernel also writes the pre-summed codebook of the NEXT step's message
         (opt_codebook_adam_sel_next: +9 % traffic inside an HBM-streaming kernel instead of a 128 MiB pass at the head of every step).
         The next message is handed over one step early -- `step(message_k, next_message=message_k1)`, a one-element look-ahead over
         the random draws of utils_wtmk_disen.py:1165; a step whose message was not announced runs the stand-alone pre-sum before
@@ -374,6 +406,10 @@ class GraphedWatermarkLoop:
         `step(..., data=...)` still works -- it re-marches before the replay, un-overlapped.  The content render's march stays
         at the head of its own step on the side stream: next to the optimiser as well, the two marches took longer than the
         optimiser and the pre-sum lost its cover."""
+        self.distortion = None if distortion in (None, "none") else (distortion if isinstance(distortion, DistortionLayer) else DistortionLayer(distortion, distortion_seed))
+        if self.distortion is not None and not self.distortion.native:
+            raise NotImplementedError(f"distortion {self.distortion.name!r} is applied by host-driven stock operators (per-image host draws; 'scaling' changes the "
+                                      f"decoder's input width every step): use the eager WatermarkLoop for it")
         if march_ahead is None and os.environ.get("NERFSIG_MARCH_AHEAD") in ("0", "1"):
             march_ahead = os.environ["NERFSIG_MARCH_AHEAD"] == "1"
         self.march_ahead = overlap_content if march_ahead is None else bool(march_ahead)
@@ -555,6 +591,9 @@ class GraphedWatermarkLoop:
         if self.content_sampler is not None:
             ct = self.data["content"]
             self.content_sampler.sample_into(self.stage_counter, ct["rays_o"], ct["rays_d"], ct["images"])
+        if self.distortion is not None:      # this step's draws, from (seed, replay count): the same on every rank
+            o = self.data["watermark"]["rays_o_block"]
+            self.distortion.draw_on_device(self.stage_counter, tuple(o.shape), o.device)
         prev = fo.set_plan_stream(self.plan_stream)    # the scatter plans need the sample positions only: beside the forward pass
         try:
             out = train_step(self.model, self.data, self.msg_dev, self.render_kwargs, self.lambda_w, self.lambda_i, side_stream=self.side_stream,
@@ -562,7 +601,8 @@ class GraphedWatermarkLoop:
                              presum_adopt=self.presum_in_adam and torch.cuda.is_current_stream_capturing(),
                              blocks_first=self.side_stream is not None and self._blocks_issued_first(),
                              content_backward_now=(self.lambda_i * dp.content_grad_scale(self.sharded)) if (self.content_backward_first and
-                                                   self.side_stream is not None and os.environ.get("NERFSIG_CONTENT_BWD_NOW", "1") == "1") else None)
+                                                   self.side_stream is not None and os.environ.get("NERFSIG_CONTENT_BWD_NOW", "1") == "1") else None,
+                             distortion=self.distortion)
         finally:
             fo.set_plan_stream(prev)
         set_weights_stream(self.weights_stream)
@@ -572,10 +612,10 @@ class GraphedWatermarkLoop:
         finally:
             set_weights_stream(None)
             set_grad_arena(None)
-        if self.side_stream is not None:   # the content render's backward ends in a side effect (the shared gradient): join it explicitly
-            torch.cuda.current_stream().wait_stream(self.side_stream)
-        if self.weights_stream is not None and self.weights_stream is not self.side_stream:
-            torch.cuda.current_stream().wait_stream(self.weights_stream)
+        # the content render's backward ends in a side effect (the shared gradient): join it explicitly; likewise the decoder's parameter gradients
+        join_stream(torch.cuda.current_stream(), self.side_stream)
+        if self.weights_stream is not self.side_stream:
+            join_stream(torch.cuda.current_stream(), self.weights_stream)
         return out
 
     def _optimise(self, defer_collective=False):

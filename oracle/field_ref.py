@@ -345,12 +345,40 @@ def normalize_img(x):
     return (x - mean) / std
 
 
-def train_step(block_o, block_d, content_o, content_d, gt_rgb, message, P, S, decoder, lambda_w=1.0, lambda_i=1.0, **kw):
-    """Trainer.train_step with distortion 'none', 3-channel images and loss_w='bce',
-    nerf/utils_wtmk_disen.py:579-646 (+ :441 for the loss)."""
+def distortion_layer(pred_rgb, distortion, draw=None):
+    """Trainer.distortion_layer, nerf/utils_wtmk_disen.py:551-577, on the clamped blocks [B,H,W,3], with the call's random draw PASSED IN:
+    noise      draw = the N(0, 0.1) tensor of :555 (`torch.normal(0, sqrt(0.1), size=pred_rgb.shape)`), added (:556);
+    brightness draw = the factor f of torchvision ColorJitter(brightness=0.5) (:573-575; one f ~ U[0.5, 1.5] per call, `adjust_brightness` =
+               blend with a black image, clamped to [0, 1] for float images);
+    blurring   draw = the sigma of torchvision GaussianBlur(kernel_size=3, sigma=(0.01, 0.5)) (:568-570; one sigma ~ U[0.01, 0.5] per call):
+               1-d kernel exp(-0.5 (x / sigma)^2) at x = linspace(-1, 1, 3), normalised; 2-d = outer product; reflect padding of 1; depthwise conv.
+    (torchvision is not installed in this image: its two transforms are restated from their published implementation,
+    torchvision/transforms/_functional_tensor.py `_blend` / `_get_gaussian_kernel1d` / `gaussian_blur`.)"""
+    if distortion in (None, "none"):
+        return pred_rgb                                                  # :553
+    if distortion == "noise":
+        return pred_rgb + draw                                           # :556
+    x = pred_rgb.permute(0, 3, 1, 2)                                     # :567 / :572
+    if distortion == "brightness":
+        y = (float(draw) * x + (1.0 - float(draw)) * torch.zeros_like(x)).clamp(0, 1)
+    elif distortion == "blurring":
+        sigma = float(draw)
+        k1 = torch.exp(-0.5 * (torch.linspace(-1.0, 1.0, 3, dtype=x.dtype) / sigma) ** 2)
+        k1 = k1 / k1.sum()
+        k2 = (k1[:, None] * k1[None, :]).expand(x.shape[1], 1, 3, 3)
+        y = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (1, 1, 1, 1), mode="reflect"), k2, groups=x.shape[1])
+    else:
+        raise NotImplementedError(distortion)
+    return y.permute(0, 2, 3, 1)                                         # :571 / :576
+
+
+def train_step(block_o, block_d, content_o, content_d, gt_rgb, message, P, S, decoder, lambda_w=1.0, lambda_i=1.0, distortion=None, draw=None, **kw):
+    """Trainer.train_step with 3-channel images and loss_w='bce', nerf/utils_wtmk_disen.py:579-646 (+ :441 for the loss).
+    distortion / draw: see distortion_layer."""
     out = run_cuda_train(block_o, block_d, message, P, S, bg_color=1, **kw)
     pred = torch.clamp(out["image"], min=0, max=1)                    # :592
-    decoded = decoder(normalize_img(pred.permute(0, 3, 1, 2)))         # :595
+    pred_dist = distortion_layer(pred, distortion, draw)               # :594
+    decoded = decoder(normalize_img(pred_dist.permute(0, 3, 1, 2)))    # :595
     cont = run_cuda_train(content_o, content_d, message, P, S, bg_color=1, **kw)  # :616
     lossi = ((cont["image"] - gt_rgb) ** 2).mean()                     # :638 (MSELoss(reduction='none').mean())
     lossw = torch.nn.functional.binary_cross_entropy_with_logits(decoded * 10.0, message.unsqueeze(-1), reduction="mean")  # :441,641

@@ -328,6 +328,18 @@ def test_split_graphs_with_rccl_exchange_rehearsed_on_one_rank():
         os.environ["NERFSIG_CAPTURE_COLLECTIVES"] = "1"
         loop2, l2, t2 = run()
         assert len(loop2.segments) == 1 and len(loop2.between) == 0 and loop2.sharded and loop2.content_backward_first
+        # segmented capture (the all-gather ends a segment) with schedules in which no early content backward exists -- the main stream
+        # must not wait for the side stream again in the new segment (an event recorded outside the capture)
+        extra = []
+        for env in ({"NERFSIG_BACKWARD_SCHEDULE": "tail"}, {"NERFSIG_CONTENT_BWD_NOW": "0"}):
+            os.environ.update(env, NERFSIG_CAPTURE_COLLECTIVES="0")
+            try:
+                loop3, l3, t3 = run()
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+            assert len(loop3.segments) == 3 and loop3.sharded
+            extra.append(l3)
     finally:
         os.environ.pop("NERFSIG_FORCE_EXCHANGE", None)
         os.environ.pop("NERFSIG_CAPTURE_COLLECTIVES", None)
@@ -335,6 +347,8 @@ def test_split_graphs_with_rccl_exchange_rehearsed_on_one_rank():
             dist.destroy_process_group()
     np.testing.assert_allclose(l1, l0, rtol=2e-3, atol=2e-4)
     np.testing.assert_allclose(l2, l0, rtol=2e-3, atol=2e-4)
+    for l3 in extra:
+        np.testing.assert_allclose(l3, l0, rtol=2e-3, atol=2e-4)
     assert float((t1 - t0).norm()) <= 0.05 * float((t0 - torch.cat([torch.from_numpy(cf.table(100 + l, scale=0.05)).reshape(-1) for l in range(64)]).cuda()).norm())
 
 

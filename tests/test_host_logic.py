@@ -464,10 +464,13 @@ def _sharded_checkpoint_worker(rank, world, port, q, tmp):
         model._select(torch.zeros(D))
     except RuntimeError:
         select_refused = True
-    state = checkpoint.checkpoint_state(model, optimizer=opt, full=True)        # collective: both ranks enter
-    assert not model._codebook_stale
-    if rank == 0:
-        torch.save(state, os.path.join(tmp, "sharded.pth"))
+    # save_checkpoint itself is the collective call -- both ranks make it, rank 0 alone writes, and the other rank returns
+    # only once the file exists
+    path = os.path.join(tmp, "sharded.pth")
+    checkpoint.save_checkpoint(path, model, optimizer=opt, full=True)
+    assert not model._codebook_stale and os.path.exists(path)
+    writers = [f for f in os.listdir(tmp) if f.endswith(".pth")]
+    assert writers == ["sharded.pth"]
     q.put((rank, refused, select_refused))
     dist.barrier()
     dist.destroy_process_group()
@@ -596,3 +599,36 @@ def test_tcnn_layout_checker_recovers_every_hypothesis_and_agrees_with_the_oracl
         s1, c1 = tool.evaluate(feat, d, sp, cp, tool.ASSUMED)
         np.testing.assert_allclose(s1.numpy(), s0.numpy(), rtol=2e-5, atol=1e-6)
         np.testing.assert_allclose(c1.numpy(), c0.numpy(), rtol=0, atol=2e-6)
+
+
+def test_distortion_layer_host_side_matches_the_oracle_restatement():
+    """nerf_signature_amd.distortion's stock-operator forms (CPU) against the oracle's restatement of Trainer.distortion_layer
+    (utils_wtmk_disen.py:551-577) with the same draws; the rotation's resampling on cases with a known answer; the reference's choice list."""
+    import math
+    import numpy as np
+    import pytest
+    from oracle import field_ref as fr
+    from nerf_signature_amd import distortion as ds
+    rng = np.random.RandomState(0)
+    x = torch.from_numpy(rng.rand(4, 6, 5, 3).astype(np.float32))
+    noise = torch.from_numpy(rng.randn(4, 6, 5, 3).astype(np.float32)) * math.sqrt(0.1)
+    assert torch.equal(ds.reference_ops(x, "noise", None, noise), fr.distortion_layer(x, "noise", noise))
+    for f in (0.5, 0.93, 1.5):
+        assert torch.allclose(ds.reference_ops(x, "brightness", torch.tensor([f])), fr.distortion_layer(x, "brightness", f), atol=1e-7)
+    for s in (0.01, 0.2, 0.5):
+        assert torch.allclose(ds.reference_ops(x, "blurring", torch.tensor([s])), fr.distortion_layer(x, "blurring", s), atol=1e-7)
+    img = torch.arange(3 * 5 * 5, dtype=torch.float32).reshape(3, 5, 5)
+    assert torch.equal(ds.rotate_nearest(img, 0.0), img)
+    assert torch.equal(ds.rotate_nearest(img, 90.0), torch.rot90(img, 1, (1, 2)))           # counter-clockwise, like torchvision's `angle`
+    r30 = ds.rotate_nearest(torch.ones(3, 12, 12), 30.0)
+    assert float(r30[:, 5:7, 5:7].min()) == 1.0 and float(r30[:, 0, 0].max()) == 0.0              # centre kept, corners filled with zeros
+    layer = ds.DistortionLayer("scaling", seed=1)
+    out = layer(x)
+    assert out.shape[0] == 4 and out.shape[1] == 6 and out.shape[3] == 3 and 3 <= out.shape[2] <= 6      # resized along W only (:564: a [3,H,W] image is a 1-d batch)
+    for name in ("none", "noise", "rotation", "scaling", "blurring", "brightness"):       # main_nerf_wtmk.py:75
+        ds.DistortionLayer(name)
+    with pytest.raises(ValueError):
+        ds.DistortionLayer("jpeg")
+    a, b = ds.DistortionLayer("brightness", seed=5), ds.DistortionLayer("brightness", seed=5)      # rank-consistent draws: same seed, same sequence
+    a.draw((2, 2, 2, 3), torch.device("cpu")), b.draw((2, 2, 2, 3), torch.device("cpu"))
+    assert float(a.param) == float(b.param) and 0.5 <= float(a.param) <= 1.5
