@@ -729,12 +729,15 @@ def bench_training(args, scene, real_stdout, secondary=None):
     gather_launch = 16 * 64 if split_encoder else gather_impl   # encode-ahead: the timed launch gathers the 16 base levels; the codebook level is its own 64 B/point launch
     gather_ref = 16 * 64 + 64 * D                  # the reference algorithm's D separate codebook gathers (side value only)
     achieved = pts_big * gather_launch / enc_s if enc_s > 0 else 0.0
-    traffic, l1_model = None, None
+    traffic, l1_model, traffic_source = None, None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:   # HBM bytes per launch of the same kernel on the same inputs, from a separate rocprofv3 --pmc run (profiles/)
             counters = json.load(open(pmc))
             traffic = counters.get("k_encode_planes_hbm_bytes_per_launch")
+            # NOT measured by this run: counters need their own rocprofv3 passes (tools/pmc_step.sh); the file says at which round / commit they were taken
+            traffic_source = {"file": "profiles/pmc_traffic.json", "round": counters.get("round"), "commit": counters.get("commit"),
+                              "context": "the launch at the head of the step, behind the optimiser + warm-up pass (tools/pmc_step.py)" if counters.get("round") else "stand-alone launches (rounds 1-2)"}
             # what actually bounds the launch: the CU's vector-L1 pipe looks up one line per clock and fills a missing one
             # in 2.4 clk (tools/micro/gather_rate.hip); counters of the block render's launch (17 levels, 1.29 M points)
             enc = counters.get("k_encode_planes", {})
@@ -797,7 +800,10 @@ def bench_training(args, scene, real_stdout, secondary=None):
             "bound": "l1_lookup", "priced_against": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
             "frac_hbm_implemented_bytes": achieved / HBM_PEAK,
             "frac_of_measured_copy_ceiling": achieved / 6.29e12,      # (6.29 TB/s: the stream-copy rate MI355X_MICROARCH.md measures)
-            "traffic": traffic,
+            "traffic": traffic, "traffic_source": traffic_source,
+            # the SURVEY 8(d) formula's bytes (D separate codebook gathers: 3072 B/point) over the same time: > 1 because the kernel does not move them
+            # (pre-summed codebook) -- both bases side by side in the driver's record
+            "reference_algorithm_frac": (pts_big * gather_ref / enc_s / HBM_PEAK) if (enc_s > 0 and not split_encoder) else None,
             "launches": enc_n, "avg_launch_s": enc_s, "points_per_launch": pts_big, "rows_per_launch": enc_rows,
             "algorithmic_bytes_per_point": gather_launch,
             "basis": ("bytes of the IMPLEMENTED algorithm, this launch: the 16 base levels, 8 corners x 8 B (the pre-summed codebook level is gathered by its own launch at the "

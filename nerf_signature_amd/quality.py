@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import blocks, rays, synthetic, trainer
+from .distortion import DistortionLayer
 from .trainer import BIT_ACC, PSNRMeter
 
 README = dict(iters=1000, lambda_w=0.005, lambda_i=1.0, lr=1e-2)       # README.md:45 + main_nerf_wtmk.py:21
@@ -155,9 +156,10 @@ def test_bitacc(stage, n_messages=200, seed=4321, distortion="none"):
     gen = torch.Generator(device="cpu").manual_seed(seed)
     wm = {"rays_o_block": stage["block_o"], "rays_d_block": stage["block_d"]}
     wrong = []
+    layer = None if distortion in (None, "none") else DistortionLayer(distortion, seed)
     for _ in range(n_messages):
         message = torch.randint(0, 2, (D,), generator=gen).float().to(dev)
-        _, _, _, decoded, _, _, _ = trainer.eval_step(model, wm, message, stage["render_kwargs"], render_whole=False)
+        _, _, _, decoded, _, _, _ = trainer.eval_step(model, wm, message, stage["render_kwargs"], render_whole=False, distortion=layer)
         acc.update(decoded.permute(1, 0), message.unsqueeze(0))
         wrong.append(round((1.0 - acc.instant_V) * D))
     return float(acc.measure()), float(np.mean(wrong)), int(np.max(wrong))
@@ -192,10 +194,14 @@ def run(mode="graphed", steps=None, scene="hotdog", n_messages=200, **train_kw):
     rec = train(stage, steps, mode, **train_kw)
     t0 = time.perf_counter()
     acc, wrong_mean, wrong_max = test_bitacc(stage, n_messages)
+    distorted = None
+    if train_kw.get("distortion", "none") != "none":      # the reference's eval_step distorts the evaluated blocks too (utils_wtmk_disen.py:666)
+        distorted = test_bitacc(stage, n_messages, distortion=train_kw["distortion"])[0]
     psnr = test_image(stage)
     torch.cuda.synchronize()
     sel = [c for c in rec["adam_steps"]]
     return {"mode": mode, "steps": rec["steps"], "bit_acc": acc, "wrong_bits_mean": wrong_mean, "wrong_bits_worst_message": wrong_max, "psnr_db": psnr,
+            **({} if distorted is None else {"bit_acc_distorted_blocks": distorted}),
             "wall_s": rec["wall_s"], "capture_s": rec["prepare_s"], "train_ms_per_step": rec["ms_per_step"], "eval_wall_s": time.perf_counter() - t0, "bit_acc_before_training": before,
             "n_messages": n_messages, "n_test_views": int(stage["test_poses"].shape[0]), "overflowed": rec["overflowed"], "recaptures": rec["recaptures"],
             "adam_steps_total": sum(sel), "adam_steps_min_max": [min(sel), max(sel)], "loss_image": rec["loss_image"], "loss_watermark": rec["loss_watermark"],

@@ -230,8 +230,9 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
     return pred_rgb, gt_rgb, content_pred_rgb, lossi, lossw, loss
 
 
-def eval_step(model, data, message, render_kwargs, render_whole=True, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce, color_space="srgb"):
-    """Trainer.eval_step (utils_wtmk_disen.py:648-702) for its default configuration (3-channel images, srgb, distortion 'none').
+def eval_step(model, data, message, render_kwargs, render_whole=True, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce, color_space="srgb", distortion=None):
+    """Trainer.eval_step (utils_wtmk_disen.py:648-702) for 3-channel images / srgb.  distortion: as in train_step -- the reference applies its
+    distortion layer to the evaluated blocks as well (:666), with a fresh draw per call.
     render_whole=False: the watermark blocks rendered with the message, decoded, BCE against the message (+ MSE against
     data['images_block'] when given) -- what test_bitacc evaluates; render_whole=True: the full view staged in max_ray_batch chunks
     (`render(staged=True)`) against data['images'] -- what test_image evaluates.  The reference never calls model.eval() on these
@@ -244,7 +245,13 @@ def eval_step(model, data, message, render_kwargs, render_whole=True, lambda_w=1
     if not render_whole:
         out = model.render(data["rays_o_block"], data["rays_d_block"], message, staged=False, bg_color=1, perturb=False, force_all_rays=True, **kw)
         pred_rgb, pred_depth = torch.clamp(out["image"], min=0, max=1), out["depth"]
-        decoded = model.msg_decoder(model.normalization(pred_rgb.permute(0, 3, 1, 2)))
+        if isinstance(distortion, str):
+            distortion = DistortionLayer(distortion) if distortion != "none" else None
+        pred_rgb_dist = pred_rgb
+        if distortion is not None:
+            distortion.draw(tuple(pred_rgb.shape), pred_rgb.device)
+            pred_rgb_dist = distortion(pred_rgb)
+        decoded = model.msg_decoder(model.normalization(pred_rgb_dist.permute(0, 3, 1, 2)))
         gt_rgb = data.get("images_block")
         if gt_rgb is not None:
             lossi = ((pred_rgb - gt_rgb) ** 2).mean()

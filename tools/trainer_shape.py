@@ -1,0 +1,88 @@
+"""The training loop a user of the UNCHANGED reference CLI gets: the reference Trainer's loop body (nerf/utils_wtmk_disen.py:1164-1190) around this
+repo's model -- per step a device-side torch.randint message, optimizer.zero_grad(), train_step under autocast(fp16), GradScaler scale / step /
+update, LambdaLR step, three loss.item() reads -- with the optimiser main_nerf_wtmk.py:110 builds (plain torch.optim.Adam over get_params) and the
+loader's per-step work (a new pose, torch.randint pixels, the reference's meshgrid-style get_rays, the ground-truth gather: provider_wtmk.py collate).
+Nothing here is captured or looked ahead.   usage: python tools/trainer_shape.py [--steps 200] [--no-fp16] [--profile] [--fix-rays]
+Prints one JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=200)
+ap.add_argument("--warmup", type=int, default=10)
+ap.add_argument("--no-fp16", action="store_true")
+ap.add_argument("--profile", action="store_true")
+ap.add_argument("--fix-rays", action="store_true", help="the one call INTEGRATION.md section 5 offers: model.fix_rays(block rays)")
+ap.add_argument("--no-item", action="store_true", help="skip the three per-step loss.item() reads (diagnostics)")
+args = ap.parse_args()
+
+from nerf_signature_amd import quality, synthetic, trainer
+
+real_stdout = os.dup(1)
+os.dup2(2, 1)
+stage = quality.watermark_stage("hotdog")
+model, dev, D, H, W = stage["model"], stage["device"], stage["D"], stage["H"], stage["W"]
+opt_ns = dict(stage["render_kwargs"], num_rays=4096, lr=1e-2, workspace="x", fp16=not args.no_fp16)      # vars(opt) is splatted into render()
+optimizer = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)                       # main_nerf_wtmk.py:110
+scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lambda it: 0.1 ** min(it / 1000, 1))             # :115
+scaler = torch.cuda.amp.GradScaler(enabled=not args.no_fp16)                                             # utils_wtmk_disen.py:495
+wm = {"rays_o_block": stage["block_o"], "rays_d_block": stage["block_d"]}
+if args.fix_rays:
+    model.fix_rays(wm["rays_o_block"], wm["rays_d_block"], opt_ns["dt_gamma"], opt_ns["max_steps"])
+poses, clean, intr = stage["poses"], stage["clean"], stage["intr"]
+
+
+def loader(k):
+    p = k % poses.shape[0]
+    inds = torch.randint(0, H * W, size=[4096], device=dev).expand([1, 4096])                            # utils_wtmk_disen.py:105
+    o, d = synthetic.get_rays(poses[p:p + 1], intr, H, W, inds)                                           # the reference's meshgrid formulation (:59-143)
+    images = torch.gather(clean[p:p + 1], 1, torch.stack(3 * [inds], -1))                                 # provider_wtmk.py collate
+    return {"watermark": wm, "content": {"rays_o": o, "rays_d": d, "images": images}}
+
+
+def step(k):
+    data = loader(k)
+    message = torch.randint(0, 2, (D,), dtype=torch.float32, device=dev)                                 # :1165
+    optimizer.zero_grad()
+    with torch.autocast("cuda", enabled=not args.no_fp16):
+        out = trainer.train_step(model, data, message, opt_ns, lambda_w=0.005, lambda_i=1.0)
+    scaler.scale(out[5]).backward()
+    scaler.step(optimizer)
+    scaler.update()
+    scheduler.step()
+    if not args.no_item:
+        return out[5].item(), out[3].item(), out[4].item()
+    return None
+
+
+for k in range(args.warmup):
+    step(k)
+torch.cuda.synchronize()
+if args.profile:
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    pr.enable()
+t0 = time.perf_counter()
+for k in range(args.steps):
+    last = step(args.warmup + k)
+torch.cuda.synchronize()
+el = time.perf_counter() - t0
+if args.profile:
+    pr.disable()
+    st = pstats.Stats(pr, stream=sys.stderr)
+    st.sort_stats("cumulative").print_stats(45)
+    st.sort_stats("tottime").print_stats(30)
+os.dup2(real_stdout, 1)
+print(json.dumps({"what": "reference Trainer loop body (utils_wtmk_disen.py:1164-1190) around this repo's model: eager, autocast(fp16) + GradScaler, plain torch.optim.Adam, "
+                          "loader-style rays per step, three .item() reads per step; NOT the headline path",
+                  "ms_per_step": el / args.steps * 1e3, "content_rays_per_s": 4096 * args.steps / el, "steps": args.steps, "fp16": not args.no_fp16,
+                  "fix_rays": bool(args.fix_rays), "loss": last[0] if last else None, "grad_scale": float(scaler.get_scale()) if not args.no_fp16 else None}), flush=True)
