@@ -298,6 +298,19 @@ def dry_launch(args):
     if hook == "hang":
         time.sleep(3600)
     rank, world, _ = dp.init_from_env(backend="gloo")
+    # first-contact check: every rank binds a GPU of its own, decided before any GPU call (no GPU here: the node is taken to have one device per
+    # rank of the launch, NERFSIG_DRY_DEVICE_COUNT overrides -- e.g. 1 to see the clash reported)
+    devices = int(os.environ.get("NERFSIG_DRY_DEVICE_COUNT", str(world)))
+    try:
+        ordinal, physical = dp.assert_distinct_devices(device_count=devices)
+    except RuntimeError as e:
+        print(f"[dry-launch] rank {rank}: {e}", file=sys.stderr)
+        raise SystemExit(5)
+    ordinals = [None] * world
+    if dist.is_initialized():
+        dist.all_gather_object(ordinals, physical)
+    else:
+        ordinals = [physical]
     D = 32
     ok = True
     shard = dp.block_shard(D)
@@ -318,7 +331,7 @@ def dry_launch(args):
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
     if rank == 0:
         print(json.dumps({"dry_launch": True, "n_gpus": world, "world_size_seen": dp.world_size(), "backend": dist.get_backend() if dist.is_initialized() else None,
-                          "block_shard_rank0": shard, "collectives_ok": bool(t.item()), "grad_exchange_bytes_per_step": ex.bytes_per_step,
+                          "block_shard_rank0": shard, "collectives_ok": bool(t.item()), "device_of_rank": ordinals, "devices_distinct": len(set(ordinals)) == world, "grad_exchange_bytes_per_step": ex.bytes_per_step,
                           "capture_collectives_env": os.environ.get("NERFSIG_CAPTURE_COLLECTIVES")}), flush=True)
     if dist.is_initialized():
         dist.barrier()
@@ -441,24 +454,27 @@ def cpu_baseline(model, D, full_step_points=None):
 
 
 def run_secondaries(args):
-    """The other single-GPU workloads of BASELINE.json, timed by THIS run so that their numbers are driver-run like the headline's: config 3
-    (counter-like scene, two cascades: ms per training step), config 5 (fern-like scene: ms per 1008x756 staged image + 48-block decode) and
-    one rank of an 8-rank job emulated on this GPU (tools/emulate_rank.py: D/8 blocks, 1/8 of the codebook optimiser, every collective of the
-    step issued on a world-size-1 RCCL group -- per-rank kernel work and launch structure without xGMI latency).  Each is a fresh child
-    process, one after the other, started and finished BEFORE this process initialises the GPU (a process that has touched the device must
-    not start others on this pool, and the headline must not share the GPU with them).  A failing child costs its own entry only."""
+    """What else the driver's run should put on record, each timed by a fresh child process, one after the other, started and finished BEFORE this
+    process initialises the GPU (a process that has touched the device must not start others on this pool, and the headline must not share
+    the GPU with them); a failing child costs its own entry only:
+      quality        the reference's whole run on this path -- 1000 captured steps with README.md:45's hyper-parameters, then Trainer.test_bitacc over 200
+                     messages and Trainer.test_image against the clean views (tools/converge.py, nerf_signature_amd/quality.py) -> the line's `quality`
+      counter, fern  BASELINE.json configs 3 and 5
+      rank_emulation one rank of 2 / 4 / 8 on this GPU, in both execution modes of the multi-rank step + fixed blocks (tools/emulate_ranks.py: kernel work and
+                     launch structure of a rank, every collective issued on a world-size-1 RCCL group, no xGMI latency)
+      eager_reference_trainer_shape   the loop a user of the UNCHANGED reference CLI drives: the reference Trainer's loop body around this repo's model,
+                     eager, autocast(fp16) + GradScaler, plain torch.optim.Adam, loader-style rays and three .item() reads per step (tools/trainer_shape.py)"""
     out = {}
     k = str(min(args.steps, 50))
     jobs = (("quality", [os.path.join(ROOT, "tools", "converge.py"), "graphed", "--steps", "1000", "--messages", "200"]),
             ("counter", [os.path.abspath(__file__), "--config", "counter", "--steps", k, "--warmup", str(min(args.warmup, 5)), "--no-cpu-baseline", "--no-secondary", "--windows", "1"]),
             ("fern", [os.path.abspath(__file__), "--config", "fern", "--steps", "5", "--warmup", "1", "--no-secondary"]),
-            ("rank_of_8_emulated", [os.path.join(ROOT, "tools", "emulate_rank.py"), "8", "--steps", k, "--warmup", str(min(args.warmup, 5)), "--no-secondary", "--windows", "1"]))
+            ("rank_emulation", [os.path.join(ROOT, "tools", "emulate_ranks.py"), "--steps", k]),
+            ("eager_reference_trainer_shape", [os.path.join(ROOT, "tools", "trainer_shape.py"), "--steps", "100"]))
     for name, argv in jobs:
         t0 = time.time()
         try:
             env = dict(os.environ, NERFSIG_BENCH_VARIANT="0")
-            if name == "rank_of_8_emulated":       # the mode the launcher's chain tries first for N > 1: the collectives captured inside the step's graph
-                env.setdefault("NERFSIG_CAPTURE_COLLECTIVES", "1")
             r = subprocess.run([sys.executable] + argv, env=env, capture_output=True, text=True, timeout=float(os.environ.get("NERFSIG_SECONDARY_TIMEOUT_S", "150")))
             lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not lines:
@@ -466,7 +482,7 @@ def run_secondaries(args):
                 continue
             j = json.loads(lines[-1])
             c = j.get("config", {})
-            if name == "quality":
+            if name in ("quality", "rank_emulation", "eager_reference_trainer_shape"):
                 out[name] = j
             elif name == "counter":
                 out[name] = {"ms_per_step": j["ms_per_step"], "content_rays_per_s": j["value"], "points_per_s": c.get("points_per_s"), "points_per_step": c.get("points_per_step_per_rank"),
@@ -477,11 +493,6 @@ def run_secondaries(args):
                 out[name] = {"ms_per_image": j["ms_per_step"], "images_per_s": j["value"], "rays_per_s": c.get("rays_per_s"), "chunks": c.get("chunks"), "steps": j["steps"],
                              "workload": "BASELINE config 5: LLFF/fern-like synthetic scene S2, 1008x756 view staged in 187 chunks of 4096 rays + 48 blocks of 11x15 through the decoder, 48-bit msg",
                              "parity": "tests/test_gpu_fullsize.py::test_fern_*"}
-            else:
-                out[name] = {"ms_per_step": j["ms_per_step"], "content_rays_per_s_x8_before_xgmi_latency": 8 * j["value"], "points_per_step_per_rank": c.get("points_per_step_per_rank"),
-                             "collectives_per_step": c.get("collectives_per_step"), "codebook_optimizer": c.get("codebook_optimizer"), "execution": c.get("execution"), "steps": j["steps"],
-                             "what": "one rank of eight on ONE GPU (tools/emulate_rank.py): 4 of the 32 blocks, the tables of 4 of the 32 bits, all collectives issued on a "
-                                     "world-size-1 RCCL group; kernel work + launch structure of a rank, no inter-GPU latency; NOT a measured 8-GPU number"}
             out[name]["child_wall_s"] = round(time.time() - t0, 1)
         except Exception as e:       # noqa: BLE001 -- a secondary figure must never take the headline down
             out[name] = {"error": repr(e)}
@@ -503,6 +514,8 @@ def bench_training(args, scene, real_stdout, secondary=None):
     from nerf_signature_amd.network import NeRFNetwork
     from nerf_signature_amd.optim import CodebookAdam
 
+    if os.environ.get("NERFSIG_DIST_BACKEND", "") != "gloo" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        dp.assert_distinct_devices()          # environment only, before the first GPU call: two ranks must never share a device over RCCL
     rank, world, local_rank = dp.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")

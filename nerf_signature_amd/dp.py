@@ -70,6 +70,47 @@ def init_from_env(backend=None):
     return rank, world, local_rank
 
 
+def device_ordinal(local_rank=None, device_count=None):
+    """The device this rank binds (`torch.cuda.set_device(ordinal)`) and the physical GPU behind it, decided from the environment alone -- no GPU
+    call: ordinal = LOCAL_RANK modulo the visible device count; physical = that entry of HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES when one of them restricts the process, else the ordinal itself.  Returns (ordinal, physical id string)."""
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if local_rank is None else int(local_rank)
+    visible = None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if os.environ.get(var, "").strip():
+            visible = [v.strip() for v in os.environ[var].split(",") if v.strip()]
+            break
+    if device_count is None:
+        device_count = len(visible) if visible is not None else torch.cuda.device_count()      # (device_count() does not initialise the device)
+    ordinal = local_rank % max(int(device_count), 1)
+    return ordinal, (visible[ordinal] if visible is not None and ordinal < len(visible) else str(ordinal))
+
+
+def assert_distinct_devices(device_count=None):
+    """Every rank of this node binds a GPU of its own -- checked over the process group's HOST side (all_gather_object of (host, physical id) on a
+    gloo group, or per rank from LOCAL_RANK / LOCAL_WORLD_SIZE alone when the group is nccl: object collectives there would touch the GPU) before
+    any kernel is launched.  Raises RuntimeError naming the clash.  Returns this rank's (ordinal, physical id)."""
+    import socket
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    ordinal, physical = device_ordinal(local_rank, device_count)
+    count = device_count if device_count is not None else (torch.cuda.device_count() if not any(os.environ.get(v, "").strip() for v in
+                                                           ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")) else None)
+    if count is not None and local_world > count:
+        raise RuntimeError(f"{local_world} ranks on this node but {count} visible GPU(s): LOCAL_RANK {local_rank} would share device {ordinal} with LOCAL_RANK "
+                           f"{(local_rank + count) % local_world if local_rank + count < local_world else local_rank - count} (NERFSIG_DIST_BACKEND=gloo rehearses more ranks than GPUs)")
+    if dist.is_initialized() and dist.get_backend() == "gloo" and dist.get_world_size() > 1:
+        mine = (socket.gethostname(), physical)
+        everyone = [None] * dist.get_world_size()
+        dist.all_gather_object(everyone, mine)
+        seen = {}
+        for r, key in enumerate(everyone):
+            if key in seen:
+                raise RuntimeError(f"ranks {seen[key]} and {r} bind the same GPU {key[1]} on {key[0]}")
+            seen[key] = r
+    return ordinal, physical
+
+
 def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 

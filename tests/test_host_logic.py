@@ -406,6 +406,11 @@ def test_bench_starts_its_own_ranks_dry_launch():
     line = json.loads(lines[0])
     assert line["dry_launch"] and line["n_gpus"] == 2 and line["world_size_seen"] == 2 and line["collectives_ok"]
     assert line["block_shard_rank0"] == [0, 16] and line["backend"] == "gloo"
+    assert line["device_of_rank"] == ["0", "1"] and line["devices_distinct"]            # every rank binds a GPU of its own, decided before any GPU call
+    # ... and a launch that would put two ranks on one GPU is refused by every rank before anything runs (no JSON line, exit code 5)
+    clash = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], env=dict(env, NERFSIG_DRY_DEVICE_COUNT="1"),
+                           capture_output=True, text=True, timeout=300)
+    assert clash.returncode != 0 and "would share device" in clash.stderr and not [l for l in clash.stdout.splitlines() if l.startswith("{")]
 
 
 def test_bench_launcher_falls_back_when_the_first_attempt_fails():
@@ -632,3 +637,22 @@ def test_distortion_layer_host_side_matches_the_oracle_restatement():
     a, b = ds.DistortionLayer("brightness", seed=5), ds.DistortionLayer("brightness", seed=5)      # rank-consistent draws: same seed, same sequence
     a.draw((2, 2, 2, 3), torch.device("cpu")), b.draw((2, 2, 2, 3), torch.device("cpu"))
     assert float(a.param) == float(b.param) and 0.5 <= float(a.param) <= 1.5
+
+
+def test_device_ordinal_follows_the_visibility_masks(monkeypatch):
+    """dp.device_ordinal: LOCAL_RANK modulo the visible device count, mapped through HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set; the clash check
+    needs no process group and no GPU."""
+    import pytest
+    from nerf_signature_amd import dp
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert dp.device_ordinal(3, device_count=8) == (3, "3")
+    assert dp.device_ordinal(9, device_count=8) == (1, "1")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,5,6,7")
+    assert dp.device_ordinal(2) == (2, "6") and dp.device_ordinal(5) == (1, "5")
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    assert dp.assert_distinct_devices(device_count=4) == (3, "3")
+    with pytest.raises(RuntimeError, match="would share device"):
+        dp.assert_distinct_devices(device_count=2)
