@@ -419,25 +419,7 @@ int dec_bn_gelu_bwd(const float *dy, const float *x, const float *gamma, const f
  *   weights_stream: pass `stream` again for one in-order launch sequence.  A different stream receives the parameter-gradient
  *            kernels (ordered after the data-gradient chain by an event), so that grad_img's consumers on `stream` need not wait
  *            for them; the caller then joins weights_stream before reading `grads`.
- *
- * Opt-in alternative for the seven 64 -> 64 layers in the middle: ONE persistent launch each way (csrc/decoder_persist.inc) when the
- * shape allows it (at most 64 images of at most 192 pixels): a workgroup owns an image for all seven layers, activations stay in
- * LDS, and the images exchange only BatchNorm's per-channel partial statistics.  Arithmetic of that route: fp16 operands, ONE MFMA
- * per product, fp32 accumulate -- what the reference's autocast(fp16) run of this module computes in (nerf/utils_wtmk_disen.py:1172);
- * the per-layer chain is split-bf16 (fp32-class).  dec_set_mode(0) (default) selects the per-layer chain for every shape,
- * dec_set_mode(1) (env NERFSIG_DECODER_CHAIN=persist) the persistent launches where dec_persistent_for(...) then says 1,
- * dec_set_mode(2) (=hybrid) the persistent FORWARD (which then also records GELU') with the per-layer backward chain.  Measured on
- * MI355X: the persistent launches alone are 69 us forward (chain 75) and 94 us backward (chain 58); in the captured training step mode 1
- * equals mode 0 and mode 2 is ~1 % faster (the one resident launch is not starved by the content render's kernels the way nine
- * small launches are).  Modes 1 and 2 stay opt-in -- they change the decoder's forward arithmetic to fp16 -- and are tested alike.
- * dec_persist_status reads the workspace's status word back (it synchronises `stream`): 0 = every exchange of the last
- * dec_forward / dec_backward completed; bit 0 / bit 1 = a workgroup of the forward / backward launch gave up waiting for another
- * image's partials (every wait is bounded: the launch cannot hang, its results are then invalid).
  */
-int dec_get_mode(void);
-int dec_set_mode(int mode);
-int dec_persistent_for(uint32_t B, uint32_t Cin, uint32_t H, uint32_t W);
-int dec_persist_status(const void *workspace, uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, nsig_stream_t stream);
 size_t dec_workspace_bytes(uint32_t B, uint32_t Cin, uint32_t H, uint32_t W);
 int dec_forward(const float *img, uint32_t input_mode, const float *mean_host, const float *std_host, const float *const *params_host,
                 uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, float eps, void *workspace, float *decoded, float *clamped_out,

@@ -75,10 +75,6 @@ SIGNATURES = {
     "dec_bn_gelu_fwd": [_vp, _vp, _vp, _u32, _u32, _u32, _fl, _vp, _vp, _vp],
     "dec_bn_gelu_bwd": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp],
     "dec_workspace_bytes": [_u32, _u32, _u32, _u32],
-    "dec_get_mode": [],
-    "dec_set_mode": [_int],
-    "dec_persistent_for": [_u32, _u32, _u32, _u32],
-    "dec_persist_status": [_vp, _u32, _u32, _u32, _u32, _vp],
     "dec_forward": [_vp, _u32, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _fl, _vp, _vp, _vp, _vp],
     "dec_backward": [_vp, _vp, _u32, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp],
     "dec_forward_distorted": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _fl, _vp, _vp, _vp, _u32, _vp, _vp, _vp],

@@ -58,8 +58,6 @@ struct DecWs {
     float *wpart0;   // [B*npair][64][9*Cin]
     float *wpart8;   // [B*npair][64][9]
     uint4 *packed;   // [kSets] fragment sets
-    uint4 *packed16; // [14] fp16 fragment sets of the 64 -> 64 layers (the persistent launches)
-    uint32_t *sync;  // error word + the granules the persistent launches exchange (zeroed by k_dec_pack)
 };
 
 // How the image reaches layer 0.  mode 0: [B][Cin][H][W], used as it is.  mode 1: the rendered blocks [B][H][W][Cin] straight
@@ -174,19 +172,12 @@ __device__ inline void split_bf16(float v, __bf16 &hi, __bf16 &lo) {
 // dgrad set   (kind 1):  A[row = ci][k = (tap', co)]  = W[co][ci][8 - tap']      (transposed, taps flipped)
 // set 14: layer 0's dgrad, rows = input channel (< Cin, rest zero), W0 is [64][Cin][3][3].
 // fragment (rb, ks = tap*4 + c4), lane (row = lane & 31, h = lane >> 5), element j: k-channel 16*c4 + 8*h + j.
-typedef _Float16 f16x8p __attribute__((ext_vector_type(8)));
-__global__ void __launch_bounds__(64) k_dec_pack(DecParams prm, uint4 *__restrict__ packed, uint32_t Cin, uint4 *__restrict__ packed16, uint4 *__restrict__ sync,
-                                                 uint32_t sync_u4) {
-    {   // the persistent launches' sync block: error word and every granule tag back to zero (decoder_persist.inc)
-        const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-        if (sync != nullptr && i < sync_u4) sync[i] = make_uint4(0u, 0u, 0u, 0u);
-    }
+__global__ void __launch_bounds__(64) k_dec_pack(DecParams prm, uint4 *__restrict__ packed, uint32_t Cin) {
     const int f = blockIdx.x, ks = f % kKS, rb = (f / kKS) & 1, set = f / (2 * kKS);
     const int lane = threadIdx.x, row = 32 * rb + (lane & 31), h = lane >> 5, tap = ks >> 2, c4 = ks & 3;
     const int layer = set < 14 ? 1 + (set >> 1) : 0, kind = set < 14 ? (set & 1) : 1;
     const float *__restrict__ w = prm.w[layer];
     bf16x8 hi, lo;
-    f16x8p hf;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int kc = 16 * c4 + 8 * h + j;
@@ -199,12 +190,10 @@ __global__ void __launch_bounds__(64) k_dec_pack(DecParams prm, uint4 *__restric
         split_bf16(v, vh, vl);
         hi[j] = vh;
         lo[j] = vl;
-        hf[j] = (_Float16)v;
     }
     uint4 *dst = packed + (size_t)set * kSetU4 + ((size_t)rb * kKS + ks) * 128;
     dst[lane] = *reinterpret_cast<uint4 *>(&hi);
     dst[64 + lane] = *reinterpret_cast<uint4 *>(&lo);
-    if (packed16 != nullptr && set < 14) packed16[(size_t)set * (2 * kKS * 64) + ((size_t)rb * kKS + ks) * 64 + lane] = *reinterpret_cast<uint4 *>(&hf);
 }
 
 // ----------------------------------------------------------------------------- batch statistics from partials
@@ -1361,8 +1350,6 @@ __global__ void __launch_bounds__(256) k_dec_sreduce(const float *__restrict__ g
     }
 }
 
-#include "decoder_persist.inc"
-
 // ----------------------------------------------------------------------------- host side
 
 static inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
@@ -1433,8 +1420,6 @@ static size_t carve(void *base, const DecGeom &g, DecWs &ws) {
     ws.wpart0 = c.take<float>((size_t)g.B * g.npair * kC * 9 * g.Cin);
     ws.wpart8 = c.take<float>((size_t)g.B * g.npair * kC * 9);
     ws.packed = c.take<uint4>(kSets * kSetU4);
-    ws.packed16 = c.take<uint4>(14 * kSet16U4);
-    ws.sync = reinterpret_cast<uint32_t *>(c.take<char>(persist_sync_bytes(g.B)));
     return c.off;
 }
 
@@ -1476,37 +1461,6 @@ static int conv_threads() {
     }();
     return n;
 }
-// The seven 64 -> 64 layers as one persistent launch each way (decoder_persist.inc) when asked for and the shape allows it: one workgroup
-// per image, all of them resident together, at most six 32-pixel tiles and the halo image + scratch within LDS.
-// OPT-IN (dec_set_mode(1) / NERFSIG_DECODER_CHAIN=persist): measured on MI355X it does not beat the per-layer chain -- forward 69 us
-// against 7 x 10.7 = 75 us, backward 94 us against 7 x 8.3 = 58 us, the training step 1.085 against 1.067-1.081 ms
-// (profiles/r03_persistent_decoder.txt).  Phase stamps (tools/dec_timing.py --persist) say why: per layer the all-to-all exchange of
-// BatchNorm's partials among the 32 workgroups costs 1.3 us of polling plus ~2 us of skew between the images (every layer
-// waits for the slowest workgroup) -- as much as the kernel boundary it replaces -- and with one workgroup per image the
-// element-wise work of a layer (statistics 1.2 us, BatchNorm + GELU + records 2.3 us) runs on 32 CUs instead of 192.
-static int g_dec_mode = -1;      // -1: not read yet; 0: per-layer chain (default); 1: persistent launches where the shape allows
-static int dec_mode() {
-    if (g_dec_mode < 0) {
-        const char *e = getenv("NERFSIG_DECODER_CHAIN");
-        g_dec_mode = (e && (!strcmp(e, "persist") || !strcmp(e, "1"))) ? 1 : (e && (!strcmp(e, "hybrid") || !strcmp(e, "2"))) ? 2 : 0;
-    }
-    return g_dec_mode;
-}
-// backward == false: the forward's route (modes 1 and 2 run the 64 -> 64 layers as ONE persistent launch); backward == true: only mode 1 does --
-// mode 2 ("hybrid") pairs the persistent forward (it also records GELU' for that purpose) with the per-layer backward chain.
-static bool persist_ok(const DecGeom &g, bool backward = false) {
-    return (backward ? dec_mode() == 1 : dec_mode() >= 1) && g.B >= 1 && g.B <= kPMaxB && g.ntile <= kPMaxTiles &&
-           persist_lds(g.H, g.W).total <= kLdsLimit - 2048 && g.B * g.npair <= 16 * 12;
-}
-template <int MODE>
-static int launch_persist(const DecParams &prm, const DecWs &ws, const DecGeom &g, hipStream_t s) {
-    static size_t allowed = 0;
-    const size_t lds = persist_lds(g.H, g.W).total;
-    if (allow_lds(k_dec_persist<MODE>, lds, allowed)) return 1;
-    k_dec_persist<MODE><<<g.B, kPT, lds, s>>>(prm, ws, g, ws.packed16, ws.sync, dec_mode() == 2);      // (hybrid: GELU' recorded for the per-layer backward)
-    return 0;
-}
-
 template <int MODE>
 static void launch_conv(dim3 grid, size_t lds, hipStream_t s, int layer, const DecParams &prm, const DecWs &ws, const DecGeom &g, float *grad_img,
                         const float *img, const DecInput &inp) {
@@ -1524,37 +1478,7 @@ using namespace nsig;
 NSIG_EXPORT int dec_timing_stamps(unsigned long long *out48) {
     return hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_dec_stamps), sizeof(unsigned long long) * 48) == hipSuccess ? 0 : 1;
 }
-NSIG_EXPORT int dec_persist_stamps(unsigned long long *out192) {
-    return hipMemcpyFromSymbol(out192, HIP_SYMBOL(g_persist_stamps), sizeof(unsigned long long) * 192) == hipSuccess ? 0 : 1;
-}
 #endif
-
-NSIG_EXPORT int dec_get_mode(void) { return dec_mode(); }
-NSIG_EXPORT int dec_set_mode(int mode) {
-    NSIG_REQUIRE(mode >= 0 && mode <= 2, "dec_set_mode: 0 = per-layer chain (split-bf16), 1 = persistent launches (fp16 operands) where the shape allows, 2 = persistent forward + per-layer backward");
-    g_dec_mode = mode;
-    return NSIG_OK;
-}
-/* 1 if dec_forward / dec_backward run the 64 -> 64 layers of this shape as persistent launches in the current mode, else 0 */
-NSIG_EXPORT int dec_persistent_for(uint32_t B, uint32_t Cin, uint32_t H, uint32_t W) {
-    DecGeom g;
-    if (B == 0 || Cin == 0 || Cin > kMaxCin || H == 0 || W == 0 || (uint64_t)H * W > kMaxP || !make_geom(B, Cin, H, W, 0.0f, g)) return 0;
-    return persist_ok(g) ? 1 : 0;
-}
-/* the error word of the workspace's sync block, read back (synchronises the stream): 0 = every exchange of the last forward / backward completed;
- * bit 0 / bit 1 = a workgroup of the forward / backward launch gave up waiting for another image's partials (results are then garbage) */
-NSIG_EXPORT int dec_persist_status(const void *workspace, uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, nsig_stream_t stream) {
-    DecGeom g;
-    DecWs ws;
-    NSIG_REQUIRE(workspace && B >= 1 && Cin >= 1 && Cin <= kMaxCin && H >= 1 && W >= 1 && (uint64_t)H * W <= kMaxP && make_geom(B, Cin, H, W, 0.0f, g), "dec_persist_status: bad arguments");
-    carve(const_cast<void *>(workspace), g, ws);
-    uint32_t word = 0;
-    if (hipMemcpyAsync(&word, ws.sync, sizeof(word), hipMemcpyDeviceToHost, as_stream(stream)) != hipSuccess || hipStreamSynchronize(as_stream(stream)) != hipSuccess) {
-        set_error("dec_persist_status: could not read the status word");
-        return -1;
-    }
-    return (int)word;
-}
 
 NSIG_EXPORT size_t dec_workspace_bytes(uint32_t B, uint32_t Cin, uint32_t H, uint32_t W) {
     DecGeom g;
@@ -1682,19 +1606,12 @@ static int dec_forward_impl(const float *img, uint32_t input_mode, const float *
     carve(workspace, g, ws);
     hipStream_t s = as_stream(stream);
     const dim3 grid(g.npair, B);
-    const bool persist = persist_ok(g);
-    static_assert(kSets * 2 * kKS * 64 * 16 >= kSyncHeadBytes + 2 * 2 * kPMaxB * 128 * 8, "k_dec_pack's threads cover the sync block");
-    k_dec_pack<<<kSets * 2 * kKS, 64, 0, s>>>(prm, ws.packed, Cin, persist ? ws.packed16 : nullptr, persist ? reinterpret_cast<uint4 *>(ws.sync) : nullptr,
-                                             (uint32_t)(persist_sync_bytes(B) / 16));
+    k_dec_pack<<<kSets * 2 * kKS, 64, 0, s>>>(prm, ws.packed, Cin);
     if (Cin == 3)
         k_dec_l0_fwd<3><<<grid, 256, l0_lds(g), s>>>(img, inp, clamped_out, prm, ws, g);
     else
         k_dec_l0_fwd<0><<<grid, 256, l0_lds(g), s>>>(img, inp, clamped_out, prm, ws, g);
-    if (persist) {
-        NSIG_REQUIRE(launch_persist<kPFwd>(prm, ws, g, s) == 0, "dec_forward: could not raise the dynamic LDS limit (persistent launch)");
-    } else {
-        for (int l = 1; l <= 7; ++l) launch_conv<kFwd>(dim3(g.npair, B, 2), conv_lds(g), s, l, prm, ws, g, nullptr, nullptr, inp);
-    }
+    for (int l = 1; l <= 7; ++l) launch_conv<kFwd>(dim3(g.npair, B, 2), conv_lds(g), s, l, prm, ws, g, nullptr, nullptr, inp);
     k_dec_l8_fwd<<<grid, 256, l8_lds(g), s>>>(prm, ws, g);
     k_dec_head_fwd<<<B, 256, 0, s>>>(prm, ws, g, decoded);
     return check_launch("dec_forward");
@@ -1743,11 +1660,7 @@ static int dec_backward_impl(const float *grad_decoded, const float *img, uint32
     const dim3 grid(g.npair, B);
     k_dec_head_bwd<<<B, 256, 0, s>>>(grad_decoded, prm, ws, g);
     k_dec_l8_bwd<<<grid, 256, l8b_lds(g), s>>>(prm, ws, g);
-    if (persist_ok(g, true)) {      // (the forward pass of this workspace packed the fp16 fragments and cleared the sync block)
-        NSIG_REQUIRE(launch_persist<kPBwd>(prm, ws, g, s) == 0, "dec_backward: could not raise the dynamic LDS limit (persistent launch)");
-    } else {
-        for (int l = 7; l >= 1; --l) launch_conv<kDgrad>(dim3(g.npair, B, 2), conv_lds(g), s, l, prm, ws, g, nullptr, nullptr, inp);
-    }
+    for (int l = 7; l >= 1; --l) launch_conv<kDgrad>(dim3(g.npair, B, 2), conv_lds(g), s, l, prm, ws, g, nullptr, nullptr, inp);
     if (inp.distort == kDistBlur) {     // the epilogue leaves d loss / d (blurred image) in the scratch image; the blur's adjoint and the clamp mask follow
         launch_conv<kDgradImg>(grid, conv_lds(g), s, 0, prm, ws, g, grad_scratch, img, inp);
         k_dec_blur_adjoint<<<ceil_div(B * H * W * Cin, 256u), 256, 0, s>>>(grad_scratch, img, inp.dparam, B, H, W, Cin, grad_img);

@@ -127,7 +127,6 @@ class _FusedDecoder(torch.autograd.Function):
         ctx.dist = dist
         ctx.save_for_backward(img, ws, *ps)
         ctx.geom = (B, Cin, H, W, bool(rendered))
-        ctx.dec_mode = nv.fn("dec_get_mode")()      # dec_backward must take the route dec_forward took (the workspace holds that route's operands)
         ctx.set_materialize_grads(False)   # no zero-filled gradient tensor for the non-differentiable `clamped` output (one fill launch on the backward's critical path)
         if rendered:
             ctx.mark_non_differentiable(clamped)
@@ -158,22 +157,15 @@ class _FusedDecoder(torch.autograd.Function):
         if side is not None:   # the buffers below are allocated on this stream but also read / written on the side stream
             for t in (flat, ws, img, grad_out, *ps):
                 t.record_stream(side)
-        mode_now = nv.fn("dec_get_mode")()
-        if mode_now != ctx.dec_mode:
-            nv.call("dec_set_mode", ctx.dec_mode)
-        try:
-            if ctx.dist is not None:     # (the draws in its buffers are still this step's: they are refreshed at the head of the next one)
-                d = ctx.dist
-                scratch = torch.empty_like(img) if d.kind == 3 else None
-                nv.call("dec_backward_distorted", nv.ptr(grad_out.contiguous().view(-1)), nv.ptr(img), mean, std, nv.ptr_array(ps), B, Cin, H, W, nv.ptr(ws),
-                        nv.ptr_array(grads), nv.ptr(grad_img), d.kind, nv.ptr(d.param), nv.ptr(d.noise), nv.ptr(scratch), nv.stream(),
-                        nv.stream() if side is None else side.cuda_stream)
-            else:
-                nv.call("dec_backward", nv.ptr(grad_out.contiguous().view(-1)), nv.ptr(img), int(rendered), mean, std, nv.ptr_array(ps), B, Cin, H, W,
-                        nv.ptr(ws), nv.ptr_array(grads), nv.ptr(grad_img), nv.stream(), nv.stream() if side is None else side.cuda_stream)
-        finally:
-            if mode_now != ctx.dec_mode:
-                nv.call("dec_set_mode", mode_now)
+        if ctx.dist is not None:     # (the draws in its buffers are still this step's: they are refreshed at the head of the next one)
+            d = ctx.dist
+            scratch = torch.empty_like(img) if d.kind == 3 else None
+            nv.call("dec_backward_distorted", nv.ptr(grad_out.contiguous().view(-1)), nv.ptr(img), mean, std, nv.ptr_array(ps), B, Cin, H, W, nv.ptr(ws),
+                    nv.ptr_array(grads), nv.ptr(grad_img), d.kind, nv.ptr(d.param), nv.ptr(d.noise), nv.ptr(scratch), nv.stream(),
+                    nv.stream() if side is None else side.cuda_stream)
+        else:
+            nv.call("dec_backward", nv.ptr(grad_out.contiguous().view(-1)), nv.ptr(img), int(rendered), mean, std, nv.ptr_array(ps), B, Cin, H, W,
+                    nv.ptr(ws), nv.ptr_array(grads), nv.ptr(grad_img), nv.stream(), nv.stream() if side is None else side.cuda_stream)
         return (grad_img, None, None, None, *grads)
 
 

@@ -49,16 +49,3 @@ def strict_mlp():
     nv.set_mlp_precision("bf16x3")
     yield
     nv.call("mlp_set_precision", before)
-
-
-@pytest.fixture
-def strict_decoder():
-    """The per-layer decoder chain (split-bf16, fp32-class; the default) pinned for tests that compare the decoder ELEMENT-WISE with an fp32 / fp64
-    reference at 1e-3-class tolerances -- so that they keep their meaning when the whole suite is run with NERFSIG_DECODER_CHAIN=persist
-    (the opt-in persistent launches with fp16 operands, whose error against fp64 is a few 1e-3:
-    tests/test_gpu_render.py::test_fused_decoder_matches_stock_operators)."""
-    from nerf_signature_amd import _native as nv
-    before = nv.fn("dec_get_mode")()
-    nv.call("dec_set_mode", 0)
-    yield
-    nv.call("dec_set_mode", before)

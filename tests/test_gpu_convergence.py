@@ -131,7 +131,7 @@ def _small_model(seed=0, codebook_scale=1e-4):
     return m, bitfield, C
 
 
-def test_two_hundred_steps_tracked_by_the_oracle_from_a_warm_state(strict_decoder):
+def test_two_hundred_steps_tracked_by_the_oracle_from_a_warm_state():
     """64 content rays + 32 blocks of 4x4 rays, README hyper-parameters.  Phase 1 (GPU only, 200 steps): the decoder leaves the chance plateau.
     Phase 2 (200 steps): the GPU loop and the oracle's autograd + torch.optim.Adam continue from that state -- parameters, Adam moments and step
     counts copied over -- on the same messages; then both are evaluated on 24 held-out messages the way test_bitacc does, and on the PSNR of the

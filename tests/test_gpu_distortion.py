@@ -56,7 +56,7 @@ def test_layer_alone_matches_the_oracle_forward_and_backward(kind):
 
 @pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("shape", [(32, 12, 12, 3), (48, 11, 15, 3), (4, 2, 2, 3)])
-def test_fused_into_the_decoder_values_and_input_gradient(kind, shape, strict_decoder):
+def test_fused_into_the_decoder_values_and_input_gradient(kind, shape):
     """decode_rendered(image, layer) == decoder(normalize(distortion_layer(clamp(image)))) of the oracle: logits, the clamped image reported as
     pred_rgb (undistorted, :592), the gradient with respect to the rendered image (what flows back into the block render) and the decoder's
     parameter gradients."""
@@ -91,7 +91,7 @@ def test_fused_into_the_decoder_values_and_input_gradient(kind, shape, strict_de
 
 
 @pytest.mark.parametrize("kind", KINDS)
-def test_train_step_with_distortion_vs_oracle(kind, strict_decoder, strict_mlp):
+def test_train_step_with_distortion_vs_oracle(kind, strict_mlp):
     import test_gpu_render as T
     from nerf_signature_amd import trainer
     m, bitfield, C = T._model()

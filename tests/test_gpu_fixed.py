@@ -99,7 +99,7 @@ def test_fixed_rays_render_is_bit_identical_and_follows_its_inputs():
     assert rec["fixed"].refreshes == refreshes and torch.equal(got4, want4)
 
 
-def test_fixed_block_cache_trains_like_the_loop_that_recomputes(strict_decoder):
+def test_fixed_block_cache_trains_like_the_loop_that_recomputes():
     """GraphedWatermarkLoop(fixed_blocks=True) against fixed_blocks=False: same messages, block rays replaced twice on the way
     (`data` at the step itself, `next_data` one step early), a checkpoint-style invalidate in between."""
     from nerf_signature_amd import trainer

@@ -1,13 +1,11 @@
 #!/usr/bin/env python
-"""Times the HiDDeN decoder alone (forward, forward + backward) on the bench shape, both routes of the 64 -> 64 layers:
-dec_set_mode(0) one launch per layer each way, dec_set_mode(1) one persistent launch each way (csrc/decoder_persist.inc)."""
+"""Times the HiDDeN decoder alone (forward, forward + backward) on the bench shape: eagerly and replayed from a hipGraph."""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from nerf_signature_amd import _native as nv
 from nerf_signature_amd.hidden_models import get_hidden_decoder_multi_views
 
 B, H, W = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (32, 12, 12)))
@@ -55,8 +53,6 @@ def graphed(fn):
     return g.replay
 
 
-for mode in (0, 1, 0, 1):
-    nv.call("dec_set_mode", mode)
-    name = "persistent" if nv.fn("dec_persistent_for")(B, 3, H, W) else "per-layer "
-    print(f"{B}x{H}x{W} {name}: forward {timeit(fwd):7.1f} us, forward+backward {timeit(fwd_bwd):7.1f} us (eager) | "
+for _ in range(2):
+    print(f"{B}x{H}x{W}: forward {timeit(fwd):7.1f} us, forward+backward {timeit(fwd_bwd):7.1f} us (eager) | "
           f"forward {timeit(graphed(fwd)):7.1f} us, forward+backward {timeit(graphed(fwd_bwd)):7.1f} us (hipGraph replay)")

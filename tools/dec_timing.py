@@ -25,9 +25,6 @@ from nerf_signature_amd.hidden_models import get_hidden_decoder_multi_views
 
 assert nv.load()._name == LIB, nv.load()._name
 B, H, W = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (32, 12, 12)))
-persist = "--persist" in sys.argv
-sys.argv = [a for a in sys.argv if a != "--persist"]
-nv.call("dec_set_mode", 1 if persist else 0)
 dec = get_hidden_decoder_multi_views(num_bits=1, redundancy=1, num_blocks=8, input_ch=3, channels=64).cuda()
 img = torch.randn(B, 3, H, W, device="cuda", requires_grad=True)
 for _ in range(3):
@@ -42,16 +39,3 @@ for m, mode in enumerate(("fwd", "dgrad", "dgrad_img")):
     st = list(out[m * 16:(m + 1) * 16])
     print(mode, " ".join(f"{names[k]}={(st[k] - st[0]) * 10:d}ns" for k in (7, 8, 1, 2, 3, 4, 5, 6) if st[k]))
 
-if persist:
-    out = (ctypes.c_ulonglong * 192)()
-    fn = nv.load().dec_persist_stamps
-    fn.argtypes = [ctypes.c_void_p]
-    assert fn(out) == 0
-    ph = ["start", "mfma", "xchg", "stats", "publish", "gathered", "combined", "epilogue", "barrier"]
-    for m, mode in enumerate(("persist fwd", "persist bwd")):
-        st = [list(out[(m * 8 + k) * 12:(m * 8 + k + 1) * 12]) for k in range(8)]
-        t0 = st[7][0]
-        print(mode, f"prologue {(st[7][1] - t0) * 10} ns; loop end {(st[7][2] - t0) * 10} ns; kernel end {(st[7][3] - t0) * 10} ns")
-        for k in range(7):
-            row = st[k]
-            print(f"   step {k} @ {(row[0] - t0) * 10:6d} ns: " + " ".join(f"{ph[j]}=+{(row[j] - row[0]) * 10}" for j in range(1, 9) if row[j] >= row[0] and row[j]))
