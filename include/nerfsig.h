@@ -436,20 +436,26 @@ int dec_backward(const float *grad_decoded, const float *img, uint32_t input_mod
  * rotation / scaling change the image geometry (and, for scaling, the decoder's input width): they stay on stock operators.
  *   dist_param  device float[1]: f (2) or sigma (3), read on the device -- a captured step draws it itself (wm_distort_draw);
  *   dist_noise  device [B, H, W, Cin] (1).
- * dec_forward_distorted / dec_backward_distorted = dec_forward / dec_backward with input_mode 1 and the layer applied on load, between
- * the clamp and the normalisation (no extra launch; the blur's adjoint is one small launch behind the image-gradient epilogue and needs
+ * dec_forward_train / dec_backward_train = dec_forward / dec_backward with input_mode 1 (the training step's call) and the layer applied on load,
+ * between the clamp and the normalisation (no extra launch; the blur's adjoint is one small launch behind the image-gradient epilogue and needs
  * grad_scratch [B, H, W, Cin]); clamped_out still receives the UNdistorted clamped blocks (the step's pred_rgb, :592).
+ * dec_forward_train can also leave the watermark loss's gradient behind (bce_seed [B], optional): the step's loss is
+ * lambda_w * mean_i BCE-with-logits(temp * decoded_i, message_i) (loss_w 'bce', utils_wtmk_disen.py:441,641-644), whose derivative with respect to
+ * decoded_i is element-wise -- bce_seed[i] = bce_scale * (sigmoid(bce_temp * decoded_i) - bce_message[i]), bce_scale = lambda_w * temp / B from the caller
+ * -- so dec_backward_train(grad_decoded = bce_seed) starts right behind the forward chain, with no loss kernel on the path between them (the loss VALUES
+ * are still wm_loss_fwd's, computed off that path).
  * wm_distort_fwd / _bwd: the layer alone on [B, H, W, C] (img = the unclamped render; out = D(clamp(img)); grad_img through the clamp).
  * wm_distort_draw: counter-based draws, a pure function of (seed, *step_counter, element): param_out[0] ~ U[0.5, 1.5] (2) /
  * U[0.01, 0.5] (3), noise_out[0 .. n_noise) ~ N(0, 0.1) (1).  step_counter may be NULL (step 0).
  */
-int dec_forward_distorted(const float *img, const float *mean_host, const float *std_host, const float *const *params_host, uint32_t B,
-                          uint32_t Cin, uint32_t H, uint32_t W, float eps, void *workspace, float *decoded, float *clamped_out,
-                          uint32_t distortion, const float *dist_param, const float *dist_noise, nsig_stream_t stream);
-int dec_backward_distorted(const float *grad_decoded, const float *img, const float *mean_host, const float *std_host,
-                           const float *const *params_host, uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, void *workspace,
-                           float *const *grads_host, float *grad_img, uint32_t distortion, const float *dist_param,
-                           const float *dist_noise, float *grad_scratch, nsig_stream_t stream, nsig_stream_t weights_stream);
+int dec_forward_train(const float *img, const float *mean_host, const float *std_host, const float *const *params_host, uint32_t B,
+                      uint32_t Cin, uint32_t H, uint32_t W, float eps, void *workspace, float *decoded, float *clamped_out,
+                      uint32_t distortion, const float *dist_param, const float *dist_noise, const float *bce_message, float bce_temp,
+                      float bce_scale, float *bce_seed, nsig_stream_t stream);
+int dec_backward_train(const float *grad_decoded, const float *img, const float *mean_host, const float *std_host,
+                       const float *const *params_host, uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, void *workspace,
+                       float *const *grads_host, float *grad_img, uint32_t distortion, const float *dist_param,
+                       const float *dist_noise, float *grad_scratch, nsig_stream_t stream, nsig_stream_t weights_stream);
 int wm_distort_draw(uint32_t distortion, uint64_t seed, const uint32_t *step_counter, uint32_t n_noise, float *param_out,
                     float *noise_out, nsig_stream_t stream);
 int wm_distort_fwd(const float *img, uint32_t B, uint32_t H, uint32_t W, uint32_t C, uint32_t distortion, const float *dist_param,

@@ -77,8 +77,8 @@ SIGNATURES = {
     "dec_workspace_bytes": [_u32, _u32, _u32, _u32],
     "dec_forward": [_vp, _u32, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _fl, _vp, _vp, _vp, _vp],
     "dec_backward": [_vp, _vp, _u32, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp],
-    "dec_forward_distorted": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _fl, _vp, _vp, _vp, _u32, _vp, _vp, _vp],
-    "dec_backward_distorted": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp],
+    "dec_forward_train": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _fl, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _fl, _fl, _vp, _vp],
+    "dec_backward_train": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp],
     "wm_distort_draw": [_u32, _c.c_uint64, _vp, _u32, _vp, _vp, _vp],
     "wm_distort_fwd": [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp],
     "wm_distort_bwd": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp],

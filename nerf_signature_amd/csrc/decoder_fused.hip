@@ -917,7 +917,11 @@ __global__ void __launch_bounds__(256) k_dec_l8_fwd(DecParams prm, DecWs ws, Dec
 }
 
 // grid (B), 256 threads: BN + GELU of the single-channel x_8, average pool, Linear(1,1) (hidden_models.py:121-123,131-135).
-__global__ void __launch_bounds__(256) k_dec_head_fwd(DecParams prm, DecWs ws, DecGeom g, float *__restrict__ decoded) {
+// bce_seed (optional): the watermark loss's gradient with respect to this image's logit, written here so that the backward chain can start without a
+// loss kernel in between: BCE-with-logits(temp * decoded, message) averaged over the B images, d/d decoded[im] = scale * (sigmoid(temp * decoded[im]) -
+// message[im]) with scale = lambda_w * temp / B folded in by the caller (utils_wtmk_disen.py:441,641-644).
+__global__ void __launch_bounds__(256) k_dec_head_fwd(DecParams prm, DecWs ws, DecGeom g, float *__restrict__ decoded, const float *__restrict__ bce_message,
+                                                      float bce_temp, float bce_scale, float *__restrict__ bce_seed) {
     __shared__ float scratch[4];
     const uint32_t im = blockIdx.x, t = threadIdx.x, n = g.B * g.npair;
     const float N = (float)(g.B * g.P);
@@ -944,7 +948,9 @@ __global__ void __launch_bounds__(256) k_dec_head_fwd(DecParams prm, DecWs ws, D
     const float pool = block_sum256(ps, scratch) / (float)g.P;
     if (t == 0) {
         ws.pool[im] = pool;
-        decoded[im] = pool * prm.lin_w[0] + prm.lin_b[0];
+        const float logit = pool * prm.lin_w[0] + prm.lin_b[0];
+        decoded[im] = logit;
+        if (bce_seed) bce_seed[im] = bce_scale * (1.0f / (1.0f + expf(-bce_temp * logit)) - bce_message[im]);
         if (im == 0) {
             ws.minv[8][0] = mean;
             ws.minv[8][1] = inv;
@@ -1589,12 +1595,14 @@ static int set_distortion(DecInput &in, uint32_t distortion, const float *param,
 
 static int dec_forward_impl(const float *img, uint32_t input_mode, const float *mean_host, const float *std_host, const float *const *params,
                             uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, float eps, void *workspace, float *decoded, float *clamped_out,
-                            uint32_t distortion, const float *dist_param, const float *dist_noise, nsig_stream_t stream) {
+                            uint32_t distortion, const float *dist_param, const float *dist_noise, const float *bce_message, float bce_temp, float bce_scale,
+                            float *bce_seed, nsig_stream_t stream) {
     NSIG_REQUIRE(img && params && workspace && decoded, "dec_forward: null pointer");
+    NSIG_REQUIRE(bce_seed == nullptr || bce_message != nullptr, "dec_forward_train: bce_seed needs bce_message");
     DecInput inp;
     NSIG_REQUIRE(make_input(input_mode, mean_host, std_host, Cin, inp) == 0, "dec_forward: input_mode is 0, or 1 with Cin <= 8 means and positive stds");
     NSIG_REQUIRE(set_distortion(inp, distortion, dist_param, dist_noise, H, W) == 0,
-                 "dec_forward_distorted: distortion is 0..3, needs input_mode 1, its device parameter (2, 3) or noise tensor (1), and H, W >= 2 for the blur");
+                 "dec_forward_train: distortion is 0..3, needs input_mode 1, its device parameter (2, 3) or noise tensor (1), and H, W >= 2 for the blur");
     DecGeom g;
     NSIG_REQUIRE(B >= 1 && Cin >= 1 && Cin <= kMaxCin && H >= 1 && W >= 1 && (uint64_t)H * W <= kMaxP && (uint64_t)B * H * W > 1 &&
                      make_geom(B, Cin, H, W, eps, g),
@@ -1613,20 +1621,23 @@ static int dec_forward_impl(const float *img, uint32_t input_mode, const float *
         k_dec_l0_fwd<0><<<grid, 256, l0_lds(g), s>>>(img, inp, clamped_out, prm, ws, g);
     for (int l = 1; l <= 7; ++l) launch_conv<kFwd>(dim3(g.npair, B, 2), conv_lds(g), s, l, prm, ws, g, nullptr, nullptr, inp);
     k_dec_l8_fwd<<<grid, 256, l8_lds(g), s>>>(prm, ws, g);
-    k_dec_head_fwd<<<B, 256, 0, s>>>(prm, ws, g, decoded);
+    k_dec_head_fwd<<<B, 256, 0, s>>>(prm, ws, g, decoded, bce_message, bce_temp, bce_scale, bce_seed);
     return check_launch("dec_forward");
 }
 
 NSIG_EXPORT int dec_forward(const float *img, uint32_t input_mode, const float *mean_host, const float *std_host, const float *const *params,
                             uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, float eps, void *workspace, float *decoded, float *clamped_out,
                             nsig_stream_t stream) {
-    return dec_forward_impl(img, input_mode, mean_host, std_host, params, B, Cin, H, W, eps, workspace, decoded, clamped_out, kDistNone, nullptr, nullptr, stream);
+    return dec_forward_impl(img, input_mode, mean_host, std_host, params, B, Cin, H, W, eps, workspace, decoded, clamped_out, kDistNone, nullptr, nullptr, nullptr,
+                            0.0f, 0.0f, nullptr, stream);
 }
 
-NSIG_EXPORT int dec_forward_distorted(const float *img, const float *mean_host, const float *std_host, const float *const *params, uint32_t B, uint32_t Cin,
-                                      uint32_t H, uint32_t W, float eps, void *workspace, float *decoded, float *clamped_out, uint32_t distortion,
-                                      const float *dist_param, const float *dist_noise, nsig_stream_t stream) {
-    return dec_forward_impl(img, 1, mean_host, std_host, params, B, Cin, H, W, eps, workspace, decoded, clamped_out, distortion, dist_param, dist_noise, stream);
+NSIG_EXPORT int dec_forward_train(const float *img, const float *mean_host, const float *std_host, const float *const *params, uint32_t B, uint32_t Cin,
+                                  uint32_t H, uint32_t W, float eps, void *workspace, float *decoded, float *clamped_out, uint32_t distortion,
+                                  const float *dist_param, const float *dist_noise, const float *bce_message, float bce_temp, float bce_scale, float *bce_seed,
+                                  nsig_stream_t stream) {
+    return dec_forward_impl(img, 1, mean_host, std_host, params, B, Cin, H, W, eps, workspace, decoded, clamped_out, distortion, dist_param, dist_noise,
+                            bce_message, bce_temp, bce_scale, bce_seed, stream);
 }
 
 static int dec_backward_impl(const float *grad_decoded, const float *img, uint32_t input_mode, const float *mean_host, const float *std_host,
@@ -1637,7 +1648,7 @@ static int dec_backward_impl(const float *grad_decoded, const float *img, uint32
     DecInput inp;
     NSIG_REQUIRE(make_input(input_mode, mean_host, std_host, Cin, inp) == 0, "dec_backward: input_mode is 0, or 1 with Cin <= 8 means and positive stds");
     NSIG_REQUIRE(set_distortion(inp, distortion, dist_param, dist_noise, H, W) == 0 && (distortion != kDistBlur || grad_scratch != nullptr),
-                 "dec_backward_distorted: distortion is 0..3, needs input_mode 1, its device parameter / noise tensor, and for the blur a scratch image");
+                 "dec_backward_train: distortion is 0..3, needs input_mode 1, its device parameter / noise tensor, and for the blur a scratch image");
     DecGeom g;
     NSIG_REQUIRE(B >= 1 && Cin >= 1 && Cin <= kMaxCin && H >= 1 && W >= 1 && (uint64_t)H * W <= kMaxP && make_geom(B, Cin, H, W, 0.0f, g),
                  "dec_backward: unsupported image shape");
@@ -1695,7 +1706,7 @@ NSIG_EXPORT int dec_backward(const float *grad_decoded, const float *img, uint32
                              nullptr, stream, weights_stream);
 }
 
-NSIG_EXPORT int dec_backward_distorted(const float *grad_decoded, const float *img, const float *mean_host, const float *std_host, const float *const *params,
+NSIG_EXPORT int dec_backward_train(const float *grad_decoded, const float *img, const float *mean_host, const float *std_host, const float *const *params,
                                        uint32_t B, uint32_t Cin, uint32_t H, uint32_t W, void *workspace, float *const *grads, float *grad_img,
                                        uint32_t distortion, const float *dist_param, const float *dist_noise, float *grad_scratch, nsig_stream_t stream,
                                        nsig_stream_t weights_stream) {

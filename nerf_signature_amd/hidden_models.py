@@ -102,8 +102,10 @@ class _FusedDecoder(torch.autograd.Function):
     clamp / permute / normalize_img of the training step happen inside layer 0; the second output is the clamped image."""
 
     @staticmethod
-    def forward(ctx, img, eps, rendered, distortion, *params):
-        """distortion: a distortion.DistortionLayer of a native kind whose draws are in its device buffers (rendered=True only), or None."""
+    def forward(ctx, img, eps, rendered, distortion, bce, *params):
+        """distortion: a distortion.DistortionLayer of a native kind whose draws are in its device buffers (rendered=True only), or None.
+        bce: (message [B] float32 on the device, temp, scale) or None (rendered=True only): the head kernel also leaves
+        scale * (sigmoid(temp * decoded) - message) in `_FusedDecoder.seed` -- the watermark loss's gradient, ready for this node's backward."""
         img = img.contiguous()
         if rendered:
             B, H, W, Cin = img.shape
@@ -116,27 +118,38 @@ class _FusedDecoder(torch.autograd.Function):
         ws = torch.empty(nv.fn("dec_workspace_bytes")(B, Cin, H, W), dtype=torch.uint8, device=img.device)
         out = torch.empty(B, dtype=torch.float32, device=img.device)
         dist = distortion if (distortion is not None and distortion.native) else None
-        if dist is not None:
+        _FusedDecoder.seed = None
+        if dist is not None or bce is not None:
             if not rendered:
-                raise ValueError("the fused distortion layer acts on the rendered blocks (rendered=True)")
-            nv.call("dec_forward_distorted", nv.ptr(img), mean, std, nv.ptr_array(ps), B, Cin, H, W, eps, nv.ptr(ws), nv.ptr(out), nv.ptr(clamped), dist.kind,
-                    nv.ptr(dist.param), nv.ptr(dist.noise), nv.stream())
+                raise ValueError("the fused distortion layer / loss seed act on the rendered blocks (rendered=True)")
+            seed = None
+            if bce is not None:
+                msg, temp, scale = bce
+                if not (msg.is_cuda and msg.dtype == torch.float32 and msg.numel() == B and msg.is_contiguous()):
+                    raise ValueError("bce: message must be a contiguous float32 device tensor with one entry per image")
+                seed = torch.empty(B, dtype=torch.float32, device=img.device)
+            nv.call("dec_forward_train", nv.ptr(img), mean, std, nv.ptr_array(ps), B, Cin, H, W, eps, nv.ptr(ws), nv.ptr(out), nv.ptr(clamped),
+                    dist.kind if dist is not None else 0, nv.ptr(dist.param) if dist is not None else None, nv.ptr(dist.noise) if dist is not None else None,
+                    nv.ptr(msg) if bce is not None else None, float(temp) if bce is not None else 0.0, float(scale) if bce is not None else 0.0, nv.ptr(seed),
+                    nv.stream())
+            _FusedDecoder.seed = None if seed is None else seed.view(B, 1)      # (the caller takes it right behind this call: trainer.train_step)
         else:
             nv.call("dec_forward", nv.ptr(img), int(rendered), mean, std, nv.ptr_array(ps), B, Cin, H, W, eps, nv.ptr(ws), nv.ptr(out), nv.ptr(clamped),
                     nv.stream())
         ctx.dist = dist
+        out = out.view(B, 1)
         ctx.save_for_backward(img, ws, *ps)
         ctx.geom = (B, Cin, H, W, bool(rendered))
         ctx.set_materialize_grads(False)   # no zero-filled gradient tensor for the non-differentiable `clamped` output (one fill launch on the backward's critical path)
         if rendered:
             ctx.mark_non_differentiable(clamped)
-            return out.view(B, 1), clamped
-        return out.view(B, 1)
+            return out, clamped
+        return out
 
     @staticmethod
     def backward(ctx, grad_out, *_):
         if grad_out is None:
-            return (None,) * (4 + len(ctx.saved_tensors) - 2)
+            return (None,) * (5 + len(ctx.saved_tensors) - 2)
         img, ws, *ps = ctx.saved_tensors
         B, Cin, H, W, rendered = ctx.geom
         mean, std = ((ctypes.c_float * Cin)(*_MEAN[:Cin]), (ctypes.c_float * Cin)(*_STD[:Cin])) if rendered else (None, None)
@@ -160,13 +173,13 @@ class _FusedDecoder(torch.autograd.Function):
         if ctx.dist is not None:     # (the draws in its buffers are still this step's: they are refreshed at the head of the next one)
             d = ctx.dist
             scratch = torch.empty_like(img) if d.kind == 3 else None
-            nv.call("dec_backward_distorted", nv.ptr(grad_out.contiguous().view(-1)), nv.ptr(img), mean, std, nv.ptr_array(ps), B, Cin, H, W, nv.ptr(ws),
+            nv.call("dec_backward_train", nv.ptr(grad_out.contiguous().view(-1)), nv.ptr(img), mean, std, nv.ptr_array(ps), B, Cin, H, W, nv.ptr(ws),
                     nv.ptr_array(grads), nv.ptr(grad_img), d.kind, nv.ptr(d.param), nv.ptr(d.noise), nv.ptr(scratch), nv.stream(),
                     nv.stream() if side is None else side.cuda_stream)
         else:
             nv.call("dec_backward", nv.ptr(grad_out.contiguous().view(-1)), nv.ptr(img), int(rendered), mean, std, nv.ptr_array(ps), B, Cin, H, W,
                     nv.ptr(ws), nv.ptr_array(grads), nv.ptr(grad_img), nv.stream(), nv.stream() if side is None else side.cuda_stream)
-        return (grad_img, None, None, None, *grads)
+        return (grad_img, None, None, None, None, *grads)
 
 
 class ConvBNRelu(nn.Module):
@@ -219,15 +232,16 @@ class HiddenDecoder_multi_views(nn.Module):
             params += [c.weight, bn.weight, bn.bias]
         return bns[0].eps, params + [self.linear.weight, self.linear.bias]
 
-    def decode_rendered(self, image, distortion=None):
-        """The training step's `msg_decoder(normalize_img(distortion_layer(clamp(image, 0, 1)).permute(0, 3, 1, 2)))` for the compositor's
+    def decode_rendered(self, image, distortion=None, bce=None):
+        """bce = (message, temp, scale): see _FusedDecoder.forward (ignored where the fused chain does not run).
+        The training step's `msg_decoder(normalize_img(distortion_layer(clamp(image, 0, 1)).permute(0, 3, 1, 2)))` for the compositor's
         [B, H, W, 3] blocks (utils_wtmk_disen.py:592-595) -> (decoded [B, 1], clamped image).  On the GPU the clamp, the distortion
         (noise / brightness / blurring: distortion.DistortionLayer with this step's draws in its buffers), the layout change and the
         normalisation are part of the fused decoder's first layer."""
         fused = self._fused_params(image.shape[0], image.shape[3], image.shape[1], image.shape[2], image) if image.dim() == 4 and image.shape[3] <= 3 else None
         native = distortion is not None and distortion.native
         if fused is not None and (distortion is None or native or distortion.name == "none"):
-            return _FusedDecoder.apply(image, fused[0], True, distortion if native else None, *fused[1])
+            return _FusedDecoder.apply(image, fused[0], True, distortion if native else None, bce, *fused[1])
         pred = torch.clamp(image, min=0, max=1)
         dist = pred if distortion is None else distortion(pred, raw=image)
         return self(normalize_img(dist.permute(0, 3, 1, 2))), pred
@@ -235,7 +249,7 @@ class HiddenDecoder_multi_views(nn.Module):
     def forward(self, img_w):
         fused = self._fused_params(*img_w.shape, img_w) if img_w.dim() == 4 else None
         if fused is not None:
-            return _FusedDecoder.apply(img_w, fused[0], False, None, *fused[1])   # num_bits = redundancy = 1: the view/sum below is the identity
+            return _FusedDecoder.apply(img_w, fused[0], False, None, None, *fused[1])   # num_bits = redundancy = 1: the view/sum below is the identity
         x = self.layers(img_w).squeeze(-1).squeeze(-1)
         x = self.linear(x)
         x = x.view(-1, self.num_bits, self.redundancy)

@@ -70,9 +70,11 @@ def backward_from_loss_kernel(out, content_scale=1.0, content_stream=None, conte
             lambda_w, lambda_i = getattr(train_step, "last_lambdas", (1.0, 1.0))
             (lambda_w * out[4] + (lambda_i * content_scale) * out[3]).backward()
         return
-    _, content, decoded, d_content, d_decoded, lambda_w, lambda_i = last
+    _, content, decoded, d_content, d_decoded, lambda_w, lambda_i, fused_seed = last
     ci = lambda_i * content_scale
-    seeds = [d_content if ci == 1.0 else d_content * ci, d_decoded if lambda_w == 1.0 else d_decoded * lambda_w]
+    # the decoder's seed: lambda_w * d(loss_w)/d(decoded) -- left behind by the decoder's own head kernel where it could (train_step), else from the loss kernel
+    seeds = [None if not content.requires_grad else (d_content if ci == 1.0 else d_content * ci),
+             fused_seed if fused_seed is not None else (d_decoded if lambda_w == 1.0 else d_decoded * lambda_w)]
     # (finetune_decoder: the codebook is frozen too, the content render then has no trainable input and no grad_fn)
     pairs = [(t, g) for t, g in zip((content, decoded), seeds) if t.requires_grad]
     if len(pairs) == 2 and content_stream is not None and content_first:
@@ -119,10 +121,14 @@ def srgb_to_linear(x):
 
 
 def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce, side_stream=None, presum_first=False,
-               presum_adopt=False, color_space="srgb", blocks_first=False, content_backward_now=None, distortion=None):
+               presum_adopt=False, color_space="srgb", blocks_first=False, content_backward_now=None, distortion=None, defer_loss_values=False):
     """data = {'watermark': {'rays_o_block', 'rays_d_block'}, 'content': {'rays_o', 'rays_d', 'images'}}.
     Returns (pred_rgb, gt_rgb, content_pred_rgb, lossi, lossw, loss) like the reference.
 
+    defer_loss_values: where both backward passes already have their seeds when the losses are reached (the content render's early seed,
+    content_backward_now; the decoder's from its own head kernel), the kernel that computes the three loss VALUES is not launched here -- between the
+    decoder's forward and backward, on the step's critical path -- but by `train_step.finish_losses()`, which the caller invokes once at the end of
+    the step (GraphedWatermarkLoop does); the returned tensors are filled then.
     distortion: the reference's `--distortion` (utils_wtmk_disen.py:551-577,594): a name (none | noise | rotation | scaling | blurring |
     brightness; this call then draws the step's random parameters) or a distortion.DistortionLayer whose owner has drawn them (the loops).
 
@@ -153,6 +159,7 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
     block_o, block_d, shard = local_blocks(wm)
     outputs = model.render(block_o, block_d, message, **kw)
     content_done = early_seed = None
+    deferred = False
     new_segment = False       # (a collective in front of the decoder ended the running capture segment: the side stream has to be forked again)
     if main is not None and blocks_first:
         # (the fork above is the content render's only parent; captured BEHIND the block render it is enqueued behind it: GraphedWatermarkLoop)
@@ -187,8 +194,18 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
         distortion = DistortionLayer(distortion) if distortion != "none" else None
         if distortion is not None:
             distortion.draw(tuple(image.shape), image.device)
+    fused_seed = None
     if model.normalization is normalize_img and hasattr(model.msg_decoder, "decode_rendered"):
-        decoded, pred_rgb = model.msg_decoder.decode_rendered(image, distortion)    # clamp + distortion + permute + normalise inside layer 0
+        bce = None
+        if loss_w is loss_w_bce and image.is_cuda and image.dim() == 4 and torch.is_grad_enabled():
+            # d(lambda_w * mean BCE-with-logits(10 * decoded, message)) / d decoded is element-wise: the decoder's head kernel writes it (its backward
+            # then starts right behind its forward: no loss kernel, no seed scaling between them)
+            keys_dev = message.to(image.device, torch.float32).contiguous()
+            if keys_dev.numel() == image.shape[0]:
+                bce = (keys_dev, 10.0, float(lambda_w) * 10.0 / image.shape[0])
+        decoded, pred_rgb = model.msg_decoder.decode_rendered(image, distortion, bce)    # clamp + distortion + permute + normalise inside layer 0
+        from .hidden_models import _FusedDecoder
+        fused_seed, _FusedDecoder.seed = getattr(_FusedDecoder, "seed", None), None
     else:
         pred_rgb = torch.clamp(image, min=0, max=1)
         pred_rgb_dist = pred_rgb if distortion is None else distortion(pred_rgb, raw=image)
@@ -209,7 +226,10 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
         with torch.cuda.stream(side_stream):
             torch.autograd.backward([content_pred_rgb], [early_seed])
         content_pred_rgb = content_pred_rgb.detach()
-        if not new_segment:       # (both streams met in front of the collective; the event belongs to the finished segment)
+        if fused_seed is not None and defer_loss_values:
+            deferred = True           # nothing on the main stream needs the content render any more, and the loss VALUES can wait for the end of the step
+        if not new_segment and (not deferred or os.environ.get("NERFSIG_DEFER_KEEP_EDGE", "1") == "1"):
+            # (new_segment: both streams met in front of the collective; the event belongs to the finished segment)
             main.wait_event(content_done)
     elif main is not None and not new_segment:
         # (new_segment: both streams already met in front of the collective and the side stream has not been forked into the new capture segment --
@@ -220,8 +240,22 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
     keys = message.to(decoded.device).unsqueeze(-1)
     if loss_w is loss_w_bce and decoded.is_cuda and all(t.dtype == torch.float32 for t in (content_pred_rgb, gt_rgb, decoded, keys)) \
             and gt_rgb.shape == content_pred_rgb.shape and keys.shape == decoded.shape:
-        lossi, lossw, loss = _WatermarkLoss.apply(content_pred_rgb, gt_rgb, decoded, keys, float(lambda_w), float(lambda_i), 10.0)
-        _WatermarkLoss.last = (loss, content_pred_rgb, decoded, *_WatermarkLoss.stash, float(lambda_w), float(lambda_i))
+        if deferred:      # values only (both backward passes have their seeds): launched by finish_losses() at the end of the step
+            losses = torch.empty(3, dtype=torch.float32, device=decoded.device)
+            lossi, lossw, loss = losses[0], losses[1], losses[2]
+            c, g, dcd, k = content_pred_rgb.contiguous(), gt_rgb.contiguous(), decoded.detach().contiguous(), keys.contiguous()
+            scratch = (torch.empty_like(c), torch.empty_like(dcd))
+
+            def finish(c=c, g=g, dcd=dcd, k=k, losses=losses, scratch=scratch, lw=float(lambda_w), li=float(lambda_i)):
+                nv.call("wm_loss_fwd", nv.ptr(c), nv.ptr(g), c.numel(), nv.ptr(dcd), nv.ptr(k), dcd.numel(), 10.0, lw, li, nv.ptr(losses), nv.ptr(scratch[0]),
+                        nv.ptr(scratch[1]), nv.stream())
+                train_step.finish_losses = None
+
+            train_step.finish_losses = finish
+            _WatermarkLoss.last = (loss, content_pred_rgb, decoded, None, None, float(lambda_w), float(lambda_i), fused_seed)
+        else:
+            lossi, lossw, loss = _WatermarkLoss.apply(content_pred_rgb, gt_rgb, decoded, keys, float(lambda_w), float(lambda_i), 10.0)
+            _WatermarkLoss.last = (loss, content_pred_rgb, decoded, *_WatermarkLoss.stash, float(lambda_w), float(lambda_i), fused_seed)
     else:
         lossi = ((content_pred_rgb - gt_rgb) ** 2).mean()
         lossw = loss_w(decoded, keys)
@@ -278,6 +312,7 @@ def test_step(model, data, message, render_kwargs, bg_color=None, perturb=False)
 
 
 test_step.__test__ = False      # (not a pytest test, whatever its name)
+train_step.finish_losses = None
 
 
 class WatermarkLoop:
@@ -609,7 +644,12 @@ class GraphedWatermarkLoop:
                              blocks_first=self.side_stream is not None and self._blocks_issued_first(),
                              content_backward_now=(self.lambda_i * dp.content_grad_scale(self.sharded)) if (self.content_backward_first and
                                                    self.side_stream is not None and os.environ.get("NERFSIG_CONTENT_BWD_NOW", "1") == "1") else None,
-                             distortion=self.distortion)
+                             distortion=self.distortion,
+                             # NERFSIG_DEFER_LOSS=1: the loss-VALUE kernel (8 us, one workgroup) launched at the end of the step instead of between the decoder's forward
+                             # and backward.  Measured (round 4, same box): one rank 0.976-0.978 against 0.966-0.969 ms, one rank of eight 0.489-0.493 either way -- the
+                             # kernel's latency is already hidden; and WITHOUT the main stream's wait for the content render's forward that used to sit in front of
+                             # it (NERFSIG_DEFER_KEEP_EDGE=0) this runtime starts the whole content chain behind the decoder: 1.13 ms.  Off.
+                             defer_loss_values=os.environ.get("NERFSIG_DEFER_LOSS", "0") == "1")
         finally:
             fo.set_plan_stream(prev)
         set_weights_stream(self.weights_stream)
@@ -623,6 +663,8 @@ class GraphedWatermarkLoop:
         join_stream(torch.cuda.current_stream(), self.side_stream)
         if self.weights_stream is not self.side_stream:
             join_stream(torch.cuda.current_stream(), self.weights_stream)
+        if train_step.finish_losses is not None:      # the step's loss values (reporting only): behind everything, off the decoder's forward -> backward path
+            train_step.finish_losses()
         return out
 
     def _optimise(self, defer_collective=False):
