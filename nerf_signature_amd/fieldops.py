@@ -391,6 +391,60 @@ class GradSink:
             p.grad = g if (p.grad is None or not accumulate) else p.grad + g
 
 
+class SharedGradient(GradSink):
+    """The sink for a model driven by SOMEBODY ELSE'S training loop (the reference's Trainer under the drop-in modules): it keeps
+    `zero_grad() / backward() / [GradScaler.unscale_] / optimizer.step()` meaning what they mean, without ever materialising the D identical dense
+    gradients.
+
+    Every selected table's gradient is the same tensor G, so G is handed to autograd's consumers as the `.grad` of ONE of the selected tables (the
+    "carrier": GradScaler unscales and inf-checks it like any gradient, exactly once) while the other D - 1 selected tables keep `.grad = None`; a
+    global optimiser pre-step hook (optim.install_shared_gradient_hook) then updates all D selected tables from G with the fused Adam pass -- torch.optim.Adam's
+    arithmetic and state format -- and clears the carrier's `.grad`, so the optimiser's own loop skips the tables.  Whatever the hook cannot serve (another
+    optimiser class, weight decay, a second message inside one accumulation) is handed back to plain autograd semantics by dissolve(): G fanned out
+    into real per-table gradients.
+
+    Accumulation across the backward passes of one step: the first backward after a zero_grad() finds the carrier's `.grad` gone (set_to_none) or zeroed in
+    place (it IS G) and starts / continues from zero; later ones add."""
+
+    def __init__(self, device):
+        super().__init__(device)
+        self.carrier = None
+        self.live = None          # the selected tables the pending G belongs to
+
+    def pending(self):
+        return self.carrier is not None and self.carrier.grad is self.G
+
+    def begin_accumulation(self, selected):
+        """Called by the field backward right before it scatters into G."""
+        if self.pending():
+            if len(selected) == len(self.live) and all(a is b for a, b in zip(selected, self.live)):
+                return                      # same message: the renders of one step add up
+            self.dissolve()                 # another message inside one accumulation: G is no longer one gradient for one set of tables
+        self.G.zero_()
+        self.live = list(selected)
+        self.carrier = selected[0]
+        if self.carrier.grad is not None:   # an ordinary gradient is already there (fan-out mode earlier in this accumulation): fold it in
+            self.G.add_(self.carrier.grad)
+        self.carrier.grad = self.G
+
+    def dissolve(self):
+        """Back to plain autograd semantics: every selected table gets its own dense gradient (carrier included), G is released."""
+        if not self.pending():
+            self.carrier = self.live = None
+            return
+        slab = torch.empty(len(self.live), T_ROWS, 2, dtype=torch.float32, device=self.G.device)
+        grads = [slab[i] for i in range(len(self.live))]
+        fanout_grad(self.G, grads)
+        for p, g in zip(self.live, grads):
+            p.grad = g if (p.grad is None or p.grad is self.G) else p.grad + g
+        self.carrier = self.live = None
+
+    def consumed(self):
+        if self.carrier is not None and self.carrier.grad is self.G:
+            self.carrier.grad = None
+        self.carrier = self.live = None
+
+
 class _FieldFunction(Function):
     """NeRFNetwork.forward as one autograd node (network_wtmk_tcnn.py:97-124).
 
@@ -418,6 +472,7 @@ class _FieldFunction(Function):
             ctx.save_for_backward(xyzs, sigmas, rgbs, masks, packed)
             if sink is not None:
                 sink.selected = list(sel)
+                ctx.sink_selected = sink.selected
         return sigmas, rgbs
 
     @staticmethod
@@ -432,6 +487,8 @@ class _FieldFunction(Function):
             raise RuntimeError("mlp_set_precision was called between a field forward pass and its backward: the saved ReLU masks belong to the forward's "
                                "arithmetic (run the backward before switching, or switch before the forward)")
         if ctx.sink is not None:
+            if isinstance(ctx.sink, SharedGradient):
+                ctx.sink.begin_accumulation(ctx.sink_selected)
             field_backward_into(xyzs, ctx.bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, ctx.sink.G, plan)
             return head + (None,) * ctx.n_sel
         G = torch.zeros(T_ROWS, 2, dtype=torch.float32, device=xyzs.device)

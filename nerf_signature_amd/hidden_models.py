@@ -218,6 +218,11 @@ class HiddenDecoder_multi_views(nn.Module):
         """The 29 parameters dec_forward takes, or None when this decoder / input is not the shape the fused chain implements."""
         if not (like.is_cuda and like.dtype == torch.float32) or os.environ.get("NERFSIG_DECODER", "") == "torch":
             return None
+        key = (B, Cin, H, W, like.device)
+        cached = self.__dict__.get("_fused_cache")
+        if (cached is not None and cached[0] == key and cached[2][0] is self.layers[0].layers[0].weight and cached[2][-1] is self.linear.bias
+                and cached[2][0].dtype == torch.float32 and cached[2][-1].dtype == torch.float32 and cached[2][0].device == like.device):
+            return cached[1], cached[2]      # (same shape, same parameter objects: the checks below were made then)
         blocks = list(self.layers)[:-1]
         if len(blocks) != 9 or self.num_bits * self.redundancy != 1:
             return None
@@ -230,7 +235,9 @@ class HiddenDecoder_multi_views(nn.Module):
         params = []
         for c, bn in zip(convs, bns):
             params += [c.weight, bn.weight, bn.bias]
-        return bns[0].eps, params + [self.linear.weight, self.linear.bias]
+        params += [self.linear.weight, self.linear.bias]
+        self.__dict__["_fused_cache"] = (key, bns[0].eps, params)
+        return bns[0].eps, params
 
     def decode_rendered(self, image, distortion=None, bce=None):
         """bce = (message, temp, scale): see _FusedDecoder.forward (ignored where the fused chain does not run).

@@ -15,6 +15,13 @@ from .hidden_models import get_hidden_decoder_multi_views, normalize_img
 from .renderer import NeRFRenderer
 
 
+def _data_parallel():
+    """More than one rank: the reference's Trainer wraps the model in DistributedDataParallel, which reduces the `.grad` autograd hands it -- the shared
+    gradient would bypass it."""
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 class NeRFNetwork(NeRFRenderer):
     def __init__(self, num_layers=2, hidden_dim=64, geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64, bound=1, message_dim=16,
                  n_views=1, finetune_decoder=False, **kwargs):
@@ -50,6 +57,10 @@ class NeRFNetwork(NeRFRenderer):
         self._packed_cache = None   # (key, packed weight image)
         self._presum_cache = None   # (key, S)
         self.grad_sink = None       # optional fieldops.GradSink: backward accumulates the shared gradient there
+        # shared_gradient_step (the drop-in modules switch it on): under a foreign training loop -- zero_grad / backward / GradScaler / torch.optim.Adam.step,
+        # the reference Trainer's -- the D identical dense gradients are never materialised: fieldops.SharedGradient + optim.install_shared_gradient_hook
+        self.shared_gradient_step = False
+        self._shared_sink = None
         self.device_select = False  # True: CUDA messages select their tables on the device (graph-capturable step)
         self.codebook_shard = None  # (first bit, last bit) this rank's optimiser owns (dp.optimizer_shard): pre-sums are partial + all-reduced
 
@@ -89,13 +100,26 @@ class NeRFNetwork(NeRFRenderer):
             torch.cuda.current_stream().wait_event(ev)
             self._presum_cache[1].record_stream(torch.cuda.current_stream())
 
+    def _message_bits(self, message):
+        """fo.message_bits with the answer remembered for a device tensor seen before (same object, unmodified): the reference's Trainer hands one device
+        tensor to both renders of a step -- one read-back per step instead of one per render."""
+        if not (torch.is_tensor(message) and message.is_cuda):
+            return fo.message_bits(message)
+        import weakref
+        cached = getattr(self, "_bits_cache", None)
+        if cached is not None and cached[0]() is message and cached[1] == (message.data_ptr(), message._version):
+            return cached[2]
+        bits = fo.message_bits(message)
+        self._bits_cache = (weakref.ref(message), (message.data_ptr(), message._version), bits)
+        return bits
+
     def _select(self, message):
         if message is None:
             return (), None, None
         if getattr(self, "_codebook_stale", False):
             raise RuntimeError("host-side table selection while the codebook optimiser is sharded over the ranks: this rank's copies of the "
                                "other ranks' tables are stale -- call GraphedWatermarkLoop.gather_codebook() on every rank first")
-        bits = fo.message_bits(message)
+        bits = self._message_bits(message)
         if len(bits) != self.message_dim:
             raise ValueError(f"message has {len(bits)} bits, the network was built with message_dim={self.message_dim}")
         selected = fo.select_tables(self.msg_encoder.tables(), bits)
@@ -154,7 +178,14 @@ class NeRFNetwork(NeRFRenderer):
             tables, S = self._select_on_device(message)
             return fo.field_apply(x, d, self.bound, self._packed(), self.encoder.tables(), tables, S, self.grad_sink, fixed)
         selected, _, S = self._select(message)
-        return fo.field_apply(x, d, self.bound, self._packed(), self.encoder.tables(), selected, S, self.grad_sink, fixed)
+        sink = self.grad_sink
+        if sink is None and self.shared_gradient_step and len(selected) and torch.is_grad_enabled() and x.is_cuda and not _data_parallel():
+            if self._shared_sink is None or self._shared_sink.G.device != x.device:
+                from .optim import install_shared_gradient_hook
+                self._shared_sink = fo.SharedGradient(x.device)
+                install_shared_gradient_hook(self._shared_sink)
+            sink = self._shared_sink
+        return fo.field_apply(x, d, self.bound, self._packed(), self.encoder.tables(), selected, S, sink, fixed)
 
     def _count_points(self, o, d, dt_gamma, max_steps):
         """Padded sample total of these rays through the current grid (one counting march, one host read)."""

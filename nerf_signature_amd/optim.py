@@ -16,6 +16,79 @@ import torch
 from . import _native as nv
 
 
+def fused_shared_step(optimizer, group, selected, G, grad_scale=1.0):
+    """torch.optim.Adam's update of the `selected` tables of `group`, all carrying the gradient G [T,2], as ONE pass (opt_codebook_adam): state in
+    `optimizer.state` in torch's own (non-capturable) format, per-table step counts."""
+    beta1, beta2 = group["betas"]
+    lr, eps = float(group["lr"]), float(group["eps"])
+    D = len(selected)
+    vp = ctypes.c_void_p * D
+    pp, pm, pv, step_sizes, inv_bc2 = vp(), vp(), vp(), (ctypes.c_float * D)(), (ctypes.c_float * D)()
+    handles = optimizer.__dict__.setdefault("_nsig_table_handles", {})      # id(table) -> (table, state dict, exp_avg, exp_avg_sq, their addresses)
+    for i, p in enumerate(selected):
+        h = handles.get(id(p))
+        if h is None or h[0] is not p or h[1].get("exp_avg") is not h[2] or h[1].get("exp_avg_sq") is not h[3]:      # (a loaded checkpoint replaces the state tensors)
+            st = optimizer.state[p]
+            if len(st) == 0:   # torch.optim.Adam._init_group
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            for t in (p, st["exp_avg"], st["exp_avg_sq"]):
+                if not (t.is_contiguous() and t.dtype == torch.float32):
+                    raise ValueError("fused_shared_step: tables and their Adam moments must be contiguous float32 tensors")
+            h = handles[id(p)] = (p, st, st["exp_avg"], st["exp_avg_sq"], p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr())
+        st = h[1]
+        st["step"] += 1
+        step = float(st["step"])
+        pp[i], pm[i], pv[i] = h[4], h[5], h[6]
+        step_sizes[i] = lr / (1.0 - beta1 ** step)
+        inv_bc2[i] = 1.0 / math.sqrt(1.0 - beta2 ** step)
+    nv.call("opt_codebook_adam", nv.ptr(G), pp, pm, pv, D, float(beta1), float(beta2), eps, step_sizes, inv_bc2, float(grad_scale), nv.stream())
+    _bump_versions(selected)
+
+
+_SHARED_SINKS = None      # weak set of fieldops.SharedGradient sinks with (possibly) pending gradients
+
+
+def install_shared_gradient_hook(sink):
+    """Register `sink` (a fieldops.SharedGradient) with the process-wide optimiser pre-step hook (installed on first use): whenever ANY optimiser is about to
+    step, a sink whose carrier table it manages is served -- by the fused pass where the optimiser is a plain Adam (the reference's,
+    main_nerf_wtmk.py:110: no weight decay / amsgrad / maximize, not capturable), by dissolving it into ordinary per-table gradients otherwise."""
+    global _SHARED_SINKS
+    import weakref
+    if _SHARED_SINKS is None:
+        _SHARED_SINKS = weakref.WeakSet()
+        from torch.optim.optimizer import register_optimizer_step_pre_hook
+        register_optimizer_step_pre_hook(_shared_gradient_pre_step)
+    _SHARED_SINKS.add(sink)
+
+
+@torch.no_grad()
+def _shared_gradient_pre_step(optimizer, args, kwargs):
+    for sink in list(_SHARED_SINKS or ()):
+        if not sink.pending():
+            continue
+        members = optimizer.__dict__.setdefault("_nsig_group_members", {})      # per param group: the ids of its parameters (rebuilt when the group's size changes)
+        group = None
+        for g in optimizer.param_groups:
+            ids = members.get(id(g))
+            if ids is None or ids[0] != len(g["params"]):
+                ids = members[id(g)] = (len(g["params"]), {id(q) for q in g["params"]})
+            if id(sink.carrier) in ids[1]:
+                group = g
+                break
+        if group is None:
+            continue                                    # not this optimiser's parameter
+        plain = (isinstance(optimizer, torch.optim.Adam) and not group.get("weight_decay", 0) and not group.get("amsgrad", False) and not group.get("maximize", False)
+                 and not group.get("capturable", False) and not group.get("differentiable", False) and not torch.is_tensor(group["lr"])
+                 and all(id(t) in ids[1] for t in sink.live))
+        if not plain:
+            sink.dissolve()                             # the optimiser sees D ordinary dense gradients
+            continue
+        fused_shared_step(optimizer, group, sink.live, sink.G)
+        sink.consumed()                                 # `.grad` of every selected table is None now: the optimiser's own loop skips them
+
+
 class CodebookAdam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, **kw):
         if kw.get("weight_decay", 0) or kw.get("amsgrad", False) or kw.get("maximize", False):
@@ -33,27 +106,7 @@ class CodebookAdam(torch.optim.Adam):
         """Adam step of the `selected` tables (all in one param group) with the shared gradient G [T,2]."""
         if not selected:
             return
-        group = self._group_of(selected[0])
-        beta1, beta2 = group["betas"]
-        lr, eps = float(group["lr"]), float(group["eps"])
-        ms, vs, step_sizes, inv_bc2 = [], [], [], []
-        for p in selected:
-            st = self.state[p]
-            if len(st) == 0:   # torch.optim.Adam._init_group
-                st["step"] = torch.tensor(0.0, dtype=torch.float32)
-                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            st["step"] += 1
-            step = float(st["step"])
-            ms.append(st["exp_avg"])
-            vs.append(st["exp_avg_sq"])
-            step_sizes.append(lr / (1.0 - beta1 ** step))
-            inv_bc2.append(1.0 / math.sqrt(1.0 - beta2 ** step))
-        D = len(selected)
-        f32 = ctypes.c_float * D
-        nv.call("opt_codebook_adam", nv.ptr(G), nv.ptr_array([p.data for p in selected]), nv.ptr_array(ms), nv.ptr_array(vs), D,
-                float(beta1), float(beta2), eps, f32(*step_sizes), f32(*inv_bc2), float(grad_scale), nv.stream())
-        _bump_versions(selected)
+        fused_shared_step(self, self._group_of(selected[0]), selected, G, grad_scale)
 
 
 def _prepare_device_state(opt, tables):

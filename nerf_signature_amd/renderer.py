@@ -581,5 +581,30 @@ class NeRFRenderer(nn.Module):
                     head += max_ray_batch
             results = {"depth": depth, "image": image}
         else:
+            if getattr(self, "auto_fix_rays", False):
+                self._maybe_fix_rays(rays_o, rays_d, **kwargs)
             results = _run(rays_o, rays_d, message, **kwargs)
         return results
+
+    def _maybe_fix_rays(self, rays_o, rays_d, dt_gamma=0, max_steps=1024, perturb=False, force_all_rays=False, **kwargs):
+        """auto_fix_rays (the drop-in modules switch it on): a training render that is handed the SAME two ray tensors (same objects, unmodified) a second
+        time -- the watermark-block rays, which the reference's dataset builds once (provider_wtmk.py:442-494) and passes every step -- declares them
+        constant by itself (NeRFNetwork.fix_rays: samples marched once, base-level planes and scatter plan kept; bit-identical renders), which
+        INTEGRATION.md section 5 otherwise asks the user to do with one call.  Identity is by object (weak references), never by address alone: the
+        content rays are fresh tensors every step and the allocator reuses their addresses."""
+        if not (self.cuda_ray and self.training and force_all_rays and not perturb and rays_o.is_cuda and torch.is_grad_enabled()
+                and getattr(self, "point_capacity", None) is None and hasattr(self, "fix_rays") and not torch.cuda.is_current_stream_capturing()):
+            return
+        import weakref
+        seen = self.__dict__.setdefault("_ray_sightings", {})
+        key, ver = id(rays_o), (rays_o._version, rays_d._version, rays_o.data_ptr(), rays_d.data_ptr(), float(dt_gamma), int(max_steps))
+        rec = seen.get(key)
+        if rec is not None and rec[0]() is rays_o and rec[1]() is rays_d and rec[2] == ver:
+            if not rec[3]:
+                self.fix_rays(rays_o, rays_d, dt_gamma, max_steps)
+                rec[3] = True
+            seen[key] = seen.pop(key)          # most recently used last
+            return
+        seen[key] = [weakref.ref(rays_o), weakref.ref(rays_d), ver, False]
+        while len(seen) > 4:
+            seen.pop(next(iter(seen)))

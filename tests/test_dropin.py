@@ -18,7 +18,9 @@ for name in ("trimesh","cv2","imageio","tensorboardX","mcubes","torch_ema","lpip
     except Exception: sys.modules[name] = MagicMock()
 import nerf, nerf.network_wtmk_tcnn, nerf.renderer_wtmk, raymarching, hash_encoding, hash_encoding_wtmk_bit, activation
 import nerf_signature_amd.network as ours
-assert nerf.network_wtmk_tcnn.NeRFNetwork is ours.NeRFNetwork
+assert issubclass(nerf.network_wtmk_tcnn.NeRFNetwork, ours.NeRFNetwork)      # the same model, with the foreign-loop accelerations switched on
+_m = nerf.network_wtmk_tcnn.NeRFNetwork(bound=1.0, cuda_ray=True, message_dim=4, n_views=1)
+assert _m.shared_gradient_step and _m.auto_fix_rays and set(_m.state_dict()) == set(ours.NeRFNetwork(bound=1.0, cuda_ray=True, message_dim=4, n_views=1).state_dict())
 assert hash_encoding.HashEmbedder.__module__ == "nerf_signature_amd.hash_encoding"
 assert hash_encoding_wtmk_bit.HashEmbedder.__module__ == "nerf_signature_amd.hash_encoding_wtmk_bit"
 assert raymarching.__file__.startswith(ROOT) and callable(raymarching.march_rays_train)

@@ -245,3 +245,64 @@ def test_capacity_overflow_is_detected_and_recaptured():
     # (the parameters moved by one more optimiser step between the two evaluations: compare the image loss loosely, the point is that
     #  no ray is dropped any more: the loss of a render with dropped rays is off by orders of magnitude)
     assert abs(float(out[3]) - float(want[3])) < 0.05 * float(want[3]) + 1e-4
+
+
+def test_shared_gradient_step_under_a_foreign_loop_matches_plain_autograd_and_adam():
+    """What the drop-in modules switch on for the reference's own Trainer (NeRFNetwork.shared_gradient_step + auto_fix_rays): zero_grad / train_step under
+    autocast / GradScaler.scale(loss).backward() / scaler.step(torch.optim.Adam) / scaler.update(), four steps with a new message each -- against the same
+    loop on a model with plain autograd gradients (D dense fan-outs, the optimiser's own loop).  Same losses, same parameters (the fused pass IS
+    torch.optim.Adam's arithmetic), same per-table Adam step counts in torch's own state format, a skipped step (injected inf) skipped on both sides, and
+    between backward() and step() exactly ONE selected table carries a `.grad` -- the shared tensor -- which GradScaler unscales once."""
+    import test_gpu_render as T
+    from nerf_signature_amd import trainer
+    bo, bd, co, cd, gt = T._data(n_content=300)
+    msgs = [torch.from_numpy(np.random.RandomState(s).randint(0, 2, 32).astype(np.float32)).cuda() for s in range(4)]
+    kw = dict(dt_gamma=0, max_steps=1024)
+    runs = []
+    for shared in (False, True):
+        torch.manual_seed(0)
+        m, _, _ = T._model()
+        m.shared_gradient_step = shared
+        m.auto_fix_rays = shared
+        data = {"watermark": {"rays_o_block": bo.cuda(), "rays_d_block": bd.cuda()}, "content": {"rays_o": co.cuda(), "rays_d": cd.cuda(), "images": gt.cuda()}}
+        opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+        losses, carriers = [], []
+        for k, msg in enumerate(msgs):
+            opt.zero_grad()
+            with torch.autocast("cuda"):
+                out = trainer.train_step(m, data, msg, kw, lambda_w=0.005, lambda_i=1.0)
+            loss = out[5] * (float("inf") if k == 2 else 1.0)           # step 2 overflows: GradScaler must skip it and halve the scale, on both sides
+            scaler.scale(loss).backward()
+            with_grad = [i for i, e in enumerate(m.msg_encoder.embeddings) if e.weight.grad is not None]
+            carriers.append(len(with_grad))
+            scaler.step(opt)
+            scaler.update()
+            losses.append(float(out[5].detach()))
+        torch.cuda.synchronize()
+        tables = [e.weight.detach().clone() for e in m.msg_encoder.embeddings]
+        steps = [float(opt.state[e.weight]["step"]) if len(opt.state[e.weight]) else 0.0 for e in m.msg_encoder.embeddings]
+        dec = torch.cat([p.detach().reshape(-1) for p in m.msg_decoder.parameters()])
+        runs.append((losses, tables, steps, dec, carriers, scaler.get_scale(), m))
+    (l0, t0, s0, d0, c0, sc0, m0), (l1, t1, s1, d1, c1, sc1, m1) = runs
+    assert c0 == [32, 32, 32, 32] and c1 == [1, 1, 1, 1]                    # plain: every selected table has a dense gradient; shared: the carrier alone
+    assert sc0 == sc1 == 512.0                                              # one skipped step on both sides
+    assert s0 == s1 and sum(s0) == 3 * 32                                   # three real steps, per-table counts as torch.optim.Adam keeps them
+    np.testing.assert_allclose(l1, l0, rtol=2e-3, atol=2e-5)
+    moved = sum(float((a - torch.from_numpy(cf.table(100 + l, scale=0.05)).cuda()).pow(2).sum()) for l, a in enumerate(t0)) ** 0.5
+    diff = sum(float((a - b).pow(2).sum()) for a, b in zip(t0, t1)) ** 0.5
+    assert moved > 0 and diff / moved < 0.05                                # (Adam with eps = 1e-15 turns last-bit differences of G into +-lr steps: aggregate bound)
+    assert float((d0 - d1).norm() / d0.norm()) < 0.05
+    assert all(e.weight.grad is None for e in m1.msg_encoder.embeddings)    # consumed by the fused pass
+    # the block rays were seen twice: the kept-planes route is in use from the second step on (same renders bit for bit: tests/test_gpu_fixed.py)
+    assert any(r.get("fixed") is not None for r in getattr(m1, "_marched", {}).values()) and not getattr(m0, "_marched", None)
+    # an optimiser the fused pass does not implement (weight decay): the shared gradient dissolves into ordinary dense gradients, the step is torch's
+    opt_w = torch.optim.Adam(m1.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-4)
+    opt_w.zero_grad()
+    out = trainer.train_step(m1, data, msgs[0], kw)
+    out[5].backward()
+    assert sum(e.weight.grad is not None for e in m1.msg_encoder.embeddings) == 1
+    before = [e.weight.detach().clone() for e in m1.msg_encoder.embeddings]
+    opt_w.step()
+    assert sum(int(not torch.equal(a, e.weight.detach())) for a, e in zip(before, m1.msg_encoder.embeddings)) == 32
+    assert sum(e.weight.grad is not None for e in m1.msg_encoder.embeddings) == 32

@@ -22,6 +22,10 @@ ap.add_argument("--no-fp16", action="store_true")
 ap.add_argument("--profile", action="store_true")
 ap.add_argument("--fix-rays", action="store_true", help="the one call INTEGRATION.md section 5 offers: model.fix_rays(block rays)")
 ap.add_argument("--no-item", action="store_true", help="skip the three per-step loss.item() reads (diagnostics)")
+ap.add_argument("--plain", action="store_true", help="the model as a library user gets it (nerf_signature_amd.network.NeRFNetwork): plain autograd gradients, the optimiser's own "
+                                                      "loop over D dense tables, no automatic kept-planes route -- what rounds 1-3 gave a drop-in user")
+ap.add_argument("--no-shared-gradient", action="store_true")
+ap.add_argument("--no-auto-fix", action="store_true")
 args = ap.parse_args()
 
 from nerf_signature_amd import quality, synthetic, trainer
@@ -30,6 +34,9 @@ real_stdout = os.dup(1)
 os.dup2(2, 1)
 stage = quality.watermark_stage("hotdog")
 model, dev, D, H, W = stage["model"], stage["device"], stage["D"], stage["H"], stage["W"]
+# the drop-in module's model (nerf_signature_amd/dropin/nerf/network_wtmk_tcnn.py) switches both on
+model.shared_gradient_step = not (args.plain or args.no_shared_gradient)
+model.auto_fix_rays = not (args.plain or args.no_auto_fix)
 opt_ns = dict(stage["render_kwargs"], num_rays=4096, lr=1e-2, workspace="x", fp16=not args.no_fp16)      # vars(opt) is splatted into render()
 optimizer = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)                       # main_nerf_wtmk.py:110
 scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lambda it: 0.1 ** min(it / 1000, 1))             # :115
@@ -71,11 +78,14 @@ if args.profile:
     import pstats
     pr = cProfile.Profile()
     pr.enable()
-t0 = time.perf_counter()
-for k in range(args.steps):
-    last = step(args.warmup + k)
-torch.cuda.synchronize()
-el = time.perf_counter() - t0
+windows = []
+for w in range(1 if args.profile else 3):
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        last = step(args.warmup + w * args.steps + k)
+    torch.cuda.synchronize()
+    windows.append((time.perf_counter() - t0) / args.steps * 1e3)
+el = float(np.median(windows)) * args.steps / 1e3
 if args.profile:
     pr.disable()
     st = pstats.Stats(pr, stream=sys.stderr)
@@ -84,5 +94,5 @@ if args.profile:
 os.dup2(real_stdout, 1)
 print(json.dumps({"what": "reference Trainer loop body (utils_wtmk_disen.py:1164-1190) around this repo's model: eager, autocast(fp16) + GradScaler, plain torch.optim.Adam, "
                           "loader-style rays per step, three .item() reads per step; NOT the headline path",
-                  "ms_per_step": el / args.steps * 1e3, "content_rays_per_s": 4096 * args.steps / el, "steps": args.steps, "fp16": not args.no_fp16,
-                  "fix_rays": bool(args.fix_rays), "loss": last[0] if last else None, "grad_scale": float(scaler.get_scale()) if not args.no_fp16 else None}), flush=True)
+                  "ms_per_step": el / args.steps * 1e3, "ms_per_step_windows": [round(w, 4) for w in windows], "content_rays_per_s": 4096 * args.steps / el, "steps": args.steps, "fp16": not args.no_fp16,
+                  "fix_rays": bool(args.fix_rays), "shared_gradient_step": bool(model.shared_gradient_step), "auto_fix_rays": bool(model.auto_fix_rays), "loss": last[0] if last else None, "grad_scale": float(scaler.get_scale()) if not args.no_fp16 else None}), flush=True)
