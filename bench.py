@@ -463,14 +463,16 @@ def run_secondaries(args):
       rank_emulation one rank of 2 / 4 / 8 on this GPU, in both execution modes of the multi-rank step + fixed blocks (tools/emulate_ranks.py: kernel work and
                      launch structure of a rank, every collective issued on a world-size-1 RCCL group, no xGMI latency)
       eager_reference_trainer_shape   the loop a user of the UNCHANGED reference CLI drives: the reference Trainer's loop body around this repo's model,
-                     eager, autocast(fp16) + GradScaler, plain torch.optim.Adam, loader-style rays and three .item() reads per step (tools/trainer_shape.py)"""
+                     eager, autocast(fp16) + GradScaler, plain torch.optim.Adam, loader-style rays and three .item() reads per step (tools/trainer_shape.py)
+      eval_loop      the eval-mode burst loop (renderer_wtmk.py:335-372) on one 400x400 view, control on the device vs read back every round (tools/eval_bench.py)"""
     out = {}
     k = str(min(args.steps, 50))
     jobs = (("quality", [os.path.join(ROOT, "tools", "converge.py"), "graphed", "--steps", "1000", "--messages", "200"]),
             ("counter", [os.path.abspath(__file__), "--config", "counter", "--steps", k, "--warmup", str(min(args.warmup, 5)), "--no-cpu-baseline", "--no-secondary", "--windows", "1"]),
             ("fern", [os.path.abspath(__file__), "--config", "fern", "--steps", "5", "--warmup", "1", "--no-secondary"]),
             ("rank_emulation", [os.path.join(ROOT, "tools", "emulate_ranks.py"), "--steps", k]),
-            ("eager_reference_trainer_shape", [os.path.join(ROOT, "tools", "trainer_shape.py"), "--steps", "100"]))
+            ("eager_reference_trainer_shape", [os.path.join(ROOT, "tools", "trainer_shape.py"), "--steps", "100"]),
+            ("eval_loop", [os.path.join(ROOT, "tools", "eval_bench.py")]))
     for name, argv in jobs:
         t0 = time.time()
         try:
@@ -482,7 +484,7 @@ def run_secondaries(args):
                 continue
             j = json.loads(lines[-1])
             c = j.get("config", {})
-            if name in ("quality", "rank_emulation", "eager_reference_trainer_shape"):
+            if name in ("quality", "rank_emulation", "eager_reference_trainer_shape", "eval_loop"):
                 out[name] = j
             elif name == "counter":
                 out[name] = {"ms_per_step": j["ms_per_step"], "content_rays_per_s": j["value"], "points_per_s": c.get("points_per_s"), "points_per_step": c.get("points_per_step_per_rank"),

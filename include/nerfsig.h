@@ -129,6 +129,27 @@ int rm_composite(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *ray
 int rm_compact_alive(const int32_t *rays_alive, uint32_t n_alive, int32_t *rays_alive_out, int32_t *n_out,
                      nsig_stream_t stream);
 
+/*
+ * The same eval loop (renderer_wtmk.py:335-372) with its CONTROL on the device: no per-round read-back of the survivor count.
+ *   ctl  device uint32[4] = {n_alive, n_step, rows = n_alive * n_step, samples marched so far}
+ * rm_eval_begin fills rays_alive with 0..N-1 and ctl with {N, 1, N, 0}.  A round is rm_eval_march -> the field pass over `rows` rows
+ * (hg_encode_planes_rows / field_fwd_rows: launches sized for the capacity N, the row count read from ctl + 2) -> rm_eval_composite ->
+ * rm_eval_compact, which compacts the alive list into rays_alive_out and writes the NEXT round's ctl: n_alive = survivors (0 once max_steps
+ * samples have been marched), n_step = clamp(N / n_alive, 1, 8).  Every launch is sized for the worst case (n_alive * n_step <= N) and
+ * early-outs on the device counts, so the host may enqueue rounds blindly and read ctl[0] back once every few rounds, only to stop.
+ * Buffers: xyzs / dirs [N, 3], deltas [N, 2], sigmas [N], rgbs [N, 3] (no 128-row padding: rows beyond `rows` are never read); rm_eval_march writes
+ * zero rows for a ray that ends inside its burst.  density_scale multiplies sigma inside the compositor (:353).  Same bursts, alive lists and images as
+ * rm_march / rm_composite / rm_compact_alive driven from the host.
+ */
+int rm_eval_begin(uint32_t N, uint32_t *ctl, int32_t *rays_alive, nsig_stream_t stream);
+int rm_eval_march(const uint32_t *ctl, uint32_t N, const int32_t *rays_alive, const float *rays_t, const float *rays_o, const float *rays_d,
+                  float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *density_bitfield, const float *fars,
+                  float *xyzs, float *dirs, float *deltas, const float *noises, nsig_stream_t stream);
+int rm_eval_composite(const uint32_t *ctl, uint32_t N, float T_thresh, float density_scale, int32_t *rays_alive, float *rays_t,
+                      const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum, float *depth, float *image,
+                      nsig_stream_t stream);
+int rm_eval_compact(uint32_t *ctl, uint32_t N, uint32_t max_steps, const int32_t *rays_alive, int32_t *rays_alive_out, nsig_stream_t stream);
+
 /* ------------------------------------------------------------------ ray generation */
 
 /* The arithmetic of get_rays (nerf/utils_wtmk_disen.py:59-143): pinhole rays through pixel centres, normalised,
@@ -281,6 +302,13 @@ int field_fwd(const float *xyzs, const float *dirs, uint32_t M, float bound, con
 size_t hg_planes_bytes(uint32_t M);
 int hg_encode_planes(const float *xyzs, uint32_t M, float bound, const float *const *base_tables_host, const float *S,
                      void *planes, nsig_stream_t stream);
+/* hg_encode_planes / field_fwd (inference outputs: sigmas + rgbs) over a row count that lives on the DEVICE (*rows_dev <= M_capacity): the
+ * launch, the plane stride and every buffer are sized for M_capacity, rows beyond the count are skipped (the eval loop above). */
+int hg_encode_planes_rows(const float *xyzs, uint32_t M_capacity, const uint32_t *rows_dev, float bound,
+                          const float *const *base_tables_host, const float *S, void *planes, nsig_stream_t stream);
+int field_fwd_rows(const float *xyzs, const float *dirs, uint32_t M_capacity, const uint32_t *rows_dev, float bound,
+                   const float *const *base_tables_host, const float *S, const void *packed, float *sigmas, float *rgbs, const void *planes,
+                   nsig_stream_t stream);
 
 /* Reads the 16 base tables (and S when given) once, each through the XCD whose workgroups will gather from it in hg_encode_planes, so that
  * the launch finds its tables in L2 instead of starting on caches a streaming pass (the optimiser's) has flushed: the bench workload's block

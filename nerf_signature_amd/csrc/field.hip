@@ -457,7 +457,17 @@ __global__ void __launch_bounds__(256) k_warm_tables(TablePtrs base, const float
 
 // Workgroup (tile, slot) encodes, for its 256 points, the levels (or the part of a level's tile range) assigned to its XCD slot.
 __global__ void __launch_bounds__(256) k_encode_planes(const float *__restrict__ xyzs, uint32_t M, float bound, TablePtrs base, LevelGeom geom,
-                                                       const float *__restrict__ S, float2 *__restrict__ planes, uint32_t stride, SlotTable tab) {
+                                                       const float *__restrict__ S, float2 *__restrict__ planes, uint32_t stride, SlotTable tab,
+                                                       const uint32_t *__restrict__ rows_dev = nullptr) {
+    // rows_dev (the eval loop's bursts, hg_encode_planes_rows): the number of rows that exist is known on the device only; the launch is sized for `M`
+    // (the buffers' capacity, which also fixes the plane stride) and rows beyond the count are skipped
+    uint32_t lim = stride;
+    if (rows_dev != nullptr) {
+        const uint32_t r = *rows_dev;
+        if (r == 0) return;
+        M = min(M, r);
+        lim = min(stride, ceil_div(M, 32u) * 32u);
+    }
     const uint32_t slot = blockIdx.x & 7u;
     const uint32_t n_tiles = ceil_div(stride, 256u);
     const int n_levels = tab.n[slot];
@@ -465,7 +475,7 @@ __global__ void __launch_bounds__(256) k_encode_planes(const float *__restrict__
     const uint32_t xs = threadIdx.x & 1u;   // which x side of the cell this lane fetches
     for (uint32_t tile = blockIdx.x >> 3; tile < n_tiles; tile += gridDim.x >> 3) {
         const uint32_t m = tile * 256 + threadIdx.x;
-        if (m >= stride) continue;          // stride is a multiple of 32: lane pairs (and DPP quads) are in or out together
+        if (m >= lim) continue;             // a multiple of 32: lane pairs (and DPP quads) are in or out together
         const uint32_t ml = min(m, M - 1);  // rows in [M, stride) replicate the last point (never consumed)
         // one 12-byte load and one 8-byte streaming store per level: the kernel is bound by the address path, every instruction counts
         const float3 pt = *reinterpret_cast<const float3 *>(xyzs + 3 * (size_t)ml);
@@ -653,8 +663,14 @@ __device__ inline void field_fwd_pipelined(const char *lds, int lane, const floa
 template <typename P>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_field_fwd_train(const float *__restrict__ dirs, uint32_t M, bool add_codebook, const float2 *__restrict__ planes, uint32_t stride,
-                  const char *__restrict__ packed, float *__restrict__ sigmas, float *__restrict__ rgbs, uint32_t *__restrict__ masks) {
+                  const char *__restrict__ packed, float *__restrict__ sigmas, float *__restrict__ rgbs, uint32_t *__restrict__ masks,
+                  const uint32_t *__restrict__ rows_dev = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    if (rows_dev != nullptr) {      // (field_fwd_rows: the row count lives on the device; M is the capacity the launch and the plane stride were sized for)
+        const uint32_t r = *rows_dev;
+        if (r == 0) return;
+        M = min(M, r);
+    }
     stage_weights(lds, packed + P::kFwdOffset, (int)P::kFwdLds);
     field_fwd_pipelined<P>(lds, threadIdx.x & 63, dirs, M, add_codebook, planes, stride, sigmas, rgbs, masks);
 }
@@ -665,8 +681,13 @@ __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyz
                                                    const float2 *__restrict__ planes, uint32_t stride,
                                                    const char *__restrict__ packed, float *__restrict__ sigmas, float *__restrict__ rgbs,
                                                    float *__restrict__ geo_out, uint32_t *__restrict__ masks, ActTrace trace = ActTrace{},
-                                                   BinHeader *__restrict__ plan_reset = nullptr) {
+                                                   BinHeader *__restrict__ plan_reset = nullptr, const uint32_t *__restrict__ rows_dev = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    if (rows_dev != nullptr) {      // (field_fwd_rows)
+        const uint32_t r = *rows_dev;
+        if (r == 0) return;
+        M = min(M, r);
+    }
     stage_weights(lds, packed + P::kFwdOffset, (int)P::kFwdLds);
     constexpr size_t kHalf = kFwdBytes;
     if (kPlanes == 2 && plan_reset != nullptr && blockIdx.x == 0 && threadIdx.x == 0) plan_reset->gmax_bits = 0;   // (as hg_encode_codebook_plane)
@@ -1241,8 +1262,8 @@ NSIG_EXPORT int hg_warm_tables(const float *const *base_tables_host, const float
 
 NSIG_EXPORT size_t hg_planes_bytes(uint32_t M) { return (size_t)(NSIG_BASE_LEVELS + 1) * ceil_div(M, 32u) * 32u * sizeof(float2); }
 
-NSIG_EXPORT int hg_encode_planes(const float *xyzs, uint32_t M, float bound, const float *const *base_tables_host, const float *S, void *planes,
-                                 nsig_stream_t stream) {
+static int encode_planes_impl(const float *xyzs, uint32_t M, float bound, const float *const *base_tables_host, const float *S, void *planes,
+                              const uint32_t *rows_dev, nsig_stream_t stream) {
     if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(xyzs && planes, "hg_encode_planes: null pointer");
     NSIG_REQUIRE(bound > 0.0f, "hg_encode_planes: bound must be positive");
@@ -1262,8 +1283,19 @@ NSIG_EXPORT int hg_encode_planes(const float *xyzs, uint32_t M, float bound, con
     // render's launch takes 244-247 us against 258-261 us with 1024 looping workgroups per slot (same-box sweep, profiles/r01_k_encoder_grid_sweep.txt)
     static const uint32_t cap = getenv("NERFSIG_ENC_PER_SLOT") ? (uint32_t)atoi(getenv("NERFSIG_ENC_PER_SLOT")) : 8192u;
     const uint32_t per_slot = tiles < cap ? tiles : cap;
-    k_encode_planes<<<per_slot * 8, 256, 0, as_stream(stream)>>>(xyzs, M, bound, base, make_level_geom(), S, reinterpret_cast<float2 *>(planes), stride, tab);
+    k_encode_planes<<<per_slot * 8, 256, 0, as_stream(stream)>>>(xyzs, M, bound, base, make_level_geom(), S, reinterpret_cast<float2 *>(planes), stride, tab, rows_dev);
     return check_launch("hg_encode_planes");
+}
+
+NSIG_EXPORT int hg_encode_planes(const float *xyzs, uint32_t M, float bound, const float *const *base_tables_host, const float *S, void *planes,
+                                 nsig_stream_t stream) {
+    return encode_planes_impl(xyzs, M, bound, base_tables_host, S, planes, nullptr, stream);
+}
+
+NSIG_EXPORT int hg_encode_planes_rows(const float *xyzs, uint32_t M_capacity, const uint32_t *rows_dev, float bound, const float *const *base_tables_host,
+                                      const float *S, void *planes, nsig_stream_t stream) {
+    NSIG_REQUIRE(rows_dev != nullptr, "hg_encode_planes_rows: null row count");
+    return encode_planes_impl(xyzs, M_capacity, bound, base_tables_host, S, planes, rows_dev, stream);
 }
 
 NSIG_EXPORT int hg_encode_codebook_plane(const float *xyzs, uint32_t M, float bound, const float *S, void *planes, void *plan_to_reset,
@@ -1280,9 +1312,9 @@ NSIG_EXPORT int hg_encode_codebook_plane(const float *xyzs, uint32_t M, float bo
     return check_launch("hg_encode_codebook_plane");
 }
 
-NSIG_EXPORT int field_fwd(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *const *base_tables_host,
+static int field_fwd_impl(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *const *base_tables_host,
                           const float *S, const void *packed, float *sigmas, float *rgbs, float *geo_feat, uint32_t *masks,
-                          const void *planes, nsig_stream_t stream) {
+                          const void *planes, const uint32_t *rows_dev, nsig_stream_t stream) {
     if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(xyzs && packed && sigmas, "field_fwd: null pointer");
     NSIG_REQUIRE(rgbs == nullptr || dirs != nullptr, "field_fwd: dirs is required when rgbs is requested");
@@ -1294,20 +1326,33 @@ NSIG_EXPORT int field_fwd(const float *xyzs, const float *dirs, uint32_t M, floa
     hipStream_t st = as_stream(stream);
     const bool f16 = mlp_precision() == 1;
     if (planes == nullptr) {  // fused: gather inside the MLP kernel (small batches)
-        if (f16) k_field_fwd<F16, 0><<<field_grid(M, true), 256, F16::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, nullptr, 0, pk, sigmas, rgbs, geo_feat, masks);
-        else k_field_fwd<Bf16x3, 0><<<field_grid(M, true), 256, Bf16x3::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, nullptr, 0, pk, sigmas, rgbs, geo_feat, masks);
+        if (f16) k_field_fwd<F16, 0><<<field_grid(M, true), 256, F16::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, nullptr, 0, pk, sigmas, rgbs, geo_feat, masks, ActTrace{}, nullptr, rows_dev);
+        else k_field_fwd<Bf16x3, 0><<<field_grid(M, true), 256, Bf16x3::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, nullptr, 0, pk, sigmas, rgbs, geo_feat, masks, ActTrace{}, nullptr, rows_dev);
         return check_launch("field_fwd");
     }
     NSIG_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 7) == 0, "field_fwd: planes must be 8-byte aligned");
     const uint32_t stride = ceil_div(M, 32u) * 32u;
     const float2 *pl = reinterpret_cast<const float2 *>(planes);
     if (f16 && fwd_pipelined() && dirs != nullptr && rgbs != nullptr && geo_feat == nullptr) {    // the training render's launch (masks) and staged no-grad renders
-        k_field_fwd_train<F16><<<field_grid(M, true, 2), 256, F16::kFwdLds, st>>>(dirs, M, S != nullptr, pl, stride, pk, sigmas, rgbs, masks);
+        k_field_fwd_train<F16><<<field_grid(M, true, 2), 256, F16::kFwdLds, st>>>(dirs, M, S != nullptr, pl, stride, pk, sigmas, rgbs, masks, rows_dev);
         return check_launch("field_fwd");
     }
-    if (f16) k_field_fwd<F16, 1><<<field_grid(M, true), 256, F16::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, geo_feat, masks);
-    else k_field_fwd<Bf16x3, 1><<<field_grid(M, true), 256, Bf16x3::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, geo_feat, masks);
+    if (f16) k_field_fwd<F16, 1><<<field_grid(M, true), 256, F16::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, geo_feat, masks, ActTrace{}, nullptr, rows_dev);
+    else k_field_fwd<Bf16x3, 1><<<field_grid(M, true), 256, Bf16x3::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, geo_feat, masks, ActTrace{}, nullptr, rows_dev);
     return check_launch("field_fwd");
+}
+
+NSIG_EXPORT int field_fwd(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *const *base_tables_host,
+                          const float *S, const void *packed, float *sigmas, float *rgbs, float *geo_feat, uint32_t *masks,
+                          const void *planes, nsig_stream_t stream) {
+    return field_fwd_impl(xyzs, dirs, M, bound, base_tables_host, S, packed, sigmas, rgbs, geo_feat, masks, planes, nullptr, stream);
+}
+
+NSIG_EXPORT int field_fwd_rows(const float *xyzs, const float *dirs, uint32_t M_capacity, const uint32_t *rows_dev, float bound,
+                               const float *const *base_tables_host, const float *S, const void *packed, float *sigmas, float *rgbs, const void *planes,
+                               nsig_stream_t stream) {
+    NSIG_REQUIRE(rows_dev != nullptr, "field_fwd_rows: null row count");
+    return field_fwd_impl(xyzs, dirs, M_capacity, bound, base_tables_host, S, packed, sigmas, rgbs, nullptr, nullptr, planes, rows_dev, stream);
 }
 
 NSIG_EXPORT int field_fwd_kept(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *S, const void *packed, float *sigmas,

@@ -908,11 +908,91 @@ __global__ void k_march_burst(uint32_t n_alive, uint32_t n_step, const int32_t *
     }
 }
 
+// The eval loop with its control state on the device (rm_eval_*): ctl = {n_alive, n_step, rows = n_alive * n_step, samples marched so far}.  A round's
+// launches are sized for the worst case (n_alive * n_step <= N rays) and early-out on the counts; the host reads ctl back only now and then, to stop.
+__global__ void k_march_burst_ctl(const uint32_t *__restrict__ ctl, const int32_t *__restrict__ rays_alive, const float *__restrict__ rays_t,
+                                  const float *__restrict__ rays_o, const float *__restrict__ rays_d, GridView g, const float *__restrict__ fars,
+                                  float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas, const float *__restrict__ noises) {
+    const uint32_t n_alive = ctl[0], n_step = ctl[1];
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const int32_t id = rays_alive[n];
+    const Ray r(rays_o + 3 * (size_t)id, rays_d + 3 * (size_t)id);
+    const float far = fars[id];
+    float t = start_param(g, rays_t[id], noises ? noises[n] : 0.0f);
+    float last = t;
+    float *px = xyzs + 3 * (size_t)n * n_step, *pd = dirs + 3 * (size_t)n * n_step, *pl = deltas + 2 * (size_t)n * n_step;
+    uint32_t step = 0;
+    float x, y, z, dt, t_exit;
+    while (t < far && step < n_step) {
+        if (probe(g, r, t, x, y, z, dt, t_exit)) {
+            px[0] = x; px[1] = y; px[2] = z;
+            pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
+            t += dt;
+            pl[0] = dt; pl[1] = t - last;
+            last = t;
+            px += 3; pd += 3; pl += 2; ++step;
+        } else t = leave_cell(g, t, t_exit);
+    }
+    for (; step < n_step; ++step) {      // the ray ended inside the burst: zero rows (rm_march zero-fills its whole buffers up front; the compositor stops at delta 0)
+        px[0] = px[1] = px[2] = 0.0f;
+        pd[0] = pd[1] = pd[2] = 0.0f;
+        pl[0] = pl[1] = 0.0f;
+        px += 3; pd += 3; pl += 2;
+    }
+}
+
+// Stable compaction (as k_compact_alive) + the next round's control words: n_alive' = survivors (0 once max_steps samples have been marched:
+// renderer_wtmk.py:335), n_step' = clamp(N / n_alive', 1, 8) (:340), rows', samples += n_step.
+__global__ void __launch_bounds__(1024) k_compact_alive_ctl(uint32_t *__restrict__ ctl, const int32_t *__restrict__ in, int32_t *__restrict__ out, uint32_t N,
+                                                            uint32_t max_steps) {
+    __shared__ uint32_t wave_cnt[16];
+    __shared__ uint32_t running;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t n = ctl[0], n_step = ctl[1], marched = ctl[3];
+    if (tid == 0) running = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + tid;
+        const int32_t v = i < n ? in[i] : -1;
+        const bool keep = v >= 0;
+        const unsigned long long ballot = __ballot(keep);
+        const uint32_t before = __popcll(ballot & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wid] = __popcll(ballot);
+        __syncthreads();
+        uint32_t wave_base = running, round_total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t c = wave_cnt[w];
+            if (w < (int)wid) wave_base += c;
+            round_total += c;
+        }
+        if (keep) out[wave_base + before] = v;
+        __syncthreads();
+        if (tid == 0) running += round_total;
+        __syncthreads();
+    }
+    if (tid == 0 && n > 0) {
+        const uint32_t done = marched + n_step;
+        const uint32_t alive = done < max_steps ? running : 0u;
+        const uint32_t next = alive ? min(max(N / alive, 1u), 8u) : 1u;
+        ctl[0] = alive;
+        ctl[1] = next;
+        ctl[2] = alive * next;
+        ctl[3] = done;
+    }
+}
+
 // raymarching.cu:819-905: in-place accumulation, T = 1 - weight_sum.
 __global__ void k_composite_burst(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *__restrict__ rays_alive,
                                   float *__restrict__ rays_t, const float *__restrict__ sigmas,
                                   const float *__restrict__ rgbs, const float *__restrict__ deltas,
-                                  float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image) {
+                                  float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image,
+                                  const uint32_t *__restrict__ ctl = nullptr, float density_scale = 1.0f) {
+    if (ctl != nullptr) {       // (rm_eval_composite: the counts live on the device; sigma is scaled here -- renderer_wtmk.py:353 -- instead of by a pass of its own)
+        n_alive = ctl[0];
+        n_step = ctl[1];
+    }
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_alive) return;
     const int32_t id = rays_alive[n];
@@ -922,7 +1002,7 @@ __global__ void k_composite_burst(uint32_t n_alive, uint32_t n_step, float T_thr
     uint32_t step = 0;
     while (step < n_step) {
         if (pl[0] == 0.0f) break;
-        const float alpha = 1.0f - __expf(-ps[0] * pl[0]);
+        const float alpha = 1.0f - __expf(-(ctl != nullptr ? density_scale * ps[0] : ps[0]) * pl[0]);
         const float T = 1.0f - wsum;
         const float w = alpha * T;
         wsum += w;
@@ -939,6 +1019,17 @@ __global__ void k_composite_burst(uint32_t n_alive, uint32_t n_step, float T_thr
     weights_sum[id] = wsum;
     depth[id] = d;
     image[3 * (size_t)id] = r; image[3 * (size_t)id + 1] = g; image[3 * (size_t)id + 2] = b;
+}
+
+__global__ void k_eval_begin(uint32_t N, uint32_t *__restrict__ ctl, int32_t *__restrict__ rays_alive) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) rays_alive[i] = (int32_t)i;
+    if (i == 0) {
+        ctl[0] = N;
+        ctl[1] = 1u;
+        ctl[2] = N;
+        ctl[3] = 0u;
+    }
 }
 
 // Stable compaction of the non-negative ray ids: ballot + popcount inside a wave, wave bases through LDS,
@@ -1220,6 +1311,37 @@ NSIG_EXPORT int rm_compact_alive(const int32_t *rays_alive, uint32_t n_alive, in
     NSIG_REQUIRE(rays_alive != rays_alive_out, "rm_compact_alive: in-place compaction is not supported");
     k_compact_alive<<<1, 1024, 0, as_stream(stream)>>>(rays_alive, n_alive, rays_alive_out, n_out);
     return check_launch("rm_compact_alive");
+}
+
+NSIG_EXPORT int rm_eval_begin(uint32_t N, uint32_t *ctl, int32_t *rays_alive, nsig_stream_t stream) {
+    NSIG_REQUIRE(ctl && rays_alive && N >= 1, "rm_eval_begin: null pointer or no rays");
+    k_eval_begin<<<ceil_div(N, 256u), 256, 0, as_stream(stream)>>>(N, ctl, rays_alive);      // all rays alive, n_step = clamp(N / N, 1, 8) = 1
+    return check_launch("rm_eval_begin");
+}
+
+NSIG_EXPORT int rm_eval_march(const uint32_t *ctl, uint32_t N, const int32_t *rays_alive, const float *rays_t, const float *rays_o, const float *rays_d,
+                              float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid, const float *fars, float *xyzs,
+                              float *dirs, float *deltas, const float *noises, nsig_stream_t stream) {
+    NSIG_REQUIRE(ctl && rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas && N >= 1, "rm_eval_march: null pointer");
+    if (int e = check_grid_args("rm_eval_march", C, H, max_steps, bound)) return e;
+    const uint32_t lanes = lanes_for_walk(N);
+    k_march_burst_ctl<<<ceil_div(N, lanes), lanes, 0, as_stream(stream)>>>(ctl, rays_alive, rays_t, rays_o, rays_d, make_grid_view(grid, bound, dt_gamma, max_steps, C, H),
+                                                                         fars, xyzs, dirs, deltas, noises);
+    return check_launch("rm_eval_march");
+}
+
+NSIG_EXPORT int rm_eval_composite(const uint32_t *ctl, uint32_t N, float T_thresh, float density_scale, int32_t *rays_alive, float *rays_t, const float *sigmas,
+                                  const float *rgbs, const float *deltas, float *weights_sum, float *depth, float *image, nsig_stream_t stream) {
+    NSIG_REQUIRE(ctl && rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image && N >= 1, "rm_eval_composite: null pointer");
+    k_composite_burst<<<ceil_div(N, 64u), 64, 0, as_stream(stream)>>>(0u, 0u, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, ctl,
+                                                                    density_scale);
+    return check_launch("rm_eval_composite");
+}
+
+NSIG_EXPORT int rm_eval_compact(uint32_t *ctl, uint32_t N, uint32_t max_steps, const int32_t *rays_alive, int32_t *rays_alive_out, nsig_stream_t stream) {
+    NSIG_REQUIRE(ctl && rays_alive && rays_alive_out && rays_alive != rays_alive_out && N >= 1, "rm_eval_compact: null pointer or in-place compaction");
+    k_compact_alive_ctl<<<1, 1024, 0, as_stream(stream)>>>(ctl, rays_alive, rays_alive_out, N, max_steps);
+    return check_launch("rm_eval_compact");
 }
 
 NSIG_EXPORT int rg_sample_rays(const float *poses, uint32_t P, const float *images, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W,

@@ -187,6 +187,29 @@ class NeRFNetwork(NeRFRenderer):
             sink = self._shared_sink
         return fo.field_apply(x, d, self.bound, self._packed(), self.encoder.tables(), selected, S, sink, fixed)
 
+    @torch.no_grad()
+    def _eval_field_rows(self, capacity, message):
+        """The field pass of the device-controlled eval loop (renderer._eval_loop_on_device): tables selected and the pre-sum computed ONCE per render;
+        returns fn(xyzs, dirs, rows_dev, sigmas, rgbs) that evaluates the first *rows_dev rows (a device count) with launches sized for `capacity`."""
+        from . import _native as nv
+        _, _, S = self._select(message)
+        packed = self._packed()
+        base = [fo._check_table(t.detach(), "base table") for t in self.encoder.tables()]
+        base_ptrs = nv.ptr_array(base)
+        use_planes = capacity >= fo.PLANES_MIN_POINTS
+        dev = packed.device
+        ws = torch.empty(int(nv.fn("hg_planes_bytes")(capacity)), dtype=torch.uint8, device=dev) if use_planes else None
+        bound = float(self.bound)
+
+        def run(xyzs, dirs, rows_dev, sigmas, rgbs):
+            if use_planes:
+                nv.call("hg_encode_planes_rows", nv.ptr(xyzs), capacity, nv.ptr(rows_dev), bound, base_ptrs, nv.ptr(S), nv.ptr(ws), nv.stream())
+            nv.call("field_fwd_rows", nv.ptr(xyzs), nv.ptr(dirs), capacity, nv.ptr(rows_dev), bound, base_ptrs, nv.ptr(S), nv.ptr(packed), nv.ptr(sigmas),
+                    nv.ptr(rgbs), nv.ptr(ws), nv.stream())
+            run.keep = (base, S, packed, ws)      # (the launches above hold raw addresses)
+
+        return run
+
     def _count_points(self, o, d, dt_gamma, max_steps):
         """Padded sample total of these rays through the current grid (one counting march, one host read)."""
         from . import _native as nv

@@ -410,8 +410,12 @@ class NeRFRenderer(nn.Module):
         return raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
 
     def _march_and_composite_eval(self, o, d, message, nears, fars, dt_gamma, perturb, max_steps, T_thresh):
-        """Bursts of 1..8 samples over the still-alive rays (renderer_wtmk.py:323-367).  The alive list is compacted
-        on the device; only the survivor count crosses to the host each round."""
+        """Bursts of 1..8 samples over the still-alive rays (renderer_wtmk.py:323-367).
+
+        Default (CUDA rays): the loop's control lives on the device (_eval_loop_on_device) -- no per-round read-back.  NERFSIG_EVAL_LOOP=host keeps
+        the round-by-round form: the alive list compacted on the device, the survivor count read back every round."""
+        if o.is_cuda and o.shape[0] > 0 and os.environ.get("NERFSIG_EVAL_LOOP", "device") != "host" and hasattr(self, "_eval_field_rows"):
+            return self._eval_loop_on_device(o, d, message, nears, fars, dt_gamma, perturb, max_steps, T_thresh)
         N, device = o.shape[0], o.device
         weights_sum = torch.zeros(N, dtype=torch.float32, device=device)
         depth = torch.zeros(N, dtype=torch.float32, device=device)
@@ -431,6 +435,40 @@ class NeRFRenderer(nn.Module):
             n_alive = int(n_out.item())
             rays_alive = compacted[:n_alive]
             step += n_step
+        return weights_sum, depth, image
+
+    def _eval_loop_on_device(self, o, d, message, nears, fars, dt_gamma, perturb, max_steps, T_thresh, check_every=8, trace=None):
+        """The same bursts, alive lists and images as the host-driven loop (tests/test_gpu_raymarch.py), with n_alive / n_step / the sample count kept in
+        a device control block (rm_eval_*): every round's launches are sized for the worst case (n_alive * n_step <= N) and early-out on the
+        device counts, the field pass evaluates exactly `rows` rows (field_fwd_rows), and the host reads the survivor count back once every
+        `check_every` rounds -- only to stop enqueueing.  At most max_steps rounds (a round marches at least one sample).
+        trace: a list that receives (n_alive, n_step, alive ids) per round (tests: costs a read-back per round)."""
+        N, device = o.shape[0], o.device
+        f32 = dict(dtype=torch.float32, device=device)
+        weights_sum, depth, image = torch.zeros(N, **f32), torch.zeros(N, **f32), torch.zeros(N, 3, **f32)
+        alive = [torch.empty(N, dtype=torch.int32, device=device), torch.empty(N, dtype=torch.int32, device=device)]
+        ctl = torch.empty(4, dtype=torch.int32, device=device)
+        rays_t = nears.clone()
+        xyzs, dirs, deltas = torch.empty(N, 3, **f32), torch.empty(N, 3, **f32), torch.empty(N, 2, **f32)
+        sigmas, rgbs = torch.empty(N, **f32), torch.empty(N, 3, **f32)
+        nv.call("rm_eval_begin", N, nv.ptr(ctl), nv.ptr(alive[0]), nv.stream())
+        field = self._eval_field_rows(N, message)          # (tables selected, pre-sum computed, buffers for N rows: once per render)
+        noises = torch.rand(N, **f32) if perturb else None
+        geom = (float(self.bound), float(dt_gamma), int(max_steps), int(self.cascade), int(self.grid_size))
+        cur = 0
+        for rnd in range(int(max_steps)):
+            if trace is not None:
+                c = ctl.tolist()
+                trace.append((c[0], c[1], alive[cur][:c[0]].clone()))
+            nv.call("rm_eval_march", nv.ptr(ctl), N, nv.ptr(alive[cur]), nv.ptr(rays_t), nv.ptr(o), nv.ptr(d), *geom, nv.ptr(self.density_bitfield),
+                    nv.ptr(fars), nv.ptr(xyzs), nv.ptr(dirs), nv.ptr(deltas), nv.ptr(noises) if rnd == 0 else None, nv.stream())
+            field(xyzs, dirs, ctl[2:3], sigmas, rgbs)
+            nv.call("rm_eval_composite", nv.ptr(ctl), N, float(T_thresh), float(self.density_scale), nv.ptr(alive[cur]), nv.ptr(rays_t), nv.ptr(sigmas),
+                    nv.ptr(rgbs), nv.ptr(deltas), nv.ptr(weights_sum), nv.ptr(depth), nv.ptr(image), nv.stream())
+            nv.call("rm_eval_compact", nv.ptr(ctl), N, int(max_steps), nv.ptr(alive[cur]), nv.ptr(alive[1 - cur]), nv.stream())
+            cur = 1 - cur
+            if (rnd % check_every == check_every - 1 or trace is not None) and int(ctl[0]) == 0:
+                break
         return weights_sum, depth, image
 
     # ------------------------------------------------------------------ density-grid maintenance

@@ -1031,3 +1031,49 @@ def test_opaque_field_early_termination_through_render(bound, dt_gamma, T_thresh
     if training:
         np.testing.assert_allclose(out["weights_sum"].cpu().numpy(), ws.numpy(), rtol=0, atol=tol)
         assert float((ws > 1 - 2 * T_thresh).float().mean()) > 0.02        # some rays really are opaque: they ended on the threshold
+
+
+@pytest.mark.parametrize("case", ["thin", "opaque", "counter"])
+def test_eval_loop_on_device_equals_the_host_driven_loop(case, monkeypatch):
+    """renderer_wtmk.py:335-372 with the loop's control on the device (rm_eval_*: no per-round read-back of the survivor count; launches sized for the worst
+    case that early-out on device counts; field_fwd_rows over a device row count) against the round-by-round form that reads n_alive back every round:
+    the SAME bursts -- (n_alive, n_step) and the alive list of every round -- and bit-identical weights_sum / depth / image, for a thin field (rays live
+    until they leave the box), an opaque one (early termination by T_thresh) and the two-cascade scene with dt_gamma > 0."""
+    from nerf_signature_amd import raymarching, synthetic
+    from nerf_signature_amd.network import NeRFNetwork
+    scene = "counter" if case == "counter" else "hotdog"
+    cfg = synthetic.SCENES[scene]
+    torch.manual_seed(0)
+    m = NeRFNetwork(bound=cfg["bound"], cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1, message_dim=cfg["message_dim"], n_views=1)
+    synthetic.init_model(m, scene, opaque=(case == "opaque"))
+    m.cuda().eval()
+    o, d = synthetic.content_rays(scene, 3000, seed=3, device="cuda")
+    msg = torch.from_numpy(np.random.RandomState(1).randint(0, 2, cfg["message_dim"]).astype(np.float32))
+    kw = dict(dt_gamma=1.0 / 128 if case == "counter" else 0.0, max_steps=1024, bg_color=1, perturb=False, staged=False)
+    rounds_host = []
+    real = raymarching.march_rays
+
+    def spy(n_alive, n_step, rays_alive, *a, **k):
+        rounds_host.append((int(n_alive), int(n_step), rays_alive[:n_alive].clone()))
+        return real(n_alive, n_step, rays_alive, *a, **k)
+
+    with torch.no_grad():
+        monkeypatch.setenv("NERFSIG_EVAL_LOOP", "host")
+        monkeypatch.setattr(raymarching, "march_rays", spy)
+        host = m.render(o, d, msg, **kw)
+        monkeypatch.setattr(raymarching, "march_rays", real)
+        monkeypatch.setenv("NERFSIG_EVAL_LOOP", "device")
+        dev = m.render(o, d, msg, **kw)
+        # ... and round by round
+        prefix, fo_, fd_ = m._flatten_rays(o, d)
+        nears, fars = raymarching.near_far_from_aabb(fo_, fd_, m.aabb_infer, m.min_near)
+        trace = []
+        ws, dp, im = m._eval_loop_on_device(fo_, fd_, msg, nears, fars, kw["dt_gamma"], False, 1024, 1e-4, trace=trace)
+    assert len(rounds_host) > (3 if case == "opaque" else 30)
+    for k in ("image", "depth"):
+        assert torch.equal(torch.nan_to_num(host[k]), torch.nan_to_num(dev[k])), k
+    live = [t for t in trace if t[0] > 0]
+    assert len(live) == len(rounds_host)
+    for (na0, ns0, ids0), (na1, ns1, ids1) in zip(rounds_host, live):
+        assert (na0, ns0) == (na1, ns1) and torch.equal(ids0, ids1)
+    assert float(ws.max()) <= 1.0 + 1e-5 and bool(torch.isfinite(ws).all())
