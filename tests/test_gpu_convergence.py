@@ -121,6 +121,19 @@ def test_second_half_of_the_run_from_a_common_state_agrees_within_a_tenth_of_a_d
         assert abs(r["last_lr"] - 1e-2 * 0.1 ** (999 / 1000)) < 1e-9, (name, r["last_lr"])
 
 
+@pytest.mark.parametrize("scene", ["counter", "fern"])
+def test_the_other_configs_learn_the_watermark_too(scene):
+    """BASELINE configs 3 (two cascades, camera inside; 32 bits) and 5 (48 bits, 11 x 15 blocks, dt_gamma 1/128) through the captured loop with the README's
+    schedule: from chance to (nearly) every bit right, no replay overflowing its buffers."""
+    from nerf_signature_amd import quality
+    rec = quality.run("graphed", 1000, scene=scene, n_messages=100)
+    print(f"\n[{scene}] bit acc {rec['bit_acc_before_training']:.3f} -> {rec['bit_acc']:.4f}, PSNR vs clean views {rec['psnr_db']:.2f} dB, {rec['train_ms_per_step']:.3f} ms/step")
+    assert 0.35 < rec["bit_acc_before_training"] < 0.65
+    assert rec["bit_acc"] >= 0.98 and rec["wrong_bits_worst_message"] <= 3
+    assert not rec["overflowed"] and rec["recaptures"] == 0
+    assert 35.0 < rec["psnr_db"] < 75.0
+
+
 def _small_model(seed=0, codebook_scale=1e-4):
     import test_gpu_render as T
     torch.manual_seed(seed)
