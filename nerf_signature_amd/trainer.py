@@ -194,8 +194,10 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
         distortion = DistortionLayer(distortion) if distortion != "none" else None
         if distortion is not None:
             distortion.draw(tuple(image.shape), image.device)
-    fused_seed = None
+    fused_seed = keys_dev = None
     if model.normalization is normalize_img and hasattr(model.msg_decoder, "decode_rendered"):
+        from .hidden_models import _FusedDecoder
+        _FusedDecoder.seed = None       # (only a seed written by THIS call's decoder pass may be used below)
         bce = None
         if loss_w is loss_w_bce and image.is_cuda and image.dim() == 4 and torch.is_grad_enabled():
             # d(lambda_w * mean BCE-with-logits(10 * decoded, message)) / d decoded is element-wise: the decoder's head kernel writes it (its backward
@@ -204,8 +206,7 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
             if keys_dev.numel() == image.shape[0]:
                 bce = (keys_dev, 10.0, float(lambda_w) * 10.0 / image.shape[0])
         decoded, pred_rgb = model.msg_decoder.decode_rendered(image, distortion, bce)    # clamp + distortion + permute + normalise inside layer 0
-        from .hidden_models import _FusedDecoder
-        fused_seed, _FusedDecoder.seed = getattr(_FusedDecoder, "seed", None), None
+        fused_seed, _FusedDecoder.seed = _FusedDecoder.seed, None
     else:
         pred_rgb = torch.clamp(image, min=0, max=1)
         pred_rgb_dist = pred_rgb if distortion is None else distortion(pred_rgb, raw=image)
@@ -237,7 +238,7 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
         main.wait_stream(side_stream)
     elif main is None:
         content_pred_rgb = model.render(content["rays_o"], content["rays_d"], message, **kw)["image"]
-    keys = message.to(decoded.device).unsqueeze(-1)
+    keys = (keys_dev if keys_dev is not None and keys_dev.device == decoded.device else message.to(decoded.device)).unsqueeze(-1)
     if loss_w is loss_w_bce and decoded.is_cuda and all(t.dtype == torch.float32 for t in (content_pred_rgb, gt_rgb, decoded, keys)) \
             and gt_rgb.shape == content_pred_rgb.shape and keys.shape == decoded.shape:
         if deferred:      # values only (both backward passes have their seeds): launched by finish_losses() at the end of the step
