@@ -183,8 +183,14 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
-    """The current torch stream as a hipStream_t, so launches compose with autograd/autocast/RCCL streams."""
+    """The current torch stream as a hipStream_t, so launches compose with autograd/autocast/RCCL streams.
+    (torch's raw-stream query: the eager loops call this ~30 times per step, and torch.cuda.current_stream() builds a Stream object each time.)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -445,19 +445,28 @@ class SharedGradient(GradSink):
         self.carrier = self.live = None
 
 
+class _Tables:
+    """The table lists of one field pass, handed to _FieldFunction as ONE opaque argument: autograd (and autocast's argument casting, which walks every
+    tensor argument) then tracks only the tables that need it."""
+    __slots__ = ("base", "sel")
+
+    def __init__(self, base, sel):
+        self.base, self.sel = list(base), list(sel)
+
+
 class _FieldFunction(Function):
     """NeRFNetwork.forward as one autograd node (network_wtmk_tcnn.py:97-124).
 
-    `tables` = 16 frozen base tables followed by the D selected codebook tables, the only differentiable
-    inputs.  Without a sink, backward returns the fan-out of the shared gradient for each selected table
-    (unselected tables are not inputs, so their grad stays None exactly as in the reference); with a sink
-    the gradient accumulates there and autograd sees None."""
+    tabs: the 16 frozen base tables and the D selected codebook tables (_Tables).  `diff` are the autograd inputs among them: without a sink every selected
+    table -- backward returns the fan-out of the shared gradient for each (unselected tables are not inputs, so their grad stays None exactly as in the
+    reference); with a sink the gradient accumulates there, autograd sees None, and ONE selected table is passed only so that the node is recorded."""
 
     @staticmethod
     @_fwd32
-    def forward(ctx, xyzs, dirs, bound, packed, S, sink, n_sel, fixed, *tables):
-        base, sel = tables[:16], tables[16:16 + n_sel]
-        need_grad = n_sel > 0 and any(t.requires_grad for t in sel)
+    def forward(ctx, xyzs, dirs, bound, packed, S, sink, tabs, fixed, *diff):
+        base, sel = tabs.base, tabs.sel
+        n_sel = len(sel)
+        need_grad = n_sel > 0 and len(diff) > 0
         xyzs = xyzs.contiguous().float()
         if fixed is not None:    # points that never change: base planes and scatter plan are kept (FixedPoints)
             ctx.plan = fixed.plan if need_grad else None
@@ -465,7 +474,7 @@ class _FieldFunction(Function):
             # before the encoder is enqueued: a plan on its own stream forks right behind the march, not behind this forward pass
             ctx.plan = ScatterPlan(xyzs, bound) if need_grad and xyzs.shape[0] >= BINNED_MIN_POINTS else None
         sigmas, rgbs, _, masks = field_forward(xyzs, dirs, bound, base, S, packed, want_masks=need_grad, fixed=fixed)
-        ctx.bound, ctx.n_sel, ctx.need_grad, ctx.sink = bound, n_sel, need_grad, sink
+        ctx.bound, ctx.n_diff, ctx.need_grad, ctx.sink = bound, len(diff), need_grad, sink
         if need_grad:
             # the saved ReLU masks are laid out for the arithmetic the forward ran in (csrc/field.hip mask_bit<P>): the backward must run in the same
             ctx.mlp_precision = nv.fn("mlp_get_precision")()
@@ -478,9 +487,9 @@ class _FieldFunction(Function):
     @staticmethod
     @_bwd
     def backward(ctx, g_sigma, g_rgb):
-        head = (None,) * 8 + (None,) * 16
+        head = (None,) * 8
         if not ctx.need_grad:
-            return head + (None,) * ctx.n_sel
+            return head + (None,) * ctx.n_diff
         xyzs, sigmas, rgbs, masks, packed = ctx.saved_tensors
         plan, ctx.plan = ctx.plan, None
         if nv.fn("mlp_get_precision")() != ctx.mlp_precision:
@@ -490,11 +499,11 @@ class _FieldFunction(Function):
             if isinstance(ctx.sink, SharedGradient):
                 ctx.sink.begin_accumulation(ctx.sink_selected)
             field_backward_into(xyzs, ctx.bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, ctx.sink.G, plan)
-            return head + (None,) * ctx.n_sel
+            return head + (None,) * ctx.n_diff
         G = torch.zeros(T_ROWS, 2, dtype=torch.float32, device=xyzs.device)
         field_backward_into(xyzs, ctx.bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, G, plan)
-        slab = torch.empty(ctx.n_sel, T_ROWS, 2, dtype=torch.float32, device=xyzs.device)
-        grads = [slab[i] for i in range(ctx.n_sel)]
+        slab = torch.empty(ctx.n_diff, T_ROWS, 2, dtype=torch.float32, device=xyzs.device)
+        grads = [slab[i] for i in range(ctx.n_diff)]
         fanout_grad(G, grads, accumulate=False)
         return head + tuple(grads)
 
@@ -504,4 +513,11 @@ def field_apply(xyzs, dirs, bound, packed, base_tables, selected, S=None, sink=N
     fixed: the FixedPoints of exactly these points (rays that do not change between steps), or None."""
     if len(selected) and S is None:
         S = codebook_presum(selected)
-    return _FieldFunction.apply(xyzs, dirs, bound, packed, S, sink, len(selected), fixed, *base_tables, *selected)
+    if not torch.is_grad_enabled():
+        diff = ()
+    elif sink is None:
+        # plain autograd: every selected table is an input (a table that does not require grad gets a gradient autograd drops)
+        diff = tuple(selected) if any(t.requires_grad for t in selected) else ()
+    else:           # the gradient goes to the sink: one differentiable input is enough to have the node recorded
+        diff = next(((t,) for t in selected if t.requires_grad), ())
+    return _FieldFunction.apply(xyzs, dirs, bound, packed, S, sink, _Tables(base_tables, selected), fixed, *diff)

@@ -933,7 +933,7 @@ class GraphedWatermarkLoop:
             # under capture are not handed to the watchdog at all.
             import time
             time.sleep(float(os.environ.get("NERFSIG_WATCHDOG_DRAIN_S", "0.5")))
-        capture_stream = torch.cuda.Stream()
+        capture_stream = torch.cuda.Stream(priority=int(os.environ.get("NERFSIG_MAIN_PRIORITY", "0")))      # (-1: the block render / decoder chain above the content chain; measured: LABNOTES section 14)
         capture_stream.wait_stream(torch.cuda.current_stream())
         prev = dp.set_boundary(boundary)
         try:

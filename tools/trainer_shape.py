@@ -25,6 +25,9 @@ ap.add_argument("--no-item", action="store_true", help="skip the three per-step 
 ap.add_argument("--plain", action="store_true", help="the model as a library user gets it (nerf_signature_amd.network.NeRFNetwork): plain autograd gradients, the optimiser's own "
                                                       "loop over D dense tables, no automatic kept-planes route -- what rounds 1-3 gave a drop-in user")
 ap.add_argument("--no-shared-gradient", action="store_true")
+ap.add_argument("--no-gc", action="store_true", help="diagnostics: Python's cyclic garbage collector off during the timed steps")
+ap.add_argument("--gc-freeze", action="store_true", help="gc.freeze() after the warm-up steps (what the drop-in model does at its first training render)")
+ap.add_argument("--phases", action="store_true", help="host wall time per phase of the loop body (perf_counter, no profiler)")
 ap.add_argument("--no-auto-fix", action="store_true")
 args = ap.parse_args()
 
@@ -55,18 +58,38 @@ def loader(k):
     return {"watermark": wm, "content": {"rays_o": o, "rays_d": d, "images": images}}
 
 
+PH = {}
+
+
+def mark(name, t0):
+    t1 = time.perf_counter()
+    if args.phases:
+        PH[name] = PH.get(name, 0.0) + (t1 - t0)
+    return t1
+
+
 def step(k):
+    t = time.perf_counter()
     data = loader(k)
+    t = mark("loader", t)
     message = torch.randint(0, 2, (D,), dtype=torch.float32, device=dev)                                 # :1165
+    t = mark("message", t)
     optimizer.zero_grad()
+    t = mark("zero_grad", t)
     with torch.autocast("cuda", enabled=not args.no_fp16):
         out = trainer.train_step(model, data, message, opt_ns, lambda_w=0.005, lambda_i=1.0)
+    t = mark("train_step (forward)", t)
     scaler.scale(out[5]).backward()
+    t = mark("backward", t)
     scaler.step(optimizer)
+    t = mark("scaler.step (unscale, inf check, optimizer)", t)
     scaler.update()
     scheduler.step()
+    t = mark("scaler.update + scheduler", t)
     if not args.no_item:
-        return out[5].item(), out[3].item(), out[4].item()
+        r = out[5].item(), out[3].item(), out[4].item()
+        mark("three .item() reads", t)
+        return r
     return None
 
 
@@ -78,6 +101,16 @@ if args.profile:
     import pstats
     pr = cProfile.Profile()
     pr.enable()
+PH.clear()         # (phases: the timed steps only -- the warm-up's first calls initialise libraries)
+if args.no_gc:
+    import gc
+    gc.collect()
+    gc.disable()
+if args.gc_freeze:
+    import gc
+    gc.collect()
+    gc.freeze()
+ms0 = torch.cuda.memory_stats()
 windows = []
 for w in range(1 if args.profile else 3):
     t0 = time.perf_counter()
@@ -91,6 +124,12 @@ if args.profile:
     st = pstats.Stats(pr, stream=sys.stderr)
     st.sort_stats("cumulative").print_stats(45)
     st.sort_stats("tottime").print_stats(30)
+if args.phases:
+    ms1 = torch.cuda.memory_stats()
+    print("allocator over the timed steps:", {k: ms1[k] - ms0[k] for k in ("num_device_alloc", "num_device_free", "num_alloc_retries", "num_sync_all_streams", "allocation.all.allocated")},
+          "reserved MB", ms1["reserved_bytes.all.current"] / 1e6, file=sys.stderr)
+    n = args.steps * len(windows)
+    print("host wall per step by phase (ms; includes waiting for the GPU where a phase synchronises):", {k: round(v / n * 1e3, 3) for k, v in PH.items()}, file=sys.stderr)
 os.dup2(real_stdout, 1)
 print(json.dumps({"what": "reference Trainer loop body (utils_wtmk_disen.py:1164-1190) around this repo's model: eager, autocast(fp16) + GradScaler, plain torch.optim.Adam, "
                           "loader-style rays per step, three .item() reads per step; NOT the headline path",
