@@ -459,6 +459,8 @@ def run_secondaries(args):
     the GPU with them); a failing child costs its own entry only:
       quality        the reference's whole run on this path -- 1000 captured steps with README.md:45's hyper-parameters, then Trainer.test_bitacc over 200
                      messages and Trainer.test_image against the clean views (tools/converge.py, nerf_signature_amd/quality.py) -> the line's `quality`
+      quality_two_ranks_gloo   the same run as two real rank processes sharing this GPU over gloo (RCCL refuses two ranks on one device): the data-parallel
+                     step -- blocks + content rays sharded, all-gather, one all-reduce, sharded optimiser -- trained to the end; its ms per step is gloo's, not a figure of merit
       counter, fern  BASELINE.json configs 3 and 5
       rank_emulation one rank of 2 / 4 / 8 on this GPU, in both execution modes of the multi-rank step + fixed blocks (tools/emulate_ranks.py: kernel work and
                      launch structure of a rank, every collective issued on a world-size-1 RCCL group, no xGMI latency)
@@ -468,6 +470,7 @@ def run_secondaries(args):
     out = {}
     k = str(min(args.steps, 50))
     jobs = (("quality", [os.path.join(ROOT, "tools", "converge.py"), "graphed", "--steps", "1000", "--messages", "200"]),
+            ("quality_two_ranks_gloo", [os.path.join(ROOT, "tools", "converge.py"), "dp2", "--steps", "1000", "--messages", "100"]),
             ("counter", [os.path.abspath(__file__), "--config", "counter", "--steps", k, "--warmup", str(min(args.warmup, 5)), "--no-cpu-baseline", "--no-secondary", "--windows", "1"]),
             ("fern", [os.path.abspath(__file__), "--config", "fern", "--steps", "5", "--warmup", "1", "--no-secondary"]),
             ("rank_emulation", [os.path.join(ROOT, "tools", "emulate_ranks.py"), "--steps", k]),
@@ -484,7 +487,7 @@ def run_secondaries(args):
                 continue
             j = json.loads(lines[-1])
             c = j.get("config", {})
-            if name in ("quality", "rank_emulation", "eager_reference_trainer_shape", "eval_loop"):
+            if name in ("quality", "quality_two_ranks_gloo", "rank_emulation", "eager_reference_trainer_shape", "eval_loop"):
                 out[name] = j
             elif name == "counter":
                 out[name] = {"ms_per_step": j["ms_per_step"], "content_rays_per_s": j["value"], "points_per_s": c.get("points_per_s"), "points_per_step": c.get("points_per_step_per_rank"),

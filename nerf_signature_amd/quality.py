@@ -81,7 +81,9 @@ def train(stage, steps=None, mode="graphed", lambda_w=README["lambda_w"], lambda
     model, dev, D, kw = stage["model"], stage["device"], stage["D"], stage["render_kwargs"]
     H, W, n_rays = stage["H"], stage["W"], stage["n_rays"]
     msgs = messages(D, start + steps + 1, msg_seed)[start:]
-    sampler = rays.DeviceRaySampler(stage["poses"], stage["clean"], stage["intr"], H, W, n_rays, stride=1, offset=0, seed=sampler_seed)
+    from . import dp as _dp
+    world, rank = _dp.world_size(), _dp.rank()          # data-parallel: every rank draws its own content batches (pose k * world + rank, own pixel stream)
+    sampler = rays.DeviceRaySampler(stage["poses"], stage["clean"], stage["intr"], H, W, n_rays, stride=world, offset=rank, seed=sampler_seed + rank)
     content = {k: torch.empty(1, n_rays, 3, dtype=torch.float32, device=dev) for k in ("rays_o", "rays_d", "images")}
     counter = torch.full((1,), start, dtype=torch.int32, device=dev)
     sampler.sample_into(counter, content["rays_o"], content["rays_d"], content["images"])
@@ -187,9 +189,13 @@ def test_image(stage, seed=9876, max_ray_batch=4096):
 test_image.__test__ = False
 
 
+LAST_STAGE = None      # (tools/converge.py's two-rank run compares the ranks' final models)
+
+
 def run(mode="graphed", steps=None, scene="hotdog", n_messages=200, **train_kw):
     """watermark_stage + train + both evaluations -> the `quality` record of bench.py."""
-    stage = watermark_stage(scene)
+    global LAST_STAGE
+    stage = LAST_STAGE = watermark_stage(scene)
     before = test_bitacc(stage, min(n_messages, 50))[0]
     rec = train(stage, steps, mode, **train_kw)
     t0 = time.perf_counter()
