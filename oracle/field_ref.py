@@ -145,10 +145,21 @@ SIGMA_WIDTHS = ((64, 32), (16, 64))             # network_wtmk_tcnn.py:52-62  (3
 COLOR_WIDTHS = ((64, 32), (64, 64), (16, 64))   # network_wtmk_tcnn.py:78-88  (31 pad 32 -> 64 -> 64 -> 3 pad 16)
 
 
-def mlp(x, mats):
+def round_operand(t, operands):
+    """The MFMA operand rounding of the product's DEFAULT arithmetic ("f16": every matrix operand -- layer input and weight -- rounded once to fp16,
+    products accumulated in fp32), as a straight-through op: the forward value is rounded, the gradient passes unchanged.  None: plain fp32."""
+    if operands is None:
+        return t
+    assert operands == "f16"
+    return t + (t.half().float() - t).detach()
+
+
+def mlp(x, mats, operands=None):
+    """operands="f16" emulates the kernels' default arithmetic (round_operand): the same values reach every ReLU up to the order of the fp32 accumulation,
+    so the same side of every kink is taken -- the element-wise pin of the default mode (tests/test_gpu_field.py)."""
     h = x
     for k, W in enumerate(mats):
-        h = h @ W.t()
+        h = round_operand(h, operands) @ round_operand(W, operands).t()
         if k + 1 < len(mats):
             h = torch.relu(h)
     return h
@@ -160,7 +171,7 @@ def density(x, message, P):
     feat = base_encode(x01, P["base_tables"])
     if message is not None:
         feat = torch.cat([feat[:, :-2], feat[:, -2:] + codebook_encode(x01, message, P["cb_tables"], P.get("faithful", False))], dim=-1)  # :106
-    h = mlp(feat, split_mlp_params(P["sigma_params"], SIGMA_WIDTHS))
+    h = mlp(feat, split_mlp_params(P["sigma_params"], SIGMA_WIDTHS), P.get("mlp_operands"))
     return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
 
 
@@ -169,7 +180,7 @@ def color(d, geo_feat, P):
     d01 = (d + 1) / 2
     enc = sh4(d01 * 2 - 1)
     cin = torch.cat([enc, geo_feat, torch.ones_like(enc[:, :1])], dim=-1)
-    return torch.sigmoid(mlp(cin, split_mlp_params(P["color_params"], COLOR_WIDTHS))[:, :3])
+    return torch.sigmoid(mlp(cin, split_mlp_params(P["color_params"], COLOR_WIDTHS), P.get("mlp_operands"))[:, :3])
 
 
 def field_forward(x, d, message, P):
