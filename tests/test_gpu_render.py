@@ -130,6 +130,21 @@ def test_train_step_losses_and_gradients_vs_oracle(mlp_prec):
     # fp16 operands: a few per cent of the points take a ReLU kink on the other side (test_field_backward_away_from_relu_kinks)
     assert rel_G < {"bf16x3": 5e-3, "f16": 5e-2}[mlp_prec]
     assert float((diff.abs() > 2e-3 * scale).float().mean()) < {"bf16x3": 1e-3, "f16": 2e-2}[mlp_prec]
+    if mlp_prec == "f16":
+        # ... and the default arithmetic against the oracle that rounds the matrix operands where the kernels do (fr.round_operand): the same side of
+        # every kink, so the whole step's codebook gradient agrees in the split-bf16 class (round 4: the default mode pinned, not only bounded)
+        P16, _ = _oracle_params(m, bitfield, C)
+        with torch.no_grad():
+            for t_new, t_old in zip(P16["cb_tables"], P["cb_tables"]):
+                t_new.copy_(t_old)
+        P16["mlp_operands"] = "f16"
+        ref16 = fr.train_step(bo, bd, co, cd, gt, msg, P16, S, copy.deepcopy(dec_cpu), dt_gamma=0.0, max_steps=1024)
+        ref16["loss"].backward()
+        G16 = P16["cb_tables"][bits[0]].grad
+        rel16 = float((G1.cpu() - G16).norm() / G16.norm())
+        print(f"[f16] shared codebook gradient rel. L2 vs the operand-rounding oracle: {rel16:.3e}")
+        assert rel16 < 5e-3 and float(((G1.cpu() - G16).abs() > 2e-3 * scale).float().mean()) < 1e-3
+        np.testing.assert_allclose(float(lossw.detach()), float(ref16["lossw"].detach()), rtol=2e-4, atol=2e-4)
     # decoder gradients as one vector (conv biases in front of a BatchNorm have a mathematically zero gradient,
     # so a per-tensor relative comparison would compare rounding noise)
     d1 = _decoder_grad_vector(m.msg_decoder).cpu()
