@@ -58,12 +58,9 @@ class HashEmbedder(nn.Module):
             nn.init.uniform_(emb.weight, a=-0.0001, b=0.0001)
 
     def tables(self):
-        """The tables' Parameters, in level order (a list cached while the Parameter objects stay the same: nn.Module attribute lookups are slow and
-        the eager loops ask several times per render)."""
-        cached = self.__dict__.get("_tables_cache")
-        if cached is None or len(cached) != len(self.embeddings) or cached[0] is not self.embeddings[0].weight or cached[-1] is not self.embeddings[-1].weight:
-            cached = self.__dict__["_tables_cache"] = [e.weight for e in self.embeddings]
-        return list(cached)
+        """The tables' Parameters, in level order (read straight from the sub-modules' parameter dicts: nn.Module attribute lookups are slow and the
+        eager loops ask several times per render)."""
+        return [m._parameters["weight"] for m in self.embeddings._modules.values()]
 
     def selected(self, message):
         bits = fo.message_bits(message)
