@@ -12,8 +12,6 @@ block render -> decoder -> BIT_ACC) and `test_image` (:816-933: staged full view
   test_bitacc / test_image   the two evaluation loops
 
 Used by tests/test_gpu_convergence.py, bench.py's `quality` block and tools/converge.py."""
-import math
-import os
 import time
 
 import numpy as np

@@ -4,7 +4,6 @@ launches of each (kernel, grid) -- the eager steps of tools/pmc_step.py, not its
 import collections
 import csv
 import glob
-import json
 import sys
 
 keep = int(sys.argv[1])
