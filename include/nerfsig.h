@@ -461,7 +461,9 @@ int dec_backward(const float *grad_decoded, const float *img, uint32_t input_mod
  * renders in front of the decoder, :594; `--distortion`, main_nerf_wtmk.py:75).  distortion: 0 none, 1 noise (x + n, the reference
  * draws n ~ N(0, 0.1) per element), 2 brightness (torchvision ColorJitter(brightness=0.5): clamp(f * x, 0, 1), one f in [0.5, 1.5]
  * per call), 3 blurring (torchvision GaussianBlur(3, sigma in [0.01, 0.5]): taps exp(-0.5 (d / sigma)^2) normalised, reflect padding).
- * rotation / scaling change the image geometry (and, for scaling, the decoder's input width): they stay on stock operators.
+ * 4 rotation (torchvision RandomRotation((-30, 30)) per image: nearest-neighbour resampling about the centre, zero fill) and 5 scaling (per image
+ * [3, H, W]: F.interpolate(scale_factor = sf in [0.75, 1.25], mode = 'linear') -- 1-d, along W only, W_out = floor(W * sf)) change the sampling geometry:
+ * kernels of their own in front of / behind the decoder (wm_distort_geom_fwd / _bwd), whose output the decoder reads as an ordinary rendered image.
  *   dist_param  device float[1]: f (2) or sigma (3), read on the device -- a captured step draws it itself (wm_distort_draw);
  *   dist_noise  device [B, H, W, Cin] (1).
  * dec_forward_train / dec_backward_train = dec_forward / dec_backward with input_mode 1 (the training step's call) and the layer applied on load,
@@ -474,7 +476,11 @@ int dec_backward(const float *grad_decoded, const float *img, uint32_t input_mod
  * are still wm_loss_fwd's, computed off that path).
  * wm_distort_fwd / _bwd: the layer alone on [B, H, W, C] (img = the unclamped render; out = D(clamp(img)); grad_img through the clamp).
  * wm_distort_draw: counter-based draws, a pure function of (seed, *step_counter, element): param_out[0] ~ U[0.5, 1.5] (2) /
- * U[0.01, 0.5] (3), noise_out[0 .. n_noise) ~ N(0, 0.1) (1).  step_counter may be NULL (step 0).
+ * U[0.01, 0.5] (3), noise_out[0 .. n_noise) ~ N(0, 0.1) (1); (4): n_noise = the number of images, param_out[2 i], [2 i + 1] = (cos, sin) of image i's angle
+ * ~ U[-30, 30) degrees.  step_counter may be NULL (step 0).  The scaling factor decides a tensor shape and is drawn by the host.
+ * wm_distort_geom_fwd: out [B, H, W_out, C] = the layer (4: dist_param = (cos, sin) per image, W_out = W; 5: dist_param[0] = sf, W_out = floor(W * sf),
+ * computed by the caller) on clamp(img [B, H, W, C]); clamped_out (optional) = clamp(img).  _bwd: grad_img [B, H, W, C] = clamp mask x the adjoint of
+ * the resampling applied to grad_out [B, H, W_out, C] (gather form, deterministic).
  */
 int dec_forward_train(const float *img, const float *mean_host, const float *std_host, const float *const *params_host, uint32_t B,
                       uint32_t Cin, uint32_t H, uint32_t W, float eps, void *workspace, float *decoded, float *clamped_out,
@@ -490,6 +496,10 @@ int wm_distort_fwd(const float *img, uint32_t B, uint32_t H, uint32_t W, uint32_
                    const float *dist_noise, float *out, nsig_stream_t stream);
 int wm_distort_bwd(const float *grad_out, const float *img, uint32_t B, uint32_t H, uint32_t W, uint32_t C, uint32_t distortion,
                    const float *dist_param, const float *dist_noise, float *grad_img, nsig_stream_t stream);
+int wm_distort_geom_fwd(const float *img, uint32_t B, uint32_t H, uint32_t W, uint32_t C, uint32_t distortion, const float *dist_param,
+                        uint32_t W_out, float *out, float *clamped_out, nsig_stream_t stream);
+int wm_distort_geom_bwd(const float *grad_out, const float *img, uint32_t B, uint32_t H, uint32_t W, uint32_t C, uint32_t distortion,
+                        const float *dist_param, uint32_t W_out, float *grad_img, nsig_stream_t stream);
 
 /* ------------------------------------------------------------------ stage-1 (clean model) training, SURVEY.md 8(f) N3 */
 

@@ -88,6 +88,8 @@ SIGNATURES = {
     "wm_distort_draw": [_u32, _c.c_uint64, _vp, _u32, _vp, _vp, _vp],
     "wm_distort_fwd": [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp],
     "wm_distort_bwd": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp],
+    "wm_distort_geom_fwd": [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _vp, _vp, _vp],
+    "wm_distort_geom_bwd": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _vp, _vp],
     "field_fwd_trace": [_vp, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "field_bwd_trace": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hg_scatter_level": [_vp, _fl, _vp, _u32, _u32, _vp, _vp],

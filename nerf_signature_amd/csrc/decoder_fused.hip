@@ -74,7 +74,7 @@ struct DecInput {
     uint32_t distort, H, W;
     const float *dparam, *dnoise;
 };
-enum : uint32_t { kDistNone = 0, kDistNoise = 1, kDistBrightness = 2, kDistBlur = 3 };
+enum : uint32_t { kDistNone = 0, kDistNoise = 1, kDistBrightness = 2, kDistBlur = 3, kDistRotation = 4, kDistScaling = 5 };
 
 __device__ inline float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
 __device__ inline int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }   // torch 'reflect' padding by one (n >= 2)
@@ -1533,9 +1533,15 @@ __global__ void __launch_bounds__(256) k_distort_draw(uint32_t kind, uint64_t se
                                                       float *__restrict__ noise) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const uint64_t key = mix64(seed ^ (0x9E3779B97F4A7C15ull * ((uint64_t)(step ? step[0] : 0u) + 1ull)));
-    if (i == 0 && param) {
+    if (i == 0 && param && kind != kDistRotation) {
         const float u = (float)(mix64(key ^ 0xFFFFFFFFFFFFFFFFull) >> 40) * (1.0f / 16777216.0f);      // [0, 1)
         param[0] = kind == kDistBrightness ? 0.5f + u : (kind == kDistBlur ? 0.01f + 0.49f * u : 0.0f);
+    }
+    if (kind == kDistRotation && i < n) {       // one angle in [-30, 30) degrees per image, stored as (cos, sin): param[2 i], param[2 i + 1]
+        const float u = (float)(mix64(key ^ (0xA0761D6478BD642Full * ((uint64_t)i + 1ull))) >> 40) * (1.0f / 16777216.0f);
+        const float a = (60.0f * u - 30.0f) * 0.0174532925199432958f;
+        param[2 * i] = cosf(a);
+        param[2 * i + 1] = sinf(a);
     }
     if (kind == kDistNoise && noise && i < n) {
         const uint64_t h = mix64(key + 0xD1B54A32D192ED03ull * ((uint64_t)i + 1ull));
@@ -1562,6 +1568,98 @@ __global__ void __launch_bounds__(256) k_distort_bwd(const float *__restrict__ g
         g = (fx >= 0.0f && fx <= 1.0f) ? g * f : 0.0f;
     }
     gx[i] = (x >= 0.0f && x <= 1.0f) ? g : 0.0f;
+}
+
+// ---- the two kinds that change the sampling geometry (rotation, scaling): kernels of their own in front of / behind the decoder, which then reads their
+// output as an ordinary rendered image (values in [0, 1]: its clamp is the identity and passes every gradient).
+//
+// rotation (torchvision RandomRotation((-30, 30)) per image: nearest-neighbour resampling about the centre, zeros outside, same size): the source of output
+// pixel (x, y), measured from the centre ((W - 1) / 2, (H - 1) / 2), is round-half-even(cos * x - sin * y, sin * x + cos * y).  Every product and sum is
+// rounded on its own (no fused multiply-add): the host-side statement of the same map (distortion.rotate_nearest) picks the same pixels bit for bit.
+__device__ inline bool rotation_source(float c, float s, int x, int y, int H, int W, int &ix, int &iy) {
+    const float cx = 0.5f * (float)(W - 1), cy = 0.5f * (float)(H - 1);
+    const float xs = __fsub_rn((float)x, cx), ys = __fsub_rn((float)y, cy);
+    const float sx = __fadd_rn(__fsub_rn(__fmul_rn(c, xs), __fmul_rn(s, ys)), cx);
+    const float sy = __fadd_rn(__fadd_rn(__fmul_rn(s, xs), __fmul_rn(c, ys)), cy);
+    ix = (int)rintf(sx);
+    iy = (int)rintf(sy);
+    return ix >= 0 && ix < W && iy >= 0 && iy < H;
+}
+// scaling (F.interpolate(image [3, H, W], scale_factor = sf, mode = 'linear'): 1-d, along W only, W_out = floor(W * sf), align_corners = False with the
+// given factor kept for the coordinates): source position max(0, (xd + 0.5) / sf - 0.5), its two neighbours blended linearly -- except where W_out == W,
+// which the operator special-cases as a plain copy whatever the factor (ATen upsample_linear1d: "special case: just copy")
+__device__ inline void scaling_source(float rscale, int xd, int W, int Wo, int &x0, int &x1, float &l0, float &l1) {
+    if (Wo == W) {
+        x0 = x1 = xd;
+        l0 = 1.0f;
+        l1 = 0.0f;
+        return;
+    }
+    float src = rscale * ((float)xd + 0.5f) - 0.5f;
+    src = src < 0.0f ? 0.0f : src;
+    x0 = (int)src;
+    x0 = x0 > W - 1 ? W - 1 : x0;
+    x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    l1 = src - (float)x0;
+    l0 = 1.0f - l1;
+}
+__device__ inline float scaling_rscale(const float *__restrict__ param) { return (float)(1.0 / (double)param[0]); }
+
+// out [B][H][Wo][C] = the layer on clamp(img [B][H][W][C]); clamped_out (optional) = clamp(img)
+__global__ void __launch_bounds__(256) k_distort_geom_fwd(const float *__restrict__ img, uint32_t kind, const float *__restrict__ param, uint32_t B, uint32_t H,
+                                                          uint32_t W, uint32_t Wo, uint32_t C, float *__restrict__ out, float *__restrict__ clamped_out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (clamped_out && i < B * H * W * C) clamped_out[i] = clamp01(img[i]);
+    if (i >= B * H * Wo * C) return;
+    const uint32_t c = i % C, x = (i / C) % Wo, y = (i / (C * Wo)) % H, im = i / (C * Wo * H);
+    const float *base = img + (size_t)im * H * W * C + c;
+    if (kind == kDistRotation) {
+        int ix, iy;
+        out[i] = rotation_source(param[2 * im], param[2 * im + 1], (int)x, (int)y, (int)H, (int)W, ix, iy) ? clamp01(base[((size_t)iy * W + ix) * C]) : 0.0f;
+    } else {
+        int x0, x1;
+        float l0, l1;
+        scaling_source(scaling_rscale(param), (int)x, (int)W, (int)Wo, x0, x1, l0, l1);
+        out[i] = l0 * clamp01(base[((size_t)y * W + x0) * C]) + l1 * clamp01(base[((size_t)y * W + x1) * C]);
+    }
+}
+// grad_img [B][H][W][C] = the clamp's mask x the layer's adjoint applied to gy [B][H][Wo][C].  Gather form (one thread per source element, fixed summation
+// order: deterministic).  rotation: an output pixel q reads source p only if |R^-1 q - p| <= 1/2 per axis, hence |q - R p| < 0.71: q lies in the 3 x 3
+// neighbourhood of round(R p) -- each candidate's source is re-derived with the forward's own arithmetic.  scaling: every output column of the row is tried.
+__global__ void __launch_bounds__(256) k_distort_geom_bwd(const float *__restrict__ gy, const float *__restrict__ img, uint32_t kind, const float *__restrict__ param,
+                                                          uint32_t B, uint32_t H, uint32_t W, uint32_t Wo, uint32_t C, float *__restrict__ gx) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * H * W * C) return;
+    const uint32_t c = i % C, x = (i / C) % W, y = (i / (C * W)) % H, im = i / (C * W * H);
+    const float v = img[i];
+    if (!(v >= 0.0f && v <= 1.0f)) {
+        gx[i] = 0.0f;
+        return;
+    }
+    const float *g = gy + (size_t)im * H * Wo * C + c;
+    float acc = 0.0f;
+    if (kind == kDistRotation) {
+        const float cs = param[2 * im], sn = param[2 * im + 1];
+        const float cx = 0.5f * (float)(W - 1), cy = 0.5f * (float)(H - 1), u = (float)x - cx, w = (float)y - cy;
+        const int qx0 = (int)rintf(cs * u + sn * w + cx), qy0 = (int)rintf(-sn * u + cs * w + cy);
+        for (int qy = qy0 - 1; qy <= qy0 + 1; ++qy)
+            for (int qx = qx0 - 1; qx <= qx0 + 1; ++qx) {
+                if (qx < 0 || qx >= (int)W || qy < 0 || qy >= (int)H) continue;
+                int ix, iy;
+                if (rotation_source(cs, sn, qx, qy, (int)H, (int)W, ix, iy) && ix == (int)x && iy == (int)y) acc += g[((size_t)qy * Wo + qx) * C];
+            }
+    } else {
+        const float rs = scaling_rscale(param);
+        for (int xd = 0; xd < (int)Wo; ++xd) {
+            int x0, x1;
+            float l0, l1;
+            scaling_source(rs, xd, (int)W, (int)Wo, x0, x1, l0, l1);
+            const float gq = g[((size_t)y * Wo + xd) * C];
+            if (x0 == (int)x) acc += l0 * gq;
+            if (x1 == (int)x) acc += l1 * gq;
+        }
+    }
+    gx[i] = acc;
 }
 
 static int make_input(uint32_t mode, const float *mean, const float *stdev, uint32_t Cin, DecInput &in) {
@@ -1716,9 +1814,11 @@ NSIG_EXPORT int dec_backward_train(const float *grad_decoded, const float *img, 
 
 NSIG_EXPORT int wm_distort_draw(uint32_t distortion, uint64_t seed, const uint32_t *step_counter, uint32_t n_noise, float *param_out, float *noise_out,
                                 nsig_stream_t stream) {
-    NSIG_REQUIRE(distortion >= kDistNoise && distortion <= kDistBlur, "wm_distort_draw: distortion is 1 (noise), 2 (brightness) or 3 (blurring)");
+    NSIG_REQUIRE(distortion >= kDistNoise && distortion <= kDistRotation,
+                 "wm_distort_draw: distortion is 1 (noise), 2 (brightness), 3 (blurring) or 4 (rotation); the scaling factor decides a tensor shape: the host draws it");
     NSIG_REQUIRE(distortion == kDistNoise ? (noise_out != nullptr && n_noise >= 1) : param_out != nullptr, "wm_distort_draw: missing output buffer");
-    const uint32_t n = distortion == kDistNoise ? n_noise : 1u;
+    NSIG_REQUIRE(distortion != kDistRotation || n_noise >= 1, "wm_distort_draw: rotation draws one angle per image (n_noise = the number of images)");
+    const uint32_t n = (distortion == kDistNoise || distortion == kDistRotation) ? n_noise : 1u;
     k_distort_draw<<<ceil_div(n, 256u), 256, 0, as_stream(stream)>>>(distortion, seed, step_counter, n, param_out, noise_out);
     return check_launch("wm_distort_draw");
 }
@@ -1752,4 +1852,24 @@ NSIG_EXPORT int wm_distort_bwd(const float *grad_out, const float *img, uint32_t
     else
         k_distort_bwd<<<ceil_div(B * H * W * C, 256u), 256, 0, as_stream(stream)>>>(grad_out, img, in, B, C, grad_img);
     return check_launch("wm_distort_bwd");
+}
+
+NSIG_EXPORT int wm_distort_geom_fwd(const float *img, uint32_t B, uint32_t H, uint32_t W, uint32_t C, uint32_t distortion, const float *dist_param, uint32_t W_out,
+                                    float *out, float *clamped_out, nsig_stream_t stream) {
+    NSIG_REQUIRE(img && out && dist_param && B >= 1 && H >= 1 && W >= 1 && C >= 1 && W_out >= 1 && (uint64_t)B * H * (W > W_out ? W : W_out) * C < (1ull << 31),
+                 "wm_distort_geom_fwd: bad arguments");
+    NSIG_REQUIRE((distortion == kDistRotation && W_out == W) || distortion == kDistScaling,
+                 "wm_distort_geom_fwd: distortion is 4 (rotation: W_out = W, dist_param = (cos, sin) per image) or 5 (scaling: dist_param[0] = the factor, W_out = floor(W * factor))");
+    k_distort_geom_fwd<<<ceil_div(B * H * (W > W_out ? W : W_out) * C, 256u), 256, 0, as_stream(stream)>>>(img, distortion, dist_param, B, H, W, W_out, C, out, clamped_out);
+    return check_launch("wm_distort_geom_fwd");
+}
+
+NSIG_EXPORT int wm_distort_geom_bwd(const float *grad_out, const float *img, uint32_t B, uint32_t H, uint32_t W, uint32_t C, uint32_t distortion,
+                                    const float *dist_param, uint32_t W_out, float *grad_img, nsig_stream_t stream) {
+    NSIG_REQUIRE(grad_out && img && grad_img && dist_param && B >= 1 && H >= 1 && W >= 1 && C >= 1 && W_out >= 1 &&
+                     (uint64_t)B * H * (W > W_out ? W : W_out) * C < (1ull << 31),
+                 "wm_distort_geom_bwd: bad arguments");
+    NSIG_REQUIRE((distortion == kDistRotation && W_out == W) || distortion == kDistScaling, "wm_distort_geom_bwd: distortion is 4 (rotation, W_out = W) or 5 (scaling)");
+    k_distort_geom_bwd<<<ceil_div(B * H * W * C, 256u), 256, 0, as_stream(stream)>>>(grad_out, img, distortion, dist_param, B, H, W, W_out, C, grad_img);
+    return check_launch("wm_distort_geom_bwd");
 }

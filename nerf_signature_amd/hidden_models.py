@@ -103,7 +103,7 @@ class _FusedDecoder(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, img, eps, rendered, distortion, bce, *params):
-        """distortion: a distortion.DistortionLayer of a native kind whose draws are in its device buffers (rendered=True only), or None.
+        """distortion: a distortion.DistortionLayer of a fused kind (noise / brightness / blurring) whose draws are in its device buffers (rendered=True only), or None.
         bce: (message [B] float32 on the device, temp, scale) or None (rendered=True only): the head kernel also leaves
         scale * (sigmoid(temp * decoded) - message) in `_FusedDecoder.seed` -- the watermark loss's gradient, ready for this node's backward."""
         img = img.contiguous()
@@ -117,7 +117,7 @@ class _FusedDecoder(torch.autograd.Function):
         ps = [p.detach().contiguous() for p in params]
         ws = torch.empty(nv.fn("dec_workspace_bytes")(B, Cin, H, W), dtype=torch.uint8, device=img.device)
         out = torch.empty(B, dtype=torch.float32, device=img.device)
-        dist = distortion if (distortion is not None and distortion.native) else None
+        dist = distortion if (distortion is not None and distortion.fused) else None
         _FusedDecoder.seed = None
         if dist is not None or bce is not None:
             if not rendered:
@@ -248,10 +248,16 @@ class HiddenDecoder_multi_views(nn.Module):
         [B, H, W, 3] blocks (utils_wtmk_disen.py:592-595) -> (decoded [B, 1], clamped image).  On the GPU the clamp, the distortion
         (noise / brightness / blurring: distortion.DistortionLayer with this step's draws in its buffers), the layout change and the
         normalisation are part of the fused decoder's first layer."""
-        fused = self._fused_params(image.shape[0], image.shape[3], image.shape[1], image.shape[2], image) if image.dim() == 4 and image.shape[3] <= 3 else None
-        native = distortion is not None and distortion.native
-        if fused is not None and (distortion is None or native or distortion.name == "none"):
-            return _FusedDecoder.apply(image, fused[0], True, distortion if native else None, bce, *fused[1])
+        geometric = distortion is not None and distortion.geometric
+        width = distortion.out_width(image.shape[2]) if geometric and image.dim() == 4 else (image.shape[2] if image.dim() == 4 else 0)
+        fused = self._fused_params(image.shape[0], image.shape[3], image.shape[1], width, image) if image.dim() == 4 and image.shape[3] <= 3 else None
+        if fused is not None and geometric:
+            # rotation / scaling: one resampling launch in front of the chain; its output lies in [0, 1], so the first layer's clamp is the identity
+            from .distortion import _DistortGeometry
+            resampled, pred = _DistortGeometry.apply(image, distortion.kind, distortion.param, width)
+            return _FusedDecoder.apply(resampled, fused[0], True, None, bce, *fused[1])[0], pred
+        if fused is not None:
+            return _FusedDecoder.apply(image, fused[0], True, distortion if (distortion is not None and distortion.fused) else None, bce, *fused[1])
         pred = torch.clamp(image, min=0, max=1)
         dist = pred if distortion is None else distortion(pred, raw=image)
         return self(normalize_img(dist.permute(0, 3, 1, 2))), pred

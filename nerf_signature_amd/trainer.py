@@ -433,9 +433,9 @@ class GraphedWatermarkLoop:
     def __init__(self, model, optimizer, render_kwargs, data, lambda_w=1.0, lambda_i=1.0, lr_lambda=None, headroom=0.0, native_dense_adam=True,
                  overlap_content=True, march_ahead=None, presum_in_adam=True, stage_in_graph=True, content_headroom=None, content_ahead=None,
                  content_sampler=None, fixed_blocks=None, encode_ahead=None, distortion="none", distortion_seed=0):
-        """distortion: noise | brightness | blurring run inside the captured step -- the layer is part of the decoder's first launch and its random
-        parameters are re-drawn on the device every replay (wm_distort_draw, keyed by distortion_seed and the replay count); rotation / scaling are
-        host-driven stock operators (scaling changes the decoder's input shape): WatermarkLoop only.
+        """distortion: noise | brightness | blurring | rotation run inside the captured step -- the first three as part of the decoder's first launch, rotation
+        as one resampling launch in front of it -- and their random parameters are re-drawn on the device every replay (wm_distort_draw, keyed by
+        distortion_seed and the replay count); scaling changes the decoder's input shape every step: WatermarkLoop only.
         presum_in_adam: the captured optimiser kernel also writes the pre-summed codebook of the NEXT step's message
         (opt_codebook_adam_sel_next: +9 % traffic inside an HBM-streaming kernel instead of a 128 MiB pass at the head of every step).
         The next message is handed over one step early -- `step(message_k, next_message=message_k1)`, a one-element look-ahead over
@@ -450,9 +450,9 @@ class GraphedWatermarkLoop:
         at the head of its own step on the side stream: next to the optimiser as well, the two marches took longer than the
         optimiser and the pre-sum lost its cover."""
         self.distortion = None if distortion in (None, "none") else (distortion if isinstance(distortion, DistortionLayer) else DistortionLayer(distortion, distortion_seed))
-        if self.distortion is not None and not self.distortion.native:
-            raise NotImplementedError(f"distortion {self.distortion.name!r} is applied by host-driven stock operators (per-image host draws; 'scaling' changes the "
-                                      f"decoder's input width every step): use the eager WatermarkLoop for it")
+        if self.distortion is not None and self.distortion.name == "scaling":
+            raise NotImplementedError("distortion 'scaling' changes the decoder's input width every step (floor(W * sf)): a captured step has static shapes -- "
+                                      "use the eager WatermarkLoop for it")
         if march_ahead is None and os.environ.get("NERFSIG_MARCH_AHEAD") in ("0", "1"):
             march_ahead = os.environ["NERFSIG_MARCH_AHEAD"] == "1"
         self.march_ahead = overlap_content if march_ahead is None else bool(march_ahead)

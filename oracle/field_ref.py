@@ -363,8 +363,15 @@ def distortion_layer(pred_rgb, distortion, draw=None):
                blend with a black image, clamped to [0, 1] for float images);
     blurring   draw = the sigma of torchvision GaussianBlur(kernel_size=3, sigma=(0.01, 0.5)) (:568-570; one sigma ~ U[0.01, 0.5] per call):
                1-d kernel exp(-0.5 (x / sigma)^2) at x = linspace(-1, 1, 3), normalised; 2-d = outer product; reflect padding of 1; depthwise conv.
-    (torchvision is not installed in this image: its two transforms are restated from their published implementation,
-    torchvision/transforms/_functional_tensor.py `_blend` / `_get_gaussian_kernel1d` / `gaussian_blur`.)"""
+    rotation   draw = the angles in degrees, one per image (:558-560: torchvision RandomRotation((-30, 30)) called once per image; defaults
+               InterpolationMode.NEAREST, expand=False, centre = image centre, fill 0): torchvision's tensor `rotate` builds the inverse affine
+               matrix of -angle, [cos a, -sin a, 0; sin a, cos a, 0], applies it to the pixel-centre grid measured from the image centre and samples
+               with grid_sample(mode='nearest', padding_mode='zeros', align_corners=False) -- restated with the same grid and the stock grid_sample,
+               in float64 (away from rounding ties the float32 result is the same);
+    scaling    draw = the factor sf (:563; one sf ~ U[0.75, 1.25] per call): F.interpolate(image [3, H, W], scale_factor=sf, mode='linear') per image
+               (:565) -- the stock operator itself: a [3, H, W] tensor is a batch of 3 signals with H channels, resized along W to floor(W * sf).
+    (torchvision is not installed in this image: its transforms are restated from their published implementation,
+    torchvision/transforms/_functional_tensor.py `_blend` / `_get_gaussian_kernel1d` / `gaussian_blur` / `rotate` / `_gen_affine_grid`.)"""
     if distortion in (None, "none"):
         return pred_rgb                                                  # :553
     if distortion == "noise":
@@ -378,6 +385,18 @@ def distortion_layer(pred_rgb, distortion, draw=None):
         k1 = k1 / k1.sum()
         k2 = (k1[:, None] * k1[None, :]).expand(x.shape[1], 1, 3, 3)
         y = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (1, 1, 1, 1), mode="reflect"), k2, groups=x.shape[1])
+    elif distortion == "rotation":
+        import math
+        B, C, H, W = x.shape
+        ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64) - (H - 1) / 2, torch.arange(W, dtype=torch.float64) - (W - 1) / 2, indexing="ij")
+        grids = []
+        for deg in draw:
+            a = math.radians(float(deg))
+            sx, sy = math.cos(a) * xs - math.sin(a) * ys, math.sin(a) * xs + math.cos(a) * ys          # source position, from the centre, in pixels
+            grids.append(torch.stack([sx / (0.5 * W), sy / (0.5 * H)], dim=-1))                        # grid_sample's normalised coordinates (align_corners=False)
+        y = torch.nn.functional.grid_sample(x.double(), torch.stack(grids), mode="nearest", padding_mode="zeros", align_corners=False).to(x.dtype)
+    elif distortion == "scaling":
+        y = torch.stack([torch.nn.functional.interpolate(image, scale_factor=float(draw), mode="linear") for image in x])      # :565
     else:
         raise NotImplementedError(distortion)
     return y.permute(0, 2, 3, 1)                                         # :571 / :576

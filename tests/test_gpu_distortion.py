@@ -2,6 +2,7 @@
 the oracle's restatement with the random draw passed in: the layer alone, fused into the decoder's first layer (values + decoder-input
 gradient), through train_step (losses + gradients), and inside the captured loop with draws generated on the device."""
 import copy
+import math
 import os
 
 import numpy as np
@@ -12,7 +13,8 @@ import closed_form as cf
 from oracle import field_ref as fr
 
 pytestmark = pytest.mark.gpu
-KINDS = ["noise", "brightness", "blurring"]
+KINDS = ["noise", "brightness", "blurring"]          # applied inside the decoder's first launch
+GEOMETRIC = ["rotation", "scaling"]                  # a resampling launch of their own in front of the decoder
 
 
 def _layer(kind, shape, seed=3, sigma=None):
@@ -22,8 +24,50 @@ def _layer(kind, shape, seed=3, sigma=None):
     layer.draw(shape, torch.device("cuda"))
     if sigma is not None and kind == "blurring":      # (a small drawn sigma is the identity to fp32: pick one that blurs)
         layer.param.fill_(sigma)
-    draw = layer.noise.cpu().clone() if kind == "noise" else float(layer.param.cpu())
+    if kind == "rotation":        # the oracle takes torchvision's parameter, degrees per image
+        draw = [math.degrees(math.atan2(float(sn), float(c))) for c, sn in layer.param.cpu().reshape(-1, 2)]
+    elif kind == "scaling":
+        draw = layer.factor
+    else:
+        draw = layer.noise.cpu().clone() if kind == "noise" else float(layer.param.cpu())
     return layer, draw
+
+
+@pytest.mark.parametrize("kind", GEOMETRIC)
+@pytest.mark.parametrize("shape", [(32, 12, 12, 3), (5, 9, 14, 3), (3, 40, 33, 3), (2, 1, 7, 3)])
+def test_geometric_layers_alone_match_the_stock_operators_forward_and_backward(kind, shape):
+    """wm_distort_geom_fwd / _bwd (rotation: nearest-neighbour resampling about the centre; scaling: 1-d linear interpolation along W to floor(W * sf)
+    columns) against the oracle's grid_sample / F.interpolate statement and its autograd: values outside [0, 1] so that the clamp and its mask matter,
+    non-square images, several draws.  rotation moves pixels: bit-exact values."""
+    from nerf_signature_amd.distortion import _DistortGeometry, reference_ops, scaled_width
+    rng = np.random.RandomState(0)
+    raw = torch.from_numpy(rng.uniform(-0.25, 1.25, shape).astype(np.float32))
+    for seed in (3, 4, 5):
+        layer, draw = _layer(kind, shape, seed=seed)
+        Wo = layer.out_width(shape[2])
+        r = torch.from_numpy(rng.randn(shape[0], shape[1], Wo, 3).astype(np.float32))
+        a = raw.cuda().requires_grad_(True)
+        out1, clamped = _DistortGeometry.apply(a, layer.kind, layer.param, Wo)
+        (out1 * r.cuda()).sum().backward()
+        b = raw.clone().requires_grad_(True)
+        out0 = fr.distortion_layer(torch.clamp(b, 0, 1), kind, draw)
+        (out0 * r).sum().backward()
+        assert torch.equal(clamped.cpu(), raw.clamp(0, 1)) and tuple(out1.shape) == tuple(out0.shape)
+        if kind == "rotation":
+            assert torch.equal(out1.detach().cpu(), out0.detach())
+            assert torch.equal(out1.detach().cpu(), reference_ops(raw.clamp(0, 1), kind, layer.param.cpu()))      # the product's host-side statement: same pixels
+        else:
+            assert Wo == scaled_width(shape[2], draw)
+            np.testing.assert_allclose(out1.detach().cpu().numpy(), out0.detach().numpy(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-5, atol=5e-6)
+        assert float(b.grad.abs().max()) > 0
+    if kind == "scaling":         # factor 1 is the identity; the columns of a constant image stay constant
+        layer.set_scaling(1.0)
+        ident = _DistortGeometry.apply(raw.cuda(), layer.kind, layer.param, shape[2])[0]
+        np.testing.assert_allclose(ident.cpu().numpy(), raw.clamp(0, 1).numpy(), atol=1e-6)
+    else:                         # angle 0 is the identity
+        layer.set_rotation([0.0] * shape[0])
+        assert torch.equal(_DistortGeometry.apply(raw.cuda(), layer.kind, layer.param, shape[2])[0].cpu(), raw.clamp(0, 1))
 
 
 @pytest.mark.parametrize("kind", KINDS)
@@ -54,7 +98,7 @@ def test_layer_alone_matches_the_oracle_forward_and_backward(kind):
         np.testing.assert_allclose(const.cpu().numpy(), 0.37, atol=1e-6)
 
 
-@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("kind", KINDS + GEOMETRIC)
 @pytest.mark.parametrize("shape", [(32, 12, 12, 3), (48, 11, 15, 3), (4, 2, 2, 3)])
 def test_fused_into_the_decoder_values_and_input_gradient(kind, shape):
     """decode_rendered(image, layer) == decoder(normalize(distortion_layer(clamp(image)))) of the oracle: logits, the clamped image reported as
@@ -79,7 +123,7 @@ def test_fused_into_the_decoder_values_and_input_gradient(kind, shape):
     loss0.backward()
     assert torch.equal(pred1.cpu(), pred0.detach())
     np.testing.assert_allclose(decoded1.detach().cpu().numpy(), decoded0.detach().numpy(), rtol=1e-3, atol=1e-3)
-    np.testing.assert_allclose(float(loss1), float(loss0), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(float(loss1.detach()), float(loss0.detach()), rtol=1e-3, atol=1e-4)
     g1, g0 = a.grad.cpu(), b.grad
     assert float(g0.abs().max()) > 0
     assert float((g1 - g0).norm() / g0.norm()) < 1e-3                                  # the decoder-input gradient
@@ -90,7 +134,7 @@ def test_fused_into_the_decoder_values_and_input_gradient(kind, shape):
     assert float((d1 - d0).norm() / d0.norm()) < 2e-2
 
 
-@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("kind", KINDS + GEOMETRIC)
 def test_train_step_with_distortion_vs_oracle(kind, strict_mlp):
     import test_gpu_render as T
     from nerf_signature_amd import trainer
@@ -141,11 +185,22 @@ def test_device_draws_are_a_function_of_seed_and_step_with_the_right_distributio
     s = np.array([draws("blurring", 1, k) for k in range(400)])
     assert 0.5 <= f.min() < 0.52 and 1.48 < f.max() <= 1.5 and abs(f.mean() - 1.0) < 0.05       # ColorJitter(brightness=0.5): U[0.5, 1.5]
     assert 0.01 <= s.min() < 0.02 and 0.48 < s.max() <= 0.5 and abs(s.mean() - 0.255) < 0.03    # GaussianBlur sigma: U[0.01, 0.5]
+    rot = DistortionLayer("rotation", 1)
+    angles = []
+    for k in range(40):
+        step.fill_(k)
+        rot.draw_on_device(step, shape, dev)
+        c, sn = rot.param.cpu().reshape(-1, 2).unbind(1)
+        assert rot.param.numel() == 2 * shape[0] and torch.allclose(c * c + sn * sn, torch.ones(shape[0]), atol=1e-6)
+        angles += [math.degrees(math.atan2(float(b), float(a))) for a, b in zip(c, sn)]
+    angles = np.array(angles)                                                           # RandomRotation((-30, 30)): one angle per image, U[-30, 30]
+    assert -30.0 <= angles.min() < -29.5 and 29.5 < angles.max() <= 30.0 and abs(angles.mean()) < 1.5 and abs(angles.std() - 60 / math.sqrt(12)) < 0.8
+    assert len(set(np.round(angles[:32], 4))) == 32                                     # per image, not per call
     with pytest.raises(NotImplementedError):
-        DistortionLayer("rotation").draw_on_device(step, shape, dev)
+        DistortionLayer("scaling").draw_on_device(step, shape, dev)                    # the factor decides a shape: a host value
 
 
-@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("kind", KINDS + ["rotation"])
 def test_captured_loop_draws_on_the_device_and_matches_the_eager_step(kind):
     """GraphedWatermarkLoop(distortion=...): every replay re-draws the layer's parameters on the device and the decoder's first launch applies them.
     With a learning rate of zero the parameters stay put, so an eager train_step on the same message with the buffers the last replay left behind
@@ -166,9 +221,9 @@ def test_captured_loop_draws_on_the_device_and_matches_the_eager_step(kind):
         out = loop.step(msg)
         torch.cuda.synchronize()
         losses.append(float(out[4].detach()))
-        seen.append(loop.distortion.noise.cpu().clone() if kind == "noise" else float(loop.distortion.param.cpu()))
+        seen.append(loop.distortion.noise.cpu().clone() if kind == "noise" else loop.distortion.param.cpu().clone())
     assert not loop.overflowed()
-    assert all((not torch.equal(seen[i], seen[i + 1])) if kind == "noise" else (seen[i] != seen[i + 1]) for i in range(2))
+    assert all(not torch.equal(seen[i], seen[i + 1]) for i in range(2))
     assert len(set(round(l, 6) for l in losses)) == 3                                   # same message, same weights, different distortion: different loss
     layer = loop.distortion
     loop.close()
@@ -178,10 +233,10 @@ def test_captured_loop_draws_on_the_device_and_matches_the_eager_step(kind):
         trainer.GraphedWatermarkLoop(m, opt, kw, data, distortion="scaling")
 
 
-@pytest.mark.parametrize("kind", ["rotation", "scaling"])
-def test_stock_operator_distortions_run_in_the_eager_loop(kind):
-    """rotation / scaling (utils_wtmk_disen.py:557-566) stay on stock operators: one eager step trains through them (scaling hands the decoder a
-    different width), gradients reach the codebook."""
+@pytest.mark.parametrize("kind", GEOMETRIC)
+def test_geometric_distortions_run_in_the_eager_loop(kind):
+    """rotation / scaling (utils_wtmk_disen.py:557-566) in the eager loop with the loop's own per-step draws: one step trains through them (scaling hands
+    the decoder a different width), gradients reach the codebook."""
     import test_gpu_render as T
     from nerf_signature_amd import trainer
     bo, bd, co, cd, gt = T._data(n_content=200)

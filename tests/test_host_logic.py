@@ -623,13 +623,28 @@ def test_distortion_layer_host_side_matches_the_oracle_restatement():
     for s in (0.01, 0.2, 0.5):
         assert torch.allclose(ds.reference_ops(x, "blurring", torch.tensor([s])), fr.distortion_layer(x, "blurring", s), atol=1e-7)
     img = torch.arange(3 * 5 * 5, dtype=torch.float32).reshape(3, 5, 5)
-    assert torch.equal(ds.rotate_nearest(img, 0.0), img)
-    assert torch.equal(ds.rotate_nearest(img, 90.0), torch.rot90(img, 1, (1, 2)))           # counter-clockwise, like torchvision's `angle`
-    r30 = ds.rotate_nearest(torch.ones(3, 12, 12), 30.0)
+    assert torch.equal(ds.rotate_nearest(img, 1.0, 0.0), img)
+    assert torch.equal(ds.rotate_nearest(img, 0.0, 1.0), torch.rot90(img, 1, (1, 2)))           # counter-clockwise, like torchvision's `angle`
+    r30 = ds.rotate_nearest(torch.ones(3, 12, 12), math.cos(math.radians(30.0)), math.sin(math.radians(30.0)))
     assert float(r30[:, 5:7, 5:7].min()) == 1.0 and float(r30[:, 0, 0].max()) == 0.0              # centre kept, corners filled with zeros
+    # rotation / scaling with the draws passed in, against the oracle's grid_sample / interpolate statement (non-square images, several angles per batch)
+    degs = [-30.0, -7.3, 11.9, 29.5]
+    cs = torch.tensor([[math.cos(math.radians(d)), math.sin(math.radians(d))] for d in degs], dtype=torch.float32).reshape(-1)
+    assert torch.equal(ds.reference_ops(x, "rotation", cs), fr.distortion_layer(x, "rotation", degs))
+    for sf in (0.75, 0.9, 1.0, 1.13, 1.2499):
+        out = ds.reference_ops(x, "scaling", sf)
+        assert out.shape == (4, 6, ds.scaled_width(5, sf), 3) and torch.equal(out, fr.distortion_layer(x, "scaling", sf))
     layer = ds.DistortionLayer("scaling", seed=1)
+    layer.draw(tuple(x.shape), torch.device("cpu"))
     out = layer(x)
-    assert out.shape[0] == 4 and out.shape[1] == 6 and out.shape[3] == 3 and 3 <= out.shape[2] <= 6      # resized along W only (:564: a [3,H,W] image is a 1-d batch)
+    assert 0.75 <= layer.factor <= 1.25 and out.shape == (4, 6, layer.out_width(5), 3)             # resized along W only (:564: a [3,H,W] image is a 1-d batch)
+    layer = ds.DistortionLayer("rotation", seed=1)
+    layer.draw(tuple(x.shape), torch.device("cpu"))
+    c, s_ = layer.param.reshape(-1, 2).unbind(1)
+    assert layer.param.shape == (8,) and torch.allclose(c * c + s_ * s_, torch.ones(4), atol=1e-6) and float(c.min()) >= math.cos(math.radians(30.0)) - 1e-6
+    assert layer(x).shape == x.shape
+    u = [ds.host_uniform(3, k, 0.75, 1.25) for k in range(2000)]                                   # the captured loop's host-side scaling factor
+    assert 0.75 <= min(u) < 0.76 and 1.24 < max(u) < 1.25 and abs(sum(u) / len(u) - 1.0) < 0.01 and u[5] == ds.host_uniform(3, 5, 0.75, 1.25) != ds.host_uniform(4, 5, 0.75, 1.25)
     for name in ("none", "noise", "rotation", "scaling", "blurring", "brightness"):       # main_nerf_wtmk.py:75
         ds.DistortionLayer(name)
     with pytest.raises(ValueError):
