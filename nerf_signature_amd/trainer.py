@@ -17,7 +17,7 @@ from . import _native as nv
 from . import fieldops as fo
 from . import dp
 from .dp import GradExchange, exchange_active, world_size
-from .distortion import DistortionLayer
+from .distortion import DistortionLayer, host_uniform, scaled_width
 from .hidden_models import normalize_img, set_grad_arena, set_weights_stream
 
 
@@ -433,9 +433,10 @@ class GraphedWatermarkLoop:
     def __init__(self, model, optimizer, render_kwargs, data, lambda_w=1.0, lambda_i=1.0, lr_lambda=None, headroom=0.0, native_dense_adam=True,
                  overlap_content=True, march_ahead=None, presum_in_adam=True, stage_in_graph=True, content_headroom=None, content_ahead=None,
                  content_sampler=None, fixed_blocks=None, encode_ahead=None, distortion="none", distortion_seed=0):
-        """distortion: noise | brightness | blurring | rotation run inside the captured step -- the first three as part of the decoder's first launch, rotation
-        as one resampling launch in front of it -- and their random parameters are re-drawn on the device every replay (wm_distort_draw, keyed by
-        distortion_seed and the replay count); scaling changes the decoder's input shape every step: WatermarkLoop only.
+        """distortion: all five of the reference's kinds run inside the captured step -- noise | brightness | blurring as part of the decoder's first launch,
+        rotation | scaling as one resampling launch in front of it.  Their random parameters are re-drawn on the device every replay (wm_distort_draw, keyed
+        by distortion_seed and the replay count), except the scaling factor: it sets the decoder's input WIDTH, so prepare() captures the step once per
+        possible width and step() draws the factor on the host (distortion.host_uniform, same key) and replays the capture of that width.
         presum_in_adam: the captured optimiser kernel also writes the pre-summed codebook of the NEXT step's message
         (opt_codebook_adam_sel_next: +9 % traffic inside an HBM-streaming kernel instead of a 128 MiB pass at the head of every step).
         The next message is handed over one step early -- `step(message_k, next_message=message_k1)`, a one-element look-ahead over
@@ -450,9 +451,6 @@ class GraphedWatermarkLoop:
         at the head of its own step on the side stream: next to the optimiser as well, the two marches took longer than the
         optimiser and the pre-sum lost its cover."""
         self.distortion = None if distortion in (None, "none") else (distortion if isinstance(distortion, DistortionLayer) else DistortionLayer(distortion, distortion_seed))
-        if self.distortion is not None and self.distortion.name == "scaling":
-            raise NotImplementedError("distortion 'scaling' changes the decoder's input width every step (floor(W * sf)): a captured step has static shapes -- "
-                                      "use the eager WatermarkLoop for it")
         if march_ahead is None and os.environ.get("NERFSIG_MARCH_AHEAD") in ("0", "1"):
             march_ahead = os.environ["NERFSIG_MARCH_AHEAD"] == "1"
         self.march_ahead = overlap_content if march_ahead is None else bool(march_ahead)
@@ -634,7 +632,7 @@ class GraphedWatermarkLoop:
         if self.content_sampler is not None:
             ct = self.data["content"]
             self.content_sampler.sample_into(self.stage_counter, ct["rays_o"], ct["rays_d"], ct["images"])
-        if self.distortion is not None:      # this step's draws, from (seed, replay count): the same on every rank
+        if self.distortion is not None and self.distortion.name != "scaling":      # this step's draws, from (seed, replay count): the same on every rank
             o = self.data["watermark"]["rays_o_block"]
             self.distortion.draw_on_device(self.stage_counter, tuple(o.shape), o.device)
         prev = fo.set_plan_stream(self.plan_stream)    # the scatter plans need the sample positions only: beside the forward pass
@@ -856,6 +854,10 @@ class GraphedWatermarkLoop:
         self.exchange.shared_scale = 1.0 if self.sharded else None
         self.opt_shard = dp.optimizer_shard(model.message_dim) if self.sharded else None
         model.codebook_shard = self.opt_shard
+        if self.distortion is not None and self.distortion.name == "scaling":      # (its one parameter is a host value: the buffer the kernels read it from)
+            o = self.data["watermark"]["rays_o_block"]
+            self.distortion._buffers(tuple(o.shape), o.device)
+            self.distortion.set_scaling(host_uniform(self.distortion.seed, self._replays, 0.75, 1.25))
         beside = self.side_stream is not None and self.backward_schedule != "tail"
         self.content_backward_first = beside
         self.weights_stream = self.side_stream if not beside else (getattr(self, "_own_weights_stream", None) or torch.cuda.Stream())
@@ -899,6 +901,29 @@ class GraphedWatermarkLoop:
         torch.cuda.synchronize()
         self._restore(snapshot)
 
+        # One capture per shape the step can take: a single one, except under `distortion='scaling'`, whose factor sets the decoder's input width
+        # (floor(W * sf), sf in [0.75, 1.25)): one capture per width, each in a memory pool of its own; step() draws the factor on the host
+        # (distortion.host_uniform: a function of the seed and the step index) and replays the capture of its width.
+        self.variants = {}
+        if self.distortion is not None and self.distortion.name == "scaling":
+            W = self.data["watermark"]["rays_o_block"].shape[2]
+            a_factor_of = {scaled_width(W, f): f for f in (0.75 + 0.5 * i / 4096.0 for i in range(4096))}
+            for w in sorted(a_factor_of):
+                self.distortion.set_scaling(a_factor_of[w])
+                self.variants[w] = self._capture(cap_block, cap_content)
+        else:
+            self.variants[None] = self._capture(cap_block, cap_content)
+        self._select(next(iter(self.variants)))
+        return self
+
+    def _select(self, key):
+        """Make the capture of this shape the one step() replays and overflowed() / point_counts() read."""
+        v = self.variants[key]
+        self.segments, self.between, self.graphs, self.out = v["segments"], v["between"], v["graphs"], v["out"]
+        self.capacity_rows, self.capacities = v["capacity_rows"], v["capacities"]
+
+    def _capture(self, cap_block, cap_content):
+        model = self.model
         self.optimizer.zero_grad(set_to_none=True)
         if self.march_ahead and not (self.fixed_blocks and not self.content_ahead):
             self._march_ahead()      # the first replay's samples (buffers outside the graph's pool, re-marched in place by every replay)
@@ -933,7 +958,9 @@ class GraphedWatermarkLoop:
             # under capture are not handed to the watchdog at all.
             import time
             time.sleep(float(os.environ.get("NERFSIG_WATCHDOG_DRAIN_S", "0.5")))
-        capture_stream = torch.cuda.Stream(priority=int(os.environ.get("NERFSIG_MAIN_PRIORITY", "0")))      # (-1: the block render / decoder chain above the content chain; measured: LABNOTES section 14)
+        if getattr(self, "_capture_stream", None) is None:      # one stream for every capture of this loop (autograd's accumulation nodes remember the stream they were made on)
+            self._capture_stream = torch.cuda.Stream(priority=int(os.environ.get("NERFSIG_MAIN_PRIORITY", "0")))      # (-1: the block render / decoder chain above the content chain; measured: LABNOTES section 14)
+        capture_stream = self._capture_stream
         capture_stream.wait_stream(torch.cuda.current_stream())
         prev = dp.set_boundary(boundary)
         try:
@@ -947,14 +974,15 @@ class GraphedWatermarkLoop:
         finally:
             dp.set_boundary(prev)
         torch.cuda.current_stream().wait_stream(capture_stream)
-        self.graphs = tuple(self.segments)
-        self.capacity_rows = [(model.local_step - 2) % 16, (model.local_step - 1) % 16]
-        # the counters are written in issue order: with a side stream train_step issues the content render first
-        self.capacities = [cap_block, cap_content] if self._blocks_issued_first() else [cap_content, cap_block]
+        fo.forget_plan_events()              # (events recorded in the finished capture: not to be waited on by whatever comes next)
+        self.model._presum_event = None
+        capacity_rows = [(model.local_step - 2) % 16, (model.local_step - 1) % 16]
         self.content_capacity = cap_content
         if self.marched is not None:        # only the content render used the ring during the capture
-            self.capacity_rows = [(model.local_step - 1) % 16]
-        return self
+            capacity_rows = [(model.local_step - 1) % 16]
+        # the counters are written in issue order: with a side stream train_step issues the content render first
+        return {"segments": self.segments, "between": self.between, "graphs": tuple(self.segments), "out": self.out, "capacity_rows": capacity_rows,
+                "capacities": [cap_block, cap_content] if self._blocks_issued_first() else [cap_content, cap_block]}
 
     def step(self, message, data=None, next_data=None, next_message=None):
         """message: CPU float tensor of 0./1.; data: optional new rays/images of THIS step, next_data: of the next one (same
@@ -974,6 +1002,9 @@ class GraphedWatermarkLoop:
             if unannounced:
                 self.model.prepare_message(self.msg_dev)     # not announced one step early: the stand-alone pass, before the replay
             self._s_for = None if next_message is None else next_message.detach().to("cpu", torch.float32).clone()
+        if self.distortion is not None and self.distortion.name == "scaling":      # this step's factor (host-side draw) and the capture of its width
+            self.distortion.set_scaling(host_uniform(self.distortion.seed, self._replays, 0.75, 1.25))
+            self._select(self.distortion.out_width(self.data["watermark"]["rays_o_block"].shape[2]))
         for i, g in enumerate(self.segments):
             g.replay()
             if i == 0:

@@ -134,14 +134,15 @@ def test_the_other_configs_learn_the_watermark_too(scene):
     assert 35.0 < rec["psnr_db"] < 75.0
 
 
-@pytest.mark.parametrize("kind", ["brightness", "blurring"])
+@pytest.mark.parametrize("kind", ["brightness", "blurring", "rotation", "scaling"])
 def test_robustness_training_through_the_device_distortion_layer(kind):
-    """`--distortion` (utils_wtmk_disen.py:551-577,594,666) inside the captured step, draws regenerated on the device every replay: after the README
-    schedule the decoder reads the message from blocks distorted the same way (as the reference's eval_step distorts them) and from clean ones."""
+    """`--distortion` (utils_wtmk_disen.py:551-577,594,666) inside the captured step, draws regenerated every replay (on the device; the scaling factor
+    on the host, selecting the capture of its width): after the README schedule the decoder reads the message from blocks distorted the same way (as
+    the reference's eval_step distorts them) and from clean ones (rotation: trained on rotated blocks only, the unrotated ones are off-distribution)."""
     from nerf_signature_amd import quality
     rec = quality.run("graphed", 1000, n_messages=100, distortion=kind)
     print(f"\n[{kind}] bit acc clean blocks {rec['bit_acc']:.4f}, distorted blocks {rec['bit_acc_distorted_blocks']:.4f}, PSNR {rec['psnr_db']:.2f} dB, {rec['train_ms_per_step']:.3f} ms/step")
-    assert rec["bit_acc"] >= 0.98 and rec["bit_acc_distorted_blocks"] >= 0.97
+    assert rec["bit_acc"] >= (0.98 if kind != "rotation" else 0.95) and rec["bit_acc_distorted_blocks"] >= 0.97
     assert not rec["overflowed"] and 40.0 < rec["psnr_db"] < 75.0
 
 
