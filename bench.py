@@ -466,7 +466,9 @@ def run_secondaries(args):
                      launch structure of a rank, every collective issued on a world-size-1 RCCL group, no xGMI latency)
       eager_reference_trainer_shape   the loop a user of the UNCHANGED reference CLI drives: the reference Trainer's loop body around this repo's model,
                      eager, autocast(fp16) + GradScaler, plain torch.optim.Adam, loader-style rays and three .item() reads per step (tools/trainer_shape.py)
-      eval_loop      the eval-mode burst loop (renderer_wtmk.py:335-372) on one 400x400 view, control on the device vs read back every round (tools/eval_bench.py)"""
+      eval_loop      the eval-mode burst loop (renderer_wtmk.py:335-372) on one 400x400 view, control on the device vs read back every round (tools/eval_bench.py)
+      distortion_layer   the five `--distortion` kinds inside the captured step, each trained through the README schedule: ms per step, bit accuracy on clean and on
+                     distorted blocks (tools/distortion_bench.py)"""
     out = {}
     k = str(min(args.steps, 50))
     jobs = (("quality", [os.path.join(ROOT, "tools", "converge.py"), "graphed", "--steps", "1000", "--messages", "200"]),
@@ -475,7 +477,8 @@ def run_secondaries(args):
             ("fern", [os.path.abspath(__file__), "--config", "fern", "--steps", "5", "--warmup", "1", "--no-secondary"]),
             ("rank_emulation", [os.path.join(ROOT, "tools", "emulate_ranks.py"), "--steps", k]),
             ("eager_reference_trainer_shape", [os.path.join(ROOT, "tools", "trainer_shape.py"), "--steps", "100"]),
-            ("eval_loop", [os.path.join(ROOT, "tools", "eval_bench.py")]))
+            ("eval_loop", [os.path.join(ROOT, "tools", "eval_bench.py")]),
+            ("distortion_layer", [os.path.join(ROOT, "tools", "distortion_bench.py")]))
     for name, argv in jobs:
         t0 = time.time()
         try:
@@ -487,7 +490,7 @@ def run_secondaries(args):
                 continue
             j = json.loads(lines[-1])
             c = j.get("config", {})
-            if name in ("quality", "quality_two_ranks_gloo", "rank_emulation", "eager_reference_trainer_shape", "eval_loop"):
+            if name in ("quality", "quality_two_ranks_gloo", "rank_emulation", "eager_reference_trainer_shape", "eval_loop", "distortion_layer"):
                 out[name] = j
             elif name == "counter":
                 out[name] = {"ms_per_step": j["ms_per_step"], "content_rays_per_s": j["value"], "points_per_s": c.get("points_per_s"), "points_per_step": c.get("points_per_step_per_rank"),
