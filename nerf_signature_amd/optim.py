@@ -24,10 +24,10 @@ def fused_shared_step(optimizer, group, selected, G, grad_scale=1.0):
     D = len(selected)
     vp = ctypes.c_void_p * D
     pp, pm, pv, step_sizes, inv_bc2 = vp(), vp(), vp(), (ctypes.c_float * D)(), (ctypes.c_float * D)()
-    handles = optimizer.__dict__.setdefault("_nsig_table_handles", {})      # id(table) -> (table, state dict, exp_avg, exp_avg_sq, their addresses)
+    handles = optimizer.__dict__.setdefault("_nsig_table_handles", {})      # id(table) -> (table, state dict, exp_avg, exp_avg_sq, their addresses, step count)
     for i, p in enumerate(selected):
         h = handles.get(id(p))
-        if h is None or h[0] is not p or h[1].get("exp_avg") is not h[2] or h[1].get("exp_avg_sq") is not h[3]:      # (a loaded checkpoint replaces the state tensors)
+        if h is None or h[0] is not p or h[1].get("exp_avg") is not h[2] or h[1].get("exp_avg_sq") is not h[3] or h[1].get("step") is not h[8]:      # (a loaded checkpoint replaces the state tensors)
             st = optimizer.state[p]
             if len(st) == 0:   # torch.optim.Adam._init_group
                 st["step"] = torch.tensor(0.0, dtype=torch.float32)
@@ -36,11 +36,14 @@ def fused_shared_step(optimizer, group, selected, G, grad_scale=1.0):
             for t in (p, st["exp_avg"], st["exp_avg_sq"]):
                 if not (t.is_contiguous() and t.dtype == torch.float32):
                     raise ValueError("fused_shared_step: tables and their Adam moments must be contiguous float32 tensors")
-            h = handles[id(p)] = (p, st, st["exp_avg"], st["exp_avg_sq"], p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr())
-        st = h[1]
-        st["step"] += 1
-        step = float(st["step"])
+            h = handles[id(p)] = (p, st, st["exp_avg"], st["exp_avg_sq"], p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                  None if st["step"].is_cuda else st["step"].numpy(), st["step"])
         pp[i], pm[i], pv[i] = h[4], h[5], h[6]
+        count = h[7]                     # the step count, torch's host tensor seen through numpy: += 1 without a dispatcher call (D of them per step)
+        if count is None:                # (a count left on the device by the captured loop: one synchronising read each)
+            count = h[8]
+        count += 1
+        step = float(count)
         step_sizes[i] = lr / (1.0 - beta1 ** step)
         inv_bc2[i] = 1.0 / math.sqrt(1.0 - beta2 ** step)
     nv.call("opt_codebook_adam", nv.ptr(G), pp, pm, pv, D, float(beta1), float(beta2), eps, step_sizes, inv_bc2, float(grad_scale), nv.stream())
