@@ -464,8 +464,10 @@ def run_secondaries(args):
       counter, fern  BASELINE.json configs 3 and 5
       rank_emulation one rank of 2 / 4 / 8 on this GPU, in both execution modes of the multi-rank step + fixed blocks (tools/emulate_ranks.py: kernel work and
                      launch structure of a rank, every collective issued on a world-size-1 RCCL group, no xGMI latency)
-      eager_reference_trainer_shape   the loop a user of the UNCHANGED reference CLI drives: the reference Trainer's loop body around this repo's model,
-                     eager, autocast(fp16) + GradScaler, plain torch.optim.Adam, loader-style rays and three .item() reads per step (tools/trainer_shape.py)
+      eager_reference_trainer_shape   the loop a user of the UNCHANGED reference CLI drives: the reference Trainer's loop body and its train_step's operator
+                     sequence (stock clamp / normalisation / MSE / BCE around model.render and model.msg_decoder) around this repo's model, eager, autocast(fp16) +
+                     GradScaler, plain torch.optim.Adam, loader-style rays and three .item() reads per step (tools/trainer_shape.py); next to it the same loop
+                     around this repo's fused trainer.train_step
       eval_loop      the eval-mode burst loop (renderer_wtmk.py:335-372) on one 400x400 view, control on the device vs read back every round (tools/eval_bench.py)
       distortion_layer   the five `--distortion` kinds inside the captured step, each trained through the README schedule: ms per step, bit accuracy on clean and on
                      distorted blocks (tools/distortion_bench.py)"""
@@ -476,7 +478,7 @@ def run_secondaries(args):
             ("counter", [os.path.abspath(__file__), "--config", "counter", "--steps", k, "--warmup", str(min(args.warmup, 5)), "--no-cpu-baseline", "--no-secondary", "--windows", "1"]),
             ("fern", [os.path.abspath(__file__), "--config", "fern", "--steps", "5", "--warmup", "1", "--no-secondary"]),
             ("rank_emulation", [os.path.join(ROOT, "tools", "emulate_ranks.py"), "--steps", k]),
-            ("eager_reference_trainer_shape", [os.path.join(ROOT, "tools", "trainer_shape.py"), "--steps", "100"]),
+            ("eager_reference_trainer_shape", [os.path.join(ROOT, "tools", "trainer_shape.py"), "--steps", "100", "--both"]),
             ("eval_loop", [os.path.join(ROOT, "tools", "eval_bench.py")]),
             ("distortion_layer", [os.path.join(ROOT, "tools", "distortion_bench.py")]))
     for name, argv in jobs:

@@ -29,6 +29,10 @@ ap.add_argument("--no-gc", action="store_true", help="diagnostics: Python's cycl
 ap.add_argument("--gc-freeze", action="store_true", help="gc.freeze() after the warm-up steps (what the drop-in model does at its first training render)")
 ap.add_argument("--phases", action="store_true", help="host wall time per phase of the loop body (perf_counter, no profiler)")
 ap.add_argument("--no-auto-fix", action="store_true")
+ap.add_argument("--fused-step", action="store_true", help="this repo's trainer.train_step (clamp / normalisation / losses fused into its kernels) instead of the operator sequence "
+                                                          "the reference's own Trainer.train_step issues around model.render and model.msg_decoder")
+ap.add_argument("--distortion", default="none")
+ap.add_argument("--both", action="store_true", help="after the timed windows, time one more window with the other train_step (see --fused-step) and report it next to the first")
 args = ap.parse_args()
 
 from nerf_signature_amd import quality, synthetic, trainer
@@ -58,6 +62,34 @@ def loader(k):
     return {"watermark": wm, "content": {"rays_o": o, "rays_d": d, "images": images}}
 
 
+mse = torch.nn.MSELoss(reduction="none")                                                                 # main_nerf_wtmk.py:108, the Trainer's `criterion`
+layer = None
+if args.distortion != "none":
+    from nerf_signature_amd.distortion import DistortionLayer
+    layer = DistortionLayer(args.distortion)
+
+
+def reference_shaped_train_step(data, message):
+    """What the UNCHANGED reference Trainer.train_step (utils_wtmk_disen.py:579-646, 3-channel images, loss_w 'bce' :441) asks of torch and of the two
+    shadowed modules, operator by operator: model.render on the blocks, clamp, distortion layer, layout change, model.normalization, model.msg_decoder,
+    model.render on the content rays, an element-wise MSE criterion and its mean, BCE-with-logits on 10 x decoded, the weighted sum.  Nothing of it is
+    fused: the drop-in modules only see the calls into `model`."""
+    from einops import rearrange
+    blocks = model.render(wm["rays_o_block"], wm["rays_d_block"], message, staged=False, bg_color=1, perturb=False, force_all_rays=True, **opt_ns)["image"]
+    pred_rgb = torch.clamp(blocks, min=0, max=1)
+    seen = pred_rgb
+    if layer is not None:
+        layer.draw(tuple(pred_rgb.shape), pred_rgb.device)
+        seen = layer(pred_rgb)
+    decoded = model.msg_decoder(model.normalization(rearrange(seen, "b h w c -> b c h w")))
+    ct = data["content"]
+    content_rgb = model.render(ct["rays_o"], ct["rays_d"], message, staged=False, bg_color=1, perturb=False, force_all_rays=True, **opt_ns)["image"]
+    lossi = mse(content_rgb, ct["images"]).mean()
+    lossw = torch.nn.functional.binary_cross_entropy_with_logits(decoded * 10.0, message.unsqueeze(-1), reduction="mean")
+    loss = 0.005 * lossw + 1.0 * lossi
+    return pred_rgb, ct["images"], content_rgb, lossi, lossw, loss
+
+
 PH = {}
 
 
@@ -77,7 +109,10 @@ def step(k):
     optimizer.zero_grad()
     t = mark("zero_grad", t)
     with torch.autocast("cuda", enabled=not args.no_fp16):
-        out = trainer.train_step(model, data, message, opt_ns, lambda_w=0.005, lambda_i=1.0)
+        if args.fused_step:
+            out = trainer.train_step(model, data, message, opt_ns, lambda_w=0.005, lambda_i=1.0, distortion=layer)
+        else:
+            out = reference_shaped_train_step(data, message)
     t = mark("train_step (forward)", t)
     scaler.scale(out[5]).backward()
     t = mark("backward", t)
@@ -119,6 +154,18 @@ for w in range(1 if args.profile else 3):
     torch.cuda.synchronize()
     windows.append((time.perf_counter() - t0) / args.steps * 1e3)
 el = float(np.median(windows)) * args.steps / 1e3
+other = None
+if args.both and not args.profile:
+    args.fused_step = not args.fused_step
+    for k in range(args.warmup):
+        step(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    torch.cuda.synchronize()
+    other = (time.perf_counter() - t0) / args.steps * 1e3
+    args.fused_step = not args.fused_step
 if args.profile:
     pr.disable()
     st = pstats.Stats(pr, stream=sys.stderr)
@@ -131,7 +178,9 @@ if args.phases:
     n = args.steps * len(windows)
     print("host wall per step by phase (ms; includes waiting for the GPU where a phase synchronises):", {k: round(v / n * 1e3, 3) for k, v in PH.items()}, file=sys.stderr)
 os.dup2(real_stdout, 1)
-print(json.dumps({"what": "reference Trainer loop body (utils_wtmk_disen.py:1164-1190) around this repo's model: eager, autocast(fp16) + GradScaler, plain torch.optim.Adam, "
-                          "loader-style rays per step, three .item() reads per step; NOT the headline path",
+print(json.dumps({"what": "reference Trainer loop body (utils_wtmk_disen.py:1164-1190) and train_step operator sequence (:579-646) around this repo's model: eager, autocast(fp16) + "
+                          "GradScaler, plain torch.optim.Adam, loader-style rays per step, three .item() reads per step; NOT the headline path",
+                  "train_step": "this repo's fused trainer.train_step" if args.fused_step else "the reference's operator sequence around model.render / model.msg_decoder (stock clamp, normalisation, MSE, BCE)",
                   "ms_per_step": el / args.steps * 1e3, "ms_per_step_windows": [round(w, 4) for w in windows], "content_rays_per_s": 4096 * args.steps / el, "steps": args.steps, "fp16": not args.no_fp16,
+                  **({} if other is None else {("ms_per_step_reference_operator_sequence" if args.fused_step else "ms_per_step_with_this_repos_fused_train_step"): round(other, 4)}),
                   "fix_rays": bool(args.fix_rays), "shared_gradient_step": bool(model.shared_gradient_step), "auto_fix_rays": bool(model.auto_fix_rays), "loss": last[0] if last else None, "grad_scale": float(scaler.get_scale()) if not args.no_fp16 else None}), flush=True)
