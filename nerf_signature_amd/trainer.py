@@ -265,6 +265,31 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
     return pred_rgb, gt_rgb, content_pred_rgb, lossi, lossw, loss
 
 
+def reference_trainer_train_step(self, data, message):
+    """Trainer.train_step of the reference (utils_wtmk_disen.py:579-646) as a method for ITS Trainer class: same arguments, same six return values
+    (pred_rgb, gt_rgb, content_pred_rgb, lossi, lossw, loss), computed by this repo's train_step -- clamp, layout change, normalisation and the distortion
+    layer inside the decoder's first launch, the three losses in one kernel -- instead of ~20 stock operators around model.render / model.msg_decoder.
+    Read from `self` exactly what the reference's method reads: model, opt (splatted into render(), color_space), lambda_w, lambda_i, distortion,
+    and opt.loss_w.  The drop-in directory's nerf/utils_wtmk_disen.py binds it (NERFSIG_DROPIN_TRAIN_STEP=0 keeps the reference's own method)."""
+    images = data["watermark"].get("images")
+    if images is not None and images.shape[-1] != 3 and not self.model.bg_radius > 0:
+        # the reference assigns bg_color only for 3-channel block images (:585-586) and reads it unconditionally (:590)
+        raise UnboundLocalError("local variable 'bg_color' referenced before assignment (utils_wtmk_disen.py:590: the watermark stage needs 3-channel block images)")
+    kind = getattr(self, "distortion", "none") or "none"
+    layer = None
+    if kind != "none":
+        layer = self.__dict__.get("_nsig_distortion_layer")
+        if layer is None or layer.name != kind:
+            layer = self.__dict__["_nsig_distortion_layer"] = DistortionLayer(kind)
+        o = data["watermark"]["rays_o_block"]
+        layer.draw(tuple(o.shape), o.device)
+    name = getattr(self.opt, "loss_w", "bce")
+    if name not in ("bce", "mse"):
+        raise NotImplementedError
+    return train_step(self.model, data, message, vars(self.opt), lambda_w=self.lambda_w, lambda_i=self.lambda_i, loss_w=loss_w_bce if name == "bce" else loss_w_mse,
+                      color_space=getattr(self.opt, "color_space", "srgb"), distortion=layer)
+
+
 def eval_step(model, data, message, render_kwargs, render_whole=True, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce, color_space="srgb", distortion=None):
     """Trainer.eval_step (utils_wtmk_disen.py:648-702) for 3-channel images / srgb.  distortion: as in train_step -- the reference applies its
     distortion layer to the evaluated blocks as well (:666), with a fresh draw per call.

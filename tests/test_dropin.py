@@ -24,9 +24,17 @@ assert _m.shared_gradient_step and _m.auto_fix_rays and set(_m.state_dict()) == 
 assert hash_encoding.HashEmbedder.__module__ == "nerf_signature_amd.hash_encoding"
 assert hash_encoding_wtmk_bit.HashEmbedder.__module__ == "nerf_signature_amd.hash_encoding_wtmk_bit"
 assert raymarching.__file__.startswith(ROOT) and callable(raymarching.march_rays_train)
-import nerf.utils_wtmk_disen as u                       # the reference's own trainer module, untouched
-assert u.__file__.startswith(REF), u.__file__
+import nerf.utils_wtmk_disen as u                       # the reference's own trainer module, executed as it is, with Trainer.train_step replaced
+import nerf._reference_utils_wtmk_disen as ref_u
+assert ref_u.__file__.startswith(REF) and u.__file__.startswith(ROOT), (ref_u.__file__, u.__file__)
 assert hasattr(u, "Trainer") and hasattr(u, "BIT_ACC") and hasattr(u, "seed_everything")
+for name in ("os", "np", "optim", "seed_everything", "PSNRMeter", "LPIPSMeter", "SSIMMeter", "BIT_ACC", "get_rays"):      # what main_nerf_wtmk.py takes through `import *`
+    assert getattr(u, name) is getattr(ref_u, name), name
+import nerf_signature_amd.trainer as our_trainer
+assert u.Trainer.__mro__[1] is ref_u.Trainer and u.Trainer.train_step is our_trainer.reference_trainer_train_step
+assert {k for k in vars(u.Trainer) if not k.startswith("__")} == {"train_step"}       # nothing else of the Trainer is touched
+import nerf.provider_wtmk as prov                       # another module of the reference: still its own file
+assert prov.__file__.startswith(REF)
 # main_nerf_wtmk.py:93-102,110: the model is built and its optimiser groups taken exactly as the CLI does
 m = nerf.network_wtmk_tcnn.NeRFNetwork(bound=1.0, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1, message_dim=32, n_views=1)
 import torch
@@ -63,5 +71,26 @@ def test_dropin_shadows_only_the_hot_path_modules(tmp_path):
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1",
                PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "nerf_signature_amd", "dropin"), ROOT, REF]))
     script = SCRIPT.replace("REF", repr(REF)).replace("ROOT", repr(ROOT))
+    out = subprocess.run([sys.executable, "-B", "-c", script], env=env, capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    assert "DROPIN_OK" in out.stdout, out.stderr[-3000:]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+def test_dropin_trainer_shadow_can_be_switched_off(tmp_path):
+    """NERFSIG_DROPIN_TRAIN_STEP=0: the shadow module re-exports the reference's Trainer itself."""
+    script = r'''
+import sys
+from unittest.mock import MagicMock
+for name in ("trimesh","cv2","imageio","tensorboardX","mcubes","torch_ema","lpips","torchmetrics","torchmetrics.functional",
+             "matplotlib","matplotlib.pyplot","torchvision","torchvision.transforms","scipy.spatial.transform","PIL","PIL.Image"):
+    try: __import__(name)
+    except Exception: sys.modules[name] = MagicMock()
+import nerf.utils_wtmk_disen as u
+import nerf._reference_utils_wtmk_disen as ref_u
+assert u.Trainer is ref_u.Trainer
+print("DROPIN_OK")
+'''
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", NERFSIG_DROPIN_TRAIN_STEP="0",
+               PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "nerf_signature_amd", "dropin"), ROOT, REF]))
     out = subprocess.run([sys.executable, "-B", "-c", script], env=env, capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
     assert "DROPIN_OK" in out.stdout, out.stderr[-3000:]

@@ -306,3 +306,61 @@ def test_shared_gradient_step_under_a_foreign_loop_matches_plain_autograd_and_ad
     opt_w.step()
     assert sum(int(not torch.equal(a, e.weight.detach())) for a, e in zip(before, m1.msg_encoder.embeddings)) == 32
     assert sum(e.weight.grad is not None for e in m1.msg_encoder.embeddings) == 32
+
+
+@pytest.mark.parametrize("distortion,loss_w", [("none", "bce"), ("brightness", "bce"), ("none", "mse")])
+def test_reference_trainer_train_step_equals_the_stock_operator_sequence(distortion, loss_w):
+    """trainer.reference_trainer_train_step -- what the drop-in directory binds as Trainer.train_step -- against the operator sequence the reference's
+    own method issues around model.render / model.msg_decoder (utils_wtmk_disen.py:579-646: clamp, distortion layer, layout change, normalisation,
+    decoder, element-wise MSE and its mean, loss_w at temperature 10, weighted sum), on a stand-in for the reference's Trainer object (the attributes
+    its method reads): same six return values, same gradients."""
+    import argparse
+    import types
+    from nerf_signature_amd import trainer
+    from nerf_signature_amd.distortion import DistortionLayer
+    bo, bd, co, cd, gt = _data(n_content=300)
+    data = {"watermark": {"rays_o_block": bo.cuda(), "rays_d_block": bd.cuda(), "images": torch.zeros(32, 6, 6, 3)},
+            "content": {"rays_o": co.cuda(), "rays_d": cd.cuda(), "images": gt.cuda()}}
+    msg = torch.from_numpy(np.random.RandomState(7).randint(0, 2, 32).astype(np.float32)).cuda()
+    opt = argparse.Namespace(dt_gamma=0, max_steps=1024, color_space="srgb", loss_w=loss_w, distortion=distortion, workspace="w", fp16=False)
+    results = []
+    for fused in (False, True):
+        torch.manual_seed(0)
+        m, _, _ = _model()
+        me = types.SimpleNamespace(model=m, opt=opt, lambda_w=0.005, lambda_i=1.0, distortion=distortion)
+        if fused:
+            out = trainer.reference_trainer_train_step(me, data, msg)
+            if distortion != "none":
+                draw = me._nsig_distortion_layer.param.clone()
+        else:
+            wm, ct = data["watermark"], data["content"]
+            img = m.render(wm["rays_o_block"], wm["rays_d_block"], msg, staged=False, bg_color=1, perturb=False, force_all_rays=True, **vars(opt))["image"]
+            pred = torch.clamp(img, min=0, max=1)
+            seen = pred
+            if distortion != "none":
+                layer = DistortionLayer(distortion)            # same seed as the method's own layer: same first draw
+                layer.draw(tuple(pred.shape), pred.device)
+                seen = layer(pred)
+                draw = layer.param.clone()
+            decoded = m.msg_decoder(m.normalization(seen.permute(0, 3, 1, 2)))
+            cpred = m.render(ct["rays_o"], ct["rays_d"], msg, staged=False, bg_color=1, perturb=False, force_all_rays=True, **vars(opt))["image"]
+            lossi = torch.nn.MSELoss(reduction="none")(cpred, ct["images"]).mean()
+            lossw = (trainer.loss_w_bce if loss_w == "bce" else trainer.loss_w_mse)(decoded, msg.unsqueeze(-1))
+            out = (pred, ct["images"], cpred, lossi, lossw, 0.005 * lossw + 1.0 * lossi)
+        out[5].backward()
+        bits = [int(v) for v in msg.cpu()]
+        G = m.msg_encoder.embeddings[2 * 0 + bits[0]].weight.grad.clone()
+        dgrad = torch.cat([p.grad.reshape(-1) for p in m.msg_decoder.parameters() if p.grad is not None])
+        results.append(([o.detach().clone() for o in out], G, dgrad, draw if distortion != "none" else None))
+    (o0, G0, d0, w0), (o1, G1, d1, w1) = results
+    if distortion != "none":
+        assert torch.equal(w0, w1)
+    for a, b in zip(o0[:3], o1[:3]):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=0, atol=1e-6)
+    for a, b in zip(o0[3:], o1[3:]):
+        np.testing.assert_allclose(float(b), float(a), rtol=2e-5, atol=1e-8)
+    assert float(G0.abs().max()) > 0 and float((G1 - G0).norm() / G0.norm()) < 2e-3
+    assert float((d1 - d0).norm() / d0.norm()) < 2e-3
+    with pytest.raises(UnboundLocalError):      # 4-channel block images without a background model: the reference's own failure (:585-590)
+        bad = dict(data, watermark=dict(data["watermark"], images=torch.zeros(32, 6, 6, 4)))
+        trainer.reference_trainer_train_step(types.SimpleNamespace(model=m, opt=opt, lambda_w=1.0, lambda_i=1.0, distortion="none"), bad, msg)

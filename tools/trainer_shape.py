@@ -29,11 +29,12 @@ ap.add_argument("--no-gc", action="store_true", help="diagnostics: Python's cycl
 ap.add_argument("--gc-freeze", action="store_true", help="gc.freeze() after the warm-up steps (what the drop-in model does at its first training render)")
 ap.add_argument("--phases", action="store_true", help="host wall time per phase of the loop body (perf_counter, no profiler)")
 ap.add_argument("--no-auto-fix", action="store_true")
-ap.add_argument("--fused-step", action="store_true", help="this repo's trainer.train_step (clamp / normalisation / losses fused into its kernels) instead of the operator sequence "
-                                                          "the reference's own Trainer.train_step issues around model.render and model.msg_decoder")
+ap.add_argument("--reference-operators", action="store_true", help="NERFSIG_DROPIN_TRAIN_STEP=0: the operator sequence the reference's own Trainer.train_step issues around model.render "
+                                                                   "and model.msg_decoder, instead of the method the drop-in directory binds in its place (this repo's fused train_step)")
 ap.add_argument("--distortion", default="none")
-ap.add_argument("--both", action="store_true", help="after the timed windows, time one more window with the other train_step (see --fused-step) and report it next to the first")
+ap.add_argument("--both", action="store_true", help="after the timed windows, time one more window with the other train_step (see --reference-operators) and report it next to the first")
 args = ap.parse_args()
+args.fused_step = not args.reference_operators
 
 from nerf_signature_amd import quality, synthetic, trainer
 
@@ -90,6 +91,9 @@ def reference_shaped_train_step(data, message):
     return pred_rgb, ct["images"], content_rgb, lossi, lossw, loss
 
 
+import types
+
+me = types.SimpleNamespace(model=model, opt=argparse.Namespace(**opt_ns, color_space="srgb", loss_w="bce"), lambda_w=0.005, lambda_i=1.0, distortion=args.distortion)      # (what the method reads of the reference's Trainer)
 PH = {}
 
 
@@ -109,8 +113,8 @@ def step(k):
     optimizer.zero_grad()
     t = mark("zero_grad", t)
     with torch.autocast("cuda", enabled=not args.no_fp16):
-        if args.fused_step:
-            out = trainer.train_step(model, data, message, opt_ns, lambda_w=0.005, lambda_i=1.0, distortion=layer)
+        if args.fused_step:      # what the drop-in directory binds as Trainer.train_step (dropin/nerf/utils_wtmk_disen.py)
+            out = trainer.reference_trainer_train_step(me, data, message)
         else:
             out = reference_shaped_train_step(data, message)
     t = mark("train_step (forward)", t)
@@ -178,9 +182,10 @@ if args.phases:
     n = args.steps * len(windows)
     print("host wall per step by phase (ms; includes waiting for the GPU where a phase synchronises):", {k: round(v / n * 1e3, 3) for k, v in PH.items()}, file=sys.stderr)
 os.dup2(real_stdout, 1)
-print(json.dumps({"what": "reference Trainer loop body (utils_wtmk_disen.py:1164-1190) and train_step operator sequence (:579-646) around this repo's model: eager, autocast(fp16) + "
-                          "GradScaler, plain torch.optim.Adam, loader-style rays per step, three .item() reads per step; NOT the headline path",
-                  "train_step": "this repo's fused trainer.train_step" if args.fused_step else "the reference's operator sequence around model.render / model.msg_decoder (stock clamp, normalisation, MSE, BCE)",
+print(json.dumps({"what": "what the UNCHANGED reference CLI runs on top of the drop-in directory: the reference Trainer's loop body (utils_wtmk_disen.py:1164-1190) -- eager, autocast(fp16) + "
+                          "GradScaler, plain torch.optim.Adam, loader-style rays per step, three .item() reads per step -- around this repo's model; NOT the headline path",
+                  "train_step": "Trainer.train_step as the drop-in directory binds it (dropin/nerf/utils_wtmk_disen.py -> trainer.reference_trainer_train_step: this repo's fused step)" if args.fused_step
+                  else "NERFSIG_DROPIN_TRAIN_STEP=0: the reference's own operator sequence around model.render / model.msg_decoder (stock clamp, normalisation, MSE, BCE)",
                   "ms_per_step": el / args.steps * 1e3, "ms_per_step_windows": [round(w, 4) for w in windows], "content_rays_per_s": 4096 * args.steps / el, "steps": args.steps, "fp16": not args.no_fp16,
-                  **({} if other is None else {("ms_per_step_reference_operator_sequence" if args.fused_step else "ms_per_step_with_this_repos_fused_train_step"): round(other, 4)}),
+                  **({} if other is None else {("ms_per_step_with_the_references_own_train_step_operators" if args.fused_step else "ms_per_step_with_the_bound_train_step"): round(other, 4)}),
                   "fix_rays": bool(args.fix_rays), "shared_gradient_step": bool(model.shared_gradient_step), "auto_fix_rays": bool(model.auto_fix_rays), "loss": last[0] if last else None, "grad_scale": float(scaler.get_scale()) if not args.no_fp16 else None}), flush=True)
