@@ -1,0 +1,192 @@
+"""The block render + decoder of an EAGER training step -- forward and backward -- as two hipGraphs.
+
+Under somebody else's training loop (the reference Trainer's, utils_wtmk_disen.py:1164-1190, on top of the drop-in modules) a step is host-bound:
+~100 launches issued one by one from Python.  The half of it that belongs to the watermark blocks has static shapes: the block rays are one pair of
+tensors per dataset (provider_wtmk.py:442-494; kept samples + base-level planes after their second sighting, NeRFNetwork.fix_rays), the decoder's
+input is [D, bh, bw, 3] every step, and the only thing a step changes in it is the CONTENT of buffers with fixed addresses -- the pre-summed
+codebook of the step's message (computed eagerly in front of the replay), the codebook level's plane, the decoder's parameters.  So those
+~30 launches (codebook plane, both MLPs, compositing, the decoder chain; and their backward: decoder chain, compositing, MLP backward, scatter into
+the shared gradient, the decoder's parameter gradients) are captured once and replayed as two graph launches, in the manner of
+torch.cuda.make_graphed_callables: the forward capture builds the autograd graph, the backward capture runs torch.autograd.grad over it.
+The content render (a new pose and new pixels every step: its sample count varies) stays eager.
+
+Same kernels, same arguments, same order on the same stream as the eager calls they replace: results are bit-identical
+(tests/test_gpu_amp_ckpt.py::test_block_graph_*).  Anything the capture does not cover makes run() return None and the caller takes the eager route:
+a distortion layer, a model without the shared-gradient sink, rays that are not (yet) kept, more than one rank, an outer capture.
+NERFSIG_DROPIN_BLOCK_GRAPH=0 turns it off."""
+import os
+
+import torch
+
+from . import fieldops as fo
+from . import hidden_models
+from .hidden_models import normalize_img
+
+
+class _Replay(torch.autograd.Function):
+    """One autograd node for both captured halves.  Inputs: one selected table (so that the node is recorded even with a frozen decoder; its
+    gradient travels through the shared-gradient sink, not through autograd) and the decoder's parameters."""
+
+    @staticmethod
+    def forward(ctx, graph, selected, anchor, *params):
+        graph.forward_graph.replay()
+        graph.generation += 1
+        ctx.graph, ctx.generation, ctx.selected, ctx.n = graph, graph.generation, selected, len(params)
+        decoded, pred = graph.decoded.clone(), graph.pred.clone()      # (static buffers: the next replay overwrites them)
+        ctx.mark_non_differentiable(pred)
+        ctx.set_materialize_grads(False)
+        return decoded, pred
+
+    @staticmethod
+    def backward(ctx, grad_decoded, _=None):
+        g = ctx.graph
+        if grad_decoded is None:
+            return (None,) * (3 + ctx.n)
+        if ctx.generation != g.generation:
+            raise RuntimeError("BlockDecodeGraph: backward of a forward pass whose saved activations a later forward has overwritten (the captured block render "
+                               "keeps ONE set of activations: run each step's backward before the next step's forward, or set NERFSIG_DROPIN_BLOCK_GRAPH=0)")
+        if g.backward_of == ctx.generation:
+            raise RuntimeError("BlockDecodeGraph: second backward through the same captured forward pass (retain_graph is not supported: NERFSIG_DROPIN_BLOCK_GRAPH=0)")
+        g.backward_of = ctx.generation
+        g.sink.begin_accumulation(ctx.selected)           # (Python state of the shared gradient: what _FieldFunction.backward does in front of its scatter)
+        g.seed.copy_(grad_decoded.reshape(g.seed.shape))
+        g.backward_graph.replay()
+        flat = g.flat.clone()
+        grads, off = [], 0
+        for p, wanted in zip(g.params, ctx.needs_input_grad[3:]):
+            n = p.numel()
+            grads.append(flat[off:off + n].view_as(p) if wanted else None)
+            off += n
+        return (None, None, None, *grads)
+
+
+class BlockDecodeGraph:
+    def __init__(self, eager_steps=3):
+        self.eager_steps = int(eager_steps)      # steps seen with the same key before capturing (kept samples exist from the second sighting on)
+        self.key, self.seen = None, 0
+        self.forward_graph = self.backward_graph = None
+        self.failed = None
+        self.generation, self.backward_of = 0, -1
+        self.captures = 0
+
+    # ------------------------------------------------------------------ what must hold for the captured launches to be the eager ones
+
+    def _record(self, model, rays_o, rays_d):
+        marched = getattr(model, "_marched", None)
+        if not marched:
+            return None
+        _, o, d = model._flatten_rays(rays_o, rays_d)
+        rec = marched.get(model._rays_key(o, d))
+        if rec is None or rec.get("fixed") is None or rec["grid_key"] != model.grid_key():
+            return None
+        if rec["fixed"].key != fo.FixedPoints._tables_key(model.encoder.tables()):
+            return None                                     # a base table moved: the eager route refreshes the kept planes in place
+        return rec
+
+    def _key(self, model, rays_o, rays_d, rec, fused, kw, sink):
+        sp, cp = model.sigma_net.params, model.color_net.params
+        return (id(model), id(rays_o), id(rays_d), rays_o._version, rays_d._version, tuple(rays_o.shape), id(rec), id(rec["fixed"]), rec["xyzs"].data_ptr(),
+                rec["capacity"], rec["fixed"].planes.data_ptr(), tuple(p.data_ptr() for p in fused[1]), tuple(tuple(p.shape) for p in fused[1]),
+                tuple(bool(p.requires_grad) for p in fused[1]), float(fused[0]), sp.data_ptr(), sp._version, cp.data_ptr(), cp._version,
+                model._packed().data_ptr(), id(sink), sink.G.data_ptr(),
+                None if model._presum_cache is None else model._presum_cache[1].data_ptr(),
+                float(kw.get("dt_gamma", 0)), int(kw.get("max_steps", 1024)), float(kw.get("T_thresh", 1e-4)), int(fo.nv.fn("mlp_get_precision")()),
+                float(model.density_scale), float(model.bound))
+
+    def run(self, model, rays_o, rays_d, message, render_kwargs):
+        """(decoded [D, 1], clamped blocks [D, bh, bw, 3]) of this step through the captured launches, or None: take the eager route."""
+        if self.failed is not None or os.environ.get("NERFSIG_DROPIN_BLOCK_GRAPH", "1") == "0":
+            return None
+        if not (torch.is_tensor(message) and rays_o.is_cuda and rays_o.dim() == 4 and model.training and torch.is_grad_enabled() and model.cuda_ray
+                and not torch.cuda.is_current_stream_capturing() and model.normalization is normalize_img and model.grad_sink is None
+                and getattr(model, "shared_gradient_step", False) and not getattr(model, "device_select", False)
+                and getattr(model, "point_capacity", None) is None and not fo_data_parallel()):
+            return None
+        rec = self._record(model, rays_o, rays_d)
+        if rec is None:
+            self.seen = 0
+            return None
+        D, H, W = rays_o.shape[0], rays_o.shape[1], rays_o.shape[2]
+        fused = model.msg_decoder._fused_params(D, 3, H, W, rays_o) if hasattr(model.msg_decoder, "_fused_params") and rays_o.dtype == torch.float32 else None
+        sink = model._shared_sink
+        if fused is None or sink is None or sink.G.device != rays_o.device or message.numel() != model.message_dim:
+            return None
+        kw = dict(render_kwargs)
+        key = self._key(model, rays_o, rays_d, rec, fused, kw, sink)
+        if key != self.key:
+            self.key, self.seen = key, 0
+            self.forward_graph = self.backward_graph = None
+        selected, bits, _ = model._select(message)          # this step's pre-summed codebook, into the buffer the captured launches read (one read of the bits, as eager)
+        anchor = next((t for t in selected if t.requires_grad), None)
+        if anchor is None:
+            return None
+        if self.forward_graph is None:
+            self.seen += 1
+            if self.seen <= self.eager_steps:
+                return None
+            try:
+                self._capture(model, rays_o, rays_d, message, kw, fused, sink, selected)
+            except Exception as e:      # noqa: BLE001 -- whatever it was: never again in this process, and say so
+                self.failed = repr(e)
+                self.forward_graph = self.backward_graph = None
+                torch.cuda.synchronize()
+                import warnings
+                warnings.warn(f"BlockDecodeGraph: capture failed ({self.failed}); the eager route is used from here on")
+                return None
+        self.sink = sink
+        self.params = list(fused[1])
+        return _Replay.apply(self, list(selected), anchor, *self.params)
+
+    # ------------------------------------------------------------------ capture
+
+    def _capture(self, model, rays_o, rays_d, message, kw, fused, sink, selected):
+        kw = dict(kw)
+        kw.update(staged=False, bg_color=1, perturb=False, force_all_rays=True)
+        params = list(fused[1])
+        n_flat = sum(p.numel() for p in params)
+        dev = rays_o.device
+        self.params = params
+        self.flat = torch.empty(n_flat, dtype=torch.float32, device=dev)           # the decoder's parameter gradients of the last backward replay
+        self.seed = torch.empty(rays_o.shape[0], 1, dtype=torch.float32, device=dev)  # d loss / d decoded, copied in before the backward replay
+        torch.cuda.synchronize()
+        model._presum_event = None                 # (recorded outside the capture: the captured render must not wait on it)
+        fo.forget_plan_events()
+        pending_before = sink.pending()
+        self.forward_graph, self.backward_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        if getattr(self, "_stream", None) is None:
+            self._stream = torch.cuda.Stream()
+        stream = self._stream
+        stream.wait_stream(torch.cuda.current_stream())
+        anchor = next(t for t in selected if t.requires_grad)
+        with torch.enable_grad(), torch.cuda.stream(stream):
+            # The decoder's parameters enter the captured passes through ALIASES (same storage, new autograd leaves made on the capture stream): the
+            # gradient accumulators of the real Parameters were created by the eager steps on the caller's stream -- usually the default stream -- and
+            # autograd synchronises a leaf's accumulator stream with the producer of its gradient: that would pull the default stream into the capture.
+            aliases = [p.detach().requires_grad_(p.requires_grad) for p in params]
+            self.forward_graph.capture_begin(capture_error_mode="thread_local")
+            try:
+                image = model.render(rays_o, rays_d, message, **kw)["image"]
+                decoded, pred = hidden_models._FusedDecoder.apply(image, fused[0], True, None, None, *aliases)
+            finally:
+                self.forward_graph.capture_end()
+            if not pending_before:
+                sink.begin_accumulation(list(selected))      # so that the captured _FieldFunction.backward finds the accumulation open and records no zero-fill
+            hidden_models.set_grad_arena(self.flat)
+            self.backward_graph.capture_begin(pool=self.forward_graph.pool(), capture_error_mode="thread_local")
+            try:
+                torch.autograd.grad([decoded], [anchor] + [a for a in aliases if a.requires_grad], [self.seed], allow_unused=True)
+            finally:
+                self.backward_graph.capture_end()
+                hidden_models.set_grad_arena(None)
+                if not pending_before:
+                    sink.consumed()
+        torch.cuda.current_stream().wait_stream(stream)
+        fo.forget_plan_events()
+        model._presum_event = None
+        self.decoded, self.pred = decoded.detach(), pred.detach()
+        self.captures += 1
+
+
+def fo_data_parallel():
+    from .network import _data_parallel
+    return _data_parallel()

@@ -121,7 +121,7 @@ def srgb_to_linear(x):
 
 
 def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce, side_stream=None, presum_first=False,
-               presum_adopt=False, color_space="srgb", blocks_first=False, content_backward_now=None, distortion=None, defer_loss_values=False):
+               presum_adopt=False, color_space="srgb", blocks_first=False, content_backward_now=None, distortion=None, defer_loss_values=False, block_graph=None):
     """data = {'watermark': {'rays_o_block', 'rays_d_block'}, 'content': {'rays_o', 'rays_d', 'images'}}.
     Returns (pred_rgb, gt_rgb, content_pred_rgb, lossi, lossw, loss) like the reference.
 
@@ -131,6 +131,8 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
     the step (GraphedWatermarkLoop does); the returned tensors are filled then.
     distortion: the reference's `--distortion` (utils_wtmk_disen.py:551-577,594): a name (none | noise | rotation | scaling | blurring |
     brightness; this call then draws the step's random parameters) or a distortion.DistortionLayer whose owner has drawn them (the loops).
+    block_graph: a blockgraph.BlockDecodeGraph (eager callers with constant block rays: the drop-in Trainer.train_step) -- the block render and the
+    decoder, forward and backward, replayed as two captured graphs once the rays are kept; it declines (and the eager launches run) whenever it does not apply.
 
     side_stream: a torch.cuda.Stream on which the content render is issued.  It depends on nothing the block render or the
     decoder produce, and both chains are sequences of small latency-bound launches, so they overlap (forward and -- autograd
@@ -157,7 +159,15 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
                 content_pred_rgb = model.render(content["rays_o"], content["rays_d"], message, **kw)["image"]
             content_pred_rgb.record_stream(main)
     block_o, block_d, shard = local_blocks(wm)
-    outputs = model.render(block_o, block_d, message, **kw)
+    graphed = None
+    if block_graph is not None and main is None and shard is None and not presum_adopt and content["rays_o"].is_cuda and model.training and torch.is_grad_enabled() \
+            and hasattr(model, "premarch") and getattr(model, "point_capacity", None) is None and not torch.cuda.is_current_stream_capturing() \
+            and os.environ.get("NERFSIG_DROPIN_PREMARCH", "1") != "0":
+        # the content render's march and its one host read, in front of the block render: the read then waits for the march alone
+        model.premarch(content["rays_o"], content["rays_d"], kw.get("dt_gamma", 0), kw.get("max_steps", 1024))
+    if block_graph is not None and main is None and shard is None and distortion in (None, "none") and not presum_adopt:
+        graphed = block_graph.run(model, block_o, block_d, message, kw)
+    outputs = model.render(block_o, block_d, message, **kw) if graphed is None else None
     content_done = early_seed = None
     deferred = False
     new_segment = False       # (a collective in front of the decoder ended the running capture segment: the side stream has to be forked again)
@@ -180,7 +190,7 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
         content_pred_rgb.record_stream(main)
     if main is not None:
         fo.flush_plans()          # the block render's scatter plan: on the plan stream, behind the content render
-    image = outputs["image"]
+    image = outputs["image"] if graphed is None else None
     if shard is not None:
         # the decoder's BatchNorm needs all D blocks (batch statistics, hidden_models.py:26): all-gather the rendered blocks, decode
         # them on every rank; the backward keeps this rank's rows.  Where the collective ends a captured segment both streams meet first
@@ -195,7 +205,9 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
         if distortion is not None:
             distortion.draw(tuple(image.shape), image.device)
     fused_seed = keys_dev = None
-    if model.normalization is normalize_img and hasattr(model.msg_decoder, "decode_rendered"):
+    if graphed is not None:
+        decoded, pred_rgb = graphed
+    elif model.normalization is normalize_img and hasattr(model.msg_decoder, "decode_rendered"):
         from .hidden_models import _FusedDecoder
         _FusedDecoder.seed = None       # (only a seed written by THIS call's decoder pass may be used below)
         bce = None
@@ -286,8 +298,12 @@ def reference_trainer_train_step(self, data, message):
     name = getattr(self.opt, "loss_w", "bce")
     if name not in ("bce", "mse"):
         raise NotImplementedError
+    graph = self.__dict__.get("_nsig_block_graph")
+    if graph is None:
+        from .blockgraph import BlockDecodeGraph
+        graph = self.__dict__["_nsig_block_graph"] = BlockDecodeGraph()
     return train_step(self.model, data, message, vars(self.opt), lambda_w=self.lambda_w, lambda_i=self.lambda_i, loss_w=loss_w_bce if name == "bce" else loss_w_mse,
-                      color_space=getattr(self.opt, "color_space", "srgb"), distortion=layer)
+                      color_space=getattr(self.opt, "color_space", "srgb"), distortion=layer, block_graph=graph)
 
 
 def eval_step(model, data, message, render_kwargs, render_whole=True, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce, color_space="srgb", distortion=None):

@@ -364,3 +364,73 @@ def test_reference_trainer_train_step_equals_the_stock_operator_sequence(distort
     with pytest.raises(UnboundLocalError):      # 4-channel block images without a background model: the reference's own failure (:585-590)
         bad = dict(data, watermark=dict(data["watermark"], images=torch.zeros(32, 6, 6, 4)))
         trainer.reference_trainer_train_step(types.SimpleNamespace(model=m, opt=opt, lambda_w=1.0, lambda_i=1.0, distortion="none"), bad, msg)
+
+
+def test_block_graph_replays_the_eager_block_render_and_decoder(monkeypatch):
+    """blockgraph.BlockDecodeGraph under the reference Trainer's loop shape (zero_grad / autocast train_step / GradScaler / torch.optim.Adam, a new device-side
+    message and new content rays every step): the bound Trainer.train_step with the block render + decoder replayed from two captured graphs against the same
+    loop with NERFSIG_DROPIN_BLOCK_GRAPH=0 -- same losses step by step, same parameters after 10 steps, one capture, replays from the fifth step on (two sightings
+    to keep the rays, three eager steps on the kept route), a step GradScaler skips skipped on both sides; then the guards: backward of a stale forward, a
+    second backward, and new block rays (the graph steps aside, the eager route runs, a new capture follows)."""
+    import argparse
+    import types
+    from nerf_signature_amd import trainer
+    bo, bd, _, _, _ = _data(n_content=300)
+    block_o, block_d = bo.cuda(), bd.cuda()
+    batches = []
+    for k in range(10):
+        _, _, co, cd, gt = _data(n_content=300, seed=10 + k)
+        batches.append({"rays_o": co.cuda(), "rays_d": cd.cuda(), "images": gt.cuda()})
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    msgs = [torch.randint(0, 2, (32,), generator=gen, device="cuda").float() for _ in range(10)]
+    opt_ns = argparse.Namespace(dt_gamma=0, max_steps=1024, color_space="srgb", loss_w="bce", distortion="none", workspace="w", fp16=True)
+    runs = []
+    for graph_on in (False, True):
+        monkeypatch.setenv("NERFSIG_DROPIN_BLOCK_GRAPH", "1" if graph_on else "0")
+        torch.manual_seed(0)
+        m, _, _ = _model()
+        m.shared_gradient_step = m.auto_fix_rays = True
+        me = types.SimpleNamespace(model=m, opt=opt_ns, lambda_w=0.005, lambda_i=1.0, distortion="none")
+        opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+        wm = {"rays_o_block": block_o, "rays_d_block": block_d, "images": torch.zeros(32, 6, 6, 3)}
+        losses = []
+        for k in range(10):
+            opt.zero_grad()
+            with torch.autocast("cuda"):
+                out = trainer.reference_trainer_train_step(me, {"watermark": wm, "content": batches[k]}, msgs[k])
+            scaler.scale(out[5] * (float("inf") if k == 7 else 1.0)).backward()
+            scaler.step(opt)
+            scaler.update()
+            losses.append([float(v.detach()) for v in out[3:6]] + [float(out[0].sum())])
+        torch.cuda.synchronize()
+        runs.append((np.array(losses), [e.weight.detach().clone() for e in m.msg_encoder.embeddings],
+                     torch.cat([p.detach().reshape(-1) for p in m.msg_decoder.parameters()]), scaler.get_scale(), me, m, opt))
+    (l0, t0, d0, s0, me0, _, _), (l1, t1, d1, s1, me1, m1, opt1) = runs
+    g = me1._nsig_block_graph
+    assert me0._nsig_block_graph.captures == 0 and g.captures == 1 and g.failed is None and g.generation == 10 - 5 and s0 == s1 == 512.0
+    # (run-to-run: the order of the float atomics in G; the eager route also seeds the decoder's backward from its head kernel, the graph from the loss kernel)
+    np.testing.assert_allclose(l1, l0, rtol=2e-5, atol=1e-7)
+    moved = sum(float((a - torch.from_numpy(cf.table(100 + l, scale=0.05)).cuda()).pow(2).sum()) for l, a in enumerate(t0)) ** 0.5
+    diff = sum(float((a - b).pow(2).sum()) for a, b in zip(t0, t1)) ** 0.5
+    assert moved > 0 and diff / moved < 0.05 and float((d0 - d1).norm() / d0.norm()) < 0.05
+    # guards
+    monkeypatch.setenv("NERFSIG_DROPIN_BLOCK_GRAPH", "1")
+    data = {"watermark": {"rays_o_block": block_o, "rays_d_block": block_d, "images": torch.zeros(32, 6, 6, 3)}, "content": batches[0]}
+    opt1.zero_grad()
+    first = trainer.reference_trainer_train_step(me1, data, msgs[0])
+    second = trainer.reference_trainer_train_step(me1, data, msgs[1])
+    with pytest.raises(RuntimeError, match="later forward"):
+        first[5].backward()
+    second[5].backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second backward"):
+        second[5].backward()
+    opt1.zero_grad()
+    shifted = {"watermark": {"rays_o_block": block_o.clone(), "rays_d_block": block_d.clone(), "images": torch.zeros(32, 6, 6, 3)}, "content": batches[0]}
+    before = g.generation
+    for k in range(6):      # new ray tensors: two sightings + three eager steps, then a second capture
+        opt1.zero_grad()
+        out = trainer.reference_trainer_train_step(me1, shifted, msgs[k])
+        out[5].backward()
+        opt1.step()
+    assert g.captures == 2 and g.generation == before + 1 and np.isfinite(float(out[5].detach()))

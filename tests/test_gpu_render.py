@@ -1092,3 +1092,47 @@ def test_eval_loop_on_device_equals_the_host_driven_loop(case, monkeypatch):
     for (na0, ns0, ids0), (na1, ns1, ids1) in zip(rounds_host, live):
         assert (na0, ns0) == (na1, ns1) and torch.equal(ids0, ids1)
     assert float(ws.max()) <= 1.0 + 1e-5 and bool(torch.isfinite(ws).all())
+
+
+def test_premarch_hands_the_same_samples_to_the_next_render_once():
+    """NeRFRenderer.premarch: the training march of a ray pair issued ahead of its render (trainer.train_step does it for the content rays of an eager step, in
+    front of the block render).  The render that follows with the same tensor objects uses those samples -- same image, depth and gradient bit for bit, no
+    second march (the counter ring advances once) -- exactly once; other tensors, an in-place change of the rays, other march arguments or a changed
+    grid march again as usual."""
+    m, _, _ = _model()
+    _, _, co, cd, _ = _data(n_content=300)
+    o, d = co.cuda(), cd.cuda()
+    msg = torch.from_numpy(cf.messages(32)[2]).cuda()
+    kw = dict(staged=False, bg_color=1, perturb=False, force_all_rays=True, dt_gamma=0, max_steps=1024)
+
+    def render(oo, dd):
+        m.zero_grad()
+        out = m.render(oo, dd, msg, **kw)
+        (out["image"] * torch.linspace(0.5, 1.5, out["image"].numel(), device="cuda").view_as(out["image"])).sum().backward()
+        bits = [int(v) for v in msg.cpu()]
+        return out["image"].detach().clone(), out["depth"].detach().clone(), m.msg_encoder.embeddings[bits[0]].weight.grad.clone()
+
+    plain = render(o, d)
+    step0 = m.local_step
+    m.premarch(o, d, 0, 1024)
+    assert m._premarched is not None and m.local_step == step0 + 1
+    ahead = render(o, d)
+    assert m._premarched is None and m.local_step == step0 + 1            # used, and no second march
+    for a, b in zip(plain[:2], ahead[:2]):      # (rays that miss the box have depth 0 / 0, as in the reference)
+        assert torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0))
+    assert float((plain[2] - ahead[2]).abs().max()) <= 1e-6 * float(plain[2].abs().max())      # (float atomics of the small-launch scatter)
+    render(o, d)
+    assert m.local_step == step0 + 2                                         # once only
+    m.premarch(o, d, 0, 1024)
+    o2 = o.clone()
+    other = render(o2, d)                                                    # other tensor objects: marches itself, the stash is dropped
+    assert m._premarched is None and torch.equal(other[0], plain[0])
+    m.premarch(o, d, 0, 1024)
+    o.add_(0.0)                                                              # an in-place write bumps the version
+    before = m.local_step
+    render(o, d)
+    assert m.local_step == before + 1
+    m.premarch(o, d, 0, 1024)
+    before = m.local_step
+    m.render(o, d, msg, **dict(kw, max_steps=512))
+    assert m.local_step == before + 1

@@ -188,4 +188,5 @@ print(json.dumps({"what": "what the UNCHANGED reference CLI runs on top of the d
                   else "NERFSIG_DROPIN_TRAIN_STEP=0: the reference's own operator sequence around model.render / model.msg_decoder (stock clamp, normalisation, MSE, BCE)",
                   "ms_per_step": el / args.steps * 1e3, "ms_per_step_windows": [round(w, 4) for w in windows], "content_rays_per_s": 4096 * args.steps / el, "steps": args.steps, "fp16": not args.no_fp16,
                   **({} if other is None else {("ms_per_step_with_the_references_own_train_step_operators" if args.fused_step else "ms_per_step_with_the_bound_train_step"): round(other, 4)}),
+                  "block_graph": (lambda g: None if g is None else {"captures": g.captures, "replays": g.generation, "failed": g.failed})(me.__dict__.get("_nsig_block_graph")),
                   "fix_rays": bool(args.fix_rays), "shared_gradient_step": bool(model.shared_gradient_step), "auto_fix_rays": bool(model.auto_fix_rays), "loss": last[0] if last else None, "grad_scale": float(scaler.get_scale()) if not args.no_fp16 else None}), flush=True)
