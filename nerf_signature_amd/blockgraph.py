@@ -12,7 +12,8 @@ The content render (a new pose and new pixels every step: its sample count varie
 
 Same kernels, same arguments, same order on the same stream as the eager calls they replace: results are bit-identical
 (tests/test_gpu_amp_ckpt.py::test_block_graph_*).  Anything the capture does not cover makes run() return None and the caller takes the eager route:
-a distortion layer, a model without the shared-gradient sink, rays that are not (yet) kept, more than one rank, an outer capture.
+the `scaling` distortion (a new decoder input width every step), a model without the shared-gradient sink, rays that are not (yet) kept, more than one
+rank, an outer capture.
 NERFSIG_DROPIN_BLOCK_GRAPH=0 turns it off."""
 import os
 
@@ -93,9 +94,13 @@ class BlockDecodeGraph:
                 float(kw.get("dt_gamma", 0)), int(kw.get("max_steps", 1024)), float(kw.get("T_thresh", 1e-4)), int(fo.nv.fn("mlp_get_precision")()),
                 float(model.density_scale), float(model.bound))
 
-    def run(self, model, rays_o, rays_d, message, render_kwargs):
-        """(decoded [D, 1], clamped blocks [D, bh, bw, 3]) of this step through the captured launches, or None: take the eager route."""
+    def run(self, model, rays_o, rays_d, message, render_kwargs, distortion=None):
+        """(decoded [D, 1], clamped blocks [D, bh, bw, 3]) of this step through the captured launches, or None: take the eager route.
+        distortion: None or a distortion.DistortionLayer whose owner has drawn this step's parameters into its (static) device buffers; every kind but
+        `scaling` (which changes the decoder's input width from step to step) is part of the captured forward."""
         if self.failed is not None or os.environ.get("NERFSIG_DROPIN_BLOCK_GRAPH", "1") == "0":
+            return None
+        if distortion is not None and (distortion.name == "scaling" or distortion.param is None or not distortion.param.is_cuda):
             return None
         if not (torch.is_tensor(message) and rays_o.is_cuda and rays_o.dim() == 4 and model.training and torch.is_grad_enabled() and model.cuda_ray
                 and not torch.cuda.is_current_stream_capturing() and model.normalization is normalize_img and model.grad_sink is None
@@ -112,7 +117,8 @@ class BlockDecodeGraph:
         if fused is None or sink is None or sink.G.device != rays_o.device or message.numel() != model.message_dim:
             return None
         kw = dict(render_kwargs)
-        key = self._key(model, rays_o, rays_d, rec, fused, kw, sink)
+        key = self._key(model, rays_o, rays_d, rec, fused, kw, sink) + (
+            (None,) if distortion is None else (distortion.name, distortion.param.data_ptr(), None if distortion.noise is None else distortion.noise.data_ptr()))
         if key != self.key:
             self.key, self.seen = key, 0
             self.forward_graph = self.backward_graph = None
@@ -125,7 +131,7 @@ class BlockDecodeGraph:
             if self.seen <= self.eager_steps:
                 return None
             try:
-                self._capture(model, rays_o, rays_d, message, kw, fused, sink, selected)
+                self._capture(model, rays_o, rays_d, message, kw, fused, sink, selected, distortion)
             except Exception as e:      # noqa: BLE001 -- whatever it was: never again in this process, and say so
                 self.failed = repr(e)
                 self.forward_graph = self.backward_graph = None
@@ -139,7 +145,7 @@ class BlockDecodeGraph:
 
     # ------------------------------------------------------------------ capture
 
-    def _capture(self, model, rays_o, rays_d, message, kw, fused, sink, selected):
+    def _capture(self, model, rays_o, rays_d, message, kw, fused, sink, selected, distortion=None):
         kw = dict(kw)
         kw.update(staged=False, bg_color=1, perturb=False, force_all_rays=True)
         params = list(fused[1])
@@ -166,7 +172,12 @@ class BlockDecodeGraph:
             self.forward_graph.capture_begin(capture_error_mode="thread_local")
             try:
                 image = model.render(rays_o, rays_d, message, **kw)["image"]
-                decoded, pred = hidden_models._FusedDecoder.apply(image, fused[0], True, None, None, *aliases)
+                if distortion is not None and distortion.geometric:      # (hidden_models.decode_rendered's two routes, with the aliases for parameters)
+                    from .distortion import _DistortGeometry
+                    resampled, pred = _DistortGeometry.apply(image, distortion.kind, distortion.param, image.shape[2])
+                    decoded = hidden_models._FusedDecoder.apply(resampled, fused[0], True, None, None, *aliases)[0]
+                else:
+                    decoded, pred = hidden_models._FusedDecoder.apply(image, fused[0], True, distortion, None, *aliases)
             finally:
                 self.forward_graph.capture_end()
             if not pending_before:

@@ -165,8 +165,8 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
             and os.environ.get("NERFSIG_DROPIN_PREMARCH", "1") != "0":
         # the content render's march and its one host read, in front of the block render: the read then waits for the march alone
         model.premarch(content["rays_o"], content["rays_d"], kw.get("dt_gamma", 0), kw.get("max_steps", 1024))
-    if block_graph is not None and main is None and shard is None and distortion in (None, "none") and not presum_adopt:
-        graphed = block_graph.run(model, block_o, block_d, message, kw)
+    if block_graph is not None and main is None and shard is None and not presum_adopt and (distortion is None or isinstance(distortion, DistortionLayer)):
+        graphed = block_graph.run(model, block_o, block_d, message, kw, distortion)
     outputs = model.render(block_o, block_d, message, **kw) if graphed is None else None
     content_done = early_seed = None
     deferred = False

@@ -366,6 +366,46 @@ def test_reference_trainer_train_step_equals_the_stock_operator_sequence(distort
         trainer.reference_trainer_train_step(types.SimpleNamespace(model=m, opt=opt, lambda_w=1.0, lambda_i=1.0, distortion="none"), bad, msg)
 
 
+@pytest.mark.parametrize("distortion", ["brightness", "noise", "rotation", "scaling"])
+def test_block_graph_with_a_distortion_layer(monkeypatch, distortion):
+    """The captured block render + decoder with the step's distortion layer inside (its draws land in static device buffers before every replay): the same
+    loop with and without the graphs, same draws (the layer's generators are seeded alike) -> same losses step by step.  `scaling` changes the decoder's
+    input width every step: the graph steps aside (no capture) and the eager launches run."""
+    import argparse
+    import types
+    from nerf_signature_amd import trainer
+    bo, bd, _, _, _ = _data(n_content=300)
+    wm = {"rays_o_block": bo.cuda(), "rays_d_block": bd.cuda(), "images": torch.zeros(32, 6, 6, 3)}
+    batches = []
+    for k in range(8):
+        _, _, co, cd, gt = _data(n_content=300, seed=30 + k)
+        batches.append({"rays_o": co.cuda(), "rays_d": cd.cuda(), "images": gt.cuda()})
+    gen = torch.Generator(device="cuda").manual_seed(6)
+    msgs = [torch.randint(0, 2, (32,), generator=gen, device="cuda").float() for _ in range(8)]
+    opt_ns = argparse.Namespace(dt_gamma=0, max_steps=1024, color_space="srgb", loss_w="bce", distortion=distortion, workspace="w", fp16=False)
+    runs = []
+    for graph_on in (False, True):
+        monkeypatch.setenv("NERFSIG_DROPIN_BLOCK_GRAPH", "1" if graph_on else "0")
+        torch.manual_seed(0)
+        m, _, _ = _model()
+        m.shared_gradient_step = m.auto_fix_rays = True
+        me = types.SimpleNamespace(model=m, opt=opt_ns, lambda_w=0.005, lambda_i=1.0, distortion=distortion)
+        opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+        losses = []
+        for k in range(8):
+            opt.zero_grad()
+            out = trainer.reference_trainer_train_step(me, {"watermark": wm, "content": batches[k]}, msgs[k])
+            out[5].backward()
+            opt.step()
+            losses.append([float(v.detach()) for v in out[3:6]])
+        runs.append((np.array(losses), me))
+    (l0, _), (l1, me1) = runs
+    g = me1._nsig_block_graph
+    assert g.failed is None and (g.captures, g.generation) == ((0, 0) if distortion == "scaling" else (1, 3))
+    np.testing.assert_allclose(l1, l0, rtol=5e-5, atol=1e-7)
+    assert len({round(float(v), 7) for v in l1[:, 1]}) == 8      # a new draw (and a new message) every step: the watermark loss never repeats
+
+
 def test_block_graph_replays_the_eager_block_render_and_decoder(monkeypatch):
     """blockgraph.BlockDecodeGraph under the reference Trainer's loop shape (zero_grad / autocast train_step / GradScaler / torch.optim.Adam, a new device-side
     message and new content rays every step): the bound Trainer.train_step with the block render + decoder replayed from two captured graphs against the same
