@@ -359,6 +359,11 @@ int field_bwd_planned(const float *xyzs, uint32_t M, float bound, const float *g
 int opt_adam_dense(uint32_t n, float *const *params_host, const float *const *grads_host, float *const *exp_avg_host,
                    float *const *exp_avg_sq_host, float *const *steps_host, const uint32_t *numel_host, const float *lr, float beta1,
                    float beta2, float eps, float grad_scale, float *scratch, nsig_stream_t stream);
+/* opt_adam_dense for torch.optim.Adam's NON-capturable state format (step counts in host tensors): the caller passes each tensor's
+ * lr / (1 - beta1^t) and 1 / sqrt(1 - beta2^t) as host arrays; one launch per 32 tensors (the drop-in model's optimiser hook). */
+int opt_adam_dense_host(uint32_t n, float *const *params_host, const float *const *grads_host, float *const *exp_avg_host,
+                        float *const *exp_avg_sq_host, const uint32_t *numel_host, const float *step_sizes_host, const float *inv_bc2_host,
+                        float beta1, float beta2, float eps, float grad_scale, nsig_stream_t stream);
 
 /*
  * rm_composite_train_fwd followed by rm_finish_fwd in the compositing launch (the ray's wave writes the background-mixed image

@@ -70,6 +70,7 @@ SIGNATURES = {
     "field_fwd_kept": [_vp, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "field_fwd": [_vp, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "field_color_fwd": [_vp, _vp, _u32, _vp, _vp, _vp],
+    "opt_adam_dense_host": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _fl, _fl, _fl, _fl, _vp],
     "opt_adam_dense": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _fl, _fl, _fl, _fl, _vp, _vp],
     "rm_composite_train_finish_fwd": [_vp, _vp, _vp, _vp, _u32, _u32, _fl, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp],
     "rm_composite_train_finish_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _fl, _u32, _vp, _vp, _vp],

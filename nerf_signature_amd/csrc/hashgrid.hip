@@ -931,6 +931,57 @@ __global__ void __launch_bounds__(256) k_adam_dense(DenseAdam a, uint32_t n, con
     }
 }
 
+// The same update with the per-tensor step size lr / (1 - beta1^t) and 1 / sqrt(1 - beta2^t) computed by the HOST (torch.optim.Adam's non-capturable state
+// keeps its step counts in host tensors: opt_adam_dense_host, the drop-in model's optimiser hook).
+struct DenseScalars {
+    float ss[kDenseMax], ib[kDenseMax];
+};
+__global__ void __launch_bounds__(256) k_adam_dense_host(DenseAdam a, uint32_t n, DenseScalars sc, float beta1, float beta2, float eps, float grad_scale) {
+    uint32_t i = 0;
+    while (i + 1 < n && blockIdx.x >= a.chunk0[i + 1]) ++i;   // uniform: which tensor this chunk belongs to
+    const uint32_t base = (blockIdx.x - a.chunk0[i]) * kDenseChunk;
+    const float ss = sc.ss[i], ib = sc.ib[i];
+    float *__restrict__ pp = a.p[i], *__restrict__ pm = a.m[i], *__restrict__ pv = a.v[i];
+    const float *__restrict__ pg = a.g[i];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t e = base + u * 256 + threadIdx.x;
+        if (e < a.numel[i]) {
+            float p = pp[e], m = pm[e], v = pv[e];
+            adam_update(pg[e] * grad_scale, p, m, v, beta1, beta2, eps, ss, ib);
+            pp[e] = p; pm[e] = m; pv[e] = v;
+        }
+    }
+}
+
+NSIG_EXPORT int opt_adam_dense_host(uint32_t n, float *const *params_host, const float *const *grads_host, float *const *exp_avg_host,
+                                    float *const *exp_avg_sq_host, const uint32_t *numel_host, const float *step_sizes_host, const float *inv_bc2_host,
+                                    float beta1, float beta2, float eps, float grad_scale, nsig_stream_t stream) {
+    NSIG_REQUIRE(params_host && grads_host && exp_avg_host && exp_avg_sq_host && numel_host && step_sizes_host && inv_bc2_host, "opt_adam_dense_host: null pointer");
+    hipStream_t st = as_stream(stream);
+    for (uint32_t first = 0; first < n; first += kDenseMax) {
+        const uint32_t cnt = n - first < (uint32_t)kDenseMax ? n - first : (uint32_t)kDenseMax;
+        DenseAdam a{};
+        DenseScalars sc{};
+        uint32_t chunks = 0;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const uint32_t j = first + i;
+            NSIG_REQUIRE(params_host[j] && grads_host[j] && exp_avg_host[j] && exp_avg_sq_host[j] && numel_host[j] > 0,
+                         "opt_adam_dense_host: tensor %u has a null pointer or no elements", j);
+            a.p[i] = params_host[j]; a.g[i] = grads_host[j]; a.m[i] = exp_avg_host[j]; a.v[i] = exp_avg_sq_host[j];
+            a.numel[i] = numel_host[j];
+            a.chunk0[i] = chunks;
+            chunks += ceil_div(numel_host[j], kDenseChunk);
+            sc.ss[i] = step_sizes_host[j];
+            sc.ib[i] = inv_bc2_host[j];
+        }
+        a.chunk0[cnt] = chunks;
+        k_adam_dense_host<<<chunks, 256, 0, st>>>(a, cnt, sc, beta1, beta2, eps, grad_scale);
+        if (int e = check_launch("opt_adam_dense_host")) return e;
+    }
+    return NSIG_OK;
+}
+
 NSIG_EXPORT int opt_adam_dense(uint32_t n, float *const *params_host, const float *const *grads_host, float *const *exp_avg_host,
                                float *const *exp_avg_sq_host, float *const *steps_host, const uint32_t *numel_host, const float *lr, float beta1,
                                float beta2, float eps, float grad_scale, float *scratch, nsig_stream_t stream) {

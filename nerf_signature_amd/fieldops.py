@@ -410,6 +410,9 @@ class SharedGradient(GradSink):
         super().__init__(device)
         self.carrier = None
         self.live = None          # the selected tables the pending G belongs to
+        # the optimiser hook that serves this sink also performs the rest of the (plain Adam) step -- the decoder's dense gradients -- in one launch
+        # (optim._dense_takeover); NERFSIG_DROPIN_DENSE_ADAM=0 leaves them to the optimiser's own multi-tensor loop
+        self.dense_takeover = os.environ.get("NERFSIG_DROPIN_DENSE_ADAM", "1") != "0"
 
     def pending(self):
         return self.carrier is not None and self.carrier.grad is self.G

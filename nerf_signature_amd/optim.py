@@ -61,8 +61,9 @@ def install_shared_gradient_hook(sink):
     import weakref
     if _SHARED_SINKS is None:
         _SHARED_SINKS = weakref.WeakSet()
-        from torch.optim.optimizer import register_optimizer_step_pre_hook
+        from torch.optim.optimizer import register_optimizer_step_post_hook, register_optimizer_step_pre_hook
         register_optimizer_step_pre_hook(_shared_gradient_pre_step)
+        register_optimizer_step_post_hook(_dense_takeover_post_step)
     _SHARED_SINKS.add(sink)
 
 
@@ -90,6 +91,69 @@ def _shared_gradient_pre_step(optimizer, args, kwargs):
             continue
         fused_shared_step(optimizer, group, sink.live, sink.G)
         sink.consumed()                                 # `.grad` of every selected table is None now: the optimiser's own loop skips them
+        if sink.dense_takeover:
+            _dense_takeover(optimizer)
+
+
+def _dense_takeover(optimizer):
+    """The rest of the step of a plain torch.optim.Adam -- every parameter that carries an ordinary dense CUDA float32 gradient: the decoder's 27 tensors --
+    as ONE launch (opt_adam_dense_host) instead of the optimiser's multi-tensor launches and their Python: same arithmetic, state in torch's own
+    non-capturable format (host step counts), per group hyper-parameters.  The gradients are set aside for the duration of optimizer.step() -- the optimiser's
+    own loop, which runs right behind this hook, then finds nothing left to do -- and put back by the post-step hook: `p.grad` reads the same after the step.
+    Groups or tensors this does not cover (weight decay, amsgrad, capturable, CPU / non-fp32 / non-contiguous tensors) are left to the optimiser."""
+    aside = []
+    for group in optimizer.param_groups:
+        if (group.get("weight_decay", 0) or group.get("amsgrad", False) or group.get("maximize", False) or group.get("capturable", False)
+                or group.get("differentiable", False) or torch.is_tensor(group["lr"])):
+            continue
+        ps = [p for p in group["params"] if p.grad is not None and p.is_cuda and p.dtype == torch.float32 and p.grad.dtype == torch.float32
+              and not p.grad.is_sparse and p.is_contiguous() and p.grad.is_contiguous()]
+        if not ps:
+            continue
+        beta1, beta2 = group["betas"]
+        lr, eps = float(group["lr"]), float(group["eps"])
+        handles = optimizer.__dict__.setdefault("_nsig_dense_handles", {})      # id(p) -> (p, state dict, exp_avg, exp_avg_sq, step count as numpy, step tensor)
+        n = len(ps)
+        vp, fl = ctypes.c_void_p * n, ctypes.c_float * n
+        pp, pg, pm, pv, numel, ss, ib = vp(), vp(), vp(), vp(), (ctypes.c_uint32 * n)(), fl(), fl()
+        skip = False
+        for i, p in enumerate(ps):
+            h = handles.get(id(p))
+            if h is None or h[0] is not p or h[1].get("exp_avg") is not h[2] or h[1].get("exp_avg_sq") is not h[3] or h[1].get("step") is not h[5]:
+                st = optimizer.state[p]
+                if len(st) == 0:   # torch.optim.Adam._init_group
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if st["step"].is_cuda or not (st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous()):
+                    skip = True    # (a state format from elsewhere: the optimiser's own business)
+                    break
+                h = handles[id(p)] = (p, st, st["exp_avg"], st["exp_avg_sq"], st["step"].numpy(), st["step"], p.data_ptr(), st["exp_avg"].data_ptr(),
+                                      st["exp_avg_sq"].data_ptr(), p.numel())
+            pp[i], pm[i], pv[i], numel[i], pg[i] = h[6], h[7], h[8], h[9], p.grad.data_ptr()
+        if skip:
+            continue
+        for i, p in enumerate(ps):
+            count = handles[id(p)][4]
+            count += 1
+            k = float(count)
+            ss[i] = lr / (1.0 - beta1 ** k)
+            ib[i] = 1.0 / math.sqrt(1.0 - beta2 ** k)
+        nv.call("opt_adam_dense_host", n, pp, pg, pm, pv, numel, ss, ib, float(beta1), float(beta2), eps, 1.0, nv.stream())
+        _bump_versions(ps)
+        for p in ps:
+            aside.append((p, p.grad))
+            p.grad = None
+    if aside:
+        optimizer.__dict__["_nsig_grads_aside"] = aside
+
+
+def _dense_takeover_post_step(optimizer, args, kwargs):
+    aside = optimizer.__dict__.pop("_nsig_grads_aside", None)
+    if aside:
+        for p, g in aside:
+            if p.grad is None:
+                p.grad = g
 
 
 class CodebookAdam(torch.optim.Adam):

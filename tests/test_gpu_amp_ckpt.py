@@ -283,6 +283,11 @@ def test_shared_gradient_step_under_a_foreign_loop_matches_plain_autograd_and_ad
         tables = [e.weight.detach().clone() for e in m.msg_encoder.embeddings]
         steps = [float(opt.state[e.weight]["step"]) if len(opt.state[e.weight]) else 0.0 for e in m.msg_encoder.embeddings]
         dec = torch.cat([p.detach().reshape(-1) for p in m.msg_decoder.parameters()])
+        # the decoder's dense gradients: stepped by the optimiser itself (plain) or by the hook's one-launch pass (shared) -- three real steps in torch's own state
+        # format either way, and the gradients still readable after optimizer.step()
+        stepped = [p for p in m.msg_decoder.parameters() if len(opt.state[p])]
+        assert len(stepped) >= 27 and {float(opt.state[p]["step"]) for p in stepped} == {3.0} and not any(opt.state[p]["step"].is_cuda for p in stepped)
+        assert all(p.grad is not None for p in stepped)
         runs.append((losses, tables, steps, dec, carriers, scaler.get_scale(), m))
     (l0, t0, s0, d0, c0, sc0, m0), (l1, t1, s1, d1, c1, sc1, m1) = runs
     assert c0 == [32, 32, 32, 32] and c1 == [1, 1, 1, 1]                    # plain: every selected table has a dense gradient; shared: the carrier alone
@@ -474,3 +479,49 @@ def test_block_graph_replays_the_eager_block_render_and_decoder(monkeypatch):
         out[5].backward()
         opt1.step()
     assert g.captures == 2 and g.generation == before + 1 and np.isfinite(float(out[5].detach()))
+
+
+def test_dense_takeover_is_torch_adam_arithmetic():
+    """optim._dense_takeover (opt_adam_dense_host: the hook's one-launch Adam over every remaining dense gradient) against torch.optim.Adam on the same
+    parameters and gradients, 5 steps, 40 tensors of ragged sizes (two launches: 32 + 8), two groups with different learning rates, a parameter without a
+    gradient in one step; the gradients are set aside while the optimiser's own loop runs and are back afterwards; a group with weight decay is left alone."""
+    from nerf_signature_amd import optim
+    g = torch.Generator(device="cuda").manual_seed(3)
+    sizes = [(1,), (7,), (64, 3, 3, 3), (1025,), (64,), (2048, 3)] * 6 + [(5, 5), (333,), (4096,), (1024,)]
+
+    def make():
+        gg = torch.Generator(device="cuda").manual_seed(3)
+        return [torch.nn.Parameter(torch.randn(*s, device="cuda", generator=gg)) for s in sizes]
+
+    a, b = make(), make()
+    kw = dict(betas=(0.9, 0.99), eps=1e-15)
+    oa = torch.optim.Adam([{"params": a[:25], "lr": 1e-2}, {"params": a[25:], "lr": 3e-4}], **kw)
+    ob = torch.optim.Adam([{"params": b[:25], "lr": 1e-2}, {"params": b[25:], "lr": 3e-4}], **kw)
+    for k in range(5):
+        grads = [torch.randn(*s, device="cuda", generator=g) * 10.0 ** (k - 2) for s in sizes]
+        for p, q, gr in zip(a, b, grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        if k == 3:
+            a[7].grad = b[7].grad = None            # a parameter without a gradient this step keeps its count, like torch
+        oa.step()
+        with torch.no_grad():
+            optim._dense_takeover(ob)
+        assert all(q.grad is None for q in b)
+        ob.step()                                   # nothing left for the optimiser's own loop: it must not move anything nor count a step
+        optim._dense_takeover_post_step(ob, (), {})
+        assert all((q.grad is None) == (k == 3 and i == 7) for i, q in enumerate(b))
+    torch.cuda.synchronize()
+    for i, (p, q) in enumerate(zip(a, b)):
+        assert float(oa.state[p]["step"]) == float(ob.state[q]["step"]) == (4.0 if i == 7 else 5.0)
+        torch.testing.assert_close(q, p, rtol=2e-6, atol=2e-7)
+        # (torch updates the first moment as lerp(m, g, 1 - beta1), the kernel as beta1 * m + (1 - beta1) * g: last-bit differences where the two nearly cancel)
+        scale = float(oa.state[p]["exp_avg"].abs().max())
+        torch.testing.assert_close(ob.state[q]["exp_avg"], oa.state[p]["exp_avg"], rtol=2e-5, atol=1e-6 * scale)
+        torch.testing.assert_close(ob.state[q]["exp_avg_sq"], oa.state[p]["exp_avg_sq"], rtol=2e-5, atol=1e-12)
+    w = make()
+    ow = torch.optim.Adam(w, lr=1e-2, weight_decay=1e-3)
+    for p in w:
+        p.grad = torch.ones_like(p)
+    with torch.no_grad():
+        optim._dense_takeover(ow)
+    assert all(p.grad is not None for p in w) and len(ow.state) == 0
