@@ -105,7 +105,10 @@ class BlockDecodeGraph:
         if not (torch.is_tensor(message) and rays_o.is_cuda and rays_o.dim() == 4 and model.training and torch.is_grad_enabled() and model.cuda_ray
                 and not torch.cuda.is_current_stream_capturing() and model.normalization is normalize_img and model.grad_sink is None
                 and getattr(model, "shared_gradient_step", False) and not getattr(model, "device_select", False)
-                and getattr(model, "point_capacity", None) is None and not fo_data_parallel()):
+                and getattr(model, "point_capacity", None) is None):
+            return None
+        from .network import _data_parallel
+        if _data_parallel():          # (more than one rank: DistributedDataParallel-style loops reduce autograd's own gradients)
             return None
         rec = self._record(model, rays_o, rays_d)
         if rec is None:
@@ -197,7 +200,3 @@ class BlockDecodeGraph:
         self.decoded, self.pred = decoded.detach(), pred.detach()
         self.captures += 1
 
-
-def fo_data_parallel():
-    from .network import _data_parallel
-    return _data_parallel()
