@@ -70,6 +70,9 @@ class BlockDecodeGraph:
         self.generation, self.backward_of = 0, -1
         self.captures = 0
 
+    def _content_key(self, content):
+        raise NotImplementedError("a BlockDecodeGraph captures the block render and the decoder only (StepGraph takes the content render too)")
+
     # ------------------------------------------------------------------ what must hold for the captured launches to be the eager ones
 
     def _record(self, model, rays_o, rays_d):
@@ -94,8 +97,10 @@ class BlockDecodeGraph:
                 float(kw.get("dt_gamma", 0)), int(kw.get("max_steps", 1024)), float(kw.get("T_thresh", 1e-4)), int(fo.nv.fn("mlp_get_precision")()),
                 float(model.density_scale), float(model.bound))
 
-    def run(self, model, rays_o, rays_d, message, render_kwargs, distortion=None):
+    def run(self, model, rays_o, rays_d, message, render_kwargs, distortion=None, content=None):
         """(decoded [D, 1], clamped blocks [D, bh, bw, 3]) of this step through the captured launches, or None: take the eager route.
+        content (StepGraph only): (content rays_o, rays_d, images, lambda_w, lambda_i) -- the whole forward pass is then captured and the result is
+        train_step's six return values.
         distortion: None or a distortion.DistortionLayer whose owner has drawn this step's parameters into its (static) device buffers; every kind but
         `scaling` (which changes the decoder's input width from step to step) is part of the captured forward."""
         if self.failed is not None or os.environ.get("NERFSIG_DROPIN_BLOCK_GRAPH", "1") == "0":
@@ -122,6 +127,8 @@ class BlockDecodeGraph:
         kw = dict(render_kwargs)
         key = self._key(model, rays_o, rays_d, rec, fused, kw, sink) + (
             (None,) if distortion is None else (distortion.name, distortion.param.data_ptr(), None if distortion.noise is None else distortion.noise.data_ptr()))
+        if content is not None:
+            key = key + self._content_key(content)
         if key != self.key:
             self.key, self.seen = key, 0
             self.forward_graph = self.backward_graph = None
@@ -129,12 +136,14 @@ class BlockDecodeGraph:
         anchor = next((t for t in selected if t.requires_grad), None)
         if anchor is None:
             return None
+        if content is not None and self.seen >= self.eager_steps and not self._stage_content(model, content, message, kw):
+            return None                                     # (more samples than the captured buffers hold: this step runs eagerly, the next capture is larger)
         if self.forward_graph is None:
             self.seen += 1
             if self.seen <= self.eager_steps:
                 return None
             try:
-                self._capture(model, rays_o, rays_d, message, kw, fused, sink, selected, distortion)
+                self._capture(model, rays_o, rays_d, message, kw, fused, sink, selected, distortion, content)
             except Exception as e:      # noqa: BLE001 -- whatever it was: never again in this process, and say so
                 self.failed = repr(e)
                 self.forward_graph = self.backward_graph = None
@@ -144,11 +153,14 @@ class BlockDecodeGraph:
                 return None
         self.sink = sink
         self.params = list(fused[1])
+        if content is not None:
+            loss, lossi, lossw, pred, cpred = _ReplayStep.apply(self, list(selected), anchor, *self.params)
+            return pred, content[2], cpred, lossi, lossw, loss
         return _Replay.apply(self, list(selected), anchor, *self.params)
 
     # ------------------------------------------------------------------ capture
 
-    def _capture(self, model, rays_o, rays_d, message, kw, fused, sink, selected, distortion=None):
+    def _capture(self, model, rays_o, rays_d, message, kw, fused, sink, selected, distortion=None, content=None):
         kw = dict(kw)
         kw.update(staged=False, bg_color=1, perturb=False, force_all_rays=True)
         params = list(fused[1])
@@ -156,7 +168,8 @@ class BlockDecodeGraph:
         dev = rays_o.device
         self.params = params
         self.flat = torch.empty(n_flat, dtype=torch.float32, device=dev)           # the decoder's parameter gradients of the last backward replay
-        self.seed = torch.empty(rays_o.shape[0], 1, dtype=torch.float32, device=dev)  # d loss / d decoded, copied in before the backward replay
+        # the backward's seed, copied in before its replay: d loss / d decoded -- or, with the whole step captured, the (scalar) gradient of the loss itself
+        self.seed = torch.empty((rays_o.shape[0], 1) if content is None else (), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
         model._presum_event = None                 # (recorded outside the capture: the captured render must not wait on it)
         fo.forget_plan_events()
@@ -181,6 +194,11 @@ class BlockDecodeGraph:
                     decoded = hidden_models._FusedDecoder.apply(resampled, fused[0], True, None, None, *aliases)[0]
                 else:
                     decoded, pred = hidden_models._FusedDecoder.apply(image, fused[0], True, distortion, None, *aliases)
+                root = decoded
+                if content is not None:      # the content render from the samples staged in front of the replay, and the three losses
+                    from .trainer import _WatermarkLoss
+                    cpred = model.render(self.c_o, self.c_d, message, **kw)["image"]
+                    lossi, lossw, root = _WatermarkLoss.apply(cpred, self.c_gt, decoded, self.msg_s.unsqueeze(-1), float(content[3]), float(content[4]), 10.0)
             finally:
                 self.forward_graph.capture_end()
             if not pending_before:
@@ -188,7 +206,7 @@ class BlockDecodeGraph:
             hidden_models.set_grad_arena(self.flat)
             self.backward_graph.capture_begin(pool=self.forward_graph.pool(), capture_error_mode="thread_local")
             try:
-                torch.autograd.grad([decoded], [anchor] + [a for a in aliases if a.requires_grad], [self.seed], allow_unused=True)
+                torch.autograd.grad([root], [anchor] + [a for a in aliases if a.requires_grad], [self.seed], allow_unused=True)
             finally:
                 self.backward_graph.capture_end()
                 hidden_models.set_grad_arena(None)
@@ -198,5 +216,84 @@ class BlockDecodeGraph:
         fo.forget_plan_events()
         model._presum_event = None
         self.decoded, self.pred = decoded.detach(), pred.detach()
+        if content is not None:
+            self.losses, self.cpred = (root.detach(), lossi.detach(), lossw.detach()), cpred.detach()
         self.captures += 1
+
+
+class _ReplayStep(torch.autograd.Function):
+    """_Replay for a StepGraph: the outputs are train_step's -- (loss, lossi, lossw, clamped blocks, content image) -- and the backward is seeded by the
+    gradient of `loss` (what `scaler.scale(loss).backward()` hands down)."""
+
+    @staticmethod
+    def forward(ctx, graph, selected, anchor, *params):
+        graph.forward_graph.replay()
+        graph.generation += 1
+        ctx.graph, ctx.generation, ctx.selected, ctx.n = graph, graph.generation, selected, len(params)
+        loss, lossi, lossw = (t.clone() for t in graph.losses)
+        pred, cpred = graph.pred.clone(), graph.cpred.clone()
+        ctx.mark_non_differentiable(pred, cpred)
+        ctx.set_materialize_grads(False)
+        return loss, lossi, lossw, pred, cpred
+
+    @staticmethod
+    def backward(ctx, g_loss, g_lossi=None, g_lossw=None, *_):
+        if g_lossi is not None or g_lossw is not None:
+            raise NotImplementedError("StepGraph: the captured backward starts from `loss` (utils_wtmk_disen.py:1174); a backward through lossi / lossw alone needs "
+                                      "NERFSIG_DROPIN_STEP_GRAPH=0")
+        return _Replay.backward(ctx, g_loss)
+
+
+class StepGraph(BlockDecodeGraph):
+    """BlockDecodeGraph with the rest of the step's forward and backward inside the two graphs: the content render and the losses.
+
+    The content rays are new tensors every step and their sample count varies, so in front of every replay (a) rays, ground truth and message are copied
+    into static buffers, (b) the rays are marched EAGERLY into a static sample record of fixed capacity (NeRFRenderer.march_ahead) and the count is read
+    back -- the one host read an eager step has anyway.  If the samples fit, the captured forward (block render, decoder, content field pass + compositing
+    over `capacity` rows, loss kernel) and later the captured backward are replayed; if they do not, THIS step runs on the eager route (nothing is dropped,
+    ever) and the next capture is sized 1.3 x larger.  NERFSIG_DROPIN_STEP_GRAPH=0: the block render + decoder alone are captured (BlockDecodeGraph)."""
+
+    HEADROOM = 1.3
+
+    def __init__(self, eager_steps=3):
+        super().__init__(eager_steps)
+        self.capacity = None
+        self.overflows = 0
+
+    def _content_key(self, content):
+        o, d, gt, lw, li = content
+        return (tuple(o.shape), tuple(gt.shape), float(lw), float(li), self.capacity)
+
+    def usable_content(self, content, loss_is_bce, color_space):
+        o, d, gt, _, _ = content
+        return (os.environ.get("NERFSIG_DROPIN_STEP_GRAPH", "1") != "0" and loss_is_bce and color_space == "srgb" and o.is_cuda and o.dtype == torch.float32
+                and d.dtype == torch.float32 and gt.dtype == torch.float32 and gt.shape[-1] == 3 and tuple(gt.shape[:-1]) == tuple(o.shape[:-1]))
+
+    def _stage_content(self, model, content, message, kw):
+        from . import raymarching
+        o, d, gt, _, _ = content
+        if getattr(self, "c_o", None) is None or self.c_o.shape != o.shape or self.c_o.device != o.device:
+            self.c_o, self.c_d, self.c_gt = torch.empty_like(o), torch.empty_like(d), torch.empty_like(gt)
+            self.msg_s = torch.empty(message.numel(), dtype=torch.float32, device=o.device)
+            self.capacity = None
+        self.c_o.copy_(o)
+        self.c_d.copy_(d)
+        self.c_gt.copy_(gt)
+        self.msg_s.copy_(message)
+        dt_gamma, max_steps = kw.get("dt_gamma", 0), kw.get("max_steps", 1024)
+        if self.capacity is None:
+            self.capacity = raymarching.padded_point_count(int(model._count_points(*model._flatten_rays(self.c_o, self.c_d)[1:], dt_gamma, max_steps) * self.HEADROOM))
+            self.forward_graph = self.backward_graph = None
+            self.key = None              # (the capacity is part of the key: the caller's key is stale now; it is rebuilt at the next step)
+        rec = model.march_ahead(self.c_o, self.c_d, dt_gamma, max_steps, capacity=self.capacity)
+        n = raymarching.padded_point_count(int(rec["counter"][0]))
+        if n > self.capacity or self.key is None:
+            if n > self.capacity:
+                self.overflows += 1
+                self.capacity = raymarching.padded_point_count(int(n * self.HEADROOM))
+                self.forward_graph = self.backward_graph = None
+                self.key = None
+            model._marched = {k: r for k, r in model._marched.items() if r is not rec}      # the eager route marches for itself
+            return False
+        return True
 

@@ -160,13 +160,26 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
             content_pred_rgb.record_stream(main)
     block_o, block_d, shard = local_blocks(wm)
     graphed = None
-    if block_graph is not None and main is None and shard is None and not presum_adopt and content["rays_o"].is_cuda and model.training and torch.is_grad_enabled() \
-            and hasattr(model, "premarch") and getattr(model, "point_capacity", None) is None and not torch.cuda.is_current_stream_capturing() \
-            and os.environ.get("NERFSIG_DROPIN_PREMARCH", "1") != "0":
-        # the content render's march and its one host read, in front of the block render: the read then waits for the march alone
+    eager_caller = block_graph is not None and main is None and shard is None and not presum_adopt
+    # the content render's march and its one host read, in front of the block render: the read then waits for the march alone (NeRFRenderer.premarch)
+    premarch = (eager_caller and content["rays_o"].is_cuda and model.training and torch.is_grad_enabled() and hasattr(model, "premarch")
+                and getattr(model, "point_capacity", None) is None and not torch.cuda.is_current_stream_capturing() and os.environ.get("NERFSIG_DROPIN_PREMARCH", "1") != "0")
+    if eager_caller and (distortion is None or isinstance(distortion, DistortionLayer)):
+        whole = None
+        if hasattr(block_graph, "usable_content") and content["images"].shape[-1] == 3:
+            whole = (content["rays_o"], content["rays_d"], content["images"], float(lambda_w), float(lambda_i))
+            if not block_graph.usable_content(whole, loss_w is loss_w_bce, color_space):
+                whole = None
+        if whole is None and premarch:       # (a StepGraph marches the content rays itself, into its own static record)
+            model.premarch(content["rays_o"], content["rays_d"], kw.get("dt_gamma", 0), kw.get("max_steps", 1024))
+            premarch = False
+        graphed = block_graph.run(model, block_o, block_d, message, kw, distortion, whole)
+        if graphed is not None and whole is not None:      # the whole step came out of the two captured graphs (blockgraph.StepGraph)
+            _WatermarkLoss.last = None
+            train_step.last_lambdas = (float(lambda_w), float(lambda_i))
+            return graphed
+    if premarch:
         model.premarch(content["rays_o"], content["rays_d"], kw.get("dt_gamma", 0), kw.get("max_steps", 1024))
-    if block_graph is not None and main is None and shard is None and not presum_adopt and (distortion is None or isinstance(distortion, DistortionLayer)):
-        graphed = block_graph.run(model, block_o, block_d, message, kw, distortion)
     outputs = model.render(block_o, block_d, message, **kw) if graphed is None else None
     content_done = early_seed = None
     deferred = False
@@ -300,8 +313,8 @@ def reference_trainer_train_step(self, data, message):
         raise NotImplementedError
     graph = self.__dict__.get("_nsig_block_graph")
     if graph is None:
-        from .blockgraph import BlockDecodeGraph
-        graph = self.__dict__["_nsig_block_graph"] = BlockDecodeGraph()
+        from .blockgraph import StepGraph
+        graph = self.__dict__["_nsig_block_graph"] = StepGraph()
     return train_step(self.model, data, message, vars(self.opt), lambda_w=self.lambda_w, lambda_i=self.lambda_i, loss_w=loss_w_bce if name == "bce" else loss_w_mse,
                       color_space=getattr(self.opt, "color_space", "srgb"), distortion=layer, block_graph=graph)
 

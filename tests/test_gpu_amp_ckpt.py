@@ -371,22 +371,25 @@ def test_reference_trainer_train_step_equals_the_stock_operator_sequence(distort
         trainer.reference_trainer_train_step(types.SimpleNamespace(model=m, opt=opt, lambda_w=1.0, lambda_i=1.0, distortion="none"), bad, msg)
 
 
+@pytest.mark.parametrize("whole_step", [False, True])
 @pytest.mark.parametrize("distortion", ["brightness", "noise", "rotation", "scaling"])
-def test_block_graph_with_a_distortion_layer(monkeypatch, distortion):
+def test_block_graph_with_a_distortion_layer(monkeypatch, distortion, whole_step):
     """The captured block render + decoder with the step's distortion layer inside (its draws land in static device buffers before every replay): the same
     loop with and without the graphs, same draws (the layer's generators are seeded alike) -> same losses step by step.  `scaling` changes the decoder's
     input width every step: the graph steps aside (no capture) and the eager launches run."""
     import argparse
     import types
     from nerf_signature_amd import trainer
+    monkeypatch.setenv("NERFSIG_DROPIN_STEP_GRAPH", "1" if whole_step else "0")
+    n_steps = 12 if whole_step else 8           # (the whole-step capture sizes its sample buffers first: four more eager steps)
     bo, bd, _, _, _ = _data(n_content=300)
     wm = {"rays_o_block": bo.cuda(), "rays_d_block": bd.cuda(), "images": torch.zeros(32, 6, 6, 3)}
     batches = []
-    for k in range(8):
+    for k in range(n_steps):
         _, _, co, cd, gt = _data(n_content=300, seed=30 + k)
         batches.append({"rays_o": co.cuda(), "rays_d": cd.cuda(), "images": gt.cuda()})
     gen = torch.Generator(device="cuda").manual_seed(6)
-    msgs = [torch.randint(0, 2, (32,), generator=gen, device="cuda").float() for _ in range(8)]
+    msgs = [torch.randint(0, 2, (32,), generator=gen, device="cuda").float() for _ in range(n_steps)]
     opt_ns = argparse.Namespace(dt_gamma=0, max_steps=1024, color_space="srgb", loss_w="bce", distortion=distortion, workspace="w", fp16=False)
     runs = []
     for graph_on in (False, True):
@@ -397,7 +400,7 @@ def test_block_graph_with_a_distortion_layer(monkeypatch, distortion):
         me = types.SimpleNamespace(model=m, opt=opt_ns, lambda_w=0.005, lambda_i=1.0, distortion=distortion)
         opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
         losses = []
-        for k in range(8):
+        for k in range(n_steps):
             opt.zero_grad()
             out = trainer.reference_trainer_train_step(me, {"watermark": wm, "content": batches[k]}, msgs[k])
             out[5].backward()
@@ -408,10 +411,11 @@ def test_block_graph_with_a_distortion_layer(monkeypatch, distortion):
     g = me1._nsig_block_graph
     assert g.failed is None and (g.captures, g.generation) == ((0, 0) if distortion == "scaling" else (1, 3))
     np.testing.assert_allclose(l1, l0, rtol=5e-5, atol=1e-7)
-    assert len({round(float(v), 7) for v in l1[:, 1]}) == 8      # a new draw (and a new message) every step: the watermark loss never repeats
+    assert len({round(float(v), 7) for v in l1[:, 1]}) == n_steps      # a new draw (and a new message) every step: the watermark loss never repeats
 
 
-def test_block_graph_replays_the_eager_block_render_and_decoder(monkeypatch):
+@pytest.mark.parametrize("whole_step", [False, True])
+def test_block_graph_replays_the_eager_block_render_and_decoder(monkeypatch, whole_step):
     """blockgraph.BlockDecodeGraph under the reference Trainer's loop shape (zero_grad / autocast train_step / GradScaler / torch.optim.Adam, a new device-side
     message and new content rays every step): the bound Trainer.train_step with the block render + decoder replayed from two captured graphs against the same
     loop with NERFSIG_DROPIN_BLOCK_GRAPH=0 -- same losses step by step, same parameters after 10 steps, one capture, replays from the fifth step on (two sightings
@@ -420,14 +424,16 @@ def test_block_graph_replays_the_eager_block_render_and_decoder(monkeypatch):
     import argparse
     import types
     from nerf_signature_amd import trainer
+    monkeypatch.setenv("NERFSIG_DROPIN_STEP_GRAPH", "1" if whole_step else "0")      # 1: blockgraph.StepGraph captures the content render and the losses as well
+    n_steps = 14 if whole_step else 10          # (the whole-step capture sizes its sample buffers first: four more eager steps)
     bo, bd, _, _, _ = _data(n_content=300)
     block_o, block_d = bo.cuda(), bd.cuda()
     batches = []
-    for k in range(10):
+    for k in range(n_steps):
         _, _, co, cd, gt = _data(n_content=300, seed=10 + k)
         batches.append({"rays_o": co.cuda(), "rays_d": cd.cuda(), "images": gt.cuda()})
     gen = torch.Generator(device="cuda").manual_seed(5)
-    msgs = [torch.randint(0, 2, (32,), generator=gen, device="cuda").float() for _ in range(10)]
+    msgs = [torch.randint(0, 2, (32,), generator=gen, device="cuda").float() for _ in range(n_steps)]
     opt_ns = argparse.Namespace(dt_gamma=0, max_steps=1024, color_space="srgb", loss_w="bce", distortion="none", workspace="w", fp16=True)
     runs = []
     for graph_on in (False, True):
@@ -440,11 +446,11 @@ def test_block_graph_replays_the_eager_block_render_and_decoder(monkeypatch):
         scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
         wm = {"rays_o_block": block_o, "rays_d_block": block_d, "images": torch.zeros(32, 6, 6, 3)}
         losses = []
-        for k in range(10):
+        for k in range(n_steps):
             opt.zero_grad()
             with torch.autocast("cuda"):
                 out = trainer.reference_trainer_train_step(me, {"watermark": wm, "content": batches[k]}, msgs[k])
-            scaler.scale(out[5] * (float("inf") if k == 7 else 1.0)).backward()
+            scaler.scale(out[5] * (float("inf") if k == n_steps - 3 else 1.0)).backward()
             scaler.step(opt)
             scaler.update()
             losses.append([float(v.detach()) for v in out[3:6]] + [float(out[0].sum())])
@@ -453,7 +459,7 @@ def test_block_graph_replays_the_eager_block_render_and_decoder(monkeypatch):
                      torch.cat([p.detach().reshape(-1) for p in m.msg_decoder.parameters()]), scaler.get_scale(), me, m, opt))
     (l0, t0, d0, s0, me0, _, _), (l1, t1, d1, s1, me1, m1, opt1) = runs
     g = me1._nsig_block_graph
-    assert me0._nsig_block_graph.captures == 0 and g.captures == 1 and g.failed is None and g.generation == 10 - 5 and s0 == s1 == 512.0
+    assert me0._nsig_block_graph.captures == 0 and g.captures == 1 and g.failed is None and g.generation == 5 and s0 == s1 == 512.0
     # (run-to-run: the order of the float atomics in G; the eager route also seeds the decoder's backward from its head kernel, the graph from the loss kernel)
     np.testing.assert_allclose(l1, l0, rtol=2e-5, atol=1e-7)
     moved = sum(float((a - torch.from_numpy(cf.table(100 + l, scale=0.05)).cuda()).pow(2).sum()) for l, a in enumerate(t0)) ** 0.5
@@ -479,6 +485,20 @@ def test_block_graph_replays_the_eager_block_render_and_decoder(monkeypatch):
         out[5].backward()
         opt1.step()
     assert g.captures == 2 and g.generation == before + 1 and np.isfinite(float(out[5].detach()))
+    if whole_step:
+        # more samples than the captured buffers hold: THAT step runs eagerly (same losses as the eager loop: nothing is dropped), the next capture is larger
+        with pytest.raises(NotImplementedError, match="lossi"):
+            trainer.reference_trainer_train_step(me1, shifted, msgs[0])[3].backward()
+        opt1.zero_grad()
+        g.capacity, g.key, g.forward_graph = 128, None, None
+        seen = []
+        for k in range(9):
+            opt1.zero_grad()
+            out = trainer.reference_trainer_train_step(me1, shifted, msgs[k])
+            out[5].backward()
+            seen.append((g.overflows, g.capacity, g.captures, float(out[3].detach())))
+            opt1.step()
+        assert seen[-1][0] == 1 and seen[-1][1] > 128 and seen[-1][2] == 3 and all(np.isfinite(v[3]) and v[3] > 0 for v in seen)
 
 
 def test_dense_takeover_is_torch_adam_arithmetic():
