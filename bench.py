@@ -478,7 +478,7 @@ def run_secondaries(args):
             ("counter", [os.path.abspath(__file__), "--config", "counter", "--steps", k, "--warmup", str(min(args.warmup, 5)), "--no-cpu-baseline", "--no-secondary", "--windows", "1"]),
             ("fern", [os.path.abspath(__file__), "--config", "fern", "--steps", "5", "--warmup", "1", "--no-secondary"]),
             ("rank_emulation", [os.path.join(ROOT, "tools", "emulate_ranks.py"), "--steps", k]),
-            ("eager_reference_trainer_shape", [os.path.join(ROOT, "tools", "trainer_shape.py"), "--steps", "300", "--both"]),
+            ("eager_reference_trainer_shape", [os.path.join(ROOT, "tools", "trainer_shape.py"), "--steps", "330", "--both", "--evaluate"]),
             ("eval_loop", [os.path.join(ROOT, "tools", "eval_bench.py")]),
             ("distortion_layer", [os.path.join(ROOT, "tools", "distortion_bench.py")]))
     for name, argv in jobs:

@@ -252,3 +252,41 @@ def test_two_hundred_steps_tracked_by_the_oracle_from_a_warm_state():
     # the watermark's own amplitude (an 86 dB signal: rms 5e-5): 0.3 dB = 3.5 % of it after 200 tracked steps (observed run to run: 0.02-0.10 dB -- the order of the
     # float atomics in G, which Adam with eps = 1e-15 turns into +-lr steps, and the fp16-operand MLPs against the oracle's fp32)
     assert abs(np.mean(a1) - np.mean(a0)) < 0.3
+
+
+def test_the_bound_trainer_train_step_trains_the_watermark_through_its_captured_graphs():
+    """The reference Trainer's loop shape (as tools/trainer_shape.py times it: zero_grad / autocast train_step / GradScaler / torch.optim.Adam / LambdaLR, a new
+    device-side message and loader-style content rays every step) around the drop-in directory's bound Trainer.train_step -- the whole step replayed from the
+    two captured graphs (blockgraph.StepGraph), the decoder's Adam step in the optimiser hook -- for the README schedule: the watermark is learnt like everywhere else."""
+    import argparse
+    import types
+    from nerf_signature_amd import quality, synthetic, trainer
+    stage = quality.watermark_stage("hotdog")
+    model, dev, D, H, W = stage["model"], stage["device"], stage["D"], stage["H"], stage["W"]
+    model.shared_gradient_step = model.auto_fix_rays = True          # what dropin/nerf/network_wtmk_tcnn.py switches on
+    opt_ns = argparse.Namespace(**stage["render_kwargs"], num_rays=4096, lr=1e-2, workspace="x", fp16=True, color_space="srgb", loss_w="bce")
+    me = types.SimpleNamespace(model=model, opt=opt_ns, lambda_w=0.005, lambda_i=1.0, distortion="none")
+    optimizer = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lambda it: 0.1 ** min(it / 1000, 1))
+    scaler = torch.amp.GradScaler("cuda")
+    wm = {"rays_o_block": stage["block_o"], "rays_d_block": stage["block_d"], "images": torch.zeros(D, 1, 1, 3)}
+    poses, clean, intr = stage["poses"], stage["clean"], stage["intr"]
+    for k in range(1000):
+        p = k % poses.shape[0]
+        inds = torch.randint(0, H * W, size=[4096], device=dev).expand([1, 4096])
+        o, d = synthetic.get_rays(poses[p:p + 1], intr, H, W, inds)
+        data = {"watermark": wm, "content": {"rays_o": o, "rays_d": d, "images": torch.gather(clean[p:p + 1], 1, torch.stack(3 * [inds], -1))}}
+        message = torch.randint(0, 2, (D,), dtype=torch.float32, device=dev)
+        optimizer.zero_grad()
+        with torch.autocast("cuda"):
+            out = trainer.reference_trainer_train_step(me, data, message)
+        scaler.scale(out[5]).backward()
+        scaler.step(optimizer)
+        scaler.update()
+        scheduler.step()
+    g = me._nsig_block_graph
+    acc, _, worst = quality.test_bitacc(stage, 100)
+    psnr = quality.test_image(stage)
+    print(f"\n[bound train_step] captures {g.captures}, replays {g.generation}, overflows {g.overflows}; bit acc {acc:.4f} (worst message {worst} bits), PSNR {psnr:.2f} dB")
+    assert g.failed is None and g.captures >= 1 and g.generation > 900
+    assert acc >= 0.98 and worst <= 3 and 40.0 < psnr < 75.0

@@ -32,6 +32,8 @@ ap.add_argument("--no-auto-fix", action="store_true")
 ap.add_argument("--reference-operators", action="store_true", help="NERFSIG_DROPIN_TRAIN_STEP=0: the operator sequence the reference's own Trainer.train_step issues around model.render "
                                                                    "and model.msg_decoder, instead of the method the drop-in directory binds in its place (this repo's fused train_step)")
 ap.add_argument("--distortion", default="none")
+ap.add_argument("--evaluate", action="store_true", help="after the timed steps: Trainer.test_bitacc over 100 random messages and test_image PSNR (quality.py) -- with --steps 330 and the "
+                                                        "default three windows the loop has run the reference's whole 1000-step schedule by then")
 ap.add_argument("--both", action="store_true", help="after the timed windows, time one more window with the other train_step (see --reference-operators) and report it next to the first")
 args = ap.parse_args()
 args.fused_step = not args.reference_operators
@@ -181,6 +183,10 @@ if args.phases:
           "reserved MB", ms1["reserved_bytes.all.current"] / 1e6, file=sys.stderr)
     n = args.steps * len(windows)
     print("host wall per step by phase (ms; includes waiting for the GPU where a phase synchronises):", {k: round(v / n * 1e3, 3) for k, v in PH.items()}, file=sys.stderr)
+quality_after = None
+if args.evaluate:
+    acc, wrong_mean, wrong_max = quality.test_bitacc(stage, 100)
+    quality_after = {"steps_trained": args.warmup + args.steps * len(windows), "bit_acc": acc, "wrong_bits_worst_message": wrong_max, "psnr_db": quality.test_image(stage)}
 os.dup2(real_stdout, 1)
 print(json.dumps({"what": "what the UNCHANGED reference CLI runs on top of the drop-in directory: the reference Trainer's loop body (utils_wtmk_disen.py:1164-1190) -- eager, autocast(fp16) + "
                           "GradScaler, plain torch.optim.Adam, loader-style rays per step, three .item() reads per step -- around this repo's model; NOT the headline path",
@@ -189,4 +195,5 @@ print(json.dumps({"what": "what the UNCHANGED reference CLI runs on top of the d
                   "ms_per_step": el / args.steps * 1e3, "ms_per_step_windows": [round(w, 4) for w in windows], "content_rays_per_s": 4096 * args.steps / el, "steps": args.steps, "fp16": not args.no_fp16,
                   **({} if other is None else {("ms_per_step_with_the_references_own_train_step_operators" if args.fused_step else "ms_per_step_with_the_bound_train_step"): round(other, 4)}),
                   "block_graph": (lambda g: None if g is None else {"captures": g.captures, "replays": g.generation, "failed": g.failed})(me.__dict__.get("_nsig_block_graph")),
+                  **({} if quality_after is None else {"quality_after": quality_after}),
                   "fix_rays": bool(args.fix_rays), "shared_gradient_step": bool(model.shared_gradient_step), "auto_fix_rays": bool(model.auto_fix_rays), "loss": last[0] if last else None, "grad_scale": float(scaler.get_scale()) if not args.no_fp16 else None}), flush=True)
