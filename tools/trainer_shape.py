@@ -160,6 +160,10 @@ for w in range(1 if args.profile else 3):
     torch.cuda.synchronize()
     windows.append((time.perf_counter() - t0) / args.steps * 1e3)
 el = float(np.median(windows)) * args.steps / 1e3
+quality_after = None
+if args.evaluate:
+    acc, wrong_mean, wrong_max = quality.test_bitacc(stage, 100)
+    quality_after = {"steps_trained": args.warmup + args.steps * len(windows), "bit_acc": acc, "wrong_bits_worst_message": wrong_max, "psnr_db": quality.test_image(stage)}
 other = None
 if args.both and not args.profile:
     args.fused_step = not args.fused_step
@@ -183,10 +187,6 @@ if args.phases:
           "reserved MB", ms1["reserved_bytes.all.current"] / 1e6, file=sys.stderr)
     n = args.steps * len(windows)
     print("host wall per step by phase (ms; includes waiting for the GPU where a phase synchronises):", {k: round(v / n * 1e3, 3) for k, v in PH.items()}, file=sys.stderr)
-quality_after = None
-if args.evaluate:
-    acc, wrong_mean, wrong_max = quality.test_bitacc(stage, 100)
-    quality_after = {"steps_trained": args.warmup + args.steps * len(windows), "bit_acc": acc, "wrong_bits_worst_message": wrong_max, "psnr_db": quality.test_image(stage)}
 os.dup2(real_stdout, 1)
 print(json.dumps({"what": "what the UNCHANGED reference CLI runs on top of the drop-in directory: the reference Trainer's loop body (utils_wtmk_disen.py:1164-1190) -- eager, autocast(fp16) + "
                           "GradScaler, plain torch.optim.Adam, loader-style rays per step, three .item() reads per step -- around this repo's model; NOT the headline path",
