@@ -33,8 +33,17 @@ for name in ("os", "np", "optim", "seed_everything", "PSNRMeter", "LPIPSMeter", 
 import nerf_signature_amd.trainer as our_trainer
 assert u.Trainer.__mro__[1] is ref_u.Trainer and u.Trainer.train_step is our_trainer.reference_trainer_train_step
 assert {k for k in vars(u.Trainer) if not k.startswith("__")} == {"train_step"}       # nothing else of the Trainer is touched
-import nerf.provider_wtmk as prov                       # another module of the reference: still its own file
+import nerf.provider_wtmk as prov                       # another module of the reference: still its own file ...
 assert prov.__file__.startswith(REF)
+import nerf.utils_wtmk as uw, nerf._reference_utils_wtmk as ref_uw, nerf_signature_amd.rays as our_rays      # ... which takes get_rays from the shadowed nerf.utils_wtmk
+assert uw.__file__.startswith(ROOT) and ref_uw.__file__.startswith(REF) and prov.get_rays is uw.get_rays and uw.get_rays is not ref_uw.get_rays
+assert {k for k in vars(ref_uw) if not k.startswith("_") and getattr(uw, k, None) is not getattr(ref_uw, k)} == {"get_rays"}
+import torch
+_poses = torch.eye(4)[None]
+_intr = [50.0, 50.0, 8.0, 8.0]
+torch.manual_seed(3); a = uw.get_rays(_poses, _intr, 16, 16, 10)          # CPU poses: the reference's own function
+torch.manual_seed(3); b = ref_uw.get_rays(_poses, _intr, 16, 16, 10)
+assert sorted(a) == sorted(b) and all(torch.equal(a[k], b[k]) for k in a)
 # main_nerf_wtmk.py:93-102,110: the model is built and its optimiser groups taken exactly as the CLI does
 m = nerf.network_wtmk_tcnn.NeRFNetwork(bound=1.0, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1, message_dim=32, n_views=1)
 import torch

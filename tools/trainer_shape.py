@@ -32,12 +32,15 @@ ap.add_argument("--no-auto-fix", action="store_true")
 ap.add_argument("--reference-operators", action="store_true", help="NERFSIG_DROPIN_TRAIN_STEP=0: the operator sequence the reference's own Trainer.train_step issues around model.render "
                                                                    "and model.msg_decoder, instead of the method the drop-in directory binds in its place (this repo's fused train_step)")
 ap.add_argument("--distortion", default="none")
+ap.add_argument("--reference-loader", action="store_true", help="NERFSIG_DROPIN_GET_RAYS=0: the reference's own meshgrid-style get_rays (utils_wtmk.py:57-143, ~25 small launches) in the "
+                                                                "loader instead of the drop-in directory's (dropin/nerf/utils_wtmk.py -> rays.get_rays: same draws, one launch)")
 ap.add_argument("--evaluate", action="store_true", help="after the timed steps: Trainer.test_bitacc over 100 random messages and test_image PSNR (quality.py) -- with --steps 330 and the "
                                                         "default three windows the loop has run the reference's whole 1000-step schedule by then")
 ap.add_argument("--both", action="store_true", help="after the timed windows, time one more window with the other train_step (see --reference-operators) and report it next to the first")
 args = ap.parse_args()
 args.fused_step = not args.reference_operators
 
+from nerf_signature_amd import _native as nv
 from nerf_signature_amd import quality, synthetic, trainer
 
 real_stdout = os.dup(1)
@@ -55,12 +58,18 @@ wm = {"rays_o_block": stage["block_o"], "rays_d_block": stage["block_d"]}
 if args.fix_rays:
     model.fix_rays(wm["rays_o_block"], wm["rays_d_block"], opt_ns["dt_gamma"], opt_ns["max_steps"])
 poses, clean, intr = stage["poses"], stage["clean"], stage["intr"]
+intr4 = tuple(float(v) for v in intr)
 
 
 def loader(k):
     p = k % poses.shape[0]
     inds = torch.randint(0, H * W, size=[4096], device=dev).expand([1, 4096])                            # utils_wtmk_disen.py:105
-    o, d = synthetic.get_rays(poses[p:p + 1], intr, H, W, inds)                                           # the reference's meshgrid formulation (:59-143)
+    if args.reference_loader or not args.fused_step:
+        o, d = synthetic.get_rays(poses[p:p + 1], intr, H, W, inds)                                       # the reference's meshgrid formulation (utils_wtmk.py:57-143)
+    else:                                                                                                 # what dropin/nerf/utils_wtmk.py binds: rg_get_rays
+        o = torch.empty(1, 4096, 3, dtype=torch.float32, device=dev)
+        d = torch.empty(1, 4096, 3, dtype=torch.float32, device=dev)
+        nv.call("rg_get_rays", nv.ptr(poses[p:p + 1].contiguous()), *intr4, int(H), int(W), nv.ptr(inds.contiguous()), 1, 4096, nv.ptr(o), nv.ptr(d), nv.stream())
     images = torch.gather(clean[p:p + 1], 1, torch.stack(3 * [inds], -1))                                 # provider_wtmk.py collate
     return {"watermark": wm, "content": {"rays_o": o, "rays_d": d, "images": images}}
 
@@ -196,4 +205,5 @@ print(json.dumps({"what": "what the UNCHANGED reference CLI runs on top of the d
                   **({} if other is None else {("ms_per_step_with_the_references_own_train_step_operators" if args.fused_step else "ms_per_step_with_the_bound_train_step"): round(other, 4)}),
                   "block_graph": (lambda g: None if g is None else {"captures": g.captures, "replays": g.generation, "failed": g.failed})(me.__dict__.get("_nsig_block_graph")),
                   **({} if quality_after is None else {"quality_after": quality_after}),
+                  "loader": "the reference's own get_rays (meshgrid formulation)" if (args.reference_loader or not args.fused_step) else "get_rays as the drop-in directory binds it (dropin/nerf/utils_wtmk.py: one launch)",
                   "fix_rays": bool(args.fix_rays), "shared_gradient_step": bool(model.shared_gradient_step), "auto_fix_rays": bool(model.auto_fix_rays), "loss": last[0] if last else None, "grad_scale": float(scaler.get_scale()) if not args.no_fp16 else None}), flush=True)
