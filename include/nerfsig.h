@@ -306,6 +306,13 @@ int hg_encode_planes(const float *xyzs, uint32_t M, float bound, const float *co
  * launch, the plane stride and every buffer are sized for M_capacity, rows beyond the count are skipped (the eval loop above). */
 int hg_encode_planes_rows(const float *xyzs, uint32_t M_capacity, const uint32_t *rows_dev, float bound,
                           const float *const *base_tables_host, const float *S, void *planes, nsig_stream_t stream);
+/* The plane set in the MIXED layout, for the fp16 MLP only (mlp_set_precision(1)): levels 0..14 as fp16 pairs -- exactly the words of the MLP's first-layer
+ * operand, rounded to nearest even here instead of at the MLP's load: bit-identical results -- followed by level 15 and the codebook level as float2 (the codebook
+ * is added to level 15 before the rounding, network_wtmk_tcnn.py:106).  76 instead of 136 bytes per point each way between encoder and MLP; same buffer size
+ * (hg_planes_bytes).  The library remembers by address which sets are mixed: field_fwd / field_fwd_rows / field_fwd_kept / hg_encode_codebook_plane read them
+ * accordingly, field_fwd_trace and the split-bf16 MLP refuse them, hg_encode_planes on the same address makes it an fp32 set again.  rows_dev may be NULL. */
+int hg_encode_planes_mixed(const float *xyzs, uint32_t M_capacity, const uint32_t *rows_dev, float bound, const float *const *base_tables_host,
+                           const float *S, void *planes, nsig_stream_t stream);
 int field_fwd_rows(const float *xyzs, const float *dirs, uint32_t M_capacity, const uint32_t *rows_dev, float bound,
                    const float *const *base_tables_host, const float *S, const void *packed, float *sigmas, float *rgbs, const void *planes,
                    nsig_stream_t stream);

@@ -45,6 +45,7 @@ SIGNATURES = {
     "rm_eval_composite": [_vp, _u32, _fl, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "rm_eval_compact": [_vp, _u32, _u32, _vp, _vp, _vp],
     "hg_encode_planes_rows": [_vp, _u32, _vp, _fl, _vp, _vp, _vp, _vp],
+    "hg_encode_planes_mixed": [_vp, _u32, _vp, _fl, _vp, _vp, _vp, _vp],
     "field_fwd_rows": [_vp, _vp, _u32, _vp, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hg_codebook_presum": [_vp, _u32, _vp, _vp],
     "hg_codebook_presum_sel": [_vp, _vp, _u32, _vp, _vp],

@@ -27,6 +27,8 @@
 //     network_wtmk_tcnn.py:90-95), so the forward saves just the ReLU sign bits (6 words per point).
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <unordered_set>
 #include "hashgrid.h"
 
 #include <stdlib.h>
@@ -399,8 +401,25 @@ __device__ inline uint32_t dpp_u(uint32_t v, int ctrl) {
 }
 
 // One level of one 256-point tile: lane pairs fetch the two x sides (see above), trilinear interpolation, one streaming store.
+// Two layouts of a plane set (17 feature planes of `stride` points):
+//   fp32   planes[level][point] float2 -- every consumer reads it;
+//   mixed  levels 0..14 as fp16 pairs (4 bytes per point), then level 15 and the codebook level as float2 -- written by hg_encode_planes_mixed for the fp16
+//          MLP, whose first-layer operand is exactly those fp16 pairs (rounded to nearest even here instead of at the MLP's load: the same bits).  Level 15
+//          stays fp32 because the codebook is added to it BEFORE the rounding (network_wtmk_tcnn.py:106).  15 x 4 + 2 x 8 = 76 instead of 136 bytes per point
+//          each way between the encoder and the MLP.
+constexpr int kHalfLevels = NSIG_BASE_LEVELS - 1;
+__device__ __host__ inline float2 *mixed_f32_plane(void *planes, uint32_t stride, int level) {      // level 15 or 16 of a mixed set
+    return reinterpret_cast<float2 *>(reinterpret_cast<uint32_t *>(planes) + (size_t)kHalfLevels * stride) + (size_t)(level - kHalfLevels) * stride;
+}
+__device__ inline float2 load_plane(const float2 *__restrict__ planes, uint32_t stride, int level, uint32_t s, bool mixed) {
+    if (!mixed) return planes[(size_t)level * stride + s];
+    if (level >= kHalfLevels) return mixed_f32_plane(const_cast<float2 *>(planes), stride, level)[s];
+    const f32x2 w = __builtin_convertvector(__builtin_bit_cast(f16x2, reinterpret_cast<const uint32_t *>(planes)[(size_t)level * stride + s]), f32x2);
+    return make_float2(w[0], w[1]);
+}
+
 __device__ inline void encode_tile_level(const float2 *__restrict__ table, float cell, bool sc1, uint32_t xs, float x, float y, float z,
-                                         float2 *__restrict__ out) {
+                                         float2 *__restrict__ out, bool half_out = false) {
     auto ld = [&](uint32_t row) -> float2 {
         if (!sc1) return table[row];
         const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(table + row), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -434,6 +453,10 @@ __device__ inline void encode_tile_level(const float2 *__restrict__ table, float
         e[4 + q] = xs ? mine : got;
     }
     const float2 val = trilerp(e, wx, wy, wz);
+    if (half_out) {      // (a level of a mixed plane set: `out` addresses 4-byte elements)
+        __builtin_nontemporal_store(cvt_pk_f16(val.x, val.y), reinterpret_cast<uint32_t *>(out));
+        return;
+    }
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
     const f32x2_t vv = {val.x, val.y};
     __builtin_nontemporal_store(vv, reinterpret_cast<f32x2_t *>(out));
@@ -458,7 +481,7 @@ __global__ void __launch_bounds__(256) k_warm_tables(TablePtrs base, const float
 // Workgroup (tile, slot) encodes, for its 256 points, the levels (or the part of a level's tile range) assigned to its XCD slot.
 __global__ void __launch_bounds__(256) k_encode_planes(const float *__restrict__ xyzs, uint32_t M, float bound, TablePtrs base, LevelGeom geom,
                                                        const float *__restrict__ S, float2 *__restrict__ planes, uint32_t stride, SlotTable tab,
-                                                       const uint32_t *__restrict__ rows_dev = nullptr) {
+                                                       const uint32_t *__restrict__ rows_dev = nullptr, bool mixed = false) {
     // rows_dev (the eval loop's bursts, hg_encode_planes_rows): the number of rows that exist is known on the device only; the launch is sized for `M`
     // (the buffers' capacity, which also fixes the plane stride) and rows beyond the count are skipped
     uint32_t lim = stride;
@@ -485,8 +508,10 @@ __global__ void __launch_bounds__(256) k_encode_planes(const float *__restrict__
             if ((tab.skip_mask >> l) & 1u) continue;
             const unsigned long long pos = (unsigned long long)tile * 4096ull;       // wave-uniform range test
             if (pos < (unsigned long long)tab.lo[slot][i] * n_tiles || pos >= (unsigned long long)tab.hi[slot][i] * n_tiles) continue;
-            encode_tile_level(reinterpret_cast<const float2 *>(l == NSIG_BASE_LEVELS ? S : base.p[l]), geom.cell[l], l >= (int)tab.sc1_from, xs, x, y, z,
-                              planes + (size_t)l * stride + m);
+            const bool half_out = mixed && l < kHalfLevels;
+            float2 *out = !mixed ? planes + (size_t)l * stride + m
+                                 : (half_out ? reinterpret_cast<float2 *>(reinterpret_cast<uint32_t *>(planes) + (size_t)l * stride + m) : mixed_f32_plane(planes, stride, l) + m);
+            encode_tile_level(reinterpret_cast<const float2 *>(l == NSIG_BASE_LEVELS ? S : base.p[l]), geom.cell[l], l >= (int)tab.sc1_from, xs, x, y, z, out, half_out);
         }
     }
 }
@@ -541,22 +566,35 @@ __device__ inline float2 codebook_half_gather(const float2 *__restrict__ S, floa
 // (~0.9 us of a tile) cannot cover that.  Here every wait is for something issued a whole evaluation earlier:
 //     head of tile i:  wait for planes + directions of tile i (requested at the head of tile i-1)
 //                      -> issue the STORES of tile i-1's results (held in 7 registers) -> request planes + directions of tile i+1 -> evaluate tile i.
-template <typename P>
+template <typename P, bool kMixed>
 __device__ inline void field_fwd_pipelined(const char *lds, int lane, const float *__restrict__ dirs, uint32_t M, bool add_codebook,
                                            const float2 *__restrict__ planes, uint32_t stride, float *__restrict__ sigmas, float *__restrict__ rgbs,
                                            uint32_t *__restrict__ masks) {
+    static_assert(!kMixed || P::kMfmaPerProduct == 1, "mixed plane sets carry fp16 operands: the fp16 MLP only");
     constexpr size_t kHalf = kFwdBytes;
     const int p = lane & 31, h = lane >> 5;
     const uint32_t n_tiles = ceil_div(M, 32u);
     const uint32_t first = blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), step = gridDim.x * 4;
-    float2 nf[8], nc = make_float2(0.0f, 0.0f);
+    // fp32 set: nf[q] = level 8 (q >> 2) + (q & 3) + 4 h.  mixed set: nh[q] holds the level's fp16 pair -- already the operand word -- except for
+    // level 15 (q = 7 of lane half 1), which arrives as float2 in nf[7] and takes the codebook before it is rounded.
+    float2 nf[8] = {}, nc = make_float2(0.0f, 0.0f);
+    uint32_t nh[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
     f32x3u nd = {0.0f, 0.0f, 0.0f};      // one 12-byte value across the loop: as three scalars the loaded triple is copied into their registers right behind the load -- a wait
     auto request = [&](uint32_t tile) {
         const uint32_t s = tile * 32 + p, sl = min(s, M - 1);
+        if constexpr (kMixed) {
+            const uint32_t *hp = reinterpret_cast<const uint32_t *>(planes);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) nf[q] = planes[(size_t)(8 * (q >> 2) + (q & 3) + 4 * h) * stride + s];  // 256 contiguous bytes per half-wave
-        if (add_codebook && h) nc = planes[(size_t)NSIG_BASE_LEVELS * stride + s];
+            for (int q = 0; q < 7; ++q) nh[q] = hp[(size_t)(8 * (q >> 2) + (q & 3) + 4 * h) * stride + s];      // 128 contiguous bytes per half-wave
+            if (h) nf[7] = mixed_f32_plane(const_cast<float2 *>(planes), stride, NSIG_BASE_LEVELS - 1)[s];
+            else nh[7] = hp[(size_t)11 * stride + s];
+            if (add_codebook && h) nc = mixed_f32_plane(const_cast<float2 *>(planes), stride, NSIG_BASE_LEVELS)[s];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) nf[q] = planes[(size_t)(8 * (q >> 2) + (q & 3) + 4 * h) * stride + s];  // 256 contiguous bytes per half-wave
+            if (add_codebook && h) nc = planes[(size_t)NSIG_BASE_LEVELS * stride + s];
+        }
         nd = *reinterpret_cast<const f32x3u *>(dirs + 3 * (size_t)sl);
     };
     if (first >= n_tiles) return;
@@ -582,8 +620,15 @@ __device__ inline void field_fwd_pipelined(const char *lds, int lane, const floa
             nf[7].x = nf[7].x + nc.x;
             nf[7].y = nf[7].y + nc.y;
         }
+        if constexpr (kMixed) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) P::put2(feat[q >> 2], q & 3, nf[q].x, nf[q].y);
+            for (int q = 0; q < 7; ++q) feat[q >> 2].v[q & 3] = nh[q];
+            const uint32_t top = cvt_pk_f16(nf[7].x, nf[7].y);
+            feat[1].v[3] = h ? top : nh[7];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) P::put2(feat[q >> 2], q & 3, nf[q].x, nf[q].y);
+        }
         float dx = nd.x, dy = nd.y, dz = nd.z;
         // A compiler barrier that consumes this tile's inputs: the wait for them (vmcnt counts in order) is placed HERE, where only they and
         // long-acknowledged stores are outstanding -- left free, the compiler issues the next tile's requests first and then has to drain them too.
@@ -660,7 +705,7 @@ __device__ inline void field_fwd_pipelined(const char *lds, int lane, const floa
 // 164 registers: three waves per SIMD would fit, but the launch uses TWO workgroups per CU (field_grid(.., 2)): the kernel takes 57 us with 512, 768 or
 // 1024 workgroups (71 us for the plain loop it replaces), and the step is shortest with 512 -- the content render's kernels run beside this launch
 // (same box, three rounds: 1.051-1.063 ms against 1.064-1.070 with 768 and 1.062-1.074 with 1024).
-template <typename P>
+template <typename P, bool kMixed = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_field_fwd_train(const float *__restrict__ dirs, uint32_t M, bool add_codebook, const float2 *__restrict__ planes, uint32_t stride,
                   const char *__restrict__ packed, float *__restrict__ sigmas, float *__restrict__ rgbs, uint32_t *__restrict__ masks,
@@ -672,7 +717,7 @@ k_field_fwd_train(const float *__restrict__ dirs, uint32_t M, bool add_codebook,
         M = min(M, r);
     }
     stage_weights(lds, packed + P::kFwdOffset, (int)P::kFwdLds);
-    field_fwd_pipelined<P>(lds, threadIdx.x & 63, dirs, M, add_codebook, planes, stride, sigmas, rgbs, masks);
+    field_fwd_pipelined<P, kMixed>(lds, threadIdx.x & 63, dirs, M, add_codebook, planes, stride, sigmas, rgbs, masks);
 }
 
 template <typename P, int kPlanes, bool kTrace = false>
@@ -681,7 +726,8 @@ __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyz
                                                    const float2 *__restrict__ planes, uint32_t stride,
                                                    const char *__restrict__ packed, float *__restrict__ sigmas, float *__restrict__ rgbs,
                                                    float *__restrict__ geo_out, uint32_t *__restrict__ masks, ActTrace trace = ActTrace{},
-                                                   BinHeader *__restrict__ plan_reset = nullptr, const uint32_t *__restrict__ rows_dev = nullptr) {
+                                                   BinHeader *__restrict__ plan_reset = nullptr, const uint32_t *__restrict__ rows_dev = nullptr,
+                                                   bool mixed = false) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     if (rows_dev != nullptr) {      // (field_fwd_rows)
         const uint32_t r = *rows_dev;
@@ -704,7 +750,7 @@ __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyz
         if (kPlanes) {
             float2 f[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) f[q] = planes[(size_t)(8 * (q >> 2) + (q & 3) + 4 * h) * stride + s];  // 256 contiguous bytes per half-wave
+            for (int q = 0; q < 8; ++q) f[q] = load_plane(planes, stride, 8 * (q >> 2) + (q & 3) + 4 * h, s, mixed);  // 256 (mixed: 128) contiguous bytes per half-wave
             if (kPlanes == 2) {
                 if (S != nullptr) {   // both halves gather (one x side each); half 1 owns level 15 and takes the sum
                     const float two_b = 2.0f * bound;
@@ -717,7 +763,7 @@ __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyz
                     }
                 }
             } else if (S != nullptr && h) {  // codebook added into channels 30:32 (network_wtmk_tcnn.py:106)
-                const float2 c = planes[(size_t)NSIG_BASE_LEVELS * stride + s];
+                const float2 c = load_plane(planes, stride, NSIG_BASE_LEVELS, s, mixed);
                 f[7].x = f[7].x + c.x;
                 f[7].y = f[7].y + c.y;
             }
@@ -1262,8 +1308,22 @@ NSIG_EXPORT int hg_warm_tables(const float *const *base_tables_host, const float
 
 NSIG_EXPORT size_t hg_planes_bytes(uint32_t M) { return (size_t)(NSIG_BASE_LEVELS + 1) * ceil_div(M, 32u) * 32u * sizeof(float2); }
 
+// Which plane sets were last written in the mixed layout (hg_encode_planes_mixed), by address: the entry points that read or complete a plane set
+// (field_fwd*, hg_encode_codebook_plane) look their `planes` argument up here; hg_encode_planes (fp32) takes an address out again.
+static std::mutex g_mixed_mutex;
+static std::unordered_set<const void *> g_mixed_sets;
+static void note_layout(const void *planes, bool mixed) {
+    std::lock_guard<std::mutex> lock(g_mixed_mutex);
+    if (mixed) g_mixed_sets.insert(planes);
+    else g_mixed_sets.erase(planes);
+}
+static bool is_mixed(const void *planes) {
+    std::lock_guard<std::mutex> lock(g_mixed_mutex);
+    return g_mixed_sets.count(planes) != 0;
+}
+
 static int encode_planes_impl(const float *xyzs, uint32_t M, float bound, const float *const *base_tables_host, const float *S, void *planes,
-                              const uint32_t *rows_dev, nsig_stream_t stream) {
+                              const uint32_t *rows_dev, nsig_stream_t stream, bool mixed = false) {
     if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(xyzs && planes, "hg_encode_planes: null pointer");
     NSIG_REQUIRE(bound > 0.0f, "hg_encode_planes: bound must be positive");
@@ -1283,8 +1343,15 @@ static int encode_planes_impl(const float *xyzs, uint32_t M, float bound, const 
     // render's launch takes 244-247 us against 258-261 us with 1024 looping workgroups per slot (same-box sweep, profiles/r01_k_encoder_grid_sweep.txt)
     static const uint32_t cap = getenv("NERFSIG_ENC_PER_SLOT") ? (uint32_t)atoi(getenv("NERFSIG_ENC_PER_SLOT")) : 8192u;
     const uint32_t per_slot = tiles < cap ? tiles : cap;
-    k_encode_planes<<<per_slot * 8, 256, 0, as_stream(stream)>>>(xyzs, M, bound, base, make_level_geom(), S, reinterpret_cast<float2 *>(planes), stride, tab, rows_dev);
+    note_layout(planes, mixed);
+    k_encode_planes<<<per_slot * 8, 256, 0, as_stream(stream)>>>(xyzs, M, bound, base, make_level_geom(), S, reinterpret_cast<float2 *>(planes), stride, tab, rows_dev, mixed);
     return check_launch("hg_encode_planes");
+}
+
+NSIG_EXPORT int hg_encode_planes_mixed(const float *xyzs, uint32_t M_capacity, const uint32_t *rows_dev, float bound, const float *const *base_tables_host,
+                                       const float *S, void *planes, nsig_stream_t stream) {
+    NSIG_REQUIRE(mlp_precision() == 1, "hg_encode_planes_mixed: the mixed layout carries the fp16 MLP's operands (mlp_set_precision(1))");
+    return encode_planes_impl(xyzs, M_capacity, bound, base_tables_host, S, planes, rows_dev, stream, true);
 }
 
 NSIG_EXPORT int hg_encode_planes(const float *xyzs, uint32_t M, float bound, const float *const *base_tables_host, const float *S, void *planes,
@@ -1306,7 +1373,7 @@ NSIG_EXPORT int hg_encode_codebook_plane(const float *xyzs, uint32_t M, float bo
     NSIG_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 7) == 0, "hg_encode_codebook_plane: planes must be 8-byte aligned");
     NSIG_REQUIRE(plan_to_reset == nullptr || (reinterpret_cast<uintptr_t>(plan_to_reset) & 15) == 0, "hg_encode_codebook_plane: plan must be 16-byte aligned");
     const uint32_t stride = ceil_div(M, 32u) * 32u;
-    float2 *plane = reinterpret_cast<float2 *>(planes) + (size_t)NSIG_BASE_LEVELS * stride;
+    float2 *plane = is_mixed(planes) ? mixed_f32_plane(planes, stride, NSIG_BASE_LEVELS) : reinterpret_cast<float2 *>(planes) + (size_t)NSIG_BASE_LEVELS * stride;
     k_encode_codebook_plane<<<ceil_div(stride, 256u), 256, 0, as_stream(stream)>>>(xyzs, M, bound, make_level_geom().cell[NSIG_BASE_LEVELS], S, plane, stride,
                                                                                   reinterpret_cast<BinHeader *>(plan_to_reset));
     return check_launch("hg_encode_codebook_plane");
@@ -1333,11 +1400,14 @@ static int field_fwd_impl(const float *xyzs, const float *dirs, uint32_t M, floa
     NSIG_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 7) == 0, "field_fwd: planes must be 8-byte aligned");
     const uint32_t stride = ceil_div(M, 32u) * 32u;
     const float2 *pl = reinterpret_cast<const float2 *>(planes);
+    const bool mixed = is_mixed(planes);
+    NSIG_REQUIRE(!mixed || f16, "field_fwd: this plane set was written in the mixed (fp16) layout; the split-bf16 MLP needs hg_encode_planes");
     if (f16 && fwd_pipelined() && dirs != nullptr && rgbs != nullptr && geo_feat == nullptr) {    // the training render's launch (masks) and staged no-grad renders
-        k_field_fwd_train<F16><<<field_grid(M, true, 2), 256, F16::kFwdLds, st>>>(dirs, M, S != nullptr, pl, stride, pk, sigmas, rgbs, masks, rows_dev);
+        if (mixed) k_field_fwd_train<F16, true><<<field_grid(M, true, 2), 256, F16::kFwdLds, st>>>(dirs, M, S != nullptr, pl, stride, pk, sigmas, rgbs, masks, rows_dev);
+        else k_field_fwd_train<F16, false><<<field_grid(M, true, 2), 256, F16::kFwdLds, st>>>(dirs, M, S != nullptr, pl, stride, pk, sigmas, rgbs, masks, rows_dev);
         return check_launch("field_fwd");
     }
-    if (f16) k_field_fwd<F16, 1><<<field_grid(M, true), 256, F16::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, geo_feat, masks, ActTrace{}, nullptr, rows_dev);
+    if (f16) k_field_fwd<F16, 1><<<field_grid(M, true), 256, F16::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, geo_feat, masks, ActTrace{}, nullptr, rows_dev, mixed);
     else k_field_fwd<Bf16x3, 1><<<field_grid(M, true), 256, Bf16x3::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, geo_feat, masks, ActTrace{}, nullptr, rows_dev);
     return check_launch("field_fwd");
 }
@@ -1367,8 +1437,10 @@ NSIG_EXPORT int field_fwd_kept(const float *xyzs, const float *dirs, uint32_t M,
     const uint32_t stride = ceil_div(M, 32u) * 32u;
     const float2 *pl = reinterpret_cast<const float2 *>(planes);
     BinHeader *hd = reinterpret_cast<BinHeader *>(plan_to_reset);
+    const bool mixed = is_mixed(planes);
+    NSIG_REQUIRE(!mixed || mlp_precision() == 1, "field_fwd_kept: this plane set was written in the mixed (fp16) layout; the split-bf16 MLP needs hg_encode_planes");
     if (mlp_precision() == 1)
-        k_field_fwd<F16, 2><<<field_grid(M, true), 256, F16::kFwdLds, st>>>(xyzs, dirs, M, bound, TablePtrs{}, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, nullptr, masks, ActTrace{}, hd);
+        k_field_fwd<F16, 2><<<field_grid(M, true), 256, F16::kFwdLds, st>>>(xyzs, dirs, M, bound, TablePtrs{}, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, nullptr, masks, ActTrace{}, hd, nullptr, mixed);
     else
         k_field_fwd<Bf16x3, 2><<<field_grid(M, true), 256, Bf16x3::kFwdLds, st>>>(xyzs, dirs, M, bound, TablePtrs{}, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, nullptr, masks, ActTrace{}, hd);
     return check_launch("field_fwd_kept");
@@ -1427,6 +1499,7 @@ NSIG_EXPORT int field_fwd_trace(const float *xyzs, const float *dirs, uint32_t M
     if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(xyzs && dirs && packed && planes && sigmas && rgbs && masks && act_hs && act_cin && act_h1 && act_h2, "field_fwd_trace: null pointer");
     NSIG_REQUIRE(bound > 0.0f, "field_fwd_trace: bound must be positive");
+    NSIG_REQUIRE(!is_mixed(planes), "field_fwd_trace: this plane set was written in the mixed (fp16) layout; stage 1 trains through fp32 planes (hg_encode_planes)");
     TablePtrs base{};
     if (int e = fill_base_tables(base_tables_host, base, "field_fwd_trace")) return e;
     const uint32_t stride = ceil_div(M, 32u) * 32u;

@@ -126,6 +126,22 @@ PLANES_MIN_POINTS = int(os.environ.get("NERFSIG_PLANES_MIN", "16384"))  # below 
 KEPT_ONE_LAUNCH = os.environ.get("NERFSIG_KEPT_ONE_LAUNCH", "0") == "1"
 
 
+def mixed_planes():
+    """The feature planes between encoder and MLP in the mixed layout (levels 0..14 as the fp16 pairs the fp16 MLP's first layer consumes, hg_encode_planes_mixed:
+    76 instead of 136 bytes per point each way, bit-identical results) -- with the default (fp16) MLP; fp32 planes for the split-bf16 one.  NERFSIG_HALF_PLANES=0: always fp32."""
+    return nv.fn("mlp_get_precision")() == 1 and os.environ.get("NERFSIG_HALF_PLANES", "1") != "0"
+
+
+def encode_planes(xyzs, M, bound, base_ptrs, S, planes, rows_dev=None):
+    """The 16 base levels (+ the codebook level through S) of M points into a plane set, in the layout the MLP that follows will read (mixed_planes)."""
+    if mixed_planes():
+        nv.call("hg_encode_planes_mixed", nv.ptr(xyzs), M, nv.ptr(rows_dev), float(bound), base_ptrs, nv.ptr(S), nv.ptr(planes), nv.stream())
+    elif rows_dev is not None:
+        nv.call("hg_encode_planes_rows", nv.ptr(xyzs), M, nv.ptr(rows_dev), float(bound), base_ptrs, nv.ptr(S), nv.ptr(planes), nv.stream())
+    else:
+        nv.call("hg_encode_planes", nv.ptr(xyzs), M, float(bound), base_ptrs, nv.ptr(S), nv.ptr(planes), nv.stream())
+
+
 def field_forward(xyzs, dirs, bound, base_tables, S, packed, want_rgb=True, want_geo=False, want_masks=False, planes=None, fixed=None):
     """sigma [M], rgb [M,3] | None, geo_feat [M,15] | None, masks | None -> field_fwd.
     planes: True/False forces the two-kernel (XCD-partitioned encoder + MLP) / fused route; None picks by size.
@@ -153,7 +169,7 @@ def field_forward(xyzs, dirs, bound, base_tables, S, packed, want_rgb=True, want
             nv.call("hg_encode_codebook_plane", nv.ptr(xyzs), M, float(bound), nv.ptr(S), nv.ptr(ws), reset, nv.stream())
     elif use_planes:
         ws = torch.empty(int(nv.fn("hg_planes_bytes")(M)), dtype=torch.uint8, device=dev)
-        nv.call("hg_encode_planes", nv.ptr(xyzs), M, float(bound), base_ptrs, nv.ptr(S), nv.ptr(ws), nv.stream())
+        encode_planes(xyzs, M, bound, base_ptrs, S, ws)
     nv.call("field_fwd", nv.ptr(xyzs), nv.ptr(dirs) if want_rgb else None, M, float(bound), base_ptrs, nv.ptr(S), nv.ptr(packed),
             nv.ptr(sigmas), nv.ptr(rgbs), nv.ptr(geo), nv.ptr(masks), nv.ptr(ws), nv.stream())
     return sigmas, rgbs, geo, masks
@@ -324,13 +340,14 @@ class FixedPoints:
 
     @staticmethod
     def _tables_key(base_tables):
-        return tuple((t.data_ptr(), t._version) for t in base_tables)
+        # (+ the layout the planes are written in: it follows the MLP's precision mode, see encode_planes)
+        return tuple((t.data_ptr(), t._version) for t in base_tables) + (mixed_planes(),)
 
     def refresh(self, xyzs, base_tables):
         if xyzs.data_ptr() != self.xyzs_ptr or xyzs.shape[0] != self.M:
             raise ValueError("FixedPoints.refresh: these are not the points the cache was built for")
         base_ptrs = nv.ptr_array([_check_table(t.detach(), "base table") for t in base_tables])
-        nv.call("hg_encode_planes", nv.ptr(xyzs), self.M, self.bound, base_ptrs, None, nv.ptr(self.planes), nv.stream())
+        encode_planes(xyzs, self.M, self.bound, base_ptrs, None, self.planes)
         nv.call("hg_scatter_plan", nv.ptr(xyzs), self.M, self.bound, nv.ptr(self.plan.buf), nv.stream())
         self.key = self._tables_key(base_tables)
         self.refreshes += 1

@@ -203,7 +203,7 @@ class NeRFNetwork(NeRFRenderer):
 
         def run(xyzs, dirs, rows_dev, sigmas, rgbs):
             if use_planes:
-                nv.call("hg_encode_planes_rows", nv.ptr(xyzs), capacity, nv.ptr(rows_dev), bound, base_ptrs, nv.ptr(S), nv.ptr(ws), nv.stream())
+                fo.encode_planes(xyzs, capacity, bound, base_ptrs, S, ws, rows_dev)
             nv.call("field_fwd_rows", nv.ptr(xyzs), nv.ptr(dirs), capacity, nv.ptr(rows_dev), bound, base_ptrs, nv.ptr(S), nv.ptr(packed), nv.ptr(sigmas),
                     nv.ptr(rgbs), nv.ptr(ws), nv.stream())
             run.keep = (base, S, packed, ws)      # (the launches above hold raw addresses)

@@ -422,3 +422,66 @@ def test_pipelined_training_launches_equal_the_plain_loops_bit_for_bit(fo, table
     finally:
         nv.call("mlp_set_precision", before_prec)
         nv.call("mlp_set_pipelined", before_pipe)
+
+
+def test_mixed_plane_sets_equal_fp32_plane_sets_bit_for_bit(fo, tables, monkeypatch):
+    """hg_encode_planes_mixed (levels 0..14 as the fp16 pairs of the fp16 MLP's first-layer operand, level 15 + codebook as float2: 76 instead of 136 bytes per
+    point) against fp32 plane sets (NERFSIG_HALF_PLANES=0) through every consumer: the pipelined training launch (sigma, rgb, ReLU masks), the plain loop
+    (geo features requested), the kept route (FixedPoints + hg_encode_codebook_plane), a device row count; with and without a codebook; point counts that are
+    and are not multiples of the tile.  Same bits everywhere.  And the guards: a mixed set is refused by the split-bf16 MLP and by the stage-1 trace kernel."""
+    from nerf_signature_amd import _native as nv
+    base, cb, base_d, cb_d = tables
+    _, sp, cp = _params(tables)
+    packed = fo.pack_weights(sp, cp)
+    before = nv.fn("mlp_get_precision")()
+    nv.set_mlp_precision("f16")
+    try:
+        msg = torch.from_numpy(cf.messages(32)[1])
+        S = fo.codebook_presum(fo.select_tables(cb_d[:64], fo.message_bits(msg)))
+        for M in (20000, 70001):
+            rng = np.random.RandomState(M)
+            pts = torch.from_numpy((rng.rand(M, 3) * 2 - 1).astype(np.float32)).cuda()
+            dirs = torch.from_numpy(cf.unit_dirs(M, seed=6)).cuda()
+            got = {}
+            for half in ("0", "1"):
+                monkeypatch.setenv("NERFSIG_HALF_PLANES", half)
+                assert fo.mixed_planes() == (half == "1")
+                out = []
+                for s_ in (S, None):
+                    out += [t for t in fo.field_forward(pts, dirs, 1.0, base_d, s_, packed, want_masks=True, planes=True) if t is not None]      # pipelined launch
+                    out += [t for t in fo.field_forward(pts, dirs, 1.0, base_d, s_, packed, want_geo=True, planes=True) if t is not None]        # plain loop
+                kept = fo.FixedPoints(pts, 1.0, base_d)
+                out += [t for t in fo.field_forward(pts, dirs, 1.0, base_d, S, packed, want_masks=True, fixed=kept) if t is not None]
+                rows = torch.tensor([M - 777], dtype=torch.int32, device="cuda")
+                ws = torch.zeros(int(nv.fn("hg_planes_bytes")(M)), dtype=torch.uint8, device="cuda")
+                sig, rgb = torch.zeros(M, device="cuda"), torch.zeros(M, 3, device="cuda")
+                base_ptrs = nv.ptr_array([t.detach() for t in base_d])
+                fo.encode_planes(pts, M, 1.0, base_ptrs, S, ws, rows)
+                nv.call("field_fwd_rows", nv.ptr(pts), nv.ptr(dirs), M, nv.ptr(rows), 1.0, base_ptrs, nv.ptr(S), nv.ptr(packed), nv.ptr(sig), nv.ptr(rgb), nv.ptr(ws), nv.stream())
+                out += [sig, rgb]
+                torch.cuda.synchronize()
+                got[half] = [t.clone() for t in out]
+            assert len(got["0"]) == len(got["1"]) >= 14
+            for a, b in zip(got["0"], got["1"]):
+                assert a.shape == b.shape and torch.equal(a, b)
+            assert float(got["1"][-1][M - 700:].abs().max()) == 0.0 and float(got["1"][-1][:M - 777].abs().max()) > 0      # rows beyond the device count: untouched
+        # guards
+        monkeypatch.setenv("NERFSIG_HALF_PLANES", "1")
+        M = 20000
+        pts, dirs = pts[:M].contiguous(), dirs[:M].contiguous()
+        ws = torch.zeros(int(nv.fn("hg_planes_bytes")(M)), dtype=torch.uint8, device="cuda")
+        base_ptrs = nv.ptr_array([t.detach() for t in base_d])
+        fo.encode_planes(pts, M, 1.0, base_ptrs, S, ws)
+        sig, rgb = torch.zeros(M, device="cuda"), torch.zeros(M, 3, device="cuda")
+        nv.set_mlp_precision("bf16x3")
+        assert not fo.mixed_planes()
+        with pytest.raises(ValueError, match="mixed"):
+            nv.call("field_fwd", nv.ptr(pts), nv.ptr(dirs), M, 1.0, base_ptrs, nv.ptr(S), nv.ptr(packed), nv.ptr(sig), nv.ptr(rgb), None, None, nv.ptr(ws), nv.stream())
+        with pytest.raises(ValueError, match="fp16"):
+            nv.call("hg_encode_planes_mixed", nv.ptr(pts), M, None, 1.0, base_ptrs, nv.ptr(S), nv.ptr(ws), nv.stream())
+        nv.call("hg_encode_planes", nv.ptr(pts), M, 1.0, base_ptrs, nv.ptr(S), nv.ptr(ws), nv.stream())       # the same address written as fp32 again: accepted
+        nv.call("field_fwd", nv.ptr(pts), nv.ptr(dirs), M, 1.0, base_ptrs, nv.ptr(S), nv.ptr(packed), nv.ptr(sig), nv.ptr(rgb), None, None, nv.ptr(ws), nv.stream())
+        torch.cuda.synchronize()
+        assert float(sig.abs().max()) > 0
+    finally:
+        nv.call("mlp_set_precision", before)
