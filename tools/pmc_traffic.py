@@ -62,7 +62,7 @@ doc = {
     "k_encode_planes": dict(traffic(enc_block) or {}, TCP_TCC_READ_REQ=(enc_block or {}).get("TCP_TCC_READ_REQ_sum"), TCP_TOTAL_CACHE_ACCESSES=(enc_block or {}).get("TCP_TOTAL_CACHE_ACCESSES_sum"),
                             launch="block render, 1,290,240 rows, head of the step"),
     "k_encode_planes_content_launch": traffic(enc_content),
-    "k_field_fwd_train": traffic(pick("k_field_fwd_train<F16> [block render]")),
+    "k_field_fwd_train": traffic(pick("k_field_fwd_train<F16, true> [block render]") or pick("k_field_fwd_train<F16, false> [block render]") or pick("k_field_fwd_train<F16> [block render]")),
     "k_field_bwd_train": traffic(pick("k_field_bwd_train<F16> [block render]")),
     "k_scatter_binned": traffic(pick("k_scatter_binned")),
     "k_codebook_adam_sel_next": traffic(pick("k_codebook_adam_sel<true, true>")),
