@@ -5,6 +5,7 @@ tag=$1
 cd $GRAFT_REPO_ROOT
 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || exit 1
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
+rm -rf $out      # (an earlier run of the same tag would otherwise leave its traces beside the new ones)
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --windows 1 > $out.log 2>&1) || exit 1
 python tools/kstats.py $out 30 40 > gpurun_out/${tag}_summary.txt
 python - $out >> gpurun_out/${tag}_summary.txt <<'PY'
@@ -34,5 +35,6 @@ if len(seq) >= 34:
     eager = seq[29:34]
     print(f"#   eager launches {eager}: avg {sum(eager) / 5:.1f} us  (compare roofline.avg_launch_s of the bench line of the same box)")
 PY
-python tools/timeline.py $out k_adam_prepare ${TL_BACK:-8} > gpurun_out/${tag}_timeline_graph_replay.txt
+python tools/timeline.py $out k_adam_prepare ${TL_BACK:-8} > gpurun_out/${tag}_timeline_fixed_blocks_variant.txt   # (the run ends with the variant's replays)
+python tools/timeline.py $out k_adam_prepare ${TL_HEAD:-45} > gpurun_out/${tag}_timeline_headline.txt
 cp $(ls $out/*/*_kernel_stats.csv | tail -1) gpurun_out/${tag}_kernel_stats.csv
