@@ -162,7 +162,7 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
     graphed = None
     eager_caller = block_graph is not None and main is None and shard is None and not presum_adopt
     # the content render's march and its one host read, in front of the block render: the read then waits for the march alone (NeRFRenderer.premarch)
-    premarch = (eager_caller and content["rays_o"].is_cuda and model.training and torch.is_grad_enabled() and hasattr(model, "premarch")
+    premarch = (eager_caller and content["rays_o"].is_cuda and model.training and torch.is_grad_enabled() and hasattr(model, "premarch") and getattr(model, "cuda_ray", False)
                 and getattr(model, "point_capacity", None) is None and not torch.cuda.is_current_stream_capturing() and os.environ.get("NERFSIG_DROPIN_PREMARCH", "1") != "0")
     if eager_caller and (distortion is None or isinstance(distortion, DistortionLayer)):
         whole = None
