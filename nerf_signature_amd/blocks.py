@@ -16,19 +16,24 @@ import torch
 
 
 def rand_poses(size, device, radius=1.0, theta_range=(np.pi / 3, 2 * np.pi / 3), phi_range=(0, 2 * np.pi)):
-    def normalize(v):
-        return v / (torch.norm(v, dim=-1, keepdim=True) + 1e-10)
-
-    thetas = torch.rand(size, device=device) * (theta_range[1] - theta_range[0]) + theta_range[0]
-    phis = torch.rand(size, device=device) * (phi_range[1] - phi_range[0]) + phi_range[0]
-    centers = torch.stack([radius * torch.sin(thetas) * torch.sin(phis), radius * torch.cos(thetas), radius * torch.sin(thetas) * torch.cos(phis)], dim=-1)
-    forward = -normalize(centers)
-    up = torch.tensor([0.0, -1.0, 0.0], device=device).unsqueeze(0).repeat(size, 1)
-    right = normalize(torch.cross(forward, up, dim=-1))
-    up = normalize(torch.cross(right, forward, dim=-1))
-    poses = torch.eye(4, dtype=torch.float, device=device).unsqueeze(0).repeat(size, 1, 1)
-    poses[:, :3, :3] = torch.stack((right, up, forward), dim=-1)
-    poses[:, :3, 3] = centers
+    """Random orbit cameras looking at the origin, [size,4,4] camera-to-world (provider_wtmk.py:61-96 -- same two uniform
+    draws, polar angle first).  The reference builds the look-at frame with two cross products against the world's -y axis;
+    on an orbit that frame has a closed form in the two angles, written out here: with s/c = sin/cos,
+        centre  = r (s_t s_p,  c_t, s_t c_p)       forward = -centre / r
+        right   = (-c_p, 0, s_p)                    up      = (c_t s_p, -s_t, c_t c_p)
+    (valid for polar angles strictly inside (0, pi), where the reference's frame is defined at all; golden G10)."""
+    lo_t, hi_t = theta_range
+    lo_p, hi_p = phi_range
+    theta = torch.rand(size, device=device) * (hi_t - lo_t) + lo_t
+    phi = torch.rand(size, device=device) * (hi_p - lo_p) + lo_p
+    st, ct, sp, cp = torch.sin(theta), torch.cos(theta), torch.sin(phi), torch.cos(phi)
+    zero = torch.zeros_like(theta)
+    poses = torch.zeros(size, 4, 4, dtype=torch.float32, device=device)
+    poses[:, :3, 0] = torch.stack([-cp, zero, sp], dim=-1)
+    poses[:, :3, 1] = torch.stack([ct * sp, -st, ct * cp], dim=-1)
+    poses[:, :3, 2] = torch.stack([-st * sp, -ct, -st * cp], dim=-1)
+    poses[:, :3, 3] = torch.stack([radius * st * sp, radius * ct, radius * st * cp], dim=-1)
+    poses[:, 3, 3] = 1.0
     return poses
 
 
