@@ -66,24 +66,26 @@ def parse_args():
 
 
 def _run_ranks(args, n, extra_env, timeout_s, capture, extra_argv=()):
-    """Start n rank processes, wait for them; returns (return code, rank 0's stdout or None, tail of rank 0's stderr or None).  A rank that
-    dies takes the others down (they would wait in a collective for ever); a run that outlasts `timeout_s` is killed the same way -- by the
-    exact PIDs started here, SIGTERM first, SIGKILL for whatever ignores it.  capture: rank 0's stdout and stderr go to temporary FILES
-    (never pipes: nothing here can block on a wedged child) and are read once every process is gone."""
+    """Start n rank processes, wait for them; returns (return code, rank 0's stdout or None, report or None).  A rank that dies takes the
+    others down (they would wait in a collective for ever); a run that outlasts `timeout_s` is killed the same way -- by the exact PIDs
+    started here, SIGTERM first, SIGKILL for whatever ignores it.  capture: rank 0's stdout and EVERY rank's stderr go to temporary FILES
+    (never pipes: nothing here can block on a wedged child) and are read once every process is gone.  report = {"first_failed_rank": the
+    rank whose non-zero exit ended the attempt (None: watchdog / none), "stderr_tail": that rank's last 20 stderr lines (rank 0's when no
+    rank failed by itself), "rank0_stderr_tail": ...}: on first contact with N GPUs the rank that dies need not be rank 0, and the
+    ranks that are torn down because of it (SIGTERM, possibly before they printed anything) say nothing about the cause."""
     import tempfile
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
     f_out = tempfile.TemporaryFile(mode="w+") if capture else None
-    f_err = tempfile.TemporaryFile(mode="w+") if capture else None
+    f_errs = [tempfile.TemporaryFile(mode="w+") for _ in range(n)] if capture else None
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), NERFSIG_LAUNCHED_BY_BENCH="1", **extra_env)
-        first = capture and r == 0
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + list(extra_argv), env=env,
-                                      stdout=f_out if first else None, stderr=f_err if first else None))
-    rc, t0 = 0, time.time()
+                                      stdout=f_out if (capture and r == 0) else None, stderr=f_errs[r] if capture else None))
+    rc, t0, first_failed = 0, time.time(), None
 
     def stop(ps):
         for q in ps:
@@ -110,7 +112,7 @@ def _run_ranks(args, n, extra_env, timeout_s, capture, extra_argv=()):
                     continue
                 pending.remove(p)
                 if code != 0 and rc == 0:
-                    rc = code
+                    rc, first_failed = code, procs.index(p)
                     stop(pending)
             if pending and timeout_s and time.time() - t0 > timeout_s:
                 rc = rc or 124
@@ -119,15 +121,21 @@ def _run_ranks(args, n, extra_env, timeout_s, capture, extra_argv=()):
             time.sleep(0.05)
     finally:
         stop(procs)
-    text = err = None
+    text = report = None
     if capture:
         f_out.seek(0)
         text = f_out.read()
-        f_err.seek(0)
-        err = "".join(f_err.readlines()[-20:])
+        tails = []
+        for r, f in enumerate(f_errs):
+            f.seek(0)
+            lines = f.readlines()
+            tails.append("".join(lines[-20:]))
+            if r != 0 and lines:                   # (ranks other than 0 used to write straight to this process's stderr: keep them visible)
+                sys.stderr.write("".join(f"[rank {r}] " + l for l in lines[-40:]))
+            f.close()
         f_out.close()
-        f_err.close()
-    return rc, text, err
+        report = {"first_failed_rank": first_failed, "stderr_tail": tails[first_failed if first_failed is not None else 0], "rank0_stderr_tail": tails[0]}
+    return rc, text, report
 
 
 def _attempt_chain(pinned, test_hook, rehearsal):
@@ -270,14 +278,17 @@ def launch_ranks(args):
         last = k == len(attempts) - 1
         env = dict(env, NERFSIG_LAUNCH_ATTEMPT=f"{k}: {name}")
         t_attempt = time.time()
-        rc, text, err = _run_ranks(args, n, env, watchdog, capture=True, extra_argv=extra)
+        rc, text, report = _run_ranks(args, n, env, watchdog, capture=True, extra_argv=extra)
         if rc == 0 and text and "{" in text:
             break
-        why = "killed by the launcher's watchdog" if rc == 124 else ("no JSON line on rank 0's stdout" if rc == 0 else "a rank exited non-zero")
-        failures.append({"attempt": k, "mode": name, "rc": rc, "why": why, "seconds": round(time.time() - t_attempt, 1), "rank0_stderr_tail": (err or "")[-4000:]})
+        report = report or {"first_failed_rank": None, "stderr_tail": "", "rank0_stderr_tail": ""}
+        who = report["first_failed_rank"]
+        why = "killed by the launcher's watchdog" if rc == 124 else ("no JSON line on rank 0's stdout" if rc == 0 else f"rank {who} exited non-zero")
+        failures.append({"attempt": k, "mode": name, "rc": rc, "why": why, "seconds": round(time.time() - t_attempt, 1), "first_failed_rank": who,
+                         "failed_rank_stderr_tail": report["stderr_tail"][-4000:], "rank0_stderr_tail": report["rank0_stderr_tail"][-4000:]})
         rc = rc or 1
-        print(f"[bench] attempt {k} ({name}) failed: rc {rc} ({why}) after {failures[-1]['seconds']} s; rank 0's last stderr lines:\n"
-              + "".join("    | " + l + "\n" for l in (err or "").splitlines()[-20:])
+        print(f"[bench] attempt {k} ({name}) failed: rc {rc} ({why}) after {failures[-1]['seconds']} s; last stderr lines of rank {0 if who is None else who}:\n"
+              + "".join("    | " + l + "\n" for l in report["stderr_tail"].splitlines()[-20:])
               + (f"[bench] starting the ranks again: {attempts[k + 1][0]}" if not last else "[bench] no attempt left"), file=sys.stderr, flush=True)
     if text and rc == 0:
         sys.stdout.write(text)

@@ -537,7 +537,8 @@ def test_bench_launcher_walks_the_whole_chain_and_still_prints_a_line_when_every
     assert line["value"] is None and line["n_gpus"] == 2
     fails = line["config"]["launch_failures"]
     assert [f["attempt"] for f in fails] == [0, 1, 2, 3] and all(f["rc"] == 3 for f in fails), (fails, out.stderr[-3000:])
-    assert all("fails on purpose" in f["rank0_stderr_tail"] for f in fails), fails
+    # the stderr on record is the FAILING rank's (whichever exits first; the other is torn down, possibly before it printed anything)
+    assert all(f["first_failed_rank"] in (0, 1) and "fails on purpose" in f["failed_rank_stderr_tail"] for f in fails), fails
     assert out.stderr.count("failed: rc 3") == 4 and "no attempt left" in out.stderr, out.stderr[-3000:]
     # hung ranks: every attempt is cut by the watchdog; the chain takes about attempts x (watchdog + kill)
     env["NERFSIG_TEST_FAIL_CAPTURED"] = "hang"
