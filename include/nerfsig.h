@@ -542,6 +542,47 @@ size_t hg_scatter_levels_scratch_bytes(uint32_t M);
 int hg_scatter_levels(const float *xyzs, float bound, const void *d_planes, uint32_t M, uint32_t stride, float *const *G_host,
                       void *scratch, nsig_stream_t stream);
 
+
+/*
+ * The captured stage-1 step (nerf_signature_amd/stage1.py GraphedCleanLoop; loop body of nerf/utils.py:852-869).
+ *
+ * *_rows: the point count is a DEVICE value (the march's counter): launches are sized for the buffers' capacity M_capacity, rows past
+ * min(M_capacity, *rows_dev) are neither read nor written; every buffer keeps the layout of M_capacity points (stride = M_capacity
+ * rounded up to 32).  field_wgrad: the five weight-gradient reductions sum_p d_pre[o][p] * act[i][p] on MFMA (split bf16, fp32
+ * accumulate; K = points), from field_fwd_trace's layer inputs + the encoder planes and field_bwd_trace's pre-activation gradients;
+ * writes all of grad_sigma_params [3072] = [W1s 64x32 | W2s 16x64] and grad_color_params [7168] = [Wc1 64x32 | Wc2 64x64 | Wc3 16x64]
+ * (tcnn's layout: INTEGRATION.md section 3); scratch = field_wgrad_scratch_bytes(M) bytes, 16-byte aligned; bit-reproducible (partial sums
+ * per workgroup, added in workgroup order).  Replaces the library GEMMs of the note above (5 x 145 us per 125 k points).
+ * clean_loss: loss[0] = mean((image - gt)^2) over n_values = N * 3 elements (nerf/utils.py:503, `.mean(-1)` then `.mean()`),
+ * grad_image = grad_scale * d loss / d image.  Optional bookkeeping of a captured loop, by the same workgroup (any pointer may be
+ * NULL): count_ring [16][2] row (*step_dev % 16) = march_counter[0..1] (the ring NeRFRenderer.step_counter is, renderer_wtmk.py:282-284),
+ * loss_ring[*step_dev % loss_ring_len] = loss, then *step_dev += 1.
+ */
+int field_fwd_trace_rows(const float *xyzs, const float *dirs, uint32_t M_capacity, const uint32_t *rows_dev, float bound,
+                         const float *const *base_tables_host, const void *packed, const void *planes, float *sigmas, float *rgbs,
+                         uint32_t *masks, float *act_hs, float *act_cin, float *act_h1, float *act_h2, nsig_stream_t stream);
+int field_bwd_trace_rows(uint32_t M_capacity, const uint32_t *rows_dev, const float *grad_sigmas, const float *grad_rgbs, const float *sigmas,
+                         const float *rgbs, const uint32_t *masks, const void *packed, float *d_hs, float *d_so, float *d_h1, float *d_h2,
+                         float *d_out, void *d_planes, nsig_stream_t stream);
+size_t field_wgrad_scratch_bytes(uint32_t M);
+int field_wgrad(uint32_t M, const uint32_t *rows_dev, const void *planes, const float *act_hs, const float *act_cin, const float *act_h1,
+                const float *act_h2, const float *d_hs, const float *d_so, const float *d_h1, const float *d_h2, const float *d_out,
+                void *scratch, float *grad_sigma_params, float *grad_color_params, nsig_stream_t stream);
+int clean_loss(const float *image, const float *gt, uint32_t n_values, float grad_scale, float *loss, float *grad_image,
+               uint32_t *step_dev, const int32_t *march_counter, int32_t *count_ring, float *loss_ring, uint32_t loss_ring_len,
+               nsig_stream_t stream);
+/*
+ * hg_scatter_levels in two halves.  hg_levels_plan needs the sample positions only -- which slice owner every (point, level, (dy,dz)
+ * pair) entry goes to, and where in that owner's queue -- so a step runs it beside its forward pass; hg_levels_scatter, behind the MLP
+ * backward, turns d_planes into queue entries at the planned places and runs the 16 x 64 owners, which WRITE every row of the 16
+ * tables G_host (no zero-fill, no atomics, fixed-point accumulation: bit-reproducible).  plan = hg_levels_plan_bytes(M) bytes,
+ * 16-byte aligned (16 headers, 16 queues of 4 M entries, 16 x M destinations); rows_dev may be NULL (= M points).
+ */
+size_t hg_levels_plan_bytes(uint32_t M);
+int hg_levels_plan(const float *xyzs, uint32_t M, const uint32_t *rows_dev, float bound, void *plan, nsig_stream_t stream);
+int hg_levels_scatter(const float *xyzs, uint32_t M, const uint32_t *rows_dev, float bound, const void *d_planes, uint32_t stride,
+                      void *plan, float *const *G_host, nsig_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,15 +30,11 @@
 #include <mutex>
 #include <unordered_set>
 #include "hashgrid.h"
+#include "mfma.h"
 
 #include <stdlib.h>
 
 namespace nsig {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ----------------------------------------------------------------------------- packed weight layout
 
@@ -124,34 +120,6 @@ __global__ void __launch_bounds__(256) k_pack_weights(const float *__restrict__ 
 }
 
 // ----------------------------------------------------------------------------- wave-level building blocks
-
-// A B operand of one K-step (8 values per lane) as split bf16: hi = bf16(v), lo = bf16(v - hi), two values per dword.
-struct Split8 {
-    uint32_t hi[4], lo[4];
-};
-// ... and as plain fp16, two values per dword.
-struct Half8 {
-    uint32_t v[4];
-};
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-__device__ inline uint32_t cvt_pk_bf16(float a, float b) {   // v_cvt_pk_bf16_f32: round to nearest even, a in the low half
-    const f32x2 v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-__device__ inline uint32_t cvt_pk_f16(float a, float b) {    // round to nearest even, a in the low half
-    const f32x2 v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
-}
-__device__ inline bf16x8 operand(const uint32_t (&w)[4]) {
-    const uint4 u = {w[0], w[1], w[2], w[3]};
-    return __builtin_bit_cast(bf16x8, u);
-}
-__device__ inline f16x8 operand_h(const uint32_t (&w)[4]) {
-    const uint4 u = {w[0], w[1], w[2], w[3]};
-    return __builtin_bit_cast(f16x8, u);
-}
 
 // The two precisions of the MFMA kernels.  A tag names the operand type, how a pair of fp32 values enters it, where the A
 // fragments of the forward / backward weights sit in the packed image and how many LDS bytes they take.
@@ -319,9 +287,6 @@ struct GradTrace {   // written by the backward
     float *d_so, *d_out;        // [16][stride] gradients of the two heads' outputs (sigma head rows 0..15; colour rows 0..2)
     float2 *d_planes;           // [16][stride] gradient of the 32 encoder features, level-major like the forward's planes
 };
-
-// row of a 32-row accumulator block held in register r (0..15) of lane half h
-__device__ inline int row_of_reg16(int h, int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 template <typename F>
 __device__ inline void store_rows64(float *__restrict__ dst, uint32_t stride, uint32_t s, int h, const f32x16 (&acc)[2], F f) {
@@ -858,8 +823,14 @@ __global__ void __launch_bounds__(256) k_field_bwd(const float *__restrict__ xyz
                                                    const float *__restrict__ sigmas, const float *__restrict__ rgbs,
                                                    const uint32_t *__restrict__ masks, const char *__restrict__ packed,
                                                    float *__restrict__ G, float *__restrict__ dfeat_out, float *__restrict__ rec_out,
-                                                   GradTrace gt = GradTrace{}, uint32_t stride = 0, ScatterPlan plan = ScatterPlan{}) {
+                                                   GradTrace gt = GradTrace{}, uint32_t stride = 0, ScatterPlan plan = ScatterPlan{},
+                                                   const uint32_t *__restrict__ rows_dev = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    if (rows_dev != nullptr) {      // (field_bwd_trace_rows: the point count is a device value; `stride` keeps the buffers' layout)
+        const uint32_t r = *rows_dev;
+        if (r == 0) return;
+        M = min(M, r);
+    }
     stage_weights(lds, packed + P::kBwdOffset, (int)P::kBwdLds);
     constexpr size_t kHalf = kBwdBytes;
     // F16: the backward is linear in the point's upstream gradient, so that gradient is first scaled by a power of two that brings
@@ -1493,9 +1464,9 @@ NSIG_EXPORT int field_bwd_planned(const float *xyzs, uint32_t M, float bound, co
 
 // ----------------------------------------------------------------------------- stage-1 (clean model) training entry points
 
-NSIG_EXPORT int field_fwd_trace(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *const *base_tables_host,
-                                const void *packed, const void *planes, float *sigmas, float *rgbs, uint32_t *masks, float *act_hs,
-                                float *act_cin, float *act_h1, float *act_h2, nsig_stream_t stream) {
+static int fwd_trace_impl(const float *xyzs, const float *dirs, uint32_t M, const uint32_t *rows_dev, float bound, const float *const *base_tables_host,
+                          const void *packed, const void *planes, float *sigmas, float *rgbs, uint32_t *masks, float *act_hs,
+                          float *act_cin, float *act_h1, float *act_h2, nsig_stream_t stream) {
     if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(xyzs && dirs && packed && planes && sigmas && rgbs && masks && act_hs && act_cin && act_h1 && act_h2, "field_fwd_trace: null pointer");
     NSIG_REQUIRE(bound > 0.0f, "field_fwd_trace: bound must be positive");
@@ -1506,13 +1477,27 @@ NSIG_EXPORT int field_fwd_trace(const float *xyzs, const float *dirs, uint32_t M
     ActTrace tr{act_hs, act_cin, act_h1, act_h2};
     k_field_fwd<Bf16x3, 1, true><<<field_grid(M), 256, Bf16x3::kFwdLds, as_stream(stream)>>>(xyzs, dirs, M, bound, base, make_level_geom(), nullptr,
                                                                                      reinterpret_cast<const float2 *>(planes), stride,
-                                                                                     reinterpret_cast<const char *>(packed), sigmas, rgbs, nullptr, masks, tr);
+                                                                                     reinterpret_cast<const char *>(packed), sigmas, rgbs, nullptr, masks, tr,
+                                                                                     nullptr, rows_dev);
     return check_launch("field_fwd_trace");
 }
 
-NSIG_EXPORT int field_bwd_trace(uint32_t M, const float *grad_sigmas, const float *grad_rgbs, const float *sigmas, const float *rgbs,
-                                const uint32_t *masks, const void *packed, float *d_hs, float *d_so, float *d_h1, float *d_h2, float *d_out,
-                                void *d_planes, nsig_stream_t stream) {
+NSIG_EXPORT int field_fwd_trace(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *const *base_tables_host,
+                                const void *packed, const void *planes, float *sigmas, float *rgbs, uint32_t *masks, float *act_hs,
+                                float *act_cin, float *act_h1, float *act_h2, nsig_stream_t stream) {
+    return fwd_trace_impl(xyzs, dirs, M, nullptr, bound, base_tables_host, packed, planes, sigmas, rgbs, masks, act_hs, act_cin, act_h1, act_h2, stream);
+}
+
+NSIG_EXPORT int field_fwd_trace_rows(const float *xyzs, const float *dirs, uint32_t M_capacity, const uint32_t *rows_dev, float bound,
+                                     const float *const *base_tables_host, const void *packed, const void *planes, float *sigmas, float *rgbs,
+                                     uint32_t *masks, float *act_hs, float *act_cin, float *act_h1, float *act_h2, nsig_stream_t stream) {
+    NSIG_REQUIRE(rows_dev != nullptr, "field_fwd_trace_rows: null row count");
+    return fwd_trace_impl(xyzs, dirs, M_capacity, rows_dev, bound, base_tables_host, packed, planes, sigmas, rgbs, masks, act_hs, act_cin, act_h1, act_h2, stream);
+}
+
+static int bwd_trace_impl(uint32_t M, const uint32_t *rows_dev, const float *grad_sigmas, const float *grad_rgbs, const float *sigmas, const float *rgbs,
+                          const uint32_t *masks, const void *packed, float *d_hs, float *d_so, float *d_h1, float *d_h2, float *d_out,
+                          void *d_planes, nsig_stream_t stream) {
     if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(grad_sigmas && grad_rgbs && sigmas && rgbs && masks && packed && d_hs && d_so && d_h1 && d_h2 && d_out && d_planes,
                  "field_bwd_trace: null pointer");
@@ -1520,6 +1505,19 @@ NSIG_EXPORT int field_bwd_trace(uint32_t M, const float *grad_sigmas, const floa
     GradTrace gt{d_hs, d_h1, d_h2, d_so, d_out, reinterpret_cast<float2 *>(d_planes)};
     k_field_bwd<Bf16x3, true><<<field_grid(M), 256, Bf16x3::kBwdLds, as_stream(stream)>>>(nullptr, M, 1.0f, 1.0f / kCodebookResolution, grad_sigmas, grad_rgbs, sigmas,
                                                                                rgbs, masks, reinterpret_cast<const char *>(packed), nullptr, nullptr,
-                                                                               nullptr, gt, stride);
+                                                                               nullptr, gt, stride, ScatterPlan{}, rows_dev);
     return check_launch("field_bwd_trace");
+}
+
+NSIG_EXPORT int field_bwd_trace(uint32_t M, const float *grad_sigmas, const float *grad_rgbs, const float *sigmas, const float *rgbs,
+                                const uint32_t *masks, const void *packed, float *d_hs, float *d_so, float *d_h1, float *d_h2, float *d_out,
+                                void *d_planes, nsig_stream_t stream) {
+    return bwd_trace_impl(M, nullptr, grad_sigmas, grad_rgbs, sigmas, rgbs, masks, packed, d_hs, d_so, d_h1, d_h2, d_out, d_planes, stream);
+}
+
+NSIG_EXPORT int field_bwd_trace_rows(uint32_t M_capacity, const uint32_t *rows_dev, const float *grad_sigmas, const float *grad_rgbs, const float *sigmas,
+                                     const float *rgbs, const uint32_t *masks, const void *packed, float *d_hs, float *d_so, float *d_h1, float *d_h2,
+                                     float *d_out, void *d_planes, nsig_stream_t stream) {
+    NSIG_REQUIRE(rows_dev != nullptr, "field_bwd_trace_rows: null row count");
+    return bwd_trace_impl(M_capacity, rows_dev, grad_sigmas, grad_rgbs, sigmas, rgbs, masks, packed, d_hs, d_so, d_h1, d_h2, d_out, d_planes, stream);
 }

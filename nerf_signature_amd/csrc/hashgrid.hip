@@ -438,6 +438,155 @@ __global__ void __launch_bounds__(kBinThreads) k_plan_dest(const float *__restri
     }
 }
 
+// ---- the planned variant over the 16 base levels (stage-1 training: every base table has its own gradient).  blockIdx.y = level.
+// Where an entry goes depends on the point's position and the level's cell only, so count and destinations are computed beside the
+// forward pass (hg_levels_plan); behind the MLP backward one pass turns the feature gradients into queue entries (k_level_entries)
+// and the 16 x 64 slice owners run.  Against the record route (k_level_records -> k_bin_count -> k_bin_scan -> k_bin_write) the step's
+// critical path loses three launches and the 32-byte records' round trip.  The point count is a device value (`rows_dev`, may be
+// null): a captured step sizes its launches for the buffers' capacity M and walks only the rows the march produced.
+__device__ inline void level_point_slices(const float *__restrict__ xyzs, uint32_t m, float bound, float cell, uint32_t (&sl)[4]) {
+    const float two_b = 2.0f * bound;
+    uint32_t iy, iz;
+    float w;
+    axis_cell((xyzs[3 * (size_t)m + 1] + bound) / two_b, cell, iy, w);
+    axis_cell((xyzs[3 * (size_t)m + 2] + bound) / two_b, cell, iz, w);
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) sl[q] = pair_slice(pair_hash(iy, iz, q));
+}
+
+// the active lanes of the wave that hold the same value as this one (a loop over the DISTINCT values: used where they are few)
+__device__ inline uint64_t wave_match(uint32_t v) {
+    uint64_t mine = 0, todo = __ballot(1);
+    while (todo) {
+        const uint32_t val = (uint32_t)__shfl((int)v, (int)(__ffsll((long long)todo) - 1), 64);
+        const uint64_t m = __ballot(v == val) & todo;
+        if (v == val) mine = m;
+        todo &= ~m;
+    }
+    return mine;
+}
+constexpr uint32_t kCoarseLevels = 6;   // levels 0..5: cells of >= 1/80 of the box, a ray's consecutive samples share them
+
+__global__ void __launch_bounds__(kBinThreads) k_levels_plan_count(const float *__restrict__ xyzs, uint32_t M, const uint32_t *__restrict__ rows_dev, float bound,
+                                                                   LevelGeom geom, BinHeader *__restrict__ hd_all) {
+    BinHeader *__restrict__ hd = hd_all + blockIdx.y;
+    const float cell = geom.cell[blockIdx.y];
+    const uint32_t n = rows_dev != nullptr ? min(M, *rows_dev) : M;
+    __shared__ uint32_t h[kBinSlices];
+    if (threadIdx.x < kBinSlices) h[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) hd->gmax_bits = 0;   // k_level_entries raises it (stream-ordered after the plan)
+    __syncthreads();
+    for (uint32_t m = blockIdx.x * kBinThreads + threadIdx.x; m < n; m += gridDim.x * kBinThreads) {
+        uint32_t sl[4];
+        level_point_slices(xyzs, m, bound, cell, sl);
+        // coarse levels: a wave's 64 consecutive samples of a ray share a few cells, hence a few slices -- lanes that agree with a lower
+        // lane let it count for them (one LDS atomic per distinct slice of the wave instead of 64 serialised ones on one address)
+        if (blockIdx.y < kCoarseLevels) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint64_t same = wave_match(sl[q]);
+                if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)same) - 1u) atomicAdd(&h[sl[q]], (uint32_t)__popcll(same));
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) atomicAdd(&h[sl[q]], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kBinSlices) hd->wg[blockIdx.x][threadIdx.x] = h[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(kBinThreads) k_levels_plan_dest(const float *__restrict__ xyzs, uint32_t M, const uint32_t *__restrict__ rows_dev, float bound,
+                                                                  LevelGeom geom, BinHeader *__restrict__ hd_all, uint4 *__restrict__ dest_all) {
+    BinHeader *__restrict__ hd = hd_all + blockIdx.y;
+    uint4 *__restrict__ dest = dest_all + (size_t)blockIdx.y * M;
+    const float cell = geom.cell[blockIdx.y];
+    const uint32_t n = rows_dev != nullptr ? min(M, *rows_dev) : M;
+    __shared__ uint32_t h[kBinSlices], running[kBinSlices], seg_tot[16][kBinSlices], seg_before[16][kBinSlices];
+    {
+        const uint32_t s = threadIdx.x & (kBinSlices - 1), g = threadIdx.x >> 6, n_wg = gridDim.x;
+        uint32_t tot = 0, before = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t w = g * 16 + i;
+            const uint32_t c = w < n_wg ? hd->wg[w][s] : 0u;
+            tot += c;
+            if (w < blockIdx.x) before += c;
+        }
+        seg_tot[g][s] = tot;
+        seg_before[g][s] = before;
+        __syncthreads();
+        if (threadIdx.x < kBinSlices) {
+            uint32_t t = 0, b = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { t += seg_tot[k][threadIdx.x]; b += seg_before[k][threadIdx.x]; }
+            uint32_t incl = t;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t v = (uint32_t)__shfl_up((int)incl, d, 64);
+                if ((int)threadIdx.x >= d) incl += v;
+            }
+            running[threadIdx.x] = incl - t + b;
+            if (blockIdx.x == 0) hd->counts[threadIdx.x] = t;
+        }
+    }
+    for (uint32_t m0 = blockIdx.x * kBinThreads; m0 < n; m0 += gridDim.x * kBinThreads) {   // uniform trip count: barriers inside
+        if (threadIdx.x < kBinSlices) h[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t m = m0 + threadIdx.x;
+        uint32_t sl[4], local[4];
+        if (m < n) {
+            level_point_slices(xyzs, m, bound, cell, sl);
+            if (blockIdx.y < kCoarseLevels) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {      // ranks inside the wave's group of equal slices: one LDS atomic per group (see k_levels_plan_count)
+                    const uint64_t same = wave_match(sl[q]);
+                    const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)same) - 1u;
+                    uint32_t base = 0;
+                    if (lane == leader) base = atomicAdd(&h[sl[q]], (uint32_t)__popcll(same));
+                    base = (uint32_t)__shfl((int)base, (int)leader, 64);
+                    local[q] = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) local[q] = atomicAdd(&h[sl[q]], 1u);
+            }
+        }
+        __syncthreads();
+        if (m < n) dest[m] = make_uint4(running[sl[0]] + local[0], running[sl[1]] + local[1], running[sl[2]] + local[2], running[sl[3]] + local[3]);
+        __syncthreads();
+        if (threadIdx.x < kBinSlices) running[threadIdx.x] += h[threadIdx.x];
+    }
+}
+
+// feature gradient of (point, level) -> its four pair entries at their planned places; raises the level's max |gradient|
+__global__ void __launch_bounds__(256) k_level_entries(const float *__restrict__ xyzs, uint32_t M, const uint32_t *__restrict__ rows_dev, float bound,
+                                                       const float2 *__restrict__ dplanes, uint32_t stride, LevelGeom geom, BinHeader *__restrict__ hd_all,
+                                                       const uint4 *__restrict__ dest_all, uint4 *__restrict__ queue_all) {
+    const uint32_t m = blockIdx.x * 256u + threadIdx.x, level = blockIdx.y;
+    const uint32_t n = rows_dev != nullptr ? min(M, *rows_dev) : M;
+    uint32_t gb = 0;
+    if (m < n) {
+        const float2 g = dplanes[(size_t)level * stride + m];
+        const uint4 dst = dest_all[(size_t)level * M + m];
+        const float two_b = 2.0f * bound, cell = geom.cell[level];
+        uint32_t idx[3];
+        float w[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) axis_cell((xyzs[3 * (size_t)m + a] + bound) / two_b, cell, idx[a], w[a]);
+        uint4 *__restrict__ queue = queue_all + (size_t)level * 4 * M;
+        queue[dst.x] = pair_entry(idx[0], pair_hash(idx[1], idx[2], 0u), w[0], w[1], w[2], g.x, g.y, 0u);
+        queue[dst.y] = pair_entry(idx[0], pair_hash(idx[1], idx[2], 1u), w[0], w[1], w[2], g.x, g.y, 1u);
+        queue[dst.z] = pair_entry(idx[0], pair_hash(idx[1], idx[2], 2u), w[0], w[1], w[2], g.x, g.y, 2u);
+        queue[dst.w] = pair_entry(idx[0], pair_hash(idx[1], idx[2], 3u), w[0], w[1], w[2], g.x, g.y, 3u);
+        gb = max(__float_as_uint(g.x) & 0x7fffffffu, __float_as_uint(g.y) & 0x7fffffffu);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) gb = max(gb, (uint32_t)__shfl_xor((int)gb, d, 64));
+    BinHeader *__restrict__ hd = hd_all + level;
+    if ((threadIdx.x & 63u) == 0 && gb > __hip_atomic_load(&hd->gmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&hd->gmax_bits, gb);
+}
+
 // (a single-precision formulation of this conversion -- split at bit 27, two exact cvt_i32 -- changes nothing: the owners are
 // bound by their LDS atomics and entry loads, not by the f64 instructions)
 __device__ inline long long to_fixed(float c, int k) { return __double2ll_rn(ldexp((double)c, k)); }
@@ -901,6 +1050,7 @@ struct DenseAdam {
     float *p[kDenseMax], *m[kDenseMax], *v[kDenseMax], *step[kDenseMax];
     const float *g[kDenseMax];
     uint32_t numel[kDenseMax], chunk0[kDenseMax + 1];   // chunk0: first chunk of tensor i
+    uint8_t slot[kDenseMax];                            // where the tensor's two step scalars sit in the scratch (k_adam_dense_prepare's index)
 };
 
 __global__ void k_adam_dense_prepare(DenseAdam a, uint32_t n, const float *__restrict__ lr, float beta1, float beta2, float *__restrict__ scratch) {
@@ -917,7 +1067,7 @@ __global__ void __launch_bounds__(256) k_adam_dense(DenseAdam a, uint32_t n, con
     uint32_t i = 0;
     while (i + 1 < n && blockIdx.x >= a.chunk0[i + 1]) ++i;   // uniform: which tensor this chunk belongs to
     const uint32_t base = (blockIdx.x - a.chunk0[i]) * kDenseChunk;
-    const float ss = scratch[i], ib = scratch[kDenseMax + i];
+    const float ss = scratch[a.slot[i]], ib = scratch[kDenseMax + a.slot[i]];
     float *__restrict__ pp = a.p[i], *__restrict__ pm = a.m[i], *__restrict__ pv = a.v[i];
     const float *__restrict__ pg = a.g[i];
 #pragma unroll
@@ -982,29 +1132,73 @@ NSIG_EXPORT int opt_adam_dense_host(uint32_t n, float *const *params_host, const
     return NSIG_OK;
 }
 
+// Large tensors (stage 1: sixteen 4 MiB base tables with their own gradients): 4096-element chunks, float4 per lane, sixteen 16-byte loads in
+// flight per lane before the first dependent store, non-temporal both ways (a 448 MiB stream that nothing re-reads before it is evicted anyway).
+constexpr uint32_t kDenseChunk4 = 4096, kDenseBigNumel = 1u << 16;
+__global__ void __launch_bounds__(256) k_adam_dense_v4(DenseAdam a, uint32_t n, const float *__restrict__ scratch, float beta1, float beta2, float eps,
+                                                       float grad_scale) {
+    uint32_t i = 0;
+    while (i + 1 < n && blockIdx.x >= a.chunk0[i + 1]) ++i;   // uniform: which tensor this chunk belongs to
+    const uint32_t base = (blockIdx.x - a.chunk0[i]) * (kDenseChunk4 / 4), n4 = a.numel[i] / 4;
+    const float ss = scratch[a.slot[i]], ib = scratch[kDenseMax + a.slot[i]];
+    float4 *__restrict__ pp = reinterpret_cast<float4 *>(a.p[i]), *__restrict__ pm = reinterpret_cast<float4 *>(a.m[i]), *__restrict__ pv = reinterpret_cast<float4 *>(a.v[i]);
+    const float4 *__restrict__ pg = reinterpret_cast<const float4 *>(a.g[i]);
+    float4 p[4], m[4], v[4], g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t e = min(base + u * 256u + threadIdx.x, n4 - 1u);      // clamped: the duplicate is not stored
+        p[u] = ld4<true>(pp + e); m[u] = ld4<true>(pm + e); v[u] = ld4<true>(pv + e); g[u] = ld4<true>(pg + e);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t e = base + u * 256u + threadIdx.x;
+        if (e >= n4) break;
+        adam_update(g[u].x * grad_scale, p[u].x, m[u].x, v[u].x, beta1, beta2, eps, ss, ib);
+        adam_update(g[u].y * grad_scale, p[u].y, m[u].y, v[u].y, beta1, beta2, eps, ss, ib);
+        adam_update(g[u].z * grad_scale, p[u].z, m[u].z, v[u].z, beta1, beta2, eps, ss, ib);
+        adam_update(g[u].w * grad_scale, p[u].w, m[u].w, v[u].w, beta1, beta2, eps, ss, ib);
+        st4<true>(pp + e, p[u]); st4<true>(pm + e, m[u]); st4<true>(pv + e, v[u]);
+    }
+}
+
 NSIG_EXPORT int opt_adam_dense(uint32_t n, float *const *params_host, const float *const *grads_host, float *const *exp_avg_host,
                                float *const *exp_avg_sq_host, float *const *steps_host, const uint32_t *numel_host, const float *lr, float beta1,
                                float beta2, float eps, float grad_scale, float *scratch, nsig_stream_t stream) {
     NSIG_REQUIRE(params_host && grads_host && exp_avg_host && exp_avg_sq_host && steps_host && numel_host && lr && scratch, "opt_adam_dense: null pointer");
     hipStream_t st = as_stream(stream);
-    for (uint32_t first = 0; first < n; first += kDenseMax) {   // 32 tensors per pair of launches
+    for (uint32_t first = 0; first < n; first += kDenseMax) {   // 32 tensors per group of launches
         const uint32_t cnt = n - first < (uint32_t)kDenseMax ? n - first : (uint32_t)kDenseMax;
-        DenseAdam a{};
-        uint32_t chunks = 0;
+        DenseAdam all{}, small{}, big{};
+        uint32_t n_small = 0, n_big = 0, chunks_small = 0, chunks_big = 0;
         for (uint32_t i = 0; i < cnt; ++i) {
             const uint32_t j = first + i;
             NSIG_REQUIRE(params_host[j] && grads_host[j] && exp_avg_host[j] && exp_avg_sq_host[j] && steps_host[j] && numel_host[j] > 0,
                          "opt_adam_dense: tensor %u has a null pointer or no elements", j);
-            a.p[i] = params_host[j]; a.g[i] = grads_host[j]; a.m[i] = exp_avg_host[j]; a.v[i] = exp_avg_sq_host[j]; a.step[i] = steps_host[j];
-            a.numel[i] = numel_host[j];
-            a.chunk0[i] = chunks;
-            chunks += ceil_div(numel_host[j], kDenseChunk);
+            all.step[i] = steps_host[j];
+            const bool wide = numel_host[j] >= kDenseBigNumel && numel_host[j] % 4 == 0 && aligned16(params_host[j]) && aligned16(grads_host[j]) &&
+                              aligned16(exp_avg_host[j]) && aligned16(exp_avg_sq_host[j]);
+            DenseAdam &d = wide ? big : small;
+            uint32_t &k = wide ? n_big : n_small, &chunks = wide ? chunks_big : chunks_small;
+            d.p[k] = params_host[j]; d.g[k] = grads_host[j]; d.m[k] = exp_avg_host[j]; d.v[k] = exp_avg_sq_host[j];
+            d.numel[k] = numel_host[j];
+            d.slot[k] = (uint8_t)i;
+            d.chunk0[k] = chunks;
+            chunks += ceil_div(numel_host[j], wide ? kDenseChunk4 : kDenseChunk);
+            ++k;
         }
-        a.chunk0[cnt] = chunks;
-        k_adam_dense_prepare<<<1, kDenseMax, 0, st>>>(a, cnt, lr, beta1, beta2, scratch + (size_t)first * 2);
+        small.chunk0[n_small] = chunks_small;
+        big.chunk0[n_big] = chunks_big;
+        float *sc = scratch + (size_t)first * 2;
+        k_adam_dense_prepare<<<1, kDenseMax, 0, st>>>(all, cnt, lr, beta1, beta2, sc);
         if (int e = check_launch("opt_adam_dense (prepare)")) return e;
-        k_adam_dense<<<chunks, 256, 0, st>>>(a, cnt, scratch + (size_t)first * 2, beta1, beta2, eps, grad_scale);
-        if (int e = check_launch("opt_adam_dense")) return e;
+        if (n_big) {
+            k_adam_dense_v4<<<chunks_big, 256, 0, st>>>(big, n_big, sc, beta1, beta2, eps, grad_scale);
+            if (int e = check_launch("opt_adam_dense (wide)")) return e;
+        }
+        if (n_small) {
+            k_adam_dense<<<chunks_small, 256, 0, st>>>(small, n_small, sc, beta1, beta2, eps, grad_scale);
+            if (int e = check_launch("opt_adam_dense")) return e;
+        }
     }
     return NSIG_OK;
 }
@@ -1115,6 +1309,56 @@ NSIG_EXPORT int hg_scatter_levels(const float *xyzs, float bound, const void *d_
     // every (level, slice) has a single owner, which stores its rows: the tables are written, not accumulated into
     return launch_binned(reinterpret_cast<const float *>(rec), M, NSIG_BASE_LEVELS, tg, 1u,
                          reinterpret_cast<char *>(scratch) + (size_t)NSIG_BASE_LEVELS * M * 32, st, "hg_scatter_levels");
+}
+
+// plan of the 16-level scatter: 16 headers | 16 queues of 4 M entries | 16 x M destinations
+static size_t levels_plan_bytes(uint32_t M) { return (size_t)NSIG_BASE_LEVELS * (sizeof(BinHeader) + (size_t)5 * M * sizeof(uint4)); }
+
+NSIG_EXPORT size_t hg_levels_plan_bytes(uint32_t M) { return levels_plan_bytes(M); }
+
+NSIG_EXPORT int hg_levels_plan(const float *xyzs, uint32_t M, const uint32_t *rows_dev, float bound, void *plan, nsig_stream_t stream) {
+    if (M == 0) return NSIG_OK;
+    NSIG_REQUIRE(xyzs && plan, "hg_levels_plan: null pointer");
+    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(plan) & 15) == 0 && M < (1u << 28) && bound > 0.0f, "hg_levels_plan: plan must be 16-byte aligned, M < 2^28, bound > 0");
+    BinHeader *hd = reinterpret_cast<BinHeader *>(plan);
+    uint4 *dest = reinterpret_cast<uint4 *>(hd + NSIG_BASE_LEVELS) + (size_t)NSIG_BASE_LEVELS * 4 * M;
+    hipStream_t st = as_stream(stream);
+    const uint32_t blocks = ceil_div(M, kBinThreads) < kBinGrid ? ceil_div(M, kBinThreads) : kBinGrid;
+    k_levels_plan_count<<<dim3(blocks, NSIG_BASE_LEVELS), kBinThreads, 0, st>>>(xyzs, M, rows_dev, bound, make_level_geom(), hd);
+    k_levels_plan_dest<<<dim3(blocks, NSIG_BASE_LEVELS), kBinThreads, 0, st>>>(xyzs, M, rows_dev, bound, make_level_geom(), hd, dest);
+    return check_launch("hg_levels_plan");
+}
+
+NSIG_EXPORT int hg_levels_scatter(const float *xyzs, uint32_t M, const uint32_t *rows_dev, float bound, const void *d_planes, uint32_t stride, void *plan,
+                                  float *const *G_host, nsig_stream_t stream) {
+    NSIG_REQUIRE(G_host, "hg_levels_scatter: null pointer");
+    ScatterTargets tg{};
+    for (int l = 0; l < NSIG_BASE_LEVELS; ++l) {
+        NSIG_REQUIRE(G_host[l], "hg_levels_scatter: table %d has a null pointer", l);
+        tg.g[l] = G_host[l];
+    }
+    hipStream_t st = as_stream(stream);
+    if (M == 0) {
+        for (int l = 0; l < NSIG_BASE_LEVELS; ++l)
+            if (hipMemsetAsync(tg.g[l], 0, (size_t)NSIG_TABLE_ROWS * 2 * sizeof(float), st) != hipSuccess) {
+                set_error("hg_levels_scatter: hipMemsetAsync failed");
+                return NSIG_ERR_LAUNCH;
+            }
+        return NSIG_OK;
+    }
+    NSIG_REQUIRE(xyzs && d_planes && plan, "hg_levels_scatter: null pointer");
+    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(plan) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_planes) & 7) == 0 && M < (1u << 28) && bound > 0.0f && stride >= M,
+                 "hg_levels_scatter: plan must be 16-byte and d_planes 8-byte aligned, M < 2^28, bound > 0, stride >= M");
+    if (int e = reserve_owner_lds("hg_levels_scatter")) return e;
+    BinHeader *hd = reinterpret_cast<BinHeader *>(plan);
+    uint4 *queue = reinterpret_cast<uint4 *>(hd + NSIG_BASE_LEVELS);
+    const uint4 *dest = queue + (size_t)NSIG_BASE_LEVELS * 4 * M;
+    k_level_entries<<<dim3(ceil_div(M, 256u), NSIG_BASE_LEVELS), 256, 0, st>>>(xyzs, M, rows_dev, bound, reinterpret_cast<const float2 *>(d_planes), stride,
+                                                                              make_level_geom(), hd, dest, queue);
+    if (int e = check_launch("hg_levels_scatter (entries)")) return e;
+    // every (level, slice) has a single owner, which stores its rows: the tables are written, not accumulated into
+    k_scatter_binned<<<dim3(kBinSlices, NSIG_BASE_LEVELS), 1024, (size_t)kBinRows * 2 * sizeof(unsigned long long), st>>>(hd, queue, M, tg, 1u);
+    return check_launch("hg_levels_scatter");
 }
 
 NSIG_EXPORT int hg_scatter_level(const float *xyzs, float bound, const void *d_plane, uint32_t M, uint32_t level, float *G, nsig_stream_t stream) {

@@ -1,24 +1,91 @@
-"""Stage-1 (clean model) training support, SURVEY.md 8(f) N3: the same field kernels with every parameter trainable.
+"""Stage-1 (clean model) training, SURVEY.md 8(f) N3: the same field kernels with every parameter trainable.
 
 Mirror of /root/reference/nerf/network_hash.py (NeRFNetwork without codebook / decoder; get_params :154-166) and of the
-loop body of the stage-1 trainer (/root/reference/nerf/utils.py:469-517 train_step, :852-869 density-grid refresh).
+loop body of the stage-1 trainer (/root/reference/nerf/utils.py:469-517 train_step, :852-869 loop with the density-grid
+refresh every `update_extra_interval` steps).
 
-Gradient flow (csrc/field.hip "stage-1"): field_fwd_trace saves each layer's input, field_bwd_trace each layer's
-pre-activation gradient and the gradient of all 32 encoder features.  The five weight gradients are reductions over the
-point dimension of (pre-activation gradient) x (layer input)^T -- plain GEMMs, done by the BLAS library; the base-table
-gradients are 16 owner-computes scatters (hg_scatter_level), the counterpart of the reference's 16
-embedding_dense_backward calls."""
+Gradient flow (csrc/field.hip "stage-1", csrc/stage1.hip, csrc/hashgrid.hip "planned variant over the 16 base levels"):
+field_fwd_trace saves each layer's input, field_bwd_trace each layer's pre-activation gradient and the gradient of all 32
+encoder features; field_wgrad reduces the five weight gradients over the points on MFMA; the base-table gradients are one
+planned owner-computes scatter over the 16 levels (hg_levels_plan beside the forward pass, hg_levels_scatter behind the
+backward) -- the counterpart of the reference's 16 embedding_dense_backward calls.
+
+Three ways to drive it:
+  * CleanNeRFNetwork under autograd (any caller, e.g. the reference's own stage-1 Trainer through render());
+  * CleanLoop            the loop body, eager;
+  * GraphedCleanLoop     the loop body as explicit kernel calls on static buffers, captured once into a hipGraph and replayed:
+                         no autograd, no allocation, no host read inside a step; the density grid is refreshed between replays
+                         every `update_extra_interval` steps as the reference does; data-parallel ranks exchange ONE flat
+                         buffer [16 table gradients | MLP gradients] per step."""
+import ctypes
+
 import torch
 from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
 
 from . import _native as nv
+from . import dp
 from . import fieldops as fo
 from . import tcnn_compat as tcnn
+from .capture import SegmentedCapture
 from .hash_encoding import HashEmbedder
+from .raymarching import padded_point_count
 from .renderer import NeRFRenderer
 
 T_ROWS = fo.T_ROWS
+N_SIGMA, N_COLOR = 3072, 7168      # sigma_net.params / color_net.params (tcnn layout)
+
+
+def _stride(M):
+    return (M + 31) // 32 * 32
+
+
+class _Traces:
+    """The buffers one field pass of `M` points (capacity) leaves for its backward: planes, layer inputs, pre-activation gradients."""
+
+    def __init__(self, M, dev, with_grads=True):
+        st = self.stride = _stride(M)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.M = M
+        self.planes = torch.empty(17, st, 2, **f32)
+        self.sig = torch.empty(M, **f32)
+        self.rgb = torch.empty(M, 3, **f32)
+        self.masks = torch.empty(st, fo.MASK_WORDS, dtype=torch.int32, device=dev)
+        self.act = [torch.empty(w, st, **f32) for w in (64, 32, 64, 64)]               # hs, cin, h1, h2
+        if with_grads:
+            self.alloc_grads()
+
+    def alloc_grads(self):
+        f32 = dict(dtype=torch.float32, device=self.sig.device)
+        st = self.stride
+        self.d = [torch.empty(w, st, **f32) for w in (64, 16, 64, 64, 16)]              # d_hs, d_so, d_h1, d_h2, d_out
+        self.d_planes = torch.empty(16, st, 2, **f32)
+        self.wgrad_scratch = torch.empty(int(nv.fn("field_wgrad_scratch_bytes")(self.M)), dtype=torch.uint8, device=self.sig.device)
+
+
+def _forward_trace(tr, xyzs, dirs, bound, base_ptrs, packed, rows=None):
+    s = nv.stream()
+    if rows is None:
+        nv.call("hg_encode_planes", nv.ptr(xyzs), tr.M, float(bound), base_ptrs, None, nv.ptr(tr.planes), s)
+        nv.call("field_fwd_trace", nv.ptr(xyzs), nv.ptr(dirs), tr.M, float(bound), base_ptrs, nv.ptr(packed), nv.ptr(tr.planes), nv.ptr(tr.sig),
+                nv.ptr(tr.rgb), nv.ptr(tr.masks), *[nv.ptr(a) for a in tr.act], s)
+    else:
+        nv.call("hg_encode_planes_rows", nv.ptr(xyzs), tr.M, nv.ptr(rows), float(bound), base_ptrs, None, nv.ptr(tr.planes), s)
+        nv.call("field_fwd_trace_rows", nv.ptr(xyzs), nv.ptr(dirs), tr.M, nv.ptr(rows), float(bound), base_ptrs, nv.ptr(packed), nv.ptr(tr.planes),
+                nv.ptr(tr.sig), nv.ptr(tr.rgb), nv.ptr(tr.masks), *[nv.ptr(a) for a in tr.act], s)
+
+
+def _backward_trace(tr, g_sigma, g_rgb, packed, g_sigma_params, g_color_params, rows=None):
+    """MLP backward + the weight gradients (written, not accumulated into); leaves d_planes for the level scatter."""
+    s = nv.stream()
+    if rows is None:
+        nv.call("field_bwd_trace", tr.M, nv.ptr(g_sigma), nv.ptr(g_rgb), nv.ptr(tr.sig), nv.ptr(tr.rgb), nv.ptr(tr.masks), nv.ptr(packed),
+                *[nv.ptr(t) for t in tr.d], nv.ptr(tr.d_planes), s)
+    else:
+        nv.call("field_bwd_trace_rows", tr.M, nv.ptr(rows), nv.ptr(g_sigma), nv.ptr(g_rgb), nv.ptr(tr.sig), nv.ptr(tr.rgb), nv.ptr(tr.masks),
+                nv.ptr(packed), *[nv.ptr(t) for t in tr.d], nv.ptr(tr.d_planes), s)
+    nv.call("field_wgrad", tr.M, nv.ptr(rows), nv.ptr(tr.planes), *[nv.ptr(a) for a in tr.act], *[nv.ptr(t) for t in tr.d], nv.ptr(tr.wgrad_scratch),
+            nv.ptr(g_sigma_params), nv.ptr(g_color_params), s)
 
 
 class _CleanFieldFunction(Function):
@@ -27,49 +94,39 @@ class _CleanFieldFunction(Function):
     def forward(ctx, xyzs, dirs, bound, sigma_params, color_params, *base):
         xyzs, dirs = xyzs.contiguous(), dirs.contiguous()
         M, dev = xyzs.shape[0], xyzs.device
-        stride = (M + 31) // 32 * 32
         packed = fo.pack_weights(sigma_params, color_params)          # the weights change every step
         base_ptrs = nv.ptr_array([fo._check_table(t.detach(), "base table") for t in base])
-        planes = torch.empty(17, stride, 2, dtype=torch.float32, device=dev)
-        s = nv.stream()
-        nv.call("hg_encode_planes", nv.ptr(xyzs), M, float(bound), base_ptrs, None, nv.ptr(planes), s)
-        sig = torch.empty(M, dtype=torch.float32, device=dev)
-        rgb = torch.empty(M, 3, dtype=torch.float32, device=dev)
-        masks = torch.empty(stride, fo.MASK_WORDS, dtype=torch.int32, device=dev)
-        act = [torch.empty(w, stride, dtype=torch.float32, device=dev) for w in (64, 32, 64, 64)]     # hs, cin, h1, h2
-        nv.call("field_fwd_trace", nv.ptr(xyzs), nv.ptr(dirs), M, float(bound), base_ptrs, nv.ptr(packed), nv.ptr(planes), nv.ptr(sig),
-                nv.ptr(rgb), nv.ptr(masks), *[nv.ptr(a) for a in act], s)
-        ctx.save_for_backward(xyzs, sig, rgb, masks, packed, planes, *act)
-        ctx.bound, ctx.M = float(bound), M
+        tr = _Traces(M, dev, with_grads=False)
+        _forward_trace(tr, xyzs, dirs, bound, base_ptrs, packed)
         ctx.table_grads = [t.requires_grad for t in base]
+        ctx.plan = None
+        if M and all(ctx.table_grads):      # where every (point, level) entry of the table scatter will go: positions only
+            ctx.plan = torch.empty(int(nv.fn("hg_levels_plan_bytes")(M)), dtype=torch.uint8, device=dev)
+            nv.call("hg_levels_plan", nv.ptr(xyzs), M, None, float(bound), nv.ptr(ctx.plan), nv.stream())
+        sig, rgb = tr.sig, tr.rgb
+        ctx.save_for_backward(sig, rgb)      # (outputs: kept through autograd's own mechanism, not as attributes of ctx)
+        tr.sig = tr.rgb = None
+        ctx.tr, ctx.packed, ctx.xyzs = tr, packed, xyzs
+        ctx.bound, ctx.M = float(bound), M
         return sig, rgb
 
     @staticmethod
     @custom_bwd(device_type="cuda")
     def backward(ctx, g_sigma, g_rgb):
-        xyzs, sig, rgb, masks, packed, planes, a_hs, a_cin, a_h1, a_h2 = ctx.saved_tensors
-        M, dev = ctx.M, xyzs.device
-        stride = planes.shape[1]
-        d_hs, d_h1, d_h2 = (torch.empty(64, stride, dtype=torch.float32, device=dev) for _ in range(3))
-        d_so, d_out = (torch.empty(16, stride, dtype=torch.float32, device=dev) for _ in range(2))
-        d_planes = torch.empty(16, stride, 2, dtype=torch.float32, device=dev)
-        nv.call("field_bwd_trace", M, nv.ptr(g_sigma.contiguous().float()), nv.ptr(g_rgb.contiguous().float()), nv.ptr(sig), nv.ptr(rgb),
-                nv.ptr(masks), nv.ptr(packed), nv.ptr(d_hs), nv.ptr(d_so), nv.ptr(d_h1), nv.ptr(d_h2), nv.ptr(d_out), nv.ptr(d_planes), nv.stream())
-        # weight gradients: (pre-activation gradient) x (layer input)^T over the M points
-        feat = planes[:16, :M]                                              # [16, M, 2] = the 32 features, level-major
-        dW1s = torch.einsum("om,lmc->olc", d_hs[:, :M], feat).reshape(64, 32)
-        dW2s = d_so[:, :M] @ a_hs[:, :M].t()
-        dWc1 = d_h1[:, :M] @ a_cin[:, :M].t()
-        dWc2 = d_h2[:, :M] @ a_h1[:, :M].t()
-        dWc3 = d_out[:, :M] @ a_h2[:, :M].t()
-        g_sp = torch.cat([dW1s.reshape(-1), dW2s.reshape(-1)])
-        g_cp = torch.cat([dWc1.reshape(-1), dWc2.reshape(-1), dWc3.reshape(-1)])
-        # base-table gradients: owner-computes scatter, all 16 levels in one launch (every row written by its owner: no zero fill)
-        if all(ctx.table_grads):
+        tr, xyzs, M, dev = ctx.tr, ctx.xyzs, ctx.M, ctx.xyzs.device
+        tr.sig, tr.rgb = ctx.saved_tensors
+        g_sp = torch.empty(N_SIGMA, dtype=torch.float32, device=dev)
+        g_cp = torch.empty(N_COLOR, dtype=torch.float32, device=dev)
+        if M == 0:
+            return (None, None, None, g_sp.zero_(), g_cp.zero_()) + tuple(torch.zeros(T_ROWS, 2, dtype=torch.float32, device=dev) if need else None
+                                                                         for need in ctx.table_grads)
+        tr.alloc_grads()
+        _backward_trace(tr, g_sigma.contiguous().float(), g_rgb.contiguous().float(), ctx.packed, g_sp, g_cp)
+        # base-table gradients: owner-computes scatter, all 16 levels at once (every row written by its owner: no zero fill)
+        if ctx.plan is not None:
             tables = torch.empty(16, T_ROWS, 2, dtype=torch.float32, device=dev)
-            scratch = torch.empty(nv.fn("hg_scatter_levels_scratch_bytes")(M), dtype=torch.uint8, device=dev)
-            nv.call("hg_scatter_levels", nv.ptr(xyzs), ctx.bound, nv.ptr(d_planes), M, stride, nv.ptr_array([tables[l] for l in range(16)]),
-                    nv.ptr(scratch), nv.stream())
+            nv.call("hg_levels_scatter", nv.ptr(xyzs), M, None, ctx.bound, nv.ptr(tr.d_planes), tr.stride, nv.ptr(ctx.plan),
+                    nv.ptr_array([tables[l] for l in range(16)]), nv.stream())
             grads = list(tables.unbind(0))
         else:
             grads = []
@@ -78,8 +135,9 @@ class _CleanFieldFunction(Function):
                     grads.append(None)
                     continue
                 G = torch.zeros(T_ROWS, 2, dtype=torch.float32, device=dev)
-                nv.call("hg_scatter_level", nv.ptr(xyzs), ctx.bound, nv.ptr(d_planes[level]), M, level, nv.ptr(G), nv.stream())
+                nv.call("hg_scatter_level", nv.ptr(xyzs), ctx.bound, nv.ptr(tr.d_planes[level]), M, level, nv.ptr(G), nv.stream())
                 grads.append(G)
+        ctx.tr = ctx.plan = None
         return (None, None, None, g_sp, g_cp) + tuple(grads)
 
 
@@ -127,10 +185,26 @@ class CleanNeRFNetwork(NeRFRenderer):
         return [{"params": self.encoder.parameters(), "lr": lr}, {"params": self.sigma_net.parameters(), "lr": lr},
                 {"params": self.encoder_dir.parameters(), "lr": lr}, {"params": self.color_net.parameters(), "lr": lr}]
 
+    def trainable(self):
+        """The 18 tensors a step updates, in the order of the flat gradient buffer: 16 base tables, sigma MLP, colour MLP."""
+        return list(self.encoder.tables()) + [self.sigma_net.params, self.color_net.params]
+
+
+def train_step(model, data, render_kwargs):
+    """nerf/utils.py:469-517 for RGB ground truth: render with perturbed samples, MSE.  Returns (pred_rgb, loss)."""
+    images = data["images"]
+    if images.shape[-1] != 3:
+        raise NotImplementedError("stage-1 train_step: RGB ground truth (the RGBA branch blends with a random background, utils.py:489-498)")
+    out = model.render(data["rays_o"], data["rays_d"], None, staged=False, bg_color=1, perturb=data.get("perturb", True),
+                       force_all_rays=data.get("force_all_rays", False), **render_kwargs)
+    loss = ((out["image"] - images) ** 2).mean(-1).mean()
+    return out["image"], loss
+
 
 class CleanLoop:
     """Loop body of the stage-1 trainer: render a batch of rays, MSE against the images, backward, optimiser step; every
-    `update_extra_interval` steps refresh the density grid (utils.py:852-869)."""
+    `update_extra_interval` steps refresh the density grid (utils.py:852-869).  With more than one rank the gradients are averaged
+    (dp.allreduce_gradients) before the optimiser step."""
 
     def __init__(self, model, optimizer, render_kwargs, update_extra_interval=16, lr_scheduler=None):
         self.model, self.optimizer, self.lr_scheduler = model, optimizer, lr_scheduler
@@ -143,11 +217,259 @@ class CleanLoop:
             self.model.update_extra_state()
         self.global_step += 1
         self.optimizer.zero_grad(set_to_none=True)
-        out = self.model.render(data["rays_o"], data["rays_d"], None, staged=False, bg_color=1, perturb=data.get("perturb", True),
-                                force_all_rays=data.get("force_all_rays", False), **self.render_kwargs)
-        loss = ((out["image"] - data["images"]) ** 2).mean(-1).mean()
+        image, loss = train_step(self.model, data, self.render_kwargs)
         loss.backward()
+        if dp.world_size() > 1:
+            dp.allreduce_gradients([p for g in self.optimizer.param_groups for p in g["params"]])
         self.optimizer.step()
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()
-        return out["image"], loss
+        return image, loss
+
+
+class GraphedCleanLoop:
+    """The stage-1 loop body captured into a hipGraph (module docstring).
+
+    One step = [draw rays (optional device-side loader)] -> capacity march with perturbed starts -> plan of the table scatter (side stream) |
+    encoder -> MLPs with saved layer inputs -> compositing + background -> MSE and its gradient -> compositing backward -> MLP backward ->
+    weight gradients -> table scatter -> [all-reduce of the flat gradient buffer] -> Adam over 16 tables + both MLPs -> re-pack of the MLP
+    weights for the next step.  Between replays, every `update_extra_interval` steps: NeRFRenderer.update_extra_state (eager; it reads the
+    sample totals of the last 16 steps back, the one host read of the loop) and a capacity check.
+
+    capacity: rows of the point buffers.  Every kernel walks only the rows the march produced (a device count), so a generous capacity
+    costs memory, not time; a step that produced more points than fit dropped its overflowing rays, exactly like the reference's bounded
+    march (raymarching.cu:416 with M = mean_count, the default of its stage-1 train_step: force_all_rays=False) -- `overflowed()` reports it,
+    and the grid-refresh check grows the buffers and captures again when a step came within 10 % of them.
+    sampler (rays.DeviceRaySampler): draws pose, pixels, rays and ground truth inside the graph from the step count; otherwise call
+    step(data) with 'rays_o', 'rays_d' [..,3] and 'images' [..,3] of `n_rays` rays (copied into the static buffers)."""
+
+    LOSS_RING = 1024
+
+    def __init__(self, model, optimizer, render_kwargs, n_rays, sampler=None, update_extra_interval=16, lr_lambda=None, headroom=0.5, perturb=True,
+                 capacity=None, overlap_plan=True, capture=True):
+        if not model.cuda_ray:
+            raise ValueError("GraphedCleanLoop drives the occupancy-grid path (cuda_ray=True)")
+        if model.density_scale != 1:
+            raise NotImplementedError("GraphedCleanLoop: density_scale != 1")
+        if not isinstance(optimizer, torch.optim.Adam) or any(g.get("weight_decay", 0) or g.get("amsgrad", False) or g.get("maximize", False)
+                                                               for g in optimizer.param_groups):
+            raise TypeError("GraphedCleanLoop steps a plain torch.optim.Adam (the reference's, main_nerf.py:122) through opt_adam_dense")
+        self.model, self.optimizer = model, optimizer
+        self.render_kwargs = dict(render_kwargs)
+        self.dt_gamma, self.max_steps = float(render_kwargs.get("dt_gamma", 0)), int(render_kwargs.get("max_steps", 1024))
+        self.T_thresh = float(render_kwargs.get("T_thresh", 1e-4))
+        self.n_rays, self.sampler, self.perturb = int(n_rays), sampler, bool(perturb)
+        self.update_extra_interval = int(update_extra_interval)
+        self.lr_lambda, self.headroom, self.capacity = lr_lambda, float(headroom), capacity
+        dev = self.device = model.density_bitfield.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        N = self.n_rays
+        self.rays_o, self.rays_d, self.gt = (torch.zeros(N, 3, **f32) for _ in range(3))
+        self.bg = torch.ones(3, **f32)
+        self.ws, self.depth, self.depth_out = (torch.empty(N, **f32) for _ in range(3))
+        self.image, self.image_out, self.g_image = (torch.empty(N, 3, **f32) for _ in range(3))
+        self.loss = torch.zeros(1, **f32)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)          # steps so far (advanced by the loss kernel)
+        self.count_ring = torch.zeros(16, 2, dtype=torch.int32, device=dev)    # the march's (points, rays) of the last 16 steps
+        self.loss_ring = torch.zeros(self.LOSS_RING, **f32)
+        # one flat gradient buffer: [16 tables | sigma MLP | colour MLP] -- the scatter owners and the weight-gradient reduction WRITE it
+        # (no zero fill), a data-parallel step all-reduces it in one collective, Adam reads it
+        self.params = model.trainable()
+        self.flat = torch.empty(16 * T_ROWS * 2 + N_SIGMA + N_COLOR, **f32)
+        self.g_tables = self.flat[:16 * T_ROWS * 2].view(16, T_ROWS, 2)
+        self.g_sigma = self.flat[16 * T_ROWS * 2:16 * T_ROWS * 2 + N_SIGMA]
+        self.g_color = self.flat[16 * T_ROWS * 2 + N_SIGMA:]
+        self.packed = torch.empty(int(nv.fn("mlp_packed_bytes")()), dtype=torch.uint8, device=dev)
+        self.base_lr = float(optimizer.param_groups[0]["lr"])
+        self.lr_dev = torch.tensor(self.base_lr, **f32)
+        self.plan_stream = torch.cuda.Stream() if overlap_plan else None
+        self.graph, self.tr, self.rec, self.plan = None, None, None, None
+        self.capture = bool(capture)      # False: the same explicit kernel sequence issued eagerly every step (tests, debugging)
+        self.global_step = 0
+        self.recaptures = 0
+        self.bytes_exchanged_per_step = self.flat.numel() * 4 if dp.exchange_active() else 0
+
+    # ---- pieces of one step (run eagerly once as warm-up, then under capture)
+    def _march(self):
+        return self.model.march_ahead(self.rays_o, self.rays_d, self.dt_gamma, self.max_steps, perturb=self.perturb, capacity=self.capacity)
+
+    def _forward_backward(self):
+        m, tr = self.model, self.tr
+        if self.sampler is not None:
+            self.sampler.sample_into(self.step_dev, self.rays_o, self.rays_d, self.gt)
+        rec = self.rec = self._march()
+        rows = rec["counter"]                                     # [points, rays] int32: element 0 is the device row count
+        xyzs, dirs, M, N = rec["xyzs"], rec["dirs"], self.capacity, self.n_rays
+        main = torch.cuda.current_stream()
+        if self.plan_stream is not None:
+            self.plan_stream.wait_stream(main)
+            with torch.cuda.stream(self.plan_stream):
+                nv.call("hg_levels_plan", nv.ptr(xyzs), M, nv.ptr(rows), float(m.bound), nv.ptr(self.plan), nv.stream())
+        else:
+            nv.call("hg_levels_plan", nv.ptr(xyzs), M, nv.ptr(rows), float(m.bound), nv.ptr(self.plan), nv.stream())
+        base_ptrs = nv.ptr_array([t.detach() for t in m.encoder.tables()])
+        _forward_trace(tr, xyzs, dirs, m.bound, base_ptrs, self.packed, rows=rows)
+        s = nv.stream()
+        nv.call("rm_composite_train_finish_fwd", nv.ptr(tr.sig), nv.ptr(tr.rgb), nv.ptr(rec["deltas"]), nv.ptr(rec["rays"]), M, N, self.T_thresh,
+                nv.ptr(rec["nears"]), nv.ptr(rec["fars"]), nv.ptr(self.bg), 0, nv.ptr(self.ws), nv.ptr(self.depth), nv.ptr(self.image),
+                nv.ptr(self.image_out), nv.ptr(self.depth_out), s)
+        # the loss of the global batch is the mean over the ranks' losses: each rank seeds 1 / world, the exchange sums
+        nv.call("clean_loss", nv.ptr(self.image_out), nv.ptr(self.gt), 3 * N, 1.0 / dp.world_size(), nv.ptr(self.loss), nv.ptr(self.g_image),
+                nv.ptr(self.step_dev), nv.ptr(rows), nv.ptr(self.count_ring), nv.ptr(self.loss_ring), self.LOSS_RING, s)
+        nv.call("rm_composite_train_finish_bwd", None, nv.ptr(self.g_image), nv.ptr(tr.sig), nv.ptr(tr.rgb), nv.ptr(rec["deltas"]), nv.ptr(rec["rays"]),
+                nv.ptr(self.ws), nv.ptr(self.image), nv.ptr(self.bg), 0, M, N, self.T_thresh, 1, nv.ptr(self.g_sig), nv.ptr(self.g_rgb), s)
+        _backward_trace(tr, self.g_sig, self.g_rgb, self.packed, self.g_sigma, self.g_color, rows=rows)
+        if self.plan_stream is not None:
+            main.wait_stream(self.plan_stream)
+        nv.call("hg_levels_scatter", nv.ptr(xyzs), M, nv.ptr(rows), float(m.bound), nv.ptr(tr.d_planes), tr.stride, nv.ptr(self.plan),
+                nv.ptr_array([self.g_tables[l] for l in range(16)]), s)
+
+    def _exchange(self):
+        if dp.exchange_active():
+            import torch.distributed as dist
+            flat = self.flat
+            dp.collective(lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM))
+
+    def _optimise(self):
+        from .optim import _step_dense
+        _step_dense(self.optimizer, self.lr_dev, 1.0)
+        nv.call("mlp_pack_weights", nv.ptr(self.model.sigma_net.params.detach()), nv.ptr(self.model.color_net.params.detach()), nv.ptr(self.packed), nv.stream())
+
+    def _whole_step(self):
+        self._forward_backward()
+        self._exchange()
+        self._optimise()
+        return self.loss
+
+    # ---- set-up
+    def _size(self):
+        """One synchronising march of the current rays: the point count the buffers have to hold (+ headroom)."""
+        m = self.model
+        if self.sampler is not None:
+            self.sampler.sample_into(self.step_dev, self.rays_o, self.rays_d, self.gt)
+        probe = m.march_ahead(self.rays_o, self.rays_d, self.dt_gamma, self.max_steps, perturb=False, capacity=128)
+        n = int(probe["counter"][0])
+        m.drop_marched()
+        return padded_point_count(int(max(n, 4096) * (1.0 + self.headroom)))
+
+    def _allocate(self):
+        dev, M = self.device, self.capacity
+        self.tr = _Traces(M, dev)
+        self.g_sig = torch.empty(M, dtype=torch.float32, device=dev)
+        self.g_rgb = torch.empty(M, 3, dtype=torch.float32, device=dev)
+        self.plan = torch.empty(int(nv.fn("hg_levels_plan_bytes")(M)), dtype=torch.uint8, device=dev)
+
+    @torch.no_grad()
+    def prepare(self):
+        if self.capacity is None:
+            self.capacity = self._size()
+        self._allocate()
+        for p, g in zip(self.params, list(self.g_tables.unbind(0)) + [self.g_sigma, self.g_color]):
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                raise ValueError("GraphedCleanLoop: parameters must be contiguous float32 CUDA tensors")
+            p.grad = g.view_as(p)          # views of the flat buffer: what the kernels write is what an optimiser / a checkpoint sees
+        nv.call("mlp_pack_weights", nv.ptr(self.model.sigma_net.params.detach()), nv.ptr(self.model.color_net.params.detach()), nv.ptr(self.packed), nv.stream())
+        # warm-up on a side stream (Adam state in its capturable format, module loading, RCCL's lazy set-up); it must not train
+        snap = self._snapshot()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._whole_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._restore(snap)
+        self.graph = SegmentedCapture()
+        if self.capture:
+            self.graph.capture(self._whole_step)
+        return self
+
+    def _snapshot(self):
+        state = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.optimizer.state[p].items()} for p in self.params if len(self.optimizer.state[p])}
+        return ([p.detach().clone() for p in self.params], state, self.step_dev.clone(), self.count_ring.clone(), self.loss_ring.clone(),
+                torch.cuda.get_rng_state(self.device))
+
+    def _restore(self, snap):
+        values, state, step_dev, count_ring, loss_ring, rng = snap
+        for p, v in zip(self.params, values):
+            p.copy_(v)
+        for p in self.params:
+            for k, v in self.optimizer.state[p].items():
+                if torch.is_tensor(v):
+                    if p in state and k in state[p]:
+                        v.copy_(state[p][k].to(v.device))
+                    else:
+                        v.zero_()      # state created by the warm-up: back to its initial value, same storage (the graph holds its address)
+        self.step_dev.copy_(step_dev)
+        self.count_ring.copy_(count_ring)
+        self.loss_ring.copy_(loss_ring)
+        torch.cuda.set_rng_state(rng, self.device)
+        nv.call("mlp_pack_weights", nv.ptr(self.model.sigma_net.params.detach()), nv.ptr(self.model.color_net.params.detach()), nv.ptr(self.packed), nv.stream())
+
+    # ---- the loop
+    @torch.no_grad()
+    def refresh_grid(self):
+        """update_extra_state between two replays (utils.py:852-857), with the loop's own ring of sample totals standing in for the renderer's."""
+        m = self.model
+        done = min(16, self.global_step)
+        if done:
+            m.step_counter.copy_(self.count_ring)
+            m.local_step = done if self.global_step < 16 else 16
+        m.update_extra_state()
+        if self.graph is not None and done:
+            peak = int(self.count_ring[:done, 0].max())
+            if peak > 0.9 * self.capacity:
+                self._grow(peak)
+
+    def _grow(self, peak):
+        torch.cuda.synchronize()
+        self.capacity = padded_point_count(int(peak * (1.0 + max(self.headroom, 0.25)) * 1.25))
+        self.graph, self.rec = None, None
+        self.model.drop_marched()
+        self.recaptures += 1
+        self.prepare()
+
+    @torch.no_grad()
+    def step(self, data=None):
+        if self.update_extra_interval > 0 and self.global_step % self.update_extra_interval == 0:
+            self.refresh_grid()
+        if self.graph is None:
+            if data is not None:
+                self._set_batch(data)
+            self.prepare()
+        if data is not None:
+            self._set_batch(data)
+        if self.lr_lambda is not None:
+            self.lr_dev.fill_(self.base_lr * self.lr_lambda(self.global_step))
+        if self.capture:
+            self.graph.replay()
+        else:
+            self._whole_step()
+        self.global_step += 1
+        return self.loss
+
+    def _set_batch(self, data):
+        if self.sampler is not None:
+            raise ValueError("GraphedCleanLoop: this loop draws its own batches (sampler=)")
+        for dst, key in ((self.rays_o, "rays_o"), (self.rays_d, "rays_d"), (self.gt, "images")):
+            src = data[key]
+            if src.numel() != dst.numel():
+                raise ValueError(f"GraphedCleanLoop: '{key}' must hold {self.n_rays} x 3 values")
+            dst.copy_(src.reshape(dst.shape), non_blocking=True)
+
+    def overflowed(self):
+        """True if one of the last (up to 16) steps produced more points than the buffers hold (one host read)."""
+        done = min(16, self.global_step)
+        return bool(done and int(self.count_ring[:done, 0].max()) > self.capacity)
+
+    def losses(self, last=None):
+        """The loss values of the last `last` steps (default: all that the ring still holds), oldest first (one host read)."""
+        n = min(self.global_step, self.LOSS_RING if last is None else last)
+        ring = self.loss_ring.cpu()
+        return [float(ring[(self.global_step - n + i) % self.LOSS_RING]) for i in range(n)]
+
+    def close(self):
+        for p in self.params:
+            p.grad = None
+        self.model.drop_marched()
+        self.graph = None
