@@ -556,7 +556,8 @@ int hg_scatter_levels(const float *xyzs, float bound, const void *d_planes, uint
  * clean_loss: loss[0] = mean((image - gt)^2) over n_values = N * 3 elements (nerf/utils.py:503, `.mean(-1)` then `.mean()`),
  * grad_image = grad_scale * d loss / d image.  Optional bookkeeping of a captured loop, by the same workgroup (any pointer may be
  * NULL): count_ring [16][2] row (*step_dev % 16) = march_counter[0..1] (the ring NeRFRenderer.step_counter is, renderer_wtmk.py:282-284),
- * loss_ring[*step_dev % loss_ring_len] = loss, then *step_dev += 1.
+ * loss_ring[*step_dev % loss_ring_len] = loss, noise_next[0..n_noise) = the next step's per-ray march offsets, U[0,1) as a pure function
+ * of (seed, *step_dev + 1, ray) (the reference draws them with torch.rand, raymarching.py:213), then *step_dev += 1.
  */
 int field_fwd_trace_rows(const float *xyzs, const float *dirs, uint32_t M_capacity, const uint32_t *rows_dev, float bound,
                          const float *const *base_tables_host, const void *packed, const void *planes, float *sigmas, float *rgbs,
@@ -570,7 +571,7 @@ int field_wgrad(uint32_t M, const uint32_t *rows_dev, const void *planes, const 
                 void *scratch, float *grad_sigma_params, float *grad_color_params, nsig_stream_t stream);
 int clean_loss(const float *image, const float *gt, uint32_t n_values, float grad_scale, float *loss, float *grad_image,
                uint32_t *step_dev, const int32_t *march_counter, int32_t *count_ring, float *loss_ring, uint32_t loss_ring_len,
-               nsig_stream_t stream);
+               float *noise_next, uint32_t n_noise, uint64_t seed, nsig_stream_t stream);
 /*
  * hg_scatter_levels in two halves.  hg_levels_plan needs the sample positions only -- which slice owner every (point, level, (dy,dz)
  * pair) entry goes to, and where in that owner's queue -- so a step runs it beside its forward pass; hg_levels_scatter, behind the MLP

@@ -560,10 +560,13 @@ __global__ void __launch_bounds__(kBinThreads) k_levels_plan_dest(const float *_
 }
 
 // feature gradient of (point, level) -> its four pair entries at their planned places; raises the level's max |gradient|
-__global__ void __launch_bounds__(256) k_level_entries(const float *__restrict__ xyzs, uint32_t M, const uint32_t *__restrict__ rows_dev, float bound,
+__global__ void __launch_bounds__(kBinThreads) k_level_entries(const float *__restrict__ xyzs, uint32_t M, const uint32_t *__restrict__ rows_dev, float bound,
                                                        const float2 *__restrict__ dplanes, uint32_t stride, LevelGeom geom, BinHeader *__restrict__ hd_all,
                                                        const uint4 *__restrict__ dest_all, uint4 *__restrict__ queue_all) {
-    const uint32_t m = blockIdx.x * 256u + threadIdx.x, level = blockIdx.y;
+    // one workgroup = one 1024-point chunk of the plan: its entries of a slice are one contiguous run of the queue, written by waves of ONE
+    // compute unit -- the 16-byte stores merge into whole lines in that XCD's L2 (256-thread workgroups scattered a run's lines over four
+    // L2s: 104 -> ... us, profiles/r05_stage1_steps.txt)
+    const uint32_t m = blockIdx.x * kBinThreads + threadIdx.x, level = blockIdx.y;
     const uint32_t n = rows_dev != nullptr ? min(M, *rows_dev) : M;
     uint32_t gb = 0;
     if (m < n) {
@@ -1353,11 +1356,19 @@ NSIG_EXPORT int hg_levels_scatter(const float *xyzs, uint32_t M, const uint32_t 
     BinHeader *hd = reinterpret_cast<BinHeader *>(plan);
     uint4 *queue = reinterpret_cast<uint4 *>(hd + NSIG_BASE_LEVELS);
     const uint4 *dest = queue + (size_t)NSIG_BASE_LEVELS * 4 * M;
-    k_level_entries<<<dim3(ceil_div(M, 256u), NSIG_BASE_LEVELS), 256, 0, st>>>(xyzs, M, rows_dev, bound, reinterpret_cast<const float2 *>(d_planes), stride,
+    k_level_entries<<<dim3(ceil_div(M, kBinThreads), NSIG_BASE_LEVELS), kBinThreads, 0, st>>>(xyzs, M, rows_dev, bound, reinterpret_cast<const float2 *>(d_planes), stride,
                                                                               make_level_geom(), hd, dest, queue);
     if (int e = check_launch("hg_levels_scatter (entries)")) return e;
     // every (level, slice) has a single owner, which stores its rows: the tables are written, not accumulated into
+#ifdef NSIG_LEVELS_SPLIT      // diagnostic build (tools/build_variant.sh): one owner launch per level, so that a kernel trace shows each level's time
+    for (int l = 0; l < NSIG_BASE_LEVELS; ++l) {
+        ScatterTargets one{};
+        one.g[0] = tg.g[l];
+        k_scatter_binned<<<dim3(kBinSlices, 1), 1024, (size_t)kBinRows * 2 * sizeof(unsigned long long), st>>>(hd + l, queue + (size_t)l * 4 * M, M, one, 1u);
+    }
+#else
     k_scatter_binned<<<dim3(kBinSlices, NSIG_BASE_LEVELS), 1024, (size_t)kBinRows * 2 * sizeof(unsigned long long), st>>>(hd, queue, M, tg, 1u);
+#endif
     return check_launch("hg_levels_scatter");
 }
 

@@ -30,7 +30,7 @@ namespace nsig {
 // Waves stride over the K-steps; a workgroup's four waves are summed through LDS and the workgroup stores ONE slab of 4096 partial sums
 // in accumulator order; k_wgrad_reduce adds the slabs in workgroup order and writes tcnn's layout ([out][in] row-major).
 constexpr uint32_t kWgradRoles = 3, kWgradSlab = 4u * 16u * 64u;   // floats per (workgroup, role): 4 products x 16 registers x 64 lanes
-constexpr uint32_t kWgradMaxWGs = 256;
+constexpr uint32_t kWgradMaxWGs = 168;     // x 3 roles x 4 waves = 2016 waves: one resident round at two waves per SIMD (196 registers)
 
 struct WgradArgs {
     const float2 *planes;                               // [16][stride] float2: encoder features 2l, 2l+1 of level l
@@ -156,8 +156,21 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float *__restrict__ 
     const uint32_t e = blockIdx.x * 256u + threadIdx.x;      // (role, product, register, lane)
     if (e >= kWgradRoles * kWgradSlab) return;
     const uint32_t role = e / kWgradSlab, i = e % kWgradSlab;
+    // sixteen slabs in flight per thread (a chain of one dependent load per slab took 60 us for 128 slabs); the partial sums are combined in
+    // a fixed order: the same bits every run
+    float part[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) part[u] = 0.0f;
+    for (uint32_t w0 = 0; w0 < n_wg; w0 += 16u) {
+        float v[16];
+#pragma unroll
+        for (uint32_t u = 0; u < 16u; ++u) v[u] = w0 + u < n_wg ? slabs[((size_t)(w0 + u) * kWgradRoles + role) * kWgradSlab + i] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) part[u] += v[u];
+    }
     float s = 0.0f;
-    for (uint32_t w = 0; w < n_wg; ++w) s += slabs[((size_t)w * kWgradRoles + role) * kWgradSlab + i];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += part[u];
     const uint32_t q = i >> 10, reg = (i >> 6) & 15u, lane = i & 63u;
     const uint32_t row = (uint32_t)row_of_reg16((int)(lane >> 5), (int)reg), col = lane & 31u;
     if (role == 0) {
@@ -177,11 +190,27 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float *__restrict__ 
 // The same single workgroup keeps a captured loop's books (every pointer optional): the march's (points, rays) totals into row step % 16 of a ring
 // -- what NeRFRenderer.step_counter holds for update_extra_state's mean_count (renderer_wtmk.py:282-284,533-536) --, the loss into a ring
 // the host reads whenever it likes, and the step count itself, advanced here: nothing of a step's tail reads it, the next replay's head does.
+__device__ inline uint64_t mix64(uint64_t z) {      // splitmix64's finaliser
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
 __global__ void __launch_bounds__(1024) k_clean_loss(const float *__restrict__ image, const float *__restrict__ gt, uint32_t n, float grad_scale,
                                                      float *__restrict__ loss, float *__restrict__ g_image, uint32_t *__restrict__ step_dev,
                                                      const int32_t *__restrict__ march_counter, int32_t *__restrict__ count_ring,
-                                                     float *__restrict__ loss_ring, uint32_t loss_ring_len) {
+                                                     float *__restrict__ loss_ring, uint32_t loss_ring_len, float *__restrict__ noise_next,
+                                                     uint32_t n_noise, uint64_t seed) {
     __shared__ float scratch[16];
+    // the NEXT step's per-ray start offsets (perturb=True: `noises = torch.rand(N)`, raymarching.py:213): U[0, 1) as a pure function of
+    // (seed, step + 1, ray) -- a replayed graph draws fresh values without a host-side generator (torch.rand under capture costs two
+    // fill launches per replay for its seed / offset tensors).  This step's march has long consumed its own values.
+    if (noise_next != nullptr) {
+        const uint64_t key = mix64(seed ^ (0x9E3779B97F4A7C15ull * ((uint64_t)(step_dev != nullptr ? *step_dev : 0u) + 2ull)));
+        for (uint32_t i = threadIdx.x; i < n_noise; i += 1024u)
+            noise_next[i] = (float)(uint32_t)(mix64(key + 0xD1B54A32D192ED03ull * ((uint64_t)i + 1ull)) >> 40) * (1.0f / 16777216.0f);
+    }
+    __syncthreads();      // (every thread has read the step count before thread 0 advances it)
     float s = 0.0f;
     const float k = grad_scale * 2.0f / (float)n;
     for (uint32_t i = threadIdx.x; i < n; i += 1024u) {
@@ -237,9 +266,11 @@ NSIG_EXPORT int field_wgrad(uint32_t M, const uint32_t *rows_dev, const void *pl
 }
 
 NSIG_EXPORT int clean_loss(const float *image, const float *gt, uint32_t n_values, float grad_scale, float *loss, float *grad_image, uint32_t *step_dev,
-                           const int32_t *march_counter, int32_t *count_ring, float *loss_ring, uint32_t loss_ring_len, nsig_stream_t stream) {
+                           const int32_t *march_counter, int32_t *count_ring, float *loss_ring, uint32_t loss_ring_len, float *noise_next,
+                           uint32_t n_noise, uint64_t seed, nsig_stream_t stream) {
     NSIG_REQUIRE(image && gt && loss && grad_image, "clean_loss: null pointer");
     NSIG_REQUIRE(n_values >= 1, "clean_loss: empty input");
-    k_clean_loss<<<1, 1024, 0, as_stream(stream)>>>(image, gt, n_values, grad_scale, loss, grad_image, step_dev, march_counter, count_ring, loss_ring, loss_ring_len);
+    k_clean_loss<<<1, 1024, 0, as_stream(stream)>>>(image, gt, n_values, grad_scale, loss, grad_image, step_dev, march_counter, count_ring, loss_ring, loss_ring_len,
+                                                    noise_next, n_noise, seed);
     return check_launch("clean_loss");
 }

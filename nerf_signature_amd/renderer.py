@@ -279,14 +279,15 @@ class NeRFRenderer(nn.Module):
     def _rays_key(o, d):
         return (o.data_ptr(), o._version, d.data_ptr(), d._version, o.shape[0])
 
-    def march_ahead(self, rays_o, rays_d, dt_gamma=0, max_steps=1024, perturb=False, phase="all", capacity=None):
+    def march_ahead(self, rays_o, rays_d, dt_gamma=0, max_steps=1024, perturb=False, phase="all", capacity=None, noises=None):
         """March the training samples of these rays now, for a render issued later with the same (unmodified) ray tensors.
 
         The march needs the rays and the occupancy grid only -- nothing a training step updates -- so a loop that knows its next
         rays runs it beside the optimiser of the current step (an HBM stream that leaves the ALUs idle) instead of at the head of
         the next one.  Needs `point_capacity` (the no-host-sync march); a repeated call for the same tensors re-marches into the
         same buffers.  run_cuda picks the samples up by the tensors' addresses and versions; any in-place change of the rays after
-        the call makes it march again as usual.
+        the call makes it march again as usual.  noises: the per-ray start offsets [N] drawn by the caller (instead of torch.rand under perturb=True:
+        a captured loop that keeps its own counter-based draws, stage1.GraphedCleanLoop).
 
         phase: "all", or the two halves separately -- "count" (near/far and the occupancy walk: writes only per-ray counts and the
         sampled parameters, scratch nobody else reads) and "write" (prefix sum + the sample buffers, which overwrite what the current
@@ -314,11 +315,11 @@ class NeRFRenderer(nn.Module):
         geom = (float(self.bound), float(dt_gamma), int(max_steps), N, int(self.cascade), int(self.grid_size))
         if phase in ("all", "count") and not raymarching.fused_limits():
             raymarching.near_far_into(o, d, self.aabb_train, self.min_near, rec["nears"], rec["fars"])
-            rec["noises"] = torch.rand(N, dtype=torch.float32, device=o.device) if perturb else None
+            rec["noises"] = noises if noises is not None else (torch.rand(N, dtype=torch.float32, device=o.device) if perturb else None)
             nv.call("rm_march_train_count", nv.ptr(o), nv.ptr(d), nv.ptr(self.density_bitfield), *geom, nv.ptr(rec["nears"]), nv.ptr(rec["fars"]),
                     nv.ptr(rec["noises"]), nv.ptr(rec["counts"]), nv.ptr(rec["t_rec"]), nv.stream())
         elif phase in ("all", "count"):       # the walk computes the rays' limits itself: no near/far launch in front of it
-            rec["noises"] = torch.rand(N, dtype=torch.float32, device=o.device) if perturb else None
+            rec["noises"] = noises if noises is not None else (torch.rand(N, dtype=torch.float32, device=o.device) if perturb else None)
             nv.call("rm_march_train_count_nf", nv.ptr(o), nv.ptr(d), nv.ptr(self.aabb_train), float(self.min_near), nv.ptr(self.density_bitfield), *geom,
                     nv.ptr(rec["noises"]), nv.ptr(rec["nears"]), nv.ptr(rec["fars"]), nv.ptr(rec["counts"]), nv.ptr(rec["t_rec"]), nv.stream())
         if phase in ("all", "write"):

@@ -246,7 +246,7 @@ class GraphedCleanLoop:
     LOSS_RING = 1024
 
     def __init__(self, model, optimizer, render_kwargs, n_rays, sampler=None, update_extra_interval=16, lr_lambda=None, headroom=0.5, perturb=True,
-                 capacity=None, overlap_plan=True, capture=True):
+                 capacity=None, overlap_plan=True, capture=True, seed=0):
         if not model.cuda_ray:
             raise ValueError("GraphedCleanLoop drives the occupancy-grid path (cuda_ray=True)")
         if model.density_scale != 1:
@@ -272,6 +272,10 @@ class GraphedCleanLoop:
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)          # steps so far (advanced by the loss kernel)
         self.count_ring = torch.zeros(16, 2, dtype=torch.int32, device=dev)    # the march's (points, rays) of the last 16 steps
         self.loss_ring = torch.zeros(self.LOSS_RING, **f32)
+        # perturb=True: the per-ray start offsets of a step (raymarching.py:213 `torch.rand(N)`): the first step's from torch's generator, every later
+        # step's written by the previous step's loss kernel as a function of (seed, step, ray)
+        self.seed = int(seed)
+        self.noises = torch.rand(N, **f32) if self.perturb else None
         # one flat gradient buffer: [16 tables | sigma MLP | colour MLP] -- the scatter owners and the weight-gradient reduction WRITE it
         # (no zero fill), a data-parallel step all-reduces it in one collective, Adam reads it
         self.params = model.trainable()
@@ -291,7 +295,8 @@ class GraphedCleanLoop:
 
     # ---- pieces of one step (run eagerly once as warm-up, then under capture)
     def _march(self):
-        return self.model.march_ahead(self.rays_o, self.rays_d, self.dt_gamma, self.max_steps, perturb=self.perturb, capacity=self.capacity)
+        return self.model.march_ahead(self.rays_o, self.rays_d, self.dt_gamma, self.max_steps, perturb=self.perturb, capacity=self.capacity,
+                                      noises=self.noises if self.perturb else None)
 
     def _forward_backward(self):
         m, tr = self.model, self.tr
@@ -315,7 +320,7 @@ class GraphedCleanLoop:
                 nv.ptr(self.image_out), nv.ptr(self.depth_out), s)
         # the loss of the global batch is the mean over the ranks' losses: each rank seeds 1 / world, the exchange sums
         nv.call("clean_loss", nv.ptr(self.image_out), nv.ptr(self.gt), 3 * N, 1.0 / dp.world_size(), nv.ptr(self.loss), nv.ptr(self.g_image),
-                nv.ptr(self.step_dev), nv.ptr(rows), nv.ptr(self.count_ring), nv.ptr(self.loss_ring), self.LOSS_RING, s)
+                nv.ptr(self.step_dev), nv.ptr(rows), nv.ptr(self.count_ring), nv.ptr(self.loss_ring), self.LOSS_RING, nv.ptr(self.noises), N, self.seed, s)
         nv.call("rm_composite_train_finish_bwd", None, nv.ptr(self.g_image), nv.ptr(tr.sig), nv.ptr(tr.rgb), nv.ptr(rec["deltas"]), nv.ptr(rec["rays"]),
                 nv.ptr(self.ws), nv.ptr(self.image), nv.ptr(self.bg), 0, M, N, self.T_thresh, 1, nv.ptr(self.g_sig), nv.ptr(self.g_rgb), s)
         _backward_trace(tr, self.g_sig, self.g_rgb, self.packed, self.g_sigma, self.g_color, rows=rows)
@@ -387,10 +392,10 @@ class GraphedCleanLoop:
     def _snapshot(self):
         state = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.optimizer.state[p].items()} for p in self.params if len(self.optimizer.state[p])}
         return ([p.detach().clone() for p in self.params], state, self.step_dev.clone(), self.count_ring.clone(), self.loss_ring.clone(),
-                torch.cuda.get_rng_state(self.device))
+                None if self.noises is None else self.noises.clone())
 
     def _restore(self, snap):
-        values, state, step_dev, count_ring, loss_ring, rng = snap
+        values, state, step_dev, count_ring, loss_ring, noises = snap
         for p, v in zip(self.params, values):
             p.copy_(v)
         for p in self.params:
@@ -403,7 +408,8 @@ class GraphedCleanLoop:
         self.step_dev.copy_(step_dev)
         self.count_ring.copy_(count_ring)
         self.loss_ring.copy_(loss_ring)
-        torch.cuda.set_rng_state(rng, self.device)
+        if noises is not None:
+            self.noises.copy_(noises)
         nv.call("mlp_pack_weights", nv.ptr(self.model.sigma_net.params.detach()), nv.ptr(self.model.color_net.params.detach()), nv.ptr(self.packed), nv.stream())
 
     # ---- the loop
