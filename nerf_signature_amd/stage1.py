@@ -17,7 +17,7 @@ Three ways to drive it:
                          no autograd, no allocation, no host read inside a step; the density grid is refreshed between replays
                          every `update_extra_interval` steps as the reference does; data-parallel ranks exchange ONE flat
                          buffer [16 table gradients | MLP gradients] per step."""
-import ctypes
+import contextlib
 
 import torch
 from torch.autograd import Function
@@ -75,8 +75,10 @@ def _forward_trace(tr, xyzs, dirs, bound, base_ptrs, packed, rows=None):
                 nv.ptr(tr.sig), nv.ptr(tr.rgb), nv.ptr(tr.masks), *[nv.ptr(a) for a in tr.act], s)
 
 
-def _backward_trace(tr, g_sigma, g_rgb, packed, g_sigma_params, g_color_params, rows=None):
-    """MLP backward + the weight gradients (written, not accumulated into); leaves d_planes for the level scatter."""
+def _backward_trace(tr, g_sigma, g_rgb, packed, g_sigma_params, g_color_params, rows=None, wgrad_stream=None):
+    """MLP backward + the weight gradients (written, not accumulated into); leaves d_planes for the level scatter.
+    wgrad_stream: the weight-gradient reduction is issued there (the caller joins it): it and the table scatter both need the backward's
+    traces and nothing of each other."""
     s = nv.stream()
     if rows is None:
         nv.call("field_bwd_trace", tr.M, nv.ptr(g_sigma), nv.ptr(g_rgb), nv.ptr(tr.sig), nv.ptr(tr.rgb), nv.ptr(tr.masks), nv.ptr(packed),
@@ -84,8 +86,11 @@ def _backward_trace(tr, g_sigma, g_rgb, packed, g_sigma_params, g_color_params, 
     else:
         nv.call("field_bwd_trace_rows", tr.M, nv.ptr(rows), nv.ptr(g_sigma), nv.ptr(g_rgb), nv.ptr(tr.sig), nv.ptr(tr.rgb), nv.ptr(tr.masks),
                 nv.ptr(packed), *[nv.ptr(t) for t in tr.d], nv.ptr(tr.d_planes), s)
-    nv.call("field_wgrad", tr.M, nv.ptr(rows), nv.ptr(tr.planes), *[nv.ptr(a) for a in tr.act], *[nv.ptr(t) for t in tr.d], nv.ptr(tr.wgrad_scratch),
-            nv.ptr(g_sigma_params), nv.ptr(g_color_params), s)
+    if wgrad_stream is not None:
+        wgrad_stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(wgrad_stream) if wgrad_stream is not None else contextlib.nullcontext():
+        nv.call("field_wgrad", tr.M, nv.ptr(rows), nv.ptr(tr.planes), *[nv.ptr(a) for a in tr.act], *[nv.ptr(t) for t in tr.d], nv.ptr(tr.wgrad_scratch),
+                nv.ptr(g_sigma_params), nv.ptr(g_color_params), nv.stream())
 
 
 class _CleanFieldFunction(Function):
@@ -310,6 +315,8 @@ class GraphedCleanLoop:
             self.plan_stream.wait_stream(main)
             with torch.cuda.stream(self.plan_stream):
                 nv.call("hg_levels_plan", nv.ptr(xyzs), M, nv.ptr(rows), float(m.bound), nv.ptr(self.plan), nv.stream())
+                self._plan_done = torch.cuda.Event()
+                self._plan_done.record()
         else:
             nv.call("hg_levels_plan", nv.ptr(xyzs), M, nv.ptr(rows), float(m.bound), nv.ptr(self.plan), nv.stream())
         base_ptrs = nv.ptr_array([t.detach() for t in m.encoder.tables()])
@@ -323,11 +330,15 @@ class GraphedCleanLoop:
                 nv.ptr(self.step_dev), nv.ptr(rows), nv.ptr(self.count_ring), nv.ptr(self.loss_ring), self.LOSS_RING, nv.ptr(self.noises), N, self.seed, s)
         nv.call("rm_composite_train_finish_bwd", None, nv.ptr(self.g_image), nv.ptr(tr.sig), nv.ptr(tr.rgb), nv.ptr(rec["deltas"]), nv.ptr(rec["rays"]),
                 nv.ptr(self.ws), nv.ptr(self.image), nv.ptr(self.bg), 0, M, N, self.T_thresh, 1, nv.ptr(self.g_sig), nv.ptr(self.g_rgb), s)
-        _backward_trace(tr, self.g_sig, self.g_rgb, self.packed, self.g_sigma, self.g_color, rows=rows)
-        if self.plan_stream is not None:
-            main.wait_stream(self.plan_stream)
+        # the weight gradients (a latency-bound streaming reduction) run beside the table scatter (store- and LDS-bound) on the plan's stream,
+        # which has long finished the plan by then (stream order: plan, then the weight gradients)
+        _backward_trace(tr, self.g_sig, self.g_rgb, self.packed, self.g_sigma, self.g_color, rows=rows, wgrad_stream=self.plan_stream)
+        if self.plan_stream is not None:      # the scatter needs the plan: an event recorded behind the plan, not the whole side stream
+            main.wait_event(self._plan_done)
         nv.call("hg_levels_scatter", nv.ptr(xyzs), M, nv.ptr(rows), float(m.bound), nv.ptr(tr.d_planes), tr.stride, nv.ptr(self.plan),
                 nv.ptr_array([self.g_tables[l] for l in range(16)]), s)
+        if self.plan_stream is not None:
+            main.wait_stream(self.plan_stream)      # ... and the step's tail needs the weight gradients
 
     def _exchange(self):
         if dp.exchange_active():
