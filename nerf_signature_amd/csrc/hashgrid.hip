@@ -438,157 +438,299 @@ __global__ void __launch_bounds__(kBinThreads) k_plan_dest(const float *__restri
     }
 }
 
-// ---- the planned variant over the 16 base levels (stage-1 training: every base table has its own gradient).  blockIdx.y = level.
-// Where an entry goes depends on the point's position and the level's cell only, so count and destinations are computed beside the
-// forward pass (hg_levels_plan); behind the MLP backward one pass turns the feature gradients into queue entries (k_level_entries)
-// and the 16 x 64 slice owners run.  Against the record route (k_level_records -> k_bin_count -> k_bin_scan -> k_bin_write) the step's
-// critical path loses three launches and the 32-byte records' round trip.  The point count is a device value (`rows_dev`, may be
-// null): a captured step sizes its launches for the buffers' capacity M and walks only the rows the march produced.
-__device__ inline void level_point_slices(const float *__restrict__ xyzs, uint32_t m, float bound, float cell, uint32_t (&sl)[4]) {
+// ---- the planned variant over the 16 base levels (stage-1 training: every base table has its own gradient).  blockIdx.y = level,
+// blockIdx.x = a CHUNK of 1024 consecutive sample points (consecutive samples of a few rays).
+// Where an entry goes depends on the sample positions and the level's cell only, so the counting and the offsets are computed beside the
+// forward pass (hg_levels_plan: k_levels_count -> k_levels_scan); behind the MLP backward one pass turns the feature gradients into queue
+// entries (k_level_entries) and the 16 x 64 slice owners run (k_scatter_binned).  Three things differ from the codebook's planned scatter:
+//   * the point count is a device value (`rows_dev`, may be null): a captured step sizes its launches for the buffers' capacity M and walks
+//     only the rows the march produced;
+//   * a chunk's entries are sorted by slice in LDS and leave as whole 128-byte lines (a run of a slice's entries is contiguous in the queue):
+//     written straight from the lanes -- 64 lanes, 64 different lines per store -- the pass was bound by the L2's request rate (82 us for
+//     8 M entries); the per-point destination array of the first version (32 MB written by the plan, read here) is gone: a chunk needs its
+//     64 run offsets only;
+//   * MERGED RUNS on the coarse levels.  A ray's consecutive samples share a cell there (level 0: ~37 samples per cell), i.e. the same 8 rows;
+//     worse, a coarse level has few distinct (y, z) cell pairs, so the slices -- bits of hash(y, z) -- are loaded very unevenly and ONE owner
+//     streamed 10-20 % of a level's entries (87 us at level 0 against 12.5 us at the fine levels, profiles/r05_stage1_steps.txt).  For levels
+//     < kMergeLevels the wave adds up each run of lanes in the same cell first (16 corner-feature sums, fp32, fixed lane order) and only the
+//     run's first lane emits entries: two per (dy, dz) pair, one for each x side (x weight 0 and 1: the owner's (1 - wx, wx) split then routes
+//     the sum to one row).  Level 0 shrinks 18-fold.  The sums differ from the unmerged ones by fp32 rounding of the partial sums (1e-7).
+constexpr uint32_t kMergeLevels = 10;        // resolutions 16..294: >= 2 samples per cell along a ray at the bench step length
+constexpr uint32_t kLevelQueueStride = 8;    // queue entries reserved per point and level (a merged level whose every point is its own run emits 8)
+constexpr uint32_t kLevelStage = 4 * kBinThreads;   // entries a chunk sorts in LDS (64 KiB: two workgroups per compute unit, or one beside the weight-gradient kernel);
+                                                    // a merged chunk with more (runs shorter than two samples on average) stores its entries straight from the lanes
+
+struct LevelsPlan {
+    BinHeader *hd;          // [16]
+    uint32_t *chunk_tab;    // [16][n_chunks][64]: entries of slice s in chunk c, then (k_levels_scan) the queue offset of that run
+    uint32_t *chunk_max;    // [16][n_chunks]: max |contribution| among a chunk's entries, as a float bit pattern (0 for chunks past the live rows)
+    uint4 *queue;           // [16][8 M]
+    uint32_t n_chunks;
+};
+static size_t levels_plan_bytes(uint32_t M) {
+    const size_t n_chunks = ceil_div(M, kBinThreads);
+    return (size_t)NSIG_BASE_LEVELS * (sizeof(BinHeader) + n_chunks * (kBinSlices + 4) * sizeof(uint32_t) + (size_t)kLevelQueueStride * M * sizeof(uint4));
+}
+static LevelsPlan levels_plan_view(void *plan, uint32_t M) {
+    LevelsPlan v;
+    v.n_chunks = ceil_div(M, kBinThreads);
+    v.hd = reinterpret_cast<BinHeader *>(plan);
+    v.chunk_tab = reinterpret_cast<uint32_t *>(v.hd + NSIG_BASE_LEVELS);
+    v.chunk_max = v.chunk_tab + (size_t)NSIG_BASE_LEVELS * v.n_chunks * kBinSlices;
+    v.queue = reinterpret_cast<uint4 *>(v.chunk_max + (size_t)NSIG_BASE_LEVELS * v.n_chunks * 4);     // (16-byte aligned: 64 + 4 words per chunk and level; a quarter of the second block is used)
+    return v;
+}
+
+struct LevelPoint {
+    uint32_t ix, iy, iz;
+    float wx, wy, wz;
+};
+__device__ inline void level_point(const float *__restrict__ xyzs, uint32_t m, float bound, float cell, LevelPoint &p) {
     const float two_b = 2.0f * bound;
-    uint32_t iy, iz;
-    float w;
-    axis_cell((xyzs[3 * (size_t)m + 1] + bound) / two_b, cell, iy, w);
-    axis_cell((xyzs[3 * (size_t)m + 2] + bound) / two_b, cell, iz, w);
-#pragma unroll
-    for (uint32_t q = 0; q < 4; ++q) sl[q] = pair_slice(pair_hash(iy, iz, q));
+    axis_cell((xyzs[3 * (size_t)m] + bound) / two_b, cell, p.ix, p.wx);
+    axis_cell((xyzs[3 * (size_t)m + 1] + bound) / two_b, cell, p.iy, p.wy);
+    axis_cell((xyzs[3 * (size_t)m + 2] + bound) / two_b, cell, p.iz, p.wz);
+}
+// does this lane open a run?  (merged levels: first lane of a 16-lane row -- the runs are added up with DPP row shifts, which stay inside a
+// row --, or another cell than the lane below; other levels: every live lane)
+__device__ inline bool run_leader(bool merged, bool live, const LevelPoint &p) {
+    if (!merged) return live;
+    const uint32_t key = live ? (p.ix | (p.iy << 10) | (p.iz << 20)) : 0xffffffffu;      // resolutions < 1024 on the merged levels
+    const uint32_t below = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x111, 0xf, 0xf, false);      // row_shr:1 (lane 0 of a row keeps ~key)
+    return live && key != below;
 }
 
-// the active lanes of the wave that hold the same value as this one (a loop over the DISTINCT values: used where they are few)
-__device__ inline uint64_t wave_match(uint32_t v) {
-    uint64_t mine = 0, todo = __ballot(1);
-    while (todo) {
-        const uint32_t val = (uint32_t)__shfl((int)v, (int)(__ffsll((long long)todo) - 1), 64);
-        const uint64_t m = __ballot(v == val) & todo;
-        if (v == val) mine = m;
-        todo &= ~m;
-    }
-    return mine;
-}
-constexpr uint32_t kCoarseLevels = 6;   // levels 0..5: cells of >= 1/80 of the box, a ray's consecutive samples share them
-
-__global__ void __launch_bounds__(kBinThreads) k_levels_plan_count(const float *__restrict__ xyzs, uint32_t M, const uint32_t *__restrict__ rows_dev, float bound,
-                                                                   LevelGeom geom, BinHeader *__restrict__ hd_all) {
-    BinHeader *__restrict__ hd = hd_all + blockIdx.y;
-    const float cell = geom.cell[blockIdx.y];
+__global__ void __launch_bounds__(kBinThreads) k_levels_count(const float *__restrict__ xyzs, uint32_t M, const uint32_t *__restrict__ rows_dev, float bound,
+                                                              LevelGeom geom, LevelsPlan pl) {
+    const uint32_t level = blockIdx.y, chunk = blockIdx.x;
     const uint32_t n = rows_dev != nullptr ? min(M, *rows_dev) : M;
+    if (chunk * kBinThreads >= n) return;
     __shared__ uint32_t h[kBinSlices];
     if (threadIdx.x < kBinSlices) h[threadIdx.x] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) hd->gmax_bits = 0;   // k_level_entries raises it (stream-ordered after the plan)
     __syncthreads();
-    for (uint32_t m = blockIdx.x * kBinThreads + threadIdx.x; m < n; m += gridDim.x * kBinThreads) {
-        uint32_t sl[4];
-        level_point_slices(xyzs, m, bound, cell, sl);
-        // coarse levels: a wave's 64 consecutive samples of a ray share a few cells, hence a few slices -- lanes that agree with a lower
-        // lane let it count for them (one LDS atomic per distinct slice of the wave instead of 64 serialised ones on one address)
-        if (blockIdx.y < kCoarseLevels) {
+    const uint32_t m = chunk * kBinThreads + threadIdx.x;
+    const bool live = m < n, merged = level < kMergeLevels;
+    LevelPoint p{};
+    if (live) level_point(xyzs, m, bound, geom.cell[level], p);
+    if (run_leader(merged, live, p)) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint64_t same = wave_match(sl[q]);
-                if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)same) - 1u) atomicAdd(&h[sl[q]], (uint32_t)__popcll(same));
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) atomicAdd(&h[sl[q]], 1u);
-        }
+        for (uint32_t q = 0; q < 4; ++q) atomicAdd(&h[pair_slice(pair_hash(p.iy, p.iz, q))], merged ? 2u : 1u);
     }
     __syncthreads();
-    if (threadIdx.x < kBinSlices) hd->wg[blockIdx.x][threadIdx.x] = h[threadIdx.x];
+    if (threadIdx.x < kBinSlices) pl.chunk_tab[((size_t)level * pl.n_chunks + chunk) * kBinSlices + threadIdx.x] = h[threadIdx.x];
 }
 
-__global__ void __launch_bounds__(kBinThreads) k_levels_plan_dest(const float *__restrict__ xyzs, uint32_t M, const uint32_t *__restrict__ rows_dev, float bound,
-                                                                  LevelGeom geom, BinHeader *__restrict__ hd_all, uint4 *__restrict__ dest_all) {
-    BinHeader *__restrict__ hd = hd_all + blockIdx.y;
-    uint4 *__restrict__ dest = dest_all + (size_t)blockIdx.y * M;
-    const float cell = geom.cell[blockIdx.y];
+// One workgroup per level: slice totals (what the owners read), slice starts, and -- in place of the counts -- the queue offset of every
+// (chunk, slice) run: the queue is slice-major, a slice's runs in chunk order.  16 segments of chunks x 64 slices = 1024 threads.
+__global__ void __launch_bounds__(kBinThreads) k_levels_scan(uint32_t M, const uint32_t *__restrict__ rows_dev, LevelsPlan pl) {
+    const uint32_t level = blockIdx.x;
     const uint32_t n = rows_dev != nullptr ? min(M, *rows_dev) : M;
-    __shared__ uint32_t h[kBinSlices], running[kBinSlices], seg_tot[16][kBinSlices], seg_before[16][kBinSlices];
-    {
-        const uint32_t s = threadIdx.x & (kBinSlices - 1), g = threadIdx.x >> 6, n_wg = gridDim.x;
-        uint32_t tot = 0, before = 0;
+    const uint32_t chunks = ceil_div(n, kBinThreads), per = ceil_div(chunks, 16u);
+    uint32_t *__restrict__ tab = pl.chunk_tab + (size_t)level * pl.n_chunks * kBinSlices;
+    __shared__ uint32_t seg[16][kBinSlices], start[kBinSlices];
+    const uint32_t s = threadIdx.x & (kBinSlices - 1), g = threadIdx.x >> 6;
+    const uint32_t c0 = min(chunks, g * per), c1 = min(chunks, c0 + per);
+    uint32_t sum = 0;
+    for (uint32_t c = c0; c < c1; ++c) sum += tab[(size_t)c * kBinSlices + s];
+    seg[g][s] = sum;
+    __syncthreads();
+    if (threadIdx.x < kBinSlices) {      // one wave: totals and their exclusive prefix
+        uint32_t t = 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const uint32_t w = g * 16 + i;
-            const uint32_t c = w < n_wg ? hd->wg[w][s] : 0u;
-            tot += c;
-            if (w < blockIdx.x) before += c;
+        for (int k = 0; k < 16; ++k) t += seg[k][threadIdx.x];
+        uint32_t incl = t;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, d, 64);
+            if ((int)threadIdx.x >= d) incl += v;
         }
-        seg_tot[g][s] = tot;
-        seg_before[g][s] = before;
-        __syncthreads();
-        if (threadIdx.x < kBinSlices) {
-            uint32_t t = 0, b = 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { t += seg_tot[k][threadIdx.x]; b += seg_before[k][threadIdx.x]; }
-            uint32_t incl = t;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t v = (uint32_t)__shfl_up((int)incl, d, 64);
-                if ((int)threadIdx.x >= d) incl += v;
-            }
-            running[threadIdx.x] = incl - t + b;
-            if (blockIdx.x == 0) hd->counts[threadIdx.x] = t;
-        }
+        start[threadIdx.x] = incl - t;
+        pl.hd[level].counts[threadIdx.x] = t;
     }
-    for (uint32_t m0 = blockIdx.x * kBinThreads; m0 < n; m0 += gridDim.x * kBinThreads) {   // uniform trip count: barriers inside
-        if (threadIdx.x < kBinSlices) h[threadIdx.x] = 0;
-        __syncthreads();
-        const uint32_t m = m0 + threadIdx.x;
-        uint32_t sl[4], local[4];
-        if (m < n) {
-            level_point_slices(xyzs, m, bound, cell, sl);
-            if (blockIdx.y < kCoarseLevels) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {      // ranks inside the wave's group of equal slices: one LDS atomic per group (see k_levels_plan_count)
-                    const uint64_t same = wave_match(sl[q]);
-                    const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)same) - 1u;
-                    uint32_t base = 0;
-                    if (lane == leader) base = atomicAdd(&h[sl[q]], (uint32_t)__popcll(same));
-                    base = (uint32_t)__shfl((int)base, (int)leader, 64);
-                    local[q] = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) local[q] = atomicAdd(&h[sl[q]], 1u);
-            }
-        }
-        __syncthreads();
-        if (m < n) dest[m] = make_uint4(running[sl[0]] + local[0], running[sl[1]] + local[1], running[sl[2]] + local[2], running[sl[3]] + local[3]);
-        __syncthreads();
-        if (threadIdx.x < kBinSlices) running[threadIdx.x] += h[threadIdx.x];
+    __syncthreads();
+    uint32_t off = start[s];
+    for (uint32_t k = 0; k < g; ++k) off += seg[k][s];
+    for (uint32_t c = c0; c < c1; ++c) {
+        const uint32_t t = tab[(size_t)c * kBinSlices + s];
+        tab[(size_t)c * kBinSlices + s] = off;
+        off += t;
     }
 }
 
-// feature gradient of (point, level) -> its four pair entries at their planned places; raises the level's max |gradient|
+// sum over the run of lanes [lane, run_end] of this 16-lane row, delivered to `lane` (meaningful at a run's first lane): four row shifts, no LDS
+template <int D>
+__device__ inline float row_shl(float v) {      // lane i reads lane i + D of its row (0 past the row's end)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + D, 0xf, 0xf, true));
+}
+__device__ inline float run_sum(float v, uint32_t l16, uint32_t run_end) {
+    float o = row_shl<1>(v);
+    v += l16 + 1u <= run_end ? o : 0.0f;
+    o = row_shl<2>(v);
+    v += l16 + 2u <= run_end ? o : 0.0f;
+    o = row_shl<4>(v);
+    v += l16 + 4u <= run_end ? o : 0.0f;
+    o = row_shl<8>(v);
+    v += l16 + 8u <= run_end ? o : 0.0f;
+    return v;
+}
+
+#ifdef NSIG_ENT_TIMING      // diagnostic build: where a workgroup of k_level_entries spends its time (10 ns ticks, summed over workgroups, merged / plain levels)
+__device__ unsigned long long g_ent_phase[2][8];
+#define ENT_STAMP(k)                                                                                          \
+    do {                                                                                                      \
+        if (threadIdx.x == 0) {                                                                               \
+            const unsigned long long now_ = wall_clock64();                                                   \
+            atomicAdd(&g_ent_phase[blockIdx.y < kMergeLevels ? 0 : 1][k], now_ - ent_t_);                     \
+            ent_t_ = now_;                                                                                    \
+        }                                                                                                     \
+    } while (0)
+#else
+#define ENT_STAMP(k)
+#endif
+
+// feature gradients of a chunk's points at one level -> queue entries, sorted by slice in LDS, stored as contiguous runs; raises the level's
+// max |contribution| (the owners' fixed-point scale)
 __global__ void __launch_bounds__(kBinThreads) k_level_entries(const float *__restrict__ xyzs, uint32_t M, const uint32_t *__restrict__ rows_dev, float bound,
-                                                       const float2 *__restrict__ dplanes, uint32_t stride, LevelGeom geom, BinHeader *__restrict__ hd_all,
-                                                       const uint4 *__restrict__ dest_all, uint4 *__restrict__ queue_all) {
-    // one workgroup = one 1024-point chunk of the plan: its entries of a slice are one contiguous run of the queue, written by waves of ONE
-    // compute unit -- the 16-byte stores merge into whole lines in that XCD's L2 (256-thread workgroups scattered a run's lines over four
-    // L2s: 104 -> ... us, profiles/r05_stage1_steps.txt)
-    const uint32_t m = blockIdx.x * kBinThreads + threadIdx.x, level = blockIdx.y;
+                                                               const float2 *__restrict__ dplanes, uint32_t stride, LevelGeom geom, LevelsPlan pl) {
+    extern __shared__ __attribute__((aligned(16))) uint4 staged[];      // [kLevelStage]
+    __shared__ uint32_t h[kBinSlices], base[kBinSlices + 1], roff[kBinSlices], wg_max;
+    __shared__ uint8_t slice_of[kLevelStage];      // which slice's run a staged entry belongs to
+    const uint32_t level = blockIdx.y, chunk = blockIdx.x;
+#ifdef NSIG_ENT_TIMING
+    unsigned long long ent_t_ = wall_clock64();
+#endif
+    // every input requested before the row count is known (rows past it are inside the buffers, their values unused): one memory latency at the
+    // head of the workgroup instead of three in a chain (count -> positions -> gradients); two 1024-thread workgroups per unit hide little
+    const uint32_t m = chunk * kBinThreads + threadIdx.x, lane = threadIdx.x & 63u, mc = min(m, M - 1u);
+    const float px = xyzs[3 * (size_t)mc], py = xyzs[3 * (size_t)mc + 1], pz = xyzs[3 * (size_t)mc + 2];
+    float2 g = dplanes[(size_t)level * stride + mc];
+    const uint32_t my_roff = threadIdx.x < kBinSlices ? pl.chunk_tab[((size_t)level * pl.n_chunks + chunk) * kBinSlices + threadIdx.x] : 0u;
     const uint32_t n = rows_dev != nullptr ? min(M, *rows_dev) : M;
-    uint32_t gb = 0;
-    if (m < n) {
-        const float2 g = dplanes[(size_t)level * stride + m];
-        const uint4 dst = dest_all[(size_t)level * M + m];
-        const float two_b = 2.0f * bound, cell = geom.cell[level];
-        uint32_t idx[3];
-        float w[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) axis_cell((xyzs[3 * (size_t)m + a] + bound) / two_b, cell, idx[a], w[a]);
-        uint4 *__restrict__ queue = queue_all + (size_t)level * 4 * M;
-        queue[dst.x] = pair_entry(idx[0], pair_hash(idx[1], idx[2], 0u), w[0], w[1], w[2], g.x, g.y, 0u);
-        queue[dst.y] = pair_entry(idx[0], pair_hash(idx[1], idx[2], 1u), w[0], w[1], w[2], g.x, g.y, 1u);
-        queue[dst.z] = pair_entry(idx[0], pair_hash(idx[1], idx[2], 2u), w[0], w[1], w[2], g.x, g.y, 2u);
-        queue[dst.w] = pair_entry(idx[0], pair_hash(idx[1], idx[2], 3u), w[0], w[1], w[2], g.x, g.y, 3u);
-        gb = max(__float_as_uint(g.x) & 0x7fffffffu, __float_as_uint(g.y) & 0x7fffffffu);
+    if (chunk * kBinThreads >= n) {
+        if (threadIdx.x == 0) pl.chunk_max[(size_t)level * pl.n_chunks + chunk] = 0u;
+        return;
     }
+    if (threadIdx.x < kBinSlices) {
+        h[threadIdx.x] = 0;
+        roff[threadIdx.x] = my_roff;      // where this chunk's run of each slice starts in the queue
+    }
+    if (threadIdx.x == 0) wg_max = 0;
+    __syncthreads();
+    ENT_STAMP(0);      // inputs arrived (the row count, the run offsets)
+    const bool live = m < n, merged = level < kMergeLevels;
+    LevelPoint p{};
+    if (live) {
+        const float two_b = 2.0f * bound, cell = geom.cell[level];
+        axis_cell((px + bound) / two_b, cell, p.ix, p.wx);
+        axis_cell((py + bound) / two_b, cell, p.iy, p.wy);
+        axis_cell((pz + bound) / two_b, cell, p.iz, p.wz);
+    } else {
+        g = make_float2(0.0f, 0.0f);
+    }
+    const bool leader = run_leader(merged, live, p);
+    uint32_t sl[4], hyz[4], rank[4];
+    if (leader) {
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) gb = max(gb, (uint32_t)__shfl_xor((int)gb, d, 64));
-    BinHeader *__restrict__ hd = hd_all + level;
-    if ((threadIdx.x & 63u) == 0 && gb > __hip_atomic_load(&hd->gmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&hd->gmax_bits, gb);
+        for (uint32_t q = 0; q < 4; ++q) {
+            hyz[q] = pair_hash(p.iy, p.iz, q);
+            sl[q] = pair_slice(hyz[q]);
+            rank[q] = atomicAdd(&h[sl[q]], merged ? 2u : 1u);
+        }
+    }
+    ENT_STAMP(1);      // cells, leaders, ranks
+    // merged levels: the 16 corner-feature contributions of a run, summed into its first lane
+    float c[4][2][2];      // [(dy, dz) pair][x side][feature]
+    uint32_t gb = max(__float_as_uint(g.x) & 0x7fffffffu, __float_as_uint(g.y) & 0x7fffffffu);
+    if (merged) {
+        const uint32_t l16 = lane & 15u;
+        const uint32_t row_leaders = (uint32_t)(__ballot(leader || !live) >> (lane & 48u)) & 0xffffu;
+        const uint32_t higher = row_leaders & ~((2u << l16) - 1u);
+        const uint32_t run_end = higher ? (uint32_t)__ffs((int)higher) - 2u : 15u;
+        gb = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const float fz = (q & 1u) ? p.wz : 1.0f - p.wz, fy = (q >> 1) ? p.wy : 1.0f - p.wy;
+            const float a0 = (g.x * fz) * fy, a1 = (g.y * fz) * fy;      // corner_weight()'s order; zero on dead lanes
+            c[q][0][0] = run_sum(a0 * (1.0f - p.wx), l16, run_end);
+            c[q][0][1] = run_sum(a1 * (1.0f - p.wx), l16, run_end);
+            c[q][1][0] = run_sum(a0 * p.wx, l16, run_end);
+            c[q][1][1] = run_sum(a1 * p.wx, l16, run_end);
+            if (leader)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) gb = max(gb, __float_as_uint(c[q][t >> 1][t & 1]) & 0x7fffffffu);
+        }
+    }
+    ENT_STAMP(2);      // run sums
+    __syncthreads();
+    ENT_STAMP(3);      // barrier
+    if (threadIdx.x < kBinSlices) {      // one wave: where each slice's run starts in the staging area
+        const uint32_t t = h[threadIdx.x];
+        uint32_t incl = t;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, d, 64);
+            if ((int)threadIdx.x >= d) incl += v;
+        }
+        base[threadIdx.x] = incl - t;
+        if (threadIdx.x == kBinSlices - 1) base[kBinSlices] = incl;
+    }
+    __syncthreads();
+    ENT_STAMP(4);      // prefix + barrier
+    const uint32_t total = base[kBinSlices];
+    const bool direct = total > kLevelStage;      // (uniform; merged levels only)
+    uint4 *__restrict__ queue = pl.queue + (size_t)level * kLevelQueueStride * M;
+    if (leader) {
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            uint4 e0, e1 = make_uint4(0u, 0u, 0u, 0u);
+            if (merged) {
+                const uint32_t key = p.ix | ((hyz[q] & (kBinRows - 1)) << 16);
+                e0 = make_uint4(key, __float_as_uint(0.0f), __float_as_uint(c[q][0][0]), __float_as_uint(c[q][0][1]));
+                e1 = make_uint4(key, __float_as_uint(1.0f), __float_as_uint(c[q][1][0]), __float_as_uint(c[q][1][1]));
+            } else {
+                e0 = pair_entry(p.ix, hyz[q], p.wx, p.wy, p.wz, g.x, g.y, q);
+            }
+            // (two spelled-out branches: one pointer that may address LDS or global memory becomes a FLAT store -- 50 us of this kernel's 66)
+            if (direct) {
+                uint4 *__restrict__ dst = queue + roff[sl[q]] + rank[q];
+                dst[0] = e0;
+                if (merged) dst[1] = e1;
+            } else {
+                const uint32_t at = base[sl[q]] + rank[q];
+                staged[at] = e0;
+                slice_of[at] = (uint8_t)sl[q];
+                if (merged) {
+                    staged[at + 1] = e1;
+                    slice_of[at + 1] = (uint8_t)sl[q];
+                }
+            }
+        }
+    }
+    ENT_STAMP(5);      // staging writes
+    __syncthreads();
+    ENT_STAMP(6);      // barrier
+    for (uint32_t j = threadIdx.x; j < (direct ? 0u : total); j += kBinThreads) {      // consecutive lanes: consecutive entries of a run = whole lines
+        const uint32_t sj = slice_of[j];
+        queue[roff[sj] + (j - base[sj])] = staged[j];
+    }
+    // the chunk's max |contribution|: a plain store; the level's owners take the maximum over the chunks themselves.  (One word per level raised with
+    // atomics by 31 k waves -- the codebook scatter's scheme, where 3 k waves do it -- was the largest single item of this kernel.)
+    if (gb) atomicMax(&wg_max, gb);      // (LDS)
+    __syncthreads();
+    if (threadIdx.x == 0) pl.chunk_max[(size_t)level * pl.n_chunks + chunk] = wg_max;
+    ENT_STAMP(7);      // copy-out issued, maximum raised
 }
+
+#ifdef NSIG_ENT_TIMING
+NSIG_EXPORT int level_entries_phase_ticks(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ent_phase), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long zero[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_ent_phase), zero, sizeof(zero)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 // (a single-precision formulation of this conversion -- split at bit 27, two exact cvt_i32 -- changes nothing: the owners are
 // bound by their LDS atomics and entry loads, not by the f64 instructions)
@@ -596,8 +738,12 @@ __device__ inline long long to_fixed(float c, int k) { return __double2ll_rn(lde
 
 // blockIdx.x = slice * replicas + replica: the slice's entries, split evenly over the replicas.  replicas == 1: the owner is
 // alone and stores its rows (no atomics, no zero-fill of the table, bit-reproducible); otherwise float atomics into G.
+// scale_by_count: the fixed-point scale leaves room for as many maximal contributions as the slice has entries (the base levels of stage 1: at
+// level 0 a million samples share 4913 rows, far more than the 2^11 per row the codebook level's scale assumes).
+// set_max (optional): [sets][n_set_max] partial maxima of |contribution| (float bit patterns) whose maximum replaces the header's gmax_bits.
 __global__ void __launch_bounds__(1024) k_scatter_binned(const BinHeader *__restrict__ hd_all, const uint4 *__restrict__ queue_all, uint32_t M,
-                                                         ScatterTargets tg, uint32_t replicas) {
+                                                         ScatterTargets tg, uint32_t replicas, uint32_t scale_by_count = 0,
+                                                         const uint32_t *__restrict__ set_max = nullptr, uint32_t n_set_max = 0) {
     extern __shared__ unsigned long long acc64[];  // [kBinRows][2] fixed point
     const BinHeader *__restrict__ hd = hd_all + blockIdx.y;
     const uint4 *__restrict__ queue = queue_all + (size_t)blockIdx.y * 4 * M;
@@ -611,11 +757,24 @@ __global__ void __launch_bounds__(1024) k_scatter_binned(const BinHeader *__rest
     // |contribution| <= gmax < 2^E; 2^11 of them stay below 2^62 with k = 51 - E.  A non-finite gradient anywhere in the launch
     // (an overflowing scaled loss under torch's GradScaler) poisons every row of G with NaN, so that the scaler's inf check sees it
     // exactly as it sees the inf/NaN float sums of the reference's dense gradients and skips the step.
-    const uint32_t gb = hd->gmax_bits;
+    uint32_t gb = hd->gmax_bits;
+    if (set_max != nullptr) {
+        __shared__ uint32_t smax;
+        if (threadIdx.x == 0) smax = 0;
+        __syncthreads();
+        uint32_t mx = 0;
+        for (uint32_t i = threadIdx.x; i < n_set_max; i += blockDim.x) mx = max(mx, set_max[(size_t)blockIdx.y * n_set_max + i]);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+        if ((threadIdx.x & 63u) == 0 && mx) atomicMax(&smax, mx);
+        __syncthreads();
+        gb = smax;
+    }
     const bool poisoned = gb >= 0x7f800000u;
     int E;
     frexpf(__uint_as_float(poisoned ? 0x3f800000u : gb), &E);
-    const int k = poisoned ? 0 : 51 - E;
+    int k = poisoned ? 0 : 51 - E;
+    if (scale_by_count && !poisoned && n > 2048u) k = 62 - E - (32 - __builtin_clz(n));      // |sum| <= n * gmax < 2^(E + ceil(log2(n + 1))) stays below 2^62
     __syncthreads();
     constexpr int kAhead = 4;
     for (uint32_t i0 = beg + threadIdx.x; i0 < end; i0 += blockDim.x * kAhead) {
@@ -1314,21 +1473,16 @@ NSIG_EXPORT int hg_scatter_levels(const float *xyzs, float bound, const void *d_
                          reinterpret_cast<char *>(scratch) + (size_t)NSIG_BASE_LEVELS * M * 32, st, "hg_scatter_levels");
 }
 
-// plan of the 16-level scatter: 16 headers | 16 queues of 4 M entries | 16 x M destinations
-static size_t levels_plan_bytes(uint32_t M) { return (size_t)NSIG_BASE_LEVELS * (sizeof(BinHeader) + (size_t)5 * M * sizeof(uint4)); }
-
 NSIG_EXPORT size_t hg_levels_plan_bytes(uint32_t M) { return levels_plan_bytes(M); }
 
 NSIG_EXPORT int hg_levels_plan(const float *xyzs, uint32_t M, const uint32_t *rows_dev, float bound, void *plan, nsig_stream_t stream) {
     if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(xyzs && plan, "hg_levels_plan: null pointer");
-    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(plan) & 15) == 0 && M < (1u << 28) && bound > 0.0f, "hg_levels_plan: plan must be 16-byte aligned, M < 2^28, bound > 0");
-    BinHeader *hd = reinterpret_cast<BinHeader *>(plan);
-    uint4 *dest = reinterpret_cast<uint4 *>(hd + NSIG_BASE_LEVELS) + (size_t)NSIG_BASE_LEVELS * 4 * M;
+    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(plan) & 15) == 0 && M < (1u << 27) && bound > 0.0f, "hg_levels_plan: plan must be 16-byte aligned, M < 2^27, bound > 0");
+    const LevelsPlan pl = levels_plan_view(plan, M);
     hipStream_t st = as_stream(stream);
-    const uint32_t blocks = ceil_div(M, kBinThreads) < kBinGrid ? ceil_div(M, kBinThreads) : kBinGrid;
-    k_levels_plan_count<<<dim3(blocks, NSIG_BASE_LEVELS), kBinThreads, 0, st>>>(xyzs, M, rows_dev, bound, make_level_geom(), hd);
-    k_levels_plan_dest<<<dim3(blocks, NSIG_BASE_LEVELS), kBinThreads, 0, st>>>(xyzs, M, rows_dev, bound, make_level_geom(), hd, dest);
+    k_levels_count<<<dim3(pl.n_chunks, NSIG_BASE_LEVELS), kBinThreads, 0, st>>>(xyzs, M, rows_dev, bound, make_level_geom(), pl);
+    k_levels_scan<<<NSIG_BASE_LEVELS, kBinThreads, 0, st>>>(M, rows_dev, pl);
     return check_launch("hg_levels_plan");
 }
 
@@ -1350,24 +1504,35 @@ NSIG_EXPORT int hg_levels_scatter(const float *xyzs, uint32_t M, const uint32_t 
         return NSIG_OK;
     }
     NSIG_REQUIRE(xyzs && d_planes && plan, "hg_levels_scatter: null pointer");
-    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(plan) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_planes) & 7) == 0 && M < (1u << 28) && bound > 0.0f && stride >= M,
-                 "hg_levels_scatter: plan must be 16-byte and d_planes 8-byte aligned, M < 2^28, bound > 0, stride >= M");
+    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(plan) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_planes) & 7) == 0 && M < (1u << 27) && bound > 0.0f && stride >= M,
+                 "hg_levels_scatter: plan must be 16-byte and d_planes 8-byte aligned, M < 2^27, bound > 0, stride >= M");
     if (int e = reserve_owner_lds("hg_levels_scatter")) return e;
-    BinHeader *hd = reinterpret_cast<BinHeader *>(plan);
-    uint4 *queue = reinterpret_cast<uint4 *>(hd + NSIG_BASE_LEVELS);
-    const uint4 *dest = queue + (size_t)NSIG_BASE_LEVELS * 4 * M;
-    k_level_entries<<<dim3(ceil_div(M, kBinThreads), NSIG_BASE_LEVELS), kBinThreads, 0, st>>>(xyzs, M, rows_dev, bound, reinterpret_cast<const float2 *>(d_planes), stride,
-                                                                              make_level_geom(), hd, dest, queue);
+    const size_t staging = (size_t)kLevelStage * sizeof(uint4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_level_entries), hipFuncAttributeMaxDynamicSharedMemorySize, (int)staging) != hipSuccess) {
+            set_error("hg_levels_scatter: cannot reserve %zu bytes of LDS", staging);
+            return NSIG_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const LevelsPlan pl = levels_plan_view(plan, M);
+    k_level_entries<<<dim3(pl.n_chunks, NSIG_BASE_LEVELS), kBinThreads, staging, st>>>(xyzs, M, rows_dev, bound, reinterpret_cast<const float2 *>(d_planes), stride,
+                                                                                     make_level_geom(), pl);
     if (int e = check_launch("hg_levels_scatter (entries)")) return e;
-    // every (level, slice) has a single owner, which stores its rows: the tables are written, not accumulated into
+    // every (level, slice) has a single owner, which stores its rows: the tables are written, not accumulated into.  (The owners address set l's
+    // queue at l * 4 * M' entries: M' = 2 M is this plan's stride of 8 M.)
+    const uint32_t M_stride = M * (kLevelQueueStride / 4);
 #ifdef NSIG_LEVELS_SPLIT      // diagnostic build (tools/build_variant.sh): one owner launch per level, so that a kernel trace shows each level's time
     for (int l = 0; l < NSIG_BASE_LEVELS; ++l) {
         ScatterTargets one{};
         one.g[0] = tg.g[l];
-        k_scatter_binned<<<dim3(kBinSlices, 1), 1024, (size_t)kBinRows * 2 * sizeof(unsigned long long), st>>>(hd + l, queue + (size_t)l * 4 * M, M, one, 1u);
+        k_scatter_binned<<<dim3(kBinSlices, 1), 1024, (size_t)kBinRows * 2 * sizeof(unsigned long long), st>>>(pl.hd + l, pl.queue + (size_t)l * kLevelQueueStride * M,
+                                                                                                               M_stride, one, 1u, 1u, pl.chunk_max + (size_t)l * pl.n_chunks, pl.n_chunks);
     }
 #else
-    k_scatter_binned<<<dim3(kBinSlices, NSIG_BASE_LEVELS), 1024, (size_t)kBinRows * 2 * sizeof(unsigned long long), st>>>(hd, queue, M, tg, 1u);
+    k_scatter_binned<<<dim3(kBinSlices, NSIG_BASE_LEVELS), 1024, (size_t)kBinRows * 2 * sizeof(unsigned long long), st>>>(pl.hd, pl.queue, M_stride, tg, 1u, 1u,
+                                                                                                                          pl.chunk_max, pl.n_chunks);
 #endif
     return check_launch("hg_levels_scatter");
 }

@@ -30,7 +30,8 @@ namespace nsig {
 // Waves stride over the K-steps; a workgroup's four waves are summed through LDS and the workgroup stores ONE slab of 4096 partial sums
 // in accumulator order; k_wgrad_reduce adds the slabs in workgroup order and writes tcnn's layout ([out][in] row-major).
 constexpr uint32_t kWgradRoles = 3, kWgradSlab = 4u * 16u * 64u;   // floats per (workgroup, role): 4 products x 16 registers x 64 lanes
-constexpr uint32_t kWgradMaxWGs = 168;     // x 3 roles x 4 waves = 2016 waves: one resident round at two waves per SIMD (196 registers)
+constexpr uint32_t kWgradMaxWGs = 84;      // x 3 roles = 252 workgroups of 4 waves: ONE per compute unit, one wave per SIMD, 16 KiB of LDS -- the kernel runs
+                                           // beside the table scatter (1024-thread workgroups with 64-128 KiB of LDS), which must still fit on the same units
 
 struct WgradArgs {
     const float2 *planes;                               // [16][stride] float2: encoder features 2l, 2l+1 of level l
@@ -48,32 +49,35 @@ __device__ inline void split8(const float (&v)[8], Split8 &s) {
 }
 
 // points p0..p0+7 of one stored row; points >= n (stale rows of a buffer sized for more points) and rows that do not exist read as zero
-__device__ inline void load_row8(const float *__restrict__ base, uint32_t stride, uint32_t row, uint32_t p0, uint32_t n, bool row_exists, Split8 &s) {
-    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+struct Raw8 {
+    float v[8];
+};
+__device__ inline void fetch_row8(const float *__restrict__ base, uint32_t stride, uint32_t row, uint32_t p0, uint32_t n, bool row_exists, Raw8 &r) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.v[j] = 0.0f;
     if (row_exists && p0 < n) {
         const float4 a = *reinterpret_cast<const float4 *>(base + (size_t)row * stride + p0);
         const float4 b = *reinterpret_cast<const float4 *>(base + (size_t)row * stride + p0 + 4);
         const float w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = p0 + j < n ? w[j] : 0.0f;
+        for (int j = 0; j < 8; ++j) r.v[j] = p0 + j < n ? w[j] : 0.0f;
     }
-    split8(v, s);
 }
 
 // ... of encoder feature i (component i & 1 of level i >> 1)
-__device__ inline void load_feat8(const float2 *__restrict__ planes, uint32_t stride, uint32_t i, uint32_t p0, uint32_t n, Split8 &s) {
-    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+__device__ inline void fetch_feat8(const float2 *__restrict__ planes, uint32_t stride, uint32_t i, uint32_t p0, uint32_t n, Raw8 &r) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.v[j] = 0.0f;
     if (p0 < n) {
         const float4 *src = reinterpret_cast<const float4 *>(planes + (size_t)(i >> 1) * stride + p0);
         const float4 q[4] = {src[0], src[1], src[2], src[3]};
         const bool odd = i & 1u;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            v[2 * t] = p0 + 2 * t < n ? (odd ? q[t].y : q[t].x) : 0.0f;
-            v[2 * t + 1] = p0 + 2 * t + 1 < n ? (odd ? q[t].w : q[t].z) : 0.0f;
+            r.v[2 * t] = p0 + 2 * t < n ? (odd ? q[t].y : q[t].x) : 0.0f;
+            r.v[2 * t + 1] = p0 + 2 * t + 1 < n ? (odd ? q[t].w : q[t].z) : 0.0f;
         }
     }
-    split8(v, s);
 }
 
 __device__ inline f32x16 mac3(const Split8 &a, const Split8 &b, f32x16 c) {      // lo parts first, hi * hi last (as Bf16x3::mac)
@@ -83,8 +87,12 @@ __device__ inline f32x16 mac3(const Split8 &a, const Split8 &b, f32x16 c) {     
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, c, 0, 0, 0);
 }
 
-__global__ void __launch_bounds__(256) k_field_wgrad(WgradArgs a, uint32_t stride, uint32_t M, const uint32_t *__restrict__ rows_dev, float *__restrict__ slabs) {
-    __shared__ float red[3][kWgradSlab];     // waves 1..3 (48 KiB); wave 0 adds them to its registers
+// One wave takes PAIRS of adjacent K-steps (32 points: each row's whole 128-byte line) and requests all their operands -- up to 24 32-byte
+// loads per lane -- before it converts the first: the kernel runs at one wave per SIMD beside the table scatter, so the loads in flight per
+// wave are what hides the memory latency.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+k_field_wgrad(WgradArgs a, uint32_t stride, uint32_t M, const uint32_t *__restrict__ rows_dev, float *__restrict__ slabs) {
+    __shared__ float red[kWgradSlab];        // 16 KiB: waves 1..3 hand their sums to wave 0 one after the other
     const uint32_t n = rows_dev != nullptr ? min(M, *rows_dev) : M;
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6, r = lane & 31u, h = lane >> 5;
     const uint32_t role = blockIdx.y;
@@ -93,61 +101,84 @@ __global__ void __launch_bounds__(256) k_field_wgrad(WgradArgs a, uint32_t strid
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[q][e] = 0.0f;
-    const uint32_t n_ks = ceil_div(n, 16u);
-    for (uint32_t ks = blockIdx.x * 4u + wid; ks < n_ks; ks += gridDim.x * 4u) {
-        const uint32_t p0 = ks * 16u + 8u * h;
-        if (role == 0) {
-            Split8 A0, A1, A2, A3, B0, B1;
-            load_row8(a.d_hs, stride, r, p0, n, true, A0);
-            load_row8(a.d_hs, stride, 32u + r, p0, n, true, A1);
-            load_row8(a.d_h1, stride, r, p0, n, true, A2);
-            load_row8(a.d_h1, stride, 32u + r, p0, n, true, A3);
-            load_feat8(a.planes, stride, r, p0, n, B0);
-            load_row8(a.cin, stride, r, p0, n, true, B1);
-            acc[0] = mac3(A0, B0, acc[0]);
-            acc[1] = mac3(A1, B0, acc[1]);
-            acc[2] = mac3(A2, B1, acc[2]);
-            acc[3] = mac3(A3, B1, acc[3]);
-        } else if (role == 1) {
-            Split8 A0, A1, B0, B1, B2, B3;
-            load_row8(a.d_so, stride, r, p0, n, r < 16u, A0);
-            load_row8(a.d_out, stride, r, p0, n, r < 16u, A1);
-            load_row8(a.hs, stride, r, p0, n, true, B0);
-            load_row8(a.hs, stride, 32u + r, p0, n, true, B1);
-            load_row8(a.h2, stride, r, p0, n, true, B2);
-            load_row8(a.h2, stride, 32u + r, p0, n, true, B3);
-            acc[0] = mac3(A0, B0, acc[0]);
-            acc[1] = mac3(A0, B1, acc[1]);
-            acc[2] = mac3(A1, B2, acc[2]);
-            acc[3] = mac3(A1, B3, acc[3]);
-        } else {
-            Split8 A0, A1, B0, B1;
-            load_row8(a.d_h2, stride, r, p0, n, true, A0);
-            load_row8(a.d_h2, stride, 32u + r, p0, n, true, A1);
-            load_row8(a.h1, stride, r, p0, n, true, B0);
-            load_row8(a.h1, stride, 32u + r, p0, n, true, B1);
-            acc[0] = mac3(A0, B0, acc[0]);
-            acc[1] = mac3(A0, B1, acc[1]);
-            acc[2] = mac3(A1, B0, acc[2]);
-            acc[3] = mac3(A1, B1, acc[3]);
+    const uint32_t n_pairs = ceil_div(n, 32u);
+    for (uint32_t kp = blockIdx.x * 4u + wid; kp < n_pairs; kp += gridDim.x * 4u) {
+        Raw8 ra[2][4], rb[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t p0 = kp * 32u + 16u * u + 8u * h;
+            if (role == 0) {
+                fetch_row8(a.d_hs, stride, r, p0, n, true, ra[u][0]);
+                fetch_row8(a.d_hs, stride, 32u + r, p0, n, true, ra[u][1]);
+                fetch_row8(a.d_h1, stride, r, p0, n, true, ra[u][2]);
+                fetch_row8(a.d_h1, stride, 32u + r, p0, n, true, ra[u][3]);
+                fetch_feat8(a.planes, stride, r, p0, n, rb[u][0]);
+                fetch_row8(a.cin, stride, r, p0, n, true, rb[u][1]);
+            } else if (role == 1) {
+                fetch_row8(a.d_so, stride, r, p0, n, r < 16u, ra[u][0]);
+                fetch_row8(a.d_out, stride, r, p0, n, r < 16u, ra[u][1]);
+                fetch_row8(a.hs, stride, r, p0, n, true, rb[u][0]);
+                fetch_row8(a.hs, stride, 32u + r, p0, n, true, rb[u][1]);
+                fetch_row8(a.h2, stride, r, p0, n, true, rb[u][2]);
+                fetch_row8(a.h2, stride, 32u + r, p0, n, true, rb[u][3]);
+            } else {
+                fetch_row8(a.d_h2, stride, r, p0, n, true, ra[u][0]);
+                fetch_row8(a.d_h2, stride, 32u + r, p0, n, true, ra[u][1]);
+                fetch_row8(a.h1, stride, r, p0, n, true, rb[u][0]);
+                fetch_row8(a.h1, stride, 32u + r, p0, n, true, rb[u][1]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (role == 0) {
+                Split8 A0, A1, A2, A3, B0, B1;
+                split8(ra[u][0].v, A0); split8(ra[u][1].v, A1); split8(ra[u][2].v, A2); split8(ra[u][3].v, A3);
+                split8(rb[u][0].v, B0); split8(rb[u][1].v, B1);
+                acc[0] = mac3(A0, B0, acc[0]);
+                acc[1] = mac3(A1, B0, acc[1]);
+                acc[2] = mac3(A2, B1, acc[2]);
+                acc[3] = mac3(A3, B1, acc[3]);
+            } else if (role == 1) {
+                Split8 A0, A1, B0, B1, B2, B3;
+                split8(ra[u][0].v, A0); split8(ra[u][1].v, A1);
+                split8(rb[u][0].v, B0); split8(rb[u][1].v, B1); split8(rb[u][2].v, B2); split8(rb[u][3].v, B3);
+                acc[0] = mac3(A0, B0, acc[0]);
+                acc[1] = mac3(A0, B1, acc[1]);
+                acc[2] = mac3(A1, B2, acc[2]);
+                acc[3] = mac3(A1, B3, acc[3]);
+            } else {
+                Split8 A0, A1, B0, B1;
+                split8(ra[u][0].v, A0); split8(ra[u][1].v, A1);
+                split8(rb[u][0].v, B0); split8(rb[u][1].v, B1);
+                acc[0] = mac3(A0, B0, acc[0]);
+                acc[1] = mac3(A0, B1, acc[1]);
+                acc[2] = mac3(A1, B0, acc[2]);
+                acc[3] = mac3(A1, B1, acc[3]);
+            }
         }
     }
-    if (wid > 0) {
+    for (uint32_t w = 1; w < 4; ++w) {       // (three rounds at the end of a kernel that streams for tens of microseconds)
+        if (wid == w) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) red[wid - 1][(q * 16 + e) * 64 + lane] = acc[q][e];
+                for (int e = 0; e < 16; ++e) red[(q * 16 + e) * 64 + lane] = acc[q][e];
+        }
+        __syncthreads();
+        if (wid == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[q][e] += red[(q * 16 + e) * 64 + lane];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (wid == 0) {
         float *__restrict__ out = slabs + ((size_t)blockIdx.x * kWgradRoles + role) * kWgradSlab;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const uint32_t i = (q * 16 + e) * 64 + lane;
-                out[i] = ((acc[q][e] + red[0][i]) + red[1][i]) + red[2][i];
-            }
+            for (int e = 0; e < 16; ++e) out[(q * 16 + e) * 64 + lane] = acc[q][e];
     }
 }
 
@@ -241,8 +272,8 @@ __global__ void __launch_bounds__(1024) k_clean_loss(const float *__restrict__ i
 
 using namespace nsig;
 
-static uint32_t wgrad_workgroups(uint32_t M) {      // K-steps of 16 points, 4 waves per workgroup, >= 4 K-steps per wave where there is work
-    const uint32_t want = ceil_div(ceil_div(M, 16u), 16u);
+static uint32_t wgrad_workgroups(uint32_t M) {      // pairs of K-steps (32 points), 4 waves per workgroup, >= 2 pairs per wave where there is work
+    const uint32_t want = ceil_div(ceil_div(M, 32u), 8u);
     return want < 32u ? 32u : (want > kWgradMaxWGs ? kWgradMaxWGs : want);
 }
 

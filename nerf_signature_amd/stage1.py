@@ -18,6 +18,7 @@ Three ways to drive it:
                          every `update_extra_interval` steps as the reference does; data-parallel ranks exchange ONE flat
                          buffer [16 table gradients | MLP gradients] per step."""
 import contextlib
+import ctypes
 
 import torch
 from torch.autograd import Function
@@ -28,6 +29,7 @@ from . import dp
 from . import fieldops as fo
 from . import tcnn_compat as tcnn
 from .capture import SegmentedCapture
+from .optim import _bump_versions
 from .hash_encoding import HashEmbedder
 from .raymarching import padded_point_count
 from .renderer import NeRFRenderer
@@ -289,6 +291,9 @@ class GraphedCleanLoop:
         self.g_sigma = self.flat[16 * T_ROWS * 2:16 * T_ROWS * 2 + N_SIGMA]
         self.g_color = self.flat[16 * T_ROWS * 2 + N_SIGMA:]
         self.packed = torch.empty(int(nv.fn("mlp_packed_bytes")()), dtype=torch.uint8, device=dev)
+        self._adam_scratch = [torch.empty(64, **f32), torch.empty(64, **f32)]
+        if any(g["betas"] != optimizer.param_groups[0]["betas"] or g["eps"] != optimizer.param_groups[0]["eps"] for g in optimizer.param_groups):
+            raise NotImplementedError("GraphedCleanLoop expects one (betas, eps) for all parameter groups (the reference's, main_nerf.py:122)")
         self.base_lr = float(optimizer.param_groups[0]["lr"])
         self.lr_dev = torch.tensor(self.base_lr, **f32)
         self.plan_stream = torch.cuda.Stream() if overlap_plan else None
@@ -337,18 +342,42 @@ class GraphedCleanLoop:
             main.wait_event(self._plan_done)
         nv.call("hg_levels_scatter", nv.ptr(xyzs), M, nv.ptr(rows), float(m.bound), nv.ptr(tr.d_planes), tr.stride, nv.ptr(self.plan),
                 nv.ptr_array([self.g_tables[l] for l in range(16)]), s)
+
+    def _join_weight_gradients(self):
         if self.plan_stream is not None:
-            main.wait_stream(self.plan_stream)      # ... and the step's tail needs the weight gradients
+            torch.cuda.current_stream().wait_stream(self.plan_stream)
 
     def _exchange(self):
         if dp.exchange_active():
             import torch.distributed as dist
             flat = self.flat
+            self._join_weight_gradients()           # one buffer, one collective: everything in it has to be there
             dp.collective(lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM))
 
+    def _adam(self, params):
+        """torch.optim.Adam's update of `params` from their `.grad` views through opt_adam_dense (state in torch's capturable format: device step counts)."""
+        opt = self.optimizer
+        group = opt.param_groups[0]
+        for p in params:
+            st = opt.state[p]
+            if len(st) == 0:
+                st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            elif not st["step"].is_cuda:
+                st["step"] = st["step"].to(p.device)
+        n = len(params)
+        numel = (ctypes.c_uint32 * n)(*[p.numel() for p in params])
+        nv.call("opt_adam_dense", n, nv.ptr_array([p.data for p in params]), nv.ptr_array([p.grad for p in params]),
+                nv.ptr_array([opt.state[p]["exp_avg"] for p in params]), nv.ptr_array([opt.state[p]["exp_avg_sq"] for p in params]),
+                nv.ptr_array([opt.state[p]["step"] for p in params]), numel, nv.ptr(self.lr_dev), float(group["betas"][0]), float(group["betas"][1]),
+                float(group["eps"]), 1.0, nv.ptr(self._adam_scratch[0 if params[0] is self.params[0] else 1]), nv.stream())
+        _bump_versions(params)
+
     def _optimise(self):
-        from .optim import _step_dense
-        _step_dense(self.optimizer, self.lr_dev, 1.0)
+        self._adam(self.params[:16])                # the tables need the scatter only: 448 MiB of streaming while the weight gradients finish
+        self._join_weight_gradients()
+        self._adam(self.params[16:])
         nv.call("mlp_pack_weights", nv.ptr(self.model.sigma_net.params.detach()), nv.ptr(self.model.color_net.params.detach()), nv.ptr(self.packed), nv.stream())
 
     def _whole_step(self):

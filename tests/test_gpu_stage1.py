@@ -133,11 +133,14 @@ def test_weight_gradients_equal_the_matrix_products_and_are_bit_reproducible():
     _, g_sp2, g_cp2, G2 = _traced_pass(m, pts, dirs, gs, gc)
     assert torch.equal(g_sp, g_sp2) and torch.equal(g_cp, g_cp2) and torch.equal(G, G2)
     assert not torch.isnan(G).any()                                                # every row of every table written
-    # the record route (hg_scatter_levels) computes the same sums in the same fixed-point arithmetic
+    # the record route (hg_scatter_levels) computes the same sums: every contribution on its own there, runs of a cell pre-summed in fp32 on the
+    # coarse levels here, and another fixed-point scale -- the same rows, values to fp32 rounding
     G3 = torch.empty_like(G)
     scratch = torch.empty(int(nv.fn("hg_scatter_levels_scratch_bytes")(M)), dtype=torch.uint8, device="cuda")
     nv.call("hg_scatter_levels", nv.ptr(pts), float(m.bound), nv.ptr(tr.d_planes), M, tr.stride, nv.ptr_array([G3[l] for l in range(16)]), nv.ptr(scratch), nv.stream())
-    assert torch.equal(G, G3)
+    for l in range(16):
+        assert torch.equal(G[l] != 0, G3[l] != 0), l
+        assert rel(G[l], G3[l]) < 1e-6, (l, rel(G[l], G3[l]))
 
 
 def test_device_row_count_entry_points_walk_only_the_live_rows():

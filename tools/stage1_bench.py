@@ -40,7 +40,8 @@ opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, **({"fu
 data = {"rays_o": o, "rays_d": d, "images": target, "perturb": False, "force_all_rays": True}
 
 if "--eager" not in flags:
-    loop = GraphedCleanLoop(m, opt, dict(dt_gamma=0, max_steps=1024), n_rays=n_rays, update_extra_interval=0 if "--no-refresh" in flags else 16, perturb=True)
+    loop = GraphedCleanLoop(m, opt, dict(dt_gamma=0, max_steps=1024), n_rays=n_rays, update_extra_interval=0 if "--no-refresh" in flags else 16, perturb=True,
+                            overlap_plan="--no-overlap" not in flags)
     loop.step(data)
     for _ in range(15):
         loop.step()
