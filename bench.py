@@ -34,6 +34,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md chip table); measured copy ceiling 6.29e12
+L2_PEAK = 34.5e12          # B/s, aggregate L2 -> L1 rate of the eight XCDs (MI355X_MICROARCH.md "L2 (per XCD)")
 MFMA_PEAK = {"f16": 2.5e15, "bf16": 2.5e15}     # dense FLOP/s
 T_BYTES = (1 << 19) * 2 * 4                      # one [2^19, 2] fp32 table
 
@@ -450,21 +451,79 @@ def cpu_baseline(model, D, full_step_points=None):
     a, b = res["run_cuda"], res["run"]
     same = None
     if full_step_points:      # the GPU line's basis: CONTENT rays per second of a FULL step (all 4608 block rays + 4096 content rays)
-        same = {"value": 4096.0 / (full_step_points / a["points_per_s"]), "unit": "content rays/s", "estimated": True,
+        estimate = 4096.0 / (full_step_points / a["points_per_s"])
+        same = {"value": estimate, "unit": "content rays/s", "estimated": True,
                 "how": f"4096 content rays / (the full step's {int(full_step_points)} points / this baseline's measured points_per_s): the oracle's time is proportional to "
                        "its point count (every point runs the same encoders + MLPs forward and backward)"}
+        # ... and MEASURED once: the whole 8704-ray step (all 32 x 12 x 12 block rays + the 4096 content rays, ~1.4 M points, forward + backward), one warm-up + one
+        # timed pass.  ~14 GB of autograd records on the host: skipped (the estimate stays) when the box has less than 24 GB free.
+        try:
+            import psutil
+            free_gb = psutil.virtual_memory().available / 2 ** 30
+        except Exception:
+            free_gb = 0.0
+        if free_gb >= 24.0 and os.environ.get("NERFSIG_CPU_FULL_STEP", "1") != "0":
+            bo_f, bd_f = synthetic.block_rays("hotdog")
+
+            def full():
+                zero()
+                o = fr.train_step(bo_f, bd_f, co, cd, gt, msg, P, S, dec, dt_gamma=0.0, max_steps=1024)
+                o["loss"].backward()
+                return o["block"]["n_points"] + o["content"]["n_points"]
+            full()
+            t0 = time.perf_counter()
+            pts_full = full()
+            t_full = time.perf_counter() - t0
+            same = {"value": 4096.0 / t_full, "unit": "content rays/s", "estimated": False, "full_step_s": round(t_full, 3), "points": int(pts_full), "rays": 4096 + bo_f.shape[0] * bo_f.shape[1] * bo_f.shape[2],
+                    "points_per_s": pts_full / t_full, "estimate_from_the_subsampled_steps": estimate,
+                    "how": "one warm-up + ONE timed full step of the oracle (fr.train_step + backward): 4096 content rays + all 4608 block rays, the GPU line's step"}
+        else:
+            same["why_not_measured"] = f"{free_gb:.0f} GiB of host memory free (< 24) or NERFSIG_CPU_FULL_STEP=0"
     return {"value": a["rays_per_s"], "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
             "same_basis": same,
             "comparable_with_the_gpu_line": "ONLY `points_per_s` (vs config.points_per_s) and `same_basis.value` (vs `value`): this entry's own `value` counts the 4608 rays of a step whose "
                                             "block rays are subsampled 1/9 (4096 content + 512 block rays, ~270 k points), the GPU line's `value` counts the 4096 content rays of a step "
                                             "that also renders all 4608 block rays (~1.41 M points)",
             "sample": f"run_cuda shape: 1 warm-up + 3 timed train steps (fwd+bwd, no optimiser) of {a['rays']} rays = the full 4096-ray content batch + "
-                      f"32 blocks at 4x4 of their 12x12 rays (block rays subsampled 1/9), {a['points']} points, {np.mean(a['batch_s']):.1f} s per step",
+                      f"32 blocks at 4x4 of their 12x12 rays (block rays subsampled 1/9), {a['points']} points, {np.mean(a['batch_s']):.1f} s per step; "
+                      "same_basis: 1 warm-up + 1 timed FULL step (all block rays)",
             "points_per_s": a["points_per_s"], "host_cpus": host_cpus, "cpus_allowed": allowed, "cgroup_cpu_quota": quota, "torch_threads": torch.get_num_threads(),
             "run_shape": {"value": b["rays_per_s"], "unit": "rays/s", "points_per_s": b["points_per_s"],
                           "sample": f"run shape (512 uniform samples/ray, renderer_wtmk.py:125-253): 1 warm-up + 3 timed fwd+bwd batches of 512 of the 4096 content rays "
                                     f"(1/8), {b['points']} points, {np.mean(b['batch_s']):.1f} s per batch"},
             "batch_seconds": {"run_cuda": a["batch_s"], "run": b["batch_s"]}}
+
+
+def _run_secondary(argv, limit_s):
+    """One secondary child in a session (process group) of its own, output into temporary files; at the limit the WHOLE group is killed -- a child that
+    starts rank processes of its own (tools/converge.py dp2) must not leave them training on the GPU beside the next secondary or the headline."""
+    import signal
+    import tempfile
+    env = dict(os.environ, NERFSIG_BENCH_VARIANT="0", NERFSIG_SECONDARY_TIMEOUT_S=str(limit_s))
+    with tempfile.TemporaryFile(mode="w+") as f_out, tempfile.TemporaryFile(mode="w+") as f_err:
+        p = subprocess.Popen([sys.executable] + list(argv), env=env, stdout=f_out, stderr=f_err, start_new_session=True)
+        timed_out = False
+        try:
+            rc = p.wait(timeout=limit_s)
+        except subprocess.TimeoutExpired:
+            timed_out = True
+            for sig, grace in ((signal.SIGTERM, 5.0), (signal.SIGKILL, 10.0)):
+                try:
+                    os.killpg(p.pid, sig)          # (the session leader's pid is the group's id: exactly the processes started here)
+                except ProcessLookupError:
+                    break
+                try:
+                    p.wait(timeout=grace)
+                except subprocess.TimeoutExpired:
+                    continue
+            rc = p.poll() if p.poll() is not None else 124
+            try:
+                os.killpg(p.pid, signal.SIGKILL)   # grandchildren that outlived a leader which exited on SIGTERM
+            except ProcessLookupError:
+                pass
+        f_out.seek(0)
+        f_err.seek(0)
+        return {"rc": rc if not timed_out else (rc or 124), "stdout": f_out.read(), "stderr": f_err.read(), "timed_out": timed_out}
 
 
 def run_secondaries(args):
@@ -484,7 +543,10 @@ def run_secondaries(args):
                      around this repo's fused trainer.train_step
       eval_loop      the eval-mode burst loop (renderer_wtmk.py:335-372) on one 400x400 view, control on the device vs read back every round (tools/eval_bench.py)
       distortion_layer   the five `--distortion` kinds inside the captured step, each trained through the README schedule: ms per step, bit accuracy on clean and on
-                     distorted blocks (tools/distortion_bench.py)"""
+                     distorted blocks (tools/distortion_bench.py)
+      stage1         the clean model's training step (all parameters trainable, stage1.GraphedCleanLoop, grid refresh every 16 steps inside the timed
+                     windows): ms per step, rays/s, per-kernel times, roofline records of the 16-level table scatter and the weight-gradient reduction (tools/stage1_bench.py)
+    Every child runs in a process group of its own and the whole group is killed at the limit (NERFSIG_SECONDARY_TIMEOUT_S, default 150 s each)."""
     out = {}
     k = str(min(args.steps, 50))
     jobs = (("quality", [os.path.join(ROOT, "tools", "converge.py"), "graphed", "--steps", "1000", "--messages", "200"]),
@@ -494,19 +556,20 @@ def run_secondaries(args):
             ("rank_emulation", [os.path.join(ROOT, "tools", "emulate_ranks.py"), "--steps", k]),
             ("eager_reference_trainer_shape", [os.path.join(ROOT, "tools", "trainer_shape.py"), "--steps", "330", "--both", "--evaluate"]),
             ("eval_loop", [os.path.join(ROOT, "tools", "eval_bench.py")]),
-            ("distortion_layer", [os.path.join(ROOT, "tools", "distortion_bench.py")]))
+            ("distortion_layer", [os.path.join(ROOT, "tools", "distortion_bench.py")]),
+            ("stage1", [os.path.join(ROOT, "tools", "stage1_bench.py"), "content", "--json", "--steps", "64", "--windows", "5"]))
+    limit = float(os.environ.get("NERFSIG_SECONDARY_TIMEOUT_S", "150"))
     for name, argv in jobs:
         t0 = time.time()
         try:
-            env = dict(os.environ, NERFSIG_BENCH_VARIANT="0")
-            r = subprocess.run([sys.executable] + argv, env=env, capture_output=True, text=True, timeout=float(os.environ.get("NERFSIG_SECONDARY_TIMEOUT_S", "150")))
-            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            if r.returncode != 0 or not lines:
-                out[name] = {"error": f"rc {r.returncode}", "stderr_tail": r.stderr[-600:]}
+            r = _run_secondary(argv, limit)
+            lines = [l for l in r["stdout"].splitlines() if l.startswith("{")]
+            if r["rc"] != 0 or not lines:
+                out[name] = {"error": f"rc {r['rc']}" + (" (killed with its whole process group at the time limit)" if r["timed_out"] else ""), "stderr_tail": r["stderr"][-600:]}
                 continue
             j = json.loads(lines[-1])
             c = j.get("config", {})
-            if name in ("quality", "quality_two_ranks_gloo", "rank_emulation", "eager_reference_trainer_shape", "eval_loop", "distortion_layer"):
+            if name in ("quality", "quality_two_ranks_gloo", "rank_emulation", "eager_reference_trainer_shape", "eval_loop", "distortion_layer", "stage1"):
                 out[name] = j
             elif name == "counter":
                 out[name] = {"ms_per_step": j["ms_per_step"], "content_rays_per_s": j["value"], "points_per_s": c.get("points_per_s"), "points_per_step": c.get("points_per_step_per_rank"),
@@ -785,6 +848,14 @@ def bench_training(args, scene, real_stdout, secondary=None):
                             "measured_over_model": (enc_s / (clk / 2.4e9)) if enc_s > 0 else None}
         except Exception:
             traffic = None
+    binding_roof = {"l2_line_bytes": None, "frac_l2": None, "line_utilisation": None}
+    if l1_model is not None and enc_s > 0:
+        fills = l1_model["misses_to_L2_per_launch"]
+        binding_roof = {"l2_line_bytes": fills * 128.0, "l2_peak_GBps": L2_PEAK / 1e9, "l2_achieved_GBps": fills * 128.0 / enc_s / 1e9, "frac_l2": fills * 128.0 / enc_s / L2_PEAK,
+                        "line_utilisation": pts_big * gather_launch / (fills * 128.0),
+                        "binding_roof_note": "fills x 128 B = bytes moved L2 -> L1 for `algorithmic_bytes_per_point` x points used: the reference's hash sends the 8 corners of a point "
+                                             "to ~4 different lines on every hashed level (profiles/r02_encoder_experiments.txt), so ~1/4 of every line is used; frac_l2 is the "
+                                             "fraction of the aggregate L2 -> L1 rate, the roof that binds this kernel (not HBM: `frac` above is an accounting figure)"}
     # whole step, implemented bytes: per point forward 1088 gathered + 32 (xyz, dir, deltas) + 16 (sigma, rgb); backward 64 (upstream
     # gradients, saved sigma/rgb/masks) + 128 (four 16-byte scatter-queue entries written and read); per step the optimiser's streams:
     # G once, param/exp_avg/exp_avg_sq of D tables read+written (6 D tables), ~D/2 partner tables + S written for the next pre-sum
@@ -843,7 +914,7 @@ def bench_training(args, scene, real_stdout, secondary=None):
             "reference_algorithm_frac": (pts_big * gather_ref / enc_s / HBM_PEAK) if (enc_s > 0 and not split_encoder) else None,
             "launches": enc_n, "avg_launch_s": enc_s, "points_per_launch": pts_big, "rows_per_launch": enc_rows,
             "algorithmic_bytes_per_point": gather_launch,
-            "basis": ("bytes of the IMPLEMENTED algorithm, this launch: the 16 base levels, 8 corners x 8 B (the pre-summed codebook level is gathered by its own launch at the "
+            "basis": "ACCOUNTING vs HBM -- the kernel is L1/L2-bound, see frac_l2 / line_utilisation; " + ("bytes of the IMPLEMENTED algorithm, this launch: the 16 base levels, 8 corners x 8 B (the pre-summed codebook level is gathered by its own launch at the "
                       "head of the step, k_encode_codebook_plane: 64 B/point, timed below)" if split_encoder else
                       "bytes of the IMPLEMENTED algorithm: 16 base levels + the pre-summed codebook level, 8 corners x 8 B (DESIGN.md sections 2 and 6)"),
             "codebook_level_launch_s": timer.stats("hg_encode_codebook_plane", big)[0] if split_encoder else None,
@@ -851,6 +922,9 @@ def bench_training(args, scene, real_stdout, secondary=None):
             "observed_limiter": "not HBM: the working set (64 MiB base + 4 MiB pre-sum) is L2/MALL-resident; PMC shows the texture-address path busy ~85 % and "
                                 "the L2->L1 line fills (~4 GB per launch) as the limiter (profiles/*pmc_encode*)",
             "frac_hbm_counters": (traffic / enc_s / HBM_PEAK) if (traffic and enc_s > 0) else None,
+            # THE BINDING ROOF: the launch is bound by L2 -> L1 line fills.  Fills from the counters (TCP_TCC_READ_REQ, one 128-byte line
+            # each) over THIS run's launch time, against the aggregate L2 rate the guide measures (34.5 TB/s, MI355X_MICROARCH.md "L2 (per XCD)").
+            **binding_roof,
             "l1_lookup_rate_model": l1_model,
             "reference_algorithm": {"bytes_per_point": gather_ref, "note": "SURVEY.md 8(d) formula (D separate codebook gathers); the kernel does not move these bytes, "
                                     "so this is a speed-up factor over a literal implementation, NOT a roofline fraction",

@@ -34,11 +34,56 @@ def set_boundary(handler):
     return prev
 
 
-def collective(fn, last=False):
+_TIMER = None         # name -> [(start, end)] while a measurement pass is on (time_collectives)
+
+
+def time_collectives(on=True):
+    """Bracket every eagerly executed collective with events on the stream it is issued from (HIP events; wall clock for CPU groups) from now on / stop.
+    A collective that is captured inside a hipGraph (NERFSIG_CAPTURE_COLLECTIVES=1) cannot be bracketed: bench.py times those in its eager pass."""
+    global _TIMER
+    _TIMER = {} if on else None
+
+
+def collective_times_us():
+    """name -> {"n", "mean", "min", "max"} in microseconds, of what time_collectives() has seen (synchronises).  The times include the wait for the slowest
+    rank to arrive -- they are what the step pays, not the wire time."""
+    out = {}
+    if _TIMER is None:
+        return out
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    for name, ev in _TIMER.items():
+        us = [(a.elapsed_time(b) * 1e3 if hasattr(a, "elapsed_time") else (b - a) * 1e6) for a, b in ev]
+        if us:
+            out[name] = {"n": len(us), "mean": sum(us) / len(us), "min": min(us), "max": max(us)}
+    return out
+
+
+def _timed(name, fn):
+    def run():
+        t = _TIMER
+        if t is None or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+            return fn()
+        if torch.cuda.is_available() and dist.is_initialized() and dist.get_backend() != "gloo":
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+        else:
+            import time
+            a = time.perf_counter()
+            fn()
+            b = time.perf_counter()
+        t.setdefault(name, []).append((a, b))
+    return run
+
+
+def collective(fn, last=False, name="collective"):
     """Run the eager collective(s) in `fn` now -- or, under a segmented capture, make this point a segment boundary.
-    NERFSIG_CAPTURE_COLLECTIVES=1 (opt-in) leaves the RCCL calls INSIDE the capture instead: one hipGraph per step for any world size,
-    no eager launches between segments (-85 us per step on a world-size-1 nccl group).  Not the default: rehearsed on one rank only, and
-    one of four rehearsals died in ProcessGroupNCCL's watchdog thread (an event query racing the capture)."""
+    NERFSIG_CAPTURE_COLLECTIVES=1 leaves the RCCL calls INSIDE the capture instead: one hipGraph per step for any world size, no eager launches
+    between segments (-85 us per step on a world-size-1 nccl group).  The capture then must not start while ProcessGroupNCCL's watchdog thread still
+    holds work of earlier eager collectives (drain_watchdog; LABNOTES section 16).  name: the key under which time_collectives() files its duration."""
+    fn = _timed(name, fn)
     if _BOUNDARY is not None and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
         if os.environ.get("NERFSIG_CAPTURE_COLLECTIVES", "") == "1":
             fn()
@@ -46,6 +91,43 @@ def collective(fn, last=False):
             _BOUNDARY(fn, last)        # last: nothing of the step follows this collective -- no further segment is opened
     else:
         fn()
+
+
+def drain_watchdog(limit_s=5.0):
+    """Block until ProcessGroupNCCL's watchdog thread holds no work of earlier (eager) collectives.  Call after torch.cuda.synchronize() and before a graph capture.
+
+    Why: the watchdog polls the end event of every eager collective (hipEventQuery, every 100 ms) until it has seen it complete, then retires the work.  One such
+    query from that thread while THIS thread was capturing killed a rehearsal in round 2 (WorkNCCL::isCompleted raising inside Watchdog::runLoop: the process
+    aborts).  Collectives issued under capture are never handed to the watchdog, so the only works it can hold are those of the warm-up steps -- all complete
+    after the synchronize; what remains is for the watchdog to notice.  Rounds 2-4 slept a fixed 0.5 s (5 polling periods).  Here the condition itself is polled:
+    the flight recorder marks an entry `retired` when the watchdog drops its work, and _dump_nccl_trace(onlyActive=True) lists the others; empty list = empty
+    watchdog.  Falls back to the fixed sleep where the recorder is off (TORCH_NCCL_TRACE_BUFFER_SIZE=0) or the call is missing.  Returns what it did (for the record)."""
+    import time
+    t0 = time.perf_counter()
+    if not (dist.is_initialized() and dist.get_backend() == "nccl"):
+        return {"how": "no nccl group", "seconds": 0.0}
+    dump = getattr(torch._C._distributed_c10d, "_dump_nccl_trace", None)
+    seen_any = False
+    if dump is not None:
+        import pickle
+        try:
+            while time.perf_counter() - t0 < limit_s:
+                doc = pickle.loads(dump(includeCollectives=True, includeStackTraces=False, onlyActive=True))
+                entries = doc.get("entries", []) if isinstance(doc, dict) else []
+                if not entries:
+                    if not seen_any:
+                        # nothing listed on the first look: either the watchdog is already empty or the recorder is off -- tell the two apart
+                        full = pickle.loads(dump(includeCollectives=True, includeStackTraces=False, onlyActive=False))
+                        if not (isinstance(full, dict) and full.get("entries")):
+                            break           # recorder off: fixed sleep below
+                    time.sleep(0.12)        # one more polling period: a work is retired in the same pass that finds it complete
+                    return {"how": "flight recorder: no active work left", "seconds": time.perf_counter() - t0, "waited_for_entries": seen_any}
+                seen_any = True
+                time.sleep(0.02)
+        except Exception as e:      # noqa: BLE001 -- a private API: any surprise falls back to the sleep
+            seen_any = repr(e)
+    time.sleep(0.5)
+    return {"how": "fixed 0.5 s sleep (flight recorder unavailable)", "seconds": time.perf_counter() - t0, "note": seen_any}
 
 
 def collective_ends_segment():
@@ -177,7 +259,7 @@ class _GatherBlocks(torch.autograd.Function):
         out = torch.empty((D,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         ctx.rows = (first, local.shape[0])
         dst, src = out.detach(), local.detach()     # aliases outside autograd: a replay runs this call long after `out` became a graph output
-        collective(lambda: _all_gather_into(dst, src))
+        collective(lambda: _all_gather_into(dst, src), name="all_gather_blocks")
         return out
 
     @staticmethod
@@ -260,7 +342,7 @@ class GradExchange:
             g0 = shared_grad.storage_offset()
             if rng is not None and rng[0].data_ptr() == shared_grad.untyped_storage().data_ptr() and rng[1] == g0 + shared_grad.numel():
                 both = torch.empty(0, dtype=torch.float32, device=shared_grad.device).set_(rng[0], g0, (rng[2] - g0,))
-                collective(lambda: dist.all_reduce(both, op=dist.ReduceOp.SUM))
+                collective(lambda: dist.all_reduce(both, op=dist.ReduceOp.SUM), name="all_reduce_gradients")
                 if self.average:
                     if s_shared == s_dec:
                         both.mul_(s_dec)
@@ -278,7 +360,7 @@ class GradExchange:
                 for h in hs:
                     h.wait()
 
-            collective(both_reduces)
+            collective(both_reduces, name="all_reduce_gradients")
             if self.average:
                 if shared_grad is not None:
                     shared_grad.mul_(s_shared)
@@ -299,7 +381,7 @@ class GradExchange:
             for h in hs:
                 h.wait()
 
-        collective(bucket_reduces)
+        collective(bucket_reduces, name="all_reduce_gradients")
         inv = s_dec if self.average else 1.0
         if shared_grad is not None and self.average:
             shared_grad.mul_(s_shared)

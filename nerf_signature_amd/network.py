@@ -138,7 +138,7 @@ class NeRFNetwork(NeRFRenderer):
                 from . import dp
                 b0, b1 = self.codebook_shard
                 S = fo.codebook_presum_sel(tables[2 * b0:2 * b1], message[b0:b1], out=S)
-                dp.collective(lambda: dist.all_reduce(S, op=dist.ReduceOp.SUM))
+                dp.collective(lambda: dist.all_reduce(S, op=dist.ReduceOp.SUM), name="all_reduce_presum")
                 self._presum_cache = (key, S)
             else:
                 self._presum_cache = (key, fo.codebook_presum_sel(tables, message, out=S))

@@ -25,9 +25,12 @@ def fused_shared_step(optimizer, group, selected, G, grad_scale=1.0):
     vp = ctypes.c_void_p * D
     pp, pm, pv, step_sizes, inv_bc2 = vp(), vp(), vp(), (ctypes.c_float * D)(), (ctypes.c_float * D)()
     handles = optimizer.__dict__.setdefault("_nsig_table_handles", {})      # id(table) -> (table, state dict, exp_avg, exp_avg_sq, their addresses, step count)
+    state = optimizer.state
     for i, p in enumerate(selected):
         h = handles.get(id(p))
-        if h is None or h[0] is not p or h[1].get("exp_avg") is not h[2] or h[1].get("exp_avg_sq") is not h[3] or h[1].get("step") is not h[8]:      # (a loaded checkpoint replaces the state tensors)
+        # validated against the LIVE state: optimizer.load_state_dict() replaces the inner dicts and their tensors (a cached dict would
+        # keep pointing at the orphaned moments)
+        if h is None or h[0] is not p or state.get(p) is not h[1] or h[1].get("exp_avg") is not h[2] or h[1].get("exp_avg_sq") is not h[3] or h[1].get("step") is not h[8]:
             st = optimizer.state[p]
             if len(st) == 0:   # torch.optim.Adam._init_group
                 st["step"] = torch.tensor(0.0, dtype=torch.float32)
@@ -119,7 +122,8 @@ def _dense_takeover(optimizer):
         skip = False
         for i, p in enumerate(ps):
             h = handles.get(id(p))
-            if h is None or h[0] is not p or h[1].get("exp_avg") is not h[2] or h[1].get("exp_avg_sq") is not h[3] or h[1].get("step") is not h[5]:
+            if (h is None or h[0] is not p or optimizer.state.get(p) is not h[1] or h[1].get("exp_avg") is not h[2] or h[1].get("exp_avg_sq") is not h[3]
+                    or h[1].get("step") is not h[5]):      # (live state, see fused_shared_step)
                 st = optimizer.state[p]
                 if len(st) == 0:   # torch.optim.Adam._init_group
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)
@@ -195,14 +199,15 @@ def _step_shared_sel(opt, tables, message_dev, G, lr_dev, grad_scale=1.0, next_m
     group = opt._group_of(tables[0])
     beta1, beta2 = group["betas"]
     cache = getattr(opt, "_sel_cache", None)
-    if cache is None or len(cache[0]) != len(tables) or any(a is not b for a, b in zip(cache[0], tables)):
+    if (cache is None or len(cache[0]) != len(tables) or any(a is not b for a, b in zip(cache[0], tables))
+            or any(opt.state.get(t) is not st for t, st in zip(tables, cache[4]))):      # (load_state_dict replaces the state: new addresses)
         _prepare_device_state(opt, tables)
         D = len(tables) // 2
         arrays = (nv.ptr_array([t.data for t in tables]), nv.ptr_array([opt.state[t]["exp_avg"] for t in tables]),
                   nv.ptr_array([opt.state[t]["exp_avg_sq"] for t in tables]), nv.ptr_array([opt.state[t]["step"] for t in tables]))
         scratch = torch.empty(2 * D, dtype=torch.float32, device=tables[0].device)
-        cache = opt._sel_cache = (list(tables), arrays, scratch, D)
-    _, (pp, pm, pv, ps), scratch, D = cache
+        cache = opt._sel_cache = (list(tables), arrays, scratch, D, [opt.state[t] for t in tables])
+    _, (pp, pm, pv, ps), scratch, D, _ = cache
     if next_message_dev is not None:
         if S_next is None or S_next.dtype != torch.float32 or not S_next.is_contiguous() or S_next.numel() != tables[0].numel():
             raise ValueError("step_shared_sel: S_next must be a contiguous float32 tensor of one table's size")

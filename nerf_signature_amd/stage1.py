@@ -352,7 +352,7 @@ class GraphedCleanLoop:
             import torch.distributed as dist
             flat = self.flat
             self._join_weight_gradients()           # one buffer, one collective: everything in it has to be there
-            dp.collective(lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM))
+            dp.collective(lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM), name="all_reduce_stage1_gradients")
 
     def _adam(self, params):
         """torch.optim.Adam's update of `params` from their `.grad` views through opt_adam_dense (state in torch's capturable format: device step counts)."""

@@ -736,7 +736,7 @@ class GraphedWatermarkLoop:
             self.optimizer.step_shared_sel(tables, msg, self.sink.G, self.lr_dev, scale_cb, next_message_dev=msg_next, S_next=S)
             if self.opt_shard is not None:  # the ranks' partial pre-sums of the next message add up to the whole one
                 import torch.distributed as dist
-                post = lambda: dp.collective(lambda: dist.all_reduce(S, op=dist.ReduceOp.SUM), last=True)
+                post = lambda: dp.collective(lambda: dist.all_reduce(S, op=dist.ReduceOp.SUM), last=True, name="all_reduce_presum")
         else:
             self.optimizer.step_shared_sel(tables, msg, self.sink.G, self.lr_dev, scale_cb)
         if self.native_dense_adam:

@@ -150,18 +150,39 @@ def round_operand(t, operands):
     products accumulated in fp32), as a straight-through op: the forward value is rounded, the gradient passes unchanged.  None: plain fp32."""
     if operands is None:
         return t
-    assert operands == "f16"
+    assert operands in ("f16", "tcnn")
     return t + (t.half().float() - t).detach()
+
+
+def _mlp_tcnn_forward(x, mats):
+    """Forward VALUES of tiny-cuda-nn's FullyFusedMLP as published (tiny-cuda-nn src/fully_fused_mlp.cu; absent from /root/reference, restated): the input
+    and the weights are __half, every layer's product is accumulated in __half fragments -- emulated as: the 16 products of one 16-wide k-step summed in fp32
+    (a tensor-core instruction's internal precision), the running sum rounded to fp16 after every k-step -- hidden activations are stored as __half, the
+    output is __half.  The reference reaches this through network_wtmk_tcnn.py:52-88 (tcnn.Network, "FullyFusedMLP")."""
+    h = x.detach().half()
+    for k, W in enumerate(mats):
+        Wh = W.detach().half().float()
+        acc = torch.zeros(h.shape[0], W.shape[0], dtype=torch.float16)
+        hf = h.float()
+        for k0 in range(0, W.shape[1], 16):
+            acc = (acc.float() + hf[:, k0:k0 + 16] @ Wh[:, k0:k0 + 16].t()).half()
+        h = torch.relu(acc) if k + 1 < len(mats) else acc
+    return h.float()
 
 
 def mlp(x, mats, operands=None):
     """operands="f16" emulates the kernels' default arithmetic (round_operand): the same values reach every ReLU up to the order of the fp32 accumulation,
-    so the same side of every kink is taken -- the element-wise pin of the default mode (tests/test_gpu_field.py)."""
+    so the same side of every kink is taken -- the element-wise pin of the default mode (tests/test_gpu_field.py).
+    operands="tcnn" emulates tiny-cuda-nn's (_mlp_tcnn_forward: fp16 operands, fp16 accumulate, fp16 activations and outputs); the VALUE is that emulation,
+    the gradient the fp16-operand path's (straight-through): the mode exists to measure how far a tcnn-like evaluation sits from the product's
+    (tests/test_gpu_field.py::test_distance_to_a_tcnn_like_evaluation), not to train with."""
     h = x
     for k, W in enumerate(mats):
         h = round_operand(h, operands) @ round_operand(W, operands).t()
         if k + 1 < len(mats):
             h = torch.relu(h)
+    if operands == "tcnn":
+        h = h + (_mlp_tcnn_forward(x, mats) - h).detach()
     return h
 
 
@@ -180,7 +201,11 @@ def color(d, geo_feat, P):
     d01 = (d + 1) / 2
     enc = sh4(d01 * 2 - 1)
     cin = torch.cat([enc, geo_feat, torch.ones_like(enc[:, :1])], dim=-1)
-    return torch.sigmoid(mlp(cin, split_mlp_params(P["color_params"], COLOR_WIDTHS), P.get("mlp_operands"))[:, :3])
+    h = mlp(cin, split_mlp_params(P["color_params"], COLOR_WIDTHS), P.get("mlp_operands"))[:, :3]
+    if P.get("mlp_operands") == "tcnn":      # network_wtmk_tcnn.py:174: torch.sigmoid on the network's __half output stays in fp16
+        rgb = torch.sigmoid(h)
+        return rgb + (torch.sigmoid(h.detach().half()).float() - rgb).detach()
+    return torch.sigmoid(h)
 
 
 def field_forward(x, d, message, P):

@@ -545,3 +545,53 @@ def test_dense_takeover_is_torch_adam_arithmetic():
     with torch.no_grad():
         optim._dense_takeover(ow)
     assert all(p.grad is not None for p in w) and len(ow.state) == 0
+
+
+def test_fused_adam_passes_follow_a_state_dict_loaded_between_steps():
+    """torch's optimizer.load_state_dict() (what the reference Trainer calls, utils_wtmk_disen.py:1500) replaces the inner state dicts AND
+    their tensors; the cached handles of the two hook passes (optim.fused_shared_step for the tables, optim._dense_takeover for dense gradients) must
+    notice and follow the loaded moments instead of updating the orphaned ones.  step -> load_state_dict(deepcopy(state_dict)) -> step, against plain
+    torch.optim.Adam doing the same; afterwards state_dict() carries the moments that were really used (they move with the step)."""
+    import copy as _copy
+    from nerf_signature_amd import optim
+    kw = dict(lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    # dense take-over
+    a = [torch.nn.Parameter(torch.randn(300, 7, device="cuda", generator=gen)) for _ in range(3)]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    oa, ob = torch.optim.Adam(a, **kw), torch.optim.Adam(b, **kw)
+    # shared-gradient table pass: 4 "tables" that all carry G
+    ta = [torch.nn.Parameter(torch.randn(1 << 19, 2, device="cuda", generator=gen) * 1e-2) for _ in range(4)]
+    tb = [torch.nn.Parameter(p.detach().clone()) for p in ta]
+    ota, otb = torch.optim.Adam(ta, **kw), torch.optim.Adam(tb, **kw)
+    for k in range(4):
+        grads = [torch.randn(300, 7, device="cuda", generator=gen) for _ in a]
+        G = torch.randn(1 << 19, 2, device="cuda", generator=gen)
+        for p, q, g in zip(a, b, grads):
+            p.grad, q.grad = g.clone(), g.clone()
+        for p in ta:
+            p.grad = G.clone()
+        oa.step()
+        ota.step()
+        with torch.no_grad():
+            optim._dense_takeover(ob)
+            ob.step()
+            optim._dense_takeover_post_step(ob, (), {})
+            optim.fused_shared_step(otb, otb.param_groups[0], tb, G)
+        if k == 1:      # a checkpoint comes back: new state dicts, new tensors (moments scaled so that following the wrong ones is visible)
+            for o in (oa, ob, ota, otb):
+                sd = _copy.deepcopy(o.state_dict())
+                for st in sd["state"].values():
+                    st["exp_avg"].mul_(0.5)
+                    st["exp_avg_sq"].mul_(2.0)
+                o.load_state_dict(sd)
+    torch.cuda.synchronize()
+    for ref_o, o, ref_p, ps in ((oa, ob, a, b), (ota, otb, ta, tb)):
+        for p, q in zip(ref_p, ps):
+            assert float(o.state[q]["step"]) == float(ref_o.state[p]["step"]) == 4.0
+            torch.testing.assert_close(q, p, rtol=1e-5, atol=1e-6)
+            scale = float(ref_o.state[p]["exp_avg"].abs().max())
+            torch.testing.assert_close(o.state[q]["exp_avg"], ref_o.state[p]["exp_avg"], rtol=2e-5, atol=1e-6 * scale)
+            torch.testing.assert_close(o.state[q]["exp_avg_sq"], ref_o.state[p]["exp_avg_sq"], rtol=2e-5, atol=1e-12)
+            saved = o.state_dict()["state"]
+        assert all(torch.equal(saved[i]["exp_avg"], o.state[q]["exp_avg"]) for i, q in enumerate(ps))

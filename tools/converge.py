@@ -27,12 +27,20 @@ def two_ranks():
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NERFSIG_DIST_BACKEND="gloo",
                    NERFSIG_SHARD_OPTIMIZER=os.environ.get("NERFSIG_SHARD_OPTIMIZER", "1"), NERFSIG_CONVERGE_RANK="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    # the inner limit ends before the caller's (bench.py's secondaries: NERFSIG_SECONDARY_TIMEOUT_S) so that the ranks are stopped by THIS process, which knows them
+    limit = max(20.0, float(os.environ.get("NERFSIG_SECONDARY_TIMEOUT_S", "255")) - 15.0)
     t0, rc = time.time(), 0
     while any(p.poll() is None for p in procs):
-        if time.time() - t0 > 240 or any(p.poll() not in (None, 0) for p in procs):
+        if time.time() - t0 > limit or any(p.poll() not in (None, 0) for p in procs):
             for p in procs:
                 if p.poll() is None:
                     p.terminate()
+            deadline = time.time() + 5.0
+            while time.time() < deadline and any(p.poll() is None for p in procs):
+                time.sleep(0.05)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
             rc = 1
             break
         time.sleep(0.1)
