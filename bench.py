@@ -51,6 +51,11 @@ def parse_args():
     ap.add_argument("--poses", type=int, default=8, help="pre-rendered clean views the per-step poses rotate through")
     ap.add_argument("--dry-launch", action="store_true", help="start the N rank processes over gloo, run the collectives of a step on CPU tensors, no kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch intra-op threads of the CPU baseline (default: the CPUs this process may use, at most 32)")
+    ap.add_argument("--no-variant", action="store_true", help="skip the fixed-blocks variant that the default N = 1 run times behind the headline")
+    ap.add_argument("--dry-device-count", type=int, default=0, help="--dry-launch: the number of GPUs the node is taken to have (default: one per rank; 1 shows the clash report)")
+    ap.add_argument("--launched-by", default="", help=argparse.SUPPRESS)          # set by this file's own launcher / supervisor for the rank processes it starts
+    ap.add_argument("--launch-attempt", default="", help=argparse.SUPPRESS)
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (BASELINE configs 3 and 5, one rank of eight emulated) that the default N = 1 run "
                                                                   "times in child processes BEFORE this process touches the GPU and reports under `secondary`")
     ap.add_argument("--windows", type=int, default=3, help="timed windows of --steps steps each: `value` / `ms_per_step` come from the FIRST (the contract's K steps); "
@@ -83,8 +88,8 @@ def _run_ranks(args, n, extra_env, timeout_s, capture, extra_argv=()):
     f_errs = [tempfile.TemporaryFile(mode="w+") for _ in range(n)] if capture else None
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), NERFSIG_LAUNCHED_BY_BENCH="1", **extra_env)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + list(extra_argv), env=env,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **extra_env)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--launched-by", "bench"] + list(extra_argv), env=env,
                                       stdout=f_out if (capture and r == 0) else None, stderr=f_errs[r] if capture else None))
     rc, t0, first_failed = 0, time.time(), None
 
@@ -166,11 +171,11 @@ def supervise_rank(args):
     modes.  The supervisors do not talk to each other: when one rank of an attempt dies the others hang in their next collective until their
     own watchdog fires, and all of them arrive at attempt k + 1 within one watchdog period, where the fresh rendezvous waits for the last.
     Rank 0's supervisor prints its worker's JSON line, or -- when no attempt succeeded -- the `"value": null` line with the reasons.
-    NERFSIG_LAUNCH_FALLBACK=0 (or a pinned NERFSIG_CAPTURE_COLLECTIVES=0|1) runs the worker in this process instead, as before."""
+    A pinned NERFSIG_CAPTURE_COLLECTIVES=0|1 runs the worker in this process instead, as before."""
     import tempfile
     rank, n = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     hook = os.environ.get("NERFSIG_TEST_FAIL_CAPTURED", "")
-    rehearsal = (args.dry_launch or os.environ.get("NERFSIG_DIST_BACKEND", "") == "gloo") and os.environ.get("NERFSIG_LAUNCH_CHAIN") != "1" and hook not in ("all", "hang")
+    rehearsal = (args.dry_launch or os.environ.get("NERFSIG_DIST_BACKEND", "") == "gloo") and hook not in ("all", "hang")
     attempts = _attempt_chain(None, hook != "", rehearsal)
     watchdog = float(os.environ.get("NERFSIG_LAUNCH_WATCHDOG_S", "90"))
     base_port = int(os.environ.get("MASTER_PORT", "29500"))
@@ -192,11 +197,12 @@ def supervise_rank(args):
         last = k == len(attempts) - 1
         port = 1024 + (base_port + 101 + 7 * k - 1024) % 60000
         child_env = {key: v for key, v in os.environ.items() if not key.startswith("TORCHELASTIC_")}
-        child_env.update(env, NERFSIG_SUPERVISED="1", NERFSIG_LAUNCH_ATTEMPT=f"{k}: {name} (supervised under an external launcher)", MASTER_ADDR="127.0.0.1",
+        child_env.update(env, MASTER_ADDR="127.0.0.1",
                          MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         t_attempt = time.time()
         with tempfile.TemporaryFile(mode="w+") as f_out, tempfile.TemporaryFile(mode="w+") as f_err:
-            p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + list(extra), env=child_env, stdout=f_out, stderr=f_err)
+            p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--launched-by", "supervisor", "--launch-attempt", f"{k}: {name} (supervised under an external launcher)"]
+                                 + list(extra), env=child_env, stdout=f_out, stderr=f_err)
             current[0] = p
             try:
                 rc = p.wait(timeout=watchdog)
@@ -257,7 +263,7 @@ def launch_ranks(args):
     stderr block (mode, return code, the last 20 lines of rank 0's stderr).  If no attempt succeeds the launcher still prints a JSON line
     -- `"value": null` with the reasons in `config.launch_failures` -- and exits non-zero: a scaling point that failed is on record as
     failed, not missing.
-    NERFSIG_CAPTURE_COLLECTIVES=0|1 or NERFSIG_LAUNCH_FALLBACK=0 pin the first attempt's mode (no second attempt)."""
+    NERFSIG_CAPTURE_COLLECTIVES=0|1 pins the mode (one attempt, no chain)."""
     n = args.gpus
     backend = os.environ.get("NERFSIG_DIST_BACKEND", "")
     if not args.dry_launch and backend != "gloo":
@@ -267,9 +273,9 @@ def launch_ranks(args):
     pinned = os.environ.get("NERFSIG_CAPTURE_COLLECTIVES")
     hook = os.environ.get("NERFSIG_TEST_FAIL_CAPTURED", "")      # tests: "1" the first attempt's ranks exit with code 3; "all": every attempt's; "hang": they sleep
     test_hook = hook != ""
-    rehearsal = (args.dry_launch or backend == "gloo") and os.environ.get("NERFSIG_LAUNCH_CHAIN") != "1" and hook not in ("all", "hang")
+    rehearsal = (args.dry_launch or backend == "gloo") and hook not in ("all", "hang")
     watchdog = float(os.environ.get("NERFSIG_LAUNCH_WATCHDOG_S", "90"))
-    if ((pinned in ("0", "1") or os.environ.get("NERFSIG_LAUNCH_FALLBACK") == "0" or args.no_graph or rehearsal) and not test_hook):
+    if ((pinned in ("0", "1") or args.no_graph or rehearsal) and not test_hook):
         rc, _, _ = _run_ranks(args, n, {}, None, capture=False)
         raise SystemExit(rc)
     attempts = _attempt_chain(pinned, test_hook, rehearsal)
@@ -277,9 +283,8 @@ def launch_ranks(args):
     t_chain = time.time()
     for k, (name, env, extra) in enumerate(attempts):
         last = k == len(attempts) - 1
-        env = dict(env, NERFSIG_LAUNCH_ATTEMPT=f"{k}: {name}")
         t_attempt = time.time()
-        rc, text, report = _run_ranks(args, n, env, watchdog, capture=True, extra_argv=extra)
+        rc, text, report = _run_ranks(args, n, env, watchdog, capture=True, extra_argv=["--launch-attempt", f"{k}: {name}"] + list(extra))
         if rc == 0 and text and "{" in text:
             break
         report = report or {"first_failed_rank": None, "stderr_tail": "", "rank0_stderr_tail": ""}
@@ -305,14 +310,14 @@ def dry_launch(args):
     from nerf_signature_amd import dp
     hook = os.environ.get("NERFSIG_TEST_FAIL_CAPTURED", "")
     if (hook == "1" and os.environ.get("NERFSIG_CAPTURE_COLLECTIVES") == "1") or hook == "all":
-        print(f"[dry-launch] test hook: rank {os.environ.get('RANK')} fails on purpose ({os.environ.get('NERFSIG_LAUNCH_ATTEMPT')})", file=sys.stderr)
+        print(f"[dry-launch] test hook: rank {os.environ.get('RANK')} fails on purpose ({args.launch_attempt})", file=sys.stderr)
         raise SystemExit(3)
     if hook == "hang":
         time.sleep(3600)
     rank, world, _ = dp.init_from_env(backend="gloo")
     # first-contact check: every rank binds a GPU of its own, decided before any GPU call (no GPU here: the node is taken to have one device per
-    # rank of the launch, NERFSIG_DRY_DEVICE_COUNT overrides -- e.g. 1 to see the clash reported)
-    devices = int(os.environ.get("NERFSIG_DRY_DEVICE_COUNT", str(world)))
+    # rank of the launch, --dry-device-count overrides -- e.g. 1 to see the clash reported)
+    devices = args.dry_device_count or world
     try:
         ordinal, physical = dp.assert_distinct_devices(device_count=devices)
     except RuntimeError as e:
@@ -357,7 +362,7 @@ class NativeTimer:
     """HIP-event timing of selected libnerfsig entry points, on the stream the kernels are launched on (torch's current
     stream).  Installed over nerf_signature_amd._native.call; each timed call records (duration, points)."""
 
-    POINTS_ARG = {"hg_encode_planes": 1, "hg_encode_codebook_plane": 1, "field_fwd_kept": 2, "field_fwd": 2, "field_bwd": 1, "field_bwd_planned": 1, "hg_scatter_sliced": 1, "hg_scatter_binned": 1,
+    POINTS_ARG = {"hg_encode_planes": 1, "hg_encode_codebook_plane": 1, "field_fwd": 2, "field_bwd": 1, "field_bwd_planned": 1, "hg_scatter_sliced": 1, "hg_scatter_binned": 1,
                   "hg_scatter_planned": 1, "hg_scatter_plan": 1}
 
     def __init__(self, nv):
@@ -386,7 +391,23 @@ class NativeTimer:
         return float(np.mean([t for t, _ in ev])), len(ev), float(np.mean([m for _, m in ev]))
 
 
-def cpu_baseline(model, D, full_step_points=None):
+# DESIGN.md section 7, written in round 4 BEFORE any run with more than one RCCL rank (ms per step, lo-hi): the emulated rank-of-R step (kernel work + launch structure of one
+# rank, collectives on a one-rank group) + a latency / bandwidth budget for the collectives over xGMI.  Round 5 adds the segmented figures for R = 2, 4 from the same budget.
+PREDICTED_MS = {(8, "captured"): (0.65, 0.73), (8, "segmented"): (0.86, 0.94), (4, "captured"): (0.70, 0.76), (4, "segmented"): (0.87, 0.94),
+                (2, "captured"): (0.87, 0.92), (2, "segmented"): (0.96, 1.03)}
+
+
+def prediction(world, mode, measured_ms, rays=4096):
+    p = PREDICTED_MS.get((world, mode))
+    if p is None:
+        return {"note": f"no prediction on record for {world} ranks, {mode}"}
+    lo, hi = p
+    mid = 0.5 * (lo + hi)
+    return {"source": "DESIGN.md section 7 (stated before the first multi-GPU run)", "mode": mode, "ms_per_step": [lo, hi], "rays_per_s": [rays * world / hi * 1e3, rays * world / lo * 1e3],
+            "measured_ms_per_step": measured_ms, "measured_over_predicted_mid": measured_ms / mid, "inside_the_predicted_band": lo <= measured_ms <= hi}
+
+
+def cpu_baseline(model, D, full_step_points=None, threads=0):
     """the oracle (CPU restatement of the reference path; reference-faithful per-bit op sequence for the
     encoders) timed on this box's host cores in BOTH shapes, 1 warm-up + 3 timed batches each, forward + backward:
       run_cuda shape (occupancy-grid march, raymarching.cu:312-693 semantics): one train step = the full 4096-ray content batch +
@@ -408,7 +429,7 @@ def cpu_baseline(model, D, full_step_points=None):
     allowed = min(allowed, quota) if quota else allowed
     # one intra-op thread per CPU this process may really use, at most 32 (same box, tools/cpu_baseline_threads.py: 4 threads 1.7e3 rays/s,
     # 8: 3.0e3, 16 = the box's share: 4.4e3, 32: 2.1e3, 64: 1.1e3, 128: 1.7e2 -- the oracle's tensor ops are small)
-    torch.set_num_threads(int(os.environ.get("NERFSIG_CPU_THREADS", 0)) or max(1, min(allowed, 32)))
+    torch.set_num_threads(int(threads) or max(1, min(allowed, 32)))
     bo, bd = synthetic.block_rays("hotdog")
     bo, bd = bo[:, :4, :4].contiguous(), bd[:, :4, :4].contiguous()
     co, cd = synthetic.content_rays("hotdog", 4096, seed=0)
@@ -462,7 +483,7 @@ def cpu_baseline(model, D, full_step_points=None):
             free_gb = psutil.virtual_memory().available / 2 ** 30
         except Exception:
             free_gb = 0.0
-        if free_gb >= 24.0 and os.environ.get("NERFSIG_CPU_FULL_STEP", "1") != "0":
+        if free_gb >= 24.0:
             bo_f, bd_f = synthetic.block_rays("hotdog")
 
             def full():
@@ -478,7 +499,7 @@ def cpu_baseline(model, D, full_step_points=None):
                     "points_per_s": pts_full / t_full, "estimate_from_the_subsampled_steps": estimate,
                     "how": "one warm-up + ONE timed full step of the oracle (fr.train_step + backward): 4096 content rays + all 4608 block rays, the GPU line's step"}
         else:
-            same["why_not_measured"] = f"{free_gb:.0f} GiB of host memory free (< 24) or NERFSIG_CPU_FULL_STEP=0"
+            same["why_not_measured"] = f"{free_gb:.0f} GiB of host memory free (< 24)"
     return {"value": a["rays_per_s"], "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
             "same_basis": same,
             "comparable_with_the_gpu_line": "ONLY `points_per_s` (vs config.points_per_s) and `same_basis.value` (vs `value`): this entry's own `value` counts the 4608 rays of a step whose "
@@ -499,7 +520,7 @@ def _run_secondary(argv, limit_s):
     starts rank processes of its own (tools/converge.py dp2) must not leave them training on the GPU beside the next secondary or the headline."""
     import signal
     import tempfile
-    env = dict(os.environ, NERFSIG_BENCH_VARIANT="0", NERFSIG_SECONDARY_TIMEOUT_S=str(limit_s))
+    env = dict(os.environ, NERFSIG_SECONDARY_TIMEOUT_S=str(limit_s))
     with tempfile.TemporaryFile(mode="w+") as f_out, tempfile.TemporaryFile(mode="w+") as f_err:
         p = subprocess.Popen([sys.executable] + list(argv), env=env, stdout=f_out, stderr=f_err, start_new_session=True)
         timed_out = False
@@ -652,7 +673,7 @@ def bench_training(args, scene, real_stdout, secondary=None):
             model.fix_rays(blk_o, blk_d, render_kwargs["dt_gamma"], render_kwargs["max_steps"])
     else:
         loop = trainer.GraphedWatermarkLoop(model, optimizer, render_kwargs, data, overlap_content=not args.no_overlap, content_headroom=0.25, content_sampler=sampler,
-                                            fixed_blocks=True if args.fixed_blocks else None, lr_lambda=lr_lambda, **hp)
+                                            fixed_blocks=args.fixed_blocks, lr_lambda=lr_lambda, **hp)
 
     timer = NativeTimer(nv)
     msg_rng = np.random.RandomState(1234)   # same stream on every rank: the message is replicated
@@ -673,8 +694,6 @@ def bench_training(args, scene, real_stdout, secondary=None):
             return loop.step(data, msg) if args.no_graph else loop.step(msg, next_message=upcoming[0])
         if args.no_graph:
             return loop.step({"watermark": data["watermark"], "content": draw_content(counter[0] - 1)}, msg)
-        if loop.content_ahead:      # the rays of the NEXT step: marched at the end of this replay, beside the optimiser
-            return loop.step(msg, next_data={"content": draw_content(counter[0])}, next_message=upcoming[0])
         return loop.step(msg, data={"content": draw_content(counter[0] - 1)} if counter[0] > 1 else None, next_message=upcoming[0])
 
     for _ in range(args.warmup):
@@ -701,6 +720,11 @@ def bench_training(args, scene, real_stdout, secondary=None):
     # more windows of the same K steps (same loop, same process): the contract's numbers come from the first; the spread says how big a
     # round-to-round difference has to be before it means anything (boxes of the pool differ by ~2 %)
     window_ms = [elapsed / args.steps * 1e3]
+    # per-collective times (HIP events around each eagerly executed collective): in the windows BEHIND the first -- the contract's K steps stay untouched -- for the
+    # segmented mode, whose collectives run between the graph segments of every replay; collectives captured inside the graph are timed in the eager pass below
+    coll_us = {}
+    if dp.exchange_active():
+        dp.time_collectives(True)
     for _ in range(max(0, args.windows - 1)):
         if dist.is_initialized():
             dist.barrier()
@@ -712,14 +736,9 @@ def bench_training(args, scene, real_stdout, secondary=None):
             dist.barrier()
         torch.cuda.synchronize()
         window_ms.append((time.perf_counter() - tw) / args.steps * 1e3)
-    if os.environ.get("NERFSIG_BENCH_REPLAY_ONLY") == "1" and not args.no_graph and len(loop.segments) == 1:
-        # diagnostics: the captured graph replayed back to back with NO host work between two replays (stale messages: timing only)
-        torch.cuda.synchronize()
-        tw = time.perf_counter()
-        for i in range(args.steps):
-            loop.segments[0].replay()
-        torch.cuda.synchronize()
-        print(f"[bench] raw replays: {(time.perf_counter() - tw) / args.steps * 1e3:.4f} ms per replay (loop.step: {window_ms[-1]:.4f})", file=sys.stderr)
+    if dp.exchange_active():
+        coll_us["between_graph_segments_of_the_replays"] = dp.collective_times_us()
+        dp.time_collectives(False)
     loss_value = float(out[5].detach())
     loss_parts = (float(out[3].detach()), float(out[4].detach()))
     # Replicated quantities must be the same number on every rank: the watermark loss (every rank decodes the same all-gathered blocks) and
@@ -745,17 +764,18 @@ def bench_training(args, scene, real_stdout, secondary=None):
         loop.side_stream = loop.plan_stream = loop.weights_stream = None
         loop.content_backward_first = False
         timer.enabled = True
+        if dp.exchange_active():
+            dp.time_collectives(True)
         for _ in range(5):
             optimizer.zero_grad(set_to_none=True)
             loop._forward_backward()
             loop.exchange(loop.sink.G)
-            if getattr(loop, "encode_ahead", False):     # the encoder runs beside the optimiser in the captured step: here one after the other,
-                loop._optimise()                         # so that the events bracket the kernel alone (rocprofv3 shows the overlapped durations)
-                loop._march_ahead()
-            else:
-                loop._optimise_and_march()
+            loop._optimise_and_march()
         torch.cuda.synchronize()
         timer.enabled = False
+        if dp.exchange_active():
+            coll_us["eager_pass_one_stream"] = dp.collective_times_us()
+            dp.time_collectives(False)
         loop.side_stream, loop.plan_stream, loop.weights_stream, loop.content_backward_first = streams
 
     if args.no_graph:
@@ -770,7 +790,7 @@ def bench_training(args, scene, real_stdout, secondary=None):
     # gathered per step (GraphedWatermarkLoop(fixed_blocks=True); bit-identical renders, tests/test_gpu_fixed.py).  NOT the headline:
     # `value` above is the step that recomputes everything every step, like the reference.
     variant = None
-    if world == 1 and scene == "hotdog" and not (args.no_graph or args.fixed_blocks or args.fixed_rays or args.host_rays) and os.environ.get("NERFSIG_BENCH_VARIANT", "1") != "0":
+    if world == 1 and scene == "hotdog" and not (args.no_graph or args.fixed_blocks or args.fixed_rays or args.host_rays or args.no_variant) and not dp.exchange_active():
         try:
             loop.close()
             loop2 = trainer.GraphedWatermarkLoop(model, optimizer, render_kwargs, data, overlap_content=not args.no_overlap, content_headroom=0.25, content_sampler=sampler,
@@ -788,7 +808,7 @@ def bench_training(args, scene, real_stdout, secondary=None):
             variant = {"what": "watermark-block rays declared constant (one pair of tensors per dataset, provider_wtmk.py:442-494): samples marched once, their 16 base-level "
                                "feature planes and scatter plan kept, per step only the codebook level is gathered for them; MLPs, compositing, decoder, backward, scatter and "
                                "optimiser run every step; renders bit-identical to the recomputing step (tests/test_gpu_fixed.py); opt-in: GraphedWatermarkLoop(fixed_blocks=True), "
-                               "NERFSIG_FIXED_BLOCKS=1, bench.py --fixed-blocks",
+                               "bench.py --fixed-blocks",
                        "ms_per_step": el2 / args.steps * 1e3, "content_rays_per_s": args.rays * args.steps / el2, "steps": args.steps,
                        "loss": float(out2[5].detach()), "capacity_overflow": bool(loop2.overflowed())}
         except Exception as e:      # a secondary figure must not take the headline down
@@ -824,9 +844,9 @@ def bench_training(args, scene, real_stdout, secondary=None):
     # ---- bytes.  IMPLEMENTED algorithm: the D selected codebook tables are pre-summed into one (linearity of the
     # trilinear interpolation), so a point gathers 16 base levels + 1 summed level, 8 corners x 8 B each.
     gather_impl = 16 * 64 + 64                     # 1088 B/point actually gathered by k_encode_planes
-    split_encoder_early = bool(getattr(loop, "encode_ahead", False) or getattr(loop, "fixed_blocks", False))
-    split_encoder = bool(getattr(loop, "encode_ahead", False) or getattr(loop, "fixed_blocks", False)) and enc_big != 0
-    gather_launch = 16 * 64 if split_encoder else gather_impl   # encode-ahead: the timed launch gathers the 16 base levels; the codebook level is its own 64 B/point launch
+    split_encoder_early = bool(getattr(loop, "fixed_blocks", False))
+    split_encoder = split_encoder_early and enc_big != 0
+    gather_launch = 16 * 64 if split_encoder else gather_impl   # (--fixed-blocks: the timed launch gathers the 16 base levels; the codebook level is its own 64 B/point launch)
     gather_ref = 16 * 64 + 64 * D                  # the reference algorithm's D separate codebook gathers (side value only)
     achieved = pts_big * gather_launch / enc_s if enc_s > 0 else 0.0
     traffic, l1_model, traffic_source = None, None, None
@@ -884,14 +904,20 @@ def bench_training(args, scene, real_stdout, secondary=None):
             "samples_per_ray_content": n_content / rays_content,
             "ray_sets": "fixed" if args.fixed_rays else f"new pose (of {args.poses} pre-rendered clean views) + new random pixels every step, " +
                         ("drawn inside the captured step from the device-resident pose/image store (rg_sample_rays)" if sampler is not None else "rays generated on the device inside the timed loop (host-driven: randint, rg_get_rays, gather, copies)"),
-            "content_march": "ahead (end of the previous replay)" if getattr(loop, "content_ahead", False) else "head of the step",
+            "content_march": "head of the step",
             "message_dim": D, "parallelism": f"dp{world}", "optimizer": "Adam(betas=(0.9,0.99), eps=1e-15): torch semantics, codebook update fused (opt_codebook_adam)",
             "hyper_parameters": "README.md:45: lambda_w 0.005, lambda_i 1.0, lr 1e-2 * 0.1 ** min(it / 1000, 1) written every step",
             "grad_exchange_bytes_per_step": loop.exchange.bytes_per_step + (rays_block_all * 12 if sharded else 0) + (T_BYTES if getattr(loop, "opt_shard", None) else 0),
             "collectives_per_step": (loop.exchange.collectives_per_step + (1 if sharded else 0) + (1 if getattr(loop, "opt_shard", None) else 0)) if dp.exchange_active() else 0,
             "codebook_optimizer": ("sharded over the ranks (each updates the tables of D/R bits, partial pre-sums all-reduced)" if getattr(loop, "opt_shard", None) else "replicated"),
             "world_size_seen_by_backend": dp.world_size(), "backend": dist.get_backend() if dist.is_initialized() else None,
-            "launch_attempt": os.environ.get("NERFSIG_LAUNCH_ATTEMPT", "n/a (single process or external launcher)"),
+            "launch_attempt": args.launch_attempt or "n/a (single process or external launcher)",
+            "collective_us": coll_us or None,
+            "collective_us_note": "HIP events on the issuing stream around every eagerly executed collective, rank 0: `between_graph_segments_of_the_replays` in the windows behind the first "
+                                  "(segmented mode only: captured collectives are graph nodes), `eager_pass_one_stream` in the 5 eager steps behind the timed run; the times include the wait for "
+                                  "the slowest rank" if coll_us else None,
+            "prediction": prediction(world, "captured" if (not args.no_graph and len(loop.segments) == 1) else "segmented", ms) if world > 1 else None,
+            "watchdog_drain_before_capture": dp.LAST_DRAIN,
             "ranks_agree_on_replicated_values": ranks_agree,
             "execution": "eager" if args.no_graph else f"hipGraph replay, {len(loop.segments)} captured segment(s)" + (" with the RCCL collectives between them" if len(loop.segments) > 1 else
                                                                   (" with the RCCL collectives captured inside" if dp.exchange_active() else "")),
@@ -918,7 +944,7 @@ def bench_training(args, scene, real_stdout, secondary=None):
                       "head of the step, k_encode_codebook_plane: 64 B/point, timed below)" if split_encoder else
                       "bytes of the IMPLEMENTED algorithm: 16 base levels + the pre-summed codebook level, 8 corners x 8 B (DESIGN.md sections 2 and 6)"),
             "codebook_level_launch_s": timer.stats("hg_encode_codebook_plane", big)[0] if split_encoder else None,
-            "scheduling": ("this launch encodes the NEXT step's block samples beside this step's optimiser (encode-ahead); timed here alone, eagerly" if getattr(loop, "encode_ahead", False) else "head of the step") + "; timed in 5 eager steps issued on one stream (no kernel beside it)",
+            "scheduling": "head of the step; timed in 5 eager steps issued on one stream (no kernel beside it)",
             "observed_limiter": "not HBM: the working set (64 MiB base + 4 MiB pre-sum) is L2/MALL-resident; PMC shows the texture-address path busy ~85 % and "
                                 "the L2->L1 line fills (~4 GB per launch) as the limiter (profiles/*pmc_encode*)",
             "frac_hbm_counters": (traffic / enc_s / HBM_PEAK) if (traffic and enc_s > 0) else None,
@@ -951,7 +977,7 @@ def bench_training(args, scene, real_stdout, secondary=None):
     if variant is not None:
         line["config"]["fixed_blocks_variant"] = variant
     if world == 1 and not args.no_cpu_baseline and scene == "hotdog":
-        line["cpu_baseline"] = cpu_baseline(model, D, full_step_points=pts_step)
+        line["cpu_baseline"] = cpu_baseline(model, D, full_step_points=pts_step, threads=args.cpu_threads)
     if secondary is not None:
         quality = secondary.pop("quality", None)
         if quality is not None:      # the reference's whole run on this path (1000 steps, README hyper-parameters) + test_bitacc / test_image: nerf_signature_amd/quality.py
@@ -1023,8 +1049,7 @@ def main():
     in_rank = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if args.gpus > 1 and not in_rank:
         launch_ranks(args)                       # never returns
-    if (args.gpus > 1 and in_rank and os.environ.get("NERFSIG_SUPERVISED") != "1" and os.environ.get("NERFSIG_LAUNCHED_BY_BENCH") != "1"
-            and os.environ.get("NERFSIG_LAUNCH_FALLBACK") != "0" and os.environ.get("NERFSIG_CAPTURE_COLLECTIVES") not in ("0", "1")
+    if (args.gpus > 1 and in_rank and not args.launched_by and os.environ.get("NERFSIG_CAPTURE_COLLECTIVES") not in ("0", "1")
             and not args.no_graph and int(os.environ.get("WORLD_SIZE", "1")) > 1):
         supervise_rank(args)                     # an external launcher started this rank: never returns
     if args.dry_launch:
@@ -1035,8 +1060,7 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
     secondary = None
-    if (args.gpus == 1 and args.config == "hotdog" and not in_rank and not (args.no_secondary or args.no_graph or args.fixed_blocks or args.fixed_rays or args.host_rays)
-            and os.environ.get("NERFSIG_BENCH_SECONDARY", "1") != "0"):
+    if (args.gpus == 1 and args.config == "hotdog" and not in_rank and not (args.no_secondary or args.no_graph or args.fixed_blocks or args.fixed_rays or args.host_rays)):
         secondary = run_secondaries(args)        # child processes, BEFORE anything here touches the GPU
     if args.config == "fern":
         bench_fern(args, real_stdout)

@@ -291,10 +291,14 @@ int mlp_set_pipelined(int mask);
  * planes: NULL = one fused kernel (features gathered inside the MLP kernel); otherwise the level-major feature planes
  *   written by hg_encode_planes for the same (xyzs, M, bound, tables, S): the two-kernel route (XCD-partitioned
  *   encoder, then the MLP kernel) is the faster one for large batches.  Both give bit-identical results.
+ * planes_layout: the layout `planes` was written in -- NSIG_PLANES_F32 (hg_encode_planes / _rows) or NSIG_PLANES_MIXED (hg_encode_planes_mixed); the owner of
+ *   the buffer says so at every call (ignored when planes is NULL).
  */
+#define NSIG_PLANES_F32 0
+#define NSIG_PLANES_MIXED 1
 int field_fwd(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *const *base_tables_host,
               const float *S, const void *packed, float *sigmas, float *rgbs, float *geo_feat, uint32_t *masks,
-              const void *planes, nsig_stream_t stream);
+              const void *planes, int planes_layout, nsig_stream_t stream);
 
 /* The encoder of field_fwd as its own pass: planes[level][point] (float2; 16 base levels + the pre-summed codebook as
  * plane 16), hg_planes_bytes(M) bytes.  Workgroup (tile, slot = blockIdx % 8) encodes only the levels assigned to
@@ -309,13 +313,13 @@ int hg_encode_planes_rows(const float *xyzs, uint32_t M_capacity, const uint32_t
 /* The plane set in the MIXED layout, for the fp16 MLP only (mlp_set_precision(1)): levels 0..14 as fp16 pairs -- exactly the words of the MLP's first-layer
  * operand, rounded to nearest even here instead of at the MLP's load: bit-identical results -- followed by level 15 and the codebook level as float2 (the codebook
  * is added to level 15 before the rounding, network_wtmk_tcnn.py:106).  76 instead of 136 bytes per point each way between encoder and MLP; same buffer size
- * (hg_planes_bytes).  The library remembers by address which sets are mixed: field_fwd / field_fwd_rows / field_fwd_kept / hg_encode_codebook_plane read them
- * accordingly, field_fwd_trace and the split-bf16 MLP refuse them, hg_encode_planes on the same address makes it an fp32 set again.  rows_dev may be NULL. */
+ * (hg_planes_bytes).  Whoever owns the buffer passes planes_layout = NSIG_PLANES_MIXED to the entry points that read or complete the set (field_fwd / field_fwd_rows /
+ * hg_encode_codebook_plane); the split-bf16 MLP refuses it, field_fwd_trace (stage 1) takes fp32 sets only.  rows_dev may be NULL. */
 int hg_encode_planes_mixed(const float *xyzs, uint32_t M_capacity, const uint32_t *rows_dev, float bound, const float *const *base_tables_host,
                            const float *S, void *planes, nsig_stream_t stream);
 int field_fwd_rows(const float *xyzs, const float *dirs, uint32_t M_capacity, const uint32_t *rows_dev, float bound,
                    const float *const *base_tables_host, const float *S, const void *packed, float *sigmas, float *rgbs, const void *planes,
-                   nsig_stream_t stream);
+                   int planes_layout, nsig_stream_t stream);
 
 /* Reads the 16 base tables (and S when given) once, each through the XCD whose workgroups will gather from it in hg_encode_planes, so that
  * the launch finds its tables in L2 instead of starting on caches a streaming pass (the optimiser's) has flushed: the bench workload's block
@@ -330,14 +334,8 @@ int hg_warm_tables(const float *const *base_tables_host, const float *S, float *
  * thing a step changes -- is gathered again, into plane 16 of the same plane set.  Same interpolation code, bit-identical planes.
  * plan_to_reset: NULL, or a scatter plan (hg_scatter_plan) kept across steps for the same points: its per-launch largest-gradient
  * word is cleared here, ahead of the step's field_bwd_planned. */
-int hg_encode_codebook_plane(const float *xyzs, uint32_t M, float bound, const float *S, void *planes, void *plan_to_reset,
+int hg_encode_codebook_plane(const float *xyzs, uint32_t M, float bound, const float *S, void *planes, int planes_layout, void *plan_to_reset,
                              nsig_stream_t stream);
-
-/* field_fwd for such points in ONE launch: the 16 base levels come from `planes` (kept), the codebook level is gathered inside the
- * MLP kernel from S (NULL = clean model) -- the two lane halves of a wave fetch the two x sides of each corner pair and swap them.
- * Bit-identical to hg_encode_codebook_plane + field_fwd(planes).  plan_to_reset as above. */
-int field_fwd_kept(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *S, const void *packed, float *sigmas,
-                   float *rgbs, uint32_t *masks, const void *planes, void *plan_to_reset, nsig_stream_t stream);
 
 /* NeRFNetwork.color (nerf/network_wtmk_tcnn.py:147-176) without the mask: rgb from dirs + geo_feat. */
 int field_color_fwd(const float *dirs, const float *geo_feat, uint32_t M, const void *packed, float *rgbs,

@@ -46,7 +46,7 @@ SIGNATURES = {
     "rm_eval_compact": [_vp, _u32, _u32, _vp, _vp, _vp],
     "hg_encode_planes_rows": [_vp, _u32, _vp, _fl, _vp, _vp, _vp, _vp],
     "hg_encode_planes_mixed": [_vp, _u32, _vp, _fl, _vp, _vp, _vp, _vp],
-    "field_fwd_rows": [_vp, _vp, _u32, _vp, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "field_fwd_rows": [_vp, _vp, _u32, _vp, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp],
     "hg_codebook_presum": [_vp, _u32, _vp, _vp],
     "hg_codebook_presum_sel": [_vp, _vp, _u32, _vp, _vp],
     "hg_encode_fwd": [_vp, _u32, _vp, _vp, _vp, _vp],
@@ -67,9 +67,8 @@ SIGNATURES = {
     "hg_planes_bytes": [_u32],
     "hg_encode_planes": [_vp, _u32, _fl, _vp, _vp, _vp, _vp],
     "hg_warm_tables": [_vp, _vp, _vp, _vp],
-    "hg_encode_codebook_plane": [_vp, _u32, _fl, _vp, _vp, _vp, _vp],
-    "field_fwd_kept": [_vp, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "field_fwd": [_vp, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "hg_encode_codebook_plane": [_vp, _u32, _fl, _vp, _vp, _int, _vp, _vp],
+    "field_fwd": [_vp, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp],
     "field_color_fwd": [_vp, _vp, _u32, _vp, _vp, _vp],
     "opt_adam_dense_host": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _fl, _fl, _fl, _fl, _vp],
     "opt_adam_dense": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _fl, _fl, _fl, _fl, _vp, _vp],

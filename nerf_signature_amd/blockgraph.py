@@ -14,12 +14,13 @@ Same kernels, same arguments, same order on the same stream as the eager calls t
 (tests/test_gpu_amp_ckpt.py::test_block_graph_*).  Anything the capture does not cover makes run() return None and the caller takes the eager route:
 the `scaling` distortion (a new decoder input width every step), a model without the shared-gradient sink, rays that are not (yet) kept, more than one
 rank, an outer capture.
-NERFSIG_DROPIN_BLOCK_GRAPH=0 turns it off."""
+NERFSIG_DROPIN_OFF=block_graph turns it off."""
 import os
 
 import torch
 
 from . import fieldops as fo
+from .switches import dropin_off
 from . import hidden_models
 from .hidden_models import normalize_img
 
@@ -45,9 +46,9 @@ class _Replay(torch.autograd.Function):
             return (None,) * (3 + ctx.n)
         if ctx.generation != g.generation:
             raise RuntimeError("BlockDecodeGraph: backward of a forward pass whose saved activations a later forward has overwritten (the captured block render "
-                               "keeps ONE set of activations: run each step's backward before the next step's forward, or set NERFSIG_DROPIN_BLOCK_GRAPH=0)")
+                               "keeps ONE set of activations: run each step's backward before the next step's forward, or set NERFSIG_DROPIN_OFF=block_graph)")
         if g.backward_of == ctx.generation:
-            raise RuntimeError("BlockDecodeGraph: second backward through the same captured forward pass (retain_graph is not supported: NERFSIG_DROPIN_BLOCK_GRAPH=0)")
+            raise RuntimeError("BlockDecodeGraph: second backward through the same captured forward pass (retain_graph is not supported: NERFSIG_DROPIN_OFF=block_graph)")
         g.backward_of = ctx.generation
         g.sink.begin_accumulation(ctx.selected)           # (Python state of the shared gradient: what _FieldFunction.backward does in front of its scatter)
         g.seed.copy_(grad_decoded.reshape(g.seed.shape))
@@ -103,7 +104,7 @@ class BlockDecodeGraph:
         train_step's six return values.
         distortion: None or a distortion.DistortionLayer whose owner has drawn this step's parameters into its (static) device buffers; every kind but
         `scaling` (which changes the decoder's input width from step to step) is part of the captured forward."""
-        if self.failed is not None or os.environ.get("NERFSIG_DROPIN_BLOCK_GRAPH", "1") == "0":
+        if self.failed is not None or dropin_off("block_graph"):
             return None
         if distortion is not None and (distortion.name == "scaling" or distortion.param is None or not distortion.param.is_cuda):
             return None
@@ -240,7 +241,7 @@ class _ReplayStep(torch.autograd.Function):
     def backward(ctx, g_loss, g_lossi=None, g_lossw=None, *_):
         if g_lossi is not None or g_lossw is not None:
             raise NotImplementedError("StepGraph: the captured backward starts from `loss` (utils_wtmk_disen.py:1174); a backward through lossi / lossw alone needs "
-                                      "NERFSIG_DROPIN_STEP_GRAPH=0")
+                                      "NERFSIG_DROPIN_OFF=step_graph")
         return _Replay.backward(ctx, g_loss)
 
 
@@ -251,7 +252,7 @@ class StepGraph(BlockDecodeGraph):
     into static buffers, (b) the rays are marched EAGERLY into a static sample record of fixed capacity (NeRFRenderer.march_ahead) and the count is read
     back -- the one host read an eager step has anyway.  If the samples fit, the captured forward (block render, decoder, content field pass + compositing
     over `capacity` rows, loss kernel) and later the captured backward are replayed; if they do not, THIS step runs on the eager route (nothing is dropped,
-    ever) and the next capture is sized 1.3 x larger.  NERFSIG_DROPIN_STEP_GRAPH=0: the block render + decoder alone are captured (BlockDecodeGraph)."""
+    ever) and the next capture is sized 1.3 x larger.  NERFSIG_DROPIN_OFF=step_graph: the block render + decoder alone are captured (BlockDecodeGraph)."""
 
     HEADROOM = 1.3
 
@@ -266,7 +267,7 @@ class StepGraph(BlockDecodeGraph):
 
     def usable_content(self, content, loss_is_bce, color_space):
         o, d, gt, _, _ = content
-        return (os.environ.get("NERFSIG_DROPIN_STEP_GRAPH", "1") != "0" and loss_is_bce and color_space == "srgb" and o.is_cuda and o.dtype == torch.float32
+        return (not dropin_off("step_graph") and loss_is_bce and color_space == "srgb" and o.is_cuda and o.dtype == torch.float32
                 and d.dtype == torch.float32 and gt.dtype == torch.float32 and gt.shape[-1] == 3 and tuple(gt.shape[:-1]) == tuple(o.shape[:-1]))
 
     def _stage_content(self, model, content, message, kw):

@@ -6,8 +6,6 @@ that follows that segment in every replay, and the next segment begins in the sa
 (trainer.GraphedWatermarkLoop carries its own copy of this logic, interleaved with its stream schedule; stage1.GraphedCleanLoop uses
 this class.)"""
 import gc
-import os
-import time
 
 import torch
 
@@ -19,7 +17,7 @@ class SegmentedCapture:
         self.segments, self.between = [], []
         self.stream = None
 
-    def capture(self, fn, drain_watchdog=None):
+    def capture(self, fn):
         """Capture fn() (no arguments; its tensors are static) on this object's stream.  Returns fn's result (static tensors)."""
         self.segments, self.between = [torch.cuda.CUDAGraph()], []
         open_capture = [True]
@@ -36,11 +34,7 @@ class SegmentedCapture:
 
         gc.collect()
         torch.cuda.synchronize()
-        if dp.exchange_active():
-            # ProcessGroupNCCL's watchdog thread polls the events of earlier (eager) collectives until it has seen them complete; a query
-            # from that thread while this one captures has killed a rehearsal (LABNOTES section 16).  Everything is complete after the
-            # synchronize above: give the watchdog one polling period to notice and empty its list.
-            time.sleep(float(os.environ.get("NERFSIG_WATCHDOG_DRAIN_S", "0.5")) if drain_watchdog is None else drain_watchdog)
+        dp.drain_watchdog()       # (a no-op without an nccl group) nothing of the warm-up's collectives may be left with ProcessGroupNCCL's watchdog thread
         if self.stream is None:
             self.stream = torch.cuda.Stream()
         self.stream.wait_stream(torch.cuda.current_stream())

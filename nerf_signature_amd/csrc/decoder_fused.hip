@@ -1450,30 +1450,17 @@ static int allow_lds(K kernel, size_t bytes, size_t &allowed) {
     return 0;
 }
 static int allow_all_lds(const DecGeom &g) {
-    static size_t a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    return allow_lds(k_dec_conv<kFwd, 256>, conv_lds(g), a[0]) | allow_lds(k_dec_conv<kDgrad, 256>, conv_lds(g), a[1]) |
-           allow_lds(k_dec_conv<kDgradImg, 256>, conv_lds(g), a[2]) | allow_lds(k_dec_l8_fwd, l8_lds(g), a[3]) |
-           allow_lds(k_dec_l8_bwd, l8b_lds(g), a[4]) | allow_lds(k_dec_wgrad, wgrad_lds(g), a[5]) |
-           allow_lds(k_dec_conv<kFwd, 512>, conv_lds(g), a[6]) | allow_lds(k_dec_conv<kDgrad, 512>, conv_lds(g), a[7]) |
-           allow_lds(k_dec_conv<kDgradImg, 512>, conv_lds(g), a[8]);
+    static size_t a[6] = {0, 0, 0, 0, 0, 0};
+    return allow_lds(k_dec_conv<kFwd, 512>, conv_lds(g), a[0]) | allow_lds(k_dec_conv<kDgrad, 512>, conv_lds(g), a[1]) |
+           allow_lds(k_dec_conv<kDgradImg, 512>, conv_lds(g), a[2]) | allow_lds(k_dec_l8_fwd, l8_lds(g), a[3]) |
+           allow_lds(k_dec_l8_bwd, l8b_lds(g), a[4]) | allow_lds(k_dec_wgrad, wgrad_lds(g), a[5]);
 }
 
-// Threads per conv workgroup: 512 = four MFMA waves + four helper waves for the request / statistics / prologue phases
-// (NERFSIG_DEC_THREADS=256 selects the four-wave form; experiments).
-static int conv_threads() {
-    static const int n = [] {
-        const char *e = getenv("NERFSIG_DEC_THREADS");
-        return e && atoi(e) == 256 ? 256 : 512;
-    }();
-    return n;
-}
+// Threads per conv workgroup: 512 = four MFMA waves + four helper waves for the request / statistics / prologue phases.
 template <int MODE>
 static void launch_conv(dim3 grid, size_t lds, hipStream_t s, int layer, const DecParams &prm, const DecWs &ws, const DecGeom &g, float *grad_img,
                         const float *img, const DecInput &inp) {
-    if (conv_threads() == 512)
-        k_dec_conv<MODE, 512><<<grid, 512, lds, s>>>(layer, prm, ws, g, grad_img, img, inp);
-    else
-        k_dec_conv<MODE, 256><<<grid, 256, lds, s>>>(layer, prm, ws, g, grad_img, img, inp);
+    k_dec_conv<MODE, 512><<<grid, 512, lds, s>>>(layer, prm, ws, g, grad_img, img, inp);
 }
 
 }  // namespace nsig

@@ -345,10 +345,7 @@ __device__ inline void color_branch(const char *lds, int lane, int h, float dx, 
 // a wave are 512 contiguous bytes; streaming loads/stores are non-temporal to leave L2 to the tables.
 struct SlotTable {
     uint8_t n[8];
-    uint8_t level[8][8];      // 0..15 base levels, 16 = pre-summed codebook
-    uint16_t lo[8][8], hi[8][8];   // the slot encodes the level for tiles in [lo, hi) / 4096 of the tile range (a level may be split over two slots)
-    uint8_t sc1_from;         // levels >= this gather with agent-scope (L1-bypassing, L2-served) loads; 255 = none (experiment: never faster)
-    uint32_t skip_mask;       // diagnostics: levels whose bit is set are not encoded (per-level cost measurements)
+    uint8_t level[8][8];      // 0..15 base levels, 16 = pre-summed codebook; every level belongs to exactly one slot
 };
 
 // Lane pairs cooperate on the gathers.  A gather costs ~2.4 clk per distinct 128-byte line per instruction plus ~1 clk per lane
@@ -383,13 +380,8 @@ __device__ inline float2 load_plane(const float2 *__restrict__ planes, uint32_t 
     return make_float2(w[0], w[1]);
 }
 
-__device__ inline void encode_tile_level(const float2 *__restrict__ table, float cell, bool sc1, uint32_t xs, float x, float y, float z,
+__device__ inline void encode_tile_level(const float2 *__restrict__ table, float cell, uint32_t xs, float x, float y, float z,
                                          float2 *__restrict__ out, bool half_out = false) {
-    auto ld = [&](uint32_t row) -> float2 {
-        if (!sc1) return table[row];
-        const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(table + row), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return __builtin_bit_cast(float2, u);
-    };
     uint32_t ix, iy, iz;
     float wx, wy, wz;
     axis_cell(x, cell, ix, wx);
@@ -401,10 +393,10 @@ __device__ inline void encode_tile_level(const float2 *__restrict__ table, float
     for (int P = 0; P < 2; ++P) {
         const uint32_t hx = dpp_u(ix, P) + xs;
         const uint32_t a0 = dpp_u(hy0, P), a1 = dpp_u(hy1, P), b0 = dpp_u(hz0, P), b1 = dpp_u(hz1, P);
-        v[P][0] = ld((hx ^ a0 ^ b0) & kRowMask);
-        v[P][1] = ld((hx ^ a0 ^ b1) & kRowMask);
-        v[P][2] = ld((hx ^ a1 ^ b0) & kRowMask);
-        v[P][3] = ld((hx ^ a1 ^ b1) & kRowMask);
+        v[P][0] = table[(hx ^ a0 ^ b0) & kRowMask];
+        v[P][1] = table[(hx ^ a0 ^ b1) & kRowMask];
+        v[P][2] = table[(hx ^ a1 ^ b0) & kRowMask];
+        v[P][3] = table[(hx ^ a1 ^ b1) & kRowMask];
     }
     float2 e[8];
 #pragma unroll
@@ -470,13 +462,10 @@ __global__ void __launch_bounds__(256) k_encode_planes(const float *__restrict__
         const float x = (pt.x + bound) / two_b, y = (pt.y + bound) / two_b, z = (pt.z + bound) / two_b;
         for (int i = 0; i < n_levels; ++i) {
             const int l = tab.level[slot][i];
-            if ((tab.skip_mask >> l) & 1u) continue;
-            const unsigned long long pos = (unsigned long long)tile * 4096ull;       // wave-uniform range test
-            if (pos < (unsigned long long)tab.lo[slot][i] * n_tiles || pos >= (unsigned long long)tab.hi[slot][i] * n_tiles) continue;
             const bool half_out = mixed && l < kHalfLevels;
             float2 *out = !mixed ? planes + (size_t)l * stride + m
                                  : (half_out ? reinterpret_cast<float2 *>(reinterpret_cast<uint32_t *>(planes) + (size_t)l * stride + m) : mixed_f32_plane(planes, stride, l) + m);
-            encode_tile_level(reinterpret_cast<const float2 *>(l == NSIG_BASE_LEVELS ? S : base.p[l]), geom.cell[l], l >= (int)tab.sc1_from, xs, x, y, z, out, half_out);
+            encode_tile_level(reinterpret_cast<const float2 *>(l == NSIG_BASE_LEVELS ? S : base.p[l]), geom.cell[l], xs, x, y, z, out, half_out);
         }
     }
 }
@@ -494,36 +483,10 @@ __global__ void __launch_bounds__(256) k_encode_codebook_plane(const float *__re
     const float two_b = 2.0f * bound;
     const float3 pt = *reinterpret_cast<const float3 *>(xyzs + 3 * (size_t)ml);
     const float x = (pt.x + bound) / two_b, y = (pt.y + bound) / two_b, z = (pt.z + bound) / two_b;
-    encode_tile_level(reinterpret_cast<const float2 *>(S), cell, false, threadIdx.x & 1u, x, y, z, plane + m);
+    encode_tile_level(reinterpret_cast<const float2 *>(S), cell, threadIdx.x & 1u, x, y, z, plane + m);
 }
 
-// The codebook level gathered inside the MLP kernel (kPlanes == 2): the two lane halves of a wave hold the same 32 points, so
-// half 0 fetches the x = 0 side of every (dy, dz) pair and half 1 the x = 1 side -- one instruction touches 32 lines, like the
-// lane pairs of encode_tile_level -- and the halves swap what they fetched.  Same rows, same trilerp(): bit-identical to the plane.
-__device__ inline float2 codebook_half_gather(const float2 *__restrict__ S, float cell, uint32_t xs, float x, float y, float z) {
-    uint32_t ix, iy, iz;
-    float wx, wy, wz;
-    axis_cell(x, cell, ix, wx);
-    axis_cell(y, cell, iy, wy);
-    axis_cell(z, cell, iz, wz);
-    const uint32_t hx = ix + xs, hy[2] = {iy * kPrimeY, (iy + 1u) * kPrimeY}, hz[2] = {iz * kPrimeZ, (iz + 1u) * kPrimeZ};
-    float2 v[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = S[(hx ^ hy[q >> 1] ^ hz[q & 1]) & kRowMask];
-    float2 e[8];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float2 got;
-        got.x = __shfl_xor(v[q].x, 32, 64);
-        got.y = __shfl_xor(v[q].y, 32, 64);
-        e[q] = xs ? got : v[q];          // corner k = 4*dx + q
-        e[4 + q] = xs ? v[q] : got;
-    }
-    return trilerp(e, wx, wy, wz);
-}
-
-// kPlanes = 0: gather the features in-kernel (fused); 1: read all 17 from the level-major planes; 2: the 16 base levels from the
-// planes, the codebook level gathered here (field_fwd_kept: points whose base planes are kept across steps).
+// (k_field_fwd's kPlanes = 0: gather the features in-kernel (fused); 1: read all 17 from the level-major planes.)
 // The training render's forward launch (all 17 feature planes in memory, sigma + rgb + ReLU masks out), software-pipelined over a wave's tiles.
 // The plain loop -- load, evaluate, store, next tile -- spends most of a tile's ~4.9 us waiting, three times: for the planes at its head, for the
 // view directions in front of the colour branch (a load issued there drains, in order, everything requested before it), and at the head of the
@@ -691,8 +654,7 @@ __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyz
                                                    const float2 *__restrict__ planes, uint32_t stride,
                                                    const char *__restrict__ packed, float *__restrict__ sigmas, float *__restrict__ rgbs,
                                                    float *__restrict__ geo_out, uint32_t *__restrict__ masks, ActTrace trace = ActTrace{},
-                                                   BinHeader *__restrict__ plan_reset = nullptr, const uint32_t *__restrict__ rows_dev = nullptr,
-                                                   bool mixed = false) {
+                                                   const uint32_t *__restrict__ rows_dev = nullptr, bool mixed = false) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     if (rows_dev != nullptr) {      // (field_fwd_rows)
         const uint32_t r = *rows_dev;
@@ -701,7 +663,6 @@ __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyz
     }
     stage_weights(lds, packed + P::kFwdOffset, (int)P::kFwdLds);
     constexpr size_t kHalf = kFwdBytes;
-    if (kPlanes == 2 && plan_reset != nullptr && blockIdx.x == 0 && threadIdx.x == 0) plan_reset->gmax_bits = 0;   // (as hg_encode_codebook_plane)
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int p = lane & 31, h = lane >> 5;
@@ -716,18 +677,7 @@ __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyz
             float2 f[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) f[q] = load_plane(planes, stride, 8 * (q >> 2) + (q & 3) + 4 * h, s, mixed);  // 256 (mixed: 128) contiguous bytes per half-wave
-            if (kPlanes == 2) {
-                if (S != nullptr) {   // both halves gather (one x side each); half 1 owns level 15 and takes the sum
-                    const float two_b = 2.0f * bound;
-                    const float3 pt = *reinterpret_cast<const float3 *>(xyzs + 3 * (size_t)sl);
-                    const float2 c = codebook_half_gather(reinterpret_cast<const float2 *>(S), geom.cell[NSIG_BASE_LEVELS], (uint32_t)h,
-                                                          (pt.x + bound) / two_b, (pt.y + bound) / two_b, (pt.z + bound) / two_b);
-                    if (h) {
-                        f[7].x = f[7].x + c.x;
-                        f[7].y = f[7].y + c.y;
-                    }
-                }
-            } else if (S != nullptr && h) {  // codebook added into channels 30:32 (network_wtmk_tcnn.py:106)
+            if (S != nullptr && h) {  // codebook added into channels 30:32 (network_wtmk_tcnn.py:106)
                 const float2 c = load_plane(planes, stride, NSIG_BASE_LEVELS, s, mixed);
                 f[7].x = f[7].x + c.x;
                 f[7].y = f[7].y + c.y;
@@ -1161,14 +1111,10 @@ NSIG_EXPORT int mlp_pack_weights(const float *sigma_params, const float *color_p
 }
 
 // Bit 0: the training render's forward goes through k_field_fwd_train, bit 1: its planned backward through k_field_bwd_train (the software-pipelined
-// launches; results bit-identical to the plain loops k_field_fwd<F16, 1> / k_field_bwd<F16>).  Default both; NERFSIG_FWD_PIPELINE=0 /
-// NERFSIG_BWD_PIPELINE=0 or mlp_set_pipelined() select the plain loops.
-static int g_mlp_pipelined = -1;
+// launches; results bit-identical to the plain loops k_field_fwd<F16, 1> / k_field_bwd<F16>).  Default both; mlp_set_pipelined() selects the
+// plain loops (the bit-identity test does).
+static int g_mlp_pipelined = 3;
 static int mlp_pipelined() {
-    if (g_mlp_pipelined < 0) {
-        const char *f = getenv("NERFSIG_FWD_PIPELINE"), *b = getenv("NERFSIG_BWD_PIPELINE");
-        g_mlp_pipelined = ((f && !strcmp(f, "0")) ? 0 : 1) | ((b && !strcmp(b, "0")) ? 0 : 2);
-    }
     return g_mlp_pipelined;
 }
 static bool fwd_pipelined() { return (mlp_pipelined() & 1) != 0; }
@@ -1184,9 +1130,7 @@ static uint32_t field_grid(uint32_t M, bool forward = false, uint32_t per_cu = 0
     // persistent workgroups (the packed weights are staged once per workgroup): 3 per CU fit the LDS budget.  Same-box sweeps
     // (profiles/r01_k_field_grid_sweep.txt): the backward is fastest with exactly the resident 768 (113-117 us; 128 with 512 or 1024),
     // the forward with 512 or 1024 (117-120 us against 124-125 with 768) and the step with 1024 (1.118-1.123 ms against 1.132-1.133).
-    static const uint32_t cap_f = getenv("NERFSIG_FIELD_FWD_WGS") ? (uint32_t)atoi(getenv("NERFSIG_FIELD_FWD_WGS")) : (uint32_t)(kCUs * 4);
-    static const uint32_t cap_b = getenv("NERFSIG_FIELD_BWD_WGS") ? (uint32_t)atoi(getenv("NERFSIG_FIELD_BWD_WGS")) : (uint32_t)(kCUs * 3);
-    const uint32_t cap = per_cu ? (getenv("NERFSIG_FIELD_FWD_WGS") ? cap_f : (uint32_t)kCUs * per_cu) : (forward ? cap_f : cap_b);
+    const uint32_t cap = (uint32_t)kCUs * (per_cu ? per_cu : (forward ? 4u : 3u));
     return blocks < cap ? blocks : cap;
 }
 
@@ -1199,73 +1143,19 @@ static int fill_base_tables(const float *const *host, TablePtrs &base, const cha
     return NSIG_OK;
 }
 
-// Level -> XCD-slot assignment of k_encode_planes: the six finest levels each get a slot of their own or share it only
-// with coarse (cache-resident) levels.  NERFSIG_SLOTS="16|15|14|..." overrides it (experiments).
-// Cost of encoding one level for the block render's 1.29 M points on ONE XCD slot, in us (profiles/r02_encoder_levels.txt: every level
-// measured alone, minus the 34 us an empty launch takes): ~45 for the eight coarse levels, whose cells span several consecutive
-// samples, up to 175 for the codebook level, where every sample touches four fresh 128-byte lines.
-static const float kLevelCost[NSIG_BASE_LEVELS + 1] = {43.4f, 41.9f, 44.7f, 47.5f, 44.3f, 47.2f, 47.2f, 46.8f, 52.7f, 77.7f, 110.2f, 132.0f, 151.4f, 148.6f, 170.0f, 159.6f, 174.7f};
-
+// Level -> XCD-slot assignment of k_encode_planes: the six finest levels each get a slot of their own or share it only with coarse
+// (cache-resident) levels; whole levels per slot.  The assignment that won round 1's same-box sweeps (profiles/r01_k_encoder_slots_sweep.txt); a
+// cost-balanced split with levels cut across slots was measured slower (287-292 against 283 us, profiles/r02_encoder_experiments.txt: with all eight
+// XCDs busy the launch is bound chip-wide by L2->L1 line fills, not by its fullest slot) and is gone.
 static SlotTable default_slots(bool with_codebook) {
+    static const uint8_t kWith[8][4] = {{16, 255, 255, 255}, {15, 255, 255, 255}, {14, 0, 255, 255}, {13, 1, 255, 255}, {12, 2, 3, 255}, {11, 4, 5, 255}, {10, 9, 255, 255}, {8, 7, 6, 255}};
+    static const uint8_t kWithout[8][4] = {{15, 255, 255, 255}, {14, 255, 255, 255}, {13, 255, 255, 255}, {12, 255, 255, 255}, {11, 0, 1, 255}, {10, 2, 3, 255}, {9, 8, 4, 255}, {7, 6, 5, 255}};
     SlotTable t{};
-    t.sc1_from = getenv("NERFSIG_ENC_SC1_FROM") ? (uint8_t)atoi(getenv("NERFSIG_ENC_SC1_FROM")) : (uint8_t)255;
-    t.skip_mask = getenv("NERFSIG_ENC_SKIP") ? (uint32_t)strtoul(getenv("NERFSIG_ENC_SKIP"), nullptr, 0) : 0u;
-    // Default: whole levels per slot, the assignment that won round 1's same-box sweeps (profiles/r01_k_encoder_slots_sweep.txt).
-    // NERFSIG_SLOTS=balanced selects the cost-balanced split below instead: by the single-slot costs it should take 226 us against
-    // 275, measured it takes 287-292 against 283 (profiles/r02_encoder_experiments.txt) -- with all eight XCDs busy the levels do not
-    // cost what they cost alone, the launch is bound chip-wide (L2->L1 line fills), not by its fullest slot.
-    static const char *kWith = "16|15|14,0|13,1|12,2,3|11,4,5|10,9|8,7,6";
-    static const char *kWithout = "15|14|13|12|11,0,1|10,2,3|9,8,4|7,6,5";
-    const char *spec = getenv(with_codebook ? "NERFSIG_SLOTS" : "NERFSIG_SLOTS_CLEAN");
-    if (spec == nullptr || *spec == 0) spec = with_codebook ? kWith : kWithout;
-    if (spec[0] != 'b') {
-        // explicit assignment of WHOLE levels
-        int slot = 0, cur = -1;
-        for (const char *c = spec;; ++c) {
-            if (*c >= '0' && *c <= '9') cur = (cur < 0 ? 0 : cur * 10) + (*c - '0');
-            else {
-                if (cur >= 0 && slot < 8 && t.n[slot] < 8 && cur <= NSIG_BASE_LEVELS) {
-                    const int k = t.n[slot]++;
-                    t.level[slot][k] = (uint8_t)cur; t.lo[slot][k] = 0; t.hi[slot][k] = 4096;
-                }
-                cur = -1;
-                if (*c == '|') ++slot;
-                if (*c == 0) break;
-            }
+    for (int slot = 0; slot < 8; ++slot)
+        for (int k = 0; k < 4; ++k) {
+            const uint8_t l = (with_codebook ? kWith : kWithout)[slot][k];
+            if (l != 255) t.level[slot][t.n[slot]++] = l;
         }
-        return t;
-    }
-    // Balanced assignment (McNaughton's wrap-around rule): levels in descending cost fill slot after slot up to total / 8; the level
-    // that overflows a slot is cut there -- by tile range -- and continues in the next one.  Every slot carries the same load, a
-    // level is cut at most once (its 4 MiB table then lives in two L2s), a slot holds at most two partial levels.
-    const int n_levels = NSIG_BASE_LEVELS + (with_codebook ? 1 : 0);
-    int order[NSIG_BASE_LEVELS + 1];
-    for (int i = 0; i < n_levels; ++i) order[i] = i;
-    for (int i = 0; i < n_levels; ++i)
-        for (int j = i + 1; j < n_levels; ++j)
-            if (kLevelCost[order[j]] > kLevelCost[order[i]]) { const int tmp = order[i]; order[i] = order[j]; order[j] = tmp; }
-    double total = 0.0;
-    for (int i = 0; i < n_levels; ++i) total += kLevelCost[i];
-    const double cap = total / 8.0;
-    int slot = 0;
-    double room = cap;
-    for (int i = 0; i < n_levels; ++i) {
-        const int l = order[i];
-        const double c = kLevelCost[l];
-        double done = 0.0;                       // fraction of the level already placed
-        while (done < 1.0 - 1e-9) {
-            double part = 1.0 - done;
-            if (part * c > room + 1e-9 && slot < 7) part = room / c;
-            const int lo = (int)(done * 4096.0 + 0.5), hi = (done + part >= 1.0 - 1e-9) ? 4096 : (int)((done + part) * 4096.0 + 0.5);
-            if (hi > lo && t.n[slot] < 8) {
-                const int k = t.n[slot]++;
-                t.level[slot][k] = (uint8_t)l; t.lo[slot][k] = (uint16_t)lo; t.hi[slot][k] = (uint16_t)hi;
-            }
-            room -= part * c;
-            done += part;
-            if (room <= 1e-6 && slot < 7) { ++slot; room = cap; }
-        }
-    }
     return t;
 }
 
@@ -1279,18 +1169,11 @@ NSIG_EXPORT int hg_warm_tables(const float *const *base_tables_host, const float
 
 NSIG_EXPORT size_t hg_planes_bytes(uint32_t M) { return (size_t)(NSIG_BASE_LEVELS + 1) * ceil_div(M, 32u) * 32u * sizeof(float2); }
 
-// Which plane sets were last written in the mixed layout (hg_encode_planes_mixed), by address: the entry points that read or complete a plane set
-// (field_fwd*, hg_encode_codebook_plane) look their `planes` argument up here; hg_encode_planes (fp32) takes an address out again.
-static std::mutex g_mixed_mutex;
-static std::unordered_set<const void *> g_mixed_sets;
-static void note_layout(const void *planes, bool mixed) {
-    std::lock_guard<std::mutex> lock(g_mixed_mutex);
-    if (mixed) g_mixed_sets.insert(planes);
-    else g_mixed_sets.erase(planes);
-}
-static bool is_mixed(const void *planes) {
-    std::lock_guard<std::mutex> lock(g_mixed_mutex);
-    return g_mixed_sets.count(planes) != 0;
+// A plane set is in one of two layouts, NSIG_PLANES_F32 ([17][stride] float2) or NSIG_PLANES_MIXED (hg_encode_planes_mixed); the OWNER of the buffer says which when
+// it hands the set to an entry point that reads or completes it (field_fwd / field_fwd_rows / hg_encode_codebook_plane: `planes_layout`).
+static int check_layout(int layout, const char *who) {
+    NSIG_REQUIRE(layout == NSIG_PLANES_F32 || layout == NSIG_PLANES_MIXED, "%s: planes_layout must be NSIG_PLANES_F32 (0) or NSIG_PLANES_MIXED (1)", who);
+    return NSIG_OK;
 }
 
 static int encode_planes_impl(const float *xyzs, uint32_t M, float bound, const float *const *base_tables_host, const float *S, void *planes,
@@ -1303,18 +1186,16 @@ static int encode_planes_impl(const float *xyzs, uint32_t M, float bound, const 
     if (int e = fill_base_tables(base_tables_host, base, "hg_encode_planes")) return e;
     const uint32_t stride = ceil_div(M, 32u) * 32u;
     const SlotTable tab = default_slots(S != nullptr);
-    int covered[NSIG_BASE_LEVELS + 1] = {};     // 4096ths of the tile range assigned, per level
+    int covered[NSIG_BASE_LEVELS + 1] = {};     // slots that encode the level: exactly one
     for (int s = 0; s < 8; ++s)
-        for (int i = 0; i < tab.n[s]; ++i) covered[tab.level[s][i]] += (int)tab.hi[s][i] - (int)tab.lo[s][i];
+        for (int i = 0; i < tab.n[s]; ++i) covered[tab.level[s][i]] += 1;
     for (int l = 0; l < NSIG_BASE_LEVELS + (S != nullptr ? 1 : 0); ++l)
-        NSIG_REQUIRE(covered[l] == 4096 || ((tab.skip_mask >> l) & 1u), "hg_encode_planes: slot table covers %d/4096 of level %d", covered[l], l);
+        NSIG_REQUIRE(covered[l] == 1, "hg_encode_planes: level %d is assigned to %d slots", l, covered[l]);
     NSIG_REQUIRE(S != nullptr || covered[NSIG_BASE_LEVELS] == 0, "hg_encode_planes: slot table names the codebook level but S is NULL");
     const uint32_t tiles = ceil_div(stride, 256u);
     // tiles per XCD slot handled by distinct workgroups before they start looping: with one tile per workgroup (cap >= tiles) the block
     // render's launch takes 244-247 us against 258-261 us with 1024 looping workgroups per slot (same-box sweep, profiles/r01_k_encoder_grid_sweep.txt)
-    static const uint32_t cap = getenv("NERFSIG_ENC_PER_SLOT") ? (uint32_t)atoi(getenv("NERFSIG_ENC_PER_SLOT")) : 8192u;
-    const uint32_t per_slot = tiles < cap ? tiles : cap;
-    note_layout(planes, mixed);
+    const uint32_t per_slot = tiles < 8192u ? tiles : 8192u;
     k_encode_planes<<<per_slot * 8, 256, 0, as_stream(stream)>>>(xyzs, M, bound, base, make_level_geom(), S, reinterpret_cast<float2 *>(planes), stride, tab, rows_dev, mixed);
     return check_launch("hg_encode_planes");
 }
@@ -1336,15 +1217,16 @@ NSIG_EXPORT int hg_encode_planes_rows(const float *xyzs, uint32_t M_capacity, co
     return encode_planes_impl(xyzs, M_capacity, bound, base_tables_host, S, planes, rows_dev, stream);
 }
 
-NSIG_EXPORT int hg_encode_codebook_plane(const float *xyzs, uint32_t M, float bound, const float *S, void *planes, void *plan_to_reset,
+NSIG_EXPORT int hg_encode_codebook_plane(const float *xyzs, uint32_t M, float bound, const float *S, void *planes, int planes_layout, void *plan_to_reset,
                                          nsig_stream_t stream) {
     if (M == 0) return NSIG_OK;
+    if (int e = check_layout(planes_layout, "hg_encode_codebook_plane")) return e;
     NSIG_REQUIRE(xyzs && S && planes, "hg_encode_codebook_plane: null pointer");
     NSIG_REQUIRE(bound > 0.0f, "hg_encode_codebook_plane: bound must be positive");
     NSIG_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 7) == 0, "hg_encode_codebook_plane: planes must be 8-byte aligned");
     NSIG_REQUIRE(plan_to_reset == nullptr || (reinterpret_cast<uintptr_t>(plan_to_reset) & 15) == 0, "hg_encode_codebook_plane: plan must be 16-byte aligned");
     const uint32_t stride = ceil_div(M, 32u) * 32u;
-    float2 *plane = is_mixed(planes) ? mixed_f32_plane(planes, stride, NSIG_BASE_LEVELS) : reinterpret_cast<float2 *>(planes) + (size_t)NSIG_BASE_LEVELS * stride;
+    float2 *plane = planes_layout == NSIG_PLANES_MIXED ? mixed_f32_plane(planes, stride, NSIG_BASE_LEVELS) : reinterpret_cast<float2 *>(planes) + (size_t)NSIG_BASE_LEVELS * stride;
     k_encode_codebook_plane<<<ceil_div(stride, 256u), 256, 0, as_stream(stream)>>>(xyzs, M, bound, make_level_geom().cell[NSIG_BASE_LEVELS], S, plane, stride,
                                                                                   reinterpret_cast<BinHeader *>(plan_to_reset));
     return check_launch("hg_encode_codebook_plane");
@@ -1352,7 +1234,7 @@ NSIG_EXPORT int hg_encode_codebook_plane(const float *xyzs, uint32_t M, float bo
 
 static int field_fwd_impl(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *const *base_tables_host,
                           const float *S, const void *packed, float *sigmas, float *rgbs, float *geo_feat, uint32_t *masks,
-                          const void *planes, const uint32_t *rows_dev, nsig_stream_t stream) {
+                          const void *planes, int planes_layout, const uint32_t *rows_dev, nsig_stream_t stream) {
     if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(xyzs && packed && sigmas, "field_fwd: null pointer");
     NSIG_REQUIRE(rgbs == nullptr || dirs != nullptr, "field_fwd: dirs is required when rgbs is requested");
@@ -1364,57 +1246,37 @@ static int field_fwd_impl(const float *xyzs, const float *dirs, uint32_t M, floa
     hipStream_t st = as_stream(stream);
     const bool f16 = mlp_precision() == 1;
     if (planes == nullptr) {  // fused: gather inside the MLP kernel (small batches)
-        if (f16) k_field_fwd<F16, 0><<<field_grid(M, true), 256, F16::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, nullptr, 0, pk, sigmas, rgbs, geo_feat, masks, ActTrace{}, nullptr, rows_dev);
-        else k_field_fwd<Bf16x3, 0><<<field_grid(M, true), 256, Bf16x3::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, nullptr, 0, pk, sigmas, rgbs, geo_feat, masks, ActTrace{}, nullptr, rows_dev);
+        if (f16) k_field_fwd<F16, 0><<<field_grid(M, true), 256, F16::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, nullptr, 0, pk, sigmas, rgbs, geo_feat, masks, ActTrace{}, rows_dev);
+        else k_field_fwd<Bf16x3, 0><<<field_grid(M, true), 256, Bf16x3::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, nullptr, 0, pk, sigmas, rgbs, geo_feat, masks, ActTrace{}, rows_dev);
         return check_launch("field_fwd");
     }
     NSIG_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 7) == 0, "field_fwd: planes must be 8-byte aligned");
     const uint32_t stride = ceil_div(M, 32u) * 32u;
     const float2 *pl = reinterpret_cast<const float2 *>(planes);
-    const bool mixed = is_mixed(planes);
+    if (int e = check_layout(planes_layout, "field_fwd")) return e;
+    const bool mixed = planes_layout == NSIG_PLANES_MIXED;
     NSIG_REQUIRE(!mixed || f16, "field_fwd: this plane set was written in the mixed (fp16) layout; the split-bf16 MLP needs hg_encode_planes");
     if (f16 && fwd_pipelined() && dirs != nullptr && rgbs != nullptr && geo_feat == nullptr) {    // the training render's launch (masks) and staged no-grad renders
         if (mixed) k_field_fwd_train<F16, true><<<field_grid(M, true, 2), 256, F16::kFwdLds, st>>>(dirs, M, S != nullptr, pl, stride, pk, sigmas, rgbs, masks, rows_dev);
         else k_field_fwd_train<F16, false><<<field_grid(M, true, 2), 256, F16::kFwdLds, st>>>(dirs, M, S != nullptr, pl, stride, pk, sigmas, rgbs, masks, rows_dev);
         return check_launch("field_fwd");
     }
-    if (f16) k_field_fwd<F16, 1><<<field_grid(M, true), 256, F16::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, geo_feat, masks, ActTrace{}, nullptr, rows_dev, mixed);
-    else k_field_fwd<Bf16x3, 1><<<field_grid(M, true), 256, Bf16x3::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, geo_feat, masks, ActTrace{}, nullptr, rows_dev);
+    if (f16) k_field_fwd<F16, 1><<<field_grid(M, true), 256, F16::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, geo_feat, masks, ActTrace{}, rows_dev, mixed);
+    else k_field_fwd<Bf16x3, 1><<<field_grid(M, true), 256, Bf16x3::kFwdLds, st>>>(xyzs, dirs, M, bound, base, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, geo_feat, masks, ActTrace{}, rows_dev);
     return check_launch("field_fwd");
 }
 
 NSIG_EXPORT int field_fwd(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *const *base_tables_host,
                           const float *S, const void *packed, float *sigmas, float *rgbs, float *geo_feat, uint32_t *masks,
-                          const void *planes, nsig_stream_t stream) {
-    return field_fwd_impl(xyzs, dirs, M, bound, base_tables_host, S, packed, sigmas, rgbs, geo_feat, masks, planes, nullptr, stream);
+                          const void *planes, int planes_layout, nsig_stream_t stream) {
+    return field_fwd_impl(xyzs, dirs, M, bound, base_tables_host, S, packed, sigmas, rgbs, geo_feat, masks, planes, planes_layout, nullptr, stream);
 }
 
 NSIG_EXPORT int field_fwd_rows(const float *xyzs, const float *dirs, uint32_t M_capacity, const uint32_t *rows_dev, float bound,
                                const float *const *base_tables_host, const float *S, const void *packed, float *sigmas, float *rgbs, const void *planes,
-                               nsig_stream_t stream) {
+                               int planes_layout, nsig_stream_t stream) {
     NSIG_REQUIRE(rows_dev != nullptr, "field_fwd_rows: null row count");
-    return field_fwd_impl(xyzs, dirs, M_capacity, bound, base_tables_host, S, packed, sigmas, rgbs, nullptr, nullptr, planes, rows_dev, stream);
-}
-
-NSIG_EXPORT int field_fwd_kept(const float *xyzs, const float *dirs, uint32_t M, float bound, const float *S, const void *packed, float *sigmas,
-                               float *rgbs, uint32_t *masks, const void *planes, void *plan_to_reset, nsig_stream_t stream) {
-    if (M == 0) return NSIG_OK;
-    NSIG_REQUIRE(xyzs && dirs && packed && sigmas && rgbs && planes, "field_fwd_kept: null pointer");
-    NSIG_REQUIRE(bound > 0.0f, "field_fwd_kept: bound must be positive");
-    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(planes) & 7) == 0, "field_fwd_kept: packed must be 16-byte, planes 8-byte aligned");
-    NSIG_REQUIRE(plan_to_reset == nullptr || (reinterpret_cast<uintptr_t>(plan_to_reset) & 15) == 0, "field_fwd_kept: plan must be 16-byte aligned");
-    const char *pk = reinterpret_cast<const char *>(packed);
-    hipStream_t st = as_stream(stream);
-    const uint32_t stride = ceil_div(M, 32u) * 32u;
-    const float2 *pl = reinterpret_cast<const float2 *>(planes);
-    BinHeader *hd = reinterpret_cast<BinHeader *>(plan_to_reset);
-    const bool mixed = is_mixed(planes);
-    NSIG_REQUIRE(!mixed || mlp_precision() == 1, "field_fwd_kept: this plane set was written in the mixed (fp16) layout; the split-bf16 MLP needs hg_encode_planes");
-    if (mlp_precision() == 1)
-        k_field_fwd<F16, 2><<<field_grid(M, true), 256, F16::kFwdLds, st>>>(xyzs, dirs, M, bound, TablePtrs{}, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, nullptr, masks, ActTrace{}, hd, nullptr, mixed);
-    else
-        k_field_fwd<Bf16x3, 2><<<field_grid(M, true), 256, Bf16x3::kFwdLds, st>>>(xyzs, dirs, M, bound, TablePtrs{}, make_level_geom(), S, pl, stride, pk, sigmas, rgbs, nullptr, masks, ActTrace{}, hd);
-    return check_launch("field_fwd_kept");
+    return field_fwd_impl(xyzs, dirs, M_capacity, bound, base_tables_host, S, packed, sigmas, rgbs, nullptr, nullptr, planes, planes_layout, rows_dev, stream);
 }
 
 NSIG_EXPORT int field_color_fwd(const float *dirs, const float *geo_feat, uint32_t M, const void *packed, float *rgbs, nsig_stream_t stream) {
@@ -1470,7 +1332,6 @@ static int fwd_trace_impl(const float *xyzs, const float *dirs, uint32_t M, cons
     if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(xyzs && dirs && packed && planes && sigmas && rgbs && masks && act_hs && act_cin && act_h1 && act_h2, "field_fwd_trace: null pointer");
     NSIG_REQUIRE(bound > 0.0f, "field_fwd_trace: bound must be positive");
-    NSIG_REQUIRE(!is_mixed(planes), "field_fwd_trace: this plane set was written in the mixed (fp16) layout; stage 1 trains through fp32 planes (hg_encode_planes)");
     TablePtrs base{};
     if (int e = fill_base_tables(base_tables_host, base, "field_fwd_trace")) return e;
     const uint32_t stride = ceil_div(M, 32u) * 32u;
@@ -1478,7 +1339,7 @@ static int fwd_trace_impl(const float *xyzs, const float *dirs, uint32_t M, cons
     k_field_fwd<Bf16x3, 1, true><<<field_grid(M), 256, Bf16x3::kFwdLds, as_stream(stream)>>>(xyzs, dirs, M, bound, base, make_level_geom(), nullptr,
                                                                                      reinterpret_cast<const float2 *>(planes), stride,
                                                                                      reinterpret_cast<const char *>(packed), sigmas, rgbs, nullptr, masks, tr,
-                                                                                     nullptr, rows_dev);
+                                                                                     rows_dev);
     return check_launch("field_fwd_trace");
 }
 

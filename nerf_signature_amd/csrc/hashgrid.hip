@@ -1170,15 +1170,11 @@ static int codebook_adam_sel(const char *who, const float *G, float *const *para
     hipStream_t st = as_stream(stream);
     k_adam_prepare<<<1, NSIG_MAX_MESSAGE_DIM, 0, st>>>(s, message, D, lr, beta1, beta2, scratch);
     if (int e = check_launch(who)) return e;
-    // non-temporal accesses by default (same-box A/B of the bench step, three pairs: 1.124-1.138 ms against 1.151-1.157 with plain
-    // accesses; the kernel alone takes the same 160-164 us either way, the next step's gather gains); NERFSIG_ADAM_NT=0 selects the plain form
-    static const bool use_nt = !(getenv("NERFSIG_ADAM_NT") && getenv("NERFSIG_ADAM_NT")[0] == '0');
-    if (next_message && use_nt)
+    // non-temporal accesses (same-box A/B of the bench step, three pairs: 1.124-1.138 ms against 1.151-1.157 with plain accesses; the kernel alone takes
+    // the same 160-164 us either way, the next step's gather gains)
+    if (next_message)
         k_codebook_adam_sel<true, true><<<NSIG_TABLE_ROWS / 2 / 256, 256, 0, st>>>(reinterpret_cast<const float4 *>(G), a, message, scratch, D, beta1, beta2, eps,
                                                                                  grad_scale, next_message, reinterpret_cast<float4 *>(S_next));
-    else if (next_message)
-        k_codebook_adam_sel<true, false><<<NSIG_TABLE_ROWS / 2 / 256, 256, 0, st>>>(reinterpret_cast<const float4 *>(G), a, message, scratch, D, beta1, beta2, eps,
-                                                                              grad_scale, next_message, reinterpret_cast<float4 *>(S_next));
     else
         k_codebook_adam_sel<false, false><<<NSIG_TABLE_ROWS / 2 / 256, 256, 0, st>>>(reinterpret_cast<const float4 *>(G), a, message, scratch, D, beta1, beta2, eps,
                                                                                grad_scale, nullptr, nullptr);

@@ -30,7 +30,10 @@ namespace nsig {
 // Waves stride over the K-steps; a workgroup's four waves are summed through LDS and the workgroup stores ONE slab of 4096 partial sums
 // in accumulator order; k_wgrad_reduce adds the slabs in workgroup order and writes tcnn's layout ([out][in] row-major).
 constexpr uint32_t kWgradRoles = 3, kWgradSlab = 4u * 16u * 64u;   // floats per (workgroup, role): 4 products x 16 registers x 64 lanes
-constexpr uint32_t kWgradMaxWGs = 84;      // x 3 roles = 252 workgroups of 4 waves: ONE per compute unit, one wave per SIMD, 16 KiB of LDS -- the kernel runs
+#ifndef NSIG_WGRAD_WGS
+#define NSIG_WGRAD_WGS 84
+#endif
+constexpr uint32_t kWgradMaxWGs = NSIG_WGRAD_WGS;      // x 3 roles = 252 workgroups of 4 waves: ONE per compute unit, one wave per SIMD, 16 KiB of LDS -- the kernel runs
                                            // beside the table scatter (1024-thread workgroups with 64-128 KiB of LDS), which must still fit on the same units
 
 struct WgradArgs {

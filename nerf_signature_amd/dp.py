@@ -102,6 +102,15 @@ def drain_watchdog(limit_s=5.0):
     after the synchronize; what remains is for the watchdog to notice.  Rounds 2-4 slept a fixed 0.5 s (5 polling periods).  Here the condition itself is polled:
     the flight recorder marks an entry `retired` when the watchdog drops its work, and _dump_nccl_trace(onlyActive=True) lists the others; empty list = empty
     watchdog.  Falls back to the fixed sleep where the recorder is off (TORCH_NCCL_TRACE_BUFFER_SIZE=0) or the call is missing.  Returns what it did (for the record)."""
+    global LAST_DRAIN
+    LAST_DRAIN = _drain_watchdog(limit_s)
+    return LAST_DRAIN
+
+
+LAST_DRAIN = None     # what the most recent drain_watchdog() did (bench.py prints it)
+
+
+def _drain_watchdog(limit_s):
     import time
     t0 = time.perf_counter()
     if not (dist.is_initialized() and dist.get_backend() == "nccl"):
@@ -148,6 +157,7 @@ def init_from_env(backend=None):
             backend = os.environ.get("NERFSIG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+            os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", "2000")      # the flight recorder drain_watchdog() reads (must be set before the group exists)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
@@ -179,8 +189,10 @@ def assert_distinct_devices(device_count=None):
     count = device_count if device_count is not None else (torch.cuda.device_count() if not any(os.environ.get(v, "").strip() for v in
                                                            ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")) else None)
     if count is not None and local_world > count:
-        raise RuntimeError(f"{local_world} ranks on this node but {count} visible GPU(s): LOCAL_RANK {local_rank} would share device {ordinal} with LOCAL_RANK "
-                           f"{(local_rank + count) % local_world if local_rank + count < local_world else local_rank - count} (NERFSIG_DIST_BACKEND=gloo rehearses more ranks than GPUs)")
+        partner = next((r for r in range(local_world) if r != local_rank and r % count == local_rank % count), None)      # (a rank's device is LOCAL_RANK mod count)
+        raise RuntimeError(f"{local_world} ranks on this node but {count} visible GPU(s): LOCAL_RANK {local_rank} would share device {ordinal}"
+                           + (f" with LOCAL_RANK {partner}" if partner is not None else " (other ranks of the node collide)")
+                           + " (NERFSIG_DIST_BACKEND=gloo rehearses more ranks than GPUs)")
     if dist.is_initialized() and dist.get_backend() == "gloo" and dist.get_world_size() > 1:
         mine = (socket.gethostname(), physical)
         everyone = [None] * dist.get_world_size()

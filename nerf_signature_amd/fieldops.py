@@ -119,11 +119,8 @@ def pack_weights(sigma_params, color_params, out=None):
     return packed
 
 
-PLANES_MIN_POINTS = int(os.environ.get("NERFSIG_PLANES_MIN", "16384"))  # below this the fused kernel wins (one launch, no feature round trip)
-# FixedPoints: field_fwd_kept (codebook level gathered inside the MLP kernel) instead of hg_encode_codebook_plane + field_fwd.  Bit-identical;
-# measured slower (0.790-0.791 against 0.779-0.784 ms per step, profiles/r02_fixed_blocks_ab.txt): the gather lengthens the latency-bound
-# MLP kernel by more than the 31 us launch it removes.  Off by default.
-KEPT_ONE_LAUNCH = os.environ.get("NERFSIG_KEPT_ONE_LAUNCH", "0") == "1"
+PLANES_MIN_POINTS = 16384      # below this the fused kernel wins (one launch, no feature round trip)
+PLANES_F32, PLANES_MIXED = 0, 1      # include/nerfsig.h NSIG_PLANES_*: the layout a plane set was written in; its owner passes it to whatever reads the set
 
 
 def mixed_planes():
@@ -133,13 +130,16 @@ def mixed_planes():
 
 
 def encode_planes(xyzs, M, bound, base_ptrs, S, planes, rows_dev=None):
-    """The 16 base levels (+ the codebook level through S) of M points into a plane set, in the layout the MLP that follows will read (mixed_planes)."""
+    """The 16 base levels (+ the codebook level through S) of M points into a plane set, in the layout the MLP that follows will read (mixed_planes).
+    Returns that layout (PLANES_F32 | PLANES_MIXED): the caller hands it to the launches that read the set."""
     if mixed_planes():
         nv.call("hg_encode_planes_mixed", nv.ptr(xyzs), M, nv.ptr(rows_dev), float(bound), base_ptrs, nv.ptr(S), nv.ptr(planes), nv.stream())
-    elif rows_dev is not None:
+        return PLANES_MIXED
+    if rows_dev is not None:
         nv.call("hg_encode_planes_rows", nv.ptr(xyzs), M, nv.ptr(rows_dev), float(bound), base_ptrs, nv.ptr(S), nv.ptr(planes), nv.stream())
     else:
         nv.call("hg_encode_planes", nv.ptr(xyzs), M, float(bound), base_ptrs, nv.ptr(S), nv.ptr(planes), nv.stream())
+    return PLANES_F32
 
 
 def field_forward(xyzs, dirs, bound, base_tables, S, packed, want_rgb=True, want_geo=False, want_masks=False, planes=None, fixed=None):
@@ -156,22 +156,18 @@ def field_forward(xyzs, dirs, bound, base_tables, S, packed, want_rgb=True, want
         dirs = dirs.contiguous().float()
     use_planes = (M >= PLANES_MIN_POINTS) if planes is None else bool(planes)
     base_ptrs = nv.ptr_array([_check_table(t.detach(), "base table") for t in base_tables])
-    ws = None
+    ws, layout = None, PLANES_F32
     if fixed is not None:
         fixed.check(xyzs, bound, base_tables)
-        ws = fixed.planes
+        ws, layout = fixed.planes, fixed.layout
         reset = nv.ptr(fixed.plan.buf) if want_masks else None
-        if want_rgb and not want_geo and KEPT_ONE_LAUNCH:     # the codebook level gathered inside the MLP kernel
-            nv.call("field_fwd_kept", nv.ptr(xyzs), nv.ptr(dirs), M, float(bound), nv.ptr(S), nv.ptr(packed), nv.ptr(sigmas), nv.ptr(rgbs), nv.ptr(masks),
-                    nv.ptr(ws), reset, nv.stream())
-            return sigmas, rgbs, geo, masks
         if S is not None:      # (a clean render -- no message -- reads the base planes only)
-            nv.call("hg_encode_codebook_plane", nv.ptr(xyzs), M, float(bound), nv.ptr(S), nv.ptr(ws), reset, nv.stream())
+            nv.call("hg_encode_codebook_plane", nv.ptr(xyzs), M, float(bound), nv.ptr(S), nv.ptr(ws), layout, reset, nv.stream())
     elif use_planes:
         ws = torch.empty(int(nv.fn("hg_planes_bytes")(M)), dtype=torch.uint8, device=dev)
-        encode_planes(xyzs, M, bound, base_ptrs, S, ws)
+        layout = encode_planes(xyzs, M, bound, base_ptrs, S, ws)
     nv.call("field_fwd", nv.ptr(xyzs), nv.ptr(dirs) if want_rgb else None, M, float(bound), base_ptrs, nv.ptr(S), nv.ptr(packed),
-            nv.ptr(sigmas), nv.ptr(rgbs), nv.ptr(geo), nv.ptr(masks), nv.ptr(ws), nv.stream())
+            nv.ptr(sigmas), nv.ptr(rgbs), nv.ptr(geo), nv.ptr(masks), nv.ptr(ws), layout, nv.stream())
     return sigmas, rgbs, geo, masks
 
 
@@ -257,13 +253,13 @@ class ScatterPlan:
         self.stream, self.ready, self.launched = _PLAN_STREAM, None, False
         self.src_ready = None
         # A render that itself runs on the plan stream (the content render of the overlapped training step) launches its plan IN LINE, between its
-        # march and its encoder.  Round 3 tried deferring it like the block render's (NERFSIG_PLAN_INLINE=0): beside the block render's encoder
+        # march and its encoder.  Round 3 tried deferring it like the block render's: beside the block render's encoder
         # the plan's 1024-thread workgroups starve for wave slots (k_plan_count 231 us instead of 8) and hold the content render back until
         # that encoder has finished -- which turns out to be the better schedule: the content render's encoder then runs beside the block
         # render's MLP (different bottlenecks) instead of beside its encoder (the same texture-address path: block encoder 285 -> 312 us, and
         # the content MLP's 150-VGPR waves find no register space, 180 us instead of 15).  Deferred: 1.056-1.063 ms per step, in line:
         # 1.046-1.057 (profiles/r03_content_plan_deferred_ab.txt).
-        if self.stream is not None and self.stream == torch.cuda.current_stream() and os.environ.get("NERFSIG_PLAN_INLINE", "1") != "0":
+        if self.stream is not None and self.stream == torch.cuda.current_stream():
             self.stream = None
         if self.stream is None:
             self.launch()
@@ -347,7 +343,7 @@ class FixedPoints:
         if xyzs.data_ptr() != self.xyzs_ptr or xyzs.shape[0] != self.M:
             raise ValueError("FixedPoints.refresh: these are not the points the cache was built for")
         base_ptrs = nv.ptr_array([_check_table(t.detach(), "base table") for t in base_tables])
-        encode_planes(xyzs, self.M, self.bound, base_ptrs, None, self.planes)
+        self.layout = encode_planes(xyzs, self.M, self.bound, base_ptrs, None, self.planes)
         nv.call("hg_scatter_plan", nv.ptr(xyzs), self.M, self.bound, nv.ptr(self.plan.buf), nv.stream())
         self.key = self._tables_key(base_tables)
         self.refreshes += 1
@@ -428,8 +424,9 @@ class SharedGradient(GradSink):
         self.carrier = None
         self.live = None          # the selected tables the pending G belongs to
         # the optimiser hook that serves this sink also performs the rest of the (plain Adam) step -- the decoder's dense gradients -- in one launch
-        # (optim._dense_takeover); NERFSIG_DROPIN_DENSE_ADAM=0 leaves them to the optimiser's own multi-tensor loop
-        self.dense_takeover = os.environ.get("NERFSIG_DROPIN_DENSE_ADAM", "1") != "0"
+        # (optim._dense_takeover); NERFSIG_DROPIN_OFF=dense_adam leaves them to the optimiser's own multi-tensor loop
+        from .switches import dropin_off
+        self.dense_takeover = not dropin_off("dense_adam")
 
     def pending(self):
         return self.carrier is not None and self.carrier.grad is self.G

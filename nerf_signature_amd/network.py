@@ -202,10 +202,9 @@ class NeRFNetwork(NeRFRenderer):
         bound = float(self.bound)
 
         def run(xyzs, dirs, rows_dev, sigmas, rgbs):
-            if use_planes:
-                fo.encode_planes(xyzs, capacity, bound, base_ptrs, S, ws, rows_dev)
+            layout = fo.encode_planes(xyzs, capacity, bound, base_ptrs, S, ws, rows_dev) if use_planes else fo.PLANES_F32
             nv.call("field_fwd_rows", nv.ptr(xyzs), nv.ptr(dirs), capacity, nv.ptr(rows_dev), bound, base_ptrs, nv.ptr(S), nv.ptr(packed), nv.ptr(sigmas),
-                    nv.ptr(rgbs), nv.ptr(ws), nv.stream())
+                    nv.ptr(rgbs), nv.ptr(ws), layout, nv.stream())
             run.keep = (base, S, packed, ws)      # (the launches above hold raw addresses)
 
         return run

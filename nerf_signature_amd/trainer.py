@@ -121,14 +121,10 @@ def srgb_to_linear(x):
 
 
 def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, loss_w=loss_w_bce, side_stream=None, presum_first=False,
-               presum_adopt=False, color_space="srgb", blocks_first=False, content_backward_now=None, distortion=None, defer_loss_values=False, block_graph=None):
+               presum_adopt=False, color_space="srgb", blocks_first=False, content_backward_now=None, distortion=None, block_graph=None):
     """data = {'watermark': {'rays_o_block', 'rays_d_block'}, 'content': {'rays_o', 'rays_d', 'images'}}.
     Returns (pred_rgb, gt_rgb, content_pred_rgb, lossi, lossw, loss) like the reference.
 
-    defer_loss_values: where both backward passes already have their seeds when the losses are reached (the content render's early seed,
-    content_backward_now; the decoder's from its own head kernel), the kernel that computes the three loss VALUES is not launched here -- between the
-    decoder's forward and backward, on the step's critical path -- but by `train_step.finish_losses()`, which the caller invokes once at the end of
-    the step (GraphedWatermarkLoop does); the returned tensors are filled then.
     distortion: the reference's `--distortion` (utils_wtmk_disen.py:551-577,594): a name (none | noise | rotation | scaling | blurring |
     brightness; this call then draws the step's random parameters) or a distortion.DistortionLayer whose owner has drawn them (the loops).
     block_graph: a blockgraph.BlockDecodeGraph (eager callers with constant block rays: the drop-in Trainer.train_step) -- the block render and the
@@ -163,7 +159,7 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
     eager_caller = block_graph is not None and main is None and shard is None and not presum_adopt
     # the content render's march and its one host read, in front of the block render: the read then waits for the march alone (NeRFRenderer.premarch)
     premarch = (eager_caller and content["rays_o"].is_cuda and model.training and torch.is_grad_enabled() and hasattr(model, "premarch") and getattr(model, "cuda_ray", False)
-                and getattr(model, "point_capacity", None) is None and not torch.cuda.is_current_stream_capturing() and os.environ.get("NERFSIG_DROPIN_PREMARCH", "1") != "0")
+                and getattr(model, "point_capacity", None) is None and not torch.cuda.is_current_stream_capturing())
     if eager_caller and (distortion is None or isinstance(distortion, DistortionLayer)):
         whole = None
         if hasattr(block_graph, "usable_content") and content["images"].shape[-1] == 3:
@@ -182,7 +178,6 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
         model.premarch(content["rays_o"], content["rays_d"], kw.get("dt_gamma", 0), kw.get("max_steps", 1024))
     outputs = model.render(block_o, block_d, message, **kw) if graphed is None else None
     content_done = early_seed = None
-    deferred = False
     new_segment = False       # (a collective in front of the decoder ended the running capture segment: the side stream has to be forked again)
     if main is not None and blocks_first:
         # (the fork above is the content render's only parent; captured BEHIND the block render it is enqueued behind it: GraphedWatermarkLoop)
@@ -252,9 +247,7 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
         with torch.cuda.stream(side_stream):
             torch.autograd.backward([content_pred_rgb], [early_seed])
         content_pred_rgb = content_pred_rgb.detach()
-        if fused_seed is not None and defer_loss_values:
-            deferred = True           # nothing on the main stream needs the content render any more, and the loss VALUES can wait for the end of the step
-        if not new_segment and (not deferred or os.environ.get("NERFSIG_DEFER_KEEP_EDGE", "1") == "1"):
+        if not new_segment:
             # (new_segment: both streams met in front of the collective; the event belongs to the finished segment)
             main.wait_event(content_done)
     elif main is not None and not new_segment:
@@ -266,22 +259,8 @@ def train_step(model, data, message, render_kwargs, lambda_w=1.0, lambda_i=1.0, 
     keys = (keys_dev if keys_dev is not None and keys_dev.device == decoded.device else message.to(decoded.device)).unsqueeze(-1)
     if loss_w is loss_w_bce and decoded.is_cuda and all(t.dtype == torch.float32 for t in (content_pred_rgb, gt_rgb, decoded, keys)) \
             and gt_rgb.shape == content_pred_rgb.shape and keys.shape == decoded.shape:
-        if deferred:      # values only (both backward passes have their seeds): launched by finish_losses() at the end of the step
-            losses = torch.empty(3, dtype=torch.float32, device=decoded.device)
-            lossi, lossw, loss = losses[0], losses[1], losses[2]
-            c, g, dcd, k = content_pred_rgb.contiguous(), gt_rgb.contiguous(), decoded.detach().contiguous(), keys.contiguous()
-            scratch = (torch.empty_like(c), torch.empty_like(dcd))
-
-            def finish(c=c, g=g, dcd=dcd, k=k, losses=losses, scratch=scratch, lw=float(lambda_w), li=float(lambda_i)):
-                nv.call("wm_loss_fwd", nv.ptr(c), nv.ptr(g), c.numel(), nv.ptr(dcd), nv.ptr(k), dcd.numel(), 10.0, lw, li, nv.ptr(losses), nv.ptr(scratch[0]),
-                        nv.ptr(scratch[1]), nv.stream())
-                train_step.finish_losses = None
-
-            train_step.finish_losses = finish
-            _WatermarkLoss.last = (loss, content_pred_rgb, decoded, None, None, float(lambda_w), float(lambda_i), fused_seed)
-        else:
-            lossi, lossw, loss = _WatermarkLoss.apply(content_pred_rgb, gt_rgb, decoded, keys, float(lambda_w), float(lambda_i), 10.0)
-            _WatermarkLoss.last = (loss, content_pred_rgb, decoded, *_WatermarkLoss.stash, float(lambda_w), float(lambda_i), fused_seed)
+        lossi, lossw, loss = _WatermarkLoss.apply(content_pred_rgb, gt_rgb, decoded, keys, float(lambda_w), float(lambda_i), 10.0)
+        _WatermarkLoss.last = (loss, content_pred_rgb, decoded, *_WatermarkLoss.stash, float(lambda_w), float(lambda_i), fused_seed)
     else:
         lossi = ((content_pred_rgb - gt_rgb) ** 2).mean()
         lossw = loss_w(decoded, keys)
@@ -295,7 +274,15 @@ def reference_trainer_train_step(self, data, message):
     (pred_rgb, gt_rgb, content_pred_rgb, lossi, lossw, loss), computed by this repo's train_step -- clamp, layout change, normalisation and the distortion
     layer inside the decoder's first launch, the three losses in one kernel -- instead of ~20 stock operators around model.render / model.msg_decoder.
     Read from `self` exactly what the reference's method reads: model, opt (splatted into render(), color_space), lambda_w, lambda_i, distortion,
-    and opt.loss_w.  The drop-in directory's nerf/utils_wtmk_disen.py binds it (NERFSIG_DROPIN_TRAIN_STEP=0 keeps the reference's own method)."""
+    and opt.loss_w.  The drop-in directory's nerf/utils_wtmk_disen.py binds it (NERFSIG_DROPIN_OFF=train_step keeps the reference's own method)."""
+    crit = getattr(self, "criterion", None)
+    if crit is not None and not (isinstance(crit, torch.nn.MSELoss) and crit.reduction == "none"):
+        # the fused step computes the reference's default content loss (criterion = MSELoss(reduction='none'), main_nerf_wtmk.py:108, applied at
+        # utils_wtmk_disen.py:638); a Trainer built with another criterion trains through the reference's own method (the class this one shadows)
+        for klass in type(self).__mro__[1:]:
+            if "train_step" in vars(klass):
+                return vars(klass)["train_step"](self, data, message)
+        raise NotImplementedError(f"reference_trainer_train_step implements criterion = MSELoss(reduction='none'); got {crit!r} and no reference method to fall back to")
     images = data["watermark"].get("images")
     if images is not None and images.shape[-1] != 3 and not self.model.bg_radius > 0:
         # the reference assigns bg_color only for 3-channel block images (:585-586) and reads it unconditionally (:590)
@@ -367,7 +354,6 @@ def test_step(model, data, message, render_kwargs, bg_color=None, perturb=False)
 
 
 test_step.__test__ = False      # (not a pytest test, whatever its name)
-train_step.finish_losses = None
 
 
 class WatermarkLoop:
@@ -485,8 +471,8 @@ class GraphedWatermarkLoop:
     points than that -- such a step dropped the rays that did not fit, like the reference's bounded mode."""
 
     def __init__(self, model, optimizer, render_kwargs, data, lambda_w=1.0, lambda_i=1.0, lr_lambda=None, headroom=0.0, native_dense_adam=True,
-                 overlap_content=True, march_ahead=None, presum_in_adam=True, stage_in_graph=True, content_headroom=None, content_ahead=None,
-                 content_sampler=None, fixed_blocks=None, encode_ahead=None, distortion="none", distortion_seed=0):
+                 overlap_content=True, march_ahead=None, presum_in_adam=True, stage_in_graph=True, content_headroom=None,
+                 content_sampler=None, fixed_blocks=False, distortion="none", distortion_seed=0):
         """distortion: all five of the reference's kinds run inside the captured step -- noise | brightness | blurring as part of the decoder's first launch,
         rotation | scaling as one resampling launch in front of it.  Their random parameters are re-drawn on the device every replay (wm_distort_draw, keyed
         by distortion_seed and the replay count), except the scaling factor: it sets the decoder's input WIDTH, so prepare() captures the step once per
@@ -505,70 +491,34 @@ class GraphedWatermarkLoop:
         at the head of its own step on the side stream: next to the optimiser as well, the two marches took longer than the
         optimiser and the pre-sum lost its cover."""
         self.distortion = None if distortion in (None, "none") else (distortion if isinstance(distortion, DistortionLayer) else DistortionLayer(distortion, distortion_seed))
-        if march_ahead is None and os.environ.get("NERFSIG_MARCH_AHEAD") in ("0", "1"):
-            march_ahead = os.environ["NERFSIG_MARCH_AHEAD"] == "1"
         self.march_ahead = overlap_content if march_ahead is None else bool(march_ahead)
-        # fixed_blocks (NERFSIG_FIXED_BLOCKS=1; off by default): the watermark-block rays are one pair of tensors per dataset
+        # fixed_blocks (off by default): the watermark-block rays are one pair of tensors per dataset
         # (nerf/provider_wtmk.py:442-494) and everything their field pass reads except the codebook is frozen in this stage, so the
         # loop marches them ONCE, keeps the base-level feature planes and the scatter plan (NeRFNetwork.fix_rays / fieldops.FixedPoints)
         # and a step only gathers the codebook level for them -- same kernels' results, bit-identical training
         # (tests/test_gpu_fixed.py).  New block rays (`data` / `next_data` with a "watermark" part), a loaded
         # checkpoint (invalidate) or a re-sized capture refresh the kept buffers in place before the next replay.
-        if fixed_blocks is None:
-            fixed_blocks = os.environ.get("NERFSIG_FIXED_BLOCKS", "0") == "1"
         self.fixed_blocks = bool(fixed_blocks)
         self._refix_pending = False
         self._kept_key = None
-        # encode_ahead (with march_ahead): the NEXT step's block samples are not only marched beside this step's optimiser but also pushed
-        # through the 16 base levels of the encoder and the scatter's binning passes there -- none of which reads anything a step updates
-        # (frozen base tables, positions) -- so the hash gather, the step's longest kernel and bound by L2->L1 line fills, runs in the
-        # shadow of the optimiser's HBM stream instead of at the head of the next step's critical path; that step then gathers the one
-        # level a step does change, the codebook, for these points (hg_encode_codebook_plane).  Every step still runs every kernel once:
-        # this is scheduling, not reuse across steps (that is fixed_blocks).  NERFSIG_ENCODE_AHEAD=0|1.
-        # OFF by default -- measured slower, 1.106-1.108 against 1.061-1.083 ms (profiles/r02_encode_ahead.txt): beside the optimiser the
-        # march chain that feeds the encoder is starved (its single-workgroup scan waits ~90 us on loads behind the optimiser's HBM
-        # stream), so the encoder starts when the optimiser ends; and the two do not overlap anyway (side by side 447 us, one after the
-        # other 463 us: tools/overlap_probe2.py).
-        if encode_ahead is None:
-            encode_ahead = os.environ.get("NERFSIG_ENCODE_AHEAD", "0") == "1"
-        self.encode_ahead = bool(encode_ahead) and self.march_ahead and not self.fixed_blocks
         # content_sampler (rays.DeviceRaySampler): the step draws its own content batch -- pose, pixels, rays, ground truth -- on the
         # device, inside the captured graph, from the replay count; `data` / `next_data` then carry no content part
         self.content_sampler = content_sampler
-        # content_ahead: the content render's samples are marched at the end of the previous replay as well.  The head of a step then
-        # holds no march at all: both encoders start right behind the opening kernel (the runtime starts the block encoder only when the
-        # whole content-march chain in front of it has finished, ~95 us of small kernels: LABNOTES.md section 8).  The content rays of the
-        # NEXT step therefore have to be in the static buffers when a replay starts: `step(..., next_data={"content": ...})`; their
-        # ground-truth pixels are held back until that step.
-        # Off by default: same-box A/B of the bench step 1.095-1.100 ms without against 1.130-1.167 ms with it
-        # (profiles/r02_content_ahead_ab.txt) -- both marches beside the optimiser outlast it, as round 1 found with the pre-sum.
-        if content_ahead is None:
-            content_ahead = os.environ.get("NERFSIG_CONTENT_AHEAD", "0") == "1"
-        self.content_ahead = self.march_ahead and bool(content_ahead)
-        if self.content_ahead and content_sampler is not None:
-            raise ValueError("content_sampler draws the batch at the head of its own step: incompatible with content_ahead")
         self.presum_in_adam = bool(presum_in_adam)
         # stage_in_graph: the captured step opens with loop_step_begin, which zero-fills G and fetches the step's message words from the
         # pinned ring itself (slot = replays so far, counted on the device) -- no host-to-device copy command between two replays
-        self.stage_in_graph = bool(stage_in_graph) and os.environ.get("NERFSIG_STAGE_IN_GRAPH", "1") != "0"
+        self.stage_in_graph = bool(stage_in_graph)
         self._s_for = None            # host copy of the message the pre-sum buffer currently belongs to (None: unknown / stale)
         self.marched = None
         self._pending_content = None
         self.native_dense_adam = native_dense_adam
-        # NERFSIG_SIDE_PRIORITY=-1: the content chain (small latency-bound launches) on a high-priority stream
-        self.side_stream = torch.cuda.Stream(priority=int(os.environ.get("NERFSIG_SIDE_PRIORITY", "0"))) if overlap_content else None
+        self.side_stream = torch.cuda.Stream() if overlap_content else None
         self.plan_stream = self.side_stream   # scatter plans queue behind the content render
-        # The decoder's parameter-gradient kernels (~85 us, needed only by the optimiser) leave the main stream, so that the block render's backward
-        # waits for the image gradient alone.  Two schedules of the backward pass (NERFSIG_BACKWARD_SCHEDULE=tail|beside):
-        #   "tail"   they queue on the content render's stream and the content render's backward behind them (one autograd call runs its nodes
-        #            last), at the step's tail, beside the block render's MLP backward and scatter;
-        #   "beside" (default) a stream of their own, the content render's backward issued first (backward_from_loss_kernel) -- it runs beside the
-        #            decoder's backward chain -- and the block render captured first (_blocks_issued_first).
-        # Round 3, before the MLP kernels were pipelined: "beside" paid only with the blocks sharded over ranks (emulated rank of 2 / 4 / 8:
-        # 0.866 -> 0.845, 0.645 -> 0.605, 0.566 -> 0.530 ms per step; one rank: +1.5 %, the block render's 95 us MLP backward covered the tail).
-        # With k_field_bwd_train (71 us) the content render's backward at the tail became the step's end: one rank 1.055-1.058 -> 1.023-1.042 ms.
-        # profiles/r03_backward_schedule.txt.
-        self.backward_schedule = os.environ.get("NERFSIG_BACKWARD_SCHEDULE", "auto")
+        # The decoder's parameter-gradient kernels (~85 us, needed only by the optimiser) leave the main stream, so that the block render's backward waits for
+        # the image gradient alone: with a side stream they get a stream of their own, the content render's backward is issued first
+        # (backward_from_loss_kernel) -- it runs beside the decoder's backward chain -- and the block render is captured first (_blocks_issued_first).
+        # The alternative (everything at the step's tail on the content render's stream) was measured slower at every world size
+        # (profiles/r03_backward_schedule.txt) and is gone.
         self.weights_stream = self.side_stream
         self.content_backward_first = False
         if not hasattr(optimizer, "step_shared_sel"):
@@ -636,8 +586,6 @@ class GraphedWatermarkLoop:
         self.model._packed()
         if self.fixed_blocks and self.graphs is not None:
             self._fix_blocks()       # the base tables may have been overwritten: the kept feature planes, in place
-        elif self.encode_ahead and self.graphs is not None:
-            self._march_ahead()      # ... likewise the planes the last replay encoded ahead for the next one
 
     @torch.no_grad()
     def gather_codebook(self, optimizer_state=True):
@@ -695,14 +643,8 @@ class GraphedWatermarkLoop:
                              presum_first=self.marched is not None,
                              presum_adopt=self.presum_in_adam and torch.cuda.is_current_stream_capturing(),
                              blocks_first=self.side_stream is not None and self._blocks_issued_first(),
-                             content_backward_now=(self.lambda_i * dp.content_grad_scale(self.sharded)) if (self.content_backward_first and
-                                                   self.side_stream is not None and os.environ.get("NERFSIG_CONTENT_BWD_NOW", "1") == "1") else None,
-                             distortion=self.distortion,
-                             # NERFSIG_DEFER_LOSS=1: the loss-VALUE kernel (8 us, one workgroup) launched at the end of the step instead of between the decoder's forward
-                             # and backward.  Measured (round 4, same box): one rank 0.976-0.978 against 0.966-0.969 ms, one rank of eight 0.489-0.493 either way -- the
-                             # kernel's latency is already hidden; and WITHOUT the main stream's wait for the content render's forward that used to sit in front of
-                             # it (NERFSIG_DEFER_KEEP_EDGE=0) this runtime starts the whole content chain behind the decoder: 1.13 ms.  Off.
-                             defer_loss_values=os.environ.get("NERFSIG_DEFER_LOSS", "0") == "1")
+                             content_backward_now=(self.lambda_i * dp.content_grad_scale(self.sharded)) if (self.content_backward_first and self.side_stream is not None) else None,
+                             distortion=self.distortion)
         finally:
             fo.set_plan_stream(prev)
         set_weights_stream(self.weights_stream)
@@ -716,8 +658,6 @@ class GraphedWatermarkLoop:
         join_stream(torch.cuda.current_stream(), self.side_stream)
         if self.weights_stream is not self.side_stream:
             join_stream(torch.cuda.current_stream(), self.weights_stream)
-        if train_step.finish_losses is not None:      # the step's loss values (reporting only): behind everything, off the decoder's forward -> backward path
-            train_step.finish_losses()
         return out
 
     def _optimise(self, defer_collective=False):
@@ -749,19 +689,15 @@ class GraphedWatermarkLoop:
         return post
 
     def _march_ahead(self):
-        kw, wm, ct = self.render_kwargs, self.data["watermark"], self.data["content"]
+        kw, wm = self.render_kwargs, self.data["watermark"]
         args = (kw.get("dt_gamma", 0), kw.get("max_steps", 1024))   # (march_ahead(..., phase="count" | "write") could split the walk from the writes: measured, slower)
         # the block render's march only: the content render's stays at the head of its step, on the side stream, where it
         # overlaps the pre-sum and the block encoder (both marches next to the optimiser took longer than the optimiser)
         block_o, block_d, _ = local_blocks(wm)       # (this rank's shard of the blocks when they are split over the ranks)
         if self.fixed_blocks:                        # marched once, outside the step (_fix_blocks)
             self.marched = self.marched[:1]
-        elif self.encode_ahead:                      # march + base-level planes + scatter plan of the next step's block samples
-            self.marched = (self.model.fix_rays(block_o, block_d, *args),)
         else:
             self.marched = (self.model.march_ahead(block_o, block_d, *args),)
-        if self.content_ahead:
-            self.marched += (self.model.march_ahead(ct["rays_o"], ct["rays_d"], *args),)
 
     @torch.no_grad()
     def _fix_blocks(self):
@@ -775,7 +711,7 @@ class GraphedWatermarkLoop:
 
     def _optimise_and_march(self):
         """The optimiser step and, beside it on the side stream, the march of the next step's samples."""
-        if not self.march_ahead or (self.fixed_blocks and not self.content_ahead):
+        if not self.march_ahead or self.fixed_blocks:
             return self._optimise()
         main = torch.cuda.current_stream()
         if self.side_stream is not None:
@@ -798,17 +734,14 @@ class GraphedWatermarkLoop:
         caches the optimiser's 836 MiB stream has flushed (282-290 us; 258-270 us behind this pass, which takes ~20 us alone).  Same-box A/B of
         the bench step: 1.026-1.031 -> 1.005-1.019 ms (profiles/r03_warm_tables.txt).  Only where the optimiser outlasts it: with the codebook
         optimiser sharded over >= 4 ranks (a 22 us pass over D/R tables) the warm-up would end the step (emulated rank of 4 / 8: +1.5 / +2 %).
-        NERFSIG_WARM_TABLES=0|1 forces it off / on."""
-        want = os.environ.get("NERFSIG_WARM_TABLES")
-        if want == "0" or (want != "1" and self.opt_shard is not None) or self.fixed_blocks or getattr(self.model, "_presum_cache", None) is None:
+        Hence off there."""
+        if self.opt_shard is not None or self.fixed_blocks or getattr(self.model, "_presum_cache", None) is None:
             return
         tables = nv.ptr_array([t.detach() for t in self.model.encoder.tables()])
         nv.call("hg_warm_tables", tables, nv.ptr(self.model._presum_cache[1]), nv.ptr(self._warm_sink), nv.stream())
 
     def point_counts(self):
         """(block, content) sample totals of the last step (one host read)."""
-        if self.marched is not None and len(self.marched) > 1:   # both renders marched ahead: each has its own counter
-            return int(self.marched[0]["counter"][0]), int(self.marched[1]["counter"][0])
         if self.marched is not None:      # the block render has its own counter, the content render the ring's latest row
             return int(self.marched[0]["counter"][0]), int(self.model.step_counter[self.capacity_rows[-1], 0])
         a, b = self.model.step_counter[self.capacity_rows, 0].tolist()
@@ -822,7 +755,7 @@ class GraphedWatermarkLoop:
         the decoder behind it -- started when all nine were done; captured first, it is the content render that waits (for the decoder's forward
         chain, beside whose backward chain it then runs): emulated rank of 2 / 4 / 8: 0.846 -> 0.828, 0.610 -> 0.605, 0.534 -> 0.527 ms; one rank
         (where the wait keeps the content render's encoder away from the block render's): 1.050-1.068 -> 1.025-1.045 ms."""
-        return self.side_stream is None or (self.content_backward_first and os.environ.get("NERFSIG_BLOCKS_FIRST", "1") == "1")
+        return self.side_stream is None or self.content_backward_first
 
     def _kept_inputs_key(self):
         """Versions of everything the kept planes / marched samples were computed from (in-place writes through torch bump them)."""
@@ -858,7 +791,7 @@ class GraphedWatermarkLoop:
                     self.data[part][k].copy_(v, non_blocking=True)
             if self.fixed_blocks and self.graphs is not None and "watermark" in data:
                 self._fix_blocks()              # new block rays: marched and their kept planes refreshed before the replay
-            if self.march_ahead and self.graphs is not None and (("watermark" in data and not self.fixed_blocks) or (self.content_ahead and "content" in data)):
+            if self.march_ahead and self.graphs is not None and "watermark" in data and not self.fixed_blocks:
                 self._march_ahead()             # this step's rays arrived only now: march them before the replay
         if next_data is not None:
             if not self.march_ahead:
@@ -867,13 +800,7 @@ class GraphedWatermarkLoop:
                 self.data["watermark"][k].copy_(v, non_blocking=True)
                 self._refix_pending = self.fixed_blocks             # (no closing march with fixed blocks: re-fixed ahead of the next replay)
             content = next_data.get("content")
-            if content is not None and self.content_ahead:
-                # the rays go in now (this replay renders from samples marched earlier and marches these at its end); the ground-truth
-                # pixels wait for their own step
-                for k in ("rays_o", "rays_d"):
-                    self.data["content"][k].copy_(content[k], non_blocking=True)
-                self._pending_content = {"images": content["images"]}
-            elif content is not None:
+            if content is not None:
                 self._pending_content = content              # marched (and compared with its images) inside its own step
 
     @torch.no_grad()
@@ -912,7 +839,7 @@ class GraphedWatermarkLoop:
             o = self.data["watermark"]["rays_o_block"]
             self.distortion._buffers(tuple(o.shape), o.device)
             self.distortion.set_scaling(host_uniform(self.distortion.seed, self._replays, 0.75, 1.25))
-        beside = self.side_stream is not None and self.backward_schedule != "tail"
+        beside = self.side_stream is not None
         self.content_backward_first = beside
         self.weights_stream = self.side_stream if not beside else (getattr(self, "_own_weights_stream", None) or torch.cuda.Stream())
         self._own_weights_stream = self.weights_stream if beside else None
@@ -941,8 +868,6 @@ class GraphedWatermarkLoop:
             if not self.march_ahead:
                 raise ValueError("fixed_blocks needs march_ahead=True (the kept samples live in the march-ahead record)")
             self._fix_blocks()       # before the warm-up, so that it runs -- and loads -- the kernels the captured step will use
-        elif self.encode_ahead:
-            self._march_ahead()      # likewise: the warm-up then renders the blocks from planes encoded ahead, as the captured step will
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -979,7 +904,7 @@ class GraphedWatermarkLoop:
     def _capture(self, cap_block, cap_content):
         model = self.model
         self.optimizer.zero_grad(set_to_none=True)
-        if self.march_ahead and not (self.fixed_blocks and not self.content_ahead):
+        if self.march_ahead and not self.fixed_blocks:
             self._march_ahead()      # the first replay's samples (buffers outside the graph's pool, re-marched in place by every replay)
         # Segmented capture: one hipGraph per stretch between collectives.  A collective reached while capturing (dp.collective: the
         # all-gather of the rendered blocks, the gradient all-reduce) ends the running capture, is remembered as the eager call that
@@ -1005,15 +930,9 @@ class GraphedWatermarkLoop:
         import gc
         gc.collect()
         torch.cuda.synchronize()
-        if exchange_active():
-            # ProcessGroupNCCL's watchdog thread polls the events of the warm-up's collectives (every 100 ms) until it has seen them complete;
-            # an event query from that thread while this one captures killed one rehearsal in four (WorkNCCL::isCompleted raising inside
-            # Watchdog::runLoop).  Everything is complete by now: give the watchdog time to notice and empty its list.  Collectives issued
-            # under capture are not handed to the watchdog at all.
-            import time
-            time.sleep(float(os.environ.get("NERFSIG_WATCHDOG_DRAIN_S", "0.5")))
+        dp.drain_watchdog()       # nothing of the warm-up's collectives may be left with ProcessGroupNCCL's watchdog thread when the capture begins (dp.py)
         if getattr(self, "_capture_stream", None) is None:      # one stream for every capture of this loop (autograd's accumulation nodes remember the stream they were made on)
-            self._capture_stream = torch.cuda.Stream(priority=int(os.environ.get("NERFSIG_MAIN_PRIORITY", "0")))      # (-1: the block render / decoder chain above the content chain; measured: LABNOTES section 14)
+            self._capture_stream = torch.cuda.Stream()
         capture_stream = self._capture_stream
         capture_stream.wait_stream(torch.cuda.current_stream())
         prev = dp.set_boundary(boundary)

@@ -86,7 +86,7 @@ def test_dropin_shadows_only_the_hot_path_modules(tmp_path):
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
 def test_dropin_trainer_shadow_can_be_switched_off(tmp_path):
-    """NERFSIG_DROPIN_TRAIN_STEP=0: the shadow module re-exports the reference's Trainer itself."""
+    """NERFSIG_DROPIN_OFF=train_step: the shadow module re-exports the reference's Trainer itself."""
     script = r'''
 import sys
 from unittest.mock import MagicMock
@@ -99,7 +99,7 @@ import nerf._reference_utils_wtmk_disen as ref_u
 assert u.Trainer is ref_u.Trainer
 print("DROPIN_OK")
 '''
-    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", NERFSIG_DROPIN_TRAIN_STEP="0",
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", NERFSIG_DROPIN_OFF="train_step",
                PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "nerf_signature_amd", "dropin"), ROOT, REF]))
     out = subprocess.run([sys.executable, "-B", "-c", script], env=env, capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
     assert "DROPIN_OK" in out.stdout, out.stderr[-3000:]

@@ -380,7 +380,6 @@ def test_block_graph_with_a_distortion_layer(monkeypatch, distortion, whole_step
     import argparse
     import types
     from nerf_signature_amd import trainer
-    monkeypatch.setenv("NERFSIG_DROPIN_STEP_GRAPH", "1" if whole_step else "0")
     n_steps = 12 if whole_step else 8           # (the whole-step capture sizes its sample buffers first: four more eager steps)
     bo, bd, _, _, _ = _data(n_content=300)
     wm = {"rays_o_block": bo.cuda(), "rays_d_block": bd.cuda(), "images": torch.zeros(32, 6, 6, 3)}
@@ -393,7 +392,7 @@ def test_block_graph_with_a_distortion_layer(monkeypatch, distortion, whole_step
     opt_ns = argparse.Namespace(dt_gamma=0, max_steps=1024, color_space="srgb", loss_w="bce", distortion=distortion, workspace="w", fp16=False)
     runs = []
     for graph_on in (False, True):
-        monkeypatch.setenv("NERFSIG_DROPIN_BLOCK_GRAPH", "1" if graph_on else "0")
+        monkeypatch.setenv("NERFSIG_DROPIN_OFF", ",".join(([] if whole_step else ["step_graph"]) + ([] if graph_on else ["block_graph"])))
         torch.manual_seed(0)
         m, _, _ = _model()
         m.shared_gradient_step = m.auto_fix_rays = True
@@ -418,13 +417,13 @@ def test_block_graph_with_a_distortion_layer(monkeypatch, distortion, whole_step
 def test_block_graph_replays_the_eager_block_render_and_decoder(monkeypatch, whole_step):
     """blockgraph.BlockDecodeGraph under the reference Trainer's loop shape (zero_grad / autocast train_step / GradScaler / torch.optim.Adam, a new device-side
     message and new content rays every step): the bound Trainer.train_step with the block render + decoder replayed from two captured graphs against the same
-    loop with NERFSIG_DROPIN_BLOCK_GRAPH=0 -- same losses step by step, same parameters after 10 steps, one capture, replays from the fifth step on (two sightings
+    loop with NERFSIG_DROPIN_OFF=block_graph -- same losses step by step, same parameters after 10 steps, one capture, replays from the fifth step on (two sightings
     to keep the rays, three eager steps on the kept route), a step GradScaler skips skipped on both sides; then the guards: backward of a stale forward, a
     second backward, and new block rays (the graph steps aside, the eager route runs, a new capture follows)."""
     import argparse
     import types
     from nerf_signature_amd import trainer
-    monkeypatch.setenv("NERFSIG_DROPIN_STEP_GRAPH", "1" if whole_step else "0")      # 1: blockgraph.StepGraph captures the content render and the losses as well
+    # whole_step: blockgraph.StepGraph captures the content render and the losses as well
     n_steps = 14 if whole_step else 10          # (the whole-step capture sizes its sample buffers first: four more eager steps)
     bo, bd, _, _, _ = _data(n_content=300)
     block_o, block_d = bo.cuda(), bd.cuda()
@@ -437,7 +436,7 @@ def test_block_graph_replays_the_eager_block_render_and_decoder(monkeypatch, who
     opt_ns = argparse.Namespace(dt_gamma=0, max_steps=1024, color_space="srgb", loss_w="bce", distortion="none", workspace="w", fp16=True)
     runs = []
     for graph_on in (False, True):
-        monkeypatch.setenv("NERFSIG_DROPIN_BLOCK_GRAPH", "1" if graph_on else "0")
+        monkeypatch.setenv("NERFSIG_DROPIN_OFF", ",".join(([] if whole_step else ["step_graph"]) + ([] if graph_on else ["block_graph"])))
         torch.manual_seed(0)
         m, _, _ = _model()
         m.shared_gradient_step = m.auto_fix_rays = True
@@ -466,7 +465,7 @@ def test_block_graph_replays_the_eager_block_render_and_decoder(monkeypatch, who
     diff = sum(float((a - b).pow(2).sum()) for a, b in zip(t0, t1)) ** 0.5
     assert moved > 0 and diff / moved < 0.05 and float((d0 - d1).norm() / d0.norm()) < 0.05
     # guards
-    monkeypatch.setenv("NERFSIG_DROPIN_BLOCK_GRAPH", "1")
+    monkeypatch.setenv("NERFSIG_DROPIN_OFF", "" if whole_step else "step_graph")
     data = {"watermark": {"rays_o_block": block_o, "rays_d_block": block_d, "images": torch.zeros(32, 6, 6, 3)}, "content": batches[0]}
     opt1.zero_grad()
     first = trainer.reference_trainer_train_step(me1, data, msgs[0])

@@ -428,7 +428,7 @@ def test_mixed_plane_sets_equal_fp32_plane_sets_bit_for_bit(fo, tables, monkeypa
     """hg_encode_planes_mixed (levels 0..14 as the fp16 pairs of the fp16 MLP's first-layer operand, level 15 + codebook as float2: 76 instead of 136 bytes per
     point) against fp32 plane sets (NERFSIG_HALF_PLANES=0) through every consumer: the pipelined training launch (sigma, rgb, ReLU masks), the plain loop
     (geo features requested), the kept route (FixedPoints + hg_encode_codebook_plane), a device row count; with and without a codebook; point counts that are
-    and are not multiples of the tile.  Same bits everywhere.  And the guards: a mixed set is refused by the split-bf16 MLP and by the stage-1 trace kernel."""
+    and are not multiples of the tile.  Same bits everywhere.  And the guards: a set declared mixed is refused by the split-bf16 MLP; the layout is an argument its owner passes (no registry by address)."""
     from nerf_signature_amd import _native as nv
     base, cb, base_d, cb_d = tables
     _, sp, cp = _params(tables)
@@ -456,8 +456,9 @@ def test_mixed_plane_sets_equal_fp32_plane_sets_bit_for_bit(fo, tables, monkeypa
                 ws = torch.zeros(int(nv.fn("hg_planes_bytes")(M)), dtype=torch.uint8, device="cuda")
                 sig, rgb = torch.zeros(M, device="cuda"), torch.zeros(M, 3, device="cuda")
                 base_ptrs = nv.ptr_array([t.detach() for t in base_d])
-                fo.encode_planes(pts, M, 1.0, base_ptrs, S, ws, rows)
-                nv.call("field_fwd_rows", nv.ptr(pts), nv.ptr(dirs), M, nv.ptr(rows), 1.0, base_ptrs, nv.ptr(S), nv.ptr(packed), nv.ptr(sig), nv.ptr(rgb), nv.ptr(ws), nv.stream())
+                layout = fo.encode_planes(pts, M, 1.0, base_ptrs, S, ws, rows)
+                assert layout == (fo.PLANES_MIXED if half == "1" else fo.PLANES_F32)
+                nv.call("field_fwd_rows", nv.ptr(pts), nv.ptr(dirs), M, nv.ptr(rows), 1.0, base_ptrs, nv.ptr(S), nv.ptr(packed), nv.ptr(sig), nv.ptr(rgb), nv.ptr(ws), layout, nv.stream())
                 out += [sig, rgb]
                 torch.cuda.synchronize()
                 got[half] = [t.clone() for t in out]
@@ -471,16 +472,19 @@ def test_mixed_plane_sets_equal_fp32_plane_sets_bit_for_bit(fo, tables, monkeypa
         pts, dirs = pts[:M].contiguous(), dirs[:M].contiguous()
         ws = torch.zeros(int(nv.fn("hg_planes_bytes")(M)), dtype=torch.uint8, device="cuda")
         base_ptrs = nv.ptr_array([t.detach() for t in base_d])
-        fo.encode_planes(pts, M, 1.0, base_ptrs, S, ws)
+        layout = fo.encode_planes(pts, M, 1.0, base_ptrs, S, ws)
+        assert layout == fo.PLANES_MIXED
         sig, rgb = torch.zeros(M, device="cuda"), torch.zeros(M, 3, device="cuda")
         nv.set_mlp_precision("bf16x3")
         assert not fo.mixed_planes()
         with pytest.raises(ValueError, match="mixed"):
-            nv.call("field_fwd", nv.ptr(pts), nv.ptr(dirs), M, 1.0, base_ptrs, nv.ptr(S), nv.ptr(packed), nv.ptr(sig), nv.ptr(rgb), None, None, nv.ptr(ws), nv.stream())
+            nv.call("field_fwd", nv.ptr(pts), nv.ptr(dirs), M, 1.0, base_ptrs, nv.ptr(S), nv.ptr(packed), nv.ptr(sig), nv.ptr(rgb), None, None, nv.ptr(ws), layout, nv.stream())
         with pytest.raises(ValueError, match="fp16"):
             nv.call("hg_encode_planes_mixed", nv.ptr(pts), M, None, 1.0, base_ptrs, nv.ptr(S), nv.ptr(ws), nv.stream())
-        nv.call("hg_encode_planes", nv.ptr(pts), M, 1.0, base_ptrs, nv.ptr(S), nv.ptr(ws), nv.stream())       # the same address written as fp32 again: accepted
-        nv.call("field_fwd", nv.ptr(pts), nv.ptr(dirs), M, 1.0, base_ptrs, nv.ptr(S), nv.ptr(packed), nv.ptr(sig), nv.ptr(rgb), None, None, nv.ptr(ws), nv.stream())
+        with pytest.raises(ValueError, match="planes_layout"):      # the layout is an explicit argument (no registry by address): anything but the two constants is refused
+            nv.call("field_fwd", nv.ptr(pts), nv.ptr(dirs), M, 1.0, base_ptrs, nv.ptr(S), nv.ptr(packed), nv.ptr(sig), nv.ptr(rgb), None, None, nv.ptr(ws), 7, nv.stream())
+        nv.call("hg_encode_planes", nv.ptr(pts), M, 1.0, base_ptrs, nv.ptr(S), nv.ptr(ws), nv.stream())       # the same buffer written as fp32 again, and said so
+        nv.call("field_fwd", nv.ptr(pts), nv.ptr(dirs), M, 1.0, base_ptrs, nv.ptr(S), nv.ptr(packed), nv.ptr(sig), nv.ptr(rgb), None, None, nv.ptr(ws), fo.PLANES_F32, nv.stream())
         torch.cuda.synchronize()
         assert float(sig.abs().max()) > 0
     finally:

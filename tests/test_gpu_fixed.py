@@ -148,9 +148,9 @@ def test_fixed_block_cache_trains_like_the_loop_that_recomputes():
     assert float((t1 - t0).norm()) <= 0.02 * float((t0 - start).norm())
 
 
-def test_kept_forward_in_one_launch_equals_plane_plus_forward(monkeypatch):
-    """field_fwd_kept (codebook level gathered inside the MLP kernel, lane halves swapping the two x sides) against
-    hg_encode_codebook_plane + field_fwd(planes) and against the ordinary 17-level route: sigma, rgb and the ReLU masks bit for bit."""
+def test_kept_forward_equals_the_ordinary_route():
+    """FixedPoints + hg_encode_codebook_plane + field_fwd(planes) against the ordinary 17-level route: sigma, rgb and the ReLU masks bit for bit; without a message the base
+    planes alone."""
     from nerf_signature_amd import fieldops as fo
     m, _, _ = _model()
     rng = np.random.RandomState(3)
@@ -162,12 +162,10 @@ def test_kept_forward_in_one_launch_equals_plane_plus_forward(monkeypatch):
     S = fo.codebook_presum(fo.select_tables(m.msg_encoder.tables(), tuple(int(v) for v in cf.messages(32)[2])))
     want = fo.field_forward(xyzs, dirs, 1.0, base, S, packed, want_masks=True, planes=True)
     kept = fo.FixedPoints(xyzs, 1.0, base)
-    for one_launch in (False, True):
-        monkeypatch.setattr(fo, "KEPT_ONE_LAUNCH", one_launch)
-        got = fo.field_forward(xyzs, dirs, 1.0, base, S, packed, want_masks=True, fixed=kept)
-        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[3], want[3])
-        clean = fo.field_forward(xyzs, dirs, 1.0, base, None, packed, fixed=kept)          # no codebook: base planes only
-        assert torch.equal(clean[0], fo.field_forward(xyzs, dirs, 1.0, base, None, packed, planes=True)[0])
+    got = fo.field_forward(xyzs, dirs, 1.0, base, S, packed, want_masks=True, fixed=kept)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[3], want[3])
+    clean = fo.field_forward(xyzs, dirs, 1.0, base, None, packed, fixed=kept)          # no codebook: base planes only
+    assert torch.equal(clean[0], fo.field_forward(xyzs, dirs, 1.0, base, None, packed, planes=True)[0])
 
 
 def test_fixed_rays_under_autocast_and_a_scaled_loss():

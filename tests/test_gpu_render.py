@@ -314,11 +314,11 @@ def test_split_graphs_with_rccl_exchange_rehearsed_on_one_rank():
     data = {"watermark": {"rays_o_block": bo.cuda(), "rays_d_block": bd.cuda()}, "content": {"rays_o": co.cuda(), "rays_d": cd.cuda(), "images": gt.cuda()}}
     msgs = [torch.from_numpy(np.random.RandomState(s).randint(0, 2, 32).astype(np.float32)) for s in range(4)]
 
-    def run():
+    def run(**loop_kw):
         torch.manual_seed(0)
         m, _, _ = _model()
         opt = CodebookAdam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=True)
-        loop = trainer.GraphedWatermarkLoop(m, opt, dict(dt_gamma=0, max_steps=1024), data)
+        loop = trainer.GraphedWatermarkLoop(m, opt, dict(dt_gamma=0, max_steps=1024), data, **loop_kw)
         held = [loop.step(msg)[5].detach().clone() for msg in msgs]
         torch.cuda.synchronize()
         return loop, [float(v) for v in held], torch.cat([e.weight.detach().reshape(-1) for e in m.msg_encoder.embeddings])
@@ -343,18 +343,12 @@ def test_split_graphs_with_rccl_exchange_rehearsed_on_one_rank():
         os.environ["NERFSIG_CAPTURE_COLLECTIVES"] = "1"
         loop2, l2, t2 = run()
         assert len(loop2.segments) == 1 and len(loop2.between) == 0 and loop2.sharded and loop2.content_backward_first
-        # segmented capture (the all-gather ends a segment) with schedules in which no early content backward exists -- the main stream
-        # must not wait for the side stream again in the new segment (an event recorded outside the capture)
-        extra = []
-        for env in ({"NERFSIG_BACKWARD_SCHEDULE": "tail"}, {"NERFSIG_CONTENT_BWD_NOW": "0"}):
-            os.environ.update(env, NERFSIG_CAPTURE_COLLECTIVES="0")
-            try:
-                loop3, l3, t3 = run()
-            finally:
-                for k in env:
-                    os.environ.pop(k, None)
-            assert len(loop3.segments) == 3 and loop3.sharded
-            extra.append(l3)
+        # segmented capture without a side stream (overlap_content=False: one stream, no early content backward): the all-gather ends a segment and nothing
+        # of the new segment may wait for a stream that was never forked into it
+        os.environ["NERFSIG_CAPTURE_COLLECTIVES"] = "0"
+        loop3, l3, t3 = run(overlap_content=False)
+        assert len(loop3.segments) == 3 and loop3.sharded and loop3.side_stream is None and not loop3.content_backward_first
+        extra = [l3]
     finally:
         os.environ.pop("NERFSIG_FORCE_EXCHANGE", None)
         os.environ.pop("NERFSIG_CAPTURE_COLLECTIVES", None)

@@ -408,7 +408,7 @@ def test_bench_starts_its_own_ranks_dry_launch():
     assert line["block_shard_rank0"] == [0, 16] and line["backend"] == "gloo"
     assert line["device_of_rank"] == ["0", "1"] and line["devices_distinct"]            # every rank binds a GPU of its own, decided before any GPU call
     # ... and a launch that would put two ranks on one GPU is refused by every rank before anything runs (no JSON line, exit code 5)
-    clash = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], env=dict(env, NERFSIG_DRY_DEVICE_COUNT="1"),
+    clash = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch", "--dry-device-count", "1"], env=env,
                            capture_output=True, text=True, timeout=300)
     assert clash.returncode != 0 and "would share device" in clash.stderr and not [l for l in clash.stdout.splitlines() if l.startswith("{")]
 
@@ -670,5 +670,78 @@ def test_device_ordinal_follows_the_visibility_masks(monkeypatch):
     monkeypatch.setenv("LOCAL_RANK", "3")
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
     assert dp.assert_distinct_devices(device_count=4) == (3, "3")
-    with pytest.raises(RuntimeError, match="would share device"):
+    with pytest.raises(RuntimeError, match="LOCAL_RANK 3 would share device 1 with LOCAL_RANK 1"):
         dp.assert_distinct_devices(device_count=2)
+    # 3 ranks on 2 GPUs at LOCAL_RANK 1 used to name a negative partner; rank 1 shares with nobody by itself (ranks 0 and 2 collide)
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "3")
+    with pytest.raises(RuntimeError, match=r"would share device 1 \(other ranks of the node collide\)"):
+        dp.assert_distinct_devices(device_count=2)
+    monkeypatch.setenv("LOCAL_RANK", "2")
+    with pytest.raises(RuntimeError, match="LOCAL_RANK 2 would share device 0 with LOCAL_RANK 0"):
+        dp.assert_distinct_devices(device_count=2)
+
+
+def test_bound_train_step_falls_back_to_the_reference_method_for_another_criterion():
+    """trainer.reference_trainer_train_step hard-codes the MSE content loss; a Trainer whose criterion is not MSELoss(reduction='none') goes through the
+    method of the class the bound one shadows (found over the MRO) instead of silently training on another loss."""
+    from nerf_signature_amd import trainer
+
+    class RefTrainer:
+        def train_step(self, data, message):
+            return ("the reference's own", data, message)
+
+    class Bound(RefTrainer):
+        train_step = trainer.reference_trainer_train_step
+
+    t = Bound()
+    t.criterion = torch.nn.L1Loss(reduction="none")
+    assert t.train_step("d", "m") == ("the reference's own", "d", "m")
+    t.criterion = torch.nn.MSELoss(reduction="mean")
+    assert t.train_step("d", "m")[0] == "the reference's own"
+    t.criterion = torch.nn.MSELoss(reduction="none")
+    with pytest.raises((AttributeError, TypeError, KeyError)):      # the fused path is taken (and trips over the dummy arguments)
+        t.train_step("d", "m")
+
+
+def test_environment_switches_are_the_documented_ones(monkeypatch):
+    """the package and bench.py read exactly the switches nerf_signature_amd/switches.py documents (at most 20); nothing else named
+    NERFSIG_* occurs in product sources (rejected experiments leave no switch behind), and the few that no other test flips are flipped here."""
+    import re
+    import subprocess
+    import sys
+    from nerf_signature_amd import switches
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    found = set()
+    files = [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    for base, _, names in os.walk(os.path.join(root, "nerf_signature_amd")):
+        files += [os.path.join(base, n) for n in names if n.endswith((".py", ".hip", ".h", ".md"))]
+    for f in files:
+        found |= set(re.findall(r"NERFSIG_[A-Z0-9_]+", open(f).read()))
+    found -= {"NERFSIG_"}
+    assert found == set(switches.DOCUMENTED), (sorted(found - set(switches.DOCUMENTED)), sorted(set(switches.DOCUMENTED) - found))
+    assert len(switches.DOCUMENTED) <= 20 and all(name in switches.__doc__ for name in switches.DOCUMENTED)
+    # NERFSIG_DROPIN_OFF: a list of known features; anything else is an error, not silently ignored
+    monkeypatch.setenv("NERFSIG_DROPIN_OFF", "dense_adam, get_rays")
+    assert switches.dropin_off("dense_adam") and switches.dropin_off("get_rays") and not switches.dropin_off("train_step")
+    monkeypatch.setenv("NERFSIG_DROPIN_OFF", "premarch")
+    with pytest.raises(ValueError, match="unknown feature"):
+        switches.dropin_off("train_step")
+    monkeypatch.delenv("NERFSIG_DROPIN_OFF")
+    assert not any(switches.dropin_off(f) for f in switches.DROPIN_FEATURES)
+    # NERFSIG_MLP: the arithmetic the library starts with (read once per process: fresh interpreters)
+    for value, want in (("bf16x3", 0), ("f16", 1), (None, 1)):
+        env = {k: v for k, v in os.environ.items() if k != "NERFSIG_MLP"}
+        if value is not None:
+            env["NERFSIG_MLP"] = value
+        out = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from nerf_signature_amd import _native as nv; print(nv.fn('mlp_get_precision')())" % root],
+                             env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and int(out.stdout.strip().splitlines()[-1]) == want, (value, out.stdout, out.stderr[-300:])
+    # NERFSIG_REPLICATE_BLOCKS: no block shard even where an exchange runs (the launcher's last fallback)
+    from nerf_signature_amd import dp
+    monkeypatch.setattr(dp, "exchange_active", lambda: True)
+    monkeypatch.setattr(dp.dist, "get_world_size", lambda: 2)
+    monkeypatch.setattr(dp.dist, "get_rank", lambda: 1)
+    assert dp.block_shard(32) == (16, 32)
+    monkeypatch.setenv("NERFSIG_REPLICATE_BLOCKS", "1")
+    assert dp.block_shard(32) is None

@@ -9,8 +9,7 @@ import sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 R = int(sys.argv[1])
-os.environ.update(NERFSIG_FORCE_EXCHANGE="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", NERFSIG_SHARD_OPTIMIZER=os.environ.get("NERFSIG_SHARD_OPTIMIZER", "1" if R >= 4 else "0"),
-                  NERFSIG_BENCH_VARIANT="0")
+os.environ.update(NERFSIG_FORCE_EXCHANGE="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", NERFSIG_SHARD_OPTIMIZER=os.environ.get("NERFSIG_SHARD_OPTIMIZER", "1" if R >= 4 else "0"))
 os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
 sys.argv = [os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + sys.argv[2:]
 

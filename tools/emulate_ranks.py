@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.update(NERFSIG_FORCE_EXCHANGE="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", NERFSIG_BENCH_VARIANT="0")
+os.environ.update(NERFSIG_FORCE_EXCHANGE="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1")
 os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
 steps = sys.argv[sys.argv.index("--steps") + 1] if "--steps" in sys.argv else "50"
 

@@ -5,7 +5,8 @@ tag=$1; steps=${2:-6}
 cd /tmp && export TMPDIR=/tmp
 groups=("FETCH_SIZE" "WRITE_SIZE" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum" \
         "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" \
-        "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_ATOMIC_sum GRBM_GUI_ACTIVE" "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT")
+        "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_ATOMIC_sum GRBM_GUI_ACTIVE" "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" \
+        "TCC_BUBBLE_sum")      # (gfx950: the 128-byte read requests to the fabric -- the share of 128-byte requests tools/pmc_traffic.py needs; a run of its own beside TCC_EA0_RDREQ's)
 dirs=()
 i=0
 for g in "${groups[@]}"; do

@@ -34,11 +34,18 @@ def pick(name, grid=None):
 def traffic(c):
     if c is None:
         return None
-    share = (c["TCC_EA0_RDREQ_128B_sum"] / c["TCC_EA0_RDREQ_sum"]) if c.get("TCC_EA0_RDREQ_128B_sum") and c.get("TCC_EA0_RDREQ_sum") else 1.0
-    rd, wr = c["FETCH_SIZE"] * 1024 * (1 + share), c["WRITE_SIZE"] * 1024
-    out = {"FETCH_SIZE_KiB": c["FETCH_SIZE"], "WRITE_SIZE_KiB": c["WRITE_SIZE"], "share_of_128B_read_requests": share, "read_bytes": rd, "write_bytes": wr,
-           "hbm_bytes_per_launch": rd + wr}
-    for k in ("TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_ATOMIC_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "TA_TA_BUSY_sum",
+    # the 128-byte read requests: TCC_BUBBLE on gfx950 (counter_defs.yaml: "Number of 128-byte read requests sent to EA").  Measured where the run has it and it
+    # counts (> 0); otherwise ASSUMED 1.0 (round 1 calibrated these kernels at 0.999 on k_codebook_presum's exactly known 128 MiB) -- and the record says which.
+    big = c.get("TCC_BUBBLE_sum") or c.get("TCC_EA0_RDREQ_128B_sum")
+    measured = bool(big) and bool(c.get("TCC_EA0_RDREQ_sum"))
+    share = min(1.0, big / c["TCC_EA0_RDREQ_sum"]) if measured else 1.0
+    # measured: bytes straight from the request counters (128-byte, 32-byte, the rest 64-byte); assumed: the guide's correction of FETCH_SIZE (= RDREQ x 64 B)
+    rd = (big * 128 + (c["TCC_EA0_RDREQ_sum"] - big - c.get("TCC_EA0_RDREQ_32B_sum", 0.0)) * 64 + c.get("TCC_EA0_RDREQ_32B_sum", 0.0) * 32) if measured else c["FETCH_SIZE"] * 1024 * (1 + share)
+    wr = c["WRITE_SIZE"] * 1024
+    out = {"FETCH_SIZE_KiB": c["FETCH_SIZE"], "WRITE_SIZE_KiB": c["WRITE_SIZE"], "share_of_128B_read_requests": share,
+           "share_source": "measured (TCC_BUBBLE_sum / TCC_EA0_RDREQ_sum; read bytes = 128 x BUBBLE + 32 x RDREQ_32B + 64 x the rest)" if measured else "ASSUMED 1.0 (TCC_BUBBLE_sum absent or zero in this run)",
+           "read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
+    for k in ("TCC_EA0_RDREQ_sum", "TCC_BUBBLE_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_ATOMIC_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "TA_TA_BUSY_sum",
               "TA_FLAT_READ_WAVEFRONTS_sum", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY",
               "SQ_WAIT_INST_ANY", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT"):
         if k in c:

@@ -7,8 +7,7 @@ import subprocess
 import sys
 
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
-base = dict(os.environ, NERFSIG_FORCE_EXCHANGE="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", NERFSIG_SHARD_OPTIMIZER="1",
-            NERFSIG_BENCH_VARIANT="0")
+base = dict(os.environ, NERFSIG_FORCE_EXCHANGE="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", NERFSIG_SHARD_OPTIMIZER="1")
 pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 modes = sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "1"]
 failed = 0
@@ -22,5 +21,8 @@ for k in range(pairs):
             print(f"capture_collectives={cap}: FAILED rc={out.returncode}\n{out.stderr[-1500:]}", flush=True)
             continue
         d = json.loads(line[0])
-        print(f"capture_collectives={cap}: {d['ms_per_step']:.4f} ms/step, {d['config']['execution']}, collectives/step {d['config']['collectives_per_step']}, loss {d['config']['loss']:.6f}", flush=True)
+        drain = d["config"].get("watchdog_drain_before_capture") or {}
+        coll = (d["config"].get("collective_us") or {}).get("eager_pass_one_stream", {})
+        print(f"run {k:3d} capture_collectives={cap}: {d['ms_per_step']:.4f} ms/step, {d['config']['execution']}, collectives/step {d['config']['collectives_per_step']}, loss {d['config']['loss']:.6f}; "
+              f"watchdog drain: {drain.get('how')} ({drain.get('seconds', 0):.2f} s); collectives (eager pass, us): " + ", ".join(f"{n} {v['mean']:.0f}" for n, v in coll.items()), flush=True)
 print(f"{failed} failed run(s)")

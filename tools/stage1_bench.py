@@ -34,6 +34,12 @@ flags = [a for a in sys.argv[1:] if a.startswith("--")]
 which = args[0] if args else "content"
 steps, windows = flag("--steps", 64), flag("--windows", 5)
 as_json = "--json" in flags
+if "--rccl1" in flags:      # a world-size-1 RCCL group: the step's all-reduce of [16 table gradients | MLP gradients] (64 MiB) issued for real -- between two captured
+    # segments, or (NERFSIG_CAPTURE_COLLECTIVES=1) inside the one graph
+    os.environ.update(NERFSIG_FORCE_EXCHANGE="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29731")
+    from nerf_signature_amd import dp
+    dp.init_from_env()
 say = (lambda *a: print(*a, file=sys.stderr)) if as_json else print
 dev = torch.device("cuda")
 
@@ -137,6 +143,7 @@ say(f"stage-1 captured step ({which}): {n_rays} rays, {pts} points, capacity {lo
     f"grid refresh every {refresh} steps inside the windows; loss {loss_last:.4e}; recaptures {loop.recaptures}")
 
 # ---- the same kernel sequence, eagerly, on one stream, every entry point between HIP events
+n_segments = len(loop.graph.segments) if loop.graph is not None else None
 steps_done, capacity, state = loop.global_step, loop.capacity, {k: v.detach().clone() for k, v in m.state_dict().items()}
 loop.close()
 m2 = fresh_model()
@@ -200,6 +207,7 @@ out = {
         "basis": "every saved layer input and pre-activation gradient row read exactly once (480 floats per point); the products are K = points reductions, 10 FLOP per byte: HBM-bound",
         "mfma": {"algorithmic_flop_per_point": wg_alg_flop, "issued_flop_per_point": wg_issued_flop,
                  "achieved_TFLOPs_issued": pts_e * wg_issued_flop / wg_s / 1e12 if wg_s else 0.0, "frac_of_dense_bf16_peak": pts_e * wg_issued_flop / wg_s / MFMA_PEAK_BF16 if wg_s else 0.0}},
+    "exchange": {"bytes_per_step": loop.bytes_exchanged_per_step, "segments": n_segments} if "--rccl1" in flags else None,
     "parity": "tests/test_gpu_stage1.py: all-parameter gradients (16 levels) vs the oracle's autograd, weight gradients vs fp64 products, captured == eager, 200 steps tracked by the CPU oracle, "
               "grid-refresh cadence, two-rank exchange == single-process gradient",
 }

@@ -29,10 +29,10 @@ ap.add_argument("--no-gc", action="store_true", help="diagnostics: Python's cycl
 ap.add_argument("--gc-freeze", action="store_true", help="gc.freeze() after the warm-up steps (what the drop-in model does at its first training render)")
 ap.add_argument("--phases", action="store_true", help="host wall time per phase of the loop body (perf_counter, no profiler)")
 ap.add_argument("--no-auto-fix", action="store_true")
-ap.add_argument("--reference-operators", action="store_true", help="NERFSIG_DROPIN_TRAIN_STEP=0: the operator sequence the reference's own Trainer.train_step issues around model.render "
+ap.add_argument("--reference-operators", action="store_true", help="NERFSIG_DROPIN_OFF=train_step: the operator sequence the reference's own Trainer.train_step issues around model.render "
                                                                    "and model.msg_decoder, instead of the method the drop-in directory binds in its place (this repo's fused train_step)")
 ap.add_argument("--distortion", default="none")
-ap.add_argument("--reference-loader", action="store_true", help="NERFSIG_DROPIN_GET_RAYS=0: the reference's own meshgrid-style get_rays (utils_wtmk.py:57-143, ~25 small launches) in the "
+ap.add_argument("--reference-loader", action="store_true", help="NERFSIG_DROPIN_OFF=get_rays: the reference's own meshgrid-style get_rays (utils_wtmk.py:57-143, ~25 small launches) in the "
                                                                 "loader instead of the drop-in directory's (dropin/nerf/utils_wtmk.py -> rays.get_rays: same draws, one launch)")
 ap.add_argument("--evaluate", action="store_true", help="after the timed steps: Trainer.test_bitacc over 100 random messages and test_image PSNR (quality.py) -- with --steps 330 and the "
                                                         "default three windows the loop has run the reference's whole 1000-step schedule by then")
@@ -200,7 +200,7 @@ os.dup2(real_stdout, 1)
 print(json.dumps({"what": "what the UNCHANGED reference CLI runs on top of the drop-in directory: the reference Trainer's loop body (utils_wtmk_disen.py:1164-1190) -- eager, autocast(fp16) + "
                           "GradScaler, plain torch.optim.Adam, loader-style rays per step, three .item() reads per step -- around this repo's model; NOT the headline path",
                   "train_step": "Trainer.train_step as the drop-in directory binds it (dropin/nerf/utils_wtmk_disen.py -> trainer.reference_trainer_train_step: this repo's fused step)" if args.fused_step
-                  else "NERFSIG_DROPIN_TRAIN_STEP=0: the reference's own operator sequence around model.render / model.msg_decoder (stock clamp, normalisation, MSE, BCE)",
+                  else "NERFSIG_DROPIN_OFF=train_step: the reference's own operator sequence around model.render / model.msg_decoder (stock clamp, normalisation, MSE, BCE)",
                   "ms_per_step": el / args.steps * 1e3, "ms_per_step_windows": [round(w, 4) for w in windows], "content_rays_per_s": 4096 * args.steps / el, "steps": args.steps, "fp16": not args.no_fp16,
                   **({} if other is None else {("ms_per_step_with_the_references_own_train_step_operators" if args.fused_step else "ms_per_step_with_the_bound_train_step"): round(other, 4)}),
                   "block_graph": (lambda g: None if g is None else {"captures": g.captures, "replays": g.generation, "failed": g.failed})(me.__dict__.get("_nsig_block_graph")),
