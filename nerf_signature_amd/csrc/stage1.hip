@@ -3,9 +3,9 @@
 //
 //   * field_wgrad    the five weight-gradient reductions dW = sum over points of (pre-activation gradient) x (layer input)^T.  The reference
 //                    leaves them to tiny-cuda-nn's CUTLASS GEMMs; a BLAS library handles their shape (64 x 64 outputs, K = 10^5..10^6
-//                    points) with one or two workgroups: 5 x 145 us of a 4096-ray step, more than everything else together
-//                    (profiles/r05_stage1_baseline_kernels.txt).  Here: split-K over the points on MFMA, slabs of partial sums, one
-//                    fixed-order reduction -- bit-reproducible.
+//                    points) with one or two workgroups: 5 x 145 us of a 4096-ray step at 140 k points, more than everything else together.
+//                    Here: split-K over the points on MFMA, tiles staged through LDS, slabs of partial sums, one fixed-order reduction --
+//                    bit-reproducible.
 //   * clean_loss     the MSE of nerf/utils.py:503 and its gradient in one launch.
 //
 // The level scatter of the base-table gradients lives beside its siblings in hashgrid.hip (hg_levels_plan / hg_levels_scatter).
@@ -16,25 +16,35 @@ namespace nsig {
 
 // ----------------------------------------------------------------------------- weight gradients
 //
-// Both factors are stored feature-major, [width][stride] fp32 (field_fwd_trace / field_bwd_trace), so 8 consecutive points of one row are
-// 32 contiguous bytes: exactly one lane's share of an A or B operand of v_mfma_f32_32x32x16 when the K dimension runs over the POINTS
-// (lane (r, h) holds row r, k = 8h..8h+7).  A 16-point K-step of a 32 x 32 output block is therefore two plain 32-byte loads per lane and no
-// transposition.  Operands enter as split bf16 (hi + lo, three MFMAs per product, fp32 accumulate): the pre-activation gradients of an
-// unscaled MSE loss sit around 1e-6 and would need a loss scale in fp16; bf16 has fp32's exponent range.
+// Both factors are stored feature-major, [width][stride] fp32 (field_fwd_trace / field_bwd_trace): a row is one feature over all points, and the
+// K dimension of the products runs over the POINTS.  An operand of v_mfma_f32_32x32x16 wants lane (r, h) to hold row r, k = 8h..8h+7: 32
+// contiguous bytes of row r.  Loaded straight from memory that way (the first version of this kernel), every 16-byte load instruction of a wave
+// touches 32 different 128-byte lines -- 32 rows x 2 halves -- and the kernel ran at 2.3-2.7 TB/s whatever its occupancy (84 -> 336 workgroups per
+// role: 546 -> 483 us at 675 k points, profiles/r05_stage1_wgrad_ab.txt): bound by the address path, not by latency.  Here a workgroup stages a TILE
+// of 32 points x all rows of its role through LDS: 8 consecutive lanes read one whole 128-byte line (8 lines per instruction instead of 32), rows
+// are padded to 36 floats so that the operand reads (two ds_read_b128 per lane) are conflict-free, and the loads of the next two tiles are in flight
+// (in registers) while the current one is multiplied.
+// Operands enter as split bf16 (hi + lo, three MFMAs per product, fp32 accumulate): the pre-activation gradients of an unscaled MSE loss sit
+// around 1e-6 and would need a loss scale in fp16; bf16 has fp32's exponent range.
 //
-// Work split: three ROLES (blockIdx.y), four 32 x 32 products each, so that a wave keeps 64 accumulator registers and every stored row is
-// read by exactly one role:
-//   role 0: dW1s[64x32] = d_hs x feat^T (2 products), dWc1[64x32] = d_h1 x cin^T (2)
-//   role 1: dW2s[16x64] = d_so x hs^T   (2),          dWc3[16x64] = d_out x h2^T (2)      (the A rows 16..31 are zero)
-//   role 2: dWc2[64x64] = d_h2 x h1^T   (4)
-// Waves stride over the K-steps; a workgroup's four waves are summed through LDS and the workgroup stores ONE slab of 4096 partial sums
-// in accumulator order; k_wgrad_reduce adds the slabs in workgroup order and writes tcnn's layout ([out][in] row-major).
+// Work split: three ROLES (blockIdx.y), four 32 x 32 products each -- ONE PER WAVE, accumulated over all tiles of the workgroup:
+//   role 0: dW1s[64x32] = d_hs x feat^T (waves 0, 1), dWc1[64x32] = d_h1 x cin^T (2, 3)
+//   role 1: dW2s[16x64] = d_so x hs^T   (0, 1),       dWc3[16x64] = d_out x h2^T (2, 3)      (the A rows 16..31 are zero)
+//   role 2: dWc2[64x64] = d_h2 x h1^T   (0..3)
+// A workgroup stores ONE slab of 4096 partial sums in accumulator order (wave q = product q); k_wgrad_reduce adds the slabs in workgroup order
+// and writes tcnn's layout ([out][in] row-major).  Fixed tile -> workgroup assignment, fixed order: bit-reproducible.
 constexpr uint32_t kWgradRoles = 3, kWgradSlab = 4u * 16u * 64u;   // floats per (workgroup, role): 4 products x 16 registers x 64 lanes
 #ifndef NSIG_WGRAD_WGS
 #define NSIG_WGRAD_WGS 84
 #endif
-constexpr uint32_t kWgradMaxWGs = NSIG_WGRAD_WGS;      // x 3 roles = 252 workgroups of 4 waves: ONE per compute unit, one wave per SIMD, 16 KiB of LDS -- the kernel runs
-                                           // beside the table scatter (1024-thread workgroups with 64-128 KiB of LDS), which must still fit on the same units
+constexpr uint32_t kWgradMaxWGs = NSIG_WGRAD_WGS;      // x 3 roles = 252 workgroups of 4 waves: ONE per compute unit, 27 KiB of LDS -- the kernel runs beside the table
+                                                       // scatter (1024-thread workgroups with 64-128 KiB of LDS), which must still fit on the same units
+constexpr uint32_t kWgradRowFloats = 36;               // 32 points + 4 floats of padding: consecutive rows start 4 banks apart (16 bytes), 8 lanes x 16 B cover all 32 banks
+constexpr uint32_t kWgradRows = 192;                   // role 0 stages the most rows (64 + 64 + 32 + 32)
+#ifndef NSIG_WGRAD_AHEAD
+#define NSIG_WGRAD_AHEAD 4
+#endif
+constexpr int kWgradAhead = NSIG_WGRAD_AHEAD;             // tiles whose loads are in flight (registers) while one is multiplied
 
 struct WgradArgs {
     const float2 *planes;                               // [16][stride] float2: encoder features 2l, 2l+1 of level l
@@ -51,38 +61,6 @@ __device__ inline void split8(const float (&v)[8], Split8 &s) {
     }
 }
 
-// points p0..p0+7 of one stored row; points >= n (stale rows of a buffer sized for more points) and rows that do not exist read as zero
-struct Raw8 {
-    float v[8];
-};
-__device__ inline void fetch_row8(const float *__restrict__ base, uint32_t stride, uint32_t row, uint32_t p0, uint32_t n, bool row_exists, Raw8 &r) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r.v[j] = 0.0f;
-    if (row_exists && p0 < n) {
-        const float4 a = *reinterpret_cast<const float4 *>(base + (size_t)row * stride + p0);
-        const float4 b = *reinterpret_cast<const float4 *>(base + (size_t)row * stride + p0 + 4);
-        const float w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r.v[j] = p0 + j < n ? w[j] : 0.0f;
-    }
-}
-
-// ... of encoder feature i (component i & 1 of level i >> 1)
-__device__ inline void fetch_feat8(const float2 *__restrict__ planes, uint32_t stride, uint32_t i, uint32_t p0, uint32_t n, Raw8 &r) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r.v[j] = 0.0f;
-    if (p0 < n) {
-        const float4 *src = reinterpret_cast<const float4 *>(planes + (size_t)(i >> 1) * stride + p0);
-        const float4 q[4] = {src[0], src[1], src[2], src[3]};
-        const bool odd = i & 1u;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            r.v[2 * t] = p0 + 2 * t < n ? (odd ? q[t].y : q[t].x) : 0.0f;
-            r.v[2 * t + 1] = p0 + 2 * t + 1 < n ? (odd ? q[t].w : q[t].z) : 0.0f;
-        }
-    }
-}
-
 __device__ inline f32x16 mac3(const Split8 &a, const Split8 &b, f32x16 c) {      // lo parts first, hi * hi last (as Bf16x3::mac)
     const bf16x8 a_hi = operand(a.hi), a_lo = operand(a.lo), b_hi = operand(b.hi), b_lo = operand(b.lo);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, c, 0, 0, 0);
@@ -90,99 +68,111 @@ __device__ inline f32x16 mac3(const Split8 &a, const Split8 &b, f32x16 c) {     
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, c, 0, 0, 0);
 }
 
-// One wave takes PAIRS of adjacent K-steps (32 points: each row's whole 128-byte line) and requests all their operands -- up to 24 32-byte
-// loads per lane -- before it converts the first: the kernel runs at one wave per SIMD beside the table scatter, so the loads in flight per
-// wave are what hides the memory latency.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
-k_field_wgrad(WgradArgs a, uint32_t stride, uint32_t M, const uint32_t *__restrict__ rows_dev, float *__restrict__ slabs) {
-    __shared__ float red[kWgradSlab];        // 16 KiB: waves 1..3 hand their sums to wave 0 one after the other
+// What one thread fetches of a tile: up to six 16-byte pieces.  Thread t = 8 g + c takes chunk c (points 4c..4c+3 of the tile) of rows g and g + 32 of every
+// 64-row factor and of row g of every 32-row one; the feature planes are float2 pairs (feature 2l, 2l+1 of level l): thread t = 16 l + c2 takes points
+// 2 c2, 2 c2 + 1 of level l.  LDS rows per role:  0: d_hs 0..63 | d_h1 64..127 | cin 128..159 | feat 160..191;  1: hs 0..63 | h2 64..127 | d_so 128..143 |
+// d_out 144..159;  2: d_h2 0..63 | h1 64..127.
+struct WgradTile {
+    float4 v[6];
+};
+
+template <int role>      // (a compile-time role: with the three cases as run-time branches inside the tile loop the compiler's wait-count bookkeeping drained every load
+                         //  -- the tiles requested ahead included -- in front of each staging pass)
+__device__ inline void wgrad_request(const WgradArgs &a, uint32_t stride, uint32_t tile, WgradTile &t) {
+    const uint32_t g = threadIdx.x >> 3, c = threadIdx.x & 7u;
+    const size_t at = (size_t)tile * 32u + 4u * c;
+    auto row = [&](const float *base, uint32_t r) { return *reinterpret_cast<const float4 *>(base + (size_t)r * stride + at); };
+    if (role == 0) {
+        t.v[0] = row(a.d_hs, g); t.v[1] = row(a.d_hs, g + 32u); t.v[2] = row(a.d_h1, g); t.v[3] = row(a.d_h1, g + 32u); t.v[4] = row(a.cin, g);
+        t.v[5] = *reinterpret_cast<const float4 *>(a.planes + (size_t)(threadIdx.x >> 4) * stride + (size_t)tile * 32u + 2u * (threadIdx.x & 15u));
+    } else if (role == 1) {
+        t.v[0] = row(a.hs, g); t.v[1] = row(a.hs, g + 32u); t.v[2] = row(a.h2, g); t.v[3] = row(a.h2, g + 32u);
+        t.v[4] = g < 16u ? row(a.d_so, g) : row(a.d_out, g - 16u);
+    } else {
+        t.v[0] = row(a.d_h2, g); t.v[1] = row(a.d_h2, g + 32u); t.v[2] = row(a.h1, g); t.v[3] = row(a.h1, g + 32u);
+    }
+}
+
+// ... into the staging area; points at or beyond n (stale rows of buffers sized for more points) enter as zeros
+template <int role>
+__device__ inline void wgrad_stage(float *__restrict__ lds, uint32_t tile, uint32_t n, const WgradTile &t) {
+    const uint32_t g = threadIdx.x >> 3, c = threadIdx.x & 7u;
+    const uint32_t p = tile * 32u + 4u * c;
+    auto put = [&](uint32_t r, float4 v) {
+        v.x = p < n ? v.x : 0.0f; v.y = p + 1u < n ? v.y : 0.0f; v.z = p + 2u < n ? v.z : 0.0f; v.w = p + 3u < n ? v.w : 0.0f;
+        *reinterpret_cast<float4 *>(lds + r * kWgradRowFloats + 4u * c) = v;
+    };
+    put(g, t.v[0]); put(g + 32u, t.v[1]); put(g + 64u, t.v[2]); put(g + 96u, t.v[3]);
+    if (role == 0) {
+        put(g + 128u, t.v[4]);
+        const uint32_t l = threadIdx.x >> 4, c2 = threadIdx.x & 15u, q = tile * 32u + 2u * c2;
+        const float4 v = t.v[5];
+        const bool in0 = q < n, in1 = q + 1u < n;
+        *reinterpret_cast<float2 *>(lds + (160u + 2u * l) * kWgradRowFloats + 2u * c2) = make_float2(in0 ? v.x : 0.0f, in1 ? v.z : 0.0f);
+        *reinterpret_cast<float2 *>(lds + (161u + 2u * l) * kWgradRowFloats + 2u * c2) = make_float2(in0 ? v.y : 0.0f, in1 ? v.w : 0.0f);
+    } else if (role == 1) {
+        put(g + 128u, t.v[4]);
+    }
+}
+
+__device__ inline void wgrad_operand(const float *__restrict__ lds, uint32_t row, bool exists, uint32_t col, Split8 &s) {
+    float v[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (exists) {
+        const float4 x = *reinterpret_cast<const float4 *>(lds + row * kWgradRowFloats + col), y = *reinterpret_cast<const float4 *>(lds + row * kWgradRowFloats + col + 4u);
+        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+    }
+    split8(v, s);
+}
+
+template <int role>
+__device__ inline void wgrad_role(float *__restrict__ stage, const WgradArgs &a, uint32_t stride, uint32_t n, float *__restrict__ slabs) {
+    const uint32_t lane = threadIdx.x & 63u, q = threadIdx.x >> 6, r = lane & 31u, h = lane >> 5;
+    // this wave's product: rows of its A and B factor in the staging area
+    uint32_t a_row, b_row;
+    bool a_exists = true;
+    if (role == 0) { a_row = 32u * q + r; b_row = (q < 2u ? 160u : 128u) + r; }
+    else if (role == 1) { a_row = (q < 2u ? 128u : 144u) + r; a_exists = r < 16u; b_row = 32u * q + r; }
+    else { a_row = 32u * (q >> 1) + r; b_row = 64u + 32u * (q & 1u) + r; }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    const uint32_t n_tiles = ceil_div(n, 32u), step = gridDim.x;
+    // Requests are UNCONDITIONAL (past the last tile: the last tile again, never staged): a request skipped on some path leaves the compiler's wait counts with
+    // a path on which fewer loads are outstanding, and it then drains everything in front of each staging pass.
+    WgradTile ahead[kWgradAhead];
+    if (n_tiles != 0) {
+#pragma unroll
+        for (int k = 0; k < kWgradAhead; ++k) wgrad_request<role>(a, stride, min(blockIdx.x + k * step, n_tiles - 1u), ahead[k]);
+    }
+    for (uint32_t t0 = blockIdx.x; t0 < n_tiles; t0 += kWgradAhead * step) {
+#pragma unroll
+        for (int k = 0; k < kWgradAhead; ++k) {      // (unrolled: which register set holds which tile is known at compile time)
+            const uint32_t tile = t0 + k * step;
+            if (tile >= n_tiles) break;              // (uniform)
+            __syncthreads();                         // every wave is done with the previous tile's operands
+            wgrad_stage<role>(stage, tile, n, ahead[k]);
+            wgrad_request<role>(a, stride, min(tile + kWgradAhead * step, n_tiles - 1u), ahead[k]);
+            __syncthreads();
+#pragma unroll
+            for (uint32_t u = 0; u < 2u; ++u) {
+                Split8 A, B;
+                wgrad_operand(stage, a_row, a_exists, 16u * u + 8u * h, A);
+                wgrad_operand(stage, b_row, true, 16u * u + 8u * h, B);
+                acc = mac3(A, B, acc);
+            }
+        }
+    }
+    float *__restrict__ out = slabs + ((size_t)blockIdx.x * kWgradRoles + role) * kWgradSlab + (size_t)q * 1024u;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[e * 64 + lane] = acc[e];
+}
+
+__global__ void __launch_bounds__(256) k_field_wgrad(WgradArgs a, uint32_t stride, uint32_t M, const uint32_t *__restrict__ rows_dev, float *__restrict__ slabs) {
+    __shared__ __attribute__((aligned(16))) float stage[kWgradRows * kWgradRowFloats];      // 27 KiB
     const uint32_t n = rows_dev != nullptr ? min(M, *rows_dev) : M;
-    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6, r = lane & 31u, h = lane >> 5;
-    const uint32_t role = blockIdx.y;
-    f32x16 acc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[q][e] = 0.0f;
-    const uint32_t n_pairs = ceil_div(n, 32u);
-    for (uint32_t kp = blockIdx.x * 4u + wid; kp < n_pairs; kp += gridDim.x * 4u) {
-        Raw8 ra[2][4], rb[2][4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint32_t p0 = kp * 32u + 16u * u + 8u * h;
-            if (role == 0) {
-                fetch_row8(a.d_hs, stride, r, p0, n, true, ra[u][0]);
-                fetch_row8(a.d_hs, stride, 32u + r, p0, n, true, ra[u][1]);
-                fetch_row8(a.d_h1, stride, r, p0, n, true, ra[u][2]);
-                fetch_row8(a.d_h1, stride, 32u + r, p0, n, true, ra[u][3]);
-                fetch_feat8(a.planes, stride, r, p0, n, rb[u][0]);
-                fetch_row8(a.cin, stride, r, p0, n, true, rb[u][1]);
-            } else if (role == 1) {
-                fetch_row8(a.d_so, stride, r, p0, n, r < 16u, ra[u][0]);
-                fetch_row8(a.d_out, stride, r, p0, n, r < 16u, ra[u][1]);
-                fetch_row8(a.hs, stride, r, p0, n, true, rb[u][0]);
-                fetch_row8(a.hs, stride, 32u + r, p0, n, true, rb[u][1]);
-                fetch_row8(a.h2, stride, r, p0, n, true, rb[u][2]);
-                fetch_row8(a.h2, stride, 32u + r, p0, n, true, rb[u][3]);
-            } else {
-                fetch_row8(a.d_h2, stride, r, p0, n, true, ra[u][0]);
-                fetch_row8(a.d_h2, stride, 32u + r, p0, n, true, ra[u][1]);
-                fetch_row8(a.h1, stride, r, p0, n, true, rb[u][0]);
-                fetch_row8(a.h1, stride, 32u + r, p0, n, true, rb[u][1]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (role == 0) {
-                Split8 A0, A1, A2, A3, B0, B1;
-                split8(ra[u][0].v, A0); split8(ra[u][1].v, A1); split8(ra[u][2].v, A2); split8(ra[u][3].v, A3);
-                split8(rb[u][0].v, B0); split8(rb[u][1].v, B1);
-                acc[0] = mac3(A0, B0, acc[0]);
-                acc[1] = mac3(A1, B0, acc[1]);
-                acc[2] = mac3(A2, B1, acc[2]);
-                acc[3] = mac3(A3, B1, acc[3]);
-            } else if (role == 1) {
-                Split8 A0, A1, B0, B1, B2, B3;
-                split8(ra[u][0].v, A0); split8(ra[u][1].v, A1);
-                split8(rb[u][0].v, B0); split8(rb[u][1].v, B1); split8(rb[u][2].v, B2); split8(rb[u][3].v, B3);
-                acc[0] = mac3(A0, B0, acc[0]);
-                acc[1] = mac3(A0, B1, acc[1]);
-                acc[2] = mac3(A1, B2, acc[2]);
-                acc[3] = mac3(A1, B3, acc[3]);
-            } else {
-                Split8 A0, A1, B0, B1;
-                split8(ra[u][0].v, A0); split8(ra[u][1].v, A1);
-                split8(rb[u][0].v, B0); split8(rb[u][1].v, B1);
-                acc[0] = mac3(A0, B0, acc[0]);
-                acc[1] = mac3(A0, B1, acc[1]);
-                acc[2] = mac3(A1, B0, acc[2]);
-                acc[3] = mac3(A1, B1, acc[3]);
-            }
-        }
-    }
-    for (uint32_t w = 1; w < 4; ++w) {       // (three rounds at the end of a kernel that streams for tens of microseconds)
-        if (wid == w) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) red[(q * 16 + e) * 64 + lane] = acc[q][e];
-        }
-        __syncthreads();
-        if (wid == 0) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[q][e] += red[(q * 16 + e) * 64 + lane];
-        }
-        __syncthreads();
-    }
-    if (wid == 0) {
-        float *__restrict__ out = slabs + ((size_t)blockIdx.x * kWgradRoles + role) * kWgradSlab;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) out[(q * 16 + e) * 64 + lane] = acc[q][e];
-    }
+    if (blockIdx.y == 0) wgrad_role<0>(stage, a, stride, n, slabs);
+    else if (blockIdx.y == 1) wgrad_role<1>(stage, a, stride, n, slabs);
+    else wgrad_role<2>(stage, a, stride, n, slabs);
 }
 
 // slab sums in workgroup order -> sigma_net.params' gradient [3072] = [W1s 64x32 | W2s 16x64], color_net.params' [7168] = [Wc1 64x32 | Wc2 64x64 | Wc3 16x64]

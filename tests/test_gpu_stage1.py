@@ -180,9 +180,14 @@ def test_captured_loop_equals_the_eager_loop():
     assert len(loop.graph.segments) == 1 and not loop.overflowed()
     np.testing.assert_allclose(l1, l0, rtol=2e-4)
     assert l0[-1] < 0.7 * l0[0]
-    for a, b in zip(m1.trainable(), m0.trainable()):      # Adam with eps = 1e-15 turns a gradient whose SIGN is rounding noise into +-lr: allow a handful
+    # Adam with eps = 1e-15 turns a gradient whose SIGN is rounding noise into +-lr per step (lr = 1e-2): the two loops size their launches differently --
+    # exact point count against capacity -- so their weight-gradient slabs are cut differently (same sums, other rounding), the MLP weights drift apart by ~1e-5
+    # and a few table entries whose gradients nearly cancel (the fine levels: 1-2 in 10^4) take the other sign for a step or two.  Both loops are bit-reproducible
+    # by themselves (tools/stage1_determinism.py).
+    for i, (a, b) in enumerate(zip(m1.trainable(), m0.trainable())):
         diff = (a - b).detach().abs()
-        assert float((diff > 2e-5).float().mean()) < 1e-4 and float(diff.max()) < 2e-3, (float((diff > 2e-5).float().mean()), float(diff.max()))
+        frac, worst = float((diff > 2e-5).float().mean()), float(diff.max())
+        assert (frac < 5e-4 and worst < 3e-2) if i < 16 else worst < 1e-4, (i, frac, worst)
     assert loop.losses() == pytest.approx(l1, rel=1e-6)
     # Adam's state sits in the optimiser in torch's own format: step counts, moments
     st = loop.optimizer.state[m1.sigma_net.params]

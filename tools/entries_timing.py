@@ -4,7 +4,7 @@ import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["NERFSIG_LIB"] = os.path.join(ROOT, "tools", "_build", "libnerfsig_enttiming.so")
-sys.argv = [sys.argv[0], "content", "--no-refresh", "--no-overlap", "--steps", "20"]
+sys.argv = [sys.argv[0], "content", "--no-overlap", "--steps", "32", "--windows", "2"]
 import runpy
 try:
     runpy.run_path(os.path.join(ROOT, "tools", "stage1_bench.py"), run_name="__main__")
