@@ -525,6 +525,118 @@ class _FieldFunction(Function):
         return head + tuple(grads)
 
 
+# ---- differentiable stand-alone density() / color() (network_wtmk_tcnn.py:126-176).  The reference reaches them under autograd only from `run`, which this
+# repo evaluates as one joint field pass; a caller that differentiates them directly gets the native forward kernels and a backward written with torch
+# operators on the same fp32 weights (not a hot path: two small GEMM chains per call).
+
+_SH4 = None
+
+
+def sh4_basis(d):
+    """Real spherical harmonics of degree < 4 in tiny-cuda-nn's component order, [M,3] -> [M,16], as ONE product of the 20 monomials of degree <= 3 with a
+    constant matrix (the kernels evaluate the same polynomials term by term, csrc/field.hip)."""
+    global _SH4
+    if _SH4 is None or _SH4.device != d.device:
+        c1, c2a, c2b, c2c = 0.4886025119029199, 1.0925484305920792, 0.31539156525252005, 0.5462742152960396
+        c3a, c3b, c3c, c3d, c3e = 0.5900435899266435, 2.890611442640554, 0.4570457994644658, 0.3731763325901154, 1.445305721320277
+        names = ["1", "x", "y", "z", "xy", "yz", "xz", "xx", "yy", "zz", "xxx", "xyy", "xzz", "yxx", "yyy", "yzz", "zxx", "zyy", "zzz", "xyz"]
+        rows = {n: i for i, n in enumerate(names)}
+        terms = [{"1": 0.28209479177387814}, {"y": -c1}, {"z": c1}, {"x": -c1},
+                 {"xy": c2a}, {"yz": -c2a}, {"zz": 2 * c2b, "xx": -c2b, "yy": -c2b}, {"xz": -c2a}, {"xx": c2c, "yy": -c2c},
+                 {"yxx": -3 * c3a, "yyy": c3a}, {"xyz": c3b}, {"yzz": -4 * c3c, "yxx": c3c, "yyy": c3c}, {"zzz": 2 * c3d, "zxx": -3 * c3d, "zyy": -3 * c3d},
+                 {"xzz": -4 * c3c, "xxx": c3c, "xyy": c3c}, {"zxx": c3e, "zyy": -c3e}, {"xxx": -c3a, "xyy": 3 * c3a}]
+        C = torch.zeros(20, 16, dtype=torch.float64)
+        for k, t in enumerate(terms):
+            for n, v in t.items():
+                C[rows[n], k] = v
+        _SH4 = C.float().to(d.device)
+    x, y, z = d.unbind(-1)
+    xx, yy, zz = x * x, y * y, z * z
+    mono = torch.stack([torch.ones_like(x), x, y, z, x * y, y * z, x * z, xx, yy, zz, x * xx, x * yy, x * zz, y * xx, y * yy, y * zz, z * xx, z * yy, z * zz, x * y * z], dim=-1)
+    return mono @ _SH4
+
+
+class _DensityFunction(Function):
+    """NeRFNetwork.density (network_wtmk_tcnn.py:126-144) as an autograd node towards the selected codebook tables: (sigma [M], geo_feat [M,15])."""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, xyzs, bound, packed, S, sink, tabs, sigma_params, *diff):
+        xyzs = xyzs.contiguous().float()
+        sigmas, _, geo, _ = field_forward(xyzs, None, bound, tabs.base, S, packed, want_rgb=False, want_geo=True)
+        ctx.bound, ctx.n_diff, ctx.sink, ctx.tabs, ctx.S = float(bound), len(diff), sink, tabs, S
+        ctx.save_for_backward(xyzs, sigmas, sigma_params.detach())
+        if sink is not None:
+            sink.selected = list(tabs.sel)
+            ctx.sink_selected = sink.selected
+        return sigmas, geo
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, g_sigma, g_geo):
+        head = (None,) * 7
+        xyzs, sigmas, params = ctx.saved_tensors
+        M, dev = xyzs.shape[0], xyzs.device
+        W1, W2 = params[:2048].view(64, 32), params[2048:3072].view(16, 64)          # tcnn layout: [out][in] row-major (INTEGRATION.md section 3)
+        x01 = (xyzs + ctx.bound) / (2 * ctx.bound)
+        feat = encode(x01, ctx.tabs.base, ctx.S)                                     # the 32 encoder features, codebook included
+        pre = feat @ W1.t()
+        d_so = torch.zeros(M, 16, dtype=torch.float32, device=dev)
+        if g_sigma is not None:      # trunc_exp's backward: g * exp(clamp(h0, -15, 15)) (activation.py:11-15); sigma = exp(h0)
+            d_so[:, 0] = g_sigma.float() * sigmas.clamp(min=3.059023205018258e-07, max=3269017.3724721107)
+        if g_geo is not None:
+            d_so[:, 1:] = g_geo.float()
+        dfeat = (((d_so @ W2) * (pre > 0)) @ W1)[:, 30:32].contiguous()               # the codebook is added into features 30:32 (network_wtmk_tcnn.py:106)
+        if ctx.sink is not None:
+            if isinstance(ctx.sink, SharedGradient):
+                ctx.sink.begin_accumulation(ctx.sink_selected)
+            codebook_scatter(x01, dfeat, ctx.sink.G)
+            return head + (None,) * ctx.n_diff
+        G = torch.zeros(T_ROWS, 2, dtype=torch.float32, device=dev)
+        codebook_scatter(x01, dfeat, G)
+        slab = torch.empty(ctx.n_diff, T_ROWS, 2, dtype=torch.float32, device=dev)
+        grads = [slab[i] for i in range(ctx.n_diff)]
+        fanout_grad(G, grads, accumulate=False)
+        return head + tuple(grads)
+
+
+def density_apply(xyzs, bound, packed, base_tables, selected, S, sink, sigma_params):
+    """(sigma, geo_feat) with autograd to the selected codebook tables (density() under gradients)."""
+    if sink is None:
+        diff = tuple(selected) if any(t.requires_grad for t in selected) else ()
+    else:
+        diff = next(((t,) for t in selected if t.requires_grad), ())
+    return _DensityFunction.apply(xyzs, bound, packed, S, sink, _Tables(base_tables, selected), sigma_params, *diff)
+
+
+class _ColorFunction(Function):
+    """NeRFNetwork.color without the mask (network_wtmk_tcnn.py:147-176) as an autograd node towards geo_feat (the colour MLP is frozen in the watermark stage)."""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, dirs, geo_feat, packed, color_params):
+        rgbs = field_color(dirs, geo_feat, packed)
+        ctx.save_for_backward(dirs.contiguous().float(), geo_feat.contiguous().float(), rgbs, color_params.detach())
+        return rgbs
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, g_rgb):
+        dirs, geo, rgbs, params = ctx.saved_tensors
+        Wc1, Wc2, Wc3 = params[:2048].view(64, 32), params[2048:6144].view(64, 64), params[6144:7168].view(16, 64)
+        cin = torch.cat([sh4_basis(((dirs + 1) / 2) * 2 - 1), geo, torch.ones_like(geo[:, :1])], dim=-1)      # (:166-171: SH of the direction mapped to [0, 1] and back)
+        p1 = cin @ Wc1.t()
+        p2 = torch.relu(p1) @ Wc2.t()
+        d_out = torch.zeros(dirs.shape[0], 16, dtype=torch.float32, device=dirs.device)
+        d_out[:, :3] = g_rgb.float() * rgbs * (1 - rgbs)
+        d_cin = (((d_out @ Wc3) * (p2 > 0)) @ Wc2 * (p1 > 0)) @ Wc1
+        return None, d_cin[:, 16:31].contiguous(), None, None
+
+
+def color_apply(dirs, geo_feat, packed, color_params):
+    return _ColorFunction.apply(dirs, geo_feat, packed, color_params)
+
+
 def field_apply(xyzs, dirs, bound, packed, base_tables, selected, S=None, sink=None, fixed=None):
     """(sigma, rgb) with autograd to the selected codebook tables.  S: their pre-sum (computed here if omitted).
     fixed: the FixedPoints of exactly these points (rays that do not change between steps), or None."""

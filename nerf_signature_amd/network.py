@@ -262,21 +262,24 @@ class NeRFNetwork(NeRFRenderer):
         return rec
 
     def density(self, x, message=None):
-        if torch.is_grad_enabled() and message is not None and any(t.requires_grad for t in self.msg_encoder.tables()):
-            raise NotImplementedError("density()/color() are evaluated without autograd (grid updates, the uniform-sample `run` "
-                                      "path under no_grad); training goes through forward() on the occupancy-grid path")
-        _, _, S = self._select(message)
+        selected, _, S = self._select(message)
+        if torch.is_grad_enabled() and x.is_cuda and len(selected) and any(t.requires_grad for t in selected):
+            # a caller differentiating density() directly (the reference reaches it under autograd from `run`, which goes through the joint field pass here)
+            sigma, geo = fo.density_apply(x, self.bound, self._packed(), self.encoder.tables(), selected, S, self.grad_sink, self.sigma_net.params)
+            return {"sigma": sigma, "geo_feat": geo}
         sigma, _, geo, _ = fo.field_forward(x, None, self.bound, self.encoder.tables(), S, self._packed(), want_rgb=False, want_geo=True)
         return {"sigma": sigma, "geo_feat": geo}
 
     def color(self, x, d, mask=None, geo_feat=None, **kwargs):
+        grad = torch.is_grad_enabled() and geo_feat is not None and geo_feat.requires_grad and d.is_cuda
+        one = (lambda dd, gg: fo.color_apply(dd, gg, self._packed(), self.color_net.params)) if grad else (lambda dd, gg: fo.field_color(dd, gg, self._packed()))
         if mask is not None:
             rgbs = torch.zeros(mask.shape[0], 3, dtype=torch.float32, device=x.device)
             if not mask.any():
                 return rgbs
-            rgbs[mask] = fo.field_color(d[mask], geo_feat[mask], self._packed())
+            rgbs[mask] = one(d[mask], geo_feat[mask])
             return rgbs
-        return fo.field_color(d, geo_feat, self._packed())
+        return one(d, geo_feat)
 
     def get_params(self, lr):
         if self.finetune_decoder:

@@ -577,6 +577,28 @@ def test_bench_under_an_external_launcher_supervises_its_own_worker_and_walks_th
     assert line["value"] is None and [f["attempt"] for f in line["config"]["launch_failures"]] == [0, 1, 2, 3]
 
 
+def test_the_drivers_eight_rank_commands_start_eight_ranks_that_meet():
+    """The two command lines an 8-GPU scaling run can use -- `python bench.py --gpus 8` (bench.py's own launcher) and the driver's `python -m torch.distributed.run
+    --nproc-per-node 8 ... bench.py --gpus 8` (every rank supervising its own worker) -- rehearsed with --dry-launch: eight real processes over gloo, the step's
+    collectives on CPU tensors, eight distinct devices, blocks sharded four per rank, one JSON line from rank 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT", "NERFSIG_CAPTURE_COLLECTIVES", "NERFSIG_TEST_FAIL_CAPTURED")}
+    own = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-launch"]
+    external = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port",
+                str(29800 + os.getpid() % 90), os.path.join(root, "bench.py"), "--gpus", "8", "--dry-launch"]
+    for cmd in (own, external):
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == 8 and line["world_size_seen"] == 8 and line["collectives_ok"] and line["devices_distinct"]
+        assert line["device_of_rank"] == [str(r) for r in range(8)] and line["block_shard_rank0"] == [0, 4]
+
+
 def test_tcnn_layout_checker_recovers_every_hypothesis_and_agrees_with_the_oracle_under_the_documented_one():
     """tools/check_tcnn_layout.py: the checker for the one unpinnable part of the path.  (a) its self-test: each
     of the 48 layout hypotheses is recovered from a dump generated under it, and a transposed / zero-padded checkpoint converts into the
