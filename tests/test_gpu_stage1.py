@@ -160,6 +160,58 @@ def test_device_row_count_entry_points_walk_only_the_live_rows():
     assert float(G2.abs().max()) == 0.0 and float(g_sp2.abs().max()) == 0.0 and float(g_cp2.abs().max()) == 0.0
 
 
+def test_bench_size_step_properties():
+    """VERDICT round 4, weak #8 ("nothing at bench size"): the samples a 4096-ray step of the bench scene really marches (a ray's consecutive samples share cells on the coarse
+    levels: the merged-run path, skewed slices) -- once through the synthetic grid (~140 k points) and once through a grid filled everywhere (what update_extra_state makes of a
+    random field: ~600 k points) -- checked through properties that need no oracle pass of that size: weight gradients against float64 products of the traces the kernel read,
+    the planned table scatter against the record route (every contribution on its own) level by level, bit-reproducibility, linearity of both in the upstream gradient."""
+    from nerf_signature_amd import _native as nv, synthetic
+    from nerf_signature_amd.stage1 import CleanNeRFNetwork
+    m = CleanNeRFNetwork(bound=1.0, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1)
+    with torch.no_grad():
+        for l, e in enumerate(m.encoder.embeddings):
+            e.weight.copy_(torch.from_numpy(synthetic.table_values(l, 0.5)))
+        grid = synthetic.density_grid(1.0)
+        bits, _ = synthetic.pack_bits_np(grid, 10.0)
+        m.density_grid.copy_(torch.from_numpy(grid))
+        m.density_bitfield.copy_(torch.from_numpy(bits))
+    m = m.cuda().train()
+    o, d = synthetic.content_rays("hotdog", 4096, 0, torch.device("cuda"))
+    for full_grid in (False, True):
+        if full_grid:
+            m.density_bitfield.fill_(255)
+        rec = m.march_ahead(o, d, 0, 1024, perturb=False, capacity=128)       # a counting march first: the exact point total
+        n = int(rec["counter"][0])
+        m.drop_marched()
+        from nerf_signature_amd.raymarching import padded_point_count
+        rec = m.march_ahead(o, d, 0, 1024, perturb=False, capacity=padded_point_count(n))
+        assert int(rec["counter"][0]) == n and (n > 500_000 if full_grid else 100_000 < n < 200_000), n
+        pts, dirs = rec["xyzs"][:n].contiguous(), rec["dirs"][:n].contiguous()
+        rng = np.random.RandomState(3)
+        gs = torch.from_numpy((rng.randn(n) * 1e-4).astype(np.float32)).cuda()
+        gc = torch.from_numpy((rng.randn(n, 3) * 1e-4).astype(np.float32)).cuda()
+        tr, g_sp, g_cp, G = _traced_pass(m, pts, dirs, gs, gc)
+        feat = tr.planes[:16, :n].double().permute(0, 2, 1).reshape(32, n)
+        hs, cin, h1, h2 = (a[:, :n].double() for a in tr.act)
+        d_hs, d_so, d_h1, d_h2, d_out = (t[:, :n].double() for t in tr.d)
+        want_s = torch.cat([(d_hs @ feat.t()).reshape(-1), (d_so @ hs.t()).reshape(-1)])
+        want_c = torch.cat([(d_h1 @ cin.t()).reshape(-1), (d_h2 @ h1.t()).reshape(-1), (d_out @ h2.t()).reshape(-1)])
+        assert rel(g_sp, want_s) < 1e-5 and rel(g_cp, want_c) < 1e-5, (n, rel(g_sp, want_s), rel(g_cp, want_c))
+        assert not torch.isnan(G).any()
+        G3 = torch.empty_like(G)
+        scratch = torch.empty(int(nv.fn("hg_scatter_levels_scratch_bytes")(n)), dtype=torch.uint8, device="cuda")
+        nv.call("hg_scatter_levels", nv.ptr(pts), float(m.bound), nv.ptr(tr.d_planes), n, tr.stride, nv.ptr_array([G3[l] for l in range(16)]), nv.ptr(scratch), nv.stream())
+        for l in range(16):
+            assert torch.equal(G[l] != 0, G3[l] != 0), (n, l)
+            assert rel(G[l], G3[l]) < 2e-6, (n, l, rel(G[l], G3[l]))
+        _, g_sp2, g_cp2, G2 = _traced_pass(m, pts, dirs, gs, gc)
+        assert torch.equal(g_sp, g_sp2) and torch.equal(g_cp, g_cp2) and torch.equal(G, G2)
+        _, g_sp4, g_cp4, G4 = _traced_pass(m, pts, dirs, gs * 4, gc * 4)                    # a power of two: exact in every float operation of the chain
+        assert torch.equal(g_sp4, g_sp * 4) and torch.equal(g_cp4, g_cp * 4) and rel(G4, G * 4) < 1e-6
+        m.drop_marched()
+        del tr, G, G2, G3, G4
+
+
 def _adam(m, lr=1e-2):
     return torch.optim.Adam(m.get_params(lr), betas=(0.9, 0.99), eps=1e-15)
 
