@@ -181,6 +181,17 @@ wg_s = timer.us("field_wgrad", n) * 1e-6
 wg_alg_flop = 2 * (64 * 32 + 16 * 64 + 64 * 32 + 64 * 64 + 16 * 64)          # per point: five products d x input^T
 wg_issued_flop = 36 * 32768 / 16                                              # 12 products of 32x32x16 per 16 points, 3 bf16 MFMAs each (split operands)
 wg_bytes = 4 * (64 + 64 + 32 + 32 + 16 + 16 + 64 + 64 + 64 + 64)              # rows of the saved layer inputs / pre-activation gradients read once: 1920 B/point
+# HBM bytes from counters (a separate rocprofv3 --pmc run, tools/pmc_stage1.sh -> profiles/pmc_stage1.json), scaled from that run's point count to this one's
+traffic_scatter = traffic_wgrad = traffic_source = None
+try:
+    pmc = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_stage1.json")))
+    k = pts_e / pmc["points_per_launch"]
+    traffic_wgrad = pmc["k_field_wgrad"]["hbm_bytes_per_launch"] * k
+    traffic_scatter = (pmc["k_level_entries"]["hbm_bytes_per_launch"] + pmc["k_scatter_binned"]["read_bytes"]) * k + pmc["k_scatter_binned"]["write_bytes"]      # (the owners store 16 whole tables whatever the point count)
+    traffic_source = {"file": "profiles/pmc_stage1.json", "round": pmc.get("round"), "commit": pmc.get("commit"), "counters_taken_at_points": pmc["points_per_launch"],
+                      "note": "NOT measured by this run: per-launch bytes of a separate rocprofv3 --pmc run, scaled linearly in the point count (the tables' 64 MiB store excepted)"}
+except Exception:
+    pass
 out = {
     "what": "stage-1 (clean model) training step, SURVEY 8(f) N3: 4096 rays of scene S0, perturbed march, 16-level encoder, both MLPs with saved layer inputs, compositing, MSE, "
             "backward, weight gradients on MFMA, 16-level owner-computes table scatter, Adam over 16 tables + both MLPs (torch.optim.Adam arithmetic), one hipGraph replay per step; "
@@ -195,15 +206,18 @@ out = {
                   "every table row stored once: no zero fill, no global atomics, bit-reproducible)",
         "bound": "hbm", "avg_launch_s": sc_s, "points_per_launch": pts_e, "algorithmic_bytes_per_point": sc_alg,
         "achieved": pts_e * sc_alg / sc_s / 1e9 if sc_s else 0.0, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": pts_e * sc_alg / sc_s / HBM_PEAK if sc_s else 0.0,
+        "traffic": traffic_scatter, "traffic_source": traffic_source, "frac_hbm_counters": (traffic_scatter / sc_s / HBM_PEAK) if (traffic_scatter and sc_s) else None,
         "basis": "the reference's algorithm: 16 x embedding_dense_backward = read-modify-write of 8 rows x 8 B per point and level (2048 B/point) + feature gradients (128) + position (12)",
         "float_atomic_roof": {"added_bytes_per_point": 1024, "peak_GBps": ATOMIC_PEAK / 1e9, "floor_s": pts_e * 1024 / ATOMIC_PEAK,
                               "this_launch_over_floor": (sc_s / (pts_e * 1024 / ATOMIC_PEAK)) if sc_s else None,
                               "note": "a global-float-atomic scatter cannot run faster than floor_s (MI355X_MICROARCH.md: ~1.3 TB/s of added bytes chip-wide); < 1 means the owner scheme beats that roof"},
         "plan_us_off_path": timer.us("hg_levels_plan", n)},
     "roofline_wgrad": {
-        "kernel": "k_field_wgrad (split-K over the points, v_mfma_f32_32x32x16_bf16 on split hi + lo operands, fp32 accumulate, slabs) + k_wgrad_reduce (fixed order)",
+        "kernel": "k_field_wgrad (split-K over the points: tiles of 32 points staged through LDS, one 32x32 product per wave, v_mfma_f32_32x32x16_bf16 on split hi + lo operands, "
+                  "fp32 accumulate, slabs) + k_wgrad_reduce (fixed order)",
         "bound": "hbm", "avg_launch_s": wg_s, "points_per_launch": pts_e, "algorithmic_bytes_per_point": wg_bytes,
         "achieved": pts_e * wg_bytes / wg_s / 1e9 if wg_s else 0.0, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": pts_e * wg_bytes / wg_s / HBM_PEAK if wg_s else 0.0,
+        "traffic": traffic_wgrad, "traffic_source": traffic_source, "frac_hbm_counters": (traffic_wgrad / wg_s / HBM_PEAK) if (traffic_wgrad and wg_s) else None,
         "basis": "every saved layer input and pre-activation gradient row read exactly once (480 floats per point); the products are K = points reductions, 10 FLOP per byte: HBM-bound",
         "mfma": {"algorithmic_flop_per_point": wg_alg_flop, "issued_flop_per_point": wg_issued_flop,
                  "achieved_TFLOPs_issued": pts_e * wg_issued_flop / wg_s / 1e12 if wg_s else 0.0, "frac_of_dense_bf16_peak": pts_e * wg_issued_flop / wg_s / MFMA_PEAK_BF16 if wg_s else 0.0}},
