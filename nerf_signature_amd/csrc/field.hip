@@ -436,9 +436,10 @@ __global__ void __launch_bounds__(256) k_warm_tables(TablePtrs base, const float
 }
 
 // Workgroup (tile, slot) encodes, for its 256 points, the levels (or the part of a level's tile range) assigned to its XCD slot.
+template <bool mixed>      // (the plane layout as a compile-time constant: the destination of a level's features is then one address computation, not a chain of branches per level)
 __global__ void __launch_bounds__(256) k_encode_planes(const float *__restrict__ xyzs, uint32_t M, float bound, TablePtrs base, LevelGeom geom,
                                                        const float *__restrict__ S, float2 *__restrict__ planes, uint32_t stride, SlotTable tab,
-                                                       const uint32_t *__restrict__ rows_dev = nullptr, bool mixed = false) {
+                                                       const uint32_t *__restrict__ rows_dev = nullptr) {
     // rows_dev (the eval loop's bursts, hg_encode_planes_rows): the number of rows that exist is known on the device only; the launch is sized for `M`
     // (the buffers' capacity, which also fixes the plane stride) and rows beyond the count are skipped
     uint32_t lim = stride;
@@ -1196,7 +1197,8 @@ static int encode_planes_impl(const float *xyzs, uint32_t M, float bound, const 
     // tiles per XCD slot handled by distinct workgroups before they start looping: with one tile per workgroup (cap >= tiles) the block
     // render's launch takes 244-247 us against 258-261 us with 1024 looping workgroups per slot (same-box sweep, profiles/r01_k_encoder_grid_sweep.txt)
     const uint32_t per_slot = tiles < 8192u ? tiles : 8192u;
-    k_encode_planes<<<per_slot * 8, 256, 0, as_stream(stream)>>>(xyzs, M, bound, base, make_level_geom(), S, reinterpret_cast<float2 *>(planes), stride, tab, rows_dev, mixed);
+    if (mixed) k_encode_planes<true><<<per_slot * 8, 256, 0, as_stream(stream)>>>(xyzs, M, bound, base, make_level_geom(), S, reinterpret_cast<float2 *>(planes), stride, tab, rows_dev);
+    else k_encode_planes<false><<<per_slot * 8, 256, 0, as_stream(stream)>>>(xyzs, M, bound, base, make_level_geom(), S, reinterpret_cast<float2 *>(planes), stride, tab, rows_dev);
     return check_launch("hg_encode_planes");
 }
 

@@ -57,7 +57,7 @@ def traffic(c):
     return out
 
 
-enc_rows = sorted(((k, v) for k, v in rows.items() if k[0] == "k_encode_planes"), key=lambda kv: -int(kv[0][1]))
+enc_rows = sorted(((k, v) for k, v in rows.items() if k[0].startswith("k_encode_planes") and "codebook" not in k[0]), key=lambda kv: -int(kv[0][1]))
 # the block render's launch: 8 workgroup slots x 1,290,240 rows (the bench workload); larger grids belong to the set-up's clean renders
 enc_block = next((v for k, v in enc_rows if int(k[1]) == 8 * 1290240), None)
 enc_content = next((v for k, v in enc_rows if int(k[1]) < 8 * 1290240), None)
