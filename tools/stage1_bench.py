@@ -142,6 +142,36 @@ say(f"stage-1 captured step ({which}): {n_rays} rays, {pts} points, capacity {lo
     f"{len(clean)} of {windows} windows x {steps} steps ({', '.join(('%.3f' % w['ms_per_step']) + ('*' if w['recaptured'] else '') for w in win)}; * = re-captured inside); "
     f"grid refresh every {refresh} steps inside the windows; loss {loss_last:.4e}; recaptures {loop.recaptures}")
 
+# ---- the same captured loop on the scene's own (sparse) occupancy grid, never refreshed: the sample count a TRAINED scene has (the ball: ~34 samples per ray) instead of
+# the full grid a random field leaves behind
+sparse = None
+if refresh:
+    try:
+        m_s = fresh_model()
+        opt_s = torch.optim.Adam(m_s.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+        loop_s = GraphedCleanLoop(m_s, opt_s, dict(dt_gamma=0, max_steps=1024), n_rays=n_rays, update_extra_interval=0, perturb=True, overlap_plan="--no-overlap" not in flags)
+        loop_s.step(data)
+        for _ in range(15):
+            loop_s.step()
+        torch.cuda.synchronize()
+        ws = []
+        for _ in range(3):
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+            for _ in range(steps):
+                loop_s.step()
+            t1.record()
+            torch.cuda.synchronize()
+            ws.append(t0.elapsed_time(t1) / steps)
+        pts_s = int(loop_s.count_ring[(loop_s.global_step - 1) % 16, 0])
+        sparse = {"ms_per_step": float(np.median(ws)), "windows_ms": ws, "points_per_step": pts_s, "rays_per_s": n_rays / float(np.median(ws)) * 1e3,
+                  "what": "the same captured step on the scene's own occupancy grid, no refresh (the sample count of a trained scene: the ball, ~34 samples per ray)"}
+        say(f"  on the sparse grid (no refresh): {pts_s} points, median {sparse['ms_per_step']:.3f} ms/step = {sparse['rays_per_s']:.3e} rays/s")
+        loop_s.close()
+        del loop_s, m_s, opt_s
+    except Exception as e:      # noqa: BLE001 -- a side figure
+        sparse = {"error": repr(e)}
+
 # ---- the same kernel sequence, eagerly, on one stream, every entry point between HIP events
 n_segments = len(loop.graph.segments) if loop.graph is not None else None
 steps_done, capacity, state = loop.global_step, loop.capacity, {k: v.detach().clone() for k, v in m.state_dict().items()}
@@ -198,7 +228,7 @@ out = {
             "update_extra_state every 16 steps between replays (inside the timed windows)",
     "ms_per_step": ms, "rays_per_s": n_rays / ms * 1e3, "rays": n_rays, "points_per_step": pts, "points_per_s": pts / ms * 1e3, "capacity_rows": capacity,
     "windows": win, "steps_per_window": steps, "grid_refresh_every": refresh, "recaptures": loop.recaptures, "capacity_overflow": bool(overflow), "loss_last": loss_last,
-    "steps_trained": steps_done,
+    "steps_trained": steps_done, "sparse_grid": sparse,
     "eager_one_stream_ms_per_step": t0.elapsed_time(t1) / n, "eager_points_per_step": pts_e,
     "kernels_us_per_step": {k: round(us, 1) for k, _, us in rows},
     "roofline_scatter": {
