@@ -16,7 +16,7 @@ Three ways to drive it:
   * GraphedCleanLoop     the loop body as explicit kernel calls on static buffers, captured once into a hipGraph and replayed:
                          no autograd, no allocation, no host read inside a step; the density grid is refreshed between replays
                          every `update_extra_interval` steps as the reference does; data-parallel ranks exchange ONE flat
-                         buffer [16 table gradients | MLP gradients] per step."""
+                         buffer [16 table gradients | MLP gradients] per step (as two collectives where the tables can then travel beside the weight-gradient reduction)."""
 import contextlib
 import ctypes
 
@@ -348,11 +348,23 @@ class GraphedCleanLoop:
             torch.cuda.current_stream().wait_stream(self.plan_stream)
 
     def _exchange(self):
-        if dp.exchange_active():
-            import torch.distributed as dist
+        """The data-parallel exchange of the flat gradient buffer (SUM; every rank seeded its loss with 1 / world).  Where a collective does not end a captured segment
+        (eager, or captured inside the graph) it is issued in two pieces: the 16 table gradients (64 MiB) right behind the scatter -- they travel while the weight-gradient
+        reduction still runs on the plan's stream, and the tables' Adam pass can follow them -- and the MLP gradients (40 KB) once that reduction has joined.  Between captured
+        segments every forked stream has to join in front of a collective anyway: one buffer, one collective."""
+        if not dp.exchange_active():
+            return
+        import torch.distributed as dist
+        n_tab = 16 * T_ROWS * 2
+        if dp.collective_ends_segment():
             flat = self.flat
             self._join_weight_gradients()           # one buffer, one collective: everything in it has to be there
             dp.collective(lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM), name="all_reduce_stage1_gradients")
+            return
+        tables, mlp = self.flat[:n_tab], self.flat[n_tab:]
+        dp.collective(lambda: dist.all_reduce(tables, op=dist.ReduceOp.SUM), name="all_reduce_stage1_tables")
+        self._join_weight_gradients()
+        dp.collective(lambda: dist.all_reduce(mlp, op=dist.ReduceOp.SUM), name="all_reduce_stage1_mlp")
 
     def _adam(self, params):
         """torch.optim.Adam's update of `params` from their `.grad` views through opt_adam_dense (state in torch's capturable format: device step counts)."""

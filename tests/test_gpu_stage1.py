@@ -325,7 +325,7 @@ class _TwoRanks:
         self.barrier = threading.Barrier(2)
         self.turn = threading.Lock()
         self.slots = [None, None]
-        self.bytes = 0
+        self.bytes, self.calls = [0, 0], [0, 0]      # per rank, over all its calls
 
     def is_initialized(self):
         return True
@@ -349,12 +349,13 @@ class _TwoRanks:
         finally:
             self.turn.acquire()
         t.copy_(parts[0] + parts[1])
-        self.bytes = t.numel() * 4
+        self.bytes[self.local.rank] += t.numel() * 4
+        self.calls[self.local.rank] += 1
 
 
 def test_two_rank_exchange_equals_the_single_process_gradient(monkeypatch):
-    """Two ranks with their own rays, one flat all-reduce (SUM of gradients seeded with 1/world): every rank then holds the gradient of the
-    single-process step on the concatenated batch, and both take the same optimiser step."""
+    """Two ranks with their own rays, the flat gradient buffer all-reduced (SUM of gradients seeded with 1/world; tables and MLP gradients as two collectives in this eager form):
+    every rank then holds the gradient of the single-process step on the concatenated batch, and both take the same optimiser step."""
     import torch.distributed as dist
     from nerf_signature_amd import dp
     from nerf_signature_amd.stage1 import GraphedCleanLoop
@@ -401,7 +402,8 @@ def test_two_rank_exchange_equals_the_single_process_gradient(monkeypatch):
         t.join(timeout=300)
     assert not errors, errors
     (l0, m0), (l1, m1) = results
-    assert group.bytes == l0.flat.numel() * 4 == (16 * (1 << 19) * 2 + 3072 + 7168) * 4
+    # (prepare() runs two warm-up steps in front of the one that counts: three steps' worth; eagerly the buffer travels in two pieces -- tables, then MLP gradients)
+    assert group.bytes[0] == group.bytes[1] == 3 * l0.flat.numel() * 4 == 3 * (16 * (1 << 19) * 2 + 3072 + 7168) * 4 and group.calls == [6, 6]
     assert torch.equal(l0.flat, l1.flat)
     print(f"\ntwo-rank vs single-process stage-1 gradient: rel. L2 tables {rel(l0.g_tables, ref.g_tables):.2e}, sigma MLP {rel(l0.g_sigma, ref.g_sigma):.2e}, "
           f"colour MLP {rel(l0.g_color, ref.g_color):.2e}; loss {0.5 * (float(l0.loss) + float(l1.loss)):.6f} vs {float(ref.loss):.6f}")
