@@ -567,6 +567,19 @@ size_t field_wgrad_scratch_bytes(uint32_t M);
 int field_wgrad(uint32_t M, const uint32_t *rows_dev, const void *planes, const float *act_hs, const float *act_cin, const float *act_h1,
                 const float *act_h2, const float *d_hs, const float *d_so, const float *d_h1, const float *d_h2, const float *d_out,
                 void *scratch, float *grad_sigma_params, float *grad_color_params, nsig_stream_t stream);
+/*
+ * field_bwd_trace(_rows) + field_wgrad in ONE launch (csrc/stage1_fused.hip): the same backward chain (d_planes: the same bits), but every layer's
+ * pre-activation gradient stays on the chip -- transposed through wave-private LDS into MFMA operands over the point dimension -- and the five weight
+ * gradients accumulate in registers over a wave's tiles; only the layer INPUTS (field_fwd_trace's act_*, the encoder planes) are read from memory.
+ * Removes 896 B per point written and read back.  Same outputs as the pair it replaces: d_planes [16][stride] float2, grad_sigma_params [3072],
+ * grad_color_params [7168] (written, tcnn's layout); weight gradients equal to field_wgrad's up to the order of the partial sums, bit-reproducible
+ * (fixed tile -> wave assignment, slabs added in workgroup order).  rows_dev may be NULL (= M points); M >= 1; scratch = field_bwd_wgrad_scratch_bytes(M)
+ * bytes; packed, planes, act_*, d_planes and scratch 16-byte aligned.  Split-bf16 arithmetic like field_bwd_trace (mlp_set_precision does not apply).
+ */
+size_t field_bwd_wgrad_scratch_bytes(uint32_t M);
+int field_bwd_wgrad(uint32_t M, const uint32_t *rows_dev, const float *grad_sigmas, const float *grad_rgbs, const float *sigmas, const float *rgbs,
+                    const uint32_t *masks, const void *packed, const void *planes, const float *act_hs, const float *act_cin, const float *act_h1,
+                    const float *act_h2, void *d_planes, void *scratch, float *grad_sigma_params, float *grad_color_params, nsig_stream_t stream);
 int clean_loss(const float *image, const float *gt, uint32_t n_values, float grad_scale, float *loss, float *grad_image,
                uint32_t *step_dev, const int32_t *march_counter, int32_t *count_ring, float *loss_ring, uint32_t loss_ring_len,
                float *noise_next, uint32_t n_noise, uint64_t seed, nsig_stream_t stream);

@@ -52,21 +52,7 @@ struct WgradArgs {
     const float *d_hs, *d_so, *d_h1, *d_h2, *d_out;     // pre-activation gradients
 };
 
-__device__ inline void split8(const float (&v)[8], Split8 &s) {
-#pragma unroll
-    for (int jp = 0; jp < 4; ++jp) {
-        const uint32_t hi = cvt_pk_bf16(v[2 * jp], v[2 * jp + 1]);
-        s.hi[jp] = hi;
-        s.lo[jp] = cvt_pk_bf16(v[2 * jp] - __uint_as_float(hi << 16), v[2 * jp + 1] - __uint_as_float(hi & 0xffff0000u));
-    }
-}
-
-__device__ inline f32x16 mac3(const Split8 &a, const Split8 &b, f32x16 c) {      // lo parts first, hi * hi last (as Bf16x3::mac)
-    const bf16x8 a_hi = operand(a.hi), a_lo = operand(a.lo), b_hi = operand(b.hi), b_lo = operand(b.lo);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, c, 0, 0, 0);
-}
+// (split8 / mac3: mfma.h)
 
 // What one thread fetches of a tile: up to six 16-byte pieces.  Thread t = 8 g + c takes chunk c (points 4c..4c+3 of the tile) of rows g and g + 32 of every
 // 64-row factor and of row g of every 32-row one; the feature planes are float2 pairs (feature 2l, 2l+1 of level l): thread t = 16 l + c2 takes points
@@ -265,6 +251,12 @@ __global__ void __launch_bounds__(1024) k_clean_loss(const float *__restrict__ i
 
 using namespace nsig;
 
+// slabs[n_wg][3 roles][4 products][16 registers][64 lanes] -> the two parameter gradients (also the tail of field_bwd_wgrad, stage1_fused.hip)
+int nsig::wgrad_reduce_launch(const float *slabs, uint32_t n_wg, float *grad_sigma_params, float *grad_color_params, hipStream_t st, const char *what) {
+    k_wgrad_reduce<<<ceil_div(kWgradRoles * kWgradSlab, 256u), 256, 0, st>>>(slabs, n_wg, grad_sigma_params, grad_color_params);
+    return check_launch(what);
+}
+
 static uint32_t wgrad_workgroups(uint32_t M) {      // pairs of K-steps (32 points), 4 waves per workgroup, >= 2 pairs per wave where there is work
     const uint32_t want = ceil_div(ceil_div(M, 32u), 8u);
     return want < 32u ? 32u : (want > kWgradMaxWGs ? kWgradMaxWGs : want);
@@ -285,8 +277,7 @@ NSIG_EXPORT int field_wgrad(uint32_t M, const uint32_t *rows_dev, const void *pl
     hipStream_t st = as_stream(stream);
     k_field_wgrad<<<dim3(n_wg, kWgradRoles), 256, 0, st>>>(a, stride, M, rows_dev, reinterpret_cast<float *>(scratch));
     if (int e = check_launch("field_wgrad")) return e;
-    k_wgrad_reduce<<<ceil_div(kWgradRoles * kWgradSlab, 256u), 256, 0, st>>>(reinterpret_cast<const float *>(scratch), n_wg, grad_sigma_params, grad_color_params);
-    return check_launch("field_wgrad (reduce)");
+    return wgrad_reduce_launch(reinterpret_cast<const float *>(scratch), n_wg, grad_sigma_params, grad_color_params, st, "field_wgrad (reduce)");
 }
 
 NSIG_EXPORT int clean_loss(const float *image, const float *gt, uint32_t n_values, float grad_scale, float *loss, float *grad_image, uint32_t *step_dev,

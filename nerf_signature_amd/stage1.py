@@ -4,11 +4,13 @@ Mirror of /root/reference/nerf/network_hash.py (NeRFNetwork without codebook / d
 loop body of the stage-1 trainer (/root/reference/nerf/utils.py:469-517 train_step, :852-869 loop with the density-grid
 refresh every `update_extra_interval` steps).
 
-Gradient flow (csrc/field.hip "stage-1", csrc/stage1.hip, csrc/hashgrid.hip "planned variant over the 16 base levels"):
-field_fwd_trace saves each layer's input, field_bwd_trace each layer's pre-activation gradient and the gradient of all 32
-encoder features; field_wgrad reduces the five weight gradients over the points on MFMA; the base-table gradients are one
-planned owner-computes scatter over the 16 levels (hg_levels_plan beside the forward pass, hg_levels_scatter behind the
-backward) -- the counterpart of the reference's 16 embedding_dense_backward calls.
+Gradient flow (csrc/field.hip "stage-1", csrc/stage1_fused.hip, csrc/stage1.hip, csrc/hashgrid.hip "planned variant over the 16 base levels"):
+field_fwd_trace saves each layer's input; field_bwd_wgrad back-propagates, keeps each layer's pre-activation gradient on the chip
+and reduces the five weight gradients over the points on MFMA in the same launch, leaving the gradient of all 32 encoder features
+(fused=False: field_bwd_trace writes the pre-activation gradients out and field_wgrad reads them back -- the two-launch route of
+the first version, kept as the cross-check); the base-table gradients are one planned owner-computes scatter over the 16 levels
+(hg_levels_plan beside the forward pass, hg_levels_scatter behind the backward) -- the counterpart of the reference's 16
+embedding_dense_backward calls.
 
 Three ways to drive it:
   * CleanNeRFNetwork under autograd (any caller, e.g. the reference's own stage-1 Trainer through render());
@@ -45,8 +47,9 @@ def _stride(M):
 class _Traces:
     """The buffers one field pass of `M` points (capacity) leaves for its backward: planes, layer inputs, pre-activation gradients."""
 
-    def __init__(self, M, dev, with_grads=True):
+    def __init__(self, M, dev, with_grads=True, fused=True):
         st = self.stride = _stride(M)
+        self.fused = fused
         f32 = dict(dtype=torch.float32, device=dev)
         self.M = M
         self.planes = torch.empty(17, st, 2, **f32)
@@ -60,8 +63,12 @@ class _Traces:
     def alloc_grads(self):
         f32 = dict(dtype=torch.float32, device=self.sig.device)
         st = self.stride
-        self.d = [torch.empty(w, st, **f32) for w in (64, 16, 64, 64, 16)]              # d_hs, d_so, d_h1, d_h2, d_out
         self.d_planes = torch.empty(16, st, 2, **f32)
+        if self.fused:      # field_bwd_wgrad: the pre-activation gradients never leave the chip
+            self.d = None
+            self.wgrad_scratch = torch.empty(int(nv.fn("field_bwd_wgrad_scratch_bytes")(self.M)), dtype=torch.uint8, device=self.sig.device)
+            return
+        self.d = [torch.empty(w, st, **f32) for w in (64, 16, 64, 64, 16)]              # d_hs, d_so, d_h1, d_h2, d_out
         self.wgrad_scratch = torch.empty(int(nv.fn("field_wgrad_scratch_bytes")(self.M)), dtype=torch.uint8, device=self.sig.device)
 
 
@@ -78,10 +85,14 @@ def _forward_trace(tr, xyzs, dirs, bound, base_ptrs, packed, rows=None):
 
 
 def _backward_trace(tr, g_sigma, g_rgb, packed, g_sigma_params, g_color_params, rows=None, wgrad_stream=None):
-    """MLP backward + the weight gradients (written, not accumulated into); leaves d_planes for the level scatter.
-    wgrad_stream: the weight-gradient reduction is issued there (the caller joins it): it and the table scatter both need the backward's
-    traces and nothing of each other."""
+    """MLP backward + the weight gradients (written, not accumulated into); leaves d_planes for the level scatter.  One launch (tr.fused), or
+    field_bwd_trace + field_wgrad.  wgrad_stream (two-launch route only): the weight-gradient reduction is issued there (the caller joins it): it
+    and the table scatter both need the backward's traces and nothing of each other."""
     s = nv.stream()
+    if tr.fused:
+        nv.call("field_bwd_wgrad", tr.M, nv.ptr(rows), nv.ptr(g_sigma), nv.ptr(g_rgb), nv.ptr(tr.sig), nv.ptr(tr.rgb), nv.ptr(tr.masks), nv.ptr(packed),
+                nv.ptr(tr.planes), *[nv.ptr(a) for a in tr.act], nv.ptr(tr.d_planes), nv.ptr(tr.wgrad_scratch), nv.ptr(g_sigma_params), nv.ptr(g_color_params), s)
+        return
     if rows is None:
         nv.call("field_bwd_trace", tr.M, nv.ptr(g_sigma), nv.ptr(g_rgb), nv.ptr(tr.sig), nv.ptr(tr.rgb), nv.ptr(tr.masks), nv.ptr(packed),
                 *[nv.ptr(t) for t in tr.d], nv.ptr(tr.d_planes), s)
@@ -253,7 +264,7 @@ class GraphedCleanLoop:
     LOSS_RING = 1024
 
     def __init__(self, model, optimizer, render_kwargs, n_rays, sampler=None, update_extra_interval=16, lr_lambda=None, headroom=0.5, perturb=True,
-                 capacity=None, overlap_plan=True, capture=True, seed=0):
+                 capacity=None, overlap_plan=True, capture=True, seed=0, fused_backward=True):
         if not model.cuda_ray:
             raise ValueError("GraphedCleanLoop drives the occupancy-grid path (cuda_ray=True)")
         if model.density_scale != 1:
@@ -299,6 +310,7 @@ class GraphedCleanLoop:
         self.plan_stream = torch.cuda.Stream() if overlap_plan else None
         self.graph, self.tr, self.rec, self.plan = None, None, None, None
         self.capture = bool(capture)      # False: the same explicit kernel sequence issued eagerly every step (tests, debugging)
+        self.fused_backward = bool(fused_backward)      # False: field_bwd_trace + field_wgrad (the latter on the plan's stream) instead of field_bwd_wgrad
         self.global_step = 0
         self.recaptures = 0
         self.bytes_exchanged_per_step = self.flat.numel() * 4 if dp.exchange_active() else 0
@@ -335,8 +347,8 @@ class GraphedCleanLoop:
                 nv.ptr(self.step_dev), nv.ptr(rows), nv.ptr(self.count_ring), nv.ptr(self.loss_ring), self.LOSS_RING, nv.ptr(self.noises), N, self.seed, s)
         nv.call("rm_composite_train_finish_bwd", None, nv.ptr(self.g_image), nv.ptr(tr.sig), nv.ptr(tr.rgb), nv.ptr(rec["deltas"]), nv.ptr(rec["rays"]),
                 nv.ptr(self.ws), nv.ptr(self.image), nv.ptr(self.bg), 0, M, N, self.T_thresh, 1, nv.ptr(self.g_sig), nv.ptr(self.g_rgb), s)
-        # the weight gradients (a latency-bound streaming reduction) run beside the table scatter (store- and LDS-bound) on the plan's stream,
-        # which has long finished the plan by then (stream order: plan, then the weight gradients)
+        # two-launch route: the weight gradients (a streaming reduction) run beside the table scatter (store- and LDS-bound) on the plan's stream,
+        # which has long finished the plan by then (stream order: plan, then the weight gradients); fused: they are done when the backward is
         _backward_trace(tr, self.g_sig, self.g_rgb, self.packed, self.g_sigma, self.g_color, rows=rows, wgrad_stream=self.plan_stream)
         if self.plan_stream is not None:      # the scatter needs the plan: an event recorded behind the plan, not the whole side stream
             main.wait_event(self._plan_done)
@@ -411,7 +423,7 @@ class GraphedCleanLoop:
 
     def _allocate(self):
         dev, M = self.device, self.capacity
-        self.tr = _Traces(M, dev)
+        self.tr = _Traces(M, dev, fused=self.fused_backward)
         self.g_sig = torch.empty(M, dtype=torch.float32, device=dev)
         self.g_rgb = torch.empty(M, 3, dtype=torch.float32, device=dev)
         self.plan = torch.empty(int(nv.fn("hg_levels_plan_bytes")(M)), dtype=torch.uint8, device=dev)

@@ -86,14 +86,15 @@ def test_all_parameter_gradients_vs_oracle():
     print(f"\nworst base-table gradient rel. L2 over the 16 levels: {worst:.2e}")
 
 
-def _traced_pass(m, pts, dirs, gs, gc, capacity=None, rows=None):
-    """forward + backward through the explicit entry points; returns (traces, sigma gradient, colour gradient, table gradients [16,T,2])."""
+def _traced_pass(m, pts, dirs, gs, gc, capacity=None, rows=None, fused=True):
+    """forward + backward through the explicit entry points (fused: field_bwd_wgrad; else field_bwd_trace + field_wgrad); returns (traces, sigma
+    gradient, colour gradient, table gradients [16,T,2])."""
     from nerf_signature_amd import _native as nv, fieldops as fo, stage1
     M = pts.shape[0] if capacity is None else capacity
     dev = pts.device
-    tr = stage1._Traces(M, dev)
+    tr = stage1._Traces(M, dev, fused=fused)
     if capacity is not None:     # poison everything past the live rows: none of it may be read
-        for t in [tr.planes, *tr.act, *tr.d, tr.d_planes]:
+        for t in [tr.planes, *tr.act, *(tr.d or []), tr.d_planes]:
             t.fill_(float("nan"))
     packed = fo.pack_weights(m.sigma_net.params, m.color_net.params)
     base_ptrs = nv.ptr_array([t.detach() for t in m.encoder.tables()])
@@ -116,13 +117,29 @@ def _random_batch(M, seed=0, dev="cuda"):
     return pts, dirs, gs, gc
 
 
+def _fused_equals_two_launches(m, pts, dirs, gs, gc, tr, g_sp, g_cp, G, want_s, want_c):
+    """field_bwd_wgrad against the pair it replaces (whose traces are `tr`): the same backward chain -> d_planes and the tables bit for bit; the weight
+    gradients against the same float64 products (another order of the partial sums); twice the same bits."""
+    M = pts.shape[0]
+    trf, f_sp, f_cp, Gf = _traced_pass(m, pts, dirs, gs, gc, fused=True)
+    assert trf.d is None
+    assert torch.equal(trf.d_planes[:, :M], tr.d_planes[:, :M]) and torch.equal(Gf, G)
+    assert rel(f_sp, want_s) < 1e-5 and rel(f_cp, want_c) < 1e-5, (rel(f_sp, want_s), rel(f_cp, want_c))
+    assert rel(f_sp, g_sp) < 1e-5 and rel(f_cp, g_cp) < 1e-5, (rel(f_sp, g_sp), rel(f_cp, g_cp))      # two summation orders, each within 1e-5 of the float64 products
+    np.testing.assert_allclose(f_cp.cpu().numpy(), want_c.float().cpu().numpy(), rtol=0, atol=2e-5 * float(want_c.abs().max()))
+    assert float(f_cp[6144 + 3 * 64:].abs().max()) == 0.0                          # rows 3..15 of the padded colour head
+    _, f_sp2, f_cp2, _ = _traced_pass(m, pts, dirs, gs, gc, fused=True)
+    assert torch.equal(f_sp, f_sp2) and torch.equal(f_cp, f_cp2)
+
+
 def test_weight_gradients_equal_the_matrix_products_and_are_bit_reproducible():
-    """field_wgrad against float64 products of the very traces it reads; twice the same bits; the planned scatter against the record route."""
+    """field_wgrad against float64 products of the very traces it reads; twice the same bits; the planned scatter against the record route;
+    field_bwd_wgrad (the one-launch route, the default) against all of it."""
     from nerf_signature_amd import _native as nv
     m, _, _ = _clean_model()
     M = 20011
     pts, dirs, gs, gc = _random_batch(M)
-    tr, g_sp, g_cp, G = _traced_pass(m, pts, dirs, gs, gc)
+    tr, g_sp, g_cp, G = _traced_pass(m, pts, dirs, gs, gc, fused=False)
     feat = tr.planes[:16, :M].double().permute(0, 2, 1).reshape(32, M)            # feature 2l + c
     hs, cin, h1, h2 = (a[:, :M].double() for a in tr.act)
     d_hs, d_so, d_h1, d_h2, d_out = (t[:, :M].double() for t in tr.d)
@@ -130,9 +147,10 @@ def test_weight_gradients_equal_the_matrix_products_and_are_bit_reproducible():
     want_c = torch.cat([(d_h1 @ cin.t()).reshape(-1), (d_h2 @ h1.t()).reshape(-1), (d_out @ h2.t()).reshape(-1)])
     assert rel(g_sp, want_s) < 1e-5 and rel(g_cp, want_c) < 1e-5, (rel(g_sp, want_s), rel(g_cp, want_c))      # split bf16 drops lo x lo: 2^-16 per product
     np.testing.assert_allclose(g_cp.cpu().numpy(), want_c.float().cpu().numpy(), rtol=0, atol=2e-5 * float(want_c.abs().max()))
-    _, g_sp2, g_cp2, G2 = _traced_pass(m, pts, dirs, gs, gc)
+    _, g_sp2, g_cp2, G2 = _traced_pass(m, pts, dirs, gs, gc, fused=False)
     assert torch.equal(g_sp, g_sp2) and torch.equal(g_cp, g_cp2) and torch.equal(G, G2)
     assert not torch.isnan(G).any()                                                # every row of every table written
+    _fused_equals_two_launches(m, pts, dirs, gs, gc, tr, g_sp, g_cp, G, want_s, want_c)
     # the record route (hg_scatter_levels) computes the same sums: every contribution on its own there, runs of a cell pre-summed in fp32 on the
     # coarse levels here, and another fixed-point scale -- the same rows, values to fp32 rounding
     G3 = torch.empty_like(G)
@@ -143,20 +161,21 @@ def test_weight_gradients_equal_the_matrix_products_and_are_bit_reproducible():
         assert rel(G[l], G3[l]) < 1e-6, (l, rel(G[l], G3[l]))
 
 
-def test_device_row_count_entry_points_walk_only_the_live_rows():
+@pytest.mark.parametrize("fused", [True, False], ids=["one_launch", "two_launches"])
+def test_device_row_count_entry_points_walk_only_the_live_rows(fused):
     """Buffers of capacity 3 x the live rows, NaN past them: tables bit for bit, MLP gradients to summation order (the split over workgroups follows the capacity)."""
     m, _, _ = _clean_model()
     n, cap = 7013, 21000
     pts, dirs, gs, gc = _random_batch(cap, seed=1)
-    _, g_sp0, g_cp0, G0 = _traced_pass(m, pts[:n].contiguous(), dirs[:n].contiguous(), gs[:n].contiguous(), gc[:n].contiguous())
+    _, g_sp0, g_cp0, G0 = _traced_pass(m, pts[:n].contiguous(), dirs[:n].contiguous(), gs[:n].contiguous(), gc[:n].contiguous(), fused=fused)
     pts[n:], dirs[n:], gs[n:], gc[n:] = float("nan"), float("nan"), float("nan"), float("nan")
     rows = torch.tensor([n, 0], dtype=torch.int32, device="cuda")
-    tr, g_sp1, g_cp1, G1 = _traced_pass(m, pts, dirs, gs, gc, capacity=cap, rows=rows)
+    tr, g_sp1, g_cp1, G1 = _traced_pass(m, pts, dirs, gs, gc, capacity=cap, rows=rows, fused=fused)
     assert torch.equal(G0, G1)
     assert rel(g_sp1, g_sp0) < 1e-6 and rel(g_cp1, g_cp0) < 1e-6
     assert torch.isnan(tr.d_planes[0, cap - 1]).all()                             # the tail was never touched
     rows.zero_()                                                                  # no live row at all: zero gradients, nothing read
-    _, g_sp2, g_cp2, G2 = _traced_pass(m, pts, dirs, gs, gc, capacity=cap, rows=rows)
+    _, g_sp2, g_cp2, G2 = _traced_pass(m, pts, dirs, gs, gc, capacity=cap, rows=rows, fused=fused)
     assert float(G2.abs().max()) == 0.0 and float(g_sp2.abs().max()) == 0.0 and float(g_cp2.abs().max()) == 0.0
 
 
@@ -190,7 +209,7 @@ def test_bench_size_step_properties():
         rng = np.random.RandomState(3)
         gs = torch.from_numpy((rng.randn(n) * 1e-4).astype(np.float32)).cuda()
         gc = torch.from_numpy((rng.randn(n, 3) * 1e-4).astype(np.float32)).cuda()
-        tr, g_sp, g_cp, G = _traced_pass(m, pts, dirs, gs, gc)
+        tr, g_sp, g_cp, G = _traced_pass(m, pts, dirs, gs, gc, fused=False)
         feat = tr.planes[:16, :n].double().permute(0, 2, 1).reshape(32, n)
         hs, cin, h1, h2 = (a[:, :n].double() for a in tr.act)
         d_hs, d_so, d_h1, d_h2, d_out = (t[:, :n].double() for t in tr.d)
@@ -204,10 +223,12 @@ def test_bench_size_step_properties():
         for l in range(16):
             assert torch.equal(G[l] != 0, G3[l] != 0), (n, l)
             assert rel(G[l], G3[l]) < 2e-6, (n, l, rel(G[l], G3[l]))
-        _, g_sp2, g_cp2, G2 = _traced_pass(m, pts, dirs, gs, gc)
+        _, g_sp2, g_cp2, G2 = _traced_pass(m, pts, dirs, gs, gc, fused=False)
         assert torch.equal(g_sp, g_sp2) and torch.equal(g_cp, g_cp2) and torch.equal(G, G2)
+        _fused_equals_two_launches(m, pts, dirs, gs, gc, tr, g_sp, g_cp, G, want_s, want_c)            # the one-launch route (the default) at this size
+        _, f_sp, f_cp, _ = _traced_pass(m, pts, dirs, gs, gc)
         _, g_sp4, g_cp4, G4 = _traced_pass(m, pts, dirs, gs * 4, gc * 4)                    # a power of two: exact in every float operation of the chain
-        assert torch.equal(g_sp4, g_sp * 4) and torch.equal(g_cp4, g_cp * 4) and rel(G4, G * 4) < 1e-6
+        assert torch.equal(g_sp4, f_sp * 4) and torch.equal(g_cp4, f_cp * 4) and rel(G4, G * 4) < 1e-6
         m.drop_marched()
         del tr, G, G2, G3, G4
 
