@@ -19,6 +19,8 @@
 //     k_wgrad_reduce (stage1.hip) adds the slabs in workgroup order and writes tcnn's parameter layout.  Fixed tile -> wave assignment: bit-reproducible.
 // One workgroup per compute unit (48 KiB of split-bf16 backward weights + 4 x 18 KiB of scratch); nothing but d_planes (128 B per point, the table
 // scatter's input) is written per point.
+#include <type_traits>
+
 #include "fieldmlp.h"
 
 namespace nsig {
@@ -39,6 +41,18 @@ struct FusedArgs {
     float *slabs;                           // out: [workgroups][12][16][64] partial sums
 };
 
+// base[uniform + lane]: the wave-uniform part of the index pinned into SGPRs (readfirstlane), the lane part a 32-bit BYTE offset -- the load or store is then
+// `global_load v, v_off, s[base:base+1]`: ONE VGPR of address for all accesses of a request.  Left to itself the compiler folds the lane offset into each
+// access's row base and keeps some 40 such 64-bit lane addresses (80 VGPRs) live over the whole tile loop as loop invariants.  `base` stays the kernel
+// argument it is (a pointer rebuilt from an integer would be a FLAT one).
+template <typename T>
+__device__ inline T *at_uniform(T *base, size_t uniform_elems, uint32_t lane_bytes) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)uniform_elems);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)uniform_elems >> 32));
+    typedef std::conditional_t<std::is_const<T>::value, const char, char> Byte;
+    return reinterpret_cast<T *>(reinterpret_cast<Byte *>(base + (((size_t)hi << 32) | lo)) + lane_bytes);
+}
+
 // ---- a layer input from memory into a wave's scratch: ROWS8 x 8 rows of 32 points; lane 8 g + c takes points 4c..4c+3 of row 8 i + g
 template <int ROWS8>
 struct RowRegs {
@@ -46,9 +60,13 @@ struct RowRegs {
 };
 template <int ROWS8>
 __device__ inline void rows_request(const float *__restrict__ base, uint32_t stride, uint32_t tile, int lane, RowRegs<ROWS8> &x) {
-    const float *at = base + (size_t)(lane >> 3) * stride + (size_t)tile * 32u + 4u * (uint32_t)(lane & 7);
+#ifdef NSIG_FUSED_NOLOAD      // (diagnostic build, tools/_ab_fused.py: the kernel without its layer-input loads)
+    for (int i = 0; i < ROWS8; ++i) x.v[i] = make_float4(1.0f, 2.0f, 3.0f, 4.0f);
+    return;
+#endif
+    const uint32_t off = (uint32_t)(lane >> 3) * stride + 4u * (uint32_t)(lane & 7);
 #pragma unroll
-    for (int i = 0; i < ROWS8; ++i) x.v[i] = *reinterpret_cast<const float4 *>(at + (size_t)(8 * i) * stride);
+    for (int i = 0; i < ROWS8; ++i) x.v[i] = *reinterpret_cast<const float4 *>(at_uniform(base, (size_t)(8 * i) * stride + (size_t)tile * 32u, off * 4u));
 }
 // points at or beyond `live` (of this tile's 32) enter as zeros: stale rows of buffers sized for more points may hold anything, and 0 x NaN is NaN
 template <int ROWS8>
@@ -57,7 +75,9 @@ __device__ inline void rows_stage(float *__restrict__ X, int lane, uint32_t live
 #pragma unroll
     for (int i = 0; i < ROWS8; ++i) {
         float4 v = x.v[i];
-        v.x = c4 < live ? v.x : 0.0f; v.y = c4 + 1u < live ? v.y : 0.0f; v.z = c4 + 2u < live ? v.z : 0.0f; v.w = c4 + 3u < live ? v.w : 0.0f;
+        if (live < 32u) {      // (uniform: only the last tile of all can be partial)
+            v.x = c4 < live ? v.x : 0.0f; v.y = c4 + 1u < live ? v.y : 0.0f; v.z = c4 + 2u < live ? v.z : 0.0f; v.w = c4 + 3u < live ? v.w : 0.0f;
+        }
         *reinterpret_cast<float4 *>(X + (8u * i + g) * kFusedRowFloats + c4) = v;
     }
 }
@@ -66,9 +86,9 @@ struct PlaneRegs {
     float4 v[4];
 };
 __device__ inline void planes_request(const float2 *__restrict__ planes, uint32_t stride, uint32_t tile, int lane, PlaneRegs &x) {
-    const float2 *at = planes + (size_t)(lane >> 4) * stride + (size_t)tile * 32u + 2u * (uint32_t)(lane & 15);
+    const uint32_t off = (uint32_t)(lane >> 4) * stride + 2u * (uint32_t)(lane & 15);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) x.v[i] = *reinterpret_cast<const float4 *>(at + (size_t)(4 * i) * stride);
+    for (int i = 0; i < 4; ++i) x.v[i] = *reinterpret_cast<const float4 *>(at_uniform(planes, (size_t)(4 * i) * stride + (size_t)tile * 32u, off * 8u));
 }
 __device__ inline void planes_stage(float *__restrict__ X, int lane, uint32_t live, const PlaneRegs &x) {
     const uint32_t q = (uint32_t)lane >> 4, c2 = 2u * ((uint32_t)lane & 15u);
@@ -99,6 +119,9 @@ __device__ inline void fetch_operand(const float *__restrict__ rows, uint32_t ro
 // acc[rb][cb] += A(rows 32 rb + r of DY) . B(rows 32 cb + r of X)^T over the tile's 32 points, one K-step (16 points) at a time
 template <int RB, int CB>
 __device__ inline void products(const float *__restrict__ DY, const float *__restrict__ X, uint32_t r, bool a_exists, int h, f32x16 *const (&acc)[RB][CB]) {
+#ifdef NSIG_FUSED_NOPROD      // (diagnostic build: the kernel without its weight-gradient products)
+    return;
+#endif
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         Split8 A[RB], B[CB];
@@ -145,8 +168,15 @@ struct TileIn {      // what a tile's backward starts from
 
 __global__ void __launch_bounds__(256) k_field_bwd_wgrad(FusedArgs a, uint32_t stride, uint32_t M, const uint32_t *__restrict__ rows_dev) {
     typedef Bf16x3 P;
-    __shared__ __attribute__((aligned(16))) char wlds[P::kBwdLds];
-    __shared__ __attribute__((aligned(16))) float scratch[4 * kFusedWaveFloats];
+    // one object, the weights FIRST: their fragments are read at immediate offsets from one lane address, and a DS immediate reaches 64 KiB (behind the 72 KiB
+    // scratch every fragment would need an address register of its own)
+    struct Lds {
+        char w[P::kBwdLds];
+        float scratch[4 * kFusedWaveFloats];
+    };
+    __shared__ __attribute__((aligned(16))) Lds lds_all;
+    char *const wlds = lds_all.w;
+    float *const scratch = lds_all.scratch;
     const uint32_t n = rows_dev != nullptr ? min(M, *rows_dev) : M;
     stage_weights(wlds, a.packed + P::kBwdOffset, (int)P::kBwdLds);
     constexpr size_t kHalf = kBwdBytes;
@@ -176,10 +206,11 @@ __global__ void __launch_bounds__(256) k_field_bwd_wgrad(FusedArgs a, uint32_t s
     uint32_t tile = blockIdx.x * 4u + wid;
     // requests are unconditional (past the wave's last tile: the last tile of all again, never used): see k_field_wgrad on the compiler's wait counts
     TileIn in{};
-    RowRegs<8> x_h2{};
+    RowRegs<8> x_h2{}, x_h1{};
     if (n_tiles != 0) {
         request_in(min(tile, n_tiles - 1u), in);
         rows_request<8>(a.h2, stride, min(tile, n_tiles - 1u), lane, x_h2);
+        rows_request<8>(a.h1, stride, min(tile, n_tiles - 1u), lane, x_h1);
     }
     for (; tile < n_tiles; tile += step) {
         const uint32_t s = tile * 32u + (uint32_t)p;
@@ -200,8 +231,8 @@ __global__ void __launch_bounds__(256) k_field_bwd_wgrad(FusedArgs a, uint32_t s
         }
         const uint32_t mask_s = in.mask_s, mask_c0 = in.mask_c0, mask_c1 = in.mask_c1;
         rows_stage<8>(X, lane, live, x_h2);                  // h2: the input of the colour head
-        RowRegs<8> x_h1;
-        rows_request<8>(a.h1, stride, tile, lane, x_h1);     // (every layer input is requested one layer ahead)
+        RowRegs<4> x_cin;
+        rows_request<4>(a.cin, stride, tile, lane, x_cin);   // (every layer input is requested TWO layers ahead: one layer's arithmetic is shorter than a trip to memory)
 
         // ---- colour head: dWc3 = d_out x h2^T (rows 0..2 of 16)
         if (h == 0) {
@@ -216,7 +247,6 @@ __global__ void __launch_bounds__(256) k_field_bwd_wgrad(FusedArgs a, uint32_t s
         mfma_layer<P, 2, 1>(wlds, kHalf, B0, lane, dout, hid);
         scratch_fence();
         products<1, 2>(DY, X, (uint32_t)p, p < 3, h, {{&acc[6], &acc[7]}});
-        __builtin_amdgcn_sched_barrier(0);
 
         // ---- colour layer 2: dWc2 = d_h2 x h1^T
         apply_mask<P>(hid, mask_c1);
@@ -225,12 +255,11 @@ __global__ void __launch_bounds__(256) k_field_bwd_wgrad(FusedArgs a, uint32_t s
         put_block(DY, 0u, hid[0], p, h);
         put_block(DY, 32u, hid[1], p, h);
         rows_stage<8>(X, lane, live, x_h1);
-        RowRegs<4> x_cin;
-        rows_request<4>(a.cin, stride, tile, lane, x_cin);
+        RowRegs<8> x_hs;
+        rows_request<8>(a.hs, stride, tile, lane, x_hs);
         mfma_layer<P, 2, 4>(wlds, kHalf, B1, lane, b4, hid);
         scratch_fence();
         products<2, 2>(DY, X, (uint32_t)p, true, h, {{&acc[8], &acc[9]}, {&acc[10], &acc[11]}});
-        __builtin_amdgcn_sched_barrier(0);
 
         // ---- colour layer 1: dWc1 = d_h1 x cin^T
         apply_mask<P>(hid, mask_c0);
@@ -239,13 +268,12 @@ __global__ void __launch_bounds__(256) k_field_bwd_wgrad(FusedArgs a, uint32_t s
         put_block(DY, 0u, hid[0], p, h);
         put_block(DY, 32u, hid[1], p, h);
         rows_stage<4>(X, lane, live, x_cin);
-        RowRegs<8> x_hs;
-        rows_request<8>(a.hs, stride, tile, lane, x_hs);
+        PlaneRegs x_pl;
+        planes_request(a.planes, stride, tile, lane, x_pl);
         f32x16 dso[1];
         mfma_layer<P, 1, 4>(wlds, kHalf, B2, lane, b4, dso);      // rows 1..15 = d geo_feat
         scratch_fence();
         products<2, 1>(DY, X, (uint32_t)p, true, h, {{&acc[2]}, {&acc[3]}});
-        __builtin_amdgcn_sched_barrier(0);
 
         // ---- sigma head: dW2s = d_so x hs^T (16 rows)
         typename P::Op dhead[1];
@@ -259,12 +287,11 @@ __global__ void __launch_bounds__(256) k_field_bwd_wgrad(FusedArgs a, uint32_t s
 #pragma unroll
         for (int r = 0; r < 8; ++r) DY[(uint32_t)row_of_reg(h, r) * kFusedRowFloats + p] = head8[r];
         rows_stage<8>(X, lane, live, x_hs);
-        PlaneRegs x_pl;
-        planes_request(a.planes, stride, tile, lane, x_pl);
+        rows_request<8>(a.h2, stride, upcoming, lane, x_h2);      // the next tile's first layer input and inputs
+        request_in(upcoming, in);
         mfma_layer<P, 2, 1>(wlds, kHalf, B3, lane, dhead, hid);
         scratch_fence();
         products<1, 2>(DY, X, (uint32_t)p, p < 16, h, {{&acc[4], &acc[5]}});
-        __builtin_amdgcn_sched_barrier(0);
 
         // ---- sigma layer 1: dW1s = d_hs x feat^T; d feature = W1s^T d_hs
         apply_mask<P>(hid, mask_s);
@@ -273,8 +300,7 @@ __global__ void __launch_bounds__(256) k_field_bwd_wgrad(FusedArgs a, uint32_t s
         put_block(DY, 0u, hid[0], p, h);
         put_block(DY, 32u, hid[1], p, h);
         planes_stage(X, lane, live, x_pl);
-        rows_request<8>(a.h2, stride, upcoming, lane, x_h2);      // the next tile's first layer input and inputs
-        request_in(upcoming, in);
+        rows_request<8>(a.h1, stride, upcoming, lane, x_h1);
         f32x16 dall[1];
         mfma_layer<P, 1, 4>(wlds, kHalf, B4F, lane, b4, dall);      // row f = d feature[f]; registers (r, r+1), r even, hold one level's pair
         scratch_fence();
@@ -283,10 +309,10 @@ __global__ void __launch_bounds__(256) k_field_bwd_wgrad(FusedArgs a, uint32_t s
         for (int r = 0; r < 16; r += 2) {
             float2 v;
             v.x = dall[0][r]; v.y = dall[0][r + 1];
-            a.d_planes[(size_t)(row_of_reg16(h, r) >> 1) * stride + s] = v;
+            // level = (row_of_reg16(h, r) >> 1) = (row_of_reg16(0, r) >> 1) + 2 h: uniform part | lane part
+            *at_uniform(a.d_planes, (size_t)(row_of_reg16(0, r) >> 1) * stride + (size_t)tile * 32u, (2u * (uint32_t)h * stride + (uint32_t)p) * 8u) = v;
         }
         scratch_fence();      // the next tile's staging overwrites what this tile's last operands were read from
-        __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- the workgroup's four waves add their blocks in wave order (four blocks per round through the scratch) and store one slab

@@ -10,7 +10,7 @@ i=0
 for g in "${groups[@]}"; do
   out=$GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_s1_$i
   rm -rf $out
-  timeout -k 10 200 rocprofv3 --pmc $g --kernel-trace --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/tools/stage1_bench.py content --windows 1 --steps 16 > $out.log 2>&1 || { echo "group $i ($g) failed"; tail -5 $out.log; }
+  timeout -k 10 240 rocprofv3 --pmc $g --kernel-trace --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/tools/stage1_bench.py content --windows 2 --steps 64 > $out.log 2>&1 || { echo "group $i ($g) failed"; tail -5 $out.log; }
   dirs+=("$out")
   i=$((i+1))
 done

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Stage-1 (clean model) training step on the bench scene: 4096 rays, all parameters trainable.
 
-    python tools/stage1_bench.py [content|block] [--eager] [--steps K] [--windows W] [--no-refresh] [--json]
+    python tools/stage1_bench.py [content|block] [--eager] [--steps K] [--windows W] [--no-refresh] [--two-launch] [--json]
 
 Default: the captured loop (stage1.GraphedCleanLoop), perturbed samples, the density grid refreshed every 16 steps INSIDE the timed
 windows (the reference's loop does it there, nerf/utils.py:852-857).  W windows of K steps each; a window in which the loop had to grow
@@ -9,6 +9,7 @@ its buffers and capture again is reported but left out of the median.  Behind th
 eagerly on ONE stream with HIP events around every entry point (nothing runs beside the timed kernel): the per-kernel table and the two
 roofline records -- the 16-level table scatter and the weight-gradient reduction.
 --json: one JSON line on stdout (bench.py's `secondary.stage1`).
+--two-launch: field_bwd_trace + field_wgrad (the first version's backward) instead of the one-launch field_bwd_wgrad.
 --eager: the autograd loop (stage1.CleanLoop) with the per-entry-point breakdown."""
 import json
 import os
@@ -118,7 +119,9 @@ if "--eager" in flags:
     sys.exit(0)
 
 refresh = 0 if "--no-refresh" in flags else 16
-loop = GraphedCleanLoop(m, opt, dict(dt_gamma=0, max_steps=1024), n_rays=n_rays, update_extra_interval=refresh, perturb=True, overlap_plan="--no-overlap" not in flags)
+fused = "--two-launch" not in flags
+loop = GraphedCleanLoop(m, opt, dict(dt_gamma=0, max_steps=1024), n_rays=n_rays, update_extra_interval=refresh, perturb=True, overlap_plan="--no-overlap" not in flags,
+                        fused_backward=fused)
 loop.step(data)
 for _ in range(31):
     loop.step()
@@ -149,7 +152,8 @@ if refresh:
     try:
         m_s = fresh_model()
         opt_s = torch.optim.Adam(m_s.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
-        loop_s = GraphedCleanLoop(m_s, opt_s, dict(dt_gamma=0, max_steps=1024), n_rays=n_rays, update_extra_interval=0, perturb=True, overlap_plan="--no-overlap" not in flags)
+        loop_s = GraphedCleanLoop(m_s, opt_s, dict(dt_gamma=0, max_steps=1024), n_rays=n_rays, update_extra_interval=0, perturb=True, overlap_plan="--no-overlap" not in flags,
+                                  fused_backward=fused)
         loop_s.step(data)
         for _ in range(15):
             loop_s.step()
@@ -179,7 +183,8 @@ loop.close()
 m2 = fresh_model()
 m2.load_state_dict(state)
 opt2 = torch.optim.Adam(m2.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
-eager = GraphedCleanLoop(m2, opt2, dict(dt_gamma=0, max_steps=1024), n_rays=n_rays, update_extra_interval=0, perturb=True, overlap_plan=False, capture=False, capacity=capacity)
+eager = GraphedCleanLoop(m2, opt2, dict(dt_gamma=0, max_steps=1024), n_rays=n_rays, update_extra_interval=0, perturb=True, overlap_plan=False, capture=False, capacity=capacity,
+                         fused_backward=fused)
 eager.step(data)
 for _ in range(3):
     eager.step()
@@ -207,16 +212,21 @@ sc_s = timer.us("hg_levels_scatter", n) * 1e-6
 sc_alg = 2048 + 128 + 12
 # implemented: queue entries written and read once (16 B each: 4 per point on the 6 plain levels, 2 per run and (dy, dz) pair on the 10 merged ones -- counted as
 # the upper bound 4 per point here), feature gradients + positions per level, every table row stored once by its owner
-wg_s = timer.us("field_wgrad", n) * 1e-6
+# Weight gradients.  One launch (default): field_bwd_wgrad = the MLP backward + the five products; what it must touch per point: the saved layer inputs (224 floats) +
+# the encoder planes (32) read once, the backward's own inputs (upstream gradients, outputs, ReLU masks: 56 B), the feature gradients written (128 B).  Two launches
+# (--two-launch): field_wgrad alone reads the layer inputs AND the pre-activation gradients field_bwd_trace wrote (480 floats).
+wg_name = "field_bwd_wgrad" if fused else "field_wgrad"
+wg_s = timer.us(wg_name, n) * 1e-6
 wg_alg_flop = 2 * (64 * 32 + 16 * 64 + 64 * 32 + 64 * 64 + 16 * 64)          # per point: five products d x input^T
-wg_issued_flop = 36 * 32768 / 16                                              # 12 products of 32x32x16 per 16 points, 3 bf16 MFMAs each (split operands)
-wg_bytes = 4 * (64 + 64 + 32 + 32 + 16 + 16 + 64 + 64 + 64 + 64)              # rows of the saved layer inputs / pre-activation gradients read once: 1920 B/point
+chain_mfma = 3 * (2 + 8 + 4 + 2 + 4)                                          # the backward chain per 32 points: 20 products of 32x32x16, 3 bf16 MFMAs each (split operands)
+wg_issued_flop = (36 * 2 + (chain_mfma if fused else 0)) * 32768 / 32         # + 12 weight-gradient blocks x 2 K-steps x 3 MFMAs per 32 points
+wg_bytes = (4 * (64 + 32 + 64 + 64) + 128 + 56 + 128) if fused else 4 * (64 + 64 + 32 + 32 + 16 + 16 + 64 + 64 + 64 + 64)      # 1208 | 1920 B/point
 # HBM bytes from counters (a separate rocprofv3 --pmc run, tools/pmc_stage1.sh -> profiles/pmc_stage1.json), scaled from that run's point count to this one's
 traffic_scatter = traffic_wgrad = traffic_source = None
 try:
     pmc = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_stage1.json")))
     k = pts_e / pmc["points_per_launch"]
-    traffic_wgrad = pmc["k_field_wgrad"]["hbm_bytes_per_launch"] * k
+    traffic_wgrad = pmc["k_field_bwd_wgrad" if fused else "k_field_wgrad"]["hbm_bytes_per_launch"] * k
     traffic_scatter = (pmc["k_level_entries"]["hbm_bytes_per_launch"] + pmc["k_scatter_binned"]["read_bytes"]) * k + pmc["k_scatter_binned"]["write_bytes"]      # (the owners store 16 whole tables whatever the point count)
     traffic_source = {"file": "profiles/pmc_stage1.json", "round": pmc.get("round"), "commit": pmc.get("commit"), "counters_taken_at_points": pmc["points_per_launch"],
                       "note": "NOT measured by this run: per-launch bytes of a separate rocprofv3 --pmc run, scaled linearly in the point count (the tables' 64 MiB store excepted)"}
@@ -224,7 +234,7 @@ except Exception:
     pass
 out = {
     "what": "stage-1 (clean model) training step, SURVEY 8(f) N3: 4096 rays of scene S0, perturbed march, 16-level encoder, both MLPs with saved layer inputs, compositing, MSE, "
-            "backward, weight gradients on MFMA, 16-level owner-computes table scatter, Adam over 16 tables + both MLPs (torch.optim.Adam arithmetic), one hipGraph replay per step; "
+            "backward with the weight gradients inside (MFMA), 16-level owner-computes table scatter, Adam over 16 tables + both MLPs (torch.optim.Adam arithmetic), one hipGraph replay per step; "
             "update_extra_state every 16 steps between replays (inside the timed windows)",
     "ms_per_step": ms, "rays_per_s": n_rays / ms * 1e3, "rays": n_rays, "points_per_step": pts, "points_per_s": pts / ms * 1e3, "capacity_rows": capacity,
     "windows": win, "steps_per_window": steps, "grid_refresh_every": refresh, "recaptures": loop.recaptures, "capacity_overflow": bool(overflow), "loss_last": loss_last,
@@ -243,12 +253,20 @@ out = {
                               "note": "a global-float-atomic scatter cannot run faster than floor_s (MI355X_MICROARCH.md: ~1.3 TB/s of added bytes chip-wide); < 1 means the owner scheme beats that roof"},
         "plan_us_off_path": timer.us("hg_levels_plan", n)},
     "roofline_wgrad": {
-        "kernel": "k_field_wgrad (split-K over the points: tiles of 32 points staged through LDS, one 32x32 product per wave, v_mfma_f32_32x32x16_bf16 on split hi + lo operands, "
-                  "fp32 accumulate, slabs) + k_wgrad_reduce (fixed order)",
+        "kernel": ("k_field_bwd_wgrad (the MLP backward with the weight gradients inside: each layer's pre-activation gradient transposed through wave-private LDS into MFMA operands over "
+                   "the points, the layer inputs staged from memory two layers ahead, 12 accumulator blocks per wave in AGPRs over all its tiles, v_mfma_f32_32x32x16_bf16 on split hi + lo "
+                   "operands, fp32 accumulate; one wave per SIMD) + k_wgrad_reduce (slabs in workgroup order)") if fused else
+                  ("k_field_wgrad (split-K over the points: tiles of 32 points staged through LDS, one 32x32 product per wave, v_mfma_f32_32x32x16_bf16 on split hi + lo operands, "
+                   "fp32 accumulate, slabs) + k_wgrad_reduce (fixed order)"),
+        "entry_point": wg_name,
         "bound": "hbm", "avg_launch_s": wg_s, "points_per_launch": pts_e, "algorithmic_bytes_per_point": wg_bytes,
         "achieved": pts_e * wg_bytes / wg_s / 1e9 if wg_s else 0.0, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": pts_e * wg_bytes / wg_s / HBM_PEAK if wg_s else 0.0,
         "traffic": traffic_wgrad, "traffic_source": traffic_source, "frac_hbm_counters": (traffic_wgrad / wg_s / HBM_PEAK) if (traffic_wgrad and wg_s) else None,
-        "basis": "every saved layer input and pre-activation gradient row read exactly once (480 floats per point); the products are K = points reductions, 10 FLOP per byte: HBM-bound",
+        "basis": ("every saved layer input row and encoder plane read exactly once (256 floats per point), the backward's inputs (56 B) read, the feature gradients (128 B) written; the "
+                  "pre-activation gradients never leave the chip.  What binds the launch is neither roof: one wave per SIMD (192 accumulator registers, 120 KiB of LDS per workgroup) "
+                  "runs the backward chain's dependent MFMA -> VALU -> LDS sequences unhidden (tools/_ab_fused.py: 163 us without the loads, 102 us without loads and products, at 673 k points)")
+                 if fused else "every saved layer input and pre-activation gradient row read exactly once (480 floats per point); the products are K = points reductions, 10 FLOP per byte: HBM-bound",
+        "replaces_us_per_step": None if not fused else {"note": "field_bwd_trace_rows + field_wgrad of the two-launch route (--two-launch), round-5 record at 620 k points", "us": 157.9 + 298.4},
         "mfma": {"algorithmic_flop_per_point": wg_alg_flop, "issued_flop_per_point": wg_issued_flop,
                  "achieved_TFLOPs_issued": pts_e * wg_issued_flop / wg_s / 1e12 if wg_s else 0.0, "frac_of_dense_bf16_peak": pts_e * wg_issued_flop / wg_s / MFMA_PEAK_BF16 if wg_s else 0.0}},
     "exchange": {"bytes_per_step": loop.bytes_exchanged_per_step, "segments": n_segments} if "--rccl1" in flags else None,
