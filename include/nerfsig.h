@@ -573,7 +573,7 @@ int field_wgrad(uint32_t M, const uint32_t *rows_dev, const void *planes, const 
  * gradients accumulate in registers over a wave's tiles; only the layer INPUTS (field_fwd_trace's act_*, the encoder planes) are read from memory.
  * Removes 896 B per point written and read back.  Same outputs as the pair it replaces: d_planes [16][stride] float2, grad_sigma_params [3072],
  * grad_color_params [7168] (written, tcnn's layout); weight gradients equal to field_wgrad's up to the order of the partial sums, bit-reproducible
- * (fixed tile -> wave assignment, slabs added in workgroup order).  rows_dev may be NULL (= M points); M >= 1; scratch = field_bwd_wgrad_scratch_bytes(M)
+ * (fixed tile -> wave assignment, slabs added in workgroup order).  rows_dev may be NULL (= M points); 1 <= M <= 2^27; scratch = field_bwd_wgrad_scratch_bytes(M)
  * bytes; packed, planes, act_*, d_planes and scratch 16-byte aligned.  Split-bf16 arithmetic like field_bwd_trace (mlp_set_precision does not apply).
  */
 size_t field_bwd_wgrad_scratch_bytes(uint32_t M);

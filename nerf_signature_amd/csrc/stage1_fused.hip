@@ -346,7 +346,7 @@ NSIG_EXPORT int field_bwd_wgrad(uint32_t M, const uint32_t *rows_dev, const floa
                                 const float *act_h2, void *d_planes, void *scratch, float *grad_sigma_params, float *grad_color_params, nsig_stream_t stream) {
     NSIG_REQUIRE(grad_sigmas && grad_rgbs && sigmas && rgbs && masks && packed && planes && act_hs && act_cin && act_h1 && act_h2 && d_planes && scratch &&
                  grad_sigma_params && grad_color_params, "field_bwd_wgrad: null pointer");
-    NSIG_REQUIRE(M >= 1 && M < (1u << 28), "field_bwd_wgrad: M=%u out of range", M);
+    NSIG_REQUIRE(M >= 1 && M <= (1u << 27), "field_bwd_wgrad: M=%u out of range (1 .. 2^27: the lane part of an address is a 32-bit byte offset of up to 28 x stride)", M);
     const void *all[] = {packed, planes, act_hs, act_cin, act_h1, act_h2, d_planes, scratch};
     for (const void *q : all) NSIG_REQUIRE((reinterpret_cast<uintptr_t>(q) & 15) == 0, "field_bwd_wgrad: packed, planes, the layer inputs, d_planes and scratch must be 16-byte aligned");
     const uint32_t stride = ceil_div(M, 32u) * 32u, n_wg = fused_workgroups(M);

@@ -48,6 +48,15 @@ def test_argument_validation_needs_no_gpu(native):
         native.call("rm_morton3D", None, 4, None, None)
     with pytest.raises(ValueError, match="out of range"):
         native.call("hg_codebook_presum", (native._vp * 1)(), 0, native._vp(16), None)
+    # field_bwd_wgrad (the fused stage-1 backward): null pointers and its point range (32-bit lane byte offsets) are refused before anything is launched
+    d = native._vp(256)
+    with pytest.raises(ValueError, match="null pointer"):
+        native.call("field_bwd_wgrad", 64, None, None, d, d, d, d, d, d, d, d, d, d, d, d, d, d, None)
+    with pytest.raises(ValueError, match="out of range"):
+        native.call("field_bwd_wgrad", (1 << 27) + 1, None, d, d, d, d, d, d, d, d, d, d, d, d, d, d, d, None)
+    with pytest.raises(ValueError, match="16-byte aligned"):
+        native.call("field_bwd_wgrad", 64, None, d, d, d, d, d, d, native._vp(264), d, d, d, d, d, d, d, d, None)
+    assert native.fn("field_bwd_wgrad_scratch_bytes")(1) == 12 * 1024 * 4 and native.fn("field_bwd_wgrad_scratch_bytes")(10 ** 6) == 256 * 12 * 1024 * 4
 
 
 def test_missing_library_fails_loudly(native, monkeypatch):
