@@ -275,7 +275,8 @@ int mlp_set_precision(int mode);
 /* Which launches evaluate the MLPs of the TRAINING render at fp16 precision: bit 0 set = the forward (all 17 planes in, sigma + rgb + masks out)
  * runs software-pipelined over a wave's tiles (next tile's inputs requested and the previous tile's results stored at a tile's head, every layer's
  * weight fragments fetched from LDS in one burst); bit 1 set = the planned backward likewise.  Cleared bits select the plain per-tile loops.
- * Results are bit-identical either way (tests/test_gpu_field.py); default 3, or from NERFSIG_FWD_PIPELINE / NERFSIG_BWD_PIPELINE = 0.
+ * Bit 0 also selects the stage-1 forward's launch (field_fwd_trace(_rows): inputs of the next tile requested in front of a tile's ~100 trace stores).
+ * Results are bit-identical either way (tests/test_gpu_field.py, tests/test_gpu_stage1.py); default 3.
  * No counterpart in the reference (tinycudann's fully fused MLP is one fixed kernel). */
 int mlp_get_pipelined(void);
 int mlp_set_pipelined(int mask);
@@ -517,7 +518,7 @@ int wm_distort_geom_bwd(const float *grad_out, const float *img, uint32_t B, uin
  * The clean model of stage 1 (nerf/network_hash.py) trains everything: base tables and both MLPs (:154-166).
  * field_fwd_trace = field_fwd on pre-encoded planes (no codebook) that also saves each layer's input, feature-major
  * [width][stride] fp32 with stride = M rounded up to 32: act_hs [64], act_cin [32] (16 SH, 15 geometry features, the
- * padded 1.0), act_h1 [64], act_h2 [64].  field_bwd_trace back-propagates (dL/dsigma, dL/drgb) and writes every
+ * padded 1.0), act_h1 [64], act_h2 [64]; M <= 2^26 for the trace entry points.  field_bwd_trace back-propagates (dL/dsigma, dL/drgb) and writes every
  * layer's pre-activation gradient (d_hs [64], d_so [16], d_h1 [64], d_h2 [64], d_out [16]; same layout) and the gradient
  * of all 32 encoder features as level-major planes d_planes [16][stride] float2.  The weight gradients are then plain
  * GEMMs over the point dimension (d_pre x act^T, left to the BLAS library); hg_scatter_level scatters one level's
@@ -573,7 +574,7 @@ int field_wgrad(uint32_t M, const uint32_t *rows_dev, const void *planes, const 
  * gradients accumulate in registers over a wave's tiles; only the layer INPUTS (field_fwd_trace's act_*, the encoder planes) are read from memory.
  * Removes 896 B per point written and read back.  Same outputs as the pair it replaces: d_planes [16][stride] float2, grad_sigma_params [3072],
  * grad_color_params [7168] (written, tcnn's layout); weight gradients equal to field_wgrad's up to the order of the partial sums, bit-reproducible
- * (fixed tile -> wave assignment, slabs added in workgroup order).  rows_dev may be NULL (= M points); 1 <= M <= 2^27; scratch = field_bwd_wgrad_scratch_bytes(M)
+ * (fixed tile -> wave assignment, slabs added in workgroup order).  rows_dev may be NULL (= M points); 1 <= M <= 2^26; scratch = field_bwd_wgrad_scratch_bytes(M)
  * bytes; packed, planes, act_*, d_planes and scratch 16-byte aligned.  Split-bf16 arithmetic like field_bwd_trace (mlp_set_precision does not apply).
  */
 size_t field_bwd_wgrad_scratch_bytes(uint32_t M);

@@ -496,6 +496,74 @@ __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyz
     }
 }
 
+// field_fwd_trace's launch: k_field_fwd<Bf16x3, 1, true> -- the same arithmetic, instruction for instruction: the same bits in every output -- with its inputs
+// software-pipelined.  The plain loop asks for a tile's 8 feature planes at the tile's head and for its direction in the middle of the tile; loads return in
+// order, so the planes wait for the ~100 trace stores of the previous tile to be acknowledged and the direction for the 32 stores of the sigma layer in front of it
+// (counters, 718 k points: 54 % of the wave cycles in s_waitcnt).  Here the NEXT tile's planes and direction are requested at a tile's head, in front of all of the
+// tile's stores: they are there when the next tile begins.  Requests are unconditional (past a wave's last tile: the launch's last tile again, never used).
+__global__ void __launch_bounds__(256) k_field_fwd_trace(const float *__restrict__ dirs, uint32_t M, const float2 *__restrict__ planes, uint32_t stride,
+                                                         const char *__restrict__ packed, float *__restrict__ sigmas, float *__restrict__ rgbs,
+                                                         uint32_t *__restrict__ masks, ActTrace trace, const uint32_t *__restrict__ rows_dev) {
+    typedef Bf16x3 P;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    if (rows_dev != nullptr) {      // (field_fwd_trace_rows)
+        const uint32_t r = *rows_dev;
+        if (r == 0) return;
+        M = min(M, r);
+    }
+    stage_weights(lds, packed + P::kFwdOffset, (int)P::kFwdLds);
+    constexpr size_t kHalf = kFwdBytes;
+    const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
+    const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t n_tiles = ceil_div(M, 32u), step = gridDim.x * 4u;
+    typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+    float2 nf[8];
+    f32x3u nd;
+    auto request = [&](uint32_t tl) {
+        const uint32_t s = tl * 32 + p, sl = min(s, M - 1);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) nf[q] = planes[(size_t)(8 * (q >> 2) + (q & 3) + 4 * h) * stride + s];      // lane half 0 owns levels {0..3, 8..11}, half 1 {4..7, 12..15}
+        nd = *reinterpret_cast<const f32x3u *>(dirs + 3 * (size_t)sl);
+    };
+    uint32_t tile = blockIdx.x * 4u + wid;
+    request(min(tile, n_tiles - 1u));
+    for (; tile < n_tiles; tile += step) {
+        const uint32_t s = tile * 32 + p;
+        const bool live = s < M;
+        float fx[8], fy[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { fx[q] = nf[q].x; fy[q] = nf[q].y; }
+        float dx = nd.x, dy = nd.y, dz = nd.z;
+        // compiler barrier that consumes the inputs: the wait for them stands here, in front of the request and the stores below
+        asm volatile("" : "+v"(fx[0]), "+v"(fx[1]), "+v"(fx[2]), "+v"(fx[3]), "+v"(fx[4]), "+v"(fx[5]), "+v"(fx[6]), "+v"(fx[7]), "+v"(fy[0]), "+v"(fy[1]), "+v"(fy[2]),
+                     "+v"(fy[3]), "+v"(fy[4]), "+v"(fy[5]), "+v"(fy[6]), "+v"(fy[7]), "+v"(dx), "+v"(dy), "+v"(dz) :: "memory");
+        request(min(tile + step, n_tiles - 1u));
+        asm volatile("" ::: "memory");
+
+        typename P::Op feat[2];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) P::put2(feat[q >> 2], q & 3, fx[q], fy[q]);
+        f32x16 hid[2];
+        typename P::Op b4[4];
+        mfma_layer<P, 2, 2>(lds, kHalf, F0, lane, feat, hid);
+        const uint32_t mask_s = relu_to_operand<P>(hid, b4);
+        store_rows64(trace.hs, stride, s, h, hid, [](float v, int) { return v > 0.0f ? v : 0.0f; });
+        f32x16 so[1];
+        mfma_layer<P, 1, 4>(lds, kHalf, F1, lane, b4, so);
+        if (live && h == 0) sigmas[s] = expf(so[0][0]);  // trunc_exp forward (activation.py:9)
+        uint32_t mask_c[2] = {0u, 0u};
+        float geo8[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) geo8[r] = so[0][r];
+        if (h == 0) geo8[0] = 1.0f;  // the slot of row 0 carries the padded constant input (weight column 31)
+        float rgb[3];
+        color_branch<P>(lds, lane, h, dx, dy, dz, geo8, mask_c, rgb, &trace, stride, s);
+        if (live && h == 0) { rgbs[3 * (size_t)s] = rgb[0]; rgbs[3 * (size_t)s + 1] = rgb[1]; rgbs[3 * (size_t)s + 2] = rgb[2]; }
+        uint32_t *mrow = masks + (size_t)tile * 192 + lane;
+        mrow[0] = mask_s; mrow[64] = mask_c[0]; mrow[128] = mask_c[1];
+    }
+}
+
 // NeRFNetwork.color: geo features come from memory instead of the sigma head.
 template <typename P>
 __global__ void __launch_bounds__(256) k_field_color(const float *__restrict__ dirs, const float *__restrict__ geo, uint32_t M,
@@ -867,8 +935,8 @@ NSIG_EXPORT int mlp_pack_weights(const float *sigma_params, const float *color_p
 }
 
 // Bit 0: the training render's forward goes through k_field_fwd_train, bit 1: its planned backward through k_field_bwd_train (the software-pipelined
-// launches; results bit-identical to the plain loops k_field_fwd<F16, 1> / k_field_bwd<F16>).  Default both; mlp_set_pipelined() selects the
-// plain loops (the bit-identity test does).
+// launches; results bit-identical to the plain loops k_field_fwd<F16, 1> / k_field_bwd<F16>); bit 0 also selects k_field_fwd_trace for field_fwd_trace(_rows)
+// (plain loop: k_field_fwd<Bf16x3, 1, true>, the same bits).  Default both; mlp_set_pipelined() selects the plain loops (the bit-identity tests do).
 static int g_mlp_pipelined = 3;
 static int mlp_pipelined() {
     return g_mlp_pipelined;
@@ -1089,14 +1157,19 @@ static int fwd_trace_impl(const float *xyzs, const float *dirs, uint32_t M, cons
     if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(xyzs && dirs && packed && planes && sigmas && rgbs && masks && act_hs && act_cin && act_h1 && act_h2, "field_fwd_trace: null pointer");
     NSIG_REQUIRE(bound > 0.0f, "field_fwd_trace: bound must be positive");
+    NSIG_REQUIRE(M <= (1u << 26), "field_fwd_trace: M=%u out of range (<= 2^26: the lane part of a trace address is a 32-bit byte offset of up to 32 x stride)", M);
     TablePtrs base{};
     if (int e = fill_base_tables(base_tables_host, base, "field_fwd_trace")) return e;
     const uint32_t stride = ceil_div(M, 32u) * 32u;
     ActTrace tr{act_hs, act_cin, act_h1, act_h2};
-    k_field_fwd<Bf16x3, 1, true><<<field_grid(M), 256, Bf16x3::kFwdLds, as_stream(stream)>>>(xyzs, dirs, M, bound, base, make_level_geom(), nullptr,
-                                                                                     reinterpret_cast<const float2 *>(planes), stride,
-                                                                                     reinterpret_cast<const char *>(packed), sigmas, rgbs, nullptr, masks, tr,
-                                                                                     rows_dev);
+    if (!fwd_pipelined())      // (mlp_set_pipelined bit 0 clear: the generic kernel's trace variant, the cross-check of tests/test_gpu_stage1.py)
+        k_field_fwd<Bf16x3, 1, true><<<field_grid(M), 256, Bf16x3::kFwdLds, as_stream(stream)>>>(xyzs, dirs, M, bound, base, make_level_geom(), nullptr,
+                                                                                         reinterpret_cast<const float2 *>(planes), stride,
+                                                                                         reinterpret_cast<const char *>(packed), sigmas, rgbs, nullptr, masks, tr,
+                                                                                         rows_dev);
+    else
+        k_field_fwd_trace<<<field_grid(M), 256, Bf16x3::kFwdLds, as_stream(stream)>>>(dirs, M, reinterpret_cast<const float2 *>(planes), stride,
+                                                                              reinterpret_cast<const char *>(packed), sigmas, rgbs, masks, tr, rows_dev);
     return check_launch("field_fwd_trace");
 }
 
@@ -1119,6 +1192,7 @@ static int bwd_trace_impl(uint32_t M, const uint32_t *rows_dev, const float *gra
     if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(grad_sigmas && grad_rgbs && sigmas && rgbs && masks && packed && d_hs && d_so && d_h1 && d_h2 && d_out && d_planes,
                  "field_bwd_trace: null pointer");
+    NSIG_REQUIRE(M <= (1u << 26), "field_bwd_trace: M=%u out of range (<= 2^26: the lane part of a trace address is a 32-bit byte offset of up to 32 x stride)", M);
     const uint32_t stride = ceil_div(M, 32u) * 32u;
     GradTrace gt{d_hs, d_h1, d_h2, d_so, d_out, reinterpret_cast<float2 *>(d_planes)};
     k_field_bwd<Bf16x3, true><<<field_grid(M), 256, Bf16x3::kBwdLds, as_stream(stream)>>>(nullptr, M, 1.0f, 1.0f / kCodebookResolution, grad_sigmas, grad_rgbs, sigmas,

@@ -2,6 +2,8 @@
 // the wave-level layer / ReLU / mask helpers, the SH encoding and the stage-1 trace records.  (Moved out of field.hip unchanged.)
 #pragma once
 
+#include <type_traits>
+
 #include "hashgrid.h"
 #include "mfma.h"
 
@@ -207,12 +209,28 @@ struct GradTrace {   // written by the backward
     float2 *d_planes;           // [16][stride] gradient of the 32 encoder features, level-major like the forward's planes
 };
 
+// base[uniform + lane]: the wave-uniform part of the index pinned into SGPRs (readfirstlane), the lane part a 32-bit BYTE offset -- the load or store is then
+// `global_load v, v_off, s[base:base+1]`: ONE VGPR of address for all accesses of a request.  Left to itself the compiler folds the lane offset into each
+// access's row base and keeps one 64-bit lane address per access live over the whole tile loop as a loop invariant (the 112 trace stores of the stage-1 forward: 224 VGPRs).  `base` stays the kernel
+// argument it is (a pointer rebuilt from an integer would be a FLAT one).
+template <typename T>
+__device__ inline T *at_uniform(T *base, size_t uniform_elems, uint32_t lane_bytes) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)uniform_elems);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)uniform_elems >> 32));
+    typedef std::conditional_t<std::is_const<T>::value, const char, char> Byte;
+    return reinterpret_cast<T *>(reinterpret_cast<Byte *>(base + (((size_t)hi << 32) | lo)) + lane_bytes);
+}
+
+// rows 32 rb + row_of_reg16(h, r) of a feature-major trace, column s: the row's uniform part (h = 0) + the tile's first point as the SGPR base, the lane's half and
+// point as a 32-bit byte offset (stride < 2^27: the entry points check)
 template <typename F>
 __device__ inline void store_rows64(float *__restrict__ dst, uint32_t stride, uint32_t s, int h, const f32x16 (&acc)[2], F f) {
+    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);      // lane 0 holds the tile's first point
+    const uint32_t lane_bytes = (4u * (uint32_t)h * stride + (s - s0)) * 4u;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dst[(size_t)(32 * rb + row_of_reg16(h, r)) * stride + s] = f(acc[rb][r], rb * 16 + r);
+        for (int r = 0; r < 16; ++r) *at_uniform(dst, (size_t)(32 * rb + row_of_reg16(0, r)) * stride + s0, lane_bytes) = f(acc[rb][r], rb * 16 + r);
 }
 
 template <typename P>
@@ -232,11 +250,13 @@ __device__ inline void color_branch(const char *lds, int lane, int h, float dx, 
     }
     auto relu = [](float v, int) { return v > 0.0f ? v : 0.0f; };
     if (trace != nullptr) {
+        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s), col = (s - s0) * 4u;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            trace->cin[(size_t)(8 * h + j) * stride + s] = h ? sh[8 + j] : sh[j];
-            const int rho = row_of_reg(h, j);  // slot (h, j) of the second K-step carries sigma-head row rho (row 0 -> the padded 1.0)
-            trace->cin[(size_t)(rho == 0 ? 31 : 15 + rho) * stride + s] = geo8[j];
+            *at_uniform(trace->cin, (size_t)j * stride + s0, 8u * (uint32_t)h * stride * 4u + col) = h ? sh[8 + j] : sh[j];      // row 8 h + j
+            // slot (h, j) of the second K-step carries sigma-head row rho = row_of_reg(h, j) -> colour input 15 + rho; rho == 0 (h = 0, j = 0) -> the padded 1.0, row 31
+            const uint32_t lane_rows = j == 0 ? (h ? 4u : 16u) : 4u * (uint32_t)h;
+            *at_uniform(trace->cin, (size_t)(15 + row_of_reg(0, j)) * stride + s0, lane_rows * stride * 4u + col) = geo8[j];
         }
     }
     f32x16 hid[2];

@@ -19,8 +19,6 @@
 //     k_wgrad_reduce (stage1.hip) adds the slabs in workgroup order and writes tcnn's parameter layout.  Fixed tile -> wave assignment: bit-reproducible.
 // One workgroup per compute unit (48 KiB of split-bf16 backward weights + 4 x 18 KiB of scratch); nothing but d_planes (128 B per point, the table
 // scatter's input) is written per point.
-#include <type_traits>
-
 #include "fieldmlp.h"
 
 namespace nsig {
@@ -40,18 +38,6 @@ struct FusedArgs {
     float2 *d_planes;                       // out: gradient of the 32 encoder features, level-major
     float *slabs;                           // out: [workgroups][12][16][64] partial sums
 };
-
-// base[uniform + lane]: the wave-uniform part of the index pinned into SGPRs (readfirstlane), the lane part a 32-bit BYTE offset -- the load or store is then
-// `global_load v, v_off, s[base:base+1]`: ONE VGPR of address for all accesses of a request.  Left to itself the compiler folds the lane offset into each
-// access's row base and keeps some 40 such 64-bit lane addresses (80 VGPRs) live over the whole tile loop as loop invariants.  `base` stays the kernel
-// argument it is (a pointer rebuilt from an integer would be a FLAT one).
-template <typename T>
-__device__ inline T *at_uniform(T *base, size_t uniform_elems, uint32_t lane_bytes) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)uniform_elems);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)uniform_elems >> 32));
-    typedef std::conditional_t<std::is_const<T>::value, const char, char> Byte;
-    return reinterpret_cast<T *>(reinterpret_cast<Byte *>(base + (((size_t)hi << 32) | lo)) + lane_bytes);
-}
 
 // ---- a layer input from memory into a wave's scratch: ROWS8 x 8 rows of 32 points; lane 8 g + c takes points 4c..4c+3 of row 8 i + g
 template <int ROWS8>
@@ -346,7 +332,7 @@ NSIG_EXPORT int field_bwd_wgrad(uint32_t M, const uint32_t *rows_dev, const floa
                                 const float *act_h2, void *d_planes, void *scratch, float *grad_sigma_params, float *grad_color_params, nsig_stream_t stream) {
     NSIG_REQUIRE(grad_sigmas && grad_rgbs && sigmas && rgbs && masks && packed && planes && act_hs && act_cin && act_h1 && act_h2 && d_planes && scratch &&
                  grad_sigma_params && grad_color_params, "field_bwd_wgrad: null pointer");
-    NSIG_REQUIRE(M >= 1 && M <= (1u << 27), "field_bwd_wgrad: M=%u out of range (1 .. 2^27: the lane part of an address is a 32-bit byte offset of up to 28 x stride)", M);
+    NSIG_REQUIRE(M >= 1 && M <= (1u << 26), "field_bwd_wgrad: M=%u out of range (1 .. 2^26, as field_fwd_trace: the lane part of an address is a 32-bit byte offset of up to 32 x stride)", M);
     const void *all[] = {packed, planes, act_hs, act_cin, act_h1, act_h2, d_planes, scratch};
     for (const void *q : all) NSIG_REQUIRE((reinterpret_cast<uintptr_t>(q) & 15) == 0, "field_bwd_wgrad: packed, planes, the layer inputs, d_planes and scratch must be 16-byte aligned");
     const uint32_t stride = ceil_div(M, 32u) * 32u, n_wg = fused_workgroups(M);

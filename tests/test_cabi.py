@@ -53,7 +53,7 @@ def test_argument_validation_needs_no_gpu(native):
     with pytest.raises(ValueError, match="null pointer"):
         native.call("field_bwd_wgrad", 64, None, None, d, d, d, d, d, d, d, d, d, d, d, d, d, d, None)
     with pytest.raises(ValueError, match="out of range"):
-        native.call("field_bwd_wgrad", (1 << 27) + 1, None, d, d, d, d, d, d, d, d, d, d, d, d, d, d, d, None)
+        native.call("field_bwd_wgrad", (1 << 26) + 1, None, d, d, d, d, d, d, d, d, d, d, d, d, d, d, d, None)
     with pytest.raises(ValueError, match="16-byte aligned"):
         native.call("field_bwd_wgrad", 64, None, d, d, d, d, d, d, native._vp(264), d, d, d, d, d, d, d, d, None)
     assert native.fn("field_bwd_wgrad_scratch_bytes")(1) == 12 * 1024 * 4 and native.fn("field_bwd_wgrad_scratch_bytes")(10 ** 6) == 256 * 12 * 1024 * 4

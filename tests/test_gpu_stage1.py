@@ -161,6 +161,40 @@ def test_weight_gradients_equal_the_matrix_products_and_are_bit_reproducible():
         assert rel(G[l], G3[l]) < 1e-6, (l, rel(G[l], G3[l]))
 
 
+def test_pipelined_trace_forward_equals_the_plain_loop_bit_for_bit():
+    """field_fwd_trace's launch (k_field_fwd_trace: the next tile's inputs requested in front of a tile's trace stores) against the generic kernel's trace variant
+    (mlp_set_pipelined bit 0 clear): outputs, ReLU masks and every saved layer input bit for bit -- with a host and with a device row count."""
+    from nerf_signature_amd import _native as nv, fieldops as fo, stage1
+    m, _, _ = _clean_model()
+    packed = fo.pack_weights(m.sigma_net.params, m.color_net.params)
+    base_ptrs = nv.ptr_array([t.detach() for t in m.encoder.tables()])
+    before = nv.fn("mlp_get_pipelined")()
+    try:
+        for M, n in ((20011, None), (21000, 7013), (33, None), (4096, 1)):
+            pts, dirs, _, _ = _random_batch(M, seed=2)
+            rows = None if n is None else torch.tensor([n, 0], dtype=torch.int32, device="cuda")
+            live = M if n is None else n
+            got = []
+            for mask in (3, 2):
+                nv.call("mlp_set_pipelined", mask)
+                tr = stage1._Traces(M, pts.device, with_grads=False)
+                for t in [tr.sig, tr.rgb, *tr.act]:
+                    t.fill_(float("nan"))
+                tr.masks.fill_(-1)
+                stage1._forward_trace(tr, pts, dirs, m.bound, base_ptrs, packed, rows=rows)
+                got.append(tr)
+            a, b = got
+            assert torch.equal(a.sig[:live], b.sig[:live]) and torch.equal(a.rgb[:live], b.rgb[:live]) and not torch.isnan(a.sig[:live]).any()
+            n_tiles = (live + 31) // 32
+            assert torch.equal(a.masks.view(-1)[:n_tiles * 192], b.masks.view(-1)[:n_tiles * 192])
+            for x, y in zip(a.act, b.act):
+                assert torch.equal(x[:, :live], y[:, :live]) and not torch.isnan(x[:, :live]).any()
+            if n is not None and n_tiles * 32 < M:      # nothing past the live tiles was written
+                assert torch.isnan(a.sig[n_tiles * 32:]).all() and torch.isnan(a.act[0][:, n_tiles * 32:]).all() and bool((a.masks.view(-1)[n_tiles * 192:] == -1).all())
+    finally:
+        nv.call("mlp_set_pipelined", before)
+
+
 @pytest.mark.parametrize("fused", [True, False], ids=["one_launch", "two_launches"])
 def test_device_row_count_entry_points_walk_only_the_live_rows(fused):
     """Buffers of capacity 3 x the live rows, NaN past them: tables bit for bit, MLP gradients to summation order (the split over workgroups follows the capacity)."""
