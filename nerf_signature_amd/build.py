@@ -64,5 +64,23 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, extra_flags, out_root=None):
+    """The same sources with extra compiler flags (defines of diagnostic builds) -> <out_root>/libnerfsig_<name>.so; select it with NERFSIG_LIB.  Per-file flags as build()."""
+    out_root = out_root or os.path.join(PKG, "..", "tools", "_build")
+    out = os.path.join(out_root, name)
+    os.makedirs(out, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    procs, objs = [], []
+    for src in sources():
+        obj = os.path.join(out, os.path.basename(src)[:-4] + ".o")
+        procs.append(subprocess.Popen([hipcc, *flags_for(src), *extra_flags, "-c", src, "-o", obj]))
+        objs.append(obj)
+    if any(p.wait() for p in procs):
+        raise RuntimeError("variant build failed")
+    lib = os.path.abspath(os.path.join(out_root, f"libnerfsig_{name}.so"))
+    subprocess.check_call([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib, *objs])
+    return lib
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

@@ -230,7 +230,8 @@ __device__ inline void store_rows64(float *__restrict__ dst, uint32_t stride, ui
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) *at_uniform(dst, (size_t)(32 * rb + row_of_reg16(0, r)) * stride + s0, lane_bytes) = f(acc[rb][r], rb * 16 + r);
+        for (int r = 0; r < 16; ++r)      // streaming stores: a trace is written once and read once, a kernel or more later, and is far larger than the L2 (same box: 148 -> 124 us)
+            __builtin_nontemporal_store(f(acc[rb][r], rb * 16 + r), at_uniform(dst, (size_t)(32 * rb + row_of_reg16(0, r)) * stride + s0, lane_bytes));
 }
 
 template <typename P>
@@ -253,10 +254,10 @@ __device__ inline void color_branch(const char *lds, int lane, int h, float dx, 
         const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s), col = (s - s0) * 4u;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            *at_uniform(trace->cin, (size_t)j * stride + s0, 8u * (uint32_t)h * stride * 4u + col) = h ? sh[8 + j] : sh[j];      // row 8 h + j
+            __builtin_nontemporal_store(h ? sh[8 + j] : sh[j], at_uniform(trace->cin, (size_t)j * stride + s0, 8u * (uint32_t)h * stride * 4u + col));      // row 8 h + j
             // slot (h, j) of the second K-step carries sigma-head row rho = row_of_reg(h, j) -> colour input 15 + rho; rho == 0 (h = 0, j = 0) -> the padded 1.0, row 31
             const uint32_t lane_rows = j == 0 ? (h ? 4u : 16u) : 4u * (uint32_t)h;
-            *at_uniform(trace->cin, (size_t)(15 + row_of_reg(0, j)) * stride + s0, lane_rows * stride * 4u + col) = geo8[j];
+            __builtin_nontemporal_store(geo8[j], at_uniform(trace->cin, (size_t)(15 + row_of_reg(0, j)) * stride + s0, lane_rows * stride * 4u + col));
         }
     }
     f32x16 hid[2];
