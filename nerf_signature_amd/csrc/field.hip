@@ -136,7 +136,7 @@ __device__ inline float2 load_plane(const float2 *__restrict__ planes, uint32_t 
 }
 
 __device__ inline void encode_tile_level(const float2 *__restrict__ table, float cell, uint32_t xs, float x, float y, float z,
-                                         float2 *__restrict__ out, bool half_out = false) {
+                                         float2 *__restrict__ out, bool half_out = false, bool streaming = true) {
     uint32_t ix, iy, iz;
     float wx, wy, wz;
     axis_cell(x, cell, ix, wx);
@@ -171,7 +171,11 @@ __device__ inline void encode_tile_level(const float2 *__restrict__ table, float
     }
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
     const f32x2_t vv = {val.x, val.y};
-    __builtin_nontemporal_store(vv, reinterpret_cast<f32x2_t *>(out));
+    // the all-fp32 plane set (stage 1, the split-bf16 MLP) goes through the caches: its consumer runs right behind this launch and found the planes in memory when
+    // they were streamed out (stage-1 forward 166 -> 133 us, this launch +2.5, same box, two rounds); the mixed set of the headline step keeps its streaming
+    // stores (LABNOTES section 12: fewer store transactions on the fabric the line fills compete for)
+    if (streaming) __builtin_nontemporal_store(vv, reinterpret_cast<f32x2_t *>(out));
+    else *reinterpret_cast<f32x2_t *>(out) = vv;
 }
 
 // Reads the tables of a slot through that slot's XCD (blockIdx % 8): its L2 then holds the slot's fine table when the encoder starts.
@@ -221,7 +225,7 @@ __global__ void __launch_bounds__(256) k_encode_planes(const float *__restrict__
             const bool half_out = mixed && l < kHalfLevels;
             float2 *out = !mixed ? planes + (size_t)l * stride + m
                                  : (half_out ? reinterpret_cast<float2 *>(reinterpret_cast<uint32_t *>(planes) + (size_t)l * stride + m) : mixed_f32_plane(planes, stride, l) + m);
-            encode_tile_level(reinterpret_cast<const float2 *>(l == NSIG_BASE_LEVELS ? S : base.p[l]), geom.cell[l], xs, x, y, z, out, half_out);
+            encode_tile_level(reinterpret_cast<const float2 *>(l == NSIG_BASE_LEVELS ? S : base.p[l]), geom.cell[l], xs, x, y, z, out, half_out, /*streaming=*/mixed);
         }
     }
 }
