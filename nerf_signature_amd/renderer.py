@@ -504,14 +504,23 @@ class NeRFRenderer(nn.Module):
     # ------------------------------------------------------------------ density-grid maintenance
 
     def _grid_blocks(self, S):
-        """All grid cells in S^3 blocks: yields (integer coords [n,3], morton index [n]) on the grid's device."""
+        """All grid cells in S^3 blocks: yields (integer coords [n,3], morton index [n]) on the grid's device; coords.block_dims = (nx, ny, nz), z fastest.
+        The blocks never change: built once per (S, grid size, device) and kept (42 MB at 128^3) -- a refresh otherwise spends six launches on them."""
         dev = self.density_bitfield.device
-        axis = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
-        for xs in axis:
-            for ys in axis:
-                for zs in axis:
-                    coords = torch.stack(custom_meshgrid(xs, ys, zs), dim=-1).reshape(-1, 3)
-                    yield coords, raymarching.morton3D(coords).long()
+        key = (int(S), int(self.grid_size), str(dev))
+        cache = self.__dict__.setdefault("_grid_block_cache", {})
+        if key not in cache:
+            blocks = []
+            axis = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
+            for xs in axis:
+                for ys in axis:
+                    for zs in axis:
+                        coords = torch.stack(custom_meshgrid(xs, ys, zs), dim=-1).reshape(-1, 3)
+                        coords.block_dims = (len(xs), len(ys), len(zs))
+                        blocks.append((coords, raymarching.morton3D(coords).long()))
+            cache.clear()      # (one geometry at a time)
+            cache[key] = blocks
+        yield from cache[key]
 
     def _cascade_extent(self, cas):
         extent = min(2 ** cas, self.bound)
@@ -550,8 +559,27 @@ class NeRFRenderer(nn.Module):
         self._grid_epoch += 1
         print(f"[mark untrained grid] {(seen == 0).sum()} from {self.grid_size ** 3 * self.cascade}")
 
+    PROBE_SORT_MIN = 1 << 16      # points from which a scattered probe is sorted before the density query
+
     def _probe_density(self, coords, cas, message):
         pts = self._cell_centres(coords, cas, jitter=True)
+        dims = getattr(coords, "block_dims", None)
+        if dims is not None and pts.is_cuda:
+            # A whole block of the grid, z fastest (the order the reference draws its jitter in, renderer_wtmk.py:470-486): queried x FASTEST instead.  The reference's
+            # hash takes x un-multiplied (hash_encoding.py:16), so points that follow each other in x land in the same or the next 128-byte line of a table on almost
+            # every level, where z-neighbours hit 64 unrelated lines per gather instruction (the 2 M-point encoder launch: LABNOTES section 17).  Every point's density
+            # is independent of its neighbours: the same bits, in the old order again below.
+            nx, ny, nz = dims
+            q = pts.view(nx, ny, nz, 3).permute(2, 1, 0, 3).reshape(-1, 3).contiguous()
+            sigma = self.density(q, message)["sigma"].reshape(nz, ny, nx).permute(2, 1, 0).reshape(-1)
+            return sigma.detach() * self.density_scale
+        if pts.is_cuda and pts.shape[0] >= self.PROBE_SORT_MIN:
+            # scattered cells (the partial refresh: a random quarter of the grid + as many occupied cells): the same locality from a sort of the QUERY on (y, z, x)
+            c = coords.long()
+            order = torch.argsort((c[:, 1] * self.grid_size + c[:, 2]) * self.grid_size + c[:, 0])
+            sigma = torch.empty(pts.shape[0], dtype=torch.float32, device=pts.device)
+            sigma[order] = self.density(pts[order], message)["sigma"].reshape(-1).detach()
+            return sigma * self.density_scale
         return self.density(pts, message)["sigma"].reshape(-1).detach() * self.density_scale
 
     @torch.no_grad()
@@ -577,7 +605,8 @@ class NeRFRenderer(nn.Module):
                 indices = torch.cat([rand_idx, occ_idx], dim=0)
                 fresh[cas, indices] = self._probe_density(torch.cat([rand_coords, occ_coords], dim=0), cas, message)
         both = (self.density_grid >= 0) & (fresh >= 0)
-        self.density_grid[both] = torch.maximum(self.density_grid[both] * decay, fresh[both])
+        # (the reference's masked assignment, renderer_wtmk.py:521-522, as a select: the same values without the nonzero() and host read of boolean indexing)
+        self.density_grid.copy_(torch.where(both, torch.maximum(self.density_grid * decay, fresh), self.density_grid))
         self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
         self.iter_density += 1
         self.density_bitfield = raymarching.packbits(self.density_grid, min(self.mean_density, self.density_thresh), self.density_bitfield)
