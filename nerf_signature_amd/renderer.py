@@ -590,6 +590,10 @@ class NeRFRenderer(nn.Module):
             return
         dev = self.density_bitfield.device
         fresh = -torch.ones_like(self.density_grid)
+        if self.iter_density == 0 and dev.type == "cuda":
+            # the scattered probe of the 17th refresh on sorts its query: load that operator's kernels now (tens of ms the first time), not in the middle of the
+            # training loop.  No random numbers drawn, nothing of the model touched.
+            torch.argsort(torch.arange(self.PROBE_SORT_MIN, dtype=torch.int64, device=dev).flip(0))
         if self.iter_density < 16:
             for coords, indices in self._grid_blocks(S):
                 for cas in range(self.cascade):
