@@ -517,6 +517,7 @@ class NeRFRenderer(nn.Module):
                     for zs in axis:
                         coords = torch.stack(custom_meshgrid(xs, ys, zs), dim=-1).reshape(-1, 3)
                         coords.block_dims = (len(xs), len(ys), len(zs))
+                        coords.centres = {}
                         blocks.append((coords, raymarching.morton3D(coords).long()))
             cache.clear()      # (one geometry at a time)
             cache[key] = blocks
@@ -529,9 +530,15 @@ class NeRFRenderer(nn.Module):
     def _cell_centres(self, coords, cas, jitter):
         """World position of grid cells of cascade `cas` (optionally jittered inside the cell)."""
         extent, half_cell = self._cascade_extent(cas)
-        pts = (2 * coords.float() / (self.grid_size - 1) - 1) * (extent - half_cell)
+        kept = getattr(coords, "centres", None)      # (a cached block of _grid_blocks: its un-jittered centres are constants too -- five launches per refresh)
+        if kept is not None and (cas, float(extent)) in kept:
+            pts = kept[(cas, float(extent))]
+        else:
+            pts = (2 * coords.float() / (self.grid_size - 1) - 1) * (extent - half_cell)
+            if kept is not None:
+                kept[(cas, float(extent))] = pts
         if jitter:
-            pts += (torch.rand_like(pts) * 2 - 1) * half_cell
+            pts = pts + (torch.rand_like(pts) * 2 - 1) * half_cell      # (the reference's `+=`: the same sum, the kept centres left alone)
         return pts
 
     @torch.no_grad()
