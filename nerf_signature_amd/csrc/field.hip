@@ -274,7 +274,8 @@ __device__ inline void field_fwd_pipelined(const char *lds, int lane, const floa
         if constexpr (kMixed) {
             const uint32_t *hp = reinterpret_cast<const uint32_t *>(planes);
 #pragma unroll
-            for (int q = 0; q < 7; ++q) nh[q] = hp[(size_t)(8 * (q >> 2) + (q & 3) + 4 * h) * stride + s];      // 128 contiguous bytes per half-wave
+            // 128 contiguous bytes per half-wave; streaming loads (the planes are read exactly once: step -0.4 % over three same-box rounds, at the edge of resolution)
+            for (int q = 0; q < 7; ++q) nh[q] = __builtin_nontemporal_load(hp + (size_t)(8 * (q >> 2) + (q & 3) + 4 * h) * stride + s);
             if (h) nf[7] = mixed_f32_plane(const_cast<float2 *>(planes), stride, NSIG_BASE_LEVELS - 1)[s];
             else nh[7] = hp[(size_t)11 * stride + s];
             if (add_codebook && h) nc = mixed_f32_plane(const_cast<float2 *>(planes), stride, NSIG_BASE_LEVELS)[s];
