@@ -110,3 +110,42 @@ def test_grid_update_with_field_network_matches_oracle():
     near = np.abs(want - thresh) <= 2e-3 * scale
     differ = _bits(m.density_bitfield.cpu().numpy(), want.shape) != _bits(st["density_bitfield"].numpy(), want.shape)
     assert not bool((differ & ~near).any()) and float(near.mean()) < 0.05
+
+
+def test_refresh_probe_order_changes_nothing_but_the_time():
+    """update_extra_state queries its full-grid probe x fastest (the cached block's transposed view) and the partial refresh's scattered probe sorted on
+    (y, z, x) -- an order the hash gather likes -- and hands the densities back in the order the reference draws its jitter in: the same grid / the same
+    densities bit for bit as the plain order, with the real field network behind density()."""
+    from nerf_signature_amd import synthetic
+    from nerf_signature_amd.stage1 import CleanNeRFNetwork
+    m = CleanNeRFNetwork(bound=1.0, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1)
+    with torch.no_grad():
+        for l, e in enumerate(m.encoder.embeddings):
+            e.weight.copy_(torch.from_numpy(synthetic.table_values(l, 0.5)))
+    m = m.cuda().train()
+    plain_blocks = type(m)._grid_blocks.__get__(m)
+
+    def unordered(S):      # the same blocks without the attributes _probe_density keys its reordering on
+        for c, i in plain_blocks(S):
+            yield c.clone(), i
+
+    grids = []
+    for reorder in (True, False):
+        m._grid_blocks = plain_blocks if reorder else unordered
+        m.density_grid.zero_()
+        m.density_bitfield.zero_()
+        m.iter_density = 0
+        torch.manual_seed(0)
+        m.update_extra_state()
+        grids.append(m.density_grid.clone())
+    assert torch.equal(grids[0], grids[1]) and float(grids[0].max()) > 0
+    m._grid_blocks = plain_blocks
+    n = m.grid_size ** 3 // 4
+    torch.manual_seed(5)
+    coords = torch.randint(0, m.grid_size, (2 * n, 3), device="cuda")
+    out = []
+    for thresh in (type(m).PROBE_SORT_MIN, 1 << 40):
+        m.PROBE_SORT_MIN = thresh
+        torch.manual_seed(7)
+        out.append(m._probe_density(coords, 0, None))
+    assert torch.equal(out[0], out[1]) and float(out[0].max()) > 0
