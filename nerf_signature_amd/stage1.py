@@ -399,9 +399,13 @@ class GraphedCleanLoop:
         _bump_versions(params)
 
     def _optimise(self):
-        self._adam(self.params[:16])                # the tables need the scatter only: 448 MiB of streaming while the weight gradients finish
-        self._join_weight_gradients()
-        self._adam(self.params[16:])
+        if self.fused_backward:                     # every gradient is there when the scatter is: one call (one prepare launch) over the 18 tensors
+            self._join_weight_gradients()
+            self._adam(self.params)
+        else:
+            self._adam(self.params[:16])            # the tables need the scatter only: 448 MiB of streaming while the weight gradients finish
+            self._join_weight_gradients()
+            self._adam(self.params[16:])
         nv.call("mlp_pack_weights", nv.ptr(self.model.sigma_net.params.detach()), nv.ptr(self.model.color_net.params.detach()), nv.ptr(self.packed), nv.stream())
 
     def _whole_step(self):
