@@ -581,6 +581,14 @@ size_t field_bwd_wgrad_scratch_bytes(uint32_t M);
 int field_bwd_wgrad(uint32_t M, const uint32_t *rows_dev, const float *grad_sigmas, const float *grad_rgbs, const float *sigmas, const float *rgbs,
                     const uint32_t *masks, const void *packed, const void *planes, const float *act_hs, const float *act_cin, const float *act_h1,
                     const float *act_h2, void *d_planes, void *scratch, float *grad_sigma_params, float *grad_color_params, nsig_stream_t stream);
+/* Stage 1's compositing in one launch: rm_composite_train_finish_fwd + the gradient half of clean_loss (grad_image = grad_scale * 2 / n_values *
+ * (image_out - gt), nerf/utils.py:503) + rm_composite_train_finish_bwd (rays in ascending gapless offset order: every gradient row written or zeroed
+ * by the kernel).  One wave per ray in all three, so a ray's image stays in registers; the same bits in every output as the three launches.  The loss value
+ * and a captured loop's books remain clean_loss's job (launched behind it). */
+int rm_composite_train_mse(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays, uint32_t M, uint32_t N, float T_thresh,
+                           const float *nears, const float *fars, const float *bg, uint32_t bg_stride, const float *gt, uint32_t n_values,
+                           float grad_scale, float *weights_sum, float *depth, float *image, float *image_out, float *depth_out, float *grad_image,
+                           float *grad_sigmas, float *grad_rgbs, nsig_stream_t stream);
 int clean_loss(const float *image, const float *gt, uint32_t n_values, float grad_scale, float *loss, float *grad_image,
                uint32_t *step_dev, const int32_t *march_counter, int32_t *count_ring, float *loss_ring, uint32_t loss_ring_len,
                float *noise_next, uint32_t n_noise, uint64_t seed, nsig_stream_t stream);

@@ -1255,6 +1255,115 @@ NSIG_EXPORT int rm_composite_train_finish_bwd(const float *grad_weights_sum, con
     return check_launch("rm_composite_train_finish_bwd");
 }
 
+// Stage 1's compositing in ONE launch (stage1.GraphedCleanLoop): k_composite_fwd with the render tail, the gradient half of k_clean_loss
+// (nerf/utils.py:503: d loss / d image = grad_k * (image - gt), grad_k = grad_scale * 2 / n_values) and k_composite_bwd with the tail's adjoint, for rays in
+// ascending gapless offset order.  A wave owns a ray in all three, so the ray's image never leaves its registers: forward over the ray's chunks, the three seed
+// values, backward over the same chunks (read again, from L2).  The same arithmetic, operation by operation, as the three launches: the same bits in every output
+// (tests/test_gpu_stage1.py).  The loss VALUE and the loop's books stay with clean_loss, launched behind this kernel: two launches in a row where there were three.
+__global__ void __launch_bounds__(256) k_composite_mse(const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ deltas,
+                                                       const int32_t *__restrict__ rays, uint32_t M, uint32_t N, float T_thresh, const float *__restrict__ gt,
+                                                       float grad_k, FinishArgs fin, float *__restrict__ weights_sum, float *__restrict__ depth,
+                                                       float *__restrict__ image, float *__restrict__ grad_image, float *__restrict__ grad_sigmas,
+                                                       float *__restrict__ grad_rgbs) {
+    const int lane = threadIdx.x & 63;
+    if (blockIdx.x >= ceil_div(N, 4u)) {      // tail blocks: rows past the last ray's samples (k_composite_bwd's self_zero)
+        const uint32_t total = (uint32_t)rays[3 * (size_t)(N - 1) + 1] + (uint32_t)rays[3 * (size_t)(N - 1) + 2];
+        for (size_t m = (size_t)total + (size_t)(blockIdx.x - ceil_div(N, 4u)) * 256 + threadIdx.x; m < M; m += (size_t)(gridDim.x - ceil_div(N, 4u)) * 256) {
+            grad_sigmas[m] = 0.0f;
+            grad_rgbs[3 * m] = 0.0f; grad_rgbs[3 * m + 1] = 0.0f; grad_rgbs[3 * m + 2] = 0.0f;
+        }
+        return;
+    }
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const uint32_t id = (uint32_t)rays[3 * (size_t)n], off = (uint32_t)rays[3 * (size_t)n + 1], cnt = (uint32_t)rays[3 * (size_t)n + 2];
+    const bool fits = cnt != 0 && off + cnt <= M;
+    // ---- forward (k_composite_fwd)
+    float r = 0, g = 0, b = 0, ws = 0, d = 0, T = 1.0f, tt = 0.0f;
+    if (fits) {
+        for (uint32_t base = 0; base < cnt; base += 64) {
+            const Chunk c = load_chunk(sigmas, rgbs, deltas, off, base, cnt, lane, T, T_thresh);
+            const float t_incl = tt + wave_scan(c.dreal, lane, [](float a, float b2) { return a + b2; });
+            r += c.w * c.c0; g += c.w * c.c1; b += c.w * c.c2; ws += c.w; d += c.w * t_incl;
+            T = __shfl(c.T_after, 63, 64);
+            tt = __shfl(t_incl, 63, 64);
+            if (T < T_thresh) break;
+        }
+        r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); ws = wave_sum(ws); d = wave_sum(d);
+    }
+    const float rest = 1.0f - ws;
+    const float *bgp = fin.bg + (size_t)id * fin.bg_stride;
+    const float bg0 = bgp[0], bg1 = bgp[1], bg2 = bgp[2];
+    const float o0 = r + rest * bg0, o1 = g + rest * bg1, o2 = b + rest * bg2;
+    // ---- the seed (k_clean_loss: g_image[i] = k * (image[i] - gt[i]))
+    const float g0 = grad_k * (o0 - gt[3 * (size_t)id]), g1 = grad_k * (o1 - gt[3 * (size_t)id + 1]), g2 = grad_k * (o2 - gt[3 * (size_t)id + 2]);
+    if (lane == 0) {
+        weights_sum[id] = ws;
+        depth[id] = d;
+        image[3 * (size_t)id] = r; image[3 * (size_t)id + 1] = g; image[3 * (size_t)id + 2] = b;
+        fin.image_out[3 * (size_t)id] = o0; fin.image_out[3 * (size_t)id + 1] = o1; fin.image_out[3 * (size_t)id + 2] = o2;
+        fin.depth_out[id] = fmaxf(d - fin.nears[id], 0.0f) / (fin.fars[id] - fin.nears[id]);
+        grad_image[3 * (size_t)id] = g0; grad_image[3 * (size_t)id + 1] = g1; grad_image[3 * (size_t)id + 2] = g2;
+    }
+    // ---- backward (k_composite_bwd with the tail's adjoint and self_zero)
+    auto zero_rows = [&](uint32_t first, uint32_t last) {
+        for (size_t m = (size_t)off + first + lane; m < (size_t)off + last && m < M; m += 64) {
+            grad_sigmas[m] = 0.0f;
+            grad_rgbs[3 * m] = 0.0f; grad_rgbs[3 * m + 1] = 0.0f; grad_rgbs[3 * m + 2] = 0.0f;
+        }
+    };
+    if (cnt == 0) return;
+    if (!fits) {
+        zero_rows(0, cnt);
+        return;
+    }
+    float sgb = 0.0f;
+    sgb += g0 * bg0; sgb += g1 * bg1; sgb += g2 * bg2;
+    const float gws = 0.0f + (-sgb);
+    const float tail = gws * (1.0f - ws);
+    const float rf = r, gf = g, bf = b;
+    T = 1.0f;
+    float ra = 0.0f, ga = 0.0f, ba = 0.0f;
+    auto add = [](float a, float c) { return a + c; };
+    for (uint32_t base = 0; base < cnt; base += 64) {
+        const Chunk c = load_chunk(sigmas, rgbs, deltas, off, base, cnt, lane, T, T_thresh);
+        const float r_incl = ra + wave_scan(c.w * c.c0, lane, add);
+        const float g_incl = ga + wave_scan(c.w * c.c1, lane, add);
+        const float b_incl = ba + wave_scan(c.w * c.c2, lane, add);
+        if (c.live) {
+            const size_t m = (size_t)off + base + lane;
+            grad_rgbs[3 * m] = g0 * c.w; grad_rgbs[3 * m + 1] = g1 * c.w; grad_rgbs[3 * m + 2] = g2 * c.w;
+            grad_sigmas[m] = c.dt * (g0 * (c.T_after * c.c0 - (rf - r_incl)) + g1 * (c.T_after * c.c1 - (gf - g_incl)) +
+                                     g2 * (c.T_after * c.c2 - (bf - b_incl)) + tail);
+        } else if (base + lane < cnt) {
+            const size_t m = (size_t)off + base + lane;
+            grad_sigmas[m] = 0.0f;
+            grad_rgbs[3 * m] = 0.0f; grad_rgbs[3 * m + 1] = 0.0f; grad_rgbs[3 * m + 2] = 0.0f;
+        }
+        T = __shfl(c.T_after, 63, 64);
+        ra = __shfl(r_incl, 63, 64); ga = __shfl(g_incl, 63, 64); ba = __shfl(b_incl, 63, 64);
+        if (T < T_thresh) {
+            zero_rows(base + 64, cnt);
+            break;
+        }
+    }
+}
+
+NSIG_EXPORT int rm_composite_train_mse(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays, uint32_t M, uint32_t N, float T_thresh,
+                                       const float *nears, const float *fars, const float *bg, uint32_t bg_stride, const float *gt, uint32_t n_values,
+                                       float grad_scale, float *weights_sum, float *depth, float *image, float *image_out, float *depth_out, float *grad_image,
+                                       float *grad_sigmas, float *grad_rgbs, nsig_stream_t stream) {
+    if (N == 0) return NSIG_OK;
+    NSIG_REQUIRE(sigmas && rgbs && deltas && rays && nears && fars && bg && gt && weights_sum && depth && image && image_out && depth_out && grad_image &&
+                 grad_sigmas && grad_rgbs, "rm_composite_train_mse: null pointer");
+    NSIG_REQUIRE(bg_stride == 0 || bg_stride == 3, "rm_composite_train_mse: bg_stride is 0 (one colour) or 3 (per ray)");
+    NSIG_REQUIRE(n_values >= 1, "rm_composite_train_mse: n_values must be positive");
+    const FinishArgs fin{nears, fars, bg, bg_stride, image_out, depth_out, 1u};
+    k_composite_mse<<<ceil_div(N, 4u) + 64u, 256, 0, as_stream(stream)>>>(sigmas, rgbs, deltas, rays, M, N, T_thresh, gt, grad_scale * 2.0f / (float)n_values, fin,
+                                                                         weights_sum, depth, image, grad_image, grad_sigmas, grad_rgbs);
+    return check_launch("rm_composite_train_mse");
+}
+
 NSIG_EXPORT int rm_composite_train_bwd(const float *grad_weights_sum, const float *grad_image, const float *sigmas,
                                        const float *rgbs, const float *deltas, const int32_t *rays,
                                        const float *weights_sum, const float *image, uint32_t M, uint32_t N,

@@ -264,7 +264,7 @@ class GraphedCleanLoop:
     LOSS_RING = 1024
 
     def __init__(self, model, optimizer, render_kwargs, n_rays, sampler=None, update_extra_interval=16, lr_lambda=None, headroom=0.5, perturb=True,
-                 capacity=None, overlap_plan=True, capture=True, seed=0, fused_backward=True):
+                 capacity=None, overlap_plan=True, capture=True, seed=0, fused_backward=True, fused_composite=True):
         if not model.cuda_ray:
             raise ValueError("GraphedCleanLoop drives the occupancy-grid path (cuda_ray=True)")
         if model.density_scale != 1:
@@ -285,7 +285,8 @@ class GraphedCleanLoop:
         self.rays_o, self.rays_d, self.gt = (torch.zeros(N, 3, **f32) for _ in range(3))
         self.bg = torch.ones(3, **f32)
         self.ws, self.depth, self.depth_out = (torch.empty(N, **f32) for _ in range(3))
-        self.image, self.image_out, self.g_image = (torch.empty(N, 3, **f32) for _ in range(3))
+        self.image, self.image_out, self.g_image, self._g_image_books = (torch.empty(N, 3, **f32) for _ in range(4))      # (_g_image_books: what clean_loss writes when
+        # it only keeps the books -- the same values as g_image)
         self.loss = torch.zeros(1, **f32)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)          # steps so far (advanced by the loss kernel)
         self.count_ring = torch.zeros(16, 2, dtype=torch.int32, device=dev)    # the march's (points, rays) of the last 16 steps
@@ -310,6 +311,7 @@ class GraphedCleanLoop:
         self.plan_stream = torch.cuda.Stream() if overlap_plan else None
         self.graph, self.tr, self.rec, self.plan = None, None, None, None
         self.capture = bool(capture)      # False: the same explicit kernel sequence issued eagerly every step (tests, debugging)
+        self.fused_composite = bool(fused_composite)    # False: compositing forward, clean_loss, compositing backward as three launches in a row
         self.fused_backward = bool(fused_backward)      # False: field_bwd_trace + field_wgrad (the latter on the plan's stream) instead of field_bwd_wgrad
         self.global_step = 0
         self.recaptures = 0
@@ -339,14 +341,24 @@ class GraphedCleanLoop:
         base_ptrs = nv.ptr_array([t.detach() for t in m.encoder.tables()])
         _forward_trace(tr, xyzs, dirs, m.bound, base_ptrs, self.packed, rows=rows)
         s = nv.stream()
-        nv.call("rm_composite_train_finish_fwd", nv.ptr(tr.sig), nv.ptr(tr.rgb), nv.ptr(rec["deltas"]), nv.ptr(rec["rays"]), M, N, self.T_thresh,
-                nv.ptr(rec["nears"]), nv.ptr(rec["fars"]), nv.ptr(self.bg), 0, nv.ptr(self.ws), nv.ptr(self.depth), nv.ptr(self.image),
-                nv.ptr(self.image_out), nv.ptr(self.depth_out), s)
-        # the loss of the global batch is the mean over the ranks' losses: each rank seeds 1 / world, the exchange sums
-        nv.call("clean_loss", nv.ptr(self.image_out), nv.ptr(self.gt), 3 * N, 1.0 / dp.world_size(), nv.ptr(self.loss), nv.ptr(self.g_image),
-                nv.ptr(self.step_dev), nv.ptr(rows), nv.ptr(self.count_ring), nv.ptr(self.loss_ring), self.LOSS_RING, nv.ptr(self.noises), N, self.seed, s)
-        nv.call("rm_composite_train_finish_bwd", None, nv.ptr(self.g_image), nv.ptr(tr.sig), nv.ptr(tr.rgb), nv.ptr(rec["deltas"]), nv.ptr(rec["rays"]),
-                nv.ptr(self.ws), nv.ptr(self.image), nv.ptr(self.bg), 0, M, N, self.T_thresh, 1, nv.ptr(self.g_sig), nv.ptr(self.g_rgb), s)
+        books = (nv.ptr(self.step_dev), nv.ptr(rows), nv.ptr(self.count_ring), nv.ptr(self.loss_ring), self.LOSS_RING, nv.ptr(self.noises), N, self.seed)
+        if self.fused_composite:
+            # compositing + background, the MSE's gradient and the compositing backward in ONE launch (a wave owns a ray in all three); the loss VALUE and the loop's
+            # books (sample totals, loss ring, the next step's march offsets, the step count) remain clean_loss's, behind it on the same stream -- two launches in a
+            # row instead of three (same box: dense -1.7 %, sparse grid -1.3 %; with clean_loss beside the MLP backward on the plan's stream the extra fork / join of
+            # the graph cost more than the launch saved: +3 %)
+            nv.call("rm_composite_train_mse", nv.ptr(tr.sig), nv.ptr(tr.rgb), nv.ptr(rec["deltas"]), nv.ptr(rec["rays"]), M, N, self.T_thresh, nv.ptr(rec["nears"]),
+                    nv.ptr(rec["fars"]), nv.ptr(self.bg), 0, nv.ptr(self.gt), 3 * N, 1.0 / dp.world_size(), nv.ptr(self.ws), nv.ptr(self.depth), nv.ptr(self.image),
+                    nv.ptr(self.image_out), nv.ptr(self.depth_out), nv.ptr(self.g_image), nv.ptr(self.g_sig), nv.ptr(self.g_rgb), s)
+            nv.call("clean_loss", nv.ptr(self.image_out), nv.ptr(self.gt), 3 * N, 1.0 / dp.world_size(), nv.ptr(self.loss), nv.ptr(self._g_image_books), *books, s)
+        else:
+            nv.call("rm_composite_train_finish_fwd", nv.ptr(tr.sig), nv.ptr(tr.rgb), nv.ptr(rec["deltas"]), nv.ptr(rec["rays"]), M, N, self.T_thresh,
+                    nv.ptr(rec["nears"]), nv.ptr(rec["fars"]), nv.ptr(self.bg), 0, nv.ptr(self.ws), nv.ptr(self.depth), nv.ptr(self.image),
+                    nv.ptr(self.image_out), nv.ptr(self.depth_out), s)
+            # the loss of the global batch is the mean over the ranks' losses: each rank seeds 1 / world, the exchange sums
+            nv.call("clean_loss", nv.ptr(self.image_out), nv.ptr(self.gt), 3 * N, 1.0 / dp.world_size(), nv.ptr(self.loss), nv.ptr(self.g_image), *books, s)
+            nv.call("rm_composite_train_finish_bwd", None, nv.ptr(self.g_image), nv.ptr(tr.sig), nv.ptr(tr.rgb), nv.ptr(rec["deltas"]), nv.ptr(rec["rays"]),
+                    nv.ptr(self.ws), nv.ptr(self.image), nv.ptr(self.bg), 0, M, N, self.T_thresh, 1, nv.ptr(self.g_sig), nv.ptr(self.g_rgb), s)
         # two-launch route: the weight gradients (a streaming reduction) run beside the table scatter (store- and LDS-bound) on the plan's stream,
         # which has long finished the plan by then (stream order: plan, then the weight gradients); fused: they are done when the backward is
         _backward_trace(tr, self.g_sig, self.g_rgb, self.packed, self.g_sigma, self.g_color, rows=rows, wgrad_stream=self.plan_stream)

@@ -301,6 +301,36 @@ def test_captured_loop_equals_the_eager_loop():
     assert float(st["step"]) == 5.0 and st["exp_avg"].shape == (3072,)
 
 
+def test_one_launch_compositing_equals_the_three_launches_bit_for_bit():
+    """rm_composite_train_mse (compositing + background, the MSE's gradient, the compositing backward: one wave per ray in one launch; clean_loss keeps the loss
+    value and the books beside the MLP backward) against the three launches in a row: six captured steps with perturbed samples from the same state -- every
+    parameter, every loss value, the image and the gradients handed to the field's backward, bit for bit."""
+    from nerf_signature_amd.stage1 import GraphedCleanLoop
+    o, d = _patch_rays(16)
+    target = torch.tensor([0.2, 0.5, 0.8]).view(1, 3).expand(256, 3).contiguous().cuda()
+    data = {"rays_o": o.cuda()[None], "rays_d": d.cuda()[None], "images": target[None]}
+    got = []
+    for one_launch in (True, False):
+        m, _, _ = _clean_model()
+        torch.manual_seed(11)      # (the first step's march offsets come from torch's generator)
+        loop = GraphedCleanLoop(m, _adam(m), KW, n_rays=256, update_extra_interval=0, perturb=True, fused_composite=one_launch, seed=3)
+        loop.step(data)
+        for _ in range(5):
+            loop.step()
+        torch.cuda.synchronize()
+        n = int(loop.count_ring[5, 0])
+        got.append(([p.detach().clone() for p in m.trainable()], loop.losses(), loop.image_out.clone(), loop.depth_out.clone(), loop.g_sig[:n].clone(),
+                    loop.g_rgb[:n].clone(), loop.noises.clone(), int(loop.step_dev), loop.count_ring.clone()))
+        loop.close()
+    a, b = got
+    assert a[1] == b[1] and len(a[1]) == 6 and a[7] == b[7] == 6
+    for x, y in zip(a[0], b[0]):
+        assert torch.equal(x, y)
+    for k in (2, 3, 4, 5, 6, 8):
+        assert torch.equal(a[k], b[k]), k
+    assert float(a[4].abs().max()) > 0
+
+
 def test_captured_loop_tracks_the_cpu_oracle_over_200_steps():
     """From a common state, 200 steps of the captured loop and of the CPU oracle (the reference's operator sequence in torch autograd + torch's
     Adam): the loss every 20th step, and the PSNR of the trained render against the target within 0.1 dB."""
