@@ -262,9 +262,10 @@ class GraphedCleanLoop:
     step(data) with 'rays_o', 'rays_d' [..,3] and 'images' [..,3] of `n_rays` rays (copied into the static buffers)."""
 
     LOSS_RING = 1024
+    PLAN_OVERLAP_MIN_ROWS = 600_000      # overlap_plan="auto": buffer capacity (rows) from which the scatter plan runs on its own stream (~400 k points per step)
 
     def __init__(self, model, optimizer, render_kwargs, n_rays, sampler=None, update_extra_interval=16, lr_lambda=None, headroom=0.5, perturb=True,
-                 capacity=None, overlap_plan=True, capture=True, seed=0, fused_backward=True, fused_composite=True):
+                 capacity=None, overlap_plan="auto", capture=True, seed=0, fused_backward=True, fused_composite=True):
         if not model.cuda_ray:
             raise ValueError("GraphedCleanLoop drives the occupancy-grid path (cuda_ray=True)")
         if model.density_scale != 1:
@@ -308,7 +309,11 @@ class GraphedCleanLoop:
             raise NotImplementedError("GraphedCleanLoop expects one (betas, eps) for all parameter groups (the reference's, main_nerf.py:122)")
         self.base_lr = float(optimizer.param_groups[0]["lr"])
         self.lr_dev = torch.tensor(self.base_lr, **f32)
-        self.plan_stream = torch.cuda.Stream() if overlap_plan else None
+        # the scatter plan beside the encoder, on a stream of its own: a fork and a join in the captured graph, ~30 us on this runtime -- more than the whole plan
+        # takes on a trained scene's sparse grid.  "auto": forked from PLAN_OVERLAP_MIN_ROWS buffer rows on (decided at every capture); same box, two rounds:
+        # 673 k points 1.102 / 1.098 ms forked against 1.141 / 1.137 serial, 125 k points 0.376 / 0.373 forked against 0.365 / 0.367 serial
+        self.overlap_plan = overlap_plan
+        self.plan_stream = torch.cuda.Stream() if overlap_plan is True else None
         self.graph, self.tr, self.rec, self.plan = None, None, None, None
         self.capture = bool(capture)      # False: the same explicit kernel sequence issued eagerly every step (tests, debugging)
         self.fused_composite = bool(fused_composite)    # False: compositing forward, clean_loss, compositing backward as three launches in a row
@@ -448,6 +453,10 @@ class GraphedCleanLoop:
     def prepare(self):
         if self.capacity is None:
             self.capacity = self._size()
+        if self.overlap_plan == "auto":
+            want = self.capacity >= self.PLAN_OVERLAP_MIN_ROWS
+            if want != (self.plan_stream is not None):
+                self.plan_stream = torch.cuda.Stream() if want else None
         self._allocate()
         for p, g in zip(self.params, list(self.g_tables.unbind(0)) + [self.g_sigma, self.g_color]):
             if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):

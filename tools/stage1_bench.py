@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Stage-1 (clean model) training step on the bench scene: 4096 rays, all parameters trainable.
 
-    python tools/stage1_bench.py [content|block] [--eager] [--steps K] [--windows W] [--no-refresh] [--two-launch] [--three-launch-composite] [--json]
+    python tools/stage1_bench.py [content|block] [--eager] [--steps K] [--windows W] [--no-refresh] [--no-overlap | --overlap] [--two-launch] [--three-launch-composite] [--json]
 
 Default: the captured loop (stage1.GraphedCleanLoop), perturbed samples, the density grid refreshed every 16 steps INSIDE the timed
 windows (the reference's loop does it there, nerf/utils.py:852-857).  W windows of K steps each; a window in which the loop had to grow
@@ -120,8 +120,9 @@ if "--eager" in flags:
 
 refresh = 0 if "--no-refresh" in flags else 16
 fused = "--two-launch" not in flags
+plan_mode = False if "--no-overlap" in flags else (True if "--overlap" in flags else "auto")      # the scatter plan on a stream of its own: never | always | from 600 k buffer rows on
 one_composite = "--three-launch-composite" not in flags      # (rm_composite_train_mse | compositing forward, clean_loss, compositing backward)
-loop = GraphedCleanLoop(m, opt, dict(dt_gamma=0, max_steps=1024), n_rays=n_rays, update_extra_interval=refresh, perturb=True, overlap_plan="--no-overlap" not in flags,
+loop = GraphedCleanLoop(m, opt, dict(dt_gamma=0, max_steps=1024), n_rays=n_rays, update_extra_interval=refresh, perturb=True, overlap_plan=plan_mode,
                         fused_backward=fused, fused_composite=one_composite)
 loop.step(data)
 for _ in range(31):
@@ -153,7 +154,7 @@ if refresh:
     try:
         m_s = fresh_model()
         opt_s = torch.optim.Adam(m_s.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
-        loop_s = GraphedCleanLoop(m_s, opt_s, dict(dt_gamma=0, max_steps=1024), n_rays=n_rays, update_extra_interval=0, perturb=True, overlap_plan="--no-overlap" not in flags,
+        loop_s = GraphedCleanLoop(m_s, opt_s, dict(dt_gamma=0, max_steps=1024), n_rays=n_rays, update_extra_interval=0, perturb=True, overlap_plan=plan_mode,
                                   fused_backward=fused, fused_composite=one_composite)
         loop_s.step(data)
         for _ in range(15):
