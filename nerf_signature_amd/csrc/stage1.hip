@@ -163,24 +163,31 @@ __global__ void __launch_bounds__(256) k_field_wgrad(WgradArgs a, uint32_t strid
 
 // slab sums in workgroup order -> sigma_net.params' gradient [3072] = [W1s 64x32 | W2s 16x64], color_net.params' [7168] = [Wc1 64x32 | Wc2 64x64 | Wc3 16x64]
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float *__restrict__ slabs, uint32_t n_wg, float *__restrict__ g_sigma, float *__restrict__ g_color) {
-    const uint32_t e = blockIdx.x * 256u + threadIdx.x;      // (role, product, register, lane)
-    if (e >= kWgradRoles * kWgradSlab) return;
+    // 64 elements per workgroup; its four waves each add a quarter of the slabs (sixteen in flight per thread: a chain of one dependent load per slab took 60 us
+    // for 128 slabs, one wave walking all 256 still 13 us -- this launch sits between the backward and the scatter), then the four partial sums are combined through
+    // LDS in wave order.  Every order fixed: the same bits every run.
+    __shared__ float quarter[4][64];
+    const uint32_t grp = threadIdx.x >> 6, j = threadIdx.x & 63u;
+    const uint32_t e = blockIdx.x * 64u + j;      // (role, product, register, lane); the grid covers kWgradRoles * kWgradSlab exactly
     const uint32_t role = e / kWgradSlab, i = e % kWgradSlab;
-    // sixteen slabs in flight per thread (a chain of one dependent load per slab took 60 us for 128 slabs); the partial sums are combined in
-    // a fixed order: the same bits every run
+    const uint32_t per = ceil_div(n_wg, 4u), w_begin = min(n_wg, grp * per), w_end = min(n_wg, w_begin + per);
     float part[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) part[u] = 0.0f;
-    for (uint32_t w0 = 0; w0 < n_wg; w0 += 16u) {
+    for (uint32_t w0 = w_begin; w0 < w_end; w0 += 16u) {
         float v[16];
 #pragma unroll
-        for (uint32_t u = 0; u < 16u; ++u) v[u] = w0 + u < n_wg ? slabs[((size_t)(w0 + u) * kWgradRoles + role) * kWgradSlab + i] : 0.0f;
+        for (uint32_t u = 0; u < 16u; ++u) v[u] = w0 + u < w_end ? slabs[((size_t)(w0 + u) * kWgradRoles + role) * kWgradSlab + i] : 0.0f;
 #pragma unroll
         for (int u = 0; u < 16; ++u) part[u] += v[u];
     }
     float s = 0.0f;
 #pragma unroll
     for (int u = 0; u < 16; ++u) s += part[u];
+    quarter[grp][j] = s;
+    __syncthreads();
+    if (grp != 0) return;
+    s = ((quarter[0][j] + quarter[1][j]) + quarter[2][j]) + quarter[3][j];
     const uint32_t q = i >> 10, reg = (i >> 6) & 15u, lane = i & 63u;
     const uint32_t row = (uint32_t)row_of_reg16((int)(lane >> 5), (int)reg), col = lane & 31u;
     if (role == 0) {
@@ -253,7 +260,8 @@ using namespace nsig;
 
 // slabs[n_wg][3 roles][4 products][16 registers][64 lanes] -> the two parameter gradients (also the tail of field_bwd_wgrad, stage1_fused.hip)
 int nsig::wgrad_reduce_launch(const float *slabs, uint32_t n_wg, float *grad_sigma_params, float *grad_color_params, hipStream_t st, const char *what) {
-    k_wgrad_reduce<<<ceil_div(kWgradRoles * kWgradSlab, 256u), 256, 0, st>>>(slabs, n_wg, grad_sigma_params, grad_color_params);
+    static_assert((kWgradRoles * kWgradSlab) % 64u == 0, "k_wgrad_reduce: 64 elements per workgroup");
+    k_wgrad_reduce<<<kWgradRoles * kWgradSlab / 64u, 256, 0, st>>>(slabs, n_wg, grad_sigma_params, grad_color_params);
     return check_launch(what);
 }
 
