@@ -803,10 +803,15 @@ __global__ void __launch_bounds__(1024) k_scatter_binned(const BinHeader *__rest
                     const uint32_t ix = cur[u][0] & 0xffffu, hyz = cur[u][0] >> 16;     // hyz: the pair's 13 row bits
                     const float wx = __uint_as_float(cur[u][1]), a0 = __uint_as_float(cur[u][2]), a1 = __uint_as_float(cur[u][3]);
                     unsigned long long *d0 = acc64 + 2u * ((ix ^ hyz) & (kBinRows - 1)), *d1 = acc64 + 2u * (((ix + 1u) ^ hyz) & (kBinRows - 1));
-                    atomicAdd(d0, (unsigned long long)to_fixed(a0 * (1.0f - wx), k));
-                    atomicAdd(d0 + 1, (unsigned long long)to_fixed(a1 * (1.0f - wx), k));
-                    atomicAdd(d1, (unsigned long long)to_fixed(a0 * wx, k));
-                    atomicAdd(d1 + 1, (unsigned long long)to_fixed(a1 * wx, k));
+                    // (an entry of a merged level carries ONE x side -- wx is exactly 0 or 1 -- and the other side's two adds would add zeros)
+                    if (wx != 1.0f) {
+                        atomicAdd(d0, (unsigned long long)to_fixed(a0 * (1.0f - wx), k));
+                        atomicAdd(d0 + 1, (unsigned long long)to_fixed(a1 * (1.0f - wx), k));
+                    }
+                    if (wx != 0.0f) {
+                        atomicAdd(d1, (unsigned long long)to_fixed(a0 * wx, k));
+                        atomicAdd(d1 + 1, (unsigned long long)to_fixed(a1 * wx, k));
+                    }
                 }
             }
 #pragma unroll
