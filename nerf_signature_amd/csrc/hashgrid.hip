@@ -754,24 +754,46 @@ __global__ void __launch_bounds__(1024) k_scatter_binned(const BinHeader *__rest
     const uint4 *__restrict__ queue = queue_all + (size_t)blockIdx.y * 4 * M;
     float *__restrict__ G = tg.g[blockIdx.y];
     const uint32_t slice = blockIdx.x / replicas, replica = blockIdx.x - slice * replicas;
-    for (uint32_t i = threadIdx.x; i < 2u * kBinRows; i += blockDim.x) acc64[i] = 0ull;
-    uint32_t start = 0;
-    for (uint32_t j = 0; j < slice; ++j) start += hd->counts[j];
-    const uint32_t n = hd->counts[slice], chunk = ceil_div(n, replicas);
+    // An owner is alone on its compute unit (128 KiB of accumulators), so every latency at its head is exposed, and with few entries the head IS the owner (41 us of
+    // the launch at 33 k points).  Order: the slice counts as ONE load per wave (was: up to 63 scalar loads, each waited for), then the first round of queue entries
+    // and the chunk maxima REQUESTED, then the accumulators cleared and the maximum reduced while those are on their way.
+    static_assert(kBinSlices == 64, "one slice count per lane");
+    const uint32_t lane = threadIdx.x & 63u, cnt = hd->counts[lane];
+    uint32_t before = lane < slice ? cnt : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) before += (uint32_t)__shfl_xor((int)before, d, 64);
+    const uint32_t start = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)cnt, (int)slice, 64)), chunk = ceil_div(n, replicas);
     const uint32_t beg = min(n, replica * chunk), end = min(n, beg + chunk);
+    // The queue walk, software-pipelined: a round's four entries per thread are requested one round ahead, and nothing in the loop is conditional.  (The first
+    // form -- four clamped loads, then `if (beyond the end) break;` in front of each entry's work -- compiled to load, s_waitcnt vmcnt(0), convert, four atomics,
+    // next load: every load is used only behind its own test, so the compiler sank it there, and a thread had ONE entry in flight whatever the unroll depth; the
+    // owners ran at the latency of ~40 dependent streaming loads.)  Requests beyond the end load the slice's last entry again; nothing is added for them.
+    constexpr int kAhead = 4;      // (2 / 4 / 8 entries ahead per thread: 375 / 369 / 370 us on the 16-level scatter at 671 k points, same box)
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t *__restrict__ q = reinterpret_cast<const u32x4_t *>(queue + start);
+    const uint32_t round = blockDim.x * kAhead;
+    u32x4_t cur[kAhead] = {}, nxt[kAhead];
+    if (beg < end) {      // (uniform)
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) cur[u] = __builtin_nontemporal_load(q + min(beg + u * blockDim.x + threadIdx.x, end - 1));
+    }
     // |contribution| <= gmax < 2^E; 2^11 of them stay below 2^62 with k = 51 - E.  A non-finite gradient anywhere in the launch
     // (an overflowing scaled loss under torch's GradScaler) poisons every row of G with NaN, so that the scaler's inf check sees it
     // exactly as it sees the inf/NaN float sums of the reference's dense gradients and skips the step.
-    uint32_t gb = hd->gmax_bits;
+    uint32_t gb = hd->gmax_bits, mx = 0;
+    __shared__ uint32_t smax;
     if (set_max != nullptr) {
-        __shared__ uint32_t smax;
-        if (threadIdx.x == 0) smax = 0;
-        __syncthreads();
-        uint32_t mx = 0;
         for (uint32_t i = threadIdx.x; i < n_set_max; i += blockDim.x) mx = max(mx, set_max[(size_t)blockIdx.y * n_set_max + i]);
+        if (threadIdx.x == 0) smax = 0;
+    }
+    if (beg < end)      // (uniform)
+        for (uint32_t i = threadIdx.x; i < 2u * kBinRows; i += blockDim.x) acc64[i] = 0ull;
+    __syncthreads();
+    if (set_max != nullptr) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
-        if ((threadIdx.x & 63u) == 0 && mx) atomicMax(&smax, mx);
+        if (lane == 0 && mx) atomicMax(&smax, mx);
         __syncthreads();
         gb = smax;
     }
@@ -780,19 +802,15 @@ __global__ void __launch_bounds__(1024) k_scatter_binned(const BinHeader *__rest
     frexpf(__uint_as_float(poisoned ? 0x3f800000u : gb), &E);
     int k = poisoned ? 0 : 51 - E;
     if (scale_by_count && !poisoned && n > 2048u) k = 62 - E - (32 - __builtin_clz(n));      // |sum| <= n * gmax < 2^(E + ceil(log2(n + 1))) stays below 2^62
-    __syncthreads();
-    // The queue walk, software-pipelined: a round's four entries per thread are requested one round ahead, and nothing in the loop is conditional.  (The first
-    // form -- four clamped loads, then `if (beyond the end) break;` in front of each entry's work -- compiled to load, s_waitcnt vmcnt(0), convert, four atomics,
-    // next load: every load is used only behind its own test, so the compiler sank it there, and a thread had ONE entry in flight whatever the unroll depth; the
-    // owners ran at the latency of ~40 dependent streaming loads.)  Requests beyond the end load the slice's last entry again; nothing is added for them.
-    constexpr int kAhead = 4;      // (2 / 4 / 8 entries ahead per thread: 375 / 369 / 370 us on the 16-level scatter at 671 k points, same box -- with the requests really in flight the owners are bound by their LDS atomics)
-    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-    if (beg < end) {      // (uniform)
-        const u32x4_t *__restrict__ q = reinterpret_cast<const u32x4_t *>(queue + start);
-        const uint32_t round = blockDim.x * kAhead;
-        u32x4_t cur[kAhead], nxt[kAhead];
-#pragma unroll
-        for (int u = 0; u < kAhead; ++u) cur[u] = __builtin_nontemporal_load(q + min(beg + u * blockDim.x + threadIdx.x, end - 1));
+    float *out = G + 2 * (size_t)slice * kBinRows;
+    if (beg >= end) {      // (uniform) nothing for this owner -- on the dense coarse levels (fewer than 2^19 rows) most slices: its rows are zeros, no accumulators needed
+        if (poisoned || replicas == 1) {
+            const float f = poisoned ? __uint_as_float(0x7fc00000u) : 0.0f;
+            for (uint32_t i4 = threadIdx.x; i4 < kBinRows / 2u; i4 += blockDim.x) *reinterpret_cast<float4 *>(out + 4u * i4) = make_float4(f, f, f, f);
+        }
+        return;
+    }
+    {
         for (uint32_t base = beg; base < end; base += round) {      // (uniform trip count)
 #pragma unroll
             for (int u = 0; u < kAhead; ++u) nxt[u] = __builtin_nontemporal_load(q + min(base + round + u * blockDim.x + threadIdx.x, end - 1));
@@ -819,12 +837,23 @@ __global__ void __launch_bounds__(1024) k_scatter_binned(const BinHeader *__rest
         }
     }
     __syncthreads();
-    float *out = G + 2 * (size_t)slice * kBinRows;
-    for (uint32_t i = threadIdx.x; i < 2u * kBinRows; i += blockDim.x) {
-        const long long v = (long long)acc64[i];
-        if (poisoned) out[i] = __uint_as_float(0x7fc00000u);
-        else if (replicas == 1) out[i] = v != 0 ? (float)ldexp((double)v, -k) : 0.0f;
-        else if (v != 0) atomicAdd(out + i, (float)ldexp((double)v, -k));
+    if (poisoned || replicas == 1) {
+        for (uint32_t i4 = threadIdx.x; i4 < kBinRows / 2u; i4 += blockDim.x) {      // two rows = four sums per thread and trip: 16-byte stores (the slice is 64 KiB-aligned in G)
+            float r[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const long long v = (long long)acc64[4u * i4 + c];
+                r[c] = poisoned ? __uint_as_float(0x7fc00000u) : (v != 0 ? (float)ldexp((double)v, -k) : 0.0f);
+            }
+            *reinterpret_cast<float4 *>(out + 4u * i4) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+    } else {
+        // replicas merge with float atomics, consecutive lanes on consecutive words: an atomic wave instruction leaves the L2 as one request per 64 bytes it touches (four
+        // lanes-of-a-row-pair per thread, 16 bytes apart, made it four times as many requests: the headline step's codebook scatter 30 -> 66 us)
+        for (uint32_t i = threadIdx.x; i < 2u * kBinRows; i += blockDim.x) {
+            const long long v = (long long)acc64[i];
+            if (v != 0) atomicAdd(out + i, (float)ldexp((double)v, -k));
+        }
     }
 }
 
@@ -1404,6 +1433,12 @@ static int reserve_owner_lds(const char *who) {
 }
 
 // sets record arrays [sets][M][8] -> sets tables; scratch = sets headers, then sets queues
+// the owners store their rows as 16-byte vectors
+static int owner_targets_aligned(const ScatterTargets &tg, uint32_t sets, const char *who) {
+    for (uint32_t i = 0; i < sets; ++i) NSIG_REQUIRE(aligned16(tg.g[i]), "%s: gradient table %u must be 16-byte aligned", who, i);
+    return NSIG_OK;
+}
+
 static int launch_binned(const float *rec, uint32_t M, uint32_t sets, const ScatterTargets &tg, uint32_t replicas, void *scratch, hipStream_t st,
                          const char *who) {
     static_assert(sizeof(BinHeader) % 16 == 0 && kBinGrid == 16 * 16, "the queues follow the headers 16-byte aligned; k_bin_scan walks 16 x 16 workgroups");
@@ -1416,6 +1451,7 @@ static int launch_binned(const float *rec, uint32_t M, uint32_t sets, const Scat
         }
     const size_t lds = (size_t)kBinRows * 2 * sizeof(unsigned long long);
     if (int e = reserve_owner_lds(who)) return e;
+    if (int e = owner_targets_aligned(tg, sets, who)) return e;
     const uint32_t blocks = ceil_div(M, kBinThreads) < kBinGrid ? ceil_div(M, kBinThreads) : kBinGrid;
     k_bin_count<<<dim3(blocks, sets), kBinThreads, 0, st>>>(rec, M, hd);
     k_bin_scan<<<sets, 1024, 0, st>>>(hd, blocks);
@@ -1458,6 +1494,7 @@ NSIG_EXPORT int hg_scatter_planned(const void *plan, uint32_t M, float *G, nsig_
     const ScatterPlan pl = scatter_plan_view(const_cast<void *>(plan), M);
     ScatterTargets tg{};
     tg.g[0] = G;
+    if (int e = owner_targets_aligned(tg, 1, "hg_scatter_planned")) return e;
     // replicas: 1 -> 63 us, 2 -> 40, 4 -> 32, 8 -> 43 on 5.2 M entries (more owners stream less each, but merge with more float atomics)
     k_scatter_binned<<<dim3(kBinSlices * kBinReplicas, 1), 1024, (size_t)kBinRows * 2 * sizeof(unsigned long long), as_stream(stream)>>>(pl.hd, pl.queue, M, tg,
                                                                                                                                            kBinReplicas);
@@ -1530,6 +1567,7 @@ NSIG_EXPORT int hg_levels_scatter(const float *xyzs, uint32_t M, const uint32_t 
     NSIG_REQUIRE((reinterpret_cast<uintptr_t>(plan) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_planes) & 7) == 0 && M < (1u << 27) && bound > 0.0f && stride >= M,
                  "hg_levels_scatter: plan must be 16-byte and d_planes 8-byte aligned, M < 2^27, bound > 0, stride >= M");
     if (int e = reserve_owner_lds("hg_levels_scatter")) return e;
+    if (int e = owner_targets_aligned(tg, NSIG_BASE_LEVELS, "hg_levels_scatter")) return e;
     const size_t staging = (size_t)kLevelStage * sizeof(uint4);
     static bool attr_set = false;
     if (!attr_set) {
