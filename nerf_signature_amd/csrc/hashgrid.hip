@@ -803,7 +803,7 @@ __global__ void __launch_bounds__(1024) k_scatter_binned(const BinHeader *__rest
     int k = poisoned ? 0 : 51 - E;
     if (scale_by_count && !poisoned && n > 2048u) k = 62 - E - (32 - __builtin_clz(n));      // |sum| <= n * gmax < 2^(E + ceil(log2(n + 1))) stays below 2^62
     float *out = G + 2 * (size_t)slice * kBinRows;
-    if (beg >= end) {      // (uniform) nothing for this owner -- on the dense coarse levels (fewer than 2^19 rows) most slices: its rows are zeros, no accumulators needed
+    if (beg >= end) {      // (uniform) nothing for this owner (two of level 0's 64 slices hold no cell pair at all; a replica beyond a short slice's end): its rows are zeros, no accumulators needed
         if (poisoned || replicas == 1) {
             const float f = poisoned ? __uint_as_float(0x7fc00000u) : 0.0f;
             for (uint32_t i4 = threadIdx.x; i4 < kBinRows / 2u; i4 += blockDim.x) *reinterpret_cast<float4 *>(out + 4u * i4) = make_float4(f, f, f, f);
