@@ -1346,7 +1346,7 @@ NSIG_EXPORT int opt_adam_dense_host(uint32_t n, float *const *params_host, const
 
 // Large tensors (stage 1: sixteen 4 MiB base tables with their own gradients): 4096-element chunks, float4 per lane, sixteen 16-byte loads in
 // flight per lane before the first dependent store, non-temporal loads and moment stores (a 448 MiB stream that nothing re-reads before it is evicted anyway).
-constexpr uint32_t kDenseChunk4 = 4096, kDenseBigNumel = 1u << 16;
+constexpr uint32_t kDenseChunk4 = 4096, kDenseBigNumel = 1u << 16, kDenseRideAlong = 1024;
 __global__ void __launch_bounds__(256) k_adam_dense_v4(DenseAdam a, uint32_t n, const float *__restrict__ scratch, float beta1, float beta2, float eps,
                                                        float grad_scale) {
     uint32_t i = 0;
@@ -1384,13 +1384,19 @@ NSIG_EXPORT int opt_adam_dense(uint32_t n, float *const *params_host, const floa
         const uint32_t cnt = n - first < (uint32_t)kDenseMax ? n - first : (uint32_t)kDenseMax;
         DenseAdam all{}, small{}, big{};
         uint32_t n_small = 0, n_big = 0, chunks_small = 0, chunks_big = 0;
+        auto vectorisable = [&](uint32_t j) {
+            return numel_host[j] % 4 == 0 && aligned16(params_host[j]) && aligned16(grads_host[j]) && aligned16(exp_avg_host[j]) && aligned16(exp_avg_sq_host[j]);
+        };
+        // a group with a large tensor launches the wide kernel anyway: its medium-sized tensors (stage 1: the two MLPs' 3072 + 7168 parameters beside sixteen 4 MiB
+        // tables) ride along as a few more workgroups instead of a launch of their own on the step's serial tail (the same update, element by element)
+        bool any_big = false;
+        for (uint32_t i = 0; i < cnt; ++i) any_big = any_big || (numel_host[first + i] >= kDenseBigNumel && vectorisable(first + i));
         for (uint32_t i = 0; i < cnt; ++i) {
             const uint32_t j = first + i;
             NSIG_REQUIRE(params_host[j] && grads_host[j] && exp_avg_host[j] && exp_avg_sq_host[j] && steps_host[j] && numel_host[j] > 0,
                          "opt_adam_dense: tensor %u has a null pointer or no elements", j);
             all.step[i] = steps_host[j];
-            const bool wide = numel_host[j] >= kDenseBigNumel && numel_host[j] % 4 == 0 && aligned16(params_host[j]) && aligned16(grads_host[j]) &&
-                              aligned16(exp_avg_host[j]) && aligned16(exp_avg_sq_host[j]);
+            const bool wide = numel_host[j] >= (any_big ? kDenseRideAlong : kDenseBigNumel) && vectorisable(j);
             DenseAdam &d = wide ? big : small;
             uint32_t &k = wide ? n_big : n_small, &chunks = wide ? chunks_big : chunks_small;
             d.p[k] = params_host[j]; d.g[k] = grads_host[j]; d.m[k] = exp_avg_host[j]; d.v[k] = exp_avg_sq_host[j];

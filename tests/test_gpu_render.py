@@ -875,6 +875,30 @@ def test_dense_adam_matches_torch_adam():
         np.testing.assert_allclose(oa.state[p]["exp_avg_sq"].cpu().numpy(), ob.state[q]["exp_avg_sq"].cpu().numpy(), rtol=2e-6, atol=0)
 
 
+def test_dense_adam_with_a_large_tensor_in_the_group_matches_torch_adam():
+    """A group that holds a large tensor runs the wide launch, and its medium-sized tensors (>= 1024 elements, a multiple of 4: stage 1's two MLP parameter
+    vectors beside the 4 MiB tables) ride along in it; the small and the odd-sized ones keep the element-wise launch.  All against torch.optim.Adam."""
+    from nerf_signature_amd.optim import CodebookAdam
+    torch.manual_seed(2)
+    shapes = [(1 << 17,), (3072,), (7168,), (1030,), (64,), (1 << 16, 2), (1024,), (5, 4097)]
+    a = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    oa = CodebookAdam(a, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, capturable=True)
+    ob = torch.optim.Adam(b, lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    lr_dev = torch.tensor(1e-2, device="cuda")
+    for step in range(4):
+        for i, (p, q) in enumerate(zip(a, b)):
+            g = torch.randn_like(p) * (10.0 ** (i % 5 - 4))
+            p.grad, q.grad = g.clone(), g.clone()
+        oa.step_dense(lr_dev)
+        ob.step()
+    for i, (p, q) in enumerate(zip(a, b)):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-6, atol=1e-7, err_msg=str(i))
+        ma = ob.state[q]["exp_avg"].cpu().numpy()      # (torch forms it as a lerp: elements near zero differ by rounding of the other association)
+        np.testing.assert_allclose(oa.state[p]["exp_avg"].cpu().numpy(), ma, rtol=2e-6, atol=1e-6 * float(np.abs(ma).max()), err_msg=str(i))
+        np.testing.assert_allclose(oa.state[p]["exp_avg_sq"].cpu().numpy(), ob.state[q]["exp_avg_sq"].cpu().numpy(), rtol=2e-6, atol=0, err_msg=str(i))
+
+
 def test_fused_decoder_gradients_are_views_of_one_flat_buffer():
     """What dp.GradExchange relies on for its single in-place all-reduce: after backward() every decoder parameter's .grad is a
     view of one contiguous buffer that they tile exactly (conv biases, whose gradient is identically zero, have none)."""
