@@ -206,7 +206,9 @@ int hg_scatter_sliced(const float *rec, uint32_t M, float *G, nsig_stream_t stre
 
 /* The same accumulation with the redundancy removed: the (point, corner-pair) hits are first grouped by slice with an exact
  * two-pass counting sort (self-contained 16-byte entries in `scratch`: hg_scatter_binned_scratch_bytes(M) bytes, 16-byte
- * aligned), then every slice owner streams only its own entries.  Three launches instead of one, ~3x less time on a million points. */
+ * aligned), then every slice owner streams only its own entries.  Three launches instead of one, ~3x less time on a million points.
+ * G (here and for hg_scatter_planned, hg_scatter_levels, hg_levels_scatter: every table) must be 16-byte aligned: an owner that is alone on its
+ * slice stores its rows as 16-byte vectors. */
 size_t hg_scatter_binned_scratch_bytes(uint32_t M);
 int hg_scatter_binned(const float *rec, uint32_t M, float *G, void *scratch, nsig_stream_t stream);
 

@@ -1572,8 +1572,8 @@ NSIG_EXPORT int hg_levels_scatter(const float *xyzs, uint32_t M, const uint32_t 
     NSIG_REQUIRE(xyzs && d_planes && plan, "hg_levels_scatter: null pointer");
     NSIG_REQUIRE((reinterpret_cast<uintptr_t>(plan) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_planes) & 7) == 0 && M < (1u << 27) && bound > 0.0f && stride >= M,
                  "hg_levels_scatter: plan must be 16-byte and d_planes 8-byte aligned, M < 2^27, bound > 0, stride >= M");
-    if (int e = reserve_owner_lds("hg_levels_scatter")) return e;
     if (int e = owner_targets_aligned(tg, NSIG_BASE_LEVELS, "hg_levels_scatter")) return e;
+    if (int e = reserve_owner_lds("hg_levels_scatter")) return e;
     const size_t staging = (size_t)kLevelStage * sizeof(uint4);
     static bool attr_set = false;
     if (!attr_set) {

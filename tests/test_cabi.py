@@ -56,6 +56,10 @@ def test_argument_validation_needs_no_gpu(native):
         native.call("field_bwd_wgrad", (1 << 26) + 1, None, d, d, d, d, d, d, d, d, d, d, d, d, d, d, d, None)
     with pytest.raises(ValueError, match="16-byte aligned"):
         native.call("field_bwd_wgrad", 64, None, d, d, d, d, d, d, native._vp(264), d, d, d, d, d, d, d, d, None)
+    # the slice owners store rows as 16-byte vectors: every gradient table of hg_levels_scatter has to be aligned
+    tables = (native._vp * 16)(*([256] * 15 + [264]))
+    with pytest.raises(ValueError, match="gradient table 15 must be 16-byte aligned"):
+        native.call("hg_levels_scatter", d, 64, None, 1.0, d, 64, d, tables, None)
     assert native.fn("field_bwd_wgrad_scratch_bytes")(1) == 12 * 1024 * 4 and native.fn("field_bwd_wgrad_scratch_bytes")(10 ** 6) == 256 * 12 * 1024 * 4
 
 
