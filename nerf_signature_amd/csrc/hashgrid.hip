@@ -562,6 +562,15 @@ template <int D>
 __device__ inline float row_shl(float v) {      // lane i reads lane i + D of its row (0 past the row's end)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + D, 0xf, 0xf, true));
 }
+// the maximum over the wave's 64 lanes (all active), the same value in every lane: four row shifts, then the four rows' first lanes
+__device__ inline uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x102, 0xf, 0xf, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xf, 0xf, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x108, 0xf, 0xf, true));
+    return max(max((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+               max((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+}
 __device__ inline float run_sum(float v, uint32_t l16, uint32_t run_end) {
     float o = row_shl<1>(v);
     v += l16 + 1u <= run_end ? o : 0.0f;
@@ -709,18 +718,44 @@ __global__ void __launch_bounds__(kBinThreads) k_level_entries(const float *__re
     ENT_STAMP(5);      // staging writes
     __syncthreads();
     ENT_STAMP(6);      // barrier
-    for (uint32_t j = threadIdx.x; j < (direct ? 0u : total); j += kBinThreads) {      // consecutive lanes: consecutive entries of a run = whole lines
-        const uint32_t sj = slice_of[j];
-        // streamed out: a queue line is written here once and read once by an owner on some other XCD -- no L2 can serve it (the launch itself takes the same time; the
-        // step is 1 % shorter for what the caches keep instead: same box, two rounds, 1.201 / 1.198 -> 1.189 / 1.187 ms with the owners' loads streamed as well)
+    // Copy-out: consecutive lanes take consecutive entries of a run = whole lines.  At most kLevelStage / kBinThreads = 4 entries per thread; all of a thread's LDS reads of
+    // one kind are issued together (as a loop over j this was, per entry, two dependent LDS round trips in front of its store: the workgroup's last phase, 25-42 % of its
+    // time -- and a workgroup's time is what this launch is made of: two workgroups per unit, ~9 us each, 19 rounds of them at 620 k points).  The empty asm statements
+    // pin the reads in front of the tests that guard the stores (a read used only behind a test is sunk behind it).
+    if (!direct && total != 0u) {      // (uniform)
         typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-        const uint4 e = staged[j];
-        const u32x4_t v = {e.x, e.y, e.z, e.w};
-        __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t *>(queue + roff[sj] + (j - base[sj])));
+        constexpr uint32_t kPer = kLevelStage / kBinThreads;
+        uint32_t sj[kPer], ro[kPer], ba[kPer];
+        u32x4_t e[kPer];
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t j = min(threadIdx.x + u * kBinThreads, total - 1u);
+            sj[u] = slice_of[j];
+            const uint4 t = staged[j];
+            e[u] = u32x4_t{t.x, t.y, t.z, t.w};
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) asm volatile("" : "+v"(sj[u]));
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            ro[u] = roff[sj[u]];
+            ba[u] = base[sj[u]];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) asm volatile("" : "+v"(ro[u]), "+v"(ba[u]), "+v"(e[u]));
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t j = threadIdx.x + u * kBinThreads;
+            // streamed out: a queue line is written here once and read once by an owner on some other XCD -- no L2 can serve it (the launch itself takes the same time; the
+            // step is 1 % shorter for what the caches keep instead: same box, two rounds, 1.201 / 1.198 -> 1.189 / 1.187 ms with the owners' loads streamed as well)
+            if (j < total) __builtin_nontemporal_store(e[u], reinterpret_cast<u32x4_t *>(queue + ro[u] + (j - ba[u])));
+        }
     }
     // the chunk's max |contribution|: a plain store; the level's owners take the maximum over the chunks themselves.  (One word per level raised with
-    // atomics by 31 k waves -- the codebook scatter's scheme, where 3 k waves do it -- was the largest single item of this kernel.)
-    if (gb) atomicMax(&wg_max, gb);      // (LDS)
+    // atomics by 31 k waves -- the codebook scatter's scheme, where 3 k waves do it -- was the largest single item of this kernel.)  The wave's maximum by
+    // lane exchanges (left to the compiler, `if (gb) atomicMax(...)` becomes a scalar loop over the wave's lanes), one LDS operation per wave.
+    gb = wave_max_u32(gb);
+    if (lane == 0 && gb) atomicMax(&wg_max, gb);      // (LDS)
     __syncthreads();
     if (threadIdx.x == 0) pl.chunk_max[(size_t)level * pl.n_chunks + chunk] = wg_max;
     ENT_STAMP(7);      // copy-out issued, maximum raised
