@@ -583,13 +583,14 @@ __device__ inline float run_sum(float v, uint32_t l16, uint32_t run_end) {
     return v;
 }
 
-#ifdef NSIG_ENT_TIMING      // diagnostic build: where a workgroup of k_level_entries spends its time (10 ns ticks, summed over workgroups, merged / plain levels)
-__device__ unsigned long long g_ent_phase[2][8];
+#ifdef NSIG_ENT_TIMING      // diagnostic build: where a workgroup of k_level_entries spends its time (10 ns ticks, summed over workgroups, per level; [level][8] = workgroups counted)
+__device__ unsigned long long g_ent_phase[16][9];
 #define ENT_STAMP(k)                                                                                          \
     do {                                                                                                      \
         if (threadIdx.x == 0) {                                                                               \
             const unsigned long long now_ = wall_clock64();                                                   \
-            atomicAdd(&g_ent_phase[blockIdx.y < kMergeLevels ? 0 : 1][k], now_ - ent_t_);                     \
+            atomicAdd(&g_ent_phase[level][k], now_ - ent_t_);                                                  \
+            if ((k) == 7) atomicAdd(&g_ent_phase[level][8], 1ull);                                             \
             ent_t_ = now_;                                                                                    \
         }                                                                                                     \
     } while (0)
@@ -762,10 +763,10 @@ __global__ void __launch_bounds__(kBinThreads) k_level_entries(const float *__re
 }
 
 #ifdef NSIG_ENT_TIMING
-NSIG_EXPORT int level_entries_phase_ticks(unsigned long long *out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ent_phase), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+NSIG_EXPORT int level_entries_phase_ticks(unsigned long long *out144, int reset) {
+    if (hipMemcpyFromSymbol(out144, HIP_SYMBOL(g_ent_phase), sizeof(unsigned long long) * 144) != hipSuccess) return 1;
     if (reset) {
-        unsigned long long zero[16] = {};
+        unsigned long long zero[144] = {};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_ent_phase), zero, sizeof(zero)) != hipSuccess) return 1;
     }
     return 0;

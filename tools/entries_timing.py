@@ -11,11 +11,14 @@ try:
 except SystemExit:
     pass
 from nerf_signature_amd import _native as nv
-out = (ctypes.c_ulonglong * 16)()
+out = (ctypes.c_ulonglong * 144)()
 fn = nv.load().level_entries_phase_ticks
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert fn(out, 0) == 0
 names = ["inputs", "cells+ranks", "run sums", "barrier", "prefix+barrier", "staging", "barrier", "copy-out+max"]
-for k, kind in enumerate(("merged levels", "plain levels")):
-    tot = sum(out[8 * k + i] for i in range(8))
-    print(kind, "share of workgroup time:", "  ".join(f"{names[i]} {100.0 * out[8 * k + i] / max(tot, 1):.0f}%" for i in range(8)), f"  (total {tot * 10 / 1e3:.0f} us over all workgroups and steps)")
+print("k_level_entries, mean us per workgroup and phase (thread 0's clock), by level:")
+print("level  " + "  ".join(f"{n:>14s}" for n in names) + "           total")
+for l in range(16):
+    n = max(out[9 * l + 8], 1)
+    v = [out[9 * l + i] * 0.01 / n for i in range(8)]
+    print(f"{l:5d}  " + "  ".join(f"{x:14.2f}" for x in v) + f"  {sum(v):14.2f}")
