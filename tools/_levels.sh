@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-level owner times of the stage-1 table scatter (variant built with -DNSIG_LEVELS_SPLIT) + phase shares inside k_level_entries (-DNSIG_ENT_TIMING)
 cd $GRAFT_REPO_ROOT
-python tools/entries_timing.py 2>&1 | grep -E "levels share|captured step"
+python tools/entries_timing.py 2>&1 | grep -E "captured step|mean us per workgroup|^level|^ +[0-9]+ "
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_levels
 rm -rf $out
 (cd /tmp && export TMPDIR=/tmp && NERFSIG_LIB=$GRAFT_REPO_ROOT/tools/_build/libnerfsig_split.so rocprofv3 --kernel-trace --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/tools/stage1_bench.py content --windows 2 --steps 32 > $out.log 2>&1)
