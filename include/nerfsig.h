@@ -605,6 +605,18 @@ size_t hg_levels_plan_bytes(uint32_t M);
 int hg_levels_plan(const float *xyzs, uint32_t M, const uint32_t *rows_dev, float bound, void *plan, nsig_stream_t stream);
 int hg_levels_scatter(const float *xyzs, uint32_t M, const uint32_t *rows_dev, float bound, const void *d_planes, uint32_t stride,
                       void *plan, float *const *G_host, nsig_stream_t stream);
+/*
+ * hg_levels_scatter with the optimiser step of the 16 tables inside the owners (one process: no gradient exchange between the two): an owner that has
+ * summed its slice's rows applies torch.optim.Adam's update to them -- opt_adam_dense's arithmetic, element by element, state in the same capturable format
+ * (device step counts, advanced here; scratch: 64 floats) -- instead of storing them, so the 64 MiB of table gradients are neither written nor read back and
+ * the tables' pass leaves the step's serial tail.  Replaces, for the tables, the reference's `optimizer.step()` behind 16 x embedding_dense_backward
+ * (nerf/utils.py:469-517 with nerf/network_hash.py:154-166).  The tables' .grad is NOT produced.  params / exp_avg / exp_avg_sq: 16 device tables [T,2],
+ * 16-byte aligned; steps: 16 device scalars; lr: device scalar.
+ */
+int hg_levels_scatter_adam(const float *xyzs, uint32_t M, const uint32_t *rows_dev, float bound, const void *d_planes, uint32_t stride,
+                           void *plan, float *const *params_host, float *const *exp_avg_host, float *const *exp_avg_sq_host,
+                           float *const *steps_host, const float *lr, float beta1, float beta2, float eps, float grad_scale, float *scratch,
+                           nsig_stream_t stream);
 
 #ifdef __cplusplus
 }

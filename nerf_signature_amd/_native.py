@@ -114,6 +114,7 @@ SIGNATURES = {
     "hg_levels_plan_bytes": [_u32],
     "hg_levels_plan": [_vp, _u32, _vp, _fl, _vp, _vp],
     "hg_levels_scatter": [_vp, _u32, _vp, _fl, _vp, _u32, _vp, _vp, _vp],
+    "hg_levels_scatter_adam": [_vp, _u32, _vp, _fl, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _fl, _fl, _fl, _fl, _vp, _vp],
 }
 _RESTYPES = {"nsig_last_error": _c.c_char_p, "nsig_host_device_pointer": _c.c_void_p, "rm_march_train_scratch_bytes": _sz, "mlp_packed_bytes": _sz, "hg_planes_bytes": _sz, "dec_workspace_bytes": _sz, "hg_scatter_levels_scratch_bytes": _sz, "hg_scatter_binned_scratch_bytes": _sz, "hg_scatter_plan_bytes": _sz, "field_wgrad_scratch_bytes": _sz, "field_bwd_wgrad_scratch_bytes": _sz, "hg_levels_plan_bytes": _sz}
 

@@ -777,6 +777,24 @@ NSIG_EXPORT int level_entries_phase_ticks(unsigned long long *out144, int reset)
 // also with the owners' loads really in flight: 369-375 us against 365-373 on the 16-level scatter; the f64 instructions are ~5 us of the owners, LABNOTES 17a)
 __device__ inline long long to_fixed(float c, int k) { return __double2ll_rn(ldexp((double)c, k)); }
 
+// torch.optim.Adam's update of one element (the dense passes further down and the owners' fused form share it)
+__device__ inline void adam_update(float g, float &p, float &m, float &v, float beta1, float beta2, float eps, float step_size, float inv_bc2_sqrt) {
+    m = m + (1.0f - beta1) * (g - m);                 // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * beta2 + ((1.0f - beta2) * g) * g;         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    const float denom = sqrtf(v) * inv_bc2_sqrt + eps;  // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+    p = p - step_size * (m / denom);                  // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+// The owners of hg_levels_scatter_adam finish with the optimiser step of their rows: a slice's gradient never leaves the chip (no 64 MiB of G written and read back,
+// no table pass on the step's serial tail).  scratch: k_adam_dense_prepare's two scalars per table ([set] = lr / (1 - beta1^t), [kOwnerAdamMax + set] = 1 / sqrt(1 - beta2^t)).
+constexpr int kOwnerAdamMax = 32;      // (= kDenseMax, the prepare kernel's scratch layout)
+struct OwnerAdam {
+    float *p[NSIG_BASE_LEVELS], *m[NSIG_BASE_LEVELS], *v[NSIG_BASE_LEVELS];
+    const float *scratch;
+    float beta1, beta2, eps, grad_scale;
+    uint32_t on;
+};
+
 // blockIdx.x = slice * replicas + replica: the slice's entries, split evenly over the replicas.  replicas == 1: the owner is
 // alone and stores its rows (no atomics, no zero-fill of the table, bit-reproducible); otherwise float atomics into G.
 // scale_by_count: the fixed-point scale leaves room for as many maximal contributions as the slice has entries (the base levels of stage 1: at
@@ -784,7 +802,7 @@ __device__ inline long long to_fixed(float c, int k) { return __double2ll_rn(lde
 // set_max (optional): [sets][n_set_max] partial maxima of |contribution| (float bit patterns) whose maximum replaces the header's gmax_bits.
 __global__ void __launch_bounds__(1024) k_scatter_binned(const BinHeader *__restrict__ hd_all, const uint4 *__restrict__ queue_all, uint32_t M,
                                                          ScatterTargets tg, uint32_t replicas, uint32_t scale_by_count = 0,
-                                                         const uint32_t *__restrict__ set_max = nullptr, uint32_t n_set_max = 0) {
+                                                         const uint32_t *__restrict__ set_max = nullptr, uint32_t n_set_max = 0, OwnerAdam adam = OwnerAdam{}) {
     extern __shared__ unsigned long long acc64[];  // [kBinRows][2] fixed point
     const BinHeader *__restrict__ hd = hd_all + blockIdx.y;
     const uint4 *__restrict__ queue = queue_all + (size_t)blockIdx.y * 4 * M;
@@ -823,7 +841,7 @@ __global__ void __launch_bounds__(1024) k_scatter_binned(const BinHeader *__rest
         for (uint32_t i = threadIdx.x; i < n_set_max; i += blockDim.x) mx = max(mx, set_max[(size_t)blockIdx.y * n_set_max + i]);
         if (threadIdx.x == 0) smax = 0;
     }
-    if (beg < end)      // (uniform)
+    if (beg < end || adam.on)      // (uniform)
         for (uint32_t i = threadIdx.x; i < 2u * kBinRows; i += blockDim.x) acc64[i] = 0ull;
     __syncthreads();
     if (set_max != nullptr) {
@@ -839,14 +857,14 @@ __global__ void __launch_bounds__(1024) k_scatter_binned(const BinHeader *__rest
     int k = poisoned ? 0 : 51 - E;
     if (scale_by_count && !poisoned && n > 2048u) k = 62 - E - (32 - __builtin_clz(n));      // |sum| <= n * gmax < 2^(E + ceil(log2(n + 1))) stays below 2^62
     float *out = G + 2 * (size_t)slice * kBinRows;
-    if (beg >= end) {      // (uniform) nothing for this owner (two of level 0's 64 slices hold no cell pair at all; a replica beyond a short slice's end): its rows are zeros, no accumulators needed
+    if (beg >= end && !adam.on) {      // (uniform) nothing for this owner (two of level 0's 64 slices hold no cell pair at all; a replica beyond a short slice's end): its rows are zeros, no accumulators needed
         if (poisoned || replicas == 1) {
             const float f = poisoned ? __uint_as_float(0x7fc00000u) : 0.0f;
             for (uint32_t i4 = threadIdx.x; i4 < kBinRows / 2u; i4 += blockDim.x) *reinterpret_cast<float4 *>(out + 4u * i4) = make_float4(f, f, f, f);
         }
         return;
     }
-    {
+    if (beg < end) {      // (uniform; an owner with the optimiser step inside comes here without entries too)
         for (uint32_t base = beg; base < end; base += round) {      // (uniform trip count)
 #pragma unroll
             for (int u = 0; u < kAhead; ++u) nxt[u] = __builtin_nontemporal_load(q + min(base + round + u * blockDim.x + threadIdx.x, end - 1));
@@ -873,6 +891,38 @@ __global__ void __launch_bounds__(1024) k_scatter_binned(const BinHeader *__rest
         }
     }
     __syncthreads();
+    if (adam.on) {      // (uniform; replicas == 1) the optimiser step of this slice's rows: parameters and moments in, the gradient from LDS, parameters and moments out
+        constexpr uint32_t kTrips = kBinRows / 2u / 1024u;      // float4 (two rows) per thread: the launch has 1024 threads
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        const size_t first = (size_t)slice * (kBinRows / 2u);
+        f32x4_t *pp = reinterpret_cast<f32x4_t *>(adam.p[blockIdx.y]) + first, *pm = reinterpret_cast<f32x4_t *>(adam.m[blockIdx.y]) + first,
+                *pv = reinterpret_cast<f32x4_t *>(adam.v[blockIdx.y]) + first;
+        const float ss = adam.scratch[blockIdx.y], ib = adam.scratch[kOwnerAdamMax + blockIdx.y];
+        f32x4_t p[kTrips], m[kTrips], v[kTrips];
+#pragma unroll
+        for (uint32_t u = 0; u < kTrips; ++u) {      // all twelve requests first (the moments stream; the parameters were gathered from by this step's encoder)
+            const uint32_t i4 = threadIdx.x + u * 1024u;
+            p[u] = pp[i4];
+            m[u] = __builtin_nontemporal_load(pm + i4);
+            v[u] = __builtin_nontemporal_load(pv + i4);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kTrips; ++u) {
+            const uint32_t i4 = threadIdx.x + u * 1024u;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const long long a = (long long)acc64[4u * i4 + c];
+                const float g = (poisoned ? __uint_as_float(0x7fc00000u) : (a != 0 ? (float)ldexp((double)a, -k) : 0.0f)) * adam.grad_scale;      // (what the plain owner stores, times opt_adam_dense's factor)
+                float pe = p[u][c], me = m[u][c], ve = v[u][c];
+                adam_update(g, pe, me, ve, adam.beta1, adam.beta2, adam.eps, ss, ib);
+                p[u][c] = pe; m[u][c] = me; v[u][c] = ve;
+            }
+            pp[i4] = p[u];      // (through the caches: the next step's encoder gathers from them; the moments stream out -- k_adam_dense_v4's policy)
+            __builtin_nontemporal_store(m[u], pm + i4);
+            __builtin_nontemporal_store(v[u], pv + i4);
+        }
+        return;
+    }
     if (poisoned || replicas == 1) {
         for (uint32_t i4 = threadIdx.x; i4 < kBinRows / 2u; i4 += blockDim.x) {      // two rows = four sums per thread and trip: 16-byte stores (the slice is 64 KiB-aligned in G)
             float r[4];
@@ -945,13 +995,6 @@ struct AdamPtrs {
     float step_size[NSIG_MAX_MESSAGE_DIM];
     float inv_bc2_sqrt[NSIG_MAX_MESSAGE_DIM];
 };
-
-__device__ inline void adam_update(float g, float &p, float &m, float &v, float beta1, float beta2, float eps, float step_size, float inv_bc2_sqrt) {
-    m = m + (1.0f - beta1) * (g - m);                 // exp_avg.lerp_(grad, 1 - beta1)
-    v = v * beta2 + ((1.0f - beta2) * g) * g;         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
-    const float denom = sqrtf(v) * inv_bc2_sqrt + eps;  // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
-    p = p - step_size * (m / denom);                  // param.addcdiv_(exp_avg, denom, value=-step_size)
-}
 
 __global__ void __launch_bounds__(256) k_codebook_adam(const float4 *__restrict__ G, AdamPtrs a, uint32_t D, float beta1, float beta2, float eps,
                                                        float grad_scale) {
@@ -1589,6 +1632,45 @@ NSIG_EXPORT int hg_levels_plan(const float *xyzs, uint32_t M, const uint32_t *ro
     return check_launch("hg_levels_plan");
 }
 
+// entries + owners of the planned 16-level scatter; adam.on: the owners end with the optimiser step of their rows instead of storing them (tg unused)
+static int levels_scatter_launch(const char *who, const float *xyzs, uint32_t M, const uint32_t *rows_dev, float bound, const void *d_planes, uint32_t stride, void *plan,
+                                 const ScatterTargets &tg, const OwnerAdam &adam, hipStream_t st) {
+    NSIG_REQUIRE(xyzs && d_planes && plan, "%s: null pointer", who);
+    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(plan) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_planes) & 7) == 0 && M < (1u << 27) && bound > 0.0f && stride >= M,
+                 "%s: plan must be 16-byte and d_planes 8-byte aligned, M < 2^27, bound > 0, stride >= M", who);
+    if (!adam.on)
+        if (int e = owner_targets_aligned(tg, NSIG_BASE_LEVELS, who)) return e;
+    if (int e = reserve_owner_lds(who)) return e;
+    const size_t staging = (size_t)kLevelStage * sizeof(uint4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_level_entries), hipFuncAttributeMaxDynamicSharedMemorySize, (int)staging) != hipSuccess) {
+            set_error("%s: cannot reserve %zu bytes of LDS", who, staging);
+            return NSIG_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const LevelsPlan pl = levels_plan_view(plan, M);
+    k_level_entries<<<dim3(pl.n_chunks, NSIG_BASE_LEVELS), kBinThreads, staging, st>>>(xyzs, M, rows_dev, bound, reinterpret_cast<const float2 *>(d_planes), stride,
+                                                                                     make_level_geom(), pl);
+    if (int e = check_launch(who)) return e;
+    // every (level, slice) has a single owner, which stores its rows: the tables are written, not accumulated into.  (The owners address set l's
+    // queue at l * 4 * M' entries: M' = 2 M is this plan's stride of 8 M.)
+    const uint32_t M_stride = M * (kLevelQueueStride / 4);
+#ifdef NSIG_LEVELS_SPLIT      // diagnostic build (tools/build_variant.sh): one owner launch per level, so that a kernel trace shows each level's time (the plain owners only)
+    for (int l = 0; l < NSIG_BASE_LEVELS; ++l) {
+        ScatterTargets one{};
+        one.g[0] = tg.g[l];
+        k_scatter_binned<<<dim3(kBinSlices, 1), 1024, (size_t)kBinRows * 2 * sizeof(unsigned long long), st>>>(pl.hd + l, pl.queue + (size_t)l * kLevelQueueStride * M,
+                                                                                                               M_stride, one, 1u, 1u, pl.chunk_max + (size_t)l * pl.n_chunks, pl.n_chunks);
+    }
+#else
+    k_scatter_binned<<<dim3(kBinSlices, NSIG_BASE_LEVELS), 1024, (size_t)kBinRows * 2 * sizeof(unsigned long long), st>>>(pl.hd, pl.queue, M_stride, tg, 1u, 1u,
+                                                                                                                          pl.chunk_max, pl.n_chunks, adam);
+#endif
+    return check_launch(who);
+}
+
 NSIG_EXPORT int hg_levels_scatter(const float *xyzs, uint32_t M, const uint32_t *rows_dev, float bound, const void *d_planes, uint32_t stride, void *plan,
                                   float *const *G_host, nsig_stream_t stream) {
     NSIG_REQUIRE(G_host, "hg_levels_scatter: null pointer");
@@ -1606,39 +1688,33 @@ NSIG_EXPORT int hg_levels_scatter(const float *xyzs, uint32_t M, const uint32_t 
             }
         return NSIG_OK;
     }
-    NSIG_REQUIRE(xyzs && d_planes && plan, "hg_levels_scatter: null pointer");
+    return levels_scatter_launch("hg_levels_scatter", xyzs, M, rows_dev, bound, d_planes, stride, plan, tg, OwnerAdam{}, st);
+}
+
+NSIG_EXPORT int hg_levels_scatter_adam(const float *xyzs, uint32_t M, const uint32_t *rows_dev, float bound, const void *d_planes, uint32_t stride, void *plan,
+                                       float *const *params_host, float *const *exp_avg_host, float *const *exp_avg_sq_host, float *const *steps_host, const float *lr,
+                                       float beta1, float beta2, float eps, float grad_scale, float *scratch, nsig_stream_t stream) {
+    NSIG_REQUIRE(params_host && exp_avg_host && exp_avg_sq_host && steps_host && lr && scratch, "hg_levels_scatter_adam: null pointer");
+    NSIG_REQUIRE(M >= 1, "hg_levels_scatter_adam: M must be positive (a step without points still runs the owners: the device row count may be zero)");
+    NSIG_REQUIRE(xyzs && d_planes && plan, "hg_levels_scatter_adam: null pointer");
     NSIG_REQUIRE((reinterpret_cast<uintptr_t>(plan) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_planes) & 7) == 0 && M < (1u << 27) && bound > 0.0f && stride >= M,
-                 "hg_levels_scatter: plan must be 16-byte and d_planes 8-byte aligned, M < 2^27, bound > 0, stride >= M");
-    if (int e = owner_targets_aligned(tg, NSIG_BASE_LEVELS, "hg_levels_scatter")) return e;
-    if (int e = reserve_owner_lds("hg_levels_scatter")) return e;
-    const size_t staging = (size_t)kLevelStage * sizeof(uint4);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_level_entries), hipFuncAttributeMaxDynamicSharedMemorySize, (int)staging) != hipSuccess) {
-            set_error("hg_levels_scatter: cannot reserve %zu bytes of LDS", staging);
-            return NSIG_ERR_LAUNCH;
-        }
-        attr_set = true;
-    }
-    const LevelsPlan pl = levels_plan_view(plan, M);
-    k_level_entries<<<dim3(pl.n_chunks, NSIG_BASE_LEVELS), kBinThreads, staging, st>>>(xyzs, M, rows_dev, bound, reinterpret_cast<const float2 *>(d_planes), stride,
-                                                                                     make_level_geom(), pl);
-    if (int e = check_launch("hg_levels_scatter (entries)")) return e;
-    // every (level, slice) has a single owner, which stores its rows: the tables are written, not accumulated into.  (The owners address set l's
-    // queue at l * 4 * M' entries: M' = 2 M is this plan's stride of 8 M.)
-    const uint32_t M_stride = M * (kLevelQueueStride / 4);
-#ifdef NSIG_LEVELS_SPLIT      // diagnostic build (tools/build_variant.sh): one owner launch per level, so that a kernel trace shows each level's time
+                 "hg_levels_scatter_adam: plan must be 16-byte and d_planes 8-byte aligned, M < 2^27, bound > 0, stride >= M");      // (before the step counts are touched)
+    static_assert(kOwnerAdamMax == kDenseMax, "k_adam_dense_prepare's scratch layout");
+    OwnerAdam adam{};
+    DenseAdam all{};
     for (int l = 0; l < NSIG_BASE_LEVELS; ++l) {
-        ScatterTargets one{};
-        one.g[0] = tg.g[l];
-        k_scatter_binned<<<dim3(kBinSlices, 1), 1024, (size_t)kBinRows * 2 * sizeof(unsigned long long), st>>>(pl.hd + l, pl.queue + (size_t)l * kLevelQueueStride * M,
-                                                                                                               M_stride, one, 1u, 1u, pl.chunk_max + (size_t)l * pl.n_chunks, pl.n_chunks);
+        NSIG_REQUIRE(params_host[l] && exp_avg_host[l] && exp_avg_sq_host[l] && steps_host[l], "hg_levels_scatter_adam: table %d has a null pointer", l);
+        NSIG_REQUIRE(aligned16(params_host[l]) && aligned16(exp_avg_host[l]) && aligned16(exp_avg_sq_host[l]), "hg_levels_scatter_adam: table %d must be 16-byte aligned", l);
+        adam.p[l] = params_host[l]; adam.m[l] = exp_avg_host[l]; adam.v[l] = exp_avg_sq_host[l];
+        all.step[l] = steps_host[l];
     }
-#else
-    k_scatter_binned<<<dim3(kBinSlices, NSIG_BASE_LEVELS), 1024, (size_t)kBinRows * 2 * sizeof(unsigned long long), st>>>(pl.hd, pl.queue, M_stride, tg, 1u, 1u,
-                                                                                                                          pl.chunk_max, pl.n_chunks);
-#endif
-    return check_launch("hg_levels_scatter");
+    adam.scratch = scratch;
+    adam.beta1 = beta1; adam.beta2 = beta2; adam.eps = eps; adam.grad_scale = grad_scale;
+    adam.on = 1u;
+    hipStream_t st = as_stream(stream);
+    k_adam_dense_prepare<<<1, kDenseMax, 0, st>>>(all, NSIG_BASE_LEVELS, lr, beta1, beta2, scratch);      // step counts + 1, the two scalars per table
+    if (int e = check_launch("hg_levels_scatter_adam (prepare)")) return e;
+    return levels_scatter_launch("hg_levels_scatter_adam", xyzs, M, rows_dev, bound, d_planes, stride, plan, ScatterTargets{}, adam, st);
 }
 
 NSIG_EXPORT int hg_scatter_level(const float *xyzs, float bound, const void *d_plane, uint32_t M, uint32_t level, float *G, nsig_stream_t stream) {

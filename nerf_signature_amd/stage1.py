@@ -265,7 +265,7 @@ class GraphedCleanLoop:
     PLAN_OVERLAP_MIN_ROWS = 600_000      # overlap_plan="auto": buffer capacity (rows) from which the scatter plan runs on its own stream (~400 k points per step)
 
     def __init__(self, model, optimizer, render_kwargs, n_rays, sampler=None, update_extra_interval=16, lr_lambda=None, headroom=0.5, perturb=True,
-                 capacity=None, overlap_plan="auto", capture=True, seed=0, fused_backward=True, fused_composite=True):
+                 capacity=None, overlap_plan="auto", capture=True, seed=0, fused_backward=True, fused_composite=True, fused_table_adam=None):
         if not model.cuda_ray:
             raise ValueError("GraphedCleanLoop drives the occupancy-grid path (cuda_ray=True)")
         if model.density_scale != 1:
@@ -318,6 +318,11 @@ class GraphedCleanLoop:
         self.capture = bool(capture)      # False: the same explicit kernel sequence issued eagerly every step (tests, debugging)
         self.fused_composite = bool(fused_composite)    # False: compositing forward, clean_loss, compositing backward as three launches in a row
         self.fused_backward = bool(fused_backward)      # False: field_bwd_trace + field_wgrad (the latter on the plan's stream) instead of field_bwd_wgrad
+        # the tables' Adam step inside the scatter's owners (hg_levels_scatter_adam): their gradient never leaves the chip -- no 64 MiB written and read back, no
+        # table pass on the step's tail; the tables' .grad is then NOT produced.  None: on unless the gradients are exchanged between ranks (which needs them in memory)
+        self.fused_table_adam = (not dp.exchange_active()) if fused_table_adam is None else bool(fused_table_adam)
+        if self.fused_table_adam and dp.exchange_active():
+            raise ValueError("GraphedCleanLoop: fused_table_adam steps the tables before any exchange -- one process only")
         self.global_step = 0
         self.recaptures = 0
         self.bytes_exchanged_per_step = self.flat.numel() * 4 if dp.exchange_active() else 0
@@ -369,8 +374,18 @@ class GraphedCleanLoop:
         _backward_trace(tr, self.g_sig, self.g_rgb, self.packed, self.g_sigma, self.g_color, rows=rows, wgrad_stream=self.plan_stream)
         if self.plan_stream is not None:      # the scatter needs the plan: an event recorded behind the plan, not the whole side stream
             main.wait_event(self._plan_done)
-        nv.call("hg_levels_scatter", nv.ptr(xyzs), M, nv.ptr(rows), float(m.bound), nv.ptr(tr.d_planes), tr.stride, nv.ptr(self.plan),
-                nv.ptr_array([self.g_tables[l] for l in range(16)]), s)
+        if self.fused_table_adam:
+            opt, tabs = self.optimizer, self.params[:16]
+            group = opt.param_groups[0]
+            self._ensure_state(tabs)
+            nv.call("hg_levels_scatter_adam", nv.ptr(xyzs), M, nv.ptr(rows), float(m.bound), nv.ptr(tr.d_planes), tr.stride, nv.ptr(self.plan),
+                    nv.ptr_array([p.data for p in tabs]), nv.ptr_array([opt.state[p]["exp_avg"] for p in tabs]),
+                    nv.ptr_array([opt.state[p]["exp_avg_sq"] for p in tabs]), nv.ptr_array([opt.state[p]["step"] for p in tabs]), nv.ptr(self.lr_dev),
+                    float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]), 1.0, nv.ptr(self._adam_scratch[0]), s)
+            _bump_versions(tabs)
+        else:
+            nv.call("hg_levels_scatter", nv.ptr(xyzs), M, nv.ptr(rows), float(m.bound), nv.ptr(tr.d_planes), tr.stride, nv.ptr(self.plan),
+                    nv.ptr_array([self.g_tables[l] for l in range(16)]), s)
 
     def _join_weight_gradients(self):
         if self.plan_stream is not None:
@@ -395,10 +410,9 @@ class GraphedCleanLoop:
         self._join_weight_gradients()
         dp.collective(lambda: dist.all_reduce(mlp, op=dist.ReduceOp.SUM), name="all_reduce_stage1_mlp")
 
-    def _adam(self, params):
-        """torch.optim.Adam's update of `params` from their `.grad` views through opt_adam_dense (state in torch's capturable format: device step counts)."""
+    def _ensure_state(self, params):
+        """torch.optim.Adam's state of `params` in its capturable format (device step counts), created on first use."""
         opt = self.optimizer
-        group = opt.param_groups[0]
         for p in params:
             st = opt.state[p]
             if len(st) == 0:
@@ -407,6 +421,12 @@ class GraphedCleanLoop:
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             elif not st["step"].is_cuda:
                 st["step"] = st["step"].to(p.device)
+
+    def _adam(self, params):
+        """torch.optim.Adam's update of `params` from their `.grad` views through opt_adam_dense (state in torch's capturable format: device step counts)."""
+        opt = self.optimizer
+        group = opt.param_groups[0]
+        self._ensure_state(params)
         n = len(params)
         numel = (ctypes.c_uint32 * n)(*[p.numel() for p in params])
         nv.call("opt_adam_dense", n, nv.ptr_array([p.data for p in params]), nv.ptr_array([p.grad for p in params]),
@@ -418,9 +438,10 @@ class GraphedCleanLoop:
     def _optimise(self):
         if self.fused_backward:                     # every gradient is there when the scatter is: one call (one prepare launch) over the 18 tensors
             self._join_weight_gradients()
-            self._adam(self.params)
+            self._adam(self.params[16:] if self.fused_table_adam else self.params)      # (fused_table_adam: the owners have stepped the 16 tables)
         else:
-            self._adam(self.params[:16])            # the tables need the scatter only: 448 MiB of streaming while the weight gradients finish
+            if not self.fused_table_adam:
+                self._adam(self.params[:16])        # the tables need the scatter only: 448 MiB of streaming while the weight gradients finish
             self._join_weight_gradients()
             self._adam(self.params[16:])
         nv.call("mlp_pack_weights", nv.ptr(self.model.sigma_net.params.detach()), nv.ptr(self.model.color_net.params.detach()), nv.ptr(self.packed), nv.stream())
@@ -458,10 +479,12 @@ class GraphedCleanLoop:
             if want != (self.plan_stream is not None):
                 self.plan_stream = torch.cuda.Stream() if want else None
         self._allocate()
-        for p, g in zip(self.params, list(self.g_tables.unbind(0)) + [self.g_sigma, self.g_color]):
+        for i, (p, g) in enumerate(zip(self.params, list(self.g_tables.unbind(0)) + [self.g_sigma, self.g_color])):
             if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
                 raise ValueError("GraphedCleanLoop: parameters must be contiguous float32 CUDA tensors")
-            p.grad = g.view_as(p)          # views of the flat buffer: what the kernels write is what an optimiser / a checkpoint sees
+            # views of the flat buffer: what the kernels write is what an optimiser / a checkpoint sees.  fused_table_adam: the tables' gradient exists inside the
+            # scatter's owners only -- no stale view is left behind
+            p.grad = None if (self.fused_table_adam and i < 16) else g.view_as(p)
         nv.call("mlp_pack_weights", nv.ptr(self.model.sigma_net.params.detach()), nv.ptr(self.model.color_net.params.detach()), nv.ptr(self.packed), nv.stream())
         # warm-up on a side stream (Adam state in its capturable format, module loading, RCCL's lazy set-up); it must not train
         snap = self._snapshot()

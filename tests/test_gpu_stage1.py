@@ -331,6 +331,36 @@ def test_one_launch_compositing_equals_the_three_launches_bit_for_bit():
     assert float(a[4].abs().max()) > 0
 
 
+def test_table_adam_inside_the_scatter_owners_equals_the_separate_pass_bit_for_bit():
+    """hg_levels_scatter_adam (an owner applies torch.optim.Adam's update to the rows it has just summed: no table gradient in memory, no table pass behind the scatter)
+    against hg_levels_scatter + opt_adam_dense: six captured steps with perturbed samples from the same state -- every parameter, both moments and the step count of every
+    tensor, and every loss value, bit for bit."""
+    from nerf_signature_amd.stage1 import GraphedCleanLoop
+    o, d = _patch_rays(16)
+    target = torch.tensor([0.2, 0.5, 0.8]).view(1, 3).expand(256, 3).contiguous().cuda()
+    data = {"rays_o": o.cuda()[None], "rays_d": d.cuda()[None], "images": target[None]}
+    got = []
+    for fused in (True, False):
+        m, _, _ = _clean_model()
+        torch.manual_seed(11)
+        loop = GraphedCleanLoop(m, _adam(m), KW, n_rays=256, update_extra_interval=0, perturb=True, fused_table_adam=fused, seed=3)
+        assert loop.fused_table_adam is fused
+        loop.step(data)
+        for _ in range(5):
+            loop.step()
+        torch.cuda.synchronize()
+        state = [(float(loop.optimizer.state[p]["step"]), loop.optimizer.state[p]["exp_avg"].clone(), loop.optimizer.state[p]["exp_avg_sq"].clone()) for p in m.trainable()]
+        got.append(([p.detach().clone() for p in m.trainable()], loop.losses(), state))
+        loop.close()
+    a, b = got
+    assert a[1] == b[1] and len(a[1]) == 6
+    for i, (x, y) in enumerate(zip(a[0], b[0])):
+        assert torch.equal(x, y), i
+    for i, (x, y) in enumerate(zip(a[2], b[2])):
+        assert x[0] == y[0] == 6.0 and torch.equal(x[1], y[1]) and torch.equal(x[2], y[2]), i
+    assert float((a[0][15] - _clean_model()[0].trainable()[15].detach()).abs().max()) > 0      # (the finest table did move)
+
+
 def test_captured_loop_tracks_the_cpu_oracle_over_200_steps():
     """From a common state, 200 steps of the captured loop and of the CPU oracle (the reference's operator sequence in torch autograd + torch's
     Adam): the loss every 20th step, and the PSNR of the trained render against the target within 0.1 dB."""
@@ -450,7 +480,8 @@ def test_two_rank_exchange_equals_the_single_process_gradient(monkeypatch):
 
     def run(o, d, gt, steps=1):
         m, _, _ = _clean_model()
-        loop = GraphedCleanLoop(m, _adam(m), KW, n_rays=o.shape[0], update_extra_interval=0, perturb=False, capture=False)
+        # (fused_table_adam=False: the single-process reference has to leave its table gradients in memory like the ranks, which exchange them)
+        loop = GraphedCleanLoop(m, _adam(m), KW, n_rays=o.shape[0], update_extra_interval=0, perturb=False, capture=False, fused_table_adam=False)
         data = {"rays_o": o.cuda(), "rays_d": d.cuda(), "images": gt.cuda()}
         for _ in range(steps):
             loop.step(data)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Stage-1 (clean model) training step on the bench scene: 4096 rays, all parameters trainable.
 
-    python tools/stage1_bench.py [content|block] [--eager] [--steps K] [--windows W] [--no-refresh] [--no-overlap | --overlap] [--two-launch] [--three-launch-composite] [--json]
+    python tools/stage1_bench.py [content|block] [--eager] [--steps K] [--windows W] [--no-refresh] [--no-overlap | --overlap] [--two-launch] [--three-launch-composite] [--separate-table-adam] [--json]
 
 Default: the captured loop (stage1.GraphedCleanLoop), perturbed samples, the density grid refreshed every 16 steps INSIDE the timed
 windows (the reference's loop does it there, nerf/utils.py:852-857).  W windows of K steps each; a window in which the loop had to grow
@@ -122,8 +122,9 @@ refresh = 0 if "--no-refresh" in flags else 16
 fused = "--two-launch" not in flags
 plan_mode = False if "--no-overlap" in flags else (True if "--overlap" in flags else "auto")      # the scatter plan on a stream of its own: never | always | from 600 k buffer rows on
 one_composite = "--three-launch-composite" not in flags      # (rm_composite_train_mse | compositing forward, clean_loss, compositing backward)
+table_adam_flag = False if "--separate-table-adam" in flags else None      # (None: the loop's default -- inside the scatter's owners unless gradients are exchanged)
 loop = GraphedCleanLoop(m, opt, dict(dt_gamma=0, max_steps=1024), n_rays=n_rays, update_extra_interval=refresh, perturb=True, overlap_plan=plan_mode,
-                        fused_backward=fused, fused_composite=one_composite)
+                        fused_backward=fused, fused_composite=one_composite, fused_table_adam=table_adam_flag)
 loop.step(data)
 for _ in range(31):
     loop.step()
@@ -155,7 +156,7 @@ if refresh:
         m_s = fresh_model()
         opt_s = torch.optim.Adam(m_s.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
         loop_s = GraphedCleanLoop(m_s, opt_s, dict(dt_gamma=0, max_steps=1024), n_rays=n_rays, update_extra_interval=0, perturb=True, overlap_plan=plan_mode,
-                                  fused_backward=fused, fused_composite=one_composite)
+                                  fused_backward=fused, fused_composite=one_composite, fused_table_adam=table_adam_flag)
         loop_s.step(data)
         for _ in range(15):
             loop_s.step()
@@ -180,30 +181,43 @@ if refresh:
 
 # ---- the same kernel sequence, eagerly, on one stream, every entry point between HIP events
 n_segments = len(loop.graph.segments) if loop.graph is not None else None
+loop_table_adam = bool(loop.fused_table_adam)
 steps_done, capacity, state = loop.global_step, loop.capacity, {k: v.detach().clone() for k, v in m.state_dict().items()}
 loop.close()
-m2 = fresh_model()
-m2.load_state_dict(state)
-opt2 = torch.optim.Adam(m2.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
-eager = GraphedCleanLoop(m2, opt2, dict(dt_gamma=0, max_steps=1024), n_rays=n_rays, update_extra_interval=0, perturb=True, overlap_plan=False, capture=False, capacity=capacity,
-                         fused_backward=fused, fused_composite=one_composite)
-eager.step(data)
-for _ in range(3):
-    eager.step()
-torch.cuda.synchronize()
-n = 10
-with CallTimer() as timer:
-    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0.record()
-    for _ in range(n):
+def eager_pass(table_adam_in_owners):
+    m2 = fresh_model()
+    m2.load_state_dict(state)
+    opt2 = torch.optim.Adam(m2.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    eager = GraphedCleanLoop(m2, opt2, dict(dt_gamma=0, max_steps=1024), n_rays=n_rays, update_extra_interval=0, perturb=True, overlap_plan=False, capture=False, capacity=capacity,
+                             fused_backward=fused, fused_composite=one_composite, fused_table_adam=table_adam_in_owners)
+    eager.step(data)
+    for _ in range(3):
         eager.step()
-    t1.record()
     torch.cuda.synchronize()
-pts_e = float(eager.count_ring[:, 0].float()[eager.count_ring[:, 0] > 0].mean())
+    with CallTimer() as tm:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            eager.step()
+        e1.record()
+        torch.cuda.synchronize()
+    pts_here = float(eager.count_ring[:, 0].float()[eager.count_ring[:, 0] > 0].mean())
+    eager.close()
+    return tm, e0.elapsed_time(e1) / n, pts_here
+
+
+n = 10
+table_adam = loop_table_adam
+timer, eager_ms, pts_e = eager_pass(table_adam)          # what the captured step runs
 rows = timer.table(n)
-say(f"  the same sequence issued eagerly on one stream: {t0.elapsed_time(t1) / n:.3f} ms/step, {pts_e:.0f} points/step")
+say(f"  the same sequence issued eagerly on one stream: {eager_ms:.3f} ms/step, {pts_e:.0f} points/step")
 for k, per, us in rows:
     say(f"  {k:32s} {per:5.1f} launches/step {us:9.1f} us/step")
+fused_scatter_s = timer.us("hg_levels_scatter_adam", n) * 1e-6 if table_adam else None
+if table_adam:      # the plain scatter + the separate table pass (the data-parallel route), for the scatter's own roofline record
+    timer, plain_ms, pts_e = eager_pass(False)
+    say(f"  with the tables' Adam step as a pass of its own (fused_table_adam=False): {plain_ms:.3f} ms/step; hg_levels_scatter {timer.us('hg_levels_scatter', n):.1f} us, "
+        f"opt_adam_dense {timer.us('opt_adam_dense', n):.1f} us")
 
 # ---- roofline records.
 # Table scatter: the reference's 16 embedding_dense_backward calls (hash_encoding.py / network_hash.py:154-166) read-modify-write 8 rows x 8 B per point and
@@ -241,7 +255,7 @@ out = {
     "ms_per_step": ms, "rays_per_s": n_rays / ms * 1e3, "rays": n_rays, "points_per_step": pts, "points_per_s": pts / ms * 1e3, "capacity_rows": capacity,
     "windows": win, "steps_per_window": steps, "grid_refresh_every": refresh, "recaptures": loop.recaptures, "capacity_overflow": bool(overflow), "loss_last": loss_last,
     "steps_trained": steps_done, "sparse_grid": sparse,
-    "eager_one_stream_ms_per_step": t0.elapsed_time(t1) / n, "eager_points_per_step": pts_e,
+    "eager_one_stream_ms_per_step": eager_ms, "eager_points_per_step": pts_e,
     "kernels_us_per_step": {k: round(us, 1) for k, _, us in rows},
     "roofline_scatter": {
         "kernel": "hg_levels_scatter = k_level_entries (16 levels x chunks of 1024 points: queue entries sorted by slice in LDS) + k_scatter_binned (16 x 64 slice owners, LDS fixed-point sums, "
@@ -254,6 +268,14 @@ out = {
                               "this_launch_over_floor": (sc_s / (pts_e * 1024 / ATOMIC_PEAK)) if sc_s else None,
                               "note": "a global-float-atomic scatter cannot run faster than floor_s (MI355X_MICROARCH.md: ~1.3 TB/s of added bytes chip-wide); < 1 means the owner scheme beats that roof"},
         "plan_us_off_path": timer.us("hg_levels_plan", n)},
+    "table_adam_in_owners": None if not table_adam else {
+        "entry_point": "hg_levels_scatter_adam (the captured step's default in one process): k_level_entries + k_scatter_binned whose owners end with torch.optim.Adam's update of their "
+                       "rows -- the 64 MiB of table gradients are neither written nor read back, the tables' pass leaves the step's tail; roofline_scatter above is the PLAIN scatter of a "
+                       "second eager pass (the route a data-parallel step takes)",
+        "avg_launch_s": fused_scatter_s, "bytes": "algorithmic 2188 B/point + parameters and both moments of 16 tables in and out (402.7 MB)",
+        "achieved_GBps": (pts_e * sc_alg + 6 * 16 * 4194304) / fused_scatter_s / 1e9 if fused_scatter_s else None,
+        "frac_hbm": (pts_e * sc_alg + 6 * 16 * 4194304) / fused_scatter_s / HBM_PEAK if fused_scatter_s else None,
+        "replaces_us": {"hg_levels_scatter": round(timer.us("hg_levels_scatter", n), 1), "opt_adam_dense_over_18_tensors": round(timer.us("opt_adam_dense", n), 1)}},
     "roofline_wgrad": {
         "kernel": ("k_field_bwd_wgrad (the MLP backward with the weight gradients inside: each layer's pre-activation gradient transposed through wave-private LDS into MFMA operands over "
                    "the points, the layer inputs staged from memory two layers ahead, 12 accumulator blocks per wave in AGPRs over all its tiles, v_mfma_f32_32x32x16_bf16 on split hi + lo "
