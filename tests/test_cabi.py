@@ -60,6 +60,12 @@ def test_argument_validation_needs_no_gpu(native):
     tables = (native._vp * 16)(*([256] * 15 + [264]))
     with pytest.raises(ValueError, match="gradient table 15 must be 16-byte aligned"):
         native.call("hg_levels_scatter", d, 64, None, 1.0, d, 64, d, tables, None)
+    # ... and the form with the optimiser step inside the owners refuses a misaligned moment table before it touches a step count
+    good, bad = (native._vp * 16)(*([256] * 16)), (native._vp * 16)(*([256] * 3 + [264] + [256] * 12))
+    with pytest.raises(ValueError, match="table 3 must be 16-byte aligned"):
+        native.call("hg_levels_scatter_adam", d, 64, None, 1.0, d, 64, d, good, bad, good, good, d, 0.9, 0.99, 1e-15, 1.0, d, None)
+    with pytest.raises(ValueError, match="null pointer"):
+        native.call("hg_levels_scatter_adam", d, 64, None, 1.0, d, 64, d, good, good, good, good, None, 0.9, 0.99, 1e-15, 1.0, d, None)
     assert native.fn("field_bwd_wgrad_scratch_bytes")(1) == 12 * 1024 * 4 and native.fn("field_bwd_wgrad_scratch_bytes")(10 ** 6) == 256 * 12 * 1024 * 4
 
 
