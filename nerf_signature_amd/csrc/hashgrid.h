@@ -139,17 +139,28 @@ __device__ inline uint4 pair_entry(uint32_t ix, uint32_t hyz, float wx, float wy
 }
 
 // A planned scatter's scratch: header, queue [4M] entries, destinations [M] (queue index of each of the point's four pairs)
+// Replicas of a slice owner (kBinReplicas > 1) merge EXACTLY: each writes its 64-bit fixed-point accumulators as a slab, takes a ticket, and the last to
+// arrive adds the other slabs to its own accumulators as integers (any order gives the same sum), converts once and adds ONE float per element to G.
+// The sums are then those of a single owner, bit for bit, whatever order the replicas ran in.  Per record set: 64 tickets, then [slice][replica] slabs.
+constexpr size_t kMergeTicketBytes = 256;
+static_assert(kMergeTicketBytes == kBinSlices * sizeof(uint32_t), "one ticket per slice");
+inline size_t scatter_merge_bytes(uint32_t replicas) { return kMergeTicketBytes + (size_t)kBinSlices * replicas * (2 * kBinRows) * sizeof(unsigned long long); }
+
 struct ScatterPlan {
     BinHeader *hd;
     uint4 *queue;
     uint4 *dest;
+    uint32_t *tickets;              // [kBinSlices], zero between launches (k_plan_count clears them; the merging owner leaves them cleared)
+    unsigned long long *slabs;      // [kBinSlices][kBinReplicas][2 * kBinRows]
 };
-inline size_t scatter_plan_bytes(uint32_t M) { return sizeof(BinHeader) + (size_t)5 * M * sizeof(uint4); }
+inline size_t scatter_plan_bytes(uint32_t M) { return sizeof(BinHeader) + (size_t)5 * M * sizeof(uint4) + scatter_merge_bytes(kBinReplicas); }
 inline ScatterPlan scatter_plan_view(void *scratch, uint32_t M) {
     ScatterPlan pl;
     pl.hd = reinterpret_cast<BinHeader *>(scratch);
     pl.queue = reinterpret_cast<uint4 *>(pl.hd + 1);
     pl.dest = pl.queue + (size_t)4 * M;
+    pl.tickets = reinterpret_cast<uint32_t *>(pl.dest + M);
+    pl.slabs = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(pl.tickets) + kMergeTicketBytes);
     return pl;
 }
 

@@ -198,11 +198,17 @@ def field_backward(xyzs, bound, g_sigma, g_rgb, sigmas, rgbs, masks, packed, G=N
 BINNED_MIN_POINTS = 65536   # below this the three launches of the binned route cost more than they save
 
 
+def binned_min_points():
+    """Launch size from which the codebook gradient goes through the fixed-point slice owners (bit-reproducible); NERFSIG_DETERMINISTIC=1: every size."""
+    from .switches import deterministic
+    return 1 if deterministic() else BINNED_MIN_POINTS
+
+
 def codebook_scatter_sliced(rec, G, binned=None):
     """G += scatter of the [M,8] record emitted by field_backward(want_rec=True).  binned: True -> hg_scatter_binned (hits
     grouped by slice first), False -> hg_scatter_sliced (every owner tests every point), None -> by size."""
     M = rec.shape[0]
-    if (M >= BINNED_MIN_POINTS) if binned is None else binned:
+    if (M >= binned_min_points()) if binned is None else binned:
         scratch = torch.empty(int(nv.fn("hg_scatter_binned_scratch_bytes")(M)), dtype=torch.uint8, device=rec.device)
         nv.call("hg_scatter_binned", nv.ptr(rec), M, nv.ptr(G), nv.ptr(scratch), nv.stream())
     else:
@@ -489,7 +495,7 @@ class _FieldFunction(Function):
             ctx.plan = fixed.plan if need_grad else None
         else:
             # before the encoder is enqueued: a plan on its own stream forks right behind the march, not behind this forward pass
-            ctx.plan = ScatterPlan(xyzs, bound) if need_grad and xyzs.shape[0] >= BINNED_MIN_POINTS else None
+            ctx.plan = ScatterPlan(xyzs, bound) if need_grad and xyzs.shape[0] >= binned_min_points() else None
         sigmas, rgbs, _, masks = field_forward(xyzs, dirs, bound, base, S, packed, want_masks=need_grad, fixed=fixed)
         ctx.bound, ctx.n_diff, ctx.need_grad, ctx.sink = bound, len(diff), need_grad, sink
         if need_grad:

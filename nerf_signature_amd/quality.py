@@ -147,6 +147,21 @@ def train(stage, steps=None, mode="graphed", lambda_w=README["lambda_w"], lambda
 
 
 @torch.no_grad()
+def state_checksums(stage):
+    """Integer checksums of everything the watermark stage trains -- the 2D codebook tables and the decoder's parameters and buffers: the sum of each tensor's
+    bit patterns (int64, wrapping).  Two runs leave the same list iff (up to a 2^-64 collision) they left the same bits; no 256 MB read-back."""
+    model = stage["model"]
+    named = [(f"msg_encoder.{i}", t) for i, t in enumerate(model.msg_encoder.tables())] + [(f"msg_decoder.{k}", v) for k, v in model.msg_decoder.state_dict().items()]
+    out = []
+    for name, t in named:
+        t = t.detach().contiguous()
+        bits = t.view(torch.int32) if t.dtype == torch.float32 else t.to(torch.int64)
+        w = torch.arange(1, bits.numel() + 1, dtype=torch.int64, device=bits.device).view(bits.shape)      # (position-weighted: a permutation of the values changes the sum)
+        out.append((name, int((bits.to(torch.int64) * w).sum().item())))
+    return out
+
+
+@torch.no_grad()
 def test_bitacc(stage, n_messages=200, seed=4321, distortion="none"):
     """Trainer.test_bitacc (utils_wtmk_disen.py:935-1030): per item a random message, eval_step(render_whole=False) on the watermark blocks
     (the model stays in whatever mode it is in -- the reference never calls model.eval() here, :951), BIT_ACC over the items.

@@ -6,6 +6,8 @@ compares it with the names that occur in the sources).  Rejected experiments are
   NERFSIG_MLP                   bf16x3 | f16 (default): arithmetic of the MLP kernels at start-up (include/nerfsig.h mlp_set_precision changes it at run time)
   NERFSIG_HALF_PLANES           0: fp32 feature planes between encoder and MLP instead of the mixed fp16 layout (bit-identical; the A/B of the layout)
   NERFSIG_DECODER               torch: the HiDDeN decoder through stock torch operators instead of the fused MFMA convolutions
+  NERFSIG_DETERMINISTIC         1: the codebook gradient of EVERY launch size through the fixed-point slice owners (bit-reproducible sums: csrc/hashgrid.hip k_scatter_binned);
+                                by default launches below 65 536 points take the cheaper record scatter, whose float atomics make G differ by an ulp from run to run
  render paths (each pair is bit-identical; the slower form is the one the parity tests compare against)
   NERFSIG_MARCH_FUSED           0 | nf | sw: the training march as stand-alone launches (near/far, scan + write) instead of the fused ones
   NERFSIG_STAGED_FUSED          0: a staged full-image render chunk by chunk (renderer_wtmk.py:555-570 literally) instead of one fused staging pass
@@ -27,7 +29,7 @@ compares it with the names that occur in the sources).  Rejected experiments are
 """
 import os
 
-DOCUMENTED = ("NERFSIG_LIB", "NERFSIG_MLP", "NERFSIG_HALF_PLANES", "NERFSIG_DECODER", "NERFSIG_MARCH_FUSED", "NERFSIG_STAGED_FUSED", "NERFSIG_EVAL_LOOP", "NERFSIG_DROPIN_OFF",
+DOCUMENTED = ("NERFSIG_LIB", "NERFSIG_MLP", "NERFSIG_HALF_PLANES", "NERFSIG_DECODER", "NERFSIG_DETERMINISTIC", "NERFSIG_MARCH_FUSED", "NERFSIG_STAGED_FUSED", "NERFSIG_EVAL_LOOP", "NERFSIG_DROPIN_OFF",
               "NERFSIG_DIST_BACKEND", "NERFSIG_FORCE_EXCHANGE", "NERFSIG_CAPTURE_COLLECTIVES", "NERFSIG_SHARD_OPTIMIZER", "NERFSIG_REPLICATE_BLOCKS", "NERFSIG_LAUNCH_WATCHDOG_S",
               "NERFSIG_SECONDARY_TIMEOUT_S", "NERFSIG_TEST_FAIL_CAPTURED")
 DROPIN_FEATURES = ("train_step", "block_graph", "step_graph", "get_rays", "dense_adam")
@@ -42,3 +44,8 @@ def dropin_off(feature):
     if unknown:
         raise ValueError(f"NERFSIG_DROPIN_OFF: unknown feature(s) {unknown}; known: {', '.join(DROPIN_FEATURES)}")
     return feature in listed
+
+
+def deterministic():
+    """True if NERFSIG_DETERMINISTIC=1 (read at every call)."""
+    return os.environ.get("NERFSIG_DETERMINISTIC", "0") == "1"

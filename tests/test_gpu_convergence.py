@@ -44,7 +44,7 @@ def _run_modes(recs, steps, **train_kw):
         rec = quality.train(stage, steps, mode, **train_kw)
         acc, wrong_mean, wrong_max = quality.test_bitacc(stage, 200)
         psnr = quality.test_image(stage)
-        recs[name] = dict(rec, bit_acc=acc, wrong_mean=wrong_mean, wrong_max=wrong_max, psnr=psnr, before=before)
+        recs[name] = dict(rec, bit_acc=acc, wrong_mean=wrong_mean, wrong_max=wrong_max, psnr=psnr, before=before, checksums=quality.state_checksums(stage))
         print(f"[{name:>14}] bit acc {before:.3f} -> {acc:.5f} (mean wrong bits/message {wrong_mean:.3f}, worst {wrong_max}); PSNR vs clean views {psnr:.3f} dB; "
               f"{rec['ms_per_step']:.3f} ms/step incl. {len(rec['log'])} host reads; overflow {rec['overflowed']}; loss_i {rec['loss_image']:.3e} loss_w {rec['loss_watermark']:.4f}")
         del stage
@@ -75,9 +75,15 @@ def test_bench_size_training_converges_the_same_in_every_execution_mode():
     recs = {}
     _run_modes(recs, steps)
     expected = _expected_adam_steps(D, steps)
-    base = recs["graphed"]
-    noise = abs(recs["graphed again"]["psnr"] - base["psnr"])
-    print(f"run-to-run spread of the captured loop (same binary, same inputs, twice): {noise:.3f} dB, {abs(recs['graphed again']['bit_acc'] - base['bit_acc']) * 32:.3f} bits")
+    base, again = recs["graphed"], recs["graphed again"]
+    # The measured path is bit-reproducible (round 6: the slice owners' replicas merge their fixed-point sums exactly, csrc/hashgrid.hip k_scatter_binned -- the
+    # determinism of the reference's embedding_dense_backward, hash_encoding_wtmk_bit.py:99-116): two runs of one binary from one seed leave the SAME codebook and
+    # decoder, bit for bit.  (Round 5 asserted a 0.5 dB bound on their PSNR difference instead and measured 0.79 dB on the driver's box: float atomics moved G by
+    # half an ulp, and the cold start's saddle amplified it.)
+    differing = [a[0] for a, b in zip(base["checksums"], again["checksums"]) if a != b]
+    print(f"captured loop twice from one seed: {len(base['checksums'])} trained tensors, {len(differing)} differ; PSNR {base['psnr']:.4f} / {again['psnr']:.4f} dB")
+    assert not differing, differing[:8]
+    assert again["psnr"] == base["psnr"] and again["bit_acc"] == base["bit_acc"] and again["log"] == base["log"]
     for name, r in recs.items():
         assert 0.35 < r["before"] < 0.65, (name, r["before"])                # untrained: chance
         assert r["bit_acc"] >= 1.0 - 1.0 / 32, (name, r["bit_acc"])          # trained: on average less than one wrong bit of 32 ...
@@ -86,13 +92,13 @@ def test_bench_size_training_converges_the_same_in_every_execution_mode():
         assert not r["overflowed"] and r["recaptures"] == 0, name            # no replay dropped a ray
         assert r["adam_steps"] == expected, name                             # per-table Adam step counts: one per selection, in every mode
         assert r["loss_image"] < 5e-6 and r["loss_watermark"] < 0.05, name
-        # PSNR of the watermarked views against the clean views = the watermark's own amplitude (MSE ~1e-6).  From a COLD start every run first sits on
-        # the decoder's chance plateau (a saddle: when it leaves is decided by the last bits of G, i.e. by the order of float atomics), so two runs of
-        # the SAME mode already end 0.1-0.15 dB apart (printed above) and the modes spread over +-0.4 dB: 1 dB (12 % in amplitude) bounds a systematic
-        # difference here; the 0.1 dB criterion is applied where it is decidable -- from a common warm state, in the next test
-        assert abs(r["psnr"] - base["psnr"]) < 1.0, (name, r["psnr"], base["psnr"])
+        # PSNR of the watermarked views against the clean views = the watermark's own amplitude (MSE ~1e-6).  The OTHER modes run the same arithmetic in another
+        # order somewhere (the eager loop's float reductions, the sharded optimiser's pre-sum), and from a COLD start every run first sits on the decoder's chance
+        # plateau -- a saddle: WHEN a run leaves it is decided by the last bits of G -- so modes end up to 0.9 dB apart (GPUTEST_r05: 60.51 .. 61.42 dB over six
+        # runs; 0.79 dB between two runs of the then non-reproducible captured loop).  2 dB (a quarter in amplitude) is twice that spread: it bounds a SYSTEMATIC
+        # difference; the 0.1 dB criterion is applied where it is decidable -- from a common warm state, in the next test
+        assert abs(r["psnr"] - base["psnr"]) < 2.0, (name, r["psnr"], base["psnr"])
         assert 50.0 < r["psnr"] < 75.0
-    assert noise < 0.5
 
 
 def test_second_half_of_the_run_from_a_common_state_agrees_within_a_tenth_of_a_db():

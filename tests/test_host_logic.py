@@ -767,3 +767,72 @@ def test_environment_switches_are_the_documented_ones(monkeypatch):
     assert dp.block_shard(32) == (16, 32)
     monkeypatch.setenv("NERFSIG_REPLICATE_BLOCKS", "1")
     assert dp.block_shard(32) is None
+
+
+def _load_bench():
+    import importlib.util
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_line_stays_below_the_drivers_tail_whatever_the_record_holds(tmp_path, monkeypatch, capfd):
+    """The driver keeps a 9 KB tail of stdout + stderr and parses the LAST line of stdout: round 5's 23.9 KB line came back `parsed: null`.  The emitter is run on
+    a synthetic record stuffed with prose and nested secondaries; the stdout line must stay below 8 KB, parse from a 9000-byte tail, carry the contract's
+    fields with `roofline` and `cpu_baseline`, and the complete record must land in bench_detail.json."""
+    import json
+    bench = _load_bench()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    prose = "x" * 3000
+    full = {"metric": "training rays/sec @4096 rays (hotdog, 32-bit msg)", "value": 4.4e6, "unit": "rays/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 0.92123456789,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 + f16 MFMA", "data": "synthetic",
+            "timing": {"ms_per_step_windows": [0.92, 0.91, 0.91], "ms_per_step_median": 0.91, "note": prose},
+            "config": {"workload": prose, "content_rays": 4096, "block_rays_total": 4608, "points_per_step_per_rank": 1404940, "execution": "hipGraph replay, 1 captured segment(s)",
+                       "hyper_parameters": prose, "fixed_blocks_variant": {"what": prose, "ms_per_step": 0.71}, "loss": 0.0025},
+            "roofline": {"kernel": "k_encode_planes", "bound": "l2_l1_fill", "achieved": 21700.0, "peak": 34500.0, "unit": "GB/s", "frac": 0.63, "frac_l2": 0.63, "traffic": 4.7e8,
+                         "frac_hbm_implemented_bytes": 0.76, "basis": prose, "observed_limiter": prose, "avg_launch_s": 2.3e-4, "points_per_launch": 1290137.0,
+                         "algorithmic_bytes_per_point": 1088, "whole_step": {"frac": 0.37, "note": prose}},
+            "roofline_mlp": {"kernel": "k_field_fwd", "bound": "mfma", "achieved": 600.0, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.24, "note": prose},
+            "cpu_baseline": {"value": 3845.5, "unit": "rays/s", "cores": 16, "kind": "port", "sample": prose, "same_basis": {"value": 375.0, "unit": "content rays/s", "how": prose}},
+            "quality": {"bit_acc": 1.0, "psnr_db": 61.3, "what": prose, "loss_log": [[i, 0.0, 0.1] for i in range(100)]},
+            "secondary": {name: {"what": prose, "ms_per_step": 1.0, "windows": [{"note": prose}] * 5, "sparse_grid": {"ms_per_step": 0.3}, "noise": {"ms_per_step": 0.9, "what": prose},
+                                 "rank_of_8": {"captured": {"ms_per_step": 0.48, "what": prose}}, "roofline_scatter": {"frac": 0.55, "kernel": prose}}
+                          for name in ("quality_two_ranks_gloo", "counter", "fern", "rank_emulation", "eager_reference_trainer_shape", "eval_loop", "distortion_layer", "stage1",
+                                       "one_more_child_added_later")}}
+    assert len(json.dumps(full)) > 60000
+    real_stdout = os.dup(1)
+    try:
+        bench.emit(full, real_stdout)
+    finally:
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+    out = capfd.readouterr().out
+    tail = ("stderr noise\n" * 50 + out)[-9000:]
+    last = [l for l in tail.splitlines() if l.strip()][-1]
+    assert len(last) < 8192 and len(last) <= bench.LINE_LIMIT
+    line = json.loads(last)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"]) and line["roofline"]["frac"] == 0.63
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"])
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert all(len(v) < 200 for v in _strings(line)), "prose leaked into the line"
+    assert line["ms_per_step"] == pytest.approx(0.92123456789, rel=1e-5)
+    assert json.load(open(tmp_path / bench.DETAIL_FILE)) == full                     # nothing is lost: the complete record is in the side file
+    # the guard of last resort: a record whose numeric blocks alone exceed the limit loses optional blocks, never the contract's
+    full["secondary"] = {f"child{i}": {"ms_per_step": float(i), "content_rays_per_s": 1e6, "points_per_step": i} for i in range(400)}
+    short = bench.compact_line(full)
+    assert len(json.dumps(short)) <= bench.LINE_LIMIT and "secondary" in short["dropped_for_length"] and "roofline" in short and "cpu_baseline" in short
+
+
+def _strings(o):
+    if isinstance(o, str):
+        yield o
+    elif isinstance(o, dict):
+        for v in o.values():
+            yield from _strings(v)
+    elif isinstance(o, list):
+        for v in o:
+            yield from _strings(v)
