@@ -108,7 +108,10 @@ __device__ inline float corner_weight(const Corner8 &c, int k, float g) {
 
 // ---- slice-binned codebook scatter: the layout shared by the binning passes (hashgrid.hip) and the producer of the queue
 // entries (k_field_bwd in field.hip, or k_bin_write from 32-byte records).  See the comment above BinHeader's users.
-constexpr uint32_t kBinThreads = 1024, kBinSlices = 64, kBinRows = NSIG_TABLE_ROWS / kBinSlices, kBinReplicas = 4;
+#ifndef NSIG_BIN_REPLICAS      // (diagnostic builds sweep it: tools/build_variant.sh rep2 -DNSIG_BIN_REPLICAS=2)
+#define NSIG_BIN_REPLICAS 4
+#endif
+constexpr uint32_t kBinThreads = 1024, kBinSlices = 64, kBinRows = NSIG_TABLE_ROWS / kBinSlices, kBinReplicas = NSIG_BIN_REPLICAS;
 constexpr uint32_t kBinGrid = 256;   // workgroups of the binning passes (each walks chunks w, w + kBinGrid, ...)
 
 struct BinHeader {                 // scratch header
@@ -139,18 +142,15 @@ __device__ inline uint4 pair_entry(uint32_t ix, uint32_t hyz, float wx, float wy
 }
 
 // A planned scatter's scratch: header, queue [4M] entries, destinations [M] (queue index of each of the point's four pairs)
-// Replicas of a slice owner (kBinReplicas > 1) merge EXACTLY: each writes its 64-bit fixed-point accumulators as a slab, takes a ticket, and the last to
-// arrive adds the other slabs to its own accumulators as integers (any order gives the same sum), converts once and adds ONE float per element to G.
-// The sums are then those of a single owner, bit for bit, whatever order the replicas ran in.  Per record set: 64 tickets, then [slice][replica] slabs.
-constexpr size_t kMergeTicketBytes = 256;
-static_assert(kMergeTicketBytes == kBinSlices * sizeof(uint32_t), "one ticket per slice");
-inline size_t scatter_merge_bytes(uint32_t replicas) { return kMergeTicketBytes + (size_t)kBinSlices * replicas * (2 * kBinRows) * sizeof(unsigned long long); }
+// Replicas of a slice owner (kBinReplicas > 1) merge EXACTLY: each leaves its 64-bit fixed-point accumulators as a slab, and a second launch (k_scatter_merge) adds
+// a slice's slabs as integers (any order gives the same sum), converts once and adds ONE float per element to G.  The sums are then those of a single owner, bit
+// for bit, whatever order the replicas ran in.  Per record set: [slice][replica] slabs of 2 * kBinRows words.
+inline size_t scatter_merge_bytes(uint32_t replicas) { return (size_t)kBinSlices * replicas * (2 * kBinRows) * sizeof(unsigned long long); }
 
 struct ScatterPlan {
     BinHeader *hd;
     uint4 *queue;
     uint4 *dest;
-    uint32_t *tickets;              // [kBinSlices], zero between launches (k_plan_count clears them; the merging owner leaves them cleared)
     unsigned long long *slabs;      // [kBinSlices][kBinReplicas][2 * kBinRows]
 };
 inline size_t scatter_plan_bytes(uint32_t M) { return sizeof(BinHeader) + (size_t)5 * M * sizeof(uint4) + scatter_merge_bytes(kBinReplicas); }
@@ -159,8 +159,7 @@ inline ScatterPlan scatter_plan_view(void *scratch, uint32_t M) {
     pl.hd = reinterpret_cast<BinHeader *>(scratch);
     pl.queue = reinterpret_cast<uint4 *>(pl.hd + 1);
     pl.dest = pl.queue + (size_t)4 * M;
-    pl.tickets = reinterpret_cast<uint32_t *>(pl.dest + M);
-    pl.slabs = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(pl.tickets) + kMergeTicketBytes);
+    pl.slabs = reinterpret_cast<unsigned long long *>(pl.dest + M);
     return pl;
 }
 

@@ -371,10 +371,9 @@ __device__ inline void point_slices(const float *__restrict__ xyzs, uint32_t m, 
     for (uint32_t q = 0; q < 4; ++q) sl[q] = pair_slice(pair_hash(iy, iz, q));
 }
 
-__global__ void __launch_bounds__(kBinThreads) k_plan_count(const float *__restrict__ xyzs, uint32_t M, float bound, BinHeader *__restrict__ hd, uint32_t *__restrict__ tickets) {
+__global__ void __launch_bounds__(kBinThreads) k_plan_count(const float *__restrict__ xyzs, uint32_t M, float bound, BinHeader *__restrict__ hd) {
     __shared__ uint32_t h[kBinSlices];
     if (threadIdx.x < kBinSlices) h[threadIdx.x] = 0;
-    if (blockIdx.x == 0 && threadIdx.x < kBinSlices) tickets[threadIdx.x] = 0;      // (the owners' merge, hashgrid.h; a merging owner also leaves its ticket cleared)
     if (blockIdx.x == 0 && threadIdx.x == 0) hd->gmax_bits = 0;   // k_field_bwd raises it (stream-ordered after the plan)
     __syncthreads();
     for (uint32_t m = blockIdx.x * kBinThreads + threadIdx.x; m < M; m += gridDim.x * kBinThreads) {
@@ -797,19 +796,22 @@ struct OwnerAdam {
 };
 
 // blockIdx.x = slice * replicas + replica: the slice's entries, split evenly over the replicas.  replicas == 1: the owner is
-// alone and stores its rows (no atomics, no zero-fill of the table, bit-reproducible).  replicas > 1 (tickets / slabs: hashgrid.h, "Replicas ... merge
-// EXACTLY"): every replica leaves its fixed-point accumulators as a slab and the last one to arrive sums them as integers, converts once and adds ONE
-// float per element to G -- the slice's sum is that of a single owner bit for bit, in whatever order the replicas (or the entries) ran; G itself
+// alone and stores its rows (no atomics, no zero-fill of the table, bit-reproducible).  replicas > 1 (`slabs`: hashgrid.h, "Replicas ... merge EXACTLY"):
+// every replica leaves its fixed-point accumulators as a slab and k_scatter_merge, the next launch, sums a slice's slabs as integers, converts once and adds
+// ONE float per element to G -- the slice's sum is that of a single owner bit for bit, in whatever order the replicas (or the entries) ran; G itself
 // accumulates over the launches of a step (block render, content render: a + b is commutative, so their order is immaterial too).  This is the
 // determinism of the reference's embedding_dense_backward (hash_encoding_wtmk_bit.py:99-116 -> a sort + segmented reduce).  (Until round 6 the replicas
-// each converted their partial sum and merged with float atomics: G moved by half an ulp from run to run, and Adam(eps = 1e-15) amplified that.)
+// each converted their partial sum and merged with float atomics: G moved by half an ulp from run to run, and Adam(eps = 1e-15) amplified that.  A merge
+// inside this launch -- slabs, a ticket per slice, the last arriver sums -- needs an agent-scope release / acquire around the ticket, i.e. a write-back and an
+// invalidate of the XCD's whole L2 per workgroup: 29 -> 150 us, profiles/r06_exact_merge_ab.txt.  A launch boundary gives the same visibility for one
+// launch gap.)
 // scale_by_count: the fixed-point scale leaves room for as many maximal contributions as the slice has entries (the base levels of stage 1: at
 // level 0 a million samples share 4913 rows, far more than the 2^11 per row the codebook level's scale assumes).
 // set_max (optional): [sets][n_set_max] partial maxima of |contribution| (float bit patterns) whose maximum replaces the header's gmax_bits.
 __global__ void __launch_bounds__(1024) k_scatter_binned(const BinHeader *__restrict__ hd_all, const uint4 *__restrict__ queue_all, uint32_t M,
                                                          ScatterTargets tg, uint32_t replicas, uint32_t scale_by_count = 0,
                                                          const uint32_t *__restrict__ set_max = nullptr, uint32_t n_set_max = 0, OwnerAdam adam = OwnerAdam{},
-                                                         uint32_t *__restrict__ tickets = nullptr, unsigned long long *__restrict__ slabs = nullptr) {
+                                                         unsigned long long *__restrict__ slabs = nullptr) {
     extern __shared__ unsigned long long acc64[];  // [kBinRows][2] fixed point
     const BinHeader *__restrict__ hd = hd_all + blockIdx.y;
     const uint4 *__restrict__ queue = queue_all + (size_t)blockIdx.y * 4 * M;
@@ -848,7 +850,7 @@ __global__ void __launch_bounds__(1024) k_scatter_binned(const BinHeader *__rest
         for (uint32_t i = threadIdx.x; i < n_set_max; i += blockDim.x) mx = max(mx, set_max[(size_t)blockIdx.y * n_set_max + i]);
         if (threadIdx.x == 0) smax = 0;
     }
-    if (beg < end || adam.on || replicas > 1)      // (uniform; a replica without entries may still be the one that merges)
+    if (beg < end || adam.on)      // (uniform)
         for (uint32_t i = threadIdx.x; i < 2u * kBinRows; i += blockDim.x) acc64[i] = 0ull;
     __syncthreads();
     if (set_max != nullptr) {
@@ -864,7 +866,7 @@ __global__ void __launch_bounds__(1024) k_scatter_binned(const BinHeader *__rest
     int k = poisoned ? 0 : 51 - E;
     if (scale_by_count && !poisoned && n > 2048u) k = 62 - E - (32 - __builtin_clz(n));      // |sum| <= n * gmax < 2^(E + ceil(log2(n + 1))) stays below 2^62
     float *out = G + 2 * (size_t)slice * kBinRows;
-    if (beg >= end && !adam.on && (replicas == 1 || poisoned || n == 0)) {      // (uniform) nothing for this owner (two of level 0's 64 slices hold no cell pair at all): its rows are zeros, no accumulators needed
+    if (beg >= end && !adam.on) {      // (uniform) nothing for this owner (two of level 0's 64 slices hold no cell pair at all; a replica beyond a short slice's end -- it leaves no slab, and the merge knows): its rows are zeros, no accumulators needed
         if (poisoned || replicas == 1) {
             const float f = poisoned ? __uint_as_float(0x7fc00000u) : 0.0f;
             for (uint32_t i4 = threadIdx.x; i4 < kBinRows / 2u; i4 += blockDim.x) *reinterpret_cast<float4 *>(out + 4u * i4) = make_float4(f, f, f, f);
@@ -941,48 +943,48 @@ __global__ void __launch_bounds__(1024) k_scatter_binned(const BinHeader *__rest
             *reinterpret_cast<float4 *>(out + 4u * i4) = make_float4(r[0], r[1], r[2], r[3]);
         }
     } else {
-        // The exact merge.  A replica with entries stores its slab (plain 16-byte stores), releases it at agent scope (the eight XCDs' L2s are not coherent with one another:
-        // the release writes the slab back, the merger's acquire drops its stale lines) and takes the slice's ticket; a replica beyond a short slice's end takes the
-        // ticket only.  The LAST arriver -- whichever it is -- adds the other slabs to its own accumulators (thread t owns the same words of every slab: no atomics),
-        // clears the ticket for the next launch, and adds the converted sums to G: one float atomic per non-zero element and launch, consecutive lanes on consecutive
-        // words (an atomic wave instruction leaves the L2 as one request per 64 bytes it touches).
+        // this replica's slab for k_scatter_merge (plain 16-byte stores; the launch boundary makes them visible)
         typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
         constexpr uint32_t kSlab = 2u * kBinRows;
-        const size_t set_slabs = (size_t)kBinSlices * replicas * kSlab;
-        unsigned long long *slice_slabs = slabs + blockIdx.y * set_slabs + (size_t)slice * replicas * kSlab;
-        uint32_t *ticket = tickets + (size_t)blockIdx.y * kBinSlices + slice;
-        if (beg < end) {
-            u64x2_t *mine = reinterpret_cast<u64x2_t *>(slice_slabs + (size_t)replica * kSlab);
-            for (uint32_t i2 = threadIdx.x; i2 < kBinRows; i2 += blockDim.x) mine[i2] = *reinterpret_cast<const u64x2_t *>(acc64 + 2u * i2);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        __shared__ uint32_t arrived;
-        if (threadIdx.x == 0) arrived = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (arrived != replicas - 1u) return;      // (uniform)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        constexpr uint32_t kTrips = kBinRows / 1024u;      // (the launch has 1024 threads)
-        u64x2_t sum[kTrips];
+        u64x2_t *mine = reinterpret_cast<u64x2_t *>(slabs + ((size_t)blockIdx.y * kBinSlices * replicas + (size_t)slice * replicas + replica) * kSlab);
+        for (uint32_t i2 = threadIdx.x; i2 < kBinRows; i2 += blockDim.x) mine[i2] = *reinterpret_cast<const u64x2_t *>(acc64 + 2u * i2);
+    }
+}
+
+// The exact merge of a slice's replicas (see k_scatter_binned).  blockIdx.x = slice * kMergeParts + part: a quarter of the slice's words per workgroup, one 8-byte
+// fixed-point sum per thread and trip -- consecutive lanes on consecutive words, for the loads and for the atomics behind them (an atomic wave instruction leaves
+// the L2 as one request per 64 bytes it touches; a row pair per lane would double them).  The scale is the one the replicas used (the launch's gmax); a poisoned
+// launch has written its NaNs already.  One float atomic per non-zero element and launch.
+constexpr uint32_t kMergeParts = 4, kMergeThreads = 1024;
+__global__ void __launch_bounds__(kMergeThreads) k_scatter_merge(const BinHeader *__restrict__ hd_all, ScatterTargets tg, uint32_t replicas,
+                                                                 const unsigned long long *__restrict__ slabs) {
+    constexpr uint32_t kSlab = 2u * kBinRows, kPartWords = kSlab / kMergeParts, kTrips = kPartWords / kMergeThreads;
+    static_assert(kPartWords % kMergeThreads == 0, "whole trips");
+    const BinHeader *__restrict__ hd = hd_all + blockIdx.y;
+    const uint32_t slice = blockIdx.x / kMergeParts, part = blockIdx.x - slice * kMergeParts;
+    const uint32_t n = hd->counts[slice], gb = hd->gmax_bits;
+    if (n == 0 || gb >= 0x7f800000u) return;      // (uniform) an empty slice; a poisoned launch
+    int E;
+    frexpf(__uint_as_float(gb), &E);
+    const int k = 51 - E;
+    const uint32_t chunk = ceil_div(n, replicas);
+    const unsigned long long *slice_slabs = slabs + ((size_t)blockIdx.y * kBinSlices + slice) * replicas * kSlab + (size_t)part * kPartWords;
+    unsigned long long sum[kTrips];
 #pragma unroll
-        for (uint32_t u = 0; u < kTrips; ++u) sum[u] = *reinterpret_cast<const u64x2_t *>(acc64 + 2u * (threadIdx.x + u * 1024u));
-        for (uint32_t r = 0; r < replicas; ++r) {
-            if (r == replica || min(n, r * chunk) >= n) continue;      // (uniform) itself; a replica that had no entries wrote no slab
-            const u64x2_t *theirs = reinterpret_cast<const u64x2_t *>(slice_slabs + (size_t)r * kSlab);
-            u64x2_t got[kTrips];
+    for (uint32_t u = 0; u < kTrips; ++u) sum[u] = 0ull;
+    for (uint32_t r = 0; r < replicas; ++r) {
+        if (min(n, r * chunk) >= n) break;      // (uniform) this replica and the ones behind it had no entries and left no slab
+        unsigned long long got[kTrips];
 #pragma unroll
-            for (uint32_t u = 0; u < kTrips; ++u) got[u] = __builtin_nontemporal_load(theirs + threadIdx.x + u * 1024u);
+        for (uint32_t u = 0; u < kTrips; ++u) got[u] = __builtin_nontemporal_load(slice_slabs + (size_t)r * kSlab + threadIdx.x + u * kMergeThreads);
 #pragma unroll
-            for (uint32_t u = 0; u < kTrips; ++u) sum[u] += got[u];
-        }
+        for (uint32_t u = 0; u < kTrips; ++u) sum[u] += got[u];
+    }
+    float *out = tg.g[blockIdx.y] + 2 * (size_t)slice * kBinRows + (size_t)part * kPartWords;
 #pragma unroll
-        for (uint32_t u = 0; u < kTrips; ++u) *reinterpret_cast<u64x2_t *>(acc64 + 2u * (threadIdx.x + u * 1024u)) = sum[u];
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < kSlab; i += blockDim.x) {
-            const long long v = (long long)acc64[i];
-            if (v != 0) atomicAdd(out + i, (float)ldexp((double)v, -k));
-        }
+    for (uint32_t u = 0; u < kTrips; ++u) {
+        const long long v = (long long)sum[u];
+        if (v != 0) atomicAdd(out + threadIdx.x + u * kMergeThreads, (float)ldexp((double)v, -k));
     }
 }
 
@@ -1584,17 +1586,9 @@ static int launch_binned(const float *rec, uint32_t M, uint32_t sets, const Scat
     k_bin_count<<<dim3(blocks, sets), kBinThreads, 0, st>>>(rec, M, hd);
     k_bin_scan<<<sets, 1024, 0, st>>>(hd, blocks);
     k_bin_write<<<dim3(blocks, sets), kBinThreads, 0, st>>>(rec, M, hd, queue);
-    uint32_t *tickets = nullptr;
-    unsigned long long *slabs = nullptr;
-    if (replicas > 1) {      // (one record set: the merge scratch follows its queue)
-        tickets = reinterpret_cast<uint32_t *>(queue + (size_t)sets * 4 * M);
-        slabs = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(tickets) + sets * kMergeTicketBytes);
-        if (hipMemsetAsync(tickets, 0, sets * kMergeTicketBytes, st) != hipSuccess) {
-            set_error("%s: hipMemsetAsync failed", who);
-            return NSIG_ERR_LAUNCH;
-        }
-    }
-    k_scatter_binned<<<dim3(kBinSlices * replicas, sets), 1024, lds, st>>>(hd, queue, M, tg, replicas, 0u, nullptr, 0u, OwnerAdam{}, tickets, slabs);
+    unsigned long long *slabs = replicas > 1 ? reinterpret_cast<unsigned long long *>(queue + (size_t)sets * 4 * M) : nullptr;      // (the merge scratch follows the queues)
+    k_scatter_binned<<<dim3(kBinSlices * replicas, sets), 1024, lds, st>>>(hd, queue, M, tg, replicas, 0u, nullptr, 0u, OwnerAdam{}, slabs);
+    if (replicas > 1) k_scatter_merge<<<dim3(kBinSlices * kMergeParts, sets), kMergeThreads, 0, st>>>(hd, tg, replicas, slabs);
     return check_launch(who);
 }
 
@@ -1619,7 +1613,7 @@ NSIG_EXPORT int hg_scatter_plan(const float *xyzs, uint32_t M, float bound, void
     const ScatterPlan pl = scatter_plan_view(plan, M);
     hipStream_t st = as_stream(stream);
     const uint32_t blocks = ceil_div(M, kBinThreads) < kBinGrid ? ceil_div(M, kBinThreads) : kBinGrid;
-    k_plan_count<<<blocks, kBinThreads, 0, st>>>(xyzs, M, bound, pl.hd, pl.tickets);
+    k_plan_count<<<blocks, kBinThreads, 0, st>>>(xyzs, M, bound, pl.hd);
     k_plan_dest<<<blocks, kBinThreads, 0, st>>>(xyzs, M, bound, pl.hd, pl.dest);
     return check_launch("hg_scatter_plan");
 }
@@ -1637,7 +1631,8 @@ NSIG_EXPORT int hg_scatter_planned(const void *plan, uint32_t M, float *G, nsig_
     // (with the owners' pipelined queue walk, round 5: 2 -> 31.0, 3 -> 28.5, 4 -> 28.9, 6 -> 37.4, 8 -> 43.2 us; the step the same for 2..4)
     k_scatter_binned<<<dim3(kBinSlices * kBinReplicas, 1), 1024, (size_t)kBinRows * 2 * sizeof(unsigned long long), as_stream(stream)>>>(pl.hd, pl.queue, M, tg,
                                                                                                                                            kBinReplicas, 0u, nullptr, 0u,
-                                                                                                                                           OwnerAdam{}, pl.tickets, pl.slabs);
+                                                                                                                                           OwnerAdam{}, pl.slabs);
+    k_scatter_merge<<<dim3(kBinSlices * kMergeParts, 1), kMergeThreads, 0, as_stream(stream)>>>(pl.hd, tg, kBinReplicas, pl.slabs);
     return check_launch("hg_scatter_planned");
 }
 

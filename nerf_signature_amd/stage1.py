@@ -535,9 +535,19 @@ class GraphedCleanLoop:
             m.local_step = done if self.global_step < 16 else 16
         m.update_extra_state()
         if self.graph is not None and done:
-            peak = int(self.count_ring[:done, 0].max())
+            peak = self._peak_over_ranks(self.count_ring[:done, 0].max())
             if peak > 0.9 * self.capacity:
                 self._grow(peak)
+
+    def _peak_over_ranks(self, peak_dev):
+        """The largest sample total of the window over ALL ranks.  Growing re-captures, and prepare()'s warm-up steps issue the step's collectives: a rank that grew
+        alone would run collectives its peers do not (ranks march different rays and cross the mark at different refreshes), and would end two optimiser steps
+        apart from them.  With the maximum every rank takes the same decision at the same refresh and arrives at the same capacity (stage1.py:542)."""
+        if dp.exchange_active() and dp.world_size() > 1:
+            import torch.distributed as dist
+            peak_dev = peak_dev.clone().to(torch.int32).reshape(1)
+            dist.all_reduce(peak_dev, op=dist.ReduceOp.MAX)
+        return int(peak_dev)
 
     def _grow(self, peak):
         torch.cuda.synchronize()

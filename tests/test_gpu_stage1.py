@@ -441,6 +441,7 @@ class _TwoRanks:
         self.turn = threading.Lock()
         self.slots = [None, None]
         self.bytes, self.calls = [0, 0], [0, 0]      # per rank, over all its calls
+        self.log = [[], []]                          # per rank: (operation, elements) of every call, in order
 
     def is_initialized(self):
         return True
@@ -463,7 +464,8 @@ class _TwoRanks:
             self.barrier.wait()
         finally:
             self.turn.acquire()
-        t.copy_(parts[0] + parts[1])
+        t.copy_(torch.maximum(parts[0], parts[1]) if op == torch.distributed.ReduceOp.MAX else parts[0] + parts[1])
+        self.log[self.local.rank].append((str(op).split(".")[-1], t.numel()))
         self.bytes[self.local.rank] += t.numel() * 4
         self.calls[self.local.rank] += 1
 
@@ -527,3 +529,66 @@ def test_two_rank_exchange_equals_the_single_process_gradient(monkeypatch):
     assert 0.5 * (float(l0.loss) + float(l1.loss)) == pytest.approx(float(ref.loss), rel=1e-5)
     for a, b in zip(m0.trainable(), m1.trainable()):
         assert torch.equal(a, b)                                                  # replicas in lockstep
+
+
+def test_one_rank_nearing_its_capacity_makes_both_ranks_grow_in_the_same_step(monkeypatch):
+    """ADVICE round 5 (stage1.py:542): the decision to grow the point buffers and capture again is taken from the maximum of the window's sample totals over ALL
+    ranks.  Rank 0's rays fill 95 % of the buffers, rank 1's a fraction: both grow at the same refresh to the same capacity, issue the same sequence of collectives
+    (a rank growing alone would run its warm-up steps' collectives against its peer's ordinary step) and stay in lockstep."""
+    import torch.distributed as dist
+    from nerf_signature_amd import dp
+    from nerf_signature_amd.stage1 import GraphedCleanLoop
+    rays = [_patch_rays(16, lo=184), _patch_rays(4, lo=20)]                           # through the middle of the ball | 16 rays near the image corner
+    rays[1] = tuple(t.repeat(16, 1) for t in rays[1])                                # (same number of rays on both ranks)
+    target = torch.full((256, 3), 0.5)
+
+    def run(r, capacity, steps):
+        m, _, _ = _clean_model()
+        loop = GraphedCleanLoop(m, _adam(m, 1e-3), KW, n_rays=256, update_extra_interval=4, perturb=False, capture=False, fused_table_adam=False, capacity=capacity)
+        data = {"rays_o": rays[r][0].cuda(), "rays_d": rays[r][1].cuda(), "images": target.cuda()}
+        totals = []
+        for it in range(steps):
+            loop.step(data if it == 0 else None)
+            totals.append(int(loop.count_ring[it % 16, 0]))
+        torch.cuda.synchronize()
+        return loop, m, totals
+
+    from nerf_signature_amd.raymarching import padded_point_count
+    n0, n1 = (run(r, None, 1)[2][0] for r in range(2))
+    capacity = padded_point_count(int(n0 / 0.95))
+    assert n1 < 0.5 * capacity < 0.9 * capacity < n0 <= capacity, (n0, n1, capacity)
+    group = _TwoRanks()
+    for name in ("is_initialized", "get_world_size", "get_rank", "get_backend", "all_reduce"):
+        monkeypatch.setattr(dist, name, getattr(group, name))
+    results, errors = [None, None], []
+
+    def rank_main(r):
+        group.turn.acquire()
+        try:
+            group.local.rank = r
+            torch.cuda.set_device(0)
+            results[r] = run(r, capacity, 6)
+        except BaseException as e:      # noqa: BLE001
+            errors.append(e)
+            group.barrier.abort()
+        finally:
+            if group.turn.locked():
+                try:
+                    group.turn.release()
+                except RuntimeError:
+                    pass
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    (l0, m0, t0), (l1, m1, t1) = results
+    assert l0.recaptures == l1.recaptures == 1 and l0.capacity == l1.capacity > capacity          # rank 1 alone would not have grown
+    assert group.log[0] == group.log[1] and ("MAX", 1) in group.log[0]                             # the same collectives, in the same order, on both ranks
+    assert l0.global_step == l1.global_step == 6 and not l0.overflowed() and not l1.overflowed()
+    for a, b in zip(m0.trainable(), m1.trainable()):
+        assert torch.equal(a, b)                                                                   # ... and the replicas are still in lockstep
+    for p in m0.trainable():
+        assert float(l0.optimizer.state[p]["step"]) == 6.0                                         # six optimiser steps: the warm-up of the re-capture trained nothing
