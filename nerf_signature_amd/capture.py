@@ -42,7 +42,19 @@ class SegmentedCapture:
         try:
             with torch.cuda.stream(self.stream):
                 self.segments[0].capture_begin(capture_error_mode="thread_local")
-                out = fn()
+                try:
+                    out = fn()
+                except BaseException:
+                    # fn() raised in the middle of a segment: the stream must not be left capturing (every later launch on it would fail with "operation not
+                    # permitted when stream is capturing").  End the open segment, drop everything captured so far, and let the error travel.
+                    if open_capture[0]:
+                        open_capture[0] = False
+                        try:
+                            self.segments[-1].capture_end()
+                        except Exception:      # noqa: BLE001 -- the capture may already be invalidated by the failing call; the original error is the one to report
+                            pass
+                    self.segments, self.between = [], []
+                    raise
                 if open_capture[0]:
                     self.segments[-1].capture_end()
         finally:

@@ -1682,8 +1682,11 @@ NSIG_EXPORT int hg_levels_plan(const float *xyzs, uint32_t M, const uint32_t *ro
 }
 
 // entries + owners of the planned 16-level scatter; adam.on: the owners end with the optimiser step of their rows instead of storing them (tg unused)
+// `prepare` (optional): launched between the entries pass and the owners -- behind everything that can fail without a launch (argument checks, the LDS reservations) and
+// behind the first launch: hg_levels_scatter_adam's step-count increment then never happens without the owners' update that goes with it.
+template <typename Prepare>
 static int levels_scatter_launch(const char *who, const float *xyzs, uint32_t M, const uint32_t *rows_dev, float bound, const void *d_planes, uint32_t stride, void *plan,
-                                 const ScatterTargets &tg, const OwnerAdam &adam, hipStream_t st) {
+                                 const ScatterTargets &tg, const OwnerAdam &adam, hipStream_t st, Prepare prepare) {
     NSIG_REQUIRE(xyzs && d_planes && plan, "%s: null pointer", who);
     NSIG_REQUIRE((reinterpret_cast<uintptr_t>(plan) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_planes) & 7) == 0 && M < (1u << 27) && bound > 0.0f && stride >= M,
                  "%s: plan must be 16-byte and d_planes 8-byte aligned, M < 2^27, bound > 0, stride >= M", who);
@@ -1703,6 +1706,7 @@ static int levels_scatter_launch(const char *who, const float *xyzs, uint32_t M,
     k_level_entries<<<dim3(pl.n_chunks, NSIG_BASE_LEVELS), kBinThreads, staging, st>>>(xyzs, M, rows_dev, bound, reinterpret_cast<const float2 *>(d_planes), stride,
                                                                                      make_level_geom(), pl);
     if (int e = check_launch(who)) return e;
+    if (int e = prepare()) return e;
     // every (level, slice) has a single owner, which stores its rows: the tables are written, not accumulated into.  (The owners address set l's
     // queue at l * 4 * M' entries: M' = 2 M is this plan's stride of 8 M.)
     const uint32_t M_stride = M * (kLevelQueueStride / 4);
@@ -1737,7 +1741,7 @@ NSIG_EXPORT int hg_levels_scatter(const float *xyzs, uint32_t M, const uint32_t 
             }
         return NSIG_OK;
     }
-    return levels_scatter_launch("hg_levels_scatter", xyzs, M, rows_dev, bound, d_planes, stride, plan, tg, OwnerAdam{}, st);
+    return levels_scatter_launch("hg_levels_scatter", xyzs, M, rows_dev, bound, d_planes, stride, plan, tg, OwnerAdam{}, st, []() { return (int)NSIG_OK; });
 }
 
 NSIG_EXPORT int hg_levels_scatter_adam(const float *xyzs, uint32_t M, const uint32_t *rows_dev, float bound, const void *d_planes, uint32_t stride, void *plan,
@@ -1761,9 +1765,10 @@ NSIG_EXPORT int hg_levels_scatter_adam(const float *xyzs, uint32_t M, const uint
     adam.beta1 = beta1; adam.beta2 = beta2; adam.eps = eps; adam.grad_scale = grad_scale;
     adam.on = 1u;
     hipStream_t st = as_stream(stream);
-    k_adam_dense_prepare<<<1, kDenseMax, 0, st>>>(all, NSIG_BASE_LEVELS, lr, beta1, beta2, scratch);      // step counts + 1, the two scalars per table
-    if (int e = check_launch("hg_levels_scatter_adam (prepare)")) return e;
-    return levels_scatter_launch("hg_levels_scatter_adam", xyzs, M, rows_dev, bound, d_planes, stride, plan, ScatterTargets{}, adam, st);
+    return levels_scatter_launch("hg_levels_scatter_adam", xyzs, M, rows_dev, bound, d_planes, stride, plan, ScatterTargets{}, adam, st, [&]() {
+        k_adam_dense_prepare<<<1, kDenseMax, 0, st>>>(all, NSIG_BASE_LEVELS, lr, beta1, beta2, scratch);      // step counts + 1, the two scalars per table
+        return check_launch("hg_levels_scatter_adam (prepare)");
+    });
 }
 
 NSIG_EXPORT int hg_scatter_level(const float *xyzs, float bound, const void *d_plane, uint32_t M, uint32_t level, float *G, nsig_stream_t stream) {

@@ -40,6 +40,30 @@ T_ROWS = fo.T_ROWS
 N_SIGMA, N_COLOR = 3072, 7168      # sigma_net.params / color_net.params (tcnn layout)
 
 
+RESOLUTIONS = (16, 22, 30, 42, 58, 80, 111, 153, 212, 294, 406, 561, 776, 1072, 1482, 2047)      # csrc/hashgrid.h kBaseResolution (hash_encoding.py:60,100 in fp32)
+_LIVE_ROWS = {}
+
+
+def live_rows(level):
+    """The rows of base table `level` that can EVER carry a gradient, sorted: what the level's grid corners hash to (hash_encoding.py:11-22: x ^ y * 2654435761 ^
+    z * 805459861, 19 bits; cell indices 0..res from a coordinate in [0, 1], upper corners one more).  A static bound, the same on every rank: the coarse levels
+    have few corners -- 5832 at level 0 -- scattered by the hash over the table's 2^19 rows, and every other row's gradient is an exact zero the owners store."""
+    if level not in _LIVE_ROWS:
+        import numpy as np
+        n = RESOLUTIONS[level] + 2
+        if n ** 3 >= 4 * T_ROWS:
+            rows = np.arange(T_ROWS, dtype=np.int64)        # (far more corners than rows: every row is hit)
+        else:
+            i = np.arange(n, dtype=np.uint32)
+            h = (i[:, None, None] ^ (i[None, :, None] * np.uint32(2654435761)) ^ (i[None, None, :] * np.uint32(805459861))) & np.uint32(T_ROWS - 1)
+            rows = np.unique(h.reshape(-1)).astype(np.int64)
+        _LIVE_ROWS[level] = torch.from_numpy(rows)
+    return _LIVE_ROWS[level]
+
+
+SPARSE_EXCHANGE_LEVELS = tuple(l for l in range(16) if (RESOLUTIONS[l] + 2) ** 3 < T_ROWS // 2)      # levels 0..4: 5832 .. 216 000 corners for 524 288 rows
+
+
 def _stride(M):
     return (M + 31) // 32 * 32
 
@@ -265,7 +289,7 @@ class GraphedCleanLoop:
     PLAN_OVERLAP_MIN_ROWS = 600_000      # overlap_plan="auto": buffer capacity (rows) from which the scatter plan runs on its own stream (~400 k points per step)
 
     def __init__(self, model, optimizer, render_kwargs, n_rays, sampler=None, update_extra_interval=16, lr_lambda=None, headroom=0.5, perturb=True,
-                 capacity=None, overlap_plan="auto", capture=True, seed=0, fused_backward=True, fused_composite=True, fused_table_adam=None):
+                 capacity=None, overlap_plan="auto", capture=True, seed=0, fused_backward=True, fused_composite=True, fused_table_adam=None, sparse_exchange=True):
         if not model.cuda_ray:
             raise ValueError("GraphedCleanLoop drives the occupancy-grid path (cuda_ray=True)")
         if model.density_scale != 1:
@@ -299,10 +323,21 @@ class GraphedCleanLoop:
         # one flat gradient buffer: [16 tables | sigma MLP | colour MLP] -- the scatter owners and the weight-gradient reduction WRITE it
         # (no zero fill), a data-parallel step all-reduces it in one collective, Adam reads it
         self.params = model.trainable()
-        self.flat = torch.empty(16 * T_ROWS * 2 + N_SIGMA + N_COLOR, **f32)
-        self.g_tables = self.flat[:16 * T_ROWS * 2].view(16, T_ROWS, 2)
-        self.g_sigma = self.flat[16 * T_ROWS * 2:16 * T_ROWS * 2 + N_SIGMA]
-        self.g_color = self.flat[16 * T_ROWS * 2 + N_SIGMA:]
+        # Data-parallel ranks exchange only what can be non-zero: the coarse levels' gradients live on the few rows their grid corners hash to
+        # (live_rows: a static set, identical on every rank), so those levels travel as their live rows, packed behind the dense levels -- 16 tables = 64 MiB
+        # become levels 5..15 dense + 347 k rows = 46.6 MiB; the sums are the dense exchange's bit for bit (the same two operands per element).  Layout of the one
+        # buffer: [levels 0..4 dense (local) | levels 5..15 dense | packed live rows of levels 0..4 | sigma MLP | colour MLP]; exchanged: everything behind levels 0..4.
+        self.sparse_exchange = bool(sparse_exchange) and dp.exchange_active()
+        n_tab = 16 * T_ROWS * 2
+        self._n_local = len(SPARSE_EXCHANGE_LEVELS) * T_ROWS * 2 if self.sparse_exchange else 0
+        assert SPARSE_EXCHANGE_LEVELS == tuple(range(len(SPARSE_EXCHANGE_LEVELS)))
+        self._live_index = (torch.cat([live_rows(l) + l * T_ROWS for l in SPARSE_EXCHANGE_LEVELS]).to(dev) if self.sparse_exchange else None)
+        n_packed = 2 * self._live_index.numel() if self.sparse_exchange else 0
+        self.flat = torch.empty(n_tab + n_packed + N_SIGMA + N_COLOR, **f32)
+        self.g_tables = self.flat[:n_tab].view(16, T_ROWS, 2)
+        self.g_packed = self.flat[n_tab:n_tab + n_packed].view(-1, 2)
+        self.g_sigma = self.flat[n_tab + n_packed:n_tab + n_packed + N_SIGMA]
+        self.g_color = self.flat[n_tab + n_packed + N_SIGMA:]
         self.packed = torch.empty(int(nv.fn("mlp_packed_bytes")()), dtype=torch.uint8, device=dev)
         self._adam_scratch = [torch.empty(64, **f32), torch.empty(64, **f32)]
         if any(g["betas"] != optimizer.param_groups[0]["betas"] or g["eps"] != optimizer.param_groups[0]["eps"] for g in optimizer.param_groups):
@@ -325,7 +360,7 @@ class GraphedCleanLoop:
             raise ValueError("GraphedCleanLoop: fused_table_adam steps the tables before any exchange -- one process only")
         self.global_step = 0
         self.recaptures = 0
-        self.bytes_exchanged_per_step = self.flat.numel() * 4 if dp.exchange_active() else 0
+        self.bytes_exchanged_per_step = (self.flat.numel() - self._n_local) * 4 if dp.exchange_active() else 0
 
     # ---- pieces of one step (run eagerly once as warm-up, then under capture)
     def _march(self):
@@ -334,6 +369,7 @@ class GraphedCleanLoop:
 
     def _forward_backward(self):
         m, tr = self.model, self.tr
+        self._wg_joined = False
         if self.sampler is not None:
             self.sampler.sample_into(self.step_dev, self.rays_o, self.rays_d, self.gt)
         rec = self.rec = self._march()
@@ -388,8 +424,11 @@ class GraphedCleanLoop:
                     nv.ptr_array([self.g_tables[l] for l in range(16)]), s)
 
     def _join_weight_gradients(self):
-        if self.plan_stream is not None:
+        """Once per step: a second wait in a LATER captured segment (the optimiser behind a collective that ended the segment in which the plan's stream was
+        forked) would make the capturing stream wait on an event recorded outside its capture (stage1.py:390)."""
+        if self.plan_stream is not None and not self._wg_joined:
             torch.cuda.current_stream().wait_stream(self.plan_stream)
+        self._wg_joined = True
 
     def _exchange(self):
         """The data-parallel exchange of the flat gradient buffer (SUM; every rank seeded its loss with 1 / world).  Where a collective does not end a captured segment
@@ -400,15 +439,20 @@ class GraphedCleanLoop:
             return
         import torch.distributed as dist
         n_tab = 16 * T_ROWS * 2
+        if self.sparse_exchange:      # the coarse levels' live rows, packed behind the dense levels (one gather; one scatter back behind the collective)
+            coarse = self.flat[:self._n_local].view(-1, 2)
+            torch.index_select(coarse, 0, self._live_index, out=self.g_packed)
         if dp.collective_ends_segment():
-            flat = self.flat
+            flat = self.flat[self._n_local:]
             self._join_weight_gradients()           # one buffer, one collective: everything in it has to be there
             dp.collective(lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM), name="all_reduce_stage1_gradients")
-            return
-        tables, mlp = self.flat[:n_tab], self.flat[n_tab:]
-        dp.collective(lambda: dist.all_reduce(tables, op=dist.ReduceOp.SUM), name="all_reduce_stage1_tables")
-        self._join_weight_gradients()
-        dp.collective(lambda: dist.all_reduce(mlp, op=dist.ReduceOp.SUM), name="all_reduce_stage1_mlp")
+        else:
+            tables, mlp = self.flat[self._n_local:n_tab + self.g_packed.numel()], self.flat[n_tab + self.g_packed.numel():]
+            dp.collective(lambda: dist.all_reduce(tables, op=dist.ReduceOp.SUM), name="all_reduce_stage1_tables")
+            self._join_weight_gradients()
+            dp.collective(lambda: dist.all_reduce(mlp, op=dist.ReduceOp.SUM), name="all_reduce_stage1_mlp")
+        if self.sparse_exchange:
+            coarse.index_copy_(0, self._live_index, self.g_packed)
 
     def _ensure_state(self, params):
         """torch.optim.Adam's state of `params` in its capturable format (device step counts), created on first use."""
@@ -529,13 +573,16 @@ class GraphedCleanLoop:
     def refresh_grid(self):
         """update_extra_state between two replays (utils.py:852-857), with the loop's own ring of sample totals standing in for the renderer's."""
         m = self.model
-        done = min(16, self.global_step)
+        # the steps since the previous refresh (the reference resets local_step there, utils.py:852-858, renderer_wtmk.py:534-538), at most the ring's 16: their totals in
+        # step order into the renderer's ring, whose first `local_step` rows update_extra_state averages
+        done = min(16, self.global_step, self.update_extra_interval if self.update_extra_interval > 0 else 16)
         if done:
-            m.step_counter.copy_(self.count_ring)
-            m.local_step = done if self.global_step < 16 else 16
+            rows = torch.tensor([(self.global_step - done + i) % 16 for i in range(done)], device=self.count_ring.device)
+            m.step_counter[:done].copy_(self.count_ring[rows])
+            m.local_step = done
         m.update_extra_state()
         if self.graph is not None and done:
-            peak = self._peak_over_ranks(self.count_ring[:done, 0].max())
+            peak = self._peak_over_ranks(self.count_ring[:min(16, self.global_step), 0].max())
             if peak > 0.9 * self.capacity:
                 self._grow(peak)
 

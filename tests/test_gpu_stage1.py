@@ -480,10 +480,10 @@ def test_two_rank_exchange_equals_the_single_process_gradient(monkeypatch):
     rng = np.random.RandomState(3)
     targets = [torch.from_numpy(rng.rand(64, 3).astype(np.float32)) for _ in range(2)]
 
-    def run(o, d, gt, steps=1):
+    def run(o, d, gt, steps=1, sparse=True):
         m, _, _ = _clean_model()
         # (fused_table_adam=False: the single-process reference has to leave its table gradients in memory like the ranks, which exchange them)
-        loop = GraphedCleanLoop(m, _adam(m), KW, n_rays=o.shape[0], update_extra_interval=0, perturb=False, capture=False, fused_table_adam=False)
+        loop = GraphedCleanLoop(m, _adam(m), KW, n_rays=o.shape[0], update_extra_interval=0, perturb=False, capture=False, fused_table_adam=False, sparse_exchange=sparse)
         data = {"rays_o": o.cuda(), "rays_d": d.cuda(), "images": gt.cuda()}
         for _ in range(steps):
             loop.step(data)
@@ -496,32 +496,51 @@ def test_two_rank_exchange_equals_the_single_process_gradient(monkeypatch):
         monkeypatch.setattr(dist, name, getattr(group, name))
     results, errors = [None, None], []
 
-    def rank_main(r):
-        group.turn.acquire()
-        try:
-            group.local.rank = r
-            torch.cuda.set_device(0)
-            assert dp.exchange_active() and dp.world_size() == 2
-            results[r] = run(rays[r][0], rays[r][1], targets[r])
-        except BaseException as e:      # noqa: BLE001
-            errors.append(e)
-            group.barrier.abort()
-        finally:
-            if group.turn.locked():
-                try:
-                    group.turn.release()
-                except RuntimeError:
-                    pass
+    def two_ranks(sparse):
+        def rank_main(r):
+            group.turn.acquire()
+            try:
+                group.local.rank = r
+                torch.cuda.set_device(0)
+                assert dp.exchange_active() and dp.world_size() == 2
+                results[r] = run(rays[r][0], rays[r][1], targets[r], sparse=sparse)
+            except BaseException as e:      # noqa: BLE001
+                errors.append(e)
+                group.barrier.abort()
+            finally:
+                if group.turn.locked():
+                    try:
+                        group.turn.release()
+                    except RuntimeError:
+                        pass
 
-    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join(timeout=300)
-    assert not errors, errors
-    (l0, m0), (l1, m1) = results
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        assert not errors, errors
+        return list(results)
+
+    # the dense exchange first (every table whole: 64 MiB), then the default: the coarse levels as their live rows
+    (d0, _), (d1, _) = two_ranks(False)
+    dense_bytes = group.bytes[0]
+    assert dense_bytes == group.bytes[1] == 3 * d0.flat.numel() * 4 == 3 * (16 * (1 << 19) * 2 + 3072 + 7168) * 4 and group.calls == [6, 6]
+    group.bytes, group.calls = [0, 0], [0, 0]
+    (l0, m0), (l1, m1) = two_ranks(True)
     # (prepare() runs two warm-up steps in front of the one that counts: three steps' worth; eagerly the buffer travels in two pieces -- tables, then MLP gradients)
-    assert group.bytes[0] == group.bytes[1] == 3 * l0.flat.numel() * 4 == 3 * (16 * (1 << 19) * 2 + 3072 + 7168) * 4 and group.calls == [6, 6]
+    from nerf_signature_amd.stage1 import SPARSE_EXCHANGE_LEVELS, live_rows
+    n_live = sum(live_rows(l).numel() for l in SPARSE_EXCHANGE_LEVELS)
+    assert SPARSE_EXCHANGE_LEVELS == (0, 1, 2, 3, 4) and n_live == 305480
+    assert l0.bytes_exchanged_per_step == (11 * (1 << 19) * 2 + 2 * n_live + 3072 + 7168) * 4 < 0.73 * d0.bytes_exchanged_per_step
+    assert group.bytes[0] == group.bytes[1] == 3 * l0.bytes_exchanged_per_step and group.calls == [6, 6]
+    print(f"\nstage-1 exchange: {d0.bytes_exchanged_per_step / 2 ** 20:.2f} MiB dense -> {l0.bytes_exchanged_per_step / 2 ** 20:.2f} MiB with levels 0..4 as their {n_live} live rows")
+    # the same sums bit for bit: every element has the same two operands either way, and a row outside the live set is an exact zero on every rank
+    assert torch.equal(l0.g_tables, d0.g_tables) and torch.equal(l0.g_sigma, d0.g_sigma) and torch.equal(l0.g_color, d0.g_color)
+    for l in SPARSE_EXCHANGE_LEVELS:
+        dead = torch.ones(1 << 19, dtype=torch.bool, device="cuda")
+        dead[live_rows(l).cuda()] = False
+        assert float(l0.g_tables[l][dead].abs().max()) == 0.0 and int((l0.g_tables[l] != 0).any(-1).sum()) > 0, l
     assert torch.equal(l0.flat, l1.flat)
     print(f"\ntwo-rank vs single-process stage-1 gradient: rel. L2 tables {rel(l0.g_tables, ref.g_tables):.2e}, sigma MLP {rel(l0.g_sigma, ref.g_sigma):.2e}, "
           f"colour MLP {rel(l0.g_color, ref.g_color):.2e}; loss {0.5 * (float(l0.loss) + float(l1.loss)):.6f} vs {float(ref.loss):.6f}")
