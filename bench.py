@@ -516,12 +516,12 @@ def cpu_baseline(model, D, full_step_points=None, threads=0):
             "batch_seconds": {"run_cuda": a["batch_s"], "run": b["batch_s"]}}
 
 
-def _run_secondary(argv, limit_s):
+def _run_secondary(argv, limit_s, extra_env=None):
     """One secondary child in a session (process group) of its own, output into temporary files; at the limit the WHOLE group is killed -- a child that
     starts rank processes of its own (tools/converge.py dp2) must not leave them training on the GPU beside the next secondary or the headline."""
     import signal
     import tempfile
-    env = dict(os.environ, NERFSIG_SECONDARY_TIMEOUT_S=str(limit_s))
+    env = dict(os.environ, NERFSIG_SECONDARY_TIMEOUT_S=str(limit_s), **(extra_env or {}))
     with tempfile.TemporaryFile(mode="w+") as f_out, tempfile.TemporaryFile(mode="w+") as f_err:
         p = subprocess.Popen([sys.executable] + list(argv), env=env, stdout=f_out, stderr=f_err, start_new_session=True)
         timed_out = False
@@ -579,12 +579,17 @@ def run_secondaries(args):
             ("eager_reference_trainer_shape", [os.path.join(ROOT, "tools", "trainer_shape.py"), "--steps", "330", "--both", "--evaluate"]),
             ("eval_loop", [os.path.join(ROOT, "tools", "eval_bench.py")]),
             ("distortion_layer", [os.path.join(ROOT, "tools", "distortion_bench.py")]),
-            ("stage1", [os.path.join(ROOT, "tools", "stage1_bench.py"), "content", "--json", "--steps", "64", "--windows", "5"]))
+            ("stage1", [os.path.join(ROOT, "tools", "stage1_bench.py"), "content", "--json", "--steps", "64", "--windows", "5"]),
+            ("stage1_counter", [os.path.join(ROOT, "tools", "stage1_bench.py"), "content", "--scene", "counter", "--json", "--steps", "64", "--windows", "3"]),      # two cascades (config-3-like S1)
+            # one rank of a data-parallel stage-1 job: the same step with its gradient exchange issued for real on a world-size-1 RCCL group (kernel work + launch
+            # structure of a rank, no xGMI latency), collectives inside the step's graph | between two captured segments
+            ("stage1_exchange_captured", [os.path.join(ROOT, "tools", "stage1_bench.py"), "content", "--json", "--rccl1", "--steps", "64", "--windows", "3"], {"NERFSIG_CAPTURE_COLLECTIVES": "1"}),
+            ("stage1_exchange_segmented", [os.path.join(ROOT, "tools", "stage1_bench.py"), "content", "--json", "--rccl1", "--steps", "64", "--windows", "3"], {"NERFSIG_CAPTURE_COLLECTIVES": "0"}))
     limit = float(os.environ.get("NERFSIG_SECONDARY_TIMEOUT_S", "150"))
-    for name, argv in jobs:
+    for name, argv, *job_env in jobs:
         t0 = time.time()
         try:
-            r = _run_secondary(argv, limit)
+            r = _run_secondary(argv, limit, job_env[0] if job_env else None)
             lines = [l for l in r["stdout"].splitlines() if l.startswith("{")]
             if r["rc"] != 0 or not lines:
                 out[name] = {"error": f"rc {r['rc']}" + (" (killed with its whole process group at the time limit)" if r["timed_out"] else ""), "stderr_tail": r["stderr"][-600:]}
@@ -593,6 +598,18 @@ def run_secondaries(args):
             c = j.get("config", {})
             if name in ("quality", "quality_two_ranks_gloo", "rank_emulation", "eager_reference_trainer_shape", "eval_loop", "distortion_layer", "stage1"):
                 out[name] = j
+            elif name == "stage1_counter":                 # -> secondary.stage1.counter
+                out.setdefault("stage1", {})["counter"] = {k: j.get(k) for k in ("ms_per_step", "rays_per_s", "points_per_step", "cascades", "recaptures", "capacity_overflow", "loss_last")}
+                out["stage1"]["counter"]["sparse_grid_ms_per_step"] = (j.get("sparse_grid") or {}).get("ms_per_step")
+                continue
+            elif name.startswith("stage1_exchange_"):      # -> secondary.stage1.exchange.{captured, segmented}
+                sg = j.get("sparse_grid") or {}
+                s1 = out.setdefault("stage1", {})
+                if not isinstance(s1.get("exchange"), dict):
+                    s1["exchange"] = {}
+                s1["exchange"][name[len("stage1_exchange_"):]] = {
+                    "ms_per_step": j["ms_per_step"], "points_per_step": j["points_per_step"], "sparse_grid_ms_per_step": sg.get("ms_per_step"), **(j.get("exchange") or {})}
+                continue
             elif name == "counter":
                 out[name] = {"ms_per_step": j["ms_per_step"], "content_rays_per_s": j["value"], "points_per_s": c.get("points_per_s"), "points_per_step": c.get("points_per_step_per_rank"),
                              "samples_per_ray_block": c.get("samples_per_ray_block"), "samples_per_ray_content": c.get("samples_per_ray_content"), "steps": j["steps"],
@@ -681,9 +698,9 @@ def compact_line(full):
                     if isinstance(v.get(key), dict):
                         s1[key] = _pick(v[key], "bound", "achieved", "peak", "unit", "frac", "avg_launch_s", "algorithmic_bytes_per_point", "points_per_launch", "mfma_frac")
                 if isinstance(v.get("exchange"), dict):
-                    s1["exchange"] = {k: x for k, x in v["exchange"].items() if isinstance(x, (int, float, bool))}
+                    s1["exchange"] = {mode: {k: x for k, x in e.items() if isinstance(x, (int, float, bool))} for mode, e in v["exchange"].items() if isinstance(e, dict)}
                 if isinstance(v.get("counter"), dict):
-                    s1["counter"] = _pick(v["counter"], "ms_per_step", "rays_per_s", "points_per_step")
+                    s1["counter"] = _pick(v["counter"], "ms_per_step", "rays_per_s", "points_per_step", "cascades", "sparse_grid_ms_per_step")
                 out[name] = s1
             elif name == "rank_emulation":
                 out[name] = {k: {m: _pick(r, "ms_per_step", "content_rays_per_s_x_ranks_before_xgmi_latency") for m, r in x.items() if isinstance(r, dict)}

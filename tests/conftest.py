@@ -68,7 +68,7 @@ _TIER0_NAMES = ("test_fused_batchnorm_gelu", "test_fused_decoder_matches", "test
 # multi-hundred-step training / statistical tests that live outside test_gpu_convergence.py: tier 3
 _TIER3_NAMES = ("test_training_trajectory_psnr_and_bit_accuracy", "test_uniform_sample_path_trains_the_codebook", "test_finetune_decoder_mode",
                 "test_other_message_lengths_train_step_and_captured_loop", "test_captured_loop_tracks_the_cpu_oracle_over_200_steps",
-                "test_fixed_block_cache_trains_like_the_loop_that_recomputes", "test_grid_refresh_runs_in_its_cadence",
+                "test_fixed_block_cache_trains_like_the_loop_that_recomputes", "test_grid_refresh_runs_in_its_cadence", "test_grid_refresh_full_and_partial",
                 "test_geometric_distortions_run_in_the_eager_loop")
 
 

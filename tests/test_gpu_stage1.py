@@ -55,14 +55,17 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def test_all_parameter_gradients_vs_oracle():
-    m, bitfield, C = _clean_model()
+@pytest.mark.parametrize("bound", [1.0, 2.0], ids=["one_cascade", "two_cascades"])
+def test_all_parameter_gradients_vs_oracle(bound):
+    """bound = 2: the config-3-like scene S1 (two cascades); the field sees positions in [-2, 2] scaled into the encoder's unit box (network_hash.py:97-99)."""
+    m, bitfield, C = _clean_model(bound=bound)
+    assert C == (1 if bound == 1.0 else 2) and m.cascade == C
     trainable = {n for n, p in m.named_parameters() if p.requires_grad and p.numel()}
     assert trainable == {f"encoder.embeddings.{l}.weight" for l in range(16)} | {"sigma_net.params", "color_net.params"}
     rng = np.random.RandomState(0)
     M = 3001
-    pts = torch.from_numpy((rng.rand(M, 3) * 2 - 1).astype(np.float32))
-    pts[:3] = torch.tensor([[-1., -1, -1], [1, 1, 1], [0.5, -0.25, 0]])
+    pts = torch.from_numpy(((rng.rand(M, 3) * 2 - 1) * bound).astype(np.float32))
+    pts[:3] = torch.tensor([[-1., -1, -1], [1, 1, 1], [0.5, -0.25, 0]]) * bound
     dirs = torch.from_numpy(cf.unit_dirs(M, seed=9))
     gs = torch.from_numpy(rng.randn(M).astype(np.float32))
     gc = torch.from_numpy(rng.randn(M, 3).astype(np.float32))
@@ -361,7 +364,8 @@ def test_table_adam_inside_the_scatter_owners_equals_the_separate_pass_bit_for_b
     assert float((a[0][15] - _clean_model()[0].trainable()[15].detach()).abs().max()) > 0      # (the finest table did move)
 
 
-def test_captured_loop_tracks_the_cpu_oracle_over_200_steps():
+@pytest.mark.parametrize("bound", [1.0, 2.0], ids=["one_cascade", "two_cascades"])
+def test_captured_loop_tracks_the_cpu_oracle_over_200_steps(bound):
     """From a common state, 200 steps of the captured loop and of the CPU oracle (the reference's operator sequence in torch autograd + torch's
     Adam): the loss every 20th step, and the PSNR of the trained render against the target within 0.1 dB."""
     from nerf_signature_amd.stage1 import GraphedCleanLoop
@@ -369,7 +373,8 @@ def test_captured_loop_tracks_the_cpu_oracle_over_200_steps():
     N = o.shape[0]
     rng = np.random.RandomState(5)
     target = torch.from_numpy((0.25 + 0.5 * rng.rand(N, 3)).astype(np.float32))
-    m, bitfield, _ = _clean_model(mlp_scale=0.5)
+    m, bitfield, C = _clean_model(bound=bound, mlp_scale=0.5)
+    assert C == (1 if bound == 1.0 else 2)            # bound = 2: the march walks both cascades (raymarching.cu:280-300), the samples' positions span [-2, 2]
     P, S = _oracle_params(m), _scene(m, bitfield)
     leaves = P["base_tables"] + [P["sigma_params"], P["color_params"]]
     opt_cpu = torch.optim.Adam(leaves, lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
@@ -611,3 +616,43 @@ def test_one_rank_nearing_its_capacity_makes_both_ranks_grow_in_the_same_step(mo
         assert torch.equal(a, b)                                                                   # ... and the replicas are still in lockstep
     for p in m0.trainable():
         assert float(l0.optimizer.state[p]["step"]) == 6.0                                         # six optimiser steps: the warm-up of the re-capture trained nothing
+
+
+@pytest.mark.parametrize("bound", [1.0, 2.0], ids=["one_cascade", "two_cascades"])
+def test_grid_refresh_full_and_partial_over_the_cascades_captured_equals_eager(bound):
+    """update_extra_state in BOTH of its forms (renderer_wtmk.py:462-514: the first 16 refreshes probe every cell of every cascade, later ones a random quarter plus
+    as many occupied cells per cascade) inside the stage-1 loop: 40 steps with a refresh every 2 steps = 16 full + 4 partial refreshes.  The captured loop and the
+    same kernel sequence issued eagerly, from one seed, leave the same density grid, bitfield, mean density, sample totals and parameters bit for bit; on two
+    cascades both cascades' grids move."""
+    from nerf_signature_amd.stage1 import GraphedCleanLoop
+    from nerf_signature_amd import raymarching
+    o, d = _patch_rays(16)
+    target = torch.full((256, 3), 0.5).cuda()
+
+    def run(capture):
+        torch.manual_seed(7)                                                         # the partial refresh draws its cells from torch's generator
+        m, _, C = _clean_model(bound=bound)
+        grid0 = m.density_grid.clone()
+        loop = GraphedCleanLoop(m, _adam(m, 1e-3), KW, n_rays=256, update_extra_interval=2, perturb=False, headroom=3.0, capture=capture)
+        data = {"rays_o": o.cuda(), "rays_d": d.cuda(), "images": target}
+        totals = []
+        for it in range(40):
+            loop.step(data if it == 0 else None)
+            totals.append(int(loop.count_ring[it % 16, 0]))
+        torch.cuda.synchronize()
+        assert m.iter_density == 20 and loop.global_step == 40 and not loop.overflowed() and loop.recaptures == 0
+        return m, loop, totals, grid0, C
+
+    m_c, loop_c, totals_c, grid0, C = run(True)
+    m_e, loop_e, totals_e, _, _ = run(False)
+    assert C == (1 if bound == 1.0 else 2)
+    assert totals_c == totals_e and sum(totals_c) > 0
+    assert torch.equal(m_c.density_grid, m_e.density_grid) and torch.equal(m_c.density_bitfield, m_e.density_bitfield)
+    assert m_c.mean_density == m_e.mean_density and m_c.mean_count == m_e.mean_count == int(sum(totals_c[36:38]) / 2)      # the refresh at step 38 saw steps 36, 37
+    for a, b in zip(m_c.trainable(), m_e.trainable()):
+        assert torch.equal(a, b)
+    for c in range(C):
+        assert not torch.equal(m_c.density_grid[c], grid0[c].cuda()), c              # every cascade's grid was refreshed
+    thresh = min(m_c.mean_density, m_c.density_thresh)
+    assert torch.equal(m_c.density_bitfield, raymarching.packbits(m_c.density_grid, thresh))
+    assert all(np.isfinite(loop_c.losses()))

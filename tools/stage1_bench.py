@@ -30,7 +30,7 @@ def flag(name, default):
     return int(sys.argv[sys.argv.index(name) + 1]) if name in sys.argv else default
 
 
-args = [a for a in sys.argv[1:] if not a.startswith("--") and not a.isdigit()]
+args = [a for a in sys.argv[1:] if not a.startswith("--") and not a.isdigit() and a not in synthetic.SCENES]
 flags = [a for a in sys.argv[1:] if a.startswith("--")]
 which = args[0] if args else "content"
 steps, windows = flag("--steps", 64), flag("--windows", 5)
@@ -45,12 +45,16 @@ say = (lambda *a: print(*a, file=sys.stderr)) if as_json else print
 dev = torch.device("cuda")
 
 
+scene = sys.argv[sys.argv.index("--scene") + 1] if "--scene" in sys.argv else "hotdog"      # hotdog = S0 (bound 1); counter = S1 (bound 2, two cascades, camera inside: BASELINE config 3)
+BOUND = synthetic.SCENES[scene]["bound"]
+
+
 def fresh_model():
-    m = CleanNeRFNetwork(bound=1.0, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1)
+    m = CleanNeRFNetwork(bound=BOUND, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1)
     with torch.no_grad():
         for l, e in enumerate(m.encoder.embeddings):
             e.weight.copy_(torch.from_numpy(synthetic.table_values(l, 0.5)))
-        grid = synthetic.density_grid(1.0)
+        grid = synthetic.density_grid(BOUND)
         bits, _ = synthetic.pack_bits_np(grid, 10.0)
         m.density_grid.copy_(torch.from_numpy(grid))
         m.density_bitfield.copy_(torch.from_numpy(bits))
@@ -60,10 +64,10 @@ def fresh_model():
 torch.manual_seed(0)
 m = fresh_model()
 if which == "block":
-    o, d = synthetic.block_rays("hotdog", dev)
+    o, d = synthetic.block_rays(scene, dev)
     o, d = o.reshape(1, -1, 3), d.reshape(1, -1, 3)
 else:
-    o, d = synthetic.content_rays("hotdog", 4096, 0, dev)
+    o, d = synthetic.content_rays(scene, 4096, 0, dev)
 target = torch.rand(1, o.shape[1], 3, device=dev)
 n_rays = o.shape[1]
 opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, **({"fused": True} if "--eager" in flags else {}))
@@ -249,7 +253,8 @@ try:
 except Exception:
     pass
 out = {
-    "what": "stage-1 (clean model) training step, SURVEY 8(f) N3: 4096 rays of scene S0, perturbed march, 16-level encoder, both MLPs with saved layer inputs, compositing, MSE, "
+    "scene": scene, "bound": BOUND, "cascades": int(m.cascade),
+    "what": "stage-1 (clean model) training step, SURVEY 8(f) N3: 4096 rays of the scene (hotdog = S0, counter = S1), perturbed march, 16-level encoder, both MLPs with saved layer inputs, compositing, MSE, "
             "backward with the weight gradients inside (MFMA), 16-level owner-computes table scatter, Adam over 16 tables + both MLPs (torch.optim.Adam arithmetic), one hipGraph replay per step; "
             "update_extra_state every 16 steps between replays (inside the timed windows)",
     "ms_per_step": ms, "rays_per_s": n_rays / ms * 1e3, "rays": n_rays, "points_per_step": pts, "points_per_s": pts / ms * 1e3, "capacity_rows": capacity,
@@ -293,7 +298,9 @@ out = {
         "replaces_us_per_step": None if not fused else {"note": "field_bwd_trace_rows + field_wgrad of the two-launch route (--two-launch), round-5 record at 620 k points", "us": 157.9 + 298.4},
         "mfma": {"algorithmic_flop_per_point": wg_alg_flop, "issued_flop_per_point": wg_issued_flop,
                  "achieved_TFLOPs_issued": pts_e * wg_issued_flop / wg_s / 1e12 if wg_s else 0.0, "frac_of_dense_bf16_peak": pts_e * wg_issued_flop / wg_s / MFMA_PEAK_BF16 if wg_s else 0.0}},
-    "exchange": {"bytes_per_step": loop.bytes_exchanged_per_step, "segments": n_segments} if "--rccl1" in flags else None,
+    # (--rccl1) what a data-parallel rank exchanges per step: levels 5..15 dense + the static live rows of levels 0..4 + both MLPs (stage1.live_rows); dense would be 64 MiB + 40 KB
+    "exchange": {"bytes_per_step": loop.bytes_exchanged_per_step, "dense_bytes_per_step": (16 * (1 << 19) * 2 + 3072 + 7168) * 4, "segments": n_segments,
+                 "ring_bytes_per_gpu_at_8_ranks": loop.bytes_exchanged_per_step * 2 * 7 / 8} if "--rccl1" in flags else None,
     "parity": "tests/test_gpu_stage1.py: all-parameter gradients (16 levels) vs the oracle's autograd, weight gradients vs fp64 products, captured == eager, 200 steps tracked by the CPU oracle, "
               "grid-refresh cadence, two-rank exchange == single-process gradient",
 }
