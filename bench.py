@@ -693,7 +693,8 @@ def compact_line(full):
                 out[name] = {"error": str(v["error"])[:80]}
             elif name == "stage1":
                 s1 = _pick(v, "ms_per_step", "rays_per_s", "points_per_step", "recaptures", "capacity_overflow", "grid_refresh_every", "host_reads_per_64_steps")
-                s1["sparse_grid"] = _pick(v.get("sparse_grid") or {}, "ms_per_step", "points_per_step", "rays_per_s")
+                s1["sparse_grid"] = _pick(v.get("sparse_grid") or {}, "ms_per_step", "points_per_step", "rays_per_s", "ms_per_step_incl_refresh", "ms_per_step_incl_host_refresh")
+                s1["refresh"] = {k: x for k, x in ((v.get("sparse_grid") or {}).get("refresh") or {}).items() if isinstance(x, (int, float))}
                 for key in ("roofline_scatter", "roofline_wgrad", "roofline_trace"):
                     if isinstance(v.get(key), dict):
                         s1[key] = _pick(v[key], "bound", "achieved", "peak", "unit", "frac", "avg_launch_s", "algorithmic_bytes_per_point", "points_per_launch", "mfma_frac")

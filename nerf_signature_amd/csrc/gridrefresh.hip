@@ -1,0 +1,222 @@
+// The density-grid refresh as device-side work (gfx950): NeRFRenderer.update_extra_state (reference: nerf/renderer_wtmk.py:445-538, called
+// every 16 training steps, nerf/utils.py:852-858) without a host read, so that a captured training loop replays it as a second hipGraph.
+//
+// What the reference does per refresh, and where it is here:
+//   * the probe points: every cell of every cascade (the first 16 refreshes) or, per cascade, H^3/4 uniformly drawn cells plus as many cells
+//     drawn (with repetition) from the occupied ones (`nonzero` + `randint`: two host synchronisations), each jittered inside its cell
+//         -> rg_refresh_draw (cell keys; the occupied draw is a binary search in a prefix sum of the occupancy flags) and rg_refresh_points
+//            (centre + jitter, and the cell's morton index).  Random numbers: splitmix64 of (seed, refresh count, cascade, draw) -- the
+//            generator the captured loop already uses for its march offsets (k_clean_loss), so a replayed graph draws fresh values.
+//   * density at the probe points                 -> the ordinary encoder + sigma-MLP launches (hg_encode_planes, field_fwd), issued by the caller
+//   * tmp_grid[cas, indices] = sigma * scale       -> rg_refresh_scatter.  The reference's index_put with repeated indices keeps whichever
+//     write lands last (undefined on a GPU); here the LARGEST candidate wins (integer atomicMax on the bits of non-negative floats): one of the
+//     values the reference may produce, and the same one every time.
+//   * EMA `max(grid * decay, tmp)` where both are >= 0, mean of clamp(grid, 0), threshold min(mean, density_thresh), packbits, mean_count
+//         -> rg_refresh_finish: k_grid_ema (per-workgroup partial sums in double, fixed order) -> k_grid_stats (one workgroup: the mean, the refresh
+//            count, the mean sample count of the window from the loop's ring) -> k_packbits_dev (threshold read from device memory).
+// Everything is a pure function of (grid, parameters, seed, refresh count): two runs leave the same bits (tests/test_gpu_stage1.py, test_gpu_grid.py).
+#include "common.h"
+
+namespace nsig {
+
+__device__ inline uint64_t rg_mix64(uint64_t z) {      // splitmix64's finaliser (as stage1.hip's mix64)
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// the key of one (refresh, cascade, purpose) stream of draws
+__device__ inline uint64_t rg_stream(uint64_t seed, int32_t iter, uint32_t cas, uint32_t purpose) {
+    return rg_mix64(seed ^ (0x9E3779B97F4A7C15ull * ((uint64_t)(uint32_t)iter * 64ull + (uint64_t)cas * 8ull + (uint64_t)purpose + 1ull)));
+}
+__device__ inline uint64_t rg_draw(uint64_t stream, uint64_t i) { return rg_mix64(stream + 0xD1B54A32D192ED03ull * (i + 1ull)); }
+__device__ inline float rg_u01(uint64_t bits) { return (float)(uint32_t)(bits >> 40) * (1.0f / 16777216.0f); }      // 24 bits, [0, 1): torch.rand's grid
+
+// keys[0, N): cells drawn uniformly (renderer_wtmk.py:490 `torch.randint(0, H, (N, 3))`); keys[N, 2N): cells drawn uniformly, with repetition, from the occupied
+// ones (:493-496 `nonzero(grid > 0)[randint(0, count, [N])]`).  occ_prefix[i] = number of occupied cells among morton indices 0..i (inclusive scan of the flags);
+// the t-th occupied cell is the first index whose prefix exceeds t.  A grid without an occupied cell (the reference raises there) draws cell 0.
+// key = (z * H + y) * H + x: sorted, the probe walks x fastest -- the order in which the encoder's gathers share lines (the hash takes x un-multiplied).
+__global__ void __launch_bounds__(256) k_refresh_draw(int32_t *__restrict__ keys, uint32_t N, uint32_t H, const int32_t *__restrict__ occ_prefix, uint64_t seed,
+                                                     const int32_t *__restrict__ iter_dev, uint32_t cas) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= 2u * N) return;
+    const int32_t iter = *iter_dev;
+    const uint32_t cells = H * H * H;
+    if (i < N) {
+        const uint64_t b = rg_draw(rg_stream(seed, iter, cas, 0u), i);
+        const uint32_t x = (uint32_t)b & (H - 1u), y = (uint32_t)(b >> 20) & (H - 1u), z = (uint32_t)(b >> 40) & (H - 1u);
+        keys[i] = (int32_t)((z * H + y) * H + x);
+        return;
+    }
+    const uint32_t total = (uint32_t)occ_prefix[cells - 1u];
+    uint32_t m = 0;
+    if (total > 0) {
+        const uint64_t b = rg_draw(rg_stream(seed, iter, cas, 1u), i - N);
+        const uint32_t t = (uint32_t)(((b >> 32) * (uint64_t)total) >> 32);      // uniform in [0, total)
+        uint32_t lo = 0, hi = cells - 1u;                                        // first index with occ_prefix > t
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((uint32_t)occ_prefix[mid] > t) hi = mid; else lo = mid + 1u;
+        }
+        m = lo;
+    }
+    const uint32_t x = compact3(m), y = compact3(m >> 1), z = compact3(m >> 2);      // morton3D_invert (raymarching.cu:57-63)
+    keys[i] = (int32_t)((z * H + y) * H + x);
+}
+
+// Probe point i: the centre of its cell in cascade `cas`, jittered inside the cell -- renderer_wtmk.py:474,480-484 operation for operation:
+//   xyzs = 2 * coords.float() / (H - 1) - 1;  cas_xyzs = xyzs * (bound - half);  cas_xyzs += (rand * 2 - 1) * half
+// keys == nullptr: the full refresh, key = i.
+__global__ void __launch_bounds__(256) k_refresh_points(const int32_t *__restrict__ keys, uint32_t n, uint32_t H, float extent, float half_cell, uint64_t seed,
+                                                       const int32_t *__restrict__ iter_dev, uint32_t cas, float *__restrict__ xyz, int32_t *__restrict__ cells) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t key = keys != nullptr ? (uint32_t)keys[i] : i;
+    const uint32_t x = key % H, y = (key / H) % H, z = key / (H * H);
+    const uint64_t stream = rg_stream(seed, *iter_dev, cas, 2u);
+    const float scale = extent - half_cell, hm1 = (float)(H - 1u);
+    const uint32_t c[3] = {x, y, z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float u = rg_u01(rg_draw(stream, 3ull * i + (uint64_t)a));
+        const float centre = ((2.0f * (float)c[a]) / hm1 - 1.0f) * scale;
+        xyz[3u * i + a] = centre + (u * 2.0f - 1.0f) * half_cell;
+    }
+    cells[i] = (int32_t)morton3(x, y, z);
+}
+
+// fresh[cell] = max(fresh[cell], sigma * density_scale): fresh starts at -1 (negative as an integer too), the candidates are >= 0, and for non-negative floats the
+// integer order of the bit patterns is the float order.  A NaN density (diverged parameters) has the largest pattern of all and stays visible.
+__global__ void __launch_bounds__(256) k_refresh_scatter(const float *__restrict__ sigmas, const int32_t *__restrict__ cells, uint32_t n, float density_scale,
+                                                        float *__restrict__ fresh) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float v = sigmas[i] * density_scale;
+    atomicMax(reinterpret_cast<int *>(fresh) + cells[i], __float_as_int(v >= 0.0f || v != v ? v : 0.0f));
+}
+
+constexpr uint32_t kEmaThreads = 256, kEmaPerThread = 16;      // 4096 cells per workgroup: 512 partial sums for one 128^3 cascade
+// renderer_wtmk.py:521-522: grid = max(grid * decay, fresh) where both are >= 0; the partial sum of clamp(grid, 0) of this workgroup's cells, in double, lanes
+// and waves combined in a fixed order.
+__global__ void __launch_bounds__(kEmaThreads) k_grid_ema(float *__restrict__ grid, const float *__restrict__ fresh, uint32_t n, float decay, double *__restrict__ partials) {
+    __shared__ double part[kEmaThreads / 64];
+    const uint32_t base = blockIdx.x * kEmaThreads * kEmaPerThread;
+    double s = 0.0;
+#pragma unroll 4
+    for (uint32_t u = 0; u < kEmaPerThread; ++u) {
+        const uint32_t i = base + u * kEmaThreads + threadIdx.x;
+        if (i < n) {
+            float g = grid[i];
+            const float f = fresh[i];
+            if (g >= 0.0f && f >= 0.0f) {
+                g = fmaxf(g * decay, f);
+                grid[i] = g;
+            }
+            s += (double)fmaxf(g, 0.0f);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (uint32_t w = 0; w < kEmaThreads / 64; ++w) t += part[w];
+        partials[blockIdx.x] = t;
+    }
+}
+
+// One workgroup: mean_density = sum(partials) / n (:523), the refresh count advanced (:525), and -- window > 0 -- mean_count = int(sum of the window's sample totals
+// / window) (:533-536) from the captured loop's ring: rows (steps - window + i) % 16, i < window, `steps` = the loop's device step count.
+__global__ void __launch_bounds__(256) k_grid_stats(const double *__restrict__ partials, uint32_t n_partials, uint32_t n, float *__restrict__ mean_density,
+                                                   int32_t *__restrict__ iter_dev, const int32_t *__restrict__ count_ring, uint32_t window,
+                                                   const uint32_t *__restrict__ step_dev, int32_t *__restrict__ mean_count) {
+    __shared__ double part[256];
+    double s = 0.0;
+    for (uint32_t i = threadIdx.x; i < n_partials; i += 256u) s += partials[i];      // (a thread's partials in index order)
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (uint32_t w = 0; w < 256u; ++w) t += part[w];
+        mean_density[0] = (float)(t / (double)n);
+        iter_dev[0] += 1;
+        if (window > 0 && count_ring != nullptr && mean_count != nullptr) {
+            const uint32_t steps = step_dev != nullptr ? *step_dev : window;
+            long long total = 0;
+            for (uint32_t i = 0; i < window; ++i) total += (long long)count_ring[2u * ((steps - window + i) % 16u)];
+            mean_count[0] = (int32_t)((double)total / (double)window);
+        }
+    }
+}
+
+// k_packbits (raymarch.hip) with the threshold min(mean_density, density_thresh) (:528) read from device memory
+__global__ void k_packbits_dev(const float *__restrict__ grid, uint32_t n_bytes, const float *__restrict__ mean_density, float density_thresh, uint8_t *__restrict__ bits) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;  // word index
+    const uint32_t first = w * 4;
+    if (first >= n_bytes) return;
+    const float thresh = fminf(mean_density[0], density_thresh);
+    uint32_t word = 0;
+    const uint32_t nb = min(4u, n_bytes - first);
+    for (uint32_t b = 0; b < nb; ++b) {
+        const float4 lo = reinterpret_cast<const float4 *>(grid)[2 * (size_t)(first + b)];
+        const float4 hi = reinterpret_cast<const float4 *>(grid)[2 * (size_t)(first + b) + 1];
+        uint32_t v = (lo.x > thresh) | ((lo.y > thresh) << 1) | ((lo.z > thresh) << 2) | ((lo.w > thresh) << 3) |
+                     ((hi.x > thresh) << 4) | ((hi.y > thresh) << 5) | ((hi.z > thresh) << 6) | ((hi.w > thresh) << 7);
+        word |= v << (8 * b);
+    }
+    if (nb == 4 && (reinterpret_cast<uintptr_t>(bits) & 3) == 0) reinterpret_cast<uint32_t *>(bits)[w] = word;
+    else for (uint32_t b = 0; b < nb; ++b) bits[first + b] = (uint8_t)(word >> (8 * b));
+}
+
+}  // namespace nsig
+
+using namespace nsig;
+
+static int check_refresh_grid(const char *who, uint32_t H) {
+    NSIG_REQUIRE(H >= 8 && H <= 1024 && (H & (H - 1)) == 0, "%s: grid size %u must be a power of two in [8,1024]", who, H);
+    return NSIG_OK;
+}
+
+NSIG_EXPORT int rg_refresh_draw(int32_t *keys, uint32_t N, uint32_t H, const int32_t *occ_prefix, uint64_t seed, const int32_t *iter_dev, uint32_t cas,
+                                nsig_stream_t stream) {
+    if (int e = check_refresh_grid("rg_refresh_draw", H)) return e;
+    NSIG_REQUIRE(keys && occ_prefix && iter_dev, "rg_refresh_draw: null pointer");
+    NSIG_REQUIRE(N >= 1 && N < (1u << 30) && cas < 8, "rg_refresh_draw: N must be in [1, 2^30), cascade < 8");
+    k_refresh_draw<<<ceil_div(2u * N, 256u), 256, 0, as_stream(stream)>>>(keys, N, H, occ_prefix, seed, iter_dev, cas);
+    return check_launch("rg_refresh_draw");
+}
+
+NSIG_EXPORT int rg_refresh_points(const int32_t *keys, uint32_t n, uint32_t H, float extent, float half_cell, uint64_t seed, const int32_t *iter_dev, uint32_t cas,
+                                  float *xyz, int32_t *cells, nsig_stream_t stream) {
+    if (int e = check_refresh_grid("rg_refresh_points", H)) return e;
+    NSIG_REQUIRE(iter_dev && xyz && cells, "rg_refresh_points: null pointer");
+    NSIG_REQUIRE(n >= 1 && extent > 0.0f && half_cell > 0.0f && cas < 8, "rg_refresh_points: n, extent and half_cell must be positive, cascade < 8");
+    NSIG_REQUIRE(keys != nullptr || n == H * H * H, "rg_refresh_points: without keys the probe is the whole grid (n = H^3)");
+    k_refresh_points<<<ceil_div(n, 256u), 256, 0, as_stream(stream)>>>(keys, n, H, extent, half_cell, seed, iter_dev, cas, xyz, cells);
+    return check_launch("rg_refresh_points");
+}
+
+NSIG_EXPORT int rg_refresh_scatter(const float *sigmas, const int32_t *cells, uint32_t n, float density_scale, float *fresh, nsig_stream_t stream) {
+    NSIG_REQUIRE(sigmas && cells && fresh, "rg_refresh_scatter: null pointer");
+    if (n == 0) return NSIG_OK;
+    k_refresh_scatter<<<ceil_div(n, 256u), 256, 0, as_stream(stream)>>>(sigmas, cells, n, density_scale, fresh);
+    return check_launch("rg_refresh_scatter");
+}
+
+NSIG_EXPORT size_t rg_refresh_partials_bytes(uint32_t n_cells) { return (size_t)ceil_div(n_cells, kEmaThreads * kEmaPerThread) * sizeof(double); }
+
+NSIG_EXPORT int rg_refresh_finish(float *grid, const float *fresh, uint32_t n_cells, float decay, void *partials, float density_thresh, uint8_t *bitfield,
+                                  float *mean_density, int32_t *iter_dev, const int32_t *count_ring, uint32_t window, const uint32_t *step_dev, int32_t *mean_count,
+                                  nsig_stream_t stream) {
+    NSIG_REQUIRE(grid && fresh && partials && bitfield && mean_density && iter_dev, "rg_refresh_finish: null pointer");
+    NSIG_REQUIRE(n_cells >= 8 && n_cells % 8 == 0 && window <= 16, "rg_refresh_finish: the cell count must be a positive multiple of 8, window <= 16");
+    NSIG_REQUIRE(window == 0 || (count_ring && mean_count), "rg_refresh_finish: a window needs the count ring and somewhere to put the mean");
+    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(grid) & 15) == 0 && (reinterpret_cast<uintptr_t>(partials) & 7) == 0, "rg_refresh_finish: grid must be 16-byte, partials 8-byte aligned");
+    hipStream_t st = as_stream(stream);
+    const uint32_t blocks = ceil_div(n_cells, kEmaThreads * kEmaPerThread), n_bytes = n_cells / 8;
+    k_grid_ema<<<blocks, kEmaThreads, 0, st>>>(grid, fresh, n_cells, decay, reinterpret_cast<double *>(partials));
+    k_grid_stats<<<1, 256, 0, st>>>(reinterpret_cast<const double *>(partials), blocks, n_cells, mean_density, iter_dev, count_ring, window, step_dev, mean_count);
+    k_packbits_dev<<<ceil_div(ceil_div(n_bytes, 4), 256), 256, 0, st>>>(grid, n_bytes, mean_density, density_thresh, bitfield);
+    return check_launch("rg_refresh_finish");
+}

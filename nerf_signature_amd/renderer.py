@@ -147,6 +147,31 @@ class NeRFRenderer(nn.Module):
             self.local_step = 0
         self._grid_epoch = 0      # bumped by everything that rewrites the occupancy grid (see grid_key)
 
+    # mean_density / mean_count (renderer_wtmk.py:523,536): plain host numbers, as in the reference -- except behind a device-side refresh
+    # (gridrefresh.DeviceGridRefresh), which leaves them in device memory: they are then read back when somebody asks, not every 16 steps.
+    def _host_number(self, name, convert):
+        src = self.__dict__.get(f"_{name}_dev")
+        if src is not None:
+            self.__dict__[f"_{name}"] = convert(src.item())
+            self.__dict__[f"_{name}_dev"] = None
+        return self.__dict__.get(f"_{name}", 0)
+
+    @property
+    def mean_density(self):
+        return self._host_number("mean_density", float)
+
+    @mean_density.setter
+    def mean_density(self, value):
+        self.__dict__["_mean_density"], self.__dict__["_mean_density_dev"] = value, None
+
+    @property
+    def mean_count(self):
+        return self._host_number("mean_count", int)
+
+    @mean_count.setter
+    def mean_count(self, value):
+        self.__dict__["_mean_count"], self.__dict__["_mean_count_dev"] = value, None
+
     def grid_key(self):
         """Identity of the occupancy grid the marcher reads: address and version of the bitfield AND an explicit epoch.  The version alone
         misses writes through a raw pointer (packbits re-packs the bitfield in place); samples kept across steps (fix_rays, the captured

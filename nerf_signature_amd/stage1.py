@@ -289,7 +289,8 @@ class GraphedCleanLoop:
     PLAN_OVERLAP_MIN_ROWS = 600_000      # overlap_plan="auto": buffer capacity (rows) from which the scatter plan runs on its own stream (~400 k points per step)
 
     def __init__(self, model, optimizer, render_kwargs, n_rays, sampler=None, update_extra_interval=16, lr_lambda=None, headroom=0.5, perturb=True,
-                 capacity=None, overlap_plan="auto", capture=True, seed=0, fused_backward=True, fused_composite=True, fused_table_adam=None, sparse_exchange=True):
+                 capacity=None, overlap_plan="auto", capture=True, seed=0, fused_backward=True, fused_composite=True, fused_table_adam=None, sparse_exchange=True,
+                 device_refresh=True):
         if not model.cuda_ray:
             raise ValueError("GraphedCleanLoop drives the occupancy-grid path (cuda_ray=True)")
         if model.density_scale != 1:
@@ -358,6 +359,12 @@ class GraphedCleanLoop:
         self.fused_table_adam = (not dp.exchange_active()) if fused_table_adam is None else bool(fused_table_adam)
         if self.fused_table_adam and dp.exchange_active():
             raise ValueError("GraphedCleanLoop: fused_table_adam steps the tables before any exchange -- one process only")
+        # the grid refresh as device-side work, replayed as a graph of its own between the step's replays (gridrefresh.DeviceGridRefresh: no host read);
+        # False: NeRFRenderer.update_extra_state, the reference's form (three host synchronisations per refresh)
+        self.device_refresh = bool(device_refresh)
+        self._refresh = None
+        self._peak_host = torch.zeros(1, dtype=torch.int32).pin_memory() if dev.type == "cuda" else None
+        self._peak_ready = None      # event behind the copy of the last window's peak into _peak_host
         self.global_step = 0
         self.recaptures = 0
         self.bytes_exchanged_per_step = (self.flat.numel() - self._n_local) * 4 if dp.exchange_active() else 0
@@ -573,28 +580,47 @@ class GraphedCleanLoop:
     def refresh_grid(self):
         """update_extra_state between two replays (utils.py:852-857), with the loop's own ring of sample totals standing in for the renderer's."""
         m = self.model
-        # the steps since the previous refresh (the reference resets local_step there, utils.py:852-858, renderer_wtmk.py:534-538), at most the ring's 16: their totals in
-        # step order into the renderer's ring, whose first `local_step` rows update_extra_state averages
+        # the steps since the previous refresh (the reference resets local_step there, utils.py:852-858, renderer_wtmk.py:534-538), at most the ring's 16
         done = min(16, self.global_step, self.update_extra_interval if self.update_extra_interval > 0 else 16)
-        if done:
-            rows = torch.tensor([(self.global_step - done + i) % 16 for i in range(done)], device=self.count_ring.device)
-            m.step_counter[:done].copy_(self.count_ring[rows])
-            m.local_step = done
-        m.update_extra_state()
+        if self.device_refresh:
+            from .gridrefresh import DeviceGridRefresh
+            if self._refresh is None:
+                self._refresh = DeviceGridRefresh(m, seed=self.seed, capture=self.capture)
+            if self.graph is None:      # (the first refresh comes before prepare(): the weights' operand image is not there yet)
+                nv.call("mlp_pack_weights", nv.ptr(m.sigma_net.params.detach()), nv.ptr(m.color_net.params.detach()), nv.ptr(self.packed), nv.stream())
+            self._refresh.run(self.packed, self.count_ring, self.step_dev, window=done)
+        else:
+            if done:      # their totals in step order into the renderer's ring, whose first `local_step` rows update_extra_state averages
+                rows = torch.tensor([(self.global_step - done + i) % 16 for i in range(done)], device=self.count_ring.device)
+                m.step_counter[:done].copy_(self.count_ring[rows])
+                m.local_step = done
+            m.update_extra_state()
         if self.graph is not None and done:
-            peak = self._peak_over_ranks(self.count_ring[:min(16, self.global_step), 0].max())
-            if peak > 0.9 * self.capacity:
+            peak = self._window_peak(min(16, self.global_step))
+            if peak is not None and peak > 0.9 * self.capacity:
                 self._grow(peak)
 
-    def _peak_over_ranks(self, peak_dev):
-        """The largest sample total of the window over ALL ranks.  Growing re-captures, and prepare()'s warm-up steps issue the step's collectives: a rank that grew
-        alone would run collectives its peers do not (ranks march different rays and cross the mark at different refreshes), and would end two optimiser steps
-        apart from them.  With the maximum every rank takes the same decision at the same refresh and arrives at the same capacity (stage1.py:542)."""
+    def _window_peak(self, rows):
+        """The largest sample total a step produced, over ALL ranks, as of the PREVIOUS refresh -- without synchronising: every refresh queues a copy of its
+        window's maximum into pinned host memory and reads the one queued a refresh earlier (growth of the sample count is a trend over hundreds of steps; a step
+        that does overflow in between drops its last rays like the reference's bounded march, and `overflowed()` reports it).
+        All ranks: growing re-captures, and prepare()'s warm-up steps issue the step's collectives -- a rank that grew alone would run collectives its peers do
+        not (ranks march different rays and cross the mark at different refreshes) and would end two optimiser steps apart from them.  The maximum over the ranks
+        (one 4-byte all-reduce, queued with the copy) makes every rank take the same decision at the same refresh and arrive at the same capacity."""
+        value = None
+        if self._peak_ready is not None:
+            self._peak_ready.synchronize()      # (queued 16 steps ago: long done)
+            value = int(self._peak_host[0])
+        cur = self.count_ring[:rows, 0].max().to(torch.int32).reshape(1)
         if dp.exchange_active() and dp.world_size() > 1:
             import torch.distributed as dist
-            peak_dev = peak_dev.clone().to(torch.int32).reshape(1)
-            dist.all_reduce(peak_dev, op=dist.ReduceOp.MAX)
-        return int(peak_dev)
+            dist.all_reduce(cur, op=dist.ReduceOp.MAX)
+        if self._peak_host is None:
+            return int(cur)
+        self._peak_host.copy_(cur, non_blocking=True)
+        self._peak_ready = torch.cuda.Event()
+        self._peak_ready.record()
+        return value
 
     def _grow(self, peak):
         torch.cuda.synchronize()

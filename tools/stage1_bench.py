@@ -127,8 +127,9 @@ fused = "--two-launch" not in flags
 plan_mode = False if "--no-overlap" in flags else (True if "--overlap" in flags else "auto")      # the scatter plan on a stream of its own: never | always | from 600 k buffer rows on
 one_composite = "--three-launch-composite" not in flags      # (rm_composite_train_mse | compositing forward, clean_loss, compositing backward)
 table_adam_flag = False if "--separate-table-adam" in flags else None      # (None: the loop's default -- inside the scatter's owners unless gradients are exchanged)
+host_refresh = "--host-refresh" in flags      # the reference's form of the grid refresh (torch operators, three host synchronisations) instead of the device-side graph
 loop = GraphedCleanLoop(m, opt, dict(dt_gamma=0, max_steps=1024), n_rays=n_rays, update_extra_interval=refresh, perturb=True, overlap_plan=plan_mode,
-                        fused_backward=fused, fused_composite=one_composite, fused_table_adam=table_adam_flag)
+                        fused_backward=fused, fused_composite=one_composite, fused_table_adam=table_adam_flag, device_refresh=not host_refresh)
 loop.step(data)
 for _ in range(31):
     loop.step()
@@ -178,6 +179,34 @@ if refresh:
         sparse = {"ms_per_step": float(np.median(ws)), "windows_ms": ws, "points_per_step": pts_s, "rays_per_s": n_rays / float(np.median(ws)) * 1e3,
                   "what": "the same captured step on the scene's own occupancy grid, no refresh (the sample count of a trained scene: the ball, ~34 samples per ray)"}
         say(f"  on the sparse grid (no refresh): {pts_s} points, median {sparse['ms_per_step']:.3f} ms/step = {sparse['rays_per_s']:.3e} rays/s")
+        # the grid refresh by itself, in both of its forms and both implementations (wall time of one refresh between two device synchronisations; behind the
+        # windows: a random field's densities would fill the sparse grid).  Device form: refreshes 0 / 16 run eagerly, 1 / 17 are captured, the rest replay.
+        import time
+
+        def time_refreshes(n):
+            out = []
+            for _ in range(n):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                loop_s.refresh_grid()
+                torch.cuda.synchronize()
+                out.append((time.perf_counter() - t) * 1e3)
+            return out
+
+        m_s.iter_density = 0
+        loop_s.device_refresh = True
+        t_dev = time_refreshes(28)
+        m_s.iter_density = 0
+        loop_s.device_refresh = False
+        t_host = time_refreshes(28)
+        sparse["refresh"] = {"device_full_ms": float(np.median(t_dev[2:16])), "device_partial_ms": float(np.median(t_dev[18:])),
+                             "host_full_ms": float(np.median(t_host[2:16])), "host_partial_ms": float(np.median(t_host[18:])),
+                             "host_reads_per_refresh": {"device": 0, "host": 3}, "every_steps": 16}
+        sparse["ms_per_step_incl_refresh"] = sparse["ms_per_step"] + sparse["refresh"]["device_partial_ms"] / 16
+        sparse["ms_per_step_incl_host_refresh"] = sparse["ms_per_step"] + sparse["refresh"]["host_partial_ms"] / 16
+        say(f"  one grid refresh: device graph {sparse['refresh']['device_full_ms']:.3f} ms (full) / {sparse['refresh']['device_partial_ms']:.3f} ms (partial), "
+            f"torch operators {sparse['refresh']['host_full_ms']:.3f} / {sparse['refresh']['host_partial_ms']:.3f} ms -> sparse-grid step incl. refresh every 16 steps: "
+            f"{sparse['ms_per_step_incl_refresh']:.3f} ms (was {sparse['ms_per_step_incl_host_refresh']:.3f})")
         loop_s.close()
         del loop_s, m_s, opt_s
     except Exception as e:      # noqa: BLE001 -- a side figure
