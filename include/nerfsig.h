@@ -60,9 +60,10 @@ int rm_packbits(const float *grid, uint32_t n_bytes, float density_thresh, uint8
 /*
  * The density-grid refresh on the device: NeRFRenderer.update_extra_state (renderer_wtmk.py:445-538; the trainer calls it every 16 steps, nerf/utils.py:852-858)
  * without its host reads (`nonzero`, two `.item()`), so that a captured training loop replays it as a graph (nerf_signature_amd/gridrefresh.py).  Per cascade:
- *   rg_refresh_draw    the partial form's cells (:488-500): keys[0,N) uniform over the grid, keys[N,2N) uniform with repetition over the occupied cells of the cascade
- *                      (occ_prefix = inclusive prefix sum, int32, of `grid[cas] > 0` in morton order); key = (z*H + y)*H + x, to be sorted by the caller
- *   rg_refresh_points  probe point and morton cell index of every key (keys NULL: the full form, key = i, n = H^3): cell centre (:474,480-482) + jitter (:484)
+ *   rg_refresh_draw    the partial form's 2N cells (:488-500): draws [0,N) uniform over the grid, [N,2N) uniform with repetition over the occupied cells of the cascade
+ *                      (occ_prefix = inclusive prefix sum, int32, of `grid[cas] > 0` in morton order); out: keys[2N] = (z*H + y)*H + x grouped by grid row (z, y) --
+ *                      the order the density query wants -- and ids[2N], the draw each came from.  scratch: rg_refresh_draw_scratch_bytes(N, H) bytes
+ *   rg_refresh_points  probe point and morton cell index of every key (keys / ids NULL: the full form, key = id = i, n = H^3): cell centre (:474,480-482) + jitter (:484)
  *   (the density query is hg_encode_planes + field_fwd)
  *   rg_refresh_scatter fresh[cell] = max(fresh[cell], sigma * density_scale), fresh pre-filled with -1 (:489,:514; repeated cells: the largest candidate, deterministically)
  * and once per refresh
@@ -71,9 +72,11 @@ int rm_packbits(const float *grid, uint32_t n_bytes, float density_thresh, uint8
  *                      window) (:533-536; count_ring [16][2] int32, rows (*step_dev - window + i) % 16).  partials: rg_refresh_partials_bytes(n_cells) bytes of scratch.
  * Random numbers are a pure function of (seed, *iter_dev, cascade, draw): a replay draws fresh values and two runs draw the same.
  */
-int rg_refresh_draw(int32_t *keys, uint32_t N, uint32_t H, const int32_t *occ_prefix, uint64_t seed, const int32_t *iter_dev, uint32_t cas, nsig_stream_t stream);
-int rg_refresh_points(const int32_t *keys, uint32_t n, uint32_t H, float extent, float half_cell, uint64_t seed, const int32_t *iter_dev, uint32_t cas,
-                      float *xyz, int32_t *cells, nsig_stream_t stream);
+size_t rg_refresh_draw_scratch_bytes(uint32_t N, uint32_t H);
+int rg_refresh_draw(int32_t *keys, int32_t *ids, uint32_t N, uint32_t H, const int32_t *occ_prefix, void *scratch, uint64_t seed, const int32_t *iter_dev,
+                    uint32_t cas, nsig_stream_t stream);
+int rg_refresh_points(const int32_t *keys, const int32_t *ids, uint32_t n, uint32_t H, float extent, float half_cell, uint64_t seed, const int32_t *iter_dev,
+                      uint32_t cas, float *xyz, int32_t *cells, nsig_stream_t stream);
 int rg_refresh_scatter(const float *sigmas, const int32_t *cells, uint32_t n, float density_scale, float *fresh, nsig_stream_t stream);
 size_t rg_refresh_partials_bytes(uint32_t n_cells);
 int rg_refresh_finish(float *grid, const float *fresh, uint32_t n_cells, float decay, void *partials, float density_thresh, uint8_t *bitfield,

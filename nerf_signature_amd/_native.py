@@ -26,8 +26,9 @@ SIGNATURES = {
     "rm_morton3D": [_vp, _u32, _vp, _vp],
     "rm_morton3D_invert": [_vp, _u32, _vp, _vp],
     "rm_packbits": [_vp, _u32, _fl, _vp, _vp],
-    "rg_refresh_draw": [_vp, _u32, _u32, _vp, _c.c_uint64, _vp, _u32, _vp],
-    "rg_refresh_points": [_vp, _u32, _u32, _fl, _fl, _c.c_uint64, _vp, _u32, _vp, _vp, _vp],
+    "rg_refresh_draw_scratch_bytes": [_u32, _u32],
+    "rg_refresh_draw": [_vp, _vp, _u32, _u32, _vp, _vp, _c.c_uint64, _vp, _u32, _vp],
+    "rg_refresh_points": [_vp, _vp, _u32, _u32, _fl, _fl, _c.c_uint64, _vp, _u32, _vp, _vp, _vp],
     "rg_refresh_scatter": [_vp, _vp, _u32, _fl, _vp, _vp],
     "rg_refresh_partials_bytes": [_u32],
     "rg_refresh_finish": [_vp, _vp, _u32, _fl, _vp, _fl, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp],
@@ -121,7 +122,7 @@ SIGNATURES = {
     "hg_levels_scatter": [_vp, _u32, _vp, _fl, _vp, _u32, _vp, _vp, _vp],
     "hg_levels_scatter_adam": [_vp, _u32, _vp, _fl, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _fl, _fl, _fl, _fl, _vp, _vp],
 }
-_RESTYPES = {"nsig_last_error": _c.c_char_p, "nsig_host_device_pointer": _c.c_void_p, "rm_march_train_scratch_bytes": _sz, "mlp_packed_bytes": _sz, "hg_planes_bytes": _sz, "dec_workspace_bytes": _sz, "hg_scatter_levels_scratch_bytes": _sz, "hg_scatter_binned_scratch_bytes": _sz, "hg_scatter_plan_bytes": _sz, "field_wgrad_scratch_bytes": _sz, "field_bwd_wgrad_scratch_bytes": _sz, "hg_levels_plan_bytes": _sz, "rg_refresh_partials_bytes": _sz}
+_RESTYPES = {"nsig_last_error": _c.c_char_p, "nsig_host_device_pointer": _c.c_void_p, "rm_march_train_scratch_bytes": _sz, "mlp_packed_bytes": _sz, "hg_planes_bytes": _sz, "dec_workspace_bytes": _sz, "hg_scatter_levels_scratch_bytes": _sz, "hg_scatter_binned_scratch_bytes": _sz, "hg_scatter_plan_bytes": _sz, "field_wgrad_scratch_bytes": _sz, "field_bwd_wgrad_scratch_bytes": _sz, "hg_levels_plan_bytes": _sz, "rg_refresh_partials_bytes": _sz, "rg_refresh_draw_scratch_bytes": _sz}
 
 _lib = None
 

@@ -4,7 +4,7 @@
 // What the reference does per refresh, and where it is here:
 //   * the probe points: every cell of every cascade (the first 16 refreshes) or, per cascade, H^3/4 uniformly drawn cells plus as many cells
 //     drawn (with repetition) from the occupied ones (`nonzero` + `randint`: two host synchronisations), each jittered inside its cell
-//         -> rg_refresh_draw (cell keys; the occupied draw is a binary search in a prefix sum of the occupancy flags) and rg_refresh_points
+//         -> rg_refresh_draw (cell keys, grouped by grid row with a counting sort; the occupied draw is a binary search in a prefix sum of the occupancy flags) and rg_refresh_points
 //            (centre + jitter, and the cell's morton index).  Random numbers: splitmix64 of (seed, refresh count, cascade, draw) -- the
 //            generator the captured loop already uses for its march offsets (k_clean_loss), so a replayed graph draws fresh values.
 //   * density at the probe points                 -> the ordinary encoder + sigma-MLP launches (hg_encode_planes, field_fwd), issued by the caller
@@ -32,53 +32,95 @@ __device__ inline uint64_t rg_stream(uint64_t seed, int32_t iter, uint32_t cas, 
 __device__ inline uint64_t rg_draw(uint64_t stream, uint64_t i) { return rg_mix64(stream + 0xD1B54A32D192ED03ull * (i + 1ull)); }
 __device__ inline float rg_u01(uint64_t bits) { return (float)(uint32_t)(bits >> 40) * (1.0f / 16777216.0f); }      // 24 bits, [0, 1): torch.rand's grid
 
-// keys[0, N): cells drawn uniformly (renderer_wtmk.py:490 `torch.randint(0, H, (N, 3))`); keys[N, 2N): cells drawn uniformly, with repetition, from the occupied
+// drawn[0, N): cells drawn uniformly (renderer_wtmk.py:490 `torch.randint(0, H, (N, 3))`); drawn[N, 2N): cells drawn uniformly, with repetition, from the occupied
 // ones (:493-496 `nonzero(grid > 0)[randint(0, count, [N])]`).  occ_prefix[i] = number of occupied cells among morton indices 0..i (inclusive scan of the flags);
 // the t-th occupied cell is the first index whose prefix exceeds t.  A grid without an occupied cell (the reference raises there) draws cell 0.
-// key = (z * H + y) * H + x: sorted, the probe walks x fastest -- the order in which the encoder's gathers share lines (the hash takes x un-multiplied).
-__global__ void __launch_bounds__(256) k_refresh_draw(int32_t *__restrict__ keys, uint32_t N, uint32_t H, const int32_t *__restrict__ occ_prefix, uint64_t seed,
-                                                     const int32_t *__restrict__ iter_dev, uint32_t cas) {
+// key = (z * H + y) * H + x.  The probe is then walked row by row of the grid ((z, y) fixed, all x): the encoder's gathers share lines along x (the hash takes x
+// un-multiplied).  The rows are the bins of a counting sort -- this kernel counts, k_refresh_bins scans, k_refresh_place places -- three small launches where a
+// comparison sort of the million keys (torch.sort: rocprim's merge sort, 186 us) cost as much as two thirds of the density query it was there to speed up.
+__global__ void __launch_bounds__(256) k_refresh_draw(int32_t *__restrict__ drawn, uint32_t N, uint32_t H, const int32_t *__restrict__ occ_prefix, uint64_t seed,
+                                                     const int32_t *__restrict__ iter_dev, uint32_t cas, int32_t *__restrict__ bins) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= 2u * N) return;
     const int32_t iter = *iter_dev;
     const uint32_t cells = H * H * H;
+    uint32_t x, y, z;
     if (i < N) {
         const uint64_t b = rg_draw(rg_stream(seed, iter, cas, 0u), i);
-        const uint32_t x = (uint32_t)b & (H - 1u), y = (uint32_t)(b >> 20) & (H - 1u), z = (uint32_t)(b >> 40) & (H - 1u);
-        keys[i] = (int32_t)((z * H + y) * H + x);
-        return;
-    }
-    const uint32_t total = (uint32_t)occ_prefix[cells - 1u];
-    uint32_t m = 0;
-    if (total > 0) {
-        const uint64_t b = rg_draw(rg_stream(seed, iter, cas, 1u), i - N);
-        const uint32_t t = (uint32_t)(((b >> 32) * (uint64_t)total) >> 32);      // uniform in [0, total)
-        uint32_t lo = 0, hi = cells - 1u;                                        // first index with occ_prefix > t
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if ((uint32_t)occ_prefix[mid] > t) hi = mid; else lo = mid + 1u;
+        x = (uint32_t)b & (H - 1u); y = (uint32_t)(b >> 20) & (H - 1u); z = (uint32_t)(b >> 40) & (H - 1u);
+    } else {
+        const uint32_t total = (uint32_t)occ_prefix[cells - 1u];
+        uint32_t m = 0;
+        if (total > 0) {
+            const uint64_t b = rg_draw(rg_stream(seed, iter, cas, 1u), i - N);
+            const uint32_t t = (uint32_t)(((b >> 32) * (uint64_t)total) >> 32);      // uniform in [0, total)
+            uint32_t lo = 0, hi = cells - 1u;                                        // first index with occ_prefix > t
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((uint32_t)occ_prefix[mid] > t) hi = mid; else lo = mid + 1u;
+            }
+            m = lo;
         }
-        m = lo;
+        x = compact3(m); y = compact3(m >> 1); z = compact3(m >> 2);      // morton3D_invert (raymarching.cu:57-63)
     }
-    const uint32_t x = compact3(m), y = compact3(m >> 1), z = compact3(m >> 2);      // morton3D_invert (raymarching.cu:57-63)
-    keys[i] = (int32_t)((z * H + y) * H + x);
+    drawn[i] = (int32_t)((z * H + y) * H + x);
+    atomicAdd(bins + (z * H + y), 1);
 }
 
-// Probe point i: the centre of its cell in cascade `cas`, jittered inside the cell -- renderer_wtmk.py:474,480-484 operation for operation:
-//   xyzs = 2 * coords.float() / (H - 1) - 1;  cas_xyzs = xyzs * (bound - half);  cas_xyzs += (rand * 2 - 1) * half
-// keys == nullptr: the full refresh, key = i.
-__global__ void __launch_bounds__(256) k_refresh_points(const int32_t *__restrict__ keys, uint32_t n, uint32_t H, float extent, float half_cell, uint64_t seed,
-                                                       const int32_t *__restrict__ iter_dev, uint32_t cas, float *__restrict__ xyz, int32_t *__restrict__ cells) {
+// bins[r] (entries of row r) -> the row's first position: an exclusive scan by ONE workgroup (H^2 bins: 16 384 at H = 128)
+__global__ void __launch_bounds__(1024) k_refresh_bins(int32_t *__restrict__ bins, uint32_t n_bins) {
+    __shared__ int32_t wave_tot[16];
+    __shared__ int32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_bins; base += 1024u) {      // (uniform trip count)
+        const uint32_t i = base + threadIdx.x;
+        const int32_t v = i < n_bins ? bins[i] : 0;
+        int32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int32_t up = __shfl_up(incl, d, 64);
+            if ((int)(threadIdx.x & 63u) >= d) incl += up;
+        }
+        if ((threadIdx.x & 63u) == 63u) wave_tot[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        int32_t before = carry;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wave_tot[w];
+        if (i < n_bins) bins[i] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023u) carry = before + incl;
+        __syncthreads();
+    }
+}
+
+// keys[p] / ids[p]: the draws grouped by grid row.  WHERE inside its row a draw lands depends on the order the atomics arrive in and may differ from run to run;
+// nothing downstream depends on it -- a draw's jitter is a function of its id, and the scatter keeps the maximum over a cell's candidates.
+__global__ void __launch_bounds__(256) k_refresh_place(const int32_t *__restrict__ drawn, uint32_t n, uint32_t H, int32_t *__restrict__ bins, int32_t *__restrict__ keys,
+                                                      int32_t *__restrict__ ids) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    const uint32_t key = keys != nullptr ? (uint32_t)keys[i] : i;
+    const int32_t key = drawn[i];
+    const int32_t p = atomicAdd(bins + (uint32_t)key / H, 1);
+    keys[p] = key;
+    ids[p] = (int32_t)i;
+}
+
+// Probe point p: the centre of its cell in cascade `cas`, jittered inside the cell -- renderer_wtmk.py:474,480-484 operation for operation:
+//   xyzs = 2 * coords.float() / (H - 1) - 1;  cas_xyzs = xyzs * (bound - half);  cas_xyzs += (rand * 2 - 1) * half
+// keys == nullptr: the full refresh, key = p.  The jitter is drawn for the draw (ids[p]; the full refresh: p), not for the position p.
+__global__ void __launch_bounds__(256) k_refresh_points(const int32_t *__restrict__ keys, const int32_t *__restrict__ ids, uint32_t n, uint32_t H, float extent,
+                                                       float half_cell, uint64_t seed, const int32_t *__restrict__ iter_dev, uint32_t cas, float *__restrict__ xyz,
+                                                       int32_t *__restrict__ cells) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t key = keys != nullptr ? (uint32_t)keys[i] : i, id = ids != nullptr ? (uint32_t)ids[i] : i;
     const uint32_t x = key % H, y = (key / H) % H, z = key / (H * H);
     const uint64_t stream = rg_stream(seed, *iter_dev, cas, 2u);
     const float scale = extent - half_cell, hm1 = (float)(H - 1u);
     const uint32_t c[3] = {x, y, z};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float u = rg_u01(rg_draw(stream, 3ull * i + (uint64_t)a));
+        const float u = rg_u01(rg_draw(stream, 3ull * id + (uint64_t)a));
         const float centre = ((2.0f * (float)c[a]) / hm1 - 1.0f) * scale;
         xyz[3u * i + a] = centre + (u * 2.0f - 1.0f) * half_cell;
     }
@@ -178,22 +220,34 @@ static int check_refresh_grid(const char *who, uint32_t H) {
     return NSIG_OK;
 }
 
-NSIG_EXPORT int rg_refresh_draw(int32_t *keys, uint32_t N, uint32_t H, const int32_t *occ_prefix, uint64_t seed, const int32_t *iter_dev, uint32_t cas,
-                                nsig_stream_t stream) {
+NSIG_EXPORT size_t rg_refresh_draw_scratch_bytes(uint32_t N, uint32_t H) { return ((size_t)2 * N + (size_t)H * H) * sizeof(int32_t); }
+
+NSIG_EXPORT int rg_refresh_draw(int32_t *keys, int32_t *ids, uint32_t N, uint32_t H, const int32_t *occ_prefix, void *scratch, uint64_t seed, const int32_t *iter_dev,
+                                uint32_t cas, nsig_stream_t stream) {
     if (int e = check_refresh_grid("rg_refresh_draw", H)) return e;
-    NSIG_REQUIRE(keys && occ_prefix && iter_dev, "rg_refresh_draw: null pointer");
-    NSIG_REQUIRE(N >= 1 && N < (1u << 30) && cas < 8, "rg_refresh_draw: N must be in [1, 2^30), cascade < 8");
-    k_refresh_draw<<<ceil_div(2u * N, 256u), 256, 0, as_stream(stream)>>>(keys, N, H, occ_prefix, seed, iter_dev, cas);
+    NSIG_REQUIRE(keys && ids && occ_prefix && scratch && iter_dev, "rg_refresh_draw: null pointer");
+    NSIG_REQUIRE(N >= 1 && N < (1u << 29) && cas < 8, "rg_refresh_draw: N must be in [1, 2^29), cascade < 8");
+    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 3) == 0, "rg_refresh_draw: scratch must be 4-byte aligned");
+    hipStream_t st = as_stream(stream);
+    int32_t *drawn = reinterpret_cast<int32_t *>(scratch), *bins = drawn + 2 * (size_t)N;
+    if (hipMemsetAsync(bins, 0, (size_t)H * H * sizeof(int32_t), st) != hipSuccess) {
+        set_error("rg_refresh_draw: hipMemsetAsync failed");
+        return NSIG_ERR_LAUNCH;
+    }
+    k_refresh_draw<<<ceil_div(2u * N, 256u), 256, 0, st>>>(drawn, N, H, occ_prefix, seed, iter_dev, cas, bins);
+    k_refresh_bins<<<1, 1024, 0, st>>>(bins, H * H);
+    k_refresh_place<<<ceil_div(2u * N, 256u), 256, 0, st>>>(drawn, 2u * N, H, bins, keys, ids);
     return check_launch("rg_refresh_draw");
 }
 
-NSIG_EXPORT int rg_refresh_points(const int32_t *keys, uint32_t n, uint32_t H, float extent, float half_cell, uint64_t seed, const int32_t *iter_dev, uint32_t cas,
-                                  float *xyz, int32_t *cells, nsig_stream_t stream) {
+NSIG_EXPORT int rg_refresh_points(const int32_t *keys, const int32_t *ids, uint32_t n, uint32_t H, float extent, float half_cell, uint64_t seed, const int32_t *iter_dev,
+                                  uint32_t cas, float *xyz, int32_t *cells, nsig_stream_t stream) {
     if (int e = check_refresh_grid("rg_refresh_points", H)) return e;
     NSIG_REQUIRE(iter_dev && xyz && cells, "rg_refresh_points: null pointer");
     NSIG_REQUIRE(n >= 1 && extent > 0.0f && half_cell > 0.0f && cas < 8, "rg_refresh_points: n, extent and half_cell must be positive, cascade < 8");
+    NSIG_REQUIRE((keys != nullptr) == (ids != nullptr), "rg_refresh_points: keys and ids come together (rg_refresh_draw) or not at all");
     NSIG_REQUIRE(keys != nullptr || n == H * H * H, "rg_refresh_points: without keys the probe is the whole grid (n = H^3)");
-    k_refresh_points<<<ceil_div(n, 256u), 256, 0, as_stream(stream)>>>(keys, n, H, extent, half_cell, seed, iter_dev, cas, xyz, cells);
+    k_refresh_points<<<ceil_div(n, 256u), 256, 0, as_stream(stream)>>>(keys, ids, n, H, extent, half_cell, seed, iter_dev, cas, xyz, cells);
     return check_launch("rg_refresh_points");
 }
 

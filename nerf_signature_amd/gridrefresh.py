@@ -3,7 +3,7 @@
 The trainer refreshes the density grid every 16 training steps (nerf/utils.py:852-858).  The reference's form synchronises with the host three times per
 refresh (`nonzero` for the occupied cells, `.item()` for the mean density and for the mean sample count) and issues ~60 small tensor operations; between the
 replays of a captured step that costs more than a step on a trained scene's sparse grid.  Here the refresh is a fixed sequence of launches on static buffers
-(csrc/gridrefresh.hip: draw -> sort -> points -> [encoder + sigma MLP] -> scatter per cascade, then EMA + mean + packbits + mean sample count), captured once per
+(csrc/gridrefresh.hip: draw + counting sort -> points -> [encoder + sigma MLP] -> scatter per cascade, then EMA + mean + packbits + mean sample count), captured once per
 form -- "full" for the first 16 refreshes, "partial" afterwards -- and replayed.  The values a host may ask for (mean_density, mean_count) stay on the device until
 somebody reads the renderer's attribute.
 
@@ -34,8 +34,8 @@ class DeviceGridRefresh:
         self.cell_index = torch.empty(cap, **i32)
         self.sigma = torch.empty(cap, **f32)
         self.keys = torch.empty(2 * self.n_draw, **i32)
-        self.keys_sorted = torch.empty(2 * self.n_draw, **i32)
-        self.order = torch.empty(2 * self.n_draw, dtype=torch.int64, device=dev)
+        self.ids = torch.empty(2 * self.n_draw, **i32)
+        self.draw_scratch = torch.empty(int(nv.fn("rg_refresh_draw_scratch_bytes")(self.n_draw, H)) // 4, **i32)
         self.occ_prefix = torch.empty(self.cells, **i32)
         self.fresh = torch.empty_like(m.density_grid)
         self.planes = torch.empty(int(nv.fn("hg_planes_bytes")(cap)), dtype=torch.uint8, device=dev)
@@ -46,11 +46,12 @@ class DeviceGridRefresh:
         self.graphs, self.seen = {}, set()
         self.stream = None
 
-    def _probe(self, cas, n, keys, packed):
+    def _probe(self, cas, n, keys, ids, packed):
         m, H = self.model, self.H
         extent, half_cell = m._cascade_extent(cas)
         s = nv.stream()
-        nv.call("rg_refresh_points", nv.ptr(keys), n, H, float(extent), float(half_cell), self.seed, nv.ptr(self.iter_dev), cas, nv.ptr(self.xyz), nv.ptr(self.cell_index), s)
+        nv.call("rg_refresh_points", nv.ptr(keys), nv.ptr(ids), n, H, float(extent), float(half_cell), self.seed, nv.ptr(self.iter_dev), cas, nv.ptr(self.xyz),
+                nv.ptr(self.cell_index), s)
         base_ptrs = nv.ptr_array([t.detach() for t in m.encoder.tables()])
         layout = fo.encode_planes(self.xyz, n, m.bound, base_ptrs, None, self.planes)
         nv.call("field_fwd", nv.ptr(self.xyz), None, n, float(m.bound), base_ptrs, None, nv.ptr(packed), nv.ptr(self.sigma), None, None, None, nv.ptr(self.planes), layout, s)
@@ -61,12 +62,12 @@ class DeviceGridRefresh:
         self.fresh.fill_(-1.0)
         for cas in range(self.C):
             if form == "full":
-                self._probe(cas, self.cells, None, packed)
+                self._probe(cas, self.cells, None, None, packed)
             else:
                 torch.cumsum(m.density_grid[cas] > 0, 0, dtype=torch.int32, out=self.occ_prefix)
-                nv.call("rg_refresh_draw", nv.ptr(self.keys), self.n_draw, self.H, nv.ptr(self.occ_prefix), self.seed, nv.ptr(self.iter_dev), cas, nv.stream())
-                torch.sort(self.keys, out=(self.keys_sorted, self.order))      # x fastest: the order in which the encoder's gathers share lines
-                self._probe(cas, 2 * self.n_draw, self.keys_sorted, packed)
+                nv.call("rg_refresh_draw", nv.ptr(self.keys), nv.ptr(self.ids), self.n_draw, self.H, nv.ptr(self.occ_prefix), nv.ptr(self.draw_scratch), self.seed,
+                        nv.ptr(self.iter_dev), cas, nv.stream())      # (grouped by grid row: the order in which the encoder's gathers share lines)
+                self._probe(cas, 2 * self.n_draw, self.keys, self.ids, packed)
         nv.call("rg_refresh_finish", nv.ptr(m.density_grid), nv.ptr(self.fresh), self.C * self.cells, self.decay, nv.ptr(self.partials), float(m.density_thresh),
                 nv.ptr(m.density_bitfield), nv.ptr(self.mean_density_dev), nv.ptr(self.iter_dev), nv.ptr(count_ring) if window else None, int(window),
                 nv.ptr(step_dev) if window else None, nv.ptr(self.mean_count_dev) if window else None, nv.stream())
@@ -75,7 +76,7 @@ class DeviceGridRefresh:
     def run(self, packed, count_ring=None, step_dev=None, window=0):
         """One refresh.  packed: the MLP weights' operand image (fieldops.pack_weights; a captured loop's static buffer); count_ring [16,2] int32 / step_dev: the loop's
         ring of (points, rays) per step and its device step count; window: how many of the ring's last rows the mean sample count averages (0: leave it alone).
-        The first refresh of a form runs eagerly (it loads the kernels and sizes torch's sort), the second is captured, later ones replay."""
+        The first refresh of a form runs eagerly (it loads the kernels), the second is captured, later ones replay."""
         m = self.model
         if m.density_grid.data_ptr() != self.fresh.data_ptr() and self.fresh.shape != m.density_grid.shape:
             raise RuntimeError("DeviceGridRefresh: the model's grid changed shape")

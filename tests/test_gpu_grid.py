@@ -149,3 +149,110 @@ def test_refresh_probe_order_changes_nothing_but_the_time():
         torch.manual_seed(7)
         out.append(m._probe_density(coords, 0, None))
     assert torch.equal(out[0], out[1]) and float(out[0].max()) > 0
+
+
+def _refresh_model(bound=2.0):
+    from nerf_signature_amd import synthetic
+    from nerf_signature_amd.stage1 import CleanNeRFNetwork
+    m = CleanNeRFNetwork(bound=bound, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1)
+    with torch.no_grad():
+        for l, e in enumerate(m.encoder.embeddings):
+            e.weight.copy_(torch.from_numpy(synthetic.table_values(l, 0.5)))
+        grid = synthetic.density_grid(bound)
+        grid[:, ::97] = -1.0                                          # some cells no camera sees (mark_untrained_grid): they must stay -1
+        bits, _ = synthetic.pack_bits_np(grid, 10.0)
+        m.density_grid.copy_(torch.from_numpy(grid))
+        m.density_bitfield.copy_(torch.from_numpy(bits))
+    return m.cuda().train()
+
+
+def test_device_side_refresh_restates_update_extra_state_step_by_step():
+    """gridrefresh.DeviceGridRefresh (csrc/gridrefresh.hip) against renderer_wtmk.py:445-538 piece by piece, on two cascades at the production size, with the real field
+    behind it: probe points inside their cells with the reference's centre arithmetic and a uniform jitter; densities = the model's density() there (and the CPU
+    oracle's on a sample); the partial form's draws (uniform cells + occupied cells only, grouped by grid row); the scatter (largest candidate per cell); the EMA where
+    both sides are >= 0, untouched and unseen (-1) cells left alone; mean, threshold, bitfield, refresh count, mean sample count of the window; the same bits from the
+    same seed, other draws from another."""
+    from nerf_signature_amd import fieldops as fo, raymarching
+    from nerf_signature_amd.gridrefresh import DeviceGridRefresh
+    m = _refresh_model(2.0)
+    C, H = m.cascade, m.grid_size
+    assert C == 2
+    packed = fo.pack_weights(m.sigma_net.params, m.color_net.params)
+    P = {"bound": 2.0, "base_tables": [e.weight.detach().cpu() for e in m.encoder.embeddings], "cb_tables": [],
+         "sigma_params": m.sigma_net.params.detach().cpu(), "color_params": m.color_net.params.detach().cpu()}
+    ring = torch.zeros(16, 2, dtype=torch.int32, device="cuda")
+    ring[:, 0] = (torch.arange(16, dtype=torch.int32) * 1000 + 13).cuda()
+    step_dev = torch.tensor([21], dtype=torch.int32, device="cuda")
+
+    def check_common(r, old, cas, n):
+        xyz, cell, sigma = r.xyz[:n], r.cell_index[:n].long(), r.sigma[:n]
+        coords = raymarching.morton3D_invert(cell.int()).float()
+        extent, half = m._cascade_extent(cas)
+        centre = (2 * coords / (H - 1) - 1) * (extent - half)
+        off = (xyz - centre) / half
+        assert float(off.abs().max()) <= 1.0 + 1e-4 and abs(float(off.mean())) < 5e-3 and abs(float(off.std()) - 3 ** -0.5) < 5e-3      # U(-1, 1) inside the cell
+        want = m.density(xyz)["sigma"]
+        assert torch.equal(sigma, want)                                                        # the density query IS the model's density()
+        pick = torch.arange(0, n, n // 1500, device="cuda")
+        with torch.no_grad():
+            cpu = fr.density(xyz[pick].cpu(), None, P)["sigma"].reshape(-1)
+        np.testing.assert_allclose(sigma[pick].cpu().numpy(), cpu.numpy(), rtol=2e-3, atol=1e-4)
+        best = torch.full((H ** 3,), -1.0, device="cuda").scatter_reduce(0, cell, sigma * m.density_scale, reduce="amax", include_self=True)
+        assert torch.equal(r.fresh[cas], best)                                                 # repeated cells: the largest candidate
+        both = (old[cas] >= 0) & (best >= 0)
+        assert torch.equal(m.density_grid[cas], torch.where(both, torch.maximum(old[cas] * 0.95, best), old[cas]))
+        assert bool((m.density_grid[cas][old[cas] < 0] == -1).all()) and int((old[cas] < 0).sum()) > 1000
+        return cell
+
+    def check_books(r, iter_before):
+        mean = float(m.density_grid.clamp(min=0).double().mean())
+        assert m.mean_density == pytest.approx(mean, rel=1e-6) and int(r.iter_dev) == m.iter_density == iter_before + 1
+        assert torch.equal(m.density_bitfield, raymarching.packbits(m.density_grid, min(m.mean_density, m.density_thresh)))
+        assert m.mean_count == int(sum(int(ring[(21 - 5 + i) % 16, 0]) for i in range(5)) / 5) and m.local_step == 0
+
+    # ---- the full form (iter_density < 16): every cell of every cascade once
+    r = DeviceGridRefresh(m, seed=3, capture=False)
+    old = m.density_grid.clone()
+    r.run(packed, ring, step_dev, window=5)
+    cell = check_common(r, old, C - 1, H ** 3)
+    assert torch.equal(torch.sort(cell).values, torch.arange(H ** 3, device="cuda"))
+    check_books(r, 0)
+    # ---- the partial form: N uniform cells + N occupied cells per cascade
+    m.iter_density = 16
+    r.iter_dev.fill_(16)
+    old = m.density_grid.clone()
+    r.run(packed, ring, step_dev, window=5)
+    N = H ** 3 // 4
+    check_common(r, old, C - 1, 2 * N)
+    keys, ids = r.keys.long(), r.ids.long()
+    assert torch.equal(torch.sort(ids).values, torch.arange(2 * N, device="cuda"))           # every draw placed exactly once ...
+    rows = keys // H
+    assert bool((rows[1:] >= rows[:-1]).all())                                                # ... grouped by grid row (z, y)
+    x, y, z = keys % H, (keys // H) % H, keys // (H * H)
+    morton = raymarching.morton3D(torch.stack([x, y, z], -1).int()).long()
+    assert torch.equal(morton, r.cell_index[:2 * N].long())
+    uniform, occupied = ids < N, ids >= N
+    for axis in (x, y, z):                                                                    # 524 288 uniform draws per axis: mean (H - 1) / 2 +- 0.051 (1 sigma)
+        assert abs(float(axis[uniform].float().mean()) - (H - 1) / 2) < 0.3
+    assert float(torch.unique(morton[uniform]).numel()) / N > 0.85                            # (with repetition: 1 - (1 - 1/M)^N of M = 4 N cells ~ 0.885 of N distinct)
+    assert bool((old[C - 1][morton[occupied]] > 0).all())                                     # the second half: occupied cells only (renderer_wtmk.py:493-496)
+    n_occ = int((old[C - 1] > 0).sum())
+    assert torch.unique(morton[occupied]).numel() > 0.9 * min(n_occ, N * (1 - np.exp(-1)))   # ... spread over them
+    untouched = torch.ones(H ** 3, dtype=torch.bool, device="cuda")
+    untouched[morton] = False
+    assert torch.equal(m.density_grid[C - 1][untouched], old[C - 1][untouched]) and int(untouched.sum()) > H ** 3 // 2
+    check_books(r, 16)
+    # ---- a pure function of (grid, parameters, seed, refresh count); captured == eager
+    finals = []
+    for seed, capture in ((3, False), (3, True), (4, False)):
+        m2 = _refresh_model(2.0)
+        r2 = DeviceGridRefresh(m2, seed=seed, capture=capture)
+        m2.iter_density = 14
+        r2.iter_dev.fill_(14)
+        for _ in range(6):                                                                    # two full (eager, captured) + four partial (eager, captured, replay, replay)
+            r2.run(packed, ring, step_dev, window=5)
+        torch.cuda.synchronize()
+        assert (len(r2.graphs) == 2) == capture
+        finals.append((m2.density_grid.clone(), m2.density_bitfield.clone(), m2.mean_density))
+    assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1]) and finals[0][2] == finals[1][2]
+    assert not torch.equal(finals[0][0], finals[2][0])
