@@ -60,8 +60,9 @@ int rm_packbits(const float *grid, uint32_t n_bytes, float density_thresh, uint8
 /*
  * The density-grid refresh on the device: NeRFRenderer.update_extra_state (renderer_wtmk.py:445-538; the trainer calls it every 16 steps, nerf/utils.py:852-858)
  * without its host reads (`nonzero`, two `.item()`), so that a captured training loop replays it as a graph (nerf_signature_amd/gridrefresh.py).  Per cascade:
+ *   rg_refresh_begin   fresh[0, n_cells) = -1 (:454)
  *   rg_refresh_draw    the partial form's 2N cells (:488-500): draws [0,N) uniform over the grid, [N,2N) uniform with repetition over the occupied cells of the cascade
- *                      (occ_prefix = inclusive prefix sum, int32, of `grid[cas] > 0` in morton order); out: keys[2N] = (z*H + y)*H + x grouped by grid row (z, y) --
+ *                      (`grid_cas > 0`, morton order; found through a prefix sum of the flags); out: keys[2N] = (z*H + y)*H + x grouped by grid row (z, y) --
  *                      the order the density query wants -- and ids[2N], the draw each came from.  scratch: rg_refresh_draw_scratch_bytes(N, H) bytes
  *   rg_refresh_points  probe point and morton cell index of every key (keys / ids NULL: the full form, key = id = i, n = H^3): cell centre (:474,480-482) + jitter (:484)
  *   (the density query is hg_encode_planes + field_fwd)
@@ -73,7 +74,8 @@ int rm_packbits(const float *grid, uint32_t n_bytes, float density_thresh, uint8
  * Random numbers are a pure function of (seed, *iter_dev, cascade, draw): a replay draws fresh values and two runs draw the same.
  */
 size_t rg_refresh_draw_scratch_bytes(uint32_t N, uint32_t H);
-int rg_refresh_draw(int32_t *keys, int32_t *ids, uint32_t N, uint32_t H, const int32_t *occ_prefix, void *scratch, uint64_t seed, const int32_t *iter_dev,
+int rg_refresh_begin(float *fresh, uint32_t n_cells, nsig_stream_t stream);
+int rg_refresh_draw(int32_t *keys, int32_t *ids, uint32_t N, uint32_t H, const float *grid_cas, void *scratch, uint64_t seed, const int32_t *iter_dev,
                     uint32_t cas, nsig_stream_t stream);
 int rg_refresh_points(const int32_t *keys, const int32_t *ids, uint32_t n, uint32_t H, float extent, float half_cell, uint64_t seed, const int32_t *iter_dev,
                       uint32_t cas, float *xyz, int32_t *cells, nsig_stream_t stream);

@@ -27,6 +27,7 @@ SIGNATURES = {
     "rm_morton3D_invert": [_vp, _u32, _vp, _vp],
     "rm_packbits": [_vp, _u32, _fl, _vp, _vp],
     "rg_refresh_draw_scratch_bytes": [_u32, _u32],
+    "rg_refresh_begin": [_vp, _u32, _vp],
     "rg_refresh_draw": [_vp, _vp, _u32, _u32, _vp, _vp, _c.c_uint64, _vp, _u32, _vp],
     "rg_refresh_points": [_vp, _vp, _u32, _u32, _fl, _fl, _c.c_uint64, _vp, _u32, _vp, _vp, _vp],
     "rg_refresh_scatter": [_vp, _vp, _u32, _fl, _vp, _vp],

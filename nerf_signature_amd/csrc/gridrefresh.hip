@@ -32,6 +32,60 @@ __device__ inline uint64_t rg_stream(uint64_t seed, int32_t iter, uint32_t cas, 
 __device__ inline uint64_t rg_draw(uint64_t stream, uint64_t i) { return rg_mix64(stream + 0xD1B54A32D192ED03ull * (i + 1ull)); }
 __device__ inline float rg_u01(uint64_t bits) { return (float)(uint32_t)(bits >> 40) * (1.0f / 16777216.0f); }      // 24 bits, [0, 1): torch.rand's grid
 
+// ---- the inclusive prefix sum of the occupancy flags `grid[cas] > 0` (morton order), in three launches of this file's own (no library scan, no memset node: the
+// captured refresh holds nothing but kernel nodes): per-workgroup counts of 4096 cells -> exclusive scan of the counts by one workgroup (k_refresh_bins) -> the
+// prefix inside each workgroup's cells, on top of its offset.  The first launch also clears the counting sort's row bins.
+constexpr uint32_t kOccThreads = 1024, kOccPerThread = 4, kOccCells = kOccThreads * kOccPerThread;
+
+__device__ inline int32_t occ_block_exclusive(int32_t mine, int32_t *wave_tot) {      // exclusive prefix of `mine` over the 1024 threads of a workgroup; wave_tot[16]
+    int32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t up = __shfl_up(incl, d, 64);
+        if ((int)(threadIdx.x & 63u) >= d) incl += up;
+    }
+    if ((threadIdx.x & 63u) == 63u) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int32_t before = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wave_tot[w];
+    return before + incl - mine;
+}
+
+__global__ void __launch_bounds__(kOccThreads) k_occ_count(const float *__restrict__ grid, uint32_t cells, int32_t *__restrict__ block_sums, int32_t *__restrict__ bins,
+                                                          uint32_t n_bins) {
+    __shared__ int32_t wave_tot[16];
+    for (uint32_t i = blockIdx.x * kOccThreads + threadIdx.x; i < n_bins; i += gridDim.x * kOccThreads) bins[i] = 0;
+    const uint32_t first = blockIdx.x * kOccCells + threadIdx.x * kOccPerThread;
+    int32_t c = 0;
+    if (first + kOccPerThread <= cells) {
+        const float4 g = *reinterpret_cast<const float4 *>(grid + first);
+        c = (g.x > 0.0f) + (g.y > 0.0f) + (g.z > 0.0f) + (g.w > 0.0f);
+    } else {
+        for (uint32_t u = 0; u < kOccPerThread; ++u) c += (first + u < cells && grid[first + u] > 0.0f);
+    }
+    const int32_t before = occ_block_exclusive(c, wave_tot);
+    if (threadIdx.x == kOccThreads - 1u) block_sums[blockIdx.x] = before + c;
+}
+
+__global__ void __launch_bounds__(kOccThreads) k_occ_prefix(const float *__restrict__ grid, uint32_t cells, const int32_t *__restrict__ block_offsets,
+                                                           int32_t *__restrict__ occ_prefix) {
+    __shared__ int32_t wave_tot[16];
+    const uint32_t first = blockIdx.x * kOccCells + threadIdx.x * kOccPerThread;
+    int32_t f[kOccPerThread];
+#pragma unroll
+    for (uint32_t u = 0; u < kOccPerThread; ++u) f[u] = (first + u < cells && grid[first + u] > 0.0f) ? 1 : 0;
+    int32_t run = occ_block_exclusive(f[0] + f[1] + f[2] + f[3], wave_tot) + block_offsets[blockIdx.x];
+#pragma unroll
+    for (uint32_t u = 0; u < kOccPerThread; ++u) {
+        run += f[u];
+        if (first + u < cells) occ_prefix[first + u] = run;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_fill_f32(float *__restrict__ p, uint32_t n, float v) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) p[i] = v;
+}
+
 // drawn[0, N): cells drawn uniformly (renderer_wtmk.py:490 `torch.randint(0, H, (N, 3))`); drawn[N, 2N): cells drawn uniformly, with repetition, from the occupied
 // ones (:493-496 `nonzero(grid > 0)[randint(0, count, [N])]`).  occ_prefix[i] = number of occupied cells among morton indices 0..i (inclusive scan of the flags);
 // the t-th occupied cell is the first index whose prefix exceeds t.  A grid without an occupied cell (the reference raises there) draws cell 0.
@@ -220,22 +274,32 @@ static int check_refresh_grid(const char *who, uint32_t H) {
     return NSIG_OK;
 }
 
-NSIG_EXPORT size_t rg_refresh_draw_scratch_bytes(uint32_t N, uint32_t H) { return ((size_t)2 * N + (size_t)H * H) * sizeof(int32_t); }
+// scratch of rg_refresh_draw, in int32 words: [2N draws | H^2 row bins | H^3 occupancy prefix | ceil(H^3 / 4096) workgroup counts]
+NSIG_EXPORT size_t rg_refresh_draw_scratch_bytes(uint32_t N, uint32_t H) {
+    const size_t cells = (size_t)H * H * H;
+    return ((size_t)2 * N + (size_t)H * H + cells + (cells + kOccCells - 1) / kOccCells) * sizeof(int32_t);
+}
 
-NSIG_EXPORT int rg_refresh_draw(int32_t *keys, int32_t *ids, uint32_t N, uint32_t H, const int32_t *occ_prefix, void *scratch, uint64_t seed, const int32_t *iter_dev,
+NSIG_EXPORT int rg_refresh_begin(float *fresh, uint32_t n_cells, nsig_stream_t stream) {
+    NSIG_REQUIRE(fresh && n_cells >= 1, "rg_refresh_begin: null pointer or no cells");
+    k_fill_f32<<<min(ceil_div(n_cells, 256u), 2048u), 256, 0, as_stream(stream)>>>(fresh, n_cells, -1.0f);
+    return check_launch("rg_refresh_begin");
+}
+
+NSIG_EXPORT int rg_refresh_draw(int32_t *keys, int32_t *ids, uint32_t N, uint32_t H, const float *grid_cas, void *scratch, uint64_t seed, const int32_t *iter_dev,
                                 uint32_t cas, nsig_stream_t stream) {
     if (int e = check_refresh_grid("rg_refresh_draw", H)) return e;
-    NSIG_REQUIRE(keys && ids && occ_prefix && scratch && iter_dev, "rg_refresh_draw: null pointer");
+    NSIG_REQUIRE(keys && ids && grid_cas && scratch && iter_dev, "rg_refresh_draw: null pointer");
     NSIG_REQUIRE(N >= 1 && N < (1u << 29) && cas < 8, "rg_refresh_draw: N must be in [1, 2^29), cascade < 8");
-    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 3) == 0, "rg_refresh_draw: scratch must be 4-byte aligned");
+    NSIG_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 3) == 0 && (reinterpret_cast<uintptr_t>(grid_cas) & 15) == 0, "rg_refresh_draw: scratch must be 4-byte, the grid 16-byte aligned");
     hipStream_t st = as_stream(stream);
-    int32_t *drawn = reinterpret_cast<int32_t *>(scratch), *bins = drawn + 2 * (size_t)N;
-    if (hipMemsetAsync(bins, 0, (size_t)H * H * sizeof(int32_t), st) != hipSuccess) {
-        set_error("rg_refresh_draw: hipMemsetAsync failed");
-        return NSIG_ERR_LAUNCH;
-    }
+    const uint32_t cells = H * H * H, n_bins = H * H, occ_blocks = ceil_div(cells, kOccCells);
+    int32_t *drawn = reinterpret_cast<int32_t *>(scratch), *bins = drawn + 2 * (size_t)N, *occ_prefix = bins + n_bins, *block_sums = occ_prefix + cells;
+    k_occ_count<<<occ_blocks, kOccThreads, 0, st>>>(grid_cas, cells, block_sums, bins, n_bins);
+    k_refresh_bins<<<1, 1024, 0, st>>>(block_sums, occ_blocks);
+    k_occ_prefix<<<occ_blocks, kOccThreads, 0, st>>>(grid_cas, cells, block_sums, occ_prefix);
     k_refresh_draw<<<ceil_div(2u * N, 256u), 256, 0, st>>>(drawn, N, H, occ_prefix, seed, iter_dev, cas, bins);
-    k_refresh_bins<<<1, 1024, 0, st>>>(bins, H * H);
+    k_refresh_bins<<<1, 1024, 0, st>>>(bins, n_bins);
     k_refresh_place<<<ceil_div(2u * N, 256u), 256, 0, st>>>(drawn, 2u * N, H, bins, keys, ids);
     return check_launch("rg_refresh_draw");
 }

@@ -7,6 +7,10 @@ replays of a captured step that costs more than a step on a trained scene's spar
 form -- "full" for the first 16 refreshes, "partial" afterwards -- and replayed.  The values a host may ask for (mean_density, mean_count) stay on the device until
 somebody reads the renderer's attribute.
 
+The captured refresh holds libnerfsig kernel nodes and nothing else.  (A first version built the occupancy prefix with torch.cumsum and cleared its buffers with
+fill_ / hipMemsetAsync inside the capture: the graph's SECOND replay, behind sixteen replays of the training step's graph, ended in "Memory access fault ... write access
+to a read-only page" on this runtime -- reproducibly, and not with serialised launches.  The prefix sum, the fills and the counting sort are this library's own kernels now.)
+
 Differences from the reference's form, all inside what it leaves undefined: the random numbers are a counter-based function of (seed, refresh count, cascade,
 draw) instead of torch's generator; cells the partial refresh probes more than once keep the largest of their candidates (the reference: whichever write lands last).
 The arithmetic of a probe point, of the EMA and of the threshold is the reference's, operation for operation."""
@@ -36,7 +40,6 @@ class DeviceGridRefresh:
         self.keys = torch.empty(2 * self.n_draw, **i32)
         self.ids = torch.empty(2 * self.n_draw, **i32)
         self.draw_scratch = torch.empty(int(nv.fn("rg_refresh_draw_scratch_bytes")(self.n_draw, H)) // 4, **i32)
-        self.occ_prefix = torch.empty(self.cells, **i32)
         self.fresh = torch.empty_like(m.density_grid)
         self.planes = torch.empty(int(nv.fn("hg_planes_bytes")(cap)), dtype=torch.uint8, device=dev)
         self.partials = torch.empty(int(nv.fn("rg_refresh_partials_bytes")(C * self.cells)) // 8, dtype=torch.float64, device=dev)
@@ -59,13 +62,12 @@ class DeviceGridRefresh:
 
     def _body(self, form, window, count_ring, step_dev, packed):
         m = self.model
-        self.fresh.fill_(-1.0)
+        nv.call("rg_refresh_begin", nv.ptr(self.fresh), self.C * self.cells, nv.stream())      # (libnerfsig launches only: the captured refresh holds kernel nodes, nothing else)
         for cas in range(self.C):
             if form == "full":
                 self._probe(cas, self.cells, None, None, packed)
             else:
-                torch.cumsum(m.density_grid[cas] > 0, 0, dtype=torch.int32, out=self.occ_prefix)
-                nv.call("rg_refresh_draw", nv.ptr(self.keys), nv.ptr(self.ids), self.n_draw, self.H, nv.ptr(self.occ_prefix), nv.ptr(self.draw_scratch), self.seed,
+                nv.call("rg_refresh_draw", nv.ptr(self.keys), nv.ptr(self.ids), self.n_draw, self.H, nv.ptr(m.density_grid[cas]), nv.ptr(self.draw_scratch), self.seed,
                         nv.ptr(self.iter_dev), cas, nv.stream())      # (grouped by grid row: the order in which the encoder's gathers share lines)
                 self._probe(cas, 2 * self.n_draw, self.keys, self.ids, packed)
         nv.call("rg_refresh_finish", nv.ptr(m.density_grid), nv.ptr(self.fresh), self.C * self.cells, self.decay, nv.ptr(self.partials), float(m.density_thresh),
