@@ -611,6 +611,19 @@ size_t field_bwd_wgrad_scratch_bytes(uint32_t M);
 int field_bwd_wgrad(uint32_t M, const uint32_t *rows_dev, const float *grad_sigmas, const float *grad_rgbs, const float *sigmas, const float *rgbs,
                     const uint32_t *masks, const void *packed, const void *planes, const float *act_hs, const float *act_cin, const float *act_h1,
                     const float *act_h2, void *d_planes, void *scratch, float *grad_sigma_params, float *grad_color_params, nsig_stream_t stream);
+/*
+ * The same pair with the saved layer inputs kept as fp16: act_hs / act_h1 / act_h2 [64][stride] and act_cin [32][stride] of _Float16 -- 448 instead of 896
+ * bytes per point written by the forward and read back by the backward.  The forward's OUTPUTS (sigmas, rgbs, masks) are field_fwd_trace's bit for bit: only
+ * what is saved is rounded (to the precision the reference's MLPs keep their activations in, tinycudann FullyFusedMLP, network_hash.py:39-49,65-75); the
+ * backward widens the rows when it stages them and multiplies in the same split-bf16 arithmetic (an fp16 value splits into bf16 hi + lo exactly).
+ * rows_dev may be NULL (= M_capacity points).
+ */
+int field_fwd_trace_f16(const float *xyzs, const float *dirs, uint32_t M_capacity, const uint32_t *rows_dev, float bound,
+                        const float *const *base_tables_host, const void *packed, const void *planes, float *sigmas, float *rgbs,
+                        uint32_t *masks, void *act_hs, void *act_cin, void *act_h1, void *act_h2, nsig_stream_t stream);
+int field_bwd_wgrad_f16(uint32_t M, const uint32_t *rows_dev, const float *grad_sigmas, const float *grad_rgbs, const float *sigmas, const float *rgbs,
+                        const uint32_t *masks, const void *packed, const void *planes, const void *act_hs, const void *act_cin, const void *act_h1,
+                        const void *act_h2, void *d_planes, void *scratch, float *grad_sigma_params, float *grad_color_params, nsig_stream_t stream);
 /* Stage 1's compositing in one launch: rm_composite_train_finish_fwd + the gradient half of clean_loss (grad_image = grad_scale * 2 / n_values *
  * (image_out - gt), nerf/utils.py:503) + rm_composite_train_finish_bwd (rays in ascending gapless offset order: every gradient row written or zeroed
  * by the kernel).  One wave per ray in all three, so a ray's image stays in registers; the same bits in every output as the three launches.  The loss value

@@ -111,11 +111,13 @@ SIGNATURES = {
     "hg_scatter_plan": [_vp, _u32, _fl, _vp, _vp],
     "hg_scatter_planned": [_vp, _u32, _vp, _vp],
     "field_fwd_trace_rows": [_vp, _vp, _u32, _vp, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "field_fwd_trace_f16": [_vp, _vp, _u32, _vp, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "field_bwd_trace_rows": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "field_wgrad_scratch_bytes": [_u32],
     "field_wgrad": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "field_bwd_wgrad_scratch_bytes": [_u32],
     "field_bwd_wgrad": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "field_bwd_wgrad_f16": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "rm_composite_train_mse": [_vp, _vp, _vp, _vp, _u32, _u32, _fl, _vp, _vp, _vp, _u32, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "clean_loss": [_vp, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _u32, _c.c_uint64, _vp],
     "hg_levels_plan_bytes": [_u32],

@@ -506,6 +506,7 @@ __global__ void __launch_bounds__(256) k_field_fwd(const float *__restrict__ xyz
 // order, so the planes wait for the ~100 trace stores of the previous tile to be acknowledged and the direction for the 32 stores of the sigma layer in front of it
 // (counters, 718 k points: 54 % of the wave cycles in s_waitcnt).  Here the NEXT tile's planes and direction are requested at a tile's head, in front of all of the
 // tile's stores: they are there when the next tile begins.  Requests are unconditional (past a wave's last tile: the launch's last tile again, never used).
+template <typename TT>
 __global__ void __launch_bounds__(256) k_field_fwd_trace(const float *__restrict__ dirs, uint32_t M, const float2 *__restrict__ planes, uint32_t stride,
                                                          const char *__restrict__ packed, float *__restrict__ sigmas, float *__restrict__ rgbs,
                                                          uint32_t *__restrict__ masks, ActTrace trace, const uint32_t *__restrict__ rows_dev) {
@@ -552,7 +553,7 @@ __global__ void __launch_bounds__(256) k_field_fwd_trace(const float *__restrict
         typename P::Op b4[4];
         mfma_layer<P, 2, 2>(lds, kHalf, F0, lane, feat, hid);
         const uint32_t mask_s = relu_to_operand<P>(hid, b4);
-        store_rows64(trace.hs, stride, s, h, hid, [](float v, int) { return v > 0.0f ? v : 0.0f; });
+        store_rows64<TT>(trace.hs, stride, s, h, hid, [](float v, int) { return v > 0.0f ? v : 0.0f; });
         f32x16 so[1];
         mfma_layer<P, 1, 4>(lds, kHalf, F1, lane, b4, so);
         if (live && h == 0) sigmas[s] = expf(so[0][0]);  // trunc_exp forward (activation.py:9)
@@ -562,7 +563,7 @@ __global__ void __launch_bounds__(256) k_field_fwd_trace(const float *__restrict
         for (int r = 0; r < 8; ++r) geo8[r] = so[0][r];
         if (h == 0) geo8[0] = 1.0f;  // the slot of row 0 carries the padded constant input (weight column 31)
         float rgb[3];
-        color_branch<P>(lds, lane, h, dx, dy, dz, geo8, mask_c, rgb, &trace, stride, s);
+        color_branch<P, TT>(lds, lane, h, dx, dy, dz, geo8, mask_c, rgb, &trace, stride, s);
         if (live && h == 0) { rgbs[3 * (size_t)s] = rgb[0]; rgbs[3 * (size_t)s + 1] = rgb[1]; rgbs[3 * (size_t)s + 2] = rgb[2]; }
         uint32_t *mrow = masks + (size_t)tile * 192 + lane;
         mrow[0] = mask_s; mrow[64] = mask_c[0]; mrow[128] = mask_c[1];
@@ -1158,7 +1159,7 @@ NSIG_EXPORT int field_bwd_planned(const float *xyzs, uint32_t M, float bound, co
 
 static int fwd_trace_impl(const float *xyzs, const float *dirs, uint32_t M, const uint32_t *rows_dev, float bound, const float *const *base_tables_host,
                           const void *packed, const void *planes, float *sigmas, float *rgbs, uint32_t *masks, float *act_hs,
-                          float *act_cin, float *act_h1, float *act_h2, nsig_stream_t stream) {
+                          float *act_cin, float *act_h1, float *act_h2, nsig_stream_t stream, bool trace_f16 = false) {
     if (M == 0) return NSIG_OK;
     NSIG_REQUIRE(xyzs && dirs && packed && planes && sigmas && rgbs && masks && act_hs && act_cin && act_h1 && act_h2, "field_fwd_trace: null pointer");
     NSIG_REQUIRE(bound > 0.0f, "field_fwd_trace: bound must be positive");
@@ -1167,14 +1168,17 @@ static int fwd_trace_impl(const float *xyzs, const float *dirs, uint32_t M, cons
     if (int e = fill_base_tables(base_tables_host, base, "field_fwd_trace")) return e;
     const uint32_t stride = ceil_div(M, 32u) * 32u;
     ActTrace tr{act_hs, act_cin, act_h1, act_h2};
-    if (!fwd_pipelined())      // (mlp_set_pipelined bit 0 clear: the generic kernel's trace variant, the cross-check of tests/test_gpu_stage1.py)
+    if (trace_f16)      // (the ActTrace pointers address _Float16 rows)
+        k_field_fwd_trace<_Float16><<<field_grid(M), 256, Bf16x3::kFwdLds, as_stream(stream)>>>(dirs, M, reinterpret_cast<const float2 *>(planes), stride,
+                                                                                        reinterpret_cast<const char *>(packed), sigmas, rgbs, masks, tr, rows_dev);
+    else if (!fwd_pipelined())      // (mlp_set_pipelined bit 0 clear: the generic kernel's trace variant, the cross-check of tests/test_gpu_stage1.py)
         k_field_fwd<Bf16x3, 1, true><<<field_grid(M), 256, Bf16x3::kFwdLds, as_stream(stream)>>>(xyzs, dirs, M, bound, base, make_level_geom(), nullptr,
                                                                                          reinterpret_cast<const float2 *>(planes), stride,
                                                                                          reinterpret_cast<const char *>(packed), sigmas, rgbs, nullptr, masks, tr,
                                                                                          rows_dev);
     else
-        k_field_fwd_trace<<<field_grid(M), 256, Bf16x3::kFwdLds, as_stream(stream)>>>(dirs, M, reinterpret_cast<const float2 *>(planes), stride,
-                                                                              reinterpret_cast<const char *>(packed), sigmas, rgbs, masks, tr, rows_dev);
+        k_field_fwd_trace<float><<<field_grid(M), 256, Bf16x3::kFwdLds, as_stream(stream)>>>(dirs, M, reinterpret_cast<const float2 *>(planes), stride,
+                                                                                     reinterpret_cast<const char *>(packed), sigmas, rgbs, masks, tr, rows_dev);
     return check_launch("field_fwd_trace");
 }
 
@@ -1182,6 +1186,13 @@ NSIG_EXPORT int field_fwd_trace(const float *xyzs, const float *dirs, uint32_t M
                                 const void *packed, const void *planes, float *sigmas, float *rgbs, uint32_t *masks, float *act_hs,
                                 float *act_cin, float *act_h1, float *act_h2, nsig_stream_t stream) {
     return fwd_trace_impl(xyzs, dirs, M, nullptr, bound, base_tables_host, packed, planes, sigmas, rgbs, masks, act_hs, act_cin, act_h1, act_h2, stream);
+}
+
+NSIG_EXPORT int field_fwd_trace_f16(const float *xyzs, const float *dirs, uint32_t M_capacity, const uint32_t *rows_dev, float bound,
+                                    const float *const *base_tables_host, const void *packed, const void *planes, float *sigmas, float *rgbs, uint32_t *masks,
+                                    void *act_hs, void *act_cin, void *act_h1, void *act_h2, nsig_stream_t stream) {
+    return fwd_trace_impl(xyzs, dirs, M_capacity, rows_dev, bound, base_tables_host, packed, planes, sigmas, rgbs, masks, reinterpret_cast<float *>(act_hs),
+                          reinterpret_cast<float *>(act_cin), reinterpret_cast<float *>(act_h1), reinterpret_cast<float *>(act_h2), stream, true);
 }
 
 NSIG_EXPORT int field_fwd_trace_rows(const float *xyzs, const float *dirs, uint32_t M_capacity, const uint32_t *rows_dev, float bound,

@@ -223,18 +223,21 @@ __device__ inline T *at_uniform(T *base, size_t uniform_elems, uint32_t lane_byt
 
 // rows 32 rb + row_of_reg16(h, r) of a feature-major trace, column s: the row's uniform part (h = 0) + the tile's first point as the SGPR base, the lane's half and
 // point as a 32-bit byte offset (stride < 2^27: the entry points check)
-template <typename F>
-__device__ inline void store_rows64(float *__restrict__ dst, uint32_t stride, uint32_t s, int h, const f32x16 (&acc)[2], F f) {
+// TT: the element type the trace is kept in -- float, or _Float16 (field_fwd_trace_f16: half the bytes; the reference's MLPs keep fp16 activations for their
+// backward, tinycudann FullyFusedMLP): the ActTrace pointers then address _Float16 rows of the same [width][stride] shape.
+template <typename TT = float, typename F>
+__device__ inline void store_rows64(float *__restrict__ dst_f32, uint32_t stride, uint32_t s, int h, const f32x16 (&acc)[2], F f) {
+    TT *__restrict__ dst = reinterpret_cast<TT *>(dst_f32);
     const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);      // lane 0 holds the tile's first point
-    const uint32_t lane_bytes = (4u * (uint32_t)h * stride + (s - s0)) * 4u;
+    const uint32_t lane_bytes = (4u * (uint32_t)h * stride + (s - s0)) * (uint32_t)sizeof(TT);
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int r = 0; r < 16; ++r)      // streaming stores: a trace is written once and read once, a kernel or more later, and is far larger than the L2 (same box: 148 -> 124 us)
-            __builtin_nontemporal_store(f(acc[rb][r], rb * 16 + r), at_uniform(dst, (size_t)(32 * rb + row_of_reg16(0, r)) * stride + s0, lane_bytes));
+            __builtin_nontemporal_store((TT)f(acc[rb][r], rb * 16 + r), at_uniform(dst, (size_t)(32 * rb + row_of_reg16(0, r)) * stride + s0, lane_bytes));
 }
 
-template <typename P>
+template <typename P, typename TT = float>
 __device__ inline void color_branch(const char *lds, int lane, int h, float dx, float dy, float dz,
                                     const float (&geo8)[8], uint32_t (&mask)[2], float (&rgb)[3], const ActTrace *trace = nullptr,
                                     uint32_t stride = 0, uint32_t s = 0) {
@@ -251,23 +254,25 @@ __device__ inline void color_branch(const char *lds, int lane, int h, float dx, 
     }
     auto relu = [](float v, int) { return v > 0.0f ? v : 0.0f; };
     if (trace != nullptr) {
-        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s), col = (s - s0) * 4u;
+        constexpr uint32_t kEl = (uint32_t)sizeof(TT);
+        TT *cin_rows = reinterpret_cast<TT *>(trace->cin);
+        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s), col = (s - s0) * kEl;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            __builtin_nontemporal_store(h ? sh[8 + j] : sh[j], at_uniform(trace->cin, (size_t)j * stride + s0, 8u * (uint32_t)h * stride * 4u + col));      // row 8 h + j
+            __builtin_nontemporal_store((TT)(h ? sh[8 + j] : sh[j]), at_uniform(cin_rows, (size_t)j * stride + s0, 8u * (uint32_t)h * stride * kEl + col));      // row 8 h + j
             // slot (h, j) of the second K-step carries sigma-head row rho = row_of_reg(h, j) -> colour input 15 + rho; rho == 0 (h = 0, j = 0) -> the padded 1.0, row 31
             const uint32_t lane_rows = j == 0 ? (h ? 4u : 16u) : 4u * (uint32_t)h;
-            __builtin_nontemporal_store(geo8[j], at_uniform(trace->cin, (size_t)(15 + row_of_reg(0, j)) * stride + s0, lane_rows * stride * 4u + col));
+            __builtin_nontemporal_store((TT)geo8[j], at_uniform(cin_rows, (size_t)(15 + row_of_reg(0, j)) * stride + s0, lane_rows * stride * kEl + col));
         }
     }
     f32x16 hid[2];
     typename P::Op b4[4];
     mfma_layer<P, 2, 2>(lds, kHalf, F2, lane, cin, hid);
     mask[0] = relu_to_operand<P>(hid, b4);
-    if (trace != nullptr) store_rows64(trace->h1, stride, s, h, hid, relu);
+    if (trace != nullptr) store_rows64<TT>(trace->h1, stride, s, h, hid, relu);
     mfma_layer<P, 2, 4>(lds, kHalf, F3, lane, b4, hid);
     mask[1] = relu_to_operand<P>(hid, b4);
-    if (trace != nullptr) store_rows64(trace->h2, stride, s, h, hid, relu);
+    if (trace != nullptr) store_rows64<TT>(trace->h2, stride, s, h, hid, relu);
     f32x16 out[1];
     mfma_layer<P, 1, 4>(lds, kHalf, F4, lane, b4, out);
 #pragma unroll

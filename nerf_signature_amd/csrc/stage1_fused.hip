@@ -40,27 +40,35 @@ struct FusedArgs {
 };
 
 // ---- a layer input from memory into a wave's scratch: ROWS8 x 8 rows of 32 points; lane 8 g + c takes points 4c..4c+3 of row 8 i + g
-template <int ROWS8>
+// TT: the trace's element type (float: 16 bytes per lane and row; _Float16: 8 bytes, widened when the rows are staged)
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <typename TT> struct RowVec { typedef float4 type; };
+template <> struct RowVec<_Float16> { typedef f16x4 type; };
+__device__ inline float4 widen(const float4 &v) { return v; }
+__device__ inline float4 widen(const f16x4 &v) { return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]); }
+template <int ROWS8, typename TT = float>
 struct RowRegs {
-    float4 v[ROWS8];
+    typename RowVec<TT>::type v[ROWS8];
 };
-template <int ROWS8>
-__device__ inline void rows_request(const float *__restrict__ base, uint32_t stride, uint32_t tile, int lane, RowRegs<ROWS8> &x) {
+template <int ROWS8, typename TT>
+__device__ inline void rows_request(const float *__restrict__ base_f32, uint32_t stride, uint32_t tile, int lane, RowRegs<ROWS8, TT> &x) {
+    typedef typename RowVec<TT>::type Vec;
 #ifdef NSIG_FUSED_NOLOAD      // (diagnostic build, tools/_ab_fused.py: the kernel without its layer-input loads)
-    for (int i = 0; i < ROWS8; ++i) x.v[i] = make_float4(1.0f, 2.0f, 3.0f, 4.0f);
+    for (int i = 0; i < ROWS8; ++i) x.v[i] = Vec{(TT)1.0f, (TT)2.0f, (TT)3.0f, (TT)4.0f};
     return;
 #endif
+    const TT *__restrict__ base = reinterpret_cast<const TT *>(base_f32);
     const uint32_t off = (uint32_t)(lane >> 3) * stride + 4u * (uint32_t)(lane & 7);
 #pragma unroll
-    for (int i = 0; i < ROWS8; ++i) x.v[i] = *reinterpret_cast<const float4 *>(at_uniform(base, (size_t)(8 * i) * stride + (size_t)tile * 32u, off * 4u));
+    for (int i = 0; i < ROWS8; ++i) x.v[i] = *reinterpret_cast<const Vec *>(at_uniform(base, (size_t)(8 * i) * stride + (size_t)tile * 32u, off * (uint32_t)sizeof(TT)));
 }
 // points at or beyond `live` (of this tile's 32) enter as zeros: stale rows of buffers sized for more points may hold anything, and 0 x NaN is NaN
-template <int ROWS8>
-__device__ inline void rows_stage(float *__restrict__ X, int lane, uint32_t live, const RowRegs<ROWS8> &x) {
+template <int ROWS8, typename TT>
+__device__ inline void rows_stage(float *__restrict__ X, int lane, uint32_t live, const RowRegs<ROWS8, TT> &x) {
     const uint32_t g = (uint32_t)lane >> 3, c4 = 4u * ((uint32_t)lane & 7u);
 #pragma unroll
     for (int i = 0; i < ROWS8; ++i) {
-        float4 v = x.v[i];
+        float4 v = widen(x.v[i]);
         if (live < 32u) {      // (uniform: only the last tile of all can be partial)
             v.x = c4 < live ? v.x : 0.0f; v.y = c4 + 1u < live ? v.y : 0.0f; v.z = c4 + 2u < live ? v.z : 0.0f; v.w = c4 + 3u < live ? v.w : 0.0f;
         }
@@ -152,6 +160,7 @@ struct TileIn {      // what a tile's backward starts from
     float gs, sig;
 };
 
+template <typename TT>
 __global__ void __launch_bounds__(256) k_field_bwd_wgrad(FusedArgs a, uint32_t stride, uint32_t M, const uint32_t *__restrict__ rows_dev) {
     typedef Bf16x3 P;
     // one object, the weights FIRST: their fragments are read at immediate offsets from one lane address, and a DS immediate reaches 64 KiB (behind the 72 KiB
@@ -192,11 +201,11 @@ __global__ void __launch_bounds__(256) k_field_bwd_wgrad(FusedArgs a, uint32_t s
     uint32_t tile = blockIdx.x * 4u + wid;
     // requests are unconditional (past the wave's last tile: the last tile of all again, never used): see k_field_wgrad on the compiler's wait counts
     TileIn in{};
-    RowRegs<8> x_h2{}, x_h1{};
+    RowRegs<8, TT> x_h2{}, x_h1{};
     if (n_tiles != 0) {
         request_in(min(tile, n_tiles - 1u), in);
-        rows_request<8>(a.h2, stride, min(tile, n_tiles - 1u), lane, x_h2);
-        rows_request<8>(a.h1, stride, min(tile, n_tiles - 1u), lane, x_h1);
+        rows_request<8, TT>(a.h2, stride, min(tile, n_tiles - 1u), lane, x_h2);
+        rows_request<8, TT>(a.h1, stride, min(tile, n_tiles - 1u), lane, x_h1);
     }
     for (; tile < n_tiles; tile += step) {
         const uint32_t s = tile * 32u + (uint32_t)p;
@@ -216,9 +225,9 @@ __global__ void __launch_bounds__(256) k_field_bwd_wgrad(FusedArgs a, uint32_t s
             head0 = in.gs * fminf(fmaxf(in.sig, e_lo), e_hi);
         }
         const uint32_t mask_s = in.mask_s, mask_c0 = in.mask_c0, mask_c1 = in.mask_c1;
-        rows_stage<8>(X, lane, live, x_h2);                  // h2: the input of the colour head
-        RowRegs<4> x_cin;
-        rows_request<4>(a.cin, stride, tile, lane, x_cin);   // (every layer input is requested TWO layers ahead: one layer's arithmetic is shorter than a trip to memory)
+        rows_stage<8, TT>(X, lane, live, x_h2);                  // h2: the input of the colour head
+        RowRegs<4, TT> x_cin;
+        rows_request<4, TT>(a.cin, stride, tile, lane, x_cin);   // (every layer input is requested TWO layers ahead: one layer's arithmetic is shorter than a trip to memory)
 
         // ---- colour head: dWc3 = d_out x h2^T (rows 0..2 of 16)
         if (h == 0) {
@@ -240,9 +249,9 @@ __global__ void __launch_bounds__(256) k_field_bwd_wgrad(FusedArgs a, uint32_t s
         scratch_fence();
         put_block(DY, 0u, hid[0], p, h);
         put_block(DY, 32u, hid[1], p, h);
-        rows_stage<8>(X, lane, live, x_h1);
-        RowRegs<8> x_hs;
-        rows_request<8>(a.hs, stride, tile, lane, x_hs);
+        rows_stage<8, TT>(X, lane, live, x_h1);
+        RowRegs<8, TT> x_hs;
+        rows_request<8, TT>(a.hs, stride, tile, lane, x_hs);
         mfma_layer<P, 2, 4>(wlds, kHalf, B1, lane, b4, hid);
         scratch_fence();
         products<2, 2>(DY, X, (uint32_t)p, true, h, {{&acc[8], &acc[9]}, {&acc[10], &acc[11]}});
@@ -253,7 +262,7 @@ __global__ void __launch_bounds__(256) k_field_bwd_wgrad(FusedArgs a, uint32_t s
         scratch_fence();
         put_block(DY, 0u, hid[0], p, h);
         put_block(DY, 32u, hid[1], p, h);
-        rows_stage<4>(X, lane, live, x_cin);
+        rows_stage<4, TT>(X, lane, live, x_cin);
         PlaneRegs x_pl;
         planes_request(a.planes, stride, tile, lane, x_pl);
         f32x16 dso[1];
@@ -272,8 +281,8 @@ __global__ void __launch_bounds__(256) k_field_bwd_wgrad(FusedArgs a, uint32_t s
         scratch_fence();
 #pragma unroll
         for (int r = 0; r < 8; ++r) DY[(uint32_t)row_of_reg(h, r) * kFusedRowFloats + p] = head8[r];
-        rows_stage<8>(X, lane, live, x_hs);
-        rows_request<8>(a.h2, stride, upcoming, lane, x_h2);      // the next tile's first layer input and inputs
+        rows_stage<8, TT>(X, lane, live, x_hs);
+        rows_request<8, TT>(a.h2, stride, upcoming, lane, x_h2);      // the next tile's first layer input and inputs
         request_in(upcoming, in);
         mfma_layer<P, 2, 1>(wlds, kHalf, B3, lane, dhead, hid);
         scratch_fence();
@@ -286,7 +295,7 @@ __global__ void __launch_bounds__(256) k_field_bwd_wgrad(FusedArgs a, uint32_t s
         put_block(DY, 0u, hid[0], p, h);
         put_block(DY, 32u, hid[1], p, h);
         planes_stage(X, lane, live, x_pl);
-        rows_request<8>(a.h1, stride, upcoming, lane, x_h1);
+        rows_request<8, TT>(a.h1, stride, upcoming, lane, x_h1);
         f32x16 dall[1];
         mfma_layer<P, 1, 4>(wlds, kHalf, B4F, lane, b4, dall);      // row f = d feature[f]; registers (r, r+1), r even, hold one level's pair
         scratch_fence();
@@ -327,19 +336,35 @@ static uint32_t fused_workgroups(uint32_t M) {      // four tiles of 32 points p
 
 NSIG_EXPORT size_t field_bwd_wgrad_scratch_bytes(uint32_t M) { return (size_t)fused_workgroups(M) * kFusedSlab * sizeof(float); }
 
+static int bwd_wgrad_impl(const char *who, bool trace_f16, uint32_t M, const uint32_t *rows_dev, const float *grad_sigmas, const float *grad_rgbs, const float *sigmas,
+                          const float *rgbs, const uint32_t *masks, const void *packed, const void *planes, const void *act_hs, const void *act_cin, const void *act_h1,
+                          const void *act_h2, void *d_planes, void *scratch, float *grad_sigma_params, float *grad_color_params, nsig_stream_t stream) {
+    NSIG_REQUIRE(grad_sigmas && grad_rgbs && sigmas && rgbs && masks && packed && planes && act_hs && act_cin && act_h1 && act_h2 && d_planes && scratch &&
+                 grad_sigma_params && grad_color_params, "%s: null pointer", who);
+    NSIG_REQUIRE(M >= 1 && M <= (1u << 26), "%s: M=%u out of range (1 .. 2^26, as field_fwd_trace: the lane part of an address is a 32-bit byte offset of up to 32 x stride)", who, M);
+    const void *all[] = {packed, planes, act_hs, act_cin, act_h1, act_h2, d_planes, scratch};
+    for (const void *q : all) NSIG_REQUIRE((reinterpret_cast<uintptr_t>(q) & 15) == 0, "%s: packed, planes, the layer inputs, d_planes and scratch must be 16-byte aligned", who);
+    const uint32_t stride = ceil_div(M, 32u) * 32u, n_wg = fused_workgroups(M);
+    FusedArgs a{grad_sigmas, grad_rgbs, sigmas, rgbs, masks, reinterpret_cast<const char *>(packed), reinterpret_cast<const float2 *>(planes),
+                reinterpret_cast<const float *>(act_hs), reinterpret_cast<const float *>(act_cin), reinterpret_cast<const float *>(act_h1), reinterpret_cast<const float *>(act_h2),
+                reinterpret_cast<float2 *>(d_planes), reinterpret_cast<float *>(scratch)};
+    hipStream_t st = as_stream(stream);
+    if (trace_f16) k_field_bwd_wgrad<_Float16><<<n_wg, 256, 0, st>>>(a, stride, M, rows_dev);
+    else k_field_bwd_wgrad<float><<<n_wg, 256, 0, st>>>(a, stride, M, rows_dev);
+    if (int e = check_launch(who)) return e;
+    return wgrad_reduce_launch(reinterpret_cast<const float *>(scratch), n_wg, grad_sigma_params, grad_color_params, st, "field_bwd_wgrad (reduce)");
+}
+
 NSIG_EXPORT int field_bwd_wgrad(uint32_t M, const uint32_t *rows_dev, const float *grad_sigmas, const float *grad_rgbs, const float *sigmas, const float *rgbs,
                                 const uint32_t *masks, const void *packed, const void *planes, const float *act_hs, const float *act_cin, const float *act_h1,
                                 const float *act_h2, void *d_planes, void *scratch, float *grad_sigma_params, float *grad_color_params, nsig_stream_t stream) {
-    NSIG_REQUIRE(grad_sigmas && grad_rgbs && sigmas && rgbs && masks && packed && planes && act_hs && act_cin && act_h1 && act_h2 && d_planes && scratch &&
-                 grad_sigma_params && grad_color_params, "field_bwd_wgrad: null pointer");
-    NSIG_REQUIRE(M >= 1 && M <= (1u << 26), "field_bwd_wgrad: M=%u out of range (1 .. 2^26, as field_fwd_trace: the lane part of an address is a 32-bit byte offset of up to 32 x stride)", M);
-    const void *all[] = {packed, planes, act_hs, act_cin, act_h1, act_h2, d_planes, scratch};
-    for (const void *q : all) NSIG_REQUIRE((reinterpret_cast<uintptr_t>(q) & 15) == 0, "field_bwd_wgrad: packed, planes, the layer inputs, d_planes and scratch must be 16-byte aligned");
-    const uint32_t stride = ceil_div(M, 32u) * 32u, n_wg = fused_workgroups(M);
-    FusedArgs a{grad_sigmas, grad_rgbs, sigmas, rgbs, masks, reinterpret_cast<const char *>(packed), reinterpret_cast<const float2 *>(planes),
-                act_hs, act_cin, act_h1, act_h2, reinterpret_cast<float2 *>(d_planes), reinterpret_cast<float *>(scratch)};
-    hipStream_t st = as_stream(stream);
-    k_field_bwd_wgrad<<<n_wg, 256, 0, st>>>(a, stride, M, rows_dev);
-    if (int e = check_launch("field_bwd_wgrad")) return e;
-    return wgrad_reduce_launch(reinterpret_cast<const float *>(scratch), n_wg, grad_sigma_params, grad_color_params, st, "field_bwd_wgrad (reduce)");
+    return bwd_wgrad_impl("field_bwd_wgrad", false, M, rows_dev, grad_sigmas, grad_rgbs, sigmas, rgbs, masks, packed, planes, act_hs, act_cin, act_h1, act_h2, d_planes, scratch,
+                          grad_sigma_params, grad_color_params, stream);
+}
+
+NSIG_EXPORT int field_bwd_wgrad_f16(uint32_t M, const uint32_t *rows_dev, const float *grad_sigmas, const float *grad_rgbs, const float *sigmas, const float *rgbs,
+                                    const uint32_t *masks, const void *packed, const void *planes, const void *act_hs, const void *act_cin, const void *act_h1,
+                                    const void *act_h2, void *d_planes, void *scratch, float *grad_sigma_params, float *grad_color_params, nsig_stream_t stream) {
+    return bwd_wgrad_impl("field_bwd_wgrad_f16", true, M, rows_dev, grad_sigmas, grad_rgbs, sigmas, rgbs, masks, packed, planes, act_hs, act_cin, act_h1, act_h2, d_planes, scratch,
+                          grad_sigma_params, grad_color_params, stream);
 }

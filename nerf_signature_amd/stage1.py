@@ -71,16 +71,21 @@ def _stride(M):
 class _Traces:
     """The buffers one field pass of `M` points (capacity) leaves for its backward: planes, layer inputs, pre-activation gradients."""
 
-    def __init__(self, M, dev, with_grads=True, fused=True):
+    def __init__(self, M, dev, with_grads=True, fused=True, half=False):
         st = self.stride = _stride(M)
         self.fused = fused
+        # half: the layer inputs kept as fp16 (448 instead of 896 bytes per point written by the forward and read back by the backward) -- what the reference's MLPs
+        # keep for their backward (tinycudann FullyFusedMLP: fp16 activations); the one-launch backward only (field_fwd_trace_f16 / field_bwd_wgrad_f16)
+        self.half = bool(half)
+        if self.half and not fused:
+            raise ValueError("fp16 traces go with the one-launch backward (fused=True): field_bwd_trace + field_wgrad read fp32 rows")
         f32 = dict(dtype=torch.float32, device=dev)
         self.M = M
         self.planes = torch.empty(17, st, 2, **f32)
         self.sig = torch.empty(M, **f32)
         self.rgb = torch.empty(M, 3, **f32)
         self.masks = torch.empty(st, fo.MASK_WORDS, dtype=torch.int32, device=dev)
-        self.act = [torch.empty(w, st, **f32) for w in (64, 32, 64, 64)]               # hs, cin, h1, h2
+        self.act = [torch.empty(w, st, dtype=torch.float16 if self.half else torch.float32, device=dev) for w in (64, 32, 64, 64)]               # hs, cin, h1, h2
         if with_grads:
             self.alloc_grads()
 
@@ -98,7 +103,12 @@ class _Traces:
 
 def _forward_trace(tr, xyzs, dirs, bound, base_ptrs, packed, rows=None):
     s = nv.stream()
-    if rows is None:
+    if tr.half:
+        nv.call("hg_encode_planes" if rows is None else "hg_encode_planes_rows", nv.ptr(xyzs), tr.M, *(() if rows is None else (nv.ptr(rows),)), float(bound), base_ptrs, None,
+                nv.ptr(tr.planes), s)
+        nv.call("field_fwd_trace_f16", nv.ptr(xyzs), nv.ptr(dirs), tr.M, nv.ptr(rows), float(bound), base_ptrs, nv.ptr(packed), nv.ptr(tr.planes), nv.ptr(tr.sig),
+                nv.ptr(tr.rgb), nv.ptr(tr.masks), *[nv.ptr(a) for a in tr.act], s)
+    elif rows is None:
         nv.call("hg_encode_planes", nv.ptr(xyzs), tr.M, float(bound), base_ptrs, None, nv.ptr(tr.planes), s)
         nv.call("field_fwd_trace", nv.ptr(xyzs), nv.ptr(dirs), tr.M, float(bound), base_ptrs, nv.ptr(packed), nv.ptr(tr.planes), nv.ptr(tr.sig),
                 nv.ptr(tr.rgb), nv.ptr(tr.masks), *[nv.ptr(a) for a in tr.act], s)
@@ -114,7 +124,7 @@ def _backward_trace(tr, g_sigma, g_rgb, packed, g_sigma_params, g_color_params, 
     and the table scatter both need the backward's traces and nothing of each other."""
     s = nv.stream()
     if tr.fused:
-        nv.call("field_bwd_wgrad", tr.M, nv.ptr(rows), nv.ptr(g_sigma), nv.ptr(g_rgb), nv.ptr(tr.sig), nv.ptr(tr.rgb), nv.ptr(tr.masks), nv.ptr(packed),
+        nv.call("field_bwd_wgrad_f16" if tr.half else "field_bwd_wgrad", tr.M, nv.ptr(rows), nv.ptr(g_sigma), nv.ptr(g_rgb), nv.ptr(tr.sig), nv.ptr(tr.rgb), nv.ptr(tr.masks), nv.ptr(packed),
                 nv.ptr(tr.planes), *[nv.ptr(a) for a in tr.act], nv.ptr(tr.d_planes), nv.ptr(tr.wgrad_scratch), nv.ptr(g_sigma_params), nv.ptr(g_color_params), s)
         return
     if rows is None:
@@ -290,7 +300,7 @@ class GraphedCleanLoop:
 
     def __init__(self, model, optimizer, render_kwargs, n_rays, sampler=None, update_extra_interval=16, lr_lambda=None, headroom=0.5, perturb=True,
                  capacity=None, overlap_plan="auto", capture=True, seed=0, fused_backward=True, fused_composite=True, fused_table_adam=None, sparse_exchange=True,
-                 device_refresh=True):
+                 device_refresh=True, trace_dtype="f32"):
         if not model.cuda_ray:
             raise ValueError("GraphedCleanLoop drives the occupancy-grid path (cuda_ray=True)")
         if model.density_scale != 1:
@@ -354,6 +364,9 @@ class GraphedCleanLoop:
         self.capture = bool(capture)      # False: the same explicit kernel sequence issued eagerly every step (tests, debugging)
         self.fused_composite = bool(fused_composite)    # False: compositing forward, clean_loss, compositing backward as three launches in a row
         self.fused_backward = bool(fused_backward)      # False: field_bwd_trace + field_wgrad (the latter on the plan's stream) instead of field_bwd_wgrad
+        if trace_dtype not in ("f32", "f16"):
+            raise ValueError("trace_dtype: 'f32' (strict: the saved layer inputs as the forward computed them) | 'f16' (half the trace bytes; the reference's precision)")
+        self.trace_half = trace_dtype == "f16"
         # the tables' Adam step inside the scatter's owners (hg_levels_scatter_adam): their gradient never leaves the chip -- no 64 MiB written and read back, no
         # table pass on the step's tail; the tables' .grad is then NOT produced.  None: on unless the gradients are exchanged between ranks (which needs them in memory)
         self.fused_table_adam = (not dp.exchange_active()) if fused_table_adam is None else bool(fused_table_adam)
@@ -516,7 +529,7 @@ class GraphedCleanLoop:
 
     def _allocate(self):
         dev, M = self.device, self.capacity
-        self.tr = _Traces(M, dev, fused=self.fused_backward)
+        self.tr = _Traces(M, dev, fused=self.fused_backward, half=self.trace_half)
         self.g_sig = torch.empty(M, dtype=torch.float32, device=dev)
         self.g_rgb = torch.empty(M, 3, dtype=torch.float32, device=dev)
         self.plan = torch.empty(int(nv.fn("hg_levels_plan_bytes")(M)), dtype=torch.uint8, device=dev)

@@ -89,13 +89,13 @@ def test_all_parameter_gradients_vs_oracle(bound):
     print(f"\nworst base-table gradient rel. L2 over the 16 levels: {worst:.2e}")
 
 
-def _traced_pass(m, pts, dirs, gs, gc, capacity=None, rows=None, fused=True):
+def _traced_pass(m, pts, dirs, gs, gc, capacity=None, rows=None, fused=True, half=False):
     """forward + backward through the explicit entry points (fused: field_bwd_wgrad; else field_bwd_trace + field_wgrad); returns (traces, sigma
     gradient, colour gradient, table gradients [16,T,2])."""
     from nerf_signature_amd import _native as nv, fieldops as fo, stage1
     M = pts.shape[0] if capacity is None else capacity
     dev = pts.device
-    tr = stage1._Traces(M, dev, fused=fused)
+    tr = stage1._Traces(M, dev, fused=fused, half=half)
     if capacity is not None:     # poison everything past the live rows: none of it may be read
         for t in [tr.planes, *tr.act, *(tr.d or []), tr.d_planes]:
             t.fill_(float("nan"))
@@ -162,6 +162,36 @@ def test_weight_gradients_equal_the_matrix_products_and_are_bit_reproducible():
     for l in range(16):
         assert torch.equal(G[l] != 0, G3[l] != 0), l
         assert rel(G[l], G3[l]) < 1e-6, (l, rel(G[l], G3[l]))
+
+
+def test_half_precision_traces_round_only_what_is_saved():
+    """trace_dtype="f16" (field_fwd_trace_f16 / field_bwd_wgrad_f16): the forward's outputs and ReLU masks, and the whole input-gradient chain (d_planes, the 16 table
+    gradients), are the fp32 route's bit for bit -- nothing of them reads a saved layer input; the saved rows are the fp32 rows rounded to fp16 (the precision the
+    reference's MLPs keep their activations in, tinycudann FullyFusedMLP); the weight gradients are the float64 products of THOSE rows (1e-5, as the fp32 route is of
+    its rows) and sit within 3e-4 of the fp32 route's -- with a host and with a device row count, partial last tile included."""
+    m, _, _ = _clean_model()
+    for M, capacity in ((20011, None), (3000, 4000)):
+        pts, dirs, gs, gc = _random_batch(M if capacity is None else capacity)
+        rows = None if capacity is None else torch.tensor([M, 0], dtype=torch.int32, device="cuda")
+        t32, s32, c32, G32 = _traced_pass(m, pts, dirs, gs, gc, capacity=capacity, rows=rows, fused=True)
+        t16, s16, c16, G16 = _traced_pass(m, pts, dirs, gs, gc, capacity=capacity, rows=rows, fused=True, half=True)
+        assert all(a.dtype == torch.float16 for a in t16.act) and sum(a.numel() * a.element_size() for a in t16.act) * 2 == sum(a.numel() * a.element_size() for a in t32.act)
+        assert torch.equal(t16.sig[:M], t32.sig[:M]) and torch.equal(t16.rgb[:M], t32.rgb[:M]) and torch.equal(t16.masks[:(M + 31) // 32 * 32], t32.masks[:(M + 31) // 32 * 32])
+        for a16, a32 in zip(t16.act, t32.act):
+            assert torch.equal(a16[:, :M], a32[:, :M].half())                     # round to nearest even, element by element
+        assert torch.equal(t16.d_planes[:, :M], t32.d_planes[:, :M]) and torch.equal(G16, G32)
+        if capacity is None:
+            # the pre-activation gradients of the chain (from the two-launch route: the same chain) x the ROUNDED layer inputs, in float64
+            tr2, _, _, _ = _traced_pass(m, pts, dirs, gs, gc, fused=False)
+            feat = tr2.planes[:16, :M].double().permute(0, 2, 1).reshape(32, M)
+            hs, cin, h1, h2 = (a[:, :M].double() for a in t16.act)
+            d_hs, d_so, d_h1, d_h2, d_out = (t[:, :M].double() for t in tr2.d)
+            want_s = torch.cat([(d_hs @ feat.t()).reshape(-1), (d_so @ hs.t()).reshape(-1)])
+            want_c = torch.cat([(d_h1 @ cin.t()).reshape(-1), (d_h2 @ h1.t()).reshape(-1), (d_out @ h2.t()).reshape(-1)])
+            assert rel(s16, want_s) < 1e-5 and rel(c16, want_c) < 1e-5, (rel(s16, want_s), rel(c16, want_c))
+        print(f"\nfp16 traces, {M} points: weight gradients vs the fp32 traces' rel. L2 sigma MLP {rel(s16, s32):.2e}, colour MLP {rel(c16, c32):.2e}")
+        assert rel(s16, s32) < 3e-4 and rel(c16, c32) < 3e-4
+        assert float(c16[6144 + 3 * 64:].abs().max()) == 0.0
 
 
 def test_pipelined_trace_forward_equals_the_plain_loop_bit_for_bit():
@@ -364,8 +394,8 @@ def test_table_adam_inside_the_scatter_owners_equals_the_separate_pass_bit_for_b
     assert float((a[0][15] - _clean_model()[0].trainable()[15].detach()).abs().max()) > 0      # (the finest table did move)
 
 
-@pytest.mark.parametrize("bound", [1.0, 2.0], ids=["one_cascade", "two_cascades"])
-def test_captured_loop_tracks_the_cpu_oracle_over_200_steps(bound):
+@pytest.mark.parametrize("bound,trace_dtype", [(1.0, "f32"), (2.0, "f32"), (1.0, "f16")], ids=["one_cascade", "two_cascades", "one_cascade_f16_traces"])
+def test_captured_loop_tracks_the_cpu_oracle_over_200_steps(bound, trace_dtype):
     """From a common state, 200 steps of the captured loop and of the CPU oracle (the reference's operator sequence in torch autograd + torch's
     Adam): the loss every 20th step, and the PSNR of the trained render against the target within 0.1 dB."""
     from nerf_signature_amd.stage1 import GraphedCleanLoop
@@ -379,7 +409,7 @@ def test_captured_loop_tracks_the_cpu_oracle_over_200_steps(bound):
     leaves = P["base_tables"] + [P["sigma_params"], P["color_params"]]
     opt_cpu = torch.optim.Adam(leaves, lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
     sched = lambda it: 0.1 ** min(it / 200, 1)      # main_nerf.py:127 over this run's length
-    loop = GraphedCleanLoop(m, _adam(m), KW, n_rays=N, update_extra_interval=0, perturb=False, lr_lambda=sched)
+    loop = GraphedCleanLoop(m, _adam(m), KW, n_rays=N, update_extra_interval=0, perturb=False, lr_lambda=sched, trace_dtype=trace_dtype)
     data = {"rays_o": o.cuda(), "rays_d": d.cuda(), "images": target.cuda()}
     cpu, gpu = [], []
     for it in range(200):

@@ -127,9 +127,10 @@ fused = "--two-launch" not in flags
 plan_mode = False if "--no-overlap" in flags else (True if "--overlap" in flags else "auto")      # the scatter plan on a stream of its own: never | always | from 600 k buffer rows on
 one_composite = "--three-launch-composite" not in flags      # (rm_composite_train_mse | compositing forward, clean_loss, compositing backward)
 table_adam_flag = False if "--separate-table-adam" in flags else None      # (None: the loop's default -- inside the scatter's owners unless gradients are exchanged)
+trace_dtype = "f16" if "--f16-traces" in flags else "f32"      # the saved layer inputs as fp16 (half the trace bytes) | fp32 (strict)
 host_refresh = "--host-refresh" in flags      # the reference's form of the grid refresh (torch operators, three host synchronisations) instead of the device-side graph
 loop = GraphedCleanLoop(m, opt, dict(dt_gamma=0, max_steps=1024), n_rays=n_rays, update_extra_interval=refresh, perturb=True, overlap_plan=plan_mode,
-                        fused_backward=fused, fused_composite=one_composite, fused_table_adam=table_adam_flag, device_refresh=not host_refresh)
+                        fused_backward=fused, fused_composite=one_composite, fused_table_adam=table_adam_flag, device_refresh=not host_refresh, trace_dtype=trace_dtype)
 loop.step(data)
 for _ in range(31):
     loop.step()
@@ -161,7 +162,7 @@ if refresh:
         m_s = fresh_model()
         opt_s = torch.optim.Adam(m_s.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
         loop_s = GraphedCleanLoop(m_s, opt_s, dict(dt_gamma=0, max_steps=1024), n_rays=n_rays, update_extra_interval=0, perturb=True, overlap_plan=plan_mode,
-                                  fused_backward=fused, fused_composite=one_composite, fused_table_adam=table_adam_flag)
+                                  fused_backward=fused, fused_composite=one_composite, fused_table_adam=table_adam_flag, trace_dtype=trace_dtype)
         loop_s.step(data)
         for _ in range(15):
             loop_s.step()
@@ -222,7 +223,7 @@ def eager_pass(table_adam_in_owners):
     m2.load_state_dict(state)
     opt2 = torch.optim.Adam(m2.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
     eager = GraphedCleanLoop(m2, opt2, dict(dt_gamma=0, max_steps=1024), n_rays=n_rays, update_extra_interval=0, perturb=True, overlap_plan=False, capture=False, capacity=capacity,
-                             fused_backward=fused, fused_composite=one_composite, fused_table_adam=table_adam_in_owners)
+                             fused_backward=fused, fused_composite=one_composite, fused_table_adam=table_adam_in_owners, trace_dtype=trace_dtype)
     eager.step(data)
     for _ in range(3):
         eager.step()
