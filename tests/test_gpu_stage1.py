@@ -178,7 +178,14 @@ def test_half_precision_traces_round_only_what_is_saved():
         assert all(a.dtype == torch.float16 for a in t16.act) and sum(a.numel() * a.element_size() for a in t16.act) * 2 == sum(a.numel() * a.element_size() for a in t32.act)
         assert torch.equal(t16.sig[:M], t32.sig[:M]) and torch.equal(t16.rgb[:M], t32.rgb[:M]) and torch.equal(t16.masks[:(M + 31) // 32 * 32], t32.masks[:(M + 31) // 32 * 32])
         for a16, a32 in zip(t16.act, t32.act):
-            assert torch.equal(a16[:, :M], a32[:, :M].half())                     # round to nearest even, element by element
+            # round to nearest even, element by element.  (The SH inputs are products the compiler rounds ONCE to fp16 -- v_fma_mixlo_f16 -- where fp32-then-fp16
+            # rounds twice: on an exact tie of the fp32 value the two differ by one fp16 ulp; measured 1 element of 640 352.)
+            want = a32[:, :M].half()
+            off = a16[:, :M] != want
+            assert float(off.float().mean()) < 1e-5, float(off.float().mean())
+            if off.any():
+                ulp = torch.maximum(want.float().abs(), torch.tensor(2.0 ** -14, device="cuda")) * 2.0 ** -10
+                assert bool(((a16[:, :M].float() - want.float()).abs()[off] <= ulp[off]).all())
         assert torch.equal(t16.d_planes[:, :M], t32.d_planes[:, :M]) and torch.equal(G16, G32)
         if capacity is None:
             # the pre-activation gradients of the chain (from the two-launch route: the same chain) x the ROUNDED layer inputs, in float64
