@@ -632,6 +632,14 @@ int rm_composite_train_mse(const float *sigmas, const float *rgbs, const float *
                            const float *nears, const float *fars, const float *bg, uint32_t bg_stride, const float *gt, uint32_t n_values,
                            float grad_scale, float *weights_sum, float *depth, float *image, float *image_out, float *depth_out, float *grad_image,
                            float *grad_sigmas, float *grad_rgbs, nsig_stream_t stream);
+/*
+ * The stage-1 trainer's exponential moving average of the parameters (main_nerf.py:130 ema_decay=0.95; utils.py:389-390,761-762: torch_ema's
+ * ExponentialMovingAverage.update() after every optimiser step): for every tensor shadow -= (shadow - param) * (1 - d), d = min(decay, (1 + u) / (10 + u)),
+ * u = *num_updates -- the count of updates INCLUDING this one (a captured loop's device step counter, already advanced by the step's loss kernel).  One launch,
+ * n <= 32 tensors.
+ */
+int opt_ema_update(uint32_t n, const float *const *params_host, float *const *shadow_host, const uint32_t *numel_host, const uint32_t *num_updates,
+                   double decay, nsig_stream_t stream);
 int clean_loss(const float *image, const float *gt, uint32_t n_values, float grad_scale, float *loss, float *grad_image,
                uint32_t *step_dev, const int32_t *march_counter, int32_t *count_ring, float *loss_ring, uint32_t loss_ring_len,
                float *noise_next, uint32_t n_noise, uint64_t seed, nsig_stream_t stream);

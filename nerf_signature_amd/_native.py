@@ -119,6 +119,7 @@ SIGNATURES = {
     "field_bwd_wgrad": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "field_bwd_wgrad_f16": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "rm_composite_train_mse": [_vp, _vp, _vp, _vp, _u32, _u32, _fl, _vp, _vp, _vp, _u32, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "opt_ema_update": [_u32, _vp, _vp, _vp, _vp, _c.c_double, _vp],
     "clean_loss": [_vp, _vp, _u32, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _u32, _c.c_uint64, _vp],
     "hg_levels_plan_bytes": [_u32],
     "hg_levels_plan": [_vp, _u32, _vp, _fl, _vp, _vp],

@@ -254,9 +254,59 @@ __global__ void __launch_bounds__(1024) k_clean_loss(const float *__restrict__ i
     }
 }
 
+// ----------------------------------------------------------------------------- EMA of the parameters
+// The stage-1 trainer keeps an exponential moving average of every parameter (main_nerf.py:130 `ema_decay=0.95`; utils.py:389-390 torch_ema's
+// ExponentialMovingAverage, updated after every optimiser step, :761-762/:892-893) and evaluates / checkpoints with it (:801-811).  torch_ema 0.3's update(), with
+// its default warm-up (use_num_updates): num_updates += 1; decay = min(decay, (1 + num_updates) / (10 + num_updates)); then for every parameter
+//     tmp = shadow - param;  tmp *= (1 - decay);  shadow -= tmp
+// -- here one launch over all tensors, the update count read from the captured loop's device step counter (which the step's loss kernel has already advanced).
+constexpr int kEmaMax = 32;
+constexpr uint32_t kEmaChunk = 4096;      // elements per workgroup
+struct DenseEma {
+    const float *p[kEmaMax];
+    float *s[kEmaMax];
+    uint32_t numel[kEmaMax], chunk0[kEmaMax + 1];
+};
+__global__ void __launch_bounds__(256) k_ema_dense(DenseEma a, uint32_t n, const uint32_t *__restrict__ num_updates, double decay) {
+    uint32_t t = 0;
+    while (t + 1 < n && blockIdx.x >= a.chunk0[t + 1]) ++t;      // (uniform)
+    const double nu = (double)*num_updates;
+    const float w = (float)(1.0 - fmin(decay, (1.0 + nu) / (10.0 + nu)));      // (python: a double, handed to mul_ as a float32 scalar)
+    const uint32_t first = (blockIdx.x - a.chunk0[t]) * kEmaChunk, numel = a.numel[t];
+    const float *__restrict__ p = a.p[t];
+    float *__restrict__ s = a.s[t];
+    if (numel % 4u == 0 && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(s)) & 15) == 0) {      // (uniform)
+        for (uint32_t i = first + 4u * threadIdx.x; i < min(numel, first + kEmaChunk); i += 1024u) {
+            const float4 pv = *reinterpret_cast<const float4 *>(p + i);
+            float4 sv = *reinterpret_cast<const float4 *>(s + i);
+            sv.x = sv.x - (sv.x - pv.x) * w; sv.y = sv.y - (sv.y - pv.y) * w; sv.z = sv.z - (sv.z - pv.z) * w; sv.w = sv.w - (sv.w - pv.w) * w;
+            *reinterpret_cast<float4 *>(s + i) = sv;
+        }
+    } else {
+        for (uint32_t i = first + threadIdx.x; i < min(numel, first + kEmaChunk); i += 256u) s[i] = s[i] - (s[i] - p[i]) * w;
+    }
+}
+
 }  // namespace nsig
 
 using namespace nsig;
+
+NSIG_EXPORT int opt_ema_update(uint32_t n, const float *const *params_host, float *const *shadow_host, const uint32_t *numel_host, const uint32_t *num_updates,
+                               double decay, nsig_stream_t stream) {
+    NSIG_REQUIRE(params_host && shadow_host && numel_host && num_updates, "opt_ema_update: null pointer");
+    NSIG_REQUIRE(n >= 1 && n <= (uint32_t)kEmaMax && decay >= 0.0 && decay <= 1.0, "opt_ema_update: 1 .. %d tensors, decay in [0, 1]", kEmaMax);
+    DenseEma a{};
+    uint32_t chunks = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        NSIG_REQUIRE(params_host[i] && shadow_host[i] && numel_host[i] > 0, "opt_ema_update: tensor %u has a null pointer or no elements", i);
+        a.p[i] = params_host[i]; a.s[i] = shadow_host[i]; a.numel[i] = numel_host[i];
+        a.chunk0[i] = chunks;
+        chunks += ceil_div(numel_host[i], kEmaChunk);
+    }
+    a.chunk0[n] = chunks;
+    k_ema_dense<<<chunks, 256, 0, as_stream(stream)>>>(a, n, num_updates, decay);
+    return check_launch("opt_ema_update");
+}
 
 // slabs[n_wg][3 roles][4 products][16 registers][64 lanes] -> the two parameter gradients (also the tail of field_bwd_wgrad, stage1_fused.hip)
 int nsig::wgrad_reduce_launch(const float *slabs, uint32_t n_wg, float *grad_sigma_params, float *grad_color_params, hipStream_t st, const char *what) {

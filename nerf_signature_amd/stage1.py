@@ -258,11 +258,24 @@ class CleanLoop:
     `update_extra_interval` steps refresh the density grid (utils.py:852-869).  With more than one rank the gradients are averaged
     (dp.allreduce_gradients) before the optimiser step."""
 
-    def __init__(self, model, optimizer, render_kwargs, update_extra_interval=16, lr_scheduler=None):
+    def __init__(self, model, optimizer, render_kwargs, update_extra_interval=16, lr_scheduler=None, ema_decay=None):
         self.model, self.optimizer, self.lr_scheduler = model, optimizer, lr_scheduler
         self.render_kwargs = dict(render_kwargs)
         self.update_extra_interval = update_extra_interval
         self.global_step = 0
+        # torch_ema.ExponentialMovingAverage(model.parameters(), decay) as utils.py:389-390 builds it (main_nerf.py:130: 0.95), restated with tensor operators
+        self.ema_decay = ema_decay
+        self.ema_shadow = None if ema_decay is None else [p.detach().clone() for p in model.trainable()]
+        self.ema_updates = 0
+
+    @torch.no_grad()
+    def _ema_update(self):
+        self.ema_updates += 1
+        decay = min(self.ema_decay, (1 + self.ema_updates) / (10 + self.ema_updates))
+        for s_, p in zip(self.ema_shadow, self.model.trainable()):
+            tmp = s_ - p
+            tmp.mul_(1.0 - decay)
+            s_.sub_(tmp)
 
     def step(self, data):
         if self.model.cuda_ray and self.global_step % self.update_extra_interval == 0:
@@ -274,6 +287,8 @@ class CleanLoop:
         if dp.world_size() > 1:
             dp.allreduce_gradients([p for g in self.optimizer.param_groups for p in g["params"]])
         self.optimizer.step()
+        if self.ema_shadow is not None:      # utils.py:761-762: after the optimiser step
+            self._ema_update()
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()
         return image, loss
@@ -300,7 +315,7 @@ class GraphedCleanLoop:
 
     def __init__(self, model, optimizer, render_kwargs, n_rays, sampler=None, update_extra_interval=16, lr_lambda=None, headroom=0.5, perturb=True,
                  capacity=None, overlap_plan="auto", capture=True, seed=0, fused_backward=True, fused_composite=True, fused_table_adam=None, sparse_exchange=True,
-                 device_refresh=True, trace_dtype="f32"):
+                 device_refresh=True, trace_dtype="f32", ema_decay=None):
         if not model.cuda_ray:
             raise ValueError("GraphedCleanLoop drives the occupancy-grid path (cuda_ray=True)")
         if model.density_scale != 1:
@@ -376,6 +391,10 @@ class GraphedCleanLoop:
         # False: NeRFRenderer.update_extra_state, the reference's form (three host synchronisations per refresh)
         self.device_refresh = bool(device_refresh)
         self._refresh = None
+        # the trainer's moving average of the parameters (main_nerf.py:130 ema_decay=0.95; torch_ema semantics, csrc/stage1.hip opt_ema_update): one launch at the
+        # step's tail, inside the graph; read it through ema_parameters() / the ema_weights() context (utils.py:801-811 evaluates and checkpoints with it)
+        self.ema_decay = None if ema_decay is None else float(ema_decay)
+        self.ema_shadow = None if ema_decay is None else [p.detach().clone() for p in self.params]
         self._peak_host = torch.zeros(1, dtype=torch.int32).pin_memory() if dev.type == "cuda" else None
         self._peak_ready = None      # event behind the copy of the last window's peak into _peak_host
         self.global_step = 0
@@ -509,6 +528,37 @@ class GraphedCleanLoop:
             self._join_weight_gradients()
             self._adam(self.params[16:])
         nv.call("mlp_pack_weights", nv.ptr(self.model.sigma_net.params.detach()), nv.ptr(self.model.color_net.params.detach()), nv.ptr(self.packed), nv.stream())
+        if self.ema_shadow is not None:
+            numel = (ctypes.c_uint32 * len(self.params))(*[p.numel() for p in self.params])
+            nv.call("opt_ema_update", len(self.params), nv.ptr_array([p.data for p in self.params]), nv.ptr_array(self.ema_shadow), numel, nv.ptr(self.step_dev),
+                    self.ema_decay, nv.stream())
+
+    def ema_parameters(self):
+        """The moving averages, in the order of model.trainable() (None without ema_decay)."""
+        return self.ema_shadow
+
+    @contextlib.contextmanager
+    def ema_weights(self):
+        """torch_ema's store() / copy_to() ... restore() around an evaluation or a checkpoint (utils.py:801-811): inside the block the model holds the averaged
+        parameters (and the captured step's operand image of the MLP weights is rebuilt from them), afterwards the trained ones again."""
+        if self.ema_shadow is None:
+            yield
+            return
+        kept = [p.detach().clone() for p in self.params]
+        repack = lambda: nv.call("mlp_pack_weights", nv.ptr(self.model.sigma_net.params.detach()), nv.ptr(self.model.color_net.params.detach()), nv.ptr(self.packed), nv.stream())
+        with torch.no_grad():
+            for p, s_ in zip(self.params, self.ema_shadow):
+                p.copy_(s_)
+            repack()
+            _bump_versions(self.params)
+        try:
+            yield
+        finally:
+            with torch.no_grad():
+                for p, k in zip(self.params, kept):
+                    p.copy_(k)
+                repack()
+                _bump_versions(self.params)
 
     def _whole_step(self):
         self._forward_backward()
@@ -568,10 +618,13 @@ class GraphedCleanLoop:
     def _snapshot(self):
         state = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.optimizer.state[p].items()} for p in self.params if len(self.optimizer.state[p])}
         return ([p.detach().clone() for p in self.params], state, self.step_dev.clone(), self.count_ring.clone(), self.loss_ring.clone(),
-                None if self.noises is None else self.noises.clone())
+                None if self.noises is None else self.noises.clone(), None if self.ema_shadow is None else [t.clone() for t in self.ema_shadow])
 
     def _restore(self, snap):
-        values, state, step_dev, count_ring, loss_ring, noises = snap
+        values, state, step_dev, count_ring, loss_ring, noises, shadow = snap
+        if shadow is not None:
+            for t, v in zip(self.ema_shadow, shadow):
+                t.copy_(v)
         for p, v in zip(self.params, values):
             p.copy_(v)
         for p in self.params:

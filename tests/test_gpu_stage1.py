@@ -694,3 +694,60 @@ def test_grid_refresh_full_and_partial_over_the_cascades_captured_equals_eager(b
     thresh = min(m_c.mean_density, m_c.density_thresh)
     assert torch.equal(m_c.density_bitfield, raymarching.packbits(m_c.density_grid, thresh))
     assert all(np.isfinite(loop_c.losses()))
+
+
+def test_parameter_ema_follows_torch_ema_inside_the_captured_step():
+    """ema_decay (the stage-1 trainer's ExponentialMovingAverage(model.parameters(), decay=0.95), main_nerf.py:130, utils.py:389-390,761-762): the shadow the
+    loop keeps inside its captured step equals torch_ema 0.3's update() restated with tensor operators on the parameters after every step -- its warm-up
+    decay min(0.95, (1 + n) / (10 + n)) included -- bit for bit; the eager autograd loop's restatement agrees with its own parameters the same way; the set-up's
+    warm-up steps leave the shadow alone; ema_weights() evaluates with the averages and puts the trained parameters back."""
+    from nerf_signature_amd.stage1 import CleanLoop, GraphedCleanLoop
+    o, d = _patch_rays(8)
+    rng = np.random.RandomState(11)
+    target = torch.from_numpy((0.25 + 0.5 * rng.rand(64, 3)).astype(np.float32)).cuda()
+    data = {"rays_o": o.cuda(), "rays_d": d.cuda(), "images": target}
+
+    def torch_ema(shadow, params, n):
+        decay = min(0.95, (1 + n) / (10 + n))
+        for s_, p in zip(shadow, params):
+            tmp = s_ - p
+            tmp.mul_(1.0 - decay)
+            s_.sub_(tmp)
+
+    finals = []
+    for capture in (False, True):
+        m, _, _ = _clean_model(mlp_scale=0.5)
+        loop = GraphedCleanLoop(m, _adam(m), KW, n_rays=64, update_extra_interval=0, perturb=False, capture=capture, ema_decay=0.95)
+        start = [p.detach().clone() for p in m.trainable()]
+        want = [p.clone() for p in start]
+        for k in range(1, 8):
+            loop.step(data if k == 1 else None)
+            if k == 1:
+                pass
+            torch_ema(want, [p.detach() for p in m.trainable()], k)
+            if not capture or k == 7:
+                for a, b in zip(loop.ema_parameters(), want):
+                    assert torch.equal(a, b), (capture, k)
+        assert not torch.equal(loop.ema_parameters()[16], m.trainable()[16]) and not torch.equal(loop.ema_parameters()[16], start[16])
+        trained = [p.detach().clone() for p in m.trainable()]
+        with loop.ema_weights():
+            for p, s_ in zip(m.trainable(), loop.ema_parameters()):
+                assert torch.equal(p, s_)
+            img = m.render(o.cuda()[None], d.cuda()[None], None, staged=False, bg_color=1, perturb=False, force_all_rays=True, **KW)["image"]
+            assert bool(torch.isfinite(img).all())
+        for p, t in zip(m.trainable(), trained):
+            assert torch.equal(p, t)
+        finals.append([t.clone() for t in loop.ema_parameters()])
+    for a, b in zip(*finals):
+        assert torch.equal(a, b)                                                  # captured == eager
+    # the autograd loop's restatement (CleanLoop): the same recurrence on its own parameters
+    m, _, _ = _clean_model(mlp_scale=0.5)
+    eager = CleanLoop(m, _adam(m), KW, update_extra_interval=10 ** 9, ema_decay=0.95)
+    eager.global_step = 1
+    want = [p.detach().clone() for p in m.trainable()]
+    batch = {"rays_o": o.cuda()[None], "rays_d": d.cuda()[None], "images": target[None], "perturb": False, "force_all_rays": True}
+    for k in range(1, 4):
+        eager.step(batch)
+        torch_ema(want, [p.detach() for p in m.trainable()], k)
+    for a, b in zip(eager.ema_shadow, want):
+        assert torch.equal(a, b)
