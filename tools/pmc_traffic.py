@@ -74,6 +74,7 @@ doc = {
     "k_field_fwd_train": traffic(pick("k_field_fwd_train<F16, true> [block render]") or pick("k_field_fwd_train<F16, false> [block render]") or pick("k_field_fwd_train<F16> [block render]")),
     "k_field_bwd_train": traffic(pick("k_field_bwd_train<F16> [block render]")),
     "k_scatter_binned": traffic(pick("k_scatter_binned")),
+    "k_scatter_merge": traffic(pick("k_scatter_merge")),      # (round 6: the exact merge of the owners' replicas)
     "k_codebook_adam_sel_next": traffic(pick("k_codebook_adam_sel<true, true>")),
     "k_warm_tables": traffic(pick("k_warm_tables")),
 }
