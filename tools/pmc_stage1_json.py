@@ -11,7 +11,7 @@ import re
 import sys
 
 KERNELS = {"k_field_bwd_wgrad": "k_field_bwd_wgrad", "k_field_wgrad": "k_field_wgrad", "k_level_entries": "k_level_entries", "k_scatter_binned": "k_scatter_binned",
-           "k_levels_count": "k_levels_count", "k_field_fwd<Bf16x3, 1, true>": "k_field_fwd_trace", "k_field_fwd_trace": "k_field_fwd_trace", "k_field_bwd<Bf16x3, true>": "k_field_bwd_trace",
+           "k_levels_count": "k_levels_count", "k_field_fwd<Bf16x3, 1, true>": "k_field_fwd_trace", "k_field_fwd_trace": "k_field_fwd_trace", "k_field_fwd_trace<float>": "k_field_fwd_trace", "k_field_bwd_wgrad<float>": "k_field_bwd_wgrad", "k_field_bwd<Bf16x3, true>": "k_field_bwd_trace",
            "k_encode_planes": "k_encode_planes", "k_encode_planes<false>": "k_encode_planes", "k_wgrad_reduce": "k_wgrad_reduce"}
 
 
@@ -30,7 +30,7 @@ def main():
         vals["_grid"] = int(m.group(2))
         if KERNELS[m.group(1)] not in rows or rows[KERNELS[m.group(1)]]["_grid"] < vals["_grid"]:      # (a kernel launched at two sizes: the bench step's -- the larger -- launch)
             rows[KERNELS[m.group(1)]] = vals
-    out = {"round": 5, "commit": commit, "points_per_launch": points,
+    out = {"round": int(sys.argv[3]) if len(sys.argv) > 3 else 6, "commit": commit, "points_per_launch": points,
            "source": "rocprofv3 --pmc, one counter group per run, kernel trace only (tools/pmc_stage1.sh) over tools/stage1_bench.py; means over the last 10 launches (the eager pass on one stream)",
            "method": "FETCH_SIZE [KiB] x 1024 x 2 (gfx950 tallies a 128-byte request at 64 B; TCC_BUBBLE does not count on this part: profiles/pmc_traffic.json calibration 1.003), WRITE_SIZE [KiB] x 1024"}
     per_point = {}
