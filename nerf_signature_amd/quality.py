@@ -162,6 +162,14 @@ def state_checksums(stage):
 
 
 @torch.no_grad()
+def trained_tensors(stage):
+    """Copies (on the device: 256 MiB of tables at D = 32) of everything the watermark stage trains, by name -- for an element-wise comparison of two runs."""
+    model = stage["model"]
+    named = [(f"msg_encoder.{i}", t) for i, t in enumerate(model.msg_encoder.tables())] + [(f"msg_decoder.{k}", v) for k, v in model.msg_decoder.state_dict().items()]
+    return [(name, t.detach().clone()) for name, t in named]
+
+
+@torch.no_grad()
 def test_bitacc(stage, n_messages=200, seed=4321, distortion="none"):
     """Trainer.test_bitacc (utils_wtmk_disen.py:935-1030): per item a random message, eval_step(render_whole=False) on the watermark blocks
     (the model stays in whatever mode it is in -- the reference never calls model.eval() here, :951), BIT_ACC over the items.

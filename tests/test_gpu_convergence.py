@@ -44,7 +44,8 @@ def _run_modes(recs, steps, **train_kw):
         rec = quality.train(stage, steps, mode, **train_kw)
         acc, wrong_mean, wrong_max = quality.test_bitacc(stage, 200)
         psnr = quality.test_image(stage)
-        recs[name] = dict(rec, bit_acc=acc, wrong_mean=wrong_mean, wrong_max=wrong_max, psnr=psnr, before=before, checksums=quality.state_checksums(stage))
+        recs[name] = dict(rec, bit_acc=acc, wrong_mean=wrong_mean, wrong_max=wrong_max, psnr=psnr, before=before, checksums=quality.state_checksums(stage),
+                          tensors=quality.trained_tensors(stage) if name.startswith("graphed") else None)
         print(f"[{name:>14}] bit acc {before:.3f} -> {acc:.5f} (mean wrong bits/message {wrong_mean:.3f}, worst {wrong_max}); PSNR vs clean views {psnr:.3f} dB; "
               f"{rec['ms_per_step']:.3f} ms/step incl. {len(rec['log'])} host reads; overflow {rec['overflowed']}; loss_i {rec['loss_image']:.3e} loss_w {rec['loss_watermark']:.4f}")
         del stage
@@ -83,6 +84,10 @@ def test_bench_size_training_converges_the_same_in_every_execution_mode():
     differing = [a[0] for a, b in zip(base["checksums"], again["checksums"]) if a != b]
     print(f"captured loop twice from one seed: {len(base['checksums'])} trained tensors, {len(differing)} differ; PSNR {base['psnr']:.4f} / {again['psnr']:.4f} dB")
     assert not differing, differing[:8]
+    unequal = [na for (na, a), (nb, b) in zip(base["tensors"], again["tensors"]) if na != nb or not torch.equal(a, b)]
+    assert len(base["tensors"]) >= 2 * D + 10 and not unequal, unequal[:8]           # torch.equal on every codebook table and every decoder parameter / buffer
+    base["tensors"] = again["tensors"] = None
+    torch.cuda.empty_cache()
     assert again["psnr"] == base["psnr"] and again["bit_acc"] == base["bit_acc"] and again["log"] == base["log"]
     for name, r in recs.items():
         assert 0.35 < r["before"] < 0.65, (name, r["before"])                # untrained: chance

@@ -2,7 +2,9 @@
 step is really issued, this rank rendering D/R blocks and -- from R = 4 -- updating the tables of D/R bits), for R = 2, 4, 8 in BOTH execution modes
 of the multi-rank step (collectives captured inside the step's graph / between captured segments: what bench.py's launcher tries first and second) and
 for R = 8 with the block rays declared constant -- all in one process, one JSON line:  {"rank_of_2": {"captured": ms, "segmented": ms}, ...}.
-Kernel work + launch structure of a rank, NO inter-GPU latency: not a measured multi-GPU number.   usage: python tools/emulate_ranks.py [--steps 50]"""
+Kernel work + launch structure of a rank, NO inter-GPU latency: not a measured multi-GPU number.   usage: python tools/emulate_ranks.py [--steps 50]
+(Stage 1 needs no entry of its own here: its ranks render their own 4096 rays each and exchange the same 46.4 MiB at every R, so one rank's step is the same at R = 2, 4, 8 --
+`tools/stage1_bench.py --rccl1` with NERFSIG_CAPTURE_COLLECTIVES=1 | 0, the bench line's secondary.stage1.exchange.{captured, segmented}.)"""
 import json
 import os
 import sys
