@@ -92,11 +92,7 @@ __global__ void __launch_bounds__(256) k_fill_f32(float *__restrict__ p, uint32_
 // key = (z * H + y) * H + x.  The probe is then walked row by row of the grid ((z, y) fixed, all x): the encoder's gathers share lines along x (the hash takes x
 // un-multiplied).  The rows are the bins of a counting sort -- this kernel counts, k_refresh_bins scans, k_refresh_place places -- three small launches where a
 // comparison sort of the million keys (torch.sort: rocprim's merge sort, 186 us) cost as much as two thirds of the density query it was there to speed up.
-__global__ void __launch_bounds__(256) k_refresh_draw(int32_t *__restrict__ drawn, uint32_t N, uint32_t H, const int32_t *__restrict__ occ_prefix, uint64_t seed,
-                                                     const int32_t *__restrict__ iter_dev, uint32_t cas, int32_t *__restrict__ bins) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= 2u * N) return;
-    const int32_t iter = *iter_dev;
+__device__ inline uint32_t draw_cell_key(uint32_t i, uint32_t N, uint32_t H, const int32_t *__restrict__ occ_prefix, uint64_t seed, int32_t iter, uint32_t cas) {
     const uint32_t cells = H * H * H;
     uint32_t x, y, z;
     if (i < N) {
@@ -117,8 +113,71 @@ __global__ void __launch_bounds__(256) k_refresh_draw(int32_t *__restrict__ draw
         }
         x = compact3(m); y = compact3(m >> 1); z = compact3(m >> 2);      // morton3D_invert (raymarching.cu:57-63)
     }
-    drawn[i] = (int32_t)((z * H + y) * H + x);
-    atomicAdd(bins + (z * H + y), 1);
+    return (z * H + y) * H + x;
+}
+
+__global__ void __launch_bounds__(256) k_refresh_draw(int32_t *__restrict__ drawn, uint32_t N, uint32_t H, const int32_t *__restrict__ occ_prefix, uint64_t seed,
+                                                     const int32_t *__restrict__ iter_dev, uint32_t cas, int32_t *__restrict__ bins) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= 2u * N) return;
+    const uint32_t key = draw_cell_key(i, N, H, occ_prefix, seed, *iter_dev, cas);
+    drawn[i] = (int32_t)key;
+    atomicAdd(bins + key / H, 1);
+}
+
+// ---- the same counting sort with the row histogram PRIVATE to a workgroup (H^2 <= 16 384 rows = 64 KiB of LDS; the occupied half of the draws lands in the few rows
+// of the scene: ~350 global atomics per row address made the two passes above 74 + 72 us at 1 M draws).  A workgroup owns kDrawChunk consecutive draws in both passes:
+// it counts them in LDS and stores its histogram; k_refresh_offsets turns the histograms into every workgroup's first position in every row; the workgroup then places
+// its draws with LDS atomics on its own cursors.  No global atomic anywhere.
+constexpr uint32_t kDrawThreads = 1024, kDrawChunk = 8 * kDrawThreads, kDrawMaxBins = 16384;
+
+__global__ void __launch_bounds__(kDrawThreads) k_refresh_draw_lds(int32_t *__restrict__ drawn, uint32_t N, uint32_t H, const int32_t *__restrict__ occ_prefix, uint64_t seed,
+                                                                  const int32_t *__restrict__ iter_dev, uint32_t cas, int32_t *__restrict__ wg_hist) {
+    extern __shared__ int32_t rows[];
+    const uint32_t n_bins = H * H;
+    for (uint32_t b = threadIdx.x; b < n_bins; b += kDrawThreads) rows[b] = 0;
+    __syncthreads();
+    const int32_t iter = *iter_dev;
+    for (uint32_t u = 0; u < kDrawChunk / kDrawThreads; ++u) {
+        const uint32_t i = blockIdx.x * kDrawChunk + u * kDrawThreads + threadIdx.x;
+        if (i < 2u * N) {
+            const uint32_t key = draw_cell_key(i, N, H, occ_prefix, seed, iter, cas);
+            drawn[i] = (int32_t)key;
+            atomicAdd(rows + key / H, 1);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < n_bins; b += kDrawThreads) wg_hist[(size_t)blockIdx.x * n_bins + b] = rows[b];
+}
+
+// wg_hist[w][r] (draws of workgroup w in row r) -> the position of workgroup w's first draw INSIDE row r; totals[r] = the row's draws (k_refresh_bins scans them next)
+__global__ void __launch_bounds__(256) k_refresh_offsets(int32_t *__restrict__ wg_hist, uint32_t n_wg, uint32_t n_bins, int32_t *__restrict__ totals) {
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    if (b >= n_bins) return;
+    int32_t run = 0;
+    for (uint32_t w = 0; w < n_wg; ++w) {
+        const int32_t c = wg_hist[(size_t)w * n_bins + b];
+        wg_hist[(size_t)w * n_bins + b] = run;
+        run += c;
+    }
+    totals[b] = run;
+}
+
+__global__ void __launch_bounds__(kDrawThreads) k_refresh_place_lds(const int32_t *__restrict__ drawn, uint32_t n, uint32_t H, const int32_t *__restrict__ wg_hist,
+                                                                   const int32_t *__restrict__ row_start, int32_t *__restrict__ keys, int32_t *__restrict__ ids) {
+    extern __shared__ int32_t rows[];
+    const uint32_t n_bins = H * H;
+    for (uint32_t b = threadIdx.x; b < n_bins; b += kDrawThreads) rows[b] = row_start[b] + wg_hist[(size_t)blockIdx.x * n_bins + b];
+    __syncthreads();
+    for (uint32_t u = 0; u < kDrawChunk / kDrawThreads; ++u) {
+        const uint32_t i = blockIdx.x * kDrawChunk + u * kDrawThreads + threadIdx.x;
+        if (i < n) {
+            const int32_t key = drawn[i];
+            const int32_t p = atomicAdd(rows + (uint32_t)key / H, 1);
+            keys[p] = key;
+            ids[p] = (int32_t)i;
+        }
+    }
 }
 
 // bins[r] (entries of row r) -> the row's first position: an exclusive scan by ONE workgroup (H^2 bins: 16 384 at H = 128)
@@ -274,10 +333,11 @@ static int check_refresh_grid(const char *who, uint32_t H) {
     return NSIG_OK;
 }
 
-// scratch of rg_refresh_draw, in int32 words: [2N draws | H^2 row bins | H^3 occupancy prefix | ceil(H^3 / 4096) workgroup counts]
+// scratch of rg_refresh_draw, in int32 words: [2N draws | H^2 row bins | H^3 occupancy prefix | ceil(H^3 / 4096) workgroup counts | (H^2 <= 16 384) ceil(2N / 8192) x H^2 histograms]
 NSIG_EXPORT size_t rg_refresh_draw_scratch_bytes(uint32_t N, uint32_t H) {
-    const size_t cells = (size_t)H * H * H;
-    return ((size_t)2 * N + (size_t)H * H + cells + (cells + kOccCells - 1) / kOccCells) * sizeof(int32_t);
+    const size_t cells = (size_t)H * H * H, n_bins = (size_t)H * H;
+    const size_t hist = n_bins <= kDrawMaxBins ? (((size_t)2 * N + kDrawChunk - 1) / kDrawChunk) * n_bins : 0;
+    return ((size_t)2 * N + n_bins + cells + (cells + kOccCells - 1) / kOccCells + hist) * sizeof(int32_t);
 }
 
 NSIG_EXPORT int rg_refresh_begin(float *fresh, uint32_t n_cells, nsig_stream_t stream) {
@@ -298,6 +358,25 @@ NSIG_EXPORT int rg_refresh_draw(int32_t *keys, int32_t *ids, uint32_t N, uint32_
     k_occ_count<<<occ_blocks, kOccThreads, 0, st>>>(grid_cas, cells, block_sums, bins, n_bins);
     k_refresh_bins<<<1, 1024, 0, st>>>(block_sums, occ_blocks);
     k_occ_prefix<<<occ_blocks, kOccThreads, 0, st>>>(grid_cas, cells, block_sums, occ_prefix);
+    if (n_bins <= kDrawMaxBins) {      // the row histogram fits a workgroup's LDS: no global atomics (k_occ_count's clearing of `bins` is then unused: the totals overwrite them)
+        static bool attr_set = false;
+        const size_t lds = (size_t)n_bins * sizeof(int32_t);
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_refresh_draw_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kDrawMaxBins * sizeof(int32_t))) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(k_refresh_place_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kDrawMaxBins * sizeof(int32_t))) != hipSuccess) {
+                set_error("rg_refresh_draw: cannot reserve %zu bytes of LDS", (size_t)kDrawMaxBins * sizeof(int32_t));
+                return NSIG_ERR_LAUNCH;
+            }
+            attr_set = true;
+        }
+        const uint32_t n_wg = ceil_div(2u * N, kDrawChunk);
+        int32_t *wg_hist = block_sums + occ_blocks;
+        k_refresh_draw_lds<<<n_wg, kDrawThreads, lds, st>>>(drawn, N, H, occ_prefix, seed, iter_dev, cas, wg_hist);
+        k_refresh_offsets<<<ceil_div(n_bins, 256u), 256, 0, st>>>(wg_hist, n_wg, n_bins, bins);
+        k_refresh_bins<<<1, 1024, 0, st>>>(bins, n_bins);
+        k_refresh_place_lds<<<n_wg, kDrawThreads, lds, st>>>(drawn, 2u * N, H, wg_hist, bins, keys, ids);
+        return check_launch("rg_refresh_draw");
+    }
     k_refresh_draw<<<ceil_div(2u * N, 256u), 256, 0, st>>>(drawn, N, H, occ_prefix, seed, iter_dev, cas, bins);
     k_refresh_bins<<<1, 1024, 0, st>>>(bins, n_bins);
     k_refresh_place<<<ceil_div(2u * N, 256u), 256, 0, st>>>(drawn, 2u * N, H, bins, keys, ids);
