@@ -127,38 +127,46 @@ __global__ void __launch_bounds__(256) k_refresh_draw(int32_t *__restrict__ draw
 
 // ---- the same counting sort with the row histogram PRIVATE to a workgroup (H^2 <= 16 384 rows = 64 KiB of LDS; the occupied half of the draws lands in the few rows
 // of the scene: ~350 global atomics per row address made the two passes above 74 + 72 us at 1 M draws).  A workgroup owns kDrawChunk consecutive draws in both passes:
-// it counts them in LDS and stores its histogram; k_refresh_offsets turns the histograms into every workgroup's first position in every row; the workgroup then places
+// it counts them (k_refresh_hist_lds) in LDS and stores its histogram; k_refresh_offsets turns the histograms into every workgroup's first position in every row; the workgroup then places
 // its draws with LDS atomics on its own cursors.  No global atomic anywhere.
 constexpr uint32_t kDrawThreads = 1024, kDrawChunk = 8 * kDrawThreads, kDrawMaxBins = 16384;
 
-__global__ void __launch_bounds__(kDrawThreads) k_refresh_draw_lds(int32_t *__restrict__ drawn, uint32_t N, uint32_t H, const int32_t *__restrict__ occ_prefix, uint64_t seed,
-                                                                  const int32_t *__restrict__ iter_dev, uint32_t cas, int32_t *__restrict__ wg_hist) {
+// (the draw itself -- a hash, and for the occupied half a 21-step binary search of dependent loads -- wants every compute unit: a launch of its own, 256-thread workgroups;
+// inside the 128 histogram workgroups it ran at their occupancy: 120 us instead of 40)
+__global__ void __launch_bounds__(256) k_refresh_draw_keys(int32_t *__restrict__ drawn, uint32_t N, uint32_t H, const int32_t *__restrict__ occ_prefix, uint64_t seed,
+                                                          const int32_t *__restrict__ iter_dev, uint32_t cas) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < 2u * N) drawn[i] = (int32_t)draw_cell_key(i, N, H, occ_prefix, seed, *iter_dev, cas);
+}
+
+__global__ void __launch_bounds__(kDrawThreads) k_refresh_hist_lds(const int32_t *__restrict__ drawn, uint32_t n, uint32_t H, int32_t *__restrict__ wg_hist) {
     extern __shared__ int32_t rows[];
     const uint32_t n_bins = H * H;
     for (uint32_t b = threadIdx.x; b < n_bins; b += kDrawThreads) rows[b] = 0;
     __syncthreads();
-    const int32_t iter = *iter_dev;
     for (uint32_t u = 0; u < kDrawChunk / kDrawThreads; ++u) {
         const uint32_t i = blockIdx.x * kDrawChunk + u * kDrawThreads + threadIdx.x;
-        if (i < 2u * N) {
-            const uint32_t key = draw_cell_key(i, N, H, occ_prefix, seed, iter, cas);
-            drawn[i] = (int32_t)key;
-            atomicAdd(rows + key / H, 1);
-        }
+        if (i < n) atomicAdd(rows + (uint32_t)drawn[i] / H, 1);
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < n_bins; b += kDrawThreads) wg_hist[(size_t)blockIdx.x * n_bins + b] = rows[b];
 }
 
-// wg_hist[w][r] (draws of workgroup w in row r) -> the position of workgroup w's first draw INSIDE row r; totals[r] = the row's draws (k_refresh_bins scans them next)
+// wg_hist[w][r] (draws of workgroup w in row r) -> the position of workgroup w's first draw INSIDE row r; totals[r] = the row's draws (k_refresh_bins scans them next).
+// A thread per row; eight workgroups' counts requested at a time (the loads do not depend on the running sum).
 __global__ void __launch_bounds__(256) k_refresh_offsets(int32_t *__restrict__ wg_hist, uint32_t n_wg, uint32_t n_bins, int32_t *__restrict__ totals) {
     const uint32_t b = blockIdx.x * 256u + threadIdx.x;
     if (b >= n_bins) return;
     int32_t run = 0;
-    for (uint32_t w = 0; w < n_wg; ++w) {
-        const int32_t c = wg_hist[(size_t)w * n_bins + b];
-        wg_hist[(size_t)w * n_bins + b] = run;
-        run += c;
+    for (uint32_t w0 = 0; w0 < n_wg; w0 += 8u) {
+        int32_t c[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) c[u] = w0 + u < n_wg ? wg_hist[(size_t)(w0 + u) * n_bins + b] : 0;
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) {
+            if (w0 + u < n_wg) wg_hist[(size_t)(w0 + u) * n_bins + b] = run;
+            run += c[u];
+        }
     }
     totals[b] = run;
 }
@@ -362,7 +370,7 @@ NSIG_EXPORT int rg_refresh_draw(int32_t *keys, int32_t *ids, uint32_t N, uint32_
         static bool attr_set = false;
         const size_t lds = (size_t)n_bins * sizeof(int32_t);
         if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_refresh_draw_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kDrawMaxBins * sizeof(int32_t))) != hipSuccess ||
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_refresh_hist_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kDrawMaxBins * sizeof(int32_t))) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void *>(k_refresh_place_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kDrawMaxBins * sizeof(int32_t))) != hipSuccess) {
                 set_error("rg_refresh_draw: cannot reserve %zu bytes of LDS", (size_t)kDrawMaxBins * sizeof(int32_t));
                 return NSIG_ERR_LAUNCH;
@@ -371,7 +379,8 @@ NSIG_EXPORT int rg_refresh_draw(int32_t *keys, int32_t *ids, uint32_t N, uint32_
         }
         const uint32_t n_wg = ceil_div(2u * N, kDrawChunk);
         int32_t *wg_hist = block_sums + occ_blocks;
-        k_refresh_draw_lds<<<n_wg, kDrawThreads, lds, st>>>(drawn, N, H, occ_prefix, seed, iter_dev, cas, wg_hist);
+        k_refresh_draw_keys<<<ceil_div(2u * N, 256u), 256, 0, st>>>(drawn, N, H, occ_prefix, seed, iter_dev, cas);
+        k_refresh_hist_lds<<<n_wg, kDrawThreads, lds, st>>>(drawn, 2u * N, H, wg_hist);
         k_refresh_offsets<<<ceil_div(n_bins, 256u), 256, 0, st>>>(wg_hist, n_wg, n_bins, bins);
         k_refresh_bins<<<1, 1024, 0, st>>>(bins, n_bins);
         k_refresh_place_lds<<<n_wg, kDrawThreads, lds, st>>>(drawn, 2u * N, H, wg_hist, bins, keys, ids);
