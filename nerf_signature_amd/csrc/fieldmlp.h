@@ -225,8 +225,34 @@ __device__ inline T *at_uniform(T *base, size_t uniform_elems, uint32_t lane_byt
 // point as a 32-bit byte offset (stride < 2^27: the entry points check)
 // TT: the element type the trace is kept in -- float, or _Float16 (field_fwd_trace_f16: half the bytes; the reference's MLPs keep fp16 activations for their
 // backward, tinycudann FullyFusedMLP): the ActTrace pointers then address _Float16 rows of the same [width][stride] shape.
+// fp16 rows, two POINTS per store: a 2-byte store per row and lane costs the forward what a 4-byte one does (it is bound by their number: ~100 per tile), so neighbouring
+// lanes trade values -- of a register pair (rows R, R + 1) the even lane ends up with row R of points (p, p + 1), the odd lane with row R + 1 of points (p - 1, p) -- and
+// each issues ONE 4-byte store per pair: 16 per layer instead of 32.  (quad_perm [1, 0, 3, 2]: the lanes of a pair swap.)
+template <typename F>
+__device__ inline void store_rows64_f16x2(float *__restrict__ dst_f32, uint32_t stride, uint32_t s, int h, const f32x16 (&acc)[2], F f) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    _Float16 *__restrict__ dst = reinterpret_cast<_Float16 *>(dst_f32);
+    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);      // lane 0 holds the tile's first point
+    const uint32_t p = s - s0, odd = p & 1u;
+    const uint32_t lane_bytes = ((4u * (uint32_t)h + odd) * stride + (p & ~1u)) * 2u;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float a = f(acc[rb][r], rb * 16 + r), b = f(acc[rb][r + 1], rb * 16 + r + 1);
+            const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, odd ? a : b), 0xB1, 0xF, 0xF, false));
+            const h2 v = odd ? h2{(_Float16)got, (_Float16)b} : h2{(_Float16)a, (_Float16)got};
+            __builtin_nontemporal_store(__builtin_bit_cast(uint32_t, v),
+                                        reinterpret_cast<uint32_t *>(at_uniform(dst, (size_t)(32 * rb + row_of_reg16(0, r)) * stride + s0, lane_bytes)));
+        }
+}
+
 template <typename TT = float, typename F>
 __device__ inline void store_rows64(float *__restrict__ dst_f32, uint32_t stride, uint32_t s, int h, const f32x16 (&acc)[2], F f) {
+    if constexpr (std::is_same<TT, _Float16>::value) {
+        store_rows64_f16x2(dst_f32, stride, s, h, acc, f);
+        return;
+    }
     TT *__restrict__ dst = reinterpret_cast<TT *>(dst_f32);
     const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);      // lane 0 holds the tile's first point
     const uint32_t lane_bytes = (4u * (uint32_t)h * stride + (s - s0)) * (uint32_t)sizeof(TT);
