@@ -222,45 +222,29 @@ __device__ inline T *at_uniform(T *base, size_t uniform_elems, uint32_t lane_byt
 }
 
 // rows 32 rb + row_of_reg16(h, r) of a feature-major trace, column s: the row's uniform part (h = 0) + the tile's first point as the SGPR base, the lane's half and
-// point as a 32-bit byte offset (stride < 2^27: the entry points check)
+// point as a 32-bit byte offset (stride < 2^27: the entry points check).
 // TT: the element type the trace is kept in -- float, or _Float16 (field_fwd_trace_f16: half the bytes; the reference's MLPs keep fp16 activations for their
 // backward, tinycudann FullyFusedMLP): the ActTrace pointers then address _Float16 rows of the same [width][stride] shape.
-// fp16 rows, two POINTS per store: a 2-byte store per row and lane costs the forward what a 4-byte one does (it is bound by their number: ~100 per tile), so neighbouring
-// lanes trade values -- of a register pair (rows R, R + 1) the even lane ends up with row R of points (p, p + 1), the odd lane with row R + 1 of points (p - 1, p) -- and
-// each issues ONE 4-byte store per pair: 16 per layer instead of 32.  (quad_perm [1, 0, 3, 2]: the lanes of a pair swap.)
-template <typename F>
-__device__ inline void store_rows64_f16x2(float *__restrict__ dst_f32, uint32_t stride, uint32_t s, int h, const f32x16 (&acc)[2], F f) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    _Float16 *__restrict__ dst = reinterpret_cast<_Float16 *>(dst_f32);
-    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);      // lane 0 holds the tile's first point
-    const uint32_t p = s - s0, odd = p & 1u;
-    const uint32_t lane_bytes = ((4u * (uint32_t)h + odd) * stride + (p & ~1u)) * 2u;
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            const float a = f(acc[rb][r], rb * 16 + r), b = f(acc[rb][r + 1], rb * 16 + r + 1);
-            const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, odd ? a : b), 0xB1, 0xF, 0xF, false));
-            const h2 v = odd ? h2{(_Float16)got, (_Float16)b} : h2{(_Float16)a, (_Float16)got};
-            __builtin_nontemporal_store(__builtin_bit_cast(uint32_t, v),
-                                        reinterpret_cast<uint32_t *>(at_uniform(dst, (size_t)(32 * rb + row_of_reg16(0, r)) * stride + s0, lane_bytes)));
-        }
-}
-
+// Two POINTS per store: the forward is bound by the NUMBER of its trace stores (~100 per tile: a store per row and lane), so neighbouring lanes trade values -- of a
+// register pair (rows R, R + 1) the even lane ends up with row R of points (p, p + 1), the odd lane with row R + 1 of points (p - 1, p) -- and each issues ONE store of
+// two elements per pair: 16 per layer instead of 32 (quad_perm [1, 0, 3, 2]: the lanes of a pair swap).  fp16: 139 -> 129 us with the bytes halved, -> 117 us with the
+// stores halved; the same elements in the same places either way.
 template <typename TT = float, typename F>
 __device__ inline void store_rows64(float *__restrict__ dst_f32, uint32_t stride, uint32_t s, int h, const f32x16 (&acc)[2], F f) {
-    if constexpr (std::is_same<TT, _Float16>::value) {
-        store_rows64_f16x2(dst_f32, stride, s, h, acc, f);
-        return;
-    }
+    typedef TT pair_t __attribute__((ext_vector_type(2)));
     TT *__restrict__ dst = reinterpret_cast<TT *>(dst_f32);
     const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);      // lane 0 holds the tile's first point
-    const uint32_t lane_bytes = (4u * (uint32_t)h * stride + (s - s0)) * (uint32_t)sizeof(TT);
+    const uint32_t p = s - s0, odd = p & 1u;
+    const uint32_t lane_bytes = ((4u * (uint32_t)h + odd) * stride + (p & ~1u)) * (uint32_t)sizeof(TT);
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)      // streaming stores: a trace is written once and read once, a kernel or more later, and is far larger than the L2 (same box: 148 -> 124 us)
-            __builtin_nontemporal_store((TT)f(acc[rb][r], rb * 16 + r), at_uniform(dst, (size_t)(32 * rb + row_of_reg16(0, r)) * stride + s0, lane_bytes));
+        for (int r = 0; r < 16; r += 2) {      // streaming stores: a trace is written once and read once, a kernel or more later, and is far larger than the L2 (same box: 148 -> 124 us)
+            const float a = f(acc[rb][r], rb * 16 + r), b = f(acc[rb][r + 1], rb * 16 + r + 1);
+            const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, odd ? a : b), 0xB1, 0xF, 0xF, false));
+            const pair_t v = odd ? pair_t{(TT)got, (TT)b} : pair_t{(TT)a, (TT)got};
+            __builtin_nontemporal_store(v, reinterpret_cast<pair_t *>(at_uniform(dst, (size_t)(32 * rb + row_of_reg16(0, r)) * stride + s0, lane_bytes)));
+        }
 }
 
 template <typename P, typename TT = float>
