@@ -225,26 +225,36 @@ __device__ inline T *at_uniform(T *base, size_t uniform_elems, uint32_t lane_byt
 // point as a 32-bit byte offset (stride < 2^27: the entry points check).
 // TT: the element type the trace is kept in -- float, or _Float16 (field_fwd_trace_f16: half the bytes; the reference's MLPs keep fp16 activations for their
 // backward, tinycudann FullyFusedMLP): the ActTrace pointers then address _Float16 rows of the same [width][stride] shape.
-// Two POINTS per store: the forward is bound by the NUMBER of its trace stores (~100 per tile: a store per row and lane), so neighbouring lanes trade values -- of a
-// register pair (rows R, R + 1) the even lane ends up with row R of points (p, p + 1), the odd lane with row R + 1 of points (p - 1, p) -- and each issues ONE store of
-// two elements per pair: 16 per layer instead of 32 (quad_perm [1, 0, 3, 2]: the lanes of a pair swap).  fp16: 139 -> 129 us with the bytes halved, -> 117 us with the
-// stores halved; the same elements in the same places either way.
+// fp16 rows go out two POINTS per store: the forward is bound by the NUMBER of its trace stores (~100 per tile: a store per row and lane), so neighbouring lanes trade
+// values -- of a register pair (rows R, R + 1) the even lane ends up with row R of points (p, p + 1), the odd lane with row R + 1 of points (p - 1, p) -- and each issues
+// ONE 4-byte store per pair: 16 per layer instead of 32 (quad_perm [1, 0, 3, 2]: the lanes of a pair swap).  139 -> 129 us with the bytes halved, -> 115 us with the stores
+// halved; the same elements in the same places.  (measured, rejected) the same pairing for fp32 rows (8-byte stores): the forward 132 -> 124 us, but the BACKWARD that reads
+// the rows 181 -> 190 us and the step +2.5 %, twice on one box (profiles/r06_stage1_f16_traces_ab3_fp32_paired.txt): fp32 rows keep one 4-byte store per row and lane.
 template <typename TT = float, typename F>
 __device__ inline void store_rows64(float *__restrict__ dst_f32, uint32_t stride, uint32_t s, int h, const f32x16 (&acc)[2], F f) {
-    typedef TT pair_t __attribute__((ext_vector_type(2)));
     TT *__restrict__ dst = reinterpret_cast<TT *>(dst_f32);
     const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);      // lane 0 holds the tile's first point
-    const uint32_t p = s - s0, odd = p & 1u;
-    const uint32_t lane_bytes = ((4u * (uint32_t)h + odd) * stride + (p & ~1u)) * (uint32_t)sizeof(TT);
+    if constexpr (std::is_same<TT, _Float16>::value) {
+        typedef TT pair_t __attribute__((ext_vector_type(2)));
+        const uint32_t p = s - s0, odd = p & 1u;
+        const uint32_t lane_bytes = ((4u * (uint32_t)h + odd) * stride + (p & ~1u)) * (uint32_t)sizeof(TT);
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {      // streaming stores: a trace is written once and read once, a kernel or more later, and is far larger than the L2 (same box: 148 -> 124 us)
-            const float a = f(acc[rb][r], rb * 16 + r), b = f(acc[rb][r + 1], rb * 16 + r + 1);
-            const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, odd ? a : b), 0xB1, 0xF, 0xF, false));
-            const pair_t v = odd ? pair_t{(TT)got, (TT)b} : pair_t{(TT)a, (TT)got};
-            __builtin_nontemporal_store(v, reinterpret_cast<pair_t *>(at_uniform(dst, (size_t)(32 * rb + row_of_reg16(0, r)) * stride + s0, lane_bytes)));
-        }
+            for (int r = 0; r < 16; r += 2) {
+                const float a = f(acc[rb][r], rb * 16 + r), b = f(acc[rb][r + 1], rb * 16 + r + 1);
+                const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, odd ? a : b), 0xB1, 0xF, 0xF, false));
+                const pair_t v = odd ? pair_t{(TT)got, (TT)b} : pair_t{(TT)a, (TT)got};
+                __builtin_nontemporal_store(v, reinterpret_cast<pair_t *>(at_uniform(dst, (size_t)(32 * rb + row_of_reg16(0, r)) * stride + s0, lane_bytes)));
+            }
+    } else {
+        const uint32_t lane_bytes = (4u * (uint32_t)h * stride + (s - s0)) * (uint32_t)sizeof(TT);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)      // streaming stores: a trace is written once and read once, a kernel or more later, and is far larger than the L2 (same box: 148 -> 124 us)
+                __builtin_nontemporal_store((TT)f(acc[rb][r], rb * 16 + r), at_uniform(dst, (size_t)(32 * rb + row_of_reg16(0, r)) * stride + s0, lane_bytes));
+    }
 }
 
 template <typename P, typename TT = float>
