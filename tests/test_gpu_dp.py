@@ -205,3 +205,17 @@ def test_sharded_codebook_optimizer_equals_replicated(strict_mlp):
                 assert torch.equal(t[l], init[l]) and len(o.state[t[l]]) == 0
     np.testing.assert_allclose((parts[0] + parts[1]).cpu().numpy(), S_ref.cpu().numpy(), rtol=0, atol=1e-6)   # fp32 summation order (values up to ~1.6)
     assert float(S_ref.abs().max()) > 0.1
+
+
+def test_stage1_loop_on_two_real_gloo_rank_processes():
+    """tools/stage1_dp_check.py: two rank PROCESSES (gloo, sharing this GPU) drive the captured stage-1 loop -- packed gradient exchange between captured segments, device-side
+    grid refresh, parameter EMA, and point buffers that only rank 0 fills to 95 %: both ranks grow at the same refresh; parameters, EMA shadows and the density grid stay
+    identical on both ranks (checked inside the ranks with all_gather + torch.equal)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stage1_dp_check.py")], env=env, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "identical on both ranks" in out.stdout and "on BOTH ranks at the same refresh (1 re-capture each)" in out.stdout, out.stdout[-1000:]
