@@ -987,7 +987,17 @@ def bench_training(args, scene, real_stdout, secondary=None):
                               "context": "the launch at the head of the step, behind the optimiser + warm-up pass (tools/pmc_step.py)" if counters.get("round") else "stand-alone launches (rounds 1-2)"}
             # what actually bounds the launch: the CU's vector-L1 pipe looks up one line per clock and fills a missing one
             # in 2.4 clk (tools/micro/gather_rate.hip); counters of the block render's launch (17 levels, 1.29 M points)
-            enc = counters.get("k_encode_planes", {})
+            enc = dict(counters.get("k_encode_planes", {}))
+            # the counters were taken on a launch of `k_encode_planes_points_per_launch` points (the one-GPU block render: 1.29 M); a rank of R renders 1/R of the blocks --
+            # lookups, fills and HBM bytes of the gather scale with the points
+            at_points = counters.get("k_encode_planes_points_per_launch")
+            if at_points and enc_big and abs(pts_big - at_points) > 0.01 * at_points:
+                k_pts = pts_big / at_points
+                for name in ("TCP_TOTAL_CACHE_ACCESSES", "TCP_TCC_READ_REQ"):
+                    if enc.get(name):
+                        enc[name] = enc[name] * k_pts
+                traffic = traffic * k_pts if traffic else traffic
+                traffic_source["scaled_to_this_launch"] = k_pts
             if enc.get("TCP_TOTAL_CACHE_ACCESSES") and enc.get("TCP_TCC_READ_REQ") and enc_big and not split_encoder_early:
                 clk = (enc["TCP_TOTAL_CACHE_ACCESSES"] + 1.4 * enc["TCP_TCC_READ_REQ"]) / 256.0
                 l1_model = {"tag_lookups_per_launch": enc["TCP_TOTAL_CACHE_ACCESSES"], "misses_to_L2_per_launch": enc["TCP_TCC_READ_REQ"],

@@ -79,6 +79,8 @@ doc = {
     "k_warm_tables": traffic(pick("k_warm_tables")),
 }
 doc["k_encode_planes_hbm_bytes_per_launch"] = doc["k_encode_planes"].get("hbm_bytes_per_launch")
+m = re.search(r"block render (\d+)", tail)      # the point count the block render's launch had when the counters were taken: bench.py scales the per-launch counts to its own launch
+doc["k_encode_planes_points_per_launch"] = int(m.group(1)) if m else None
 adam = doc.get("k_codebook_adam_sel_next") or {}
 if adam.get("hbm_bytes_per_launch"):
     exact = 836 * 2 ** 20      # G once + (param, exp_avg, exp_avg_sq) of 32 tables read and written + partner tables + S (bench.py step_bytes): 836 MiB
