@@ -80,8 +80,8 @@ class DeviceGridRefresh:
         ring of (points, rays) per step and its device step count; window: how many of the ring's last rows the mean sample count averages (0: leave it alone).
         The first refresh of a form runs eagerly (it loads the kernels), the second is captured, later ones replay."""
         m = self.model
-        if m.density_grid.data_ptr() != self.fresh.data_ptr() and self.fresh.shape != m.density_grid.shape:
-            raise RuntimeError("DeviceGridRefresh: the model's grid changed shape")
+        if self.fresh.shape != m.density_grid.shape or m.density_grid.device != self.device:
+            raise RuntimeError("DeviceGridRefresh: the model's grid changed shape or device since this object was built")
         form = "full" if m.iter_density < 16 else "partial"
         window = int(window) if (count_ring is not None and window) else 0
         key = (form, window, packed.data_ptr(), m.density_grid.data_ptr(), m.density_bitfield.data_ptr(), 0 if count_ring is None else count_ring.data_ptr())
