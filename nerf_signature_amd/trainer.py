@@ -542,18 +542,23 @@ class GraphedWatermarkLoop:
         self.exchange = GradExchange(list(model.msg_decoder.parameters()), average=not native_dense_adam)
         self.data = {"watermark": {k: v.clone() for k, v in data["watermark"].items()},
                      "content": {k: v.clone() for k, v in data["content"].items()}}
-        self.msg_all = torch.zeros(2 * D, dtype=torch.float32, device=dev)     # this step's message, then the next step's
-        self.msg_dev, self.msg_next_dev = self.msg_all[:D], self.msg_all[D:]
+        # this step's message, then the next step's, then this step's learning rate: what the host hands a step, staged together -- with an lr schedule the
+        # step's opening kernel fetches the rate with the message (a `fill_` of its own between two replays was a 4 us launch on the critical path)
+        self.msg_all = torch.zeros(2 * D + 1, dtype=torch.float32, device=dev)
+        self.msg_dev, self.msg_next_dev = self.msg_all[:D], self.msg_all[D:2 * D]
         # The host runs ahead of the GPU by many replays, so the pinned staging buffer of a step must not be rewritten until its
         # asynchronous copy has executed: a ring of buffers, each guarded by an event.
-        self.msg_ring = torch.zeros(16, 2 * D, dtype=torch.float32).pin_memory()      # one row per in-flight step
+        # words a step stages (= the ring's row width): without a schedule the rate is whatever the tensor holds (a caller may write it) and is not staged
+        self.stage_width = 2 * D + (1 if lr_lambda is not None else 0)
+        self.msg_ring = torch.zeros(16, self.stage_width, dtype=torch.float32).pin_memory()      # one row per in-flight step
         self.msg_events = [None] * len(self.msg_ring)
         self.stage_counter = torch.zeros(1, dtype=torch.int32, device=dev)           # replays so far (advanced by loop_step_begin)
         self.ring_dev = nv.fn("nsig_host_device_pointer")(ctypes.c_void_p(self.msg_ring.data_ptr())) if self.stage_in_graph else None
         if self.stage_in_graph and not self.ring_dev:
             self.stage_in_graph = False         # the ring is not device-mapped on this platform: keep the per-step copy
         self.base_lr = float(optimizer.param_groups[0]["lr"])
-        self.lr_dev = torch.tensor(self.base_lr, dtype=torch.float32, device=dev)
+        self.lr_dev = self.msg_all[2 * D]        # (a 0-dim view: the optimiser's tensor lr)
+        self.lr_dev.fill_(self.base_lr)
         for g in optimizer.param_groups:
             g["lr"] = self.lr_dev          # tensor lr: the captured optimiser reads it on the device
         self.tables = model.msg_encoder.tables()
@@ -626,7 +631,7 @@ class GraphedWatermarkLoop:
     def _forward_backward(self):
         if self.stage_in_graph and torch.cuda.is_current_stream_capturing():
             nv.call("loop_step_begin", nv.ptr(self.sink.G), self.sink.G.numel(), ctypes.c_void_p(self.ring_dev), len(self.msg_ring),
-                    self.msg_all.numel(), nv.ptr(self.stage_counter), nv.ptr(self.msg_all), nv.stream())
+                    self.stage_width, nv.ptr(self.stage_counter), nv.ptr(self.msg_all), nv.stream())
         else:
             self.sink.zero_()
             if self.content_sampler is not None and torch.cuda.is_current_stream_capturing():
@@ -773,14 +778,14 @@ class GraphedWatermarkLoop:
         D = self.msg_dev.numel()
         self.msg_ring[slot][:D].copy_(message.detach().to("cpu", torch.float32))
         # an unannounced next message: the optimiser pre-sums for this step's bits again (harmless) and _s_for goes stale
-        self.msg_ring[slot][D:].copy_((message if next_message is None else next_message).detach().to("cpu", torch.float32))
+        self.msg_ring[slot][D:2 * D].copy_((message if next_message is None else next_message).detach().to("cpu", torch.float32))
+        if self.lr_lambda is not None:      # this step's learning rate travels with its message
+            self.msg_ring[slot][2 * D] = self.base_lr * self.lr_lambda(self.steps_done)
         if eager_copy:      # (a replay with stage_in_graph fetches the row itself; step() then guards the slot with an event behind the replay)
-            self.msg_all.copy_(self.msg_ring[slot], non_blocking=True)
+            self.msg_all[:self.stage_width].copy_(self.msg_ring[slot][:self.stage_width], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
             self.msg_events[slot] = ev
-        if self.lr_lambda is not None:
-            self.lr_dev.fill_(self.base_lr * self.lr_lambda(self.steps_done))
         if self._pending_content is not None:     # the content part that came with the block rays marched at the end of the last replay
             for k, v in self._pending_content.items():
                 self.data["content"][k].copy_(v, non_blocking=True)

@@ -31,7 +31,7 @@ torch.cuda.synchronize()
 print("PMC_STEP_BEGIN", flush=True)
 for k in range(steps):
     loop.msg_all[:D].copy_(msgs[k].to(dev))
-    loop.msg_all[D:].copy_(msgs[k + 1].to(dev))
+    loop.msg_all[D:2 * D].copy_(msgs[k + 1].to(dev))
     optimizer.zero_grad(set_to_none=True)
     loop._forward_backward()
     loop._optimise_and_march()
