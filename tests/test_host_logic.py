@@ -836,3 +836,50 @@ def _strings(o):
     elif isinstance(o, list):
         for v in o:
             yield from _strings(v)
+
+
+def test_static_live_rows_bound_every_row_a_level_can_touch():
+    """stage1.live_rows (the packed data-parallel exchange of the coarse levels): the rows the oracle's encoder gathers from -- for points all over [0, 1]^3, corners and
+    faces of the box included -- lie inside the static set; the set is the hash of the level's (res + 2)^3 grid corners (hash_encoding.py:11-22), sorted and unique;
+    levels 0..4 are the ones worth packing."""
+    from nerf_signature_amd import stage1
+    rng = np.random.RandomState(0)
+    pts = rng.rand(20000, 3).astype(np.float32)
+    pts[:8] = np.array([[i & 1, (i >> 1) & 1, (i >> 2) & 1] for i in range(8)], np.float32)
+    pts[8:2008, 0] = 1.0
+    pts[2008:4008, 1] = 0.0
+    x = torch.from_numpy(pts)
+    assert stage1.SPARSE_EXCHANGE_LEVELS == (0, 1, 2, 3, 4)
+    for level in (0, 2, 4, 5):
+        live = stage1.live_rows(level)
+        assert torch.equal(live, torch.unique(live)) and int(live.min()) >= 0 and int(live.max()) < (1 << 19)
+        res = stage1.RESOLUTIONS[level]
+        cell = torch.tensor(1.0, dtype=torch.float32) / torch.tensor(float(res), dtype=torch.float32)
+        idx = torch.floor(x.clamp(0, 1) / cell).to(torch.int64)                       # hash_encoding.py:33-39
+        assert int(idx.max()) <= res
+        rows = set()
+        for dx in (0, 1):
+            for dy in (0, 1):
+                for dz in (0, 1):
+                    c = idx + torch.tensor([dx, dy, dz])
+                    h = (c[:, 0] ^ (c[:, 1] * 2654435761) ^ (c[:, 2] * 805459861)) & ((1 << 19) - 1)       # :11-22 (uint32 arithmetic: the low 19 bits agree)
+                    rows.update(h.tolist())
+        assert rows <= set(live.tolist()), level
+        assert live.numel() <= (res + 2) ** 3
+    assert sum(stage1.live_rows(l).numel() for l in stage1.SPARSE_EXCHANGE_LEVELS) == 305480
+
+
+def test_gpu_suite_runs_sharpest_first():
+    """tests/conftest.py orders the GPU suite so that a stop at the first failure (the driver's `-x`) cannot erase parity evidence: kernels against the reference's native
+    module / goldens / oracle, then glue and gradients, then full-size workloads, and every multi-hundred-step training run last."""
+    import conftest
+    rank = conftest.gpu_suite_rank
+    order = [("test_gpu_ref_native.py", "test_near_far_vs_reference"), ("test_gpu_raymarch.py", "test_near_far_bit_exact"), ("test_gpu_field.py", "test_hash_rows_bit_exact_vs_reference"),
+             ("test_gpu_render.py", "test_fused_decoder_matches_stock_operators"), ("test_gpu_render.py", "test_render_matches_reference_glue_golden"),
+             ("test_gpu_stage1.py", "test_all_parameter_gradients_vs_oracle"), ("test_gpu_amp_ckpt.py", "test_checkpoint_save_load_renders_bit_identically"),
+             ("test_gpu_fullsize.py", "test_full_workload_march_is_bit_exact"), ("test_gpu_render.py", "test_training_trajectory_psnr_and_bit_accuracy_track_the_oracle"),
+             ("test_gpu_stage1.py", "test_captured_loop_tracks_the_cpu_oracle_over_200_steps"), ("test_gpu_convergence.py", "test_two_hundred_steps_tracked_by_the_oracle_from_a_warm_state"),
+             ("test_gpu_convergence.py", "test_bench_size_training_converges_the_same_in_every_execution_mode")]
+    keys = [rank(*t) for t in order]
+    assert keys == sorted(keys), keys
+    assert rank("test_gpu_amp_ckpt.py", "test_dense_takeover_is_torch_adam_arithmetic")[0] < rank("test_gpu_convergence.py", "test_anything")[0] == 3
